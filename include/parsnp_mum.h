@@ -1,0 +1,83 @@
+/* include/parsnp_mum.h -- C ABI of the MI355X multi-MUM engine (libparsnp_hip.so).
+ *
+ * This is the drop-in boundary for the one hot path of marbl/parsnp that this project replaces: the
+ * csgmum calls made by Aligner::setMums1.  The reference has no FFI for it (csgmum is #included C,
+ * src/parsnp.cpp:73-78); the entry points below are what a binding for that path would bind, one per
+ * reference call site.  Plain pointers and sizes only; every function returns 0 on success or a negative
+ * PM_E* code (no exceptions cross the boundary).  pm_last_error() gives a message for the calling thread.
+ *
+ * Sequences are ASCII over {A,C,G,T,N}, exactly the strings parsnp_core holds after ingest
+ * (src/parsnp.cpp:2999-3141): any other byte is treated as N.  'N' matches 'N' (src/csgmum/csg.c:13-25).
+ * Coordinates are 0-based; all arithmetic is integer (int32 reference positions, int64 query positions).
+ */
+#ifndef PARSNP_MUM_H
+#define PARSNP_MUM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_OK 0
+#define PM_ENODEV (-1)   /* no usable gfx950 device / HIP runtime error at start-up */
+#define PM_EINVAL (-2)   /* bad argument */
+#define PM_ENOMEM (-3)   /* host or device allocation failed */
+#define PM_EHIP (-4)     /* a HIP call or kernel failed */
+#define PM_ELIMIT (-5)   /* a size limit of the engine was exceeded (see pm_limits) */
+
+typedef struct pm_session pm_session; /* genomes resident in HBM (2-bit + N-mask, both strands) */
+typedef struct pm_result pm_result;   /* output of one batch call, owned by the library until pm_result_free */
+
+const char* pm_last_error(void);
+/* "hip" for libparsnp_hip.so. (The test-only CPU provider under oracle/ answers "oracle".) */
+const char* pm_provider(void);
+
+/* Upload the n genomes once (genome 0 = reference).  Replaces the per-call substr()+reversec()+strcpy of
+ * src/parsnp.cpp:1540-1561: regions are addressed by (start,len) into these resident copies.
+ * device < 0 selects the current HIP device. */
+int pm_session_create(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens);
+void pm_session_destroy(pm_session* s);
+int pm_session_genomes(const pm_session* s);
+
+/* Multi-MUM candidates for a batch of regions.  For region r (r = 0..n_regions-1) and genome g:
+ *   starts[r*n_genomes+g], lens[r*n_genomes+g] : the substring of genome g   (TRegion start/length, src/LCR.cpp:12-37;
+ *                                                 the reference chunk of src/parsnp.cpp:1519-1547 when g == 0)
+ *   minsize[r]                                 : minimum MUM length          (src/parsnp.cpp:1502-1514)
+ * Per region this is the whole of src/parsnp.cpp:1563-1695:
+ *   new_CSG/build_CSG/find_leaves (csg.c:105-575)  -> device index of the reference substring
+ *   Find_UM x 2 per query (mum.c:177-250)          -> R-unique maximal matches, both strands
+ *   Intersect_UM x 2 (mum.c:125-175)               -> forward carry + fold into Master
+ *   Merge_Master (mum.c:92-123)                    -> strand choice in ini order, ties to reverse
+ *   extraction loop (parsnp.cpp:1633-1695)         -> candidates (k, LON, per-genome SP and strand)
+ * The candidate list is bit-identical to the reference's list_mums for the same region. */
+int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, const int64_t* lens,
+                       const int32_t* minsize, pm_result** out);
+
+/* Result accessors.  Candidates of region r are c in [off[r], off[r+1]).  For candidate c:
+ *   k[c]   reference offset inside the region (Mum.DSP[0]-1-ini_region, parsnp.cpp:1671)
+ *   lon[c] length (Mum.LON, :1687)
+ *   sp[c*(n_genomes-1)+g-1]  start inside genome g's substring, on the chosen strand's string (SPF[g-1].MSP[k], :1681)
+ *   fwd[c*(n_genomes-1)+g-1] 1 = forward, 0 = reverse complement (SPF[g-1].forward[k], :1678)            */
+int64_t pm_result_regions(const pm_result* r);
+int64_t pm_result_total(const pm_result* r);
+const int64_t* pm_result_offsets(const pm_result* r);
+const int32_t* pm_result_k(const pm_result* r);
+const int32_t* pm_result_lon(const pm_result* r);
+const int64_t* pm_result_sp(const pm_result* r);
+const uint8_t* pm_result_fwd(const pm_result* r);
+void pm_result_free(pm_result* r);
+
+/* Single-strand entry point mirroring Find_UM (+ optionally Intersect_UM's carry) for parity tests:
+ * dense per-reference-position arrays for events of length >= min_len (caller allocates n entries each).
+ * propagate = 0: raw Pair/SP after Find_UM (mum.c:177-250); 1: after the forward carry of Intersect_UM (mum.c:125-175). */
+int pm_find_um(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int propagate,
+               int32_t* UP, int32_t* EP, int64_t* SP);
+
+/* Device-side timing of the last pm_multi_mum_batch on this session (HIP events on the engine's stream):
+ * names[i] / ms[i] for i < *count (count in: capacity, out: filled).  Used by bench.py's roofline line. */
+int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

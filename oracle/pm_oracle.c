@@ -1,0 +1,74 @@
+/* oracle/pm_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ * CPU provider of the include/parsnp_mum.h ABI built on oracle/mum_oracle.c.  It exists so that the host-side
+ * logic (parsnp_amd/csrc/host) can be exercised and compared with the reference binary on machines without a GPU
+ * (tests -m "not gpu").  It is linked ONLY into oracle/_ref/parsnp_core_oracle and loaded ONLY by tests/;
+ * the product binary links libparsnp_hip.so and has no path to this file. */
+#include "../include/parsnp_mum.h"
+#include "mum_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+struct pm_session { int n; uint8_t** seq; int64_t* len; };
+struct pm_result { int64_t nreg, total; int nq; int64_t* off; int32_t* k; int32_t* lon; int64_t* sp; uint8_t* fwd; };
+static const char* g_err = "";
+const char* pm_last_error(void) { return g_err; }
+const char* pm_provider(void) { return "oracle"; }
+
+int pm_session_create(pm_session** out, int device, int n, const uint8_t* const* seqs, const int64_t* lens) {
+    (void)device;
+    if (!out || n < 1) { g_err = "bad argument"; return PM_EINVAL; }
+    pm_session* s = calloc(1, sizeof *s);
+    s->n = n; s->seq = calloc((size_t)n, sizeof *s->seq); s->len = calloc((size_t)n, sizeof *s->len);
+    for (int i = 0; i < n; i++) {
+        s->len[i] = lens[i]; s->seq[i] = malloc((size_t)lens[i] + 1);
+        for (int64_t j = 0; j < lens[i]; j++) { uint8_t c = seqs[i][j]; s->seq[i][j] = (c=='A'||c=='C'||c=='G'||c=='T') ? c : 'N'; }
+    }
+    *out = s; return PM_OK;
+}
+void pm_session_destroy(pm_session* s) { if (!s) return; for (int i = 0; i < s->n; i++) free(s->seq[i]); free(s->seq); free(s->len); free(s); }
+int pm_session_genomes(const pm_session* s) { return s->n; }
+
+int pm_multi_mum_batch(pm_session* s, int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, pm_result** out) {
+    int n = s->n, q = n - 1;
+    pm_result* r = calloc(1, sizeof *r);
+    r->nreg = nreg; r->nq = q; r->off = calloc((size_t)nreg + 1, sizeof(int64_t));
+    int64_t cap = 0;
+    const uint8_t** ptr = malloc(sizeof(*ptr) * (size_t)n);
+    for (int64_t x = 0; x < nreg; x++) {
+        for (int g = 0; g < n; g++) {
+            int64_t st = starts[x * n + g], ln = lens[x * n + g];
+            if (st < 0 || ln < 0 || st + ln > s->len[g]) { g_err = "region out of range"; return PM_EINVAL; }
+            ptr[g] = s->seq[g] + st;
+        }
+        int64_t c, *k, *sp; int32_t* lon; uint8_t* fw;
+        int ml = minsize[x] < 1 ? 1 : minsize[x];
+        if (oracle_multi_mum(n, ptr, lens + x * n, minsize[x], ml, &c, &k, &lon, &sp, &fw, NULL, NULL)) { g_err = "oracle failed"; return PM_ENOMEM; }
+        int64_t base = r->off[x];
+        if (base + c > cap) {
+            cap = (base + c) * 2 + 16;
+            r->k = realloc(r->k, sizeof(int32_t) * (size_t)cap); r->lon = realloc(r->lon, sizeof(int32_t) * (size_t)cap);
+            r->sp = realloc(r->sp, sizeof(int64_t) * (size_t)(cap * (q > 0 ? q : 1))); r->fwd = realloc(r->fwd, (size_t)(cap * (q > 0 ? q : 1)));
+        }
+        for (int64_t i = 0; i < c; i++) { r->k[base + i] = (int32_t)k[i]; r->lon[base + i] = lon[i]; }
+        memcpy(r->sp + base * q, sp, sizeof(int64_t) * (size_t)(c * q)); memcpy(r->fwd + base * q, fw, (size_t)(c * q));
+        r->off[x + 1] = base + c;
+        oracle_free(k); oracle_free(lon); oracle_free(sp); oracle_free(fw);
+    }
+    free(ptr);
+    r->total = r->off[nreg]; *out = r; return PM_OK;
+}
+int64_t pm_result_regions(const pm_result* r) { return r->nreg; }
+int64_t pm_result_total(const pm_result* r) { return r->total; }
+const int64_t* pm_result_offsets(const pm_result* r) { return r->off; }
+const int32_t* pm_result_k(const pm_result* r) { return r->k; }
+const int32_t* pm_result_lon(const pm_result* r) { return r->lon; }
+const int64_t* pm_result_sp(const pm_result* r) { return r->sp; }
+const uint8_t* pm_result_fwd(const pm_result* r) { return r->fwd; }
+void pm_result_free(pm_result* r) { if (!r) return; free(r->off); free(r->k); free(r->lon); free(r->sp); free(r->fwd); free(r); }
+
+int pm_find_um(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int propagate, int32_t* UP, int32_t* EP, int64_t* SP) {
+    if (oracle_find_um(ref, n, query, m, min_len, UP, EP, SP)) return PM_ENOMEM;
+    if (propagate) oracle_propagate(n, UP, EP, SP);
+    return PM_OK;
+}
+int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) { (void)s; (void)names; (void)ms; if (count) *count = 0; return PM_OK; }

@@ -1,0 +1,626 @@
+// aligner.cpp -- MUM validation, recursive extension and LCB formation on the host.
+// See aligner.h for the map onto the reference.  The match finding itself (csgmum) is NOT here: it is
+// requested through include/parsnp_mum.h in batches and runs on the GPU.
+#include "aligner.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "minlen.h"
+
+namespace parsnp {
+
+namespace {
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+[[noreturn]] void fatal(const std::string& msg) {
+    std::cerr << "parsnp_core: " << msg << std::endl;
+    exit(1);
+}
+// Order of a std::sort that only looks at the reference start (TMum/TRegion/Cluster operator<, TMum.cpp:151-156,
+// LCR.cpp:42-46, LCB.cpp:53-57).  Sorting (key, index) handles with the same algorithm and comparator performs the
+// same comparisons and moves as sorting the objects, so the (unstable) permutation is the reference's.
+struct Handle { long key; int idx; };
+inline bool operator<(const Handle& a, const Handle& b) { return a.key < b.key; }
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- Bitmap
+void Bitmap::init(size_t nbits) {
+    nbits_ = nbits;
+    w_.assign((nbits + 63) / 64 + 1, 0);
+    if (nbits) w_[(nbits - 1) >> 6] |= 1ull << ((nbits - 1) & 63);
+}
+void Bitmap::set_range(long a, long b) {
+    if (a < 0) a = 0;
+    if (b > (long)nbits_) b = (long)nbits_;
+    while (a < b) {
+        size_t wi = (size_t)a >> 6;
+        int lo = (int)(a & 63);
+        long span = std::min<long>(64 - lo, b - a);
+        uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
+        store(wi, w_[wi] | mask);
+        a += span;
+    }
+}
+void Bitmap::clear_range(long a, long b) {
+    if (a < 0) a = 0;
+    if (b > (long)nbits_) b = (long)nbits_;
+    while (a < b) {
+        size_t wi = (size_t)a >> 6;
+        int lo = (int)(a & 63);
+        long span = std::min<long>(64 - lo, b - a);
+        uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
+        store(wi, w_[wi] & ~mask);
+        a += span;
+    }
+}
+long Bitmap::next_set(long from) const {
+    if (from < 0) from = 0;
+    if ((size_t)from >= nbits_) return (long)nbits_;
+    size_t wi = (size_t)from >> 6;
+    uint64_t w = w_[wi] & (~0ull << (from & 63));
+    const size_t nw = (nbits_ + 63) / 64;
+    while (!w) { if (++wi >= nw) return (long)nbits_; w = w_[wi]; }
+    return (long)(wi * 64 + (size_t)__builtin_ctzll(w));
+}
+long Bitmap::prev_set(long from) const {
+    if (from < 0) return -1;
+    if ((size_t)from >= nbits_) from = (long)nbits_ - 1;
+    size_t wi = (size_t)from >> 6;
+    int hi = (int)(from & 63);
+    uint64_t w = w_[wi] & (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1));
+    while (!w) { if (wi == 0) return -1; w = w_[--wi]; }
+    return (long)(wi * 64 + 63 - (size_t)__builtin_clzll(w));
+}
+void Bitmap::rollback() {
+    for (size_t i = log_.size(); i-- > 0;) w_[log_[i].first] = log_[i].second;
+    log_.clear();
+}
+
+// ---------------------------------------------------------------------------------------------- Region
+static Region make_region(std::vector<long>& start, std::vector<long>& end) {   // TRegion ctor, LCR.cpp:16-37
+    Region r;
+    r.start = start; r.end = end;
+    long s = 500000000, l = 0;
+    r.length.resize(start.size());
+    for (size_t i = 0; i < start.size(); i++) {
+        r.length[i] = end[i] - start[i];
+        if (r.length[i] < s) s = r.length[i];
+        if (r.length[i] > l) l = r.length[i];
+    }
+    r.slength = s; r.llength = l;
+    return r;
+}
+bool Region::same_as(const Region& o) const {
+    for (size_t i = 0; i < start.size(); i++)
+        if (start[i] != o.start[i] || end[i] != o.end[i]) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------- Aligner
+Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session)
+    : n(g.size()), prm(p), genomes(g), session_(session) {
+    layout.resize(n);
+    for (size_t i = 0; i < n; i++) layout[i].init(genomes[i].seq.size() + 1);
+}
+
+Region Aligner::neighbour_region(const Mum& m, bool left) const {
+    std::vector<long> start(n), end(n);
+    for (size_t i = 0; i < n; i++) {
+        if (left) {   // walk left to the previous marked base; at the genome start the region begins at 1 (:1216-1231)
+            long p = layout[i].prev_set(m.start[i] - 1);
+            if (p < 0) p = 0;
+            start[i] = p + 1;
+            end[i] = m.start[i] - 1;
+        } else {      // walk right to the next marked base or the genome end (:1254-1268)
+            long nxt = m.end[i] + 1, size = (long)genomes[i].seq.size();
+            long p = nxt >= size ? nxt : layout[i].next_set(nxt);
+            start[i] = m.end[i] + 1;
+            end[i] = p - 1;
+        }
+    }
+    return make_region(start, end);
+}
+
+int Aligner::min_length(bool anchors, long slength) const {
+    int v = 0;
+    const std::string& e = anchors ? prm.anchors : prm.mums;
+    if (!min_mum_length(e, slength, &v)) fatal("cannot evaluate minimum MUM length expression '" + e + "'");
+    return v;
+}
+
+std::string Aligner::key_of(const Request& q) {
+    std::string k;
+    k.resize(q.start.size() * 16 + 4);
+    memcpy(&k[0], q.start.data(), q.start.size() * 8);
+    memcpy(&k[q.start.size() * 8], q.len.data(), q.len.size() * 8);
+    memcpy(&k[q.start.size() * 16], &q.minsize, 4);
+    return k;
+}
+
+// The reference cuts the reference side of a region into chunks of p bases and re-streams every query against each
+// chunk (parsnp.cpp:1519-1547); one finder request per chunk.
+std::vector<Aligner::Request> Aligner::chunk_requests(const Region& r, int minsize) const {
+    std::vector<Request> out;
+    long len0 = r.length[0];
+    long p = prm.p > len0 ? len0 : prm.p;
+    if (p <= 0 && len0 > 0) fatal("LCB p must be positive");
+    long partpos = 0;
+    while (partpos < len0) {
+        if (partpos + p > len0) {
+            p = len0 - partpos;
+            if (p < 50) { p = 50 + p; partpos = partpos - 50; }
+            if (partpos < 0) fatal("reference chunk underflow (p < 50)");
+        }
+        Request q;
+        q.start.resize(n); q.len.resize(n);
+        q.minsize = minsize;
+        q.ref_ini = r.start[0] + partpos;
+        for (size_t g = 0; g < n; g++) {
+            long st = g == 0 ? r.start[0] + partpos : r.start[g];
+            long ln = g == 0 ? p : r.length[g];
+            long size = (long)genomes[g].seq.size();
+            if (st < 0 || st > size) fatal("region start outside genome");   // std::string::substr would throw
+            if (ln < 0) ln = 0;              // substr(pos, npos-like): the reference only builds such regions when slength > q
+            if (st + ln > size) ln = size - st;
+            q.start[g] = st; q.len[g] = ln;
+        }
+        out.push_back(std::move(q));
+        partpos += p;
+    }
+    return out;
+}
+
+void Aligner::run_batch(const std::vector<const Request*>& reqs, std::vector<Raw>* out) {
+    out->clear();
+    out->resize(reqs.size());
+    if (reqs.empty()) return;
+    double t0 = now_s();
+    std::vector<int64_t> starts(reqs.size() * n), lens(reqs.size() * n);
+    std::vector<int32_t> mins(reqs.size());
+    for (size_t i = 0; i < reqs.size(); i++) {
+        memcpy(&starts[i * n], reqs[i]->start.data(), n * 8);
+        memcpy(&lens[i * n], reqs[i]->len.data(), n * 8);
+        mins[i] = reqs[i]->minsize;
+    }
+    pm_result* res = nullptr;
+    int rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);
+    if (rc != PM_OK) fatal(std::string("multi-MUM engine failed: ") + pm_last_error());
+    const int64_t* off = pm_result_offsets(res);
+    const int32_t* k = pm_result_k(res);
+    const int32_t* lon = pm_result_lon(res);
+    const int64_t* sp = pm_result_sp(res);
+    const uint8_t* fw = pm_result_fwd(res);
+    const size_t q = n - 1;
+    for (size_t i = 0; i < reqs.size(); i++) {
+        Raw& r = (*out)[i];
+        size_t a = (size_t)off[i], b = (size_t)off[i + 1];
+        r.k.assign(k + a, k + b);
+        r.lon.assign(lon + a, lon + b);
+        r.sp.assign(sp + a * q, sp + b * q);
+        r.fwd.assign(fw + a * q, fw + b * q);
+    }
+    pm_result_free(res);
+    stats.finder_calls++;
+    stats.finder_regions += (long)reqs.size();
+    stats.finder_s += now_s() - t0;
+}
+
+// setMums1 for one region: minimum length, finder request(s), validation.
+void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accepted, bool speculative) {
+    int minsize = min_length(anchors, r.slength);
+    if (anchors) l = (float)minsize;
+    std::vector<Request> reqs = chunk_requests(r, minsize);
+    for (Request& q : reqs) {
+        std::string key = key_of(q);
+        auto it = cache_.find(key);
+        if (it == cache_.end()) {
+            if (speculative) {
+                if (wanted_keys_.emplace(key, (int)wanted_.size()).second) wanted_.push_back(q);
+                continue;
+            }
+            stats.cache_misses++;
+            std::vector<const Request*> one{&q};
+            std::vector<Raw> raw;
+            run_batch(one, &raw);
+            it = cache_.emplace(std::move(key), std::move(raw[0])).first;
+        } else if (!speculative) {
+            stats.cache_hits++;
+        }
+        validate(r, q, it->second, accepted);
+    }
+    if (!speculative) stats.regions_processed++;
+}
+
+// Candidate -> MUM: bounds, reverse-strand coordinate flip, overlap trimming against the layout, reverse-strand
+// sequence check, layout marking (parsnp.cpp:1717-1841, TMum ctor TMum.cpp:13-72).
+void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted) {
+    const size_t nq = n - 1;
+    std::vector<long> startpos(n);
+    for (size_t c = 0; c < raw.k.size(); c++) {
+        const long lon = raw.lon[c];
+        bool bad = false;
+        for (size_t j = 0; j < n; j++) {
+            unsigned long dsp = j == 0 ? (unsigned long)raw.k[c] + 1 + (unsigned long)q.ref_ini
+                                       : (unsigned long)raw.sp[c * nq + j - 1] + 1 + (unsigned long)r.start[j];
+            if (dsp - (unsigned long)r.start[j] > (unsigned long)(unsigned int)r.length[j]) bad = true;   // :1723
+            startpos[j] = (long)(dsp - 1);
+        }
+        if (bad) continue;
+        Mum m;
+        m.id = next_id_++;
+        m.length = lon;
+        m.start.resize(n); m.end.resize(n); m.fwd.resize(n);
+        bool ok = true;
+        for (size_t j = 0; j < n; j++) {
+            m.fwd[j] = j == 0 ? 1 : raw.fwd[c * nq + j - 1];
+            const long size = (long)genomes[j].seq.size();
+            // reverse strand: flipped against the WHOLE genome length even inside a sub-region (TMum.cpp:33-35)
+            m.start[j] = m.fwd[j] ? startpos[j] : size - (startpos[j] + lon);
+            if (m.start[j] + lon > size || m.start[j] < 0) ok = false;   // never for in-range candidates; the reference would misbehave
+            m.end[j] = m.start[j] + lon;
+        }
+        if (!ok || m.length < 5) continue;
+        trim(m);
+        if (m.length < 2 || m.start.size() <= 1) continue;
+        if (!m.fwd[0]) continue;
+        // reverse-strand members must spell the reverse complement of the reference member (:1791-1825)
+        const std::string& g0 = genomes[0].seq;
+        bool mismatch = false;
+        for (size_t j = 0; j < n && !mismatch; j++) {
+            if (m.fwd[j]) continue;
+            const std::string& gj = genomes[j].seq;
+            long l1 = m.start[j], l2 = m.length;
+            if (l1 > (long)gj.size() || m.start[0] > (long)g0.size()) fatal("MUM outside genome");
+            long have = std::min<long>(l2, (long)gj.size() - l1), have0 = std::min<long>(l2, (long)g0.size() - m.start[0]);
+            if (have != have0) { mismatch = true; break; }
+            for (long x = 0; x < have; x++) {
+                char cj = gj[(size_t)(l1 + have - 1 - x)], want;
+                switch (cj) { case 'A': want = 'T'; break; case 'C': want = 'G'; break; case 'G': want = 'C'; break;
+                              case 'T': want = 'A'; break; default: want = 'N'; }
+                if (g0[(size_t)(m.start[0] + x)] != want) { mismatch = true; break; }
+            }
+        }
+        if (mismatch) continue;
+        for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end[j]);
+        m.slength = r.slength;
+        pool.push_back(std::move(m));
+        accepted->push_back((int)pool.size() - 1);
+    }
+}
+
+// Overlap trimming against already marked bases: from the left, then from the right, genome by genome; every trim
+// shortens the MUM in ALL genomes (Aligner::trim :1399-1477, TMum::trimleft/right TMum.cpp:104-148).
+void Aligner::trim(Mum& m) const {
+    for (size_t j = 0; j < n; j++) {
+        for (long x = m.start[j]; x < m.end[j]; x++) {
+            if (!layout[j].get(x)) break;
+            for (size_t i = 0; i < n; i++) m.start[i] += 1;
+            m.length -= 1; m.slength -= 1;
+        }
+        for (long x = m.end[j] - 1; x >= m.start[j]; x--) {
+            if (!layout[j].get(x)) break;
+            for (size_t i = 0; i < n; i++) m.end[i] -= 1;
+            m.length -= 1; m.slength -= 1;
+        }
+    }
+}
+
+bool Aligner::find_anchors() {
+    double t0 = now_s();
+    std::vector<long> start(n, 0), end(n);
+    for (size_t i = 0; i < n; i++) end[i] = (long)genomes[i].seq.size();
+    Region whole = make_region(start, end);
+    std::vector<int> found;
+    std::cerr << std::endl << "        Constructing device index of the reference...\n";
+    std::cerr << "        Performing initial search for exact matches in the sequences...\n";
+    region_mums(whole, true, &found, false);
+    mums = found;
+    m0 = (long)found.size();
+    // seed regions: left and right neighbour of every anchor, longer than q in every genome (:2150-2172)
+    Region lR, rR;
+    bool have_r = false;
+    for (size_t i = 0; i < found.size(); i++) {
+        lR = neighbour_region(pool[found[i]], true);
+        if (lR.slength > prm.q && (i == 0 || !(have_r && lR.same_as(rR)))) regions.push_back(lR);
+        rR = neighbour_region(pool[found[i]], false);
+        have_r = true;
+        if (rR.slength > prm.q && !rR.same_as(lR)) regions.push_back(rR);
+    }
+    stats.anchor_s = now_s() - t0;
+    return m0 != 0;
+}
+
+// One pass of the reference's work-list loop (doWork :192-308).  Work-list entries are handles into `rpool`.
+bool Aligner::extend_pass(bool speculative) {
+    std::vector<Region> rpool = std::move(regions);
+    regions.clear();
+    std::vector<Handle> work;
+    work.reserve(rpool.size());
+    for (size_t i = 0; i < rpool.size(); i++) work.push_back(Handle{rpool[i].start[0], (int)i});
+    size_t head = 0;
+    std::vector<int> found;
+    while (head < work.size()) {
+        const int cur = work[head++].idx;
+        found.clear();
+        {
+            Region curRegion = rpool[(size_t)cur];   // the pool may grow below
+            region_mums(curRegion, false, &found, speculative);
+        }
+        Region lR, rR;
+        for (size_t i = 0; i < found.size(); i++) {
+            if (i == 0) lR = neighbour_region(pool[found[0]], true);
+            rR = neighbour_region(pool[found[i]], false);
+            if (lR.slength > prm.q) { rpool.push_back(lR); work.push_back(Handle{lR.start[0], (int)rpool.size() - 1}); }
+            if (rR.slength > prm.q) { rpool.push_back(rR); work.push_back(Handle{rR.start[0], (int)rpool.size() - 1}); }
+            if (i + 1 < found.size()) lR = neighbour_region(pool[found[i + 1]], true);
+            mums.push_back(found[i]);
+        }
+        if (head < work.size()) std::sort(work.begin() + (long)head, work.end());
+        // drop a region equal to its successor (adjacent duplicates only, :294-306)
+        long rsize = (long)(work.size() - head);
+        if (rsize) {
+            for (long x = 0; x < rsize - 1; x++) {
+                if (rpool[(size_t)work[head + (size_t)x].idx].same_as(rpool[(size_t)work[head + (size_t)x + 1].idx])) {
+                    work.erase(work.begin() + (long)head + x);
+                    x -= 1; rsize -= 1;
+                }
+            }
+        }
+    }
+    return !mums.empty();
+}
+
+bool Aligner::extend() {
+    double t0 = now_s();
+    if (getenv("PARSNP_NO_SPECULATION") == nullptr) {
+        // Speculative breadth-first sweep: discover the regions the exact replay below will ask for, generation by
+        // generation, and compute each generation in ONE batched engine call.  Everything it does to the layout, the
+        // MUM pool and the work list is undone afterwards; only the cache of raw engine results (a pure function of
+        // the request coordinates) survives.  The reference's processing order is observable, so the
+        // authoritative pass is the in-order replay that follows; a request the sweep did not predict is computed on
+        // demand there.
+        for (size_t i = 0; i < n; i++) layout[i].begin_log();
+        const std::vector<Region> saved_regions = regions;
+        const std::vector<int> saved_mums = mums;
+        const size_t saved_pool = pool.size();
+        const long saved_id = next_id_;
+        std::vector<Region> gen = regions;
+        while (!gen.empty()) {
+            stats.spec_rounds++;
+            wanted_.clear(); wanted_keys_.clear();
+            for (const Region& r : gen) {
+                int minsize = min_length(false, r.slength);
+                for (Request& q : chunk_requests(r, minsize)) {
+                    std::string key = key_of(q);
+                    if (cache_.count(key)) continue;
+                    if (wanted_keys_.emplace(std::move(key), (int)wanted_.size()).second) wanted_.push_back(std::move(q));
+                }
+            }
+            std::vector<const Request*> ptrs;
+            for (const Request& q : wanted_) ptrs.push_back(&q);
+            std::vector<Raw> raws;
+            run_batch(ptrs, &raws);
+            for (size_t i = 0; i < wanted_.size(); i++) cache_.emplace(key_of(wanted_[i]), std::move(raws[i]));
+            std::vector<Region> next;
+            std::vector<int> found;
+            for (const Region& r : gen) {
+                found.clear();
+                region_mums(r, false, &found, true);
+                for (size_t i = 0; i < found.size(); i++) {
+                    Region a = neighbour_region(pool[found[i]], true), b = neighbour_region(pool[found[i]], false);
+                    if (a.slength > prm.q) next.push_back(std::move(a));
+                    if (b.slength > prm.q) next.push_back(std::move(b));
+                }
+            }
+            // same clean-up the reference applies to its work list: order by reference start, drop adjacent duplicates
+            std::stable_sort(next.begin(), next.end(), [](const Region& x, const Region& y) { return x.start[0] < y.start[0]; });
+            gen.clear();
+            for (Region& r : next)
+                if (gen.empty() || !gen.back().same_as(r)) gen.push_back(std::move(r));
+        }
+        for (size_t i = 0; i < n; i++) { layout[i].rollback(); layout[i].end_log(); }
+        pool.resize(saved_pool);
+        next_id_ = saved_id;
+        mums = saved_mums;
+        regions = saved_regions;
+        wanted_.clear(); wanted_keys_.clear();
+    }
+    bool any = extend_pass(false);
+    cache_.clear();
+    stats.extend_s = now_s() - t0;
+    return any;
+}
+
+// filterRandom1 (:327-425): a MUM no longer than rvalue survives only if it is collinear (0..5000 bases, no marked
+// base in between) with its successor -- and, when it has one, its predecessor -- in every genome.
+void Aligner::filter_mums(int rvalue) {
+    double t0 = now_s();
+    {
+        std::vector<Handle> h(mums.size());
+        for (size_t i = 0; i < mums.size(); i++) h[i] = Handle{pool[(size_t)mums[i]].start[0], mums[i]};
+        std::sort(h.begin(), h.end());
+        for (size_t i = 0; i < mums.size(); i++) mums[i] = h[i].idx;
+    }
+    long numums = (long)mums.size();
+    for (long x = 0; x < numums - 1; x++) {
+        const Mum& mt = pool[(size_t)mums[(size_t)x]];
+        if (mt.length > rvalue) continue;
+        const Mum& nt = pool[(size_t)mums[(size_t)x + 1]];
+        const Mum* prev = x > 0 ? &pool[(size_t)mums[(size_t)x - 1]] : nullptr;
+        bool adjacent = nt.start.size() >= n;
+        for (size_t k = 0; k < n && adjacent; k++) {
+            long gap = labs(nt.start[k]) - labs(mt.end[k]);
+            if (gap < 0 || gap > 5000) { adjacent = false; break; }
+            for (int m = (int)mt.end[k] + 1; m < nt.start[k]; m++)
+                if (layout[k].get(m)) { adjacent = false; break; }
+            if (prev) {
+                long pgap = labs(mt.start[k]) - labs(prev->end[k]);
+                if (pgap < 0 || pgap > 5000) { adjacent = false; break; }
+                for (int m = (int)prev->end[k] + 1; m < mt.start[k]; m++)
+                    if (layout[k].get(m)) { adjacent = false; break; }
+            }
+        }
+        if (!adjacent) {
+            filtered += 1;
+            for (size_t k = 0; k < n; k++) layout[k].clear_range(mt.start[k], mt.end[k]);
+            mums.erase(mums.begin() + x);
+            x -= 1; numums -= 1;
+        }
+    }
+    stats.filter_s += now_s() - t0;
+}
+
+static Lcb lcb_of(const std::vector<Mum>& pool, int idx, int type = 1) {   // Cluster(TMum), LCB.cpp:21-28
+    Lcb c;
+    c.type = type;
+    c.mums.push_back(idx);
+    c.start = pool[(size_t)idx].start;
+    c.end = pool[(size_t)idx].end;
+    c.length = pool[(size_t)idx].length;
+    return c;
+}
+
+// Greedy collinear chaining of the MUMs in reference order (setFinalClusters :2563-2719).  The float32 / double
+// mix of the gap-ratio test is the reference's.
+void Aligner::chain() {
+    double t0 = now_s();
+    lcbs.clear();
+    {
+        std::vector<Handle> h(mums.size());
+        for (size_t i = 0; i < mums.size(); i++) h[i] = Handle{pool[(size_t)mums[i]].start[0], mums[i]};
+        std::sort(h.begin(), h.end());
+        for (size_t i = 0; i < mums.size(); i++) mums[i] = h[i].idx;
+    }
+    if (mums.empty()) return;
+    Lcb cluster = lcb_of(pool, mums[0]);
+    bool addmum = true;
+    const int d = prm.d;
+    const float diag_diff = prm.diag_diff;
+    for (size_t x = 1; x < mums.size(); x++) {
+        const Mum& nt = pool[(size_t)mums[x]];
+        if (nt.length < random) { addmum = true; continue; }
+        if (!addmum) cluster = lcb_of(pool, mums[x - 1]);
+        addmum = true;
+        float max_gap = 0;
+        float min_gap = d + 10;
+        const Mum& back = pool[(size_t)cluster.mums.back()];
+        const Mum& front = pool[(size_t)cluster.mums.front()];
+        for (size_t k = 0; k < n; k++) {
+            const long fgap = nt.start[k] - cluster.end[k];      // forward: next start - chain end
+            const long rgap = back.start[k] - nt.end[k];         // reverse: previous MUM start - next end
+            const bool f = nt.fwd[k] != 0;
+            if (f && fgap > max_gap) max_gap = fgap;
+            else if (!f && rgap > max_gap) max_gap = fgap;       // sic (:2608-2611)
+            if (f && fgap < min_gap) min_gap = fgap;
+            else if (!f && rgap < min_gap) min_gap = rgap;
+            if ((nt.fwd[k] != back.fwd[k]) || (nt.fwd[k] != front.fwd[k])) addmum = false;
+            else if (f && fgap < 0) addmum = false;
+            else if (!f && fgap >= 0) addmum = false;
+            else if (f && fgap > d) addmum = false;
+            else if (!f && rgap > d) addmum = false;
+            if (!addmum) break;
+        }
+        if (addmum) {
+            if (min_gap == 0) min_gap = 1;
+            if (max_gap == 0) max_gap = 1;
+            bool join;
+            if (diag_diff > 1.0) {
+                join = max_gap - min_gap < diag_diff;
+                if (!join) continue;   // neither joined nor closed: the MUM is passed over (:2684-2692)
+            } else {
+                join = min_gap / max_gap >= 1.0 - diag_diff;
+            }
+            if (join) {
+                cluster.end = nt.end;
+                cluster.length += nt.length;
+                cluster.mums.push_back(mums[x]);
+            } else {
+                addmum = false;
+                lcbs.push_back(cluster);
+            }
+        } else {
+            lcbs.push_back(cluster);
+        }
+    }
+    if (!addmum) cluster = lcb_of(pool, mums.back());
+    lcbs.push_back(cluster);
+    stats.lcb_s += now_s() - t0;
+}
+
+static void sort_lcbs(std::vector<Lcb>& v) {
+    std::vector<Handle> h(v.size());
+    for (size_t i = 0; i < v.size(); i++) h[i] = Handle{v[i].start[0], (int)i};
+    std::sort(h.begin(), h.end());
+    std::vector<Lcb> out;
+    out.reserve(v.size());
+    for (auto& x : h) out.push_back(std::move(v[(size_t)x.idx]));
+    v.swap(out);
+}
+
+// filterRandomClustersSimple1 (:433-497): LCBs whose MUM lengths sum to <= c are dissolved (the last one is never
+// examined); their MUMs leave the layout and the MUM list.
+void Aligner::filter_lcbs() {
+    double t0 = now_s();
+    sort_lcbs(lcbs);
+    long count = (long)lcbs.size();
+    for (long x = 0; x < count - 1; x++) {
+        if (lcbs[(size_t)x].length > prm.c) continue;
+        filtered_lcbs += 1;
+        for (int idx : lcbs[(size_t)x].mums) {
+            filtered += 1;
+            const Mum& mt = pool[(size_t)idx];
+            for (size_t k = 0; k < n; k++) layout[k].clear_range(mt.start[k], mt.end[k]);
+            auto it = std::find(mums.begin(), mums.end(), idx);   // first MUM with that id
+            if (it != mums.end()) mums.erase(it);
+        }
+        lcbs.erase(lcbs.begin() + x);
+        x -= 1; count -= 1;
+    }
+    stats.lcb_s += now_s() - t0;
+}
+
+// setInterClusterRegions (:2389-2460): between consecutive LCBs that do not overlap in any genome, a type-0 filler
+// from the end of the first to the next marked base is PREPENDED; fillers are never printed but shift LCB numbers.
+void Aligner::fill_between() {
+    double t0 = now_s();
+    sort_lcbs(lcbs);
+    std::vector<Lcb> fillers;
+    for (size_t x = 0; x + 1 < lcbs.size(); x++) {
+        const Lcb& ct = lcbs[x];
+        const Lcb& nx = lcbs[x + 1];
+        bool add = true;
+        std::vector<long> start, end;
+        int flag = 0;
+        for (size_t a = 0; a < n; a++) {
+            if (nx.start[a] - ct.end[a] <= 0) { add = false; break; }
+            long stop = (long)genomes[a].seq.size();
+            start.push_back(ct.end[a]);
+            if (ct.end[a] + 1 <= stop) {            // the scan runs: first marked base in (end, stop]; [stop] is the sentinel
+                long m = layout[a].next_set(ct.end[a] + 1);
+                flag = 1;
+                end.push_back(m - 1);
+            } else if (!flag) {                     // scan did not run: the flag of the previous genome decides (:2419-2433)
+                end.push_back(stop - 1);
+            }
+        }
+        if (!add) continue;
+        if (end.size() != n) fatal("inter-cluster region bookkeeping would overrun in the reference");
+        Lcb f;
+        f.type = 0;
+        f.start = start;
+        f.end.resize(n);
+        for (size_t a = 0; a < n; a++) f.end[a] = end[a] + 1;   // Cluster(bmum,0).addMum(emum): end = emum.end = end+1
+        f.length = 2;
+        for (size_t a = 0; a < n; a++)
+            if (f.end[a] - f.start[a] < 5) { add = false; break; }
+        if (add) fillers.push_back(std::move(f));
+    }
+    lcbs.insert(lcbs.begin(), fillers.begin(), fillers.end());
+    stats.lcb_s += now_s() - t0;
+}
+
+}  // namespace parsnp

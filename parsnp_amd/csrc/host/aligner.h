@@ -1,0 +1,156 @@
+// aligner.h -- host side of the parsnp_core replacement: everything of the reference's Aligner that sits
+// AROUND the csgmum calls (the csgmum work itself runs on the GPU behind include/parsnp_mum.h).
+//
+// Reference map (all src/parsnp.cpp unless noted):
+//   Genome / ingest()          main() FASTA loop                      :2913-3160
+//   Bitmap                     mumlayout (vector<vector<bool>>)       :3181-3186
+//   Mum                        TMum                                   src/TMum.cpp:8-162
+//   Region                     TRegion                                src/LCR.cpp:12-58
+//   Lcb                        Cluster                                src/LCB.cpp:8-57
+//   Aligner::find_anchors      setInitialClusters()                   :2121-2174
+//   Aligner::validate          setMums1, second half                  :1713-1841
+//   Aligner::trim              trim                                   :1399-1477
+//   Aligner::neighbour_region  determineRegion                        :1199-1290
+//   Aligner::extend            doWork                                 :173-317
+//   Aligner::filter_mums       filterRandom1                          :327-425
+//   Aligner::chain             setFinalClusters()                     :2563-2719
+//   Aligner::filter_lcbs       filterRandomClustersSimple1            :433-497
+//   Aligner::fill_between      setInterClusterRegions                 :2389-2460
+//   write_output               writeOutput                            :505-1191
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/parsnp_mum.h"
+
+namespace parsnp {
+
+struct Params {
+    int c = 0, d = 0, q = 0, p = 0, do_align = 0, cores = 2, random = 0;
+    bool unaligned = false, recomb_filter = false, anchors_only = false, calc_mumi = false, extend_mums = false;
+    float diag_diff = 1.0f, factor = 0.0f;
+    std::string anchors, mums, anchorfile, mumfile, prefix, outdir;
+};
+
+struct Genome {
+    std::string path, fname, header;   // files / fasta / headers of the reference's Aligner
+    std::string seq;                   // 'A','C','G','T','N' only; query contigs joined by d+10 'N'
+    int size_nopad = 0;                // genome_sizes: length without the contig padding
+    float gc = 0, at = 0;              // gcCount / atCount
+    std::map<int, std::string> pos2hdr;
+};
+// returns false (after printing the reference's message) when the file cannot be opened
+bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* out);
+
+// n+1 bits per genome, bit [n] is the sentinel (parsnp.cpp:3184-3185)
+class Bitmap {
+public:
+    void init(size_t nbits_with_sentinel);
+    bool get(long i) const { return (w_[(size_t)i >> 6] >> (i & 63)) & 1; }
+    void set_range(long a, long b);     // [a,b) := 1
+    void clear_range(long a, long b);   // [a,b) := 0
+    long next_set(long from) const;     // smallest i >= from with bit set; the sentinel guarantees one for from <= n
+    long prev_set(long from) const;     // largest i <= from with bit set, or -1
+    size_t bits() const { return nbits_; }
+    // undo log support (speculative replay): words changed since begin_log() are restored by rollback()
+    void begin_log() { logging_ = true; log_.clear(); }
+    void rollback();
+    void end_log() { logging_ = false; log_.clear(); }
+private:
+    std::vector<uint64_t> w_;
+    size_t nbits_ = 0;
+    bool logging_ = false;
+    std::vector<std::pair<size_t, uint64_t>> log_;
+    inline void store(size_t wi, uint64_t v) { if (logging_ && w_[wi] != v) log_.emplace_back(wi, w_[wi]); w_[wi] = v; }
+};
+
+struct Mum {
+    long id = 0;
+    long length = 0;
+    long slength = 0;
+    std::vector<long> start, end;
+    std::vector<int> fwd;
+};
+
+struct Region {
+    std::vector<long> start, end, length;
+    long slength = 0, llength = 0;
+    bool same_as(const Region& o) const;   // TRegion operator== (LCR.cpp:48-58)
+};
+
+struct Lcb {
+    int type = 1;
+    std::vector<int> mums;         // indices into Aligner::pool
+    std::vector<long> start, end;
+    long length = 0;
+};
+
+// raw candidate list of one finder request (one reference chunk of one region)
+struct Raw {
+    std::vector<int32_t> k, lon;
+    std::vector<int64_t> sp;
+    std::vector<uint8_t> fwd;
+};
+
+struct Stats {   // wall-clock split reported next to the reference's own phase timers
+    double anchor_s = 0, extend_s = 0, filter_s = 0, lcb_s = 0, finder_s = 0;
+    long finder_calls = 0, finder_regions = 0, regions_processed = 0, cache_hits = 0, cache_misses = 0, spec_rounds = 0;
+};
+
+class Aligner {
+public:
+    Aligner(std::vector<Genome>& genomes, const Params& prm, pm_session* session);
+    size_t n;
+    Params prm;
+    std::vector<Genome>& genomes;
+    std::vector<Bitmap> layout;
+    std::vector<Mum> pool;        // every MUM ever accepted; `mums` and Lcb::mums index into it
+    std::vector<int> mums;        // this->mums of the reference, in its order
+    std::vector<Lcb> lcbs;        // this->clusters
+    std::vector<Region> regions;  // this->regions (work list of extend())
+    float l = 0;                  // anchor min length ("Mum anchor size")
+    long m0 = 0, filtered = 0, filtered_lcbs = 0;
+    int random = 0;
+    float anchor_time = 0, coarsen_time = 0, random_time = 0, clusters_time = 0, iclusters_time = 0;
+    Stats stats;
+
+    bool find_anchors();       // returns m0 != 0
+    bool extend();             // returns !mums.empty()
+    void filter_mums(int rvalue);
+    void chain();
+    void filter_lcbs();
+    void fill_between();
+
+    Region neighbour_region(const Mum& m, bool left) const;
+
+private:
+    pm_session* session_;
+    long next_id_ = 1;
+    // --- finder plumbing -------------------------------------------------------------------------------------
+    struct Request { std::vector<int64_t> start, len; int32_t minsize; int64_t ref_ini; };
+    std::vector<Request> chunk_requests(const Region& r, int minsize) const;   // the p-chunk loop, :1519-1547
+    void run_batch(const std::vector<const Request*>& reqs, std::vector<Raw>* out);
+    // cache of raw results keyed by request coordinates (results are a pure function of them)
+    std::unordered_map<std::string, Raw> cache_;
+    static std::string key_of(const Request& q);
+    // --- setMums1 ---------------------------------------------------------------------------------------------
+    int min_length(bool anchors, long slength) const;
+    // finder for one region + validate(); `speculative`: a missing cache entry is recorded in `wanted_` and the
+    // region is treated as yielding nothing instead of calling the GPU.
+    void region_mums(const Region& r, bool anchors, std::vector<int>* accepted, bool speculative);
+    void validate(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted);
+    void trim(Mum& m) const;
+    bool extend_pass(bool speculative);
+    std::vector<Request> wanted_;
+    std::unordered_map<std::string, int> wanted_keys_;
+};
+
+// XMFA + log (writeOutput).  gap_note: set when at least one inter-MUM gap needed the (absent) MUSCLE aligner.
+void write_output(Aligner& a, const std::string& stem, bool* gap_note);
+
+std::string reverse_complement(const std::string& s);   // Aligner::reversec, :1294-1393
+
+}  // namespace parsnp

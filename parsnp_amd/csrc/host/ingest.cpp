@@ -1,0 +1,116 @@
+// ingest.cpp -- FASTA -> in-memory genome, behaviour of the reference's main() loop (src/parsnp.cpp:2913-3160).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "aligner.h"
+
+namespace parsnp {
+
+namespace {
+// what one sequence byte does (switch at parsnp.cpp:3003-3132, evaluated on toupper(ch))
+enum Act : uint8_t { SKIP = 0, BASE_A, BASE_C, BASE_G, BASE_T, BASE_U, BASE_N, HEADER };
+struct Table {
+    uint8_t act[256];
+    Table() {
+        memset(act, SKIP, sizeof act);
+        for (int c = 0; c < 256; c++) {
+            switch (toupper(c)) {
+                case 'A': act[c] = BASE_A; break;
+                case 'C': act[c] = BASE_C; break;
+                case 'G': act[c] = BASE_G; break;
+                case 'T': act[c] = BASE_T; break;
+                case 'U': act[c] = BASE_U; break;
+                case 'X': case 'Y': case 'S': case 'W': case 'K': case 'H': case 'R': case 'M': case 'V': case 'D':
+                case 'B': case '-': case 'N': act[c] = BASE_N; break;
+                case '>': act[c] = HEADER; break;
+                default: break;   // '\n', '\t', ' ' and every other byte are dropped
+            }
+        }
+    }
+};
+const Table kTable;
+}  // namespace
+
+bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* g) {
+    g->path = path;
+    size_t slash = path.rfind('/');
+    g->fname = slash == std::string::npos ? path : path.substr(slash + 1);
+    std::ifstream f(path.c_str(), std::ios::binary);
+    if (!f) {
+        if (is_ref) std::cout << " Cannot open reference file ! " << std::endl;
+        else std::cout << " Cannot open query file: " << path << std::endl;
+        return false;
+    }
+    std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    f.close();
+
+    const size_t kLine = 2499;   // getline(buf, 2500): at most 2499 bytes, longer lines put the stream in fail state
+    size_t pos = 0;
+    bool failed = false;
+    auto read_line = [&](std::string* out) {
+        size_t nl = data.find('\n', pos);
+        size_t end = nl == std::string::npos ? data.size() : nl;
+        if (end - pos > kLine) { if (out) *out = data.substr(pos, kLine); failed = true; pos += kLine; return; }
+        if (out) *out = data.substr(pos, end - pos);
+        if (nl == std::string::npos) { if (end == pos) failed = true; pos = data.size(); }   // EOF with nothing read: failbit
+        else pos = nl + 1;
+    };
+    read_line(&g->header);
+    g->pos2hdr.clear();
+    g->pos2hdr[1] = "s1";
+
+    long long a = 0, c = 0, gg = 0, t = 0, nn = 0;
+    int padding = 0;
+    unsigned seqcount = 1;
+    std::string& s = g->seq;
+    s.clear();
+    s.reserve(data.size() > pos ? data.size() - pos + 1024 : 1024);
+    while (pos < data.size() && !failed) {
+        unsigned char ch = (unsigned char)data[pos++];
+        switch (kTable.act[ch]) {
+            case BASE_A: a++; s.push_back(reverse ? 'T' : 'A'); break;
+            case BASE_C: c++; s.push_back(reverse ? 'G' : 'C'); break;
+            case BASE_G: gg++; s.push_back(reverse ? 'C' : 'G'); break;
+            case BASE_T: t++; s.push_back(reverse ? 'A' : 'T'); break;
+            case BASE_U: t++; s.push_back('T'); break;          // not complemented (parsnp.cpp:3066-3069)
+            case BASE_N: nn++; s.push_back('N'); break;
+            case HEADER: {
+                read_line(nullptr);
+                if (!is_ref) { s.append((size_t)(d + 10), 'N'); nn += d + 10; padding += d + 10; }   // :3114-3118
+                seqcount++;
+                g->pos2hdr[(int)(nn + c + t + a + gg)] = "s" + std::to_string(seqcount);
+                break;
+            }
+            default: break;
+        }
+    }
+    if (reverse) std::reverse(s.begin(), s.end());
+    g->size_nopad = (int)s.size() - padding;
+    g->gc = float(gg) + float(c);
+    g->at = float(a) + float(t);
+    std::cout << g->fname << ",Len:" << s.size() << ",GC:" << ((float(gg) + float(c)) / float(s.size() - nn)) * 100 << std::endl;
+    return true;
+}
+
+std::string reverse_complement(const std::string& in) {
+    std::string out;
+    out.reserve(in.size());
+    for (char ch : in) {
+        switch (toupper((unsigned char)ch)) {
+            case 'A': out.push_back('T'); break;
+            case 'C': out.push_back('G'); break;
+            case 'G': out.push_back('C'); break;
+            case 'T': case 'U': out.push_back(toupper((unsigned char)ch) == 'T' ? 'A' : 'T'); break;
+            case '\r': case '\n': case '\t': case ' ': case '>': case '.': break;   // dropped (parsnp.cpp:1369-1380)
+            default: out.push_back('N'); break;
+        }
+    }
+    std::reverse(out.begin(), out.end());
+    return out;
+}
+
+}  // namespace parsnp

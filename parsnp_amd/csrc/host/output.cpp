@@ -1,0 +1,252 @@
+// output.cpp -- parsnpAligner.xmfa + parsnpAligner.log, the output contract of the reference's
+// Aligner::writeOutput (src/parsnp.cpp:505-1191).  MUM columns are lower case, inter-MUM gap columns upper case.
+// Gaps in which every genome has >= 1 base and some genome has >= 2 go to libMUSCLE in the reference
+// (:790-865, src/MuscleInterface.cpp:37-78); that aligner is outside this project's hot path, so such
+// gaps are emitted left-justified and '-'-padded and the log carries a note.  Every other byte of both files is the
+// reference's.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+#include "aligner.h"
+
+namespace parsnp {
+
+namespace {
+std::string lower(std::string s) { std::transform(s.begin(), s.end(), s.begin(), ::tolower); return s; }
+std::string upper(std::string s) { std::transform(s.begin(), s.end(), s.begin(), ::toupper); return s; }
+std::string sub(const std::string& g, long pos, long len) {   // std::string::substr semantics incl. size_t wrap of len
+    if (pos < 0 || (size_t)pos > g.size()) { std::cerr << "parsnp_core: substr out of range" << std::endl; exit(1); }
+    return g.substr((size_t)pos, (size_t)len);
+}
+
+// rows of one LCB: MUMs interleaved with the gaps between consecutive MUMs (:663-916)
+void build_rows(const Aligner& a, const Lcb& ct, std::vector<std::string>* rows, bool* gap_note) {
+    const size_t n = a.n;
+    rows->assign(n, "");
+    const Mum& first = a.pool[(size_t)ct.mums[0]];
+    auto mum_text = [&](const Mum& m, size_t i) {
+        std::string t = sub(a.genomes[i].seq, m.start[i], m.length);
+        return lower(first.fwd[i] ? t : reverse_complement(t));
+    };
+    for (size_t t = 0; t < ct.mums.size(); t++) {
+        const Mum& m = a.pool[(size_t)ct.mums[t]];
+        const bool last = t + 1 == ct.mums.size();
+        for (size_t i = 0; i < n; i++) (*rows)[i] += mum_text(m, i);
+        if (last) break;
+        const Mum& nx = a.pool[(size_t)ct.mums[t + 1]];
+        std::vector<std::string> gap(n);
+        unsigned max_len = 0, min_len = 1000000;
+        for (size_t i = 0; i < n; i++) {
+            const std::string& g = a.genomes[i].seq;
+            if (!first.fwd[i]) {
+                if (m.start[i] - nx.end[i] >= 1) gap[i] = upper(reverse_complement(sub(g, nx.end[i], m.start[i] - nx.end[i])));
+            } else {
+                gap[i] = upper(sub(g, m.end[i], nx.start[i] - m.end[i]));
+            }
+            if (gap[i].size() > max_len) max_len = (unsigned)gap[i].size();
+            if (gap[i].size() < min_len) min_len = (unsigned)gap[i].size();
+        }
+        if (max_len > 1 && min_len > 0) {
+            // reference: MUSCLE(maxiters=1) over the n gap strings.  Here: unaligned, padded to the longest.
+            *gap_note = true;
+            for (size_t i = 0; i < n; i++) (*rows)[i] += gap[i] + std::string(max_len - gap[i].size(), '-');
+        } else if (max_len > 0) {
+            for (size_t i = 0; i < n; i++) (*rows)[i] += gap[i] + std::string(max_len - gap[i].size(), '-');
+        }
+    }
+}
+}  // namespace
+
+void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
+    using namespace std;
+    const size_t n = a.n;
+    const Params& prm = a.prm;
+    if (prm.do_align) cerr << "Writing output files & aligning LCBs..." << endl;
+    const string dir = prm.outdir + "/";
+    {
+        ofstream probe((dir + "parsnpAligner.log").c_str());
+        if (!probe.good()) {
+            if (system(("mkdir " + prm.outdir).c_str())) {
+                cerr << "ParSNP:: error creating output directory, exiting.." << endl;
+                exit(1);
+            }
+        }
+    }
+    if (prm.recomb_filter) { int rc = system(("mkdir " + dir + "blocks/").c_str()); (void)rc; }
+    ofstream xmfa((dir + stem + ".xmfa").c_str());
+    ofstream log((dir + stem + ".log").c_str());
+    { ofstream allmums("allmums.out"); }   // the reference leaves an empty file in the cwd (:600-601)
+
+    int printable = 0;
+    for (const Lcb& c : a.lcbs) if (c.type == 1) printable++;
+    xmfa << "#FormatVersion Mauve" << endl;
+    xmfa << "#SequenceCount " << (int)n << endl;
+    for (size_t i = 0; i < n; i++) {
+        xmfa << "##SequenceIndex " << i + 1 << endl;
+        xmfa << "##SequenceFile " << a.genomes[i].fname << endl;
+        xmfa << "##SequenceHeader " << a.genomes[i].header << endl;
+        xmfa << "##SequenceLength " << a.genomes[i].size_nopad << "bp" << endl;
+    }
+    xmfa << "#IntervalCount " << printable << endl;
+
+    // rows of every printable LCB (the reference does this under OpenMP; rows are independent)
+    vector<vector<string>> rows(a.lcbs.size());
+    vector<char> notes(a.lcbs.size(), 0);
+    const long nl = (long)a.lcbs.size();
+#pragma omp parallel for schedule(dynamic) num_threads(prm.cores > 0 ? prm.cores : 1)
+    for (long z = 0; z < nl; z++) {
+        const Lcb& ct = a.lcbs[(size_t)z];
+        rows[(size_t)z].assign(n, "");
+        if (ct.type == 1 && !ct.mums.empty() && prm.do_align != 0) {
+            bool note = false;
+            build_rows(a, ct, &rows[(size_t)z], &note);
+            notes[(size_t)z] = note;
+        }
+    }
+    for (char c : notes) if (c) *gap_note = true;
+
+    int prev_end = 0;
+    for (size_t z = 0; z < a.lcbs.size(); z++) {
+        Lcb ct = a.lcbs[z];
+        vector<string>& row = rows[z];
+        if (!(ct.type == 1 && !ct.mums.empty() && prm.do_align != 0 && row[0].size() > (size_t)(prm.c * 1))) continue;
+        // trim the overlap with the previous printed LCB on the reference (:928-952, quirks kept: the column scan
+        // never advances, and the start shift counts the non-gap columns of the whole reference row -- for genomes
+        // after the first through the already shortened row 0, whose buffer still holds the old tail)
+        int lcb_start = (int)ct.start[0] + 1, lcb_end = (int)ct.end[0];
+        int overlap = std::max(0, prev_end - lcb_start);
+        if (overlap > 0) {
+            if (row[0].empty() || row[0][0] == '-') { cerr << "parsnp_core: overlap trim would not terminate in the reference" << endl; exit(1); }
+            const int cols = overlap;
+            const string orig0 = row[0];
+            const size_t newsize = orig0.size() > (size_t)cols ? orig0.size() - (size_t)cols : 0;
+            auto stale0 = [&](size_t pos) -> char {   // row 0 as the reference sees it after its erase(0, cols)
+                if (pos < newsize) return orig0[pos + (size_t)cols];
+                if (pos == newsize) return '\0';
+                return pos < orig0.size() ? orig0[pos] : '\0';
+            };
+            for (size_t i = 0; i < n; i++) {
+                int count = 0;
+                for (size_t pos = 0; pos < row[i].size(); pos++) {
+                    char ch = i == 0 ? (pos < orig0.size() ? orig0[pos] : '\0') : stale0(pos);
+                    if (ch != '-') count++;
+                }
+                ct.start[i] += count;
+                row[i].erase(0, (size_t)cols);
+            }
+        }
+        prev_end = lcb_end;
+        if (!(row[0].size() > (size_t)(prm.c * 1))) continue;
+        char b[16];
+        snprintf(b, sizeof b, "%d", (int)z + 1);
+        ofstream block;
+        if (prm.recomb_filter) {
+            string bdir = dir + "blocks/b" + b;
+            int rc = system(("mkdir -p " + bdir).c_str()); (void)rc;
+            block.open((bdir + "/seq.fna").c_str());
+        }
+        const Mum& first = a.pool[(size_t)ct.mums.front()];
+        const Mum& lastm = a.pool[(size_t)ct.mums.back()];
+        for (size_t i = 0; i < n; i++) {
+            std::ostringstream hd;
+            if (first.fwd[i]) hd << "> " << i + 1 << ":" << ct.start[i] + 1 << "-" << ct.end[i] << " ";
+            else hd << "> " << i + 1 << ":" << lastm.start[i] + 1 << "-" << first.end[i] << " ";
+            // contig label and offset: last pos2hdr entry at or before the LCB start (:994-1037)
+            bool hit = false;
+            string hdr, lasthdr;
+            int seqstart = 0, laststart = 0;
+            bool closed = false;
+            for (const auto& kv : a.genomes[i].pos2hdr) {
+                if (hit && ct.start[i] < kv.first) { closed = true; break; }
+                else if (ct.start[i] >= kv.first) { hit = true; laststart = kv.first; lasthdr = kv.second; }
+            }
+            (void)closed;
+            if (hit) { hdr = lasthdr; seqstart = laststart; }
+            int offset = 0;
+            if (hdr == "") { hdr = "s1"; offset = -1; }
+            else if (hdr != "s1") offset = -1;
+            if (!first.fwd[i]) hd << "- cluster" << b << " " << hdr << ":p" << (ct.start[i] - seqstart) + 1 + first.length + offset;
+            else hd << "+ cluster" << b << " " << hdr << ":p" << (ct.start[i] - seqstart) + 1 + offset;
+            xmfa << hd.str() << endl;
+            if (prm.recomb_filter) block << hd.str() << endl;
+            const string& s = row[i];
+            size_t k = 0;
+            const size_t width = 80;
+            for (; k + width < s.size(); k += width) {
+                xmfa << s.substr(k, width) << endl;
+                if (prm.recomb_filter) block << s.substr(k, width) << endl;
+            }
+            xmfa << s.substr(k) << endl;
+            if (prm.recomb_filter) block << s.substr(k) << endl;
+        }
+        xmfa << "=" << endl;
+    }
+
+    // ---- log (:1082-1190); stream flags are sticky exactly as in the reference
+    log << "Number of sequences analyzed:" << setiosflags(ios::fixed) << setprecision(1) << setw(10) << n << endl << endl;
+    for (size_t i = 0; i < n; i++) {
+        log << "Sequence " << i + 1 << " : " << a.genomes[i].path << endl;
+        log << a.genomes[i].fname << endl;
+        log << "Length:" << setw(10) << a.genomes[i].size_nopad << " bps" << endl;
+        log << " GC:" << setw(10) << setiosflags(ios::fixed) << setprecision(1) << a.genomes[i].gc << endl;
+        log << " AT:" << setw(10) << setiosflags(ios::fixed) << setprecision(1) << a.genomes[i].at << endl;
+    }
+    log << setw(2) << setiosflags(ios::left) << "d value:   " << setw(2) << prm.d << endl;
+    log << setw(2) << "q value:   " << setw(2) << prm.q << endl << endl;
+    log << setw(2) << "Mum anchor size:   " << setw(2) << a.l << endl;
+    log << setw(2) << "Number of MUM anchors found:   " << setw(2) << a.m0 << endl;
+    const long total = (long)a.mums.size() + a.filtered;
+    log << setw(2) << "Number of MUMs found:   " << setw(2) << (total >= a.m0 ? total - a.m0 : 0) << endl;
+    log << setw(2) << "Total MUMs found((Anchors+MUMs)-filtered):   " << setw(2) << a.mums.size() << endl << endl;
+    log << setw(2) << "Random MUM length:   " << setw(2) << a.random << endl;
+    log << setw(2) << "Minimum Cluster length:   " << setw(2) << prm.c << endl;
+    log << setw(2) << "Number of MUMs filtered:   " << setw(2) << a.filtered << endl;
+    log << setw(2) << "Number of Clusters filtered:   " << setw(2) << a.filtered_lcbs << endl << endl;
+    long ccount = 0;
+    for (const Lcb& c : a.lcbs) if (c.type && !c.mums.empty()) ccount++;
+    log << setw(2) << "Number of clusters created:   " << setw(2) << ccount << endl;
+    if (a.lcbs.empty()) log << setw(2) << "Number of clusters created:   " << setw(2) << "NONE" << endl;
+    if (ccount == 0) { cerr << "parsnp_core: no clusters (the reference divides by zero here)" << endl; exit(1); }
+    log << setw(2) << "Average number of MUMs per cluster:   " << setw(2) << a.mums.size() / (size_t)ccount << endl;
+    vector<long> coverage(n, 0);
+    long avg = 0, totcoverage = 0, totsize = 0;
+    for (size_t i = 0; i < n; i++) {
+        for (const Lcb& c : a.lcbs) {
+            if (!c.type || c.mums.empty()) continue;
+            const Mum& f = a.pool[(size_t)c.mums.front()];
+            const Mum& bk = a.pool[(size_t)c.mums.back()];
+            long span = f.fwd[i] ? labs((bk.start[i] + bk.length) - f.start[i]) : labs((f.start[i] + f.length) - bk.start[i]);
+            coverage[i] += span;
+            if (i == 0) avg += span;
+        }
+    }
+    log << setw(2) << "Average cluster length:   " << avg / ccount << " bps" << endl;
+    float percent;
+    for (size_t i = 0; i < n; i++) {
+        percent = (float)coverage[i] / ((float)a.genomes[i].gc + (float)a.genomes[i].at);
+        log << setw(2) << "Cluster coverage in sequence " << i + 1 << ":   " << setiosflags(ios::fixed) << setprecision(1)
+            << 100.00 * percent << "%" << endl;
+        totcoverage += coverage[i];
+        totsize += a.genomes[i].size_nopad;
+    }
+    percent = (float)totcoverage / (float)totsize;
+    log << setw(2) << "Total coverage among all sequences:   " << setiosflags(ios::fixed) << setprecision(1) << 100.00 * percent
+        << "%" << endl << endl;
+    log << setw(2) << " MUM anchor search elapsed time:   " << a.anchor_time << "s " << endl;
+    log << setw(2) << " MUM coarsening elapsed time:   " << a.coarsen_time << "s " << endl;
+    if (prm.random) log << setw(2) << " MUM filtering elapsed time:   " << a.random_time << "s " << endl;
+    log << setw(2) << " MUM clustering elapsed time:   " << a.clusters_time << "s " << endl;
+    log << setw(2) << " Inter-clustering elapsed time:   " << a.iclusters_time << "s " << endl;
+    log << setw(2) << " Total running time:   "
+        << a.anchor_time + a.coarsen_time + a.random_time + a.clusters_time + a.iclusters_time << "s " << endl;
+    if (*gap_note)
+        log << "NOTE: multi-column inter-MUM gaps were emitted unaligned ('-' padded); MUM and LCB coordinates are unaffected." << endl;
+    log.close();
+}
+
+}  // namespace parsnp

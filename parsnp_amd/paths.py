@@ -1,0 +1,9 @@
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "parsnp_amd")
+CSRC = os.path.join(PKG, "csrc")
+BIN_DIR = os.path.join(PKG, "bin")
+LIB_DIR = os.path.join(PKG, "lib")
+CORE_BIN = os.path.join(BIN_DIR, "parsnp_core")
+HIP_LIB = os.path.join(LIB_DIR, "libparsnp_hip.so")

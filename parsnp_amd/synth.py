@@ -1,0 +1,125 @@
+"""Seeded synthetic genome sets for the BASELINE.json configurations.
+
+All sets use numpy default_rng(seed), bases uniform over ACGT, one contig per genome, FASTA wrapped at 80 columns,
+files ref.fna + g0000.fna ... with headers >ref / >g0000 ...
+
+  population model  a pool of segregating sites (Bernoulli density `div`) with one alternate allele each; every genome
+                    carries each alternate allele with probability 1/2; a fraction of the sites are 1-bp deletions.
+                    (Independent per-genome mutation leaves no core genome at 200 genomes.)
+  musclefree model  segregating sites on a jittered grid, >= 40 bp apart: every inter-MUM gap is one column, so the
+                    XMFA does not depend on the gap aligner and can be compared byte for byte.
+  rearranged model  per-genome independent substitutions plus inversions / translocations of 20 kb blocks.
+"""
+import os
+
+import numpy as np
+
+_BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _alt(rng, ref_bases):
+    """an alternate allele different from the reference base"""
+    idx = np.searchsorted(_BASES, ref_bases)  # ACGT is sorted
+    return _BASES[(idx + rng.integers(1, 4, len(ref_bases))) % 4]
+
+
+def random_genome(rng, n):
+    return _BASES[rng.integers(0, 4, n)]
+
+
+def population(seed, n, n_genomes, div, indel_frac=0.0, sites=None):
+    """-> (ref bytes, [genome bytes]) under the population model."""
+    rng = np.random.default_rng(seed)
+    ref = random_genome(rng, n)
+    if sites is None:
+        sites = np.flatnonzero(rng.random(n) < div)
+    alt = _alt(rng, ref[sites])
+    is_del = rng.random(len(sites)) < indel_frac
+    out = []
+    for _ in range(n_genomes):
+        carry = rng.random(len(sites)) < 0.5
+        g = ref.copy()
+        sub = sites[carry & ~is_del]
+        g[sub] = alt[carry & ~is_del]
+        keep = np.ones(n, dtype=bool)
+        keep[sites[carry & is_del]] = False
+        out.append(g[keep].tobytes())
+    return ref.tobytes(), out
+
+
+def musclefree(seed, n, n_genomes, div):
+    """sites on a grid of step 1/div with jitter <= step-40."""
+    rng = np.random.default_rng(seed)
+    step = int(round(1.0 / div))
+    base = np.arange(step // 2, n - step, step)
+    jitter = rng.integers(0, max(1, step - 40), len(base))
+    sites = base + jitter
+    return population(seed + 1, n, n_genomes, div, 0.0, sites=sites)
+
+
+def rearranged(seed, n, n_genomes, div, frac=0.15, block=20000):
+    rng = np.random.default_rng(seed)
+    ref = random_genome(rng, n)
+    out = []
+    for _ in range(n_genomes):
+        g = ref.copy()
+        m = rng.random(n) < div
+        g[m] = _alt(rng, g[m])
+        s = g.tobytes()
+        nblocks = max(1, int(frac * n / block))
+        for _b in range(nblocks):
+            a = int(rng.integers(0, max(1, len(s) - block)))
+            seg = s[a:a + block]
+            rest = s[:a] + s[a + block:]
+            if rng.random() < 0.5:   # inversion in place
+                s = s[:a] + seg.translate(_COMP)[::-1] + s[a + block:]
+            else:                    # translocation
+                b = int(rng.integers(0, len(rest)))
+                s = rest[:b] + seg + rest[b:]
+        out.append(s)
+    return ref.tobytes(), out
+
+
+def write_fasta(path, name, seq: bytes, width=80):
+    with open(path, "wb") as f:
+        f.write(b">" + name.encode() + b"\n")
+        a = np.frombuffer(seq, dtype=np.uint8)
+        full = (len(a) // width) * width
+        if full:
+            rows = a[:full].reshape(-1, width)
+            nl = np.full((rows.shape[0], 1), 10, dtype=np.uint8)
+            f.write(np.hstack([rows, nl]).tobytes())
+        if len(a) > full:
+            f.write(a[full:].tobytes() + b"\n")
+
+
+def write_set(outdir, ref: bytes, genomes):
+    """-> (ref path, [query paths]) with the file / header names the goldens were generated with."""
+    os.makedirs(outdir, exist_ok=True)
+    rp = os.path.join(outdir, "ref.fna")
+    write_fasta(rp, "ref", ref)
+    qs = []
+    for i, g in enumerate(genomes):
+        p = os.path.join(outdir, "g%04d.fna" % i)
+        write_fasta(p, "g%04d" % i, g)
+        qs.append(p)
+    return rp, qs
+
+
+CONFIGS = {
+    # name: (model, kwargs)  -- sizes of BASELINE.json configs 2, 3, 5 and the reduced sets used by tests
+    "viral50": ("musclefree", dict(seed=3, n=30000, n_genomes=50, div=0.01)),
+    "bact200": ("population", dict(seed=5, n=5_000_000, n_genomes=200, div=0.02, indel_frac=0.05)),
+    "bact8": ("population", dict(seed=5, n=5_000_000, n_genomes=8, div=0.02, indel_frac=0.05)),
+    "pop20x1m": ("population", dict(seed=7, n=1_000_000, n_genomes=20, div=0.02, indel_frac=0.05)),
+    "pop6x200k": ("population", dict(seed=9, n=200_000, n_genomes=6, div=0.02, indel_frac=0.05)),
+    "rearr6x300k": ("rearranged", dict(seed=11, n=300_000, n_genomes=6, div=0.004, frac=0.15)),
+    "rearr500": ("rearranged", dict(seed=13, n=5_000_000, n_genomes=500, div=0.05, frac=0.10)),
+}
+
+
+def make(name, **override):
+    model, kw = CONFIGS[name]
+    kw = dict(kw, **override)
+    return {"population": population, "musclefree": musclefree, "rearranged": rearranged}[model](**kw)
