@@ -67,11 +67,14 @@ const int64_t* pm_result_sp(const pm_result* r);
 const uint8_t* pm_result_fwd(const pm_result* r);
 void pm_result_free(pm_result* r);
 
-/* Single-strand entry point mirroring Find_UM (+ optionally Intersect_UM's carry) for parity tests:
- * dense per-reference-position arrays for events of length >= min_len (caller allocates n entries each).
- * propagate = 0: raw Pair/SP after Find_UM (mum.c:177-250); 1: after the forward carry of Intersect_UM (mum.c:125-175). */
-int pm_find_um(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int propagate,
-               int32_t* UP, int32_t* EP, int64_t* SP);
+/* Single-strand entry point mirroring Find_UM (src/csgmum/mum.c:177-250) for parity tests: the event stream of one
+ * query strand against ref -- every maximal exact match (j, l, len) of length >= min_len whose reference side is unique
+ * in ref -- in increasing l.  strand 0: the query as given, 1: its reverse complement (Aligner::reversec).
+ * rep[i] is the uniqueness point pos_label - l of mum.c:219-224 (longest repeated prefix of ref[l..)) where it is
+ * >= min(min_len,16) and 0 below that (values that small cannot change any MUM).
+ * At most cap events are written; *count receives the total. */
+int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int strand,
+                   int64_t cap, int64_t* count, int64_t* ev_j, int64_t* ev_l, int32_t* ev_len, int32_t* ev_rep);
 
 /* Device-side timing of the last pm_multi_mum_batch on this session (HIP events on the engine's stream):
  * names[i] / ms[i] for i < *count (count in: capacity, out: filled).  Used by bench.py's roofline line. */

@@ -66,9 +66,18 @@ const int64_t* pm_result_sp(const pm_result* r) { return r->sp; }
 const uint8_t* pm_result_fwd(const pm_result* r) { return r->fwd; }
 void pm_result_free(pm_result* r) { if (!r) return; free(r->off); free(r->k); free(r->lon); free(r->sp); free(r->fwd); free(r); }
 
-int pm_find_um(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int propagate, int32_t* UP, int32_t* EP, int64_t* SP) {
-    if (oracle_find_um(ref, n, query, m, min_len, UP, EP, SP)) return PM_ENOMEM;
-    if (propagate) oracle_propagate(n, UP, EP, SP);
+int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int strand,
+                   int64_t cap, int64_t* count, int64_t* ev_j, int64_t* ev_l, int32_t* ev_len, int32_t* ev_rep) {
+    uint8_t* q = malloc((size_t)m + 1);
+    for (int64_t i = 0; i < m; i++) {
+        uint8_t c = strand ? query[m - 1 - i] : query[i];
+        if (strand) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+        q[i] = c;
+    }
+    int64_t c = oracle_events(ref, n, q, m, min_len < 1 ? 1 : min_len, cap, ev_j, ev_l, ev_len, ev_rep);
+    free(q);
+    if (c < 0) return PM_ENOMEM;
+    *count = c;
     return PM_OK;
 }
 int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) { (void)s; (void)names; (void)ms; if (count) *count = 0; return PM_OK; }

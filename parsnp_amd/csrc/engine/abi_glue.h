@@ -1,0 +1,101 @@
+// abi_glue.h -- the extern "C" surface of include/parsnp_mum.h on top of Engine<Backend>.
+// Included exactly once by a translation unit that has defined `PmBackend` (the backend type),
+// `pm_backend_name` and `pm_backend_open(int device, std::string* err)`.
+#pragma once
+#include <memory>
+#include <new>
+
+#include "../../../include/parsnp_mum.h"
+#include "engine_core.h"
+
+struct pm_session {
+    std::unique_ptr<PmBackend> backend;
+    std::unique_ptr<pm::Engine<PmBackend>> engine;
+    std::vector<pm::PhaseTime> timing;
+};
+struct pm_result { pm::BatchResult r; };
+
+namespace {
+thread_local std::string g_pm_error;
+int fail(int code, const std::string& msg) { g_pm_error = msg; return code; }
+}  // namespace
+
+extern "C" {
+
+const char* pm_last_error(void) { return g_pm_error.c_str(); }
+const char* pm_provider(void) { return pm_backend_name; }
+
+int pm_session_create(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens) {
+    if (!out || n_genomes < 1 || !seqs || !lens) return fail(PM_EINVAL, "bad argument");
+    try {
+        std::unique_ptr<pm_session> s(new pm_session);
+        std::string err;
+        s->backend.reset(pm_backend_open(device, &err));
+        if (!s->backend) return fail(PM_ENODEV, err);
+        s->engine.reset(new pm::Engine<PmBackend>(*s->backend));
+        int rc = s->engine->load_genomes(n_genomes, seqs, lens);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        *out = s.release();
+        return PM_OK;
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed"); }
+}
+void pm_session_destroy(pm_session* s) { delete s; }
+int pm_session_genomes(const pm_session* s) { return s ? s->engine->ngen : 0; }
+
+int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, const int64_t* lens, const int32_t* minsize, pm_result** out) {
+    if (!s || !out || n_regions < 0 || (n_regions > 0 && (!starts || !lens || !minsize))) return fail(PM_EINVAL, "bad argument");
+    try {
+        std::unique_ptr<pm_result> r(new pm_result);
+        int rc = s->engine->run(n_regions, starts, lens, minsize, &r->r);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        s->timing = s->engine->timing;
+        *out = r.release();
+        return PM_OK;
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed"); }
+}
+int64_t pm_result_regions(const pm_result* r) { return r->r.nregions; }
+int64_t pm_result_total(const pm_result* r) { return r->r.total; }
+const int64_t* pm_result_offsets(const pm_result* r) { return r->r.off.data(); }
+const int32_t* pm_result_k(const pm_result* r) { return r->r.k.data(); }
+const int32_t* pm_result_lon(const pm_result* r) { return r->r.lon.data(); }
+const int64_t* pm_result_sp(const pm_result* r) { return r->r.sp.data(); }
+const uint8_t* pm_result_fwd(const pm_result* r) { return r->r.fwd.data(); }
+void pm_result_free(pm_result* r) { delete r; }
+
+int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int strand,
+                   int64_t cap, int64_t* count, int64_t* ev_j, int64_t* ev_l, int32_t* ev_len, int32_t* ev_rep) {
+    if (!ref || !query || !count || n < 0 || m < 0) return fail(PM_EINVAL, "bad argument");
+    const uint8_t* seqs[2] = {ref, query};
+    int64_t lens[2] = {n, m};
+    pm_session* s = nullptr;
+    int rc = pm_session_create(&s, -1, 2, seqs, lens);
+    if (rc) return rc;
+    int64_t starts[2] = {0, 0};
+    pm::BatchResult br;
+    rc = s->engine->run(1, starts, lens, &min_len, &br, true);
+    if (rc) { fail(rc, s->engine->error); pm_session_destroy(s); return rc; }
+    const auto& K = s->engine->ev_key_h; const auto& V = s->engine->ev_val_h;
+    const uint64_t lmask = (1ull << s->engine->ev_lbits) - 1;
+    int64_t c = 0;
+    for (size_t i = 0; i < K.size(); i++) {
+        if ((int)(K[i] & 1) != (strand ? 1 : 0)) continue;
+        int64_t l = (int64_t)((K[i] >> 1) & lmask);
+        if (c < cap) { ev_j[c] = (int64_t)(V[i] >> 32); ev_l[c] = l; ev_len[c] = (int32_t)(V[i] & 0xffffffffu); ev_rep[c] = s->engine->rep_h[(size_t)l]; }
+        c++;
+    }
+    *count = c;
+    pm_session_destroy(s);
+    return PM_OK;
+}
+
+int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) {
+    if (!s || !count) return PM_EINVAL;
+    int capn = *count, n = 0;
+    for (const auto& t : s->timing) { if (n < capn) { names[n] = t.name; ms[n] = t.ms; } n++; }
+    *count = n < capn ? n : capn;
+    return PM_OK;
+}
+
+}  // extern "C"

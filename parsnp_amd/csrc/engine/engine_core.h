@@ -1,0 +1,290 @@
+// engine_core.h -- orchestration of one pm_multi_mum_batch call, templated on the execution backend.
+// HipBackend (engine_hip.hip) = the product: HIP kernels on gfx950, one stream, HIP-event timing.
+// tests/emu/ instantiates it with a sequential host backend to check the logic without a GPU (tests only).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace pm {
+
+struct BatchResult {
+    int64_t nregions = 0, total = 0;
+    int nq = 0;
+    std::vector<int64_t> off;
+    std::vector<int32_t> k, lon;
+    std::vector<int64_t> sp;
+    std::vector<uint8_t> fwd;
+};
+
+struct PhaseTime { const char* name; float ms; };
+
+inline int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) b++; return b; }
+
+template <class B>
+class Engine {
+public:
+    explicit Engine(B& backend) : be(backend) {}
+    ~Engine() { release(); }
+
+    std::string error;
+    std::vector<PhaseTime> timing;
+    int64_t last_events = 0, last_candidates = 0;
+
+    int ngen = 0;
+    std::vector<int64_t> glen_h;
+
+    // ---- genomes -> packed strands in device memory
+    int load_genomes(int n, const uint8_t* const* seqs, const int64_t* lens) {
+        ngen = n;
+        glen_h.assign(lens, lens + n);
+        std::vector<int64_t> goff(2 * (size_t)n);
+        int64_t words = 2;                       // leading guard (64 bases)
+        int64_t maxlen = 0;
+        for (int g = 0; g < n; g++) {
+            maxlen = std::max(maxlen, lens[g]);
+            for (int s = 0; s < 2; s++) {
+                goff[2 * (size_t)g + s] = words * 32;
+                words += (lens[g] + 31) / 32 + 2;   // + trailing guard
+            }
+        }
+        words += 2;
+        total_words = words;
+        b2 = (uint64_t*)be.alloc((size_t)words * 8);
+        nm = (uint32_t*)be.alloc((size_t)words * 4);
+        d_goff = (int64_t*)be.alloc(sizeof(int64_t) * 2 * (size_t)n);
+        d_glen = (int64_t*)be.alloc(sizeof(int64_t) * (size_t)n);
+        uint8_t* stage = (uint8_t*)be.alloc((size_t)std::max<int64_t>(maxlen, 1));
+        if (!b2 || !nm || !d_goff || !d_glen || !stage) { error = "device allocation failed (genomes)"; return -3; }
+        be.memset(b2, 0, (size_t)words * 8);
+        be.memset(nm, 0, (size_t)words * 4);
+        be.h2d(d_goff, goff.data(), sizeof(int64_t) * goff.size());
+        be.h2d(d_glen, lens, sizeof(int64_t) * (size_t)n);
+        for (int g = 0; g < n; g++) {
+            if (lens[g] == 0) continue;
+            be.h2d(stage, seqs[g], (size_t)lens[g]);
+            for (int s = 0; s < 2; s++)
+                be.launch("pack", (lens[g] + 31) / 32, PackStrand{stage, lens[g], s, b2, nm, goff[2 * (size_t)g + s] / 32});
+            be.sync();   // stage is reused
+        }
+        be.free(stage);
+        P = Packed{b2, nm, d_goff, d_glen};
+        return 0;
+    }
+
+    // ---- one batch of regions (include/parsnp_mum.h: pm_multi_mum_batch)
+    int run(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events = false) {
+        timing.clear();
+        const int nq = ngen - 1;
+        out->nregions = nreg; out->nq = nq; out->total = 0;
+        out->off.assign((size_t)nreg + 1, 0);
+        out->k.clear(); out->lon.clear(); out->sp.clear(); out->fwd.clear();
+        if (nreg == 0) return 0;
+        if (nq < 1) { error = "need at least one query genome"; return -2; }
+
+        // -- host: per-region parameters and slices
+        std::vector<RegionInfo> R((size_t)nreg);
+        std::vector<int64_t> posbase((size_t)nreg + 1), tilebase((size_t)nreg + 1);
+        int64_t npos = 0, ntiles = 0, tsize = 0;
+        int32_t max_nr = 1;
+        for (int64_t r = 0; r < nreg; r++) {
+            RegionInfo& ri = R[(size_t)r];
+            for (int g = 0; g < ngen; g++) {
+                int64_t st = starts[r * ngen + g], ln = lens[r * ngen + g];
+                if (st < 0 || ln < 0 || st + ln > glen_h[(size_t)g]) { error = "region outside its genome"; return -2; }
+                if (ln >= (1ll << 31)) { error = "region longer than 2^31"; return -5; }
+            }
+            ri.ref_pos = starts[r * ngen];
+            ri.nR = (int32_t)lens[r * ngen];
+            ri.minsize = minsize[r];
+            ri.minlen = minsize[r] < 1 ? 1 : minsize[r];
+            ri.K = ri.minlen < 16 ? ri.minlen : 16;
+            ri.stride = ri.minlen - ri.K + 1;
+            int64_t slots = 16;
+            while (slots < 2 * (int64_t)ri.nR) slots <<= 1;
+            ri.tmask = (uint32_t)(slots - 1);
+            ri.tbase = tsize; tsize += slots;
+            ri.posbase = npos; posbase[(size_t)r] = npos; npos += ri.nR;
+            ri.tile_base = ntiles; tilebase[(size_t)r] = ntiles; ntiles += (ri.nR + kTile - 1) / kTile;
+            max_nr = std::max(max_nr, ri.nR);
+        }
+        posbase[(size_t)nreg] = npos; tilebase[(size_t)nreg] = ntiles;
+        const int64_t npairs = nreg * nq;
+        const int lbits = bits_for((uint64_t)max_nr);
+        if (bits_for((uint64_t)npairs) + lbits + 1 > 64) { error = "batch too large for 64-bit event keys"; return -5; }
+        if (npairs >= (1ll << 31) || nreg >= (1ll << 31)) { error = "too many regions in one batch"; return -5; }
+
+        be.mark("setup");
+        ensure(d_R, (size_t)nreg);
+        ensure(d_starts, (size_t)(nreg * ngen)); ensure(d_lens, (size_t)(nreg * ngen));
+        ensure(d_posbase, (size_t)nreg + 1); ensure(d_tilebase, (size_t)nreg + 1);
+        be.h2d(d_R.p, R.data(), sizeof(RegionInfo) * (size_t)nreg);
+        be.h2d(d_starts.p, starts, sizeof(int64_t) * (size_t)(nreg * ngen));
+        be.h2d(d_lens.p, lens, sizeof(int64_t) * (size_t)(nreg * ngen));
+        be.h2d(d_posbase.p, posbase.data(), sizeof(int64_t) * ((size_t)nreg + 1));
+        be.h2d(d_tilebase.p, tilebase.data(), sizeof(int64_t) * ((size_t)nreg + 1));
+        ensure(d_err, 1); be.memset(d_err.p, 0, 4);
+
+        // -- reference index + repeat lengths
+        ensure(d_tags, (size_t)tsize); ensure(d_heads, (size_t)tsize);
+        ensure(d_next, (size_t)std::max<int64_t>(npos, 1)); ensure(d_rep, (size_t)std::max<int64_t>(npos, 1));
+        ensure(d_epm, (size_t)std::max<int64_t>(npos, 1));
+        be.memset(d_tags.p, 0xff, sizeof(uint64_t) * (size_t)tsize);
+        be.memset(d_heads.p, 0xff, sizeof(int32_t) * (size_t)tsize);
+        be.mark("index");
+        be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_tags.p, d_heads.p, d_next.p});
+        be.mark("repeat");
+        be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_tags.p, d_heads.p, d_next.p, d_rep.p, d_err.p, work_budget});
+
+        // -- work units
+        be.mark("units");
+        ensure(d_ucount, (size_t)npairs + 1); ensure(d_uoff, (size_t)npairs + 1);
+        be.launch("count_units", npairs, CountUnits{d_R.p, d_lens.p, ngen, d_ucount.p});
+        be.memset(d_ucount.p + npairs, 0, 8);
+        be.exclusive_scan(d_ucount.p, d_uoff.p, (size_t)npairs + 1);
+        int64_t nunits = 0;
+        be.d2h(&nunits, d_uoff.p + npairs, 8);
+        if (nunits >= (1ll << 31)) { error = "too many work units in one batch"; return -5; }
+        ensure(d_upair, (size_t)std::max<int64_t>(nunits, 1)); ensure(d_uinfo, (size_t)std::max<int64_t>(nunits, 1));
+        be.launch("fill_units", npairs, FillUnits{d_uoff.p, d_ucount.p, d_upair.p, d_uinfo.p});
+
+        // -- events (retry with a larger buffer on overflow)
+        ensure(d_counter, 2);
+        uint64_t nev = 0;
+        size_t cap = std::max<size_t>(ev_cap_hint, 1 << 16);
+        for (;;) {
+            ensure(d_evkey, cap); ensure(d_evval, cap);
+            be.memset(d_counter.p, 0, 16);
+            be.mark("seed_extend");
+            be.launch("seed_extend", nunits * 64,
+                      SeedExtend{P, d_R.p, d_starts.p, d_lens.p, ngen, d_upair.p, d_uinfo.p, d_tags.p, d_heads.p, d_next.p, d_rep.p,
+                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)cap, lbits, d_err.p, work_budget});
+            be.d2h(&nev, d_counter.p, 8);
+            if (nev <= cap) break;
+            cap = (size_t)(nev + nev / 8 + 1024);
+        }
+        ev_cap_hint = std::max(ev_cap_hint, (size_t)(nev + nev / 4));
+        last_events = (int64_t)nev;
+        uint32_t errbits = 0;
+        be.d2h(&errbits, d_err.p, 4);
+        if (errbits & kErrWork) { error = "per-thread work budget exceeded (degenerate repeat structure in a region)"; return -5; }
+
+        // -- sort by (pair, l, strand); scan
+        be.mark("sort");
+        ensure(d_evkey2, std::max<size_t>(nev, 1)); ensure(d_evval2, std::max<size_t>(nev, 1));
+        const int keybits = bits_for((uint64_t)npairs) + lbits + 1;
+        uint64_t *skey = d_evkey.p, *sval = d_evval.p;
+        if (nev > 0) { be.sort_pairs(d_evkey.p, d_evkey2.p, d_evval.p, d_evval2.p, (size_t)nev, keybits); skey = d_evkey2.p; sval = d_evval2.p; }
+        be.mark("scan");
+        ensure(d_lo, (size_t)npairs + 1);
+        be.launch("pair_bounds", npairs, PairBounds{skey, (int64_t)nev, lbits, npairs, d_lo.p});
+        ensure(d_state, std::max<size_t>(nev, 1)); ensure(d_emax, std::max<size_t>(nev, 1));
+        be.launch("pair_scan", npairs, PairScan{skey, sval, d_lo.p, lbits, d_state.p, d_emax.p});
+
+        if (want_events) {   // parity hook (pm_find_events): sorted events + rep'
+            ev_key_h.resize((size_t)nev); ev_val_h.resize((size_t)nev); rep_h.resize((size_t)npos);
+            if (nev) { be.d2h(ev_key_h.data(), skey, 8 * (size_t)nev); be.d2h(ev_val_h.data(), sval, 8 * (size_t)nev); }
+            if (npos) be.d2h(rep_h.data(), d_rep.p, 4 * (size_t)npos);
+            ev_lbits = lbits;
+        }
+
+        // -- Master.EP, candidates
+        be.mark("master_ep");
+        be.launch("master_ep", ntiles, MasterEP{d_R.p, nreg, d_tilebase.p, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p});
+        uint64_t ncand = 0;
+        size_t ccap = std::max<size_t>(cand_cap_hint, 1 << 12);
+        for (;;) {
+            ensure(d_cand, ccap); ensure(d_cand2, ccap);
+            be.memset(d_counter.p, 0, 16);
+            be.mark("candidates");
+            be.launch("find_candidates", ntiles, FindCandidates{d_R.p, nreg, d_tilebase.p, d_epm.p, d_cand.p, d_counter.p, (uint64_t)ccap});
+            be.d2h(&ncand, d_counter.p, 8);
+            if (ncand <= ccap) break;
+            ccap = (size_t)(ncand + ncand / 8 + 1024);
+        }
+        cand_cap_hint = std::max(cand_cap_hint, (size_t)(ncand + ncand / 4));
+        last_candidates = (int64_t)ncand;
+        if (ncand == 0) { be.mark(nullptr); collect_timing(); return 0; }
+        uint64_t* scand = d_cand.p;
+        be.sort_keys(d_cand.p, d_cand2.p, (size_t)ncand, 32 + bits_for((uint64_t)nreg)); scand = d_cand2.p;
+
+        // -- per-candidate genome fold
+        be.mark("fold");
+        ensure(d_at, (size_t)ncand * (size_t)nq);
+        ensure(d_ok, (size_t)ncand); ensure(d_ok_k, (size_t)ncand); ensure(d_ok_lon, (size_t)ncand);
+        ensure(d_osp, (size_t)ncand * (size_t)nq); ensure(d_ofwd, (size_t)ncand * (size_t)nq);
+        be.launch("state_at_candidate", (int64_t)ncand * nq, StateAtCandidate{d_R.p, scand, ngen, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_at.p});
+        be.launch("fold_genomes", (int64_t)ncand, FoldGenomes{d_R.p, scand, ngen, d_at.p, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_ok.p});
+
+        // -- results to the host
+        be.mark("download");
+        std::vector<uint64_t> cand_h((size_t)ncand);
+        std::vector<uint8_t> ok_h((size_t)ncand), fwd_h((size_t)ncand * (size_t)nq);
+        std::vector<int32_t> k_h((size_t)ncand), lon_h((size_t)ncand), sp_h((size_t)ncand * (size_t)nq);
+        be.d2h(cand_h.data(), scand, 8 * (size_t)ncand);
+        be.d2h(ok_h.data(), d_ok.p, (size_t)ncand);
+        be.d2h(k_h.data(), d_ok_k.p, 4 * (size_t)ncand);
+        be.d2h(lon_h.data(), d_ok_lon.p, 4 * (size_t)ncand);
+        be.d2h(sp_h.data(), d_osp.p, 4 * (size_t)ncand * (size_t)nq);
+        be.d2h(fwd_h.data(), d_ofwd.p, (size_t)ncand * (size_t)nq);
+        be.mark(nullptr);
+        for (size_t c = 0; c < (size_t)ncand; c++) {
+            if (!ok_h[c]) continue;
+            int64_t r = (int64_t)(cand_h[c] >> 32);
+            out->off[(size_t)r + 1]++;
+            out->k.push_back(k_h[c]); out->lon.push_back(lon_h[c]);
+            for (int g = 0; g < nq; g++) { out->sp.push_back(sp_h[c * (size_t)nq + (size_t)g]); out->fwd.push_back(fwd_h[c * (size_t)nq + (size_t)g]); }
+        }
+        for (int64_t r = 0; r < nreg; r++) out->off[(size_t)r + 1] += out->off[(size_t)r];
+        out->total = out->off[(size_t)nreg];
+        collect_timing();
+        return 0;
+    }
+
+    // parity hook output (valid after run(..., want_events = true))
+    std::vector<uint64_t> ev_key_h, ev_val_h;
+    std::vector<int32_t> rep_h;
+    int ev_lbits = 0;
+    int64_t work_budget = 1 << 22;
+
+    void release() {
+        auto drop = [&](auto& b) { if (b.p) be.free(b.p); b.p = nullptr; b.cap = 0; };
+        drop(d_R); drop(d_starts); drop(d_lens); drop(d_posbase); drop(d_tilebase); drop(d_err); drop(d_tags); drop(d_heads); drop(d_next);
+        drop(d_rep); drop(d_epm); drop(d_ucount); drop(d_uoff); drop(d_upair); drop(d_uinfo); drop(d_counter); drop(d_evkey); drop(d_evval);
+        drop(d_evkey2); drop(d_evval2); drop(d_lo); drop(d_state); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
+        drop(d_ok_k); drop(d_ok_lon); drop(d_osp); drop(d_ofwd);
+        if (b2) be.free(b2); if (nm) be.free(nm); if (d_goff) be.free(d_goff); if (d_glen) be.free(d_glen);
+        b2 = nullptr; nm = nullptr; d_goff = nullptr; d_glen = nullptr;
+    }
+
+private:
+    B& be;
+    template <class T> struct Buf { T* p = nullptr; size_t cap = 0; };
+    template <class T> void ensure(Buf<T>& b, size_t n) {
+        if (n <= b.cap && b.p) return;
+        if (b.p) be.free(b.p);
+        size_t want = n + n / 4 + 16;
+        b.p = (T*)be.alloc(want * sizeof(T));
+        b.cap = b.p ? want : 0;
+        if (!b.p) { fprintf(stderr, "parsnp engine: device allocation of %zu bytes failed\n", want * sizeof(T)); abort(); }
+    }
+    void collect_timing() { timing = be.collect(); }
+
+    uint64_t* b2 = nullptr; uint32_t* nm = nullptr; int64_t* d_goff = nullptr; int64_t* d_glen = nullptr;
+    int64_t total_words = 0;
+    Packed P{};
+    size_t ev_cap_hint = 0, cand_cap_hint = 0;
+    Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase, d_tilebase; Buf<uint32_t> d_err;
+    Buf<uint64_t> d_tags; Buf<int32_t> d_heads, d_next, d_rep, d_epm;
+    Buf<int64_t> d_ucount, d_uoff; Buf<int32_t> d_upair, d_uinfo;
+    Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2;
+    Buf<int64_t> d_lo; Buf<EventState> d_state; Buf<int32_t> d_emax;
+    Buf<uint64_t> d_cand, d_cand2; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
+};
+
+}  // namespace pm

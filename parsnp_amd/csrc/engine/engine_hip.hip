@@ -1,0 +1,126 @@
+// engine_hip.hip -- libparsnp_hip.so: the MI355X (gfx950) backend of the multi-MUM engine and its C ABI.
+// One HIP stream per session; every kernel of kernels.h is launched as 256-thread workgroups (4 wavefronts) with
+// one functor call per thread; radix sort / exclusive scan are rocPRIM device primitives on the same stream.
+// Phase timing uses HIP events recorded on that stream (pm_last_timing).
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "engine_core.h"
+
+namespace {
+
+template <class F>
+__global__ __launch_bounds__(256) void pm_kernel(F f, int64_t n) {
+    int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tid < n) f(tid);
+}
+
+struct HipBackend {
+    hipStream_t stream = nullptr;
+    std::string err;
+    void* tmp = nullptr;
+    size_t tmp_cap = 0;
+    std::vector<std::pair<const char*, hipEvent_t>> marks;
+    std::vector<hipEvent_t> pool;
+
+    bool check(hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        if (err.empty()) err = std::string(what) + ": " + hipGetErrorString(e);
+        return false;
+    }
+    bool ok() const { return err.empty(); }
+    std::string error() const { return err; }
+
+    ~HipBackend() {
+        for (auto& m : marks) pool.push_back(m.second);
+        for (auto e : pool) (void)hipEventDestroy(e);
+        if (tmp) (void)hipFree(tmp);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    void* alloc(size_t n) { void* p = nullptr; if (!check(hipMalloc(&p, n ? n : 1), "hipMalloc")) return nullptr; return p; }
+    void free(void* p) { check(hipFree(p), "hipFree"); }
+    void memset(void* p, int v, size_t n) { check(hipMemsetAsync(p, v, n, stream), "hipMemsetAsync"); }
+    void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync"); }
+    void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); check(hipStreamSynchronize(stream), "sync"); }
+    void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+
+    template <class F> void launch(const char* name, int64_t n, F f) {
+        if (n <= 0) return;
+        int64_t blocks = (n + 255) / 256;
+        if (blocks > 0x7fffffffll) { if (err.empty()) err = std::string("grid too large: ") + name; return; }
+        hipLaunchKernelGGL(pm_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, stream, f, n);
+        check(hipGetLastError(), name);
+    }
+    void need_tmp(size_t n) {
+        if (n <= tmp_cap) return;
+        if (tmp) (void)hipFree(tmp);
+        tmp = nullptr; tmp_cap = 0;
+        if (check(hipMalloc(&tmp, n + n / 4 + 256), "hipMalloc(tmp)")) tmp_cap = n + n / 4 + 256;
+    }
+    void exclusive_scan(const int64_t* in, int64_t* out, size_t n) {
+        size_t bytes = 0;
+        check(rocprim::exclusive_scan(nullptr, bytes, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), stream), "scan size");
+        need_tmp(bytes);
+        check(rocprim::exclusive_scan(tmp, bytes, in, out, (int64_t)0, n, rocprim::plus<int64_t>(), stream), "exclusive_scan");
+    }
+    void sort_pairs(uint64_t* ki, uint64_t* ko, uint64_t* vi, uint64_t* vo, size_t n, int bits) {
+        size_t bytes = 0;
+        check(rocprim::radix_sort_pairs(nullptr, bytes, ki, ko, vi, vo, n, 0, (unsigned)bits, stream), "sort size");
+        need_tmp(bytes);
+        check(rocprim::radix_sort_pairs(tmp, bytes, ki, ko, vi, vo, n, 0, (unsigned)bits, stream), "radix_sort_pairs");
+    }
+    void sort_keys(uint64_t* ki, uint64_t* ko, size_t n, int bits) {
+        size_t bytes = 0;
+        check(rocprim::radix_sort_keys(nullptr, bytes, ki, ko, n, 0, (unsigned)bits, stream), "sort size");
+        need_tmp(bytes);
+        check(rocprim::radix_sort_keys(tmp, bytes, ki, ko, n, 0, (unsigned)bits, stream), "radix_sort_keys");
+    }
+    // phase timing: mark(name) opens a phase, mark(nullptr) closes the last one
+    void mark(const char* name) {
+        hipEvent_t e;
+        if (!pool.empty()) { e = pool.back(); pool.pop_back(); }
+        else if (!check(hipEventCreate(&e), "hipEventCreate")) return;
+        check(hipEventRecord(e, stream), "hipEventRecord");
+        marks.emplace_back(name, e);
+    }
+    std::vector<pm::PhaseTime> collect() {
+        std::vector<pm::PhaseTime> out;
+        sync();
+        for (size_t i = 0; i + 1 < marks.size(); i++) {
+            if (!marks[i].first) continue;
+            float ms = 0;
+            check(hipEventElapsedTime(&ms, marks[i].second, marks[i + 1].second), "hipEventElapsedTime");
+            bool merged = false;
+            for (auto& t : out) if (!strcmp(t.name, marks[i].first)) { t.ms += ms; merged = true; }
+            if (!merged) out.push_back(pm::PhaseTime{marks[i].first, ms});
+        }
+        for (auto& m : marks) pool.push_back(m.second);
+        marks.clear();
+        return out;
+    }
+};
+
+}  // namespace
+
+typedef HipBackend PmBackend;
+static const char* pm_backend_name = "hip";
+static PmBackend* pm_backend_open(int device, std::string* err) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        *err = std::string("no HIP device available (") + (e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + "); this engine has no CPU path";
+        return nullptr;
+    }
+    if (device >= 0) {
+        if (device >= count || hipSetDevice(device) != hipSuccess) { *err = "cannot select the requested HIP device"; return nullptr; }
+    }
+    HipBackend* b = new HipBackend;
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; delete b; return nullptr; }
+    return b;
+}
+#include "abi_glue.h"

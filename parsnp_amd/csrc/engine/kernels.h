@@ -1,0 +1,479 @@
+// kernels.h -- device code of the multi-MUM engine, written as per-thread functors.
+//
+// Every kernel is a struct with `operator()(int64_t tid)`: one call is the work of one GPU thread.  The HIP
+// build (engine_hip.hip) launches them as 256-thread workgroups on gfx950; tests/emu instantiates the same functors
+// in a sequential loop on the host so that the kernel LOGIC can be checked without a GPU (test infrastructure only
+// -- the product has no host execution path).  All cross-thread communication is through global atomics, so both
+// executions compute the same result.
+//
+// Data layout in HBM (see DESIGN.md "Data layout"):
+//   b2[]  2 bits per base, 32 bases per uint64 word   (A=0 C=1 G=2 T=3, N stored as 0)
+//   nm[]  1 bit per base, 32 bases per uint32 word    (1 = N)   -- 'N' matches 'N' (src/csgmum/csg.c:13-25)
+//   every genome is stored twice (forward, reverse complement), each strand starting on a word boundary with
+//   64 guard bases either side, so a 32-base window can be read at any offset without bounds checks.
+//
+// Reference semantics being computed: SURVEY.md 3.3 (= Find_UM / Intersect_UM / Merge_Master / extraction of
+// src/csgmum/mum.c and src/parsnp.cpp:1570-1695), file:line citations at each functor.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define PM_HD __host__ __device__ inline
+#else
+#define PM_HD inline
+#endif
+
+namespace pm {
+
+// ------------------------------------------------------------------------------------------ portable intrinsics
+PM_HD int ctz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((unsigned long long)x) - 1;
+#else
+    return __builtin_ctzll(x);
+#endif
+}
+PM_HD int clz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return __builtin_clzll(x);
+#endif
+}
+PM_HD int ctz32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffs((int)x) - 1;
+#else
+    return __builtin_ctz(x);
+#endif
+}
+PM_HD int clz32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clz((int)x);
+#else
+    return __builtin_clz(x);
+#endif
+}
+PM_HD uint64_t atomic_cas64(uint64_t* p, uint64_t expect, uint64_t val) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)val);
+#else
+    uint64_t old = *p; if (old == expect) *p = val; return old;
+#endif
+}
+PM_HD int32_t atomic_exch32(int32_t* p, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicExch(p, v);
+#else
+    int32_t o = *p; *p = v; return o;
+#endif
+}
+PM_HD uint64_t atomic_add64(uint64_t* p, uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint64_t)atomicAdd((unsigned long long*)p, (unsigned long long)v);
+#else
+    uint64_t o = *p; *p = o + v; return o;
+#endif
+}
+PM_HD void atomic_max32(int32_t* p, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax(p, v);
+#else
+    if (v > *p) *p = v;
+#endif
+}
+PM_HD void atomic_or32(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr(p, v);
+#else
+    *p |= v;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------ shared structures
+struct Packed {            // the resident genomes
+    const uint64_t* b2;
+    const uint32_t* nm;
+    const int64_t* goff;   // [2*g + strand] global base offset of the strand
+    const int64_t* glen;   // [g] genome length
+};
+
+struct RegionInfo {        // one per region of a batch
+    int64_t ref_pos;       // start of the reference substring in genome 0
+    int32_t nR;            // its length
+    int32_t K;             // seed length  = min(max(minsize,1), 16)
+    int32_t stride;        // query sampling step = max(minsize,1) - K + 1
+    int32_t minlen;        // max(minsize, 1): shortest event that can matter
+    int32_t minsize;       // as requested (candidate test, parsnp.cpp:1663)
+    uint32_t tmask;        // hash-table slice size - 1 (power of two)
+    int64_t tbase;         // hash-table slice start
+    int64_t posbase;       // start of this region in the per-reference-position arrays
+    int64_t tile_base;     // first 16-position tile of this region
+};
+
+constexpr uint64_t kEmpty = ~0ull;
+constexpr int kTile = 16;          // reference positions per master-fold thread
+constexpr int kUnitSamples = 256;  // query samples per work unit (64 threads x 4)
+
+// error bits raised by kernels
+constexpr uint32_t kErrWork = 1u;  // per-thread work budget exceeded (degenerate repeat structure)
+
+// 32 bases starting at global base position p
+PM_HD uint64_t win2(const uint64_t* b2, int64_t p) {
+    int64_t w = p >> 5;
+    int sh = (int)(p & 31) * 2;
+    uint64_t lo = b2[w];
+    if (sh == 0) return lo;
+    return (lo >> sh) | (b2[w + 1] << (64 - sh));
+}
+PM_HD uint32_t winm(const uint32_t* nm, int64_t p) {
+    int64_t w = p >> 5;
+    int sh = (int)(p & 31);
+    uint32_t lo = nm[w];
+    if (sh == 0) return lo;
+    return (lo >> sh) | (nm[w + 1] << (32 - sh));
+}
+// number of equal bases going right from (a, b), at most maxlen
+PM_HD int32_t lce_fwd(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
+    int32_t n = 0;
+    while (n < maxlen) {
+        uint64_t x = win2(P.b2, a + n) ^ win2(P.b2, b + n);
+        uint32_t mx = winm(P.nm, a + n) ^ winm(P.nm, b + n);
+        uint64_t d = (x | (x >> 1)) & 0x5555555555555555ull;
+        int c = d ? (ctz64(d) >> 1) : 32;
+        if (mx) { int cm = ctz32(mx); if (cm < c) c = cm; }
+        n += c;
+        if (c < 32) break;
+    }
+    return n < maxlen ? n : maxlen;
+}
+// number of equal bases going left from (a-1, b-1), at most maxlen
+PM_HD int32_t lce_bwd(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
+    int32_t n = 0;
+    while (n < maxlen) {
+        uint64_t x = win2(P.b2, a - n - 32) ^ win2(P.b2, b - n - 32);
+        uint32_t mx = winm(P.nm, a - n - 32) ^ winm(P.nm, b - n - 32);
+        uint64_t d = (x | (x >> 1)) & 0x5555555555555555ull;
+        int c = d ? (clz64(d) >> 1) : 32;
+        if (mx) { int cm = clz32(mx); if (cm < c) c = cm; }
+        n += c;
+        if (c < 32) break;
+    }
+    return n < maxlen ? n : maxlen;
+}
+// K-mer at p as a 48-bit tag: 2K base bits | K mask bits << 32
+PM_HD uint64_t kmer_tag(const Packed& P, int64_t p, int K) {
+    uint64_t b = win2(P.b2, p);
+    uint32_t m = winm(P.nm, p);
+    if (K < 32) b &= (1ull << (2 * K)) - 1;
+    if (K < 32) m &= (uint32_t)((1ull << K) - 1);
+    return b | ((uint64_t)m << 32);
+}
+PM_HD uint32_t hash_tag(uint64_t t) {
+    t ^= t >> 29; t *= 0xbf58476d1ce4e5b9ull; t ^= t >> 32; t *= 0x94d049bb133111ebull; t ^= t >> 29;
+    return (uint32_t)t;
+}
+// largest r in [0, count) with base[r] <= x (base ascending, base[0] <= x)
+PM_HD int64_t upper_slot(const int64_t* base, int64_t count, int64_t x) {
+    int64_t lo = 0, hi = count;
+    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (base[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------ genome packing
+// tid = output word of one strand. ascii: the genome as uploaded ('A','C','G','T', anything else = N).
+struct PackStrand {
+    const uint8_t* ascii; int64_t L; int strand; uint64_t* b2; uint32_t* nm; int64_t word0;   // word0: first word of the strand
+    PM_HD void operator()(int64_t tid) const {
+        uint64_t bits = 0; uint32_t mask = 0;
+        for (int i = 0; i < 32; i++) {
+            int64_t p = tid * 32 + i;
+            if (p >= L) break;
+            uint8_t c = strand ? ascii[L - 1 - p] : ascii[p];
+            uint32_t code;
+            switch (c) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break; default: code = 4; }
+            if (code == 4) mask |= 1u << i;
+            else bits |= (uint64_t)(strand ? 3 - code : code) << (2 * i);
+        }
+        b2[word0 + tid] = bits; nm[word0 + tid] = mask;
+    }
+};
+
+// ------------------------------------------------------------------------------------------ reference index
+// Replaces new_CSG/build_CSG/find_leaves (src/csgmum/csg.c:105-575): a chained hash of the reference substring's
+// K-mers.  tid = flat reference position over the batch.
+struct IndexInsert {
+    Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;   // posbase[nregions+1]
+    uint64_t* tags; int32_t* heads; int32_t* next;
+    PM_HD void operator()(int64_t tid) const {
+        int64_t r = upper_slot(posbase, nregions, tid);
+        const RegionInfo& ri = R[r];
+        int32_t l = (int32_t)(tid - ri.posbase);
+        next[tid] = -1;
+        if (l + ri.K > ri.nR) return;
+        uint64_t tag = kmer_tag(P, P.goff[0] + ri.ref_pos + l, ri.K);
+        uint32_t h = hash_tag(tag) & ri.tmask;
+        for (;;) {
+            uint64_t seen = tags[ri.tbase + h];
+            if (seen == kEmpty) seen = atomic_cas64(&tags[ri.tbase + h], kEmpty, tag);
+            if (seen == kEmpty || seen == tag) break;
+            h = (h + 1) & ri.tmask;
+        }
+        next[tid] = atomic_exch32(&heads[ri.tbase + h], l);
+    }
+};
+PM_HD int32_t index_lookup(const RegionInfo& ri, const uint64_t* tags, const int32_t* heads, uint64_t tag) {
+    uint32_t h = hash_tag(tag) & ri.tmask;
+    for (;;) {
+        uint64_t seen = tags[ri.tbase + h];
+        if (seen == tag) return heads[ri.tbase + h];
+        if (seen == kEmpty) return -1;
+        h = (h + 1) & ri.tmask;
+    }
+}
+
+// rep'[l]: longest prefix of R[l..) that occurs at another position of R if that is >= K, else 0.
+// (= the uniqueness point pos_label-l of mum.c:219-224 wherever it can influence the output; SURVEY 3.3-1,-7.)
+struct RepeatLength {
+    Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;
+    const uint64_t* tags; const int32_t* heads; const int32_t* next; int32_t* rep; uint32_t* err; int64_t budget;
+    PM_HD void operator()(int64_t tid) const {
+        int64_t r = upper_slot(posbase, nregions, tid);
+        const RegionInfo& ri = R[r];
+        int32_t l = (int32_t)(tid - ri.posbase);
+        int32_t best = 0;
+        if (l + ri.K <= ri.nR) {
+            int64_t base = P.goff[0] + ri.ref_pos;
+            uint64_t tag = kmer_tag(P, base + l, ri.K);
+            int64_t work = 0;
+            for (int32_t o = index_lookup(ri, tags, heads, tag); o >= 0; o = next[ri.posbase + o]) {
+                if (o == l) continue;
+                int32_t lim = ri.nR - (l > o ? l : o) - ri.K;
+                int32_t len = ri.K + lce_fwd(P, base + l + ri.K, base + o + ri.K, lim);
+                if (len > best) best = len;
+                work += 1 + (len >> 5);
+                if (work > budget) { atomic_or32(err, kErrWork); break; }
+            }
+        }
+        rep[tid] = best;
+    }
+};
+
+// ------------------------------------------------------------------------------------------ work units
+// units of one (region, query genome) pair: 2 strands x ceil(samples / 256)
+struct CountUnits {
+    const RegionInfo* R; const int64_t* lens; int32_t ngen; int64_t* count;   // lens[r*ngen + g]
+    PM_HD void operator()(int64_t pair) const {
+        int64_t r = pair / (ngen - 1); int g = (int)(pair % (ngen - 1)) + 1;
+        const RegionInfo& ri = R[r];
+        int64_t m = lens[r * ngen + g];
+        int64_t ns = (m >= ri.K && ri.nR >= ri.K) ? (m - ri.K) / ri.stride + 1 : 0;
+        count[pair] = 2 * ((ns + kUnitSamples - 1) / kUnitSamples);
+    }
+};
+struct FillUnits {
+    const int64_t* off; const int64_t* count; int32_t* unit_pair; int32_t* unit_info;
+    PM_HD void operator()(int64_t pair) const {
+        int64_t o = off[pair], c = count[pair], half = c / 2;
+        for (int64_t u = 0; u < c; u++) { unit_pair[o + u] = (int32_t)pair; unit_info[o + u] = (int32_t)(u < half ? (u << 1) : (((u - half) << 1) | 1)); }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ seed & extend
+// Replaces Find_UM (src/csgmum/mum.c:177-250): enumerates every R-unique maximal exact match of length >= minlen
+// between one query strand and the reference substring.  tid = unit*64 + lane; a lane takes samples
+// lane, lane+64, lane+128, lane+192 of its unit; sample s sits at query offset s*stride.  A match of length
+// >= minlen contains >= 1 whole sampled K-mer; it is reported from the first one only.
+struct SeedExtend {
+    Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen;
+    const int32_t* unit_pair; const int32_t* unit_info;
+    const uint64_t* tags; const int32_t* heads; const int32_t* next; const int32_t* rep;
+    uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_count; uint64_t ev_cap; int lbits; uint32_t* err; int64_t budget;
+    PM_HD void operator()(int64_t tid) const {
+        int64_t unit = tid >> 6; int lane = (int)(tid & 63);
+        int32_t pair = unit_pair[unit]; int32_t info = unit_info[unit];
+        int strand = info & 1; int64_t chunk = info >> 1;
+        int64_t r = pair / (ngen - 1); int g = (int)(pair % (ngen - 1)) + 1;
+        const RegionInfo& ri = R[r];
+        const int64_t m = lens[r * ngen + g], qs = starts[r * ngen + g];
+        const int64_t qbase = strand ? P.goff[2 * g + 1] + (P.glen[g] - qs - m) : P.goff[2 * g] + qs;
+        const int64_t rbase = P.goff[0] + ri.ref_pos;
+        const int K = ri.K;
+        int64_t work = 0;
+        for (int u = 0; u < kUnitSamples / 64; u++) {
+            int64_t s = chunk * kUnitSamples + u * 64 + lane;
+            int64_t j = s * ri.stride;
+            if (j + K > m) continue;
+            uint64_t tag = kmer_tag(P, qbase + j, K);
+            for (int32_t l = index_lookup(ri, tags, heads, tag); l >= 0; l = next[ri.posbase + l]) {
+                if (++work > budget) { atomic_or32(err, kErrWork); return; }
+                // left: only `stride` bases matter -- a longer left arm means an earlier sample owns the match
+                int32_t lim = (int32_t)(j < l ? j : l);
+                if (lim > ri.stride) lim = ri.stride;
+                int32_t left = lce_bwd(P, qbase + j, rbase + l, lim);
+                if (left >= ri.stride) continue;
+                int64_t mr = m - j - K; int32_t rr = ri.nR - l - K;
+                int32_t right = lce_fwd(P, qbase + j + K, rbase + l + K, (int32_t)(mr < rr ? mr : rr));
+                int32_t len = left + K + right;
+                if (len < ri.minlen) continue;
+                int32_t l0 = l - left; int64_t j0 = j - left;
+                if (len <= rep[ri.posbase + l0]) continue;           // not unique in R
+                uint64_t slot = atomic_add64(ev_count, 1);
+                if (slot < ev_cap) {
+                    ev_key[slot] = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
+                    ev_val[slot] = ((uint64_t)j0 << 32) | (uint32_t)len;
+                }
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ per-pair scan
+// After sorting by (pair, l, strand): first event of every pair
+struct PairBounds {
+    const uint64_t* key; int64_t nev; int lbits; int64_t npairs; int64_t* lo;   // lo[npairs+1]
+    PM_HD void operator()(int64_t pair) const {
+        uint64_t want = (uint64_t)pair << (lbits + 1);
+        int64_t a = 0, b = nev;
+        while (a < b) { int64_t mid = (a + b) >> 1; if (key[mid] < want) a = mid + 1; else b = mid; }
+        lo[pair] = a;
+        if (pair == npairs - 1) lo[npairs] = nev;
+    }
+};
+// State after every event of a pair, both strands side by side.  This is Test_UM (mum.c:27-45) + the forward carry
+// of Intersect_UM (mum.c:125-175) in closed form (SURVEY 3.3-3,-4): per strand, over the events with l <= k,
+//   e1 = furthest end, w = the event that reaches it (first in (l, j) order), e2 = second furthest end;
+//   EP[k] = e1, UP[k] = max(l_w + rep[l_w], e2), SP[k] = j_w + (k - l_w).
+struct StrandState { int32_t e1, e2, w; };
+struct EventState { StrandState s[2]; };
+struct PairScan {
+    const uint64_t* key; const uint64_t* val; const int64_t* lo; int lbits; EventState* st; int32_t* emax;
+    PM_HD void operator()(int64_t pair) const {
+        EventState cur; cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1};
+        const uint64_t lmask = (1ull << lbits) - 1;
+        for (int64_t i = lo[pair]; i < lo[pair + 1]; i++) {
+            uint64_t k = key[i], v = val[i];
+            int sd = (int)(k & 1);
+            int32_t l = (int32_t)((k >> 1) & lmask), j = (int32_t)(v >> 32), end = l + (int32_t)(v & 0xffffffffu);
+            StrandState& s = cur.s[sd];
+            bool take = s.w < 0;
+            if (!take) {
+                if (end > s.e1) take = true;
+                else if (end == s.e1) {   // equal reach: the earlier (l, j) is the one Test_UM/Intersect_UM keep
+                    uint64_t wk = key[s.w], wv = val[s.w];
+                    int32_t wl = (int32_t)((wk >> 1) & lmask), wj = (int32_t)(wv >> 32);
+                    take = l < wl || (l == wl && j < wj);
+                }
+            }
+            if (take) { if (s.w >= 0 && s.e1 > s.e2) s.e2 = s.e1; s.e1 = end; s.w = (int32_t)i; }
+            else if (end > s.e2) s.e2 = end;
+            st[i] = cur;
+            emax[i] = cur.s[0].e1 > cur.s[1].e1 ? cur.s[0].e1 : cur.s[1].e1;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ Master.EP
+// Master[k].EP = min over query genomes of max(EP_fwd[k], EP_rev[k])  (Intersect_UM's min fold mum.c:163 +
+// Merge_Master mum.c:92-123; order independent).  tid = one tile of 16 reference positions.
+struct MasterEP {
+    const RegionInfo* R; int64_t nregions; const int64_t* tile_base;   // tile_base[nregions+1]
+    int32_t ngen; const uint64_t* key; const int64_t* lo; const int32_t* emax; int lbits; int32_t* epm;
+    PM_HD void operator()(int64_t tid) const {
+        int64_t r = upper_slot(tile_base, nregions, tid);
+        const RegionInfo& ri = R[r];
+        int32_t k0 = (int32_t)(tid - ri.tile_base) * kTile;
+        int32_t ep[kTile];
+        for (int t = 0; t < kTile; t++) ep[t] = ri.nR;
+        const uint64_t lmask = (1ull << lbits) - 1;
+        for (int g = 0; g < ngen - 1; g++) {
+            int64_t pair = r * (ngen - 1) + g;
+            int64_t a = lo[pair], b = lo[pair + 1], end = b;
+            // first event with l > k0
+            uint64_t want = ((((uint64_t)pair << lbits) | (uint64_t)k0) << 1) | 1ull;
+            while (a < b) { int64_t mid = (a + b) >> 1; if (key[mid] <= want) a = mid + 1; else b = mid; }
+            int32_t cur = a > lo[pair] ? emax[a - 1] : 0;
+            int64_t e = a;
+            for (int t = 0; t < kTile; t++) {
+                int32_t k = k0 + t;
+                while (e < end && (int32_t)((key[e] >> 1) & lmask) <= k) { cur = emax[e]; e++; }
+                if (cur < ep[t]) ep[t] = cur;
+            }
+        }
+        for (int t = 0; t < kTile; t++) if (k0 + t < ri.nR) epm[ri.posbase + k0 + t] = ep[t];
+    }
+};
+
+// Candidate positions: Master[k].EP > Master[k-1].EP and EP-k >= minsize (parsnp.cpp:1657-1663; the UP < EP part
+// of the test is applied in FoldGenomes).  tid = tile.
+struct FindCandidates {
+    const RegionInfo* R; int64_t nregions; const int64_t* tile_base; const int32_t* epm;
+    uint64_t* cand; uint64_t* cand_count; uint64_t cand_cap;
+    PM_HD void operator()(int64_t tid) const {
+        int64_t r = upper_slot(tile_base, nregions, tid);
+        const RegionInfo& ri = R[r];
+        int32_t k0 = (int32_t)(tid - ri.tile_base) * kTile;
+        int32_t prev = k0 > 0 ? epm[ri.posbase + k0 - 1] : 0;
+        for (int t = 0; t < kTile && k0 + t < ri.nR; t++) {
+            int32_t k = k0 + t, e = epm[ri.posbase + k];
+            if (e > prev && e - k >= ri.minsize) {
+                uint64_t slot = atomic_add64(cand_count, 1);
+                if (slot < cand_cap) cand[slot] = ((uint64_t)r << 32) | (uint32_t)k;
+            }
+            prev = e;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ per-candidate fold
+struct GenomeAtK { int32_t epf, upf, spf, epr, upr, spr; };
+// tid = cand * (ngen-1) + g : both strands of one query genome at one candidate position
+struct StateAtCandidate {
+    const RegionInfo* R; const uint64_t* cand; int32_t ngen; const uint64_t* key; const uint64_t* val; const int64_t* lo;
+    const EventState* st; const int32_t* rep; int lbits; GenomeAtK* out;
+    PM_HD void operator()(int64_t tid) const {
+        int64_t c = tid / (ngen - 1); int g = (int)(tid % (ngen - 1));
+        int64_t r = (int64_t)(cand[c] >> 32); int32_t k = (int32_t)(cand[c] & 0xffffffffu);
+        const RegionInfo& ri = R[r];
+        int64_t pair = r * (ngen - 1) + g;
+        int64_t a = lo[pair], b = lo[pair + 1];
+        uint64_t want = ((((uint64_t)pair << lbits) | (uint64_t)k) << 1) | 1ull;
+        while (a < b) { int64_t mid = (a + b) >> 1; if (key[mid] <= want) a = mid + 1; else b = mid; }
+        GenomeAtK o{0, 0, 0, 0, 0, 0};
+        if (a > lo[pair]) {
+            const EventState& s = st[a - 1];
+            const uint64_t lmask = (1ull << lbits) - 1;
+            for (int sd = 0; sd < 2; sd++) {
+                if (s.s[sd].w < 0) continue;
+                uint64_t wk = key[s.s[sd].w], wv = val[s.s[sd].w];
+                int32_t wl = (int32_t)((wk >> 1) & lmask), wj = (int32_t)(wv >> 32);
+                int32_t up = wl + rep[ri.posbase + wl];
+                if (s.s[sd].e2 > up) up = s.s[sd].e2;
+                if (sd == 0) { o.epf = s.s[0].e1; o.upf = up; o.spf = wj + (k - wl); }
+                else { o.epr = s.s[1].e1; o.upr = up; o.spr = wj + (k - wl); }
+            }
+        }
+        out[tid] = o;
+    }
+};
+// tid = candidate.  Intersect_UM's (UP=max, EP=min) fold and Merge_Master's strand choice, genome after genome in
+// ini order (mum.c:162-163, :92-123; ties -> reverse), then the UP < EP test of parsnp.cpp:1657.
+struct FoldGenomes {
+    const RegionInfo* R; const uint64_t* cand; int32_t ngen; const GenomeAtK* at;
+    int32_t* out_k; int32_t* out_lon; int32_t* out_sp; uint8_t* out_fwd; uint8_t* out_ok;
+    PM_HD void operator()(int64_t c) const {
+        int64_t r = (int64_t)(cand[c] >> 32); int32_t k = (int32_t)(cand[c] & 0xffffffffu);
+        int32_t em = R[r].nR, um = 0;
+        for (int g = 0; g < ngen - 1; g++) {
+            const GenomeAtK& s = at[c * (ngen - 1) + g];
+            int32_t fe = em < s.epf ? em : s.epf, fu = um > s.upf ? um : s.upf;
+            int32_t re = em < s.epr ? em : s.epr, ru = um > s.upr ? um : s.upr;
+            if (fe > re) { em = fe; um = fu; out_sp[c * (ngen - 1) + g] = s.spf; out_fwd[c * (ngen - 1) + g] = 1; }
+            else { em = re; um = ru; out_sp[c * (ngen - 1) + g] = s.spr; out_fwd[c * (ngen - 1) + g] = 0; }
+        }
+        out_k[c] = k; out_lon[c] = em - k;
+        out_ok[c] = (um < em && em - k >= R[r].minsize) ? 1 : 0;
+    }
+};
+
+}  // namespace pm

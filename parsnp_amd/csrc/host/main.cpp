@@ -11,6 +11,7 @@
 
 #include "aligner.h"
 #include "ini.h"
+#include "minlen.h"
 
 using namespace parsnp;
 
@@ -33,6 +34,14 @@ int main(int argc, char* argv[]) {
     }
     if (show_version) { std::cout << "Parsnp " << version << std::endl; exit(0); }
     if (argc < 2) { std::cout << "ERROR: No parameter file specified!" << std::endl; exit(1); }
+    if (argc >= 4 && !strcmp(argv[1], "--min-length")) {   // diagnostic: minimum MUM length of an expression for S values
+        for (int i = 3; i < argc; i++) {
+            int v = 0;
+            if (!min_mum_length(argv[2], atol(argv[i]), &v)) { std::cout << "ERROR: cannot evaluate " << argv[2] << std::endl; exit(1); }
+            std::cout << argv[i] << " " << v << std::endl;
+        }
+        exit(0);
+    }
 
     const double t_begin = now_s();
     time_t tstart, start, end;

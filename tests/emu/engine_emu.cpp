@@ -1,0 +1,37 @@
+// tests/emu/engine_emu.cpp -- TEST INFRASTRUCTURE ONLY.
+// Runs the engine's kernel functors (parsnp_amd/csrc/engine/kernels.h) one "thread" after another on the host, behind
+// the same C ABI, so the kernel logic and the orchestration can be checked against the oracle without a GPU.
+// Built into tests/emu/libpm_emu.so by tests; never built or loaded by the product.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../parsnp_amd/csrc/engine/engine_core.h"
+
+struct HostBackend {
+    void* alloc(size_t n) { return malloc(n ? n : 1); }
+    void free(void* p) { ::free(p); }
+    void memset(void* p, int v, size_t n) { ::memset(p, v, n); }
+    void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+    void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+    void sync() {}
+    template <class F> void launch(const char*, int64_t n, F f) { for (int64_t i = 0; i < n; i++) f(i); }
+    void exclusive_scan(const int64_t* in, int64_t* out, size_t n) { int64_t a = 0; for (size_t i = 0; i < n; i++) { int64_t v = in[i]; out[i] = a; a += v; } }
+    void sort_pairs(uint64_t* ki, uint64_t* ko, uint64_t* vi, uint64_t* vo, size_t n, int) {
+        std::vector<size_t> idx(n);
+        for (size_t i = 0; i < n; i++) idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ki[a] < ki[b]; });
+        for (size_t i = 0; i < n; i++) { ko[i] = ki[idx[i]]; vo[i] = vi[idx[i]]; }
+    }
+    void sort_keys(uint64_t* ki, uint64_t* ko, size_t n, int) { memcpy(ko, ki, 8 * n); std::sort(ko, ko + n); }
+    void mark(const char*) {}
+    std::vector<pm::PhaseTime> collect() { return {}; }
+    bool ok() const { return true; }
+    std::string error() const { return ""; }
+};
+typedef HostBackend PmBackend;
+static const char* pm_backend_name = "emu";
+static PmBackend* pm_backend_open(int, std::string*) { return new HostBackend; }
+#include "../../parsnp_amd/csrc/engine/abi_glue.h"

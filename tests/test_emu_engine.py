@@ -1,0 +1,97 @@
+"""The engine's kernel functors (parsnp_amd/csrc/engine/kernels.h) and orchestration (engine_core.h), executed
+sequentially on the host by tests/emu, against the CPU restatement.  Checks the LOGIC of what the GPU runs; the
+GPU execution itself is checked by the -m gpu tests."""
+import numpy as np
+import pytest
+
+import oracles
+from parsnp_amd.binding import Lib, Session
+from seqgen import adversarial_case, mutate, random_seq
+from parsnp_amd import driver, synth
+import test_host_logic
+
+
+@pytest.fixture(scope="module")
+def libs(emu, cpu_checkers):
+    return Lib(emu[0]), oracles.load_restatement()
+
+
+def same(a, b):
+    return all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4]))
+
+
+def test_random_regions(libs):
+    E, O = libs
+    rng = np.random.default_rng(5)
+    total = 0
+    for it in range(400):
+        ref, qs = adversarial_case(rng, 10, 90, int(rng.integers(1, 5)))
+        minsize = int(rng.integers(1, 12))
+        a = oracles.restatement_multi_mum(O, [ref] + qs, minsize, 1)
+        with Session(E, [ref] + qs) as s:
+            b = s.whole(minsize)
+        assert same(a, b), (it, ref, qs, minsize)
+        total += len(a[0])
+    assert total > 500
+
+
+def batch_case(rng, E, O, n_regions=40, glen=3000, nq=4, big_minsize=False):
+    ref = random_seq(rng, glen)
+    qs = []
+    for g in range(nq):
+        q = mutate(rng, ref, sub=0.04, indel=0.004)
+        if g % 2:
+            a = glen // 4; b = a + glen // 3
+            q = q[:a] + oracles.revcomp(q[a:b]) + q[b:]
+        qs.append(q)
+    seqs = [ref] + qs
+    starts = np.zeros((n_regions, nq + 1), np.int64); lens = np.zeros_like(starts); mins = np.zeros(n_regions, np.int32)
+    for r in range(n_regions):
+        aligned = big_minsize or rng.random() < 0.5   # the same window in every genome -> multi-MUMs exist
+        f0 = rng.random(); f1 = rng.random()
+        for g, s in enumerate(seqs):
+            if aligned:
+                ln = min(len(s), int(200 + f1 * (len(s) // 2))); st = int(f0 * (len(s) - ln))
+            else:
+                ln = int(rng.integers(0, 400)) if rng.random() < 0.8 else int(rng.integers(400, len(s)))
+                st = int(rng.integers(0, len(s) - ln + 1))
+            starts[r, g] = st; lens[r, g] = ln
+        mins[r] = int(rng.integers(14, 30)) if big_minsize else int(rng.integers(3, 14))
+    with Session(E, seqs) as s:
+        got = s.multi_mum_batch(starts, lens, mins)
+    n = 0
+    for r in range(n_regions):
+        sub = [seqs[g][starts[r, g]:starts[r, g] + lens[r, g]] for g in range(nq + 1)]
+        want = oracles.restatement_multi_mum(O, sub, int(mins[r]), 1)
+        assert same(want, got[r]), (r, starts[r], lens[r], mins[r])
+        n += len(want[0])
+    return n
+
+
+def test_batched_regions(libs):
+    E, O = libs
+    rng = np.random.default_rng(6)
+    assert sum(batch_case(rng, E, O) for _ in range(5)) > 50
+    assert batch_case(rng, E, O, n_regions=12, glen=20000, nq=3, big_minsize=True) > 5
+
+
+def test_events(libs):
+    E, O = libs
+    rng = np.random.default_rng(7)
+    for it in range(300):
+        ref, (q,) = adversarial_case(rng, 10, 120)
+        min_len = int(rng.integers(1, 20))
+        K = min(min_len, 16)
+        for strand in (0, 1):
+            qq = oracles.revcomp(q) if strand else q
+            j0, l0, n0, r0 = oracles.restatement_events(O, ref, qq, min_len)
+            j1, l1, n1, r1 = E.find_events(ref, q, min_len, strand)
+            a = sorted(zip(l0.tolist(), j0.tolist(), n0.tolist(), [x if x >= K else 0 for x in r0.tolist()]))
+            b = sorted(zip(l1.tolist(), j1.tolist(), n1.tolist(), r1.tolist()))
+            assert a == b, (it, ref, q, min_len, strand)
+
+
+def test_end_to_end_with_emulated_engine(emu, tmp_path):
+    r, gs = synth.make("viral50")
+    rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
+    test_host_logic.check(emu[1], "viral50", rp, qs, str(tmp_path / "out"), True)

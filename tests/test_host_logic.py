@@ -1,0 +1,71 @@
+"""Host side of the parsnp_core replacement (ini, ingest, validation, recursive extension, LCB chaining, XMFA/log)
+checked end to end against the reference binary's committed goldens, with the CPU checker standing in for the GPU
+engine behind the C ABI (oracle/_ref/parsnp_core_oracle -- test build only)."""
+import json
+import os
+
+import pytest
+
+import xmfa_util
+from parsnp_amd import driver, synth
+from test_golden import mers
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+E2E = json.load(open(os.path.join(G, "e2e.json")))
+
+
+def check(core, name, rp, qs, out, exact_xmfa, env=None):
+    rc, _ = driver.run_core(core, rp, qs, out, env=env)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    x = os.path.join(out, "parsnpAligner.xmfa")
+    want = E2E[name]
+    assert xmfa_util.mum_lcb_signature(x) == want["signature"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
+    if exact_xmfa:
+        assert xmfa_util.md5(x) == want["xmfa_md5"]
+    assert os.path.exists(os.path.join(out, "allmums.out"))
+
+
+def test_mers(cpu_checkers, tmp_path):
+    ref, qs = mers(base=str(tmp_path))
+    check(cpu_checkers, "mers", ref, qs, str(tmp_path / "out"), exact_xmfa=False)
+
+
+@pytest.mark.parametrize("name,exact", [("viral50", True), ("pop6x200k", False), ("rearr6x300k", True)])
+def test_synthetic(cpu_checkers, tmp_path, name, exact):
+    r, gs = synth.make(name)
+    rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
+    check(cpu_checkers, name, rp, qs, str(tmp_path / "out"), exact)
+
+
+def test_no_speculation_same_result(cpu_checkers, tmp_path):
+    """the batched speculative sweep must not change the result of the in-order replay"""
+    r, gs = synth.make("pop6x200k")
+    rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
+    env = dict(os.environ, PARSNP_NO_SPECULATION="1")
+    check(cpu_checkers, "pop6x200k", rp, qs, str(tmp_path / "out"), False, env=env)
+
+
+def test_cli_surface(cpu_checkers, tmp_path):
+    import subprocess
+    assert subprocess.run([cpu_checkers, "-v"], capture_output=True, text=True).stdout.strip() == "Parsnp v1.0.1"
+    assert "parameter file" in subprocess.run([cpu_checkers, "-h"], capture_output=True, text=True).stdout
+    assert subprocess.run([cpu_checkers], capture_output=True).returncode == 1
+    # missing reference file -> exit(1) with the reference's message
+    ini = tmp_path / "x.ini"
+    ini.write_text(driver.ini_text("/nonexistent/ref.fna", [], str(tmp_path)))
+    p = subprocess.run([cpu_checkers, str(ini)], capture_output=True, text=True)
+    assert p.returncode == 1 and "Cannot open reference file" in p.stdout
+
+
+def test_no_mums_found(cpu_checkers, tmp_path):
+    """unrelated genomes: rc 0, 'NO MUMS FOUND' in the log, no XMFA (src/parsnp.cpp:3223-3229)"""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    ref = synth.random_genome(rng, 5000).tobytes(); q = synth.random_genome(rng, 5000).tobytes()
+    rp, qs = synth.write_set(str(tmp_path / "in"), ref, [q])
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(cpu_checkers, rp, qs, out)
+    assert rc == 0
+    assert not os.path.exists(os.path.join(out, "parsnpAligner.xmfa"))
+    assert open(os.path.join(out, "parsnpAligner.log")).read().strip() == "NO MUMS FOUND"
