@@ -1,0 +1,55 @@
+"""The C-ABI library loads and exports every symbol include/parsnp_mum.h declares (no compute calls: no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from parsnp_amd.paths import HIP_LIB, ROOT
+
+
+def declared():
+    txt = open(os.path.join(ROOT, "include", "parsnp_mum.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pm_[a-z_]+)\s*\(", txt)))
+
+
+def test_header_declares_the_surface():
+    d = declared()
+    for name in ("pm_session_create", "pm_session_destroy", "pm_multi_mum_batch", "pm_result_free", "pm_find_events", "pm_last_error"):
+        assert name in d
+
+
+def test_hip_library_exports_every_declared_symbol():
+    if not os.path.exists(HIP_LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(HIP_LIB)
+    for name in declared():
+        assert hasattr(lib, name), name
+    lib.pm_provider.restype = ctypes.c_char_p
+    assert lib.pm_provider() == b"hip"
+
+
+def test_product_has_no_cpu_path(tmp_path):
+    """without a GPU the product must fail loudly, not fall back"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from parsnp_amd.binding import Lib, PmError, Session
+    with pytest.raises(PmError):
+        Session(Lib(HIP_LIB), [b"ACGT", b"ACGT"])
+
+
+def test_product_does_not_reference_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "parsnp_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                if re.search(r"oracle/|mum_oracle|pm_oracle|libpm_emu|tests/emu", open(os.path.join(base, f), errors="ignore").read()):
+                    bad.append(os.path.join(base, f))
+    # comments in headers may MENTION the test providers; nothing may include, link or load them
+    for p in bad:
+        txt = open(p, errors="ignore").read()
+        assert not re.search(r'#include\s*"[^"]*(oracle|emu)', txt), p
+        assert not re.search(r"(CDLL|dlopen|-l)\s*\(?[\"']?[^\n]*(pm_oracle|mum_oracle|pm_emu)", txt), p

@@ -1,0 +1,186 @@
+"""Parity of the HIP engine (parsnp_amd/lib/libparsnp_hip.so, through the C ABI) on a real MI355X:
+against the CPU restatement on seeded inputs, against the reference's own csgmum code where oracle/_ref ships it,
+against the committed goldens, and end to end through parsnp_core against the reference binary's goldens."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracles
+import test_emu_engine as T
+import test_host_logic
+import xmfa_util
+from parsnp_amd import driver, synth
+from parsnp_amd.binding import Lib, Session
+from parsnp_amd.paths import CORE_BIN, HIP_LIB
+from seqgen import adversarial_case, mutate, random_seq
+from test_golden import G, mers, read_fasta
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def libs(cpu_checkers):
+    H = Lib(HIP_LIB)          # raises if the HIP library is missing: no fallback
+    assert H.provider == "hip"
+    return H, oracles.load_restatement()
+
+
+def test_random_regions(libs):
+    H, O = libs
+    rng = np.random.default_rng(15)
+    total = 0
+    for it in range(300):
+        ref, qs = adversarial_case(rng, 10, 90, int(rng.integers(1, 5)))
+        minsize = int(rng.integers(1, 12))
+        a = oracles.restatement_multi_mum(O, [ref] + qs, minsize, 1)
+        with Session(H, [ref] + qs) as s:
+            b = s.whole(minsize)
+        assert T.same(a, b), (it, ref, qs, minsize)
+        total += len(a[0])
+    assert total > 400
+
+
+@pytest.mark.skipif(not oracles.have_reference(), reason="oracle/_ref/libcsgmum_ref.so not shipped")
+def test_random_regions_vs_reference_code(libs):
+    H, _ = libs
+    R = oracles.load_reference()
+    rng = np.random.default_rng(16)
+    n = 0
+    for it in range(300):
+        ref, qs = adversarial_case(rng, 10, 90, int(rng.integers(1, 5)))
+        if any(not any(c in ref for c in q) for q in qs) or any(not any(c in ref for c in oracles.revcomp(q)) for q in qs):
+            continue
+        minsize = int(rng.integers(3, 11))
+        a = oracles.reference_multi_mum(R, [ref] + qs, minsize)
+        with Session(H, [ref] + qs) as s:
+            b = s.whole(minsize)
+        assert T.same(a, b), (it, ref, qs, minsize)
+        n += len(a[0])
+    assert n > 300
+
+
+def test_batched_regions(libs):
+    H, O = libs
+    rng = np.random.default_rng(17)
+    assert sum(T.batch_case(rng, H, O) for _ in range(6)) > 50
+    assert T.batch_case(rng, H, O, n_regions=24, glen=40000, nq=4, big_minsize=True) > 10
+
+
+def test_empty_and_ragged(libs):
+    H, O = libs
+    seqs = [b"ACGTACGTTTGACCA", b"", b"ACGTACGTTTGACCA", b"N" * 40, b"TGGTCAAACGTACGT"]
+    with Session(H, seqs) as s:
+        k, lon, sp, fw = s.whole(4)
+        assert len(k) == 0                       # an empty genome has no match: no multi-MUM
+        starts = np.zeros((3, 5), np.int64); lens = np.array([[15, 0, 15, 40, 15], [0, 0, 0, 0, 0], [15, 0, 15, 0, 15]], np.int64)
+        out = s.multi_mum_batch(starts, lens, [4, 4, 4])
+        assert all(len(o[0]) == 0 for o in out)
+    seqs = [b"ACGTACGTTTGACCA", b"ACGTACGTTTGACCA", b"TGGTCAAACGTACGT"]
+    a = oracles.restatement_multi_mum(O, seqs, 4, 1)
+    with Session(H, seqs) as s:
+        b = s.whole(4)
+    assert T.same(a, b) and len(a[0]) == 1 and a[3][0].tolist() == [1, 0]
+
+
+def test_events(libs):
+    H, O = libs
+    rng = np.random.default_rng(18)
+    for it in range(150):
+        ref, (q,) = adversarial_case(rng, 10, 120)
+        min_len = int(rng.integers(1, 20)); K = min(min_len, 16)
+        for strand in (0, 1):
+            qq = oracles.revcomp(q) if strand else q
+            j0, l0, n0, r0 = oracles.restatement_events(O, ref, qq, min_len)
+            j1, l1, n1, r1 = H.find_events(ref, q, min_len, strand)
+            a = sorted(zip(l0.tolist(), j0.tolist(), n0.tolist(), [x if x >= K else 0 for x in r0.tolist()]))
+            b = sorted(zip(l1.tolist(), j1.tolist(), n1.tolist(), r1.tolist()))
+            assert a == b, (it, ref, q, min_len, strand)
+
+
+def test_mers_anchor_golden(libs, tmp_path):
+    H, _ = libs
+    ref, qs = mers(base=str(tmp_path))
+    seqs = [read_fasta(ref)] + [read_fasta(p) for p in qs]
+    g2 = np.load(os.path.join(G, "mers_anchor.npz"))
+    with Session(H, seqs) as s:
+        k, lon, sp, fw = s.whole(17)
+    assert np.array_equal(k, g2["k"]) and np.array_equal(lon, g2["lon"]) and np.array_equal(sp, g2["sp"]) and np.array_equal(fw, g2["fwd"])
+
+
+def test_medium_vs_restatement(libs):
+    H, O = libs
+    rng = np.random.default_rng(19)
+    ref = random_seq(rng, 120000)
+    qs = []
+    for g in range(5):
+        q = mutate(rng, ref, sub=0.02, indel=0.002)
+        if g == 2:
+            q = q[:30000] + oracles.revcomp(q[30000:70000]) + q[70000:]
+        if g == 3:   # contig padding like ingest: 310 N
+            q = q[:50000] + b"N" * 310 + q[50000:]
+        qs.append(q)
+    a = oracles.restatement_multi_mum(O, [ref] + qs, 19, 19)
+    with Session(H, [ref] + qs) as s:
+        b = s.whole(19)
+    assert len(a[0]) > 300 and T.same(a, b)
+
+
+def test_properties_at_scale(libs):
+    """5 Mb genomes (BASELINE config-3 size, 4 queries): size-independent properties of the candidate list --
+    every candidate is an exact match in every genome on the reported strand, maximal on at least one side in some
+    genome, candidates are sorted and their reference intervals strictly advance; a planted inversion comes back on
+    the reverse strand; determinism across two runs."""
+    H, _ = libs
+    ref, gs = synth.population(seed=21, n=5_000_000, n_genomes=4, div=0.02, indel_frac=0.05)
+    g1 = gs[1]; gs[1] = g1[:1_000_000] + oracles.revcomp(g1[1_000_000:1_200_000]) + g1[1_200_000:]
+    seqs = [ref] + gs
+    with Session(H, seqs) as s:
+        k, lon, sp, fw = s.whole(25)
+        k2, lon2, sp2, fw2 = s.whole(25)
+        timing = s.last_timing()
+    assert np.array_equal(k, k2) and np.array_equal(lon, lon2) and np.array_equal(sp, sp2) and np.array_equal(fw, fw2)
+    assert len(k) > 20000 and (lon >= 25).all()
+    assert (np.diff(k) > 0).all() and (np.diff(k + lon) > 0).all()
+    assert (fw[:, 1] == 0).sum() > 500 and (fw[:, 0] == 1).all()
+    R = np.frombuffer(ref, np.uint8)
+    rcs = [np.frombuffer(oracles.revcomp(g), np.uint8) for g in gs]
+    fws = [np.frombuffer(g, np.uint8) for g in gs]
+    idx = np.random.default_rng(0).choice(len(k), 3000, replace=False)
+    for c in idx:
+        want = R[k[c]:k[c] + lon[c]]
+        for g in range(4):
+            src = fws[g] if fw[c, g] else rcs[g]
+            assert np.array_equal(src[sp[c, g]:sp[c, g] + lon[c]], want), (c, g)
+    print("timing", timing)
+
+
+E2E = json.load(open(os.path.join(G, "e2e.json")))
+
+
+def test_parsnp_core_mers(libs, tmp_path):
+    ref, qs = mers(base=str(tmp_path))
+    test_host_logic.check(CORE_BIN, "mers", ref, qs, str(tmp_path / "out"), exact_xmfa=False)
+
+
+@pytest.mark.parametrize("name,exact", [("viral50", True), ("pop6x200k", False), ("rearr6x300k", True)])
+def test_parsnp_core_synthetic(libs, tmp_path, name, exact):
+    r, gs = synth.make(name)
+    rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
+    test_host_logic.check(CORE_BIN, name, rp, qs, str(tmp_path / "out"), exact)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(oracles.REFDIR, "parsnp_core_ref")), reason="reference binary not shipped")
+def test_parsnp_core_vs_reference_binary_fresh_input(libs, tmp_path):
+    """an input that has no committed golden: run the shipped reference binary and the product side by side"""
+    r, gs = synth.population(seed=77, n=400_000, n_genomes=9, div=0.02, indel_frac=0.05)
+    g = gs[4]; gs[4] = g[:100_000] + oracles.revcomp(g[100_000:140_000]) + g[140_000:]
+    rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
+    ref_bin = os.path.join(oracles.REFDIR, "parsnp_core_ref")
+    rc1, _ = driver.run_core(ref_bin, rp, qs, str(tmp_path / "ref"))
+    rc2, _ = driver.run_core(CORE_BIN, rp, qs, str(tmp_path / "hip"))
+    assert rc1 == 0 and rc2 == 0
+    a, b = str(tmp_path / "ref" / "parsnpAligner.xmfa"), str(tmp_path / "hip" / "parsnpAligner.xmfa")
+    assert xmfa_util.mum_lcb_signature(a) == xmfa_util.mum_lcb_signature(b)
+    assert xmfa_util.log_counters(str(tmp_path / "ref" / "parsnpAligner.log")) == xmfa_util.log_counters(str(tmp_path / "hip" / "parsnpAligner.log"))
