@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- genomes/sec of the MUM + LCB hot path (phases A-D of parsnp_core: anchor multi-MUM search,
+recursive inter-anchor extension, LCB formation) on MI355X, on BASELINE.json's headline configuration.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bact200] [--genomes G]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic genomes (reference + G queries) whose packed
+sequences are already resident in HBM (ingest, upload and XMFA writing are outside the timed region and reported
+separately).  N > 1: partition mode's natural split -- every rank owns one partition (the shared reference + its own
+G query genomes) on its own GPU, no data-path collective; value = genomes of all ranks / max-over-ranks time
+("scaling": "weak").
+
+The JSON line also carries
+  roofline      dominant kernel of the anchor launch, timed live with HIP events on the engine's stream:
+                achieved = algorithmic bytes per launch (m/4 + 16 m + 16 n per query genome) / duration
+  cpu_baseline  the REFERENCE binary (oracle/_ref/parsnp_core_ref, built from /root/reference in the build container)
+                on the host cores of this box, on a bounded sample of the same workload, single thread (the reference's
+                MUM+LCB path is single-threaded, src/parsnp.cpp:1600-1619).
+"""
+import argparse
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def make_inputs(workdir, workload, genomes, rank):
+    from parsnp_amd import synth
+    model, kw = synth.CONFIGS[workload]
+    kw = dict(kw)
+    if genomes:
+        kw["n_genomes"] = genomes
+    if model == "population":
+        kw["carry_seed"] = None if rank == 0 else 1000 + rank   # same reference + site pool, a different partition per rank
+    ref, gs = getattr(synth, model)(**kw)
+    rp, qs = synth.write_set(os.path.join(workdir, "in"), ref, gs)
+    return rp, qs, len(ref), sum(len(g) for g in gs) / max(1, len(gs)), kw
+
+
+def cpu_baseline(workdir, rp, qs, sample_queries):
+    """the reference binary on a bounded sample (ref + the first `sample_queries` genomes), 1 thread"""
+    from parsnp_amd import driver
+    refbin = os.path.join(ROOT, "oracle", "_ref", "parsnp_core_ref")
+    if not os.path.exists(refbin):
+        return None
+    out = os.path.join(workdir, "cpu_baseline")
+    t0 = time.time()
+    rc, _ = driver.run_core(refbin, rp, qs[:sample_queries], out, threads=1)
+    wall = time.time() - t0
+    if rc != 0:
+        return None
+    log = open(os.path.join(out, "parsnpAligner.log")).read()
+    timers = [float(x) for x in re.findall(r"(?:anchor search|coarsening|filtering|Inter-clustering) elapsed time:\s+([0-9.]+)s", log)]
+    path_s = sum(timers)
+    if path_s <= 0:
+        path_s = wall
+    return {"value": round(sample_queries / path_s, 5), "unit": "genomes/s", "cores": 1, "kind": "reference",
+            "sample": "reference parsnp_core (oracle/_ref) on ref + first %d query genomes of the workload; phases A-D by its own "
+                      "1-s log timers = %.0f s, whole process %.1f s; host has %d cores" % (sample_queries, path_s, wall, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="bact200")
+    ap.add_argument("--genomes", type=int, default=0, help="override the number of query genomes per partition")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="query genomes in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU path); run it through gpurun")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")   # RCCL
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from parsnp_amd import driver
+    from parsnp_amd.core_api import CoreRun
+
+    workdir = tempfile.mkdtemp(prefix="parsnp_bench_r%d_" % rank, dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        t0 = time.time()
+        rp, qs, n_ref, m_avg, kw = make_inputs(workdir, args.workload, args.genomes, rank)
+        gen_s = time.time() - t0
+        out = os.path.join(workdir, "out")
+        os.makedirs(out, exist_ok=True)
+        ini = os.path.join(out, "parsnpAligner.ini")
+        open(ini, "w").write(driver.ini_text(rp, qs, out, threads=8))
+        # quiet: the reference's progress chatter goes to a file
+        so, se = os.dup(1), os.dup(2)
+        logf = os.open(os.path.join(out, "bench.log"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+        os.dup2(logf, 1); os.dup2(logf, 2)
+        try:
+            run = CoreRun(ini)
+            for _ in range(args.warmup):
+                run.step()
+            barrier()
+            t0 = time.perf_counter()
+            reports = [run.step() for _ in range(args.steps)]
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0
+            barrier()
+            t_out = time.time()
+            run.write()
+            output_s = time.time() - t_out
+            run.close()
+        finally:
+            os.dup2(so, 1); os.dup2(se, 2)
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            cb = torch.tensor([reports[-1]["core_bp"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(cb, op=dist.ReduceOp.SUM)
+            core_bp_total = int(cb.item())
+        else:
+            core_bp_total = reports[-1]["core_bp"]
+
+        if rank == 0:
+            rep = reports[-1]
+            G = len(qs)
+            value = world * G * args.steps / elapsed
+            # dominant kernel of the anchor launch, averaged over the timed steps
+            phases = {}
+            for r in reports:
+                for k, v in r["anchor_ms"].items():
+                    phases[k] = phases.get(k, 0.0) + v / len(reports)
+            kernels = {k: v for k, v in phases.items() if k not in ("setup", "download", "units")}
+            dom = max(kernels, key=kernels.get) if kernels else None
+            b_alg = m_avg / 4 + 16 * m_avg + 16 * n_ref          # bytes per query genome
+            roof = None
+            if dom:
+                gbs = b_alg * G / (kernels[dom] * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "launch_ms": round(kernels[dom], 4),
+                        "alg_bytes_per_launch": int(b_alg * G)}
+            line = {
+                "metric": "genomes/sec (MUM+LCB end-to-end)", "value": round(value, 4), "unit": "genomes/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                "config": {"workload": "%s: %d query genomes x %.2f Mb vs 1 reference (%s model, %s), --no-partition per GPU%s"
+                           % (args.workload, G, n_ref / 1e6, dict(bact200="population").get(args.workload, "synthetic"),
+                              ", ".join("%s=%s" % (k, v) for k, v in sorted(kw.items()) if k not in ("n", "n_genomes")),
+                              "" if world == 1 else "; one partition per rank, %d ranks" % world),
+                           "genomes_per_gpu": G, "genome_bp": n_ref, "parallelism": "partition-per-gpu x%d" % world},
+                "core_bp_aligned": core_bp_total,
+                "mums": rep["mums"], "anchors": rep["anchors"], "lcbs": rep["lcbs"],
+                "split_s": {"path": rep["path_s"], "anchor": rep["anchor_s"], "extend": rep["extend_s"], "lcb": rep["lcb_s"],
+                            "engine_calls_wall": rep["finder_s"], "ingest": rep["ingest_s"], "upload": rep["upload_s"],
+                            "output": output_s, "generate": gen_s},
+                "engine_ms": {k: round(v, 3) for k, v in rep["engine_ms"].items()},
+                "anchor_launch_ms": {k: round(v, 3) for k, v in phases.items()},
+                "regions": {"processed": rep["regions_processed"], "engine_calls": rep["finder_calls"], "cache_misses": rep["cache_misses"],
+                            "speculative_rounds": rep["spec_rounds"]},
+                "roofline": roof,
+                "cpu_baseline": cpu_baseline(workdir, rp, qs, args.cpu_sample) if args.cpu_sample > 0 else None,
+            }
+            print(json.dumps(line))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+    finally:
+        if not args.keep:
+            shutil.rmtree(workdir, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -184,7 +184,10 @@ public:
         ensure(d_lo, (size_t)npairs + 1);
         be.launch("pair_bounds", npairs, PairBounds{skey, (int64_t)nev, lbits, npairs, d_lo.p});
         ensure(d_state, std::max<size_t>(nev, 1)); ensure(d_emax, std::max<size_t>(nev, 1));
-        be.launch("pair_scan", npairs, PairScan{skey, sval, d_lo.p, lbits, d_state.p, d_emax.p});
+        const int64_t nchunks = ((int64_t)nev + kChunk - 1) / kChunk;
+        ensure(d_summary, (size_t)std::max<int64_t>(nchunks, 1)); ensure(d_startshere, (size_t)std::max<int64_t>(nchunks, 1));
+        be.launch("chunk_reduce", nchunks, ChunkReduce{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p});
+        be.launch("chunk_scan", nchunks, ChunkScan{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p, d_state.p, d_emax.p});
 
         if (want_events) {   // parity hook (pm_find_events): sorted events + rep'
             ev_key_h.resize((size_t)nev); ev_val_h.resize((size_t)nev); rep_h.resize((size_t)npos);
@@ -256,7 +259,7 @@ public:
         auto drop = [&](auto& b) { if (b.p) be.free(b.p); b.p = nullptr; b.cap = 0; };
         drop(d_R); drop(d_starts); drop(d_lens); drop(d_posbase); drop(d_tilebase); drop(d_err); drop(d_tags); drop(d_heads); drop(d_next);
         drop(d_rep); drop(d_epm); drop(d_ucount); drop(d_uoff); drop(d_upair); drop(d_uinfo); drop(d_counter); drop(d_evkey); drop(d_evval);
-        drop(d_evkey2); drop(d_evval2); drop(d_lo); drop(d_state); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
+        drop(d_evkey2); drop(d_evval2); drop(d_lo); drop(d_state); drop(d_summary); drop(d_startshere); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
         drop(d_ok_k); drop(d_ok_lon); drop(d_osp); drop(d_ofwd);
         if (b2) be.free(b2); if (nm) be.free(nm); if (d_goff) be.free(d_goff); if (d_glen) be.free(d_glen);
         b2 = nullptr; nm = nullptr; d_goff = nullptr; d_glen = nullptr;
@@ -283,7 +286,7 @@ private:
     Buf<uint64_t> d_tags; Buf<int32_t> d_heads, d_next, d_rep, d_epm;
     Buf<int64_t> d_ucount, d_uoff; Buf<int32_t> d_upair, d_uinfo;
     Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2;
-    Buf<int64_t> d_lo; Buf<EventState> d_state; Buf<int32_t> d_emax;
+    Buf<int64_t> d_lo; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
     Buf<uint64_t> d_cand, d_cand2; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
 };
 

@@ -340,33 +340,88 @@ struct PairBounds {
         if (pair == npairs - 1) lo[npairs] = nev;
     }
 };
-// State after every event of a pair, both strands side by side.  This is Test_UM (mum.c:27-45) + the forward carry
-// of Intersect_UM (mum.c:125-175) in closed form (SURVEY 3.3-3,-4): per strand, over the events with l <= k,
-//   e1 = furthest end, w = the event that reaches it (first in (l, j) order), e2 = second furthest end;
-//   EP[k] = e1, UP[k] = max(l_w + rep[l_w], e2), SP[k] = j_w + (k - l_w).
 struct StrandState { int32_t e1, e2, w; };
 struct EventState { StrandState s[2]; };
-struct PairScan {
-    const uint64_t* key; const uint64_t* val; const int64_t* lo; int lbits; EventState* st; int32_t* emax;
-    PM_HD void operator()(int64_t pair) const {
-        EventState cur; cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1};
+#ifndef PM_CHUNK
+#define PM_CHUNK 128
+#endif
+constexpr int kChunk = PM_CHUNK;   // events per scan thread
+
+// add event i to a strand state
+PM_HD void state_push(StrandState& s, const uint64_t* key, const uint64_t* val, uint64_t lmask, int64_t i, int32_t l, int32_t j, int32_t end) {
+    bool take = s.w < 0;
+    if (!take) {
+        if (end > s.e1) take = true;
+        else if (end == s.e1) {   // equal reach: the earlier (l, j) is the one Test_UM / Intersect_UM keep
+            uint64_t wk = key[s.w], wv = val[s.w];
+            int32_t wl = (int32_t)((wk >> 1) & lmask), wj = (int32_t)(wv >> 32);
+            take = l < wl || (l == wl && j < wj);
+        }
+    }
+    if (take) { if (s.w >= 0 && s.e1 > s.e2) s.e2 = s.e1; s.e1 = end; s.w = (int32_t)i; }
+    else if (end > s.e2) s.e2 = end;
+}
+// a (earlier events) followed by b (later events) of the same pair and strand
+PM_HD StrandState state_join(const StrandState& a, const StrandState& b, const uint64_t* key, const uint64_t* val, uint64_t lmask) {
+    if (a.w < 0) return b;
+    if (b.w < 0) return a;
+    bool a_wins = a.e1 > b.e1;
+    if (a.e1 == b.e1) {
+        uint64_t ak = key[a.w], bk = key[b.w];
+        int32_t al = (int32_t)((ak >> 1) & lmask), bl = (int32_t)((bk >> 1) & lmask);
+        a_wins = al < bl || (al == bl && (int32_t)(val[a.w] >> 32) <= (int32_t)(val[b.w] >> 32));
+    }
+    StrandState o;
+    if (a_wins) { o.e1 = a.e1; o.w = a.w; o.e2 = a.e2 > b.e1 ? a.e2 : b.e1; }
+    else { o.e1 = b.e1; o.w = b.w; o.e2 = b.e2 > a.e1 ? b.e2 : a.e1; }
+    return o;
+}
+// Pass 1, tid = chunk of kChunk consecutive sorted events: state of the chunk's TRAILING pair (events of the chunk
+// that belong to the same pair as its last event) and whether that pair starts inside the chunk.
+struct ChunkReduce {
+    const uint64_t* key; const uint64_t* val; int64_t nev; int lbits; EventState* summary; uint8_t* starts_here;
+    PM_HD void operator()(int64_t c) const {
         const uint64_t lmask = (1ull << lbits) - 1;
-        for (int64_t i = lo[pair]; i < lo[pair + 1]; i++) {
+        int64_t a = c * kChunk, b = a + kChunk < nev ? a + kChunk : nev;
+        uint64_t pair = key[b - 1] >> (lbits + 1);
+        EventState cur; cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1};
+        int64_t i = b - 1;
+        while (i > a && (key[i - 1] >> (lbits + 1)) == pair) i--;       // first event of the trailing pair inside the chunk
+        starts_here[c] = (i > a) || a == 0 || (key[a - 1] >> (lbits + 1)) != pair;
+        for (; i < b; i++) {
             uint64_t k = key[i], v = val[i];
-            int sd = (int)(k & 1);
-            int32_t l = (int32_t)((k >> 1) & lmask), j = (int32_t)(v >> 32), end = l + (int32_t)(v & 0xffffffffu);
-            StrandState& s = cur.s[sd];
-            bool take = s.w < 0;
-            if (!take) {
-                if (end > s.e1) take = true;
-                else if (end == s.e1) {   // equal reach: the earlier (l, j) is the one Test_UM/Intersect_UM keep
-                    uint64_t wk = key[s.w], wv = val[s.w];
-                    int32_t wl = (int32_t)((wk >> 1) & lmask), wj = (int32_t)(wv >> 32);
-                    take = l < wl || (l == wl && j < wj);
-                }
+            int32_t l = (int32_t)((k >> 1) & lmask);
+            state_push(cur.s[k & 1], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
+        }
+        summary[c] = cur;
+    }
+};
+// Pass 2, tid = chunk: carry-in from the preceding chunks of the same pair (look back to the chunk the pair starts
+// in), then the running state after every event.  This is Test_UM (mum.c:27-45) + the forward carry of Intersect_UM
+// (mum.c:125-175) in closed form (SURVEY 3.3-3,-4): per strand, over the events with l <= k,
+//   e1 = furthest end, w = the event that reaches it (first in (l, j) order), e2 = second furthest end;
+//   EP[k] = e1, UP[k] = max(l_w + rep[l_w], e2), SP[k] = j_w + (k - l_w).
+struct ChunkScan {
+    const uint64_t* key; const uint64_t* val; int64_t nev; int lbits; const EventState* summary; const uint8_t* starts_here;
+    EventState* st; int32_t* emax;
+    PM_HD void operator()(int64_t c) const {
+        const uint64_t lmask = (1ull << lbits) - 1;
+        int64_t a = c * kChunk, b = a + kChunk < nev ? a + kChunk : nev;
+        EventState cur; cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1};
+        uint64_t pair = key[a] >> (lbits + 1);
+        if (a > 0 && (key[a - 1] >> (lbits + 1)) == pair) {
+            // the pair began in an earlier chunk: fold the summaries back to (and including) the chunk it starts in
+            for (int64_t p = c - 1; p >= 0; p--) {
+                cur.s[0] = state_join(summary[p].s[0], cur.s[0], key, val, lmask);
+                cur.s[1] = state_join(summary[p].s[1], cur.s[1], key, val, lmask);
+                if (starts_here[p]) break;
             }
-            if (take) { if (s.w >= 0 && s.e1 > s.e2) s.e2 = s.e1; s.e1 = end; s.w = (int32_t)i; }
-            else if (end > s.e2) s.e2 = end;
+        }
+        for (int64_t i = a; i < b; i++) {
+            uint64_t k = key[i], v = val[i];
+            if ((k >> (lbits + 1)) != pair) { pair = k >> (lbits + 1); cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1}; }
+            int32_t l = (int32_t)((k >> 1) & lmask);
+            state_push(cur.s[k & 1], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
             st[i] = cur;
             emax[i] = cur.s[0].e1 > cur.s[1].e1 ? cur.s[0].e1 : cur.s[1].e1;
         }

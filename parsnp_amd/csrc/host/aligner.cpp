@@ -204,6 +204,18 @@ void Aligner::run_batch(const std::vector<const Request*>& reqs, std::vector<Raw
         r.fwd.assign(fw + a * q, fw + b * q);
     }
     pm_result_free(res);
+    {
+        int cnt = 64; const char* names[64]; float ms[64];
+        if (pm_last_timing(session_, &cnt, names, ms) == PM_OK) {
+            if (stats.finder_calls == 0) stats.anchor_ms.clear();
+            for (int i = 0; i < cnt; i++) {
+                if (stats.finder_calls == 0) stats.anchor_ms.emplace_back(names[i], ms[i]);
+                bool merged = false;
+                for (auto& kv : stats.engine_ms) if (kv.first == names[i]) { kv.second += ms[i]; merged = true; }
+                if (!merged) stats.engine_ms.emplace_back(names[i], ms[i]);
+            }
+        }
+    }
     stats.finder_calls++;
     stats.finder_regions += (long)reqs.size();
     stats.finder_s += now_s() - t0;

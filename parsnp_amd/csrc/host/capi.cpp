@@ -1,0 +1,53 @@
+// capi.cpp -- in-process C API over CoreRun for bench.py and tests (libparsnp_core.so): open once (ingest +
+// upload), then step the timed path (phases A-D) any number of times on the resident genomes.
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+#include "core.h"
+
+using namespace parsnp;
+
+extern "C" {
+
+struct pc_run { CoreRun run; StepReport last; std::string json; };
+
+// returns 0 or the process exit code parsnp_core would have used
+int pc_open(const char* ini_path, pc_run** out) {
+    pc_run* r = new pc_run;
+    int rc = r->run.open(ini_path);
+    if (rc) { delete r; return rc; }
+    *out = r;
+    return 0;
+}
+// one pass of phases A-D; returns a JSON report (valid until the next call on this handle)
+const char* pc_step(pc_run* r) {
+    r->last = r->run.step();
+    const StepReport& s = r->last;
+    std::ostringstream o;
+    o.precision(9);
+    o << "{\"provider\": \"" << pm_provider() << "\", \"queries\": " << r->run.qfiles << ", \"path_s\": " << s.path_s << ", \"anchor_s\": " << s.anchor_s
+      << ", \"extend_s\": " << s.extend_s << ", \"filter_s\": " << s.filter_s << ", \"lcb_s\": " << s.lcb_s << ", \"finder_s\": " << s.finder_s
+      << ", \"ingest_s\": " << r->run.ingest_s << ", \"upload_s\": " << r->run.upload_s << ", \"anchors\": " << s.anchors << ", \"mums\": " << s.mums
+      << ", \"lcbs\": " << s.lcbs << ", \"core_bp\": " << s.core_bp << ", \"finder_calls\": " << s.finder_calls << ", \"finder_regions\": "
+      << s.finder_regions << ", \"regions_processed\": " << s.regions_processed << ", \"cache_hits\": " << s.cache_hits << ", \"cache_misses\": "
+      << s.cache_misses << ", \"spec_rounds\": " << s.spec_rounds << ", \"mums_found\": " << (s.mums_found ? "true" : "false");
+    for (int which = 0; which < 2; which++) {
+        o << ", \"" << (which ? "anchor_ms" : "engine_ms") << "\": {";
+        const auto& v = which ? s.anchor_ms : s.engine_ms;
+        for (size_t i = 0; i < v.size(); i++) o << (i ? ", " : "") << "\"" << v[i].first << "\": " << v[i].second;
+        o << "}";
+    }
+    o << "}";
+    r->json = o.str();
+    return r->json.c_str();
+}
+int pc_write(pc_run* r) {
+    if (!r->last.mums_found) return 1;
+    bool note = false;
+    r->run.write(&note);
+    return 0;
+}
+void pc_close(pc_run* r) { delete r; }
+
+}  // extern "C"

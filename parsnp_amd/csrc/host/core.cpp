@@ -1,0 +1,150 @@
+#include "core.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+
+#include "ini.h"
+
+namespace parsnp {
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+CoreRun::~CoreRun() {
+    align.reset();
+    if (session) pm_session_destroy(session);
+}
+
+int CoreRun::open(const std::string& ini_path) {
+    IniFile ini;
+    ini.read(ini_path);
+    prm.c = ini.get_int("LCB", "c");
+    prm.d = ini.get_int("LCB", "d");
+    prm.diag_diff = (float)ini.get_double("LCB", "diagdiff");
+    if (prm.diag_diff < 0.0 || prm.diag_diff > 10000000) prm.diag_diff = 1.0;
+    prm.q = ini.get_int("LCB", "q");
+    prm.p = ini.get_int("LCB", "p");
+    prm.do_align = ini.get_int("LCB", "doalign");
+    prm.unaligned = ini.get_bool("LCB", "unaligned");
+    std::cout << prm.unaligned << std::endl;
+    prm.cores = ini.get_int("LCB", "cores");
+    prm.recomb_filter = ini.get_bool("LCB", "recombfilter");
+    prm.anchors = ini.get("MUM", "anchors");
+    prm.anchorfile = ini.get("MUM", "anchorfile");
+    prm.anchors_only = ini.get_bool("MUM", "anchorsonly");
+    prm.calc_mumi = ini.get_bool("MUM", "calcmumi");
+    prm.extend_mums = ini.get_bool("MUM", "extendmums");
+    prm.mums = ini.get("MUM", "mums");
+    prm.mumfile = ini.get("MUM", "mumfile");
+    prm.random = ini.get_int("MUM", "filter");
+    prm.factor = (float)ini.get_double("MUM", "factor");
+    prm.prefix = ini.get("Output", "prefix", "parsnp");
+    prm.outdir = ini.get("Output", "outdir", "output");
+    const bool reverse_ref = ini.get_bool("Reference", "reverse");
+    qfiles = (int)ini.count("Query") / 2;
+
+    if (prm.calc_mumi || !prm.anchorfile.empty() || !prm.mumfile.empty() || prm.unaligned) {
+        // calcmumi (setMumi), anchorfile/mumfile replay and parsnp.unalign are outside the accelerated path
+        std::cerr << "parsnp_core (MI355X build): calcmumi / anchorfile / mumfile / unaligned are not supported by this build" << std::endl;
+        return 1;
+    }
+
+    time_t start, end;
+    time(&start);
+    const double t0 = now_s();
+    genomes.assign((size_t)qfiles + 1, Genome());
+    for (int i = 0; i <= qfiles; i++) {
+        std::string path;
+        bool rev;
+        if (i == 0) { path = ini.get("Reference", "file"); rev = reverse_ref; }
+        else {
+            char buf[64];
+            snprintf(buf, sizeof buf, "file%d", i);
+            path = ini.get("Query", buf);
+            snprintf(buf, sizeof buf, "reverse%d", i);
+            rev = ini.get_bool("Query", buf);
+        }
+        if (!ingest(path, i == 0, rev, prm.d, &genomes[(size_t)i])) return 1;
+    }
+    ingest_s = now_s() - t0;
+
+    std::cerr << "\n*****************************************************" << std::endl;
+    std::cerr << "\nparsnpAligner:: rapid whole genome SNP typing" << std::endl;
+    std::cerr << "\n*****************************************************\n" << std::endl;
+    time(&end);
+    std::cerr << "ParSNP: Preparing to construct global multiple alignment framework" << std::endl;
+    std::cerr << "\nPreparing to verify and process input sequences..." << std::endl;
+    printf("        Finished processing input sequences, elapsed time: %.0lf seconds\n\n", difftime(end, start));
+
+    // genomes -> HBM (2-bit + N mask, both strands); the engine addresses regions by coordinates from here on
+    const double t1 = now_s();
+    std::vector<const uint8_t*> ptr(genomes.size());
+    std::vector<int64_t> len(genomes.size());
+    for (size_t i = 0; i < genomes.size(); i++) { ptr[i] = (const uint8_t*)genomes[i].seq.data(); len[i] = (int64_t)genomes[i].seq.size(); }
+    int rc = pm_session_create(&session, -1, (int)genomes.size(), ptr.data(), len.data());
+    if (rc != PM_OK) {
+        std::cerr << "parsnp_core: cannot start the multi-MUM engine (" << pm_provider() << "): " << pm_last_error() << std::endl;
+        return 3;
+    }
+    upload_s = now_s() - t1;
+    return 0;
+}
+
+StepReport CoreRun::step() {
+    StepReport r;
+    align.reset(new Aligner(genomes, prm, session));
+    Aligner& a = *align;
+    time_t start, end;
+    time(&start);
+    std::cerr << "Searching for initial MUM anchors..." << std::endl;
+    const double t0 = now_s();
+    bool found = a.find_anchors();
+    time(&end);
+    a.anchor_time = (float)difftime(end, start);
+    time(&start);
+    if (!prm.anchors_only) {
+        std::cerr << "Performing recursive MUM search between MUM anchors..." << std::endl;
+        found = a.extend();
+    }
+    time(&end);
+    r.mums_found = found;
+    if (found) {
+        printf("        Finished recursive MUM search, elapsed time: %.0lf seconds\n\n", difftime(end, start));
+        a.coarsen_time = (float)difftime(end, start);
+        if (prm.random) {
+            std::cerr << "Filtering spurious matches..." << std::endl;
+            time(&start);
+            a.random = prm.random;
+            a.filter_mums(prm.random);
+            time(&end);
+            printf("        Finished filtering spurious matches, elapsed time: %.0lf seconds\n\n", difftime(end, start));
+            a.random_time = (float)difftime(end, start);
+        }
+        time(&start);
+        std::cerr << "Creating and verifying final LCBs..." << std::endl;
+        a.chain();
+        a.filter_lcbs();
+        a.chain();
+        a.fill_between();
+        time(&end);
+        a.iclusters_time = (float)difftime(end, start);
+        printf("        LCBs created, elapsed time: %.0lf seconds\n\n", difftime(end, start));
+    }
+    r.path_s = now_s() - t0;
+    const Stats& s = a.stats;
+    r.anchor_s = s.anchor_s; r.extend_s = s.extend_s; r.filter_s = s.filter_s; r.lcb_s = s.lcb_s; r.finder_s = s.finder_s;
+    r.finder_calls = s.finder_calls; r.finder_regions = s.finder_regions; r.regions_processed = s.regions_processed;
+    r.cache_hits = s.cache_hits; r.cache_misses = s.cache_misses; r.spec_rounds = s.spec_rounds;
+    r.engine_ms = s.engine_ms; r.anchor_ms = s.anchor_ms;
+    r.anchors = a.m0; r.mums = (long)a.mums.size(); r.lcbs = (long)a.lcbs.size();
+    for (const Lcb& c : a.lcbs)
+        if (c.type == 1 && !c.mums.empty()) r.core_bp += c.end[0] - c.start[0];
+    return r;
+}
+
+void CoreRun::write(bool* gap_note) { write_output(*align, "parsnpAligner", gap_note); }
+
+}  // namespace parsnp

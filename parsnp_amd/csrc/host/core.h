@@ -1,0 +1,39 @@
+// core.h -- one parsnp_core run as an object: configuration, ingest, upload, the timed path (phases A-D of the
+// reference's main(), src/parsnp.cpp:3187-3270) and output.  Used by main.cpp (the drop-in binary) and by capi.cpp
+// (in-process stepping for bench.py and tests).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "aligner.h"
+
+namespace parsnp {
+
+struct StepReport {
+    double path_s = 0, anchor_s = 0, extend_s = 0, filter_s = 0, lcb_s = 0, finder_s = 0;
+    long finder_calls = 0, finder_regions = 0, regions_processed = 0, cache_hits = 0, cache_misses = 0, spec_rounds = 0;
+    long anchors = 0, mums = 0, lcbs = 0, core_bp = 0;
+    bool mums_found = false;
+    std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
+};
+
+class CoreRun {
+public:
+    ~CoreRun();
+    // reads the ini, ingests every genome (printing what the reference prints) and uploads them to the engine.
+    // returns 0, or the exit code the reference would use (1) / 3 when the engine cannot start.
+    int open(const std::string& ini_path);
+    // phases A-D on a fresh Aligner over the resident genomes
+    StepReport step();
+    // XMFA + log of the last step (phase E)
+    void write(bool* gap_note);
+    Params prm;
+    std::vector<Genome> genomes;
+    int qfiles = 0;
+    double ingest_s = 0, upload_s = 0;
+    std::unique_ptr<Aligner> align;
+    pm_session* session = nullptr;
+};
+
+}  // namespace parsnp

@@ -28,14 +28,17 @@ def random_genome(rng, n):
     return _BASES[rng.integers(0, 4, n)]
 
 
-def population(seed, n, n_genomes, div, indel_frac=0.0, sites=None):
-    """-> (ref bytes, [genome bytes]) under the population model."""
+def population(seed, n, n_genomes, div, indel_frac=0.0, sites=None, carry_seed=None):
+    """-> (ref bytes, [genome bytes]) under the population model.  carry_seed: draw the genomes from a separate
+    stream (same reference and site pool, different genomes -- one partition per rank in bench.py)."""
     rng = np.random.default_rng(seed)
     ref = random_genome(rng, n)
     if sites is None:
         sites = np.flatnonzero(rng.random(n) < div)
     alt = _alt(rng, ref[sites])
     is_del = rng.random(len(sites)) < indel_frac
+    if carry_seed is not None:
+        rng = np.random.default_rng(carry_seed)
     out = []
     for _ in range(n_genomes):
         carry = rng.random(len(sites)) < 0.5
