@@ -171,6 +171,7 @@ def main():
                 "split_s": {"path": rep["path_s"], "anchor": rep["anchor_s"], "extend": rep["extend_s"], "lcb": rep["lcb_s"],
                             "engine_calls_wall": rep["finder_s"], "ingest": rep["ingest_s"], "upload": rep["upload_s"],
                             "output": output_s, "generate": gen_s},
+                "host_split_s": rep.get("host_split_s"),
                 "engine_ms": {k: round(v, 3) for k, v in rep["engine_ms"].items()},
                 "anchor_launch_ms": {k: round(v, 3) for k, v in phases.items()},
                 "regions": {"processed": rep["regions_processed"], "engine_calls": rep["finder_calls"], "cache_misses": rep["cache_misses"],

@@ -108,6 +108,7 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session)
 }
 
 Region Aligner::neighbour_region(const Mum& m, bool left) const {
+    struct Tm { double t0; double* acc; ~Tm() { *acc += now_s() - t0; } } tm{now_s(), const_cast<double*>(&stats.t_neighbour)};
     std::vector<long> start(n), end(n);
     for (size_t i = 0; i < n; i++) {
         if (left) {   // walk left to the previous marked base; at the genome start the region begins at 1 (:1216-1231)
@@ -195,6 +196,7 @@ void Aligner::run_batch(const std::vector<const Request*>& reqs, std::vector<Raw
     const int64_t* sp = pm_result_sp(res);
     const uint8_t* fw = pm_result_fwd(res);
     const size_t q = n - 1;
+    double tu = now_s();
     for (size_t i = 0; i < reqs.size(); i++) {
         Raw& r = (*out)[i];
         size_t a = (size_t)off[i], b = (size_t)off[i + 1];
@@ -204,6 +206,7 @@ void Aligner::run_batch(const std::vector<const Request*>& reqs, std::vector<Raw
         r.fwd.assign(fw + a * q, fw + b * q);
     }
     pm_result_free(res);
+    stats.t_unpack += now_s() - tu;
     {
         int cnt = 64; const char* names[64]; float ms[64];
         if (pm_last_timing(session_, &cnt, names, ms) == PM_OK) {
@@ -227,8 +230,10 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
     if (anchors) l = (float)minsize;
     std::vector<Request> reqs = chunk_requests(r, minsize);
     for (Request& q : reqs) {
+        double tk = now_s();
         std::string key = key_of(q);
         auto it = cache_.find(key);
+        stats.t_key += now_s() - tk;
         if (it == cache_.end()) {
             if (speculative) {
                 if (wanted_keys_.emplace(key, (int)wanted_.size()).second) wanted_.push_back(q);
@@ -242,7 +247,7 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
         } else if (!speculative) {
             stats.cache_hits++;
         }
-        validate(r, q, it->second, accepted);
+        { double tv = now_s(); validate(r, q, it->second, accepted); stats.t_validate += now_s() - tv; }
     }
     if (!speculative) stats.regions_processed++;
 }
@@ -371,7 +376,9 @@ bool Aligner::extend_pass(bool speculative) {
             if (i + 1 < found.size()) lR = neighbour_region(pool[found[i + 1]], true);
             mums.push_back(found[i]);
         }
+        double ts = now_s();
         if (head < work.size()) std::sort(work.begin() + (long)head, work.end());
+        stats.t_sort += now_s() - ts;
         // drop a region equal to its successor (adjacent duplicates only, :294-306)
         long rsize = (long)(work.size() - head);
         if (rsize) {
@@ -441,7 +448,10 @@ bool Aligner::extend() {
         regions = saved_regions;
         wanted_.clear(); wanted_keys_.clear();
     }
+    stats.t_sweep = now_s() - t0;
+    double tr = now_s();
     bool any = extend_pass(false);
+    stats.t_replay = now_s() - tr;
     cache_.clear();
     stats.extend_s = now_s() - t0;
     return any;

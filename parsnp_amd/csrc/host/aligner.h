@@ -101,6 +101,7 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     // device-side phase times (HIP events, pm_last_timing): summed over every engine call of the step, and of the
     // anchor call alone (the one launch that sees whole genomes)
     std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
+    double t_validate = 0, t_neighbour = 0, t_key = 0, t_sweep = 0, t_replay = 0, t_sort = 0, t_unpack = 0;   // host split
 };
 
 class Aligner {

@@ -16,6 +16,7 @@ struct StepReport {
     long anchors = 0, mums = 0, lcbs = 0, core_bp = 0;
     bool mums_found = false;
     std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
+    Stats host;
 };
 
 class CoreRun {

@@ -5,7 +5,7 @@ oracle/Makefile).  Run in the build container only:  python tests/golden/make_go
   find_um.npz       G1  raw + propagated (UP,EP,SP) of 50 random small (R,Q) pairs and 4 MERS genome/strand pairs
   mers_anchor.npz   G2  candidate list + Master arrays of the MERS anchor pass (47 genomes)
   e2e.json          G3  XMFA md5, MUM/LCB signature md5 and log counters of the reference binary on
-                        MERS, viral50, pop6x200k, rearr6x300k (inputs: tests/golden/mers_virus.tar.xz / parsnp_amd.synth seeds)
+                        MERS, viral50, pop6x200k, rearr6x300k, pop20x1m (21 x 1 Mb), bact8 (9 x 5 Mb) (inputs: tests/golden/mers_virus.tar.xz / parsnp_amd.synth seeds)
 """
 import glob
 import json
@@ -98,7 +98,7 @@ def main():
                          ref_records=[h for h, _ in xmfa_util.records(x)[1] if h.startswith("> 1:")][:50])
     # file names matter (##SequenceFile): MERS under its own names, synthetic sets as ref.fna / g%04d.fna
     run("mers", mref, mqs)
-    for name in ("viral50", "pop6x200k", "rearr6x300k"):
+    for name in ("viral50", "pop6x200k", "rearr6x300k", "pop20x1m", "bact8"):   # the last one takes ~80 s
         r, gs = synth.make(name)
         rp, qs = synth.write_set(os.path.join(tmp, name), r, gs)
         run(name, rp, qs)

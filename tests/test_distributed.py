@@ -1,0 +1,77 @@
+"""The N>1 path (partition mode: one partition per rank, results all-gathered) with 2 processes on the gloo backend.
+On CPU the partitions run the test build of the host (CPU checker behind the C ABI); on the GPU box the same code
+drives parsnp_amd/bin/parsnp_core with one GPU per rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from parsnp_amd import partition_run
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+core, ref, outdir, listfile = sys.argv[2:6]
+files = open(listfile).read().split()
+res = partition_run.run_partitioned(core, ref, files, outdir, 3, rank, world, dist)
+json.dump(res, open(os.path.join(outdir, "result_rank%d.json" % rank), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_partition_plan_matches_driver_arithmetic():
+    from parsnp_amd import partition_run
+    files = ["g%03d" % i for i in range(2000)]
+    chunks = partition_run.plan_partitions(files, 250)
+    assert [len(c) for c in chunks] == [250] * 8 and sum(chunks, []) == files
+    chunks = partition_run.plan_partitions(files[:1100], 250)     # 4 full partitions of 275
+    assert [len(c) for c in chunks] == [275] * 4
+    chunks = partition_run.plan_partitions(files[:13], 3)         # size 13 // 4 = 3 -> 5 chunks, the last one short
+    assert [len(c) for c in chunks] == [3, 3, 3, 3, 1]
+
+
+def test_interval_intersection():
+    from parsnp_amd import partition_run
+    a = [(1, 100), (200, 300)]; b = [(50, 250)]; c = [(60, 70), (90, 220), (290, 400)]
+    assert partition_run.intersect([a, b]) == [(50, 100), (200, 250)]
+    assert partition_run.intersect([a, b, c]) == [(60, 70), (90, 100), (200, 220)]
+    assert partition_run.intersect([a]) == a and partition_run.intersect([]) == []
+
+
+def test_two_ranks_gloo(cpu_checkers, tmp_path):
+    from parsnp_amd import driver, partition_run, synth
+    import xmfa_util
+    ref, gs = synth.population(seed=31, n=40000, n_genomes=12, div=0.02, indel_frac=0.05)
+    rp, qs = synth.write_set(str(tmp_path / "in"), ref, gs)
+    files = driver.driver_order(qs)
+    listfile = tmp_path / "files.txt"
+    listfile.write_text("\n".join(files))
+    worker = tmp_path / "worker.py"
+    worker.write_text(WORKER)
+    out2 = str(tmp_path / "two")
+    os.makedirs(out2)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29561", str(worker), ROOT, cpu_checkers, rp, out2, str(listfile)]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r0 = json.load(open(os.path.join(out2, "result_rank0.json")))
+    r1 = json.load(open(os.path.join(out2, "result_rank1.json")))
+    assert r0 == r1                                          # every rank holds the merged view
+    assert [p["index"] for p in r0["partitions"]] == [0, 1, 2, 3] and all(p["ok"] for p in r0["partitions"])
+    # single-process run of the same plan: identical partitions, identical intersection
+    out1 = str(tmp_path / "one")
+    single = partition_run.run_partitioned(cpu_checkers, rp, files, out1, 3)
+    assert [p["intervals"] for p in single["partitions"]] == [[list(i) for i in p["intervals"]] for p in r0["partitions"]] or \
+           [[list(i) for i in p["intervals"]] for p in single["partitions"]] == [p["intervals"] for p in r0["partitions"]]
+    assert [list(i) for i in single["intersection"]] == r0["intersection"]
+    assert len(r0["intersection"]) >= 1
+    for a, b in zip(single["partitions"], r0["partitions"]):
+        assert xmfa_util.md5(os.path.join(a["dir"], "parsnpAligner.xmfa")) == xmfa_util.md5(os.path.join(b["dir"], "parsnpAligner.xmfa"))

@@ -164,7 +164,7 @@ def test_parsnp_core_mers(libs, tmp_path):
     test_host_logic.check(CORE_BIN, "mers", ref, qs, str(tmp_path / "out"), exact_xmfa=False)
 
 
-@pytest.mark.parametrize("name,exact", [("viral50", True), ("pop6x200k", False), ("rearr6x300k", True)])
+@pytest.mark.parametrize("name,exact", [("viral50", True), ("pop6x200k", False), ("rearr6x300k", True), ("pop20x1m", False), ("bact8", False)])
 def test_parsnp_core_synthetic(libs, tmp_path, name, exact):
     r, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
