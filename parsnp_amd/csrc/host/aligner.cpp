@@ -81,21 +81,17 @@ void Bitmap::rollback() {
 }
 
 // ---------------------------------------------------------------------------------------------- Region
-static Region make_region(std::vector<long>& start, std::vector<long>& end) {   // TRegion ctor, LCR.cpp:16-37
-    Region r;
-    r.start = start; r.end = end;
+static void finish_region(Region& r, size_t n) {   // TRegion ctor, LCR.cpp:16-37
     long s = 500000000, l = 0;
-    r.length.resize(start.size());
-    for (size_t i = 0; i < start.size(); i++) {
-        r.length[i] = end[i] - start[i];
+    for (size_t i = 0; i < n; i++) {
+        r.length[i] = r.end[i] - r.start[i];
         if (r.length[i] < s) s = r.length[i];
         if (r.length[i] > l) l = r.length[i];
     }
     r.slength = s; r.llength = l;
-    return r;
 }
-bool Region::same_as(const Region& o) const {
-    for (size_t i = 0; i < start.size(); i++)
+bool Region::same_as(const Region& o, size_t n) const {
+    for (size_t i = 0; i < n; i++)
         if (start[i] != o.start[i] || end[i] != o.end[i]) return false;
     return true;
 }
@@ -107,9 +103,13 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session)
     for (size_t i = 0; i < n; i++) layout[i].init(genomes[i].seq.size() + 1);
 }
 
-Region Aligner::neighbour_region(const Mum& m, bool left) const {
-    struct Tm { double t0; double* acc; ~Tm() { *acc += now_s() - t0; } } tm{now_s(), const_cast<double*>(&stats.t_neighbour)};
-    std::vector<long> start(n), end(n);
+Region Aligner::new_region() {
+    Region r;
+    r.start = rows_.alloc(n); r.end = rows_.alloc(n); r.length = rows_.alloc(n);
+    return r;
+}
+void Aligner::neighbour_into(const Mum& m, bool left, Region* out) const {
+    long* start = out->start; long* end = out->end;
     for (size_t i = 0; i < n; i++) {
         if (left) {   // walk left to the previous marked base; at the genome start the region begins at 1 (:1216-1231)
             long p = layout[i].prev_set(m.start[i] - 1);
@@ -123,7 +123,13 @@ Region Aligner::neighbour_region(const Mum& m, bool left) const {
             end[i] = p - 1;
         }
     }
-    return make_region(start, end);
+    finish_region(*out, n);
+}
+Region Aligner::neighbour_region(const Mum& m, bool left) {
+    struct Tm { double t0; double* acc; ~Tm() { *acc += now_s() - t0; } } tm{now_s(), &stats.t_neighbour};
+    Region r = new_region();
+    neighbour_into(m, left, &r);
+    return r;
 }
 
 int Aligner::min_length(bool anchors, long slength) const {
@@ -270,7 +276,10 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
         Mum m;
         m.id = next_id_++;
         m.length = lon;
-        m.start.resize(n); m.end.resize(n); m.fwd.resize(n);
+        const Arena<long>::Mark rmark = rows_.mark();
+        const Arena<int>::Mark imark = irows_.mark();
+        m.start = rows_.alloc(n); m.end = rows_.alloc(n); m.fwd = irows_.alloc(n);
+        auto reject = [&]() { rows_.rewind(rmark); irows_.rewind(imark); };
         bool ok = true;
         for (size_t j = 0; j < n; j++) {
             m.fwd[j] = j == 0 ? 1 : raw.fwd[c * nq + j - 1];
@@ -280,10 +289,10 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
             if (m.start[j] + lon > size || m.start[j] < 0) ok = false;   // never for in-range candidates; the reference would misbehave
             m.end[j] = m.start[j] + lon;
         }
-        if (!ok || m.length < 5) continue;
+        if (!ok || m.length < 5) { reject(); continue; }
         trim(m);
-        if (m.length < 2 || m.start.size() <= 1) continue;
-        if (!m.fwd[0]) continue;
+        if (m.length < 2 || n <= 1) { reject(); continue; }
+        if (!m.fwd[0]) { reject(); continue; }
         // reverse-strand members must spell the reverse complement of the reference member (:1791-1825)
         const std::string& g0 = genomes[0].seq;
         bool mismatch = false;
@@ -301,10 +310,10 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
                 if (g0[(size_t)(m.start[0] + x)] != want) { mismatch = true; break; }
             }
         }
-        if (mismatch) continue;
+        if (mismatch) { reject(); continue; }
         for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end[j]);
         m.slength = r.slength;
-        pool.push_back(std::move(m));
+        pool.push_back(m);
         accepted->push_back((int)pool.size() - 1);
     }
 }
@@ -328,67 +337,123 @@ void Aligner::trim(Mum& m) const {
 
 bool Aligner::find_anchors() {
     double t0 = now_s();
-    std::vector<long> start(n, 0), end(n);
-    for (size_t i = 0; i < n; i++) end[i] = (long)genomes[i].seq.size();
-    Region whole = make_region(start, end);
+    Region whole = new_region();
+    for (size_t i = 0; i < n; i++) { whole.start[i] = 0; whole.end[i] = (long)genomes[i].seq.size(); }
+    finish_region(whole, n);
     std::vector<int> found;
     std::cerr << std::endl << "        Constructing device index of the reference...\n";
     std::cerr << "        Performing initial search for exact matches in the sequences...\n";
     region_mums(whole, true, &found, false);
     mums = found;
     m0 = (long)found.size();
-    // seed regions: left and right neighbour of every anchor, longer than q in every genome (:2150-2172)
-    Region lR, rR;
-    bool have_r = false;
+    // seed regions: left and right neighbour of every anchor, longer than q in every genome (:2150-2172).  The layout
+    // is final here, so the 2*m0 bitmap walks are independent: computed in parallel, consumed in order.
+    double tn = now_s();
+    std::vector<Region> lRs(found.size()), rRs(found.size());
+    for (size_t i = 0; i < found.size(); i++) { lRs[i] = new_region(); rRs[i] = new_region(); }
+    const long nf = (long)found.size();
+#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1)
+    for (long i = 0; i < nf; i++) {
+        neighbour_into(pool[(size_t)found[(size_t)i]], true, &lRs[(size_t)i]);
+        neighbour_into(pool[(size_t)found[(size_t)i]], false, &rRs[(size_t)i]);
+    }
+    stats.t_neighbour += now_s() - tn;
     for (size_t i = 0; i < found.size(); i++) {
-        lR = neighbour_region(pool[found[i]], true);
-        if (lR.slength > prm.q && (i == 0 || !(have_r && lR.same_as(rR)))) regions.push_back(lR);
-        rR = neighbour_region(pool[found[i]], false);
-        have_r = true;
-        if (rR.slength > prm.q && !rR.same_as(lR)) regions.push_back(rR);
+        const Region& lR = lRs[i];
+        if (lR.slength > prm.q && (i == 0 || !lR.same_as(rRs[i - 1], n))) regions.push_back(lR);
+        const Region& rR = rRs[i];
+        if (rR.slength > prm.q && !rR.same_as(lR, n)) regions.push_back(rR);
     }
     stats.anchor_s = now_s() - t0;
     return m0 != 0;
 }
 
-// One pass of the reference's work-list loop (doWork :192-308).  Work-list entries are handles into `rpool`.
+// One pass of the reference's work-list loop (doWork :192-308): pop the front region, find its MUMs, push the left /
+// right neighbour regions of every new MUM, std::sort the list by reference start, drop a region equal to its successor.
+//
+// The list is kept in a std::map while its keys are unique: then the sorted order is unique too, so sort+dedup equals
+// "insert unless an identical region is already there", and nothing has to be re-sorted per iteration (the reference
+// spends a third of its recursion time there).  The moment two DIFFERENT regions share a reference start the unstable
+// std::sort's tie order becomes observable; from then on the literal vector + std::sort + adjacent-dedup of the
+// reference runs on exactly the array the reference would hold, until the keys are unique again.
 bool Aligner::extend_pass(bool speculative) {
     std::vector<Region> rpool = std::move(regions);
     regions.clear();
-    std::vector<Handle> work;
-    work.reserve(rpool.size());
-    for (size_t i = 0; i < rpool.size(); i++) work.push_back(Handle{rpool[i].start[0], (int)i});
+    std::map<long, int> uniq;            // key -> rpool index       (fast mode)
+    std::vector<Handle> work;            // literal mode
+    bool literal = false;
+    {   // the seed list is processed in push order until the first sort (:194-195 precede :291-292)
+        work.reserve(rpool.size());
+        for (size_t i = 0; i < rpool.size(); i++) work.push_back(Handle{rpool[i].start[0], (int)i});
+        literal = true;
+    }
     size_t head = 0;
     std::vector<int> found;
-    while (head < work.size()) {
-        const int cur = work[head++].idx;
+    std::vector<Handle> kids;
+    const bool force_literal = getenv("PARSNP_FORCE_LITERAL_WORKLIST") != nullptr;   // debug: always the reference's vector + std::sort
+    auto keys_unique = [&]() {
+        for (size_t x = head; x + 1 < work.size(); x++) if (!(work[x].key < work[x + 1].key)) return false;
+        return true;
+    };
+    for (;;) {
+        int cur;
+        if (literal) { if (head >= work.size()) break; cur = work[head++].idx; }
+        else { if (uniq.empty()) break; cur = uniq.begin()->second; uniq.erase(uniq.begin()); }
         found.clear();
         {
-            Region curRegion = rpool[(size_t)cur];   // the pool may grow below
+            Region curRegion = rpool[(size_t)cur];   // rows live in the arena; the pool vector may grow below
             region_mums(curRegion, false, &found, speculative);
         }
+        kids.clear();
         Region lR, rR;
         for (size_t i = 0; i < found.size(); i++) {
-            if (i == 0) lR = neighbour_region(pool[found[0]], true);
-            rR = neighbour_region(pool[found[i]], false);
-            if (lR.slength > prm.q) { rpool.push_back(lR); work.push_back(Handle{lR.start[0], (int)rpool.size() - 1}); }
-            if (rR.slength > prm.q) { rpool.push_back(rR); work.push_back(Handle{rR.start[0], (int)rpool.size() - 1}); }
-            if (i + 1 < found.size()) lR = neighbour_region(pool[found[i + 1]], true);
+            if (i == 0) lR = neighbour_region(pool[(size_t)found[0]], true);
+            rR = neighbour_region(pool[(size_t)found[i]], false);
+            if (lR.slength > prm.q) { rpool.push_back(lR); kids.push_back(Handle{lR.start[0], (int)rpool.size() - 1}); }
+            if (rR.slength > prm.q) { rpool.push_back(rR); kids.push_back(Handle{rR.start[0], (int)rpool.size() - 1}); }
+            if (i + 1 < found.size()) lR = neighbour_region(pool[(size_t)found[i + 1]], true);
             mums.push_back(found[i]);
         }
         double ts = now_s();
-        if (head < work.size()) std::sort(work.begin() + (long)head, work.end());
-        stats.t_sort += now_s() - ts;
-        // drop a region equal to its successor (adjacent duplicates only, :294-306)
-        long rsize = (long)(work.size() - head);
-        if (rsize) {
-            for (long x = 0; x < rsize - 1; x++) {
-                if (rpool[(size_t)work[head + (size_t)x].idx].same_as(rpool[(size_t)work[head + (size_t)x + 1].idx])) {
-                    work.erase(work.begin() + (long)head + x);
-                    x -= 1; rsize -= 1;
-                }
+        if (!literal) {
+            // can the children be merged without a tie between different regions?
+            bool clean = true;
+            for (size_t a = 0; a < kids.size() && clean; a++) {
+                auto it = uniq.find(kids[a].key);
+                if (it != uniq.end() && !rpool[(size_t)it->second].same_as(rpool[(size_t)kids[a].idx], n)) clean = false;
+                for (size_t b = 0; b < a && clean; b++)
+                    if (kids[b].key == kids[a].key && !rpool[(size_t)kids[b].idx].same_as(rpool[(size_t)kids[a].idx], n)) clean = false;
+            }
+            if (clean) {
+                for (const Handle& k : kids) uniq.emplace(k.key, k.idx);   // an identical region is already there: dropped
+            } else {
+                work.clear(); head = 0;
+                for (const auto& kv : uniq) work.push_back(Handle{kv.first, kv.second});
+                uniq.clear();
+                literal = true;
+                if (!speculative) stats.tie_fallbacks++;
             }
         }
+        if (literal) {
+            if (!speculative) stats.literal_iterations++;
+            for (const Handle& k : kids) work.push_back(k);
+            if (head < work.size()) std::sort(work.begin() + (long)head, work.end());
+            long rsize = (long)(work.size() - head);
+            if (rsize) {   // drop a region equal to its successor (adjacent duplicates only, :294-306)
+                for (long x = 0; x < rsize - 1; x++) {
+                    if (rpool[(size_t)work[head + (size_t)x].idx].same_as(rpool[(size_t)work[head + (size_t)x + 1].idx], n)) {
+                        work.erase(work.begin() + (long)head + x);
+                        x -= 1; rsize -= 1;
+                    }
+                }
+            }
+            if (!force_literal && keys_unique()) {
+                for (size_t x = head; x < work.size(); x++) uniq.emplace_hint(uniq.end(), work[x].key, work[x].idx);
+                work.clear(); head = 0;
+                literal = false;
+            }
+        }
+        stats.t_sort += now_s() - ts;
     }
     return !mums.empty();
 }
@@ -407,6 +472,8 @@ bool Aligner::extend() {
         const std::vector<int> saved_mums = mums;
         const size_t saved_pool = pool.size();
         const long saved_id = next_id_;
+        const Arena<long>::Mark rmark = rows_.mark();
+        const Arena<int>::Mark imark = irows_.mark();
         std::vector<Region> gen = regions;
         while (!gen.empty()) {
             stats.spec_rounds++;
@@ -430,19 +497,20 @@ bool Aligner::extend() {
                 found.clear();
                 region_mums(r, false, &found, true);
                 for (size_t i = 0; i < found.size(); i++) {
-                    Region a = neighbour_region(pool[found[i]], true), b = neighbour_region(pool[found[i]], false);
-                    if (a.slength > prm.q) next.push_back(std::move(a));
-                    if (b.slength > prm.q) next.push_back(std::move(b));
+                    Region a = neighbour_region(pool[(size_t)found[i]], true), b = neighbour_region(pool[(size_t)found[i]], false);
+                    if (a.slength > prm.q) next.push_back(a);
+                    if (b.slength > prm.q) next.push_back(b);
                 }
             }
             // same clean-up the reference applies to its work list: order by reference start, drop adjacent duplicates
             std::stable_sort(next.begin(), next.end(), [](const Region& x, const Region& y) { return x.start[0] < y.start[0]; });
             gen.clear();
             for (Region& r : next)
-                if (gen.empty() || !gen.back().same_as(r)) gen.push_back(std::move(r));
+                if (gen.empty() || !gen.back().same_as(r, n)) gen.push_back(r);
         }
         for (size_t i = 0; i < n; i++) { layout[i].rollback(); layout[i].end_log(); }
         pool.resize(saved_pool);
+        rows_.rewind(rmark); irows_.rewind(imark);
         next_id_ = saved_id;
         mums = saved_mums;
         regions = saved_regions;
@@ -473,7 +541,7 @@ void Aligner::filter_mums(int rvalue) {
         if (mt.length > rvalue) continue;
         const Mum& nt = pool[(size_t)mums[(size_t)x + 1]];
         const Mum* prev = x > 0 ? &pool[(size_t)mums[(size_t)x - 1]] : nullptr;
-        bool adjacent = nt.start.size() >= n;
+        bool adjacent = true;
         for (size_t k = 0; k < n && adjacent; k++) {
             long gap = labs(nt.start[k]) - labs(mt.end[k]);
             if (gap < 0 || gap > 5000) { adjacent = false; break; }
@@ -496,12 +564,12 @@ void Aligner::filter_mums(int rvalue) {
     stats.filter_s += now_s() - t0;
 }
 
-static Lcb lcb_of(const std::vector<Mum>& pool, int idx, int type = 1) {   // Cluster(TMum), LCB.cpp:21-28
+static Lcb lcb_of(const std::vector<Mum>& pool, size_t n, int idx, int type = 1) {   // Cluster(TMum), LCB.cpp:21-28
     Lcb c;
     c.type = type;
     c.mums.push_back(idx);
-    c.start = pool[(size_t)idx].start;
-    c.end = pool[(size_t)idx].end;
+    c.start.assign(pool[(size_t)idx].start, pool[(size_t)idx].start + n);
+    c.end.assign(pool[(size_t)idx].end, pool[(size_t)idx].end + n);
     c.length = pool[(size_t)idx].length;
     return c;
 }
@@ -518,14 +586,14 @@ void Aligner::chain() {
         for (size_t i = 0; i < mums.size(); i++) mums[i] = h[i].idx;
     }
     if (mums.empty()) return;
-    Lcb cluster = lcb_of(pool, mums[0]);
+    Lcb cluster = lcb_of(pool, n, mums[0]);
     bool addmum = true;
     const int d = prm.d;
     const float diag_diff = prm.diag_diff;
     for (size_t x = 1; x < mums.size(); x++) {
         const Mum& nt = pool[(size_t)mums[x]];
         if (nt.length < random) { addmum = true; continue; }
-        if (!addmum) cluster = lcb_of(pool, mums[x - 1]);
+        if (!addmum) cluster = lcb_of(pool, n, mums[x - 1]);
         addmum = true;
         float max_gap = 0;
         float min_gap = d + 10;
@@ -557,7 +625,7 @@ void Aligner::chain() {
                 join = min_gap / max_gap >= 1.0 - diag_diff;
             }
             if (join) {
-                cluster.end = nt.end;
+                cluster.end.assign(nt.end, nt.end + n);
                 cluster.length += nt.length;
                 cluster.mums.push_back(mums[x]);
             } else {
@@ -568,7 +636,7 @@ void Aligner::chain() {
             lcbs.push_back(cluster);
         }
     }
-    if (!addmum) cluster = lcb_of(pool, mums.back());
+    if (!addmum) cluster = lcb_of(pool, n, mums.back());
     lcbs.push_back(cluster);
     stats.lcb_s += now_s() - t0;
 }

@@ -19,7 +19,9 @@
 //   write_output               writeOutput                            :505-1191
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -67,18 +69,52 @@ private:
     inline void store(size_t wi, uint64_t v) { if (logging_ && w_[wi] != v) log_.emplace_back(wi, w_[wi]); w_[wi] = v; }
 };
 
-struct Mum {
+// bump allocator with stable addresses and rewind (per-genome coordinate rows of MUMs and regions live here: at 200
+// genomes the reference's three std::vector per object dominate its run time)
+template <class T>
+class Arena {
+public:
+    T* alloc(size_t n) {
+        if (blocks_.empty() || off_ + n > cap_[cur_]) {
+            size_t next = blocks_.empty() ? 0 : cur_ + 1;
+            if (next == blocks_.size()) {
+                size_t c = std::max(n, kBlock);
+                blocks_.emplace_back(new T[c]);
+                cap_.push_back(c);
+            } else if (cap_[next] < n) {
+                blocks_[next].reset(new T[n]); cap_[next] = n;
+            }
+            cur_ = next; off_ = 0;
+        }
+        T* p = blocks_[cur_].get() + off_;
+        off_ += n;
+        return p;
+    }
+    struct Mark { size_t cur, off; bool empty; };
+    Mark mark() const { return Mark{cur_, off_, blocks_.empty()}; }
+    void rewind(const Mark& m) { if (m.empty) { cur_ = 0; off_ = 0; } else { cur_ = m.cur; off_ = m.off; } }
+private:
+    static constexpr size_t kBlock = 1 << 20;
+    std::vector<std::unique_ptr<T[]>> blocks_;
+    std::vector<size_t> cap_;
+    size_t cur_ = 0, off_ = 0;
+};
+
+struct Mum {             // rows of n entries in Aligner's arenas
     long id = 0;
     long length = 0;
     long slength = 0;
-    std::vector<long> start, end;
-    std::vector<int> fwd;
+    long* start = nullptr;
+    long* end = nullptr;
+    int* fwd = nullptr;
 };
 
-struct Region {
-    std::vector<long> start, end, length;
+struct Region {          // rows of n entries in Aligner's arenas; immutable once built
+    long* start = nullptr;
+    long* end = nullptr;
+    long* length = nullptr;
     long slength = 0, llength = 0;
-    bool same_as(const Region& o) const;   // TRegion operator== (LCR.cpp:48-58)
+    bool same_as(const Region& o, size_t n) const;   // TRegion operator== (LCR.cpp:48-58)
 };
 
 struct Lcb {
@@ -101,6 +137,7 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     // device-side phase times (HIP events, pm_last_timing): summed over every engine call of the step, and of the
     // anchor call alone (the one launch that sees whole genomes)
     std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
+    long tie_fallbacks = 0, literal_iterations = 0;   // work-list ties between different regions (extend_pass)
     double t_validate = 0, t_neighbour = 0, t_key = 0, t_sweep = 0, t_replay = 0, t_sort = 0, t_unpack = 0;   // host split
 };
 
@@ -128,11 +165,15 @@ public:
     void filter_lcbs();
     void fill_between();
 
-    Region neighbour_region(const Mum& m, bool left) const;
+    Region neighbour_region(const Mum& m, bool left);
+    void neighbour_into(const Mum& m, bool left, Region* out) const;   // rows of *out already allocated
+    Region new_region();
 
 private:
     pm_session* session_;
     long next_id_ = 1;
+    Arena<long> rows_;      // MUM and region coordinate rows
+    Arena<int> irows_;      // MUM strand rows
     // --- finder plumbing -------------------------------------------------------------------------------------
     struct Request { std::vector<int64_t> start, len; int32_t minsize; int64_t ref_ini; };
     std::vector<Request> chunk_requests(const Region& r, int minsize) const;   // the p-chunk loop, :1519-1547

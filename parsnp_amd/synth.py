@@ -84,6 +84,40 @@ def rearranged(seed, n, n_genomes, div, frac=0.15, block=20000):
     return ref.tobytes(), out
 
 
+def pop_rearranged(seed, n, n_genomes, div, indel_frac=0.05, frac=0.10, block=20000, carry_seed=None):
+    """population model + per-genome inversions / translocations of `block`-sized segments covering `frac` of the genome
+    (BASELINE config 5: stresses the recursive extension with asymmetric inter-MUM regions)."""
+    ref, gs = population(seed, n, n_genomes, div, indel_frac, carry_seed=carry_seed)
+    rng = np.random.default_rng(seed + 7919 if carry_seed is None else carry_seed + 7919)
+    out = []
+    for s in gs:
+        for _b in range(max(1, int(frac * n / block))):
+            a = int(rng.integers(0, max(1, len(s) - block)))
+            seg = s[a:a + block]
+            if rng.random() < 0.5:
+                s = s[:a] + seg.translate(_COMP)[::-1] + s[a + block:]
+            else:
+                rest = s[:a] + s[a + block:]
+                b = int(rng.integers(0, len(rest)))
+                s = rest[:b] + seg + rest[b:]
+        out.append(s)
+    return ref, out
+
+
+def write_multicontig(path, name, seq: bytes, cuts, width=80, crlf=False, lower=False):
+    """FASTA with one record per contig (cuts = interior cut positions)"""
+    nl = b"\r\n" if crlf else b"\n"
+    with open(path, "wb") as f:
+        edges = [0] + sorted(cuts) + [len(seq)]
+        for c in range(len(edges) - 1):
+            f.write(b">" + ("%s_contig%d some description" % (name, c + 1)).encode() + nl)
+            part = seq[edges[c]:edges[c + 1]]
+            if lower:
+                part = part.lower()
+            for i in range(0, len(part), width):
+                f.write(part[i:i + width] + nl)
+
+
 def write_fasta(path, name, seq: bytes, width=80):
     with open(path, "wb") as f:
         f.write(b">" + name.encode() + b"\n")
@@ -118,11 +152,38 @@ CONFIGS = {
     "pop20x1m": ("population", dict(seed=7, n=1_000_000, n_genomes=20, div=0.02, indel_frac=0.05)),
     "pop6x200k": ("population", dict(seed=9, n=200_000, n_genomes=6, div=0.02, indel_frac=0.05)),
     "rearr6x300k": ("rearranged", dict(seed=11, n=300_000, n_genomes=6, div=0.004, frac=0.15)),
-    "rearr500": ("rearranged", dict(seed=13, n=5_000_000, n_genomes=500, div=0.05, frac=0.10)),
+    "rearr500": ("pop_rearranged", dict(seed=13, n=5_000_000, n_genomes=500, div=0.05, frac=0.10)),
+    "poprearr10x400k": ("pop_rearranged", dict(seed=13, n=400_000, n_genomes=10, div=0.05, frac=0.10)),
 }
 
 
 def make(name, **override):
     model, kw = CONFIGS[name]
     kw = dict(kw, **override)
-    return {"population": population, "musclefree": musclefree, "rearranged": rearranged}[model](**kw)
+    return {"population": population, "musclefree": musclefree, "rearranged": rearranged, "pop_rearranged": pop_rearranged}[model](**kw)
+
+
+def messy_set(outdir, seed=23, n=150_000, n_genomes=6):
+    """multi-contig reference and queries, IUPAC codes, N runs, lower case, CRLF: exercises ingest (src/parsnp.cpp:2999-3160),
+    the d+10 N padding between query contigs and the contig labels of the XMFA headers.  -> (ref path, [query paths])"""
+    rng = np.random.default_rng(seed)
+    ref, gs = population(seed, n, n_genomes, 0.02, 0.05)
+
+    def dirty(s):
+        a = np.frombuffer(s, dtype=np.uint8).copy()
+        idx = rng.integers(0, len(a), 40)
+        a[idx] = np.frombuffer(b"RYKMSWBDHVN-", dtype=np.uint8)[rng.integers(0, 12, 40)]
+        st = int(rng.integers(1000, len(a) - 1000))
+        a[st:st + int(rng.integers(5, 120))] = ord("N")
+        return a.tobytes()
+
+    os.makedirs(outdir, exist_ok=True)
+    rp = os.path.join(outdir, "ref.fna")
+    write_multicontig(rp, "ref", dirty(ref), sorted(int(x) for x in rng.integers(5000, n - 5000, 2)))
+    qs = []
+    for i, g in enumerate(gs):
+        p = os.path.join(outdir, "g%04d.fna" % i)
+        cuts = sorted(int(x) for x in rng.integers(5000, len(g) - 5000, int(rng.integers(1, 4))))
+        write_multicontig(p, "g%04d" % i, dirty(g), cuts, crlf=(i == 1), lower=(i == 2))
+        qs.append(p)
+    return rp, qs

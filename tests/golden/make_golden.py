@@ -88,9 +88,9 @@ def main():
     # ---- G3
     e2e = {}
 
-    def run(name, rp, qs):
+    def run(name, rp, qs, **kw):
         out = os.path.join(tmp, "out_" + name)
-        rc, _ = driver.run_core(REFBIN, rp, qs, out)
+        rc, _ = driver.run_core(REFBIN, rp, qs, out, **kw)
         assert rc == 0, name
         x = os.path.join(out, "parsnpAligner.xmfa")
         e2e[name] = dict(xmfa_md5=xmfa_util.md5(x), signature=xmfa_util.mum_lcb_signature(x),
@@ -102,6 +102,14 @@ def main():
         r, gs = synth.make(name)
         rp, qs = synth.write_set(os.path.join(tmp, name), r, gs)
         run(name, rp, qs)
+    r, gs = synth.make("poprearr10x400k")
+    rp, qs = synth.write_set(os.path.join(tmp, "poprearr10x400k"), r, gs)
+    run("poprearr10x400k", rp, qs)
+    rp, qs = synth.messy_set(os.path.join(tmp, "messy"))
+    run("messy", rp, qs)
+    r, gs = synth.make("pop6x200k")
+    rp, qs = synth.write_set(os.path.join(tmp, "pchunk"), r, gs)
+    run("pchunk", rp, qs, partpos=66660)      # 3 reference chunks + the <50 bp tail rule (src/parsnp.cpp:1527-1538)
     json.dump(e2e, open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
     shutil.rmtree(tmp)
     print("goldens written:", sorted(os.listdir(HERE)))

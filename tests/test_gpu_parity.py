@@ -171,6 +171,17 @@ def test_parsnp_core_synthetic(libs, tmp_path, name, exact):
     test_host_logic.check(CORE_BIN, name, rp, qs, str(tmp_path / "out"), exact)
 
 
+@pytest.mark.parametrize("name", ["poprearr10x400k", "messy", "pchunk"])
+def test_parsnp_core_harsh_inputs(libs, tmp_path, name):
+    rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(CORE_BIN, rp, qs, out, **kw)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    want = E2E[name]
+    assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == want["signature"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(oracles.REFDIR, "parsnp_core_ref")), reason="reference binary not shipped")
 def test_parsnp_core_vs_reference_binary_fresh_input(libs, tmp_path):
     """an input that has no committed golden: run the shipped reference binary and the product side by side"""

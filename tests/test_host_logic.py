@@ -38,12 +38,47 @@ def test_synthetic(cpu_checkers, tmp_path, name, exact):
     check(cpu_checkers, name, rp, qs, str(tmp_path / "out"), exact)
 
 
+def harsh_inputs(name, base):
+    if name == "messy":
+        return synth.messy_set(os.path.join(base, "in")) + ({},)
+    if name == "pchunk":
+        r, gs = synth.make("pop6x200k")
+        return synth.write_set(os.path.join(base, "in"), r, gs) + (dict(partpos=66660),)
+    r, gs = synth.make(name)
+    return synth.write_set(os.path.join(base, "in"), r, gs) + ({},)
+
+
+@pytest.mark.parametrize("name", ["poprearr10x400k", "messy", "pchunk"])
+def test_harsh_inputs(cpu_checkers, tmp_path, name):
+    """rearranged 5 %-divergent population (asymmetric regions, reverse LCBs); multi-contig / IUPAC / CRLF / lower-case
+    FASTA; reference longer than the chunk size p (3 chunks + the <50 bp tail rule)"""
+    rp, qs, kw = harsh_inputs(name, str(tmp_path))
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(cpu_checkers, rp, qs, out, **kw)
+    assert rc == 0
+    want = E2E[name]
+    assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == want["signature"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
+
+
 def test_no_speculation_same_result(cpu_checkers, tmp_path):
     """the batched speculative sweep must not change the result of the in-order replay"""
     r, gs = synth.make("pop6x200k")
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
     env = dict(os.environ, PARSNP_NO_SPECULATION="1")
     check(cpu_checkers, "pop6x200k", rp, qs, str(tmp_path / "out"), False, env=env)
+
+
+@pytest.mark.parametrize("name", ["pop6x200k", "poprearr10x400k"])
+def test_literal_worklist_same_result(cpu_checkers, tmp_path, name):
+    """the map-based work list (unique keys) and the reference's literal vector + std::sort + adjacent-dedup agree"""
+    rp, qs, kw = harsh_inputs(name, str(tmp_path))
+    out = str(tmp_path / "out")
+    env = dict(os.environ, PARSNP_FORCE_LITERAL_WORKLIST="1")
+    rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, **kw)
+    assert rc == 0
+    assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["signature"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 
 
 def test_cli_surface(cpu_checkers, tmp_path):
