@@ -67,6 +67,13 @@ const int64_t* pm_result_sp(const pm_result* r);
 const uint8_t* pm_result_fwd(const pm_result* r);
 void pm_result_free(pm_result* r);
 
+/* calcmumi mode (Aligner::setMumi, src/parsnp.cpp:1869-2115): every query genome ALONE against the reference chunk
+ * starts[0],lens[0] (query g: starts[g],lens[g]).  covered[g-1] = number of reference positions covered by the
+ * pairwise MUMs of length >= 15 of query g, i.e. total_M_LON of :2064-2069 before the length-ratio and clamp rules
+ * (:2074-2077), which stay with the caller together with the "%d:%f" distance (:2080).
+ * Replaces, per query: Find_UM x2, Intersect_UM x2, Merge_Master and the coverage loop (:2015-2063). */
+int pm_mumi_coverage(pm_session* s, const int64_t* starts, const int64_t* lens, int64_t* covered);
+
 /* Single-strand entry point mirroring Find_UM (src/csgmum/mum.c:177-250) for parity tests: the event stream of one
  * query strand against ref -- every maximal exact match (j, l, len) of length >= min_len whose reference side is unique
  * in ref -- in increasing l.  strand 0: the query as given, 1: its reverse complement (Aligner::reversec).

@@ -247,6 +247,37 @@ int oracle_multi_mum(int cnt, const uint8_t* const* seqs, const int64_t* lens, i
 }
 void oracle_free(void* p) { free(p); }
 
+/* ------------------------------------------------------------------ calcmumi, one query genome (src/parsnp.cpp:1991-2069) */
+int64_t oracle_mumi_coverage(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int min_event_len) {
+    Index ix;
+    if (index_build(&ix, ref, n)) return -1;
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    int32_t *fUP = malloc(nn * 4), *fEP = malloc(nn * 4), *rUP = malloc(nn * 4), *rEP = malloc(nn * 4);
+    int64_t *fSP = malloc(nn * 8), *rSP = malloc(nn * 8);
+    uint8_t* mark = calloc(nn, 1);
+    uint8_t* rc = malloc((size_t)(m > 0 ? m : 1));
+    for (int64_t i = 0; i < m; i++) rc[i] = comp(query[m - 1 - i]);
+    find_um_ix(&ix, query, m, min_event_len, fUP, fEP, fSP);
+    find_um_ix(&ix, rc, m, min_event_len, rUP, rEP, rSP);
+    oracle_propagate(n, fUP, fEP, fSP);
+    oracle_propagate(n, rUP, rEP, rSP);
+    int32_t last = 0;                                   /* M_EP1: EP of the last ACCEPTED position (:2044-2047) */
+    for (int64_t k = 0; k < n; k++) {
+        /* Master starts at (UP 0, EP n): the fold of :2017-2019 leaves the strand with the larger EP, ties to reverse */
+        int32_t fE = fEP[k] < n ? fEP[k] : (int32_t)n, rE = rEP[k] < n ? rEP[k] : (int32_t)n;
+        int32_t EP = fE > rE ? fE : rE, UP = fE > rE ? fUP[k] : rUP[k];
+        if (EP > last && UP < EP && EP - k < n) {
+            last = EP;
+            if (EP - k >= 15) for (int64_t x = k; x < EP; x++) mark[x] = 1;
+        }
+    }
+    int64_t cov = 0;
+    for (int64_t k = 0; k < n; k++) cov += mark[k];
+    free(fUP); free(fEP); free(rUP); free(rEP); free(fSP); free(rSP); free(mark); free(rc);
+    index_free(&ix);
+    return cov;
+}
+
 /* ------------------------------------------------------------------ minimum MUM length (Converter/Calculator restated)
  * float32 arithmetic throughout, Log(x) = float( double(logf(x)) / log(2.0) ) (src/Converter.cpp:268-270),
  * result ceil()ed in float (Converter.cpp:283-284) and again by the caller (src/parsnp.cpp:1506,1513). */

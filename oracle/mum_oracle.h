@@ -32,6 +32,10 @@ int oracle_multi_mum(int cnt, const uint8_t* const* seqs, const int64_t* lens, i
                      int32_t* masterUP, int32_t* masterEP);
 void oracle_free(void* p);
 
+/* calcmumi (Aligner::setMumi, src/parsnp.cpp:1977-2069): number of reference positions covered by the pairwise MUMs
+ * (length >= 15) of one query genome against ref, both strands merged as Merge_Master does. */
+int64_t oracle_mumi_coverage(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int min_event_len);
+
 /* minsize = int(ceil(Calculator(Converter(expr), S))) for the expression forms the driver emits
  * (src/Converter.cpp:11-286, src/parsnp.cpp:1502-1514). Returns INT32_MIN on a parse error. */
 int32_t oracle_min_length(const char* expr, int64_t S);

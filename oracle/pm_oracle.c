@@ -80,4 +80,12 @@ int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t 
     *count = c;
     return PM_OK;
 }
+int pm_mumi_coverage(pm_session* s, const int64_t* starts, const int64_t* lens, int64_t* covered) {
+    for (int g = 1; g < s->n; g++) {
+        int64_t c = oracle_mumi_coverage(s->seq[0] + starts[0], lens[0], s->seq[g] + starts[g], lens[g], 15);
+        if (c < 0) return PM_ENOMEM;
+        covered[g - 1] = c;
+    }
+    return PM_OK;
+}
 int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) { (void)s; (void)names; (void)ms; if (count) *count = 0; return PM_OK; }

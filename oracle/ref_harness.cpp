@@ -119,6 +119,39 @@ int ref_multi_mum(int cnt, const char** seqs, const long* lens, const char** rcs
     return 0;
 }
 
+// calcmumi for one query genome: the body of the OpenMP loop of Aligner::setMumi (src/parsnp.cpp:1991-2069).
+long ref_mumi_coverage(const char* ref, long n, const char* query, const char* query_rc, long m, int factor) {
+    Graph g(ref, n, factor);
+    std::vector<UM> Master(n), MasterRC(n), Pair(n), PairRC(n);
+    std::vector<ulong> msp(n, 0), tempMSP(n, 0);
+    std::vector<char> ff(n, 1), fr(n, 0);
+    SP SPF[1], SPR[1];
+    ulong two[2] = {0, 0};
+    SPF[0].MSP = msp.data(); SPF[0].forward = ff.data(); SPR[0].MSP = two; SPR[0].forward = fr.data();
+    for (long i = 0; i < n; i++) {
+        Pair[i].UP = Pair[i].EP = Master[i].UP = 0; PairRC[i].UP = PairRC[i].EP = 0;
+        Master[i].EP = (int)n; MasterRC[i].EP = (int)n; MasterRC[i].UP = 0;
+    }
+    std::string q = term(query, m), qr = term(query_rc, m);
+    Find_UM(g.csg, q.c_str(), SPF[0].MSP, Pair.data());
+    Find_UM(g.csg, qr.c_str(), tempMSP.data(), PairRC.data());
+    Intersect_UM(g.csg, Master.data(), Pair.data(), (int)n, SPF[0].MSP);
+    Intersect_UM(g.csg, MasterRC.data(), PairRC.data(), (int)n, tempMSP.data());
+    Merge_Master(Master.data(), MasterRC.data(), (int)n, (int)m, SPF, SPR, tempMSP.data(), 0);
+    std::vector<char> amums(n, 0);
+    int M_EP1 = 0;
+    for (long k = 0; k < n; k++) {
+        if (Master[k].EP > M_EP1 && Master[k].UP < Master[k].EP && Master[k].EP - k < n) {
+            M_EP1 = Master[k].EP;
+            int lon = M_EP1 - (int)k;
+            if (lon >= 15) for (int ii = 0; ii < lon; ii++) amums[k + ii] = 1;
+        }
+    }
+    long total = 0;
+    for (long k = 0; k < n; k++) total += amums[k];
+    return total;
+}
+
 void ref_free(void* p) { free(p); }
 
 }  // extern "C"

@@ -108,6 +108,15 @@ class Session:
         lens = np.array([[len(s) for s in self._seqs]], np.int64)
         return self.multi_mum_batch(np.zeros_like(lens), lens, [minsize])[0]
 
+    def mumi_coverage(self):
+        """calcmumi: reference positions covered by pairwise MUMs >= 15, per query genome (whole genomes)"""
+        lens = (C.c_int64 * self.n)(*[len(s) for s in self._seqs])
+        starts = (C.c_int64 * self.n)(*([0] * self.n))
+        cov = (C.c_int64 * max(1, self.n - 1))()
+        self.lib.L.pm_mumi_coverage.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        self.lib._check(self.lib.L.pm_mumi_coverage(self.h, starts, lens, cov))
+        return [int(cov[i]) for i in range(self.n - 1)]
+
     def last_timing(self):
         cnt = C.c_int(64); names = (C.c_char_p * 64)(); ms = (C.c_float * 64)()
         self.lib.L.pm_last_timing(self.h, C.byref(cnt), names, ms)

@@ -90,6 +90,20 @@ int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t 
     return PM_OK;
 }
 
+int pm_mumi_coverage(pm_session* s, const int64_t* starts, const int64_t* lens, int64_t* covered) {
+    if (!s || !starts || !lens || !covered) return fail(PM_EINVAL, "bad argument");
+    try {
+        pm::BatchResult br;
+        int32_t fifteen = 15;
+        int rc = s->engine->run(1, starts, lens, &fifteen, &br, false, true);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        s->timing = s->engine->timing;
+        for (size_t g = 0; g < s->engine->mumi_covered.size(); g++) covered[g] = s->engine->mumi_covered[g];
+        return PM_OK;
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed"); }
+}
+
 int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) {
     if (!s || !count) return PM_EINVAL;
     int capn = *count, n = 0;

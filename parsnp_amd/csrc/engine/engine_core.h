@@ -78,7 +78,9 @@ public:
     }
 
     // ---- one batch of regions (include/parsnp_mum.h: pm_multi_mum_batch)
-    int run(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events = false) {
+    std::vector<int64_t> mumi_covered;   // result of run(..., mumi = true): per query genome
+    int run(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events = false,
+            bool mumi = false) {
         timing.clear();
         const int nq = ngen - 1;
         out->nregions = nreg; out->nq = nq; out->total = 0;
@@ -92,6 +94,7 @@ public:
         std::vector<int64_t> posbase((size_t)nreg + 1), tilebase((size_t)nreg + 1);
         int64_t npos = 0, ntiles = 0, tsize = 0;
         int32_t max_nr = 1;
+        size_t ev_guess = 1 << 16;     // first-call event buffer: a match of length >= minsize every max(8,minsize) bases is generous
         for (int64_t r = 0; r < nreg; r++) {
             RegionInfo& ri = R[(size_t)r];
             for (int g = 0; g < ngen; g++) {
@@ -112,6 +115,7 @@ public:
             ri.posbase = npos; posbase[(size_t)r] = npos; npos += ri.nR;
             ri.tile_base = ntiles; tilebase[(size_t)r] = ntiles; ntiles += (ri.nR + kTile - 1) / kTile;
             max_nr = std::max(max_nr, ri.nR);
+            for (int g = 1; g < ngen; g++) ev_guess += (size_t)(2 * lens[r * ngen + g] / std::max(8, ri.minlen));
         }
         posbase[(size_t)nreg] = npos; tilebase[(size_t)nreg] = ntiles;
         const int64_t npairs = nreg * nq;
@@ -156,7 +160,7 @@ public:
         // -- events (retry with a larger buffer on overflow)
         ensure(d_counter, 2);
         uint64_t nev = 0;
-        size_t cap = std::max<size_t>(ev_cap_hint, 1 << 16);
+        size_t cap = std::min<size_t>(std::max<size_t>(ev_cap_hint, ev_guess), (size_t)1 << 31);
         for (;;) {
             ensure(d_evkey, cap); ensure(d_evval, cap);
             be.memset(d_counter.p, 0, 16);
@@ -168,7 +172,7 @@ public:
             if (nev <= cap) break;
             cap = (size_t)(nev + nev / 8 + 1024);
         }
-        ev_cap_hint = std::max(ev_cap_hint, (size_t)(nev + nev / 4));
+        ev_cap_hint = (size_t)(nev + nev / 4);
         last_events = (int64_t)nev;
         uint32_t errbits = 0;
         be.d2h(&errbits, d_err.p, 4);
@@ -194,6 +198,17 @@ public:
             if (nev) { be.d2h(ev_key_h.data(), skey, 8 * (size_t)nev); be.d2h(ev_val_h.data(), sval, 8 * (size_t)nev); }
             if (npos) be.d2h(rep_h.data(), d_rep.p, 4 * (size_t)npos);
             ev_lbits = lbits;
+        }
+
+        if (mumi) {
+            be.mark("mumi_coverage");
+            ensure(d_cov, (size_t)npairs);
+            be.launch("mumi_coverage", npairs, MumiCoverage{d_R.p, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, ngen, d_cov.p});
+            mumi_covered.resize((size_t)npairs);
+            be.d2h(mumi_covered.data(), d_cov.p, 8 * (size_t)npairs);
+            be.mark(nullptr);
+            collect_timing();
+            return 0;
         }
 
         // -- Master.EP, candidates
@@ -236,12 +251,19 @@ public:
         be.d2h(sp_h.data(), d_osp.p, 4 * (size_t)ncand * (size_t)nq);
         be.d2h(fwd_h.data(), d_ofwd.p, (size_t)ncand * (size_t)nq);
         be.mark(nullptr);
+        size_t nok = 0;
+        for (size_t c = 0; c < (size_t)ncand; c++) nok += ok_h[c] ? 1 : 0;
+        out->k.resize(nok); out->lon.resize(nok); out->sp.resize(nok * (size_t)nq); out->fwd.resize(nok * (size_t)nq);
+        size_t w = 0;
         for (size_t c = 0; c < (size_t)ncand; c++) {
             if (!ok_h[c]) continue;
-            int64_t r = (int64_t)(cand_h[c] >> 32);
-            out->off[(size_t)r + 1]++;
-            out->k.push_back(k_h[c]); out->lon.push_back(lon_h[c]);
-            for (int g = 0; g < nq; g++) { out->sp.push_back(sp_h[c * (size_t)nq + (size_t)g]); out->fwd.push_back(fwd_h[c * (size_t)nq + (size_t)g]); }
+            out->off[(size_t)(cand_h[c] >> 32) + 1]++;
+            out->k[w] = k_h[c]; out->lon[w] = lon_h[c];
+            const int32_t* sps = &sp_h[c * (size_t)nq];
+            int64_t* spd = &out->sp[w * (size_t)nq];
+            for (int g = 0; g < nq; g++) spd[g] = sps[g];
+            memcpy(&out->fwd[w * (size_t)nq], &fwd_h[c * (size_t)nq], (size_t)nq);
+            w++;
         }
         for (int64_t r = 0; r < nreg; r++) out->off[(size_t)r + 1] += out->off[(size_t)r];
         out->total = out->off[(size_t)nreg];
@@ -259,7 +281,7 @@ public:
         auto drop = [&](auto& b) { if (b.p) be.free(b.p); b.p = nullptr; b.cap = 0; };
         drop(d_R); drop(d_starts); drop(d_lens); drop(d_posbase); drop(d_tilebase); drop(d_err); drop(d_tags); drop(d_heads); drop(d_next);
         drop(d_rep); drop(d_epm); drop(d_ucount); drop(d_uoff); drop(d_upair); drop(d_uinfo); drop(d_counter); drop(d_evkey); drop(d_evval);
-        drop(d_evkey2); drop(d_evval2); drop(d_lo); drop(d_state); drop(d_summary); drop(d_startshere); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
+        drop(d_evkey2); drop(d_evval2); drop(d_lo); drop(d_cov); drop(d_state); drop(d_summary); drop(d_startshere); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
         drop(d_ok_k); drop(d_ok_lon); drop(d_osp); drop(d_ofwd);
         if (b2) be.free(b2); if (nm) be.free(nm); if (d_goff) be.free(d_goff); if (d_glen) be.free(d_glen);
         b2 = nullptr; nm = nullptr; d_goff = nullptr; d_glen = nullptr;
@@ -286,7 +308,7 @@ private:
     Buf<uint64_t> d_tags; Buf<int32_t> d_heads, d_next, d_rep, d_epm;
     Buf<int64_t> d_ucount, d_uoff; Buf<int32_t> d_upair, d_uinfo;
     Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2;
-    Buf<int64_t> d_lo; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
+    Buf<int64_t> d_lo, d_cov; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
     Buf<uint64_t> d_cand, d_cand2; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
 };
 

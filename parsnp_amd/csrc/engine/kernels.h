@@ -113,7 +113,10 @@ struct RegionInfo {        // one per region of a batch
 
 constexpr uint64_t kEmpty = ~0ull;
 constexpr int kTile = 16;          // reference positions per master-fold thread
-constexpr int kUnitSamples = 256;  // query samples per work unit (64 threads x 4)
+#ifndef PM_UNIT
+#define PM_UNIT 256
+#endif
+constexpr int kUnitSamples = PM_UNIT;  // query samples per work unit (64 threads x PM_UNIT/64)
 
 // error bits raised by kernels
 constexpr uint32_t kErrWork = 1u;  // per-thread work budget exceeded (degenerate repeat structure)
@@ -425,6 +428,49 @@ struct ChunkScan {
             st[i] = cur;
             emax[i] = cur.s[0].e1 > cur.s[1].e1 ? cur.s[0].e1 : cur.s[1].e1;
         }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ MUMi coverage
+// calcmumi mode (Aligner::setMumi, src/parsnp.cpp:1977-2063): each query genome ALONE against the reference chunk.
+// Master = that genome's strand-merged (UP,EP); a position is accepted when EP exceeds the EP of the last accepted
+// position, UP < EP and EP-k < len (:2044); accepted matches of length >= 15 mark [k, EP) (:2050-2056); the result is
+// the number of marked positions.  (UP,EP) only change where an event starts, so the scan runs over events.
+// tid = pair (region 0, query genome).
+struct MumiCoverage {
+    const RegionInfo* R; const uint64_t* key; const uint64_t* val; const int64_t* lo; const EventState* st; const int32_t* rep;
+    int lbits; int32_t ngen; int64_t* covered;
+    PM_HD void operator()(int64_t pair) const {
+        const RegionInfo& ri = R[pair / (ngen - 1)];
+        const uint64_t lmask = (1ull << lbits) - 1;
+        int32_t last_ep = 0, cov_end = 0; int64_t cov = 0;
+        const int64_t a = lo[pair], b = lo[pair + 1];
+        for (int64_t i = a; i < b; i++) {
+            int32_t l = (int32_t)((key[i] >> 1) & lmask);
+            int32_t lnext = i + 1 < b ? (int32_t)((key[i + 1] >> 1) & lmask) : ri.nR;
+            if (lnext == l) continue;                    // the state after the last event starting at l is the one at k = l
+            const EventState& s = st[i];
+            int32_t ep[2] = {0, 0}, up[2] = {0, 0};
+            for (int sd = 0; sd < 2; sd++) {
+                if (s.s[sd].w < 0) continue;
+                int32_t wl = (int32_t)((key[s.s[sd].w] >> 1) & lmask);
+                ep[sd] = s.s[sd].e1;
+                up[sd] = wl + rep[ri.posbase + wl];
+                if (s.s[sd].e2 > up[sd]) up[sd] = s.s[sd].e2;
+            }
+            int c = ep[0] > ep[1] ? 0 : 1;               // Merge_Master: forward only if strictly better
+            int32_t EP = ep[c], UP = up[c];
+            if (!(EP > last_ep && UP < EP)) continue;
+            int32_t k = l;
+            if (!(EP - k < ri.nR)) { k = l + 1; if (k >= lnext || k >= ri.nR) continue; }   // EP-k < len fails only for a full-length match at k = 0
+            last_ep = EP;
+            if (EP - k >= 15) {
+                int32_t from = k > cov_end ? k : cov_end;
+                if (EP > from) cov += EP - from;
+                if (EP > cov_end) cov_end = EP;
+            }
+        }
+        covered[pair] = cov;
     }
 };
 

@@ -262,15 +262,28 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
 // sequence check, layout marking (parsnp.cpp:1717-1841, TMum ctor TMum.cpp:13-72).
 void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted) {
     const size_t nq = n - 1;
-    std::vector<long> startpos(n);
-    for (size_t c = 0; c < raw.k.size(); c++) {
+    const size_t ncand = raw.k.size();
+    std::vector<long> gsize(n);
+    for (size_t j = 0; j < n; j++) gsize[j] = (long)genomes[j].seq.size();
+    // genome-j start of candidate c exactly as the TMum constructor derives it (TMum.cpp:25-40): forward = DSP-1,
+    // reverse = flipped against the WHOLE genome length even inside a sub-region
+    auto start_of = [&](size_t c, size_t j) -> long {
+        unsigned long dsp = j == 0 ? (unsigned long)raw.k[c] + 1 + (unsigned long)q.ref_ini
+                                   : (unsigned long)raw.sp[c * nq + j - 1] + 1 + (unsigned long)r.start[j];
+        long sp = (long)(dsp - 1);
+        bool fw = j == 0 || raw.fwd[c * nq + j - 1];
+        return fw ? sp : gsize[j] - (sp + (long)raw.lon[c]);
+    };
+    const size_t kAhead = 6;
+    for (size_t c = 0; c < ncand; c++) {
+        if (c + kAhead < ncand)   // the layout rows of 200 genomes are 200 independent streams: fetch them ahead
+            for (size_t j = 0; j < n; j++) layout[j].prefetch(start_of(c + kAhead, j));
         const long lon = raw.lon[c];
         bool bad = false;
         for (size_t j = 0; j < n; j++) {
             unsigned long dsp = j == 0 ? (unsigned long)raw.k[c] + 1 + (unsigned long)q.ref_ini
                                        : (unsigned long)raw.sp[c * nq + j - 1] + 1 + (unsigned long)r.start[j];
             if (dsp - (unsigned long)r.start[j] > (unsigned long)(unsigned int)r.length[j]) bad = true;   // :1723
-            startpos[j] = (long)(dsp - 1);
         }
         if (bad) continue;
         Mum m;
@@ -280,34 +293,36 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
         const Arena<int>::Mark imark = irows_.mark();
         m.start = rows_.alloc(n); m.end = rows_.alloc(n); m.fwd = irows_.alloc(n);
         auto reject = [&]() { rows_.rewind(rmark); irows_.rewind(imark); };
-        bool ok = true;
+        bool ok = true, touches = false, any_reverse = false;
         for (size_t j = 0; j < n; j++) {
             m.fwd[j] = j == 0 ? 1 : raw.fwd[c * nq + j - 1];
-            const long size = (long)genomes[j].seq.size();
-            // reverse strand: flipped against the WHOLE genome length even inside a sub-region (TMum.cpp:33-35)
-            m.start[j] = m.fwd[j] ? startpos[j] : size - (startpos[j] + lon);
-            if (m.start[j] + lon > size || m.start[j] < 0) ok = false;   // never for in-range candidates; the reference would misbehave
+            m.start[j] = start_of(c, j);
+            if (m.start[j] + lon > gsize[j] || m.start[j] < 0) { ok = false; m.end[j] = m.start[j] + lon; continue; }   // never for in-range candidates
             m.end[j] = m.start[j] + lon;
+            any_reverse |= !m.fwd[j];
+            if (lon > 0) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end[j] - 1);
         }
         if (!ok || m.length < 5) { reject(); continue; }
-        trim(m);
+        if (touches) trim(m);   // trim() only acts when the first or last base of some genome is already marked
         if (m.length < 2 || n <= 1) { reject(); continue; }
         if (!m.fwd[0]) { reject(); continue; }
         // reverse-strand members must spell the reverse complement of the reference member (:1791-1825)
-        const std::string& g0 = genomes[0].seq;
         bool mismatch = false;
-        for (size_t j = 0; j < n && !mismatch; j++) {
-            if (m.fwd[j]) continue;
-            const std::string& gj = genomes[j].seq;
-            long l1 = m.start[j], l2 = m.length;
-            if (l1 > (long)gj.size() || m.start[0] > (long)g0.size()) fatal("MUM outside genome");
-            long have = std::min<long>(l2, (long)gj.size() - l1), have0 = std::min<long>(l2, (long)g0.size() - m.start[0]);
-            if (have != have0) { mismatch = true; break; }
-            for (long x = 0; x < have; x++) {
-                char cj = gj[(size_t)(l1 + have - 1 - x)], want;
-                switch (cj) { case 'A': want = 'T'; break; case 'C': want = 'G'; break; case 'G': want = 'C'; break;
-                              case 'T': want = 'A'; break; default: want = 'N'; }
-                if (g0[(size_t)(m.start[0] + x)] != want) { mismatch = true; break; }
+        if (any_reverse) {
+            const std::string& g0 = genomes[0].seq;
+            for (size_t j = 0; j < n && !mismatch; j++) {
+                if (m.fwd[j]) continue;
+                const std::string& gj = genomes[j].seq;
+                long l1 = m.start[j], l2 = m.length;
+                if (l1 > (long)gj.size() || m.start[0] > (long)g0.size()) fatal("MUM outside genome");
+                long have = std::min<long>(l2, (long)gj.size() - l1), have0 = std::min<long>(l2, (long)g0.size() - m.start[0]);
+                if (have != have0) { mismatch = true; break; }
+                for (long x = 0; x < have; x++) {
+                    char cj = gj[(size_t)(l1 + have - 1 - x)], want;
+                    switch (cj) { case 'A': want = 'T'; break; case 'C': want = 'G'; break; case 'G': want = 'C'; break;
+                                  case 'T': want = 'A'; break; default: want = 'N'; }
+                    if (g0[(size_t)(m.start[0] + x)] != want) { mismatch = true; break; }
+                }
             }
         }
         if (mismatch) { reject(); continue; }

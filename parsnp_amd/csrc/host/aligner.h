@@ -44,14 +44,15 @@ struct Genome {
     float gc = 0, at = 0;              // gcCount / atCount
     std::map<int, std::string> pos2hdr;
 };
-// returns false (after printing the reference's message) when the file cannot be opened
-bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* out);
+// returns false when the file cannot be opened; *console receives what the reference prints to stdout for this file
+bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* out, std::string* console);
 
 // n+1 bits per genome, bit [n] is the sentinel (parsnp.cpp:3184-3185)
 class Bitmap {
 public:
     void init(size_t nbits_with_sentinel);
     bool get(long i) const { return (w_[(size_t)i >> 6] >> (i & 63)) & 1; }
+    void prefetch(long i) const { if (i >= 0 && (size_t)i < nbits_) __builtin_prefetch(&w_[(size_t)i >> 6], 1, 1); }
     void set_range(long a, long b);     // [a,b) := 1
     void clear_range(long a, long b);   // [a,b) := 0
     long next_set(long from) const;     // smallest i >= from with bit set; the sentinel guarantees one for from <= n

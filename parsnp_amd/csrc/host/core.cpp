@@ -46,9 +46,9 @@ int CoreRun::open(const std::string& ini_path) {
     const bool reverse_ref = ini.get_bool("Reference", "reverse");
     qfiles = (int)ini.count("Query") / 2;
 
-    if (prm.calc_mumi || !prm.anchorfile.empty() || !prm.mumfile.empty() || prm.unaligned) {
-        // calcmumi (setMumi), anchorfile/mumfile replay and parsnp.unalign are outside the accelerated path
-        std::cerr << "parsnp_core (MI355X build): calcmumi / anchorfile / mumfile / unaligned are not supported by this build" << std::endl;
+    if (!prm.anchorfile.empty() || !prm.mumfile.empty() || prm.unaligned) {
+        // anchorfile/mumfile replay and parsnp.unalign are outside the accelerated path
+        std::cerr << "parsnp_core (MI355X build): anchorfile / mumfile / unaligned are not supported by this build" << std::endl;
         return 1;
     }
 
@@ -56,18 +56,27 @@ int CoreRun::open(const std::string& ini_path) {
     time(&start);
     const double t0 = now_s();
     genomes.assign((size_t)qfiles + 1, Genome());
-    for (int i = 0; i <= qfiles; i++) {
-        std::string path;
-        bool rev;
-        if (i == 0) { path = ini.get("Reference", "file"); rev = reverse_ref; }
-        else {
-            char buf[64];
-            snprintf(buf, sizeof buf, "file%d", i);
-            path = ini.get("Query", buf);
-            snprintf(buf, sizeof buf, "reverse%d", i);
-            rev = ini.get_bool("Query", buf);
+    {   // files are independent: parsed in parallel, reported in file order (the reference reads them one by one)
+        std::vector<std::string> paths((size_t)qfiles + 1), console((size_t)qfiles + 1);
+        std::vector<char> rev((size_t)qfiles + 1), good((size_t)qfiles + 1, 0);
+        for (int i = 0; i <= qfiles; i++) {
+            if (i == 0) { paths[0] = ini.get("Reference", "file"); rev[0] = reverse_ref; }
+            else {
+                char buf[64];
+                snprintf(buf, sizeof buf, "file%d", i);
+                paths[(size_t)i] = ini.get("Query", buf);
+                snprintf(buf, sizeof buf, "reverse%d", i);
+                rev[(size_t)i] = ini.get_bool("Query", buf);
+            }
         }
-        if (!ingest(path, i == 0, rev, prm.d, &genomes[(size_t)i])) return 1;
+#pragma omp parallel for schedule(dynamic) num_threads(prm.cores > 0 ? prm.cores : 1)
+        for (int i = 0; i <= qfiles; i++)
+            good[(size_t)i] = ingest(paths[(size_t)i], i == 0, rev[(size_t)i] != 0, prm.d, &genomes[(size_t)i], &console[(size_t)i]);
+        for (int i = 0; i <= qfiles; i++) {
+            std::cout << console[(size_t)i];
+            if (!good[(size_t)i]) return 1;
+        }
+        std::cout.flush();
     }
     ingest_s = now_s() - t0;
 
@@ -90,6 +99,37 @@ int CoreRun::open(const std::string& ini_path) {
         return 3;
     }
     upload_s = now_s() - t1;
+    return 0;
+}
+
+int CoreRun::mumi() {
+    const size_t n = genomes.size();
+    // setMumi only ever looks at the first p bases of the reference (its chunk loop stops after one pass, :1909)
+    long len0 = (long)genomes[0].seq.size();
+    long p = prm.p > len0 ? len0 : prm.p;
+    std::cerr << std::endl << "        Constructing device index of the reference...\n";
+    std::cerr << "        Calculating pairwise MUMi distances...\n";
+    std::cout << prm.outdir << std::endl;
+    std::string path = prm.outdir + "/all.mumi";
+    std::cout << path << std::endl;
+    FILE* f = fopen(path.c_str(), "w");
+    if (!f) { std::cerr << "parsnp_core: cannot write " << path << std::endl; return 1; }
+    std::vector<int64_t> starts(n, 0), lens(n), covered(n > 1 ? n - 1 : 1, 0);
+    lens[0] = p;
+    for (size_t g = 1; g < n; g++) lens[g] = (int64_t)genomes[g].seq.size();
+    if (n > 1 && p > 0) {
+        int rc = pm_mumi_coverage(session, starts.data(), lens.data(), covered.data());
+        if (rc != PM_OK) { std::cerr << "parsnp_core: MUMi engine failed: " << pm_last_error() << std::endl; fclose(f); return 1; }
+    }
+    for (size_t g = 1; g < n; g++) {
+        int total = (int)covered[g - 1];
+        int minlen = (int)p;
+        float ratio = float(len0) / float(lens[g]);             // r1.length.at(0) / rs[g].len_region (:2074)
+        if (ratio > 1.3 || ratio < 0.7) total = 0;
+        if (total > minlen) total = minlen;
+        fprintf(f, "%d:%f\n", (int)g, 1.0 - (float(total) / float(minlen)));   // (:2080)
+    }
+    fclose(f);
     return 0;
 }
 

@@ -25,6 +25,9 @@ public:
     // reads the ini, ingests every genome (printing what the reference prints) and uploads them to the engine.
     // returns 0, or the exit code the reference would use (1) / 3 when the engine cannot start.
     int open(const std::string& ini_path);
+    // calcmumi=1: pairwise MUMi distance of every query to the reference -> <outdir>/all.mumi (Aligner::setMumi,
+    // src/parsnp.cpp:1869-2115); returns 0 on success
+    int mumi();
     // phases A-D on a fresh Aligner over the resident genomes
     StepReport step();
     // XMFA + log of the last step (phase E)

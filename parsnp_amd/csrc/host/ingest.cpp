@@ -35,14 +35,16 @@ struct Table {
 const Table kTable;
 }  // namespace
 
-bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* g) {
+bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* g, std::string* console) {
+    std::ostringstream con;
     g->path = path;
     size_t slash = path.rfind('/');
     g->fname = slash == std::string::npos ? path : path.substr(slash + 1);
     std::ifstream f(path.c_str(), std::ios::binary);
     if (!f) {
-        if (is_ref) std::cout << " Cannot open reference file ! " << std::endl;
-        else std::cout << " Cannot open query file: " << path << std::endl;
+        if (is_ref) con << " Cannot open reference file ! " << std::endl;
+        else con << " Cannot open query file: " << path << std::endl;
+        *console = con.str();
         return false;
     }
     std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -92,7 +94,8 @@ bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* g
     g->size_nopad = (int)s.size() - padding;
     g->gc = float(gg) + float(c);
     g->at = float(a) + float(t);
-    std::cout << g->fname << ",Len:" << s.size() << ",GC:" << ((float(gg) + float(c)) / float(s.size() - nn)) * 100 << std::endl;
+    con << g->fname << ",Len:" << s.size() << ",GC:" << ((float(gg) + float(c)) / float(s.size() - nn)) * 100 << std::endl;
+    *console = con.str();
     return true;
 }
 

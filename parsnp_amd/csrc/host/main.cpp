@@ -48,6 +48,11 @@ int main(int argc, char* argv[]) {
     CoreRun run;
     int rc = run.open(argv[1]);
     if (rc) exit(rc);
+    if (run.prm.calc_mumi) {          // main() :3188-3209: distances only, no alignment
+        std::ofstream touch((run.prm.outdir + "/parsnpAligner.log").c_str());
+        std::cerr << "Calculating mumi distances.." << std::endl;
+        exit(run.mumi());
+    }
     std::ofstream mfile((run.prm.outdir + "/parsnpAligner.log").c_str());
     StepReport rep = run.step();
     if (!rep.mums_found) {

@@ -8,7 +8,7 @@ import random
 import subprocess
 
 DEFAULTS = dict(anchors="1.1*(Log(S))", mums="1.1*(Log(S))", extend=0, recombfilt=0, threads=1, diagdiff=0.12, aligner=2,
-                mincluster=21, clusterd=300, partpos=15000000, unaligned=0)
+                mincluster=21, clusterd=300, partpos=15000000, unaligned=0, calcmumi=0)
 
 _TEMPLATE = """;Parsnp configuration File
 ;
@@ -20,7 +20,7 @@ reverse=0
 anchors={anchors}
 anchorfile=
 anchorsonly=0
-calcmumi=0
+calcmumi={calcmumi}
 mums={mums}
 mumfile=
 filter=1

@@ -4,6 +4,7 @@ oracle/Makefile).  Run in the build container only:  python tests/golden/make_go
   calc_table.json   G5  minimum-MUM-length table from the reference's Converter/Calculator
   find_um.npz       G1  raw + propagated (UP,EP,SP) of 50 random small (R,Q) pairs and 4 MERS genome/strand pairs
   mers_anchor.npz   G2  candidate list + Master arrays of the MERS anchor pass (47 genomes)
+  mumi.json         G4  all.mumi (calcmumi=1) of the reference binary on MERS, the messy multi-contig set and a p-limited set
   e2e.json          G3  XMFA md5, MUM/LCB signature md5 and log counters of the reference binary on
                         MERS, viral50, pop6x200k, rearr6x300k, pop20x1m (21 x 1 Mb), bact8 (9 x 5 Mb) (inputs: tests/golden/mers_virus.tar.xz / parsnp_amd.synth seeds)
 """
@@ -111,6 +112,21 @@ def main():
     rp, qs = synth.write_set(os.path.join(tmp, "pchunk"), r, gs)
     run("pchunk", rp, qs, partpos=66660)      # 3 reference chunks + the <50 bp tail rule (src/parsnp.cpp:1527-1538)
     json.dump(e2e, open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
+    # ---- G4: calcmumi=1 -> all.mumi
+    mumi = {}
+
+    def run_mumi(name, rp, qs, **kw):
+        out = os.path.join(tmp, "mumi_" + name)
+        rc, _ = driver.run_core(REFBIN, rp, qs, out, calcmumi=1, **kw)
+        assert rc == 0, name
+        mumi[name] = sorted(open(os.path.join(out, "all.mumi")).read().split(), key=lambda x: int(x.split(":")[0]))
+    run_mumi("mers", mref, mqs)
+    rp, qs = synth.messy_set(os.path.join(tmp, "messy2"))
+    run_mumi("messy", rp, qs)
+    r, gs = synth.make("pop6x200k")
+    rp, qs = synth.write_set(os.path.join(tmp, "pop_p"), r, gs)
+    run_mumi("pop6x200k_p", rp, qs, partpos=40000)
+    json.dump(mumi, open(os.path.join(HERE, "mumi.json"), "w"), indent=0)
     shutil.rmtree(tmp)
     print("goldens written:", sorted(os.listdir(HERE)))
 

@@ -95,3 +95,31 @@ def test_end_to_end_with_emulated_engine(emu, tmp_path):
     r, gs = synth.make("viral50")
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
     test_host_logic.check(emu[1], "viral50", rp, qs, str(tmp_path / "out"), True)
+
+
+def mumi_cases(rng, count):
+    for it in range(count):
+        ref, qs = adversarial_case(rng, 20, int(rng.choice([60, 250])), int(rng.integers(1, 4)))
+        if it % 3 == 0:
+            qs[0] = mutate(rng, ref, sub=0.03)
+        if it % 40 == 0:
+            qs[0] = ref
+        yield ref, qs
+
+
+def check_mumi(E, O, count, seed):
+    import ctypes as C
+    O.oracle_mumi_coverage.restype = C.c_int64
+    rng = np.random.default_rng(seed)
+    tot = 0
+    for ref, qs in mumi_cases(rng, count):
+        want = [O.oracle_mumi_coverage(ref, C.c_int64(len(ref)), q, C.c_int64(len(q)), 1) for q in qs]
+        with Session(E, [ref] + qs) as s:
+            got = s.mumi_coverage()
+        assert got == want, (ref, qs)
+        tot += sum(want)
+    assert tot > 1000
+
+
+def test_mumi_coverage(libs):
+    check_mumi(libs[0], libs[1], 300, 8)

@@ -156,6 +156,10 @@ def test_properties_at_scale(libs):
     print("timing", timing)
 
 
+def test_mumi_coverage(libs):
+    T.check_mumi(libs[0], libs[1], 200, 28)
+
+
 E2E = json.load(open(os.path.join(G, "e2e.json")))
 
 
@@ -169,6 +173,11 @@ def test_parsnp_core_synthetic(libs, tmp_path, name, exact):
     r, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
     test_host_logic.check(CORE_BIN, name, rp, qs, str(tmp_path / "out"), exact)
+
+
+@pytest.mark.parametrize("name", ["mers", "messy", "pop6x200k_p"])
+def test_parsnp_core_calcmumi(libs, tmp_path, name):
+    test_host_logic.check_mumi(CORE_BIN, name, str(tmp_path))
 
 
 @pytest.mark.parametrize("name", ["poprearr10x400k", "messy", "pchunk"])

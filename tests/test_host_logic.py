@@ -81,6 +81,34 @@ def test_literal_worklist_same_result(cpu_checkers, tmp_path, name):
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 
 
+MUMI = json.load(open(os.path.join(G, "mumi.json")))
+
+
+def mumi_inputs(name, base):
+    if name == "mers":
+        return mers(base=base) + ({},)
+    if name == "messy":
+        return synth.messy_set(os.path.join(base, "in")) + ({},)
+    r, gs = synth.make("pop6x200k")
+    return synth.write_set(os.path.join(base, "in"), r, gs) + (dict(partpos=40000),)
+
+
+def check_mumi(core, name, base):
+    """calcmumi=1: <outdir>/all.mumi "idx:dist" lines identical to the reference binary's (order is unspecified there)"""
+    rp, qs, kw = mumi_inputs(name, base)
+    out = os.path.join(base, "out")
+    rc, _ = driver.run_core(core, rp, qs, out, calcmumi=1, **kw)
+    assert rc == 0
+    lines = sorted(open(os.path.join(out, "all.mumi")).read().split(), key=lambda x: int(x.split(":")[0]))
+    assert lines == MUMI[name]
+    assert not os.path.exists(os.path.join(out, "parsnpAligner.xmfa"))
+
+
+@pytest.mark.parametrize("name", ["mers", "messy", "pop6x200k_p"])
+def test_calcmumi(cpu_checkers, tmp_path, name):
+    check_mumi(cpu_checkers, name, str(tmp_path))
+
+
 def test_cli_surface(cpu_checkers, tmp_path):
     import subprocess
     assert subprocess.run([cpu_checkers, "-v"], capture_output=True, text=True).stdout.strip() == "Parsnp v1.0.1"

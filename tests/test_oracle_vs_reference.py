@@ -93,3 +93,26 @@ def test_min_length_table(libs):
         want = [int(x.split()[1]) for x in out if x]
         got = [O.oracle_min_length(expr.encode(), s) for s in S]
         assert got == want, expr
+
+
+def test_mumi_coverage_random(libs):
+    import ctypes as C
+    O, R = libs
+    O.oracle_mumi_coverage.restype = C.c_int64
+    R.ref_mumi_coverage.restype = C.c_long
+    rng = np.random.default_rng(3)
+    tot = 0
+    for it in range(1000):
+        ref, (q,) = adversarial_case(rng, 20, int(rng.choice([60, 200])))
+        if it % 3 == 0:
+            q = mutate(rng, ref, sub=0.03)
+        if it % 50 == 0:
+            q = ref
+        if not any(c in ref for c in q) or not any(c in ref for c in oracles.revcomp(q)):
+            continue
+        a = R.ref_mumi_coverage(ref, C.c_long(len(ref)), q, oracles.revcomp(q), C.c_long(len(q)), 2)
+        b = O.oracle_mumi_coverage(ref, C.c_int64(len(ref)), q, C.c_int64(len(q)), 1)
+        c = O.oracle_mumi_coverage(ref, C.c_int64(len(ref)), q, C.c_int64(len(q)), 15)   # events < 15 cannot matter
+        assert a == b == c, (it, ref, q)
+        tot += a
+    assert tot > 10000
