@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -55,25 +56,23 @@ public:
         }
         words += 2;
         total_words = words;
-        b2 = (uint64_t*)be.alloc((size_t)words * 8);
-        nm = (uint32_t*)be.alloc((size_t)words * 4);
+        blk = (SeqBlock*)be.alloc((size_t)words * sizeof(SeqBlock));
         d_goff = (int64_t*)be.alloc(sizeof(int64_t) * 2 * (size_t)n);
         d_glen = (int64_t*)be.alloc(sizeof(int64_t) * (size_t)n);
         uint8_t* stage = (uint8_t*)be.alloc((size_t)std::max<int64_t>(maxlen, 1));
-        if (!b2 || !nm || !d_goff || !d_glen || !stage) { error = "device allocation failed (genomes)"; return -3; }
-        be.memset(b2, 0, (size_t)words * 8);
-        be.memset(nm, 0, (size_t)words * 4);
+        if (!blk || !d_goff || !d_glen || !stage) { error = "device allocation failed (genomes)"; return -3; }
+        be.memset(blk, 0, (size_t)words * sizeof(SeqBlock));
         be.h2d(d_goff, goff.data(), sizeof(int64_t) * goff.size());
         be.h2d(d_glen, lens, sizeof(int64_t) * (size_t)n);
         for (int g = 0; g < n; g++) {
             if (lens[g] == 0) continue;
             be.h2d(stage, seqs[g], (size_t)lens[g]);
             for (int s = 0; s < 2; s++)
-                be.launch("pack", (lens[g] + 31) / 32, PackStrand{stage, lens[g], s, b2, nm, goff[2 * (size_t)g + s] / 32});
+                be.launch("pack", (lens[g] + 31) / 32, PackStrand{stage, lens[g], s, blk, goff[2 * (size_t)g + s] / 32});
             be.sync();   // stage is reused
         }
         be.free(stage);
-        P = Packed{b2, nm, d_goff, d_glen};
+        P = Packed{blk, d_goff, d_glen};
         return 0;
     }
 
@@ -109,7 +108,7 @@ public:
             ri.K = ri.minlen < 16 ? ri.minlen : 16;
             ri.stride = ri.minlen - ri.K + 1;
             int64_t slots = 16;
-            while (slots < 2 * (int64_t)ri.nR) slots <<= 1;
+            while (2 * slots < 3 * (int64_t)ri.nR) slots <<= 1;   // load factor <= 2/3
             ri.tmask = (uint32_t)(slots - 1);
             ri.tbase = tsize; tsize += slots;
             ri.posbase = npos; posbase[(size_t)r] = npos; npos += ri.nR;
@@ -135,15 +134,14 @@ public:
         ensure(d_err, 1); be.memset(d_err.p, 0, 4);
 
         // -- reference index + repeat lengths
-        ensure(d_tags, (size_t)tsize); ensure(d_heads, (size_t)tsize);
+        ensure(d_slots, (size_t)tsize);
         ensure(d_next, (size_t)std::max<int64_t>(npos, 1)); ensure(d_rep, (size_t)std::max<int64_t>(npos, 1));
         ensure(d_epm, (size_t)std::max<int64_t>(npos, 1));
-        be.memset(d_tags.p, 0xff, sizeof(uint64_t) * (size_t)tsize);
-        be.memset(d_heads.p, 0xff, sizeof(int32_t) * (size_t)tsize);
+        be.memset(d_slots.p, 0xff, sizeof(uint64_t) * (size_t)tsize);
         be.mark("index");
-        be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_tags.p, d_heads.p, d_next.p});
+        be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p});
         be.mark("repeat");
-        be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_tags.p, d_heads.p, d_next.p, d_rep.p, d_err.p, work_budget});
+        be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p, d_rep.p, d_err.p, work_budget});
 
         // -- work units
         be.mark("units");
@@ -157,20 +155,28 @@ public:
         ensure(d_upair, (size_t)std::max<int64_t>(nunits, 1)); ensure(d_uinfo, (size_t)std::max<int64_t>(nunits, 1));
         be.launch("fill_units", npairs, FillUnits{d_uoff.p, d_ucount.p, d_upair.p, d_uinfo.p});
 
-        // -- events (retry with a larger buffer on overflow)
-        ensure(d_counter, 2);
+        // -- events: kSlices append buffers (retry with larger ones on overflow), gathered, then sorted by (pair, l, strand)
+        ensure(d_counter, (size_t)kSlices * kSliceStride);
+        ensure(d_sliceoff, (size_t)kSlices + 1);
         uint64_t nev = 0;
-        size_t cap = std::min<size_t>(std::max<size_t>(ev_cap_hint, ev_guess), (size_t)1 << 31);
+        size_t slice_cap = (std::min<size_t>(std::max<size_t>(ev_cap_hint, ev_guess), (size_t)1 << 31) + kSlices - 1) / kSlices + 64;
+        std::vector<uint64_t> counts((size_t)kSlices * kSliceStride);
+        std::vector<int64_t> sliceoff((size_t)kSlices + 1);
         for (;;) {
-            ensure(d_evkey, cap); ensure(d_evval, cap);
-            be.memset(d_counter.p, 0, 16);
+            ensure(d_evkey, slice_cap * kSlices); ensure(d_evval, slice_cap * kSlices);
+            be.memset(d_counter.p, 0, 8 * (size_t)kSlices * kSliceStride);
             be.mark("seed_extend");
             be.launch("seed_extend", nunits * 64,
-                      SeedExtend{P, d_R.p, d_starts.p, d_lens.p, ngen, d_upair.p, d_uinfo.p, d_tags.p, d_heads.p, d_next.p, d_rep.p,
-                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)cap, lbits, d_err.p, work_budget});
-            be.d2h(&nev, d_counter.p, 8);
-            if (nev <= cap) break;
-            cap = (size_t)(nev + nev / 8 + 1024);
+                      SeedExtend{P, d_R.p, d_starts.p, d_lens.p, ngen, d_upair.p, d_uinfo.p, d_slots.p, d_next.p, d_rep.p,
+                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err.p, work_budget,
+                                 getenv("PM_DEBUG_SEED") ? atoi(getenv("PM_DEBUG_SEED")) : 0});
+            be.d2h(counts.data(), d_counter.p, 8 * counts.size());
+            uint64_t worst = 0;
+            nev = 0;
+            for (int sl = 0; sl < kSlices; sl++) { uint64_t c = counts[(size_t)sl * kSliceStride]; sliceoff[(size_t)sl] = (int64_t)nev; nev += c; worst = std::max(worst, c); }
+            sliceoff[(size_t)kSlices] = (int64_t)nev;
+            if (worst <= slice_cap) break;
+            slice_cap = (size_t)(worst + worst / 8 + 64);
         }
         ev_cap_hint = (size_t)(nev + nev / 4);
         last_events = (int64_t)nev;
@@ -178,12 +184,16 @@ public:
         be.d2h(&errbits, d_err.p, 4);
         if (errbits & kErrWork) { error = "per-thread work budget exceeded (degenerate repeat structure in a region)"; return -5; }
 
-        // -- sort by (pair, l, strand); scan
         be.mark("sort");
         ensure(d_evkey2, std::max<size_t>(nev, 1)); ensure(d_evval2, std::max<size_t>(nev, 1));
+        ensure(d_evkey3, std::max<size_t>(nev, 1)); ensure(d_evval3, std::max<size_t>(nev, 1));
         const int keybits = bits_for((uint64_t)npairs) + lbits + 1;
-        uint64_t *skey = d_evkey.p, *sval = d_evval.p;
-        if (nev > 0) { be.sort_pairs(d_evkey.p, d_evkey2.p, d_evval.p, d_evval2.p, (size_t)nev, keybits); skey = d_evkey2.p; sval = d_evval2.p; }
+        uint64_t *skey = d_evkey3.p, *sval = d_evval3.p;
+        if (nev > 0) {
+            be.h2d(d_sliceoff.p, sliceoff.data(), 8 * sliceoff.size());
+            be.launch("compact_events", (int64_t)nev, CompactEvents{d_evkey.p, d_evval.p, d_sliceoff.p, (uint64_t)slice_cap, d_evkey2.p, d_evval2.p});
+            be.sort_pairs(d_evkey2.p, d_evkey3.p, d_evval2.p, d_evval3.p, (size_t)nev, keybits);
+        }
         be.mark("scan");
         ensure(d_lo, (size_t)npairs + 1);
         be.launch("pair_bounds", npairs, PairBounds{skey, (int64_t)nev, lbits, npairs, d_lo.p});
@@ -279,12 +289,14 @@ public:
 
     void release() {
         auto drop = [&](auto& b) { if (b.p) be.free(b.p); b.p = nullptr; b.cap = 0; };
-        drop(d_R); drop(d_starts); drop(d_lens); drop(d_posbase); drop(d_tilebase); drop(d_err); drop(d_tags); drop(d_heads); drop(d_next);
+        drop(d_R); drop(d_starts); drop(d_lens); drop(d_posbase); drop(d_tilebase); drop(d_err); drop(d_slots); drop(d_next);
         drop(d_rep); drop(d_epm); drop(d_ucount); drop(d_uoff); drop(d_upair); drop(d_uinfo); drop(d_counter); drop(d_evkey); drop(d_evval);
-        drop(d_evkey2); drop(d_evval2); drop(d_lo); drop(d_cov); drop(d_state); drop(d_summary); drop(d_startshere); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
+        drop(d_evkey2); drop(d_evval2); drop(d_evkey3); drop(d_evval3); drop(d_sliceoff); drop(d_lo); drop(d_cov); drop(d_state); drop(d_summary); drop(d_startshere); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
         drop(d_ok_k); drop(d_ok_lon); drop(d_osp); drop(d_ofwd);
-        if (b2) be.free(b2); if (nm) be.free(nm); if (d_goff) be.free(d_goff); if (d_glen) be.free(d_glen);
-        b2 = nullptr; nm = nullptr; d_goff = nullptr; d_glen = nullptr;
+        if (blk) be.free(blk);
+        if (d_goff) be.free(d_goff);
+        if (d_glen) be.free(d_glen);
+        blk = nullptr; d_goff = nullptr; d_glen = nullptr;
     }
 
 private:
@@ -300,14 +312,14 @@ private:
     }
     void collect_timing() { timing = be.collect(); }
 
-    uint64_t* b2 = nullptr; uint32_t* nm = nullptr; int64_t* d_goff = nullptr; int64_t* d_glen = nullptr;
+    SeqBlock* blk = nullptr; int64_t* d_goff = nullptr; int64_t* d_glen = nullptr;
     int64_t total_words = 0;
     Packed P{};
     size_t ev_cap_hint = 0, cand_cap_hint = 0;
     Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase, d_tilebase; Buf<uint32_t> d_err;
-    Buf<uint64_t> d_tags; Buf<int32_t> d_heads, d_next, d_rep, d_epm;
+    Buf<uint64_t> d_slots; Buf<int32_t> d_next, d_rep, d_epm;
     Buf<int64_t> d_ucount, d_uoff; Buf<int32_t> d_upair, d_uinfo;
-    Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2;
+    Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2, d_evkey3, d_evval3; Buf<int64_t> d_sliceoff;
     Buf<int64_t> d_lo, d_cov; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
     Buf<uint64_t> d_cand, d_cand2; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
 };

@@ -7,9 +7,11 @@
 // executions compute the same result.
 //
 // Data layout in HBM (see DESIGN.md "Data layout"):
-//   b2[]  2 bits per base, 32 bases per uint64 word   (A=0 C=1 G=2 T=3, N stored as 0)
-//   nm[]  1 bit per base, 32 bases per uint32 word    (1 = N)   -- 'N' matches 'N' (src/csgmum/csg.c:13-25)
-//   every genome is stored twice (forward, reverse complement), each strand starting on a word boundary with
+//   blk[]  one 16-byte block per 32 bases: { uint64 b2 : 2 bits per base (A=0 C=1 G=2 T=3, N stored as 0),
+//                                             uint32 nm : 1 bit per base (1 = N), uint32 pad }
+//          -- 'N' matches 'N' (src/csgmum/csg.c:13-25); both planes of a 32-base window come from two adjacent
+//          16-byte loads, i.e. normally one 64-byte sector.
+//   every genome is stored twice (forward, reverse complement), each strand starting on a block boundary with
 //   64 guard bases either side, so a 32-base window can be read at any offset without bounds checks.
 //
 // Reference semantics being computed: SURVEY.md 3.3 (= Find_UM / Intersect_UM / Merge_Master / extraction of
@@ -75,6 +77,23 @@ PM_HD uint64_t atomic_add64(uint64_t* p, uint64_t v) {
     uint64_t o = *p; *p = o + v; return o;
 #endif
 }
+// Reserve n consecutive slots of a global append buffer.  On the device every lane of the (full, converged) wavefront
+// calls this once: the 64 counts are prefix-summed with cross-lane shuffles and ONE atomic per wavefront is issued
+// (a single hot counter otherwise costs 60 % of SeedExtend).  The host emulation has no wavefronts: plain add.
+PM_HD uint64_t wave_reserve(uint64_t* counter, uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = (int)__lane_id();
+    uint32_t x = n;
+    for (int d = 1; d < 64; d <<= 1) { uint32_t y = (uint32_t)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
+    const uint32_t total = (uint32_t)__shfl((int)x, 63, 64);
+    unsigned long long base = 0;
+    if (lane == 63 && total) base = atomicAdd((unsigned long long*)counter, (unsigned long long)total);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 63, 64) << 32) | (uint32_t)__shfl((int)(base & 0xffffffffu), 63, 64);
+    return (uint64_t)base + (x - n);
+#else
+    uint64_t o = *counter; *counter = o + n; return o;
+#endif
+}
 PM_HD void atomic_max32(int32_t* p, int32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicMax(p, v);
@@ -91,9 +110,9 @@ PM_HD void atomic_or32(uint32_t* p, uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------ shared structures
+struct alignas(16) SeqBlock { uint64_t b2; uint32_t nm; uint32_t pad; };   // 32 bases
 struct Packed {            // the resident genomes
-    const uint64_t* b2;
-    const uint32_t* nm;
+    const SeqBlock* blk;
     const int64_t* goff;   // [2*g + strand] global base offset of the strand
     const int64_t* glen;   // [g] genome length
 };
@@ -105,7 +124,7 @@ struct RegionInfo {        // one per region of a batch
     int32_t stride;        // query sampling step = max(minsize,1) - K + 1
     int32_t minlen;        // max(minsize, 1): shortest event that can matter
     int32_t minsize;       // as requested (candidate test, parsnp.cpp:1663)
-    uint32_t tmask;        // hash-table slice size - 1 (power of two)
+    uint32_t tmask;        // hash-table slice size - 1 (power of two, >= 1.5 nR)
     int64_t tbase;         // hash-table slice start
     int64_t posbase;       // start of this region in the per-reference-position arrays
     int64_t tile_base;     // first 16-position tile of this region
@@ -117,31 +136,30 @@ constexpr int kTile = 16;          // reference positions per master-fold thread
 #define PM_UNIT 256
 #endif
 constexpr int kUnitSamples = PM_UNIT;  // query samples per work unit (64 threads x PM_UNIT/64)
+constexpr int kSlices = 1024;          // the event buffer is appended through this many independent counters
+constexpr int kSliceStride = 8;        // uint64 words between two counters: one 64-byte line each
 
 // error bits raised by kernels
 constexpr uint32_t kErrWork = 1u;  // per-thread work budget exceeded (degenerate repeat structure)
 
-// 32 bases starting at global base position p
-PM_HD uint64_t win2(const uint64_t* b2, int64_t p) {
-    int64_t w = p >> 5;
-    int sh = (int)(p & 31) * 2;
-    uint64_t lo = b2[w];
-    if (sh == 0) return lo;
-    return (lo >> sh) | (b2[w + 1] << (64 - sh));
-}
-PM_HD uint32_t winm(const uint32_t* nm, int64_t p) {
+// 32 bases starting at global base position p: 2-bit plane and N-mask plane
+PM_HD void window(const SeqBlock* blk, int64_t p, uint64_t* bits, uint32_t* mask) {
     int64_t w = p >> 5;
     int sh = (int)(p & 31);
-    uint32_t lo = nm[w];
-    if (sh == 0) return lo;
-    return (lo >> sh) | (nm[w + 1] << (32 - sh));
+    SeqBlock lo = blk[w];
+    if (sh == 0) { *bits = lo.b2; *mask = lo.nm; return; }
+    SeqBlock hi = blk[w + 1];
+    *bits = (lo.b2 >> (2 * sh)) | (hi.b2 << (64 - 2 * sh));
+    *mask = (lo.nm >> sh) | (hi.nm << (32 - sh));
 }
 // number of equal bases going right from (a, b), at most maxlen
 PM_HD int32_t lce_fwd(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
     int32_t n = 0;
     while (n < maxlen) {
-        uint64_t x = win2(P.b2, a + n) ^ win2(P.b2, b + n);
-        uint32_t mx = winm(P.nm, a + n) ^ winm(P.nm, b + n);
+        uint64_t xa, xb; uint32_t ma, mb;
+        window(P.blk, a + n, &xa, &ma);
+        window(P.blk, b + n, &xb, &mb);
+        uint64_t x = xa ^ xb; uint32_t mx = ma ^ mb;
         uint64_t d = (x | (x >> 1)) & 0x5555555555555555ull;
         int c = d ? (ctz64(d) >> 1) : 32;
         if (mx) { int cm = ctz32(mx); if (cm < c) c = cm; }
@@ -154,8 +172,10 @@ PM_HD int32_t lce_fwd(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
 PM_HD int32_t lce_bwd(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
     int32_t n = 0;
     while (n < maxlen) {
-        uint64_t x = win2(P.b2, a - n - 32) ^ win2(P.b2, b - n - 32);
-        uint32_t mx = winm(P.nm, a - n - 32) ^ winm(P.nm, b - n - 32);
+        uint64_t xa, xb; uint32_t ma, mb;
+        window(P.blk, a - n - 32, &xa, &ma);
+        window(P.blk, b - n - 32, &xb, &mb);
+        uint64_t x = xa ^ xb; uint32_t mx = ma ^ mb;
         uint64_t d = (x | (x >> 1)) & 0x5555555555555555ull;
         int c = d ? (clz64(d) >> 1) : 32;
         if (mx) { int cm = clz32(mx); if (cm < c) c = cm; }
@@ -166,15 +186,15 @@ PM_HD int32_t lce_bwd(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
 }
 // K-mer at p as a 48-bit tag: 2K base bits | K mask bits << 32
 PM_HD uint64_t kmer_tag(const Packed& P, int64_t p, int K) {
-    uint64_t b = win2(P.b2, p);
-    uint32_t m = winm(P.nm, p);
+    uint64_t b; uint32_t m;
+    window(P.blk, p, &b, &m);
     if (K < 32) b &= (1ull << (2 * K)) - 1;
     if (K < 32) m &= (uint32_t)((1ull << K) - 1);
     return b | ((uint64_t)m << 32);
 }
-PM_HD uint32_t hash_tag(uint64_t t) {
+PM_HD uint64_t hash_tag(uint64_t t) {   // low bits: slot, high 32 bits: fingerprint
     t ^= t >> 29; t *= 0xbf58476d1ce4e5b9ull; t ^= t >> 32; t *= 0x94d049bb133111ebull; t ^= t >> 29;
-    return (uint32_t)t;
+    return t;
 }
 // largest r in [0, count) with base[r] <= x (base ascending, base[0] <= x)
 PM_HD int64_t upper_slot(const int64_t* base, int64_t count, int64_t x) {
@@ -186,7 +206,7 @@ PM_HD int64_t upper_slot(const int64_t* base, int64_t count, int64_t x) {
 // ------------------------------------------------------------------------------------------ genome packing
 // tid = output word of one strand. ascii: the genome as uploaded ('A','C','G','T', anything else = N).
 struct PackStrand {
-    const uint8_t* ascii; int64_t L; int strand; uint64_t* b2; uint32_t* nm; int64_t word0;   // word0: first word of the strand
+    const uint8_t* ascii; int64_t L; int strand; SeqBlock* blk; int64_t word0;   // word0: first block of the strand
     PM_HD void operator()(int64_t tid) const {
         uint64_t bits = 0; uint32_t mask = 0;
         for (int i = 0; i < 32; i++) {
@@ -198,39 +218,62 @@ struct PackStrand {
             if (code == 4) mask |= 1u << i;
             else bits |= (uint64_t)(strand ? 3 - code : code) << (2 * i);
         }
-        b2[word0 + tid] = bits; nm[word0 + tid] = mask;
+        blk[word0 + tid] = SeqBlock{bits, mask, 0};
     }
 };
 
 // ------------------------------------------------------------------------------------------ reference index
-// Replaces new_CSG/build_CSG/find_leaves (src/csgmum/csg.c:105-575): a chained hash of the reference substring's
-// K-mers.  tid = flat reference position over the batch.
+// Replaces new_CSG/build_CSG/find_leaves (src/csgmum/csg.c:105-575): an open-addressing hash of the reference
+// substring's K-mers.  One 8-byte slot per distinct K-mer:  [63:32] fingerprint | [31] more-than-one-occurrence flag |
+// [30:0] head position; further occurrences hang off next[].  A fingerprint hit is confirmed against the K-mer at the
+// head position (the caller reads those reference bases anyway).
+constexpr uint64_t kMulti = 1ull << 31;
+PM_HD int32_t slot_head(uint64_t s) { return (int32_t)(s & 0x7fffffffu); }
+
+// tid = flat reference position over the batch.
 struct IndexInsert {
     Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;   // posbase[nregions+1]
-    uint64_t* tags; int32_t* heads; int32_t* next;
+    uint64_t* slots; int32_t* next;
     PM_HD void operator()(int64_t tid) const {
         int64_t r = upper_slot(posbase, nregions, tid);
         const RegionInfo& ri = R[r];
         int32_t l = (int32_t)(tid - ri.posbase);
         next[tid] = -1;
         if (l + ri.K > ri.nR) return;
-        uint64_t tag = kmer_tag(P, P.goff[0] + ri.ref_pos + l, ri.K);
-        uint32_t h = hash_tag(tag) & ri.tmask;
+        const int64_t base = P.goff[0] + ri.ref_pos;
+        const uint64_t tag = kmer_tag(P, base + l, ri.K);
+        const uint64_t hv = hash_tag(tag);
+        const uint64_t fp = hv & 0xffffffff00000000ull;
+        uint32_t h = (uint32_t)hv & ri.tmask;
         for (;;) {
-            uint64_t seen = tags[ri.tbase + h];
-            if (seen == kEmpty) seen = atomic_cas64(&tags[ri.tbase + h], kEmpty, tag);
-            if (seen == kEmpty || seen == tag) break;
+            uint64_t* slot = &slots[ri.tbase + h];
+            uint64_t seen = *slot;
+            if (seen == kEmpty) {
+                seen = atomic_cas64(slot, kEmpty, fp | (uint64_t)l);
+                if (seen == kEmpty) return;                       // first occurrence of this K-mer
+            }
+            if ((seen & 0xffffffff00000000ull) == fp && kmer_tag(P, base + slot_head(seen), ri.K) == tag) {
+                for (;;) {                                          // push onto this K-mer's chain
+                    next[tid] = slot_head(seen);
+                    uint64_t prev = atomic_cas64(slot, seen, fp | kMulti | (uint64_t)l);
+                    if (prev == seen) return;
+                    seen = prev;                                    // another occurrence got in first: same K-mer, new head
+                }
+            }
             h = (h + 1) & ri.tmask;
         }
-        next[tid] = atomic_exch32(&heads[ri.tbase + h], l);
     }
 };
-PM_HD int32_t index_lookup(const RegionInfo& ri, const uint64_t* tags, const int32_t* heads, uint64_t tag) {
-    uint32_t h = hash_tag(tag) & ri.tmask;
+// -> slot value of the K-mer `tag` in region ri, or kEmpty
+PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_t* slots, uint64_t tag) {
+    const uint64_t hv = hash_tag(tag);
+    const uint64_t fp = hv & 0xffffffff00000000ull;
+    uint32_t h = (uint32_t)hv & ri.tmask;
+    const int64_t base = P.goff[0] + ri.ref_pos;
     for (;;) {
-        uint64_t seen = tags[ri.tbase + h];
-        if (seen == tag) return heads[ri.tbase + h];
-        if (seen == kEmpty) return -1;
+        uint64_t seen = slots[ri.tbase + h];
+        if (seen == kEmpty) return kEmpty;
+        if ((seen & 0xffffffff00000000ull) == fp && kmer_tag(P, base + slot_head(seen), ri.K) == tag) return seen;
         h = (h + 1) & ri.tmask;
     }
 }
@@ -239,7 +282,7 @@ PM_HD int32_t index_lookup(const RegionInfo& ri, const uint64_t* tags, const int
 // (= the uniqueness point pos_label-l of mum.c:219-224 wherever it can influence the output; SURVEY 3.3-1,-7.)
 struct RepeatLength {
     Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;
-    const uint64_t* tags; const int32_t* heads; const int32_t* next; int32_t* rep; uint32_t* err; int64_t budget;
+    const uint64_t* slots; const int32_t* next; int32_t* rep; uint32_t* err; int64_t budget;
     PM_HD void operator()(int64_t tid) const {
         int64_t r = upper_slot(posbase, nregions, tid);
         const RegionInfo& ri = R[r];
@@ -248,14 +291,17 @@ struct RepeatLength {
         if (l + ri.K <= ri.nR) {
             int64_t base = P.goff[0] + ri.ref_pos;
             uint64_t tag = kmer_tag(P, base + l, ri.K);
-            int64_t work = 0;
-            for (int32_t o = index_lookup(ri, tags, heads, tag); o >= 0; o = next[ri.posbase + o]) {
-                if (o == l) continue;
-                int32_t lim = ri.nR - (l > o ? l : o) - ri.K;
-                int32_t len = ri.K + lce_fwd(P, base + l + ri.K, base + o + ri.K, lim);
-                if (len > best) best = len;
-                work += 1 + (len >> 5);
-                if (work > budget) { atomic_or32(err, kErrWork); break; }
+            uint64_t slot = index_lookup(P, ri, slots, tag);
+            if (slot != kEmpty && (slot & kMulti)) {
+                int64_t work = 0;
+                for (int32_t o = slot_head(slot); o >= 0; o = next[ri.posbase + o]) {
+                    if (o == l) continue;
+                    int32_t lim = ri.nR - (l > o ? l : o) - ri.K;
+                    int32_t len = ri.K + lce_fwd(P, base + l + ri.K, base + o + ri.K, lim);
+                    if (len > best) best = len;
+                    work += 1 + (len >> 5);
+                    if (work > budget) { atomic_or32(err, kErrWork); break; }
+                }
             }
         }
         rep[tid] = best;
@@ -290,8 +336,9 @@ struct FillUnits {
 struct SeedExtend {
     Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen;
     const int32_t* unit_pair; const int32_t* unit_info;
-    const uint64_t* tags; const int32_t* heads; const int32_t* next; const int32_t* rep;
-    uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_count; uint64_t ev_cap; int lbits; uint32_t* err; int64_t budget;
+    const uint64_t* slots; const int32_t* next; const int32_t* rep;
+    uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
+    int debug;   // PM_DEBUG_SEED experiments (profiling only; results are wrong when set): 1 no emit, 2 stop after lookup, 4 stop after left arm
     PM_HD void operator()(int64_t tid) const {
         int64_t unit = tid >> 6; int lane = (int)(tid & 63);
         int32_t pair = unit_pair[unit]; int32_t info = unit_info[unit];
@@ -303,31 +350,67 @@ struct SeedExtend {
         const int64_t rbase = P.goff[0] + ri.ref_pos;
         const int K = ri.K;
         int64_t work = 0;
-        for (int u = 0; u < kUnitSamples / 64; u++) {
+        // events are appended to one of kSlices sub-buffers (all four wavefronts of a workgroup use the same one): a
+        // single counter serialises the ~10^6 wavefront reservations of a recursion batch
+        const uint64_t slice = (uint64_t)((unit >> 2) & (kSlices - 1));
+        uint64_t* ev_count = ev_counters + slice * kSliceStride;
+        const uint64_t ev_cap = slice_cap;
+        uint64_t* const key_out = ev_key + slice * slice_cap;
+        uint64_t* const val_out = ev_val + slice * slice_cap;
+        // the first event of each of the thread's samples waits in registers and is written with ONE reservation per
+        // wavefront; a second event of the same sample (repeated K-mer) is rare and takes its own slot
+        constexpr int kPer = kUnitSamples / 64;
+        uint64_t bk[kPer], bv[kPer];
+        bool stop = false;
+#pragma unroll
+        for (int u = 0; u < kPer; u++) {
+            bk[u] = kEmpty; bv[u] = 0;
             int64_t s = chunk * kUnitSamples + u * 64 + lane;
             int64_t j = s * ri.stride;
-            if (j + K > m) continue;
+            if (stop || j + K > m) continue;
             uint64_t tag = kmer_tag(P, qbase + j, K);
-            for (int32_t l = index_lookup(ri, tags, heads, tag); l >= 0; l = next[ri.posbase + l]) {
-                if (++work > budget) { atomic_or32(err, kErrWork); return; }
+            uint64_t slot = index_lookup(P, ri, slots, tag);
+            if (slot == kEmpty) continue;
+            if (debug & 2) { if (slot == 12345) atomic_or32(err, 2u); continue; }
+            const bool multi = (slot & kMulti) != 0;
+            for (int32_t l = slot_head(slot); l >= 0; l = multi ? next[ri.posbase + l] : -1) {
+                if (++work > budget) { atomic_or32(err, kErrWork); stop = true; break; }
                 // left: only `stride` bases matter -- a longer left arm means an earlier sample owns the match
                 int32_t lim = (int32_t)(j < l ? j : l);
                 if (lim > ri.stride) lim = ri.stride;
                 int32_t left = lce_bwd(P, qbase + j, rbase + l, lim);
                 if (left >= ri.stride) continue;
+                if (debug & 4) { if (left == 12345) atomic_or32(err, 2u); continue; }
                 int64_t mr = m - j - K; int32_t rr = ri.nR - l - K;
                 int32_t right = lce_fwd(P, qbase + j + K, rbase + l + K, (int32_t)(mr < rr ? mr : rr));
                 int32_t len = left + K + right;
                 if (len < ri.minlen) continue;
                 int32_t l0 = l - left; int64_t j0 = j - left;
                 if (len <= rep[ri.posbase + l0]) continue;           // not unique in R
-                uint64_t slot = atomic_add64(ev_count, 1);
-                if (slot < ev_cap) {
-                    ev_key[slot] = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
-                    ev_val[slot] = ((uint64_t)j0 << 32) | (uint32_t)len;
-                }
+                if (debug & 1) { if (len == 123456789) atomic_or32(err, 2u); continue; }
+                const uint64_t ek = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
+                const uint64_t evv = ((uint64_t)j0 << 32) | (uint32_t)len;
+                if (bk[u] == kEmpty) { bk[u] = ek; bv[u] = evv; }
+                else { uint64_t at = atomic_add64(ev_count, 1); if (at < ev_cap) { key_out[at] = ek; val_out[at] = evv; } }
             }
         }
+        uint32_t nb = 0;
+#pragma unroll
+        for (int u = 0; u < kPer; u++) nb += bk[u] != kEmpty;
+        uint64_t at = wave_reserve(ev_count, nb);
+#pragma unroll
+        for (int u = 0; u < kPer; u++)
+            if (bk[u] != kEmpty) { if (at < ev_cap) { key_out[at] = bk[u]; val_out[at] = bv[u]; } at++; }
+    }
+};
+
+// gather the kSlices sub-buffers into one contiguous array.  tid = output event; off[kSlices+1] = prefix of the counts
+struct CompactEvents {
+    const uint64_t* key_in; const uint64_t* val_in; const int64_t* off; uint64_t slice_cap; uint64_t* key_out; uint64_t* val_out;
+    PM_HD void operator()(int64_t tid) const {
+        int64_t sl = upper_slot(off, kSlices, tid);
+        int64_t src = sl * (int64_t)slice_cap + (tid - off[sl]);
+        key_out[tid] = key_in[src]; val_out[tid] = val_in[src];
     }
 };
 

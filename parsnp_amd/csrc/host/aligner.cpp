@@ -33,7 +33,7 @@ void Bitmap::init(size_t nbits) {
     w_.assign((nbits + 63) / 64 + 1, 0);
     if (nbits) w_[(nbits - 1) >> 6] |= 1ull << ((nbits - 1) & 63);
 }
-void Bitmap::set_range(long a, long b) {
+void Bitmap::set_range_slow(long a, long b) {
     if (a < 0) a = 0;
     if (b > (long)nbits_) b = (long)nbits_;
     while (a < b) {
@@ -100,7 +100,8 @@ bool Region::same_as(const Region& o, size_t n) const {
 Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session)
     : n(g.size()), prm(p), genomes(g), session_(session) {
     layout.resize(n);
-    for (size_t i = 0; i < n; i++) layout[i].init(genomes[i].seq.size() + 1);
+    gsize_.resize(n);
+    for (size_t i = 0; i < n; i++) { layout[i].init(genomes[i].seq.size() + 1); gsize_[i] = (long)genomes[i].seq.size(); }
 }
 
 Region Aligner::new_region() {
@@ -132,29 +133,61 @@ Region Aligner::neighbour_region(const Mum& m, bool left) {
     return r;
 }
 
-int Aligner::min_length(bool anchors, long slength) const {
+int Aligner::min_length(bool anchors, long slength) {
+    auto& memo = minlen_memo_[anchors ? 1 : 0];
+    auto it = memo.find(slength);
+    if (it != memo.end()) return it->second;
     int v = 0;
     const std::string& e = anchors ? prm.anchors : prm.mums;
     if (!min_mum_length(e, slength, &v)) fatal("cannot evaluate minimum MUM length expression '" + e + "'");
+    memo.emplace(slength, v);
     return v;
 }
 
-std::string Aligner::key_of(const Request& q) {
-    std::string k;
-    k.resize(q.start.size() * 16 + 4);
-    memcpy(&k[0], q.start.data(), q.start.size() * 8);
-    memcpy(&k[q.start.size() * 8], q.len.data(), q.len.size() * 8);
-    memcpy(&k[q.start.size() * 16], &q.minsize, 4);
-    return k;
+static uint64_t hash_rows(const long* a, const long* b, size_t n, int32_t minsize) {
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)(uint32_t)minsize;
+    for (size_t i = 0; i < n; i++) {
+        h = (h ^ (uint64_t)a[i]) * 0xff51afd7ed558ccdull; h ^= h >> 32;
+        h = (h ^ (uint64_t)b[i]) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
+    }
+    return h;
+}
+
+Aligner::CacheEntry* Aligner::cache_find(const Request& q) {
+    auto range = cache_.equal_range(q.hash);
+    for (auto it = range.first; it != range.second; ++it) {
+        CacheEntry& e = it->second;
+        if (e.minsize == q.minsize && !memcmp(e.start, q.start, n * sizeof(long)) && !memcmp(e.len, q.len, n * sizeof(long))) return &e;
+    }
+    return nullptr;
+}
+Aligner::CacheEntry* Aligner::cache_put(const Request& q, bool pending) {
+    CacheEntry e;
+    long* st = cache_rows_.alloc(n); long* ln = cache_rows_.alloc(n);
+    memcpy(st, q.start, n * sizeof(long)); memcpy(ln, q.len, n * sizeof(long));
+    e.start = st; e.len = ln; e.minsize = q.minsize; e.pending = pending;
+    return &cache_.emplace(q.hash, std::move(e))->second;
 }
 
 // The reference cuts the reference side of a region into chunks of p bases and re-streams every query against each
 // chunk (parsnp.cpp:1519-1547); one finder request per chunk.
-std::vector<Aligner::Request> Aligner::chunk_requests(const Region& r, int minsize) const {
-    std::vector<Request> out;
+void Aligner::chunk_requests(const Region& r, int minsize, std::vector<Request>* out) {
+    out->clear();
     long len0 = r.length[0];
     long p = prm.p > len0 ? len0 : prm.p;
     if (p <= 0 && len0 > 0) fatal("LCB p must be positive");
+    if (p == len0 && len0 > 0) {
+        // the common case: one chunk = the region itself; its rows are the request unless substr() would clamp them
+        bool plain = true;
+        for (size_t g = 0; g < n && plain; g++) {
+            if (r.start[g] < 0 || r.start[g] > gsize_[g]) fatal("region start outside genome");   // std::string::substr would throw
+            plain = r.length[g] >= 0 && r.start[g] + r.length[g] <= gsize_[g];
+        }
+        if (plain) {
+            out->push_back(Request{r.start, r.length, minsize, r.start[0], hash_rows(r.start, r.length, n, minsize)});
+            return;
+        }
+    }
     long partpos = 0;
     while (partpos < len0) {
         if (partpos + p > len0) {
@@ -162,26 +195,21 @@ std::vector<Aligner::Request> Aligner::chunk_requests(const Region& r, int minsi
             if (p < 50) { p = 50 + p; partpos = partpos - 50; }
             if (partpos < 0) fatal("reference chunk underflow (p < 50)");
         }
-        Request q;
-        q.start.resize(n); q.len.resize(n);
-        q.minsize = minsize;
-        q.ref_ini = r.start[0] + partpos;
+        long* st = req_rows_.alloc(n); long* ln = req_rows_.alloc(n);
         for (size_t g = 0; g < n; g++) {
-            long st = g == 0 ? r.start[0] + partpos : r.start[g];
-            long ln = g == 0 ? p : r.length[g];
-            long size = (long)genomes[g].seq.size();
-            if (st < 0 || st > size) fatal("region start outside genome");   // std::string::substr would throw
-            if (ln < 0) ln = 0;              // substr(pos, npos-like): the reference only builds such regions when slength > q
-            if (st + ln > size) ln = size - st;
-            q.start[g] = st; q.len[g] = ln;
+            long s0 = g == 0 ? r.start[0] + partpos : r.start[g];
+            long l0 = g == 0 ? p : r.length[g];
+            if (s0 < 0 || s0 > gsize_[g]) fatal("region start outside genome");   // std::string::substr would throw
+            if (l0 < 0) l0 = 0;
+            if (s0 + l0 > gsize_[g]) l0 = gsize_[g] - s0;                         // substr clamps
+            st[g] = s0; ln[g] = l0;
         }
-        out.push_back(std::move(q));
+        out->push_back(Request{st, ln, minsize, r.start[0] + partpos, hash_rows(st, ln, n, minsize)});
         partpos += p;
     }
-    return out;
 }
 
-void Aligner::run_batch(const std::vector<const Request*>& reqs, std::vector<Raw>* out) {
+void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out) {
     out->clear();
     out->resize(reqs.size());
     if (reqs.empty()) return;
@@ -189,9 +217,9 @@ void Aligner::run_batch(const std::vector<const Request*>& reqs, std::vector<Raw
     std::vector<int64_t> starts(reqs.size() * n), lens(reqs.size() * n);
     std::vector<int32_t> mins(reqs.size());
     for (size_t i = 0; i < reqs.size(); i++) {
-        memcpy(&starts[i * n], reqs[i]->start.data(), n * 8);
-        memcpy(&lens[i * n], reqs[i]->len.data(), n * 8);
-        mins[i] = reqs[i]->minsize;
+        memcpy(&starts[i * n], reqs[i].start, n * 8);
+        memcpy(&lens[i * n], reqs[i].len, n * 8);
+        mins[i] = reqs[i].minsize;
     }
     pm_result* res = nullptr;
     int rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);
@@ -234,27 +262,27 @@ void Aligner::run_batch(const std::vector<const Request*>& reqs, std::vector<Raw
 void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accepted, bool speculative) {
     int minsize = min_length(anchors, r.slength);
     if (anchors) l = (float)minsize;
-    std::vector<Request> reqs = chunk_requests(r, minsize);
+    std::vector<Request> reqs;
+    const Arena<long>::Mark qmark = req_rows_.mark();
+    chunk_requests(r, minsize, &reqs);
     for (Request& q : reqs) {
         double tk = now_s();
-        std::string key = key_of(q);
-        auto it = cache_.find(key);
+        CacheEntry* e = cache_find(q);
         stats.t_key += now_s() - tk;
-        if (it == cache_.end()) {
-            if (speculative) {
-                if (wanted_keys_.emplace(key, (int)wanted_.size()).second) wanted_.push_back(q);
-                continue;
-            }
+        if (!e || e->pending) {
+            if (speculative) continue;     // the sweep only consumes what its batch computed
             stats.cache_misses++;
-            std::vector<const Request*> one{&q};
+            std::vector<Request> one{q};
             std::vector<Raw> raw;
             run_batch(one, &raw);
-            it = cache_.emplace(std::move(key), std::move(raw[0])).first;
+            if (!e) e = cache_put(q, false);
+            e->raw = std::move(raw[0]); e->pending = false;
         } else if (!speculative) {
             stats.cache_hits++;
         }
-        { double tv = now_s(); validate(r, q, it->second, accepted); stats.t_validate += now_s() - tv; }
+        { double tv = now_s(); validate(r, q, e->raw, accepted); stats.t_validate += now_s() - tv; }
     }
+    req_rows_.rewind(qmark);
     if (!speculative) stats.regions_processed++;
 }
 
@@ -263,29 +291,10 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
 void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted) {
     const size_t nq = n - 1;
     const size_t ncand = raw.k.size();
-    std::vector<long> gsize(n);
-    for (size_t j = 0; j < n; j++) gsize[j] = (long)genomes[j].seq.size();
-    // genome-j start of candidate c exactly as the TMum constructor derives it (TMum.cpp:25-40): forward = DSP-1,
-    // reverse = flipped against the WHOLE genome length even inside a sub-region
-    auto start_of = [&](size_t c, size_t j) -> long {
-        unsigned long dsp = j == 0 ? (unsigned long)raw.k[c] + 1 + (unsigned long)q.ref_ini
-                                   : (unsigned long)raw.sp[c * nq + j - 1] + 1 + (unsigned long)r.start[j];
-        long sp = (long)(dsp - 1);
-        bool fw = j == 0 || raw.fwd[c * nq + j - 1];
-        return fw ? sp : gsize[j] - (sp + (long)raw.lon[c]);
-    };
-    const size_t kAhead = 6;
+    const std::vector<long>& gsize = gsize_;
+    const unsigned long ref_ini = (unsigned long)q.ref_ini;
     for (size_t c = 0; c < ncand; c++) {
-        if (c + kAhead < ncand)   // the layout rows of 200 genomes are 200 independent streams: fetch them ahead
-            for (size_t j = 0; j < n; j++) layout[j].prefetch(start_of(c + kAhead, j));
         const long lon = raw.lon[c];
-        bool bad = false;
-        for (size_t j = 0; j < n; j++) {
-            unsigned long dsp = j == 0 ? (unsigned long)raw.k[c] + 1 + (unsigned long)q.ref_ini
-                                       : (unsigned long)raw.sp[c * nq + j - 1] + 1 + (unsigned long)r.start[j];
-            if (dsp - (unsigned long)r.start[j] > (unsigned long)(unsigned int)r.length[j]) bad = true;   // :1723
-        }
-        if (bad) continue;
         Mum m;
         m.id = next_id_++;
         m.length = lon;
@@ -293,15 +302,23 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
         const Arena<int>::Mark imark = irows_.mark();
         m.start = rows_.alloc(n); m.end = rows_.alloc(n); m.fwd = irows_.alloc(n);
         auto reject = [&]() { rows_.rewind(rmark); irows_.rewind(imark); };
-        bool ok = true, touches = false, any_reverse = false;
+        bool bad = false, ok = true, touches = false, any_reverse = false;
+        const int64_t* sp = &raw.sp[c * nq];
+        const uint8_t* fw = &raw.fwd[c * nq];
         for (size_t j = 0; j < n; j++) {
-            m.fwd[j] = j == 0 ? 1 : raw.fwd[c * nq + j - 1];
-            m.start[j] = start_of(c, j);
-            if (m.start[j] + lon > gsize[j] || m.start[j] < 0) { ok = false; m.end[j] = m.start[j] + lon; continue; }   // never for in-range candidates
-            m.end[j] = m.start[j] + lon;
-            any_reverse |= !m.fwd[j];
-            if (lon > 0) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end[j] - 1);
+            // DSP of the reference (:1671,:1681) and its bound test (:1723)
+            const unsigned long dsp = j == 0 ? (unsigned long)raw.k[c] + 1 + ref_ini : (unsigned long)sp[j - 1] + 1 + (unsigned long)r.start[j];
+            bad |= dsp - (unsigned long)r.start[j] > (unsigned long)(unsigned int)r.length[j];
+            const long startpos = (long)(dsp - 1);
+            const int f = j == 0 ? 1 : fw[j - 1];
+            // reverse strand: flipped against the WHOLE genome length even inside a sub-region (TMum.cpp:33-35)
+            const long st = f ? startpos : gsize[j] - (startpos + lon);
+            m.fwd[j] = f; m.start[j] = st; m.end[j] = st + lon;
+            any_reverse |= !f;
+            if (st + lon > gsize[j] || st < 0) ok = false;          // never for in-range candidates
+            else if (lon > 0) touches |= layout[j].get(st) | layout[j].get(st + lon - 1);
         }
+        if (bad) { reject(); next_id_--; continue; }   // the reference skips before constructing the TMum (no id consumed)
         if (!ok || m.length < 5) { reject(); continue; }
         if (touches) trim(m);   // trim() only acts when the first or last base of some genome is already marked
         if (m.length < 2 || n <= 1) { reject(); continue; }
@@ -492,20 +509,24 @@ bool Aligner::extend() {
         std::vector<Region> gen = regions;
         while (!gen.empty()) {
             stats.spec_rounds++;
-            wanted_.clear(); wanted_keys_.clear();
+            wanted_.clear(); wanted_entries_.clear();
+            const Arena<long>::Mark qmark = req_rows_.mark();
+            std::vector<Request> reqs;
             for (const Region& r : gen) {
                 int minsize = min_length(false, r.slength);
-                for (Request& q : chunk_requests(r, minsize)) {
-                    std::string key = key_of(q);
-                    if (cache_.count(key)) continue;
-                    if (wanted_keys_.emplace(std::move(key), (int)wanted_.size()).second) wanted_.push_back(std::move(q));
+                chunk_requests(r, minsize, &reqs);
+                for (Request& q : reqs) {
+                    if (cache_find(q)) continue;                       // known, or already wanted in this round
+                    wanted_entries_.push_back(cache_put(q, true));
+                    Request w = q;                                      // the cache entry owns a stable copy of the rows
+                    w.start = wanted_entries_.back()->start; w.len = wanted_entries_.back()->len;
+                    wanted_.push_back(w);
                 }
             }
-            std::vector<const Request*> ptrs;
-            for (const Request& q : wanted_) ptrs.push_back(&q);
+            req_rows_.rewind(qmark);
             std::vector<Raw> raws;
-            run_batch(ptrs, &raws);
-            for (size_t i = 0; i < wanted_.size(); i++) cache_.emplace(key_of(wanted_[i]), std::move(raws[i]));
+            run_batch(wanted_, &raws);
+            for (size_t i = 0; i < wanted_.size(); i++) { wanted_entries_[i]->raw = std::move(raws[i]); wanted_entries_[i]->pending = false; }
             std::vector<Region> next;
             std::vector<int> found;
             for (const Region& r : gen) {
@@ -529,7 +550,7 @@ bool Aligner::extend() {
         next_id_ = saved_id;
         mums = saved_mums;
         regions = saved_regions;
-        wanted_.clear(); wanted_keys_.clear();
+        wanted_.clear(); wanted_entries_.clear();
     }
     stats.t_sweep = now_s() - t0;
     double tr = now_s();

@@ -53,7 +53,14 @@ public:
     void init(size_t nbits_with_sentinel);
     bool get(long i) const { return (w_[(size_t)i >> 6] >> (i & 63)) & 1; }
     void prefetch(long i) const { if (i >= 0 && (size_t)i < nbits_) __builtin_prefetch(&w_[(size_t)i >> 6], 1, 1); }
-    void set_range(long a, long b);     // [a,b) := 1
+    void set_range(long a, long b) {    // [a,b) := 1
+        if (a >= 0 && b <= (long)nbits_ && a < b && ((size_t)a >> 6) == ((size_t)(b - 1) >> 6)) {   // inside one word: the common case
+            const size_t wi = (size_t)a >> 6;
+            const long span = b - a;
+            store(wi, w_[wi] | ((span == 64 ? ~0ull : ((1ull << span) - 1)) << (a & 63)));
+        } else set_range_slow(a, b);
+    }
+    void set_range_slow(long a, long b);
     void clear_range(long a, long b);   // [a,b) := 0
     long next_set(long from) const;     // smallest i >= from with bit set; the sentinel guarantees one for from <= n
     long prev_set(long from) const;     // largest i <= from with bit set, or -1
@@ -176,14 +183,22 @@ private:
     Arena<long> rows_;      // MUM and region coordinate rows
     Arena<int> irows_;      // MUM strand rows
     // --- finder plumbing -------------------------------------------------------------------------------------
-    struct Request { std::vector<int64_t> start, len; int32_t minsize; int64_t ref_ini; };
-    std::vector<Request> chunk_requests(const Region& r, int minsize) const;   // the p-chunk loop, :1519-1547
-    void run_batch(const std::vector<const Request*>& reqs, std::vector<Raw>* out);
-    // cache of raw results keyed by request coordinates (results are a pure function of them)
-    std::unordered_map<std::string, Raw> cache_;
-    static std::string key_of(const Request& q);
+    // one engine request = one reference chunk of one region; rows of n entries (the region's own rows when the
+    // region is a single unclamped chunk, else rows in req_rows_)
+    struct Request { const long* start; const long* len; int32_t minsize; long ref_ini; uint64_t hash; };
+    void chunk_requests(const Region& r, int minsize, std::vector<Request>* out);   // the p-chunk loop, :1519-1547
+    void run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out);
+    // cache of raw results keyed by request coordinates (results are a pure function of them); entries own a copy of
+    // the coordinates and are compared in full on a hash hit
+    struct CacheEntry { const long* start; const long* len; int32_t minsize; bool pending; Raw raw; };
+    std::unordered_multimap<uint64_t, CacheEntry> cache_;
+    Arena<long> cache_rows_, req_rows_;
+    CacheEntry* cache_find(const Request& q);
+    CacheEntry* cache_put(const Request& q, bool pending);
+    std::unordered_map<long, int> minlen_memo_[2];
+    std::vector<long> gsize_;
     // --- setMums1 ---------------------------------------------------------------------------------------------
-    int min_length(bool anchors, long slength) const;
+    int min_length(bool anchors, long slength);
     // finder for one region + validate(); `speculative`: a missing cache entry is recorded in `wanted_` and the
     // region is treated as yielding nothing instead of calling the GPU.
     void region_mums(const Region& r, bool anchors, std::vector<int>* accepted, bool speculative);
@@ -191,7 +206,7 @@ private:
     void trim(Mum& m) const;
     bool extend_pass(bool speculative);
     std::vector<Request> wanted_;
-    std::unordered_map<std::string, int> wanted_keys_;
+    std::vector<CacheEntry*> wanted_entries_;
 };
 
 // XMFA + log (writeOutput).  gap_note: set when at least one inter-MUM gap needed the (absent) MUSCLE aligner.
