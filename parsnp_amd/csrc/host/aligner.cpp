@@ -286,68 +286,156 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
     if (!speculative) stats.regions_processed++;
 }
 
-// Candidate -> MUM: bounds, reverse-strand coordinate flip, overlap trimming against the layout, reverse-strand
-// sequence check, layout marking (parsnp.cpp:1717-1841, TMum ctor TMum.cpp:13-72).
-void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted) {
+// rows of candidate c exactly as the reference derives them: DSP (:1671,:1681) with its bound test (:1723), then the
+// TMum constructor (TMum.cpp:25-60): forward = DSP-1, reverse = flipped against the WHOLE genome length even inside a
+// sub-region.  Returns false when the reference skips the candidate before constructing the TMum.
+bool Aligner::candidate_rows(const Region& r, const Request& q, const Raw& raw, size_t c, Mum& m, bool* ok, bool* any_reverse) const {
     const size_t nq = n - 1;
-    const size_t ncand = raw.k.size();
-    const std::vector<long>& gsize = gsize_;
+    const long lon = raw.lon[c];
     const unsigned long ref_ini = (unsigned long)q.ref_ini;
+    const int64_t* sp = &raw.sp[c * nq];
+    const uint8_t* fw = &raw.fwd[c * nq];
+    bool bad = false, good = true, rev = false;
+    for (size_t j = 0; j < n; j++) {
+        const unsigned long dsp = j == 0 ? (unsigned long)raw.k[c] + 1 + ref_ini : (unsigned long)sp[j - 1] + 1 + (unsigned long)r.start[j];
+        bad |= dsp - (unsigned long)r.start[j] > (unsigned long)(unsigned int)r.length[j];
+        const long startpos = (long)(dsp - 1);
+        const int f = j == 0 ? 1 : fw[j - 1];
+        const long st = f ? startpos : gsize_[j] - (startpos + lon);
+        m.fwd[j] = f; m.start[j] = st; m.end[j] = st + lon;
+        rev |= !f;
+        if (st + lon > gsize_[j] || st < 0) good = false;          // never for in-range candidates
+    }
+    m.length = lon;
+    *ok = good; *any_reverse = rev;
+    return !bad;
+}
+
+// the rest of the per-candidate block of setMums1 (:1781-1833): trim against the layout, length tests, reverse-strand
+// members must spell the reverse complement of the reference member (:1791-1825).  Does NOT mark the layout.
+bool Aligner::settle(Mum& m, bool touches, bool any_reverse) const {
+    if (m.length < 5) return false;
+    if (touches) trim(m);   // trim() only acts when the first or last base of some genome is already marked
+    if (m.length < 2 || n <= 1) return false;
+    if (!m.fwd[0]) return false;
+    if (any_reverse) {
+        const std::string& g0 = genomes[0].seq;
+        for (size_t j = 0; j < n; j++) {
+            if (m.fwd[j]) continue;
+            const std::string& gj = genomes[j].seq;
+            long l1 = m.start[j], l2 = m.length;
+            if (l1 > (long)gj.size() || m.start[0] > (long)g0.size()) fatal("MUM outside genome");
+            long have = std::min<long>(l2, (long)gj.size() - l1), have0 = std::min<long>(l2, (long)g0.size() - m.start[0]);
+            if (have != have0) return false;
+            for (long x = 0; x < have; x++) {
+                char cj = gj[(size_t)(l1 + have - 1 - x)], want;
+                switch (cj) { case 'A': want = 'T'; break; case 'C': want = 'G'; break; case 'G': want = 'C'; break;
+                              case 'T': want = 'A'; break; default: want = 'N'; }
+                if (g0[(size_t)(m.start[0] + x)] != want) return false;
+            }
+        }
+    }
+    return true;
+}
+
+// Candidate -> MUM, in candidate order (parsnp.cpp:1717-1841).
+void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted) {
+    const size_t ncand = raw.k.size();
+    const int threads = prm.cores > 1 ? prm.cores : 1;
+    static const size_t par_min = getenv("PARSNP_PARALLEL_MIN") ? (size_t)atol(getenv("PARSNP_PARALLEL_MIN")) : 4096;   // test hook
+    if (ncand >= par_min && threads > 1 && !layout[0].logging()) { validate_parallel(r, q, raw, accepted, threads); return; }
     for (size_t c = 0; c < ncand; c++) {
-        const long lon = raw.lon[c];
         Mum m;
-        m.id = next_id_++;
-        m.length = lon;
         const Arena<long>::Mark rmark = rows_.mark();
         const Arena<int>::Mark imark = irows_.mark();
         m.start = rows_.alloc(n); m.end = rows_.alloc(n); m.fwd = irows_.alloc(n);
-        auto reject = [&]() { rows_.rewind(rmark); irows_.rewind(imark); };
-        bool bad = false, ok = true, touches = false, any_reverse = false;
-        const int64_t* sp = &raw.sp[c * nq];
-        const uint8_t* fw = &raw.fwd[c * nq];
-        for (size_t j = 0; j < n; j++) {
-            // DSP of the reference (:1671,:1681) and its bound test (:1723)
-            const unsigned long dsp = j == 0 ? (unsigned long)raw.k[c] + 1 + ref_ini : (unsigned long)sp[j - 1] + 1 + (unsigned long)r.start[j];
-            bad |= dsp - (unsigned long)r.start[j] > (unsigned long)(unsigned int)r.length[j];
-            const long startpos = (long)(dsp - 1);
-            const int f = j == 0 ? 1 : fw[j - 1];
-            // reverse strand: flipped against the WHOLE genome length even inside a sub-region (TMum.cpp:33-35)
-            const long st = f ? startpos : gsize[j] - (startpos + lon);
-            m.fwd[j] = f; m.start[j] = st; m.end[j] = st + lon;
-            any_reverse |= !f;
-            if (st + lon > gsize[j] || st < 0) ok = false;          // never for in-range candidates
-            else if (lon > 0) touches |= layout[j].get(st) | layout[j].get(st + lon - 1);
-        }
-        if (bad) { reject(); next_id_--; continue; }   // the reference skips before constructing the TMum (no id consumed)
-        if (!ok || m.length < 5) { reject(); continue; }
-        if (touches) trim(m);   // trim() only acts when the first or last base of some genome is already marked
-        if (m.length < 2 || n <= 1) { reject(); continue; }
-        if (!m.fwd[0]) { reject(); continue; }
-        // reverse-strand members must spell the reverse complement of the reference member (:1791-1825)
-        bool mismatch = false;
-        if (any_reverse) {
-            const std::string& g0 = genomes[0].seq;
-            for (size_t j = 0; j < n && !mismatch; j++) {
-                if (m.fwd[j]) continue;
-                const std::string& gj = genomes[j].seq;
-                long l1 = m.start[j], l2 = m.length;
-                if (l1 > (long)gj.size() || m.start[0] > (long)g0.size()) fatal("MUM outside genome");
-                long have = std::min<long>(l2, (long)gj.size() - l1), have0 = std::min<long>(l2, (long)g0.size() - m.start[0]);
-                if (have != have0) { mismatch = true; break; }
-                for (long x = 0; x < have; x++) {
-                    char cj = gj[(size_t)(l1 + have - 1 - x)], want;
-                    switch (cj) { case 'A': want = 'T'; break; case 'C': want = 'G'; break; case 'G': want = 'C'; break;
-                                  case 'T': want = 'A'; break; default: want = 'N'; }
-                    if (g0[(size_t)(m.start[0] + x)] != want) { mismatch = true; break; }
-                }
-            }
-        }
-        if (mismatch) { reject(); continue; }
+        bool ok, any_reverse;
+        if (!candidate_rows(r, q, raw, c, m, &ok, &any_reverse)) { rows_.rewind(rmark); irows_.rewind(imark); continue; }
+        m.id = next_id_++;
+        bool touches = false;
+        if (ok && m.length > 0)
+            for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end[j] - 1);
+        if (!ok || !settle(m, touches, any_reverse)) { rows_.rewind(rmark); irows_.rewind(imark); continue; }
         for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end[j]);
         m.slength = r.slength;
         pool.push_back(m);
         accepted->push_back((int)pool.size() - 1);
     }
+}
+
+// The same result for a long candidate list (the anchor call), with the per-genome work spread over threads.
+// A candidate whose ranges touch nothing marked before it -- neither the layout nor an EARLIER candidate of this
+// list -- cannot be trimmed, and nothing it marks can be seen by such a candidate: these "clean" candidates are
+// settled and marked in parallel.  The others see exactly what the sequential loop would show them once the clean
+// ones are marked (a later clean candidate never overlaps them, or it would not be clean), and run through the
+// sequential path in their original order.
+void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted, int threads) {
+    const size_t ncand = raw.k.size();
+    long* srow = rows_.alloc(ncand * n); long* erow = rows_.alloc(ncand * n); int* frow = irows_.alloc(ncand * n);
+    std::vector<Mum> cand(ncand);
+    std::vector<uint8_t> state(ncand, 0);   // bit0 constructed, bit1 ok, bit2 any_reverse, bit3 dirty, bit4 accepted
+    const long nc = (long)ncand;
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (long c = 0; c < nc; c++) {
+        Mum& m = cand[(size_t)c];
+        m.start = srow + (size_t)c * n; m.end = erow + (size_t)c * n; m.fwd = frow + (size_t)c * n;
+        bool ok, rev;
+        if (candidate_rows(r, q, raw, (size_t)c, m, &ok, &rev)) state[(size_t)c] = 1 | (ok ? 2 : 0) | (rev ? 4 : 0);
+    }
+    // dirty = overlaps the layout or an earlier candidate in some genome (each thread owns whole genomes)
+    long maxlen = 0;
+    for (size_t j = 0; j < n; j++) maxlen = std::max(maxlen, gsize_[j]);
+#pragma omp parallel num_threads(threads)
+    {
+        Bitmap scratch;
+        scratch.init((size_t)maxlen + 1);
+#pragma omp for schedule(dynamic, 1)
+        for (long j = 0; j < (long)n; j++) {
+            for (size_t c = 0; c < ncand; c++) {
+                if ((state[c] & 3) != 3 || cand[c].length < 5) continue;        // never marks anything
+                const long a = cand[c].start[(size_t)j], b = cand[c].end[(size_t)j];
+                if (layout[(size_t)j].any_set(a, b) || scratch.any_set(a, b)) {
+                    uint8_t* sp = &state[c];
+                    __atomic_fetch_or(sp, (uint8_t)8, __ATOMIC_RELAXED);
+                }
+                scratch.set_range(a, b);
+            }
+            for (size_t c = 0; c < ncand; c++)
+                if ((state[c] & 3) == 3 && cand[c].length >= 5) scratch.clear_range(cand[c].start[(size_t)j], cand[c].end[(size_t)j]);
+        }
+    }
+    // clean candidates: settle in parallel (no trimming possible), then mark genome by genome
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (long c = 0; c < nc; c++) {
+        const uint8_t st = state[(size_t)c];
+        if ((st & 3) != 3 || (st & 8)) continue;
+        if (settle(cand[(size_t)c], false, (st & 4) != 0)) state[(size_t)c] |= 16;
+    }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (long j = 0; j < (long)n; j++)
+        for (size_t c = 0; c < ncand; c++)
+            if ((state[c] & 24) == 16) layout[(size_t)j].set_range(cand[c].start[(size_t)j], cand[c].end[(size_t)j]);
+    // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them
+    for (size_t c = 0; c < ncand; c++) {
+        const uint8_t st = state[c];
+        if (!(st & 1)) continue;
+        Mum& m = cand[c];
+        m.id = next_id_++;
+        bool acc = (st & 16) != 0;
+        if ((st & 2) && (st & 8)) {
+            bool touches = false;
+            if (m.length > 0)
+                for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end[j] - 1);
+            acc = settle(m, touches, (st & 4) != 0);
+            if (acc) for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end[j]);
+        }
+        if (!acc) continue;
+        m.slength = r.slength;
+        pool.push_back(m);
+        accepted->push_back((int)pool.size() - 1);
+        stats.parallel_dirty += (st & 8) ? 1 : 0;
+    }
+    stats.parallel_candidates += (long)ncand;
 }
 
 // Overlap trimming against already marked bases: from the left, then from the right, genome by genome; every trim

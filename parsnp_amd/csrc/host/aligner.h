@@ -67,6 +67,14 @@ public:
     size_t bits() const { return nbits_; }
     // undo log support (speculative replay): words changed since begin_log() are restored by rollback()
     void begin_log() { logging_ = true; log_.clear(); }
+    bool logging() const { return logging_; }
+    bool any_set(long a, long b) const {   // any marked base in [a,b)?
+        if (a < 0) a = 0;
+        if (b > (long)nbits_) b = (long)nbits_;
+        if (a >= b) return false;
+        long p = next_set(a);
+        return p < b;
+    }
     void rollback();
     void end_log() { logging_ = false; log_.clear(); }
 private:
@@ -145,7 +153,7 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     // device-side phase times (HIP events, pm_last_timing): summed over every engine call of the step, and of the
     // anchor call alone (the one launch that sees whole genomes)
     std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
-    long tie_fallbacks = 0, literal_iterations = 0;   // work-list ties between different regions (extend_pass)
+    long tie_fallbacks = 0, literal_iterations = 0, parallel_candidates = 0, parallel_dirty = 0;   // work-list ties between different regions (extend_pass)
     double t_validate = 0, t_neighbour = 0, t_key = 0, t_sweep = 0, t_replay = 0, t_sort = 0, t_unpack = 0;   // host split
 };
 
@@ -203,6 +211,9 @@ private:
     // region is treated as yielding nothing instead of calling the GPU.
     void region_mums(const Region& r, bool anchors, std::vector<int>* accepted, bool speculative);
     void validate(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted);
+    void validate_parallel(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted, int threads);
+    bool candidate_rows(const Region& r, const Request& q, const Raw& raw, size_t c, Mum& m, bool* ok, bool* any_reverse) const;
+    bool settle(Mum& m, bool touches, bool any_reverse) const;
     void trim(Mum& m) const;
     bool extend_pass(bool speculative);
     std::vector<Request> wanted_;

@@ -39,6 +39,9 @@ def test_synthetic(cpu_checkers, tmp_path, name, exact):
 
 
 def harsh_inputs(name, base):
+    if name in ("pop6x200k", "rearr6x300k"):
+        r, gs = synth.make(name)
+        return synth.write_set(os.path.join(base, "in"), r, gs) + ({},)
     if name == "messy":
         return synth.messy_set(os.path.join(base, "in")) + ({},)
     if name == "pchunk":
@@ -76,6 +79,21 @@ def test_literal_worklist_same_result(cpu_checkers, tmp_path, name):
     out = str(tmp_path / "out")
     env = dict(os.environ, PARSNP_FORCE_LITERAL_WORKLIST="1")
     rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, **kw)
+    assert rc == 0
+    assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["signature"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
+
+
+@pytest.mark.parametrize("name,par_min", [("poprearr10x400k", None), ("rearr6x300k", None), ("pop6x200k", "8"), ("messy", "2"), ("pchunk", "8")])
+def test_threaded_validation_same_result(cpu_checkers, tmp_path, name, par_min):
+    """cores > 1: long candidate lists are validated with the clean/dirty parallel scheme; the result must not change.
+    PARSNP_PARALLEL_MIN lowers the list-length threshold so that small sets (and the recursion's short lists) use it too."""
+    rp, qs, kw = harsh_inputs(name, str(tmp_path))
+    out = str(tmp_path / "out")
+    env = dict(os.environ)
+    if par_min:
+        env["PARSNP_PARALLEL_MIN"] = par_min
+    rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, threads=4, timing=str(tmp_path / "t.json"), **kw)
     assert rc == 0
     assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["signature"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
