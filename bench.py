@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--workload", default="bact200")
     ap.add_argument("--genomes", type=int, default=0, help="override the number of query genomes per partition")
     ap.add_argument("--cpu-sample", type=int, default=2, help="query genomes in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--host-threads", type=int, default=16, help="ini [LCB] cores: host threads for ingest, candidate validation, output")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
@@ -108,7 +109,7 @@ def main():
         out = os.path.join(workdir, "out")
         os.makedirs(out, exist_ok=True)
         ini = os.path.join(out, "parsnpAligner.ini")
-        open(ini, "w").write(driver.ini_text(rp, qs, out, threads=8))
+        open(ini, "w").write(driver.ini_text(rp, qs, out, threads=args.host_threads))
         # quiet: the reference's progress chatter goes to a file
         so, se = os.dup(1), os.dup(2)
         logf = os.open(os.path.join(out, "bench.log"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
@@ -165,7 +166,7 @@ def main():
                            % (args.workload, G, n_ref / 1e6, dict(bact200="population").get(args.workload, "synthetic"),
                               ", ".join("%s=%s" % (k, v) for k, v in sorted(kw.items()) if k not in ("n", "n_genomes")),
                               "" if world == 1 else "; one partition per rank, %d ranks" % world),
-                           "genomes_per_gpu": G, "genome_bp": n_ref, "parallelism": "partition-per-gpu x%d" % world},
+                           "genomes_per_gpu": G, "genome_bp": n_ref, "host_threads": args.host_threads, "parallelism": "partition-per-gpu x%d" % world},
                 "core_bp_aligned": core_bp_total,
                 "mums": rep["mums"], "anchors": rep["anchors"], "lcbs": rep["lcbs"],
                 "split_s": {"path": rep["path_s"], "anchor": rep["anchor_s"], "extend": rep["extend_s"], "lcb": rep["lcb_s"],

@@ -271,7 +271,16 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
         stats.t_key += now_s() - tk;
         if (!e || e->pending) {
             if (speculative) continue;     // the sweep only consumes what its batch computed
-            stats.cache_misses++;
+            if (speculation_ && remaining_ && (sweeps_ == 0 || misses_since_sweep_ >= 64)) {
+                std::vector<Region> rest;
+                rest.push_back(r);
+                remaining_(&rest);
+                sweeps_++; misses_since_sweep_ = 0;
+                speculate(std::move(rest));
+                e = cache_find(q);
+                if (e && !e->pending) { validate(r, q, e->raw, accepted); continue; }
+            }
+            stats.cache_misses++; misses_since_sweep_++;
             std::vector<Request> one{q};
             std::vector<Raw> raw;
             run_batch(one, &raw);
@@ -292,22 +301,32 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
 bool Aligner::candidate_rows(const Region& r, const Request& q, const Raw& raw, size_t c, Mum& m, bool* ok, bool* any_reverse) const {
     const size_t nq = n - 1;
     const long lon = raw.lon[c];
-    const unsigned long ref_ini = (unsigned long)q.ref_ini;
-    const int64_t* sp = &raw.sp[c * nq];
-    const uint8_t* fw = &raw.fwd[c * nq];
-    bool bad = false, good = true, rev = false;
-    for (size_t j = 0; j < n; j++) {
-        const unsigned long dsp = j == 0 ? (unsigned long)raw.k[c] + 1 + ref_ini : (unsigned long)sp[j - 1] + 1 + (unsigned long)r.start[j];
-        bad |= dsp - (unsigned long)r.start[j] > (unsigned long)(unsigned int)r.length[j];
-        const long startpos = (long)(dsp - 1);
-        const int f = j == 0 ? 1 : fw[j - 1];
-        const long st = f ? startpos : gsize_[j] - (startpos + lon);
-        m.fwd[j] = f; m.start[j] = st; m.end[j] = st + lon;
-        rev |= !f;
-        if (st + lon > gsize_[j] || st < 0) good = false;          // never for in-range candidates
+    const int64_t* __restrict sp = &raw.sp[c * nq];
+    const uint8_t* __restrict fw = &raw.fwd[c * nq];
+    const long* __restrict rstart = r.start;
+    const long* __restrict rlen = r.length;
+    const long* __restrict gs = gsize_.data();
+    long* __restrict ms = m.start; long* __restrict me = m.end; int* __restrict mf = m.fwd;
+    // genome 0: DSP = k + 1 + ini of the reference chunk, always forward
+    const unsigned long dsp0 = (unsigned long)raw.k[c] + 1 + (unsigned long)q.ref_ini;
+    unsigned long bad = dsp0 - (unsigned long)rstart[0] > (unsigned long)(unsigned int)rlen[0];
+    long st0 = (long)(dsp0 - 1);
+    ms[0] = st0; me[0] = st0 + lon; mf[0] = 1;
+    unsigned long notgood = (st0 + lon > gs[0]) | (st0 < 0), rev = 0;
+    for (size_t j = 1; j < n; j++) {
+        // dsp - r.start[j] == sp + 1 in unsigned arithmetic (:1723); startpos = dsp - 1
+        const unsigned long spj = (unsigned long)sp[j - 1];
+        bad |= spj + 1 > (unsigned long)(unsigned int)rlen[j];
+        const long startpos = (long)(spj + (unsigned long)rstart[j]);
+        const long f = fw[j - 1] != 0;
+        const long flipped = gs[j] - (startpos + lon);
+        const long st = f ? startpos : flipped;
+        ms[j] = st; me[j] = st + lon; mf[j] = (int)fw[j - 1];
+        rev |= (unsigned long)!f;
+        notgood |= (unsigned long)(st + lon > gs[j]) | (unsigned long)(st < 0);          // never for in-range candidates
     }
     m.length = lon;
-    *ok = good; *any_reverse = rev;
+    *ok = !notgood; *any_reverse = rev != 0;
     return !bad;
 }
 
@@ -344,6 +363,8 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
     const int threads = prm.cores > 1 ? prm.cores : 1;
     static const size_t par_min = getenv("PARSNP_PARALLEL_MIN") ? (size_t)atol(getenv("PARSNP_PARALLEL_MIN")) : 4096;   // test hook
     if (ncand >= par_min && threads > 1 && !layout[0].logging()) { validate_parallel(r, q, raw, accepted, threads); return; }
+    const double tser = now_s();
+    struct Rep { double t0; size_t n; ~Rep() { if (n > 1000 && getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[validate serial] %zu candidates %.4f s\n", n, now_s() - t0); } } rep_{tser, ncand};
     for (size_t c = 0; c < ncand; c++) {
         Mum m;
         const Arena<long>::Mark rmark = rows_.mark();
@@ -371,6 +392,9 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
 // sequential path in their original order.
 void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted, int threads) {
     const size_t ncand = raw.k.size();
+    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    double tp = now_s();
+    auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[validate_parallel] %-10s %.4f s\n", what, t - tp); tp = t; } };
     long* srow = rows_.alloc(ncand * n); long* erow = rows_.alloc(ncand * n); int* frow = irows_.alloc(ncand * n);
     std::vector<Mum> cand(ncand);
     std::vector<uint8_t> state(ncand, 0);   // bit0 constructed, bit1 ok, bit2 any_reverse, bit3 dirty, bit4 accepted
@@ -382,28 +406,25 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         bool ok, rev;
         if (candidate_rows(r, q, raw, (size_t)c, m, &ok, &rev)) state[(size_t)c] = 1 | (ok ? 2 : 0) | (rev ? 4 : 0);
     }
-    // dirty = overlaps the layout or an earlier candidate in some genome (each thread owns whole genomes)
-    long maxlen = 0;
-    for (size_t j = 0; j < n; j++) maxlen = std::max(maxlen, gsize_[j]);
-#pragma omp parallel num_threads(threads)
-    {
-        Bitmap scratch;
-        scratch.init((size_t)maxlen + 1);
-#pragma omp for schedule(dynamic, 1)
-        for (long j = 0; j < (long)n; j++) {
-            for (size_t c = 0; c < ncand; c++) {
-                if ((state[c] & 3) != 3 || cand[c].length < 5) continue;        // never marks anything
-                const long a = cand[c].start[(size_t)j], b = cand[c].end[(size_t)j];
-                if (layout[(size_t)j].any_set(a, b) || scratch.any_set(a, b)) {
-                    uint8_t* sp = &state[c];
-                    __atomic_fetch_or(sp, (uint8_t)8, __ATOMIC_RELAXED);
-                }
-                scratch.set_range(a, b);
-            }
-            for (size_t c = 0; c < ncand; c++)
-                if ((state[c] & 3) == 3 && cand[c].length >= 5) scratch.clear_range(cand[c].start[(size_t)j], cand[c].end[(size_t)j]);
+    lap("rows");
+    // dirty = overlaps the layout or an earlier candidate in some genome.  Each thread owns a stripe of genomes and
+    // walks the candidates in order (rows are candidate-major: a stripe reads contiguous entries of every row).
+    std::vector<Bitmap> scratch(n);
+    const int nstripes = threads;
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (int t = 0; t < nstripes; t++) {
+        const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
+        for (size_t j = j0; j < j1; j++) scratch[j].init_zero_lazy((size_t)gsize_[j] + 1);
+        for (size_t c = 0; c < ncand; c++) {
+            if ((state[c] & 3) != 3 || cand[c].length < 5) continue;        // never marks anything
+            const long* st = cand[c].start; const long lon = cand[c].length;
+            bool hit = false;
+            for (size_t j = j0; j < j1; j++) hit |= scratch[j].test_and_set(st[j], st[j] + lon) | layout[j].any_set(st[j], st[j] + lon);
+            if (hit) __atomic_fetch_or(&state[c], (uint8_t)8, __ATOMIC_RELAXED);
         }
+        for (size_t j = j0; j < j1; j++) scratch[j].release();
     }
+    lap("overlap");
     // clean candidates: settle in parallel (no trimming possible), then mark genome by genome
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (long c = 0; c < nc; c++) {
@@ -411,10 +432,14 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         if ((st & 3) != 3 || (st & 8)) continue;
         if (settle(cand[(size_t)c], false, (st & 4) != 0)) state[(size_t)c] |= 16;
     }
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-    for (long j = 0; j < (long)n; j++)
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (int t = 0; t < nstripes; t++) {
+        const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
         for (size_t c = 0; c < ncand; c++)
-            if ((state[c] & 24) == 16) layout[(size_t)j].set_range(cand[c].start[(size_t)j], cand[c].end[(size_t)j]);
+            if ((state[c] & 24) == 16)
+                for (size_t j = j0; j < j1; j++) layout[j].set_range(cand[c].start[j], cand[c].end[j]);
+    }
+    lap("settle+mark");
     // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them
     for (size_t c = 0; c < ncand; c++) {
         const uint8_t st = state[c];
@@ -436,6 +461,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         stats.parallel_dirty += (st & 8) ? 1 : 0;
     }
     stats.parallel_candidates += (long)ncand;
+    lap("sequential");
 }
 
 // Overlap trimming against already marked bases: from the left, then from the right, genome by genome; every trim
@@ -511,6 +537,10 @@ bool Aligner::extend_pass(bool speculative) {
     std::vector<int> found;
     std::vector<Handle> kids;
     const bool force_literal = getenv("PARSNP_FORCE_LITERAL_WORKLIST") != nullptr;   // debug: always the reference's vector + std::sort
+    remaining_ = [&](std::vector<Region>* out) {   // what is still on the work list, in order
+        if (literal) for (size_t x = head; x < work.size(); x++) out->push_back(rpool[(size_t)work[x].idx]);
+        else for (const auto& kv : uniq) out->push_back(rpool[(size_t)kv.second]);
+    };
     auto keys_unique = [&]() {
         for (size_t x = head; x + 1 < work.size(); x++) if (!(work[x].key < work[x + 1].key)) return false;
         return true;
@@ -578,72 +608,82 @@ bool Aligner::extend_pass(bool speculative) {
     return !mums.empty();
 }
 
+// Batch-compute the engine requests of `gen` that are not cached yet (one engine call).
+void Aligner::prefetch(const std::vector<Region>& gen) {
+    wanted_.clear(); wanted_entries_.clear();
+    const Arena<long>::Mark qmark = req_rows_.mark();
+    std::vector<Request> reqs;
+    for (const Region& r : gen) {
+        int minsize = min_length(false, r.slength);
+        chunk_requests(r, minsize, &reqs);
+        for (Request& q : reqs) {
+            if (cache_find(q)) continue;                       // known, or already wanted in this round
+            wanted_entries_.push_back(cache_put(q, true));
+            Request w = q;                                      // the cache entry owns a stable copy of the rows
+            w.start = wanted_entries_.back()->start; w.len = wanted_entries_.back()->len;
+            wanted_.push_back(w);
+        }
+    }
+    req_rows_.rewind(qmark);
+    std::vector<Raw> raws;
+    run_batch(wanted_, &raws);
+    for (size_t i = 0; i < wanted_.size(); i++) { wanted_entries_[i]->raw = std::move(raws[i]); wanted_entries_[i]->pending = false; }
+    wanted_.clear(); wanted_entries_.clear();
+}
+
+// Speculative breadth-first sweep from the regions in `gen`: discover the regions the exact in-order replay will ask
+// for, generation by generation, and compute each generation in ONE batched engine call.  Everything it does to the
+// layout, the MUM pool and the arenas is undone afterwards; only the cache of raw engine results (a pure function of
+// the request coordinates) survives.  The reference's processing order is observable, so the replay stays
+// authoritative; a request the sweep did not predict is computed on demand there.
+void Aligner::speculate(std::vector<Region> gen) {
+    double t0 = now_s();
+    for (size_t i = 0; i < n; i++) layout[i].begin_log();
+    const std::vector<int> saved_mums = mums;
+    const size_t saved_pool = pool.size();
+    const long saved_id = next_id_;
+    const Arena<long>::Mark rmark = rows_.mark();
+    const Arena<int>::Mark imark = irows_.mark();
+    while (!gen.empty()) {
+        stats.spec_rounds++;
+        prefetch(gen);
+        std::vector<Region> next;
+        std::vector<int> found;
+        for (const Region& r : gen) {
+            found.clear();
+            region_mums(r, false, &found, true);
+            for (size_t i = 0; i < found.size(); i++) {
+                Region a = neighbour_region(pool[(size_t)found[i]], true), b = neighbour_region(pool[(size_t)found[i]], false);
+                if (a.slength > prm.q) next.push_back(a);
+                if (b.slength > prm.q) next.push_back(b);
+            }
+        }
+        // same clean-up the reference applies to its work list: order by reference start, drop adjacent duplicates
+        std::stable_sort(next.begin(), next.end(), [](const Region& x, const Region& y) { return x.start[0] < y.start[0]; });
+        gen.clear();
+        for (Region& r : next)
+            if (gen.empty() || !gen.back().same_as(r, n)) gen.push_back(r);
+    }
+    for (size_t i = 0; i < n; i++) { layout[i].rollback(); layout[i].end_log(); }
+    pool.resize(saved_pool);
+    rows_.rewind(rmark); irows_.rewind(imark);
+    next_id_ = saved_id;
+    mums = saved_mums;
+    stats.t_sweep += now_s() - t0;
+}
+
+// Recursive extension.  Every seed region is known before the loop starts, so their engine results come from one
+// batched call.  Children only exist once their parent has been processed in order; the first time the replay needs one
+// that is not cached, a speculative sweep over everything still on the work list predicts and batches the rest.
 bool Aligner::extend() {
     double t0 = now_s();
-    if (getenv("PARSNP_NO_SPECULATION") == nullptr) {
-        // Speculative breadth-first sweep: discover the regions the exact replay below will ask for, generation by
-        // generation, and compute each generation in ONE batched engine call.  Everything it does to the layout, the
-        // MUM pool and the work list is undone afterwards; only the cache of raw engine results (a pure function of
-        // the request coordinates) survives.  The reference's processing order is observable, so the
-        // authoritative pass is the in-order replay that follows; a request the sweep did not predict is computed on
-        // demand there.
-        for (size_t i = 0; i < n; i++) layout[i].begin_log();
-        const std::vector<Region> saved_regions = regions;
-        const std::vector<int> saved_mums = mums;
-        const size_t saved_pool = pool.size();
-        const long saved_id = next_id_;
-        const Arena<long>::Mark rmark = rows_.mark();
-        const Arena<int>::Mark imark = irows_.mark();
-        std::vector<Region> gen = regions;
-        while (!gen.empty()) {
-            stats.spec_rounds++;
-            wanted_.clear(); wanted_entries_.clear();
-            const Arena<long>::Mark qmark = req_rows_.mark();
-            std::vector<Request> reqs;
-            for (const Region& r : gen) {
-                int minsize = min_length(false, r.slength);
-                chunk_requests(r, minsize, &reqs);
-                for (Request& q : reqs) {
-                    if (cache_find(q)) continue;                       // known, or already wanted in this round
-                    wanted_entries_.push_back(cache_put(q, true));
-                    Request w = q;                                      // the cache entry owns a stable copy of the rows
-                    w.start = wanted_entries_.back()->start; w.len = wanted_entries_.back()->len;
-                    wanted_.push_back(w);
-                }
-            }
-            req_rows_.rewind(qmark);
-            std::vector<Raw> raws;
-            run_batch(wanted_, &raws);
-            for (size_t i = 0; i < wanted_.size(); i++) { wanted_entries_[i]->raw = std::move(raws[i]); wanted_entries_[i]->pending = false; }
-            std::vector<Region> next;
-            std::vector<int> found;
-            for (const Region& r : gen) {
-                found.clear();
-                region_mums(r, false, &found, true);
-                for (size_t i = 0; i < found.size(); i++) {
-                    Region a = neighbour_region(pool[(size_t)found[i]], true), b = neighbour_region(pool[(size_t)found[i]], false);
-                    if (a.slength > prm.q) next.push_back(a);
-                    if (b.slength > prm.q) next.push_back(b);
-                }
-            }
-            // same clean-up the reference applies to its work list: order by reference start, drop adjacent duplicates
-            std::stable_sort(next.begin(), next.end(), [](const Region& x, const Region& y) { return x.start[0] < y.start[0]; });
-            gen.clear();
-            for (Region& r : next)
-                if (gen.empty() || !gen.back().same_as(r, n)) gen.push_back(r);
-        }
-        for (size_t i = 0; i < n; i++) { layout[i].rollback(); layout[i].end_log(); }
-        pool.resize(saved_pool);
-        rows_.rewind(rmark); irows_.rewind(imark);
-        next_id_ = saved_id;
-        mums = saved_mums;
-        regions = saved_regions;
-        wanted_.clear(); wanted_entries_.clear();
-    }
-    stats.t_sweep = now_s() - t0;
+    speculation_ = getenv("PARSNP_NO_SPECULATION") == nullptr;
+    sweeps_ = 0; misses_since_sweep_ = 0;
+    if (speculation_) prefetch(regions);
     double tr = now_s();
     bool any = extend_pass(false);
-    stats.t_replay = now_s() - tr;
+    stats.t_replay = now_s() - tr - stats.t_sweep;
+    remaining_ = nullptr;
     cache_.clear();
     stats.extend_s = now_s() - t0;
     return any;

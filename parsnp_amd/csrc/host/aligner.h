@@ -20,6 +20,7 @@
 #pragma once
 #include <cstdint>
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -51,6 +52,23 @@ bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* o
 class Bitmap {
 public:
     void init(size_t nbits_with_sentinel);
+    void init_zero_lazy(size_t nbits) { nbits_ = nbits; w_.assign((nbits + 63) / 64 + 1, 0); }   // scratch: no sentinel
+    void release() { std::vector<uint64_t>().swap(w_); nbits_ = 0; }
+    bool test_and_set(long a, long b) {    // [a,b) := 1; was any of it marked?  (scratch use: no undo log)
+        if (a < 0) a = 0;
+        if (b > (long)nbits_) b = (long)nbits_;
+        bool hit = false;
+        while (a < b) {
+            const size_t wi = (size_t)a >> 6;
+            const int lo = (int)(a & 63);
+            const long span = std::min<long>(64 - lo, b - a);
+            const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
+            hit |= (w_[wi] & mask) != 0;
+            w_[wi] |= mask;
+            a += span;
+        }
+        return hit;
+    }
     bool get(long i) const { return (w_[(size_t)i >> 6] >> (i & 63)) & 1; }
     void prefetch(long i) const { if (i >= 0 && (size_t)i < nbits_) __builtin_prefetch(&w_[(size_t)i >> 6], 1, 1); }
     void set_range(long a, long b) {    // [a,b) := 1
@@ -68,12 +86,16 @@ public:
     // undo log support (speculative replay): words changed since begin_log() are restored by rollback()
     void begin_log() { logging_ = true; log_.clear(); }
     bool logging() const { return logging_; }
-    bool any_set(long a, long b) const {   // any marked base in [a,b)?
+    bool any_set(long a, long b) const {   // any marked base in [a,b)?  (touches only the words of the range)
         if (a < 0) a = 0;
         if (b > (long)nbits_) b = (long)nbits_;
         if (a >= b) return false;
-        long p = next_set(a);
-        return p < b;
+        size_t wa = (size_t)a >> 6, wb = (size_t)(b - 1) >> 6;
+        uint64_t first = ~0ull << (a & 63), last = ((b & 63) == 0) ? ~0ull : ((1ull << (b & 63)) - 1);
+        if (wa == wb) return (w_[wa] & first & last) != 0;
+        if (w_[wa] & first) return true;
+        for (size_t w = wa + 1; w < wb; w++) if (w_[w]) return true;
+        return (w_[wb] & last) != 0;
     }
     void rollback();
     void end_log() { logging_ = false; log_.clear(); }
@@ -216,6 +238,12 @@ private:
     bool settle(Mum& m, bool touches, bool any_reverse) const;
     void trim(Mum& m) const;
     bool extend_pass(bool speculative);
+    void prefetch(const std::vector<Region>& gen);
+    void speculate(std::vector<Region> gen);
+    std::function<void(std::vector<Region>*)> remaining_;
+    bool speculation_ = true;
+    int sweeps_ = 0;
+    long misses_since_sweep_ = 0;
     std::vector<Request> wanted_;
     std::vector<CacheEntry*> wanted_entries_;
 };

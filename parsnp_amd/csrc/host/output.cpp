@@ -111,6 +111,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     for (char c : notes) if (c) *gap_note = true;
 
     int prev_end = 0;
+    string rec;
     for (size_t z = 0; z < a.lcbs.size(); z++) {
         Lcb ct = a.lcbs[z];
         vector<string>& row = rows[z];
@@ -172,19 +173,19 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
             else if (hdr != "s1") offset = -1;
             if (!first.fwd[i]) hd << "- cluster" << b << " " << hdr << ":p" << (ct.start[i] - seqstart) + 1 + first.length + offset;
             else hd << "+ cluster" << b << " " << hdr << ":p" << (ct.start[i] - seqstart) + 1 + offset;
-            xmfa << hd.str() << endl;
-            if (prm.recomb_filter) block << hd.str() << endl;
+            // one record, wrapped at 80 columns, assembled in memory and written at once (same bytes as line-by-line)
             const string& s = row[i];
+            rec.clear();
+            rec.reserve(hd.str().size() + s.size() + s.size() / 80 + 8);
+            rec += hd.str(); rec += '\n';
             size_t k = 0;
             const size_t width = 80;
-            for (; k + width < s.size(); k += width) {
-                xmfa << s.substr(k, width) << endl;
-                if (prm.recomb_filter) block << s.substr(k, width) << endl;
-            }
-            xmfa << s.substr(k) << endl;
-            if (prm.recomb_filter) block << s.substr(k) << endl;
+            for (; k + width < s.size(); k += width) { rec.append(s, k, width); rec += '\n'; }
+            rec.append(s, k, string::npos); rec += '\n';
+            xmfa.write(rec.data(), (std::streamsize)rec.size());
+            if (prm.recomb_filter) block.write(rec.data(), (std::streamsize)rec.size());
         }
-        xmfa << "=" << endl;
+        xmfa << "=\n";
     }
 
     // ---- log (:1082-1190); stream flags are sticky exactly as in the reference

@@ -45,6 +45,6 @@ def emu():
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-DPM_CHUNK=5", src, "-o", EMU_LIB], check=True)
     hsrc = [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".cpp") and f != "capi.cpp"]
     if not _newer(EMU_CORE, hsrc + [os.path.join(host, f) for f in os.listdir(host)] + [EMU_LIB]):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fopenmp", "-w"] + hsrc + ["-L" + os.path.dirname(EMU_LIB), "-lpm_emu",
+        subprocess.run(["g++", "-O3", "-mavx2", "-std=c++17", "-fopenmp", "-w"] + hsrc + ["-L" + os.path.dirname(EMU_LIB), "-lpm_emu",
                         "-Wl,-rpath,$ORIGIN", "-o", EMU_CORE], check=True)
     return EMU_LIB, EMU_CORE
