@@ -87,11 +87,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU path); run it through gpurun")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())   # (more ranks than GPUs only happens in smoke tests of this script)
     dist = None
+    tdev = "cuda"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")   # RCCL
+        if torch.cuda.device_count() >= world:
+            dist.init_process_group("nccl")   # RCCL, one rank per GPU
+        else:                                  # smoke test of this script on a box with fewer GPUs than ranks
+            dist.init_process_group("gloo")
+            tdev = "cpu"
 
     def barrier():
         if dist is not None:
@@ -131,10 +136,10 @@ def main():
         finally:
             os.dup2(so, 1); os.dup2(se, 2)
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-            cb = torch.tensor([reports[-1]["core_bp"]], dtype=torch.float64, device="cuda")
+            cb = torch.tensor([reports[-1]["core_bp"]], dtype=torch.float64, device=tdev)
             dist.all_reduce(cb, op=dist.ReduceOp.SUM)
             core_bp_total = int(cb.item())
         else:
@@ -153,10 +158,16 @@ def main():
             dom = max(kernels, key=kernels.get) if kernels else None
             b_alg = m_avg / 4 + 16 * m_avg + 16 * n_ref          # bytes per query genome
             roof = None
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01", "traffic_seed_extend.json")
+            if dom == "seed_extend" and args.workload == "bact200" and G == 200 and os.path.exists(tpath):
+                # HBM bytes of this kernel's anchor launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) on this
+                # exact workload; see the file for provenance and the (un)correction applied
+                traffic = json.load(open(tpath))["hbm_bytes"]
             if dom:
                 gbs = b_alg * G / (kernels[dom] * 1e-3) / 1e9
                 roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "launch_ms": round(kernels[dom], 4),
+                        "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "launch_ms": round(kernels[dom], 4),
                         "alg_bytes_per_launch": int(b_alg * G)}
             line = {
                 "metric": "genomes/sec (MUM+LCB end-to-end)", "value": round(value, 4), "unit": "genomes/s", "n_gpus": world,

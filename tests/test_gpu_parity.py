@@ -204,3 +204,19 @@ def test_parsnp_core_vs_reference_binary_fresh_input(libs, tmp_path):
     a, b = str(tmp_path / "ref" / "parsnpAligner.xmfa"), str(tmp_path / "hip" / "parsnpAligner.xmfa")
     assert xmfa_util.mum_lcb_signature(a) == xmfa_util.mum_lcb_signature(b)
     assert xmfa_util.log_counters(str(tmp_path / "ref" / "parsnpAligner.log")) == xmfa_util.log_counters(str(tmp_path / "hip" / "parsnpAligner.log"))
+
+
+def test_bench_two_ranks_smoke(libs, tmp_path):
+    """bench.py's multi-rank path (barrier, max-over-ranks, aggregate value) with 2 ranks; on a 1-GPU box the ranks share
+    the GPU and rendezvous over gloo, on a multi-GPU node the same command uses RCCL with one GPU per rank"""
+    import subprocess, sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "pop6x200k", "--cpu-sample", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["genomes_per_gpu"] == 6
+    assert abs(d["value"] - 2 * 6 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.02
+    assert d["roofline"]["kernel"] and d["mums"] > 2000
