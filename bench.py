@@ -87,7 +87,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU path); run it through gpurun")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())   # (more ranks than GPUs only happens in smoke tests of this script)
+    dev = local_rank % torch.cuda.device_count()   # (more ranks than GPUs only happens in smoke tests of this script)
+    torch.cuda.set_device(dev)
+    # torch ships its own HIP runtime; the engine links the system one, whose "current device" torch cannot set:
+    # tell the engine which GPU this rank owns
+    os.environ["PARSNP_DEVICE"] = str(dev)
     dist = None
     tdev = "cuda"
     if world > 1:

@@ -2,6 +2,7 @@
 // One HIP stream per session; every kernel of kernels.h is launched as 256-thread workgroups (4 wavefronts) with
 // one functor call per thread; radix sort / exclusive scan are rocPRIM device primitives on the same stream.
 // Phase timing uses HIP events recorded on that stream (pm_last_timing).
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -115,6 +116,10 @@ static PmBackend* pm_backend_open(int device, std::string* err) {
     if (e != hipSuccess || count == 0) {
         *err = std::string("no HIP device available (") + (e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + "); this engine has no CPU path";
         return nullptr;
+    }
+    if (device < 0) {   // PARSNP_DEVICE: the GPU of this process when the caller cannot pass one (one process per GPU)
+        const char* e = getenv("PARSNP_DEVICE");
+        if (e && *e) device = atoi(e);
     }
     if (device >= 0) {
         if (device >= count || hipSetDevice(device) != hipSuccess) { *err = "cannot select the requested HIP device"; return nullptr; }
