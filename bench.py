@@ -69,6 +69,24 @@ def cpu_baseline(workdir, rp, qs, sample_queries):
                       "1-s log timers = %.0f s, whole process %.1f s; host has %d cores" % (sample_queries, path_s, wall, os.cpu_count())}
 
 
+def exchange_intervals(torch, dist, tdev, intervals):
+    """all-gather the per-rank [start,end] lists (padded to the longest) and intersect them -> bases aligned in every partition"""
+    from parsnp_amd.partition_run import intersect
+    world = dist.get_world_size()
+    mine = torch.tensor(intervals if intervals else [[0, -1]], dtype=torch.int64, device=tdev).reshape(-1, 2)
+    count = torch.tensor([mine.shape[0]], dtype=torch.int64, device=tdev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count)
+    longest = int(max(int(c.item()) for c in counts))
+    padded = torch.full((longest, 2), -1, dtype=torch.int64, device=tdev)
+    padded[:, 0] = 0
+    padded[:mine.shape[0]] = mine
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded)
+    lists = [[(int(a), int(b)) for a, b in g[:int(c.item())].cpu().tolist() if b >= a] for g, c in zip(gathered, counts)]
+    return sum(b - a + 1 for a, b in intersect(lists))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +147,16 @@ def main():
                 run.step()
             barrier()
             t0 = time.perf_counter()
-            reports = [run.step() for _ in range(args.steps)]
+            reports = []
+            merged_bp = None
+            for _ in range(args.steps):
+                rep = run.step()
+                if dist is not None:
+                    # partition mode's exchange step: every rank's LCB reference intervals are all-gathered (RCCL) and
+                    # intersected -- the positions aligned in EVERY partition (partition.py:35-61, 539-583)
+                    merged_bp = exchange_intervals(torch, dist, tdev, rep["lcb_ref_intervals"])
+                rep.pop("lcb_ref_intervals", None)
+                reports.append(rep)
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
             barrier()
@@ -183,6 +210,7 @@ def main():
                               "" if world == 1 else "; one partition per rank, %d ranks" % world),
                            "genomes_per_gpu": G, "genome_bp": n_ref, "host_threads": args.host_threads, "parallelism": "partition-per-gpu x%d" % world},
                 "core_bp_aligned": core_bp_total,
+                "core_bp_in_every_partition": merged_bp,
                 "mums": rep["mums"], "anchors": rep["anchors"], "lcbs": rep["lcbs"],
                 "split_s": {"path": rep["path_s"], "anchor": rep["anchor_s"], "extend": rep["extend_s"], "lcb": rep["lcb_s"],
                             "engine_calls_wall": rep["finder_s"], "ingest": rep["ingest_s"], "upload": rep["upload_s"],

@@ -41,7 +41,16 @@ const char* pc_step(pc_run* r) {
         for (size_t i = 0; i < v.size(); i++) o << (i ? ", " : "") << "\"" << v[i].first << "\": " << v[i].second;
         o << "}";
     }
-    o << "}";
+    // reference interval of every real LCB, 1-based inclusive as the XMFA prints it ('> 1:a-b'): the unit that
+    // partition mode intersects across partitions (partition.py:35-61)
+    o << ", \"lcb_ref_intervals\": [";
+    bool first = true;
+    for (const Lcb& c : r->run.align->lcbs) {
+        if (c.type != 1 || c.mums.empty()) continue;
+        o << (first ? "" : ", ") << "[" << c.start[0] + 1 << ", " << c.end[0] << "]";
+        first = false;
+    }
+    o << "]}";
     r->json = o.str();
     return r->json.c_str();
 }

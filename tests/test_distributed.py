@@ -75,3 +75,29 @@ def test_two_ranks_gloo(cpu_checkers, tmp_path):
     assert len(r0["intersection"]) >= 1
     for a, b in zip(single["partitions"], r0["partitions"]):
         assert xmfa_util.md5(os.path.join(a["dir"], "parsnpAligner.xmfa")) == xmfa_util.md5(os.path.join(b["dir"], "parsnpAligner.xmfa"))
+
+
+EXCHANGE = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from bench import exchange_intervals
+dist.init_process_group("gloo")
+r = dist.get_rank()
+iv = [[1, 100], [200, 300]] if r == 0 else [[50, 250], [260, 270], [400, 500]]
+got = exchange_intervals(torch, dist, "cpu", iv)
+assert got == 113, got
+assert exchange_intervals(torch, dist, "cpu", [] if r == 0 else iv) == 0
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_bench_interval_exchange_two_ranks(tmp_path):
+    """bench.py's N>1 exchange step (all-gather of ragged LCB interval lists + intersection) on gloo"""
+    w = tmp_path / "ex.py"
+    w.write_text(EXCHANGE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29563", str(w), ROOT]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]

@@ -220,3 +220,4 @@ def test_bench_two_ranks_smoke(libs, tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["genomes_per_gpu"] == 6
     assert abs(d["value"] - 2 * 6 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.02
     assert d["roofline"]["kernel"] and d["mums"] > 2000
+    assert 0 < d["core_bp_in_every_partition"] <= d["core_bp_aligned"] // 2 + 1000
