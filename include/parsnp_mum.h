@@ -36,6 +36,19 @@ const char* pm_provider(void);
  * src/parsnp.cpp:1540-1561: regions are addressed by (start,len) into these resident copies.
  * device < 0 selects the current HIP device. */
 int pm_session_create(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens);
+/* Sharded run over the GPUs of one node: rank r of `world` keeps the reference and a contiguous block of
+ * the query genomes (block r of world equal blocks of genomes 1..n-1, in ini order) resident on its GPU; seqs[] of the
+ * other genomes is not read.  Every rank makes the same sequence of pm_multi_mum_batch / pm_mumi_coverage calls with
+ * the same arguments and receives the same results.  Per batch the engine exchanges
+ *   (1) Master.EP, reduced with min over the ranks           (allreduce_min, one int32 per reference position), and
+ *   (2) the per-genome (EP,UP,SP) columns at the candidates  (allgather of equal-size blocks),
+ * through the two callbacks (host buffers; 0 = success), which the embedding process implements with
+ * torch.distributed -- RCCL over xGMI on the GPUs, gloo in the CPU tests.  The strand/UP fold then runs over all
+ * genomes in ini order on every rank, so results are bit-identical to the unsharded run. */
+typedef int (*pm_allreduce_min_i32_fn)(void* ctx, int32_t* buf, int64_t count);
+typedef int (*pm_allgather_fn)(void* ctx, const void* send, int64_t send_bytes, void* recv /* world * send_bytes */);
+int pm_session_create_sharded(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens,
+                              int rank, int world, pm_allreduce_min_i32_fn allreduce_min, pm_allgather_fn allgather, void* ctx);
 void pm_session_destroy(pm_session* s);
 int pm_session_genomes(const pm_session* s);
 

@@ -25,6 +25,12 @@ int pm_session_create(pm_session** out, int device, int n, const uint8_t* const*
     }
     *out = s; return PM_OK;
 }
+int pm_session_create_sharded(pm_session** out, int device, int n, const uint8_t* const* seqs, const int64_t* lens, int rank, int world,
+                              pm_allreduce_min_i32_fn ar, pm_allgather_fn ag, void* ctx) {
+    (void)rank; (void)ar; (void)ag; (void)ctx;
+    if (world != 1) { g_err = "the CPU checker is not sharded"; return PM_EINVAL; }
+    return pm_session_create(out, device, n, seqs, lens);
+}
 void pm_session_destroy(pm_session* s) { if (!s) return; for (int i = 0; i < s->n; i++) free(s->seq[i]); free(s->seq); free(s->len); free(s); }
 int pm_session_genomes(const pm_session* s) { return s->n; }
 

@@ -25,7 +25,7 @@ extern "C" {
 const char* pm_last_error(void) { return g_pm_error.c_str(); }
 const char* pm_provider(void) { return pm_backend_name; }
 
-int pm_session_create(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens) {
+static int session_create(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens, const pm::Collectives* coll) {
     if (!out || n_genomes < 1 || !seqs || !lens) return fail(PM_EINVAL, "bad argument");
     try {
         std::unique_ptr<pm_session> s(new pm_session);
@@ -33,12 +33,23 @@ int pm_session_create(pm_session** out, int device, int n_genomes, const uint8_t
         s->backend.reset(pm_backend_open(device, &err));
         if (!s->backend) return fail(PM_ENODEV, err);
         s->engine.reset(new pm::Engine<PmBackend>(*s->backend));
+        if (coll) s->engine->set_shard(*coll);
         int rc = s->engine->load_genomes(n_genomes, seqs, lens);
         if (rc) return fail(rc, s->engine->error);
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
         *out = s.release();
         return PM_OK;
     } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed"); }
+}
+int pm_session_create(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens) {
+    return session_create(out, device, n_genomes, seqs, lens, nullptr);
+}
+int pm_session_create_sharded(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens, int rank,
+                              int world, pm_allreduce_min_i32_fn allreduce_min, pm_allgather_fn allgather, void* ctx) {
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && (!allreduce_min || !allgather))) return fail(PM_EINVAL, "bad shard description");
+    pm::Collectives c;
+    c.rank = rank; c.world = world; c.allreduce_min_i32 = allreduce_min; c.allgather = allgather; c.ctx = ctx;
+    return session_create(out, device, n_genomes, seqs, lens, &c);
 }
 void pm_session_destroy(pm_session* s) { delete s; }
 int pm_session_genomes(const pm_session* s) { return s ? s->engine->ngen : 0; }

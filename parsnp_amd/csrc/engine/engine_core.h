@@ -25,6 +25,16 @@ struct BatchResult {
 
 struct PhaseTime { const char* name; float ms; };
 
+// Sharded run: the query genomes are split into contiguous blocks, one per rank/GPU; every rank holds the
+// reference.  The two exchange steps of a batch go through these callbacks (host buffers; the embedding process
+// implements them with torch.distributed -- RCCL on GPUs, gloo in tests).  Return 0 on success.
+struct Collectives {
+    int rank = 0, world = 1;
+    int (*allreduce_min_i32)(void* ctx, int32_t* buf, int64_t count) = nullptr;
+    int (*allgather)(void* ctx, const void* send, int64_t send_bytes, void* recv) = nullptr;   // recv: world * send_bytes
+    void* ctx = nullptr;
+};
+
 inline int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) b++; return b; }
 
 template <class B>
@@ -39,15 +49,27 @@ public:
 
     int ngen = 0;
     std::vector<int64_t> glen_h;
+    Collectives coll;                 // world == 1: not sharded
+    int g_first = 1, g_last = 1;      // query genomes [g_first, g_last) are resident on this GPU
+    void set_shard(const Collectives& c) { coll = c; }
+    // contiguous split of the n-1 query genomes over the ranks
+    static void shard_range(int n, int rank, int world, int* first, int* last) {
+        int q = n - 1;
+        *first = 1 + (int)((int64_t)q * rank / world);
+        *last = 1 + (int)((int64_t)q * (rank + 1) / world);
+    }
 
     // ---- genomes -> packed strands in device memory
     int load_genomes(int n, const uint8_t* const* seqs, const int64_t* lens) {
         ngen = n;
         glen_h.assign(lens, lens + n);
+        shard_range(n, coll.rank, coll.world, &g_first, &g_last);
+        auto resident = [&](int g) { return g == 0 || (g >= g_first && g < g_last); };
         std::vector<int64_t> goff(2 * (size_t)n);
         int64_t words = 2;                       // leading guard (64 bases)
         int64_t maxlen = 0;
         for (int g = 0; g < n; g++) {
+            if (!resident(g)) { goff[2 * (size_t)g] = goff[2 * (size_t)g + 1] = 64; continue; }   // never read
             maxlen = std::max(maxlen, lens[g]);
             for (int s = 0; s < 2; s++) {
                 goff[2 * (size_t)g + s] = words * 32;
@@ -65,7 +87,7 @@ public:
         be.h2d(d_goff, goff.data(), sizeof(int64_t) * goff.size());
         be.h2d(d_glen, lens, sizeof(int64_t) * (size_t)n);
         for (int g = 0; g < n; g++) {
-            if (lens[g] == 0) continue;
+            if (lens[g] == 0 || !resident(g)) continue;
             be.h2d(stage, seqs[g], (size_t)lens[g]);
             for (int s = 0; s < 2; s++)
                 be.launch("pack", (lens[g] + 31) / 32, PackStrand{stage, lens[g], s, blk, goff[2 * (size_t)g + s] / 32});
@@ -146,7 +168,7 @@ public:
         // -- work units
         be.mark("units");
         ensure(d_ucount, (size_t)npairs + 1); ensure(d_uoff, (size_t)npairs + 1);
-        be.launch("count_units", npairs, CountUnits{d_R.p, d_lens.p, ngen, d_ucount.p});
+        be.launch("count_units", npairs, CountUnits{d_R.p, d_lens.p, ngen, d_ucount.p, g_first, g_last});
         be.memset(d_ucount.p + npairs, 0, 8);
         be.exclusive_scan(d_ucount.p, d_uoff.p, (size_t)npairs + 1);
         int64_t nunits = 0;
@@ -216,6 +238,17 @@ public:
             be.launch("mumi_coverage", npairs, MumiCoverage{d_R.p, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, ngen, d_cov.p});
             mumi_covered.resize((size_t)npairs);
             be.d2h(mumi_covered.data(), d_cov.p, 8 * (size_t)npairs);
+            if (coll.world > 1) {   // every rank computed its own genome block: gather the blocks
+                int widest = 0;
+                for (int r = 0; r < coll.world; r++) { int a, b; shard_range(ngen, r, coll.world, &a, &b); widest = std::max(widest, b - a); }
+                std::vector<int64_t> send((size_t)std::max(widest, 1), 0), recv((size_t)std::max(widest, 1) * (size_t)coll.world);
+                for (int g = g_first; g < g_last; g++) send[(size_t)(g - g_first)] = mumi_covered[(size_t)(g - 1)];
+                if (coll.allgather(coll.ctx, send.data(), (int64_t)(8 * send.size()), recv.data())) { error = "all-gather of MUMi coverage failed"; return -4; }
+                for (int r = 0; r < coll.world; r++) {
+                    int a, b; shard_range(ngen, r, coll.world, &a, &b);
+                    for (int g = a; g < b; g++) mumi_covered[(size_t)(g - 1)] = recv[(size_t)r * send.size() + (size_t)(g - a)];
+                }
+            }
             be.mark(nullptr);
             collect_timing();
             return 0;
@@ -223,7 +256,14 @@ public:
 
         // -- Master.EP, candidates
         be.mark("master_ep");
-        be.launch("master_ep", ntiles, MasterEP{d_R.p, nreg, d_tilebase.p, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p});
+        be.launch("master_ep", ntiles, MasterEP{d_R.p, nreg, d_tilebase.p, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, g_first, g_last});
+        if (coll.world > 1 && npos > 0) {   // exchange 1: Master.EP = min over the ranks' genome blocks
+            be.mark("exchange_ep");
+            std::vector<int32_t> h((size_t)npos);
+            be.d2h(h.data(), d_epm.p, 4 * (size_t)npos);
+            if (coll.allreduce_min_i32(coll.ctx, h.data(), npos)) { error = "all-reduce of Master.EP failed"; return -4; }
+            be.h2d(d_epm.p, h.data(), 4 * (size_t)npos);
+        }
         uint64_t ncand = 0;
         size_t ccap = std::max<size_t>(cand_cap_hint, 1 << 12);
         for (;;) {
@@ -247,6 +287,28 @@ public:
         ensure(d_ok, (size_t)ncand); ensure(d_ok_k, (size_t)ncand); ensure(d_ok_lon, (size_t)ncand);
         ensure(d_osp, (size_t)ncand * (size_t)nq); ensure(d_ofwd, (size_t)ncand * (size_t)nq);
         be.launch("state_at_candidate", (int64_t)ncand * nq, StateAtCandidate{d_R.p, scand, ngen, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_at.p});
+        if (coll.world > 1) {   // exchange 2: every rank contributes the (EP,UP,SP) columns of its genome block
+            be.mark("exchange_states");
+            const size_t nqz = (size_t)nq, cz = (size_t)ncand;
+            std::vector<GenomeAtK> all(cz * nqz);
+            be.d2h(all.data(), d_at.p, sizeof(GenomeAtK) * all.size());
+            int widest = 0;
+            for (int r = 0; r < coll.world; r++) { int a, b; shard_range(ngen, r, coll.world, &a, &b); widest = std::max(widest, b - a); }
+            const size_t blk = cz * (size_t)widest;
+            std::vector<GenomeAtK> send(std::max<size_t>(blk, 1)), recv(std::max<size_t>(blk, 1) * (size_t)coll.world);
+            const size_t mine = (size_t)(g_last - g_first);
+            for (size_t c = 0; c < cz; c++)
+                for (size_t x = 0; x < mine; x++) send[c * (size_t)widest + x] = all[c * nqz + (size_t)(g_first - 1) + x];
+            if (coll.allgather(coll.ctx, send.data(), (int64_t)(sizeof(GenomeAtK) * send.size()), recv.data())) { error = "all-gather of candidate states failed"; return -4; }
+            for (int r = 0; r < coll.world; r++) {
+                int a, b; shard_range(ngen, r, coll.world, &a, &b);
+                const GenomeAtK* src = recv.data() + (size_t)r * send.size();
+                for (size_t c = 0; c < cz; c++)
+                    for (int x = 0; x < b - a; x++) all[c * nqz + (size_t)(a - 1 + x)] = src[c * (size_t)widest + (size_t)x];
+            }
+            be.h2d(d_at.p, all.data(), sizeof(GenomeAtK) * all.size());
+            be.mark("fold");
+        }
         be.launch("fold_genomes", (int64_t)ncand, FoldGenomes{d_R.p, scand, ngen, d_at.p, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_ok.p});
 
         // -- results to the host

@@ -312,11 +312,12 @@ struct RepeatLength {
 // units of one (region, query genome) pair: 2 strands x ceil(samples / 256)
 struct CountUnits {
     const RegionInfo* R; const int64_t* lens; int32_t ngen; int64_t* count;   // lens[r*ngen + g]
+    int32_t g_first, g_last;   // query genomes [g_first, g_last) live on this GPU (all of them unless the run is sharded)
     PM_HD void operator()(int64_t pair) const {
         int64_t r = pair / (ngen - 1); int g = (int)(pair % (ngen - 1)) + 1;
         const RegionInfo& ri = R[r];
         int64_t m = lens[r * ngen + g];
-        int64_t ns = (m >= ri.K && ri.nR >= ri.K) ? (m - ri.K) / ri.stride + 1 : 0;
+        int64_t ns = (m >= ri.K && ri.nR >= ri.K && g >= g_first && g < g_last) ? (m - ri.K) / ri.stride + 1 : 0;
         count[pair] = 2 * ((ns + kUnitSamples - 1) / kUnitSamples);
     }
 };
@@ -563,6 +564,7 @@ struct MumiCoverage {
 struct MasterEP {
     const RegionInfo* R; int64_t nregions; const int64_t* tile_base;   // tile_base[nregions+1]
     int32_t ngen; const uint64_t* key; const int64_t* lo; const int32_t* emax; int lbits; int32_t* epm;
+    int32_t g_first, g_last;   // sharded run: the min over the other genomes arrives by all-reduce
     PM_HD void operator()(int64_t tid) const {
         int64_t r = upper_slot(tile_base, nregions, tid);
         const RegionInfo& ri = R[r];
@@ -570,7 +572,7 @@ struct MasterEP {
         int32_t ep[kTile];
         for (int t = 0; t < kTile; t++) ep[t] = ri.nR;
         const uint64_t lmask = (1ull << lbits) - 1;
-        for (int g = 0; g < ngen - 1; g++) {
+        for (int g = g_first - 1; g < g_last - 1; g++) {
             int64_t pair = r * (ngen - 1) + g;
             int64_t a = lo[pair], b = lo[pair + 1], end = b;
             // first event with l > k0

@@ -20,6 +20,19 @@ int pc_open(const char* ini_path, pc_run** out) {
     *out = r;
     return 0;
 }
+// the same for rank `rank` of a sharded run (every rank opens the same ini; see pm_session_create_sharded)
+int pc_open_sharded(const char* ini_path, int rank, int world, pm_allreduce_min_i32_fn allreduce_min, pm_allgather_fn allgather, void* ctx,
+                    pc_run** out) {
+    pc_run* r = new pc_run;
+    r->run.shard.rank = rank; r->run.shard.world = world;
+    r->run.shard.allreduce_min = allreduce_min; r->run.shard.allgather = allgather; r->run.shard.ctx = ctx;
+    int rc = r->run.open(ini_path);
+    if (rc) { delete r; return rc; }
+    *out = r;
+    return 0;
+}
+// calcmumi on an opened run: writes <outdir>/all.mumi (rank 0 of a sharded run should be the only one to call pc_write)
+int pc_mumi(pc_run* r) { return r->run.mumi(); }
 // one pass of phases A-D; returns a JSON report (valid until the next call on this handle)
 const char* pc_step(pc_run* r) {
     r->last = r->run.step();

@@ -93,7 +93,10 @@ int CoreRun::open(const std::string& ini_path) {
     std::vector<const uint8_t*> ptr(genomes.size());
     std::vector<int64_t> len(genomes.size());
     for (size_t i = 0; i < genomes.size(); i++) { ptr[i] = (const uint8_t*)genomes[i].seq.data(); len[i] = (int64_t)genomes[i].seq.size(); }
-    int rc = pm_session_create(&session, -1, (int)genomes.size(), ptr.data(), len.data());
+    int rc = shard.world > 1
+                 ? pm_session_create_sharded(&session, -1, (int)genomes.size(), ptr.data(), len.data(), shard.rank, shard.world,
+                                             shard.allreduce_min, shard.allgather, shard.ctx)
+                 : pm_session_create(&session, -1, (int)genomes.size(), ptr.data(), len.data());
     if (rc != PM_OK) {
         std::cerr << "parsnp_core: cannot start the multi-MUM engine (" << pm_provider() << "): " << pm_last_error() << std::endl;
         return 3;
@@ -112,7 +115,7 @@ int CoreRun::mumi() {
     std::cout << prm.outdir << std::endl;
     std::string path = prm.outdir + "/all.mumi";
     std::cout << path << std::endl;
-    FILE* f = fopen(path.c_str(), "w");
+    FILE* f = fopen(shard.rank == 0 ? path.c_str() : "/dev/null", "w");   // sharded run: every rank computes, rank 0 writes
     if (!f) { std::cerr << "parsnp_core: cannot write " << path << std::endl; return 1; }
     std::vector<int64_t> starts(n, 0), lens(n), covered(n > 1 ? n - 1 : 1, 0);
     lens[0] = p;

@@ -19,9 +19,18 @@ struct StepReport {
     Stats host;
 };
 
+// sharded run: one process per GPU, query genomes split into contiguous blocks (include/parsnp_mum.h)
+struct ShardSpec {
+    int rank = 0, world = 1;
+    pm_allreduce_min_i32_fn allreduce_min = nullptr;
+    pm_allgather_fn allgather = nullptr;
+    void* ctx = nullptr;
+};
+
 class CoreRun {
 public:
     ~CoreRun();
+    ShardSpec shard;   // set before open()
     // reads the ini, ingests every genome (printing what the reference prints) and uploads them to the engine.
     // returns 0, or the exit code the reference would use (1) / 3 when the engine cannot start.
     int open(const std::string& ini_path);

@@ -101,3 +101,32 @@ def test_bench_interval_exchange_two_ranks(tmp_path):
            "--master-port", "29563", str(w), ROOT]
     p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("name,world", [("pop6x200k", 2), ("poprearr10x400k", 3), ("mumi", 2)])
+def test_sharded_run_gloo(emu, tmp_path, name, world):
+    """query genomes sharded over ranks, Master.EP all-reduced (min), candidate columns all-gathered.
+    The engine here is the host-emulated kernel code (tests/emu) and the collectives run on gloo; the result must be
+    the single-process result (= the reference binary's golden)."""
+    import json
+    import test_host_logic as H
+    import xmfa_util
+    from parsnp_amd import driver
+    core_lib = os.path.join(ROOT, "tests", "emu", "libparsnp_core_emu.so")
+    mumi = name == "mumi"
+    rp, qs, kw = H.mumi_inputs("pop6x200k_p", str(tmp_path)) if mumi else H.harsh_inputs(name, str(tmp_path))
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    ini = os.path.join(out, "run.ini")
+    open(ini, "w").write(driver.ini_text(rp, qs, out, calcmumi=1 if mumi else 0, **kw))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PARSNP_CORE_LIB=core_lib, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", "29571", "-m", "parsnp_amd.sharded", ini]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=out, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    if mumi:
+        lines = sorted(open(os.path.join(out, "all.mumi")).read().split(), key=lambda x: int(x.split(":")[0]))
+        assert lines == H.MUMI["pop6x200k_p"]
+    else:
+        assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == H.E2E[name]["signature"]
+        assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == H.E2E[name]["log"]

@@ -221,3 +221,27 @@ def test_bench_two_ranks_smoke(libs, tmp_path):
     assert abs(d["value"] - 2 * 6 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.02
     assert d["roofline"]["kernel"] and d["mums"] > 2000
     assert 0 < d["core_bp_in_every_partition"] <= d["core_bp_aligned"] // 2 + 1000
+
+
+@pytest.mark.parametrize("name,world", [("poprearr10x400k", 2), ("bact8", 4)])
+def test_sharded_run_on_gpu(libs, tmp_path, name, world):
+    """SURVEY 8e-2 with the HIP engine: `world` ranks, each with its block of the query genomes resident (on this 1-GPU
+    box they share the GPU and exchange over gloo; with one GPU per rank the same launcher uses RCCL)"""
+    import subprocess, sys
+    from conftest import ROOT
+    if name == "bact8":
+        r, gs = synth.make(name)
+        rp, qs = synth.write_set(str(tmp_path / "in"), r, gs); kw = {}
+    else:
+        rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    ini = os.path.join(out, "run.ini")
+    open(ini, "w").write(driver.ini_text(rp, qs, out, threads=4, **kw))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", "29581", "-m", "parsnp_amd.sharded", ini]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=out, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["signature"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
