@@ -113,7 +113,7 @@ public:
         // -- host: per-region parameters and slices
         std::vector<RegionInfo> R((size_t)nreg);
         std::vector<int64_t> posbase((size_t)nreg + 1), tilebase((size_t)nreg + 1);
-        int64_t npos = 0, ntiles = 0, tsize = 0;
+        int64_t npos = 0, ntiles = 0, tsize = 0, fwords = 0;
         int32_t max_nr = 1;
         size_t ev_guess = 1 << 16;     // first-call event buffer: a match of length >= minsize every max(8,minsize) bases is generous
         for (int64_t r = 0; r < nreg; r++) {
@@ -133,6 +133,9 @@ public:
             while (2 * slots < 3 * (int64_t)ri.nR) slots <<= 1;   // load factor <= 2/3
             ri.tmask = (uint32_t)(slots - 1);
             ri.tbase = tsize; tsize += slots;
+            int64_t fbits = 64;
+            while (fbits < 8 * (int64_t)ri.nR) fbits <<= 1;
+            ri.fmask = (uint32_t)(fbits - 1); ri.fbase = fwords; fwords += fbits / 32; ri.pad_ = 0;
             ri.posbase = npos; posbase[(size_t)r] = npos; npos += ri.nR;
             ri.tile_base = ntiles; tilebase[(size_t)r] = ntiles; ntiles += (ri.nR + kTile - 1) / kTile;
             max_nr = std::max(max_nr, ri.nR);
@@ -156,14 +159,15 @@ public:
         ensure(d_err, 1); be.memset(d_err.p, 0, 4);
 
         // -- reference index + repeat lengths
-        ensure(d_slots, (size_t)tsize);
+        ensure(d_slots, (size_t)tsize); ensure(d_filter, (size_t)fwords);
+        be.memset(d_filter.p, 0, sizeof(uint32_t) * (size_t)fwords);
         ensure(d_next, (size_t)std::max<int64_t>(npos, 1)); ensure(d_rep, (size_t)std::max<int64_t>(npos, 1));
         ensure(d_epm, (size_t)std::max<int64_t>(npos, 1));
         be.memset(d_slots.p, 0xff, sizeof(uint64_t) * (size_t)tsize);
         be.mark("index");
-        be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p});
+        be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p, d_filter.p});
         be.mark("repeat");
-        be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p, d_rep.p, d_err.p, work_budget});
+        be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_filter.p, d_next.p, d_rep.p, d_err.p, work_budget});
 
         // -- work units
         be.mark("units");
@@ -175,7 +179,7 @@ public:
         be.d2h(&nunits, d_uoff.p + npairs, 8);
         if (nunits >= (1ll << 31)) { error = "too many work units in one batch"; return -5; }
         ensure(d_upair, (size_t)std::max<int64_t>(nunits, 1)); ensure(d_uinfo, (size_t)std::max<int64_t>(nunits, 1));
-        be.launch("fill_units", npairs, FillUnits{d_uoff.p, d_ucount.p, d_upair.p, d_uinfo.p});
+        be.launch("fill_units", nunits, FillUnits{d_uoff.p, d_ucount.p, npairs, d_upair.p, d_uinfo.p});
 
         // -- events: kSlices append buffers (retry with larger ones on overflow), gathered, then sorted by (pair, l, strand)
         ensure(d_counter, (size_t)kSlices * kSliceStride);
@@ -189,7 +193,7 @@ public:
             be.memset(d_counter.p, 0, 8 * (size_t)kSlices * kSliceStride);
             be.mark("seed_extend");
             be.launch("seed_extend", nunits * 64,
-                      SeedExtend{P, d_R.p, d_starts.p, d_lens.p, ngen, d_upair.p, d_uinfo.p, d_slots.p, d_next.p, d_rep.p,
+                      SeedExtend{P, d_R.p, d_starts.p, d_lens.p, ngen, d_upair.p, d_uinfo.p, d_slots.p, d_filter.p, d_next.p, d_rep.p,
                                  d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err.p, work_budget,
                                  getenv("PM_DEBUG_SEED") ? atoi(getenv("PM_DEBUG_SEED")) : 0});
             be.d2h(counts.data(), d_counter.p, 8 * counts.size());
@@ -351,7 +355,7 @@ public:
 
     void release() {
         auto drop = [&](auto& b) { if (b.p) be.free(b.p); b.p = nullptr; b.cap = 0; };
-        drop(d_R); drop(d_starts); drop(d_lens); drop(d_posbase); drop(d_tilebase); drop(d_err); drop(d_slots); drop(d_next);
+        drop(d_R); drop(d_starts); drop(d_lens); drop(d_posbase); drop(d_tilebase); drop(d_err); drop(d_slots); drop(d_filter); drop(d_next);
         drop(d_rep); drop(d_epm); drop(d_ucount); drop(d_uoff); drop(d_upair); drop(d_uinfo); drop(d_counter); drop(d_evkey); drop(d_evval);
         drop(d_evkey2); drop(d_evval2); drop(d_evkey3); drop(d_evval3); drop(d_sliceoff); drop(d_lo); drop(d_cov); drop(d_state); drop(d_summary); drop(d_startshere); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
         drop(d_ok_k); drop(d_ok_lon); drop(d_osp); drop(d_ofwd);
@@ -379,7 +383,7 @@ private:
     Packed P{};
     size_t ev_cap_hint = 0, cand_cap_hint = 0;
     Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase, d_tilebase; Buf<uint32_t> d_err;
-    Buf<uint64_t> d_slots; Buf<int32_t> d_next, d_rep, d_epm;
+    Buf<uint64_t> d_slots; Buf<uint32_t> d_filter; Buf<int32_t> d_next, d_rep, d_epm;
     Buf<int64_t> d_ucount, d_uoff; Buf<int32_t> d_upair, d_uinfo;
     Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2, d_evkey3, d_evval3; Buf<int64_t> d_sliceoff;
     Buf<int64_t> d_lo, d_cov; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;

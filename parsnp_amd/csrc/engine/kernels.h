@@ -128,14 +128,17 @@ struct RegionInfo {        // one per region of a batch
     int64_t tbase;         // hash-table slice start
     int64_t posbase;       // start of this region in the per-reference-position arrays
     int64_t tile_base;     // first 16-position tile of this region
+    int64_t fbase;         // first uint32 word of this region's presence filter
+    uint32_t fmask;        // filter bits - 1 (power of two, >= 8 nR): one hashed bit per K-mer of the reference substring
+    uint32_t pad_;
 };
 
 constexpr uint64_t kEmpty = ~0ull;
 constexpr int kTile = 16;          // reference positions per master-fold thread
 #ifndef PM_UNIT
-#define PM_UNIT 256
+#define PM_UNIT 64
 #endif
-constexpr int kUnitSamples = PM_UNIT;  // query samples per work unit (64 threads x PM_UNIT/64)
+constexpr int kUnitSamples = PM_UNIT;  // query samples per work unit (64 lanes x PM_UNIT/64): 64 keeps SeedExtend at 8 waves/SIMD
 constexpr int kSlices = 1024;          // the event buffer is appended through this many independent counters
 constexpr int kSliceStride = 8;        // uint64 words between two counters: one 64-byte line each
 
@@ -192,9 +195,14 @@ PM_HD uint64_t kmer_tag(const Packed& P, int64_t p, int K) {
     if (K < 32) m &= (uint32_t)((1ull << K) - 1);
     return b | ((uint64_t)m << 32);
 }
-PM_HD uint64_t hash_tag(uint64_t t) {   // low bits: slot, high 32 bits: fingerprint
-    t ^= t >> 29; t *= 0xbf58476d1ce4e5b9ull; t ^= t >> 32; t *= 0x94d049bb133111ebull; t ^= t >> 29;
-    return t;
+PM_HD uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+// hash of a 48-bit K-mer tag.  low 32 bits: slot index, bits 35..: filter bit, high 32 bits: fingerprint.  Built from two
+// 32-bit finalisers (the kernel is VALU bound and 64-bit multiplies cost ~10 vector ops each on gfx950).
+PM_HD uint64_t hash_tag(uint64_t t) {
+    const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    const uint32_t a = fmix32(lo ^ (hi * 0x9e3779b1u));
+    const uint32_t b = fmix32(a ^ lo ^ 0x68bc21ebu) + hi;
+    return ((uint64_t)b << 32) | a;
 }
 // largest r in [0, count) with base[r] <= x (base ascending, base[0] <= x)
 PM_HD int64_t upper_slot(const int64_t* base, int64_t count, int64_t x) {
@@ -233,7 +241,7 @@ PM_HD int32_t slot_head(uint64_t s) { return (int32_t)(s & 0x7fffffffu); }
 // tid = flat reference position over the batch.
 struct IndexInsert {
     Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;   // posbase[nregions+1]
-    uint64_t* slots; int32_t* next;
+    uint64_t* slots; int32_t* next; uint32_t* filter;
     PM_HD void operator()(int64_t tid) const {
         int64_t r = upper_slot(posbase, nregions, tid);
         const RegionInfo& ri = R[r];
@@ -245,6 +253,10 @@ struct IndexInsert {
         const uint64_t hv = hash_tag(tag);
         const uint64_t fp = hv & 0xffffffff00000000ull;
         uint32_t h = (uint32_t)hv & ri.tmask;
+        {   // presence filter: most query K-mers of a non-matching strand are rejected by one bit that lives in L2
+            const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
+            atomic_or32(&filter[ri.fbase + (bit >> 5)], 1u << (bit & 31));
+        }
         for (;;) {
             uint64_t* slot = &slots[ri.tbase + h];
             uint64_t seen = *slot;
@@ -264,9 +276,24 @@ struct IndexInsert {
         }
     }
 };
+// continue a lookup whose first slot (index h) has already been read as `seen`
+PM_HD uint64_t index_resolve(const Packed& P, const RegionInfo& ri, const uint64_t* slots, uint64_t tag, uint64_t seen, uint32_t h) {
+    const uint64_t fp = hash_tag(tag) & 0xffffffff00000000ull;
+    const int64_t base = P.goff[0] + ri.ref_pos;
+    for (;;) {
+        if (seen == kEmpty) return kEmpty;
+        if ((seen & 0xffffffff00000000ull) == fp && kmer_tag(P, base + slot_head(seen), ri.K) == tag) return seen;
+        h = (h + 1) & ri.tmask;
+        seen = slots[ri.tbase + h];
+    }
+}
 // -> slot value of the K-mer `tag` in region ri, or kEmpty
-PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_t* slots, uint64_t tag) {
+PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_t* slots, const uint32_t* filter, uint64_t tag) {
     const uint64_t hv = hash_tag(tag);
+    {
+        const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
+        if (!((filter[ri.fbase + (bit >> 5)] >> (bit & 31)) & 1u)) return kEmpty;
+    }
     const uint64_t fp = hv & 0xffffffff00000000ull;
     uint32_t h = (uint32_t)hv & ri.tmask;
     const int64_t base = P.goff[0] + ri.ref_pos;
@@ -282,7 +309,7 @@ PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_
 // (= the uniqueness point pos_label-l of mum.c:219-224 wherever it can influence the output; SURVEY 3.3-1,-7.)
 struct RepeatLength {
     Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;
-    const uint64_t* slots; const int32_t* next; int32_t* rep; uint32_t* err; int64_t budget;
+    const uint64_t* slots; const uint32_t* filter; const int32_t* next; int32_t* rep; uint32_t* err; int64_t budget;
     PM_HD void operator()(int64_t tid) const {
         int64_t r = upper_slot(posbase, nregions, tid);
         const RegionInfo& ri = R[r];
@@ -291,7 +318,7 @@ struct RepeatLength {
         if (l + ri.K <= ri.nR) {
             int64_t base = P.goff[0] + ri.ref_pos;
             uint64_t tag = kmer_tag(P, base + l, ri.K);
-            uint64_t slot = index_lookup(P, ri, slots, tag);
+            uint64_t slot = index_lookup(P, ri, slots, filter, tag);
             if (slot != kEmpty && (slot & kMulti)) {
                 int64_t work = 0;
                 for (int32_t o = slot_head(slot); o >= 0; o = next[ri.posbase + o]) {
@@ -321,11 +348,14 @@ struct CountUnits {
         count[pair] = 2 * ((ns + kUnitSamples - 1) / kUnitSamples);
     }
 };
+// tid = work unit: which (pair, strand, chunk) it is (off[] = exclusive prefix of the per-pair unit counts)
 struct FillUnits {
-    const int64_t* off; const int64_t* count; int32_t* unit_pair; int32_t* unit_info;
-    PM_HD void operator()(int64_t pair) const {
-        int64_t o = off[pair], c = count[pair], half = c / 2;
-        for (int64_t u = 0; u < c; u++) { unit_pair[o + u] = (int32_t)pair; unit_info[o + u] = (int32_t)(u < half ? (u << 1) : (((u - half) << 1) | 1)); }
+    const int64_t* off; const int64_t* count; int64_t npairs; int32_t* unit_pair; int32_t* unit_info;
+    PM_HD void operator()(int64_t tid) const {
+        int64_t pair = upper_slot(off, npairs, tid);     // the last pair whose first unit is <= tid owns it
+        int64_t u = tid - off[pair], half = count[pair] / 2;
+        unit_pair[tid] = (int32_t)pair;
+        unit_info[tid] = (int32_t)(u < half ? (u << 1) : (((u - half) << 1) | 1));
     }
 };
 
@@ -337,14 +367,15 @@ struct FillUnits {
 struct SeedExtend {
     Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen;
     const int32_t* unit_pair; const int32_t* unit_info;
-    const uint64_t* slots; const int32_t* next; const int32_t* rep;
+    const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
     int debug;   // PM_DEBUG_SEED experiments (profiling only; results are wrong when set): 1 no emit, 2 stop after lookup, 4 stop after left arm
     PM_HD void operator()(int64_t tid) const {
         int64_t unit = tid >> 6; int lane = (int)(tid & 63);
         int32_t pair = unit_pair[unit]; int32_t info = unit_info[unit];
         int strand = info & 1; int64_t chunk = info >> 1;
-        int64_t r = pair / (ngen - 1); int g = (int)(pair % (ngen - 1)) + 1;
+        const uint32_t nqq = (uint32_t)(ngen - 1);
+        int64_t r = (int64_t)((uint32_t)pair / nqq); int g = (int)((uint32_t)pair % nqq) + 1;
         const RegionInfo& ri = R[r];
         const int64_t m = lens[r * ngen + g], qs = starts[r * ngen + g];
         const int64_t qbase = strand ? P.goff[2 * g + 1] + (P.glen[g] - qs - m) : P.goff[2 * g] + qs;
@@ -366,11 +397,11 @@ struct SeedExtend {
 #pragma unroll
         for (int u = 0; u < kPer; u++) {
             bk[u] = kEmpty; bv[u] = 0;
-            int64_t s = chunk * kUnitSamples + u * 64 + lane;
-            int64_t j = s * ri.stride;
+            const int32_t sidx = (int32_t)chunk * kUnitSamples + u * 64 + lane;
+            const int64_t j = (int64_t)sidx * ri.stride;
             if (stop || j + K > m) continue;
             uint64_t tag = kmer_tag(P, qbase + j, K);
-            uint64_t slot = index_lookup(P, ri, slots, tag);
+            uint64_t slot = index_lookup(P, ri, slots, filter, tag);
             if (slot == kEmpty) continue;
             if (debug & 2) { if (slot == 12345) atomic_or32(err, 2u); continue; }
             const bool multi = (slot & kMulti) != 0;

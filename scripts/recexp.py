@@ -10,7 +10,7 @@ starts=np.zeros((NR,G+1),np.int64); lens=np.zeros((NR,G+1),np.int64); mins=np.fu
 for r in range(NR):
     st=int(rng.integers(0,n-200)); ln=int(rng.integers(31,80))
     starts[r,:]=st; lens[r,:]=ln
-with Session(Lib(),[ref]+gs) as s:
+with Session(Lib(sys.argv[1] if len(sys.argv) > 1 else None),[ref]+gs) as s:
     s.multi_mum_batch(starts,lens,mins)
     for dbg in ("0","1","4","2"):
         os.environ["PM_DEBUG_SEED"]=dbg

@@ -2,7 +2,7 @@ import sys,time,os; sys.path.insert(0,"."); sys.path.insert(0,"tests")
 from parsnp_amd import synth
 from parsnp_amd.binding import Lib, Session
 ref,gs=synth.population(seed=5,n=5_000_000,n_genomes=40,div=0.02,indel_frac=0.05)
-with Session(Lib(),[ref]+gs) as s:
+with Session(Lib(sys.argv[1] if len(sys.argv) > 1 else None),[ref]+gs) as s:
     s.whole(25)
     for dbg in ("0","1","4","2"):
         os.environ["PM_DEBUG_SEED"]=dbg
