@@ -75,6 +75,20 @@ def test_batched_regions(libs):
     assert batch_case(rng, E, O, n_regions=12, glen=20000, nq=3, big_minsize=True) > 5
 
 
+def test_long_minimum_lengths(libs):
+    """minsize > 47 makes the sampling stride exceed one 32-base window (left arm continues from memory), and matches
+    longer than the 64 prefetched bases continue from memory on the right"""
+    E, O = libs
+    rng = np.random.default_rng(11)
+    for minsize in (48, 60, 90, 130):
+        ref = random_seq(rng, 6000)
+        qs = [mutate(rng, ref, sub=0.004, indel=0.0005), oracles.revcomp(mutate(rng, ref, sub=0.004))]
+        a = oracles.restatement_multi_mum(O, [ref] + qs, minsize, 1)
+        with Session(E, [ref] + qs) as s:
+            b = s.whole(minsize)
+        assert same(a, b) and len(a[0]) > 3, minsize
+
+
 def test_events(libs):
     E, O = libs
     rng = np.random.default_rng(7)
