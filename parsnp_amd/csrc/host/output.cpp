@@ -1,9 +1,8 @@
 // output.cpp -- parsnpAligner.xmfa + parsnpAligner.log, the output contract of the reference's
 // Aligner::writeOutput (src/parsnp.cpp:505-1191).  MUM columns are lower case, inter-MUM gap columns upper case.
 // Gaps in which every genome has >= 1 base and some genome has >= 2 go to libMUSCLE in the reference
-// (:790-865, src/MuscleInterface.cpp:37-78); that aligner is outside this project's hot path, so such
-// gaps are emitted left-justified and '-'-padded and the log carries a note.  Every other byte of both files is the
-// reference's.
+// (:790-865, src/MuscleInterface.cpp:37-78); here they go to gapalign.cpp, the restatement of that aligner.  Should it
+// ever decline an input, the gap is emitted left-justified and '-'-padded and the log carries a note.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +12,7 @@
 #include <sstream>
 
 #include "aligner.h"
+#include "gapalign.h"
 
 namespace parsnp {
 
@@ -52,9 +52,14 @@ void build_rows(const Aligner& a, const Lcb& ct, std::vector<std::string>* rows,
             if (gap[i].size() < min_len) min_len = (unsigned)gap[i].size();
         }
         if (max_len > 1 && min_len > 0) {
-            // reference: MUSCLE(maxiters=1) over the n gap strings.  Here: unaligned, padded to the longest.
-            *gap_note = true;
-            for (size_t i = 0; i < n; i++) (*rows)[i] += gap[i] + std::string(max_len - gap[i].size(), '-');
+            // reference: MUSCLE(maxiters=1) over the n gap strings (:848-861); a single genome is never aligned
+            std::vector<std::string> aligned;
+            if (n > 1 && gap_align(gap, &aligned)) {
+                for (size_t i = 0; i < n; i++) (*rows)[i] += aligned[i];
+            } else {
+                if (n > 1) *gap_note = true;   // n == 1: the reference appends the gap as it is (:809-826)
+                for (size_t i = 0; i < n; i++) (*rows)[i] += gap[i] + std::string(max_len - gap[i].size(), '-');
+            }
         } else if (max_len > 0) {
             for (size_t i = 0; i < n; i++) (*rows)[i] += gap[i] + std::string(max_len - gap[i].size(), '-');
         }

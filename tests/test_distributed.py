@@ -129,4 +129,5 @@ def test_sharded_run_gloo(emu, tmp_path, name, world):
         assert lines == H.MUMI["pop6x200k_p"]
     else:
         assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == H.E2E[name]["signature"]
+        assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == H.E2E[name]["xmfa_md5"]
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == H.E2E[name]["log"]

@@ -57,7 +57,8 @@ def run(core, rp, qs, out, kw):
     x = os.path.join(out, "parsnpAligner.xmfa")
     lg = os.path.join(out, "parsnpAligner.log")
     return (p.returncode, xmfa_util.mum_lcb_signature(x) if os.path.exists(x) else None,
-            xmfa_util.log_counters(lg) if os.path.exists(lg) else None)
+            xmfa_util.log_counters(lg) if os.path.exists(lg) else None,
+            xmfa_util.md5(x) if os.path.exists(x) else None)
 
 
 def side_by_side(core, name, tmp_path):

@@ -188,6 +188,7 @@ def test_parsnp_core_harsh_inputs(libs, tmp_path, name):
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
     want = E2E[name]
     assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == want["signature"]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == want["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
 
 
@@ -203,6 +204,7 @@ def test_parsnp_core_vs_reference_binary_fresh_input(libs, tmp_path):
     assert rc1 == 0 and rc2 == 0
     a, b = str(tmp_path / "ref" / "parsnpAligner.xmfa"), str(tmp_path / "hip" / "parsnpAligner.xmfa")
     assert xmfa_util.mum_lcb_signature(a) == xmfa_util.mum_lcb_signature(b)
+    assert xmfa_util.md5(a) == xmfa_util.md5(b)
     assert xmfa_util.log_counters(str(tmp_path / "ref" / "parsnpAligner.log")) == xmfa_util.log_counters(str(tmp_path / "hip" / "parsnpAligner.log"))
 
 
@@ -244,4 +246,5 @@ def test_sharded_run_on_gpu(libs, tmp_path, name, world):
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=out, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["signature"]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]

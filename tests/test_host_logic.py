@@ -14,15 +14,15 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 E2E = json.load(open(os.path.join(G, "e2e.json")))
 
 
-def check(core, name, rp, qs, out, exact_xmfa, env=None):
+def check(core, name, rp, qs, out, exact_xmfa=True, env=None):
     rc, _ = driver.run_core(core, rp, qs, out, env=env)
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
     x = os.path.join(out, "parsnpAligner.xmfa")
     want = E2E[name]
     assert xmfa_util.mum_lcb_signature(x) == want["signature"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
-    if exact_xmfa:
-        assert xmfa_util.md5(x) == want["xmfa_md5"]
+    assert xmfa_util.md5(x) == want["xmfa_md5"]   # every byte, inter-MUM gap columns (the reference's MUSCLE call) included
+    assert "NOTE" not in open(os.path.join(out, "parsnpAligner.log")).read()
     assert os.path.exists(os.path.join(out, "allmums.out"))
 
 
@@ -62,6 +62,7 @@ def test_harsh_inputs(cpu_checkers, tmp_path, name):
     want = E2E[name]
     assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == want["signature"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == want["xmfa_md5"]
 
 
 def test_no_speculation_same_result(cpu_checkers, tmp_path):
@@ -81,6 +82,7 @@ def test_literal_worklist_same_result(cpu_checkers, tmp_path, name):
     rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, **kw)
     assert rc == 0
     assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["signature"]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 
 
@@ -96,6 +98,7 @@ def test_threaded_validation_same_result(cpu_checkers, tmp_path, name, par_min):
     rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, threads=4, timing=str(tmp_path / "t.json"), **kw)
     assert rc == 0
     assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["signature"]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 
 
