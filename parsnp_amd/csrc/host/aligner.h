@@ -248,8 +248,10 @@ private:
     std::vector<CacheEntry*> wanted_entries_;
 };
 
-// XMFA + log (writeOutput).  gap_note: set when at least one inter-MUM gap needed the (absent) MUSCLE aligner.
+// XMFA + log (writeOutput).  gap_note: set when the gap aligner (gapalign.h) declined an inter-MUM gap and it was written '-'-padded.
 void write_output(Aligner& a, const std::string& stem, bool* gap_note);
+// parsnp.unalign (setUnalignableRegions); marks every base of the layout bitmaps.
+void write_unaligned(Aligner& a);
 
 std::string reverse_complement(const std::string& s);   // Aligner::reversec, :1294-1393
 

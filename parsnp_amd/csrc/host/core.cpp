@@ -46,9 +46,9 @@ int CoreRun::open(const std::string& ini_path) {
     const bool reverse_ref = ini.get_bool("Reference", "reverse");
     qfiles = (int)ini.count("Query") / 2;
 
-    if (!prm.anchorfile.empty() || !prm.mumfile.empty() || prm.unaligned) {
-        // anchorfile/mumfile replay and parsnp.unalign are outside the accelerated path
-        std::cerr << "parsnp_core (MI355X build): anchorfile / mumfile / unaligned are not supported by this build" << std::endl;
+    if (!prm.anchorfile.empty() || !prm.mumfile.empty()) {
+        // replay of a stored anchor / MUM list is outside the accelerated path; the driver never sets these keys
+        std::cerr << "parsnp_core (MI355X build): anchorfile / mumfile are not supported by this build" << std::endl;
         return 1;
     }
 
@@ -188,6 +188,9 @@ StepReport CoreRun::step() {
     return r;
 }
 
-void CoreRun::write(bool* gap_note) { write_output(*align, "parsnpAligner", gap_note); }
+void CoreRun::write(bool* gap_note) {
+    write_output(*align, "parsnpAligner", gap_note);
+    if (prm.unaligned) write_unaligned(*align);   // src/parsnp.cpp:3283-3287
+}
 
 }  // namespace parsnp

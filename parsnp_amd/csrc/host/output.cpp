@@ -255,4 +255,54 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     log.close();
 }
 
+// parsnp.unalign (Aligner::setUnalignableRegions, src/parsnp.cpp:2310-2381): round-robin over the genomes, each round
+// emitting the next run of bases no MUM covers.  Quirks kept: the record holds end-start bases (the last base of the run is
+// dropped), runs of one base are skipped, a trailing single character of the 80-column wrap is not printed, and the
+// coordinates are 0-based positions of the padded in-memory genome.
+void write_unaligned(Aligner& a) {
+    using namespace std;
+    const size_t n = a.n;
+    ofstream out((a.prm.outdir + "/parsnp.unalign").c_str());
+    vector<long> lastpos(n, 0);
+    vector<char> exhausted(n, 0);   // no unmarked base left at or after lastpos: the reference rescans to the same answer
+    string rec;
+    bool stop = false;
+    while (!stop) {
+        for (size_t k = 0; k < n; k++) {
+            Bitmap& bm = a.layout[k];
+            const long size = (long)bm.bits();
+            long startpos = -1, endpos = -1;
+            if (!exhausted[k]) {
+                long m = lastpos[k];
+                while (m < size && bm.get(m)) m++;
+                if (m >= size) exhausted[k] = 1;
+                else {
+                    startpos = m;
+                    while (m < size && !bm.get(m)) m++;
+                    endpos = m - 1;
+                    bm.set_range(startpos, m);
+                    if (m < size) lastpos[k] = endpos + 1;
+                }
+            }
+            if (startpos != endpos) {
+                rec.clear();
+                rec += ">" + to_string(k + 1) + ":" + to_string(startpos) + "-" + to_string(endpos) + " + " + a.genomes[k].fname + "\n";
+                const string& g = a.genomes[k].seq;
+                const size_t len = (size_t)(endpos - startpos);
+                const size_t from = (size_t)startpos;
+                const size_t avail = from <= g.size() ? min(len, g.size() - from) : 0;
+                size_t pos = 0;
+                while (pos + 80 < avail) { rec.append(g, from + pos, 80); rec.push_back('\n'); pos += 80; }
+                if (pos + 1 < avail) { rec.append(g, from + pos, avail - pos); rec.push_back('\n'); }
+                if (avail == 0) rec += "-\n";
+                rec += "=\n";
+                out.write(rec.data(), (streamsize)rec.size());
+            } else if (startpos == -1 && k == n - 1) {
+                stop = true;
+            }
+        }
+    }
+    out.close();
+}
+
 }  // namespace parsnp

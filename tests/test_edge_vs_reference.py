@@ -38,6 +38,8 @@ def cases():
         "short_query": (ref, [gs[0], gs[1][:3000]], {}),
         "heavy_rearr": (r3, g3, {}),
         "single_query": (ref, gs[:1], {}),
+        "unaligned_out": (r3, g3[:4], dict(unaligned=1)),          # parsnp.unalign (setUnalignableRegions)
+        "recomb_blocks": (ref, gs[:3], dict(recombfilt=1)),         # blocks/b<k>/seq.fna
     }
 
 
@@ -56,9 +58,14 @@ def run(core, rp, qs, out, kw):
     p = subprocess.run([core, ini], cwd=out, capture_output=True, text=True, timeout=900)
     x = os.path.join(out, "parsnpAligner.xmfa")
     lg = os.path.join(out, "parsnpAligner.log")
+    extra = []   # every other file the run left in its output directory (parsnp.unalign, blocks/b*/seq.fna)
+    for d, _, fs in sorted(os.walk(out)):
+        for f in sorted(fs):
+            if f in ("parsnp.unalign", "seq.fna"):
+                extra.append((os.path.relpath(os.path.join(d, f), out), xmfa_util.md5(os.path.join(d, f))))
     return (p.returncode, xmfa_util.mum_lcb_signature(x) if os.path.exists(x) else None,
             xmfa_util.log_counters(lg) if os.path.exists(lg) else None,
-            xmfa_util.md5(x) if os.path.exists(x) else None)
+            xmfa_util.md5(x) if os.path.exists(x) else None, extra)
 
 
 def side_by_side(core, name, tmp_path):
@@ -68,6 +75,10 @@ def side_by_side(core, name, tmp_path):
     b = run(core, rp, qs, str(tmp_path / "mine"), kw)
     assert a == b
     assert a[0] == 0
+    if name == "unaligned_out":
+        assert [f for f, _ in a[4]] == ["parsnp.unalign"]
+    if name == "recomb_blocks":
+        assert a[4] and all(f.startswith("blocks/") for f, _ in a[4])
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
