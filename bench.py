@@ -12,8 +12,9 @@ G query genomes) on its own GPU, no data-path collective; value = genomes of all
 ("scaling": "weak").
 
 The JSON line also carries
-  roofline      dominant kernel of the anchor launch, timed live with HIP events on the engine's stream:
-                achieved = algorithmic bytes per launch (m/4 + 16 m + 16 n per query genome) / duration
+  roofline      dominant kernel (SeedExtend), timed live with HIP events on the engine's stream over every engine launch of
+                the timed steps: achieved = algorithmic bytes per launch (m/4 + 16 m + 16 n per query genome and
+                region) / average launch duration; the anchor launch alone is reported beside it
   cpu_baseline  the REFERENCE binary (oracle/_ref/parsnp_core_ref, built from /root/reference in the build container)
                 on the host cores of this box, on a bounded sample of the same workload, single thread (the reference's
                 MUM+LCB path is single-threaded, src/parsnp.cpp:1600-1619).
@@ -180,26 +181,34 @@ def main():
             rep = reports[-1]
             G = len(qs)
             value = world * G * args.steps / elapsed
-            # dominant kernel of the anchor launch, averaged over the timed steps
-            phases = {}
+            # dominant kernel: per-phase HIP-event times of every engine launch of the timed steps (anchor launch +
+            # recursion launches), summed per step and averaged over the steps
+            phases, totals = {}, {}
             for r in reports:
                 for k, v in r["anchor_ms"].items():
                     phases[k] = phases.get(k, 0.0) + v / len(reports)
-            kernels = {k: v for k, v in phases.items() if k not in ("setup", "download", "units")}
+                for k, v in r["engine_ms"].items():
+                    totals[k] = totals.get(k, 0.0) + v / len(reports)
+            kernels = {k: v for k, v in totals.items() if k not in ("setup", "download", "units")}
             dom = max(kernels, key=kernels.get) if kernels else None
-            b_alg = m_avg / 4 + 16 * m_avg + 16 * n_ref          # bytes per query genome
+            launches = sum(r["finder_calls"] for r in reports) / len(reports)          # engine launches per step
+            alg_step = sum(r["alg_bytes"] for r in reports) / len(reports)             # SURVEY 8d bytes of all of them
+            b_alg = m_avg / 4 + 16 * m_avg + 16 * n_ref          # bytes per query genome of the anchor launch
             roof = None
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "r01", "traffic_seed_extend.json")
             if dom == "seed_extend" and args.workload == "bact200" and G == 200 and os.path.exists(tpath):
-                # HBM bytes of this kernel's anchor launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) on this
-                # exact workload; see the file for provenance and the (un)correction applied
-                traffic = json.load(open(tpath))["hbm_bytes"]
-            if dom:
-                gbs = b_alg * G / (kernels[dom] * 1e-3) / 1e9
+                # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) on this exact
+                # workload; see the file for provenance, the calibration and the correction applied
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            if dom and launches:
+                launch_ms = kernels[dom] / launches
+                gbs = alg_step / (kernels[dom] * 1e-3) / 1e9
                 roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "launch_ms": round(kernels[dom], 4),
-                        "alg_bytes_per_launch": int(b_alg * G)}
+                        "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "launch_ms": round(launch_ms, 4),
+                        "launches_per_step": launches, "alg_bytes_per_launch": int(alg_step / launches),
+                        "anchor_launch": {"launch_ms": round(phases.get(dom, 0.0), 4), "alg_bytes": int(b_alg * G),
+                                          "achieved": round(b_alg * G / (phases[dom] * 1e-3) / 1e9, 2) if phases.get(dom) else None}}
             line = {
                 "metric": "genomes/sec (MUM+LCB end-to-end)", "value": round(value, 4), "unit": "genomes/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),

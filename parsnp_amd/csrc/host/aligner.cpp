@@ -220,6 +220,7 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out)
         memcpy(&starts[i * n], reqs[i].start, n * 8);
         memcpy(&lens[i * n], reqs[i].len, n * 8);
         mins[i] = reqs[i].minsize;
+        for (size_t g = 1; g < n; g++) stats.alg_bytes += (double)reqs[i].len[g] * 16.25 + 16.0 * (double)reqs[i].len[0];
     }
     pm_result* res = nullptr;
     int rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);

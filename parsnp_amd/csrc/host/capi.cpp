@@ -42,7 +42,7 @@ const char* pc_step(pc_run* r) {
     o << "{\"provider\": \"" << pm_provider() << "\", \"queries\": " << r->run.qfiles << ", \"path_s\": " << s.path_s << ", \"anchor_s\": " << s.anchor_s
       << ", \"extend_s\": " << s.extend_s << ", \"filter_s\": " << s.filter_s << ", \"lcb_s\": " << s.lcb_s << ", \"finder_s\": " << s.finder_s
       << ", \"ingest_s\": " << r->run.ingest_s << ", \"upload_s\": " << r->run.upload_s << ", \"anchors\": " << s.anchors << ", \"mums\": " << s.mums
-      << ", \"lcbs\": " << s.lcbs << ", \"core_bp\": " << s.core_bp << ", \"finder_calls\": " << s.finder_calls << ", \"finder_regions\": "
+      << ", \"lcbs\": " << s.lcbs << ", \"core_bp\": " << s.core_bp << ", \"alg_bytes\": " << (long long)s.alg_bytes << ", \"finder_calls\": " << s.finder_calls << ", \"finder_regions\": "
       << s.finder_regions << ", \"regions_processed\": " << s.regions_processed << ", \"cache_hits\": " << s.cache_hits << ", \"cache_misses\": "
       << s.cache_misses << ", \"spec_rounds\": " << s.spec_rounds << ", \"mums_found\": " << (s.mums_found ? "true" : "false")
       << ", \"host_split_s\": {\"validate\": " << s.host.t_validate << ", \"neighbour\": " << s.host.t_neighbour << ", \"key\": " << s.host.t_key
