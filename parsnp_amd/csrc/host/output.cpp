@@ -163,16 +163,14 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
             if (first.fwd[i]) hd << "> " << i + 1 << ":" << ct.start[i] + 1 << "-" << ct.end[i] << " ";
             else hd << "> " << i + 1 << ":" << lastm.start[i] + 1 << "-" << first.end[i] << " ";
             // contig label and offset: last pos2hdr entry at or before the LCB start (:994-1037)
-            bool hit = false;
-            string hdr, lasthdr;
-            int seqstart = 0, laststart = 0;
-            bool closed = false;
-            for (const auto& kv : a.genomes[i].pos2hdr) {
-                if (hit && ct.start[i] < kv.first) { closed = true; break; }
-                else if (ct.start[i] >= kv.first) { hit = true; laststart = kv.first; lasthdr = kv.second; }
+            // (the reference scans the map in key order; the entry it ends on is the last key <= start)
+            string hdr;
+            int seqstart = 0;
+            {
+                const auto& p2h = a.genomes[i].pos2hdr;
+                auto it = p2h.upper_bound((int)ct.start[i]);
+                if (it != p2h.begin()) { --it; hdr = it->second; seqstart = it->first; }
             }
-            (void)closed;
-            if (hit) { hdr = lasthdr; seqstart = laststart; }
             int offset = 0;
             if (hdr == "") { hdr = "s1"; offset = -1; }
             else if (hdr != "s1") offset = -1;

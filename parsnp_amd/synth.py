@@ -144,6 +144,39 @@ def write_set(outdir, ref: bytes, genomes):
     return rp, qs
 
 
+def write_contigs(path, name, contigs, width=80):
+    with open(path, "wb") as f:
+        for c, part in enumerate(contigs):
+            f.write(b">" + ("%s_contig%d" % (name, c + 1)).encode() + b"\n")
+            for i in range(0, len(part), width):
+                f.write(part[i:i + width] + b"\n")
+
+
+def draft_set(outdir, seed=31, n=300_000, n_genomes=8, contigs=60, div=0.02, indel_frac=0.05):
+    """draft assemblies: every genome (the reference too) is cut at its own random positions into `contigs` contigs, the
+    contigs are shuffled and about half of them reverse-complemented.  Ingest joins contigs with d+10 N's
+    (src/parsnp.cpp:3040-3075), so every genome carries `contigs`-1 identical N runs: the repeat structure that the seed
+    index handles worst, and many short reverse-strand LCBs.  -> (ref path, [query paths])"""
+    rng = np.random.default_rng(seed)
+    ref, gs = population(seed, n, n_genomes, div, indel_frac)
+    os.makedirs(outdir, exist_ok=True)
+
+    def cut(g):
+        edges = [0] + sorted(int(x) for x in rng.choice(np.arange(200, len(g) - 200), contigs - 1, replace=False)) + [len(g)]
+        parts = [g[edges[i]:edges[i + 1]] for i in range(contigs)]
+        order = rng.permutation(contigs)
+        return [parts[i].translate(_COMP)[::-1] if rng.random() < 0.5 else parts[i] for i in order]
+
+    rp = os.path.join(outdir, "ref.fna")
+    write_contigs(rp, "ref", cut(ref))
+    qs = []
+    for i, g in enumerate(gs):
+        p = os.path.join(outdir, "g%04d.fna" % i)
+        write_contigs(p, "g%04d" % i, cut(g))
+        qs.append(p)
+    return rp, qs
+
+
 CONFIGS = {
     # name: (model, kwargs)  -- sizes of BASELINE.json configs 2, 3, 5 and the reduced sets used by tests
     "viral50": ("musclefree", dict(seed=3, n=30000, n_genomes=50, div=0.01)),

@@ -45,7 +45,49 @@ def mers_paths(tmp):
     return ref, qs
 
 
+def e2e_goldens(tmp, mref, mqs, only=None, e2e=None):
+    """XMFA md5 / MUM-LCB signature / log counters of the reference binary; only = names to (re)generate into e2e"""
+    e2e = {} if e2e is None else e2e
+
+    def run(name, make, **kw):
+        if only and name not in only:
+            return
+        rp, qs = make()
+        out = os.path.join(tmp, "out_" + name)
+        rc, _ = driver.run_core(REFBIN, rp, qs, out, **kw)
+        assert rc == 0, name
+        x = os.path.join(out, "parsnpAligner.xmfa")
+        e2e[name] = dict(xmfa_md5=xmfa_util.md5(x), signature=xmfa_util.mum_lcb_signature(x),
+                         log=xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")),
+                         ref_records=[h for h, _ in xmfa_util.records(x)[1] if h.startswith("> 1:")][:50])
+
+    def synthetic(name, sub=None):
+        def make():
+            r, gs = synth.make(name)
+            return synth.write_set(os.path.join(tmp, sub or name), r, gs)
+        return make
+    # file names matter (##SequenceFile): MERS under its own names, synthetic sets as ref.fna / g%04d.fna
+    run("mers", lambda: (mref, mqs))
+    for name in ("viral50", "pop6x200k", "rearr6x300k", "pop20x1m", "bact8", "poprearr10x400k"):   # bact8 takes ~80 s
+        run(name, synthetic(name))
+    run("messy", lambda: synth.messy_set(os.path.join(tmp, "messy")))
+    run("pchunk", synthetic("pop6x200k", "pchunk"), partpos=66660)      # 3 reference chunks + the <50 bp tail rule (src/parsnp.cpp:1527-1538)
+    # draft assemblies: shuffled / reverse-complemented contigs joined by N runs
+    run("draft8x300k", lambda: synth.draft_set(os.path.join(tmp, "draft8"), n=300_000, n_genomes=8, contigs=60))
+    run("draft20x1m", lambda: synth.draft_set(os.path.join(tmp, "draft20"), n=1_000_000, n_genomes=20, contigs=300))
+    return e2e
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--e2e-only":     # regenerate / add single end-to-end goldens
+        tmp = tempfile.mkdtemp()
+        mref, mqs = mers_paths(tmp)
+        path = os.path.join(HERE, "e2e.json")
+        e2e = e2e_goldens(tmp, mref, mqs, only=set(sys.argv[2:]), e2e=json.load(open(path)))
+        json.dump(e2e, open(path, "w"), indent=1)
+        shutil.rmtree(tmp)
+        print("e2e goldens:", sorted(e2e))
+        return
     R = oracles.load_reference()
     # ---- G5
     rng = np.random.default_rng(4)
@@ -87,30 +129,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "mers_anchor.npz"), k=k, lon=lon, sp=sp, fwd=fw, masterUP=mu, masterEP=me)
 
     # ---- G3
-    e2e = {}
-
-    def run(name, rp, qs, **kw):
-        out = os.path.join(tmp, "out_" + name)
-        rc, _ = driver.run_core(REFBIN, rp, qs, out, **kw)
-        assert rc == 0, name
-        x = os.path.join(out, "parsnpAligner.xmfa")
-        e2e[name] = dict(xmfa_md5=xmfa_util.md5(x), signature=xmfa_util.mum_lcb_signature(x),
-                         log=xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")),
-                         ref_records=[h for h, _ in xmfa_util.records(x)[1] if h.startswith("> 1:")][:50])
-    # file names matter (##SequenceFile): MERS under its own names, synthetic sets as ref.fna / g%04d.fna
-    run("mers", mref, mqs)
-    for name in ("viral50", "pop6x200k", "rearr6x300k", "pop20x1m", "bact8"):   # the last one takes ~80 s
-        r, gs = synth.make(name)
-        rp, qs = synth.write_set(os.path.join(tmp, name), r, gs)
-        run(name, rp, qs)
-    r, gs = synth.make("poprearr10x400k")
-    rp, qs = synth.write_set(os.path.join(tmp, "poprearr10x400k"), r, gs)
-    run("poprearr10x400k", rp, qs)
-    rp, qs = synth.messy_set(os.path.join(tmp, "messy"))
-    run("messy", rp, qs)
-    r, gs = synth.make("pop6x200k")
-    rp, qs = synth.write_set(os.path.join(tmp, "pchunk"), r, gs)
-    run("pchunk", rp, qs, partpos=66660)      # 3 reference chunks + the <50 bp tail rule (src/parsnp.cpp:1527-1538)
+    e2e = e2e_goldens(tmp, mref, mqs)
     json.dump(e2e, open(os.path.join(HERE, "e2e.json"), "w"), indent=1)
     # ---- G4: calcmumi=1 -> all.mumi
     mumi = {}

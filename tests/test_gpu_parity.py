@@ -180,7 +180,7 @@ def test_parsnp_core_calcmumi(libs, tmp_path, name):
     test_host_logic.check_mumi(CORE_BIN, name, str(tmp_path))
 
 
-@pytest.mark.parametrize("name", ["poprearr10x400k", "messy", "pchunk"])
+@pytest.mark.parametrize("name", ["poprearr10x400k", "messy", "pchunk", "draft8x300k", "draft20x1m"])
 def test_parsnp_core_harsh_inputs(libs, tmp_path, name):
     rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
     out = str(tmp_path / "out")

@@ -44,6 +44,10 @@ def harsh_inputs(name, base):
         return synth.write_set(os.path.join(base, "in"), r, gs) + ({},)
     if name == "messy":
         return synth.messy_set(os.path.join(base, "in")) + ({},)
+    if name == "draft8x300k":
+        return synth.draft_set(os.path.join(base, "in"), n=300_000, n_genomes=8, contigs=60) + ({},)
+    if name == "draft20x1m":
+        return synth.draft_set(os.path.join(base, "in"), n=1_000_000, n_genomes=20, contigs=300) + ({},)
     if name == "pchunk":
         r, gs = synth.make("pop6x200k")
         return synth.write_set(os.path.join(base, "in"), r, gs) + (dict(partpos=66660),)
@@ -51,10 +55,11 @@ def harsh_inputs(name, base):
     return synth.write_set(os.path.join(base, "in"), r, gs) + ({},)
 
 
-@pytest.mark.parametrize("name", ["poprearr10x400k", "messy", "pchunk"])
+@pytest.mark.parametrize("name", ["poprearr10x400k", "messy", "pchunk", "draft8x300k"])
 def test_harsh_inputs(cpu_checkers, tmp_path, name):
     """rearranged 5 %-divergent population (asymmetric regions, reverse LCBs); multi-contig / IUPAC / CRLF / lower-case
-    FASTA; reference longer than the chunk size p (3 chunks + the <50 bp tail rule)"""
+    FASTA; reference longer than the chunk size p (3 chunks + the <50 bp tail rule); draft assemblies (60 shuffled,
+    half reverse-complemented contigs per genome, joined by N runs)"""
     rp, qs, kw = harsh_inputs(name, str(tmp_path))
     out = str(tmp_path / "out")
     rc, _ = driver.run_core(cpu_checkers, rp, qs, out, **kw)
@@ -110,6 +115,10 @@ def mumi_inputs(name, base):
         return mers(base=base) + ({},)
     if name == "messy":
         return synth.messy_set(os.path.join(base, "in")) + ({},)
+    if name == "draft8x300k":
+        return synth.draft_set(os.path.join(base, "in"), n=300_000, n_genomes=8, contigs=60) + ({},)
+    if name == "draft20x1m":
+        return synth.draft_set(os.path.join(base, "in"), n=1_000_000, n_genomes=20, contigs=300) + ({},)
     r, gs = synth.make("pop6x200k")
     return synth.write_set(os.path.join(base, "in"), r, gs) + (dict(partpos=40000),)
 
