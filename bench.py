@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--workload", default="bact200")
     ap.add_argument("--genomes", type=int, default=0, help="override the number of query genomes per partition")
     ap.add_argument("--cpu-sample", type=int, default=2, help="query genomes in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--host-threads", type=int, default=16, help="ini [LCB] cores: host threads for ingest, candidate validation, output")
+    ap.add_argument("--host-threads", type=int, default=24, help="ini [LCB] cores: host threads for ingest, candidate validation, output")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
@@ -150,8 +150,11 @@ def main():
             t0 = time.perf_counter()
             reports = []
             merged_bp = None
+            step_ms = []
             for _ in range(args.steps):
+                ts = time.perf_counter()
                 rep = run.step()
+                step_ms.append(round(1e3 * (time.perf_counter() - ts), 2))
                 if dist is not None:
                     # partition mode's exchange step: every rank's LCB reference intervals are all-gathered (RCCL) and
                     # intersected -- the positions aligned in EVERY partition (partition.py:35-61, 539-583)
@@ -189,7 +192,7 @@ def main():
                     phases[k] = phases.get(k, 0.0) + v / len(reports)
                 for k, v in r["engine_ms"].items():
                     totals[k] = totals.get(k, 0.0) + v / len(reports)
-            kernels = {k: v for k, v in totals.items() if k not in ("setup", "download", "units")}
+            kernels = {k: v for k, v in totals.items() if k not in ("setup", "download", "units", "call_wall")}
             dom = max(kernels, key=kernels.get) if kernels else None
             launches = sum(r["finder_calls"] for r in reports) / len(reports)          # engine launches per step
             alg_step = sum(r["alg_bytes"] for r in reports) / len(reports)             # SURVEY 8d bytes of all of them
@@ -218,10 +221,11 @@ def main():
                               ", ".join("%s=%s" % (k, v) for k, v in sorted(kw.items()) if k not in ("n", "n_genomes")),
                               "" if world == 1 else "; one partition per rank, %d ranks" % world),
                            "genomes_per_gpu": G, "genome_bp": n_ref, "host_threads": args.host_threads, "parallelism": "partition-per-gpu x%d" % world},
+                "step_ms": step_ms,
                 "core_bp_aligned": core_bp_total,
                 "core_bp_in_every_partition": merged_bp,
                 "mums": rep["mums"], "anchors": rep["anchors"], "lcbs": rep["lcbs"],
-                "split_s": {"path": rep["path_s"], "anchor": rep["anchor_s"], "extend": rep["extend_s"], "lcb": rep["lcb_s"],
+                "split_s": {"path": rep["path_s"], "setup": rep.get("setup_s"), "anchor": rep["anchor_s"], "extend": rep["extend_s"], "lcb": rep["lcb_s"],
                             "engine_calls_wall": rep["finder_s"], "ingest": rep["ingest_s"], "upload": rep["upload_s"],
                             "output": output_s, "generate": gen_s},
                 "host_split_s": rep.get("host_split_s"),

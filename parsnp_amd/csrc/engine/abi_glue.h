@@ -2,6 +2,7 @@
 // Included exactly once by a translation unit that has defined `PmBackend` (the backend type),
 // `pm_backend_name` and `pm_backend_open(int device, std::string* err)`.
 #pragma once
+#include <chrono>
 #include <memory>
 #include <new>
 
@@ -58,10 +59,13 @@ int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, 
     if (!s || !out || n_regions < 0 || (n_regions > 0 && (!starts || !lens || !minsize))) return fail(PM_EINVAL, "bad argument");
     try {
         std::unique_ptr<pm_result> r(new pm_result);
+        const auto w0 = std::chrono::steady_clock::now();
         int rc = s->engine->run(n_regions, starts, lens, minsize, &r->r);
         if (rc) return fail(rc, s->engine->error);
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
         s->timing = s->engine->timing;
+        // wall clock of the whole call on the host (uploads, launches, waits, result assembly) next to the device phases
+        s->timing.push_back(pm::PhaseTime{"call_wall", std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count()});
         *out = r.release();
         return PM_OK;
     } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed"); }

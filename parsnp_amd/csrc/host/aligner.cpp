@@ -222,6 +222,7 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out)
         mins[i] = reqs[i].minsize;
         for (size_t g = 1; g < n; g++) stats.alg_bytes += (double)reqs[i].len[g] * 16.25 + 16.0 * (double)reqs[i].len[0];
     }
+    stats.t_pack += now_s() - t0;
     pm_result* res = nullptr;
     int rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);
     if (rc != PM_OK) fatal(std::string("multi-MUM engine failed: ") + pm_last_error());
@@ -729,16 +730,6 @@ void Aligner::filter_mums(int rvalue) {
     stats.filter_s += now_s() - t0;
 }
 
-static Lcb lcb_of(const std::vector<Mum>& pool, size_t n, int idx, int type = 1) {   // Cluster(TMum), LCB.cpp:21-28
-    Lcb c;
-    c.type = type;
-    c.mums.push_back(idx);
-    c.start.assign(pool[(size_t)idx].start, pool[(size_t)idx].start + n);
-    c.end.assign(pool[(size_t)idx].end, pool[(size_t)idx].end + n);
-    c.length = pool[(size_t)idx].length;
-    return c;
-}
-
 // Greedy collinear chaining of the MUMs in reference order (setFinalClusters :2563-2719).  The float32 / double
 // mix of the gap-ratio test is the reference's.
 void Aligner::chain() {
@@ -751,58 +742,71 @@ void Aligner::chain() {
         for (size_t i = 0; i < mums.size(); i++) mums[i] = h[i].idx;
     }
     if (mums.empty()) return;
-    Lcb cluster = lcb_of(pool, n, mums[0]);
-    bool addmum = true;
     const int d = prm.d;
     const float diag_diff = prm.diag_diff;
-    for (size_t x = 1; x < mums.size(); x++) {
-        const Mum& nt = pool[(size_t)mums[x]];
-        if (nt.length < random) { addmum = true; continue; }
-        if (!addmum) cluster = lcb_of(pool, n, mums[x - 1]);
-        addmum = true;
+    // the test of one MUM against the open chain (:2596-2700).  It reads the chain only through its last MUM: the chain
+    // end IS that MUM's end, and every member has the strand flags of the first, so "back" decides alone.
+    enum : uint8_t { JOIN = 0, CLOSE = 1, PASS = 2 };
+    auto judge = [&](const Mum& nt, const Mum& back) -> uint8_t {
+        bool addmum = true;
         float max_gap = 0;
         float min_gap = d + 10;
-        const Mum& back = pool[(size_t)cluster.mums.back()];
-        const Mum& front = pool[(size_t)cluster.mums.front()];
+        const long* cend = back.end;
         for (size_t k = 0; k < n; k++) {
-            const long fgap = nt.start[k] - cluster.end[k];      // forward: next start - chain end
+            const long fgap = nt.start[k] - cend[k];             // forward: next start - chain end
             const long rgap = back.start[k] - nt.end[k];         // reverse: previous MUM start - next end
             const bool f = nt.fwd[k] != 0;
             if (f && fgap > max_gap) max_gap = fgap;
             else if (!f && rgap > max_gap) max_gap = fgap;       // sic (:2608-2611)
             if (f && fgap < min_gap) min_gap = fgap;
             else if (!f && rgap < min_gap) min_gap = rgap;
-            if ((nt.fwd[k] != back.fwd[k]) || (nt.fwd[k] != front.fwd[k])) addmum = false;
+            if (nt.fwd[k] != back.fwd[k]) addmum = false;
             else if (f && fgap < 0) addmum = false;
             else if (!f && fgap >= 0) addmum = false;
             else if (f && fgap > d) addmum = false;
             else if (!f && rgap > d) addmum = false;
             if (!addmum) break;
         }
-        if (addmum) {
-            if (min_gap == 0) min_gap = 1;
-            if (max_gap == 0) max_gap = 1;
-            bool join;
-            if (diag_diff > 1.0) {
-                join = max_gap - min_gap < diag_diff;
-                if (!join) continue;   // neither joined nor closed: the MUM is passed over (:2684-2692)
-            } else {
-                join = min_gap / max_gap >= 1.0 - diag_diff;
-            }
-            if (join) {
-                cluster.end.assign(nt.end, nt.end + n);
-                cluster.length += nt.length;
-                cluster.mums.push_back(mums[x]);
-            } else {
-                addmum = false;
-                lcbs.push_back(cluster);
-            }
+        if (!addmum) return CLOSE;
+        if (min_gap == 0) min_gap = 1;
+        if (max_gap == 0) max_gap = 1;
+        if (diag_diff > 1.0) return max_gap - min_gap < diag_diff ? JOIN : PASS;   // PASS: neither joined nor closed (:2684-2692)
+        return min_gap / max_gap >= 1.0 - diag_diff ? JOIN : CLOSE;
+    };
+    // almost always the chain's last MUM is the previous MUM of the list: those verdicts are independent, computed ahead
+    const long m = (long)mums.size();
+    std::vector<uint8_t> ahead((size_t)m, CLOSE);
+#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 4096)
+    for (long x = 1; x < m; x++) ahead[(size_t)x] = judge(pool[(size_t)mums[(size_t)x]], pool[(size_t)mums[(size_t)x - 1]]);
+
+    auto open_chain = [&](int idx) { Lcb c; c.type = 1; c.mums.push_back(idx); c.length = pool[(size_t)idx].length; return c; };
+    auto close_chain = [&](Lcb& c) {      // start of the first MUM, end of the last (Cluster(TMum) LCB.cpp:21-28 + the joins)
+        const Mum& f = pool[(size_t)c.mums.front()];
+        const Mum& b = pool[(size_t)c.mums.back()];
+        c.start.assign(f.start, f.start + n);
+        c.end.assign(b.end, b.end + n);
+        lcbs.push_back(c);
+    };
+    Lcb cluster = open_chain(mums[0]);
+    bool addmum = true;
+    for (long x = 1; x < m; x++) {
+        const Mum& nt = pool[(size_t)mums[(size_t)x]];
+        if (nt.length < random) { addmum = true; continue; }
+        if (!addmum) cluster = open_chain(mums[(size_t)x - 1]);
+        addmum = true;
+        const int back = cluster.mums.back();
+        const uint8_t v = back == mums[(size_t)x - 1] ? ahead[(size_t)x] : judge(nt, pool[(size_t)back]);
+        if (v == PASS) continue;
+        if (v == JOIN) {
+            cluster.length += nt.length;
+            cluster.mums.push_back(mums[(size_t)x]);
         } else {
-            lcbs.push_back(cluster);
+            addmum = false;
+            close_chain(cluster);
         }
     }
-    if (!addmum) cluster = lcb_of(pool, n, mums.back());
-    lcbs.push_back(cluster);
+    if (!addmum) cluster = open_chain(mums.back());
+    close_chain(cluster);
     stats.lcb_s += now_s() - t0;
 }
 

@@ -39,14 +39,14 @@ const char* pc_step(pc_run* r) {
     const StepReport& s = r->last;
     std::ostringstream o;
     o.precision(9);
-    o << "{\"provider\": \"" << pm_provider() << "\", \"queries\": " << r->run.qfiles << ", \"path_s\": " << s.path_s << ", \"anchor_s\": " << s.anchor_s
+    o << "{\"provider\": \"" << pm_provider() << "\", \"queries\": " << r->run.qfiles << ", \"setup_s\": " << s.setup_s << ", \"path_s\": " << s.path_s << ", \"anchor_s\": " << s.anchor_s
       << ", \"extend_s\": " << s.extend_s << ", \"filter_s\": " << s.filter_s << ", \"lcb_s\": " << s.lcb_s << ", \"finder_s\": " << s.finder_s
       << ", \"ingest_s\": " << r->run.ingest_s << ", \"upload_s\": " << r->run.upload_s << ", \"anchors\": " << s.anchors << ", \"mums\": " << s.mums
       << ", \"lcbs\": " << s.lcbs << ", \"core_bp\": " << s.core_bp << ", \"alg_bytes\": " << (long long)s.alg_bytes << ", \"finder_calls\": " << s.finder_calls << ", \"finder_regions\": "
       << s.finder_regions << ", \"regions_processed\": " << s.regions_processed << ", \"cache_hits\": " << s.cache_hits << ", \"cache_misses\": "
       << s.cache_misses << ", \"spec_rounds\": " << s.spec_rounds << ", \"mums_found\": " << (s.mums_found ? "true" : "false")
       << ", \"host_split_s\": {\"validate\": " << s.host.t_validate << ", \"neighbour\": " << s.host.t_neighbour << ", \"key\": " << s.host.t_key
-      << ", \"sweep\": " << s.host.t_sweep << ", \"replay\": " << s.host.t_replay << ", \"sort\": " << s.host.t_sort << ", \"unpack\": " << s.host.t_unpack << "}"
+      << ", \"sweep\": " << s.host.t_sweep << ", \"replay\": " << s.host.t_replay << ", \"sort\": " << s.host.t_sort << ", \"unpack\": " << s.host.t_unpack << ", \"pack\": " << s.host.t_pack << "}"
       << ", \"tie_fallbacks\": " << s.host.tie_fallbacks << ", \"literal_iterations\": " << s.host.literal_iterations;
     for (int which = 0; which < 2; which++) {
         o << ", \"" << (which ? "anchor_ms" : "engine_ms") << "\": {";

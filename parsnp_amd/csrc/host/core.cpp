@@ -138,7 +138,10 @@ int CoreRun::mumi() {
 
 StepReport CoreRun::step() {
     StepReport r;
+    const double ts = now_s();
+    align.reset();
     align.reset(new Aligner(genomes, prm, session));
+    r.setup_s = now_s() - ts;
     Aligner& a = *align;
     time_t start, end;
     time(&start);
@@ -168,10 +171,13 @@ StepReport CoreRun::step() {
         }
         time(&start);
         std::cerr << "Creating and verifying final LCBs..." << std::endl;
-        a.chain();
-        a.filter_lcbs();
-        a.chain();
-        a.fill_between();
+        const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+        double tl = now_s();
+        auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[lcb] %-12s %.4f s\n", what, t - tl); tl = t; } };
+        a.chain(); lap("chain");
+        a.filter_lcbs(); lap("filter_lcbs");
+        a.chain(); lap("chain");
+        a.fill_between(); lap("fill_between");
         time(&end);
         a.iclusters_time = (float)difftime(end, start);
         printf("        LCBs created, elapsed time: %.0lf seconds\n\n", difftime(end, start));
