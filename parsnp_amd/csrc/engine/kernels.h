@@ -287,21 +287,28 @@ PM_HD uint64_t index_resolve(const Packed& P, const RegionInfo& ri, const uint64
         seen = slots[ri.tbase + h];
     }
 }
-// -> slot value of the K-mer `tag` in region ri, or kEmpty
-PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_t* slots, const uint32_t* filter, uint64_t tag) {
+// -> slot value of the K-mer `tag` in region ri, or kEmpty.  both: fetch the filter word and the first slot together
+// (one memory latency instead of two on a hit; one more probe on a miss)
+PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_t* slots, const uint32_t* filter, uint64_t tag, bool both = false) {
     const uint64_t hv = hash_tag(tag);
-    {
-        const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
-        if (!((filter[ri.fbase + (bit >> 5)] >> (bit & 31)) & 1u)) return kEmpty;
-    }
     const uint64_t fp = hv & 0xffffffff00000000ull;
     uint32_t h = (uint32_t)hv & ri.tmask;
     const int64_t base = P.goff[0] + ri.ref_pos;
+    const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
+    uint64_t seen;
+    if (both) {
+        const uint32_t fw = filter[ri.fbase + (bit >> 5)];
+        seen = slots[ri.tbase + h];
+        if (!((fw >> (bit & 31)) & 1u)) return kEmpty;
+    } else {
+        if (!((filter[ri.fbase + (bit >> 5)] >> (bit & 31)) & 1u)) return kEmpty;
+        seen = slots[ri.tbase + h];
+    }
     for (;;) {
-        uint64_t seen = slots[ri.tbase + h];
         if (seen == kEmpty) return kEmpty;
         if ((seen & 0xffffffff00000000ull) == fp && kmer_tag(P, base + slot_head(seen), ri.K) == tag) return seen;
         h = (h + 1) & ri.tmask;
+        seen = slots[ri.tbase + h];
     }
 }
 
@@ -309,7 +316,9 @@ PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_
 // (= the uniqueness point pos_label-l of mum.c:219-224 wherever it can influence the output; SURVEY 3.3-1,-7.)
 struct RepeatLength {
     Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;
-    const uint64_t* slots; const uint32_t* filter; const int32_t* next; int32_t* rep; uint32_t* err; int64_t budget;
+    const uint64_t* slots; const uint32_t* filter; const int32_t* next; int32_t* rep; uint32_t* repeated; uint32_t* err; int64_t budget;
+    // repeated: one bit per flat reference position, set when the K-mer starting there occurs elsewhere in R (rep' >= K);
+    // n/8 bytes, L2 resident -- SeedExtend's followers read it instead of probing the index
     PM_HD void operator()(int64_t tid) const {
         int64_t r = upper_slot(posbase, nregions, tid);
         const RegionInfo& ri = R[r];
@@ -332,6 +341,7 @@ struct RepeatLength {
             }
         }
         rep[tid] = best;
+        if (best) atomic_or32(&repeated[tid >> 5], 1u << (tid & 31));
     }
 };
 
@@ -367,13 +377,20 @@ struct FillUnits {
 struct SeedExtend {
     Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen;
     const int32_t* unit_pair; const int32_t* unit_info;
-    const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep;
+    const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep; const uint32_t* repeated;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
-    int debug;   // PM_DEBUG_SEED experiments (profiling only; results are wrong when set): 1 no emit, 2 stop after lookup, 4 stop after left arm
+    int debug;   // PM_DEBUG_SEED experiments (profiling only; results are wrong when set): 1 no emit, 2 stop after lookup, 4 stop after left arm; 64 stop after the query K-mer, 128 stop after the right arm, 256 / 512 one strand only; 8 = every lane probes the index itself, 16 / 32 = variants with the same results (filter+slot fetched together, rep fetched before the right arm)
     PM_HD void operator()(int64_t tid) const {
         int64_t unit = tid >> 6; int lane = (int)(tid & 63);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the unit is the same for the 64 lanes of a wavefront: say so, and its record (pair, region, lengths, offsets)
+        // is fetched with scalar loads instead of 64-lane vector loads of one address
+        unit = (int64_t)__builtin_amdgcn_readfirstlane((int)unit);
+#endif
         int32_t pair = unit_pair[unit]; int32_t info = unit_info[unit];
         int strand = info & 1; int64_t chunk = info >> 1;
+        if ((debug & 256) && strand) return;     // profiling: forward-strand units only
+        if ((debug & 512) && !strand) return;    // profiling: reverse-strand units only
         const uint32_t nqq = (uint32_t)(ngen - 1);
         int64_t r = (int64_t)((uint32_t)pair / nqq); int g = (int)((uint32_t)pair % nqq) + 1;
         const RegionInfo& ri = R[r];
@@ -399,9 +416,46 @@ struct SeedExtend {
             bk[u] = kEmpty; bv[u] = 0;
             const int32_t sidx = (int32_t)chunk * kUnitSamples + u * 64 + lane;
             const int64_t j = (int64_t)sidx * ri.stride;
-            if (stop || j + K > m) continue;
-            uint64_t tag = kmer_tag(P, qbase + j, K);
-            uint64_t slot = index_lookup(P, ri, slots, filter, tag);
+            const bool valid = !stop && j + K <= m;
+            const uint64_t tag = valid ? kmer_tag(P, qbase + j, K) : 0;
+            if (debug & 64) { if (tag == 12345) atomic_or32(err, 2u); continue; }
+            // Index probes are the scarce resource (random 64-B requests at the fabric's request rate).  Consecutive lanes
+            // hold consecutive samples, and inside a match the K-mer of sample s+t sits t*stride bases after the K-mer of
+            // sample s.  So only every 8th lane (a leader) probes the index; a follower first looks where its leader's
+            // hit predicts its own K-mer: if the reference K-mer there equals its own and occurs nowhere else in R, that
+            // position is what the probe would have returned (two L2-resident loads).  Otherwise it probes itself.
+            uint64_t slot = kEmpty;
+            const int sub = lane & 7;
+            const bool follow = ri.stride <= K && m >= 64 * (int64_t)ri.stride && !(debug & 8);   // short query pieces (recursion): one probe phase is faster
+            int32_t lead = -1;
+            if (follow) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (valid && sub == 0) slot = index_lookup(P, ri, slots, filter, tag, (debug & 16) != 0);
+                const int32_t mine = (sub == 0 && slot != kEmpty && !(slot & kMulti)) ? slot_head(slot) : -1;
+                lead = __shfl(mine, lane & ~7, 64);
+#else
+                // host emulation (one thread at a time): the leader's probe is recomputed by each of its followers
+                if (sub == 0) { if (valid) slot = index_lookup(P, ri, slots, filter, tag); }
+                else if (valid) {
+                    const uint64_t ls = index_lookup(P, ri, slots, filter, kmer_tag(P, qbase + j - (int64_t)sub * ri.stride, K));
+                    if (ls != kEmpty && !(ls & kMulti)) lead = slot_head(ls);
+                }
+#endif
+                if (valid && sub != 0) {
+                    bool predicted = false;
+                    if (lead >= 0) {
+                        const int32_t cand = lead + sub * ri.stride;
+                        const int64_t fp = ri.posbase + cand;
+                        if (cand + K <= ri.nR && !((repeated[fp >> 5] >> (fp & 31)) & 1u) && kmer_tag(P, rbase + cand, K) == tag) {
+                            slot = (uint64_t)(uint32_t)cand;     // a unique K-mer: head = cand, no chain
+                            predicted = true;
+                        }
+                    }
+                    if (!predicted) slot = index_lookup(P, ri, slots, filter, tag, (debug & 16) != 0);
+                }
+            } else if (valid) {
+                slot = index_lookup(P, ri, slots, filter, tag, (debug & 16) != 0);
+            }
             if (slot == kEmpty) continue;
             if (debug & 2) { if (slot == 12345) atomic_or32(err, 2u); continue; }
             const bool multi = (slot & kMulti) != 0;
@@ -413,12 +467,14 @@ struct SeedExtend {
                 int32_t left = lce_bwd(P, qbase + j, rbase + l, lim);
                 if (left >= ri.stride) continue;
                 if (debug & 4) { if (left == 12345) atomic_or32(err, 2u); continue; }
+                const int32_t rep_early = (debug & 32) ? rep[ri.posbase + l - left] : 0;   // issued before the right arm's loads
                 int64_t mr = m - j - K; int32_t rr = ri.nR - l - K;
                 int32_t right = lce_fwd(P, qbase + j + K, rbase + l + K, (int32_t)(mr < rr ? mr : rr));
                 int32_t len = left + K + right;
+                if (debug & 128) { if (len == 123456789) atomic_or32(err, 2u); continue; }
                 if (len < ri.minlen) continue;
                 int32_t l0 = l - left; int64_t j0 = j - left;
-                if (len <= rep[ri.posbase + l0]) continue;           // not unique in R
+                if (len <= ((debug & 32) ? rep_early : rep[ri.posbase + l0])) continue;           // not unique in R
                 if (debug & 1) { if (len == 123456789) atomic_or32(err, 2u); continue; }
                 const uint64_t ek = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
                 const uint64_t evv = ((uint64_t)j0 << 32) | (uint32_t)len;
