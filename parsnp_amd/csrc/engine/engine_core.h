@@ -180,8 +180,8 @@ public:
         int64_t nunits = 0;
         be.d2h(&nunits, d_uoff.p + npairs, 8);
         if (nunits >= (1ll << 31)) { error = "too many work units in one batch"; return -5; }
-        ensure(d_upair, (size_t)std::max<int64_t>(nunits, 1)); ensure(d_uinfo, (size_t)std::max<int64_t>(nunits, 1));
-        be.launch("fill_units", nunits, FillUnits{d_uoff.p, d_ucount.p, npairs, d_upair.p, d_uinfo.p});
+        ensure(d_units, (size_t)std::max<int64_t>(nunits, 1));
+        be.launch("fill_units", nunits, FillUnits{P, d_starts.p, d_lens.p, ngen, d_uoff.p, d_ucount.p, npairs, d_units.p});
 
         // -- events: kSlices append buffers (retry with larger ones on overflow), gathered, then sorted by (pair, l, strand)
         ensure(d_counter, (size_t)kSlices * kSliceStride);
@@ -195,7 +195,7 @@ public:
             be.memset(d_counter.p, 0, 8 * (size_t)kSlices * kSliceStride);
             be.mark("seed_extend");
             be.launch("seed_extend", nunits * 64,
-                      SeedExtend{P, d_R.p, d_starts.p, d_lens.p, ngen, d_upair.p, d_uinfo.p, d_slots.p, d_filter.p, d_next.p, d_rep.p, d_repeated.p,
+                      SeedExtend{P, d_R.p, d_units.p, d_slots.p, d_filter.p, d_next.p, d_rep.p, d_repeated.p,
                                  d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err.p, work_budget,
                                  getenv("PM_DEBUG_SEED") ? atoi(getenv("PM_DEBUG_SEED")) : 0});
             be.d2h(counts.data(), d_counter.p, 8 * counts.size());
@@ -358,7 +358,7 @@ public:
     void release() {
         auto drop = [&](auto& b) { if (b.p) be.free(b.p); b.p = nullptr; b.cap = 0; };
         drop(d_R); drop(d_starts); drop(d_lens); drop(d_posbase); drop(d_tilebase); drop(d_err); drop(d_slots); drop(d_filter); drop(d_next);
-        drop(d_rep); drop(d_repeated); drop(d_epm); drop(d_ucount); drop(d_uoff); drop(d_upair); drop(d_uinfo); drop(d_counter); drop(d_evkey); drop(d_evval);
+        drop(d_rep); drop(d_repeated); drop(d_epm); drop(d_ucount); drop(d_uoff); drop(d_units); drop(d_counter); drop(d_evkey); drop(d_evval);
         drop(d_evkey2); drop(d_evval2); drop(d_evkey3); drop(d_evval3); drop(d_sliceoff); drop(d_lo); drop(d_cov); drop(d_state); drop(d_summary); drop(d_startshere); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
         drop(d_ok_k); drop(d_ok_lon); drop(d_osp); drop(d_ofwd);
         if (blk) be.free(blk);
@@ -386,7 +386,7 @@ private:
     size_t ev_cap_hint = 0, cand_cap_hint = 0;
     Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase, d_tilebase; Buf<uint32_t> d_err;
     Buf<uint64_t> d_slots; Buf<uint32_t> d_filter, d_repeated; Buf<int32_t> d_next, d_rep, d_epm;
-    Buf<int64_t> d_ucount, d_uoff; Buf<int32_t> d_upair, d_uinfo;
+    Buf<int64_t> d_ucount, d_uoff; Buf<UnitRec> d_units;
     Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2, d_evkey3, d_evval3; Buf<int64_t> d_sliceoff;
     Buf<int64_t> d_lo, d_cov; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
     Buf<uint64_t> d_cand, d_cand2; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;

@@ -94,6 +94,22 @@ PM_HD uint64_t wave_reserve(uint64_t* counter, uint32_t n) {
     uint64_t o = *counter; *counter = o + n; return o;
 #endif
 }
+// the same for at most one slot per lane: ballot + popcount instead of a 6-step shuffle scan
+PM_HD uint64_t wave_reserve01(uint64_t* counter, bool want) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return 0;
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const int first = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if ((int)__lane_id() == first) base = atomicAdd((unsigned long long*)counter, (unsigned long long)__popcll(mask));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, first);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), first);
+    return (((uint64_t)hi << 32) | lo) + before;
+#else
+    uint64_t o = *counter; *counter = o + (want ? 1 : 0); return o;
+#endif
+}
 PM_HD void atomic_max32(int32_t* p, int32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicMax(p, v);
@@ -149,11 +165,11 @@ constexpr uint32_t kErrWork = 1u;  // per-thread work budget exceeded (degenerat
 PM_HD void window(const SeqBlock* blk, int64_t p, uint64_t* bits, uint32_t* mask) {
     int64_t w = p >> 5;
     int sh = (int)(p & 31);
+    // both blocks always (guard blocks exist), no branch: for sh = 0 the second term shifts out completely
     SeqBlock lo = blk[w];
-    if (sh == 0) { *bits = lo.b2; *mask = lo.nm; return; }
     SeqBlock hi = blk[w + 1];
-    *bits = (lo.b2 >> (2 * sh)) | (hi.b2 << (64 - 2 * sh));
-    *mask = (lo.nm >> sh) | (hi.nm << (32 - sh));
+    *bits = (lo.b2 >> (2 * sh)) | ((hi.b2 << 1) << (63 - 2 * sh));
+    *mask = (lo.nm >> sh) | ((hi.nm << 1) << (31 - sh));
 }
 // number of equal bases going right from (a, b), at most maxlen
 PM_HD int32_t lce_fwd(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
@@ -358,14 +374,31 @@ struct CountUnits {
         count[pair] = 2 * ((ns + kUnitSamples - 1) / kUnitSamples);
     }
 };
+// everything a SeedExtend wavefront needs to know about its unit, in one 32-byte record (one scalar load)
+struct alignas(32) UnitRec {
+    int64_t qbase;      // global base offset of the query piece on this unit's strand
+    int32_t region;     // index into RegionInfo
+    int32_t pair;       // region * (ngen-1) + (query genome - 1): the event key prefix
+    int32_t m;          // length of the query piece
+    int32_t info;       // chunk << 1 | strand
+    int32_t pad_[2];
+};
 // tid = work unit: which (pair, strand, chunk) it is (off[] = exclusive prefix of the per-pair unit counts)
 struct FillUnits {
-    const int64_t* off; const int64_t* count; int64_t npairs; int32_t* unit_pair; int32_t* unit_info;
+    Packed P; const int64_t* starts; const int64_t* lens; int32_t ngen;
+    const int64_t* off; const int64_t* count; int64_t npairs; UnitRec* units;
     PM_HD void operator()(int64_t tid) const {
         int64_t pair = upper_slot(off, npairs, tid);     // the last pair whose first unit is <= tid owns it
         int64_t u = tid - off[pair], half = count[pair] / 2;
-        unit_pair[tid] = (int32_t)pair;
-        unit_info[tid] = (int32_t)(u < half ? (u << 1) : (((u - half) << 1) | 1));
+        const int64_t r = pair / (ngen - 1); const int g = (int)(pair % (ngen - 1)) + 1;
+        const int strand = u < half ? 0 : 1;
+        const int64_t m = lens[r * ngen + g], qs = starts[r * ngen + g];
+        UnitRec rec;
+        rec.qbase = strand ? P.goff[2 * g + 1] + (P.glen[g] - qs - m) : P.goff[2 * g] + qs;   // reverse strand: the piece, mirrored
+        rec.region = (int32_t)r; rec.pair = (int32_t)pair; rec.m = (int32_t)m;
+        rec.info = (int32_t)(strand ? (((u - half) << 1) | 1) : (u << 1));
+        rec.pad_[0] = rec.pad_[1] = 0;
+        units[tid] = rec;
     }
 };
 
@@ -375,8 +408,7 @@ struct FillUnits {
 // lane, lane+64, lane+128, lane+192 of its unit; sample s sits at query offset s*stride.  A match of length
 // >= minlen contains >= 1 whole sampled K-mer; it is reported from the first one only.
 struct SeedExtend {
-    Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen;
-    const int32_t* unit_pair; const int32_t* unit_info;
+    Packed P; const RegionInfo* R; const UnitRec* units;
     const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep; const uint32_t* repeated;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
     int debug;   // PM_DEBUG_SEED experiments (profiling only; results are wrong when set): 1 no emit, 2 stop after lookup, 4 stop after left arm; 64 stop after the query K-mer, 128 stop after the right arm, 256 / 512 one strand only; 8 = every lane probes the index itself, 16 / 32 = variants with the same results (filter+slot fetched together, rep fetched before the right arm)
@@ -387,15 +419,14 @@ struct SeedExtend {
         // is fetched with scalar loads instead of 64-lane vector loads of one address
         unit = (int64_t)__builtin_amdgcn_readfirstlane((int)unit);
 #endif
-        int32_t pair = unit_pair[unit]; int32_t info = unit_info[unit];
+        const UnitRec rec = units[unit];
+        const int32_t pair = rec.pair, info = rec.info;
         int strand = info & 1; int64_t chunk = info >> 1;
         if ((debug & 256) && strand) return;     // profiling: forward-strand units only
         if ((debug & 512) && !strand) return;    // profiling: reverse-strand units only
-        const uint32_t nqq = (uint32_t)(ngen - 1);
-        int64_t r = (int64_t)((uint32_t)pair / nqq); int g = (int)((uint32_t)pair % nqq) + 1;
-        const RegionInfo& ri = R[r];
-        const int64_t m = lens[r * ngen + g], qs = starts[r * ngen + g];
-        const int64_t qbase = strand ? P.goff[2 * g + 1] + (P.glen[g] - qs - m) : P.goff[2 * g] + qs;
+        const RegionInfo& ri = R[rec.region];
+        const int64_t m = rec.m;
+        const int64_t qbase = rec.qbase;
         const int64_t rbase = P.goff[0] + ri.ref_pos;
         const int K = ri.K;
         int64_t work = 0;
@@ -485,7 +516,7 @@ struct SeedExtend {
         uint32_t nb = 0;
 #pragma unroll
         for (int u = 0; u < kPer; u++) nb += bk[u] != kEmpty;
-        uint64_t at = wave_reserve(ev_count, nb);
+        uint64_t at = kPer == 1 ? wave_reserve01(ev_count, nb != 0) : wave_reserve(ev_count, nb);
 #pragma unroll
         for (int u = 0; u < kPer; u++)
             if (bk[u] != kEmpty) { if (at < ev_cap) { key_out[at] = bk[u]; val_out[at] = bv[u]; } at++; }

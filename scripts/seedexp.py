@@ -1,4 +1,4 @@
-import sys,time,os; sys.path.insert(0,"."); sys.path.insert(0,"tests")
+import sys,time,os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,"tests"))
 from parsnp_amd import synth
 from parsnp_amd.binding import Lib, Session
 ref,gs=synth.population(seed=5,n=5_000_000,n_genomes=40,div=0.02,indel_frac=0.05)
