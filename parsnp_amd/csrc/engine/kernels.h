@@ -171,6 +171,36 @@ PM_HD void window(const SeqBlock* blk, int64_t p, uint64_t* bits, uint32_t* mask
     *bits = (lo.b2 >> (2 * sh)) | ((hi.b2 << 1) << (63 - 2 * sh));
     *mask = (lo.nm >> sh) | ((hi.nm << 1) << (31 - sh));
 }
+// the same from two blocks already in registers, and matching of two windows
+struct Win { uint64_t b; uint32_t m; };
+PM_HD Win funnel(const SeqBlock& lo, const SeqBlock& hi, int sh) {
+    Win w;
+    w.b = (lo.b2 >> (2 * sh)) | ((hi.b2 << 1) << (63 - 2 * sh));
+    w.m = (lo.nm >> sh) | ((hi.nm << 1) << (31 - sh));
+    return w;
+}
+// window starting t bases (0 <= t < 64) into block b1, out of the consecutive blocks b1, b2, b3
+PM_HD Win funnel3(const SeqBlock& b1, const SeqBlock& b2, const SeqBlock& b3, int t) {
+    const bool up = t >= 32;
+    SeqBlock lo, hi;
+    lo.b2 = up ? b2.b2 : b1.b2; lo.nm = up ? b2.nm : b1.nm; lo.pad = 0;
+    hi.b2 = up ? b3.b2 : b2.b2; hi.nm = up ? b3.nm : b2.nm; hi.pad = 0;
+    return funnel(lo, hi, t & 31);
+}
+PM_HD int match_fwd(const Win& a, const Win& b) {      // equal bases from the first base of both windows, 0..32
+    const uint64_t x = a.b ^ b.b; const uint32_t mx = a.m ^ b.m;
+    const uint64_t d = (x | (x >> 1)) & 0x5555555555555555ull;
+    int c = d ? (ctz64(d) >> 1) : 32;
+    if (mx) { const int cm = ctz32(mx); if (cm < c) c = cm; }
+    return c;
+}
+PM_HD int match_bwd(const Win& a, const Win& b) {      // equal bases from the last base of both windows backwards, 0..32
+    const uint64_t x = a.b ^ b.b; const uint32_t mx = a.m ^ b.m;
+    const uint64_t d = (x | (x >> 1)) & 0x5555555555555555ull;
+    int c = d ? (clz64(d) >> 1) : 32;
+    if (mx) { const int cm = clz32(mx); if (cm < c) c = cm; }
+    return c;
+}
 // number of equal bases going right from (a, b), at most maxlen
 PM_HD int32_t lce_fwd(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
     int32_t n = 0;
@@ -328,6 +358,21 @@ PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_
     }
 }
 
+// -> first slot of the probe sequence that carries the fingerprint of `tag` (NOT confirmed against the reference K-mer:
+// the caller reads those bases anyway and falls back to index_lookup on the 2^-32 mismatch), or kEmpty
+PM_HD uint64_t index_probe(const RegionInfo& ri, const uint64_t* slots, const uint32_t* filter, uint64_t tag) {
+    const uint64_t hv = hash_tag(tag);
+    const uint64_t fp = hv & 0xffffffff00000000ull;
+    uint32_t h = (uint32_t)hv & ri.tmask;
+    const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
+    if (!((filter[ri.fbase + (bit >> 5)] >> (bit & 31)) & 1u)) return kEmpty;
+    for (;;) {
+        const uint64_t seen = slots[ri.tbase + h];
+        if (seen == kEmpty || (seen & 0xffffffff00000000ull) == fp) return seen;
+        h = (h + 1) & ri.tmask;
+    }
+}
+
 // rep'[l]: longest prefix of R[l..) that occurs at another position of R if that is >= K, else 0.
 // (= the uniqueness point pos_label-l of mum.c:219-224 wherever it can influence the output; SURVEY 3.3-1,-7.)
 struct RepeatLength {
@@ -411,7 +456,7 @@ struct SeedExtend {
     Packed P; const RegionInfo* R; const UnitRec* units;
     const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep; const uint32_t* repeated;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
-    int debug;   // PM_DEBUG_SEED experiments (profiling only; results are wrong when set): 1 no emit, 2 stop after lookup, 4 stop after left arm; 64 stop after the query K-mer, 128 stop after the right arm, 256 / 512 one strand only; 8 = every lane probes the index itself, 16 / 32 = variants with the same results (filter+slot fetched together, rep fetched before the right arm)
+    int debug;   // PM_DEBUG_SEED experiments (profiling only; results are wrong when set): 1 no emit, 2 stop after lookup, 4 stop after left arm; 64 stop after the query K-mer, 128 stop after the right arm, 256 / 512 one strand only; 8 = every lane probes the index itself (same results)
     PM_HD void operator()(int64_t tid) const {
         int64_t unit = tid >> 6; int lane = (int)(tid & 63);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -448,64 +493,106 @@ struct SeedExtend {
             const int32_t sidx = (int32_t)chunk * kUnitSamples + u * 64 + lane;
             const int64_t j = (int64_t)sidx * ri.stride;
             const bool valid = !stop && j + K <= m;
-            const uint64_t tag = valid ? kmer_tag(P, qbase + j, K) : 0;
+            // the four query blocks around the sample: the K-mer, the 32 bases before it and the 32 bases after it all come
+            // out of them, and they are in flight while the index is probed
+            const int64_t qp = qbase + j;
+            const int shq = (int)(qp & 31);
+            SeqBlock q0 = SeqBlock{0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
+            if (valid) { const SeqBlock* qb = P.blk + (qp >> 5) - 1; q0 = qb[0]; q1 = qb[1]; q2 = qb[2]; q3 = qb[3]; }
+            const uint64_t kbits = K < 32 ? (1ull << (2 * K)) - 1 : ~0ull;
+            const uint32_t kmask = K < 32 ? (uint32_t)((1ull << K) - 1) : ~0u;
+            const Win qT = funnel(q1, q2, shq);
+            const uint64_t tag = (qT.b & kbits) | ((uint64_t)(qT.m & kmask) << 32);
             if (debug & 64) { if (tag == 12345) atomic_or32(err, 2u); continue; }
             // Index probes are the scarce resource (random 64-B requests at the fabric's request rate).  Consecutive lanes
             // hold consecutive samples, and inside a match the K-mer of sample s+t sits t*stride bases after the K-mer of
             // sample s.  So only every 8th lane (a leader) probes the index; a follower first looks where its leader's
             // hit predicts its own K-mer: if the reference K-mer there equals its own and occurs nowhere else in R, that
-            // position is what the probe would have returned (two L2-resident loads).  Otherwise it probes itself.
+            // position is what the probe would have returned.  Otherwise it probes itself.
             uint64_t slot = kEmpty;
             const int sub = lane & 7;
             const bool follow = ri.stride <= K && m >= 64 * (int64_t)ri.stride && !(debug & 8);   // short query pieces (recursion): one probe phase is faster
             int32_t lead = -1;
             if (follow) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                if (valid && sub == 0) slot = index_lookup(P, ri, slots, filter, tag, (debug & 16) != 0);
+                if (valid && sub == 0) slot = index_probe(ri, slots, filter, tag);
                 const int32_t mine = (sub == 0 && slot != kEmpty && !(slot & kMulti)) ? slot_head(slot) : -1;
                 lead = __shfl(mine, lane & ~7, 64);
 #else
                 // host emulation (one thread at a time): the leader's probe is recomputed by each of its followers
-                if (sub == 0) { if (valid) slot = index_lookup(P, ri, slots, filter, tag); }
+                if (sub == 0) { if (valid) slot = index_probe(ri, slots, filter, tag); }
                 else if (valid) {
-                    const uint64_t ls = index_lookup(P, ri, slots, filter, kmer_tag(P, qbase + j - (int64_t)sub * ri.stride, K));
+                    const uint64_t ls = index_probe(ri, slots, filter, kmer_tag(P, qbase + j - (int64_t)sub * ri.stride, K));
                     if (ls != kEmpty && !(ls & kMulti)) lead = slot_head(ls);
                 }
 #endif
-                if (valid && sub != 0) {
-                    bool predicted = false;
-                    if (lead >= 0) {
-                        const int32_t cand = lead + sub * ri.stride;
-                        const int64_t fp = ri.posbase + cand;
-                        if (cand + K <= ri.nR && !((repeated[fp >> 5] >> (fp & 31)) & 1u) && kmer_tag(P, rbase + cand, K) == tag) {
-                            slot = (uint64_t)(uint32_t)cand;     // a unique K-mer: head = cand, no chain
-                            predicted = true;
-                        }
-                    }
-                    if (!predicted) slot = index_lookup(P, ri, slots, filter, tag, (debug & 16) != 0);
-                }
             } else if (valid) {
-                slot = index_lookup(P, ri, slots, filter, tag, (debug & 16) != 0);
+                slot = index_probe(ri, slots, filter, tag);
             }
-            if (slot == kEmpty) continue;
-            if (debug & 2) { if (slot == 12345) atomic_or32(err, 2u); continue; }
-            const bool multi = (slot & kMulti) != 0;
-            for (int32_t l = slot_head(slot); l >= 0; l = multi ? next[ri.posbase + l] : -1) {
+            // the four reference blocks around the (presumed) position: confirmation of the K-mer, left arm and the
+            // first 32 bases of the right arm in ONE round of loads
+            int32_t l = -1;
+            int shr = 0;
+            SeqBlock r0 = SeqBlock{0, 0, 0}, r1 = r0, r2 = r0, r3 = r0;
+            bool multi = false;
+            if (valid) {
+                bool predicted = false;
+                if (follow && sub != 0) {
+                    const int32_t cand = lead >= 0 ? lead + sub * ri.stride : -1;
+                    if (cand >= 0 && cand + K <= ri.nR) {
+                        const int64_t fpos = ri.posbase + cand;
+                        const uint32_t rw = repeated[fpos >> 5];
+                        const int64_t rp = rbase + cand;
+                        const SeqBlock* rb = P.blk + (rp >> 5) - 1;
+                        r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
+                        const Win rT = funnel(r1, r2, shr);
+                        if (!((rw >> (fpos & 31)) & 1u) && ((rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32)) == tag) { l = cand; predicted = true; }
+                    }
+                    if (!predicted) slot = index_probe(ri, slots, filter, tag);
+                }
+                if (!predicted && slot != kEmpty) {
+                    l = slot_head(slot);
+                    int64_t rp = rbase + l;
+                    const SeqBlock* rb = P.blk + (rp >> 5) - 1;
+                    r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
+                    const Win rT = funnel(r1, r2, shr);
+                    if (((rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32)) != tag) {
+                        // another K-mer with the same 32-bit fingerprint: the confirmed lookup decides
+                        slot = index_lookup(P, ri, slots, filter, tag);
+                        l = slot == kEmpty ? -1 : slot_head(slot);
+                        if (l >= 0) { rp = rbase + l; rb = P.blk + (rp >> 5) - 1; r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31); }
+                    }
+                    multi = l >= 0 && (slot & kMulti) != 0;
+                }
+            }
+            if (l < 0) continue;
+            if (debug & 2) { if (l == 123456789) atomic_or32(err, 2u); continue; }
+            bool first_entry = true;
+            for (; l >= 0; l = multi ? next[ri.posbase + l] : -1, first_entry = false) {
                 if (++work > budget) { atomic_or32(err, kErrWork); stop = true; break; }
                 // left: only `stride` bases matter -- a longer left arm means an earlier sample owns the match
                 int32_t lim = (int32_t)(j < l ? j : l);
                 if (lim > ri.stride) lim = ri.stride;
-                int32_t left = lce_bwd(P, qbase + j, rbase + l, lim);
+                const bool in_regs = first_entry && ri.stride <= 32;     // both arms start inside the loaded blocks
+                int32_t left;
+                if (in_regs) { left = match_bwd(funnel(q0, q1, shq), funnel(r0, r1, shr)); if (left > lim) left = lim; }
+                else left = lce_bwd(P, qp, rbase + l, lim);
                 if (left >= ri.stride) continue;
                 if (debug & 4) { if (left == 12345) atomic_or32(err, 2u); continue; }
-                const int32_t rep_early = (debug & 32) ? rep[ri.posbase + l - left] : 0;   // issued before the right arm's loads
-                int64_t mr = m - j - K; int32_t rr = ri.nR - l - K;
-                int32_t right = lce_fwd(P, qbase + j + K, rbase + l + K, (int32_t)(mr < rr ? mr : rr));
+                const int32_t rep_l0 = rep[ri.posbase + l - left];         // in flight while the right arm is compared
+                const int64_t mr = m - j - K; const int32_t rr = ri.nR - l - K;
+                const int32_t maxr = (int32_t)(mr < rr ? mr : rr);
+                int32_t right;
+                if (in_regs) {
+                    right = match_fwd(funnel3(q1, q2, q3, shq + K), funnel3(r1, r2, r3, shr + K));
+                    if (right >= 32 && maxr > 32) right = 32 + lce_fwd(P, qp + K + 32, rbase + l + K + 32, maxr - 32);
+                    if (right > maxr) right = maxr;
+                } else right = lce_fwd(P, qp + K, rbase + l + K, maxr);
                 int32_t len = left + K + right;
                 if (debug & 128) { if (len == 123456789) atomic_or32(err, 2u); continue; }
                 if (len < ri.minlen) continue;
                 int32_t l0 = l - left; int64_t j0 = j - left;
-                if (len <= ((debug & 32) ? rep_early : rep[ri.posbase + l0])) continue;           // not unique in R
+                if (len <= rep_l0) continue;           // not unique in R
                 if (debug & 1) { if (len == 123456789) atomic_or32(err, 2u); continue; }
                 const uint64_t ek = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
                 const uint64_t evv = ((uint64_t)j0 << 32) | (uint32_t)len;
