@@ -217,6 +217,22 @@ PM_HD int32_t lce_fwd(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
     }
     return n < maxlen ? n : maxlen;
 }
+// the same, 64 bases per round: three consecutive blocks of each sequence are fetched together (one memory latency per
+// 64 bases instead of one per 32)
+PM_HD int32_t lce_fwd64(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
+    int32_t n = 0;
+    while (n < maxlen) {
+        const int64_t pa = a + n, pb = b + n;
+        const SeqBlock* ba = P.blk + (pa >> 5); const SeqBlock* bb = P.blk + (pb >> 5);
+        const int sa = (int)(pa & 31), sb = (int)(pb & 31);
+        const SeqBlock a0 = ba[0], a1 = ba[1], a2 = ba[2], b0 = bb[0], b1 = bb[1], b2 = bb[2];
+        int c = match_fwd(funnel(a0, a1, sa), funnel(b0, b1, sb));
+        if (c == 32) c += match_fwd(funnel(a1, a2, sa), funnel(b1, b2, sb));
+        n += c;
+        if (c < 64) break;
+    }
+    return n < maxlen ? n : maxlen;
+}
 // number of equal bases going left from (a-1, b-1), at most maxlen
 PM_HD int32_t lce_bwd(const Packed& P, int64_t a, int64_t b, int32_t maxlen) {
     int32_t n = 0;
@@ -456,7 +472,7 @@ struct SeedExtend {
     Packed P; const RegionInfo* R; const UnitRec* units;
     const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep; const uint32_t* repeated;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
-    int debug;   // PM_DEBUG_SEED experiments (profiling only; results are wrong when set): 1 no emit, 2 stop after lookup, 4 stop after left arm; 64 stop after the query K-mer, 128 stop after the right arm, 256 / 512 one strand only; 8 = every lane probes the index itself (same results)
+    int debug;   // PM_DEBUG_SEED experiments (profiling only; results are wrong when set): 1 no emit, 2 stop after lookup, 4 stop after left arm; 64 stop after the query K-mer, 128 stop after the right arm, 256 / 512 one strand only; 8 = every lane probes the index itself, 2048 = 32-base rounds in the right arm (same results)
     PM_HD void operator()(int64_t tid) const {
         int64_t unit = tid >> 6; int lane = (int)(tid & 63);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -529,40 +545,51 @@ struct SeedExtend {
             } else if (valid) {
                 slot = index_probe(ri, slots, filter, tag);
             }
-            // the four reference blocks around the (presumed) position: confirmation of the K-mer, left arm and the
-            // first 32 bases of the right arm in ONE round of loads
+            // the four reference blocks around the presumed position -- a follower's prediction, or the head of the probed
+            // slot -- are fetched by all lanes in ONE round: confirmation of the K-mer, left arm and the first 32 bases of
+            // the right arm come out of them
             int32_t l = -1;
             int shr = 0;
             SeqBlock r0 = SeqBlock{0, 0, 0}, r1 = r0, r2 = r0, r3 = r0;
             bool multi = false;
-            if (valid) {
-                bool predicted = false;
-                if (follow && sub != 0) {
-                    const int32_t cand = lead >= 0 ? lead + sub * ri.stride : -1;
-                    if (cand >= 0 && cand + K <= ri.nR) {
-                        const int64_t fpos = ri.posbase + cand;
-                        const uint32_t rw = repeated[fpos >> 5];
-                        const int64_t rp = rbase + cand;
+            {
+                int32_t at = -1;
+                bool is_pred = false;
+                if (valid) {
+                    if (follow && sub != 0) {
+                        const int32_t cand = lead >= 0 ? lead + sub * ri.stride : -1;
+                        if (cand >= 0 && cand + K <= ri.nR) { at = cand; is_pred = true; }
+                    } else if (slot != kEmpty) at = slot_head(slot);
+                }
+                bool ok = false;
+                if (at >= 0) {
+                    const int64_t rp = rbase + at;
+                    const SeqBlock* rb = P.blk + (rp >> 5) - 1;
+                    const int64_t fpos = ri.posbase + at;
+                    const uint32_t rw = is_pred ? repeated[fpos >> 5] : 0u;
+                    r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
+                    const Win rT = funnel(r1, r2, shr);
+                    ok = ((rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32)) == tag && !((rw >> (fpos & 31)) & 1u);
+                }
+                if (ok) { l = at; multi = !is_pred && (slot & kMulti) != 0; }
+                else if (valid && (is_pred || (follow && sub != 0) || at >= 0)) {
+                    // a follower without a confirmed prediction probes for itself; a probed slot whose K-mer differs
+                    // (same 32-bit fingerprint, 2^-32) is settled by the confirmed lookup
+                    slot = (follow && sub != 0 && !(at >= 0 && !is_pred)) ? index_probe(ri, slots, filter, tag) : index_lookup(P, ri, slots, filter, tag);
+                    if (slot != kEmpty) {
+                        int32_t h2 = slot_head(slot);
+                        int64_t rp = rbase + h2;
                         const SeqBlock* rb = P.blk + (rp >> 5) - 1;
                         r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
                         const Win rT = funnel(r1, r2, shr);
-                        if (!((rw >> (fpos & 31)) & 1u) && ((rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32)) == tag) { l = cand; predicted = true; }
+                        if (((rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32)) != tag) {
+                            slot = index_lookup(P, ri, slots, filter, tag);
+                            h2 = slot == kEmpty ? -1 : slot_head(slot);
+                            if (h2 >= 0) { rp = rbase + h2; rb = P.blk + (rp >> 5) - 1; r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31); }
+                        }
+                        l = h2;
+                        multi = l >= 0 && (slot & kMulti) != 0;
                     }
-                    if (!predicted) slot = index_probe(ri, slots, filter, tag);
-                }
-                if (!predicted && slot != kEmpty) {
-                    l = slot_head(slot);
-                    int64_t rp = rbase + l;
-                    const SeqBlock* rb = P.blk + (rp >> 5) - 1;
-                    r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
-                    const Win rT = funnel(r1, r2, shr);
-                    if (((rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32)) != tag) {
-                        // another K-mer with the same 32-bit fingerprint: the confirmed lookup decides
-                        slot = index_lookup(P, ri, slots, filter, tag);
-                        l = slot == kEmpty ? -1 : slot_head(slot);
-                        if (l >= 0) { rp = rbase + l; rb = P.blk + (rp >> 5) - 1; r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31); }
-                    }
-                    multi = l >= 0 && (slot & kMulti) != 0;
                 }
             }
             if (l < 0) continue;
@@ -585,7 +612,7 @@ struct SeedExtend {
                 int32_t right;
                 if (in_regs) {
                     right = match_fwd(funnel3(q1, q2, q3, shq + K), funnel3(r1, r2, r3, shr + K));
-                    if (right >= 32 && maxr > 32) right = 32 + lce_fwd(P, qp + K + 32, rbase + l + K + 32, maxr - 32);
+                    if (right >= 32 && maxr > 32) right = 32 + ((debug & 2048) ? lce_fwd(P, qp + K + 32, rbase + l + K + 32, maxr - 32) : lce_fwd64(P, qp + K + 32, rbase + l + K + 32, maxr - 32));
                     if (right > maxr) right = maxr;
                 } else right = lce_fwd(P, qp + K, rbase + l + K, maxr);
                 int32_t len = left + K + right;
