@@ -69,14 +69,14 @@ int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, 
 /* Result accessors.  Candidates of region r are c in [off[r], off[r+1]).  For candidate c:
  *   k[c]   reference offset inside the region (Mum.DSP[0]-1-ini_region, parsnp.cpp:1671)
  *   lon[c] length (Mum.LON, :1687)
- *   sp[c*(n_genomes-1)+g-1]  start inside genome g's substring, on the chosen strand's string (SPF[g-1].MSP[k], :1681)
+ *   sp[c*(n_genomes-1)+g-1]  start inside genome g's substring, on the chosen strand's string (SPF[g-1].MSP[k], :1681; region lengths are < 2^31, so int32)
  *   fwd[c*(n_genomes-1)+g-1] 1 = forward, 0 = reverse complement (SPF[g-1].forward[k], :1678)            */
 int64_t pm_result_regions(const pm_result* r);
 int64_t pm_result_total(const pm_result* r);
 const int64_t* pm_result_offsets(const pm_result* r);
 const int32_t* pm_result_k(const pm_result* r);
 const int32_t* pm_result_lon(const pm_result* r);
-const int64_t* pm_result_sp(const pm_result* r);
+const int32_t* pm_result_sp(const pm_result* r);
 const uint8_t* pm_result_fwd(const pm_result* r);
 void pm_result_free(pm_result* r);
 

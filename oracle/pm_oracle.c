@@ -9,7 +9,7 @@
 #include <string.h>
 
 struct pm_session { int n; uint8_t** seq; int64_t* len; };
-struct pm_result { int64_t nreg, total; int nq; int64_t* off; int32_t* k; int32_t* lon; int64_t* sp; uint8_t* fwd; };
+struct pm_result { int64_t nreg, total; int nq; int64_t* off; int32_t* k; int32_t* lon; int32_t* sp; uint8_t* fwd; };
 static const char* g_err = "";
 const char* pm_last_error(void) { return g_err; }
 const char* pm_provider(void) { return "oracle"; }
@@ -53,10 +53,11 @@ int pm_multi_mum_batch(pm_session* s, int64_t nreg, const int64_t* starts, const
         if (base + c > cap) {
             cap = (base + c) * 2 + 16;
             r->k = realloc(r->k, sizeof(int32_t) * (size_t)cap); r->lon = realloc(r->lon, sizeof(int32_t) * (size_t)cap);
-            r->sp = realloc(r->sp, sizeof(int64_t) * (size_t)(cap * (q > 0 ? q : 1))); r->fwd = realloc(r->fwd, (size_t)(cap * (q > 0 ? q : 1)));
+            r->sp = realloc(r->sp, sizeof(int32_t) * (size_t)(cap * (q > 0 ? q : 1))); r->fwd = realloc(r->fwd, (size_t)(cap * (q > 0 ? q : 1)));
         }
         for (int64_t i = 0; i < c; i++) { r->k[base + i] = (int32_t)k[i]; r->lon[base + i] = lon[i]; }
-        memcpy(r->sp + base * q, sp, sizeof(int64_t) * (size_t)(c * q)); memcpy(r->fwd + base * q, fw, (size_t)(c * q));
+        for (int64_t i = 0; i < c * q; i++) r->sp[base * q + i] = (int32_t)sp[i];
+        memcpy(r->fwd + base * q, fw, (size_t)(c * q));
         r->off[x + 1] = base + c;
         oracle_free(k); oracle_free(lon); oracle_free(sp); oracle_free(fw);
     }
@@ -68,7 +69,7 @@ int64_t pm_result_total(const pm_result* r) { return r->total; }
 const int64_t* pm_result_offsets(const pm_result* r) { return r->off; }
 const int32_t* pm_result_k(const pm_result* r) { return r->k; }
 const int32_t* pm_result_lon(const pm_result* r) { return r->lon; }
-const int64_t* pm_result_sp(const pm_result* r) { return r->sp; }
+const int32_t* pm_result_sp(const pm_result* r) { return r->sp; }
 const uint8_t* pm_result_fwd(const pm_result* r) { return r->fwd; }
 void pm_result_free(pm_result* r) { if (!r) return; free(r->off); free(r->k); free(r->lon); free(r->sp); free(r->fwd); free(r); }
 

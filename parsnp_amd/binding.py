@@ -30,7 +30,7 @@ class Lib:
                                          C.POINTER(C.c_void_p)]
         for name, t in (("pm_result_regions", C.c_int64), ("pm_result_total", C.c_int64), ("pm_result_offsets", C.POINTER(C.c_int64)),
                         ("pm_result_k", C.POINTER(C.c_int32)), ("pm_result_lon", C.POINTER(C.c_int32)),
-                        ("pm_result_sp", C.POINTER(C.c_int64)), ("pm_result_fwd", C.POINTER(C.c_uint8))):
+                        ("pm_result_sp", C.POINTER(C.c_int32)), ("pm_result_fwd", C.POINTER(C.c_uint8))):
             getattr(L, name).restype = t
             getattr(L, name).argtypes = [C.c_void_p]
         L.pm_result_free.argtypes = [C.c_void_p]
@@ -95,7 +95,7 @@ class Session:
             if total:
                 k = np.ctypeslib.as_array(L.pm_result_k(res), (total,)).copy()
                 lon = np.ctypeslib.as_array(L.pm_result_lon(res), (total,)).copy()
-                sp = np.ctypeslib.as_array(L.pm_result_sp(res), (total * q,)).copy().reshape(total, q)
+                sp = np.ctypeslib.as_array(L.pm_result_sp(res), (total * q,)).astype(np.int64).reshape(total, q)
                 fw = np.ctypeslib.as_array(L.pm_result_fwd(res), (total * q,)).copy().reshape(total, q)
             else:
                 k = np.zeros(0, np.int32); lon = np.zeros(0, np.int32); sp = np.zeros((0, q), np.int64); fw = np.zeros((0, q), np.uint8)

@@ -73,10 +73,10 @@ int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, 
 int64_t pm_result_regions(const pm_result* r) { return r->r.nregions; }
 int64_t pm_result_total(const pm_result* r) { return r->r.total; }
 const int64_t* pm_result_offsets(const pm_result* r) { return r->r.off.data(); }
-const int32_t* pm_result_k(const pm_result* r) { return r->r.k.data(); }
-const int32_t* pm_result_lon(const pm_result* r) { return r->r.lon.data(); }
-const int64_t* pm_result_sp(const pm_result* r) { return r->r.sp.data(); }
-const uint8_t* pm_result_fwd(const pm_result* r) { return r->r.fwd.data(); }
+const int32_t* pm_result_k(const pm_result* r) { return r->r.k(); }
+const int32_t* pm_result_lon(const pm_result* r) { return r->r.lon(); }
+const int32_t* pm_result_sp(const pm_result* r) { return r->r.sp(); }
+const uint8_t* pm_result_fwd(const pm_result* r) { return r->r.fwd(); }
 void pm_result_free(pm_result* r) { delete r; }
 
 int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int strand,

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -14,13 +16,42 @@
 
 namespace pm {
 
+// Host buffers the results are downloaded into (pinned memory in the HIP build).  They are recycled: a result gives its
+// blocks back when it is freed, the next batch of the same shape takes them, so the steady state allocates nothing and
+// touches no fresh pages.  Shared by the session and every result it handed out (a result may outlive the session).
+struct HostPool {
+    void* (*alloc_fn)(size_t) = nullptr;
+    void (*free_fn)(void*) = nullptr;
+    struct Block { void* p = nullptr; size_t cap = 0; };
+    std::vector<Block> idle;
+    Block take(size_t n) {
+        size_t best = idle.size();
+        for (size_t i = 0; i < idle.size(); i++)
+            if (idle[i].cap >= n && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+        if (best != idle.size() && idle[best].cap <= 2 * n + (1u << 20)) { Block b = idle[best]; idle.erase(idle.begin() + (long)best); return b; }
+        Block b; b.cap = n + n / 8 + 256; b.p = alloc_fn(b.cap);
+        if (!b.p) throw std::bad_alloc();
+        return b;
+    }
+    void give(Block b) { if (b.p) idle.push_back(b); }
+    ~HostPool() { for (auto& b : idle) free_fn(b.p); }
+};
+
 struct BatchResult {
     int64_t nregions = 0, total = 0;
     int nq = 0;
     std::vector<int64_t> off;
-    std::vector<int32_t> k, lon;
-    std::vector<int64_t> sp;
-    std::vector<uint8_t> fwd;
+    HostPool::Block kb, lonb, spb, fwdb;     // int32 k[total], int32 lon[total], int32 sp[total*nq], uint8 fwd[total*nq]
+    std::shared_ptr<HostPool> pool;
+    const int32_t* k() const { return (const int32_t*)kb.p; }
+    const int32_t* lon() const { return (const int32_t*)lonb.p; }
+    const int32_t* sp() const { return (const int32_t*)spb.p; }
+    const uint8_t* fwd() const { return (const uint8_t*)fwdb.p; }
+    void release() { if (pool) { pool->give(kb); pool->give(lonb); pool->give(spb); pool->give(fwdb); } kb = lonb = spb = fwdb = HostPool::Block(); }
+    BatchResult() = default;
+    BatchResult(const BatchResult&) = delete;
+    BatchResult& operator=(const BatchResult&) = delete;
+    ~BatchResult() { release(); }
 };
 
 struct PhaseTime { const char* name; float ms; };
@@ -40,7 +71,8 @@ inline int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) b++; ret
 template <class B>
 class Engine {
 public:
-    explicit Engine(B& backend) : be(backend) {}
+    explicit Engine(B& backend) : be(backend), pool(std::make_shared<HostPool>()) { pool->alloc_fn = &B::host_alloc; pool->free_fn = &B::host_free; }
+    std::shared_ptr<HostPool> pool;
     ~Engine() { release(); }
 
     std::string error;
@@ -106,7 +138,8 @@ public:
         const int nq = ngen - 1;
         out->nregions = nreg; out->nq = nq; out->total = 0;
         out->off.assign((size_t)nreg + 1, 0);
-        out->k.clear(); out->lon.clear(); out->sp.clear(); out->fwd.clear();
+        out->release();
+        out->pool = pool;
         if (nreg == 0) return 0;
         if (nq < 1) { error = "need at least one query genome"; return -2; }
 
@@ -317,32 +350,29 @@ public:
         }
         be.launch("fold_genomes", (int64_t)ncand, FoldGenomes{d_R.p, scand, ngen, d_at.p, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_ok.p});
 
-        // -- results to the host
+        // -- accepted candidates, compacted on the device and downloaded straight into the result's (pinned) blocks
+        be.mark("compact");
+        ensure(d_okcnt, (size_t)ncand + 1); ensure(d_okpos, (size_t)ncand + 1);
+        be.launch("ok_count", (int64_t)ncand + 1, OkCount{d_ok.p, (int64_t)ncand, d_okcnt.p});
+        be.exclusive_scan(d_okcnt.p, d_okpos.p, (size_t)ncand + 1);
+        int64_t nok = 0;
+        be.d2h(&nok, d_okpos.p + ncand, 8);
+        const size_t nokz = (size_t)nok, nqz2 = (size_t)nq;
+        ensure(d_creg, std::max<size_t>(nokz, 1)); ensure(d_ck, std::max<size_t>(nokz, 1)); ensure(d_clon, std::max<size_t>(nokz, 1));
+        ensure(d_csp, std::max<size_t>(nokz * nqz2, 1)); ensure(d_cfwd, std::max<size_t>(nokz * nqz2, 1));
+        be.launch("compact_candidates", (int64_t)ncand * nq,
+                  CompactCandidates{scand, d_ok.p, d_okpos.p, nq, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_creg.p, d_ck.p, d_clon.p, d_csp.p, d_cfwd.p});
         be.mark("download");
-        std::vector<uint64_t> cand_h((size_t)ncand);
-        std::vector<uint8_t> ok_h((size_t)ncand), fwd_h((size_t)ncand * (size_t)nq);
-        std::vector<int32_t> k_h((size_t)ncand), lon_h((size_t)ncand), sp_h((size_t)ncand * (size_t)nq);
-        be.d2h(cand_h.data(), scand, 8 * (size_t)ncand);
-        be.d2h(ok_h.data(), d_ok.p, (size_t)ncand);
-        be.d2h(k_h.data(), d_ok_k.p, 4 * (size_t)ncand);
-        be.d2h(lon_h.data(), d_ok_lon.p, 4 * (size_t)ncand);
-        be.d2h(sp_h.data(), d_osp.p, 4 * (size_t)ncand * (size_t)nq);
-        be.d2h(fwd_h.data(), d_ofwd.p, (size_t)ncand * (size_t)nq);
+        std::vector<int32_t> reg_h(nokz);
+        out->kb = pool->take(4 * nokz); out->lonb = pool->take(4 * nokz);
+        out->spb = pool->take(4 * nokz * nqz2); out->fwdb = pool->take(nokz * nqz2);
+        be.d2h(reg_h.data(), d_creg.p, 4 * nokz);
+        be.d2h(out->kb.p, d_ck.p, 4 * nokz);
+        be.d2h(out->lonb.p, d_clon.p, 4 * nokz);
+        be.d2h(out->spb.p, d_csp.p, 4 * nokz * nqz2);
+        be.d2h(out->fwdb.p, d_cfwd.p, nokz * nqz2);
         be.mark(nullptr);
-        size_t nok = 0;
-        for (size_t c = 0; c < (size_t)ncand; c++) nok += ok_h[c] ? 1 : 0;
-        out->k.resize(nok); out->lon.resize(nok); out->sp.resize(nok * (size_t)nq); out->fwd.resize(nok * (size_t)nq);
-        size_t w = 0;
-        for (size_t c = 0; c < (size_t)ncand; c++) {
-            if (!ok_h[c]) continue;
-            out->off[(size_t)(cand_h[c] >> 32) + 1]++;
-            out->k[w] = k_h[c]; out->lon[w] = lon_h[c];
-            const int32_t* sps = &sp_h[c * (size_t)nq];
-            int64_t* spd = &out->sp[w * (size_t)nq];
-            for (int g = 0; g < nq; g++) spd[g] = sps[g];
-            memcpy(&out->fwd[w * (size_t)nq], &fwd_h[c * (size_t)nq], (size_t)nq);
-            w++;
-        }
+        for (size_t w = 0; w < nokz; w++) out->off[(size_t)reg_h[w] + 1]++;
         for (int64_t r = 0; r < nreg; r++) out->off[(size_t)r + 1] += out->off[(size_t)r];
         out->total = out->off[(size_t)nreg];
         collect_timing();
@@ -390,6 +420,7 @@ private:
     Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2, d_evkey3, d_evval3; Buf<int64_t> d_sliceoff;
     Buf<int64_t> d_lo, d_cov; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
     Buf<uint64_t> d_cand, d_cand2; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
+    Buf<int64_t> d_okcnt, d_okpos; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;
 };
 
 }  // namespace pm

@@ -45,6 +45,13 @@ struct HipBackend {
     }
     void* alloc(size_t n) { void* p = nullptr; if (!check(hipMalloc(&p, n ? n : 1), "hipMalloc")) return nullptr; return p; }
     void free(void* p) { check(hipFree(p), "hipFree"); }
+    // pinned host memory for result downloads (no staging copy, full PCIe rate); static: results may outlive the session
+    static bool pinned() { static const bool v = !(getenv("PARSNP_PINNED") && atoi(getenv("PARSNP_PINNED")) == 0); return v; }   // PARSNP_PINNED=0: pageable buffers (measurement)
+    static void* host_alloc(size_t n) {
+        if (!pinned()) return malloc(n ? n : 1);
+        void* p = nullptr; return hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+    }
+    static void host_free(void* p) { if (pinned()) (void)hipHostFree(p); else ::free(p); }
     void memset(void* p, int v, size_t n) { check(hipMemsetAsync(p, v, n, stream), "hipMemsetAsync"); }
     void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync"); }
     void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); check(hipStreamSynchronize(stream), "sync"); }

@@ -894,4 +894,23 @@ struct FoldGenomes {
     }
 };
 
+// accepted candidates only, densely, in candidate order: what the host receives.  pos = exclusive prefix of ok.
+struct OkCount {
+    const uint8_t* ok; int64_t ncand; int64_t* cnt;     // cnt[ncand] = 0 closes the scan
+    PM_HD void operator()(int64_t c) const { cnt[c] = c < ncand ? (ok[c] ? 1 : 0) : 0; }
+};
+// tid = (candidate, query genome)
+struct CompactCandidates {
+    const uint64_t* cand; const uint8_t* ok; const int64_t* pos; int32_t nq;
+    const int32_t* k; const int32_t* lon; const int32_t* sp; const uint8_t* fwd;
+    int32_t* out_region; int32_t* out_k; int32_t* out_lon; int32_t* out_sp; uint8_t* out_fwd;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = tid / nq; const int g = (int)(tid % nq);
+        if (!ok[c]) return;
+        const int64_t w = pos[c];
+        out_sp[w * nq + g] = sp[tid]; out_fwd[w * nq + g] = fwd[tid];
+        if (g == 0) { out_region[w] = (int32_t)(cand[c] >> 32); out_k[w] = k[c]; out_lon[w] = lon[c]; }
+    }
+};
+
 }  // namespace pm

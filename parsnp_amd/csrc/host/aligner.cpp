@@ -97,11 +97,24 @@ bool Region::same_as(const Region& o, size_t n) const {
 }
 
 // ---------------------------------------------------------------------------------------------- Aligner
-Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session)
-    : n(g.size()), prm(p), genomes(g), session_(session) {
+Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, AlignerMemory* memory)
+    : n(g.size()), prm(p), genomes(g), session_(session), own_memory_(memory ? nullptr : new AlignerMemory),
+      memory_(memory ? memory : own_memory_.get()), rows_(memory_->rows), irows_(memory_->irows), cache_rows_(memory_->cache_rows),
+      req_rows_(memory_->req_rows) {
     layout.resize(n);
     gsize_.resize(n);
     for (size_t i = 0; i < n; i++) { layout[i].init(genomes[i].seq.size() + 1); gsize_[i] = (long)genomes[i].seq.size(); }
+}
+
+Aligner::~Aligner() {
+    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    double t = now_s();
+    auto lap = [&](const char* what) { if (dbg) { double u = now_s(); fprintf(stderr, "[release] %-10s %.4f s\n", what, u - t); t = u; } };
+    cache_.clear(); lap("cache");
+    std::vector<Bitmap>().swap(layout); lap("layout");
+    std::vector<Mum>().swap(pool); lap("pool");
+    std::vector<Lcb>().swap(lcbs); lap("lcbs");
+    own_memory_.reset(); lap("arenas");
 }
 
 Region Aligner::new_region() {
@@ -226,22 +239,21 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out)
     pm_result* res = nullptr;
     int rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);
     if (rc != PM_OK) fatal(std::string("multi-MUM engine failed: ") + pm_last_error());
+    std::shared_ptr<pm_result> own(res, pm_result_free);
     const int64_t* off = pm_result_offsets(res);
     const int32_t* k = pm_result_k(res);
     const int32_t* lon = pm_result_lon(res);
-    const int64_t* sp = pm_result_sp(res);
+    const int32_t* sp = pm_result_sp(res);
     const uint8_t* fw = pm_result_fwd(res);
     const size_t q = n - 1;
     double tu = now_s();
     for (size_t i = 0; i < reqs.size(); i++) {
         Raw& r = (*out)[i];
         size_t a = (size_t)off[i], b = (size_t)off[i + 1];
-        r.k.assign(k + a, k + b);
-        r.lon.assign(lon + a, lon + b);
-        r.sp.assign(sp + a * q, sp + b * q);
-        r.fwd.assign(fw + a * q, fw + b * q);
+        r.k = k + a; r.lon = lon + a; r.sp = sp + a * q; r.fwd = fw + a * q;
+        r.count = b - a;
+        r.owner = own;
     }
-    pm_result_free(res);
     stats.t_unpack += now_s() - tu;
     {
         int cnt = 64; const char* names[64]; float ms[64];
@@ -303,7 +315,7 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
 bool Aligner::candidate_rows(const Region& r, const Request& q, const Raw& raw, size_t c, Mum& m, bool* ok, bool* any_reverse) const {
     const size_t nq = n - 1;
     const long lon = raw.lon[c];
-    const int64_t* __restrict sp = &raw.sp[c * nq];
+    const int32_t* __restrict sp = &raw.sp[c * nq];
     const uint8_t* __restrict fw = &raw.fwd[c * nq];
     const long* __restrict rstart = r.start;
     const long* __restrict rlen = r.length;
@@ -317,7 +329,7 @@ bool Aligner::candidate_rows(const Region& r, const Request& q, const Raw& raw, 
     unsigned long notgood = (st0 + lon > gs[0]) | (st0 < 0), rev = 0;
     for (size_t j = 1; j < n; j++) {
         // dsp - r.start[j] == sp + 1 in unsigned arithmetic (:1723); startpos = dsp - 1
-        const unsigned long spj = (unsigned long)sp[j - 1];
+        const unsigned long spj = (unsigned long)(long)sp[j - 1];
         bad |= spj + 1 > (unsigned long)(unsigned int)rlen[j];
         const long startpos = (long)(spj + (unsigned long)rstart[j]);
         const long f = fw[j - 1] != 0;
@@ -361,7 +373,7 @@ bool Aligner::settle(Mum& m, bool touches, bool any_reverse) const {
 
 // Candidate -> MUM, in candidate order (parsnp.cpp:1717-1841).
 void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted) {
-    const size_t ncand = raw.k.size();
+    const size_t ncand = raw.count;
     const int threads = prm.cores > 1 ? prm.cores : 1;
     static const size_t par_min = getenv("PARSNP_PARALLEL_MIN") ? (size_t)atol(getenv("PARSNP_PARALLEL_MIN")) : 4096;   // test hook
     if (ncand >= par_min && threads > 1 && !layout[0].logging()) { validate_parallel(r, q, raw, accepted, threads); return; }
@@ -393,7 +405,7 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
 // ones are marked (a later clean candidate never overlaps them, or it would not be clean), and run through the
 // sequential path in their original order.
 void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted, int threads) {
-    const size_t ncand = raw.k.size();
+    const size_t ncand = raw.count;
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double tp = now_s();
     auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[validate_parallel] %-10s %.4f s\n", what, t - tp); tp = t; } };

@@ -131,6 +131,7 @@ public:
     struct Mark { size_t cur, off; bool empty; };
     Mark mark() const { return Mark{cur_, off_, blocks_.empty()}; }
     void rewind(const Mark& m) { if (m.empty) { cur_ = 0; off_ = 0; } else { cur_ = m.cur; off_ = m.off; } }
+    void reset() { cur_ = 0; off_ = 0; }      // start over, keeping the blocks (and their mapped pages)
 private:
     static constexpr size_t kBlock = 1 << 20;
     std::vector<std::unique_ptr<T[]>> blocks_;
@@ -163,10 +164,13 @@ struct Lcb {
 };
 
 // raw candidate list of one finder request (one reference chunk of one region)
+// (a view into the engine's result, which stays alive as long as a cache entry refers to it: nothing is copied)
 struct Raw {
-    std::vector<int32_t> k, lon;
-    std::vector<int64_t> sp;
-    std::vector<uint8_t> fwd;
+    const int32_t* k = nullptr; const int32_t* lon = nullptr;
+    const int32_t* sp = nullptr;
+    const uint8_t* fwd = nullptr;
+    size_t count = 0;
+    std::shared_ptr<pm_result> owner;
 };
 
 struct Stats {   // wall-clock split reported next to the reference's own phase timers
@@ -181,9 +185,18 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     double t_validate = 0, t_neighbour = 0, t_key = 0, t_sweep = 0, t_replay = 0, t_sort = 0, t_unpack = 0;   // host split
 };
 
+// The arenas of a run.  A caller that runs the path repeatedly (CoreRun::step) keeps one of these across runs: giving
+// hundreds of MB back to the OS and faulting them in again costs more than the reset.
+struct AlignerMemory {
+    Arena<long> rows, cache_rows, req_rows;
+    Arena<int> irows;
+    void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); }
+};
+
 class Aligner {
 public:
-    Aligner(std::vector<Genome>& genomes, const Params& prm, pm_session* session);
+    Aligner(std::vector<Genome>& genomes, const Params& prm, pm_session* session, AlignerMemory* memory = nullptr);
+    ~Aligner();
     size_t n;
     Params prm;
     std::vector<Genome>& genomes;
@@ -212,8 +225,10 @@ public:
 private:
     pm_session* session_;
     long next_id_ = 1;
-    Arena<long> rows_;      // MUM and region coordinate rows
-    Arena<int> irows_;      // MUM strand rows
+    std::unique_ptr<AlignerMemory> own_memory_;   // when the caller did not lend one
+    AlignerMemory* memory_;
+    Arena<long>& rows_;      // MUM and region coordinate rows
+    Arena<int>& irows_;      // MUM strand rows
     // --- finder plumbing -------------------------------------------------------------------------------------
     // one engine request = one reference chunk of one region; rows of n entries (the region's own rows when the
     // region is a single unclamped chunk, else rows in req_rows_)
@@ -224,7 +239,8 @@ private:
     // the coordinates and are compared in full on a hash hit
     struct CacheEntry { const long* start; const long* len; int32_t minsize; bool pending; Raw raw; };
     std::unordered_multimap<uint64_t, CacheEntry> cache_;
-    Arena<long> cache_rows_, req_rows_;
+    Arena<long>& cache_rows_;
+    Arena<long>& req_rows_;
     CacheEntry* cache_find(const Request& q);
     CacheEntry* cache_put(const Request& q, bool pending);
     std::unordered_map<long, int> minlen_memo_[2];

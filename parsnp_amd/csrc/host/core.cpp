@@ -140,8 +140,11 @@ StepReport CoreRun::step() {
     StepReport r;
     const double ts = now_s();
     align.reset();
-    align.reset(new Aligner(genomes, prm, session));
+    const double tm = now_s();
+    memory.reset();
+    align.reset(new Aligner(genomes, prm, session, &memory));
     r.setup_s = now_s() - ts;
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[setup] release of the previous run %.4f s, new state %.4f s\n", tm - ts, now_s() - tm);
     Aligner& a = *align;
     time_t start, end;
     time(&start);

@@ -47,6 +47,7 @@ public:
     std::vector<Genome> genomes;
     int qfiles = 0;
     double ingest_s = 0, upload_s = 0;
+    AlignerMemory memory;                 // arenas kept across step() calls (declared before align: destroyed after it)
     std::unique_ptr<Aligner> align;
     pm_session* session = nullptr;
 };

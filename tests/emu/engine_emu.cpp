@@ -13,6 +13,8 @@
 struct HostBackend {
     void* alloc(size_t n) { return malloc(n ? n : 1); }
     void free(void* p) { ::free(p); }
+    static void* host_alloc(size_t n) { return malloc(n ? n : 1); }
+    static void host_free(void* p) { ::free(p); }
     void memset(void* p, int v, size_t n) { ::memset(p, v, n); }
     void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
