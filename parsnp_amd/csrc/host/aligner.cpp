@@ -30,7 +30,9 @@ inline bool operator<(const Handle& a, const Handle& b) { return a.key < b.key; 
 // ---------------------------------------------------------------------------------------------- Bitmap
 void Bitmap::init(size_t nbits) {
     nbits_ = nbits;
-    w_.assign((nbits + 63) / 64 + 1, 0);
+    const size_t words = (nbits + 63) / 64 + 1;
+    if (w_.size() == words) std::fill(w_.begin(), w_.end(), 0); else w_.assign(words, 0);   // a recycled bitmap keeps its pages
+    logging_ = false; log_.clear();
     if (nbits) w_[(nbits - 1) >> 6] |= 1ull << ((nbits - 1) & 63);
 }
 void Bitmap::set_range_slow(long a, long b) {
@@ -101,6 +103,8 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
     : n(g.size()), prm(p), genomes(g), session_(session), own_memory_(memory ? nullptr : new AlignerMemory),
       memory_(memory ? memory : own_memory_.get()), rows_(memory_->rows), irows_(memory_->irows), cache_rows_(memory_->cache_rows),
       req_rows_(memory_->req_rows) {
+    // the layout bitmaps are allocated afresh (zero pages on demand, touched first by the thread that replays the
+    // recursion): recycling them, cleared in parallel, left their pages on other NUMA nodes and cost 15 ms per run
     layout.resize(n);
     gsize_.resize(n);
     for (size_t i = 0; i < n; i++) { layout[i].init(genomes[i].seq.size() + 1); gsize_[i] = (long)genomes[i].seq.size(); }
@@ -423,7 +427,8 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     lap("rows");
     // dirty = overlaps the layout or an earlier candidate in some genome.  Each thread owns a stripe of genomes and
     // walks the candidates in order (rows are candidate-major: a stripe reads contiguous entries of every row).
-    std::vector<Bitmap> scratch(n);
+    std::vector<Bitmap>& scratch = memory_->scratch;
+    scratch.resize(n);
     const int nstripes = threads;
 #pragma omp parallel for schedule(static, 1) num_threads(threads)
     for (int t = 0; t < nstripes; t++) {
@@ -436,7 +441,6 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             for (size_t j = j0; j < j1; j++) hit |= scratch[j].test_and_set(st[j], st[j] + lon) | layout[j].any_set(st[j], st[j] + lon);
             if (hit) __atomic_fetch_or(&state[c], (uint8_t)8, __ATOMIC_RELAXED);
         }
-        for (size_t j = j0; j < j1; j++) scratch[j].release();
     }
     lap("overlap");
     // clean candidates: settle in parallel (no trimming possible), then mark genome by genome

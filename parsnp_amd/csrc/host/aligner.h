@@ -52,7 +52,11 @@ bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* o
 class Bitmap {
 public:
     void init(size_t nbits_with_sentinel);
-    void init_zero_lazy(size_t nbits) { nbits_ = nbits; w_.assign((nbits + 63) / 64 + 1, 0); }   // scratch: no sentinel
+    void init_zero_lazy(size_t nbits) {   // scratch: no sentinel; storage (and its mapped pages) is kept when the size repeats
+        const size_t words = (nbits + 63) / 64 + 1;
+        nbits_ = nbits;
+        if (w_.size() == words) std::fill(w_.begin(), w_.end(), 0); else w_.assign(words, 0);
+    }
     void release() { std::vector<uint64_t>().swap(w_); nbits_ = 0; }
     bool test_and_set(long a, long b) {    // [a,b) := 1; was any of it marked?  (scratch use: no undo log)
         if (a < 0) a = 0;
@@ -190,6 +194,7 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
 struct AlignerMemory {
     Arena<long> rows, cache_rows, req_rows;
     Arena<int> irows;
+    std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
     void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); }
 };
 
