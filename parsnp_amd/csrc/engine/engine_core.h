@@ -200,9 +200,11 @@ public:
         be.mark("index");
         be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p, d_filter.p});
         be.mark("repeat");
+        ensure(d_run, (size_t)std::max<int64_t>(npos, 1));
+        be.launch("run_length", npos, RunLength{P, d_R.p, nreg, d_posbase.p, d_run.p});
         ensure(d_repeated, (size_t)(npos / 32 + 1));
         be.memset(d_repeated.p, 0, 4 * (size_t)(npos / 32 + 1));
-        be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_filter.p, d_next.p, d_rep.p, d_repeated.p, d_err.p, work_budget});
+        be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_filter.p, d_next.p, d_run.p, d_rep.p, d_repeated.p, d_err.p, work_budget});
 
         // -- work units
         be.mark("units");
@@ -388,7 +390,7 @@ public:
     void release() {
         auto drop = [&](auto& b) { if (b.p) be.free(b.p); b.p = nullptr; b.cap = 0; };
         drop(d_R); drop(d_starts); drop(d_lens); drop(d_posbase); drop(d_tilebase); drop(d_err); drop(d_slots); drop(d_filter); drop(d_next);
-        drop(d_rep); drop(d_repeated); drop(d_epm); drop(d_ucount); drop(d_uoff); drop(d_units); drop(d_counter); drop(d_evkey); drop(d_evval);
+        drop(d_rep); drop(d_run); drop(d_repeated); drop(d_epm); drop(d_ucount); drop(d_uoff); drop(d_units); drop(d_counter); drop(d_evkey); drop(d_evval);
         drop(d_evkey2); drop(d_evval2); drop(d_evkey3); drop(d_evval3); drop(d_sliceoff); drop(d_lo); drop(d_cov); drop(d_state); drop(d_summary); drop(d_startshere); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
         drop(d_ok_k); drop(d_ok_lon); drop(d_osp); drop(d_ofwd);
         if (blk) be.free(blk);
@@ -415,7 +417,7 @@ private:
     Packed P{};
     size_t ev_cap_hint = 0, cand_cap_hint = 0;
     Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase, d_tilebase; Buf<uint32_t> d_err;
-    Buf<uint64_t> d_slots; Buf<uint32_t> d_filter, d_repeated; Buf<int32_t> d_next, d_rep, d_epm;
+    Buf<uint64_t> d_slots; Buf<uint32_t> d_filter, d_repeated; Buf<int32_t> d_next, d_rep, d_run, d_epm;
     Buf<int64_t> d_ucount, d_uoff; Buf<UnitRec> d_units;
     Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2, d_evkey3, d_evval3; Buf<int64_t> d_sliceoff;
     Buf<int64_t> d_lo, d_cov; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;

@@ -391,9 +391,23 @@ PM_HD uint64_t index_probe(const RegionInfo& ri, const uint64_t* slots, const ui
 
 // rep'[l]: longest prefix of R[l..) that occurs at another position of R if that is >= K, else 0.
 // (= the uniqueness point pos_label-l of mum.c:219-224 wherever it can influence the output; SURVEY 3.3-1,-7.)
+// run[l]: number of consecutive positions from l that hold the same symbol as l, inside the region.  Lets RepeatLength
+// compare two suffixes that start inside single-symbol runs (N padding, homopolymers) in O(1) instead of base by base:
+// a run of r identical symbols puts r positions on one K-mer chain, and r^2 comparisons of O(r) bases each are what used
+// to exhaust the work budget.  tid = flat reference position.
+struct RunLength {
+    Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase; int32_t* run;
+    PM_HD void operator()(int64_t tid) const {
+        int64_t r = upper_slot(posbase, nregions, tid);
+        const RegionInfo& ri = R[r];
+        const int32_t l = (int32_t)(tid - ri.posbase);
+        const int64_t base = P.goff[0] + ri.ref_pos;
+        run[tid] = 1 + lce_fwd(P, base + l, base + l + 1, ri.nR - l - 1);   // the sequence against itself shifted by one base
+    }
+};
 struct RepeatLength {
     Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;
-    const uint64_t* slots; const uint32_t* filter; const int32_t* next; int32_t* rep; uint32_t* repeated; uint32_t* err; int64_t budget;
+    const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* run; int32_t* rep; uint32_t* repeated; uint32_t* err; int64_t budget;
     // repeated: one bit per flat reference position, set when the K-mer starting there occurs elsewhere in R (rep' >= K);
     // n/8 bytes, L2 resident -- SeedExtend's followers read it instead of probing the index
     PM_HD void operator()(int64_t tid) const {
@@ -407,12 +421,24 @@ struct RepeatLength {
             uint64_t slot = index_lookup(P, ri, slots, filter, tag);
             if (slot != kEmpty && (slot & kMulti)) {
                 int64_t work = 0;
+                const int32_t r1 = run[tid];
+                const bool single = r1 >= ri.K;          // the K-mer is one symbol K times: so is every K-mer of its chain
                 for (int32_t o = slot_head(slot); o >= 0; o = next[ri.posbase + o]) {
                     if (o == l) continue;
-                    int32_t lim = ri.nR - (l > o ? l : o) - ri.K;
-                    int32_t len = ri.K + lce_fwd(P, base + l + ri.K, base + o + ri.K, lim);
+                    const int32_t cap = ri.nR - (l > o ? l : o);
+                    int32_t len, cost;
+                    if (single) {
+                        // both suffixes begin with a run: different run lengths part where the shorter run ends
+                        const int32_t r2 = run[ri.posbase + o];
+                        if (r1 != r2) { len = r1 < r2 ? r1 : r2; cost = 1; }
+                        else { const int32_t more = lce_fwd(P, base + l + r1, base + o + r1, cap - r1); len = r1 + more; cost = 1 + (more >> 5); }
+                        if (len > cap) len = cap;
+                    } else {
+                        len = ri.K + lce_fwd(P, base + l + ri.K, base + o + ri.K, cap - ri.K);
+                        cost = 1 + (len >> 5);
+                    }
                     if (len > best) best = len;
-                    work += 1 + (len >> 5);
+                    work += cost;
                     if (work > budget) { atomic_or32(err, kErrWork); break; }
                 }
             }

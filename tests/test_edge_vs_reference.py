@@ -38,6 +38,14 @@ def cases():
         "short_query": (ref, [gs[0], gs[1][:3000]], {}),
         "heavy_rearr": (r3, g3, {}),
         "single_query": (ref, gs[:1], {}),
+        # long single-symbol runs (scaffold gaps, homopolymers): one K-mer chain with thousands of entries
+        "long_runs": (ref[:20000] + b"N" * 9000 + ref[20000:40000] + b"A" * 3000 + ref[40000:],
+                      [gs[0][:20000] + b"N" * 9000 + gs[0][20000:40000] + b"A" * 2500 + gs[0][40000:],
+                       gs[1][:20000] + b"N" * 6000 + gs[1][20000:],
+                       gs[2][:30000] + b"N" * 12000 + gs[2][30000:]], {}),
+        "longer_runs": (ref[:20000] + b"N" * 40000 + ref[20000:],
+                        [gs[0][:20000] + b"N" * 40000 + gs[0][20000:], gs[1][:20000] + b"N" * 25000 + gs[1][20000:40000] + b"T" * 30000 + gs[1][40000:],
+                         gs[2], gs[3][:50000] + b"N" * 50000 + gs[3][50000:]], {}),
         "unaligned_out": (r3, g3[:4], dict(unaligned=1)),          # parsnp.unalign (setUnalignableRegions)
         "recomb_blocks": (ref, gs[:3], dict(recombfilt=1)),         # blocks/b<k>/seq.fna
     }
@@ -84,6 +92,12 @@ def side_by_side(core, name, tmp_path):
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_edge_case_host_logic(cpu_checkers, tmp_path, name):
     side_by_side(cpu_checkers, name, tmp_path)
+
+
+def test_long_runs_with_emulated_engine(emu, tmp_path):
+    """the engine's own kernels (run sequentially on the host) on thousands-long N / homopolymer runs: the run-length
+    shortcut of RepeatLength and SeedExtend's walk over a K-mer chain with thousands of entries"""
+    side_by_side(emu[1], "long_runs", tmp_path)
 
 
 @pytest.mark.gpu
