@@ -338,39 +338,19 @@ struct IndexInsert {
         }
     }
 };
-// continue a lookup whose first slot (index h) has already been read as `seen`
-PM_HD uint64_t index_resolve(const Packed& P, const RegionInfo& ri, const uint64_t* slots, uint64_t tag, uint64_t seen, uint32_t h) {
-    const uint64_t fp = hash_tag(tag) & 0xffffffff00000000ull;
-    const int64_t base = P.goff[0] + ri.ref_pos;
-    for (;;) {
-        if (seen == kEmpty) return kEmpty;
-        if ((seen & 0xffffffff00000000ull) == fp && kmer_tag(P, base + slot_head(seen), ri.K) == tag) return seen;
-        h = (h + 1) & ri.tmask;
-        seen = slots[ri.tbase + h];
-    }
-}
-// -> slot value of the K-mer `tag` in region ri, or kEmpty.  both: fetch the filter word and the first slot together
-// (one memory latency instead of two on a hit; one more probe on a miss)
-PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_t* slots, const uint32_t* filter, uint64_t tag, bool both = false) {
+// -> slot value of the K-mer `tag` in region ri (confirmed against the reference K-mer at the head position), or kEmpty
+PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_t* slots, const uint32_t* filter, uint64_t tag) {
     const uint64_t hv = hash_tag(tag);
     const uint64_t fp = hv & 0xffffffff00000000ull;
     uint32_t h = (uint32_t)hv & ri.tmask;
     const int64_t base = P.goff[0] + ri.ref_pos;
     const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
-    uint64_t seen;
-    if (both) {
-        const uint32_t fw = filter[ri.fbase + (bit >> 5)];
-        seen = slots[ri.tbase + h];
-        if (!((fw >> (bit & 31)) & 1u)) return kEmpty;
-    } else {
-        if (!((filter[ri.fbase + (bit >> 5)] >> (bit & 31)) & 1u)) return kEmpty;
-        seen = slots[ri.tbase + h];
-    }
+    if (!((filter[ri.fbase + (bit >> 5)] >> (bit & 31)) & 1u)) return kEmpty;
     for (;;) {
+        const uint64_t seen = slots[ri.tbase + h];
         if (seen == kEmpty) return kEmpty;
         if ((seen & 0xffffffff00000000ull) == fp && kmer_tag(P, base + slot_head(seen), ri.K) == tag) return seen;
         h = (h + 1) & ri.tmask;
-        seen = slots[ri.tbase + h];
     }
 }
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SeedExtend variants (PM_DEBUG_SEED bits 16 / 32 keep the results): kernel time per step and of the anchor launch
+# SeedExtend variants (PM_DEBUG_SEED bits 8 and 2048 keep the results): kernel time per step and of the anchor launch
 for d in "$@"; do
   PM_DEBUG_SEED=$d python bench.py --steps 3 --warmup 1 --cpu-sample 0 2>/dev/null | python -c "
 import json,sys
