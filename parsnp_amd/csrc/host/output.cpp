@@ -24,8 +24,45 @@ std::string sub(const std::string& g, long pos, long len) {   // std::string::su
     return g.substr((size_t)pos, (size_t)len);
 }
 
-// rows of one LCB: MUMs interleaved with the gaps between consecutive MUMs (:663-916)
-void build_rows(const Aligner& a, const Lcb& ct, std::vector<std::string>* rows, bool* gap_note) {
+// rows of one LCB: MUMs interleaved with the gaps between consecutive MUMs (:663-916), in three steps so that the gap
+// alignments of ALL LCBs can be spread over the threads (one long LCB holds hundreds of them):
+//   gap_strings()  the unaligned gap strings between consecutive MUMs and whether the reference would align them
+//   gap_align()    per gap, by the caller, in one flat parallel loop
+//   build_rows()   concatenation
+struct Gap {
+    std::vector<std::string> seq;       // per genome
+    std::vector<std::string> aligned;   // filled when `align`
+    unsigned max_len = 0;
+    bool align = false, failed = false;
+};
+
+void gap_strings(const Aligner& a, const Lcb& ct, std::vector<Gap>* gaps) {
+    const size_t n = a.n;
+    const Mum& first = a.pool[(size_t)ct.mums[0]];
+    gaps->assign(ct.mums.size() - 1, Gap());
+    for (size_t t = 0; t + 1 < ct.mums.size(); t++) {
+        const Mum& m = a.pool[(size_t)ct.mums[t]];
+        const Mum& nx = a.pool[(size_t)ct.mums[t + 1]];
+        Gap& gp = (*gaps)[t];
+        gp.seq.assign(n, "");
+        unsigned max_len = 0, min_len = 1000000;
+        for (size_t i = 0; i < n; i++) {
+            const std::string& g = a.genomes[i].seq;
+            if (!first.fwd[i]) {
+                if (m.start[i] - nx.end[i] >= 1) gp.seq[i] = upper(reverse_complement(sub(g, nx.end[i], m.start[i] - nx.end[i])));
+            } else {
+                gp.seq[i] = upper(sub(g, m.end[i], nx.start[i] - m.end[i]));
+            }
+            if (gp.seq[i].size() > max_len) max_len = (unsigned)gp.seq[i].size();
+            if (gp.seq[i].size() < min_len) min_len = (unsigned)gp.seq[i].size();
+        }
+        gp.max_len = max_len;
+        // reference: MUSCLE(maxiters=1) over the n gap strings (:848-861); a single genome is never aligned (:809-826)
+        gp.align = max_len > 1 && min_len > 0 && n > 1;
+    }
+}
+
+void build_rows(const Aligner& a, const Lcb& ct, const std::vector<Gap>& gaps, std::vector<std::string>* rows, bool* gap_note) {
     const size_t n = a.n;
     rows->assign(n, "");
     const Mum& first = a.pool[(size_t)ct.mums[0]];
@@ -35,33 +72,14 @@ void build_rows(const Aligner& a, const Lcb& ct, std::vector<std::string>* rows,
     };
     for (size_t t = 0; t < ct.mums.size(); t++) {
         const Mum& m = a.pool[(size_t)ct.mums[t]];
-        const bool last = t + 1 == ct.mums.size();
         for (size_t i = 0; i < n; i++) (*rows)[i] += mum_text(m, i);
-        if (last) break;
-        const Mum& nx = a.pool[(size_t)ct.mums[t + 1]];
-        std::vector<std::string> gap(n);
-        unsigned max_len = 0, min_len = 1000000;
-        for (size_t i = 0; i < n; i++) {
-            const std::string& g = a.genomes[i].seq;
-            if (!first.fwd[i]) {
-                if (m.start[i] - nx.end[i] >= 1) gap[i] = upper(reverse_complement(sub(g, nx.end[i], m.start[i] - nx.end[i])));
-            } else {
-                gap[i] = upper(sub(g, m.end[i], nx.start[i] - m.end[i]));
-            }
-            if (gap[i].size() > max_len) max_len = (unsigned)gap[i].size();
-            if (gap[i].size() < min_len) min_len = (unsigned)gap[i].size();
-        }
-        if (max_len > 1 && min_len > 0) {
-            // reference: MUSCLE(maxiters=1) over the n gap strings (:848-861); a single genome is never aligned
-            std::vector<std::string> aligned;
-            if (n > 1 && gap_align(gap, &aligned)) {
-                for (size_t i = 0; i < n; i++) (*rows)[i] += aligned[i];
-            } else {
-                if (n > 1) *gap_note = true;   // n == 1: the reference appends the gap as it is (:809-826)
-                for (size_t i = 0; i < n; i++) (*rows)[i] += gap[i] + std::string(max_len - gap[i].size(), '-');
-            }
-        } else if (max_len > 0) {
-            for (size_t i = 0; i < n; i++) (*rows)[i] += gap[i] + std::string(max_len - gap[i].size(), '-');
+        if (t + 1 == ct.mums.size()) break;
+        const Gap& gp = gaps[t];
+        if (gp.align && !gp.failed) {
+            for (size_t i = 0; i < n; i++) (*rows)[i] += gp.aligned[i];
+        } else if (gp.max_len > 0) {
+            if (gp.failed) *gap_note = true;
+            for (size_t i = 0; i < n; i++) (*rows)[i] += gp.seq[i] + std::string(gp.max_len - gp.seq[i].size(), '-');
         }
     }
 }
@@ -99,18 +117,30 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     }
     xmfa << "#IntervalCount " << printable << endl;
 
-    // rows of every printable LCB (the reference does this under OpenMP; rows are independent)
+    // rows of every printable LCB (the reference does this under OpenMP over the LCBs; rows are independent)
     vector<vector<string>> rows(a.lcbs.size());
     vector<char> notes(a.lcbs.size(), 0);
     const long nl = (long)a.lcbs.size();
-#pragma omp parallel for schedule(dynamic) num_threads(prm.cores > 0 ? prm.cores : 1)
+    const int threads = prm.cores > 0 ? prm.cores : 1;
+    vector<vector<Gap>> gaps(a.lcbs.size());
+    auto printable_lcb = [&](const Lcb& ct) { return ct.type == 1 && !ct.mums.empty() && prm.do_align != 0; };
+#pragma omp parallel for schedule(dynamic) num_threads(threads)
+    for (long z = 0; z < nl; z++)
+        if (printable_lcb(a.lcbs[(size_t)z])) gap_strings(a, a.lcbs[(size_t)z], &gaps[(size_t)z]);
+    vector<Gap*> jobs;
+    for (auto& g : gaps) for (Gap& gp : g) if (gp.align) jobs.push_back(&gp);
+    const long nj = (long)jobs.size();
+#pragma omp parallel for schedule(dynamic) num_threads(threads)
+    for (long x = 0; x < nj; x++) { Gap& gp = *jobs[(size_t)x]; gp.failed = !gap_align(gp.seq, &gp.aligned); }
+#pragma omp parallel for schedule(dynamic) num_threads(threads)
     for (long z = 0; z < nl; z++) {
         const Lcb& ct = a.lcbs[(size_t)z];
         rows[(size_t)z].assign(n, "");
-        if (ct.type == 1 && !ct.mums.empty() && prm.do_align != 0) {
+        if (printable_lcb(ct)) {
             bool note = false;
-            build_rows(a, ct, &rows[(size_t)z], &note);
+            build_rows(a, ct, gaps[(size_t)z], &rows[(size_t)z], &note);
             notes[(size_t)z] = note;
+            vector<Gap>().swap(gaps[(size_t)z]);
         }
     }
     for (char c : notes) if (c) *gap_note = true;
