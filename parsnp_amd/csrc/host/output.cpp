@@ -26,9 +26,9 @@ std::string sub(const std::string& g, long pos, long len) {   // std::string::su
 
 // rows of one LCB: MUMs interleaved with the gaps between consecutive MUMs (:663-916), in three steps so that the gap
 // alignments of ALL LCBs can be spread over the threads (one long LCB holds hundreds of them):
-//   gap_strings()  the unaligned gap strings between consecutive MUMs and whether the reference would align them
-//   gap_align()    per gap, by the caller, in one flat parallel loop
-//   build_rows()   concatenation
+//   gaps_to_align()  the gaps the reference would hand to MUSCLE (the others are padded on the fly)
+//   gap_align()      per gap, by the caller, in one flat parallel loop
+//   build_rows()     concatenation
 struct Gap {
     std::vector<std::string> seq;       // per genome
     std::vector<std::string> aligned;   // filled when `align`
@@ -36,33 +36,41 @@ struct Gap {
     bool align = false, failed = false;
 };
 
-void gap_strings(const Aligner& a, const Lcb& ct, std::vector<Gap>* gaps) {
+// the gap between MUM t and MUM t+1 of an LCB (gp is reused by the caller: no allocation in the common one-column case)
+void gap_between(const Aligner& a, const Lcb& ct, size_t t, Gap* gp) {
     const size_t n = a.n;
     const Mum& first = a.pool[(size_t)ct.mums[0]];
-    gaps->assign(ct.mums.size() - 1, Gap());
-    for (size_t t = 0; t + 1 < ct.mums.size(); t++) {
-        const Mum& m = a.pool[(size_t)ct.mums[t]];
-        const Mum& nx = a.pool[(size_t)ct.mums[t + 1]];
-        Gap& gp = (*gaps)[t];
-        gp.seq.assign(n, "");
-        unsigned max_len = 0, min_len = 1000000;
-        for (size_t i = 0; i < n; i++) {
-            const std::string& g = a.genomes[i].seq;
-            if (!first.fwd[i]) {
-                if (m.start[i] - nx.end[i] >= 1) gp.seq[i] = upper(reverse_complement(sub(g, nx.end[i], m.start[i] - nx.end[i])));
-            } else {
-                gp.seq[i] = upper(sub(g, m.end[i], nx.start[i] - m.end[i]));
-            }
-            if (gp.seq[i].size() > max_len) max_len = (unsigned)gp.seq[i].size();
-            if (gp.seq[i].size() < min_len) min_len = (unsigned)gp.seq[i].size();
+    const Mum& m = a.pool[(size_t)ct.mums[t]];
+    const Mum& nx = a.pool[(size_t)ct.mums[t + 1]];
+    gp->seq.resize(n);
+    unsigned max_len = 0, min_len = 1000000;
+    for (size_t i = 0; i < n; i++) {
+        const std::string& g = a.genomes[i].seq;
+        if (!first.fwd[i]) {
+            if (m.start[i] - nx.end[i] >= 1) gp->seq[i] = upper(reverse_complement(sub(g, nx.end[i], m.start[i] - nx.end[i])));
+            else gp->seq[i].clear();
+        } else {
+            gp->seq[i] = upper(sub(g, m.end[i], nx.start[i] - m.end[i]));
         }
-        gp.max_len = max_len;
-        // reference: MUSCLE(maxiters=1) over the n gap strings (:848-861); a single genome is never aligned (:809-826)
-        gp.align = max_len > 1 && min_len > 0 && n > 1;
+        if (gp->seq[i].size() > max_len) max_len = (unsigned)gp->seq[i].size();
+        if (gp->seq[i].size() < min_len) min_len = (unsigned)gp->seq[i].size();
+    }
+    gp->max_len = max_len;
+    // reference: MUSCLE(maxiters=1) over the n gap strings (:848-861); a single genome is never aligned (:809-826)
+    gp->align = max_len > 1 && min_len > 0 && n > 1;
+    gp->failed = false;
+}
+
+// the gaps of an LCB that go to the aligner, in order, each with its position t
+void gaps_to_align(const Aligner& a, const Lcb& ct, std::vector<std::pair<size_t, Gap>>* out) {
+    Gap gp;
+    for (size_t t = 0; t + 1 < ct.mums.size(); t++) {
+        gap_between(a, ct, t, &gp);
+        if (gp.align) out->emplace_back(t, gp);
     }
 }
 
-void build_rows(const Aligner& a, const Lcb& ct, const std::vector<Gap>& gaps, std::vector<std::string>* rows, bool* gap_note) {
+void build_rows(const Aligner& a, const Lcb& ct, const std::vector<std::pair<size_t, Gap>>& aligned, std::vector<std::string>* rows, bool* gap_note) {
     const size_t n = a.n;
     rows->assign(n, "");
     const Mum& first = a.pool[(size_t)ct.mums[0]];
@@ -70,17 +78,20 @@ void build_rows(const Aligner& a, const Lcb& ct, const std::vector<Gap>& gaps, s
         std::string t = sub(a.genomes[i].seq, m.start[i], m.length);
         return lower(first.fwd[i] ? t : reverse_complement(t));
     };
+    Gap gp;
+    size_t next_aligned = 0;
     for (size_t t = 0; t < ct.mums.size(); t++) {
         const Mum& m = a.pool[(size_t)ct.mums[t]];
         for (size_t i = 0; i < n; i++) (*rows)[i] += mum_text(m, i);
         if (t + 1 == ct.mums.size()) break;
-        const Gap& gp = gaps[t];
-        if (gp.align && !gp.failed) {
-            for (size_t i = 0; i < n; i++) (*rows)[i] += gp.aligned[i];
-        } else if (gp.max_len > 0) {
-            if (gp.failed) *gap_note = true;
-            for (size_t i = 0; i < n; i++) (*rows)[i] += gp.seq[i] + std::string(gp.max_len - gp.seq[i].size(), '-');
+        if (next_aligned < aligned.size() && aligned[next_aligned].first == t) {
+            const Gap& ag = aligned[next_aligned++].second;
+            if (!ag.failed) { for (size_t i = 0; i < n; i++) (*rows)[i] += ag.aligned[i]; continue; }
+            *gap_note = true;
         }
+        gap_between(a, ct, t, &gp);
+        if (gp.max_len > 0)
+            for (size_t i = 0; i < n; i++) (*rows)[i] += gp.seq[i] + std::string(gp.max_len - gp.seq[i].size(), '-');
     }
 }
 }  // namespace
@@ -122,13 +133,13 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     vector<char> notes(a.lcbs.size(), 0);
     const long nl = (long)a.lcbs.size();
     const int threads = prm.cores > 0 ? prm.cores : 1;
-    vector<vector<Gap>> gaps(a.lcbs.size());
+    vector<vector<pair<size_t, Gap>>> gaps(a.lcbs.size());
     auto printable_lcb = [&](const Lcb& ct) { return ct.type == 1 && !ct.mums.empty() && prm.do_align != 0; };
 #pragma omp parallel for schedule(dynamic) num_threads(threads)
     for (long z = 0; z < nl; z++)
-        if (printable_lcb(a.lcbs[(size_t)z])) gap_strings(a, a.lcbs[(size_t)z], &gaps[(size_t)z]);
+        if (printable_lcb(a.lcbs[(size_t)z])) gaps_to_align(a, a.lcbs[(size_t)z], &gaps[(size_t)z]);
     vector<Gap*> jobs;
-    for (auto& g : gaps) for (Gap& gp : g) if (gp.align) jobs.push_back(&gp);
+    for (auto& g : gaps) for (auto& tg : g) jobs.push_back(&tg.second);
     const long nj = (long)jobs.size();
 #pragma omp parallel for schedule(dynamic) num_threads(threads)
     for (long x = 0; x < nj; x++) { Gap& gp = *jobs[(size_t)x]; gp.failed = !gap_align(gp.seq, &gp.aligned); }
@@ -140,7 +151,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
             bool note = false;
             build_rows(a, ct, gaps[(size_t)z], &rows[(size_t)z], &note);
             notes[(size_t)z] = note;
-            vector<Gap>().swap(gaps[(size_t)z]);
+            vector<pair<size_t, Gap>>().swap(gaps[(size_t)z]);
         }
     }
     for (char c : notes) if (c) *gap_note = true;
