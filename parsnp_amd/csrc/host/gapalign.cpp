@@ -191,10 +191,12 @@ bool clustalw_weights(const Tree& t, std::vector<float>* w) {
 }
 
 // ---------------------------------------------------------------------------------------------- profiles
-struct Msa {
-    std::vector<unsigned> ids;
-    std::vector<std::string> rows;
-    size_t cols() const { return rows.empty() ? 0 : rows[0].size(); }
+struct Msa {                    // column-major: column c holds the ns characters col[c*ns .. c*ns+ns)
+    std::vector<unsigned> ids;  // ns sequence ids, row order
+    std::vector<char> col;
+    size_t ns = 0, nc = 0;
+    size_t cols() const { return nc; }
+    char at(size_t s, size_t c) const { return col[c * ns + s]; }
 };
 
 struct ProfPos {
@@ -217,7 +219,7 @@ void sort_counts(const float c[4], unsigned order[4]) {   // profilefrommsa.cpp:
 }
 
 void build_profile(const Msa& m, const std::vector<float>& seq_weight, std::vector<ProfPos>* prof) {
-    const size_t ns = m.rows.size(), nc = m.cols();
+    const size_t ns = m.ns, nc = m.nc;
     // msa2.cpp:418-431 + msa.cpp:369-381: this alignment's weights, rescaled to sum 1
     std::vector<float> w(ns);
     float total = 0;
@@ -229,11 +231,11 @@ void build_profile(const Msa& m, const std::vector<float>& seq_weight, std::vect
         float cnt[4] = {0, 0, 0, 0};
         float start = 0, end = 0;
         for (size_t s = 0; s < ns; s++) {
-            const char ch = m.rows[s][c];
+            const char ch = m.at(s, c);
             const float ws = w[s];
             if (is_gap(ch)) {
-                if (c == 0 || !is_gap(m.rows[s][c - 1])) start += ws;
-                if (c + 1 == nc || !is_gap(m.rows[s][c + 1])) end += ws;
+                if (c == 0 || !is_gap(m.at(s, c - 1))) start += ws;
+                if (c + 1 == nc || !is_gap(m.at(s, c + 1))) end += ws;
                 continue;
             }
             const uint8_t l = kAlpha.letter[(uint8_t)ch];
@@ -391,15 +393,17 @@ bool align_two(const Msa& a, const Msa& b, const std::vector<float>& seq_weight,
     build_profile(b, seq_weight, &pb);
     std::string path;
     if (!nw_small(pa, pb, &path)) return false;
-    const size_t na = a.rows.size(), nb = b.rows.size();
+    const size_t na = a.ns, nb = b.ns, ns = na + nb;
     out->ids = a.ids;
     out->ids.insert(out->ids.end(), b.ids.begin(), b.ids.end());
-    out->rows.assign(na + nb, std::string(path.size(), '-'));
+    out->ns = ns; out->nc = path.size();
+    out->col.assign(ns * path.size(), '-');
     size_t ca = 0, cb = 0;
-    for (size_t c = 0; c < path.size(); c++) {   // aligngivenpath.cpp:124-255
+    for (size_t c = 0; c < path.size(); c++) {   // aligngivenpath.cpp:124-255: a column of A, of B, or of both, stacked
         const char t = path[c];
-        if (t != 'I') { for (size_t s = 0; s < na; s++) out->rows[s][c] = a.rows[s][ca]; ca++; }
-        if (t != 'D') { for (size_t s = 0; s < nb; s++) out->rows[na + s][c] = b.rows[s][cb]; cb++; }
+        char* dst = &out->col[c * ns];
+        if (t != 'I') { if (ca >= a.nc) return false; memcpy(dst, &a.col[ca * na], na); ca++; }
+        if (t != 'D') { if (cb >= b.nc) return false; memcpy(dst + na, &b.col[cb * nb], nb); cb++; }
     }
     return ca == a.cols() && cb == b.cols();
 }
@@ -428,13 +432,14 @@ bool gap_align(const std::vector<std::string>& seqs, std::vector<std::string>* r
     for (;;) {
         if (tree.leaf(v)) {
             at[v].ids.assign(1, v);
-            at[v].rows.assign(1, s[v]);
+            at[v].col.assign(s[v].begin(), s[v].end());
+            at[v].ns = 1; at[v].nc = s[v].size();
         } else {
             Msa& l = at[tree.left[v]];
             Msa& r = at[tree.right[v]];
             if (!align_two(l, r, weight, &at[v])) return false;
-            Msa().rows.swap(l.rows);
-            Msa().rows.swap(r.rows);
+            std::vector<char>().swap(l.col);
+            std::vector<char>().swap(r.col);
         }
         if (v == tree.root()) break;
         const unsigned p = tree.parent[v];
@@ -444,7 +449,11 @@ bool gap_align(const std::vector<std::string>& seqs, std::vector<std::string>* r
     }
     const Msa& fin = at[tree.root()];
     std::vector<std::string> out(n);
-    for (size_t k = 0; k < fin.ids.size(); k++) out[fin.ids[k]] = fin.rows[k];
+    for (size_t k = 0; k < fin.ids.size(); k++) {
+        std::string& row = out[fin.ids[k]];
+        row.resize(fin.nc);
+        for (size_t c = 0; c < fin.nc; c++) row[c] = fin.at(k, c);
+    }
     rows->swap(out);
     return true;
 }

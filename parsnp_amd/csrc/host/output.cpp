@@ -4,6 +4,7 @@
 // (:790-865, src/MuscleInterface.cpp:37-78); here they go to gapalign.cpp, the restatement of that aligner.  Should it
 // ever decline an input, the gap is emitted left-justified and '-'-padded and the log carries a note.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -73,6 +74,11 @@ void gaps_to_align(const Aligner& a, const Lcb& ct, std::vector<std::pair<size_t
 void build_rows(const Aligner& a, const Lcb& ct, const std::vector<std::pair<size_t, Gap>>& aligned, std::vector<std::string>* rows, bool* gap_note) {
     const size_t n = a.n;
     rows->assign(n, "");
+    {   // final row length, roughly: reference span plus a little for gap columns (avoids repeated regrowth)
+        const long span = ct.end[0] - ct.start[0];
+        const size_t guess = span > 0 ? (size_t)span + (size_t)span / 16 + 64 : 64;
+        for (size_t i = 0; i < n; i++) (*rows)[i].reserve(guess);
+    }
     const Mum& first = a.pool[(size_t)ct.mums[0]];
     auto mum_text = [&](const Mum& m, size_t i) {
         std::string t = sub(a.genomes[i].seq, m.start[i], m.length);
@@ -134,15 +140,35 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     const long nl = (long)a.lcbs.size();
     const int threads = prm.cores > 0 ? prm.cores : 1;
     vector<vector<pair<size_t, Gap>>> gaps(a.lcbs.size());
+    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    auto clock_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tl = clock_s();
+    auto lap = [&](const char* what) { if (dbg) { double t = clock_s(); fprintf(stderr, "[output] %-14s %.4f s\n", what, t - tl); tl = t; } };
     auto printable_lcb = [&](const Lcb& ct) { return ct.type == 1 && !ct.mums.empty() && prm.do_align != 0; };
 #pragma omp parallel for schedule(dynamic) num_threads(threads)
     for (long z = 0; z < nl; z++)
         if (printable_lcb(a.lcbs[(size_t)z])) gaps_to_align(a, a.lcbs[(size_t)z], &gaps[(size_t)z]);
+    lap("gap strings");
     vector<Gap*> jobs;
     for (auto& g : gaps) for (auto& tg : g) jobs.push_back(&tg.second);
+    // longest first: the cost of one alignment grows with the square of the gap length, and a long one started last
+    // would leave every other thread idle
+    std::sort(jobs.begin(), jobs.end(), [](const Gap* x, const Gap* y) { return x->max_len > y->max_len; });
     const long nj = (long)jobs.size();
-#pragma omp parallel for schedule(dynamic) num_threads(threads)
-    for (long x = 0; x < nj; x++) { Gap& gp = *jobs[(size_t)x]; gp.failed = !gap_align(gp.seq, &gp.aligned); }
+    vector<double> jt(dbg ? (size_t)nj : 0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (long x = 0; x < nj; x++) {
+        Gap& gp = *jobs[(size_t)x];
+        const double t0 = dbg ? clock_s() : 0;
+        gp.failed = !gap_align(gp.seq, &gp.aligned);
+        if (dbg) jt[(size_t)x] = clock_s() - t0;
+    }
+    if (dbg && nj) {
+        double sum = 0, mx = 0; long arg = 0;
+        for (long x = 0; x < nj; x++) { sum += jt[(size_t)x]; if (jt[(size_t)x] > mx) { mx = jt[(size_t)x]; arg = x; } }
+        fprintf(stderr, "[output] %ld gap alignments, %.3f s of work, longest %.3f s (gap of %u columns)\n", nj, sum, mx, jobs[(size_t)arg]->max_len);
+    }
+    lap("gap alignment");
 #pragma omp parallel for schedule(dynamic) num_threads(threads)
     for (long z = 0; z < nl; z++) {
         const Lcb& ct = a.lcbs[(size_t)z];
@@ -155,6 +181,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         }
     }
     for (char c : notes) if (c) *gap_note = true;
+    lap("rows");
 
     int prev_end = 0;
     string rec;
@@ -232,6 +259,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         xmfa << "=\n";
     }
 
+    lap("xmfa records");
     // ---- log (:1082-1190); stream flags are sticky exactly as in the reference
     log << "Number of sequences analyzed:" << setiosflags(ios::fixed) << setprecision(1) << setw(10) << n << endl << endl;
     for (size_t i = 0; i < n; i++) {
