@@ -49,11 +49,17 @@ def make_inputs(workdir, workload, genomes, rank):
 
 
 def cpu_baseline(workdir, rp, qs, sample_queries):
-    """the reference binary on a bounded sample (ref + the first `sample_queries` genomes), 1 thread"""
+    """the reference binary on a bounded sample (ref + the first `sample_queries` genomes), 1 thread; where the prebuilt
+    reference binary did not travel, the CPU restatement of the path (oracle provider behind the same host code)"""
     from parsnp_amd import driver
     refbin = os.path.join(ROOT, "oracle", "_ref", "parsnp_core_ref")
+    kind, what = "reference", "reference parsnp_core (oracle/_ref)"
     if not os.path.exists(refbin):
-        return None
+        refbin = os.path.join(ROOT, "oracle", "_ref", "parsnp_core_oracle")
+        kind, what = "port", "CPU restatement (oracle/_ref/parsnp_core_oracle: this repo's host code over oracle/mum_oracle.c)"
+        sample_queries = 1
+        if not os.path.exists(refbin):
+            return None
     out = os.path.join(workdir, "cpu_baseline")
     t0 = time.time()
     rc, _ = driver.run_core(refbin, rp, qs[:sample_queries], out, threads=1)
@@ -65,9 +71,9 @@ def cpu_baseline(workdir, rp, qs, sample_queries):
     path_s = sum(timers)
     if path_s <= 0:
         path_s = wall
-    return {"value": round(sample_queries / path_s, 5), "unit": "genomes/s", "cores": 1, "kind": "reference",
-            "sample": "reference parsnp_core (oracle/_ref) on ref + first %d query genomes of the workload; phases A-D by its own "
-                      "1-s log timers = %.0f s, whole process %.1f s; host has %d cores" % (sample_queries, path_s, wall, os.cpu_count())}
+    return {"value": round(sample_queries / path_s, 5), "unit": "genomes/s", "cores": 1, "kind": kind,
+            "sample": "%s on ref + first %d query genomes of the workload; phases A-D by its own "
+                      "1-s log timers = %.0f s, whole process %.1f s; host has %d cores" % (what, sample_queries, path_s, wall, os.cpu_count())}
 
 
 def exchange_intervals(torch, dist, tdev, intervals):
@@ -234,7 +240,7 @@ def main():
                 "regions": {"processed": rep["regions_processed"], "engine_calls": rep["finder_calls"], "cache_misses": rep["cache_misses"],
                             "speculative_rounds": rep["spec_rounds"]},
                 "roofline": roof,
-                "cpu_baseline": cpu_baseline(workdir, rp, qs, args.cpu_sample) if args.cpu_sample > 0 else None,
+                "cpu_baseline": cpu_baseline(workdir, rp, qs, args.cpu_sample) if (args.cpu_sample > 0 and world == 1) else None,
             }
             print(json.dumps(line))
         if dist is not None:
