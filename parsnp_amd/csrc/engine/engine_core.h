@@ -297,7 +297,16 @@ public:
 
         // -- Master.EP, candidates
         be.mark("master_ep");
-        be.launch("master_ep", ntiles, MasterEP{d_R.p, nreg, d_tilebase.p, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, g_first, g_last});
+        {
+            std::vector<int64_t> cbase((size_t)nreg + 1, 0);
+            for (int64_t r = 0; r < nreg; r++) cbase[(size_t)r + 1] = cbase[(size_t)r] + (((int64_t)R[(size_t)r].nR + (1 << kCoarseShift) - 1) >> kCoarseShift) + 1;
+            const int64_t centries = cbase[(size_t)nreg] * nq;
+            if (centries >= (1ll << 31)) { error = "coarse event index too large"; return -5; }
+            ensure(d_cbase, (size_t)nreg + 1); ensure(d_coarse, (size_t)std::max<int64_t>(centries, 1));
+            be.h2d(d_cbase.p, cbase.data(), 8 * ((size_t)nreg + 1));
+            be.launch("coarse_index", centries, CoarseIndex{d_R.p, nreg, d_cbase.p, nq, skey, d_lo.p, lbits, d_coarse.p});
+        }
+        be.launch("master_ep", ntiles, MasterEP{d_R.p, nreg, d_tilebase.p, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last});
         if (coll.world > 1 && npos > 0) {   // exchange 1: Master.EP = min over the ranks' genome blocks
             be.mark("exchange_ep");
             std::vector<int32_t> h((size_t)npos);
@@ -422,7 +431,7 @@ private:
     Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2, d_evkey3, d_evval3; Buf<int64_t> d_sliceoff;
     Buf<int64_t> d_lo, d_cov; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
     Buf<uint64_t> d_cand, d_cand2; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
-    Buf<int64_t> d_okcnt, d_okpos; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;
+    Buf<int64_t> d_okcnt, d_okpos, d_cbase; Buf<int32_t> d_coarse; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;
 };
 
 }  // namespace pm

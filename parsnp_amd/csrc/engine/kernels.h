@@ -799,9 +799,32 @@ struct MumiCoverage {
 // ------------------------------------------------------------------------------------------ Master.EP
 // Master[k].EP = min over query genomes of max(EP_fwd[k], EP_rev[k])  (Intersect_UM's min fold mum.c:163 +
 // Merge_Master mum.c:92-123; order independent).  tid = one tile of 16 reference positions.
+// Coarse index over the sorted events of every (region, genome) pair: coarse[..b] = number of the pair's events with
+// l < b * 1024.  MasterEP's per-tile binary search then runs over the events of one 1024-position block (a handful)
+// instead of all events of the pair (17 dependent probes per genome at 5 Mb).  tid = table entry; the entries of region r
+// are [cbase[r]*nq, cbase[r+1]*nq), genome-major, blocks_r + 1 entries per genome.
+constexpr int kCoarseShift = 10;
+struct CoarseIndex {
+    const RegionInfo* R; int64_t nregions; const int64_t* cbase; int32_t nq;
+    const uint64_t* key; const int64_t* lo; int lbits; int32_t* coarse;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t r = upper_slot(cbase, nregions, tid / nq);
+        const int64_t per = cbase[r + 1] - cbase[r];            // blocks + 1
+        const int64_t rel = tid - cbase[r] * nq;
+        const int g = (int)(rel / per); const int64_t b = rel % per;
+        const int64_t pair = r * nq + g;
+        int64_t a = lo[pair], e = lo[pair + 1];
+        if (b == per - 1) { coarse[tid] = (int32_t)(e - a); return; }
+        const uint64_t want = (((uint64_t)pair << lbits) | (uint64_t)(b << kCoarseShift)) << 1;     // first event with l >= b * 1024
+        int64_t x = a, y = e;
+        while (x < y) { int64_t mid = (x + y) >> 1; if (key[mid] < want) x = mid + 1; else y = mid; }
+        coarse[tid] = (int32_t)(x - a);
+    }
+};
 struct MasterEP {
     const RegionInfo* R; int64_t nregions; const int64_t* tile_base;   // tile_base[nregions+1]
     int32_t ngen; const uint64_t* key; const int64_t* lo; const int32_t* emax; int lbits; int32_t* epm;
+    const int64_t* cbase; const int32_t* coarse;
     int32_t g_first, g_last;   // sharded run: the min over the other genomes arrives by all-reduce
     PM_HD void operator()(int64_t tid) const {
         int64_t r = upper_slot(tile_base, nregions, tid);
@@ -810,13 +833,17 @@ struct MasterEP {
         int32_t ep[kTile];
         for (int t = 0; t < kTile; t++) ep[t] = ri.nR;
         const uint64_t lmask = (1ull << lbits) - 1;
+        const int64_t per = cbase[r + 1] - cbase[r];
+        const int64_t cblock = k0 >> kCoarseShift;             // a tile of 16 positions lies inside one 1024-position block
         for (int g = g_first - 1; g < g_last - 1; g++) {
             int64_t pair = r * (ngen - 1) + g;
-            int64_t a = lo[pair], b = lo[pair + 1], end = b;
-            // first event with l > k0
+            const int64_t first = lo[pair], end = lo[pair + 1];
+            const int32_t* cg = coarse + cbase[r] * (ngen - 1) + (int64_t)g * per + cblock;
+            int64_t a = first + cg[0], b = first + cg[1];
+            // first event with l > k0 (it is inside the block, or the first event of the next block)
             uint64_t want = ((((uint64_t)pair << lbits) | (uint64_t)k0) << 1) | 1ull;
             while (a < b) { int64_t mid = (a + b) >> 1; if (key[mid] <= want) a = mid + 1; else b = mid; }
-            int32_t cur = a > lo[pair] ? emax[a - 1] : 0;
+            int32_t cur = a > first ? emax[a - 1] : 0;
             int64_t e = a;
             for (int t = 0; t < kTile; t++) {
                 int32_t k = k0 + t;
