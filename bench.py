@@ -76,6 +76,18 @@ def cpu_baseline(workdir, rp, qs, sample_queries):
                       "1-s log timers = %.0f s, whole process %.1f s; host has %d cores" % (what, sample_queries, path_s, wall, os.cpu_count())}
 
 
+def usable_cpus():
+    """CPUs this process may use: affinity mask, capped by the cgroup CPU quota (cpu.max) where there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def exchange_intervals(torch, dist, tdev, intervals):
     """all-gather the per-rank [start,end] lists (padded to the longest) and intersect them -> bases aligned in every partition"""
     from parsnp_amd.partition_run import intersect
@@ -102,7 +114,9 @@ def main():
     ap.add_argument("--workload", default="bact200")
     ap.add_argument("--genomes", type=int, default=0, help="override the number of query genomes per partition")
     ap.add_argument("--cpu-sample", type=int, default=2, help="query genomes in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--host-threads", type=int, default=24, help="ini [LCB] cores: host threads for ingest, candidate validation, output")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="ini [LCB] cores: host threads for ingest, candidate validation, output (0 = 24, fewer when the CPUs this "
+                         "container may use, shared by the ranks of the node, do not allow it)")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
@@ -134,6 +148,10 @@ def main():
 
     from parsnp_amd import driver
     from parsnp_amd.core_api import CoreRun
+    if args.host_threads <= 0:
+        # the parallel host phases are short bursts, so 1.5 threads per usable CPU still helps; all ranks share the node
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        args.host_threads = max(4, min(24, int(1.5 * usable_cpus() / max(1, local_world))))
 
     # scratch for the synthetic FASTA (~1 GB per rank at 200 x 5 Mb) and, on rank 0, the XMFA (~1 GB): RAM disk when it has
     # room for every rank of this node, else the default temp dir
