@@ -257,7 +257,7 @@ def main():
                            % (args.workload, G, n_ref / 1e6, dict(bact200="population").get(args.workload, "synthetic"),
                               ", ".join("%s=%s" % (k, v) for k, v in sorted(kw.items()) if k not in ("n", "n_genomes")),
                               "" if world == 1 else "; one partition per rank, %d ranks" % world),
-                           "genomes_per_gpu": G, "genome_bp": n_ref, "host_threads": args.host_threads, "parallelism": "partition-per-gpu x%d" % world},
+                           "genomes_per_gpu": G, "genome_bp": n_ref, "host_threads": args.host_threads, "host_cpus_usable": usable_cpus(), "parallelism": "partition-per-gpu x%d" % world},
                 "step_ms": step_ms,
                 "core_bp_aligned": core_bp_total,
                 "core_bp_in_every_partition": merged_bp,
