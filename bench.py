@@ -20,6 +20,7 @@ The JSON line also carries
                 MUM+LCB path is single-threaded, src/parsnp.cpp:1600-1619).
 """
 import argparse
+import gc
 import json
 import os
 import re
@@ -182,6 +183,10 @@ def main():
             run = CoreRun(ini)
             for _ in range(args.warmup):
                 run.step()
+            # the interpreter's cyclic collector would otherwise fire inside one of the few timed steps (a full collection
+            # with torch imported costs ~40 ms): collect now, keep it off while timing
+            gc.collect()
+            gc.disable()
             barrier()
             t0 = time.perf_counter()
             reports = []
@@ -199,6 +204,7 @@ def main():
                 reports.append(rep)
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
+            gc.enable()
             barrier()
             t_out = time.time()
             if rank == 0:
