@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <omp.h>
 
 #include "minlen.h"
 
@@ -44,6 +45,18 @@ void Bitmap::set_range_slow(long a, long b) {
         long span = std::min<long>(64 - lo, b - a);
         uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
         store(wi, w_[wi] | mask);
+        a += span;
+    }
+}
+void Bitmap::set_range_atomic(long a, long b) {
+    if (a < 0) a = 0;
+    if (b > (long)nbits_) b = (long)nbits_;
+    while (a < b) {
+        const size_t wi = (size_t)a >> 6;
+        const int lo = (int)(a & 63);
+        const long span = std::min<long>(64 - lo, b - a);
+        const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
+        __atomic_fetch_or(&w_[wi], mask, __ATOMIC_RELAXED);
         a += span;
     }
 }
@@ -540,7 +553,7 @@ bool Aligner::find_anchors() {
 // spends a third of its recursion time there).  The moment two DIFFERENT regions share a reference start the unstable
 // std::sort's tie order becomes observable; from then on the literal vector + std::sort + adjacent-dedup of the
 // reference runs on exactly the array the reference would hold, until the keys are unique again.
-bool Aligner::extend_pass(bool speculative) {
+bool Aligner::extend_pass(bool speculative, bool sorted_start) {
     std::vector<Region> rpool = std::move(regions);
     regions.clear();
     std::map<long, int> uniq;            // key -> rpool index       (fast mode)
@@ -563,6 +576,26 @@ bool Aligner::extend_pass(bool speculative) {
         for (size_t x = head; x + 1 < work.size(); x++) if (!(work[x].key < work[x + 1].key)) return false;
         return true;
     };
+    // literal mode: sort the waiting part, drop a region equal to its successor (adjacent duplicates only, :294-306), and go
+    // back to the map when the keys are unique again
+    auto normalize = [&]() {
+        if (head < work.size()) std::sort(work.begin() + (long)head, work.end());
+        long rsize = (long)(work.size() - head);
+        if (rsize) {
+            for (long x = 0; x < rsize - 1; x++) {
+                if (rpool[(size_t)work[head + (size_t)x].idx].same_as(rpool[(size_t)work[head + (size_t)x + 1].idx], n)) {
+                    work.erase(work.begin() + (long)head + x);
+                    x -= 1; rsize -= 1;
+                }
+            }
+        }
+        if (!force_literal && keys_unique()) {
+            for (size_t x = head; x < work.size(); x++) uniq.emplace_hint(uniq.end(), work[x].key, work[x].idx);
+            work.clear(); head = 0;
+            literal = false;
+        }
+    };
+    if (sorted_start) normalize();     // continuation of a run whose first region has been processed already: the list is sorted
     for (;;) {
         int cur;
         if (literal) { if (head >= work.size()) break; cur = work[head++].idx; }
@@ -605,21 +638,7 @@ bool Aligner::extend_pass(bool speculative) {
         if (literal) {
             if (!speculative) stats.literal_iterations++;
             for (const Handle& k : kids) work.push_back(k);
-            if (head < work.size()) std::sort(work.begin() + (long)head, work.end());
-            long rsize = (long)(work.size() - head);
-            if (rsize) {   // drop a region equal to its successor (adjacent duplicates only, :294-306)
-                for (long x = 0; x < rsize - 1; x++) {
-                    if (rpool[(size_t)work[head + (size_t)x].idx].same_as(rpool[(size_t)work[head + (size_t)x + 1].idx], n)) {
-                        work.erase(work.begin() + (long)head + x);
-                        x -= 1; rsize -= 1;
-                    }
-                }
-            }
-            if (!force_literal && keys_unique()) {
-                for (size_t x = head; x < work.size(); x++) uniq.emplace_hint(uniq.end(), work[x].key, work[x].idx);
-                work.clear(); head = 0;
-                literal = false;
-            }
+            normalize();
         }
         stats.t_sort += now_s() - ts;
     }
@@ -690,6 +709,191 @@ void Aligner::speculate(std::vector<Region> gen) {
     stats.t_sweep += now_s() - t0;
 }
 
+// The regions of `w` (sorted by reference start) fall into clusters: maximal runs that overlap or touch on the reference
+// (the left region of a MUM and the right region of its predecessor are the same gap, one base apart at the start, so
+// pairs are the rule).  Are the clusters pairwise disjoint in EVERY genome?  Then no MUM found in one cluster (nor in
+// anything derived from it: children lie inside their parent) can touch, trim or bound anything found in another, and the
+// order in which the reference would interleave the clusters is not observable.  first[c] = index of cluster c's first
+// region, first[nclusters] = w.size().
+bool Aligner::disjoint_clusters(const std::vector<Region>& w, std::vector<size_t>* first) const {
+    first->clear();
+    const size_t m = w.size();
+    long reach = -1;
+    for (size_t i = 0; i < m; i++) {
+        if (i == 0 || w[i].start[0] > reach + 1) first->push_back(i);
+        if (w[i].end[0] > reach) reach = w[i].end[0];
+    }
+    first->push_back(m);
+    const long nc = (long)first->size() - 1;
+    if (nc < 2) return true;
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(prm.cores > 0 ? prm.cores : 1) reduction(| : bad)
+    for (long g = 1; g < (long)n; g++) {
+        if (bad) continue;
+        std::vector<std::pair<long, long>> iv((size_t)nc);
+        for (long c = 0; c < nc; c++) {
+            long lo = w[(*first)[(size_t)c]].start[g], hi = w[(*first)[(size_t)c]].end[g];
+            for (size_t i = (*first)[(size_t)c] + 1; i < (*first)[(size_t)c + 1]; i++) {
+                if (w[i].start[g] < lo) lo = w[i].start[g];
+                if (w[i].end[g] > hi) hi = w[i].end[g];
+            }
+            iv[(size_t)c] = std::make_pair(lo, hi);
+        }
+        std::sort(iv.begin(), iv.end());
+        for (long c = 0; c + 1 < nc; c++)
+            if (iv[(size_t)c + 1].first <= iv[(size_t)c].second + 1) { bad = 1; break; }   // touching counts too
+    }
+    return !bad;
+}
+
+// The recursive extension, generation by generation.  The reference pops the region with the smallest reference start,
+// processes it and merges its children into the sorted list (doWork :173-317).  Whenever the regions waiting on the list
+// are pairwise disjoint in every genome that order cannot be seen in the result (the set of accepted MUMs; MUM ids are
+// never read), so all of them -- one generation -- are validated by all threads at once, their engine results coming
+// from one batched call, and their children form the next generation.  The first seed is processed alone, as the
+// reference does before its first sort (:194-195 precede :291-292).  The moment a generation is not disjoint (rearranged
+// genomes, repeats) the in-order replay takes over on exactly the list the reference would hold.
+bool Aligner::extend_generations() {
+    // what a restart of the in-order replay needs (taken when a LATER generation turns out not to be disjoint: by then the
+    // reference's own list -- and with it the tie order of its unstable sort -- can no longer be reconstructed)
+    const std::vector<Region> seeds = regions;
+    const size_t pool0 = pool.size();
+    const std::vector<int> mums0 = mums;
+    auto restart_in_order = [&]() {
+        pool.resize(pool0);
+        mums = mums0;
+        const long nl = (long)n;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(prm.cores > 0 ? prm.cores : 1)
+        for (long g = 0; g < nl; g++) {        // the layout before the extension = the marks of the MUMs accepted so far
+            layout[(size_t)g].init(genomes[(size_t)g].seq.size() + 1);
+            for (size_t x = 0; x < pool0; x++) layout[(size_t)g].set_range(pool[x].start[g], pool[x].end[g]);
+        }
+        regions = seeds;
+        stats.generation_restarts++;
+        if (speculation_) prefetch(regions);
+        return extend_pass(false);
+    };
+    std::vector<Region> gen = std::move(regions);
+    regions.clear();
+    const int threads = prm.cores > 0 ? prm.cores : 1;
+    while ((int)memory_->per_thread.size() < threads) memory_->per_thread.emplace_back(new AlignerMemory::PerThread);
+    struct Out { std::vector<Mum> accepted; std::vector<Region> kids; };
+    int gi = 0;                                  // 0: the first seed alone; 1: the other seeds + its children; 2..: children
+    while (!gen.empty()) {
+        std::vector<Region> now;
+        std::vector<size_t> first;               // clusters of `now`
+        bool trouble = false;
+        if (gi == 0) {                           // the first pushed seed, before anything is sorted
+            now.push_back(gen.front());
+            first = {0, 1};
+        } else {                                 // sort by reference start, drop a region equal to its successor (:291-306)
+            std::vector<Handle> h(gen.size());
+            for (size_t i = 0; i < gen.size(); i++) h[i] = Handle{gen[i].start[0], (int)i};
+            std::sort(h.begin(), h.end());
+            for (size_t i = 0; i < h.size(); i++) {
+                const Region& r = gen[(size_t)h[i].idx];
+                if (!now.empty() && now.back().start[0] == r.start[0]) {
+                    if (now.back().same_as(r, n)) continue;
+                    trouble = true;              // two different regions share a reference start: the unstable sort decides
+                }
+                now.push_back(r);
+            }
+            if (!trouble) trouble = !disjoint_clusters(now, &first);
+        }
+        // engine results of the generation in one call; every region must be one plain request
+        std::vector<CacheEntry*> entry(now.size(), nullptr);
+        std::vector<Request> req(now.size());
+        if (!trouble) {
+            prefetch(now);
+            std::vector<Request> reqs;
+            const Arena<long>::Mark qmark = req_rows_.mark();
+            for (size_t i = 0; i < now.size() && !trouble; i++) {
+                const Region& r = now[i];
+                chunk_requests(r, min_length(false, r.slength), &reqs);
+                if (reqs.size() != 1 || reqs[0].start != r.start || reqs[0].len != r.length) { trouble = true; break; }   // chunked reference (p)
+                entry[i] = cache_find(reqs[0]);
+                if (!entry[i] || entry[i]->pending) { trouble = true; break; }
+                req[i] = reqs[0];
+            }
+            req_rows_.rewind(qmark);
+        }
+        if (trouble) {
+            stats.generation_handover = gi;
+            if (gi == 0) { regions = std::move(gen); if (speculation_) prefetch(regions); return extend_pass(false); }
+            // after the first seed the reference's list is [other seeds in push order, children of the first in push order],
+            // sorted: exactly `gen` as it stands
+            if (gi == 1) { regions = std::move(gen); if (speculation_) prefetch(regions); return extend_pass(false, true); }
+            return restart_in_order();
+        }
+        if (gi == 0) gen.erase(gen.begin()); else gen.clear();
+        const long m = (long)now.size();
+        const long nclusters = (long)first.size() - 1;
+        std::vector<Out> out((size_t)m);
+        int cluster_trouble = 0;
+        double tv = now_s();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(| : cluster_trouble)
+        for (long cl = 0; cl < nclusters; cl++) {
+            AlignerMemory::PerThread& tl = *memory_->per_thread[(size_t)omp_get_thread_num()];
+            long pending_min = -1;                // smallest reference start among the children produced so far in this cluster
+            for (size_t x = first[(size_t)cl]; x < first[(size_t)cl + 1]; x++) {      // the cluster's regions, in the reference's order
+                const Region& r = now[x];
+                // a child that sorts before (or with) this region would have been processed first, and its engine result
+                // is not there yet: give up on the whole generation
+                if (pending_min >= 0 && pending_min <= r.start[0]) { cluster_trouble = 1; break; }
+                const Raw& raw = entry[x]->raw;
+                Out& o = out[x];
+                for (size_t c = 0; c < raw.count; c++) {      // = validate(), with per-thread rows and atomic marks
+                    Mum mm;
+                    const Arena<long>::Mark rmark = tl.rows.mark();
+                    const Arena<int>::Mark imark = tl.irows.mark();
+                    mm.start = tl.rows.alloc(n); mm.end = tl.rows.alloc(n); mm.fwd = tl.irows.alloc(n);
+                    bool ok, any_reverse;
+                    if (!candidate_rows(r, req[x], raw, c, mm, &ok, &any_reverse)) { tl.rows.rewind(rmark); tl.irows.rewind(imark); continue; }
+                    bool touches = false;
+                    if (ok && mm.length > 0)
+                        for (size_t j = 0; j < n; j++) touches |= layout[j].get(mm.start[j]) | layout[j].get(mm.end[j] - 1);
+                    if (!ok || !settle(mm, touches, any_reverse)) { tl.rows.rewind(rmark); tl.irows.rewind(imark); continue; }
+                    for (size_t j = 0; j < n; j++) layout[j].set_range_atomic(mm.start[j], mm.end[j]);
+                    mm.slength = r.slength;
+                    o.accepted.push_back(mm);
+                }
+                // children: left of the first new MUM, right of each, left of the next (:215-254); one that equals a region
+                // still waiting in this cluster is dropped, as the work list drops a region equal to one it holds
+                auto neighbour = [&](const Mum& mu, bool left) {
+                    Region k;
+                    k.start = tl.rows.alloc(n); k.end = tl.rows.alloc(n); k.length = tl.rows.alloc(n);
+                    neighbour_into(mu, left, &k);
+                    return k;
+                };
+                auto keep = [&](const Region& k) {
+                    if (k.slength <= prm.q) return;
+                    for (size_t y = x + 1; y < first[(size_t)cl + 1]; y++) if (now[y].same_as(k, n)) return;
+                    o.kids.push_back(k);
+                    if (pending_min < 0 || k.start[0] < pending_min) pending_min = k.start[0];
+                };
+                Region lR, rR;
+                for (size_t i = 0; i < o.accepted.size(); i++) {
+                    if (i == 0) lR = neighbour(o.accepted[0], true);
+                    rR = neighbour(o.accepted[i], false);
+                    keep(lR);
+                    keep(rR);
+                    if (i + 1 < o.accepted.size()) lR = neighbour(o.accepted[i + 1], true);
+                }
+            }
+        }
+        if (cluster_trouble) { stats.generation_handover = gi; return restart_in_order(); }
+        stats.t_validate += now_s() - tv;
+        stats.generations++; stats.generation_regions += m;
+        for (long x = 0; x < m; x++) {           // commit in list order
+            for (Mum& mm : out[(size_t)x].accepted) { mm.id = next_id_++; pool.push_back(mm); mums.push_back((int)pool.size() - 1); }
+            for (Region& k : out[(size_t)x].kids) gen.push_back(k);
+            stats.regions_processed++; stats.cache_hits++;
+        }
+        gi++;
+    }
+    return !mums.empty();
+}
+
 // Recursive extension.  Every seed region is known before the loop starts, so their engine results come from one
 // batched call.  Children only exist once their parent has been processed in order; the first time the replay needs one
 // that is not cached, a speculative sweep over everything still on the work list predicts and batches the rest.
@@ -697,13 +901,17 @@ bool Aligner::extend() {
     double t0 = now_s();
     speculation_ = getenv("PARSNP_NO_SPECULATION") == nullptr;
     sweeps_ = 0; misses_since_sweep_ = 0;
-    if (speculation_) prefetch(regions);
     double tr = now_s();
-    bool any = extend_pass(false);
+    bool any;
+    if (getenv("PARSNP_SEQUENTIAL_REPLAY") == nullptr) any = extend_generations();
+    else { if (speculation_) prefetch(regions); tr = now_s(); any = extend_pass(false); }
     stats.t_replay = now_s() - tr - stats.t_sweep;
     remaining_ = nullptr;
     cache_.clear();
     stats.extend_s = now_s() - t0;
+    if (getenv("PARSNP_DEBUG_TIMERS"))
+        fprintf(stderr, "[extend] %ld parallel generations (%ld regions), in-order replay from generation %ld, %ld restarts, %ld regions in all\n",
+                stats.generations, stats.generation_regions, stats.generation_handover, stats.generation_restarts, stats.regions_processed);
     return any;
 }
 

@@ -83,6 +83,7 @@ public:
         } else set_range_slow(a, b);
     }
     void set_range_slow(long a, long b);
+    void set_range_atomic(long a, long b);   // [a,b) := 1 with atomic word updates: threads marking neighbouring ranges may share a word
     void clear_range(long a, long b);   // [a,b) := 0
     long next_set(long from) const;     // smallest i >= from with bit set; the sentinel guarantees one for from <= n
     long prev_set(long from) const;     // largest i <= from with bit set, or -1
@@ -185,6 +186,8 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     // device-side phase times (HIP events, pm_last_timing): summed over every engine call of the step, and of the
     // anchor call alone (the one launch that sees whole genomes)
     std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
+    long generations = 0, generation_regions = 0, generation_handover = -1;   // parallel generations, regions in them, generation at which the in-order replay took over (-1: never)
+    long generation_restarts = 0;   // generation-parallel extension abandoned after its second generation (see extend_generations)
     long tie_fallbacks = 0, literal_iterations = 0, parallel_candidates = 0, parallel_dirty = 0;   // work-list ties between different regions (extend_pass)
     double t_validate = 0, t_neighbour = 0, t_key = 0, t_sweep = 0, t_replay = 0, t_sort = 0, t_unpack = 0;   // host split
 };
@@ -195,7 +198,9 @@ struct AlignerMemory {
     Arena<long> rows, cache_rows, req_rows;
     Arena<int> irows;
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
-    void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); }
+    struct PerThread { Arena<long> rows; Arena<int> irows; };
+    std::vector<std::unique_ptr<PerThread>> per_thread;   // rows written by the threads of the generation-parallel replay
+    void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); for (auto& t : per_thread) { t->rows.reset(); t->irows.reset(); } }
 };
 
 class Aligner {
@@ -260,7 +265,9 @@ private:
     bool candidate_rows(const Region& r, const Request& q, const Raw& raw, size_t c, Mum& m, bool* ok, bool* any_reverse) const;
     bool settle(Mum& m, bool touches, bool any_reverse) const;
     void trim(Mum& m) const;
-    bool extend_pass(bool speculative);
+    bool extend_pass(bool speculative, bool sorted_start = false);
+    bool extend_generations();
+    bool disjoint_clusters(const std::vector<Region>& w, std::vector<size_t>* first) const;
     void prefetch(const std::vector<Region>& gen);
     void speculate(std::vector<Region> gen);
     std::function<void(std::vector<Region>*)> remaining_;

@@ -175,6 +175,25 @@ def test_parsnp_core_synthetic(libs, tmp_path, name, exact):
     test_host_logic.check(CORE_BIN, name, rp, qs, str(tmp_path / "out"), exact)
 
 
+@pytest.mark.parametrize("name,mode", [("pop20x1m", "generations"), ("pop20x1m", "in_order"), ("draft20x1m", "generations"), ("poprearr10x400k", "generations")])
+def test_parsnp_core_replay_modes_threaded(libs, tmp_path, name, mode):
+    """8 host threads: the generation-parallel replay of the recursion (clusters of regions validated concurrently, atomic
+    marks) and the forced in-order replay give the reference's bytes"""
+    if name == "pop20x1m":
+        r, gs = synth.make(name)
+        rp, qs = synth.write_set(str(tmp_path / "in"), r, gs); kw = {}
+    else:
+        rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
+    env = dict(os.environ)
+    if mode == "in_order":
+        env["PARSNP_SEQUENTIAL_REPLAY"] = "1"
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=8, **kw)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
+
+
 @pytest.mark.parametrize("name", ["mers", "messy", "pop6x200k_p"])
 def test_parsnp_core_calcmumi(libs, tmp_path, name):
     test_host_logic.check_mumi(CORE_BIN, name, str(tmp_path))

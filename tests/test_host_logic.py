@@ -78,6 +78,20 @@ def test_no_speculation_same_result(cpu_checkers, tmp_path):
     check(cpu_checkers, "pop6x200k", rp, qs, str(tmp_path / "out"), False, env=env)
 
 
+@pytest.mark.parametrize("name,threads", [("pop6x200k", 1), ("pop6x200k", 6), ("messy", 3), ("draft8x300k", 4), ("pchunk", 2)])
+def test_in_order_replay_same_result(cpu_checkers, tmp_path, name, threads):
+    """the recursion is normally replayed generation by generation (clusters of overlapping regions in parallel) and falls
+    back to the reference's in-order replay when a generation is not disjoint; PARSNP_SEQUENTIAL_REPLAY=1 forces the
+    in-order replay from the start.  Both must give the reference's bytes, with one thread and with several."""
+    rp, qs, kw = harsh_inputs(name, str(tmp_path))
+    for tag, extra in (("gen", {}), ("seq", {"PARSNP_SEQUENTIAL_REPLAY": "1"})):
+        out = str(tmp_path / tag)
+        rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=dict(os.environ, **extra), threads=threads, **kw)
+        assert rc == 0
+        assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"], tag
+        assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"], tag
+
+
 @pytest.mark.parametrize("name", ["pop6x200k", "poprearr10x400k"])
 def test_literal_worklist_same_result(cpu_checkers, tmp_path, name):
     """the map-based work list (unique keys) and the reference's literal vector + std::sort + adjacent-dedup agree"""
