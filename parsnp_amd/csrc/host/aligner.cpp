@@ -804,7 +804,7 @@ bool Aligner::extend_generations() {
         std::vector<CacheEntry*> entry(now.size(), nullptr);
         std::vector<Request> req(now.size());
         if (!trouble) {
-            prefetch(now);
+            prefetch(gi == 0 ? gen : now);       // the first call fetches every seed's result: one engine call for all of them
             std::vector<Request> reqs;
             const Arena<long>::Mark qmark = req_rows_.mark();
             for (size_t i = 0; i < now.size() && !trouble; i++) {
