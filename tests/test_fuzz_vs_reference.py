@@ -1,0 +1,94 @@
+"""Seeded random small genome sets -- random sizes, divergence, indels, inversions, translocations, duplicated blocks, N runs,
+multi-contig files, random LCB parameters and thread counts -- through the REFERENCE binary and through our parsnp_core
+side by side: same exit code, same XMFA bytes, same log counters.  CPU run: host logic over the CPU checker; GPU run: the
+product."""
+import os
+
+import numpy as np
+import pytest
+
+import oracles
+import xmfa_util
+from parsnp_amd import driver, synth
+from parsnp_amd.paths import CORE_BIN
+
+REFBIN = os.path.join(oracles.REFDIR, "parsnp_core_ref")
+pytestmark = pytest.mark.skipif(not os.path.exists(REFBIN), reason="reference binary not built/shipped")
+
+
+def random_case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3_000, 60_000))
+    ng = int(rng.integers(2, 9))
+    div = float(rng.choice([0.002, 0.01, 0.03, 0.06]))
+    ref, gs = synth.population(seed=int(rng.integers(1, 1 << 30)), n=n, n_genomes=ng, div=div, indel_frac=float(rng.choice([0.0, 0.05, 0.3])))
+    gs = [bytearray(g) for g in gs]
+    for g in gs:                                            # per-genome structural edits
+        for _ in range(int(rng.integers(0, 4))):
+            L = len(g)
+            a = int(rng.integers(0, max(1, L - 2000))); b = a + int(rng.integers(200, 2000))
+            kind = int(rng.integers(0, 5))
+            if kind == 0:   g[a:b] = oracles.revcomp(bytes(g[a:b]))                       # inversion
+            elif kind == 1: blk = g[a:b]; del g[a:b]; p = int(rng.integers(0, len(g))); g[p:p] = blk   # translocation
+            elif kind == 2: g[b:b] = g[a:b]                                             # tandem duplication
+            elif kind == 3: g[a:a] = b"N" * int(rng.integers(1, 400))                   # N run
+            else:           del g[a:b]                                                  # deletion
+    gs = [bytes(g) for g in gs]
+    if rng.random() < 0.2:
+        gs[0] = oracles.revcomp(gs[0])
+    kw = {}
+    if rng.random() < 0.3: kw["mincluster"] = int(rng.choice([10, 21, 60]))
+    if rng.random() < 0.3: kw["clusterd"] = int(rng.choice([30, 100, 300, 1000]))
+    if rng.random() < 0.2: kw["diagdiff"] = float(rng.choice([0.05, 0.12, 0.4, 20]))
+    if rng.random() < 0.2: kw["anchors"] = str(int(rng.integers(12, 30))); kw["mums"] = str(int(rng.integers(8, 20)))
+    if rng.random() < 0.15: kw["partpos"] = int(rng.integers(2000, max(2001, n // 2)))
+    kw["threads"] = int(rng.choice([1, 1, 3, 6]))
+    contigs = int(rng.choice([1, 1, 1, 3, 7]))
+    return ref, gs, kw, contigs
+
+
+def write(base, ref, gs, contigs, seed):
+    if contigs == 1:
+        return synth.write_set(base, ref, gs)
+    rng = np.random.default_rng(seed)
+    os.makedirs(base, exist_ok=True)
+
+    def cut(g):
+        if len(g) < 400 * contigs:
+            return [g]
+        edges = [0] + sorted(int(x) for x in rng.choice(np.arange(200, len(g) - 200), contigs - 1, replace=False)) + [len(g)]
+        return [g[edges[i]:edges[i + 1]] for i in range(contigs)]
+    rp = os.path.join(base, "ref.fna")
+    synth.write_contigs(rp, "ref", cut(ref))
+    qs = []
+    for i, g in enumerate(gs):
+        p = os.path.join(base, "g%04d.fna" % i)
+        synth.write_contigs(p, "g%04d" % i, cut(g))
+        qs.append(p)
+    return rp, qs
+
+
+def run(core, rp, qs, out, kw):
+    rc, _ = driver.run_core(core, rp, qs, out, timeout=600, **kw)
+    x = os.path.join(out, "parsnpAligner.xmfa")
+    lg = os.path.join(out, "parsnpAligner.log")
+    return (rc, xmfa_util.md5(x) if os.path.exists(x) else None, xmfa_util.log_counters(lg) if os.path.exists(x) else open(lg).read())
+
+
+def side_by_side(core, seed, tmp_path):
+    ref, gs, kw, contigs = random_case(seed)
+    rp, qs = write(str(tmp_path / "in"), ref, gs, contigs, seed)
+    a = run(REFBIN, rp, qs, str(tmp_path / "ref"), kw)
+    b = run(core, rp, qs, str(tmp_path / "mine"), kw)
+    assert a == b, (seed, kw, contigs)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_host_logic(cpu_checkers, tmp_path, seed):
+    side_by_side(cpu_checkers, seed, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_on_gpu(tmp_path, seed):
+    side_by_side(CORE_BIN, seed, tmp_path)
