@@ -16,17 +16,17 @@ REFBIN = os.path.join(oracles.REFDIR, "parsnp_core_ref")
 pytestmark = pytest.mark.skipif(not os.path.exists(REFBIN), reason="reference binary not built/shipped")
 
 
-def random_case(seed):
-    rng = np.random.default_rng(1000 + seed)
-    n = int(rng.integers(3_000, 60_000))
-    ng = int(rng.integers(2, 9))
+def random_case(seed, big=False):
+    rng = np.random.default_rng((5000 if big else 1000) + seed)
+    n = int(rng.integers(200_000, 600_000)) if big else int(rng.integers(3_000, 60_000))
+    ng = int(rng.integers(6, 15)) if big else int(rng.integers(2, 9))
     div = float(rng.choice([0.002, 0.01, 0.03, 0.06]))
     ref, gs = synth.population(seed=int(rng.integers(1, 1 << 30)), n=n, n_genomes=ng, div=div, indel_frac=float(rng.choice([0.0, 0.05, 0.3])))
     gs = [bytearray(g) for g in gs]
     for g in gs:                                            # per-genome structural edits
-        for _ in range(int(rng.integers(0, 4))):
+        for _ in range(int(rng.integers(0, 12 if big else 4))):
             L = len(g)
-            a = int(rng.integers(0, max(1, L - 2000))); b = a + int(rng.integers(200, 2000))
+            a = int(rng.integers(0, max(1, L - 2000))); b = a + int(rng.integers(200, 20000 if big else 2000))
             kind = int(rng.integers(0, 5))
             if kind == 0:   g[a:b] = oracles.revcomp(bytes(g[a:b]))                       # inversion
             elif kind == 1: blk = g[a:b]; del g[a:b]; p = int(rng.integers(0, len(g))); g[p:p] = blk   # translocation
@@ -42,7 +42,7 @@ def random_case(seed):
     if rng.random() < 0.2: kw["diagdiff"] = float(rng.choice([0.05, 0.12, 0.4, 20]))
     if rng.random() < 0.2: kw["anchors"] = str(int(rng.integers(12, 30))); kw["mums"] = str(int(rng.integers(8, 20)))
     if rng.random() < 0.15: kw["partpos"] = int(rng.integers(2000, max(2001, n // 2)))
-    kw["threads"] = int(rng.choice([1, 1, 3, 6]))
+    kw["threads"] = int(rng.choice([4, 8, 12])) if big else int(rng.choice([1, 1, 3, 6]))
     contigs = int(rng.choice([1, 1, 1, 3, 7]))
     return ref, gs, kw, contigs
 
@@ -75,8 +75,8 @@ def run(core, rp, qs, out, kw):
     return (rc, xmfa_util.md5(x) if os.path.exists(x) else None, xmfa_util.log_counters(lg) if os.path.exists(x) else open(lg).read())
 
 
-def side_by_side(core, seed, tmp_path):
-    ref, gs, kw, contigs = random_case(seed)
+def side_by_side(core, seed, tmp_path, big=False):
+    ref, gs, kw, contigs = random_case(seed, big)
     rp, qs = write(str(tmp_path / "in"), ref, gs, contigs, seed)
     a = run(REFBIN, rp, qs, str(tmp_path / "ref"), kw)
     b = run(core, rp, qs, str(tmp_path / "mine"), kw)
@@ -92,3 +92,11 @@ def test_fuzz_host_logic(cpu_checkers, tmp_path, seed):
 @pytest.mark.parametrize("seed", range(60))
 def test_fuzz_on_gpu(tmp_path, seed):
     side_by_side(CORE_BIN, seed, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_bigger_sets_on_gpu(tmp_path, seed):
+    """0.2-0.6 Mb, 6-14 genomes, up to 11 structural edits per genome, 4-12 host threads: the threaded paths (parallel
+    validation, generation-parallel replay with its hand-over and restart) against the reference's single-threaded result"""
+    side_by_side(CORE_BIN, seed, tmp_path, big=True)
