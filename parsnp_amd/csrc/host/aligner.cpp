@@ -472,6 +472,8 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     }
     lap("settle+mark");
     // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them
+    pool.reserve(pool.size() + ncand);
+    accepted->reserve(accepted->size() + ncand);
     for (size_t c = 0; c < ncand; c++) {
         const uint8_t st = state[c];
         if (!(st & 1)) continue;
