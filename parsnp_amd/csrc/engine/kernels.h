@@ -3,8 +3,9 @@
 // Every kernel is a struct with `operator()(int64_t tid)`: one call is the work of one GPU thread.  The HIP
 // build (engine_hip.hip) launches them as 256-thread workgroups on gfx950; tests/emu instantiates the same functors
 // in a sequential loop on the host so that the kernel LOGIC can be checked without a GPU (test infrastructure only
-// -- the product has no host execution path).  All cross-thread communication is through global atomics, so both
-// executions compute the same result.
+// -- the product has no host execution path).  Cross-thread communication is through global atomics, plus three
+// wavefront-level steps on the device (event slot reservation by ballot / shuffle scan, the leader's index hit broadcast to
+// its followers) whose host versions compute the same values one thread at a time, so both executions give the same result.
 //
 // Data layout in HBM (see DESIGN.md "Data layout"):
 //   blk[]  one 16-byte block per 32 bases: { uint64 b2 : 2 bits per base (A=0 C=1 G=2 T=3, N stored as 0),
