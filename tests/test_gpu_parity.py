@@ -156,6 +156,31 @@ def test_properties_at_scale(libs):
     print("timing", timing)
 
 
+@pytest.mark.parametrize("name,genomes", [("bact200", 40), ("rearr500", 24)])
+def test_xmfa_consistency_at_scale(libs, tmp_path, name, genomes):
+    """BASELINE-size genomes (5 Mb; config 3 shape and config 5 shape with fewer genomes), whole run with 8 host threads:
+    size-independent properties of the XMFA -- rows of an LCB have one length, MUM columns are gap-free and identical in
+    every row, every record spells the genome interval its header names (reverse-complemented for '-' records) -- plus
+    run-to-run determinism."""
+    model, kw = synth.CONFIGS[name]
+    kw = dict(kw, n_genomes=genomes)
+    ref, gs = {"population": synth.population, "pop_rearranged": synth.pop_rearranged}[model](**kw)
+    rp, qs = synth.write_set(str(tmp_path / "in"), ref, gs)
+    sums = []
+    for rep in range(2):
+        out = str(tmp_path / ("out%d" % rep))
+        rc, _ = driver.run_core(CORE_BIN, rp, qs, out, threads=8)
+        assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+        sums.append(xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")))
+    assert sums[0] == sums[1]
+    st = xmfa_util.consistency(str(tmp_path / "out0" / "parsnpAligner.xmfa"), [ref] + gs)
+    assert st["lcbs"] > 100 and st["records"] == st["lcbs"] * (genomes + 1)
+    assert st["bad_length"] == 0 and st["bad_mum_column"] == 0 and st["bad_sequence"] == 0, st
+    if name == "rearr500":
+        assert st["reverse"] > 50, st
+    print(name, st)
+
+
 def test_mumi_coverage(libs):
     T.check_mumi(libs[0], libs[1], 200, 28)
 

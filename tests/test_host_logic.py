@@ -38,6 +38,18 @@ def test_synthetic(cpu_checkers, tmp_path, name, exact):
     check(cpu_checkers, name, rp, qs, str(tmp_path / "out"), exact)
 
 
+@pytest.mark.parametrize("name", ["pop6x200k", "rearr6x300k", "poprearr10x400k"])
+def test_xmfa_self_consistency(cpu_checkers, tmp_path, name):
+    """the size-independent XMFA properties used at full size on the GPU (tests/xmfa_util.consistency), here on sets whose
+    bytes are also pinned by goldens: equal row lengths, clean MUM columns, every record spells its genome interval"""
+    r, gs = synth.make(name)
+    rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
+    rc, _ = driver.run_core(cpu_checkers, rp, qs, str(tmp_path / "out"))
+    assert rc == 0
+    st = xmfa_util.consistency(str(tmp_path / "out" / "parsnpAligner.xmfa"), [r] + gs)
+    assert st["lcbs"] > 10 and st["bad_length"] == 0 and st["bad_mum_column"] == 0 and st["bad_sequence"] == 0, st
+
+
 def harsh_inputs(name, base):
     if name in ("pop6x200k", "rearr6x300k"):
         r, gs = synth.make(name)

@@ -47,3 +47,50 @@ def log_counters(path):
             "Number of Clusters filtered", "Number of clusters created", "Average cluster length", "Total coverage among all sequences",
             "Cluster coverage in sequence")
     return [l.rstrip() for l in open(path) if l.strip().startswith(keep)]
+
+
+_COMP = bytes.maketrans(b"ACGTN", b"TGCAN")
+
+
+def consistency(path, genomes):
+    """Size-independent self-check of an XMFA against the genomes it was made from (single-contig genomes, in file order):
+    per LCB all rows have one length, MUM (lower-case) columns hold no gap and agree in every row, and every record
+    spells genome[start-1:end] (reverse-complemented for '-' records) once its gap characters are removed.
+    -> dict of counts; records whose LCB was overlap-trimmed by the writer (src/parsnp.cpp:928-952 shifts the start by a
+    column count, a reference quirk) are counted separately in `shifted` instead of `bad_sequence`."""
+    import re
+    head, recs = records(path)
+    stats = dict(lcbs=0, records=0, bad_length=0, bad_mum_column=0, bad_sequence=0, shifted=0, reverse=0)
+    block = []
+    for hdr, seq in recs:
+        if hdr != "=":
+            block.append((hdr, seq))
+            continue
+        if not block:
+            continue
+        stats["lcbs"] += 1
+        lengths = {len(s) for _, s in block}
+        if len(lengths) != 1:
+            stats["bad_length"] += 1
+        first = block[0][1]
+        lower = [i for i, c in enumerate(first) if c.islower()]
+        for _, s in block:
+            if len(s) == len(first) and any(not s[i].islower() or s[i] != first[i] for i in lower):
+                stats["bad_mum_column"] += 1
+        for h, s in block:
+            m = re.match(r"> (\d+):(\d+)-(\d+) ([+-]) ", h)
+            g, a, b, strand = int(m.group(1)) - 1, int(m.group(2)), int(m.group(3)), m.group(4)
+            stats["records"] += 1
+            want = genomes[g][a - 1:b].upper()
+            if strand == "-":
+                stats["reverse"] += 1
+                want = want.translate(_COMP)[::-1]
+            got = s.replace("-", "").upper().encode()
+            if got != want:
+                # trimmed at the front by the writer: the sequence is a suffix of what the coordinates say, or vice versa
+                if want.endswith(got) or got.endswith(want):
+                    stats["shifted"] += 1
+                else:
+                    stats["bad_sequence"] += 1
+        block = []
+    return stats
