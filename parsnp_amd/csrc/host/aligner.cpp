@@ -1073,10 +1073,13 @@ void Aligner::filter_lcbs() {
 void Aligner::fill_between() {
     double t0 = now_s();
     sort_lcbs(lcbs);
-    std::vector<Lcb> fillers;
-    for (size_t x = 0; x + 1 < lcbs.size(); x++) {
-        const Lcb& ct = lcbs[x];
-        const Lcb& nx = lcbs[x + 1];
+    // every pair of consecutive LCBs is looked at on its own (bitmap reads only): all threads, results kept in order
+    const long npairs = (long)lcbs.size() - 1;
+    std::vector<std::unique_ptr<Lcb>> made(npairs > 0 ? (size_t)npairs : 0);
+#pragma omp parallel for schedule(dynamic, 16) num_threads(prm.cores > 0 ? prm.cores : 1)
+    for (long x = 0; x < npairs; x++) {
+        const Lcb& ct = lcbs[(size_t)x];
+        const Lcb& nx = lcbs[(size_t)x + 1];
         bool add = true;
         std::vector<long> start, end;
         int flag = 0;
@@ -1094,16 +1097,18 @@ void Aligner::fill_between() {
         }
         if (!add) continue;
         if (end.size() != n) fatal("inter-cluster region bookkeeping would overrun in the reference");
-        Lcb f;
-        f.type = 0;
-        f.start = start;
-        f.end.resize(n);
-        for (size_t a = 0; a < n; a++) f.end[a] = end[a] + 1;   // Cluster(bmum,0).addMum(emum): end = emum.end = end+1
-        f.length = 2;
+        std::unique_ptr<Lcb> f(new Lcb);
+        f->type = 0;
+        f->start = start;
+        f->end.resize(n);
+        for (size_t a = 0; a < n; a++) f->end[a] = end[a] + 1;   // Cluster(bmum,0).addMum(emum): end = emum.end = end+1
+        f->length = 2;
         for (size_t a = 0; a < n; a++)
-            if (f.end[a] - f.start[a] < 5) { add = false; break; }
-        if (add) fillers.push_back(std::move(f));
+            if (f->end[a] - f->start[a] < 5) { add = false; break; }
+        if (add) made[(size_t)x] = std::move(f);
     }
+    std::vector<Lcb> fillers;
+    for (auto& f : made) if (f) fillers.push_back(std::move(*f));
     lcbs.insert(lcbs.begin(), fillers.begin(), fillers.end());
     stats.lcb_s += now_s() - t0;
 }
