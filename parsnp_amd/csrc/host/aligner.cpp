@@ -440,19 +440,52 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     lap("rows");
     // dirty = overlaps the layout or an earlier candidate in some genome.  Each thread owns a stripe of genomes and
     // walks the candidates in order (rows are candidate-major: a stripe reads contiguous entries of every row).
-    std::vector<Bitmap>& scratch = memory_->scratch;
-    scratch.resize(n);
+    // First a cheap sufficient test: a candidate that lies entirely after, or entirely before, EVERYTHING earlier in a
+    // genome overlaps nothing earlier there (running max of ends / min of starts).  It can only err towards "dirty", and
+    // treating a clean candidate as dirty is harmless (it takes the ordered path and sees the same marks); where genomes
+    // are rearranged enough for it to flag too many, the exact test with scratch bitmaps decides instead.
     const int nstripes = threads;
+    const bool layout_empty = pool.empty();      // nothing accepted yet: the layout holds no mark (the anchor call)
+    {
 #pragma omp parallel for schedule(static, 1) num_threads(threads)
-    for (int t = 0; t < nstripes; t++) {
-        const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
-        for (size_t j = j0; j < j1; j++) scratch[j].init_zero_lazy((size_t)gsize_[j] + 1);
-        for (size_t c = 0; c < ncand; c++) {
-            if ((state[c] & 3) != 3 || cand[c].length < 5) continue;        // never marks anything
-            const long* st = cand[c].start; const long lon = cand[c].length;
-            bool hit = false;
-            for (size_t j = j0; j < j1; j++) hit |= scratch[j].test_and_set(st[j], st[j] + lon) | layout[j].any_set(st[j], st[j] + lon);
-            if (hit) __atomic_fetch_or(&state[c], (uint8_t)8, __ATOMIC_RELAXED);
+        for (int t = 0; t < nstripes; t++) {
+            const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
+            std::vector<long> maxend_l(j1 - j0 + 16, -1), minstart_l(j1 - j0 + 16, (long)1 << 62);   // per stripe: no cache line shared with a neighbour
+            long* maxend = maxend_l.data() + 8 - j0; long* minstart = minstart_l.data() + 8 - j0;
+            for (size_t c = 0; c < ncand; c++) {
+                if ((state[c] & 3) != 3 || cand[c].length < 5) continue;        // never marks anything
+                const long* st = cand[c].start; const long lon = cand[c].length;
+                bool hit = false;
+                for (size_t j = j0; j < j1; j++) {
+                    const long a = st[j], b = a + lon;
+                    hit |= !(a >= maxend[j] || b <= minstart[j]);
+                    if (!layout_empty) hit |= layout[j].any_set(a, b);
+                    if (b > maxend[j]) maxend[j] = b;
+                    if (a < minstart[j]) minstart[j] = a;
+                }
+                if (hit) __atomic_fetch_or(&state[c], (uint8_t)8, __ATOMIC_RELAXED);
+            }
+        }
+    }
+    size_t flagged = 0;
+    for (size_t c = 0; c < ncand; c++) flagged += (state[c] >> 3) & 1;
+    static const bool force_exact = getenv("PARSNP_EXACT_OVERLAP") != nullptr;   // test hook: always the bitmap test
+    if (dbg) fprintf(stderr, "[validate_parallel] cheap overlap test flags %zu of %zu\n", flagged, ncand);
+    if (flagged * 8 > ncand || force_exact) {
+        for (size_t c = 0; c < ncand; c++) state[c] &= (uint8_t)~8;
+        std::vector<Bitmap>& scratch = memory_->scratch;
+        scratch.resize(n);
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+        for (int t = 0; t < nstripes; t++) {
+            const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
+            for (size_t j = j0; j < j1; j++) scratch[j].init_zero_lazy((size_t)gsize_[j] + 1);
+            for (size_t c = 0; c < ncand; c++) {
+                if ((state[c] & 3) != 3 || cand[c].length < 5) continue;
+                const long* st = cand[c].start; const long lon = cand[c].length;
+                bool hit = false;
+                for (size_t j = j0; j < j1; j++) hit |= scratch[j].test_and_set(st[j], st[j] + lon) | layout[j].any_set(st[j], st[j] + lon);
+                if (hit) __atomic_fetch_or(&state[c], (uint8_t)8, __ATOMIC_RELAXED);
+            }
         }
     }
     lap("overlap");
