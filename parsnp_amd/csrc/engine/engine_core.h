@@ -16,7 +16,7 @@
 
 namespace pm {
 
-// Host buffers the results are downloaded into (pinned memory in the HIP build).  They are recycled: a result gives its
+// Host buffers the results are downloaded into (ordinary memory; pinned with PARSNP_PINNED=1).  They are recycled: a result gives its
 // blocks back when it is freed, the next batch of the same shape takes them, so the steady state allocates nothing and
 // touches no fresh pages.  Shared by the session and every result it handed out (a result may outlive the session).
 struct HostPool {

@@ -45,8 +45,11 @@ struct HipBackend {
     }
     void* alloc(size_t n) { void* p = nullptr; if (!check(hipMalloc(&p, n ? n : 1), "hipMalloc")) return nullptr; return p; }
     void free(void* p) { check(hipFree(p), "hipFree"); }
-    // pinned host memory for result downloads (no staging copy, full PCIe rate); static: results may outlive the session
-    static bool pinned() { static const bool v = !(getenv("PARSNP_PINNED") && atoi(getenv("PARSNP_PINNED")) == 0); return v; }   // PARSNP_PINNED=0: pageable buffers (measurement)
+    // host memory for result downloads; static: results may outlive the session.  Ordinary (pageable) memory by default:
+    // the blocks are recycled, so nothing is faulted in per call, and the host's reads of the candidate columns are ~25 %
+    // faster than from pinned memory (measured: 112 vs 132 ms per step) while the download itself takes the same time.
+    // PARSNP_PINNED=1 selects pinned blocks.
+    static bool pinned() { static const bool v = getenv("PARSNP_PINNED") && atoi(getenv("PARSNP_PINNED")) != 0; return v; }
     static void* host_alloc(size_t n) {
         if (!pinned()) return malloc(n ? n : 1);
         void* p = nullptr; return hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
