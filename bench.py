@@ -89,6 +89,38 @@ def usable_cpus():
     return n
 
 
+def bind_to_numa_node(torch, dev, local_rank, local_world):
+    """Keep this rank's threads and memory on ONE NUMA node (what `numactl --cpunodebind` would do): the host phases walk
+    per-genome bitmaps that one thread zeroes and others read, and remote accesses cost 20 % of the step on the 2-socket
+    GPU boxes.  Node = the GPU's own node where sysfs tells, else spread the ranks evenly.  -> node or None"""
+    try:
+        nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+        if len(nodes) < 2:
+            return None
+        node = None
+        try:
+            p = torch.cuda.get_device_properties(dev)
+            bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            v = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+            if v in nodes:
+                node = v
+        except Exception:   # noqa: BLE001 -- older torch / no sysfs entry
+            pass
+        if node is None:
+            node = nodes[(local_rank * len(nodes)) // max(1, local_world) % len(nodes)]
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def exchange_intervals(torch, dist, tdev, intervals):
     """all-gather the per-rank [start,end] lists (padded to the longest) and intersect them -> bases aligned in every partition"""
     from parsnp_amd.partition_run import intersect
@@ -150,6 +182,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    numa_node = None if os.environ.get("PARSNP_BENCH_NO_BIND") else bind_to_numa_node(
+        torch, dev, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     from parsnp_amd import driver
     from parsnp_amd.core_api import CoreRun
     if args.host_threads <= 0:
@@ -263,7 +297,7 @@ def main():
                            % (args.workload, G, n_ref / 1e6, dict(bact200="population").get(args.workload, "synthetic"),
                               ", ".join("%s=%s" % (k, v) for k, v in sorted(kw.items()) if k not in ("n", "n_genomes")),
                               "" if world == 1 else "; one partition per rank, %d ranks" % world),
-                           "genomes_per_gpu": G, "genome_bp": n_ref, "host_threads": args.host_threads, "host_cpus_usable": usable_cpus(), "parallelism": "partition-per-gpu x%d" % world},
+                           "genomes_per_gpu": G, "genome_bp": n_ref, "host_threads": args.host_threads, "host_cpus_usable": usable_cpus(), "numa_node": numa_node, "parallelism": "partition-per-gpu x%d" % world},
                 "step_ms": step_ms,
                 "core_bp_aligned": core_bp_total,
                 "core_bp_in_every_partition": merged_bp,
