@@ -206,10 +206,11 @@ public:
         be.memset(d_repeated.p, 0, 4 * (size_t)(npos / 32 + 1));
         be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_filter.p, d_next.p, d_run.p, d_rep.p, d_repeated.p, d_err.p, work_budget});
 
-        // -- work units
+        // -- work units (pairs that fit 64 bases on both sides go to SmallPairEvents instead; PM_NO_SMALL_PAIRS=1: measurement)
+        const int no_small = (mumi || getenv("PM_NO_SMALL_PAIRS")) ? 1 : 0;
         be.mark("units");
         ensure(d_ucount, (size_t)npairs + 1); ensure(d_uoff, (size_t)npairs + 1);
-        be.launch("count_units", npairs, CountUnits{d_R.p, d_lens.p, ngen, d_ucount.p, g_first, g_last});
+        be.launch("count_units", npairs, CountUnits{d_R.p, d_lens.p, ngen, d_ucount.p, g_first, g_last, no_small});
         be.memset(d_ucount.p + npairs, 0, 8);
         be.exclusive_scan(d_ucount.p, d_uoff.p, (size_t)npairs + 1);
         int64_t nunits = 0;
@@ -233,6 +234,9 @@ public:
                       SeedExtend{P, d_R.p, d_units.p, d_slots.p, d_filter.p, d_next.p, d_rep.p, d_repeated.p,
                                  d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err.p, work_budget,
                                  getenv("PM_DEBUG_SEED") ? atoi(getenv("PM_DEBUG_SEED")) : 0});
+            if (!no_small)
+                be.launch("small_pair_events", npairs * 2,
+                          SmallPairEvents{P, d_R.p, d_starts.p, d_lens.p, ngen, d_rep.p, d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, g_first, g_last});
             be.d2h(counts.data(), d_counter.p, 8 * counts.size());
             uint64_t worst = 0;
             nev = 0;

@@ -430,15 +430,20 @@ struct RepeatLength {
 };
 
 // ------------------------------------------------------------------------------------------ work units
+// A (region, query piece) pair whose two sides both fit 64 bases -- nine in ten of the recursion's pairs -- is compared
+// diagonal by diagonal in registers (SmallPairEvents) instead of going through the K-mer index.
+PM_HD bool small_pair(int64_t nR, int64_t m) { return nR <= 64 && m <= 64; }
 // units of one (region, query genome) pair: 2 strands x ceil(samples / 256)
 struct CountUnits {
     const RegionInfo* R; const int64_t* lens; int32_t ngen; int64_t* count;   // lens[r*ngen + g]
     int32_t g_first, g_last;   // query genomes [g_first, g_last) live on this GPU (all of them unless the run is sharded)
+    int no_small;              // debug: every pair through SeedExtend
     PM_HD void operator()(int64_t pair) const {
         int64_t r = pair / (ngen - 1); int g = (int)(pair % (ngen - 1)) + 1;
         const RegionInfo& ri = R[r];
         int64_t m = lens[r * ngen + g];
         int64_t ns = (m >= ri.K && ri.nR >= ri.K && g >= g_first && g < g_last) ? (m - ri.K) / ri.stride + 1 : 0;
+        if (small_pair(ri.nR, m) && !no_small) ns = 0;          // handled by SmallPairEvents, without index probes
         count[pair] = 2 * ((ns + kUnitSamples - 1) / kUnitSamples);
     }
 };
@@ -641,6 +646,88 @@ struct SeedExtend {
 #pragma unroll
         for (int u = 0; u < kPer; u++)
             if (bk[u] != kEmpty) { if (at < ev_cap) { key_out[at] = bk[u]; val_out[at] = bv[u]; } at++; }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ small pairs
+PM_HD uint64_t even_bits(uint64_t x) {      // bits 0,2,4,... of x packed into the low 32 bits
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+    x = (x | (x >> 16)) & 0x00000000ffffffffull;
+    return x;
+}
+// 64 bases starting at global base position p as three one-bit-per-base planes (low base bit, high base bit, N)
+PM_HD void planes64(const SeqBlock* blk, int64_t p, uint64_t* b0, uint64_t* b1, uint64_t* nm) {
+    const SeqBlock* b = blk + (p >> 5);
+    const int sh = (int)(p & 31);
+    const SeqBlock x0 = b[0], x1 = b[1], x2 = b[2];
+    const uint64_t lo = (x0.b2 >> (2 * sh)) | ((x1.b2 << 1) << (63 - 2 * sh));
+    const uint64_t hi = (x1.b2 >> (2 * sh)) | ((x2.b2 << 1) << (63 - 2 * sh));
+    *b0 = even_bits(lo) | (even_bits(hi) << 32);
+    *b1 = even_bits(lo >> 1) | (even_bits(hi >> 1) << 32);
+    const uint64_t m01 = (uint64_t)x0.nm | ((uint64_t)x1.nm << 32);
+    *nm = (m01 >> sh) | (((uint64_t)x2.nm << 1) << (63 - sh));
+}
+// The same events as SeedExtend -- every maximal exact match of length >= minlen between the query piece and the
+// reference substring that is unique in R (len > rep') -- for pairs whose sides both fit 64 bases, found without the
+// index: both sides sit in registers as bit planes, every diagonal is one shift + XOR, and a run of equal bases is a run
+// of ones.  tid = (pair, strand); one lane does all diagonals of its pair (a few thousand bit operations), so the 3 million
+// such pairs of a recursion batch are 50 000 wavefronts instead of 3 million nearly empty SeedExtend units.
+struct SmallPairEvents {
+    Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen;
+    const int32_t* rep;
+    uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits;
+    int32_t g_first, g_last;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t pair = tid >> 1; const int strand = (int)(tid & 1);
+        const int32_t nq = ngen - 1;
+        const int64_t r = pair / nq; const int g = (int)(pair % nq) + 1;
+        const RegionInfo& ri = R[r];
+        const int64_t m = lens[r * ngen + g], qs = starts[r * ngen + g];
+        const int32_t nR = ri.nR, L = ri.minlen;
+        const uint64_t slice = (uint64_t)((tid >> 8) & (kSlices - 1));      // one sub-buffer per workgroup, as in SeedExtend
+        uint64_t* ev_count = ev_counters + slice * kSliceStride;
+        uint64_t* const key_out = ev_key + slice * slice_cap;
+        uint64_t* const val_out = ev_val + slice * slice_cap;
+        uint64_t first_key = kEmpty, first_val = 0;
+        if (small_pair(nR, m) && m >= L && nR >= L && g >= g_first && g < g_last) {
+            const int64_t qbase = strand ? P.goff[2 * g + 1] + (P.glen[g] - qs - m) : P.goff[2 * g] + qs;
+            uint64_t r0, r1, rn, q0, q1, qn;
+            planes64(P.blk, P.goff[0] + ri.ref_pos, &r0, &r1, &rn);
+            planes64(P.blk, qbase, &q0, &q1, &qn);
+            const uint64_t vr = nR >= 64 ? ~0ull : ((1ull << nR) - 1), vq = m >= 64 ? ~0ull : ((1ull << m) - 1);
+            for (int32_t d = -(int32_t)(m - L); d <= nR - L; d++) {        // diagonal: reference position = query position + d
+                uint64_t eq;
+                if (d >= 0) eq = ~(((r0 >> d) ^ q0) | ((r1 >> d) ^ q1) | ((rn >> d) ^ qn)) & (vr >> d) & vq;      // bit t: query t, reference t + d
+                else eq = ~((r0 ^ (q0 >> -d)) | (r1 ^ (q1 >> -d)) | (rn ^ (qn >> -d))) & vr & (vq >> -d);         // bit t: reference t, query t - d
+                uint64_t x = eq;                                            // any run of at least L ones?
+                int k = 1;
+                while (2 * k <= L) { x &= x >> k; k *= 2; }
+                if (L > k) x &= x >> (L - k);
+                if (!x) continue;
+                while (eq) {
+                    const int s = ctz64(eq);
+                    const uint64_t t = eq >> s;
+                    const int len = ~t ? ctz64(~t) : 64 - s;
+                    if (len >= L) {
+                        const int32_t l0 = d >= 0 ? s + d : s;
+                        const int32_t j0 = d >= 0 ? s : s - d;
+                        if (len > rep[ri.posbase + l0]) {
+                            const uint64_t ek = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
+                            const uint64_t evv = ((uint64_t)j0 << 32) | (uint32_t)len;
+                            if (first_key == kEmpty) { first_key = ek; first_val = evv; }
+                            else { const uint64_t at = atomic_add64(ev_count, 1); if (at < slice_cap) { key_out[at] = ek; val_out[at] = evv; } }
+                        }
+                    }
+                    eq = s + len >= 64 ? 0 : eq & (~0ull << (s + len));
+                }
+            }
+        }
+        const uint64_t at = wave_reserve01(ev_count, first_key != kEmpty);
+        if (first_key != kEmpty && at < slice_cap) { key_out[at] = first_key; val_out[at] = first_val; }
     }
 };
 
