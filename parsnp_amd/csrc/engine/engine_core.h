@@ -108,7 +108,7 @@ public:
                 words += (lens[g] + 31) / 32 + 2;   // + trailing guard
             }
         }
-        words += 2;
+        words += 8;                              // SmallPairEvents reads a 128-base window + 2 blocks from any position of the last strand
         total_words = words;
         blk = (SeqBlock*)be.alloc((size_t)words * sizeof(SeqBlock));
         d_goff = (int64_t*)be.alloc(sizeof(int64_t) * 2 * (size_t)n);

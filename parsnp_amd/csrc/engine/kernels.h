@@ -430,9 +430,9 @@ struct RepeatLength {
 };
 
 // ------------------------------------------------------------------------------------------ work units
-// A (region, query piece) pair whose two sides both fit 64 bases -- nine in ten of the recursion's pairs -- is compared
-// diagonal by diagonal in registers (SmallPairEvents) instead of going through the K-mer index.
-PM_HD bool small_pair(int64_t nR, int64_t m) { return nR <= 64 && m <= 64; }
+// A (region, query piece) pair whose two sides both fit 128 bases -- practically all of the recursion's pairs -- is
+// compared diagonal by diagonal in registers (SmallPairEvents) instead of going through the K-mer index.
+PM_HD bool small_pair(int64_t nR, int64_t m) { return nR <= 128 && m <= 128; }
 // units of one (region, query genome) pair: 2 strands x ceil(samples / 256)
 struct CountUnits {
     const RegionInfo* R; const int64_t* lens; int32_t ngen; int64_t* count;   // lens[r*ngen + g]
@@ -671,8 +671,62 @@ PM_HD void planes64(const SeqBlock* blk, int64_t p, uint64_t* b0, uint64_t* b1, 
     const uint64_t m01 = (uint64_t)x0.nm | ((uint64_t)x1.nm << 32);
     *nm = (m01 >> sh) | (((uint64_t)x2.nm << 1) << (63 - sh));
 }
+// 64- or 128-base bit planes with the few operations the diagonal scan needs
+struct W64 {
+    uint64_t v;
+    static PM_HD W64 load(const SeqBlock* blk, int64_t p, int plane) {
+        uint64_t b0, b1, nm; planes64(blk, p, &b0, &b1, &nm);
+        W64 w; w.v = plane == 0 ? b0 : plane == 1 ? b1 : nm; return w;
+    }
+    static PM_HD W64 ones(int n) { W64 w; w.v = n >= 64 ? ~0ull : ((1ull << n) - 1); return w; }
+    PM_HD W64 shr(int k) const { W64 w; w.v = v >> k; return w; }
+    PM_HD W64 operator^(const W64& o) const { W64 w; w.v = v ^ o.v; return w; }
+    PM_HD W64 operator|(const W64& o) const { W64 w; w.v = v | o.v; return w; }
+    PM_HD W64 operator&(const W64& o) const { W64 w; w.v = v & o.v; return w; }
+    PM_HD W64 operator~() const { W64 w; w.v = ~v; return w; }
+    PM_HD bool any() const { return v != 0; }
+    PM_HD int low() const { return ctz64(v); }                      // index of the lowest one (any() must hold)
+    PM_HD int run_at(int s) const { const uint64_t t = ~(v >> s); return t ? ctz64(t) : 64 - s; }   // length of the run of ones starting at s
+    PM_HD W64 clear_below(int k) const { W64 w; w.v = k >= 64 ? 0 : v & (~0ull << k); return w; }
+    static constexpr int kBits = 64;
+};
+struct W128 {
+    uint64_t lo, hi;
+    static PM_HD W128 load(const SeqBlock* blk, int64_t p, int plane) {
+        uint64_t a0, a1, an, c0, c1, cn; planes64(blk, p, &a0, &a1, &an); planes64(blk, p + 64, &c0, &c1, &cn);
+        W128 w; w.lo = plane == 0 ? a0 : plane == 1 ? a1 : an; w.hi = plane == 0 ? c0 : plane == 1 ? c1 : cn; return w;
+    }
+    static PM_HD W128 ones(int n) {
+        W128 w;
+        w.lo = n >= 64 ? ~0ull : ((1ull << n) - 1);
+        w.hi = n >= 128 ? ~0ull : n > 64 ? ((1ull << (n - 64)) - 1) : 0;
+        return w;
+    }
+    PM_HD W128 shr(int k) const {
+        W128 w;
+        if (k >= 64) { w.lo = k >= 128 ? 0 : hi >> (k - 64); w.hi = 0; }
+        else { w.lo = (lo >> k) | ((hi << 1) << (63 - k)); w.hi = hi >> k; }
+        return w;
+    }
+    PM_HD W128 operator^(const W128& o) const { W128 w; w.lo = lo ^ o.lo; w.hi = hi ^ o.hi; return w; }
+    PM_HD W128 operator|(const W128& o) const { W128 w; w.lo = lo | o.lo; w.hi = hi | o.hi; return w; }
+    PM_HD W128 operator&(const W128& o) const { W128 w; w.lo = lo & o.lo; w.hi = hi & o.hi; return w; }
+    PM_HD W128 operator~() const { W128 w; w.lo = ~lo; w.hi = ~hi; return w; }
+    PM_HD bool any() const { return (lo | hi) != 0; }
+    PM_HD int low() const { return lo ? ctz64(lo) : 64 + ctz64(hi); }
+    PM_HD int run_at(int s) const { const W128 t = ~shr(s); return t.any() ? t.low() : 128 - s; }
+    PM_HD W128 clear_below(int k) const {
+        W128 w;
+        if (k >= 128) { w.lo = 0; w.hi = 0; }
+        else if (k >= 64) { w.lo = 0; w.hi = hi & (~0ull << (k - 64)); }
+        else { w.lo = lo & (~0ull << k); w.hi = hi; }
+        return w;
+    }
+    static constexpr int kBits = 128;
+};
+
 // The same events as SeedExtend -- every maximal exact match of length >= minlen between the query piece and the
-// reference substring that is unique in R (len > rep') -- for pairs whose sides both fit 64 bases, found without the
+// reference substring that is unique in R (len > rep') -- for pairs whose sides both fit 128 bases, found without the
 // index: both sides sit in registers as bit planes, every diagonal is one shift + XOR, and a run of equal bases is a run
 // of ones.  tid = (pair, strand); one lane does all diagonals of its pair (a few thousand bit operations), so the 3 million
 // such pairs of a recursion batch are 50 000 wavefronts instead of 3 million nearly empty SeedExtend units.
@@ -681,6 +735,30 @@ struct SmallPairEvents {
     const int32_t* rep;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits;
     int32_t g_first, g_last;
+
+    template <class W, class Emit>
+    PM_HD void scan(int64_t rpos, int64_t qpos, int32_t nR, int32_t m, int32_t L, Emit emit) const {
+        const W r0 = W::load(P.blk, rpos, 0), r1 = W::load(P.blk, rpos, 1), rn = W::load(P.blk, rpos, 2);
+        const W q0 = W::load(P.blk, qpos, 0), q1 = W::load(P.blk, qpos, 1), qn = W::load(P.blk, qpos, 2);
+        const W vr = W::ones(nR), vq = W::ones(m);
+        for (int32_t d = -(m - L); d <= nR - L; d++) {        // diagonal: reference position = query position + d
+            W eq;
+            if (d >= 0) eq = ~((r0.shr(d) ^ q0) | (r1.shr(d) ^ q1) | (rn.shr(d) ^ qn)) & vr.shr(d) & vq;      // bit t: query t, reference t + d
+            else eq = ~((r0 ^ q0.shr(-d)) | (r1 ^ q1.shr(-d)) | (rn ^ qn.shr(-d))) & vr & vq.shr(-d);         // bit t: reference t, query t - d
+            W x = eq;                                            // any run of at least L ones?
+            int k = 1;
+            while (2 * k <= L) { x = x & x.shr(k); k *= 2; }
+            if (L > k) x = x & x.shr(L - k);
+            if (!x.any()) continue;
+            while (eq.any()) {
+                const int s = eq.low();
+                const int len = eq.run_at(s);
+                if (len >= L) emit(d >= 0 ? s + d : s, d >= 0 ? s : s - d, len);      // (l0, j0, len)
+                eq = eq.clear_below(s + len);
+            }
+        }
+    }
+
     PM_HD void operator()(int64_t tid) const {
         const int64_t pair = tid >> 1; const int strand = (int)(tid & 1);
         const int32_t nq = ngen - 1;
@@ -695,36 +773,16 @@ struct SmallPairEvents {
         uint64_t first_key = kEmpty, first_val = 0;
         if (small_pair(nR, m) && m >= L && nR >= L && g >= g_first && g < g_last) {
             const int64_t qbase = strand ? P.goff[2 * g + 1] + (P.glen[g] - qs - m) : P.goff[2 * g] + qs;
-            uint64_t r0, r1, rn, q0, q1, qn;
-            planes64(P.blk, P.goff[0] + ri.ref_pos, &r0, &r1, &rn);
-            planes64(P.blk, qbase, &q0, &q1, &qn);
-            const uint64_t vr = nR >= 64 ? ~0ull : ((1ull << nR) - 1), vq = m >= 64 ? ~0ull : ((1ull << m) - 1);
-            for (int32_t d = -(int32_t)(m - L); d <= nR - L; d++) {        // diagonal: reference position = query position + d
-                uint64_t eq;
-                if (d >= 0) eq = ~(((r0 >> d) ^ q0) | ((r1 >> d) ^ q1) | ((rn >> d) ^ qn)) & (vr >> d) & vq;      // bit t: query t, reference t + d
-                else eq = ~((r0 ^ (q0 >> -d)) | (r1 ^ (q1 >> -d)) | (rn ^ (qn >> -d))) & vr & (vq >> -d);         // bit t: reference t, query t - d
-                uint64_t x = eq;                                            // any run of at least L ones?
-                int k = 1;
-                while (2 * k <= L) { x &= x >> k; k *= 2; }
-                if (L > k) x &= x >> (L - k);
-                if (!x) continue;
-                while (eq) {
-                    const int s = ctz64(eq);
-                    const uint64_t t = eq >> s;
-                    const int len = ~t ? ctz64(~t) : 64 - s;
-                    if (len >= L) {
-                        const int32_t l0 = d >= 0 ? s + d : s;
-                        const int32_t j0 = d >= 0 ? s : s - d;
-                        if (len > rep[ri.posbase + l0]) {
-                            const uint64_t ek = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
-                            const uint64_t evv = ((uint64_t)j0 << 32) | (uint32_t)len;
-                            if (first_key == kEmpty) { first_key = ek; first_val = evv; }
-                            else { const uint64_t at = atomic_add64(ev_count, 1); if (at < slice_cap) { key_out[at] = ek; val_out[at] = evv; } }
-                        }
-                    }
-                    eq = s + len >= 64 ? 0 : eq & (~0ull << (s + len));
-                }
-            }
+            const int64_t rbase = P.goff[0] + ri.ref_pos;
+            auto emit = [&](int32_t l0, int32_t j0, int32_t len) {
+                if (len <= rep[ri.posbase + l0]) return;             // not unique in R
+                const uint64_t ek = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
+                const uint64_t evv = ((uint64_t)j0 << 32) | (uint32_t)len;
+                if (first_key == kEmpty) { first_key = ek; first_val = evv; }
+                else { const uint64_t at = atomic_add64(ev_count, 1); if (at < slice_cap) { key_out[at] = ek; val_out[at] = evv; } }
+            };
+            if (nR <= 64 && m <= 64) scan<W64>(rbase, qbase, nR, (int32_t)m, L, emit);
+            else scan<W128>(rbase, qbase, nR, (int32_t)m, L, emit);
         }
         const uint64_t at = wave_reserve01(ev_count, first_key != kEmpty);
         if (first_key != kEmpty && at < slice_cap) { key_out[at] = first_key; val_out[at] = first_val; }
