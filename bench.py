@@ -284,7 +284,7 @@ def main():
             if dom and launches:
                 launch_ms = kernels[dom] / launches
                 gbs = alg_step / (kernels[dom] * 1e-3) / 1e9
-                roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                roof = {"bound": "hbm", "kernel": "seed_extend (SeedExtend + SmallPairEvents)" if dom == "seed_extend" else dom, "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "launch_ms": round(launch_ms, 4),
                         "launches_per_step": launches, "alg_bytes_per_launch": int(alg_step / launches),
                         "anchor_launch": {"launch_ms": round(phases.get(dom, 0.0), 4), "alg_bytes": int(b_alg * G),

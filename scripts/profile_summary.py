@@ -98,20 +98,27 @@ def main():
             if k in cw:
                 cal[k]["write_size_bytes"] = cw[k]["sum"] * 1024 / cw[k]["dispatches"]
     json.dump(cal, open(os.path.join(summ, "calibration.json"), "w"), indent=1)
-    se = per.get("SeedExtend")
+    # the event search of one engine call = SeedExtend (index-seeded samples) + SmallPairEvents (pairs that fit 128 bases,
+    # compared in registers): bench.py times them together as the `seed_extend` phase, so they are summed here too
+    se, sp = per.get("SeedExtend"), per.get("SmallPairEvents")
     if se and se["fetch_bytes"] is not None and se["write_bytes"] is not None:
         n = se["dispatches"]
+        fetch = se["fetch_bytes"] + (sp["fetch_bytes"] if sp and sp["fetch_bytes"] else 0)
+        write = se["write_bytes"] + (sp["write_bytes"] if sp and sp["write_bytes"] else 0)
+        st_se, st_sp = stats.get("SeedExtend", {}), stats.get("SmallPairEvents", {})
+        calls = st_se.get("calls")
         # SeedExtend's loads are scattered 8-16 B probes (hash slots, next[], 16-B sequence blocks).  If the gather
         # calibration shows 64 counted bytes per scattered lane (one minimum-size fabric request each), the counter is exact
         # for this pattern and is used as it is; the 2x correction of the guide applies to wide coalesced streams only.
-        t = {"kernel": "seed_extend", "workload": "bact200, every SeedExtend launch of one bench step (anchor + recursion)",
-             "dispatches": n, "fetch_bytes_per_launch": se["fetch_bytes"] / n, "write_bytes_per_launch": se["write_bytes"] / n,
-             "hbm_bytes_per_launch": (se["fetch_bytes"] + se["write_bytes"]) / n,
+        t = {"kernel": "seed_extend = SeedExtend + SmallPairEvents", "workload": "bact200, the event search of every engine call of one bench step (anchor + recursion)",
+             "dispatches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
+             "hbm_bytes_per_launch": (fetch + write) / n,
              "correction": "none (scattered-probe pattern; see calibration.json: gather kernels count 64 B per lane)",
-             "rocprof_avg_launch_ms": stats.get("SeedExtend", {}).get("avg_ms"),
-             "rocprof_calls": stats.get("SeedExtend", {}).get("calls")}
+             "rocprof_avg_launch_ms": ((st_se.get("total_ms", 0) + st_sp.get("total_ms", 0)) / calls) if calls else None,
+             "rocprof_calls": calls,
+             "rocprof_seed_extend_avg_ms": st_se.get("avg_ms"), "rocprof_small_pair_events_avg_ms": st_sp.get("avg_ms")}
         json.dump(t, open(os.path.join(summ, "traffic_seed_extend.json"), "w"), indent=1)
-    print(json.dumps({"stats": {k: v for k, v in stats.items() if v["total_ms"] > 1}, "calibration": cal, "seed_extend": per.get("SeedExtend")}, indent=1))
+    print(json.dumps({"stats": {k: v for k, v in stats.items() if v["total_ms"] > 1}, "calibration": cal, "seed_extend": per.get("SeedExtend"), "small_pair_events": per.get("SmallPairEvents")}, indent=1))
 
 
 if __name__ == "__main__":
