@@ -97,16 +97,20 @@ def bind_to_numa_node(torch, dev, local_rank, local_world):
         nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
         if len(nodes) < 2:
             return None
-        node = None
-        try:
-            p = torch.cuda.get_device_properties(dev)
-            bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
-            v = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
-            if v in nodes:
-                node = v
-        except Exception:   # noqa: BLE001 -- older torch / no sysfs entry
-            pass
-        if node is None:
+        def gpu_node(d):
+            try:
+                p = torch.cuda.get_device_properties(d)
+                bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+                v = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+                return v if v in nodes else None
+            except Exception:   # noqa: BLE001 -- older torch / no sysfs entry
+                return None
+        # the GPUs' own nodes, if sysfs knows them for every rank of this node and they spread the ranks evenly
+        per_rank = [gpu_node(r % torch.cuda.device_count()) for r in range(max(1, local_world))]
+        balanced = None not in per_rank and max(per_rank.count(x) for x in nodes) <= -(-max(1, local_world) // len(nodes))
+        if balanced:
+            node = per_rank[local_rank % len(per_rank)]
+        else:
             node = nodes[(local_rank * len(nodes)) // max(1, local_world) % len(nodes)]
         cpus = set()
         for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
