@@ -795,7 +795,10 @@ bool Aligner::extend_generations() {
     const std::vector<Region> seeds = regions;
     const size_t pool0 = pool.size();
     const std::vector<int> mums0 = mums;
+    std::vector<int> seeds_raw;                   // engine results of the seeds, for the restart
+    std::function<void()> before_restart = [] {};
     auto restart_in_order = [&]() {
+        before_restart();
         pool.resize(pool0);
         mums = mums0;
         const long nl = (long)n;
@@ -811,16 +814,59 @@ bool Aligner::extend_generations() {
     };
     std::vector<Region> gen = std::move(regions);
     regions.clear();
+    // Engine results are held per region here (no cache, no hashing of 2 x n coordinates per lookup): raw_of[i] indexes
+    // raws for gen[i], -1 = not fetched yet.  A hand-over to the in-order replay files them into its cache first.
+    std::vector<Raw> raws;
+    std::vector<int> gen_raw(gen.size(), -1);
+    auto plain_request = [&](const Region& r, Request* q) {       // the region as ONE engine request, if it is one
+        const long len0 = r.length[0];
+        if (len0 <= 0 || prm.p < len0) return false;              // chunked reference (p): chunk_requests' business
+        for (size_t g = 0; g < n; g++)
+            if (r.start[g] < 0 || r.length[g] < 0 || r.start[g] + r.length[g] > gsize_[g]) return false;
+        *q = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0};
+        return true;
+    };
+    auto fetch = [&](const std::vector<Region>& rs, std::vector<int>* raw_of) {      // one engine call for the regions without a result
+        std::vector<Request> want; std::vector<size_t> who;
+        for (size_t i = 0; i < rs.size(); i++) {
+            if ((*raw_of)[i] >= 0) continue;
+            Request q;
+            if (!plain_request(rs[i], &q)) return false;
+            want.push_back(q); who.push_back(i);
+        }
+        if (want.empty()) return true;
+        std::vector<Raw> got;
+        run_batch(want, &got);
+        for (size_t k = 0; k < who.size(); k++) { (*raw_of)[who[k]] = (int)raws.size(); raws.push_back(std::move(got[k])); }
+        return true;
+    };
+    auto file_into_cache = [&](const std::vector<Region>& rs, const std::vector<int>& raw_of) {
+        for (size_t i = 0; i < rs.size(); i++) {
+            if (raw_of[i] < 0) continue;
+            Request q;
+            if (!plain_request(rs[i], &q)) continue;
+            q.hash = hash_rows(q.start, q.len, n, q.minsize);
+            if (cache_find(q)) continue;
+            cache_put(q, false)->raw = raws[(size_t)raw_of[i]];
+        }
+    };
+    before_restart = [&] { if (seeds_raw.size() == seeds.size()) file_into_cache(seeds, seeds_raw); };
     const int threads = prm.cores > 0 ? prm.cores : 1;
     while ((int)memory_->per_thread.size() < threads) memory_->per_thread.emplace_back(new AlignerMemory::PerThread);
     struct Out { std::vector<Mum> accepted; std::vector<Region> kids; };
     int gi = 0;                                  // 0: the first seed alone; 1: the other seeds + its children; 2..: children
+    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    double tl = now_s();
+    auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[generation %d] %-12s %.4f s\n", gi, what, t - tl); tl = t; } };
     while (!gen.empty()) {
         std::vector<Region> now;
+        std::vector<int> now_raw;
         std::vector<size_t> first;               // clusters of `now`
         bool trouble = false;
         if (gi == 0) {                           // the first pushed seed, before anything is sorted
-            now.push_back(gen.front());
+            trouble = !fetch(gen, &gen_raw);     // ... but every seed's engine result in ONE call
+            seeds_raw = gen_raw;
+            now.push_back(gen.front()); now_raw.push_back(gen_raw.front());
             first = {0, 1};
         } else {                                 // sort by reference start, drop a region equal to its successor (:291-306)
             std::vector<Handle> h(gen.size());
@@ -832,36 +878,24 @@ bool Aligner::extend_generations() {
                     if (now.back().same_as(r, n)) continue;
                     trouble = true;              // two different regions share a reference start: the unstable sort decides
                 }
-                now.push_back(r);
+                now.push_back(r); now_raw.push_back(gen_raw[(size_t)h[i].idx]);
             }
             if (!trouble) trouble = !disjoint_clusters(now, &first);
+            if (!trouble) trouble = !fetch(now, &now_raw);       // children: one more call (usually nothing to fetch)
         }
-        // engine results of the generation in one call; every region must be one plain request
-        std::vector<CacheEntry*> entry(now.size(), nullptr);
+        lap("sort+fetch");
         std::vector<Request> req(now.size());
-        if (!trouble) {
-            prefetch(gi == 0 ? gen : now);       // the first call fetches every seed's result: one engine call for all of them
-            std::vector<Request> reqs;
-            const Arena<long>::Mark qmark = req_rows_.mark();
-            for (size_t i = 0; i < now.size() && !trouble; i++) {
-                const Region& r = now[i];
-                chunk_requests(r, min_length(false, r.slength), &reqs);
-                if (reqs.size() != 1 || reqs[0].start != r.start || reqs[0].len != r.length) { trouble = true; break; }   // chunked reference (p)
-                entry[i] = cache_find(reqs[0]);
-                if (!entry[i] || entry[i]->pending) { trouble = true; break; }
-                req[i] = reqs[0];
-            }
-            req_rows_.rewind(qmark);
-        }
+        for (size_t i = 0; i < now.size() && !trouble; i++) if (!plain_request(now[i], &req[i])) trouble = true;
         if (trouble) {
             stats.generation_handover = gi;
+            file_into_cache(gen, gen_raw);
             if (gi == 0) { regions = std::move(gen); if (speculation_) prefetch(regions); return extend_pass(false); }
             // after the first seed the reference's list is [other seeds in push order, children of the first in push order],
             // sorted: exactly `gen` as it stands
             if (gi == 1) { regions = std::move(gen); if (speculation_) prefetch(regions); return extend_pass(false, true); }
             return restart_in_order();
         }
-        if (gi == 0) gen.erase(gen.begin()); else gen.clear();
+        if (gi == 0) { gen.erase(gen.begin()); gen_raw.erase(gen_raw.begin()); } else { gen.clear(); gen_raw.clear(); }
         const long m = (long)now.size();
         const long nclusters = (long)first.size() - 1;
         std::vector<Out> out((size_t)m);
@@ -876,7 +910,7 @@ bool Aligner::extend_generations() {
                 // a child that sorts before (or with) this region would have been processed first, and its engine result
                 // is not there yet: give up on the whole generation
                 if (pending_min >= 0 && pending_min <= r.start[0]) { cluster_trouble = 1; break; }
-                const Raw& raw = entry[x]->raw;
+                const Raw& raw = raws[(size_t)now_raw[x]];
                 Out& o = out[x];
                 for (size_t c = 0; c < raw.count; c++) {      // = validate(), with per-thread rows and atomic marks
                     Mum mm;
@@ -919,12 +953,14 @@ bool Aligner::extend_generations() {
         }
         if (cluster_trouble) { stats.generation_handover = gi; return restart_in_order(); }
         stats.t_validate += now_s() - tv;
+        lap("validate");
         stats.generations++; stats.generation_regions += m;
         for (long x = 0; x < m; x++) {           // commit in list order
             for (Mum& mm : out[(size_t)x].accepted) { mm.id = next_id_++; pool.push_back(mm); mums.push_back((int)pool.size() - 1); }
-            for (Region& k : out[(size_t)x].kids) gen.push_back(k);
+            for (Region& k : out[(size_t)x].kids) { gen.push_back(k); gen_raw.push_back(-1); }
             stats.regions_processed++; stats.cache_hits++;
         }
+        lap("commit");
         gi++;
     }
     return !mums.empty();
