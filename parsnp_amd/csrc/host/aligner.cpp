@@ -32,7 +32,8 @@ inline bool operator<(const Handle& a, const Handle& b) { return a.key < b.key; 
 void Bitmap::init(size_t nbits) {
     nbits_ = nbits;
     const size_t words = (nbits + 63) / 64 + 1;
-    if (w_.size() == words) std::fill(w_.begin(), w_.end(), 0); else w_.assign(words, 0);   // a recycled bitmap keeps its pages
+    if (w_.size() == words) std::fill(w_.begin(), w_.end(), 0);   // a recycled bitmap keeps its pages
+    else { decltype(w_)().swap(w_); w_.resize(words); }          // fresh zero pages, untouched until used
     logging_ = false; log_.clear();
     if (nbits) w_[(nbits - 1) >> 6] |= 1ull << ((nbits - 1) & 63);
 }

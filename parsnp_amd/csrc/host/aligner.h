@@ -55,9 +55,9 @@ public:
     void init_zero_lazy(size_t nbits) {   // scratch: no sentinel; storage (and its mapped pages) is kept when the size repeats
         const size_t words = (nbits + 63) / 64 + 1;
         nbits_ = nbits;
-        if (w_.size() == words) std::fill(w_.begin(), w_.end(), 0); else w_.assign(words, 0);
+        if (w_.size() == words) std::fill(w_.begin(), w_.end(), 0); else { decltype(w_)().swap(w_); w_.resize(words); }
     }
-    void release() { std::vector<uint64_t>().swap(w_); nbits_ = 0; }
+    void release() { decltype(w_)().swap(w_); nbits_ = 0; }
     bool test_and_set(long a, long b) {    // [a,b) := 1; was any of it marked?  (scratch use: no undo log)
         if (a < 0) a = 0;
         if (b > (long)nbits_) b = (long)nbits_;
@@ -105,7 +105,19 @@ public:
     void rollback();
     void end_log() { logging_ = false; log_.clear(); }
 private:
-    std::vector<uint64_t> w_;
+    // zero-on-demand storage: calloc hands out fresh zero pages for a block this size and resize() does not write to
+    // them, so a new bitmap costs nothing until its words are touched (125 MB of bitmaps per run at 200 x 5 Mb)
+    template <class T> struct ZeroAlloc {
+        typedef T value_type;
+        ZeroAlloc() = default;
+        template <class U> ZeroAlloc(const ZeroAlloc<U>&) {}
+        T* allocate(size_t k) { void* p = calloc(k ? k : 1, sizeof(T)); if (!p) throw std::bad_alloc(); return (T*)p; }
+        void deallocate(T* p, size_t) { free(p); }
+        template <class U, class... A> void construct(U*, A&&...) {}      // storage is zero already
+        template <class U> bool operator==(const ZeroAlloc<U>&) const { return true; }
+        template <class U> bool operator!=(const ZeroAlloc<U>&) const { return false; }
+    };
+    std::vector<uint64_t, ZeroAlloc<uint64_t>> w_;
     size_t nbits_ = 0;
     bool logging_ = false;
     std::vector<std::pair<size_t, uint64_t>> log_;
