@@ -246,14 +246,23 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out)
     out->resize(reqs.size());
     if (reqs.empty()) return;
     double t0 = now_s();
-    std::vector<int64_t> starts(reqs.size() * n), lens(reqs.size() * n);
+    // the flat arrays of the C ABI live in the run's memory: 2 x 13 MB for the recursion batch, not faulted in per call
+    std::vector<int64_t>& starts = memory_->batch_starts; std::vector<int64_t>& lens = memory_->batch_lens;
+    if (starts.size() < reqs.size() * n) { starts.resize(reqs.size() * n); lens.resize(reqs.size() * n); }
     std::vector<int32_t> mins(reqs.size());
-    for (size_t i = 0; i < reqs.size(); i++) {
-        memcpy(&starts[i * n], reqs[i].start, n * 8);
-        memcpy(&lens[i * n], reqs[i].len, n * 8);
-        mins[i] = reqs[i].minsize;
-        for (size_t g = 1; g < n; g++) stats.alg_bytes += (double)reqs[i].len[g] * 16.25 + 16.0 * (double)reqs[i].len[0];
+    double alg = 0;
+    const long nreq = (long)reqs.size();
+#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) reduction(+ : alg) if (nreq > 256)
+    for (long i = 0; i < nreq; i++) {
+        const Request& q = reqs[(size_t)i];
+        memcpy(&starts[(size_t)i * n], q.start, n * 8);
+        memcpy(&lens[(size_t)i * n], q.len, n * 8);
+        mins[(size_t)i] = q.minsize;
+        double a = 0;
+        for (size_t g = 1; g < n; g++) a += (double)q.len[g] * 16.25 + 16.0 * (double)q.len[0];
+        alg += a;
     }
+    stats.alg_bytes += alg;
     stats.t_pack += now_s() - t0;
     pm_result* res = nullptr;
     int rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);

@@ -210,6 +210,7 @@ struct AlignerMemory {
     Arena<long> rows, cache_rows, req_rows;
     Arena<int> irows;
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
+    std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
     struct PerThread { Arena<long> rows; Arena<int> irows; };
     std::vector<std::unique_ptr<PerThread>> per_thread;   // rows written by the threads of the generation-parallel replay
     void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); for (auto& t : per_thread) { t->rows.reset(); t->irows.reset(); } }
