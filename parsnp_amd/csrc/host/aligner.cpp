@@ -1041,11 +1041,19 @@ void Aligner::filter_mums(int rvalue) {
 void Aligner::chain() {
     double t0 = now_s();
     lcbs.clear();
+    unique_order = true;
     {
         std::vector<Handle> h(mums.size());
         for (size_t i = 0; i < mums.size(); i++) h[i] = Handle{pool[(size_t)mums[i]].start[0], mums[i]};
-        std::sort(h.begin(), h.end());
-        for (size_t i = 0; i < mums.size(); i++) mums[i] = h[i].idx;
+        // strictly increasing keys (the list as filter_mums left it) have one sorted order: nothing to do.  With ties
+        // the order std::sort leaves is the reference's, so it runs.
+        bool increasing = true;
+        for (size_t i = 1; i < h.size() && increasing; i++) increasing = h[i - 1].key < h[i].key;
+        unique_order = increasing;
+        if (!increasing) {
+            std::sort(h.begin(), h.end());
+            for (size_t i = 0; i < mums.size(); i++) mums[i] = h[i].idx;
+        }
     }
     if (mums.empty()) return;
     const int d = prm.d;

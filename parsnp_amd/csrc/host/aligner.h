@@ -230,6 +230,7 @@ public:
     std::vector<Region> regions;  // this->regions (work list of extend())
     float l = 0;                  // anchor min length ("Mum anchor size")
     long m0 = 0, filtered = 0, filtered_lcbs = 0;
+    bool unique_order = false;   // chain(): the MUM list had no two MUMs with the same reference start (one sorted order)
     int random = 0;
     float anchor_time = 0, coarsen_time = 0, random_time = 0, clusters_time = 0, iclusters_time = 0;
     Stats stats;

@@ -178,8 +178,14 @@ StepReport CoreRun::step() {
         double tl = now_s();
         auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[lcb] %-12s %.4f s\n", what, t - tl); tl = t; } };
         a.chain(); lap("chain");
+        const long dissolved = a.filtered_lcbs;
         a.filter_lcbs(); lap("filter_lcbs");
-        a.chain(); lap("chain");
+        // the reference chains again (:3261-3268).  With no LCB dissolved and no two MUMs sharing a reference start the
+        // MUM list and its sorted order are unchanged, and the second pass would rebuild exactly the list at hand
+        // (chain order = order of the first MUMs on the reference = the order sort_lcbs left).
+        bool same = a.filtered_lcbs == dissolved && a.unique_order && !getenv("PARSNP_CHAIN_TWICE");
+        for (size_t i = 1; i < a.lcbs.size() && same; i++) same = a.lcbs[i - 1].start[0] < a.lcbs[i].start[0];
+        if (!same) { a.chain(); lap("chain"); }
         a.fill_between(); lap("fill_between");
         time(&end);
         a.iclusters_time = (float)difftime(end, start);
