@@ -115,14 +115,17 @@ bool Region::same_as(const Region& o, size_t n) const {
 // ---------------------------------------------------------------------------------------------- Aligner
 Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, AlignerMemory* memory)
     : n(g.size()), prm(p), genomes(g), session_(session), own_memory_(memory ? nullptr : new AlignerMemory),
-      memory_(memory ? memory : own_memory_.get()), rows_(memory_->rows), irows_(memory_->irows), cache_rows_(memory_->cache_rows),
+      memory_(memory ? memory : own_memory_.get()), rows_(memory_->rows), irows_(memory_->irows), brows_(memory_->brows), cache_rows_(memory_->cache_rows),
       req_rows_(memory_->req_rows) {
     // the layout bitmaps are allocated afresh and zeroed by THIS thread: zeroing them with all threads (or recycling
     // bitmaps cleared in parallel) saves 12 ms here and costs 17 ms later -- their pages end up spread over the NUMA nodes of
     // the worker threads, away from the thread that does most of the walking (measured both ways at 200 x 5 Mb)
     layout.resize(n);
     gsize_.resize(n);
-    for (size_t i = 0; i < n; i++) { layout[i].init(genomes[i].seq.size() + 1); gsize_[i] = (long)genomes[i].seq.size(); }
+    for (size_t i = 0; i < n; i++) {
+        if (genomes[i].seq.size() > (size_t)INT32_MAX - 64) fatal("genome longer than 2^31 bases: " + genomes[i].path);   // Mum rows are int32
+        layout[i].init(genomes[i].seq.size() + 1); gsize_[i] = (long)genomes[i].seq.size();
+    }
 }
 
 Aligner::~Aligner() {
@@ -145,14 +148,14 @@ void Aligner::neighbour_into(const Mum& m, bool left, Region* out) const {
     long* start = out->start; long* end = out->end;
     for (size_t i = 0; i < n; i++) {
         if (left) {   // walk left to the previous marked base; at the genome start the region begins at 1 (:1216-1231)
-            long p = layout[i].prev_set(m.start[i] - 1);
+            long p = layout[i].prev_set((long)m.start[i] - 1);
             if (p < 0) p = 0;
             start[i] = p + 1;
-            end[i] = m.start[i] - 1;
+            end[i] = (long)m.start[i] - 1;
         } else {      // walk right to the next marked base or the genome end (:1254-1268)
-            long nxt = m.end[i] + 1, size = (long)genomes[i].seq.size();
+            long nxt = m.end(i) + 1, size = (long)genomes[i].seq.size();
             long p = nxt >= size ? nxt : layout[i].next_set(nxt);
-            start[i] = m.end[i] + 1;
+            start[i] = nxt;
             end[i] = p - 1;
         }
     }
@@ -348,12 +351,12 @@ bool Aligner::candidate_rows(const Region& r, const Request& q, const Raw& raw, 
     const long* __restrict rstart = r.start;
     const long* __restrict rlen = r.length;
     const long* __restrict gs = gsize_.data();
-    long* __restrict ms = m.start; long* __restrict me = m.end; int* __restrict mf = m.fwd;
+    int32_t* __restrict ms = m.start; uint8_t* __restrict mf = m.fwd;
     // genome 0: DSP = k + 1 + ini of the reference chunk, always forward
     const unsigned long dsp0 = (unsigned long)raw.k[c] + 1 + (unsigned long)q.ref_ini;
     unsigned long bad = dsp0 - (unsigned long)rstart[0] > (unsigned long)(unsigned int)rlen[0];
     long st0 = (long)(dsp0 - 1);
-    ms[0] = st0; me[0] = st0 + lon; mf[0] = 1;
+    ms[0] = (int32_t)st0; mf[0] = 1;   // out-of-range values wrap here, but such a candidate is refused below (bad / notgood)
     unsigned long notgood = (st0 + lon > gs[0]) | (st0 < 0), rev = 0;
     for (size_t j = 1; j < n; j++) {
         // dsp - r.start[j] == sp + 1 in unsigned arithmetic (:1723); startpos = dsp - 1
@@ -363,7 +366,7 @@ bool Aligner::candidate_rows(const Region& r, const Request& q, const Raw& raw, 
         const long f = fw[j - 1] != 0;
         const long flipped = gs[j] - (startpos + lon);
         const long st = f ? startpos : flipped;
-        ms[j] = st; me[j] = st + lon; mf[j] = (int)fw[j - 1];
+        ms[j] = (int32_t)st; mf[j] = fw[j - 1];
         rev |= (unsigned long)!f;
         notgood |= (unsigned long)(st + lon > gs[j]) | (unsigned long)(st < 0);          // never for in-range candidates
     }
@@ -409,17 +412,17 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
     struct Rep { double t0; size_t n; ~Rep() { if (n > 1000 && getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[validate serial] %zu candidates %.4f s\n", n, now_s() - t0); } } rep_{tser, ncand};
     for (size_t c = 0; c < ncand; c++) {
         Mum m;
-        const Arena<long>::Mark rmark = rows_.mark();
-        const Arena<int>::Mark imark = irows_.mark();
-        m.start = rows_.alloc(n); m.end = rows_.alloc(n); m.fwd = irows_.alloc(n);
+        const Arena<int32_t>::Mark imark = irows_.mark();
+        const Arena<uint8_t>::Mark bmark = brows_.mark();
+        m.start = irows_.alloc(n); m.fwd = brows_.alloc(n);
         bool ok, any_reverse;
-        if (!candidate_rows(r, q, raw, c, m, &ok, &any_reverse)) { rows_.rewind(rmark); irows_.rewind(imark); continue; }
+        if (!candidate_rows(r, q, raw, c, m, &ok, &any_reverse)) { irows_.rewind(imark); brows_.rewind(bmark); continue; }
         m.id = next_id_++;
         bool touches = false;
         if (ok && m.length > 0)
-            for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end[j] - 1);
-        if (!ok || !settle(m, touches, any_reverse)) { rows_.rewind(rmark); irows_.rewind(imark); continue; }
-        for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end[j]);
+            for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end(j) - 1);
+        if (!ok || !settle(m, touches, any_reverse)) { irows_.rewind(imark); brows_.rewind(bmark); continue; }
+        for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end(j));
         m.slength = r.slength;
         pool.push_back(m);
         accepted->push_back((int)pool.size() - 1);
@@ -437,14 +440,14 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double tp = now_s();
     auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[validate_parallel] %-10s %.4f s\n", what, t - tp); tp = t; } };
-    long* srow = rows_.alloc(ncand * n); long* erow = rows_.alloc(ncand * n); int* frow = irows_.alloc(ncand * n);
+    int32_t* srow = irows_.alloc(ncand * n); uint8_t* frow = brows_.alloc(ncand * n);
     std::vector<Mum> cand(ncand);
     std::vector<uint8_t> state(ncand, 0);   // bit0 constructed, bit1 ok, bit2 any_reverse, bit3 dirty, bit4 accepted
     const long nc = (long)ncand;
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (long c = 0; c < nc; c++) {
         Mum& m = cand[(size_t)c];
-        m.start = srow + (size_t)c * n; m.end = erow + (size_t)c * n; m.fwd = frow + (size_t)c * n;
+        m.start = srow + (size_t)c * n; m.fwd = frow + (size_t)c * n;
         bool ok, rev;
         if (candidate_rows(r, q, raw, (size_t)c, m, &ok, &rev)) state[(size_t)c] = 1 | (ok ? 2 : 0) | (rev ? 4 : 0);
     }
@@ -465,7 +468,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             long* maxend = maxend_l.data() + 8 - j0; long* minstart = minstart_l.data() + 8 - j0;
             for (size_t c = 0; c < ncand; c++) {
                 if ((state[c] & 3) != 3 || cand[c].length < 5) continue;        // never marks anything
-                const long* st = cand[c].start; const long lon = cand[c].length;
+                const int32_t* st = cand[c].start; const long lon = cand[c].length;
                 bool hit = false;
                 for (size_t j = j0; j < j1; j++) {
                     const long a = st[j], b = a + lon;
@@ -492,9 +495,9 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             for (size_t j = j0; j < j1; j++) scratch[j].init_zero_lazy((size_t)gsize_[j] + 1);
             for (size_t c = 0; c < ncand; c++) {
                 if ((state[c] & 3) != 3 || cand[c].length < 5) continue;
-                const long* st = cand[c].start; const long lon = cand[c].length;
+                const int32_t* st = cand[c].start; const long lon = cand[c].length;
                 bool hit = false;
-                for (size_t j = j0; j < j1; j++) hit |= scratch[j].test_and_set(st[j], st[j] + lon) | layout[j].any_set(st[j], st[j] + lon);
+                for (size_t j = j0; j < j1; j++) hit |= scratch[j].test_and_set(st[j], (long)st[j] + lon) | layout[j].any_set(st[j], (long)st[j] + lon);
                 if (hit) __atomic_fetch_or(&state[c], (uint8_t)8, __ATOMIC_RELAXED);
             }
         }
@@ -512,7 +515,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
         for (size_t c = 0; c < ncand; c++)
             if ((state[c] & 24) == 16)
-                for (size_t j = j0; j < j1; j++) layout[j].set_range(cand[c].start[j], cand[c].end[j]);
+                for (size_t j = j0; j < j1; j++) layout[j].set_range(cand[c].start[j], cand[c].end(j));
     }
     lap("settle+mark");
     // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them
@@ -527,9 +530,9 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         if ((st & 2) && (st & 8)) {
             bool touches = false;
             if (m.length > 0)
-                for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end[j] - 1);
+                for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end(j) - 1);
             acc = settle(m, touches, (st & 4) != 0);
-            if (acc) for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end[j]);
+            if (acc) for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end(j));
         }
         if (!acc) continue;
         m.slength = r.slength;
@@ -545,14 +548,13 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
 // shortens the MUM in ALL genomes (Aligner::trim :1399-1477, TMum::trimleft/right TMum.cpp:104-148).
 void Aligner::trim(Mum& m) const {
     for (size_t j = 0; j < n; j++) {
-        for (long x = m.start[j]; x < m.end[j]; x++) {
+        for (long x = m.start[j]; x < m.end(j); x++) {      // start moves right in every genome, end stays
             if (!layout[j].get(x)) break;
             for (size_t i = 0; i < n; i++) m.start[i] += 1;
             m.length -= 1; m.slength -= 1;
         }
-        for (long x = m.end[j] - 1; x >= m.start[j]; x--) {
+        for (long x = m.end(j) - 1; x >= m.start[j]; x--) { // end moves left in every genome: end = start + length
             if (!layout[j].get(x)) break;
-            for (size_t i = 0; i < n; i++) m.end[i] -= 1;
             m.length -= 1; m.slength -= 1;
         }
     }
@@ -726,7 +728,8 @@ void Aligner::speculate(std::vector<Region> gen) {
     const size_t saved_pool = pool.size();
     const long saved_id = next_id_;
     const Arena<long>::Mark rmark = rows_.mark();
-    const Arena<int>::Mark imark = irows_.mark();
+    const Arena<int32_t>::Mark imark = irows_.mark();
+    const Arena<uint8_t>::Mark bmark = brows_.mark();
     while (!gen.empty()) {
         stats.spec_rounds++;
         prefetch(gen);
@@ -749,7 +752,7 @@ void Aligner::speculate(std::vector<Region> gen) {
     }
     for (size_t i = 0; i < n; i++) { layout[i].rollback(); layout[i].end_log(); }
     pool.resize(saved_pool);
-    rows_.rewind(rmark); irows_.rewind(imark);
+    rows_.rewind(rmark); irows_.rewind(imark); brows_.rewind(bmark);
     next_id_ = saved_id;
     mums = saved_mums;
     stats.t_sweep += now_s() - t0;
@@ -815,7 +818,7 @@ bool Aligner::extend_generations() {
 #pragma omp parallel for schedule(dynamic, 4) num_threads(prm.cores > 0 ? prm.cores : 1)
         for (long g = 0; g < nl; g++) {        // the layout before the extension = the marks of the MUMs accepted so far
             layout[(size_t)g].init(genomes[(size_t)g].seq.size() + 1);
-            for (size_t x = 0; x < pool0; x++) layout[(size_t)g].set_range(pool[x].start[g], pool[x].end[g]);
+            for (size_t x = 0; x < pool0; x++) layout[(size_t)g].set_range(pool[x].start[g], pool[x].end((size_t)g));
         }
         regions = seeds;
         stats.generation_restarts++;
@@ -924,16 +927,16 @@ bool Aligner::extend_generations() {
                 Out& o = out[x];
                 for (size_t c = 0; c < raw.count; c++) {      // = validate(), with per-thread rows and atomic marks
                     Mum mm;
-                    const Arena<long>::Mark rmark = tl.rows.mark();
-                    const Arena<int>::Mark imark = tl.irows.mark();
-                    mm.start = tl.rows.alloc(n); mm.end = tl.rows.alloc(n); mm.fwd = tl.irows.alloc(n);
+                    const Arena<int32_t>::Mark imark = tl.irows.mark();
+                    const Arena<uint8_t>::Mark bmark = tl.brows.mark();
+                    mm.start = tl.irows.alloc(n); mm.fwd = tl.brows.alloc(n);
                     bool ok, any_reverse;
-                    if (!candidate_rows(r, req[x], raw, c, mm, &ok, &any_reverse)) { tl.rows.rewind(rmark); tl.irows.rewind(imark); continue; }
+                    if (!candidate_rows(r, req[x], raw, c, mm, &ok, &any_reverse)) { tl.irows.rewind(imark); tl.brows.rewind(bmark); continue; }
                     bool touches = false;
                     if (ok && mm.length > 0)
-                        for (size_t j = 0; j < n; j++) touches |= layout[j].get(mm.start[j]) | layout[j].get(mm.end[j] - 1);
-                    if (!ok || !settle(mm, touches, any_reverse)) { tl.rows.rewind(rmark); tl.irows.rewind(imark); continue; }
-                    for (size_t j = 0; j < n; j++) layout[j].set_range_atomic(mm.start[j], mm.end[j]);
+                        for (size_t j = 0; j < n; j++) touches |= layout[j].get(mm.start[j]) | layout[j].get(mm.end(j) - 1);
+                    if (!ok || !settle(mm, touches, any_reverse)) { tl.irows.rewind(imark); tl.brows.rewind(bmark); continue; }
+                    for (size_t j = 0; j < n; j++) layout[j].set_range_atomic(mm.start[j], mm.end(j));
                     mm.slength = r.slength;
                     o.accepted.push_back(mm);
                 }
@@ -1015,20 +1018,20 @@ void Aligner::filter_mums(int rvalue) {
         const Mum* prev = x > 0 ? &pool[(size_t)mums[(size_t)x - 1]] : nullptr;
         bool adjacent = true;
         for (size_t k = 0; k < n && adjacent; k++) {
-            long gap = labs(nt.start[k]) - labs(mt.end[k]);
+            long gap = labs(nt.start[k]) - labs(mt.end(k));
             if (gap < 0 || gap > 5000) { adjacent = false; break; }
-            for (int m = (int)mt.end[k] + 1; m < nt.start[k]; m++)
+            for (int m = (int)mt.end(k) + 1; m < nt.start[k]; m++)
                 if (layout[k].get(m)) { adjacent = false; break; }
             if (prev) {
-                long pgap = labs(mt.start[k]) - labs(prev->end[k]);
+                long pgap = labs(mt.start[k]) - labs(prev->end(k));
                 if (pgap < 0 || pgap > 5000) { adjacent = false; break; }
-                for (int m = (int)prev->end[k] + 1; m < mt.start[k]; m++)
+                for (int m = (int)prev->end(k) + 1; m < mt.start[k]; m++)
                     if (layout[k].get(m)) { adjacent = false; break; }
             }
         }
         if (!adjacent) {
             filtered += 1;
-            for (size_t k = 0; k < n; k++) layout[k].clear_range(mt.start[k], mt.end[k]);
+            for (size_t k = 0; k < n; k++) layout[k].clear_range(mt.start[k], mt.end(k));
             mums.erase(mums.begin() + x);
             x -= 1; numums -= 1;
         }
@@ -1065,10 +1068,10 @@ void Aligner::chain() {
         bool addmum = true;
         float max_gap = 0;
         float min_gap = d + 10;
-        const long* cend = back.end;
+        const long blen = back.length;
         for (size_t k = 0; k < n; k++) {
-            const long fgap = nt.start[k] - cend[k];             // forward: next start - chain end
-            const long rgap = back.start[k] - nt.end[k];         // reverse: previous MUM start - next end
+            const long fgap = (long)nt.start[k] - ((long)back.start[k] + blen);   // forward: next start - chain end
+            const long rgap = (long)back.start[k] - nt.end(k);   // reverse: previous MUM start - next end
             const bool f = nt.fwd[k] != 0;
             if (f && fgap > max_gap) max_gap = fgap;
             else if (!f && rgap > max_gap) max_gap = fgap;       // sic (:2608-2611)
@@ -1098,7 +1101,8 @@ void Aligner::chain() {
         const Mum& f = pool[(size_t)c.mums.front()];
         const Mum& b = pool[(size_t)c.mums.back()];
         c.start.assign(f.start, f.start + n);
-        c.end.assign(b.end, b.end + n);
+        c.end.resize(n);
+        for (size_t k = 0; k < n; k++) c.end[k] = b.end(k);
         lcbs.push_back(c);
     };
     Lcb cluster = open_chain(mums[0]);
@@ -1146,7 +1150,7 @@ void Aligner::filter_lcbs() {
         for (int idx : lcbs[(size_t)x].mums) {
             filtered += 1;
             const Mum& mt = pool[(size_t)idx];
-            for (size_t k = 0; k < n; k++) layout[k].clear_range(mt.start[k], mt.end[k]);
+            for (size_t k = 0; k < n; k++) layout[k].clear_range(mt.start[k], mt.end(k));
             auto it = std::find(mums.begin(), mums.end(), idx);   // first MUM with that id
             if (it != mums.end()) mums.erase(it);
         }

@@ -156,13 +156,18 @@ private:
     size_t cur_ = 0, off_ = 0;
 };
 
-struct Mum {             // rows of n entries in Aligner's arenas
+// rows of n entries in Aligner's arenas.  TMum keeps start, end and a strand flag per genome as vector<long>/<bool>
+// (TMum.h); end == start + length in every genome at all times (constructor TMum.cpp:25-60, trimleft/trimright
+// :104-148 move start or end together with length), so only start is stored, as int32 (a genome longer than 2^31 - 1
+// is refused at construction): 5 bytes per genome and MUM instead of 20 -- the host phases that walk 60 000 anchors x
+// 200 genomes are bound by the bytes of these rows, not by arithmetic.
+struct Mum {
     long id = 0;
     long length = 0;
     long slength = 0;
-    long* start = nullptr;
-    long* end = nullptr;
-    int* fwd = nullptr;
+    int32_t* start = nullptr;
+    uint8_t* fwd = nullptr;
+    long end(size_t j) const { return (long)start[j] + length; }
 };
 
 struct Region {          // rows of n entries in Aligner's arenas; immutable once built
@@ -208,12 +213,13 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
 // hundreds of MB back to the OS and faulting them in again costs more than the reset.
 struct AlignerMemory {
     Arena<long> rows, cache_rows, req_rows;
-    Arena<int> irows;
+    Arena<int32_t> irows;                    // MUM start rows
+    Arena<uint8_t> brows;                    // MUM strand rows
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
     std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
-    struct PerThread { Arena<long> rows; Arena<int> irows; };
+    struct PerThread { Arena<long> rows; Arena<int32_t> irows; Arena<uint8_t> brows; };
     std::vector<std::unique_ptr<PerThread>> per_thread;   // rows written by the threads of the generation-parallel replay
-    void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); for (auto& t : per_thread) { t->rows.reset(); t->irows.reset(); } }
+    void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); brows.reset(); for (auto& t : per_thread) { t->rows.reset(); t->irows.reset(); t->brows.reset(); } }
 };
 
 class Aligner {
@@ -251,8 +257,9 @@ private:
     long next_id_ = 1;
     std::unique_ptr<AlignerMemory> own_memory_;   // when the caller did not lend one
     AlignerMemory* memory_;
-    Arena<long>& rows_;      // MUM and region coordinate rows
-    Arena<int>& irows_;      // MUM strand rows
+    Arena<long>& rows_;      // region coordinate rows
+    Arena<int32_t>& irows_;  // MUM start rows
+    Arena<uint8_t>& brows_;  // MUM strand rows
     // --- finder plumbing -------------------------------------------------------------------------------------
     // one engine request = one reference chunk of one region; rows of n entries (the region's own rows when the
     // region is a single unclamped chunk, else rows in req_rows_)

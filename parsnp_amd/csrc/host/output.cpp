@@ -48,10 +48,10 @@ void gap_between(const Aligner& a, const Lcb& ct, size_t t, Gap* gp) {
     for (size_t i = 0; i < n; i++) {
         const std::string& g = a.genomes[i].seq;
         if (!first.fwd[i]) {
-            if (m.start[i] - nx.end[i] >= 1) gp->seq[i] = upper(reverse_complement(sub(g, nx.end[i], m.start[i] - nx.end[i])));
+            if (m.start[i] - nx.end(i) >= 1) gp->seq[i] = upper(reverse_complement(sub(g, nx.end(i), m.start[i] - nx.end(i))));
             else gp->seq[i].clear();
         } else {
-            gp->seq[i] = upper(sub(g, m.end[i], nx.start[i] - m.end[i]));
+            gp->seq[i] = upper(sub(g, m.end(i), nx.start[i] - m.end(i)));
         }
         if (gp->seq[i].size() > max_len) max_len = (unsigned)gp->seq[i].size();
         if (gp->seq[i].size() < min_len) min_len = (unsigned)gp->seq[i].size();
@@ -229,7 +229,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         for (size_t i = 0; i < n; i++) {
             std::ostringstream hd;
             if (first.fwd[i]) hd << "> " << i + 1 << ":" << ct.start[i] + 1 << "-" << ct.end[i] << " ";
-            else hd << "> " << i + 1 << ":" << lastm.start[i] + 1 << "-" << first.end[i] << " ";
+            else hd << "> " << i + 1 << ":" << lastm.start[i] + 1 << "-" << first.end(i) << " ";
             // contig label and offset: last pos2hdr entry at or before the LCB start (:994-1037)
             // (the reference scans the map in key order; the entry it ends on is the last key <= start)
             string hdr;
