@@ -251,6 +251,8 @@ def main():
             run.close()
         finally:
             os.dup2(so, 1); os.dup2(se, 2)
+            if os.environ.get("PARSNP_BENCH_LOG") and rank == 0:     # keep the host's chatter (PARSNP_DEBUG_TIMERS laps)
+                shutil.copyfile(os.path.join(out, "bench.log"), os.environ["PARSNP_BENCH_LOG"])
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

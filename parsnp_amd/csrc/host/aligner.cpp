@@ -521,6 +521,17 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them
     pool.reserve(pool.size() + ncand);
     accepted->reserve(accepted->size() + ncand);
+    // the flagged candidates read two words per genome that another core has just written: requested two candidates ahead
+    std::vector<uint32_t> ordered;
+    for (size_t c = 0; c < ncand; c++) if ((state[c] & 11) == 11) ordered.push_back((uint32_t)c);
+    auto warm = [&](size_t o) {
+        if (o >= ordered.size()) return;
+        const Mum& w = cand[ordered[o]];
+        if (w.length <= 0) return;
+        for (size_t j = 0; j < n; j++) { layout[j].prefetch(w.start[j]); layout[j].prefetch(w.end(j) - 1); }
+    };
+    warm(0); warm(1);
+    size_t onext = 0;
     for (size_t c = 0; c < ncand; c++) {
         const uint8_t st = state[c];
         if (!(st & 1)) continue;
@@ -528,6 +539,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         m.id = next_id_++;
         bool acc = (st & 16) != 0;
         if ((st & 2) && (st & 8)) {
+            warm(++onext + 1);
             bool touches = false;
             if (m.length > 0)
                 for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end(j) - 1);
@@ -577,10 +589,37 @@ bool Aligner::find_anchors() {
     std::vector<Region> lRs(found.size()), rRs(found.size());
     for (size_t i = 0; i < found.size(); i++) { lRs[i] = new_region(); rRs[i] = new_region(); }
     const long nf = (long)found.size();
+    static const bool check_derived = getenv("PARSNP_CHECK_NEIGHBOURS") != nullptr;
+#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1)
+    for (long i = 0; i < nf; i++) neighbour_into(pool[(size_t)found[(size_t)i]], false, &rRs[(size_t)i]);
+    // left neighbour: where the walk to the right of the previous anchor ended exactly at this anchor in every genome,
+    // the walk back from this anchor crosses the same unmarked bases and stops at the previous anchor's last base
+    // (prev_set :1216-1231), or one base later when the base after it is marked: no second walk over the bitmap.
 #pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1)
     for (long i = 0; i < nf; i++) {
-        neighbour_into(pool[(size_t)found[(size_t)i]], true, &lRs[(size_t)i]);
-        neighbour_into(pool[(size_t)found[(size_t)i]], false, &rRs[(size_t)i]);
+        const Mum& m = pool[(size_t)found[(size_t)i]];
+        Region& lR = lRs[(size_t)i];
+        bool derived = i > 0;
+        if (derived) {
+            const Region& pr = rRs[(size_t)i - 1];
+            for (size_t j = 0; j < n; j++) if (pr.end[j] + 1 != (long)m.start[j]) { derived = false; break; }
+        }
+        if (derived) {
+            const Mum& pm = pool[(size_t)found[(size_t)i - 1]];
+            for (size_t j = 0; j < n; j++) {
+                const long e = pm.end(j);
+                lR.start[j] = layout[j].get(e) ? e + 1 : e;
+                lR.end[j] = (long)m.start[j] - 1;
+            }
+            finish_region(lR, n);
+            if (check_derived) {       // test hook: the walk must give the same region
+                std::vector<long> a(lR.start, lR.start + n), b(lR.end, lR.end + n);
+                neighbour_into(m, true, &lR);
+                if (!std::equal(a.begin(), a.end(), lR.start) || !std::equal(b.begin(), b.end(), lR.end)) fatal("derived left neighbour differs from the bitmap walk");
+            }
+        } else {
+            neighbour_into(m, true, &lR);
+        }
     }
     stats.t_neighbour += now_s() - tn;
     for (size_t i = 0; i < found.size(); i++) {

@@ -104,6 +104,18 @@ def test_in_order_replay_same_result(cpu_checkers, tmp_path, name, threads):
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"], tag
 
 
+@pytest.mark.parametrize("name", ["pop6x200k", "poprearr10x400k", "messy", "draft8x300k"])
+def test_derived_left_neighbours_equal_the_walk(cpu_checkers, tmp_path, name):
+    """the seed regions left of an anchor are derived from the walk right of the previous anchor where that walk ended
+    at this anchor in every genome; PARSNP_CHECK_NEIGHBOURS=1 repeats every derived region with the bitmap walk of
+    determineRegion (parsnp.cpp:1199-1290) and aborts on a difference"""
+    rp, qs, kw = harsh_inputs(name, str(tmp_path))
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=dict(os.environ, PARSNP_CHECK_NEIGHBOURS="1"), threads=3, **kw)
+    assert rc == 0
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
+
+
 @pytest.mark.parametrize("name", ["pop6x200k", "poprearr10x400k"])
 def test_literal_worklist_same_result(cpu_checkers, tmp_path, name):
     """the map-based work list (unique keys) and the reference's literal vector + std::sort + adjacent-dedup agree"""
