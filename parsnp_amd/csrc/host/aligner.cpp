@@ -586,47 +586,67 @@ bool Aligner::find_anchors() {
     // seed regions: left and right neighbour of every anchor, longer than q in every genome (:2150-2172).  The layout
     // is final here, so the 2*m0 bitmap walks are independent: computed in parallel, consumed in order.
     double tn = now_s();
-    std::vector<Region> lRs(found.size()), rRs(found.size());
-    for (size_t i = 0; i < found.size(); i++) { lRs[i] = new_region(); rRs[i] = new_region(); }
+    // Only a region longer than q in every genome is ever looked at again (one in fifteen at 200 x 5 Mb), and a region
+    // that is dropped cannot equal one that is kept (equal rows, equal slength): rows are worked out in per-thread
+    // scratch and kept -- copied into the arena -- only for those.
+    std::vector<Region> lRs(found.size()), rRs(found.size());   // start == nullptr: dropped
     const long nf = (long)found.size();
     static const bool check_derived = getenv("PARSNP_CHECK_NEIGHBOURS") != nullptr;
-#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1)
-    for (long i = 0; i < nf; i++) neighbour_into(pool[(size_t)found[(size_t)i]], false, &rRs[(size_t)i]);
     // left neighbour: where the walk to the right of the previous anchor ended exactly at this anchor in every genome,
     // the walk back from this anchor crosses the same unmarked bases and stops at the previous anchor's last base
     // (prev_set :1216-1231), or one base later when the base after it is marked: no second walk over the bitmap.
-#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1)
-    for (long i = 0; i < nf; i++) {
-        const Mum& m = pool[(size_t)found[(size_t)i]];
-        Region& lR = lRs[(size_t)i];
-        bool derived = i > 0;
-        if (derived) {
-            const Region& pr = rRs[(size_t)i - 1];
-            for (size_t j = 0; j < n; j++) if (pr.end[j] + 1 != (long)m.start[j]) { derived = false; break; }
-        }
-        if (derived) {
-            const Mum& pm = pool[(size_t)found[(size_t)i - 1]];
-            for (size_t j = 0; j < n; j++) {
-                const long e = pm.end(j);
-                lR.start[j] = layout[j].get(e) ? e + 1 : e;
-                lR.end[j] = (long)m.start[j] - 1;
+    // Each thread takes a contiguous run of anchors, left then right of each, so the bitmap words stay in its cache.
+    const int nthreads = prm.cores > 0 ? prm.cores : 1;
+    const long q = prm.q;
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
+    for (int t = 0; t < nthreads; t++) {
+        const long i0 = nf * t / nthreads, i1 = nf * (t + 1) / nthreads;
+        std::vector<long> buf(9 * n);
+        auto scratch = [&](int k) { Region r; r.start = &buf[(size_t)k * 3 * n]; r.end = r.start + n; r.length = r.end + n; return r; };
+        Region lS = scratch(0), rS[2] = {scratch(1), scratch(2)};
+        auto keep = [&](const Region& s, Region* out) {
+            if (s.slength <= q) return;
+            Region r;
+#pragma omp critical(parsnp_anchor_regions)
+            r = new_region();
+            memcpy(r.start, s.start, n * sizeof(long)); memcpy(r.end, s.end, n * sizeof(long)); memcpy(r.length, s.length, n * sizeof(long));
+            r.slength = s.slength; r.llength = s.llength;
+            *out = r;
+        };
+        for (long i = i0; i < i1; i++) {
+            const Mum& m = pool[(size_t)found[(size_t)i]];
+            Region& pr = rS[(i - i0 + 1) & 1];       // right neighbour of the previous anchor of this run
+            Region& rR = rS[(i - i0) & 1];
+            bool derived = i > i0;
+            if (derived)
+                for (size_t j = 0; j < n; j++) if (pr.end[j] + 1 != (long)m.start[j]) { derived = false; break; }
+            if (derived) {
+                const Mum& pm = pool[(size_t)found[(size_t)i - 1]];
+                for (size_t j = 0; j < n; j++) {
+                    const long e = pm.end(j);
+                    lS.start[j] = layout[j].get(e) ? e + 1 : e;
+                    lS.end[j] = (long)m.start[j] - 1;
+                }
+                finish_region(lS, n);
+                if (check_derived) {       // test hook: the walk must give the same region
+                    std::vector<long> a(lS.start, lS.start + n), b(lS.end, lS.end + n);
+                    neighbour_into(m, true, &lS);
+                    if (!std::equal(a.begin(), a.end(), lS.start) || !std::equal(b.begin(), b.end(), lS.end)) fatal("derived left neighbour differs from the bitmap walk");
+                }
+            } else {
+                neighbour_into(m, true, &lS);
             }
-            finish_region(lR, n);
-            if (check_derived) {       // test hook: the walk must give the same region
-                std::vector<long> a(lR.start, lR.start + n), b(lR.end, lR.end + n);
-                neighbour_into(m, true, &lR);
-                if (!std::equal(a.begin(), a.end(), lR.start) || !std::equal(b.begin(), b.end(), lR.end)) fatal("derived left neighbour differs from the bitmap walk");
-            }
-        } else {
-            neighbour_into(m, true, &lR);
+            keep(lS, &lRs[(size_t)i]);
+            neighbour_into(m, false, &rR);
+            keep(rR, &rRs[(size_t)i]);
         }
     }
     stats.t_neighbour += now_s() - tn;
     for (size_t i = 0; i < found.size(); i++) {
         const Region& lR = lRs[i];
-        if (lR.slength > prm.q && (i == 0 || !lR.same_as(rRs[i - 1], n))) regions.push_back(lR);
+        if (lR.start && (i == 0 || !rRs[i - 1].start || !lR.same_as(rRs[i - 1], n))) regions.push_back(lR);
         const Region& rR = rRs[i];
-        if (rR.slength > prm.q && !rR.same_as(lR, n)) regions.push_back(rR);
+        if (rR.start && (!lR.start || !rR.same_as(lR, n))) regions.push_back(rR);
     }
     stats.anchor_s = now_s() - t0;
     return m0 != 0;
