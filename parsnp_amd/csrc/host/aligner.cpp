@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <iostream>
 #include <omp.h>
 
@@ -124,11 +125,20 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
     gsize_.resize(n);
     for (size_t i = 0; i < n; i++) {
         if (genomes[i].seq.size() > (size_t)INT32_MAX - 64) fatal("genome longer than 2^31 bases: " + genomes[i].path);   // Mum rows are int32
-        layout[i].init(genomes[i].seq.size() + 1); gsize_[i] = (long)genomes[i].seq.size();
+        gsize_[i] = (long)genomes[i].seq.size();
     }
+    // 125 MB of bitmaps at 200 x 5 Mb; whether calloc hands out fresh zero pages or has to clear recycled heap is the
+    // allocator's choice (glibc raises its mmap threshold once blocks of this size have been freed), so the set-up runs
+    // beside the anchor call -- the host has nothing else to do while the engine searches -- and is awaited by the first
+    // reader of the layout (validate, or the end of find_anchors).
+    layout_ready_ = std::async(std::launch::async, [this] {
+        for (size_t i = 0; i < n; i++) layout[i].init(genomes[i].seq.size() + 1);
+    });
 }
+void Aligner::wait_layout() { if (layout_ready_.valid()) layout_ready_.get(); }
 
 Aligner::~Aligner() {
+    wait_layout();
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double t = now_s();
     auto lap = [&](const char* what) { if (dbg) { double u = now_s(); fprintf(stderr, "[release] %-10s %.4f s\n", what, u - t); t = u; } };
@@ -404,6 +414,7 @@ bool Aligner::settle(Mum& m, bool touches, bool any_reverse) const {
 
 // Candidate -> MUM, in candidate order (parsnp.cpp:1717-1841).
 void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted) {
+    wait_layout();
     const size_t ncand = raw.count;
     const int threads = prm.cores > 1 ? prm.cores : 1;
     static const size_t par_min = getenv("PARSNP_PARALLEL_MIN") ? (size_t)atol(getenv("PARSNP_PARALLEL_MIN")) : 4096;   // test hook
@@ -510,6 +521,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         if ((st & 3) != 3 || (st & 8)) continue;
         if (settle(cand[(size_t)c], false, (st & 4) != 0)) state[(size_t)c] |= 16;
     }
+    lap("settle");
 #pragma omp parallel for schedule(static, 1) num_threads(threads)
     for (int t = 0; t < nstripes; t++) {
         const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
@@ -517,7 +529,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             if ((state[c] & 24) == 16)
                 for (size_t j = j0; j < j1; j++) layout[j].set_range(cand[c].start[j], cand[c].end(j));
     }
-    lap("settle+mark");
+    lap("mark");
     // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them
     pool.reserve(pool.size() + ncand);
     accepted->reserve(accepted->size() + ncand);
@@ -581,6 +593,7 @@ bool Aligner::find_anchors() {
     std::cerr << std::endl << "        Constructing device index of the reference...\n";
     std::cerr << "        Performing initial search for exact matches in the sequences...\n";
     region_mums(whole, true, &found, false);
+    wait_layout();
     mums = found;
     m0 = (long)found.size();
     // seed regions: left and right neighbour of every anchor, longer than q in every genome (:2150-2172).  The layout

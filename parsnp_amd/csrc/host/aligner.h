@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <algorithm>
 #include <functional>
+#include <future>
 #include <map>
 #include <memory>
 #include <string>
@@ -252,7 +253,10 @@ public:
     void neighbour_into(const Mum& m, bool left, Region* out) const;   // rows of *out already allocated
     Region new_region();
 
+    void wait_layout();           // the layout bitmaps are set up in the background (constructor); find_anchors() awaits them
+
 private:
+    std::future<void> layout_ready_;
     pm_session* session_;
     long next_id_ = 1;
     std::unique_ptr<AlignerMemory> own_memory_;   // when the caller did not lend one
