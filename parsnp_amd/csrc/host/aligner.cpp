@@ -115,25 +115,24 @@ bool Region::same_as(const Region& o, size_t n) const {
 
 // ---------------------------------------------------------------------------------------------- Aligner
 Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, AlignerMemory* memory)
-    : n(g.size()), prm(p), genomes(g), session_(session), own_memory_(memory ? nullptr : new AlignerMemory),
-      memory_(memory ? memory : own_memory_.get()), rows_(memory_->rows), irows_(memory_->irows), brows_(memory_->brows), cache_rows_(memory_->cache_rows),
+    : own_memory_(memory ? nullptr : new AlignerMemory), memory_(memory ? memory : own_memory_.get()),
+      n(g.size()), prm(p), genomes(g), layout(memory_->layout), session_(session), rows_(memory_->rows), irows_(memory_->irows), brows_(memory_->brows), cache_rows_(memory_->cache_rows),
       req_rows_(memory_->req_rows) {
-    // the layout bitmaps are allocated afresh and zeroed by THIS thread: zeroing them with all threads (or recycling
-    // bitmaps cleared in parallel) saves 12 ms here and costs 17 ms later -- their pages end up spread over the NUMA nodes of
-    // the worker threads, away from the thread that does most of the walking (measured both ways at 200 x 5 Mb)
     layout.resize(n);
     gsize_.resize(n);
     for (size_t i = 0; i < n; i++) {
         if (genomes[i].seq.size() > (size_t)INT32_MAX - 64) fatal("genome longer than 2^31 bases: " + genomes[i].path);   // Mum rows are int32
         gsize_[i] = (long)genomes[i].seq.size();
     }
-    // 125 MB of bitmaps at 200 x 5 Mb; whether calloc hands out fresh zero pages or has to clear recycled heap is the
-    // allocator's choice (glibc raises its mmap threshold once blocks of this size have been freed), so the set-up runs
-    // beside the anchor call -- the host has nothing else to do while the engine searches -- and is awaited by the first
-    // reader of the layout (validate, or the end of find_anchors).
+    // 125 MB of bitmaps at 200 x 5 Mb.  Their storage stays mapped in the run's AlignerMemory (fresh pages cost a fault
+    // each when they are first marked, and giving them back costs as much again: 78 vs 61 ms per step), so a repeated
+    // run only has to clear them -- beside the anchor call, while the host has nothing else to do; the first reader of
+    // the layout (validate, or the end of find_anchors) awaits it.  One thread clears them, not all: pages first touched by
+    // the worker threads end up spread over their NUMA nodes, away from the thread that does most of the walking.
     layout_ready_ = std::async(std::launch::async, [this] {
         for (size_t i = 0; i < n; i++) layout[i].init(genomes[i].seq.size() + 1);
     });
+    if (getenv("PARSNP_SYNC_LAYOUT")) wait_layout();    // measurement switch: clear before anything else, as a plain constructor would
 }
 void Aligner::wait_layout() { if (layout_ready_.valid()) layout_ready_.get(); }
 
@@ -143,7 +142,6 @@ Aligner::~Aligner() {
     double t = now_s();
     auto lap = [&](const char* what) { if (dbg) { double u = now_s(); fprintf(stderr, "[release] %-10s %.4f s\n", what, u - t); t = u; } };
     cache_.clear(); lap("cache");
-    std::vector<Bitmap>().swap(layout); lap("layout");
     std::vector<Mum>().swap(pool); lap("pool");
     std::vector<Lcb>().swap(lcbs); lap("lcbs");
     own_memory_.reset(); lap("arenas");

@@ -216,6 +216,7 @@ struct AlignerMemory {
     Arena<long> rows, cache_rows, req_rows;
     Arena<int32_t> irows;                    // MUM start rows
     Arena<uint8_t> brows;                    // MUM strand rows
+    std::vector<Bitmap> layout;              // the run's mumlayout: storage kept mapped across runs, cleared per run
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
     std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
     struct PerThread { Arena<long> rows; Arena<int32_t> irows; Arena<uint8_t> brows; };
@@ -224,13 +225,15 @@ struct AlignerMemory {
 };
 
 class Aligner {
+    std::unique_ptr<AlignerMemory> own_memory_;   // when the caller did not lend one (declared first: `layout` refers into it)
+    AlignerMemory* memory_;
 public:
     Aligner(std::vector<Genome>& genomes, const Params& prm, pm_session* session, AlignerMemory* memory = nullptr);
     ~Aligner();
     size_t n;
     Params prm;
     std::vector<Genome>& genomes;
-    std::vector<Bitmap> layout;
+    std::vector<Bitmap>& layout;  // mumlayout; lives in the run's AlignerMemory
     std::vector<Mum> pool;        // every MUM ever accepted; `mums` and Lcb::mums index into it
     std::vector<int> mums;        // this->mums of the reference, in its order
     std::vector<Lcb> lcbs;        // this->clusters
@@ -259,8 +262,6 @@ private:
     std::future<void> layout_ready_;
     pm_session* session_;
     long next_id_ = 1;
-    std::unique_ptr<AlignerMemory> own_memory_;   // when the caller did not lend one
-    AlignerMemory* memory_;
     Arena<long>& rows_;      // region coordinate rows
     Arena<int32_t>& irows_;  // MUM start rows
     Arena<uint8_t>& brows_;  // MUM strand rows
