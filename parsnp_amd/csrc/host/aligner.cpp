@@ -1012,25 +1012,26 @@ bool Aligner::extend_generations() {
                 }
                 // children: left of the first new MUM, right of each, left of the next (:215-254); one that equals a region
                 // still waiting in this cluster is dropped, as the work list drops a region equal to one it holds
-                auto neighbour = [&](const Mum& mu, bool left) {
-                    Region k;
-                    k.start = tl.rows.alloc(n); k.end = tl.rows.alloc(n); k.length = tl.rows.alloc(n);
-                    neighbour_into(mu, left, &k);
-                    return k;
-                };
+                // (worked out in two scratch rows of the thread; only a child that is kept gets rows in the arena)
+                if (tl.scratch.size() < 6 * n) tl.scratch.resize(6 * n);
+                auto slot = [&](int k) { Region r; r.start = &tl.scratch[(size_t)k * 3 * n]; r.end = r.start + n; r.length = r.end + n; return r; };
+                Region lR = slot(0), rR = slot(1);
                 auto keep = [&](const Region& k) {
                     if (k.slength <= prm.q) return;
                     for (size_t y = x + 1; y < first[(size_t)cl + 1]; y++) if (now[y].same_as(k, n)) return;
-                    o.kids.push_back(k);
-                    if (pending_min < 0 || k.start[0] < pending_min) pending_min = k.start[0];
+                    Region c;
+                    c.start = tl.rows.alloc(n); c.end = tl.rows.alloc(n); c.length = tl.rows.alloc(n);
+                    memcpy(c.start, k.start, n * sizeof(long)); memcpy(c.end, k.end, n * sizeof(long)); memcpy(c.length, k.length, n * sizeof(long));
+                    c.slength = k.slength; c.llength = k.llength;
+                    o.kids.push_back(c);
+                    if (pending_min < 0 || c.start[0] < pending_min) pending_min = c.start[0];
                 };
-                Region lR, rR;
                 for (size_t i = 0; i < o.accepted.size(); i++) {
-                    if (i == 0) lR = neighbour(o.accepted[0], true);
-                    rR = neighbour(o.accepted[i], false);
+                    if (i == 0) neighbour_into(o.accepted[0], true, &lR);
+                    neighbour_into(o.accepted[i], false, &rR);
                     keep(lR);
                     keep(rR);
-                    if (i + 1 < o.accepted.size()) lR = neighbour(o.accepted[i + 1], true);
+                    if (i + 1 < o.accepted.size()) neighbour_into(o.accepted[i + 1], true, &lR);
                 }
             }
         }
