@@ -310,7 +310,17 @@ public:
             be.h2d(d_cbase.p, cbase.data(), 8 * ((size_t)nreg + 1));
             be.launch("coarse_index", centries, CoarseIndex{d_R.p, nreg, d_cbase.p, nq, skey, d_lo.p, lbits, d_coarse.p});
         }
-        be.launch("master_ep", ntiles, MasterEP{d_R.p, nreg, d_tilebase.p, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last});
+        {
+            // a batch with few tiles is cut until ~512 k threads are in flight (a recursion batch of 30 000 tiles: 16 slices,
+            // 1.35 -> 0.45 ms); the anchor call has 312 500 tiles at 5 Mb and is better off without the atomics (1.6 ms in
+            // one slice, 1.8 in four, 2.3 in eight -- measured, PM_EP_SPLIT forces a count)
+            static const int forced = getenv("PM_EP_SPLIT") ? atoi(getenv("PM_EP_SPLIT")) : 0;
+            const int gspan = std::max(g_last - g_first, 1);
+            int gsplit = forced > 0 ? forced : ntiles >= (1 << 17) ? 1 : (int)std::min<int64_t>(gspan, ((1 << 19) + ntiles - 1) / std::max<int64_t>(ntiles, 1));
+            gsplit = std::max(1, std::min(gsplit, gspan));
+            if (gsplit > 1) be.launch("ep_init", ntiles, EpInit{d_R.p, nreg, d_tilebase.p, d_epm.p});
+            be.launch("master_ep", ntiles * gsplit, MasterEP{d_R.p, nreg, d_tilebase.p, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, ntiles, gsplit});
+        }
         if (coll.world > 1 && npos > 0) {   // exchange 1: Master.EP = min over the ranks' genome blocks
             be.mark("exchange_ep");
             std::vector<int32_t> h((size_t)npos);

@@ -118,6 +118,13 @@ PM_HD void atomic_max32(int32_t* p, int32_t v) {
     if (v > *p) *p = v;
 #endif
 }
+PM_HD void atomic_min32(int32_t* p, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
 PM_HD void atomic_or32(uint32_t* p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicOr(p, v);
@@ -967,12 +974,27 @@ struct CoarseIndex {
         coarse[tid] = (int32_t)(x - a);
     }
 };
+// The genomes of a tile are a serial chain of dependent loads (pair bounds, coarse entry, probe, emax): ~200 x 6 memory
+// latencies per thread, and a recursion batch has only ~30 000 tiles -- a fraction of the 524 288 thread slots.  So the
+// genome loop is cut into `gsplit` slices, one thread each (tid = slice * ntiles + tile: a wavefront still walks
+// neighbouring tiles of one slice), and the slices meet in an atomic min on Master.EP, which EpInit has set to nR.
+struct EpInit {
+    const RegionInfo* R; int64_t nregions; const int64_t* tile_base; int32_t* epm;
+    PM_HD void operator()(int64_t tid) const {
+        int64_t r = upper_slot(tile_base, nregions, tid);
+        const RegionInfo& ri = R[r];
+        int32_t k0 = (int32_t)(tid - ri.tile_base) * kTile;
+        for (int t = 0; t < kTile; t++) if (k0 + t < ri.nR) epm[ri.posbase + k0 + t] = ri.nR;
+    }
+};
 struct MasterEP {
     const RegionInfo* R; int64_t nregions; const int64_t* tile_base;   // tile_base[nregions+1]
     int32_t ngen; const uint64_t* key; const int64_t* lo; const int32_t* emax; int lbits; int32_t* epm;
     const int64_t* cbase; const int32_t* coarse;
     int32_t g_first, g_last;   // sharded run: the min over the other genomes arrives by all-reduce
-    PM_HD void operator()(int64_t tid) const {
+    int64_t ntiles; int32_t gsplit;   // gsplit == 1: one thread per tile, plain stores
+    PM_HD void operator()(int64_t tid_all) const {
+        const int64_t slice = tid_all / ntiles, tid = tid_all - slice * ntiles;
         int64_t r = upper_slot(tile_base, nregions, tid);
         const RegionInfo& ri = R[r];
         int32_t k0 = (int32_t)(tid - ri.tile_base) * kTile;
@@ -981,7 +1003,9 @@ struct MasterEP {
         const uint64_t lmask = (1ull << lbits) - 1;
         const int64_t per = cbase[r + 1] - cbase[r];
         const int64_t cblock = k0 >> kCoarseShift;             // a tile of 16 positions lies inside one 1024-position block
-        for (int g = g_first - 1; g < g_last - 1; g++) {
+        const int gspan = g_last - g_first;
+        const int ga = g_first - 1 + (int)((int64_t)gspan * slice / gsplit), gb = g_first - 1 + (int)((int64_t)gspan * (slice + 1) / gsplit);
+        for (int g = ga; g < gb; g++) {
             int64_t pair = r * (ngen - 1) + g;
             const int64_t first = lo[pair], end = lo[pair + 1];
             const int32_t* cg = coarse + cbase[r] * (ngen - 1) + (int64_t)g * per + cblock;
@@ -997,7 +1021,8 @@ struct MasterEP {
                 if (cur < ep[t]) ep[t] = cur;
             }
         }
-        for (int t = 0; t < kTile; t++) if (k0 + t < ri.nR) epm[ri.posbase + k0 + t] = ep[t];
+        if (gsplit == 1) { for (int t = 0; t < kTile; t++) if (k0 + t < ri.nR) epm[ri.posbase + k0 + t] = ep[t]; }
+        else { for (int t = 0; t < kTile; t++) if (k0 + t < ri.nR && ep[t] < ri.nR) atomic_min32(&epm[ri.posbase + k0 + t], ep[t]); }
     }
 };
 
