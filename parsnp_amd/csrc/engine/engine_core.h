@@ -10,6 +10,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -149,13 +150,48 @@ public:
         int64_t npos = 0, ntiles = 0, tsize = 0, fwords = 0;
         int32_t max_nr = 1;
         size_t ev_guess = 1 << 16;     // first-call event buffer: a match of length >= minsize every max(8,minsize) bases is generous
+        // the request rows (2 x 8 bytes per region and genome: 26 MB for a recursion batch of 8 000 regions x 201) are
+        // checked and copied into a page-locked staging block by a few threads, and go to the device from there in one
+        // DMA each -- a copy out of the caller's pageable arrays is staged by the runtime at a fifth of the rate
+        const size_t nrow = (size_t)nreg * (size_t)ngen;
+        int64_t* stage = (int64_t*)be.staging(2 * nrow * sizeof(int64_t));
+        if (!stage) { error = "cannot allocate the request staging block"; return -3; }
+        std::vector<size_t> guess_r((size_t)nreg, 0);
+        {
+            const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, nreg / 512));
+            std::vector<int> bad((size_t)nt, 0);
+            auto part = [&](int t) {
+                const int64_t r0 = nreg * t / nt, r1 = nreg * (t + 1) / nt;
+                for (int64_t r = r0; r < r1; r++) {
+                    const int64_t* st = starts + r * ngen; const int64_t* ln = lens + r * ngen;
+                    const int div = std::max(8, minsize[r] < 1 ? 1 : minsize[r]);
+                    size_t gs = 0;
+                    int b = 0;
+                    for (int g = 0; g < ngen; g++) {
+                        if (st[g] < 0 || ln[g] < 0 || st[g] + ln[g] > glen_h[(size_t)g]) b |= 1;
+                        if (ln[g] >= (1ll << 31)) b |= 2;
+                        if (g) gs += (size_t)(2 * ln[g] / div);
+                    }
+                    guess_r[(size_t)r] = gs;
+                    bad[(size_t)t] |= b;
+                    memcpy(stage + r * ngen, st, sizeof(int64_t) * (size_t)ngen);
+                    memcpy(stage + nrow + r * ngen, ln, sizeof(int64_t) * (size_t)ngen);
+                }
+            };
+            if (nt == 1) part(0);
+            else {
+                std::vector<std::thread> th;
+                for (int t = 1; t < nt; t++) th.emplace_back(part, t);
+                part(0);
+                for (auto& x : th) x.join();
+            }
+            int b = 0;
+            for (int x : bad) b |= x;
+            if (b & 1) { error = "region outside its genome"; return -2; }
+            if (b & 2) { error = "region longer than 2^31"; return -5; }
+        }
         for (int64_t r = 0; r < nreg; r++) {
             RegionInfo& ri = R[(size_t)r];
-            for (int g = 0; g < ngen; g++) {
-                int64_t st = starts[r * ngen + g], ln = lens[r * ngen + g];
-                if (st < 0 || ln < 0 || st + ln > glen_h[(size_t)g]) { error = "region outside its genome"; return -2; }
-                if (ln >= (1ll << 31)) { error = "region longer than 2^31"; return -5; }
-            }
             ri.ref_pos = starts[r * ngen];
             ri.nR = (int32_t)lens[r * ngen];
             ri.minsize = minsize[r];
@@ -172,7 +208,7 @@ public:
             ri.posbase = npos; posbase[(size_t)r] = npos; npos += ri.nR;
             ri.tile_base = ntiles; tilebase[(size_t)r] = ntiles; ntiles += (ri.nR + kTile - 1) / kTile;
             max_nr = std::max(max_nr, ri.nR);
-            for (int g = 1; g < ngen; g++) ev_guess += (size_t)(2 * lens[r * ngen + g] / std::max(8, ri.minlen));
+            ev_guess += guess_r[(size_t)r];
         }
         posbase[(size_t)nreg] = npos; tilebase[(size_t)nreg] = ntiles;
         const int64_t npairs = nreg * nq;
@@ -185,8 +221,8 @@ public:
         ensure(d_starts, (size_t)(nreg * ngen)); ensure(d_lens, (size_t)(nreg * ngen));
         ensure(d_posbase, (size_t)nreg + 1); ensure(d_tilebase, (size_t)nreg + 1);
         be.h2d(d_R.p, R.data(), sizeof(RegionInfo) * (size_t)nreg);
-        be.h2d(d_starts.p, starts, sizeof(int64_t) * (size_t)(nreg * ngen));
-        be.h2d(d_lens.p, lens, sizeof(int64_t) * (size_t)(nreg * ngen));
+        be.h2d_staged(d_starts.p, stage, sizeof(int64_t) * nrow);
+        be.h2d_staged(d_lens.p, stage + nrow, sizeof(int64_t) * nrow);
         be.h2d(d_posbase.p, posbase.data(), sizeof(int64_t) * ((size_t)nreg + 1));
         be.h2d(d_tilebase.p, tilebase.data(), sizeof(int64_t) * ((size_t)nreg + 1));
         ensure(d_err, 1); be.memset(d_err.p, 0, 4);

@@ -41,6 +41,7 @@ struct HipBackend {
         for (auto& m : marks) pool.push_back(m.second);
         for (auto e : pool) (void)hipEventDestroy(e);
         if (tmp) (void)hipFree(tmp);
+        if (stage_p) (void)hipHostFree(stage_p);
         if (stream) (void)hipStreamDestroy(stream);
     }
     void* alloc(size_t n) { void* p = nullptr; if (!check(hipMalloc(&p, n ? n : 1), "hipMalloc")) return nullptr; return p; }
@@ -59,6 +60,19 @@ struct HipBackend {
     void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync"); }
     void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); check(hipStreamSynchronize(stream), "sync"); }
     void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+    // page-locked block for the request rows of a call (kept, grown on demand); h2d_staged queues the DMA without waiting:
+    // the block is not written again before the call's last synchronisation
+    void* stage_p = nullptr; size_t stage_cap = 0;
+    void* staging(size_t n) {
+        if (n > stage_cap) {
+            if (stage_p) (void)hipHostFree(stage_p);
+            stage_p = nullptr; stage_cap = 0;
+            if (!check(hipHostMalloc(&stage_p, n + n / 4 + 4096, hipHostMallocDefault), "hipHostMalloc(staging)")) return nullptr;
+            stage_cap = n + n / 4 + 4096;
+        }
+        return stage_p;
+    }
+    void h2d_staged(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D (staged)"); }
 
     template <class F> void launch(const char* name, int64_t n, F f) {
         if (n <= 0) return;
