@@ -476,6 +476,8 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             std::vector<long> maxend_l(j1 - j0 + 16, -1), minstart_l(j1 - j0 + 16, (long)1 << 62);   // per stripe: no cache line shared with a neighbour
             long* maxend = maxend_l.data() + 8 - j0; long* minstart = minstart_l.data() + 8 - j0;
             for (size_t c = 0; c < ncand; c++) {
+                // a stripe reads a few entries of every row, 4 n bytes apart: no hardware prefetcher follows that
+                __builtin_prefetch(srow + (c + 24) * n + j0); __builtin_prefetch(srow + (c + 24) * n + j1 - 1);
                 if ((state[c] & 3) != 3 || cand[c].length < 5) continue;        // never marks anything
                 const int32_t* st = cand[c].start; const long lon = cand[c].length;
                 bool hit = false;
@@ -523,9 +525,12 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
 #pragma omp parallel for schedule(static, 1) num_threads(threads)
     for (int t = 0; t < nstripes; t++) {
         const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
-        for (size_t c = 0; c < ncand; c++)
+        for (size_t c = 0; c < ncand; c++) {
+            __builtin_prefetch(srow + (c + 24) * n + j0); __builtin_prefetch(srow + (c + 24) * n + j1 - 1);
             if ((state[c] & 24) == 16)
-                for (size_t j = j0; j < j1; j++) layout[j].set_range(cand[c].start[j], cand[c].end(j));
+                { const int32_t* st = cand[c].start; const long lon = cand[c].length;     // accepted: inside the genome, length >= 5
+                  for (size_t j = j0; j < j1; j++) layout[j].set_range_inside(st[j], (long)st[j] + lon); }
+        }
     }
     lap("mark");
     // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them

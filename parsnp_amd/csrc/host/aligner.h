@@ -84,6 +84,16 @@ public:
         } else set_range_slow(a, b);
     }
     void set_range_slow(long a, long b);
+    // [a,b) := 1 for a range known to lie inside the bitmap, no undo log active (the bulk marking of validate_parallel)
+    void set_range_inside(long a, long b) {
+        uint64_t* w = w_.data();
+        const size_t wa = (size_t)a >> 6, wb = (size_t)(b - 1) >> 6;
+        const uint64_t first = ~0ull << (a & 63), last = ~0ull >> (63 - ((b - 1) & 63));
+        if (wa == wb) { w[wa] |= first & last; return; }
+        w[wa] |= first;
+        for (size_t i = wa + 1; i < wb; i++) w[i] = ~0ull;
+        w[wb] |= last;
+    }
     void set_range_atomic(long a, long b);   // [a,b) := 1 with atomic word updates: threads marking neighbouring ranges may share a word
     void clear_range(long a, long b);   // [a,b) := 0
     long next_set(long from) const;     // smallest i >= from with bit set; the sentinel guarantees one for from <= n
