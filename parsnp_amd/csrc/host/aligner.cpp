@@ -536,17 +536,62 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them
     pool.reserve(pool.size() + ncand);
     accepted->reserve(accepted->size() + ncand);
-    // the flagged candidates read two words per genome that another core has just written: requested two candidates ahead
-    std::vector<uint32_t> ordered;
+    std::vector<uint32_t> ordered;        // the flagged candidates, in candidate order
     for (size_t c = 0; c < ncand; c++) if ((state[c] & 11) == 11) ordered.push_back((uint32_t)c);
+    // Two flagged candidates whose ranges meet in no genome read and write different bits: they commute.  A flagged
+    // candidate that meets NO other flagged candidate ("free") is settled by any thread, marks atomic; only the tangled
+    // rest -- runs of candidates overlapping each other -- keeps the candidate order.  Per genome the test is exact:
+    // intervals sorted by start, one overlaps an earlier one iff it starts before the running maximum end; it and the
+    // holder of that maximum are tangled (every member of an overlapping pair is caught as one or the other).
+    const size_t nord = ordered.size();
+    std::vector<uint8_t> tangled(nord, 1), settled(nord, 0);
+    static const bool no_free = getenv("PARSNP_ORDERED_FLAGGED") != nullptr;     // test hook: everything flagged stays ordered
+    static const size_t free_min = getenv("PARSNP_FREE_MIN") ? (size_t)atol(getenv("PARSNP_FREE_MIN")) : 32;   // test hook
+    if (nord >= free_min && !no_free) {
+        std::fill(tangled.begin(), tangled.end(), 0);
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+        for (int t = 0; t < nstripes; t++) {
+            const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
+            std::vector<std::pair<long, uint32_t>> iv(nord);
+            for (size_t j = j0; j < j1; j++) {
+                for (size_t o = 0; o < nord; o++) iv[o] = std::make_pair((long)cand[ordered[o]].start[j], (uint32_t)o);
+                std::sort(iv.begin(), iv.end());
+                long maxend = -1; uint32_t holder = 0;
+                for (size_t x = 0; x < nord; x++) {
+                    const uint32_t o = iv[x].second;
+                    const long a = iv[x].first, b = a + cand[ordered[o]].length;
+                    if (a < maxend) { __atomic_store_n(&tangled[o], (uint8_t)1, __ATOMIC_RELAXED); __atomic_store_n(&tangled[holder], (uint8_t)1, __ATOMIC_RELAXED); }
+                    if (b > maxend) { maxend = b; holder = o; }
+                }
+            }
+        }
+        const long no = (long)nord;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+        for (long o = 0; o < no; o++) {
+            if (tangled[(size_t)o]) continue;
+            Mum& m = cand[ordered[(size_t)o]];
+            bool touches = false;
+            if (m.length > 0)
+                for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end(j) - 1);
+            if (settle(m, touches, (state[ordered[(size_t)o]] & 4) != 0)) {
+                for (size_t j = 0; j < n; j++) layout[j].set_range_atomic(m.start[j], m.end(j));
+                settled[(size_t)o] = 1;
+            }
+        }
+    }
+    lap("free");
+    // what is left reads two words per genome that another core has just written: requested two candidates ahead
+    std::vector<uint32_t> left;
+    for (size_t o = 0; o < nord; o++) if (tangled[o]) left.push_back(ordered[o]);
+    if (dbg) fprintf(stderr, "[validate_parallel] %zu flagged, %zu of them tangled\n", nord, left.size());
     auto warm = [&](size_t o) {
-        if (o >= ordered.size()) return;
-        const Mum& w = cand[ordered[o]];
+        if (o >= left.size()) return;
+        const Mum& w = cand[left[o]];
         if (w.length <= 0) return;
         for (size_t j = 0; j < n; j++) { layout[j].prefetch(w.start[j]); layout[j].prefetch(w.end(j) - 1); }
     };
     warm(0); warm(1);
-    size_t onext = 0;
+    size_t onext = 0, oi = 0;
     for (size_t c = 0; c < ncand; c++) {
         const uint8_t st = state[c];
         if (!(st & 1)) continue;
@@ -554,12 +599,17 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         m.id = next_id_++;
         bool acc = (st & 16) != 0;
         if ((st & 2) && (st & 8)) {
-            warm(++onext + 1);
-            bool touches = false;
-            if (m.length > 0)
-                for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end(j) - 1);
-            acc = settle(m, touches, (st & 4) != 0);
-            if (acc) for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end(j));
+            const size_t o = oi++;                 // position in `ordered`
+            if (!tangled[o]) acc = settled[o] != 0;
+            else {
+                warm(++onext + 1);
+                bool touches = false;
+                if (m.length > 0)
+                    for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end(j) - 1);
+                acc = settle(m, touches, (st & 4) != 0);
+                if (acc) for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end(j));
+                stats.parallel_tangled++;
+            }
         }
         if (!acc) continue;
         m.slength = r.slength;

@@ -216,7 +216,7 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
     long generations = 0, generation_regions = 0, generation_handover = -1;   // parallel generations, regions in them, generation at which the in-order replay took over (-1: never)
     long generation_restarts = 0;   // generation-parallel extension abandoned after its second generation (see extend_generations)
-    long tie_fallbacks = 0, literal_iterations = 0, parallel_candidates = 0, parallel_dirty = 0;   // work-list ties between different regions (extend_pass)
+    long tie_fallbacks = 0, literal_iterations = 0, parallel_candidates = 0, parallel_dirty = 0, parallel_tangled = 0;   // work-list ties between different regions (extend_pass)
     double t_validate = 0, t_neighbour = 0, t_key = 0, t_sweep = 0, t_replay = 0, t_sort = 0, t_unpack = 0;   // host split
 };
 

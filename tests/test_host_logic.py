@@ -135,7 +135,7 @@ def test_threaded_validation_same_result(cpu_checkers, tmp_path, name, par_min):
     PARSNP_PARALLEL_MIN lowers the list-length threshold so that small sets (and the recursion's short lists) use it too."""
     rp, qs, kw = harsh_inputs(name, str(tmp_path))
     out = str(tmp_path / "out")
-    env = dict(os.environ)
+    env = dict(os.environ, PARSNP_FREE_MIN="2")     # flagged candidates that meet no other flagged one are settled in parallel
     if par_min:
         env["PARSNP_PARALLEL_MIN"] = par_min
     rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, threads=4, timing=str(tmp_path / "t.json"), **kw)
