@@ -169,6 +169,33 @@ void Aligner::neighbour_into(const Mum& m, bool left, Region* out) const {
     }
     finish_region(*out, n);
 }
+// neighbour_into for a caller that only wants regions longer than q in every genome (:2158-2170, :233-238 drop the
+// others unseen): gives up at the first genome that is not, returning false with the genome, the length there and the
+// position at which the walk stopped.  Between anchors of a population sample most gaps are a single base: one genome
+// looked at instead of all of them.
+bool Aligner::neighbour_if_longer(const Mum& m, bool left, long q, Region* out, long* short_j, long* short_len, long* short_stop) const {
+    long* start = out->start; long* end = out->end; long* length = out->length;
+    long s = 500000000, l = 0;
+    for (size_t i = 0; i < n; i++) {
+        long a, b, stop;
+        if (left) {
+            long p = layout[i].prev_set((long)m.start[i] - 1);
+            if (p < 0) p = 0;
+            a = p + 1; b = (long)m.start[i] - 1; stop = p;
+        } else {
+            const long nxt = m.end(i) + 1, size = (long)genomes[i].seq.size();
+            const long p = nxt >= size ? nxt : layout[i].next_set(nxt);
+            a = nxt; b = p - 1; stop = p;
+        }
+        const long len = b - a;
+        if (len <= q) { *short_j = (long)i; *short_len = len; *short_stop = stop; return false; }
+        start[i] = a; end[i] = b; length[i] = len;
+        if (len < s) s = len;
+        if (len > l) l = len;
+    }
+    out->slength = s; out->llength = l;
+    return true;
+}
 Region Aligner::neighbour_region(const Mum& m, bool left) {
     struct Tm { double t0; double* acc; ~Tm() { *acc += now_s() - t0; } } tm{now_s(), &stats.t_neighbour};
     Region r = new_region();
@@ -679,32 +706,47 @@ bool Aligner::find_anchors() {
             r.slength = s.slength; r.llength = s.llength;
             *out = r;
         };
+        // what is known about the right neighbour of the previous anchor of this run: its rows (kept), or a genome in
+        // which it was shorter than q and where its walk stopped.  If it stopped at THIS anchor there, the left neighbour
+        // of this anchor spans the same gap plus at most the base before it: not longer than q either.
+        bool have_pr = false;
+        long drop_j = -1, drop_stop = 0;
+        long sj = 0, sl = 0, sp = 0;
+        auto checked = [&](const Mum& m, bool left, bool kept, const Region& got) {      // test hook: the full walk must agree
+            std::vector<long> b(3 * n);
+            Region f; f.start = b.data(); f.end = f.start + n; f.length = f.end + n;
+            neighbour_into(m, left, &f);
+            if ((f.slength > q) != kept) fatal("seed region kept/dropped differently from the full bitmap walk");
+            if (kept && (!std::equal(f.start, f.start + n, got.start) || !std::equal(f.end, f.end + n, got.end) || f.slength != got.slength || f.llength != got.llength))
+                fatal("seed region differs from the full bitmap walk");
+        };
         for (long i = i0; i < i1; i++) {
             const Mum& m = pool[(size_t)found[(size_t)i]];
-            Region& pr = rS[(i - i0 + 1) & 1];       // right neighbour of the previous anchor of this run
+            Region& pr = rS[(i - i0 + 1) & 1];       // right neighbour of the previous anchor of this run (valid when have_pr)
             Region& rR = rS[(i - i0) & 1];
-            bool derived = i > i0;
-            if (derived)
+            bool l_kept = false, l_done = false;
+            if (i > i0 && drop_j >= 0 && drop_stop == (long)m.start[(size_t)drop_j]) l_done = true;
+            else if (i > i0 && have_pr) {
+                bool derived = true;
                 for (size_t j = 0; j < n; j++) if (pr.end[j] + 1 != (long)m.start[j]) { derived = false; break; }
-            if (derived) {
-                const Mum& pm = pool[(size_t)found[(size_t)i - 1]];
-                for (size_t j = 0; j < n; j++) {
-                    const long e = pm.end(j);
-                    lS.start[j] = layout[j].get(e) ? e + 1 : e;
-                    lS.end[j] = (long)m.start[j] - 1;
+                if (derived) {
+                    const Mum& pm = pool[(size_t)found[(size_t)i - 1]];
+                    for (size_t j = 0; j < n; j++) {
+                        const long e = pm.end(j);
+                        lS.start[j] = layout[j].get(e) ? e + 1 : e;
+                        lS.end[j] = (long)m.start[j] - 1;
+                    }
+                    finish_region(lS, n);
+                    l_kept = lS.slength > q; l_done = true;
                 }
-                finish_region(lS, n);
-                if (check_derived) {       // test hook: the walk must give the same region
-                    std::vector<long> a(lS.start, lS.start + n), b(lS.end, lS.end + n);
-                    neighbour_into(m, true, &lS);
-                    if (!std::equal(a.begin(), a.end(), lS.start) || !std::equal(b.begin(), b.end(), lS.end)) fatal("derived left neighbour differs from the bitmap walk");
-                }
-            } else {
-                neighbour_into(m, true, &lS);
             }
-            keep(lS, &lRs[(size_t)i]);
-            neighbour_into(m, false, &rR);
-            keep(rR, &rRs[(size_t)i]);
+            if (!l_done) l_kept = neighbour_if_longer(m, true, q, &lS, &sj, &sl, &sp);
+            if (check_derived) checked(m, true, l_kept, lS);
+            if (l_kept) keep(lS, &lRs[(size_t)i]);
+            have_pr = neighbour_if_longer(m, false, q, &rR, &sj, &sl, &sp);
+            drop_j = (!have_pr && sl <= q - 1) ? sj : -1; drop_stop = sp;
+            if (check_derived) checked(m, false, have_pr, rR);
+            if (have_pr) keep(rR, &rRs[(size_t)i]);
         }
     }
     stats.t_neighbour += now_s() - tn;
@@ -1081,12 +1123,14 @@ bool Aligner::extend_generations() {
                     o.kids.push_back(c);
                     if (pending_min < 0 || c.start[0] < pending_min) pending_min = c.start[0];
                 };
+                long sj, sl, sp;
+                bool lok = false;
                 for (size_t i = 0; i < o.accepted.size(); i++) {
-                    if (i == 0) neighbour_into(o.accepted[0], true, &lR);
-                    neighbour_into(o.accepted[i], false, &rR);
-                    keep(lR);
-                    keep(rR);
-                    if (i + 1 < o.accepted.size()) neighbour_into(o.accepted[i + 1], true, &lR);
+                    if (i == 0) lok = neighbour_if_longer(o.accepted[0], true, prm.q, &lR, &sj, &sl, &sp);
+                    const bool rok = neighbour_if_longer(o.accepted[i], false, prm.q, &rR, &sj, &sl, &sp);
+                    if (lok) keep(lR);
+                    if (rok) keep(rR);
+                    if (i + 1 < o.accepted.size()) lok = neighbour_if_longer(o.accepted[i + 1], true, prm.q, &lR, &sj, &sl, &sp);
                 }
             }
         }

@@ -264,6 +264,7 @@ public:
 
     Region neighbour_region(const Mum& m, bool left);
     void neighbour_into(const Mum& m, bool left, Region* out) const;   // rows of *out already allocated
+    bool neighbour_if_longer(const Mum& m, bool left, long q, Region* out, long* short_j, long* short_len, long* short_stop) const;
     Region new_region();
 
     void wait_layout();           // the layout bitmaps are set up in the background (constructor); find_anchors() awaits them
