@@ -1177,7 +1177,27 @@ void Aligner::filter_mums(int rvalue) {
     {
         std::vector<Handle> h(mums.size());
         for (size_t i = 0; i < mums.size(); i++) h[i] = Handle{pool[(size_t)mums[i]].start[0], mums[i]};
-        std::sort(h.begin(), h.end());
+        // the list is the anchors followed by the MUMs of the recursion, each in reference order: two increasing runs.
+        // With all keys different there is one sorted order and a merge finds it; with equal keys the order std::sort
+        // leaves is the reference's (sort( mums ) :338), so it runs on the list as it stands.
+        size_t cut = 1;
+        while (cut < h.size() && h[cut - 1].key < h[cut].key) cut++;
+        bool merged = cut < h.size();
+        for (size_t i = cut + 1; i < h.size() && merged; i++) merged = h[i - 1].key < h[i].key;
+        if (merged) {
+            std::vector<Handle> out(h.size());
+            size_t a = 0, b = cut, o = 0;
+            while (a < cut && b < h.size()) {
+                if (h[a].key == h[b].key) { merged = false; break; }
+                out[o++] = h[a].key < h[b].key ? h[a++] : h[b++];
+            }
+            if (merged) {
+                while (a < cut) out[o++] = h[a++];
+                while (b < h.size()) out[o++] = h[b++];
+                h.swap(out);
+            }
+        }
+        if (!merged && cut < h.size()) std::sort(h.begin(), h.end());
         for (size_t i = 0; i < mums.size(); i++) mums[i] = h[i].idx;
     }
     long numums = (long)mums.size();
@@ -1262,9 +1282,16 @@ void Aligner::chain() {
     };
     // almost always the chain's last MUM is the previous MUM of the list: those verdicts are independent, computed ahead
     const long m = (long)mums.size();
+    // (a verdict depends on the two MUMs alone: the second chaining pass, after a few LCBs were dissolved, reuses the
+    // verdicts of every MUM whose predecessor is still the same)
     std::vector<uint8_t> ahead((size_t)m, CLOSE);
+    if (judged_pred_.size() < pool.size()) { judged_pred_.assign(pool.size(), -1); judged_verdict_.assign(pool.size(), CLOSE); }
 #pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 4096)
-    for (long x = 1; x < m; x++) ahead[(size_t)x] = judge(pool[(size_t)mums[(size_t)x]], pool[(size_t)mums[(size_t)x - 1]]);
+    for (long x = 1; x < m; x++) {
+        const int cur = mums[(size_t)x], prev = mums[(size_t)x - 1];
+        if (judged_pred_[(size_t)cur] != prev) { judged_verdict_[(size_t)cur] = judge(pool[(size_t)cur], pool[(size_t)prev]); judged_pred_[(size_t)cur] = prev; }
+        ahead[(size_t)x] = judged_verdict_[(size_t)cur];
+    }
 
     auto open_chain = [&](int idx) { Lcb c; c.type = 1; c.mums.push_back(idx); c.length = pool[(size_t)idx].length; return c; };
     auto close_chain = [&](Lcb& c) {      // start of the first MUM, end of the last (Cluster(TMum) LCB.cpp:21-28 + the joins)

@@ -271,6 +271,8 @@ public:
 
 private:
     std::future<void> layout_ready_;
+    std::vector<int> judged_pred_;            // chain(): predecessor against which a MUM was last judged, and the verdict
+    std::vector<uint8_t> judged_verdict_;
     pm_session* session_;
     long next_id_ = 1;
     Arena<long>& rows_;      // region coordinate rows
