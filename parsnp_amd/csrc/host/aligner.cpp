@@ -127,14 +127,17 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
     // 125 MB of bitmaps at 200 x 5 Mb.  Their storage stays mapped in the run's AlignerMemory (fresh pages cost a fault
     // each when they are first marked, and giving them back costs as much again: 78 vs 61 ms per step), so a repeated
     // run only has to clear them -- beside the anchor call, while the host has nothing else to do; the first reader of
-    // the layout (validate, or the end of find_anchors) awaits it.  One thread clears them, not all: pages first touched by
-    // the worker threads end up spread over their NUMA nodes, away from the thread that does most of the walking.
-    layout_ready_ = std::async(std::launch::async, [this] {
-        for (size_t i = 0; i < n; i++) layout[i].init(genomes[i].seq.size() + 1);
-    });
+    // the layout (validate, or the end of find_anchors) awaits it.
+    // (a few threads, not one: one core clears ~10 GB/s and would still be at it when the 11 ms anchor call returns;
+    // not all: pages first touched by the worker threads can end up away from the thread that does most of the walking)
+    const size_t parts = std::min<size_t>(4, std::max<size_t>(1, n / 8));
+    for (size_t k = 0; k < parts; k++)
+        layout_ready_.push_back(std::async(std::launch::async, [this, k, parts] {
+            for (size_t i = n * k / parts; i < n * (k + 1) / parts; i++) layout[i].init(genomes[i].seq.size() + 1);
+        }));
     if (getenv("PARSNP_SYNC_LAYOUT")) wait_layout();    // measurement switch: clear before anything else, as a plain constructor would
 }
-void Aligner::wait_layout() { if (layout_ready_.valid()) layout_ready_.get(); }
+void Aligner::wait_layout() { for (auto& f : layout_ready_) f.get(); layout_ready_.clear(); }
 
 Aligner::~Aligner() {
     wait_layout();
@@ -998,21 +1001,40 @@ bool Aligner::extend_generations() {
     // raws for gen[i], -1 = not fetched yet.  A hand-over to the in-order replay files them into its cache first.
     std::vector<Raw> raws;
     std::vector<int> gen_raw(gen.size(), -1);
-    auto plain_request = [&](const Region& r, Request* q) {       // the region as ONE engine request, if it is one
+    auto plain_shape = [&](const Region& r) {                    // the region is ONE engine request (rows only: any thread)
         const long len0 = r.length[0];
         if (len0 <= 0 || prm.p < len0) return false;              // chunked reference (p): chunk_requests' business
         for (size_t g = 0; g < n; g++)
             if (r.start[g] < 0 || r.length[g] < 0 || r.start[g] + r.length[g] > gsize_[g]) return false;
+        return true;
+    };
+    auto plain_request = [&](const Region& r, Request* q) {
+        if (!plain_shape(r)) return false;
         *q = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0};
         return true;
     };
+    // the same for a list: the row checks (8 000 regions x 201 genomes per generation) by all threads, the minimum
+    // lengths (memoised per slength) by this one
+    auto plain_requests = [&](const std::vector<Region>& rs, const std::vector<int>* skip, std::vector<Request>* out) {
+        const long m = (long)rs.size();
+        std::vector<uint8_t> ok((size_t)m, 1);
+#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 256)
+        for (long i = 0; i < m; i++) if (!skip || (*skip)[(size_t)i] < 0) ok[(size_t)i] = plain_shape(rs[(size_t)i]) ? 1 : 0;
+        out->assign((size_t)m, Request{nullptr, nullptr, 0, 0, 0});
+        for (long i = 0; i < m; i++) {
+            if (skip && (*skip)[(size_t)i] >= 0) continue;
+            if (!ok[(size_t)i]) return false;
+            const Region& r = rs[(size_t)i];
+            (*out)[(size_t)i] = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0};
+        }
+        return true;
+    };
     auto fetch = [&](const std::vector<Region>& rs, std::vector<int>* raw_of) {      // one engine call for the regions without a result
-        std::vector<Request> want; std::vector<size_t> who;
+        std::vector<Request> want, all; std::vector<size_t> who;
+        if (!plain_requests(rs, raw_of, &all)) return false;
         for (size_t i = 0; i < rs.size(); i++) {
             if ((*raw_of)[i] >= 0) continue;
-            Request q;
-            if (!plain_request(rs[i], &q)) return false;
-            want.push_back(q); who.push_back(i);
+            want.push_back(all[i]); who.push_back(i);
         }
         if (want.empty()) return true;
         std::vector<Raw> got;
@@ -1064,8 +1086,8 @@ bool Aligner::extend_generations() {
             if (!trouble) trouble = !fetch(now, &now_raw);       // children: one more call (usually nothing to fetch)
         }
         lap("sort+fetch");
-        std::vector<Request> req(now.size());
-        for (size_t i = 0; i < now.size() && !trouble; i++) if (!plain_request(now[i], &req[i])) trouble = true;
+        std::vector<Request> req;
+        if (!trouble && !plain_requests(now, nullptr, &req)) trouble = true;
         if (trouble) {
             stats.generation_handover = gi;
             file_into_cache(gen, gen_raw);

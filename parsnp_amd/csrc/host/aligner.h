@@ -270,7 +270,7 @@ public:
     void wait_layout();           // the layout bitmaps are set up in the background (constructor); find_anchors() awaits them
 
 private:
-    std::future<void> layout_ready_;
+    std::vector<std::future<void>> layout_ready_;
     std::vector<int> judged_pred_;            // chain(): predecessor against which a MUM was last judged, and the verdict
     std::vector<uint8_t> judged_verdict_;
     pm_session* session_;
