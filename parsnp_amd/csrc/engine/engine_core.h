@@ -386,7 +386,7 @@ public:
         ensure(d_at, (size_t)ncand * (size_t)nq);
         ensure(d_ok, (size_t)ncand); ensure(d_ok_k, (size_t)ncand); ensure(d_ok_lon, (size_t)ncand);
         ensure(d_osp, (size_t)ncand * (size_t)nq); ensure(d_ofwd, (size_t)ncand * (size_t)nq);
-        be.launch("state_at_candidate", (int64_t)ncand * nq, StateAtCandidate{d_R.p, scand, ngen, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_at.p});
+        be.launch("state_at_candidate", (int64_t)ncand * nq, StateAtCandidate{d_R.p, scand, ngen, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_at.p, d_cbase.p, d_coarse.p});
         if (coll.world > 1) {   // exchange 2: every rank contributes the (EP,UP,SP) columns of its genome block
             be.mark("exchange_states");
             const size_t nqz = (size_t)nq, cz = (size_t)ncand;

@@ -1053,12 +1053,15 @@ struct GenomeAtK { int32_t epf, upf, spf, epr, upr, spr; };
 struct StateAtCandidate {
     const RegionInfo* R; const uint64_t* cand; int32_t ngen; const uint64_t* key; const uint64_t* val; const int64_t* lo;
     const EventState* st; const int32_t* rep; int lbits; GenomeAtK* out;
+    const int64_t* cbase; const int32_t* coarse;      // CoarseIndex: the probe runs over the events of k's 1024-position block
     PM_HD void operator()(int64_t tid) const {
         int64_t c = tid / (ngen - 1); int g = (int)(tid % (ngen - 1));
         int64_t r = (int64_t)(cand[c] >> 32); int32_t k = (int32_t)(cand[c] & 0xffffffffu);
         const RegionInfo& ri = R[r];
         int64_t pair = r * (ngen - 1) + g;
-        int64_t a = lo[pair], b = lo[pair + 1];
+        const int64_t per = cbase[r + 1] - cbase[r];
+        const int32_t* cg = coarse + cbase[r] * (ngen - 1) + (int64_t)g * per + (k >> kCoarseShift);
+        int64_t a = lo[pair] + cg[0], b = lo[pair] + cg[1];
         uint64_t want = ((((uint64_t)pair << lbits) | (uint64_t)k) << 1) | 1ull;
         while (a < b) { int64_t mid = (a + b) >> 1; if (key[mid] <= want) a = mid + 1; else b = mid; }
         GenomeAtK o{0, 0, 0, 0, 0, 0};

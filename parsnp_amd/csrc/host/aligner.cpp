@@ -137,7 +137,13 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
         }));
     if (getenv("PARSNP_SYNC_LAYOUT")) wait_layout();    // measurement switch: clear before anything else, as a plain constructor would
 }
-void Aligner::wait_layout() { for (auto& f : layout_ready_) f.get(); layout_ready_.clear(); }
+void Aligner::wait_layout() {
+    if (layout_ready_.empty()) return;
+    const double t = now_s();
+    for (auto& f : layout_ready_) f.get();
+    layout_ready_.clear();
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[setup] waited %.4f s for the layout to be cleared\n", now_s() - t);
+}
 
 Aligner::~Aligner() {
     wait_layout();
