@@ -104,6 +104,22 @@ def test_in_order_replay_same_result(cpu_checkers, tmp_path, name, threads):
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"], tag
 
 
+@pytest.mark.parametrize("switch", ["PARSNP_ORDERED_FLAGGED", "PARSNP_CHAIN_TWICE", "PARSNP_SYNC_LAYOUT", "PARSNP_EXACT_OVERLAP"])
+@pytest.mark.parametrize("name", ["poprearr10x400k", "draft8x300k"])
+def test_plain_variants_of_the_host_shortcuts(cpu_checkers, tmp_path, name, switch):
+    """every host shortcut has a switch that takes the plain route instead -- flagged candidates all in candidate order,
+    the second chaining pass always run, the layout cleared before anything else, the overlap flags from scratch
+    bitmaps -- and the bytes must not change (the default route is pinned by the goldens in the other tests)"""
+    rp, qs, kw = harsh_inputs(name, str(tmp_path))
+    out = str(tmp_path / "out")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2")
+    env[switch] = "1"
+    rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, threads=4, **kw)
+    assert rc == 0
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
+
+
 @pytest.mark.parametrize("name", ["pop6x200k", "poprearr10x400k", "messy", "draft8x300k"])
 def test_derived_left_neighbours_equal_the_walk(cpu_checkers, tmp_path, name):
     """the seed regions left of an anchor are derived from the walk right of the previous anchor where that walk ended
