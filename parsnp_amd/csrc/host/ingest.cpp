@@ -2,7 +2,6 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
-#include <fstream>
 #include <iostream>
 #include <sstream>
 
@@ -40,15 +39,27 @@ bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* g
     g->path = path;
     size_t slash = path.rfind('/');
     g->fname = slash == std::string::npos ? path : path.substr(slash + 1);
-    std::ifstream f(path.c_str(), std::ios::binary);
+    FILE* f = fopen(path.c_str(), "rb");
     if (!f) {
         if (is_ref) con << " Cannot open reference file ! " << std::endl;
         else con << " Cannot open query file: " << path << std::endl;
         *console = con.str();
         return false;
     }
-    std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    f.close();
+    std::string data;
+    {   // the whole file in one read (a stream iterator costs more per byte than the parse below)
+        struct Close { FILE* f; ~Close() { fclose(f); } } closer{f};
+        long size = (fseek(f, 0, SEEK_END) == 0) ? ftell(f) : -1;
+        if (size >= 0 && fseek(f, 0, SEEK_SET) == 0) {
+            data.resize((size_t)size);
+            size_t got = size ? fread(&data[0], 1, (size_t)size, f) : 0;
+            data.resize(got);
+        } else {            // not seekable: read in pieces
+            char buf[1 << 16];
+            size_t got;
+            while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);
+        }
+    }
 
     const size_t kLine = 2499;   // getline(buf, 2500): at most 2499 bytes, longer lines put the stream in fail state
     size_t pos = 0;
@@ -65,31 +76,45 @@ bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* g
     g->pos2hdr.clear();
     g->pos2hdr[1] = "s1";
 
-    long long a = 0, c = 0, gg = 0, t = 0, nn = 0;
+    // what a byte appends (0: nothing) and which counter it feeds; headers are the only bytes that need more than that
+    unsigned char emit[256]; uint8_t cls[256];
+    for (int ch = 0; ch < 256; ch++) {
+        cls[ch] = kTable.act[ch];
+        switch (kTable.act[ch]) {
+            case BASE_A: emit[ch] = reverse ? 'T' : 'A'; break;
+            case BASE_C: emit[ch] = reverse ? 'G' : 'C'; break;
+            case BASE_G: emit[ch] = reverse ? 'C' : 'G'; break;
+            case BASE_T: emit[ch] = reverse ? 'A' : 'T'; break;
+            case BASE_U: emit[ch] = 'T'; break;                 // not complemented (parsnp.cpp:3066-3069)
+            case BASE_N: emit[ch] = 'N'; break;
+            default: emit[ch] = 0; break;
+        }
+    }
+    long long count[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // per Act
     int padding = 0;
     unsigned seqcount = 1;
     std::string& s = g->seq;
     s.clear();
-    s.reserve(data.size() > pos ? data.size() - pos + 1024 : 1024);
+    s.resize(data.size() > pos ? data.size() - pos : 0);      // a byte appends at most one base; contig padding grows it below
+    size_t w = 0;
+    const unsigned char* in = (const unsigned char*)data.data();
     while (pos < data.size() && !failed) {
-        unsigned char ch = (unsigned char)data[pos++];
-        switch (kTable.act[ch]) {
-            case BASE_A: a++; s.push_back(reverse ? 'T' : 'A'); break;
-            case BASE_C: c++; s.push_back(reverse ? 'G' : 'C'); break;
-            case BASE_G: gg++; s.push_back(reverse ? 'C' : 'G'); break;
-            case BASE_T: t++; s.push_back(reverse ? 'A' : 'T'); break;
-            case BASE_U: t++; s.push_back('T'); break;          // not complemented (parsnp.cpp:3066-3069)
-            case BASE_N: nn++; s.push_back('N'); break;
-            case HEADER: {
-                read_line(nullptr);
-                if (!is_ref) { s.append((size_t)(d + 10), 'N'); nn += d + 10; padding += d + 10; }   // :3114-3118
-                seqcount++;
-                g->pos2hdr[(int)(nn + c + t + a + gg)] = "s" + std::to_string(seqcount);
-                break;
-            }
-            default: break;
+        const unsigned char ch = in[pos++];
+        const unsigned char e = emit[ch];
+        if (e) { s[w++] = (char)e; count[cls[ch]]++; continue; }
+        if (cls[ch] != HEADER) continue;
+        read_line(nullptr);
+        if (!is_ref) {                                         // :3114-3118
+            const size_t pad = (size_t)(d + 10);
+            if (s.size() < w + pad + (data.size() - pos)) s.resize(w + pad + (data.size() - pos));
+            memset(&s[w], 'N', pad); w += pad;
+            count[BASE_N] += d + 10; padding += d + 10;
         }
+        seqcount++;
+        g->pos2hdr[(int)(count[BASE_N] + count[BASE_C] + count[BASE_T] + count[BASE_U] + count[BASE_A] + count[BASE_G])] = "s" + std::to_string(seqcount);
     }
+    s.resize(w);
+    const long long a = count[BASE_A], c = count[BASE_C], gg = count[BASE_G], t = count[BASE_T] + count[BASE_U], nn = count[BASE_N];
     if (reverse) std::reverse(s.begin(), s.end());
     g->size_nopad = (int)s.size() - padding;
     g->gc = float(gg) + float(c);
