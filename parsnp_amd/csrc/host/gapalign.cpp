@@ -12,6 +12,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <unordered_map>
 
 namespace parsnp {
 namespace {
@@ -60,12 +61,26 @@ struct Tree {
 
 void kmer_distances(const std::vector<std::string>& s, std::vector<float>* dist) {
     const unsigned n = (unsigned)s.size();
-    // per sequence: its distinct 6-mers with their 8-bit (wrapping) multiplicities, in first-occurrence order
-    std::vector<std::vector<std::pair<uint32_t, uint8_t>>> tuples(n);
+    // The number of common 6-mers of two sequences depends on the two strings alone, and the sequences of a gap are
+    // mostly copies of a few alleles: counted once per pair of DISTINCT strings, then laid out per pair of sequences.
+    std::vector<unsigned> cls(n);
+    std::vector<unsigned> rep;                       // first sequence of every distinct string
+    {
+        std::unordered_map<std::string, unsigned> seen;
+        seen.reserve(2 * n);
+        for (unsigned i = 0; i < n; i++) {
+            auto it = seen.emplace(s[i], (unsigned)rep.size());
+            if (it.second) rep.push_back(i);
+            cls[i] = it.first->second;
+        }
+    }
+    const unsigned u = (unsigned)rep.size();
+    // per distinct string: its distinct 6-mers with their 8-bit (wrapping) multiplicities, in first-occurrence order
+    std::vector<std::vector<std::pair<uint32_t, uint8_t>>> tuples(u);
     std::vector<uint8_t> count(6 * 6 * 6 * 6 * 6 * 6, 0);
     std::vector<uint32_t> seen;
-    for (unsigned i = 0; i < n; i++) {
-        const std::string& q = s[i];
+    for (unsigned a = 0; a < u; a++) {
+        const std::string& q = s[rep[a]];
         if (q.size() < 5) continue;
         seen.clear();
         uint32_t t = 0;
@@ -76,20 +91,23 @@ void kmer_distances(const std::vector<std::string>& s, std::vector<float>* dist)
             if (p >= 5) { if (count[t] == 0) seen.push_back(t); ++count[t]; }   // unsigned char counts wrap (fastdistnuc.cpp:82-90)
         }
         // a count that wrapped back to 0 contributes nothing; a 6-mer listed twice (0 -> 256 -> 0 -> ...) is emitted once
-        for (uint32_t u : seen) { if (count[u]) { tuples[i].emplace_back(u, count[u]); count[u] = 0; } }
+        for (uint32_t x : seen) { if (count[x]) { tuples[a].emplace_back(x, count[x]); count[x] = 0; } }
     }
-    std::vector<unsigned> common((size_t)n * n, 0);
-    for (unsigned i = 0; i < n; i++) {
-        if (s[i].size() < 5) continue;
-        for (auto& tc : tuples[i]) count[tc.first] = tc.second;
-        for (unsigned j = 0; j <= i; j++) {
-            if (s[j].size() < 5) continue;
+    std::vector<unsigned> ucommon((size_t)u * u, 0);
+    for (unsigned a = 0; a < u; a++) {
+        if (s[rep[a]].size() < 5) continue;
+        for (auto& tc : tuples[a]) count[tc.first] = tc.second;
+        for (unsigned b = 0; b <= a; b++) {
+            if (s[rep[b]].size() < 5) continue;
             unsigned sum = 0;
-            for (auto& tc : tuples[j]) { uint8_t c1 = count[tc.first]; sum += c1 < tc.second ? c1 : tc.second; }
-            common[(size_t)i * n + j] = common[(size_t)j * n + i] = sum;
+            for (auto& tc : tuples[b]) { uint8_t c1 = count[tc.first]; sum += c1 < tc.second ? c1 : tc.second; }
+            ucommon[(size_t)a * u + b] = ucommon[(size_t)b * u + a] = sum;
         }
-        for (auto& tc : tuples[i]) count[tc.first] = 0;
+        for (auto& tc : tuples[a]) count[tc.first] = 0;
     }
+    std::vector<unsigned> common((size_t)n * n);
+    for (unsigned i = 0; i < n; i++)
+        for (unsigned j = 0; j < n; j++) common[(size_t)i * n + j] = ucommon[(size_t)cls[i] * u + cls[j]];
     dist->assign((size_t)n * (n - 1) / 2 + 1, 0.0f);
     for (unsigned i = 0; i < n; i++) {
         double c11 = common[(size_t)i * n + i];
@@ -226,34 +244,45 @@ void build_profile(const Msa& m, const std::vector<float>& seq_weight, std::vect
     for (size_t s = 0; s < ns; s++) { w[s] = seq_weight[m.ids[s]]; total += w[s]; }
     if (total != 0) { const float f = 1.0f / total; for (size_t s = 0; s < ns; s++) w[s] *= f; }
     prof->assign(nc, ProfPos());
-    for (size_t c = 0; c < nc; c++) {
-        ProfPos& pp = (*prof)[c];
-        float cnt[4] = {0, 0, 0, 0};
-        float start = 0, end = 0;
-        for (size_t s = 0; s < ns; s++) {
+    // A column's sums run over the sequences in MSA order, each a chain of dependent float additions (the order is part of
+    // the result).  Four columns are summed side by side: four independent chains per pass over the sequences.
+    constexpr size_t kBlock = 4;
+    for (size_t c0 = 0; c0 < nc; c0 += kBlock) {
+        const size_t nb = nc - c0 < kBlock ? nc - c0 : kBlock;
+        float cnt[kBlock][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        float start[kBlock] = {0, 0, 0, 0}, end[kBlock] = {0, 0, 0, 0};
+        auto add = [&](size_t b, size_t s, float ws) {
+            const size_t c = c0 + b;
             const char ch = m.at(s, c);
-            const float ws = w[s];
             if (is_gap(ch)) {
-                if (c == 0 || !is_gap(m.at(s, c - 1))) start += ws;
-                if (c + 1 == nc || !is_gap(m.at(s, c + 1))) end += ws;
-                continue;
+                if (c == 0 || !is_gap(m.at(s, c - 1))) start[b] += ws;
+                if (c + 1 == nc || !is_gap(m.at(s, c + 1))) end[b] += ws;
+                return;
             }
             const uint8_t l = kAlpha.letter[(uint8_t)ch];
-            if (l < 4) cnt[l] += ws;
-            else if (l == 14) { cnt[2] += ws / 2; cnt[0] += ws / 2; }   // msa2.cpp:66-71: the amino-acid code AX_R (=14) meets NX_X
-            else { const float f = ws / 20; for (unsigned k = 0; k < 4; k++) cnt[k] += f; }   // msa2.cpp:76-80
+            if (l < 4) cnt[b][l] += ws;
+            else if (l == 14) { cnt[b][2] += ws / 2; cnt[b][0] += ws / 2; }   // msa2.cpp:66-71: the amino-acid code AX_R (=14) meets NX_X
+            else { const float f = ws / 20; for (unsigned k = 0; k < 4; k++) cnt[b][k] += f; }   // msa2.cpp:76-80
+        };
+        if (nb == kBlock) {
+            for (size_t s = 0; s < ns; s++) { const float ws = w[s]; add(0, s, ws); add(1, s, ws); add(2, s, ws); add(3, s, ws); }
+        } else {
+            for (size_t s = 0; s < ns; s++) { const float ws = w[s]; for (size_t b = 0; b < nb; b++) add(b, s, ws); }
         }
-        for (unsigned k = 0; k < 4; k++) pp.counts[k] = cnt[k];
-        sort_counts(pp.counts, pp.order);
-        for (unsigned i = 0; i < 4; i++) {
-            float sum = 0;
-            for (unsigned j = 0; j < 4; j++) sum += pp.counts[j] * kMatrix[i][j];
-            pp.scores[i] = sum;
+        for (size_t b = 0; b < nb; b++) {
+            ProfPos& pp = (*prof)[c0 + b];
+            for (unsigned k = 0; k < 4; k++) pp.counts[k] = cnt[b][k];
+            sort_counts(pp.counts, pp.order);
+            for (unsigned i = 0; i < 4; i++) {
+                float sum = 0;
+                for (unsigned j = 0; j < 4; j++) sum += pp.counts[j] * kMatrix[i][j];
+                pp.scores[i] = sum;
+            }
+            const float start_occ = (float)(1.0 - start[b]);
+            const float end_occ = (float)(1.0 - end[b]);
+            pp.open = start_occ * kGapOpen / 2;
+            pp.close = end_occ * kGapOpen / 2;
         }
-        const float start_occ = (float)(1.0 - start);
-        const float end_occ = (float)(1.0 - end);
-        pp.open = start_occ * kGapOpen / 2;
-        pp.close = end_occ * kGapOpen / 2;
     }
 }
 
