@@ -1204,7 +1204,9 @@ void Aligner::filter_mums(int rvalue) {
     double t0 = now_s();
     {
         std::vector<Handle> h(mums.size());
-        for (size_t i = 0; i < mums.size(); i++) h[i] = Handle{pool[(size_t)mums[i]].start[0], mums[i]};
+        const long nh = (long)mums.size();        // one cache miss per MUM (its row): spread over the threads
+#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
+        for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{pool[(size_t)mums[(size_t)i]].start[0], mums[(size_t)i]};
         // the list is the anchors followed by the MUMs of the recursion, each in reference order: two increasing runs.
         // With all keys different there is one sorted order and a merge finds it; with equal keys the order std::sort
         // leaves is the reference's (sort( mums ) :338), so it runs on the list as it stands.
@@ -1265,7 +1267,9 @@ void Aligner::chain() {
     unique_order = true;
     {
         std::vector<Handle> h(mums.size());
-        for (size_t i = 0; i < mums.size(); i++) h[i] = Handle{pool[(size_t)mums[i]].start[0], mums[i]};
+        const long nh = (long)mums.size();        // one cache miss per MUM (its row): spread over the threads
+#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
+        for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{pool[(size_t)mums[(size_t)i]].start[0], mums[(size_t)i]};
         // strictly increasing keys (the list as filter_mums left it) have one sorted order: nothing to do.  With ties
         // the order std::sort leaves is the reference's, so it runs.
         bool increasing = true;
@@ -1314,9 +1318,12 @@ void Aligner::chain() {
     // verdicts of every MUM whose predecessor is still the same)
     std::vector<uint8_t> ahead((size_t)m, CLOSE);
     if (judged_pred_.size() < pool.size()) { judged_pred_.assign(pool.size(), -1); judged_verdict_.assign(pool.size(), CLOSE); }
+    std::vector<long> lens((size_t)m);          // gathered here: the sequential pass below would miss the cache once per MUM
+    lens[0] = pool[(size_t)mums[0]].length;
 #pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 4096)
     for (long x = 1; x < m; x++) {
         const int cur = mums[(size_t)x], prev = mums[(size_t)x - 1];
+        lens[(size_t)x] = pool[(size_t)cur].length;
         if (judged_pred_[(size_t)cur] != prev) { judged_verdict_[(size_t)cur] = judge(pool[(size_t)cur], pool[(size_t)prev]); judged_pred_[(size_t)cur] = prev; }
         ahead[(size_t)x] = judged_verdict_[(size_t)cur];
     }
@@ -1333,15 +1340,15 @@ void Aligner::chain() {
     Lcb cluster = open_chain(mums[0]);
     bool addmum = true;
     for (long x = 1; x < m; x++) {
-        const Mum& nt = pool[(size_t)mums[(size_t)x]];
-        if (nt.length < random) { addmum = true; continue; }
+        const long nt_length = lens[(size_t)x];
+        if (nt_length < random) { addmum = true; continue; }
         if (!addmum) cluster = open_chain(mums[(size_t)x - 1]);
         addmum = true;
         const int back = cluster.mums.back();
-        const uint8_t v = back == mums[(size_t)x - 1] ? ahead[(size_t)x] : judge(nt, pool[(size_t)back]);
+        const uint8_t v = back == mums[(size_t)x - 1] ? ahead[(size_t)x] : judge(pool[(size_t)mums[(size_t)x]], pool[(size_t)back]);
         if (v == PASS) continue;
         if (v == JOIN) {
-            cluster.length += nt.length;
+            cluster.length += nt_length;
             cluster.mums.push_back(mums[(size_t)x]);
         } else {
             addmum = false;
