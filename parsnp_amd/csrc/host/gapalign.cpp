@@ -77,7 +77,9 @@ void kmer_distances(const std::vector<std::string>& s, std::vector<float>* dist)
     const unsigned u = (unsigned)rep.size();
     // per distinct string: its distinct 6-mers with their 8-bit (wrapping) multiplicities, in first-occurrence order
     std::vector<std::vector<std::pair<uint32_t, uint8_t>>> tuples(u);
-    std::vector<uint8_t> count(6 * 6 * 6 * 6 * 6 * 6, 0);
+    // (kept per thread and left all-zero after use: a block this size per call would go through mmap/munmap, and with
+    // every thread aligning gaps at once those calls serialise the whole process)
+    static thread_local std::vector<uint8_t> count(6 * 6 * 6 * 6 * 6 * 6, 0);
     std::vector<uint32_t> seen;
     for (unsigned a = 0; a < u; a++) {
         const std::string& q = s[rep[a]];
@@ -105,17 +107,15 @@ void kmer_distances(const std::vector<std::string>& s, std::vector<float>* dist)
         }
         for (auto& tc : tuples[a]) count[tc.first] = 0;
     }
-    std::vector<unsigned> common((size_t)n * n);
-    for (unsigned i = 0; i < n; i++)
-        for (unsigned j = 0; j < n; j++) common[(size_t)i * n + j] = ucommon[(size_t)cls[i] * u + cls[j]];
+    auto common = [&](unsigned i, unsigned j) { return ucommon[(size_t)cls[i] * u + cls[j]]; };
     dist->assign((size_t)n * (n - 1) / 2 + 1, 0.0f);
     for (unsigned i = 0; i < n; i++) {
-        double c11 = common[(size_t)i * n + i];
+        double c11 = common(i, i);
         if (c11 == 0) c11 = 1;
         for (unsigned j = 0; j < i; j++) {
-            double c22 = common[(size_t)j * n + j];
+            double c22 = common(j, j);
             if (c22 == 0) c22 = 1;
-            const unsigned c12 = common[(size_t)i * n + j];
+            const unsigned c12 = common(i, j);
             const double d1 = 3.0 * (c11 - c12) / c11;
             const double d2 = 3.0 * (c22 - c12) / c22;
             (*dist)[tri(i, j)] = (float)(d1 < d2 ? d1 : d2);
