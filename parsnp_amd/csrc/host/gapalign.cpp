@@ -321,6 +321,26 @@ bool nw_small(std::vector<ProfPos>& pa, std::vector<ProfPos>& pb, std::string* p
     float *mcurr = b0.data(), *mnext = b1.data(), *mprev = b2.data();
     auto set_m = [&](unsigned i, unsigned j, uint8_t bit) { uint8_t& t = tb[i * stride + j]; t &= (uint8_t)~kXM; t |= bit; };
 
+    // column-wise copies of profile B: the row of match scores is then four multiply-adds over contiguous floats.  A
+    // count of 0 ends match_score()'s loop; here its term is added as +-0, which changes nothing (counts are sorted, so
+    // the zeros are last), and the terms keep their order.
+    std::vector<float> soa((size_t)lb * 6);
+    float* sb[4] = {soa.data(), soa.data() + lb, soa.data() + 2 * (size_t)lb, soa.data() + 3 * (size_t)lb};
+    float* openb = soa.data() + 4 * (size_t)lb; float* closeb = soa.data() + 5 * (size_t)lb;
+    for (unsigned j = 0; j < lb; j++) {
+        for (unsigned l = 0; l < 4; l++) sb[l][j] = pb[j].scores[l];
+        openb[j] = pb[j].open; closeb[j] = pb[j].close;
+    }
+    auto score_row = [&](const ProfPos& a, float* out) {        // out[j + 1] = match_score(a, pb[j]) for 1 <= j < lb
+        const float f0 = a.counts[a.order[0]], f1 = a.counts[a.order[1]], f2 = a.counts[a.order[2]], f3 = a.counts[a.order[3]];
+        const float *s0 = sb[a.order[0]], *s1 = sb[a.order[1]], *s2 = sb[a.order[2]], *s3 = sb[a.order[3]];
+        for (unsigned j = 1; j < lb; j++) {
+            float sc = 0.0f;
+            sc += f0 * s0[j]; sc += f1 * s1[j]; sc += f2 * s2[j]; sc += f3 * s3[j];
+            out[j + 1] = sc - 0.0f;
+        }
+    };
+
     float iij = kMinusInf;
     for (unsigned j = 0; j <= lb; j++) drow[j] = kMinusInf;
     mprev[0] = 0;
@@ -350,18 +370,27 @@ bool nw_small(std::vector<ProfPos>& pa, std::vector<ProfPos>& pb, std::string* p
         mcurr[0] = kMinusInf;
         if (i == 1) { mcurr[1] = match_score(pa[0], pb[0]); set_m(i, 1, kMM); }
         else { mcurr[1] = match_score(pa[i - 1], pb[0]) + pa[0].open + (i - 2) * e + pa[i - 2].close; set_m(i, 1, kDM); }
-        for (unsigned j = 1; j < lb; j++) mnext[j + 1] = match_score(pa[i], pb[j]);
+        score_row(pa[i], mnext);
         uint8_t* tbnext = &tb[(i + 1) * stride];
-        for (unsigned j = 1; j < lb; j++) {
-            REC_D(i, j)
-            REC_I(i, j)
-            const float dm = drow[j] + pa[i - 1].close;
-            const float im = iij + pb[j - 1].close;
+        const float open_a = pa[i - 1].open, close_a = pa[i - 1].close;
+        for (unsigned j = 1; j < lb; j++) {      // REC_D, REC_I and the three-way choice without branches (same tests, same ties)
+            const float dd = drow[j] + e;
+            const float md = mprev[j] + open_a;
+            const bool from_m = !(dd > md);
+            const float dj = from_m ? md : dd;
+            drow[j] = dj;
+            iij += e;
+            const float mi = mcurr[j - 1] + openb[j - 1];
+            const bool open_i = mi >= iij;
+            iij = open_i ? mi : iij;
+            tbrow[j] |= (uint8_t)((from_m ? kMD : 0) | (open_i ? kMI : 0));
+            const float dm = dj + close_a;
+            const float im = iij + closeb[j - 1];
             const float mm = mcurr[j];
-            tbnext[j + 1] &= (uint8_t)~kXM;
-            if (mm >= dm && mm >= im) { mnext[j + 1] += mm; tbnext[j + 1] |= kMM; }
-            else if (dm >= mm && dm >= im) { mnext[j + 1] += dm; tbnext[j + 1] |= kDM; }
-            else { mnext[j + 1] += im; tbnext[j + 1] |= kIM; }
+            const bool pm = mm >= dm && mm >= im;
+            const bool pd = !pm && dm >= mm && dm >= im;
+            mnext[j + 1] += pm ? mm : (pd ? dm : im);
+            tbnext[j + 1] = (uint8_t)((tbnext[j + 1] & (uint8_t)~kXM) | (pm ? kMM : (pd ? kDM : kIM)));
         }
         REC_D(i, lb)
         REC_I(i, lb)
