@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""A longer side-by-side campaign than the committed fuzz tests, on the CPU checker (build container, needs
+oracle/_ref/parsnp_core_ref): seeds beyond those of tests/test_fuzz_vs_reference.py, every run threaded, with the rarely
+taken host routes forced (parallel validation of short lists, free/tangled split of the flagged candidates) and every
+derived or early-exit seed region re-done with the full bitmap walk.
+    python scripts/fuzz_campaign.py [first_small last_small [n_big]]      (default 24 160 14: ~15 min)"""
+import os
+import pathlib
+import shutil
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.chdir(ROOT)
+import test_fuzz_vs_reference as F  # noqa: E402
+
+core = os.path.join(ROOT, "oracle", "_ref", "parsnp_core_oracle")
+os.environ.update(PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_NEIGHBOURS="1")
+first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (24, 160)
+n_big = int(sys.argv[3]) if len(sys.argv) > 3 else 14
+bad = []
+
+
+def one(seed, big):
+    base = pathlib.Path(tempfile.mkdtemp(prefix="fz_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None))
+    try:
+        ref, gs, kw, contigs = F.random_case(seed, big)
+        if kw.get("threads", 1) < 2:
+            kw["threads"] = 3
+        rp, qs = F.write(str(base / "in"), ref, gs, contigs, seed)
+        a = F.run(F.REFBIN, rp, qs, str(base / "ref"), kw)
+        b = F.run(core, rp, qs, str(base / "mine"), kw)
+        if a != b:
+            bad.append((seed, big, kw))
+            print("MISMATCH", seed, big, kw, flush=True)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
+for seed in range(first, last):
+    one(seed, False)
+print("small sets done:", last - first, "mismatches:", len(bad), flush=True)
+for seed in range(n_big):
+    one(seed, True)
+print("all done:", last - first + n_big, "runs, mismatches:", bad, flush=True)
+sys.exit(1 if bad else 0)
