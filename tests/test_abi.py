@@ -41,6 +41,25 @@ def test_product_has_no_cpu_path(tmp_path):
         Session(Lib(HIP_LIB), [b"ACGT", b"ACGT"])
 
 
+def test_bench_and_core_refuse_to_run_without_a_gpu(tmp_path):
+    """bench.py and parsnp_core exit non-zero with a message when no HIP device is present (parsnp_core: code 3)"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--cpu-sample", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU path" in (r.stdout + r.stderr)
+    from parsnp_amd import driver, synth
+    from parsnp_amd.paths import CORE_BIN
+    ref, gs = synth.make("pop6x200k", n=5000, n_genomes=2)
+    rp, qs = synth.write_set(str(tmp_path / "in"), ref, gs)
+    rc, _ = driver.run_core(CORE_BIN, rp, qs, str(tmp_path / "out"))
+    assert rc == 3
+    assert not os.path.exists(str(tmp_path / "out" / "parsnpAligner.xmfa"))
+
+
 def test_product_does_not_reference_the_oracle():
     bad = []
     for base, _, files in os.walk(os.path.join(ROOT, "parsnp_amd")):
