@@ -80,6 +80,31 @@ const int32_t* pm_result_sp(const pm_result* r);
 const uint8_t* pm_result_fwd(const pm_result* r);
 void pm_result_free(pm_result* r);
 
+/* MUM-row mode.  After pm_session_rows(s, 1) the results of pm_multi_mum_batch carry, instead of sp / fwd (those accessors
+ * then return NULL), what the second half of setMums1 derives from them per candidate (src/parsnp.cpp:1717-1780 and the
+ * TMum constructor src/TMum.cpp:25-60), built on the device; n = n_genomes, genome 0 = the reference:
+ *   start[c*n+j]   start of the MUM in genome j on the genome's forward coordinates: window start + sp for a forward
+ *                  member, genome length - (window start + sp + lon) for a reverse one (flipped against the WHOLE genome)
+ *   strand[c*n+j]  1 forward, 0 reverse (genome 0: always 1)
+ *   flags[c]       PM_ROW_BAD      a start position outside its window: the reference skips the candidate (:1723)
+ *                  PM_ROW_OUTSIDE  start < 0 or start + lon > genome length in some genome (`notgood`)
+ *                  PM_ROW_REVERSE  some member is on the reverse strand
+ *                  PM_ROW_DIRTY    (only when pm_result_dirty_known) overlaps an earlier candidate of the list in some
+ *                                  genome by the running-extent test of the anchor validation; computed for one-region
+ *                                  batches with at least 4096 accepted candidates
+ * The window of genome j is the starts/lens row the caller passed, so the rows equal the reference's only for requests
+ * whose rows ARE the region (one unclamped reference chunk); a caller with clamped or chunked rows keeps to sp / fwd.
+ * The blocks are writable: the caller may trim the rows in place (Aligner::trim) and keep them as its MUM table. */
+#define PM_ROW_BAD 1u
+#define PM_ROW_OUTSIDE 2u
+#define PM_ROW_REVERSE 4u
+#define PM_ROW_DIRTY 8u
+int pm_session_rows(pm_session* s, int enable);
+int32_t* pm_result_start(pm_result* r);
+uint8_t* pm_result_strand(pm_result* r);
+const uint32_t* pm_result_flags(const pm_result* r);
+int pm_result_dirty_known(const pm_result* r);
+
 /* calcmumi mode (Aligner::setMumi, src/parsnp.cpp:1869-2115): every query genome ALONE against the reference chunk
  * starts[0],lens[0] (query g: starts[g],lens[g]).  covered[g-1] = number of reference positions covered by the
  * pairwise MUMs of length >= 15 of query g, i.e. total_M_LON of :2064-2069 before the length-ratio and clamp rules

@@ -95,4 +95,10 @@ int pm_mumi_coverage(pm_session* s, const int64_t* starts, const int64_t* lens, 
     }
     return PM_OK;
 }
+/* MUM-row mode is a device feature of the HIP engine; this checker keeps to sp / fwd and says so */
+int pm_session_rows(pm_session* s, int enable) { (void)s; return enable ? PM_EINVAL : PM_OK; }
+int32_t* pm_result_start(pm_result* r) { (void)r; return 0; }
+uint8_t* pm_result_strand(pm_result* r) { (void)r; return 0; }
+const uint32_t* pm_result_flags(const pm_result* r) { (void)r; return 0; }
+int pm_result_dirty_known(const pm_result* r) { (void)r; return 0; }
 int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) { (void)s; (void)names; (void)ms; if (count) *count = 0; return PM_OK; }

@@ -40,7 +40,8 @@ static int session_create(pm_session** out, int device, int n_genomes, const uin
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
         *out = s.release();
         return PM_OK;
-    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed"); }
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
 }
 int pm_session_create(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens) {
     return session_create(out, device, n_genomes, seqs, lens, nullptr);
@@ -68,7 +69,8 @@ int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, 
         s->timing.push_back(pm::PhaseTime{"call_wall", std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count()});
         *out = r.release();
         return PM_OK;
-    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed"); }
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
 }
 int64_t pm_result_regions(const pm_result* r) { return r->r.nregions; }
 int64_t pm_result_total(const pm_result* r) { return r->r.total; }
@@ -78,6 +80,11 @@ const int32_t* pm_result_lon(const pm_result* r) { return r->r.lon(); }
 const int32_t* pm_result_sp(const pm_result* r) { return r->r.sp(); }
 const uint8_t* pm_result_fwd(const pm_result* r) { return r->r.fwd(); }
 void pm_result_free(pm_result* r) { delete r; }
+int pm_session_rows(pm_session* s, int enable) { if (!s) return fail(PM_EINVAL, "bad argument"); s->engine->want_rows = enable != 0; return PM_OK; }
+int32_t* pm_result_start(pm_result* r) { return r->r.start(); }
+uint8_t* pm_result_strand(pm_result* r) { return r->r.strand(); }
+const uint32_t* pm_result_flags(const pm_result* r) { return r->r.flags(); }
+int pm_result_dirty_known(const pm_result* r) { return r->r.dirty_known ? 1 : 0; }
 
 int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int strand,
                    int64_t cap, int64_t* count, int64_t* ev_j, int64_t* ev_l, int32_t* ev_len, int32_t* ev_rep) {
@@ -87,10 +94,14 @@ int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t 
     pm_session* s = nullptr;
     int rc = pm_session_create(&s, -1, 2, seqs, lens);
     if (rc) return rc;
+    std::unique_ptr<pm_session> guard(s);
     int64_t starts[2] = {0, 0};
     pm::BatchResult br;
-    rc = s->engine->run(1, starts, lens, &min_len, &br, true);
-    if (rc) { fail(rc, s->engine->error); pm_session_destroy(s); return rc; }
+    try {
+        rc = s->engine->run(1, starts, lens, &min_len, &br, true);
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
+    if (rc) return fail(rc, s->engine->error);
     const auto& K = s->engine->ev_key_h; const auto& V = s->engine->ev_val_h;
     const uint64_t lmask = (1ull << s->engine->ev_lbits) - 1;
     int64_t c = 0;
@@ -101,7 +112,6 @@ int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t 
         c++;
     }
     *count = c;
-    pm_session_destroy(s);
     return PM_OK;
 }
 
@@ -116,7 +126,8 @@ int pm_mumi_coverage(pm_session* s, const int64_t* starts, const int64_t* lens, 
         s->timing = s->engine->timing;
         for (size_t g = 0; g < s->engine->mumi_covered.size(); g++) covered[g] = s->engine->mumi_covered[g];
         return PM_OK;
-    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed"); }
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
 }
 
 int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) {

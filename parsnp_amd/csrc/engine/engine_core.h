@@ -43,12 +43,21 @@ struct BatchResult {
     int nq = 0;
     std::vector<int64_t> off;
     HostPool::Block kb, lonb, spb, fwdb;     // int32 k[total], int32 lon[total], int32 sp[total*nq], uint8 fwd[total*nq]
+    // a session in MUM-row mode (pm_session_rows) fills these instead of sp / fwd:
+    HostPool::Block startb, strandb, flagsb; // int32 start[total*(nq+1)], uint8 strand[total*(nq+1)], uint32 flags[total]
+    bool rows = false, dirty_known = false;  // dirty_known: the kRowDirty bits were computed (one-region batch with a long list)
     std::shared_ptr<HostPool> pool;
+    int32_t* start() const { return (int32_t*)startb.p; }
+    uint8_t* strand() const { return (uint8_t*)strandb.p; }
+    const uint32_t* flags() const { return (const uint32_t*)flagsb.p; }
     const int32_t* k() const { return (const int32_t*)kb.p; }
     const int32_t* lon() const { return (const int32_t*)lonb.p; }
     const int32_t* sp() const { return (const int32_t*)spb.p; }
     const uint8_t* fwd() const { return (const uint8_t*)fwdb.p; }
-    void release() { if (pool) { pool->give(kb); pool->give(lonb); pool->give(spb); pool->give(fwdb); } kb = lonb = spb = fwdb = HostPool::Block(); }
+    void release() {
+        if (pool) { pool->give(kb); pool->give(lonb); pool->give(spb); pool->give(fwdb); pool->give(startb); pool->give(strandb); pool->give(flagsb); }
+        kb = lonb = spb = fwdb = startb = strandb = flagsb = HostPool::Block();
+    }
     BatchResult() = default;
     BatchResult(const BatchResult&) = delete;
     BatchResult& operator=(const BatchResult&) = delete;
@@ -81,6 +90,7 @@ public:
     int64_t last_events = 0, last_candidates = 0;
 
     int ngen = 0;
+    bool want_rows = false;           // pm_session_rows: results as MUM rows (start, strand, flags) instead of (sp, fwd)
     std::vector<int64_t> glen_h;
     Collectives coll;                 // world == 1: not sharded
     int g_first = 1, g_last = 1;      // query genomes [g_first, g_last) are resident on this GPU
@@ -132,6 +142,9 @@ public:
     }
 
     // ---- one batch of regions (include/parsnp_mum.h: pm_multi_mum_batch)
+    // Host round trips of one call: the event counters (+ error word), the candidate count, the accepted count and the
+    // result download.  Everything else the device needs from the host (region table, prefix arrays, request rows) is
+    // assembled in ONE page-locked block and sent by asynchronous copies on the engine's stream.
     std::vector<int64_t> mumi_covered;   // result of run(..., mumi = true): per query genome
     int run(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events = false,
             bool mumi = false) {
@@ -143,36 +156,47 @@ public:
         out->pool = pool;
         if (nreg == 0) return 0;
         if (nq < 1) { error = "need at least one query genome"; return -2; }
+        const int no_small = (mumi || getenv("PM_NO_SMALL_PAIRS")) ? 1 : 0;   // PM_NO_SMALL_PAIRS=1: measurement
 
-        // -- host: per-region parameters and slices
-        std::vector<RegionInfo> R((size_t)nreg);
-        std::vector<int64_t> posbase((size_t)nreg + 1), tilebase((size_t)nreg + 1);
-        int64_t npos = 0, ntiles = 0, tsize = 0, fwords = 0;
-        int32_t max_nr = 1;
-        size_t ev_guess = 1 << 16;     // first-call event buffer: a match of length >= minsize every max(8,minsize) bases is generous
-        // the request rows (2 x 8 bytes per region and genome: 26 MB for a recursion batch of 8 000 regions x 201) are
-        // checked and copied into a page-locked staging block by a few threads, and go to the device from there in one
-        // DMA each -- a copy out of the caller's pageable arrays is staged by the runtime at a fifth of the rate
+        // -- host: the page-locked parameter block  [ RegionInfo x nreg | posbase | cbase | starts rows | lens rows ]
         const size_t nrow = (size_t)nreg * (size_t)ngen;
-        int64_t* stage = (int64_t*)be.staging(2 * nrow * sizeof(int64_t));
-        if (!stage) { error = "cannot allocate the request staging block"; return -3; }
-        std::vector<size_t> guess_r((size_t)nreg, 0);
+        const size_t regz = (size_t)nreg;
+        const size_t bytes_R = sizeof(RegionInfo) * regz, bytes_pre = 8 * (regz + 1);
+        uint8_t* block = (uint8_t*)be.staging(bytes_R + 2 * bytes_pre + 16 * nrow + 64);
+        if (!block) { error = "cannot allocate the request staging block"; return -3; }
+        RegionInfo* R = (RegionInfo*)block;
+        int64_t* posbase = (int64_t*)(block + bytes_R);
+        int64_t* cbase = posbase + regz + 1;
+        int64_t* stage = cbase + regz + 1;
+        std::vector<size_t> guess_r(regz, 0);
+        std::vector<int64_t> units_r(regz, 0);
         {
+            // the request rows (2 x 8 bytes per region and genome: 26 MB for a recursion batch of 8 000 regions x 201) are
+            // checked and copied by a few threads; the same pass counts the SeedExtend work units of every region (what
+            // CountUnits computes on the device) so that the grid size needs no read-back
             const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, nreg / 512));
             std::vector<int> bad((size_t)nt, 0);
             auto part = [&](int t) {
                 const int64_t r0 = nreg * t / nt, r1 = nreg * (t + 1) / nt;
                 for (int64_t r = r0; r < r1; r++) {
                     const int64_t* st = starts + r * ngen; const int64_t* ln = lens + r * ngen;
-                    const int div = std::max(8, minsize[r] < 1 ? 1 : minsize[r]);
+                    const int minlen = minsize[r] < 1 ? 1 : minsize[r];
+                    const int div = std::max(8, minlen);
+                    const int K = minlen < 16 ? minlen : 16, stride = minlen - K + 1;
+                    const int64_t nR = ln[0];
                     size_t gs = 0;
+                    int64_t units = 0;
                     int b = 0;
                     for (int g = 0; g < ngen; g++) {
                         if (st[g] < 0 || ln[g] < 0 || st[g] + ln[g] > glen_h[(size_t)g]) b |= 1;
                         if (ln[g] >= (1ll << 31)) b |= 2;
-                        if (g) gs += (size_t)(2 * ln[g] / div);
+                        if (!g) continue;
+                        gs += (size_t)(2 * ln[g] / div);
+                        int64_t ns = (ln[g] >= K && nR >= K && g >= g_first && g < g_last) ? (ln[g] - K) / stride + 1 : 0;
+                        if (small_pair(nR, ln[g]) && !no_small) ns = 0;
+                        units += 2 * ((ns + kUnitSamples - 1) / kUnitSamples);
                     }
-                    guess_r[(size_t)r] = gs;
+                    guess_r[(size_t)r] = gs; units_r[(size_t)r] = units;
                     bad[(size_t)t] |= b;
                     memcpy(stage + r * ngen, st, sizeof(int64_t) * (size_t)ngen);
                     memcpy(stage + nrow + r * ngen, ln, sizeof(int64_t) * (size_t)ngen);
@@ -190,6 +214,10 @@ public:
             if (b & 1) { error = "region outside its genome"; return -2; }
             if (b & 2) { error = "region longer than 2^31"; return -5; }
         }
+        int64_t npos = 0, tsize = 0, fwords = 0, nunits = 0;
+        int32_t max_nr = 1;
+        size_t ev_guess = 1 << 16;     // first-call event buffer: a match of length >= minsize every max(8,minsize) bases is generous
+        cbase[0] = 0;
         for (int64_t r = 0; r < nreg; r++) {
             RegionInfo& ri = R[(size_t)r];
             ri.ref_pos = starts[r * ngen];
@@ -206,26 +234,34 @@ public:
             while (fbits < 8 * (int64_t)ri.nR) fbits <<= 1;
             ri.fmask = (uint32_t)(fbits - 1); ri.fbase = fwords; fwords += fbits / 32; ri.pad_ = 0;
             ri.posbase = npos; posbase[(size_t)r] = npos; npos += ri.nR;
-            ri.tile_base = ntiles; tilebase[(size_t)r] = ntiles; ntiles += (ri.nR + kTile - 1) / kTile;
+            cbase[(size_t)r + 1] = cbase[(size_t)r] + (((int64_t)ri.nR + kChunkPos - 1) >> kCoarseShift) + 1;
             max_nr = std::max(max_nr, ri.nR);
             ev_guess += guess_r[(size_t)r];
+            nunits += units_r[(size_t)r];
         }
-        posbase[(size_t)nreg] = npos; tilebase[(size_t)nreg] = ntiles;
+        posbase[regz] = npos;
         const int64_t npairs = nreg * nq;
+        const int64_t nchunks = cbase[regz] - nreg;                  // 256-position chunks of the batch
+        const int64_t centries = cbase[regz] * nq;
         const int lbits = bits_for((uint64_t)max_nr);
         if (bits_for((uint64_t)npairs) + lbits + 1 > 64) { error = "batch too large for 64-bit event keys"; return -5; }
         if (npairs >= (1ll << 31) || nreg >= (1ll << 31)) { error = "too many regions in one batch"; return -5; }
+        if (nunits >= (1ll << 31)) { error = "too many work units in one batch"; return -5; }
+        if (centries >= (1ll << 31)) { error = "coarse event index too large"; return -5; }
 
         be.mark("setup");
-        ensure(d_R, (size_t)nreg);
-        ensure(d_starts, (size_t)(nreg * ngen)); ensure(d_lens, (size_t)(nreg * ngen));
-        ensure(d_posbase, (size_t)nreg + 1); ensure(d_tilebase, (size_t)nreg + 1);
-        be.h2d(d_R.p, R.data(), sizeof(RegionInfo) * (size_t)nreg);
+        ensure(d_R, regz);
+        ensure(d_starts, nrow); ensure(d_lens, nrow);
+        ensure(d_posbase, regz + 1); ensure(d_cbase, regz + 1);
+        be.h2d_staged(d_R.p, R, bytes_R);
+        be.h2d_staged(d_posbase.p, posbase, bytes_pre);
+        be.h2d_staged(d_cbase.p, cbase, bytes_pre);
         be.h2d_staged(d_starts.p, stage, sizeof(int64_t) * nrow);
         be.h2d_staged(d_lens.p, stage + nrow, sizeof(int64_t) * nrow);
-        be.h2d(d_posbase.p, posbase.data(), sizeof(int64_t) * ((size_t)nreg + 1));
-        be.h2d(d_tilebase.p, tilebase.data(), sizeof(int64_t) * ((size_t)nreg + 1));
-        ensure(d_err, 1); be.memset(d_err.p, 0, 4);
+        // event counters: kSlices counters one 64-byte line apart, then the error word of the batch (read back together)
+        const size_t ncounter = (size_t)kSlices * kSliceStride + 8;
+        ensure(d_counter, ncounter);
+        uint32_t* d_err = (uint32_t*)(d_counter.p + (size_t)kSlices * kSliceStride);
 
         // -- reference index + repeat lengths
         ensure(d_slots, (size_t)tsize); ensure(d_filter, (size_t)fwords);
@@ -233,6 +269,7 @@ public:
         ensure(d_next, (size_t)std::max<int64_t>(npos, 1)); ensure(d_rep, (size_t)std::max<int64_t>(npos, 1));
         ensure(d_epm, (size_t)std::max<int64_t>(npos, 1));
         be.memset(d_slots.p, 0xff, sizeof(uint64_t) * (size_t)tsize);
+        be.memset(d_counter.p, 0, 8 * ncounter);
         be.mark("index");
         be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p, d_filter.p});
         be.mark("repeat");
@@ -240,60 +277,56 @@ public:
         be.launch("run_length", npos, RunLength{P, d_R.p, nreg, d_posbase.p, d_run.p});
         ensure(d_repeated, (size_t)(npos / 32 + 1));
         be.memset(d_repeated.p, 0, 4 * (size_t)(npos / 32 + 1));
-        be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_filter.p, d_next.p, d_run.p, d_rep.p, d_repeated.p, d_err.p, work_budget});
+        be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_filter.p, d_next.p, d_run.p, d_rep.p, d_repeated.p, d_err, work_budget});
 
-        // -- work units (pairs that fit 64 bases on both sides go to SmallPairEvents instead; PM_NO_SMALL_PAIRS=1: measurement)
-        const int no_small = (mumi || getenv("PM_NO_SMALL_PAIRS")) ? 1 : 0;
+        // -- work units (pairs that fit 128 bases on both sides go to SmallPairEvents instead)
         be.mark("units");
         ensure(d_ucount, (size_t)npairs + 1); ensure(d_uoff, (size_t)npairs + 1);
         be.launch("count_units", npairs, CountUnits{d_R.p, d_lens.p, ngen, d_ucount.p, g_first, g_last, no_small});
         be.memset(d_ucount.p + npairs, 0, 8);
         be.exclusive_scan(d_ucount.p, d_uoff.p, (size_t)npairs + 1);
-        int64_t nunits = 0;
-        be.d2h(&nunits, d_uoff.p + npairs, 8);
-        if (nunits >= (1ll << 31)) { error = "too many work units in one batch"; return -5; }
         ensure(d_units, (size_t)std::max<int64_t>(nunits, 1));
         be.launch("fill_units", nunits, FillUnits{P, d_starts.p, d_lens.p, ngen, d_uoff.p, d_ucount.p, npairs, d_units.p});
 
         // -- events: kSlices append buffers (retry with larger ones on overflow), gathered, then sorted by (pair, l, strand)
-        ensure(d_counter, (size_t)kSlices * kSliceStride);
         ensure(d_sliceoff, (size_t)kSlices + 1);
         uint64_t nev = 0;
         size_t slice_cap = (std::min<size_t>(std::max<size_t>(ev_cap_hint, ev_guess), (size_t)1 << 31) + kSlices - 1) / kSlices + 64;
-        std::vector<uint64_t> counts((size_t)kSlices * kSliceStride);
-        std::vector<int64_t> sliceoff((size_t)kSlices + 1);
-        for (;;) {
+        std::vector<uint64_t> counts(ncounter);
+        uint32_t errbits = 0;
+        for (bool again = false;; again = true) {
             ensure(d_evkey, slice_cap * kSlices); ensure(d_evval, slice_cap * kSlices);
-            be.memset(d_counter.p, 0, 8 * (size_t)kSlices * kSliceStride);
+            if (again) be.memset(d_counter.p, 0, 8 * (size_t)kSlices * kSliceStride);
             be.mark("seed_extend");
             be.launch("seed_extend", nunits * 64,
                       SeedExtend{P, d_R.p, d_units.p, d_slots.p, d_filter.p, d_next.p, d_rep.p, d_repeated.p,
-                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err.p, work_budget,
+                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err, work_budget,
                                  getenv("PM_DEBUG_SEED") ? atoi(getenv("PM_DEBUG_SEED")) : 0});
             if (!no_small)
                 be.launch("small_pair_events", npairs * 2,
                           SmallPairEvents{P, d_R.p, d_starts.p, d_lens.p, ngen, d_rep.p, d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, g_first, g_last});
-            be.d2h(counts.data(), d_counter.p, 8 * counts.size());
+            be.mark("sort");
+            be.launch_wave("slice_offsets", 1, SliceOffsets{d_counter.p, d_sliceoff.p});
+            be.d2h(counts.data(), d_counter.p, 8 * counts.size());            // round trip 1: event counts + error word
             uint64_t worst = 0;
             nev = 0;
-            for (int sl = 0; sl < kSlices; sl++) { uint64_t c = counts[(size_t)sl * kSliceStride]; sliceoff[(size_t)sl] = (int64_t)nev; nev += c; worst = std::max(worst, c); }
-            sliceoff[(size_t)kSlices] = (int64_t)nev;
+            for (int sl = 0; sl < kSlices; sl++) { const uint64_t c = counts[(size_t)sl * kSliceStride]; nev += c; worst = std::max(worst, c); }
+            errbits = (uint32_t)counts[(size_t)kSlices * kSliceStride];
             if (worst <= slice_cap) break;
             slice_cap = (size_t)(worst + worst / 8 + 64);
         }
         ev_cap_hint = (size_t)(nev + nev / 4);
         last_events = (int64_t)nev;
-        uint32_t errbits = 0;
-        be.d2h(&errbits, d_err.p, 4);
-        if (errbits & kErrWork) { error = "per-thread work budget exceeded (degenerate repeat structure in a region)"; return -5; }
+        // a rank of a sharded run that ran out of budget must not leave the others waiting in the collectives: the
+        // verdict travels with the first exchange (below) and every rank returns the error together
+        const bool sharded = coll.world > 1;
+        if ((errbits & kErrWork) && !sharded) { error = "per-thread work budget exceeded (degenerate repeat structure in a region)"; return -5; }
 
-        be.mark("sort");
         ensure(d_evkey2, std::max<size_t>(nev, 1)); ensure(d_evval2, std::max<size_t>(nev, 1));
         ensure(d_evkey3, std::max<size_t>(nev, 1)); ensure(d_evval3, std::max<size_t>(nev, 1));
         const int keybits = bits_for((uint64_t)npairs) + lbits + 1;
         uint64_t *skey = d_evkey3.p, *sval = d_evval3.p;
         if (nev > 0) {
-            be.h2d(d_sliceoff.p, sliceoff.data(), 8 * sliceoff.size());
             be.launch("compact_events", (int64_t)nev, CompactEvents{d_evkey.p, d_evval.p, d_sliceoff.p, (uint64_t)slice_cap, d_evkey2.p, d_evval2.p});
             be.sort_pairs(d_evkey2.p, d_evkey3.p, d_evval2.p, d_evval3.p, (size_t)nev, keybits);
         }
@@ -301,10 +334,10 @@ public:
         ensure(d_lo, (size_t)npairs + 1);
         be.launch("pair_bounds", npairs, PairBounds{skey, (int64_t)nev, lbits, npairs, d_lo.p});
         ensure(d_state, std::max<size_t>(nev, 1)); ensure(d_emax, std::max<size_t>(nev, 1));
-        const int64_t nchunks = ((int64_t)nev + kChunk - 1) / kChunk;
-        ensure(d_summary, (size_t)std::max<int64_t>(nchunks, 1)); ensure(d_startshere, (size_t)std::max<int64_t>(nchunks, 1));
-        be.launch("chunk_reduce", nchunks, ChunkReduce{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p});
-        be.launch("chunk_scan", nchunks, ChunkScan{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p, d_state.p, d_emax.p});
+        const int64_t nscan = ((int64_t)nev + kChunk - 1) / kChunk;
+        ensure(d_summary, (size_t)std::max<int64_t>(nscan, 1)); ensure(d_startshere, (size_t)std::max<int64_t>(nscan, 1));
+        be.launch("chunk_reduce", nscan, ChunkReduce{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p});
+        be.launch("chunk_scan", nscan, ChunkScan{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p, d_state.p, d_emax.p});
 
         if (want_events) {   // parity hook (pm_find_events): sorted events + rep'
             ev_key_h.resize((size_t)nev); ev_val_h.resize((size_t)nev); rep_h.resize((size_t)npos);
@@ -319,16 +352,20 @@ public:
             be.launch("mumi_coverage", npairs, MumiCoverage{d_R.p, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, ngen, d_cov.p});
             mumi_covered.resize((size_t)npairs);
             be.d2h(mumi_covered.data(), d_cov.p, 8 * (size_t)npairs);
-            if (coll.world > 1) {   // every rank computed its own genome block: gather the blocks
+            if (sharded) {   // every rank computed its own genome block: gather the blocks (+ the ranks' error words)
                 int widest = 0;
                 for (int r = 0; r < coll.world; r++) { int a, b; shard_range(ngen, r, coll.world, &a, &b); widest = std::max(widest, b - a); }
-                std::vector<int64_t> send((size_t)std::max(widest, 1), 0), recv((size_t)std::max(widest, 1) * (size_t)coll.world);
+                const size_t per = (size_t)std::max(widest, 1) + 1;
+                std::vector<int64_t> send(per, 0), recv(per * (size_t)coll.world);
                 for (int g = g_first; g < g_last; g++) send[(size_t)(g - g_first)] = mumi_covered[(size_t)(g - 1)];
+                send[per - 1] = errbits;
                 if (coll.allgather(coll.ctx, send.data(), (int64_t)(8 * send.size()), recv.data())) { error = "all-gather of MUMi coverage failed"; return -4; }
                 for (int r = 0; r < coll.world; r++) {
                     int a, b; shard_range(ngen, r, coll.world, &a, &b);
-                    for (int g = a; g < b; g++) mumi_covered[(size_t)(g - 1)] = recv[(size_t)r * send.size() + (size_t)(g - a)];
+                    for (int g = a; g < b; g++) mumi_covered[(size_t)(g - 1)] = recv[(size_t)r * per + (size_t)(g - a)];
+                    errbits |= (uint32_t)recv[(size_t)r * per + per - 1];
                 }
+                if (errbits & kErrWork) { error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
             }
             be.mark(nullptr);
             collect_timing();
@@ -337,57 +374,42 @@ public:
 
         // -- Master.EP, candidates
         be.mark("master_ep");
-        {
-            std::vector<int64_t> cbase((size_t)nreg + 1, 0);
-            for (int64_t r = 0; r < nreg; r++) cbase[(size_t)r + 1] = cbase[(size_t)r] + (((int64_t)R[(size_t)r].nR + (1 << kCoarseShift) - 1) >> kCoarseShift) + 1;
-            const int64_t centries = cbase[(size_t)nreg] * nq;
-            if (centries >= (1ll << 31)) { error = "coarse event index too large"; return -5; }
-            ensure(d_cbase, (size_t)nreg + 1); ensure(d_coarse, (size_t)std::max<int64_t>(centries, 1));
-            be.h2d(d_cbase.p, cbase.data(), 8 * ((size_t)nreg + 1));
-            be.launch("coarse_index", centries, CoarseIndex{d_R.p, nreg, d_cbase.p, nq, skey, d_lo.p, lbits, d_coarse.p});
-        }
-        {
-            // a batch with few tiles is cut until ~512 k threads are in flight (a recursion batch of 30 000 tiles: 16 slices,
-            // 1.35 -> 0.45 ms); the anchor call has 312 500 tiles at 5 Mb and is better off without the atomics (1.6 ms in
-            // one slice, 1.8 in four, 2.3 in eight -- measured, PM_EP_SPLIT forces a count)
-            static const int forced = getenv("PM_EP_SPLIT") ? atoi(getenv("PM_EP_SPLIT")) : 0;
-            const int gspan = std::max(g_last - g_first, 1);
-            int gsplit = forced > 0 ? forced : ntiles >= (1 << 17) ? 1 : (int)std::min<int64_t>(gspan, ((1 << 19) + ntiles - 1) / std::max<int64_t>(ntiles, 1));
-            gsplit = std::max(1, std::min(gsplit, gspan));
-            if (gsplit > 1) be.launch("ep_init", ntiles, EpInit{d_R.p, nreg, d_tilebase.p, d_epm.p});
-            be.launch("master_ep", ntiles * gsplit, MasterEP{d_R.p, nreg, d_tilebase.p, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, ntiles, gsplit});
-        }
-        if (coll.world > 1 && npos > 0) {   // exchange 1: Master.EP = min over the ranks' genome blocks
+        ensure(d_coarse, (size_t)std::max<int64_t>(centries, 1));
+        be.memset(d_coarse.p, 0, 4 * (size_t)std::max<int64_t>(centries, 1));
+        be.launch("coarse_fill", (int64_t)nev, CoarseFill{skey, (int64_t)nev, lbits, d_lo.p, d_R.p, d_cbase.p, nq, d_coarse.p});
+        be.launch_wave("master_ep", nchunks, MasterEP{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last});
+        if (sharded) {   // exchange 1: Master.EP = min over the ranks' genome blocks; the last word carries the error verdict
             be.mark("exchange_ep");
-            std::vector<int32_t> h((size_t)npos);
-            be.d2h(h.data(), d_epm.p, 4 * (size_t)npos);
-            if (coll.allreduce_min_i32(coll.ctx, h.data(), npos)) { error = "all-reduce of Master.EP failed"; return -4; }
-            be.h2d(d_epm.p, h.data(), 4 * (size_t)npos);
+            std::vector<int32_t> h((size_t)npos + 1);
+            if (npos) be.d2h(h.data(), d_epm.p, 4 * (size_t)npos);
+            h[(size_t)npos] = (errbits & kErrWork) ? -1 : 0;
+            if (coll.allreduce_min_i32(coll.ctx, h.data(), npos + 1)) { error = "all-reduce of Master.EP failed"; return -4; }
+            if (h[(size_t)npos] < 0) { error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
+            if (npos) be.h2d(d_epm.p, h.data(), 4 * (size_t)npos);
         }
-        uint64_t ncand = 0;
-        size_t ccap = std::max<size_t>(cand_cap_hint, 1 << 12);
-        for (;;) {
-            ensure(d_cand, ccap); ensure(d_cand2, ccap);
-            be.memset(d_counter.p, 0, 16);
-            be.mark("candidates");
-            be.launch("find_candidates", ntiles, FindCandidates{d_R.p, nreg, d_tilebase.p, d_epm.p, d_cand.p, d_counter.p, (uint64_t)ccap});
-            be.d2h(&ncand, d_counter.p, 8);
-            if (ncand <= ccap) break;
-            ccap = (size_t)(ncand + ncand / 8 + 1024);
-        }
-        cand_cap_hint = std::max(cand_cap_hint, (size_t)(ncand + ncand / 4));
+        be.mark("candidates");
+        const int64_t nwv = (npos + 63) / 64;
+        ensure(d_wmask, (size_t)nwv + 1); ensure(d_wcount, (size_t)nwv + 1); ensure(d_woff, (size_t)nwv + 1);
+        be.launch_wave("cand_mark", nwv, CandMark{d_R.p, nreg, d_posbase.p, npos, d_epm.p, d_wmask.p, d_wcount.p});
+        be.memset(d_wcount.p + nwv, 0, 8);
+        be.exclusive_scan(d_wcount.p, d_woff.p, (size_t)nwv + 1);
+        int64_t ncand_i = 0;
+        be.d2h(&ncand_i, d_woff.p + nwv, 8);                                   // round trip 2: candidate count
+        const uint64_t ncand = (uint64_t)ncand_i;
         last_candidates = (int64_t)ncand;
         if (ncand == 0) { be.mark(nullptr); collect_timing(); return 0; }
-        uint64_t* scand = d_cand.p;
-        be.sort_keys(d_cand.p, d_cand2.p, (size_t)ncand, 32 + bits_for((uint64_t)nreg)); scand = d_cand2.p;
+        ensure(d_cand, (size_t)ncand);
+        be.launch("cand_write", nwv * 64, CandWrite{d_R.p, nreg, d_posbase.p, d_wmask.p, d_woff.p, d_cand.p, ncand});
+        const uint64_t* scand = d_cand.p;        // in (region, k) order by construction
 
         // -- per-candidate genome fold
         be.mark("fold");
-        ensure(d_at, (size_t)ncand * (size_t)nq);
         ensure(d_ok, (size_t)ncand); ensure(d_ok_k, (size_t)ncand); ensure(d_ok_lon, (size_t)ncand);
         ensure(d_osp, (size_t)ncand * (size_t)nq); ensure(d_ofwd, (size_t)ncand * (size_t)nq);
-        be.launch("state_at_candidate", (int64_t)ncand * nq, StateAtCandidate{d_R.p, scand, ngen, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_at.p, d_cbase.p, d_coarse.p});
-        if (coll.world > 1) {   // exchange 2: every rank contributes the (EP,UP,SP) columns of its genome block
+        const GenomeAtK* at = nullptr;
+        if (sharded) {   // exchange 2: every rank contributes the (EP,UP,SP) columns of its genome block
+            ensure(d_at, (size_t)ncand * (size_t)nq);
+            be.launch("state_at_candidate", (int64_t)ncand * nq, StateAtCandidate{d_R.p, scand, ngen, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_at.p, d_cbase.p, d_coarse.p});
             be.mark("exchange_states");
             const size_t nqz = (size_t)nq, cz = (size_t)ncand;
             std::vector<GenomeAtK> all(cz * nqz);
@@ -408,31 +430,57 @@ public:
             }
             be.h2d(d_at.p, all.data(), sizeof(GenomeAtK) * all.size());
             be.mark("fold");
+            at = d_at.p;
         }
-        be.launch("fold_genomes", (int64_t)ncand, FoldGenomes{d_R.p, scand, ngen, d_at.p, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_ok.p});
+        be.launch_wave("fold_candidates", (int64_t)ncand,
+                       FoldCandidates{d_R.p, scand, ngen, at, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_cbase.p, d_coarse.p,
+                                      d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_ok.p});
 
-        // -- accepted candidates, compacted on the device and downloaded straight into the result's (pinned) blocks
+        // -- accepted candidates, compacted on the device and downloaded straight into the result's blocks
         be.mark("compact");
         ensure(d_okcnt, (size_t)ncand + 1); ensure(d_okpos, (size_t)ncand + 1);
         be.launch("ok_count", (int64_t)ncand + 1, OkCount{d_ok.p, (int64_t)ncand, d_okcnt.p});
         be.exclusive_scan(d_okcnt.p, d_okpos.p, (size_t)ncand + 1);
         int64_t nok = 0;
-        be.d2h(&nok, d_okpos.p + ncand, 8);
-        const size_t nokz = (size_t)nok, nqz2 = (size_t)nq;
+        be.d2h(&nok, d_okpos.p + ncand, 8);                                    // round trip 3: accepted count
+        const size_t nokz = (size_t)nok, nqz2 = (size_t)nq, ngz = (size_t)ngen;
         ensure(d_creg, std::max<size_t>(nokz, 1)); ensure(d_ck, std::max<size_t>(nokz, 1)); ensure(d_clon, std::max<size_t>(nokz, 1));
-        ensure(d_csp, std::max<size_t>(nokz * nqz2, 1)); ensure(d_cfwd, std::max<size_t>(nokz * nqz2, 1));
-        be.launch("compact_candidates", (int64_t)ncand * nq,
-                  CompactCandidates{scand, d_ok.p, d_okpos.p, nq, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_creg.p, d_ck.p, d_clon.p, d_csp.p, d_cfwd.p});
-        be.mark("download");
         std::vector<int32_t> reg_h(nokz);
         out->kb = pool->take(4 * nokz); out->lonb = pool->take(4 * nokz);
-        out->spb = pool->take(4 * nokz * nqz2); out->fwdb = pool->take(nokz * nqz2);
-        be.d2h(reg_h.data(), d_creg.p, 4 * nokz);
-        be.d2h(out->kb.p, d_ck.p, 4 * nokz);
-        be.d2h(out->lonb.p, d_clon.p, 4 * nokz);
-        be.d2h(out->spb.p, d_csp.p, 4 * nokz * nqz2);
-        be.d2h(out->fwdb.p, d_cfwd.p, nokz * nqz2);
+        out->rows = want_rows; out->dirty_known = false;
+        if (!want_rows) {
+            ensure(d_csp, std::max<size_t>(nokz * nqz2, 1)); ensure(d_cfwd, std::max<size_t>(nokz * nqz2, 1));
+            be.launch("compact_sp", (int64_t)ncand * nq,
+                      CompactSp{scand, d_ok.p, d_okpos.p, nq, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_creg.p, d_ck.p, d_clon.p, d_csp.p, d_cfwd.p});
+            be.mark("download");
+            out->spb = pool->take(4 * nokz * nqz2); out->fwdb = pool->take(nokz * nqz2);
+            be.d2h_async(out->spb.p, d_csp.p, 4 * nokz * nqz2);
+            be.d2h_async(out->fwdb.p, d_cfwd.p, nokz * nqz2);
+        } else {
+            ensure(d_csp, std::max<size_t>(nokz * ngz, 1)); ensure(d_cfwd, std::max<size_t>(nokz * ngz, 1)); ensure(d_cflags, std::max<size_t>(nokz, 1));
+            be.memset(d_cflags.p, 0, 4 * std::max<size_t>(nokz, 1));
+            be.launch("compact_candidates", (int64_t)ncand * ngen,
+                      CompactCandidates{scand, d_ok.p, d_okpos.p, ngen, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_starts.p, d_lens.p, d_glen,
+                                        d_creg.p, d_ck.p, d_clon.p, d_csp.p, d_cfwd.p, d_cflags.p});
+            if (nreg == 1 && nok >= dirty_min) {     // a long list of one region (the anchor call): the cheap overlap test on the device
+                const int64_t nblocks = (nok + kDirtyBlock - 1) / kDirtyBlock, groups = (ngen + 63) / 64;
+                ensure(d_bmax, (size_t)nblocks * ngz); ensure(d_bmin, (size_t)nblocks * ngz);
+                be.launch_wave("dirty_extent", nblocks * groups, DirtyExtent{d_csp.p, d_clon.p, d_cflags.p, nok, ngen, d_bmax.p, d_bmin.p});
+                be.launch_wave("dirty_prefix", groups, DirtyPrefix{nblocks, ngen, d_bmax.p, d_bmin.p});
+                be.launch_wave("dirty_mark", nblocks * groups, DirtyMark{d_csp.p, d_clon.p, nok, ngen, d_bmax.p, d_bmin.p, d_cflags.p});
+                out->dirty_known = true;
+            }
+            be.mark("download");
+            out->startb = pool->take(4 * nokz * ngz); out->strandb = pool->take(nokz * ngz); out->flagsb = pool->take(4 * nokz);
+            be.d2h_async(out->startb.p, d_csp.p, 4 * nokz * ngz);
+            be.d2h_async(out->strandb.p, d_cfwd.p, nokz * ngz);
+            be.d2h_async(out->flagsb.p, d_cflags.p, 4 * nokz);
+        }
+        be.d2h_async(reg_h.data(), d_creg.p, 4 * nokz);
+        be.d2h_async(out->kb.p, d_ck.p, 4 * nokz);
+        be.d2h_async(out->lonb.p, d_clon.p, 4 * nokz);
         be.mark(nullptr);
+        be.sync();                                                             // round trip 4: the results
         for (size_t w = 0; w < nokz; w++) out->off[(size_t)reg_h[w] + 1]++;
         for (int64_t r = 0; r < nreg; r++) out->off[(size_t)r + 1] += out->off[(size_t)r];
         out->total = out->off[(size_t)nreg];
@@ -445,29 +493,37 @@ public:
     std::vector<int32_t> rep_h;
     int ev_lbits = 0;
     int64_t work_budget = 1 << 22;
+    // shortest one-region candidate list that gets the device overlap test (the host's PARSNP_PARALLEL_MIN; PM_DIRTY_MIN: test hook)
+    int64_t dirty_min = getenv("PM_DIRTY_MIN") ? atol(getenv("PM_DIRTY_MIN")) : 4096;
 
     void release() {
-        auto drop = [&](auto& b) { if (b.p) be.free(b.p); b.p = nullptr; b.cap = 0; };
-        drop(d_R); drop(d_starts); drop(d_lens); drop(d_posbase); drop(d_tilebase); drop(d_err); drop(d_slots); drop(d_filter); drop(d_next);
-        drop(d_rep); drop(d_run); drop(d_repeated); drop(d_epm); drop(d_ucount); drop(d_uoff); drop(d_units); drop(d_counter); drop(d_evkey); drop(d_evval);
-        drop(d_evkey2); drop(d_evval2); drop(d_evkey3); drop(d_evval3); drop(d_sliceoff); drop(d_lo); drop(d_cov); drop(d_state); drop(d_summary); drop(d_startshere); drop(d_emax); drop(d_cand); drop(d_cand2); drop(d_at); drop(d_ok);
-        drop(d_ok_k); drop(d_ok_lon); drop(d_osp); drop(d_ofwd);
+        for (BufBase* b : all_bufs) { if (b->raw) be.free(b->raw); b->raw = nullptr; b->cap = 0; }
         if (blk) be.free(blk);
         if (d_goff) be.free(d_goff);
         if (d_glen) be.free(d_glen);
         blk = nullptr; d_goff = nullptr; d_glen = nullptr;
     }
 
+    // device allocation failure inside run(): mapped to PM_ENOMEM at the C ABI (abi_glue.h), never abort()
+    struct DeviceOutOfMemory { size_t bytes; };
+
 private:
     B& be;
-    template <class T> struct Buf { T* p = nullptr; size_t cap = 0; };
+    // every device buffer of the engine registers itself here, so release() cannot miss one
+    struct BufBase { void* raw = nullptr; size_t cap = 0; };
+    std::vector<BufBase*> all_bufs;
+    template <class T> struct Buf : BufBase {
+        T* p = nullptr;
+    };
     template <class T> void ensure(Buf<T>& b, size_t n) {
         if (n <= b.cap && b.p) return;
-        if (b.p) be.free(b.p);
-        size_t want = n + n / 4 + 16;
-        b.p = (T*)be.alloc(want * sizeof(T));
-        b.cap = b.p ? want : 0;
-        if (!b.p) { fprintf(stderr, "parsnp engine: device allocation of %zu bytes failed\n", want * sizeof(T)); abort(); }
+        if (std::find(all_bufs.begin(), all_bufs.end(), (BufBase*)&b) == all_bufs.end()) all_bufs.push_back(&b);
+        if (b.raw) be.free(b.raw);
+        b.raw = nullptr; b.p = nullptr; b.cap = 0;
+        const size_t want = n + n / 4 + 16;
+        b.raw = be.alloc(want * sizeof(T));
+        if (!b.raw) throw DeviceOutOfMemory{want * sizeof(T)};
+        b.p = (T*)b.raw; b.cap = want;
     }
     void collect_timing() { timing = be.collect(); }
 
@@ -475,13 +531,15 @@ private:
     int64_t total_words = 0;
     Packed P{};
     size_t ev_cap_hint = 0, cand_cap_hint = 0;
-    Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase, d_tilebase; Buf<uint32_t> d_err;
+    Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase;
     Buf<uint64_t> d_slots; Buf<uint32_t> d_filter, d_repeated; Buf<int32_t> d_next, d_rep, d_run, d_epm;
     Buf<int64_t> d_ucount, d_uoff; Buf<UnitRec> d_units;
     Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2, d_evkey3, d_evval3; Buf<int64_t> d_sliceoff;
     Buf<int64_t> d_lo, d_cov; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
-    Buf<uint64_t> d_cand, d_cand2; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
+    Buf<uint64_t> d_cand; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
+    Buf<uint64_t> d_wmask; Buf<int64_t> d_wcount, d_woff;
     Buf<int64_t> d_okcnt, d_okpos, d_cbase; Buf<int32_t> d_coarse; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;
+    Buf<uint32_t> d_cflags; Buf<int32_t> d_bmax, d_bmin;
 };
 
 }  // namespace pm

@@ -21,6 +21,13 @@ __global__ __launch_bounds__(256) void pm_kernel(F f, int64_t n) {
     if (tid < n) f(tid);
 }
 
+// one wavefront per work item: 64-thread workgroups, f.wave(item) with the lanes cooperating (shuffles, LDS)
+template <class F>
+__global__ __launch_bounds__(64) void pm_wave_kernel(F f, int64_t n) {
+    const int64_t w = (int64_t)blockIdx.x;
+    if (w < n) f.wave(w);
+}
+
 struct HipBackend {
     hipStream_t stream = nullptr;
     std::string err;
@@ -59,6 +66,7 @@ struct HipBackend {
     void memset(void* p, int v, size_t n) { check(hipMemsetAsync(p, v, n, stream), "hipMemsetAsync"); }
     void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync"); }
     void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); check(hipStreamSynchronize(stream), "sync"); }
+    void d2h_async(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); }
     void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
     // page-locked block for the request rows of a call (kept, grown on demand); h2d_staged queues the DMA without waiting:
     // the block is not written again before the call's last synchronisation
@@ -79,6 +87,12 @@ struct HipBackend {
         int64_t blocks = (n + 255) / 256;
         if (blocks > 0x7fffffffll) { if (err.empty()) err = std::string("grid too large: ") + name; return; }
         hipLaunchKernelGGL(pm_kernel<F>, dim3((unsigned)blocks), dim3(256), 0, stream, f, n);
+        check(hipGetLastError(), name);
+    }
+    template <class F> void launch_wave(const char* name, int64_t n, F f) {
+        if (n <= 0) return;
+        if (n > 0x7fffffffll) { if (err.empty()) err = std::string("grid too large: ") + name; return; }
+        hipLaunchKernelGGL(pm_wave_kernel<F>, dim3((unsigned)n), dim3(64), 0, stream, f, n);
         check(hipGetLastError(), name);
     }
     void need_tmp(size_t n) {

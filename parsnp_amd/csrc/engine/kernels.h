@@ -133,6 +133,39 @@ PM_HD void atomic_or32(uint32_t* p, uint32_t v) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ wavefront steps
+// The kernels below are launched one WAVEFRONT per work item (64-thread workgroups, `wave(w)` instead of
+// `operator()(tid)`); lanes cooperate through shuffles and LDS.  The host emulation (tests only) runs `wave(w)` as one
+// sequential loop that computes the same values.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline int32_t wave_incl_sum(int32_t x) {
+    const int lane = (int)__lane_id();
+    for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    return x;
+}
+__device__ inline int64_t wave_incl_sum64(int64_t x) {
+    const int lane = (int)__lane_id();
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t y = ((int64_t)__shfl_up((int)(x >> 32), d, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+__device__ inline int32_t wave_incl_min(int32_t x) {
+    const int lane = (int)__lane_id();
+    for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(x, d, 64); if (lane >= d && y < x) x = y; }
+    return x;
+}
+__device__ inline int32_t wave_all_max(int32_t x) {
+    for (int d = 32; d >= 1; d >>= 1) { const int32_t y = __shfl_xor(x, d, 64); if (y > x) x = y; }
+    return x;
+}
+__device__ inline uint32_t wave_all_or(uint32_t x) {
+    for (int d = 32; d >= 1; d >>= 1) x |= (uint32_t)__shfl_xor((int)x, d, 64);
+    return x;
+}
+#endif
+
 // ------------------------------------------------------------------------------------------ shared structures
 struct alignas(16) SeqBlock { uint64_t b2; uint32_t nm; uint32_t pad; };   // 32 bases
 struct Packed {            // the resident genomes
@@ -151,14 +184,12 @@ struct RegionInfo {        // one per region of a batch
     uint32_t tmask;        // hash-table slice size - 1 (power of two, >= 1.5 nR)
     int64_t tbase;         // hash-table slice start
     int64_t posbase;       // start of this region in the per-reference-position arrays
-    int64_t tile_base;     // first 16-position tile of this region
     int64_t fbase;         // first uint32 word of this region's presence filter
     uint32_t fmask;        // filter bits - 1 (power of two, >= 8 nR): one hashed bit per K-mer of the reference substring
     uint32_t pad_;
 };
 
 constexpr uint64_t kEmpty = ~0ull;
-constexpr int kTile = 16;          // reference positions per master-fold thread
 #ifndef PM_UNIT
 #define PM_UNIT 64
 #endif
@@ -796,6 +827,25 @@ struct SmallPairEvents {
     }
 };
 
+// exclusive prefix of the kSlices event counters (one wavefront; no host round trip between the event search and the gather)
+struct SliceOffsets {
+    const uint64_t* counters; int64_t* off;     // off[kSlices + 1]
+    PM_HD void wave(int64_t) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int lane = (int)__lane_id();
+        constexpr int per = kSlices / 64;
+        int64_t c[per]; int64_t sum = 0;
+        for (int i = 0; i < per; i++) { c[i] = (int64_t)counters[(size_t)(lane * per + i) * kSliceStride]; sum += c[i]; }
+        int64_t run = wave_incl_sum64(sum) - sum;
+        for (int i = 0; i < per; i++) { off[lane * per + i] = run; run += c[i]; }
+        if (lane == 63) off[kSlices] = run;
+#else
+        int64_t run = 0;
+        for (int i = 0; i < kSlices; i++) { off[i] = run; run += (int64_t)counters[(size_t)i * kSliceStride]; }
+        off[kSlices] = run;
+#endif
+    }
+};
 // gather the kSlices sub-buffers into one contiguous array.  tid = output event; off[kSlices+1] = prefix of the counts
 struct CompactEvents {
     const uint64_t* key_in; const uint64_t* val_in; const int64_t* off; uint64_t slice_cap; uint64_t* key_out; uint64_t* val_out;
@@ -951,153 +1001,278 @@ struct MumiCoverage {
 
 // ------------------------------------------------------------------------------------------ Master.EP
 // Master[k].EP = min over query genomes of max(EP_fwd[k], EP_rev[k])  (Intersect_UM's min fold mum.c:163 +
-// Merge_Master mum.c:92-123; order independent).  tid = one tile of 16 reference positions.
-// Coarse index over the sorted events of every (region, genome) pair: coarse[..b] = number of the pair's events with
-// l < b * 1024.  MasterEP's per-tile binary search then runs over the events of one 1024-position block (a handful)
-// instead of all events of the pair (17 dependent probes per genome at 5 Mb).  tid = table entry; the entries of region r
-// are [cbase[r]*nq, cbase[r+1]*nq), genome-major, blocks_r + 1 entries per genome.
-constexpr int kCoarseShift = 10;
-struct CoarseIndex {
-    const RegionInfo* R; int64_t nregions; const int64_t* cbase; int32_t nq;
-    const uint64_t* key; const int64_t* lo; int lbits; int32_t* coarse;
-    PM_HD void operator()(int64_t tid) const {
-        const int64_t r = upper_slot(cbase, nregions, tid / nq);
-        const int64_t per = cbase[r + 1] - cbase[r];            // blocks + 1
-        const int64_t rel = tid - cbase[r] * nq;
-        const int g = (int)(rel / per); const int64_t b = rel % per;
-        const int64_t pair = r * nq + g;
-        int64_t a = lo[pair], e = lo[pair + 1];
-        if (b == per - 1) { coarse[tid] = (int32_t)(e - a); return; }
-        const uint64_t want = (((uint64_t)pair << lbits) | (uint64_t)(b << kCoarseShift)) << 1;     // first event with l >= b * 1024
-        int64_t x = a, y = e;
-        while (x < y) { int64_t mid = (x + y) >> 1; if (key[mid] < want) x = mid + 1; else y = mid; }
-        coarse[tid] = (int32_t)(x - a);
+// Merge_Master mum.c:92-123; order independent).
+//
+// Coarse index over the sorted events of every (region, genome) pair: coarse[.., b, g] = number of the pair's events
+// with l < b * 256.  The entries of region r are [cbase[r]*nq, cbase[r+1]*nq), BLOCK-major (per block the nq genomes
+// side by side: a wavefront with its lanes over the genomes reads them coalesced), blocks_r + 1 rows.
+// Written by streaming over the sorted events (tid = event): event i of a pair closes every block row between its
+// predecessor's block and its own; the pair's last event closes the remaining rows with the pair's event count.  Rows of
+// pairs without events stay at the 0 the table was cleared to.
+constexpr int kCoarseShift = 8;
+constexpr int kChunkPos = 1 << kCoarseShift;     // reference positions per MasterEP wavefront = one coarse block
+struct CoarseFill {
+    const uint64_t* key; int64_t nev; int lbits; const int64_t* lo; const RegionInfo* R; const int64_t* cbase; int32_t nq; int32_t* coarse;
+    PM_HD void operator()(int64_t i) const {
+        const uint64_t lmask = (1ull << lbits) - 1;
+        const uint64_t k = key[i];
+        const int64_t pair = (int64_t)(k >> (lbits + 1));
+        const int64_t r = pair / nq; const int g = (int)(pair % nq);
+        const int64_t rows = cbase[r + 1] - cbase[r];              // blocks + 1
+        int32_t* col = coarse + cbase[r] * nq + g;                  // row b of this pair: col[b * nq]
+        const int64_t rank = i - lo[pair];
+        const int64_t b = (int64_t)((k >> 1) & lmask) >> kCoarseShift;
+        int64_t bprev = -1;                                         // first event of the pair: rows 0..b are 0 already
+        if (rank > 0) bprev = (int64_t)((key[i - 1] >> 1) & lmask) >> kCoarseShift;
+        else bprev = b;
+        for (int64_t x = bprev + 1; x <= b; x++) col[x * nq] = (int32_t)rank;
+        if (i + 1 == nev || (int64_t)(key[i + 1] >> (lbits + 1)) != pair)
+            for (int64_t x = b + 1; x < rows; x++) col[x * nq] = (int32_t)(rank + 1);
     }
 };
-// The genomes of a tile are a serial chain of dependent loads (pair bounds, coarse entry, probe, emax): ~200 x 6 memory
-// latencies per thread, and a recursion batch has only ~30 000 tiles -- a fraction of the 524 288 thread slots.  So the
-// genome loop is cut into `gsplit` slices, one thread each (tid = slice * ntiles + tile: a wavefront still walks
-// neighbouring tiles of one slice), and the slices meet in an atomic min on Master.EP, which EpInit has set to nR.
-struct EpInit {
-    const RegionInfo* R; int64_t nregions; const int64_t* tile_base; int32_t* epm;
-    PM_HD void operator()(int64_t tid) const {
-        int64_t r = upper_slot(tile_base, nregions, tid);
-        const RegionInfo& ri = R[r];
-        int32_t k0 = (int32_t)(tid - ri.tile_base) * kTile;
-        for (int t = 0; t < kTile; t++) if (k0 + t < ri.nR) epm[ri.posbase + k0 + t] = ri.nR;
-    }
-};
+// chunk (= wavefront) w of the batch -> its region: chunks of region r are [cbase[r] - r, cbase[r+1] - (r+1))
+PM_HD int64_t region_of_chunk(const int64_t* cbase, int64_t nregions, int64_t w) {
+    int64_t lo = 0, hi = nregions;
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (cbase[mid] - mid <= w) lo = mid; else hi = mid; }
+    return lo;
+}
+// One wavefront per chunk of 256 reference positions (lane = 4 consecutive positions).  The events of the chunk are
+// staged in LDS, 64 genomes at a time (lanes over the genomes: coarse rows, pair bounds and carry-in values are
+// coalesced loads; every event of the batch is read from HBM exactly once); then all lanes walk one genome's entries
+// together (LDS broadcast reads) and keep, per position, the value of the last entry that starts at or before it
+// -- the genome's EP there -- folding it into the running minimum.  Replaces a thread per 16 positions that walked the
+// genomes serially through ~6 dependent global loads each (1.6 ms for the 5 Mb anchor call).
+constexpr int kEpCap = 2048;                      // staged entries per round (16 KB of LDS)
 struct MasterEP {
-    const RegionInfo* R; int64_t nregions; const int64_t* tile_base;   // tile_base[nregions+1]
+    const RegionInfo* R; int64_t nregions;
     int32_t ngen; const uint64_t* key; const int64_t* lo; const int32_t* emax; int lbits; int32_t* epm;
     const int64_t* cbase; const int32_t* coarse;
     int32_t g_first, g_last;   // sharded run: the min over the other genomes arrives by all-reduce
-    int64_t ntiles; int32_t gsplit;   // gsplit == 1: one thread per tile, plain stores
-    PM_HD void operator()(int64_t tid_all) const {
-        const int64_t slice = tid_all / ntiles, tid = tid_all - slice * ntiles;
-        int64_t r = upper_slot(tile_base, nregions, tid);
+    PM_HD void wave(int64_t w) const {
+        const int32_t nq = ngen - 1;
+        const int64_t r = region_of_chunk(cbase, nregions, w);
         const RegionInfo& ri = R[r];
-        int32_t k0 = (int32_t)(tid - ri.tile_base) * kTile;
-        int32_t ep[kTile];
-        for (int t = 0; t < kTile; t++) ep[t] = ri.nR;
+        const int64_t b = w - (cbase[r] - r);
+        const int32_t k0 = (int32_t)(b << kCoarseShift);
         const uint64_t lmask = (1ull << lbits) - 1;
-        const int64_t per = cbase[r + 1] - cbase[r];
-        const int64_t cblock = k0 >> kCoarseShift;             // a tile of 16 positions lies inside one 1024-position block
-        const int gspan = g_last - g_first;
-        const int ga = g_first - 1 + (int)((int64_t)gspan * slice / gsplit), gb = g_first - 1 + (int)((int64_t)gspan * (slice + 1) / gsplit);
-        for (int g = ga; g < gb; g++) {
-            int64_t pair = r * (ngen - 1) + g;
-            const int64_t first = lo[pair], end = lo[pair + 1];
-            const int32_t* cg = coarse + cbase[r] * (ngen - 1) + (int64_t)g * per + cblock;
-            int64_t a = first + cg[0], b = first + cg[1];
-            // first event with l > k0 (it is inside the block, or the first event of the next block)
-            uint64_t want = ((((uint64_t)pair << lbits) | (uint64_t)k0) << 1) | 1ull;
-            while (a < b) { int64_t mid = (a + b) >> 1; if (key[mid] <= want) a = mid + 1; else b = mid; }
-            int32_t cur = a > first ? emax[a - 1] : 0;
-            int64_t e = a;
-            for (int t = 0; t < kTile; t++) {
-                int32_t k = k0 + t;
-                while (e < end && (int32_t)((key[e] >> 1) & lmask) <= k) { cur = emax[e]; e++; }
-                if (cur < ep[t]) ep[t] = cur;
+        const int32_t* row = coarse + cbase[r] * nq + b * nq;
+        const int ga = g_first - 1, gb = g_last - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __shared__ uint64_t s_ent[kEpCap];
+        __shared__ int32_t s_off[65];
+        __shared__ int32_t s_vin[64];
+        const int lane = (int)__lane_id();
+        const int32_t p0 = lane * 4;               // first of this lane's positions, relative to k0
+        int32_t ep[4] = {ri.nR, ri.nR, ri.nR, ri.nR};
+        for (int g0 = ga; g0 < gb; g0 += 64) {
+            const int g = g0 + lane;
+            const bool act = g < gb;
+            int64_t a = 0; int32_t cnt = 0, vin = 0;
+            if (act) {
+                const int64_t first = lo[r * nq + g];
+                a = first + row[g]; cnt = row[nq + g] - row[g];
+                vin = a > first ? emax[a - 1] : 0;
+            }
+            const int32_t incl = wave_incl_sum(cnt);
+            const int32_t total = __shfl(incl, 63, 64);
+            const int here = gb - g0 < 64 ? gb - g0 : 64;
+            if (total <= kEpCap) {
+                s_off[lane] = incl - cnt; s_vin[lane] = vin;
+                if (lane == 63) s_off[64] = total;
+                for (int32_t i = 0; i < cnt; i++) {
+                    const int32_t l = (int32_t)((key[a + i] >> 1) & lmask) - k0;
+                    s_ent[incl - cnt + i] = ((uint64_t)(uint32_t)l << 32) | (uint32_t)emax[a + i];
+                }
+                __syncthreads();
+                for (int gg = 0; gg < here; gg++) {
+                    const int32_t o0 = s_off[gg], o1 = s_off[gg + 1];
+                    int32_t v0 = s_vin[gg], v1 = v0, v2 = v0, v3 = v0;
+                    for (int32_t i = o0; i < o1; i++) {
+                        const uint64_t e = s_ent[i];
+                        const int32_t l = (int32_t)(e >> 32), v = (int32_t)(uint32_t)e;
+                        if (l <= p0) v0 = v;
+                        if (l <= p0 + 1) v1 = v;
+                        if (l <= p0 + 2) v2 = v;
+                        if (l <= p0 + 3) v3 = v;
+                    }
+                    ep[0] = v0 < ep[0] ? v0 : ep[0]; ep[1] = v1 < ep[1] ? v1 : ep[1];
+                    ep[2] = v2 < ep[2] ? v2 : ep[2]; ep[3] = v3 < ep[3] ? v3 : ep[3];
+                }
+                __syncthreads();
+            } else {
+                // more events than the staging area holds (degenerate repeats): the same walk straight from global memory
+                for (int gg = 0; gg < here; gg++) {
+                    const int64_t aa = ((int64_t)__shfl((int)(a >> 32), gg, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)a, gg, 64);
+                    const int32_t cc = __shfl(cnt, gg, 64);
+                    int32_t v0 = __shfl(vin, gg, 64), v1 = v0, v2 = v0, v3 = v0;
+                    for (int32_t i = 0; i < cc; i++) {
+                        const int32_t l = (int32_t)((key[aa + i] >> 1) & lmask) - k0, v = emax[aa + i];
+                        if (l <= p0) v0 = v;
+                        if (l <= p0 + 1) v1 = v;
+                        if (l <= p0 + 2) v2 = v;
+                        if (l <= p0 + 3) v3 = v;
+                    }
+                    ep[0] = v0 < ep[0] ? v0 : ep[0]; ep[1] = v1 < ep[1] ? v1 : ep[1];
+                    ep[2] = v2 < ep[2] ? v2 : ep[2]; ep[3] = v3 < ep[3] ? v3 : ep[3];
+                }
             }
         }
-        if (gsplit == 1) { for (int t = 0; t < kTile; t++) if (k0 + t < ri.nR) epm[ri.posbase + k0 + t] = ep[t]; }
-        else { for (int t = 0; t < kTile; t++) if (k0 + t < ri.nR && ep[t] < ri.nR) atomic_min32(&epm[ri.posbase + k0 + t], ep[t]); }
+        for (int t = 0; t < 4; t++) if (k0 + p0 + t < ri.nR) epm[ri.posbase + k0 + p0 + t] = ep[t];
+#else
+        for (int32_t k = k0; k < k0 + kChunkPos && k < ri.nR; k++) {
+            int32_t ep = ri.nR;
+            for (int g = ga; g < gb; g++) {
+                const int64_t first = lo[r * nq + g];
+                const int64_t a = first + row[g], e = first + row[nq + g];
+                int32_t v = a > first ? emax[a - 1] : 0;
+                for (int64_t i = a; i < e; i++) if ((int32_t)((key[i] >> 1) & lmask) <= k) v = emax[i];
+                if (v < ep) ep = v;
+            }
+            epm[ri.posbase + k] = ep;
+        }
+#endif
     }
 };
 
 // Candidate positions: Master[k].EP > Master[k-1].EP and EP-k >= minsize (parsnp.cpp:1657-1663; the UP < EP part
-// of the test is applied in FoldGenomes).  tid = tile.
-struct FindCandidates {
-    const RegionInfo* R; int64_t nregions; const int64_t* tile_base; const int32_t* epm;
-    uint64_t* cand; uint64_t* cand_count; uint64_t cand_cap;
-    PM_HD void operator()(int64_t tid) const {
-        int64_t r = upper_slot(tile_base, nregions, tid);
-        const RegionInfo& ri = R[r];
-        int32_t k0 = (int32_t)(tid - ri.tile_base) * kTile;
-        int32_t prev = k0 > 0 ? epm[ri.posbase + k0 - 1] : 0;
-        for (int t = 0; t < kTile && k0 + t < ri.nR; t++) {
-            int32_t k = k0 + t, e = epm[ri.posbase + k];
-            if (e > prev && e - k >= ri.minsize) {
-                uint64_t slot = atomic_add64(cand_count, 1);
-                if (slot < cand_cap) cand[slot] = ((uint64_t)r << 32) | (uint32_t)k;
-            }
-            prev = e;
+// of the test is applied in the fold).  Two passes without atomics, output in (region, k) order -- what the sort
+// after the old one-counter version produced: CandMark (tid = flat reference position) leaves one 64-bit hit mask and one
+// count per wavefront, an exclusive scan turns the counts into offsets, CandWrite places the hits.
+PM_HD bool cand_hit(const RegionInfo& ri, const int32_t* epm, int32_t l) {
+    const int32_t e = epm[ri.posbase + l];
+    const int32_t prev = l > 0 ? epm[ri.posbase + l - 1] : 0;
+    return e > prev && e - l >= ri.minsize;
+}
+struct CandMark {
+    const RegionInfo* R; int64_t nregions; const int64_t* posbase; int64_t npos; const int32_t* epm;
+    uint64_t* wmask; int64_t* wcount;      // per 64 positions
+    PM_HD void wave(int64_t w) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int64_t tid = w * 64 + (int64_t)__lane_id();
+        bool hit = false;
+        if (tid < npos) { const RegionInfo& ri = R[upper_slot(posbase, nregions, tid)]; hit = cand_hit(ri, epm, (int32_t)(tid - ri.posbase)); }
+        const unsigned long long m = __ballot(hit);
+        if (__lane_id() == 0) { wmask[w] = m; wcount[w] = __popcll(m); }
+#else
+        uint64_t m = 0;
+        for (int t = 0; t < 64 && w * 64 + t < npos; t++) {
+            const int64_t tid = w * 64 + t;
+            const RegionInfo& ri = R[upper_slot(posbase, nregions, tid)];
+            if (cand_hit(ri, epm, (int32_t)(tid - ri.posbase))) m |= 1ull << t;
         }
+        wmask[w] = m; wcount[w] = __builtin_popcountll(m);
+#endif
+    }
+};
+struct CandWrite {
+    const RegionInfo* R; int64_t nregions; const int64_t* posbase; const uint64_t* wmask; const int64_t* woff;
+    uint64_t* cand; uint64_t cand_cap;
+    PM_HD void operator()(int64_t tid) const {
+        const uint64_t m = wmask[tid >> 6];
+        const int t = (int)(tid & 63);
+        if (!((m >> t) & 1)) return;
+        const uint64_t at = (uint64_t)woff[tid >> 6] + (uint64_t)
+#if defined(__HIP_DEVICE_COMPILE__)
+            __popcll(m & ((1ull << t) - 1));
+#else
+            __builtin_popcountll(m & ((1ull << t) - 1));
+#endif
+        if (at >= cand_cap) return;
+        const int64_t r = upper_slot(posbase, nregions, tid);
+        cand[at] = ((uint64_t)r << 32) | (uint32_t)(tid - R[r].posbase);
     }
 };
 
 // ------------------------------------------------------------------------------------------ per-candidate fold
 struct GenomeAtK { int32_t epf, upf, spf, epr, upr, spr; };
-// tid = cand * (ngen-1) + g : both strands of one query genome at one candidate position
+// both strands of query genome g (0-based) at candidate (r, k): the propagated Pair[k] / SP[k] of Find_UM + Intersect_UM
+PM_HD GenomeAtK state_at(const RegionInfo& ri, int64_t r, int32_t k, int g, int32_t nq, const uint64_t* key, const uint64_t* val,
+                         const int64_t* lo, const EventState* st, const int32_t* rep, int lbits, const int64_t* cbase, const int32_t* coarse) {
+    const int64_t pair = r * nq + g;
+    const int32_t* row = coarse + cbase[r] * nq + (int64_t)(k >> kCoarseShift) * nq;
+    const int64_t first = lo[pair];
+    int64_t a = first + row[g], b = first + row[nq + g];
+    const uint64_t want = ((((uint64_t)pair << lbits) | (uint64_t)k) << 1) | 1ull;
+    while (a < b) { const int64_t mid = (a + b) >> 1; if (key[mid] <= want) a = mid + 1; else b = mid; }
+    GenomeAtK o{0, 0, 0, 0, 0, 0};
+    if (a > first) {
+        const EventState s = st[a - 1];
+        const uint64_t lmask = (1ull << lbits) - 1;
+        for (int sd = 0; sd < 2; sd++) {
+            if (s.s[sd].w < 0) continue;
+            const uint64_t wk = key[s.s[sd].w], wv = val[s.s[sd].w];
+            const int32_t wl = (int32_t)((wk >> 1) & lmask), wj = (int32_t)(wv >> 32);
+            int32_t up = wl + rep[ri.posbase + wl];
+            if (s.s[sd].e2 > up) up = s.s[sd].e2;
+            if (sd == 0) { o.epf = s.s[0].e1; o.upf = up; o.spf = wj + (k - wl); }
+            else { o.epr = s.s[1].e1; o.upr = up; o.spr = wj + (k - wl); }
+        }
+    }
+    return o;
+}
+// tid = cand * (ngen-1) + g.  Only a sharded run launches this (the columns of the rank's genomes are exchanged before
+// the fold); an unsharded run computes the states inside FoldCandidates.
 struct StateAtCandidate {
     const RegionInfo* R; const uint64_t* cand; int32_t ngen; const uint64_t* key; const uint64_t* val; const int64_t* lo;
     const EventState* st; const int32_t* rep; int lbits; GenomeAtK* out;
-    const int64_t* cbase; const int32_t* coarse;      // CoarseIndex: the probe runs over the events of k's 1024-position block
+    const int64_t* cbase; const int32_t* coarse;
     PM_HD void operator()(int64_t tid) const {
-        int64_t c = tid / (ngen - 1); int g = (int)(tid % (ngen - 1));
-        int64_t r = (int64_t)(cand[c] >> 32); int32_t k = (int32_t)(cand[c] & 0xffffffffu);
-        const RegionInfo& ri = R[r];
-        int64_t pair = r * (ngen - 1) + g;
-        const int64_t per = cbase[r + 1] - cbase[r];
-        const int32_t* cg = coarse + cbase[r] * (ngen - 1) + (int64_t)g * per + (k >> kCoarseShift);
-        int64_t a = lo[pair] + cg[0], b = lo[pair] + cg[1];
-        uint64_t want = ((((uint64_t)pair << lbits) | (uint64_t)k) << 1) | 1ull;
-        while (a < b) { int64_t mid = (a + b) >> 1; if (key[mid] <= want) a = mid + 1; else b = mid; }
-        GenomeAtK o{0, 0, 0, 0, 0, 0};
-        if (a > lo[pair]) {
-            const EventState& s = st[a - 1];
-            const uint64_t lmask = (1ull << lbits) - 1;
-            for (int sd = 0; sd < 2; sd++) {
-                if (s.s[sd].w < 0) continue;
-                uint64_t wk = key[s.s[sd].w], wv = val[s.s[sd].w];
-                int32_t wl = (int32_t)((wk >> 1) & lmask), wj = (int32_t)(wv >> 32);
-                int32_t up = wl + rep[ri.posbase + wl];
-                if (s.s[sd].e2 > up) up = s.s[sd].e2;
-                if (sd == 0) { o.epf = s.s[0].e1; o.upf = up; o.spf = wj + (k - wl); }
-                else { o.epr = s.s[1].e1; o.upr = up; o.spr = wj + (k - wl); }
-            }
-        }
-        out[tid] = o;
+        const int32_t nq = ngen - 1;
+        const int64_t c = tid / nq; const int g = (int)(tid % nq);
+        const int64_t r = (int64_t)(cand[c] >> 32); const int32_t k = (int32_t)(cand[c] & 0xffffffffu);
+        out[tid] = state_at(R[r], r, k, g, nq, key, val, lo, st, rep, lbits, cbase, coarse);
     }
 };
-// tid = candidate.  Intersect_UM's (UP=max, EP=min) fold and Merge_Master's strand choice, genome after genome in
-// ini order (mum.c:162-163, :92-123; ties -> reverse), then the UP < EP test of parsnp.cpp:1657.
-struct FoldGenomes {
+// One wavefront per candidate, lanes over the query genomes.  Intersect_UM's (UP=max, EP=min) fold and Merge_Master's
+// strand choice run genome after genome in ini order (mum.c:162-163, :92-123; ties -> reverse):
+//     fe = min(em, epf), re = min(em, epr);  forward iff fe > re;  em = max(fe, re) = min(em, max(epf, epr));  um = max(um, up of the chosen strand)
+// so em before genome g is the exclusive prefix minimum of max(epf, epr) -- one shuffle scan per 64 genomes -- and the
+// strand flags and um follow from it independently per lane.  Then the UP < EP test of parsnp.cpp:1657.
+// `at` == nullptr: the per-genome states are computed here (never written to memory); else read from `at`.
+// Output per candidate and genome: the start of the MUM inside the genome's request window on the chosen strand (sp) and
+// the strand, as before; and out_ok / k / lon per candidate.
+struct FoldCandidates {
     const RegionInfo* R; const uint64_t* cand; int32_t ngen; const GenomeAtK* at;
+    const uint64_t* key; const uint64_t* val; const int64_t* lo; const EventState* st; const int32_t* rep; int lbits;
+    const int64_t* cbase; const int32_t* coarse;
     int32_t* out_k; int32_t* out_lon; int32_t* out_sp; uint8_t* out_fwd; uint8_t* out_ok;
-    PM_HD void operator()(int64_t c) const {
-        int64_t r = (int64_t)(cand[c] >> 32); int32_t k = (int32_t)(cand[c] & 0xffffffffu);
-        int32_t em = R[r].nR, um = 0;
-        for (int g = 0; g < ngen - 1; g++) {
-            const GenomeAtK& s = at[c * (ngen - 1) + g];
-            int32_t fe = em < s.epf ? em : s.epf, fu = um > s.upf ? um : s.upf;
-            int32_t re = em < s.epr ? em : s.epr, ru = um > s.upr ? um : s.upr;
-            if (fe > re) { em = fe; um = fu; out_sp[c * (ngen - 1) + g] = s.spf; out_fwd[c * (ngen - 1) + g] = 1; }
-            else { em = re; um = ru; out_sp[c * (ngen - 1) + g] = s.spr; out_fwd[c * (ngen - 1) + g] = 0; }
+    PM_HD void wave(int64_t c) const {
+        const int32_t nq = ngen - 1;
+        const int64_t r = (int64_t)(cand[c] >> 32); const int32_t k = (int32_t)(cand[c] & 0xffffffffu);
+        const RegionInfo& ri = R[r];
+        int32_t em = ri.nR, um = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int lane = (int)__lane_id();
+        for (int g0 = 0; g0 < nq; g0 += 64) {
+            const int g = g0 + lane;
+            const bool act = g < nq;
+            GenomeAtK s{0, 0, 0, 0, 0, 0};
+            if (act) s = at ? at[c * nq + g] : state_at(ri, r, k, g, nq, key, val, lo, st, rep, lbits, cbase, coarse);
+            const int32_t m = act ? (s.epf > s.epr ? s.epf : s.epr) : 0x7fffffff;
+            const int32_t incl = wave_incl_min(m);
+            int32_t before = __shfl_up(incl, 1, 64);
+            if (lane == 0 || before > em) before = em;
+            const int32_t fe = before < s.epf ? before : s.epf, re = before < s.epr ? before : s.epr;
+            const bool fwd = fe > re;
+            const int32_t u = act ? (fwd ? s.upf : s.upr) : 0;
+            if (act) { out_sp[c * nq + g] = fwd ? s.spf : s.spr; out_fwd[c * nq + g] = fwd ? 1 : 0; }
+            const int32_t last = __shfl(incl, 63, 64);
+            if (last < em) em = last;
+            const int32_t umax = wave_all_max(u);
+            if (umax > um) um = umax;
+        }
+        if (lane == 0) { out_k[c] = k; out_lon[c] = em - k; out_ok[c] = (um < em && em - k >= ri.minsize) ? 1 : 0; }
+#else
+        for (int g = 0; g < nq; g++) {
+            const GenomeAtK s = at ? at[c * nq + g] : state_at(ri, r, k, g, nq, key, val, lo, st, rep, lbits, cbase, coarse);
+            const int32_t fe = em < s.epf ? em : s.epf, fu = um > s.upf ? um : s.upf;
+            const int32_t re = em < s.epr ? em : s.epr, ru = um > s.upr ? um : s.upr;
+            if (fe > re) { em = fe; um = fu; out_sp[c * nq + g] = s.spf; out_fwd[c * nq + g] = 1; }
+            else { em = re; um = ru; out_sp[c * nq + g] = s.spr; out_fwd[c * nq + g] = 0; }
         }
         out_k[c] = k; out_lon[c] = em - k;
-        out_ok[c] = (um < em && em - k >= R[r].minsize) ? 1 : 0;
+        out_ok[c] = (um < em && em - k >= ri.minsize) ? 1 : 0;
+#endif
     }
 };
 
@@ -1106,8 +1281,9 @@ struct OkCount {
     const uint8_t* ok; int64_t ncand; int64_t* cnt;     // cnt[ncand] = 0 closes the scan
     PM_HD void operator()(int64_t c) const { cnt[c] = c < ncand ? (ok[c] ? 1 : 0) : 0; }
 };
-// tid = (candidate, query genome)
-struct CompactCandidates {
+// tid = (candidate, query genome): the accepted candidates densely, as (sp, strand) per query genome (the documented
+// result of pm_multi_mum_batch; a session switched to MUM rows with pm_session_rows gets CompactCandidates instead)
+struct CompactSp {
     const uint64_t* cand; const uint8_t* ok; const int64_t* pos; int32_t nq;
     const int32_t* k; const int32_t* lon; const int32_t* sp; const uint8_t* fwd;
     int32_t* out_region; int32_t* out_k; int32_t* out_lon; int32_t* out_sp; uint8_t* out_fwd;
@@ -1117,6 +1293,143 @@ struct CompactCandidates {
         const int64_t w = pos[c];
         out_sp[w * nq + g] = sp[tid]; out_fwd[w * nq + g] = fwd[tid];
         if (g == 0) { out_region[w] = (int32_t)(cand[c] >> 32); out_k[w] = k[c]; out_lon[w] = lon[c]; }
+    }
+};
+// Flag bits of an accepted candidate as the host's validation wants them (src/parsnp.cpp:1717-1780, TMum.cpp:25-60)
+constexpr uint32_t kRowBad = 1;        // a start position outside its region window: the reference skips it before building the TMum (:1723)
+constexpr uint32_t kRowOutside = 2;    // the MUM would leave a genome (`notgood`)
+constexpr uint32_t kRowReverse = 4;    // some member is on the reverse strand
+constexpr uint32_t kRowDirty = 8;      // overlaps an earlier candidate of the list in some genome (cheap running-extent test)
+// tid = (candidate, genome column 0..ngen-1).  Writes the accepted candidates densely and AS MUM ROWS: per genome the
+// start on the genome's forward coordinates exactly as the TMum constructor derives it -- forward: window start + sp,
+// reverse: flipped against the WHOLE genome length (TMum.cpp:33-35) -- and the strand byte; column 0 is the reference.
+// The host used to rebuild these rows from (sp, fwd) per candidate (`rows`, 1.6 ms of the anchor validation at 200 x 5 Mb).
+struct CompactCandidates {
+    const uint64_t* cand; const uint8_t* ok; const int64_t* pos; int32_t ngen;
+    const int32_t* k; const int32_t* lon; const int32_t* sp; const uint8_t* fwd;
+    const int64_t* starts; const int64_t* lens; const int64_t* glen;
+    int32_t* out_region; int32_t* out_k; int32_t* out_lon; int32_t* out_start; uint8_t* out_strand; uint32_t* out_flags;   // out_flags zeroed
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = tid / ngen; const int j = (int)(tid % ngen);
+        if (!ok[c]) return;
+        const int64_t w = pos[c];
+        const int64_t r = (int64_t)(cand[c] >> 32);
+        const int64_t lo = lon[c];
+        const int64_t ws = starts[r * ngen + j], wl = lens[r * ngen + j];
+        int64_t st; uint32_t f, bits = 0;
+        if (j == 0) {
+            st = (int64_t)k[c] + ws; f = 1;
+            if ((uint64_t)k[c] + 1 > (uint64_t)(uint32_t)wl) bits |= kRowBad;
+            out_region[w] = (int32_t)r; out_k[w] = k[c]; out_lon[w] = lon[c];
+        } else {
+            const int64_t q = sp[c * (ngen - 1) + j - 1];
+            f = fwd[c * (ngen - 1) + j - 1];
+            if ((uint64_t)q + 1 > (uint64_t)(uint32_t)wl) bits |= kRowBad;
+            const int64_t at = q + ws;
+            st = f ? at : glen[j] - (at + lo);
+            if (!f) bits |= kRowReverse;
+        }
+        if (st + lo > glen[j] || st < 0) bits |= kRowOutside;
+        out_start[w * ngen + j] = (int32_t)st; out_strand[w * ngen + j] = (uint8_t)f;
+        if (bits) atomic_or32(&out_flags[w], bits);
+    }
+};
+
+// The cheap overlap test of the anchor validation (host: validate_parallel): walking the accepted candidates in order, one
+// that lies entirely after, or entirely before, everything earlier in a genome overlaps nothing earlier there; else it
+// is "dirty" and takes the ordered host path.  Three passes over the [candidate][genome] start rows, a wavefront per
+// (block of 256 candidates, group of 64 genomes), lane = genome (coalesced 256-byte row pieces):
+//   DirtyExtent  extent (max end, min start) of each block per genome
+//   DirtyPrefix  exclusive prefix of the block extents per genome (one wavefront per genome group, blocks in order)
+//   DirtyMark    the walk itself from the block's carry-in
+// Only candidates that can mark anything take part (constructed, inside, length >= 5: src/parsnp.cpp:1781).
+constexpr int kDirtyBlock = 256;
+PM_HD bool row_marks(uint32_t flags, int32_t lon) { return !(flags & (kRowBad | kRowOutside)) && lon >= 5; }
+struct DirtyExtent {
+    const int32_t* start; const int32_t* lon; const uint32_t* flags; int64_t n; int32_t ngen; int32_t* bmax; int32_t* bmin;   // [block][ngen]
+    PM_HD void wave(int64_t w) const {
+        const int64_t groups = (ngen + 63) / 64, blk = w / groups; const int g0 = (int)(w % groups) * 64;
+        const int64_t c0 = blk * kDirtyBlock, c1 = c0 + kDirtyBlock < n ? c0 + kDirtyBlock : n;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int j = g0 + (int)__lane_id();
+        if (j >= ngen) return;
+        int32_t mx = -1, mn = 0x7fffffff;
+        for (int64_t c = c0; c < c1; c++) {
+            const int32_t a = start[c * ngen + j], l = lon[c];
+            if (!row_marks(flags[c], l)) continue;
+            if (a + l > mx) mx = a + l;
+            if (a < mn) mn = a;
+        }
+        bmax[blk * ngen + j] = mx; bmin[blk * ngen + j] = mn;
+#else
+        for (int j = g0; j < g0 + 64 && j < ngen; j++) {
+            int32_t mx = -1, mn = 0x7fffffff;
+            for (int64_t c = c0; c < c1; c++) {
+                const int32_t a = start[c * ngen + j], l = lon[c];
+                if (!row_marks(flags[c], l)) continue;
+                if (a + l > mx) mx = a + l;
+                if (a < mn) mn = a;
+            }
+            bmax[blk * ngen + j] = mx; bmin[blk * ngen + j] = mn;
+        }
+#endif
+    }
+};
+struct DirtyPrefix {
+    int64_t nblocks; int32_t ngen; int32_t* bmax; int32_t* bmin;       // in place: extents of the blocks BEFORE each block
+    PM_HD void wave(int64_t w) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int j0 = (int)w * 64 + (int)__lane_id(), j1 = j0 + 1;
+        if (j0 >= ngen) return;
+#else
+        const int j0 = (int)w * 64, j1 = j0 + 64 < ngen ? j0 + 64 : ngen;
+#endif
+        for (int j = j0; j < j1; j++) {
+            int32_t mx = -1, mn = 0x7fffffff;
+            for (int64_t b = 0; b < nblocks; b++) {
+                const int32_t x = bmax[b * ngen + j], y = bmin[b * ngen + j];
+                bmax[b * ngen + j] = mx; bmin[b * ngen + j] = mn;
+                if (x > mx) mx = x;
+                if (y < mn) mn = y;
+            }
+        }
+    }
+};
+struct DirtyMark {
+    const int32_t* start; const int32_t* lon; int64_t n; int32_t ngen; const int32_t* bmax; const int32_t* bmin; uint32_t* flags;
+    PM_HD void wave(int64_t w) const {
+        const int64_t groups = (ngen + 63) / 64, blk = w / groups; const int g0 = (int)(w % groups) * 64;
+        const int64_t c0 = blk * kDirtyBlock, c1 = c0 + kDirtyBlock < n ? c0 + kDirtyBlock : n;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int j = g0 + (int)__lane_id();
+        const bool act = j < ngen;
+        int32_t mx = act ? bmax[blk * ngen + j] : -1, mn = act ? bmin[blk * ngen + j] : 0x7fffffff;
+        for (int64_t c = c0; c < c1; c++) {
+            const int32_t l = lon[c];
+            const uint32_t fl = flags[c];      // bits other than kRowDirty do not change during this kernel
+            if (!row_marks(fl, l)) continue;    // uniform over the wavefront
+            bool hit = false;
+            if (act) {
+                const int32_t a = start[c * ngen + j], b = a + l;
+                hit = !(a >= mx || b <= mn);
+                if (b > mx) mx = b;
+                if (a < mn) mn = a;
+            }
+            if (__ballot(hit) && __lane_id() == 0) atomic_or32(&flags[c], kRowDirty);
+        }
+#else
+        for (int j = g0; j < g0 + 64 && j < ngen; j++) {
+            int32_t mx = bmax[blk * ngen + j], mn = bmin[blk * ngen + j];
+            for (int64_t c = c0; c < c1; c++) {
+                const int32_t l = lon[c];
+                if (!row_marks(flags[c], l)) continue;
+                const int32_t a = start[c * ngen + j], b = a + l;
+                if (!(a >= mx || b <= mn)) flags[c] |= kRowDirty;
+                if (b > mx) mx = b;
+                if (a < mn) mn = a;
+            }
+        }
+#endif
     }
 };
 

@@ -263,7 +263,7 @@ void Aligner::chunk_requests(const Region& r, int minsize, std::vector<Request>*
             plain = r.length[g] >= 0 && r.start[g] + r.length[g] <= gsize_[g];
         }
         if (plain) {
-            out->push_back(Request{r.start, r.length, minsize, r.start[0], hash_rows(r.start, r.length, n, minsize)});
+            out->push_back(Request{r.start, r.length, minsize, r.start[0], hash_rows(r.start, r.length, n, minsize), true});
             return;
         }
     }
@@ -288,11 +288,18 @@ void Aligner::chunk_requests(const Region& r, int minsize, std::vector<Request>*
     }
 }
 
-void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out) {
+void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out, bool rows) {
     out->clear();
     out->resize(reqs.size());
     if (reqs.empty()) return;
     double t0 = now_s();
+    // results as MUM rows built on the device where the provider can (the HIP engine) and every request is its region
+    static const bool no_rows = getenv("PARSNP_NO_DEVICE_ROWS") != nullptr;      // test hook: the host builds the rows from sp / fwd
+    rows = rows && rows_supported_ && !no_rows;
+    if (rows != rows_mode_) {
+        if (pm_session_rows(session_, rows ? 1 : 0) == PM_OK) rows_mode_ = rows;
+        else { rows_supported_ = false; rows = rows_mode_ = false; }
+    }
     // the flat arrays of the C ABI live in the run's memory: 2 x 13 MB for the recursion batch, not faulted in per call
     std::vector<int64_t>& starts = memory_->batch_starts; std::vector<int64_t>& lens = memory_->batch_lens;
     if (starts.size() < reqs.size() * n) { starts.resize(reqs.size() * n); lens.resize(reqs.size() * n); }
@@ -320,12 +327,18 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out)
     const int32_t* lon = pm_result_lon(res);
     const int32_t* sp = pm_result_sp(res);
     const uint8_t* fw = pm_result_fwd(res);
+    int32_t* rstart = rows ? pm_result_start(res) : nullptr;
+    uint8_t* rstrand = rows ? pm_result_strand(res) : nullptr;
+    const uint32_t* rflags = rows ? pm_result_flags(res) : nullptr;
+    const bool dirty_known = rows && pm_result_dirty_known(res) != 0;
     const size_t q = n - 1;
     double tu = now_s();
     for (size_t i = 0; i < reqs.size(); i++) {
         Raw& r = (*out)[i];
         size_t a = (size_t)off[i], b = (size_t)off[i + 1];
-        r.k = k + a; r.lon = lon + a; r.sp = sp + a * q; r.fwd = fw + a * q;
+        r.k = k + a; r.lon = lon + a;
+        if (rows) { r.start = rstart + a * n; r.strand = rstrand + a * n; r.flags = rflags + a; r.dirty_known = dirty_known; }
+        else { r.sp = sp + a * q; r.fwd = fw + a * q; }
         r.count = b - a;
         r.owner = own;
     }
@@ -372,7 +385,7 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
             stats.cache_misses++; misses_since_sweep_++;
             std::vector<Request> one{q};
             std::vector<Raw> raw;
-            run_batch(one, &raw);
+            run_batch(one, &raw, q.plain);
             if (!e) e = cache_put(q, false);
             e->raw = std::move(raw[0]); e->pending = false;
         } else if (!speculative) {
@@ -388,6 +401,14 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
 // TMum constructor (TMum.cpp:25-60): forward = DSP-1, reverse = flipped against the WHOLE genome length even inside a
 // sub-region.  Returns false when the reference skips the candidate before constructing the TMum.
 bool Aligner::candidate_rows(const Region& r, const Request& q, const Raw& raw, size_t c, Mum& m, bool* ok, bool* any_reverse) const {
+    if (raw.start) {      // built on the device (CompactCandidates): copy the row, read the verdicts
+        memcpy(m.start, raw.start + c * n, n * sizeof(int32_t));
+        memcpy(m.fwd, raw.strand + c * n, n);
+        m.length = raw.lon[c];
+        const uint32_t f = raw.flags[c];
+        *ok = !(f & PM_ROW_OUTSIDE); *any_reverse = (f & PM_ROW_REVERSE) != 0;
+        return !(f & PM_ROW_BAD);
+    }
     const size_t nq = n - 1;
     const long lon = raw.lon[c];
     const int32_t* __restrict sp = &raw.sp[c * nq];
@@ -485,14 +506,29 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double tp = now_s();
     auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[validate_parallel] %-10s %.4f s\n", what, t - tp); tp = t; } };
-    int32_t* srow = irows_.alloc(ncand * n); uint8_t* frow = brows_.alloc(ncand * n);
+    // rows: built on the device where the engine delivers them (the candidates' rows ARE the result blocks then: nothing
+    // is copied, trim() works on them in place and the result is kept alive), else from (sp, fwd) here
+    const bool device_rows = raw.start != nullptr;
+    int32_t* srow = device_rows ? raw.start : irows_.alloc(ncand * n);
+    uint8_t* frow = device_rows ? raw.strand : brows_.alloc(ncand * n);
+    if (device_rows) kept_results_.push_back(raw.owner);
     std::vector<Mum> cand(ncand);
     std::vector<uint8_t> state(ncand, 0);   // bit0 constructed, bit1 ok, bit2 any_reverse, bit3 dirty, bit4 accepted
     const long nc = (long)ncand;
+    const bool layout_empty = pool.empty();      // nothing accepted yet: the layout holds no mark (the anchor call)
+    static const bool force_exact = getenv("PARSNP_EXACT_OVERLAP") != nullptr;   // test hook: always the bitmap test
+    static const bool host_overlap = getenv("PARSNP_HOST_OVERLAP") != nullptr;   // test hook: the cheap test on the host although the device ran it
+    const bool device_dirty = device_rows && raw.dirty_known && layout_empty && !host_overlap;
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (long c = 0; c < nc; c++) {
         Mum& m = cand[(size_t)c];
         m.start = srow + (size_t)c * n; m.fwd = frow + (size_t)c * n;
+        if (device_rows) {
+            const uint32_t f = raw.flags[c];
+            m.length = raw.lon[c];
+            if (!(f & PM_ROW_BAD)) state[(size_t)c] = (uint8_t)(1 | ((f & PM_ROW_OUTSIDE) ? 0 : 2) | ((f & PM_ROW_REVERSE) ? 4 : 0) | ((device_dirty && (f & PM_ROW_DIRTY)) ? 8 : 0));
+            continue;
+        }
         bool ok, rev;
         if (candidate_rows(r, q, raw, (size_t)c, m, &ok, &rev)) state[(size_t)c] = 1 | (ok ? 2 : 0) | (rev ? 4 : 0);
     }
@@ -504,8 +540,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // treating a clean candidate as dirty is harmless (it takes the ordered path and sees the same marks); where genomes
     // are rearranged enough for it to flag too many, the exact test with scratch bitmaps decides instead.
     const int nstripes = threads;
-    const bool layout_empty = pool.empty();      // nothing accepted yet: the layout holds no mark (the anchor call)
-    {
+    if (!device_dirty) {
 #pragma omp parallel for schedule(static, 1) num_threads(threads)
         for (int t = 0; t < nstripes; t++) {
             const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
@@ -530,7 +565,6 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     }
     size_t flagged = 0;
     for (size_t c = 0; c < ncand; c++) flagged += (state[c] >> 3) & 1;
-    static const bool force_exact = getenv("PARSNP_EXACT_OVERLAP") != nullptr;   // test hook: always the bitmap test
     if (dbg) fprintf(stderr, "[validate_parallel] cheap overlap test flags %zu of %zu\n", flagged, ncand);
     if (flagged * 8 > ncand || force_exact) {
         for (size_t c = 0; c < ncand; c++) state[c] &= (uint8_t)~8;
@@ -887,7 +921,9 @@ void Aligner::prefetch(const std::vector<Region>& gen) {
     }
     req_rows_.rewind(qmark);
     std::vector<Raw> raws;
-    run_batch(wanted_, &raws);
+    bool all_plain = true;
+    for (const Request& w : wanted_) all_plain = all_plain && w.plain;
+    run_batch(wanted_, &raws, all_plain);
     for (size_t i = 0; i < wanted_.size(); i++) { wanted_entries_[i]->raw = std::move(raws[i]); wanted_entries_[i]->pending = false; }
     wanted_.clear(); wanted_entries_.clear();
 }
@@ -1016,7 +1052,7 @@ bool Aligner::extend_generations() {
     };
     auto plain_request = [&](const Region& r, Request* q) {
         if (!plain_shape(r)) return false;
-        *q = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0};
+        *q = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0, true};
         return true;
     };
     // the same for a list: the row checks (8 000 regions x 201 genomes per generation) by all threads, the minimum
@@ -1031,7 +1067,7 @@ bool Aligner::extend_generations() {
             if (skip && (*skip)[(size_t)i] >= 0) continue;
             if (!ok[(size_t)i]) return false;
             const Region& r = rs[(size_t)i];
-            (*out)[(size_t)i] = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0};
+            (*out)[(size_t)i] = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0, true};
         }
         return true;
     };
@@ -1044,7 +1080,7 @@ bool Aligner::extend_generations() {
         }
         if (want.empty()) return true;
         std::vector<Raw> got;
-        run_batch(want, &got);
+        run_batch(want, &got, true);
         for (size_t k = 0; k < who.size(); k++) { (*raw_of)[who[k]] = (int)raws.size(); raws.push_back(std::move(got[k])); }
         return true;
     };

@@ -202,6 +202,9 @@ struct Raw {
     const int32_t* k = nullptr; const int32_t* lon = nullptr;
     const int32_t* sp = nullptr;
     const uint8_t* fwd = nullptr;
+    // MUM-row mode of the engine (pm_session_rows): rows of n entries per candidate built on the device, and their flags
+    int32_t* start = nullptr; uint8_t* strand = nullptr; const uint32_t* flags = nullptr;
+    bool dirty_known = false;
     size_t count = 0;
     std::shared_ptr<pm_result> owner;
 };
@@ -281,9 +284,11 @@ private:
     // --- finder plumbing -------------------------------------------------------------------------------------
     // one engine request = one reference chunk of one region; rows of n entries (the region's own rows when the
     // region is a single unclamped chunk, else rows in req_rows_)
-    struct Request { const long* start; const long* len; int32_t minsize; long ref_ini; uint64_t hash; };
+    struct Request { const long* start; const long* len; int32_t minsize; long ref_ini; uint64_t hash; bool plain = false; };   // plain: the rows are the region's own (one unclamped chunk)
     void chunk_requests(const Region& r, int minsize, std::vector<Request>* out);   // the p-chunk loop, :1519-1547
-    void run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out);
+    void run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out, bool rows = false);   // rows: every request is its region (plain)
+    bool rows_mode_ = false, rows_supported_ = true;
+    std::vector<std::shared_ptr<pm_result>> kept_results_;   // results whose row blocks hold the rows of accepted MUMs
     // cache of raw results keyed by request coordinates (results are a pure function of them); entries own a copy of
     // the coordinates and are compared in full on a hash hit
     struct CacheEntry { const long* start; const long* len; int32_t minsize; bool pending; Raw raw; };

@@ -28,9 +28,11 @@ def random_genome(rng, n):
     return _BASES[rng.integers(0, 4, n)]
 
 
-def population(seed, n, n_genomes, div, indel_frac=0.0, sites=None, carry_seed=None):
+def population(seed, n, n_genomes, div, indel_frac=0.0, sites=None, carry_seed=None, select=None):
     """-> (ref bytes, [genome bytes]) under the population model.  carry_seed: draw the genomes from a separate
-    stream (same reference and site pool, different genomes -- one partition per rank in bench.py)."""
+    stream (same reference and site pool, different genomes -- one partition per rank in bench.py).  select: indices
+    of the genomes to materialise (the random stream still advances over all of them, so genome i is the same bytes
+    whether or not its neighbours are built) -- one partition of BASELINE config 4 without building 2000 genomes."""
     rng = np.random.default_rng(seed)
     ref = random_genome(rng, n)
     if sites is None:
@@ -40,8 +42,10 @@ def population(seed, n, n_genomes, div, indel_frac=0.0, sites=None, carry_seed=N
     if carry_seed is not None:
         rng = np.random.default_rng(carry_seed)
     out = []
-    for _ in range(n_genomes):
+    for gi in range(n_genomes):
         carry = rng.random(len(sites)) < 0.5
+        if select is not None and gi not in select:
+            continue
         g = ref.copy()
         sub = sites[carry & ~is_del]
         g[sub] = alt[carry & ~is_del]
@@ -131,13 +135,14 @@ def write_fasta(path, name, seq: bytes, width=80):
             f.write(a[full:].tobytes() + b"\n")
 
 
-def write_set(outdir, ref: bytes, genomes):
-    """-> (ref path, [query paths]) with the file / header names the goldens were generated with."""
+def write_set(outdir, ref: bytes, genomes, ids=None):
+    """-> (ref path, [query paths]) with the file / header names the goldens were generated with (ids: the genome
+    numbers to name the files after, default 0..)."""
     os.makedirs(outdir, exist_ok=True)
     rp = os.path.join(outdir, "ref.fna")
     write_fasta(rp, "ref", ref)
     qs = []
-    for i, g in enumerate(genomes):
+    for i, g in zip(ids if ids is not None else range(len(genomes)), genomes):
         p = os.path.join(outdir, "g%04d.fna" % i)
         write_fasta(p, "g%04d" % i, g)
         qs.append(p)
@@ -186,8 +191,29 @@ CONFIGS = {
     "pop6x200k": ("population", dict(seed=9, n=200_000, n_genomes=6, div=0.02, indel_frac=0.05)),
     "rearr6x300k": ("rearranged", dict(seed=11, n=300_000, n_genomes=6, div=0.004, frac=0.15)),
     "rearr500": ("pop_rearranged", dict(seed=13, n=5_000_000, n_genomes=500, div=0.05, frac=0.10)),
+    "rearr50": ("pop_rearranged", dict(seed=13, n=5_000_000, n_genomes=50, div=0.05, frac=0.10)),   # = the first 50 genomes of rearr500
+    "bact2000": ("population", dict(seed=6, n=5_000_000, n_genomes=2000, div=0.02, indel_frac=0.05)),
     "poprearr10x400k": ("pop_rearranged", dict(seed=13, n=400_000, n_genomes=10, div=0.05, frac=0.10)),
 }
+
+
+def config4_partition(part=0, n_total=2000, size=250):
+    """genome numbers of partition `part` of BASELINE config 4 in the reference driver's order: file names sorted, shuffled
+    with random.Random(42), cut into chunks of `size` (parsnp:29, :1509-1510, :1555-1564).  -> list of genome numbers"""
+    import random
+    names = sorted("g%04d.fna" % i for i in range(n_total))
+    random.Random(42).shuffle(names)
+    return [int(x[1:5]) for x in names[part * size:(part + 1) * size]]
+
+
+def make_partition(part=0, **override):
+    """(ref, genomes, ids) of one 250-genome partition of bact2000, genomes in the driver's order"""
+    ids = config4_partition(part)
+    model, kw = CONFIGS["bact2000"]
+    kw = dict(kw, **override)
+    ref, gs = population(select=set(ids), **kw)
+    by_id = dict(zip(sorted(ids), gs))
+    return ref, [by_id[i] for i in ids], ids
 
 
 def make(name, **override):

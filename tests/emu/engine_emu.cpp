@@ -18,11 +18,13 @@ struct HostBackend {
     void memset(void* p, int v, size_t n) { ::memset(p, v, n); }
     void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+    void d2h_async(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void sync() {}
     std::vector<char> stage;
     void* staging(size_t n) { if (stage.size() < n) stage.resize(n); return stage.data(); }
     void h2d_staged(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     template <class F> void launch(const char*, int64_t n, F f) { for (int64_t i = 0; i < n; i++) f(i); }
+    template <class F> void launch_wave(const char*, int64_t n, F f) { for (int64_t i = 0; i < n; i++) f.wave(i); }
     void exclusive_scan(const int64_t* in, int64_t* out, size_t n) { int64_t a = 0; for (size_t i = 0; i < n; i++) { int64_t v = in[i]; out[i] = a; a += v; } }
     void sort_pairs(uint64_t* ki, uint64_t* ko, uint64_t* vi, uint64_t* vo, size_t n, int) {
         std::vector<size_t> idx(n);

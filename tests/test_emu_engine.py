@@ -1,6 +1,8 @@
 """The engine's kernel functors (parsnp_amd/csrc/engine/kernels.h) and orchestration (engine_core.h), executed
 sequentially on the host by tests/emu, against the CPU restatement.  Checks the LOGIC of what the GPU runs; the
 GPU execution itself is checked by the -m gpu tests."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,7 @@ from parsnp_amd.binding import Lib, Session
 from seqgen import adversarial_case, mutate, random_seq
 from parsnp_amd import driver, synth
 import test_host_logic
+import xmfa_util
 
 
 @pytest.fixture(scope="module")
@@ -109,6 +112,27 @@ def test_end_to_end_with_emulated_engine(emu, tmp_path):
     r, gs = synth.make("viral50")
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
     test_host_logic.check(emu[1], "viral50", rp, qs, str(tmp_path / "out"), True)
+
+
+@pytest.mark.parametrize("name", ["rearr6x300k", "pop6x200k"])
+@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows"])
+def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
+    """MUM rows (start, strand, flags) and the cheap overlap flags built by the engine (CompactCandidates, Dirty* kernels)
+    feed the threaded anchor validation; thresholds lowered so that the small sets take that route.  The variants switch
+    the overlap test / the row construction back to the host: same bytes either way."""
+    r, gs = synth.make(name)
+    rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8")
+    if variant == "host_overlap":
+        env["PARSNP_HOST_OVERLAP"] = "1"
+    if variant == "host_rows":
+        env["PARSNP_NO_DEVICE_ROWS"] = "1"
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(emu[1], rp, qs, out, env=env, threads=4)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    want = test_host_logic.E2E[name]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == want["xmfa_md5"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
 
 
 def mumi_cases(rng, count):

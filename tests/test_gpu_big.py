@@ -1,0 +1,61 @@
+"""BASELINE-size parity on a real MI355X: parsnp_core (24 host threads, both replay modes) against the REFERENCE binary's
+XMFA md5, MUM/LCB signature and log counters at the sizes BASELINE.json quotes -- config 3 (200 x 5 Mb, --no-partition),
+one 250-genome partition of config 4 (2000 x 5 Mb, Random(42) order) and config 5 cut to its first 50 genomes
+(5 % segregating sites, 10 % of every genome rearranged).  The goldens (tests/golden/e2e_big.json) were produced in the
+build container by tests/golden/make_golden_big.py from oracle/_ref/parsnp_core_ref; the inputs are regenerated here
+from the same seeds (parsnp_amd.synth)."""
+import json
+import os
+import shutil
+import tempfile
+
+import pytest
+
+import xmfa_util
+from parsnp_amd import driver, synth
+from parsnp_amd.paths import CORE_BIN
+
+pytestmark = pytest.mark.gpu
+
+BIG_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_big.json")
+BIG = json.load(open(BIG_PATH)) if os.path.exists(BIG_PATH) else {}
+
+
+@pytest.fixture(scope="module")
+def scratch():
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > (6 << 30) else None
+    d = tempfile.mkdtemp(prefix="parsnp_big_", dir=base)
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def inputs(name, base):
+    d = os.path.join(base, name, "in")
+    if name == "bact2000_p0":
+        ref, gs, ids = synth.make_partition(0)
+        return synth.write_set(d, ref, gs, ids)
+    ref, gs = synth.make(name)
+    return synth.write_set(d, ref, gs)
+
+
+@pytest.mark.parametrize("name", ["bact200", "bact2000_p0", "rearr50"])
+def test_baseline_size_against_reference(scratch, name):
+    if name not in BIG:
+        pytest.skip("no reference golden for %s in tests/golden/e2e_big.json" % name)
+    want = BIG[name]
+    rp, qs = inputs(name, scratch)
+    assert len(qs) == want["n_queries"]
+    for mode in ("generations", "in_order"):
+        env = dict(os.environ, OMP_WAIT_POLICY="passive")
+        if mode == "in_order":
+            env["PARSNP_SEQUENTIAL_REPLAY"] = "1"
+        out = os.path.join(scratch, name, "out_" + mode)
+        rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=24)
+        assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+        x = os.path.join(out, "parsnpAligner.xmfa")
+        assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"], mode
+        assert xmfa_util.mum_lcb_signature(x) == want["signature"], mode
+        assert xmfa_util.md5(x) == want["xmfa_md5"], mode
+        assert "NOTE" not in open(os.path.join(out, "parsnpAligner.log")).read()
+        shutil.rmtree(out, ignore_errors=True)
+    shutil.rmtree(os.path.join(scratch, name), ignore_errors=True)

@@ -219,6 +219,28 @@ def test_parsnp_core_replay_modes_threaded(libs, tmp_path, name, mode):
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 
 
+@pytest.mark.parametrize("name", ["rearr6x300k", "poprearr10x400k", "pop20x1m"])
+@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows"])
+def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant):
+    """the MUM rows and the cheap overlap flags come from the device (CompactCandidates, DirtyExtent/Prefix/Mark) and feed
+    the threaded anchor validation in place; switching either back to the host must not change a byte"""
+    if name == "poprearr10x400k":
+        rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
+    else:
+        r, gs = synth.make(name)
+        rp, qs = synth.write_set(str(tmp_path / "in"), r, gs); kw = {}
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8")
+    if variant == "host_overlap":
+        env["PARSNP_HOST_OVERLAP"] = "1"
+    if variant == "host_rows":
+        env["PARSNP_NO_DEVICE_ROWS"] = "1"
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=8, **kw)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
+
+
 @pytest.mark.parametrize("name", ["mers", "messy", "pop6x200k_p"])
 def test_parsnp_core_calcmumi(libs, tmp_path, name):
     test_host_logic.check_mumi(CORE_BIN, name, str(tmp_path))
