@@ -121,6 +121,20 @@ int pm_mumi_coverage(pm_session* s, const int64_t* starts, const int64_t* lens, 
 int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int strand,
                    int64_t cap, int64_t* count, int64_t* ev_j, int64_t* ev_l, int32_t* ev_len, int32_t* ev_rep);
 
+/* Inter-MUM gap alignment for a whole batch of gaps on the device.  Replaces MuscleInterface::CallMuscleFast
+ * (src/MuscleInterface.cpp:37-78; call site src/parsnp.cpp:854-855): libMUSCLE 3.7 with SEQTYPE_DNA, one iteration,
+ * ClustalW weights, over the n_seqs[j] gap strings of gap j -- the rows it returns are byte-identical to MUSCLE's.
+ *   seq_off[0 .. total_seqs]   offsets into chars of all sequences of all jobs, job after job (ASCII, upper case)
+ *   max_cols[j], row_off[j]    row capacity of job j and where its rows go: sequence i of job j is written to
+ *                              out_rows[row_off[j] + i*max_cols[j] ..], cols[j] columns of it
+ *   cols[j] = -1               the device declined the job (more than 512 sequences, an intermediate alignment wider than
+ *                              160 columns or than max_cols[j], an empty sequence, or a case in which MUSCLE itself quits):
+ *                              the caller aligns it on the host
+ * device < 0: PARSNP_DEVICE or the current device.  Returns PM_OK or a PM_E* code (pm_gap_last_error()). */
+int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
+                       const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols);
+const char* pm_gap_last_error(void);
+
 /* Device-side timing of the last pm_multi_mum_batch on this session (HIP events on the engine's stream):
  * names[i] / ms[i] for i < *count (count in: capacity, out: filled).  Used by bench.py's roofline line. */
 int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms);

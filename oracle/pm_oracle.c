@@ -101,4 +101,12 @@ int32_t* pm_result_start(pm_result* r) { (void)r; return 0; }
 uint8_t* pm_result_strand(pm_result* r) { (void)r; return 0; }
 const uint32_t* pm_result_flags(const pm_result* r) { (void)r; return 0; }
 int pm_result_dirty_known(const pm_result* r) { (void)r; return 0; }
+/* the device gap aligner belongs to the HIP library; this checker declines every job, so the host aligner runs */
+int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
+                       const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols) {
+    (void)device; (void)n_seqs; (void)seq_off; (void)chars; (void)max_cols; (void)row_off; (void)out_rows; (void)out_bytes;
+    for (int64_t j = 0; j < n_jobs; j++) cols[j] = -1;
+    return PM_OK;
+}
+const char* pm_gap_last_error(void) { return ""; }
 int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) { (void)s; (void)names; (void)ms; if (count) *count = 0; return PM_OK; }

@@ -1,0 +1,680 @@
+// gapalign_hip.hip -- the inter-MUM gap aligner on the MI355X: pm_gap_align_batch (include/parsnp_mum.h).
+//
+// Replaces, for a whole run's worth of gaps at once, what the reference's XMFA writer does gap by gap:
+// MuscleInterface::CallMuscleFast (src/MuscleInterface.cpp:37-78, called at src/parsnp.cpp:854-855), i.e. the one
+// libMUSCLE 3.7 configuration SEQTYPE_DNA / MaxIters 1 / stable / ClustalW weights.  The arithmetic is the restatement
+// of parsnp_amd/csrc/host/gapalign.cpp (pinned there against the reference's own libMUSCLE), stage by stage with the
+// same float32/float64 mix, the same order of additions and the same tie rules; this file is compiled with
+// -ffp-contract=off so that no multiply-add is fused (the host build has no FMA either).
+//
+// One alignment (n sequences, up to kMaxCols columns) = one wavefront; a launch runs a fixed number of wavefront
+// "slots" that pull jobs from a queue (longest first), so the workspace is per slot, not per job:
+//   distances    muscle/libMUSCLE/fastdistnuc.cpp:103-262  distinct strings once; 6-mer multiset intersection through an
+//                8-bit count table in LDS (46 656 bytes, the reference's own table size)
+//   guide tree   upgma2.cpp:133-355                         lanes over the clusters: (value, index) arg-min reductions
+//   weights      clwwt.cpp:65-163                           lane per leaf, path sums in double
+//   profiles     profilefrommsa.cpp:262-331                 lane per column, sequences in MSA order (the order of the
+//                                                           float additions is part of the result)
+//   pairwise DP  nwsmall.cpp:447-620                        lane per row of profile A, anti-diagonal sweep: a cell needs
+//                                                           its upper / upper-left neighbours from the lane above
+//                                                           (shuffles) and its left neighbour from itself; trace-back
+//                                                           bits in LDS, bittraceback.cpp:130-209 by one lane
+//   merge        aligngivenpath.cpp:124-366                 rows re-spelled through a column map, lanes over columns
+// A job the device declines (more than kMaxSeqs sequences, an alignment wider than its row capacity or kMaxCols, an
+// empty sequence, MUSCLE's own "quit" conditions) is reported with cols = -1 and stays with the caller's host path.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/parsnp_mum.h"
+
+namespace {
+
+constexpr int kMaxSeqs = 512;      // sequences per alignment on the device
+constexpr int kMaxCols = 160;      // columns of any intermediate alignment on the device
+constexpr int kTable = 46656;      // 6^6 (fastdistnuc.cpp:82)
+constexpr float kMinusInf = (float)-1e37;
+constexpr float kBigDist = (float)1e29;
+constexpr float kGapOpen = -400.0f;
+constexpr float kGapExtend = 0.0f;
+constexpr float kSueff = (float)0.1;
+constexpr unsigned kNone = 0xffffffffu;
+enum : uint8_t { kMM = 0, kDM = 1, kIM = 2, kXM = 3, kMD = 4, kMI = 8 };
+
+__constant__ float c_matrix[4][4] = {      // nucmx.cpp:8-25: BLASTZ scores + 2*30
+    {91.0f + 60.0f, -114.0f + 60.0f, -31.0f + 60.0f, -123.0f + 60.0f},
+    {-114.0f + 60.0f, 100.0f + 60.0f, -125.0f + 60.0f, -31.0f + 60.0f},
+    {-31.0f + 60.0f, -125.0f + 60.0f, 100.0f + 60.0f, -114.0f + 60.0f},
+    {-123.0f + 60.0f, -31.0f + 60.0f, -114.0f + 60.0f, 91.0f + 60.0f},
+};
+__constant__ uint8_t c_letter[256];         // alpha.cpp:125-166: 0..3 residues, 4..15 wildcards, 16 gap, 255 none
+
+struct Job { int64_t first_seq; int32_t n; int32_t max_cols; int64_t row_off; };
+
+// per-slot workspace (global memory), sized for the widest job of the launch
+struct Slot {
+    float* dist;            // n(n-1)/2 + 1
+    uint16_t* ucommon;      // u x u
+    uint16_t* tcode;        // per distinct string: its distinct 6-mers ...
+    uint8_t* tcnt;          // ... and their 8-bit multiplicities
+    int32_t* ntup;          // [n]
+    uint64_t* hash;         // [n]
+    int32_t* len;           // [n]
+    int32_t* cls;           // [n] representative (first sequence with the same string)
+    int32_t* repidx;        // [n] rank of a representative among the representatives
+    int32_t* replist;       // [n]
+    uint32_t* left; uint32_t* right; uint32_t* parent;   // [2n]
+    double* to_parent;      // [2n]
+    float* height;          // [n]
+    uint32_t* under;        // [2n]
+    double* strength;       // [2n]
+    float* weight;          // [n]
+    int32_t* lo;            // [2n] first row of a node's alignment
+    int32_t* ncols;         // [2n]
+    int32_t* perm;          // [n] row -> sequence
+    uint8_t* cur;           // [n] which of a row's two buffers is current
+    uint8_t* rows;          // [n][2][cap]
+};
+
+struct Params {
+    const Job* jobs; int64_t njobs; const int64_t* seq_off; const uint8_t* chars;
+    uint8_t* out_rows; int32_t* out_cols; unsigned long long* next; uint8_t* ws; int64_t ws_stride; int32_t nmax, cap;
+};
+
+__device__ inline unsigned tri(unsigned a, unsigned b) { return a >= b ? b + (a * (a - 1)) / 2 : a + (b * (b - 1)) / 2; }
+__device__ inline bool is_gap(uint8_t c) { return c == '-' || c == '.'; }
+
+__device__ inline int wave_sum(int x) { for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64); return x; }
+// arg-min over (value, index): strictly smaller value wins, equal values -> the lower index (a sequential scan that
+// replaces its best only on `<` keeps the first one it met)
+__device__ inline void wave_argmin(float& v, unsigned& i) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ov = __shfl_xor(v, d, 64); const unsigned oi = (unsigned)__shfl_xor((int)i, d, 64);
+        if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+// LDS of the one wavefront of a workgroup, used phase after phase
+struct __align__(16) Shared {
+    union {
+        uint8_t table[kTable];                                    // distances: 6-mer counts
+        struct { float mind[kMaxSeqs]; unsigned nearest[kMaxSeqs]; unsigned node[kMaxSeqs]; } t;      // tree
+        struct {
+            float fa[4][kMaxCols]; uint8_t orda[kMaxCols]; float opena[kMaxCols], closea[kMaxCols];   // profile A: sorted counts, their letters
+            float sb[4][kMaxCols]; float openb[kMaxCols], closeb[kMaxCols];                           // profile B: scores per letter
+            float bD[kMaxCols + 2], bM[kMaxCols + 2], bN[kMaxCols + 2]; uint8_t bX[kMaxCols + 2];     // row handed from one 64-row stripe to the next
+            uint8_t tb[(kMaxCols + 1) * (kMaxCols + 1)];
+            uint8_t path[2 * kMaxCols + 2];
+            int16_t mapa[2 * kMaxCols + 2], mapb[2 * kMaxCols + 2];
+            float result[3];
+        } p;
+    };
+    uint16_t codes[kMaxCols];
+    int32_t flag;
+};
+
+// ---- profile of the alignment held by rows [lo, lo+ns) (nc columns) -> either the A arrays or the B arrays
+__device__ void build_profile(Shared& S, const Slot& W, int cap, int lo, int ns, int nc, bool as_a) {
+    const int lane = (int)__lane_id();
+    // msa2.cpp:418-431 + msa.cpp:369-381: this alignment's weights, rescaled to sum 1 (sequential float sum, MSA order)
+    float total = 0;
+    for (int s = 0; s < ns; s++) total += W.weight[W.perm[lo + s]];
+    const float f = total != 0 ? 1.0f / total : 1.0f;
+    const bool scale = total != 0;
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+        const int c = c0 + lane;
+        if (c < nc) {
+            float cnt[4] = {0, 0, 0, 0}, start = 0, end = 0;
+            for (int s = 0; s < ns; s++) {
+                const int p = lo + s;
+                float ws = W.weight[W.perm[p]];
+                if (scale) ws *= f;
+                const uint8_t* row = W.rows + ((size_t)p * 2 + W.cur[p]) * (size_t)cap;
+                const uint8_t ch = row[c];
+                if (is_gap(ch)) {
+                    if (c == 0 || !is_gap(row[c - 1])) start += ws;
+                    if (c + 1 == nc || !is_gap(row[c + 1])) end += ws;
+                    continue;
+                }
+                const uint8_t l = c_letter[ch];
+                if (l < 4) cnt[l] += ws;
+                else if (l == 14) { cnt[2] += ws / 2; cnt[0] += ws / 2; }
+                else { const float q = ws / 20; cnt[0] += q; cnt[1] += q; cnt[2] += q; cnt[3] += q; }
+            }
+            unsigned order[4] = {0, 1, 2, 3};       // profilefrommsa.cpp:180-204: bubble sort, strict <
+            bool any = true;
+            while (any) {
+                any = false;
+                for (unsigned k = 0; k < 3; k++) {
+                    const unsigned a = order[k], b = order[k + 1];
+                    if (cnt[a] < cnt[b]) { order[k + 1] = a; order[k] = b; any = true; }
+                }
+            }
+            const float start_occ = (float)(1.0 - start), end_occ = (float)(1.0 - end);
+            const float open = start_occ * kGapOpen / 2, close = end_occ * kGapOpen / 2;
+            if (as_a) {
+                for (unsigned k = 0; k < 4; k++) S.p.fa[k][c] = cnt[order[k]];
+                S.p.orda[c] = (uint8_t)(order[0] | (order[1] << 2) | (order[2] << 4) | (order[3] << 6));
+                S.p.opena[c] = open; S.p.closea[c] = close;
+            } else {
+                for (unsigned i = 0; i < 4; i++) {
+                    float sum = 0;
+                    for (unsigned j = 0; j < 4; j++) sum += cnt[j] * c_matrix[i][j];
+                    S.p.sb[i][c] = sum;
+                }
+                S.p.openb[c] = open; S.p.closeb[c] = close;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// scorepp.cpp:83-95 with all four terms (a count of 0 ends the reference's loop; its term is +-0 here, the zeros come last)
+__device__ inline float match_ab(const Shared& S, const float f[4], uint8_t ord, int j) {
+    float sc = 0.0f;
+    sc += f[0] * S.p.sb[ord & 3][j];
+    sc += f[1] * S.p.sb[(ord >> 2) & 3][j];
+    sc += f[2] * S.p.sb[(ord >> 4) & 3][j];
+    sc += f[3] * S.p.sb[(ord >> 6) & 3][j];
+    return sc - 0.0f;
+}
+
+// nwsmall.cpp:447-620 + bittraceback.cpp:130-209 -> S.p.path[0..*plen) in forward order; false = the reference gives up
+__device__ bool nw_small(Shared& S, int la, int lb, int* plen) {
+    const int lane = (int)__lane_id();
+    const float e = kGapExtend;
+    const int stride = lb + 1;
+    if (lane == 0) {          // termgaps.cpp:19-33 (TERMGAPS_Half falls through into _Ext): 0, then *= -1
+        S.p.opena[0] = 0.0f * -1.0f; if (la > 1) S.p.closea[la - 1] = 0.0f * -1.0f;
+        S.p.openb[0] = 0.0f * -1.0f; if (lb > 1) S.p.closeb[lb - 1] = 0.0f * -1.0f;
+    }
+    for (int x = lane; x <= la; x += 64) S.p.tb[x * stride] = 0;
+    for (int x = lane; x <= lb; x += 64) S.p.tb[x] = 0;
+    __syncthreads();
+    const float open_a0 = S.p.opena[0], open_b0 = S.p.openb[0];
+    for (int r0 = 0; r0 < la; r0 += 64) {
+        const int i = r0 + lane + 1;                    // this lane's row (1-based)
+        const bool row_ok = i <= la;
+        float fr[4] = {0, 0, 0, 0}, fn[4] = {0, 0, 0, 0}; uint8_t ordr = 0, ordn = 0;
+        float open_a = 0, close_a = 0, close_am2 = 0;
+        if (row_ok) {
+            for (int k = 0; k < 4; k++) fr[k] = S.p.fa[k][i - 1];
+            ordr = S.p.orda[i - 1]; open_a = S.p.opena[i - 1]; close_a = S.p.closea[i - 1];
+            if (i >= 2) close_am2 = S.p.closea[i - 2];
+            if (i < la) { for (int k = 0; k < 4; k++) fn[k] = S.p.fa[k][i]; ordn = S.p.orda[i]; }
+        }
+        const int rows_here = la - r0 < 64 ? la - r0 : 64;
+        // outputs of this lane's last two steps
+        float lastD = kMinusInf, lastM = kMinusInf, lastI = kMinusInf;   // D[i][j-1]: unused; M[i][j-1]; I[i][j-1]
+        float q1 = 0, q2 = 0; uint8_t x1 = 0, x2 = 0;                     // M[i+1][j+1] produced one / two steps ago
+        float outD = kMinusInf, outM = kMinusInf;                         // D[i][j], M[i][j] of the last step (for the lane below)
+        for (int t = 0; t < rows_here + lb - 1; t++) {
+            // what the lane above produced: at its last step (up) and two steps ago (diagonal)
+            float upD = __shfl_up(outD, 1, 64), upM = __shfl_up(outM, 1, 64), dgM = __shfl_up(q2, 1, 64);
+            uint8_t dgX = (uint8_t)__shfl_up((int)x2, 1, 64);
+            const int j = t - lane + 1;
+            const bool act = row_ok && j >= 1 && j <= lb;
+            if (lane == 0 && act) {
+                if (r0 == 0) { upD = kMinusInf; upM = kMinusInf; }        // row 0: M[0][j] = D[0][j] = -inf for j >= 1
+                else { upD = S.p.bD[j]; upM = S.p.bM[j]; dgM = S.p.bN[j]; dgX = S.p.bX[j]; }
+            }
+            q2 = q1; x2 = x1;
+            if (act) {
+                float m; uint8_t xm;
+                if (j == 1) {
+                    if (i == la) {
+                        if (la > 1) m = match_ab(S, fr, ordr, 0) + (la - 2) * e + open_a0 + close_am2;
+                        else m = match_ab(S, fr, ordr, 0) + open_a0 + S.p.closea[0];
+                        xm = kDM;
+                    } else if (i == 1) { m = match_ab(S, fr, ordr, 0); xm = kMM; }
+                    else { m = match_ab(S, fr, ordr, 0) + open_a0 + (i - 2) * e + close_am2; xm = kDM; }
+                } else if (i == 1) {
+                    m = match_ab(S, fr, ordr, j - 1) + open_b0 + (j - 2) * e + S.p.closeb[j - 2]; xm = kIM;
+                } else { m = dgM; xm = dgX; }
+                // REC_D
+                const float dd = upD + e, md = upM + open_a;
+                const bool from_m = !(dd > md);
+                const float D = from_m ? md : dd;
+                // REC_I
+                float iij = j == 1 ? kMinusInf : lastI;
+                iij += e;
+                const float mi = (j == 1 ? kMinusInf : lastM) + S.p.openb[j - 1];
+                const bool open_i = mi >= iij;
+                const float I = open_i ? mi : iij;
+                S.p.tb[i * stride + j] = (uint8_t)(xm | (from_m ? kMD : 0) | (open_i ? kMI : 0));
+                if (i < la && j < lb) {
+                    const float dm = D + close_a, im = I + S.p.closeb[j - 1], mm = m;
+                    const bool pm = mm >= dm && mm >= im;
+                    const bool pd = !pm && dm >= mm && dm >= im;
+                    float nx = match_ab(S, fn, ordn, j);
+                    nx += pm ? mm : (pd ? dm : im);
+                    q1 = nx; x1 = pm ? kMM : (pd ? kDM : kIM);
+                }
+                lastM = m; lastI = I; outD = D; outM = m;
+                if (lane == 63 && i < la) { S.p.bD[j] = D; S.p.bM[j] = m; if (j < lb) { S.p.bN[j + 1] = q1; S.p.bX[j + 1] = x1; } }
+                if (i == la && j == lb) { S.p.result[0] = m; S.p.result[1] = D; S.p.result[2] = I; }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    bool ok = true;
+    if (lane == 0) {
+        const float mab = S.p.result[0], dab = S.p.result[1], iab = S.p.result[2];
+        float score = mab; char type = 'M';
+        if (dab > score) { score = dab; type = 'D'; }
+        if (iab > score) { score = iab; type = 'I'; }
+        int a = la, b = lb, n = 0;
+        uint8_t* rev = S.p.path;
+        for (;;) {
+            if (n >= 2 * kMaxCols + 2) { ok = false; break; }
+            rev[n++] = (uint8_t)type;
+            const uint8_t bits = S.p.tb[a * stride + b];
+            char next;
+            if (type == 'M') {
+                const uint8_t x = bits & kXM;
+                if (x == kMM) next = 'M'; else if (x == kDM) next = 'D'; else if (x == kIM) next = 'I'; else { ok = false; break; }
+                if (a == 0 || b == 0) { ok = false; break; }
+                --a; --b;
+            } else if (type == 'D') {
+                next = (bits & kMD) ? 'M' : 'D';
+                if (a == 0) { ok = false; break; }
+                --a;
+            } else {
+                next = (bits & kMI) ? 'M' : 'I';
+                if (b == 0) { ok = false; break; }
+                --b;
+            }
+            if (a == 0 && b == 0) break;
+            type = next;
+        }
+        for (int x = 0; x < n / 2; x++) { const uint8_t tmp = rev[x]; rev[x] = rev[n - 1 - x]; rev[n - 1 - x] = tmp; }
+        S.flag = ok ? n : -1;
+    }
+    __syncthreads();
+    *plen = S.flag;
+    return S.flag >= 0;
+}
+
+__device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& job, int* out_cols) {
+    const int lane = (int)__lane_id();
+    const int n = job.n, cap = P.cap;
+    if (n < 2 || n > kMaxSeqs) return false;
+    // ---- sequences: lengths, FixAlpha (seq.cpp:331-344) happens when the rows are filled
+    int bad = 0;
+    for (int i = lane; i < n; i += 64) {
+        const int64_t a = P.seq_off[job.first_seq + i], b = P.seq_off[job.first_seq + i + 1];
+        const int L = (int)(b - a);
+        W.len[i] = L;
+        if (L <= 0 || L > cap || L > kMaxCols) bad = 1;
+        uint64_t h = 1469598103934665603ull;
+        for (int x = 0; x < L; x++) { uint8_t ch = P.chars[a + x]; if (c_letter[ch] >= 16) ch = 'N'; h = (h ^ ch) * 1099511628211ull; }
+        W.hash[i] = h ^ (uint64_t)L;
+    }
+    if (wave_sum(bad)) return false;
+    __syncthreads();
+    auto seq_char = [&](int i, int x) -> uint8_t { uint8_t ch = P.chars[P.seq_off[job.first_seq + i] + x]; return c_letter[ch] >= 16 ? (uint8_t)'N' : ch; };
+
+    // ---- distinct strings: cls[i] = first sequence spelling the same string
+    for (int i = lane; i < n; i += 64) {
+        int rep = i;
+        const uint64_t h = W.hash[i]; const int L = W.len[i];
+        for (int o = 0; o < i; o++) {
+            if (W.hash[o] != h || W.len[o] != L) continue;
+            bool same = true;
+            for (int x = 0; x < L && same; x++) same = seq_char(o, x) == seq_char(i, x);
+            if (same) { rep = o; break; }
+        }
+        W.cls[i] = rep;
+    }
+    __syncthreads();
+    int u = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool is_rep = i < n && W.cls[i] == i;
+        const unsigned long long m = __ballot(is_rep);
+        if (is_rep) { const int r = u + __popcll(m & ((1ull << lane) - 1)); W.repidx[i] = r; W.replist[r] = i; }
+        u += __popcll(m);
+    }
+    __syncthreads();
+    // ---- per distinct string: its distinct 6-mers with 8-bit (wrapping) multiplicities (fastdistnuc.cpp:82-90)
+    for (int x = lane * 16; x < kTable; x += 64 * 16) *(uint4*)&S.table[x] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (int a = 0; a < u; a++) {
+        const int i = W.replist[a], L = W.len[i];
+        int nt = 0;
+        if (L >= 6) {
+            for (int p = lane; p < L; p += 64) {
+                uint32_t t = 0;
+                if (p >= 5) for (int x = p - 5; x <= p; x++) { uint8_t l = c_letter[seq_char(i, x)]; if (l >= 4) l = 4; t = t * 6 + l; }
+                S.codes[p] = (uint16_t)t;
+            }
+            __syncthreads();
+            for (int p0 = 0; p0 < L; p0 += 64) {
+                const int p = p0 + lane;
+                bool emit = false; int cnt = 0;
+                if (p >= 5 && p < L) {
+                    const uint16_t mine = S.codes[p];
+                    bool first = true;
+                    for (int q = 5; q < L; q++) { if (S.codes[q] == mine) { cnt++; if (q < p) first = false; } }
+                    emit = first && (cnt & 255) != 0;
+                }
+                const unsigned long long m = __ballot(emit);
+                if (emit) {
+                    const int at = nt + __popcll(m & ((1ull << lane) - 1));
+                    W.tcode[(size_t)a * kMaxCols + at] = S.codes[p]; W.tcnt[(size_t)a * kMaxCols + at] = (uint8_t)(cnt & 255);
+                }
+                nt += __popcll(m);
+            }
+            __syncthreads();
+        }
+        if (lane == 0) W.ntup[a] = nt;
+    }
+    __syncthreads();
+    for (int a = 0; a < u; a++) {
+        const int na = W.ntup[a];
+        for (int t = lane; t < na; t += 64) S.table[W.tcode[(size_t)a * kMaxCols + t]] = W.tcnt[(size_t)a * kMaxCols + t];
+        __syncthreads();
+        for (int b = 0; b <= a; b++) {
+            const int nb = W.ntup[b];
+            int sum = 0;
+            for (int t = lane; t < nb; t += 64) {
+                const uint8_t c1 = S.table[W.tcode[(size_t)b * kMaxCols + t]], c2 = W.tcnt[(size_t)b * kMaxCols + t];
+                sum += c1 < c2 ? c1 : c2;
+            }
+            sum = wave_sum(sum);
+            if (lane == 0) { W.ucommon[(size_t)a * u + b] = (uint16_t)sum; W.ucommon[(size_t)b * u + a] = (uint16_t)sum; }
+        }
+        __syncthreads();
+        for (int t = lane; t < na; t += 64) S.table[W.tcode[(size_t)a * kMaxCols + t]] = 0;
+        __syncthreads();
+    }
+    // ---- distances (fastdistnuc.cpp:236-262)
+    for (int i = 1; i < n; i++) {
+        const int ci = W.repidx[W.cls[i]];
+        double c11 = W.ucommon[(size_t)ci * u + ci];
+        if (c11 == 0) c11 = 1;
+        for (int j = lane; j < i; j += 64) {
+            const int cj = W.repidx[W.cls[j]];
+            double c22 = W.ucommon[(size_t)cj * u + cj];
+            if (c22 == 0) c22 = 1;
+            const unsigned c12 = W.ucommon[(size_t)ci * u + cj];
+            const double d1 = 3.0 * (c11 - c12) / c11;
+            const double d2 = 3.0 * (c22 - c12) / c22;
+            W.dist[tri((unsigned)i, (unsigned)j)] = (float)(d1 < d2 ? d1 : d2);
+        }
+    }
+    if (lane == 0) W.dist[(size_t)n * (n - 1) / 2] = 0.0f;
+    __syncthreads();
+
+    // ---- UPGMB (upgma2.cpp:133-355): 0.1 * average + 0.9 * minimum linkage, stale row minima kept
+    const unsigned un = (unsigned)n;
+    for (unsigned x = lane; x < un; x += 64) {
+        float best = kBigDist; unsigned arg = kNone;
+        for (unsigned j = 0; j < un; j++) {
+            if (j == x) continue;
+            const float d = W.dist[tri(x, j)];
+            if (d < best) { best = d; arg = j; }
+        }
+        S.t.mind[x] = best; S.t.nearest[x] = arg; S.t.node[x] = x;
+    }
+    __syncthreads();
+    for (unsigned k = 0; k + 1 < un; k++) {
+        float best = kBigDist; unsigned lmin = kNone;
+        for (unsigned j = lane; j < un; j += 64) {
+            if (S.t.node[j] == kNone) continue;
+            if (S.t.mind[j] < best) { best = S.t.mind[j]; lmin = j; }
+        }
+        wave_argmin(best, lmin);
+        if (lmin == kNone) return false;
+        const unsigned rmin = S.t.nearest[lmin];
+        if (rmin == kNone || rmin >= un) return false;
+        float new_min = kBigDist; unsigned new_nearest = kNone;
+        for (unsigned j = lane; j < un; j += 64) {
+            if (j == lmin || j == rmin || S.t.node[j] == kNone) continue;
+            const unsigned vl = tri(lmin, j), vr = tri(rmin, j);
+            const float dl = W.dist[vl], dr = W.dist[vr];
+            const float nd = kSueff * ((dl + dr) / 2) + (1 - kSueff) * (dl < dr ? dl : dr);
+            if (S.t.nearest[j] == rmin) S.t.nearest[j] = lmin;
+            W.dist[vl] = nd;
+            if (nd < new_min) { new_min = nd; new_nearest = j; }
+        }
+        wave_argmin(new_min, new_nearest);
+        __syncthreads();
+        if (lane == 0) {
+            const float dlr = W.dist[tri(lmin, rmin)];
+            const float h = dlr / 2;
+            const unsigned ul = S.t.node[lmin], ur = S.t.node[rmin];
+            const float hl = ul < un ? 0 : W.height[ul - un];
+            const float hr = ur < un ? 0 : W.height[ur - un];
+            const unsigned v = un + k;
+            W.left[v] = ul; W.right[v] = ur;
+            W.parent[ul] = v; W.parent[ur] = v;
+            W.to_parent[ul] = (double)(h - hl); W.to_parent[ur] = (double)(h - hr);
+            W.height[k] = h;
+            S.t.node[lmin] = v; S.t.nearest[lmin] = new_nearest; S.t.mind[lmin] = new_min; S.t.node[rmin] = kNone;
+        }
+        __syncthreads();
+    }
+    const unsigned root = 2 * un - 2, nodes = 2 * un - 1;
+    // ---- ClustalW weights (clwwt.cpp:65-163)
+    if (lane == 0) {
+        for (unsigned v = 0; v < nodes; v++) W.under[v] = v < un ? 1 : W.under[W.left[v]] + W.under[W.right[v]];
+        W.lo[root] = 0;
+        for (unsigned v = root; v >= un; v--) { W.lo[W.left[v]] = W.lo[v]; W.lo[W.right[v]] = W.lo[v] + (int32_t)W.under[W.left[v]]; }
+        for (unsigned l = 0; l < un; l++) W.perm[W.lo[l]] = (int32_t)l;
+    }
+    __syncthreads();
+    if (n == 2) { if (lane < 2) W.weight[lane] = 0.5f; }
+    else {
+        for (unsigned v = lane; v < nodes; v += 64) W.strength[v] = v == root ? 0.0 : W.to_parent[v] / (double)W.under[v];
+        __syncthreads();
+        for (unsigned l = lane; l < un; l += 64) {
+            double sum = 0;
+            for (unsigned v = l; v != root; v = W.parent[v]) sum += W.strength[v];
+            if (sum < 0.0001) sum = 1.0;
+            W.weight[l] = (float)sum;
+        }
+        __syncthreads();
+        float total = 0.0;
+        for (unsigned l = 0; l < un; l++) total += W.weight[l];
+        if (total == 0.0) return false;
+        __syncthreads();
+        for (unsigned l = lane; l < un; l += 64) W.weight[l] /= total;
+    }
+    __syncthreads();
+    // ---- leaves: one-row alignments
+    for (int p = 0; p < n; p++) {
+        const int i = W.perm[p], L = W.len[i];
+        uint8_t* row = W.rows + ((size_t)p * 2) * (size_t)cap;
+        for (int x = lane; x < L; x += 64) row[x] = seq_char(i, x);
+        if (lane == 0) { W.cur[p] = 0; W.ncols[i] = L; }
+    }
+    __syncthreads();
+    // ---- progressive alignment (progressivealign.cpp:16-82): children are created before their parent, so ascending
+    // node order computes every alignment after its two inputs (the reference's left-first post-order does the same
+    // merges in another order)
+    for (unsigned v = un; v < nodes; v++) {
+        const unsigned a = W.left[v], b = W.right[v];
+        const int loa = W.lo[a], nsa = (int)W.under[a], la = W.ncols[a];
+        const int lob = W.lo[b], nsb = (int)W.under[b], lb = W.ncols[b];
+        if (la <= 0 || lb <= 0 || la > kMaxCols || lb > kMaxCols) return false;
+        build_profile(S, W, cap, loa, nsa, la, true);
+        build_profile(S, W, cap, lob, nsb, lb, false);
+        int plen = 0;
+        if (!nw_small(S, la, lb, &plen)) return false;
+        if (plen > cap || plen > kMaxCols) return false;
+        // aligngivenpath.cpp:124-255: a column of A, of B, or of both
+        if (lane == 0) {
+            int ca = 0, cb = 0; bool ok = true;
+            for (int c = 0; c < plen; c++) {
+                const uint8_t t = S.p.path[c];
+                if (t != 'I') { if (ca >= la) ok = false; S.p.mapa[c] = (int16_t)ca; ca++; } else S.p.mapa[c] = -1;
+                if (t != 'D') { if (cb >= lb) ok = false; S.p.mapb[c] = (int16_t)cb; cb++; } else S.p.mapb[c] = -1;
+            }
+            S.flag = (ok && ca == la && cb == lb) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!S.flag) return false;
+        for (int s = 0; s < nsa + nsb; s++) {
+            const bool in_a = s < nsa;
+            const int p = in_a ? loa + s : lob + (s - nsa);
+            const uint8_t curb = W.cur[p];
+            const uint8_t* src = W.rows + ((size_t)p * 2 + curb) * (size_t)cap;
+            uint8_t* dst = W.rows + ((size_t)p * 2 + (curb ^ 1)) * (size_t)cap;
+            for (int c = lane; c < plen; c += 64) { const int m = in_a ? S.p.mapa[c] : S.p.mapb[c]; dst[c] = m >= 0 ? src[m] : (uint8_t)'-'; }
+        }
+        __syncthreads();
+        for (int s = lane; s < nsa + nsb; s += 64) { const int p = s < nsa ? loa + s : lob + (s - nsa); W.cur[p] ^= 1; }
+        if (lane == 0) W.ncols[v] = plen;
+        __syncthreads();
+    }
+    const int nc = W.ncols[root];
+    if (nc > job.max_cols) return false;
+    for (int p = 0; p < n; p++) {
+        const uint8_t* src = W.rows + ((size_t)p * 2 + W.cur[p]) * (size_t)cap;
+        uint8_t* dst = P.out_rows + job.row_off + (int64_t)W.perm[p] * job.max_cols;
+        for (int c = lane; c < nc; c += 64) dst[c] = src[c];
+    }
+    *out_cols = nc;
+    return true;
+}
+
+__device__ Slot carve(uint8_t* base, int nmax, int cap) {
+    Slot W;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { uint8_t* p = base + off; off += (bytes + 15) & ~(size_t)15; return p; };
+    const size_t n = (size_t)nmax;
+    W.dist = (float*)take(4 * (n * (n - 1) / 2 + 1));
+    W.ucommon = (uint16_t*)take(2 * n * n);
+    W.tcode = (uint16_t*)take(2 * n * kMaxCols);
+    W.tcnt = take(n * kMaxCols);
+    W.ntup = (int32_t*)take(4 * n);
+    W.hash = (uint64_t*)take(8 * n);
+    W.len = (int32_t*)take(4 * n); W.cls = (int32_t*)take(4 * n); W.repidx = (int32_t*)take(4 * n); W.replist = (int32_t*)take(4 * n);
+    W.left = (uint32_t*)take(8 * n); W.right = (uint32_t*)take(8 * n); W.parent = (uint32_t*)take(8 * n);
+    W.to_parent = (double*)take(16 * n);
+    W.height = (float*)take(4 * n);
+    W.under = (uint32_t*)take(8 * n);
+    W.strength = (double*)take(16 * n);
+    W.weight = (float*)take(4 * n);
+    W.lo = (int32_t*)take(8 * n); W.ncols = (int32_t*)take(8 * n);
+    W.perm = (int32_t*)take(4 * n);
+    W.cur = take(n);
+    W.rows = take(2 * n * (size_t)cap);
+    return W;
+}
+size_t slot_bytes(int nmax, int cap) {
+    const size_t n = (size_t)nmax;
+    auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    return r(4 * (n * (n - 1) / 2 + 1)) + r(2 * n * n) + r(2 * n * kMaxCols) + r(n * kMaxCols) + r(4 * n) + r(8 * n) + 4 * r(4 * n) + 3 * r(8 * n) + r(16 * n) +
+           r(4 * n) + r(8 * n) + r(16 * n) + r(4 * n) + 2 * r(8 * n) + r(4 * n) + r(n) + r(2 * n * (size_t)cap) + 256;
+}
+
+__global__ __launch_bounds__(64) void gap_align_kernel(Params P) {
+    __shared__ Shared S;
+    const Slot W = carve(P.ws + (size_t)blockIdx.x * (size_t)P.ws_stride, P.nmax, P.cap);
+    for (;;) {
+        if (threadIdx.x == 0) S.flag = (int32_t)atomicAdd(P.next, 1ull);
+        __syncthreads();
+        const int64_t j = S.flag;
+        __syncthreads();
+        if (j >= P.njobs) break;
+        const Job job = P.jobs[j];
+        int cols = -1;
+        if (!align_job(S, W, P, job, &cols)) cols = -1;
+        __syncthreads();
+        if (threadIdx.x == 0) P.out_cols[j] = cols;
+    }
+}
+
+thread_local std::string g_err;
+int fail(int code, const std::string& m) { g_err = m; return code; }
+bool g_tables_ready = false;
+}  // namespace
+
+extern "C" const char* pm_gap_last_error(void) { return g_err.c_str(); }
+
+extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
+                                  const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols) {
+    if (n_jobs < 0 || (n_jobs > 0 && (!n_seqs || !seq_off || !chars || !max_cols || !row_off || !out_rows || !cols))) return fail(PM_EINVAL, "bad argument");
+    if (n_jobs == 0) return PM_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(PM_ENODEV, "no HIP device available; the gap aligner of this library has no CPU path");
+    if (device < 0) { const char* e = getenv("PARSNP_DEVICE"); if (e && *e) device = atoi(e); }
+    if (device >= 0 && (device >= count || hipSetDevice(device) != hipSuccess)) return fail(PM_ENODEV, "cannot select the requested HIP device");
+#define GA_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { release(); return fail(PM_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+    std::vector<void*> owned;
+    hipStream_t stream = nullptr;
+    auto release = [&]() { for (void* p : owned) (void)hipFree(p); owned.clear(); if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; } };
+    if (!g_tables_ready) {
+        uint8_t letter[256];
+        memset(letter, 255, sizeof letter);
+        const char* res = "ACGT";
+        for (int i = 0; i < 4; i++) { letter[(uint8_t)res[i]] = (uint8_t)i; letter[(uint8_t)(res[i] + 32)] = (uint8_t)i; }
+        letter[(uint8_t)'U'] = letter[(uint8_t)'u'] = 3;
+        const char* wild = "MRWSYKVHDBXN";
+        for (int i = 0; i < 12; i++) { letter[(uint8_t)wild[i]] = (uint8_t)(4 + i); letter[(uint8_t)(wild[i] + 32)] = (uint8_t)(4 + i); }
+        letter[(uint8_t)'-'] = letter[(uint8_t)'.'] = 16;
+        GA_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_letter), letter, 256));
+        g_tables_ready = true;
+    }
+    // jobs the device takes, longest first (the cost of one alignment grows with the square of its width)
+    std::vector<Job> jobs; std::vector<int64_t> which;
+    int64_t seq = 0, total_chars = 0;
+    int nmax = 2, cap = 1;
+    std::vector<int> widest((size_t)n_jobs, 0);
+    for (int64_t j = 0; j < n_jobs; j++) {
+        cols[j] = -1;
+        const int n = n_seqs[j];
+        int w = 0; bool ok = n >= 2 && n <= kMaxSeqs && max_cols[j] >= 1;
+        for (int i = 0; i < n && ok; i++) { const int64_t L = seq_off[seq + i + 1] - seq_off[seq + i]; if (L <= 0 || L > kMaxCols) ok = false; else w = std::max<int>(w, (int)L); }
+        if (ok && row_off[j] + (int64_t)n * max_cols[j] > out_bytes) ok = false;
+        if (ok) { jobs.push_back(Job{seq, n, max_cols[j], row_off[j]}); which.push_back(j); widest[(size_t)j] = w; nmax = std::max(nmax, n); cap = std::max(cap, std::min<int>(max_cols[j], kMaxCols)); }
+        seq += n;
+    }
+    total_chars = seq_off[seq];
+    if (jobs.empty()) return PM_OK;
+    {
+        std::vector<size_t> order(jobs.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return widest[(size_t)which[a]] > widest[(size_t)which[b]]; });
+        std::vector<Job> j2; std::vector<int64_t> w2;
+        for (size_t i : order) { j2.push_back(jobs[i]); w2.push_back(which[i]); }
+        jobs.swap(j2); which.swap(w2);
+    }
+    hipDeviceProp_t prop;
+    GA_CHECK(hipGetDeviceProperties(&prop, device >= 0 ? device : 0));
+    const int64_t slots = std::min<int64_t>((int64_t)jobs.size(), (int64_t)prop.multiProcessorCount * 3);   // 3 workgroups of 50 KB LDS fit a CU
+    const size_t stride = slot_bytes(nmax, cap);
+    GA_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    auto dalloc = [&](size_t bytes, void** p) { hipError_t e = hipMalloc(p, bytes ? bytes : 1); if (e == hipSuccess) owned.push_back(*p); return e; };
+    Job* d_jobs; int64_t* d_off; uint8_t* d_chars; uint8_t* d_out; int32_t* d_cols; unsigned long long* d_next; uint8_t* d_ws;
+    GA_CHECK(dalloc(sizeof(Job) * jobs.size(), (void**)&d_jobs));
+    GA_CHECK(dalloc(8 * (size_t)(seq + 1), (void**)&d_off));
+    GA_CHECK(dalloc((size_t)total_chars, (void**)&d_chars));
+    GA_CHECK(dalloc((size_t)out_bytes, (void**)&d_out));
+    GA_CHECK(dalloc(4 * jobs.size(), (void**)&d_cols));
+    GA_CHECK(dalloc(8, (void**)&d_next));
+    GA_CHECK(dalloc(stride * (size_t)slots, (void**)&d_ws));
+    GA_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, stream));
+    GA_CHECK(hipMemcpyAsync(d_off, seq_off, 8 * (size_t)(seq + 1), hipMemcpyHostToDevice, stream));
+    GA_CHECK(hipMemcpyAsync(d_chars, chars, (size_t)total_chars, hipMemcpyHostToDevice, stream));
+    GA_CHECK(hipMemsetAsync(d_next, 0, 8, stream));
+    Params P{d_jobs, (int64_t)jobs.size(), d_off, d_chars, d_out, d_cols, d_next, d_ws, (int64_t)stride, nmax, cap};
+    hipLaunchKernelGGL(gap_align_kernel, dim3((unsigned)slots), dim3(64), 0, stream, P);
+    GA_CHECK(hipGetLastError());
+    std::vector<int32_t> got(jobs.size());
+    GA_CHECK(hipMemcpyAsync(got.data(), d_cols, 4 * jobs.size(), hipMemcpyDeviceToHost, stream));
+    GA_CHECK(hipMemcpyAsync(out_rows, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, stream));
+    GA_CHECK(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < jobs.size(); i++) cols[which[i]] = got[i];
+    release();
+#undef GA_CHECK
+    return PM_OK;
+}

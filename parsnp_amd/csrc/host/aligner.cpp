@@ -185,7 +185,12 @@ void Aligner::neighbour_into(const Mum& m, bool left, Region* out) const {
 bool Aligner::neighbour_if_longer(const Mum& m, bool left, long q, Region* out, long* short_j, long* short_len, long* short_stop) const {
     long* start = out->start; long* end = out->end; long* length = out->length;
     long s = 500000000, l = 0;
+    // most regions are dropped in the first genome or two; one that survives those is usually kept, and then every genome's
+    // walk starts with a cache miss in a different bitmap: ask for all of those words at once
+    constexpr size_t kProbe = 3;
     for (size_t i = 0; i < n; i++) {
+        if (i == kProbe)
+            for (size_t x = kProbe; x < n; x++) layout[x].prefetch_read(left ? (long)m.start[x] - 1 : m.end(x) + 1);
         long a, b, stop;
         if (left) {
             long p = layout[i].prev_set((long)m.start[i] - 1);
@@ -1156,7 +1161,17 @@ bool Aligner::extend_generations() {
                 if (pending_min >= 0 && pending_min <= r.start[0]) { cluster_trouble = 1; break; }
                 const Raw& raw = raws[(size_t)now_raw[x]];
                 Out& o = out[x];
+                // the words the touch test of a candidate reads (first and last base in every genome) are requested one
+                // candidate ahead: 2 n cache misses in n different bitmaps otherwise
+                auto warm = [&](const Raw& w, size_t c) {
+                    if (!w.start || c >= w.count) return;
+                    const int32_t* st = w.start + c * n; const long lon = w.lon[c];
+                    for (size_t j = 0; j < n; j++) { layout[j].prefetch((long)st[j]); layout[j].prefetch((long)st[j] + lon - 1); }
+                };
+                if (x == first[(size_t)cl]) warm(raw, 0);
+                if (x + 1 < first[(size_t)cl + 1]) warm(raws[(size_t)now_raw[x + 1]], 0);
                 for (size_t c = 0; c < raw.count; c++) {      // = validate(), with per-thread rows and atomic marks
+                    warm(raw, c + 1);
                     Mum mm;
                     const Arena<int32_t>::Mark imark = tl.irows.mark();
                     const Arena<uint8_t>::Mark bmark = tl.brows.mark();

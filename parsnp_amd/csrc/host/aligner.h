@@ -76,6 +76,7 @@ public:
     }
     bool get(long i) const { return (w_[(size_t)i >> 6] >> (i & 63)) & 1; }
     void prefetch(long i) const { if (i >= 0 && (size_t)i < nbits_) __builtin_prefetch(&w_[(size_t)i >> 6], 1, 1); }
+    void prefetch_read(long i) const { if (i >= 0 && (size_t)i < nbits_) __builtin_prefetch(&w_[(size_t)i >> 6], 0, 1); }
     void set_range(long a, long b) {    // [a,b) := 1
         if (a >= 0 && b <= (long)nbits_ && a < b && ((size_t)a >> 6) == ((size_t)(b - 1) >> 6)) {   // inside one word: the common case
             const size_t wi = (size_t)a >> 6;

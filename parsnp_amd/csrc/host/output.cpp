@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <future>
 #include <iomanip>
 #include <iostream>
 #include <sstream>
@@ -155,18 +156,72 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     // would leave every other thread idle
     std::sort(jobs.begin(), jobs.end(), [](const Gap* x, const Gap* y) { return x->max_len > y->max_len; });
     const long nj = (long)jobs.size();
+    // The gaps go to the device in ONE batch (pm_gap_align_batch: one wavefront per gap, include/parsnp_mum.h); the few the
+    // device does not take -- wider than its 160-column limit, or declined -- are aligned here by the host threads, the
+    // widest ones while the device works on the rest.  PARSNP_HOST_GAPS=1: everything on the host (measurement / tests).
+    constexpr unsigned kDeviceCols = 160;
+    static const bool host_gaps = getenv("PARSNP_HOST_GAPS") != nullptr;
+    vector<char> on_device((size_t)nj, 0);
+    vector<int32_t> d_nseq, d_maxcols, d_cols; vector<int64_t> d_seqoff{0}, d_rowoff; vector<uint8_t> d_chars, d_out;
+    vector<long> d_job;
+    if (!host_gaps) {
+        int64_t out_bytes = 0;
+        for (long x = 0; x < nj; x++) {
+            const Gap& gp = *jobs[(size_t)x];
+            if (gp.max_len > kDeviceCols || gp.seq.size() > 512) continue;
+            on_device[(size_t)x] = 1; d_job.push_back(x);
+            const int32_t cap = (int32_t)std::min<unsigned>(kDeviceCols, gp.max_len + gp.max_len / 2 + 16);
+            d_nseq.push_back((int32_t)gp.seq.size()); d_maxcols.push_back(cap); d_rowoff.push_back(out_bytes);
+            out_bytes += (int64_t)gp.seq.size() * cap;
+            for (const string& q : gp.seq) { d_chars.insert(d_chars.end(), q.begin(), q.end()); d_seqoff.push_back((int64_t)d_chars.size()); }
+        }
+        d_out.resize((size_t)out_bytes); d_cols.assign(d_job.size(), -1);
+    }
+    std::future<int> device_done;
+    if (!d_job.empty())
+        device_done = std::async(std::launch::async, [&] {
+            return pm_gap_align_batch(-1, (int64_t)d_job.size(), d_nseq.data(), d_seqoff.data(), d_chars.data(), d_maxcols.data(), d_rowoff.data(),
+                                      d_out.data(), (int64_t)d_out.size(), d_cols.data());
+        });
     vector<double> jt(dbg ? (size_t)nj : 0);
+    auto host_align = [&](const vector<long>& which) {
+        const long nw = (long)which.size();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-    for (long x = 0; x < nj; x++) {
-        Gap& gp = *jobs[(size_t)x];
-        const double t0 = dbg ? clock_s() : 0;
-        gp.failed = !gap_align(gp.seq, &gp.aligned);
-        if (dbg) jt[(size_t)x] = clock_s() - t0;
+        for (long y = 0; y < nw; y++) {
+            const long x = which[(size_t)y];
+            Gap& gp = *jobs[(size_t)x];
+            const double t0 = dbg ? clock_s() : 0;
+            gp.failed = !gap_align(gp.seq, &gp.aligned);
+            if (dbg) jt[(size_t)x] = clock_s() - t0;
+        }
+    };
+    vector<long> rest;
+    for (long x = 0; x < nj; x++) if (!on_device[(size_t)x]) rest.push_back(x);
+    host_align(rest);
+    long declined = 0;
+    if (!d_job.empty()) {
+        if (device_done.get() != PM_OK) { cerr << "parsnp_core: gap alignment on the device failed: " << pm_gap_last_error() << endl; exit(1); }
+        lap("gaps: device");
+        rest.clear();
+        const long nd = (long)d_job.size();
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (long y = 0; y < nd; y++) {
+            if (d_cols[(size_t)y] < 0) continue;
+            Gap& gp = *jobs[(size_t)d_job[(size_t)y]];
+            gp.aligned.resize(gp.seq.size());
+            const char* base = (const char*)d_out.data() + d_rowoff[(size_t)y];
+            for (size_t i = 0; i < gp.seq.size(); i++) gp.aligned[i].assign(base + i * (size_t)d_maxcols[(size_t)y], (size_t)d_cols[(size_t)y]);
+            gp.failed = false;
+        }
+        for (long y = 0; y < nd; y++) if (d_cols[(size_t)y] < 0) rest.push_back(d_job[(size_t)y]);
+        declined = (long)rest.size();
+        host_align(rest);
     }
     if (dbg && nj) {
         double sum = 0, mx = 0; long arg = 0;
         for (long x = 0; x < nj; x++) { sum += jt[(size_t)x]; if (jt[(size_t)x] > mx) { mx = jt[(size_t)x]; arg = x; } }
-        fprintf(stderr, "[output] %ld gap alignments, %.3f s of work, longest %.3f s (gap of %u columns)\n", nj, sum, mx, jobs[(size_t)arg]->max_len);
+        fprintf(stderr, "[output] %ld gap alignments: %zu on the device (%ld declined), %.3f s of host work, longest %.3f s (gap of %u columns)\n",
+                nj, d_job.size(), declined, sum, mx, jobs[(size_t)arg]->max_len);
     }
     lap("gap alignment");
 #pragma omp parallel for schedule(dynamic) num_threads(threads)

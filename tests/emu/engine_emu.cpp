@@ -42,3 +42,10 @@ typedef HostBackend PmBackend;
 static const char* pm_backend_name = "emu";
 static PmBackend* pm_backend_open(int, std::string*) { return new HostBackend; }
 #include "../../parsnp_amd/csrc/engine/abi_glue.h"
+
+// the device gap aligner is a HIP kernel with no host emulation: decline every job, the host aligner takes them
+extern "C" int pm_gap_align_batch(int, int64_t n_jobs, const int32_t*, const int64_t*, const uint8_t*, const int32_t*, const int64_t*, uint8_t*, int64_t, int32_t* cols) {
+    for (int64_t j = 0; j < n_jobs; j++) cols[j] = -1;
+    return PM_OK;
+}
+extern "C" const char* pm_gap_last_error(void) { return ""; }

@@ -1,0 +1,122 @@
+"""The inter-MUM gap aligner ON THE DEVICE (pm_gap_align_batch in parsnp_amd/lib/libparsnp_hip.so, one wavefront per gap)
+against the reference's MUSCLE call: the committed vectors produced by the reference (tests/golden/gapalign.json), the
+host restatement (parsnp_amd/csrc/host/gapalign.cpp, itself pinned against libMUSCLE) on fresh seeded sets including
+200-sequence gaps, and -- where it ships -- the reference's own MuscleInterface (oracle/_ref/muscle_ref).
+The bar is identical rows; jobs the device declines (cols = -1) must be exactly the ones outside its documented limits."""
+import ctypes as C
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import gapgen
+from parsnp_amd.paths import HIP_LIB
+from test_gapalign import aligner  # noqa: F401  (fixture: the host restatement)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEVICE_COLS = 160
+
+
+@pytest.fixture(scope="module")
+def device():
+    lib = C.CDLL(HIP_LIB)
+    lib.pm_gap_align_batch.restype = C.c_int
+    lib.pm_gap_last_error.restype = C.c_char_p
+
+    def run(blocks, slack=None):
+        """-> per block: list of rows, or None where the device declined"""
+        nseq = np.array([len(b) for b in blocks], np.int32)
+        flat = [s.encode() for b in blocks for s in b]
+        off = np.zeros(len(flat) + 1, np.int64)
+        off[1:] = np.cumsum([len(s) for s in flat])
+        chars = np.frombuffer(b"".join(flat) or b"\0", np.uint8).copy()
+        maxc = np.array([min(DEVICE_COLS, (max(len(s) for s in b) * 3) // 2 + 16) if slack is None else slack for b in blocks], np.int32)
+        row_off = np.zeros(len(blocks), np.int64)
+        row_off[1:] = np.cumsum(nseq[:-1].astype(np.int64) * maxc[:-1])
+        out = np.zeros(int((nseq.astype(np.int64) * maxc).sum()) + 1, np.uint8)
+        cols = np.full(len(blocks), -7, np.int32)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))   # noqa: E731
+        rc = lib.pm_gap_align_batch(C.c_int(-1), C.c_int64(len(blocks)), p(nseq, C.c_int32), p(off, C.c_int64), p(chars, C.c_uint8),
+                                    p(maxc, C.c_int32), p(row_off, C.c_int64), p(out, C.c_uint8), C.c_int64(len(out)), p(cols, C.c_int32))
+        assert rc == 0, lib.pm_gap_last_error()
+        res = []
+        for j, b in enumerate(blocks):
+            if cols[j] < 0:
+                res.append(None)
+                continue
+            base = int(row_off[j])
+            res.append([out[base + i * int(maxc[j]): base + i * int(maxc[j]) + int(cols[j])].tobytes().decode() for i in range(len(b))])
+        return res
+    return run
+
+
+def fits(block):
+    return len(block) >= 2 and all(0 < len(s) <= DEVICE_COLS for s in block)
+
+
+def test_committed_vectors(device):
+    data = json.load(open(os.path.join(ROOT, "tests", "golden", "gapalign.json")))
+    got = device([blk["in"] for blk in data])
+    done = 0
+    for blk, rows in zip(data, got):
+        if rows is None:      # declined: only what is outside the limits (a sequence or an alignment wider than 160 columns)
+            assert not fits(blk["in"]) or max(len(r) for r in blk["out"]) > (max(len(s) for s in blk["in"]) * 3) // 2 + 16 or max(len(r) for r in blk["out"]) > DEVICE_COLS, blk["in"]
+            continue
+        assert rows == blk["out"], blk["in"]
+        done += 1
+    assert done > 200
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_fresh_sets_against_host_restatement(device, aligner, seed):  # noqa: F811
+    blks = gapgen.blocks(seed, 400, lengths=(1, 2, 3, 4, 5, 6, 7, 10, 15, 30, 60, 120))
+    got = device(blks)
+    done = 0
+    for blk, rows in zip(blks, got):
+        want = aligner(blk)
+        if rows is None:
+            assert not fits(blk) or len(want[0]) > min(DEVICE_COLS, (max(len(s) for s in blk) * 3) // 2 + 16), blk
+            continue
+        assert rows == want, blk
+        done += 1
+    assert done > 300
+
+
+def test_many_sequences_per_gap(device, aligner):  # noqa: F811
+    """gaps as the headline workload has them: 201 sequences that are copies of a few alleles, and 201 all different"""
+    rng = random.Random(5)
+    blks = []
+    for k in range(60):
+        L = rng.choice([2, 3, 5, 8, 13, 21, 40, 90])
+        base = "".join(rng.choice("ACGT") for _ in range(L))
+        alleles = [gapgen.mutate(rng, base, rng.choice([0.05, 0.2, 0.5])) for _ in range(rng.choice([2, 3, 5, 9]))]
+        if k % 3 == 0:
+            blks.append([gapgen.mutate(rng, base, 0.15) for _ in range(201)])
+        else:
+            blks.append([rng.choice(alleles) for _ in range(201)])
+    blks.append(["ACGTN"[i % 5] * (1 + i % 7) for i in range(512)])      # the most sequences the device takes
+    got = device(blks)
+    for blk, rows in zip(blks, got):
+        assert rows is not None, blk[:3]
+        assert rows == aligner(blk), blk[:3]
+
+
+def test_declines_and_limits(device):
+    got = device([["ACGT", "ACG"], ["A" * 161, "A" * 100], ["ACGT"] * 513, ["ACGTACGTAA", "TTTTTTTTTT"]], slack=None)
+    assert got[0] is not None and got[3] is not None
+    assert got[1] is None and got[2] is None          # wider than 160 columns / more than 512 sequences
+    # a row capacity smaller than the alignment: declined, not overrun
+    tight = device([["ACGTACGTAA", "TTTTTTTTTTAC"]], slack=12)
+    assert tight[0] is None or len(tight[0][0]) <= 12
+
+
+@pytest.mark.skipif(not os.path.exists(gapgen.MUSCLE_REF), reason="oracle/_ref/muscle_ref not shipped")
+def test_fresh_sets_against_reference(device):
+    blks = [b for b in gapgen.blocks(31, 300, lengths=(1, 2, 3, 5, 7, 10, 15, 30, 60, 120)) if fits(b)]
+    got = device(blks)
+    for blk, want, rows in zip(blks, gapgen.reference_align(blks), got):
+        if rows is not None:
+            assert rows == want, blk
