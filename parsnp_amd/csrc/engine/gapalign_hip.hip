@@ -79,13 +79,18 @@ struct Slot {
     int32_t* perm;          // [n] row -> sequence
     uint8_t* cur;           // [n] which of a row's two buffers is current
     uint8_t* rows;          // [n][2][cap]
+    uint8_t* table;         // [46656] 6-mer counts of one string (fastdistnuc.cpp:82), all zero between uses
 };
 
 struct Params {
     const Job* jobs; int64_t njobs; const int64_t* seq_off; const uint8_t* chars;
     uint8_t* out_rows; int32_t* out_cols; unsigned long long* next; uint8_t* ws; int64_t ws_stride; int32_t nmax, cap;
+    volatile int32_t* dbg;     // PM_GAP_DEBUG: per slot (job, stage) in host memory the host can read while the kernel runs
 };
 
+// every lane's outstanding loads / stores (global and LDS) have completed before any lane goes on: the lanes of the one
+// wavefront of a workgroup talk to each other through global workspace and LDS
+#define GA_SYNC() do { __builtin_amdgcn_s_waitcnt(0); __threadfence_block(); __syncthreads(); } while (0)
 __device__ inline unsigned tri(unsigned a, unsigned b) { return a >= b ? b + (a * (a - 1)) / 2 : a + (b * (b - 1)) / 2; }
 __device__ inline bool is_gap(uint8_t c) { return c == '-' || c == '.'; }
 
@@ -101,19 +106,16 @@ __device__ inline void wave_argmin(float& v, unsigned& i) {
 
 // LDS of the one wavefront of a workgroup, used phase after phase
 struct __align__(16) Shared {
-    union {
-        uint8_t table[kTable];                                    // distances: 6-mer counts
-        struct { float mind[kMaxSeqs]; unsigned nearest[kMaxSeqs]; unsigned node[kMaxSeqs]; } t;      // tree
-        struct {
+    struct { float mind[kMaxSeqs]; unsigned nearest[kMaxSeqs]; unsigned node[kMaxSeqs]; } t;      // tree
+    struct {
             float fa[4][kMaxCols]; uint8_t orda[kMaxCols]; float opena[kMaxCols], closea[kMaxCols];   // profile A: sorted counts, their letters
             float sb[4][kMaxCols]; float openb[kMaxCols], closeb[kMaxCols];                           // profile B: scores per letter
             float bD[kMaxCols + 2], bM[kMaxCols + 2], bN[kMaxCols + 2]; uint8_t bX[kMaxCols + 2];     // row handed from one 64-row stripe to the next
             uint8_t tb[(kMaxCols + 1) * (kMaxCols + 1)];
             uint8_t path[2 * kMaxCols + 2];
             int16_t mapa[2 * kMaxCols + 2], mapb[2 * kMaxCols + 2];
-            float result[3];
-        } p;
-    };
+        float result[3];
+    } p;
     uint16_t codes[kMaxCols];
     int32_t flag;
 };
@@ -148,7 +150,7 @@ __device__ void build_profile(Shared& S, const Slot& W, int cap, int lo, int ns,
             }
             unsigned order[4] = {0, 1, 2, 3};       // profilefrommsa.cpp:180-204: bubble sort, strict <
             bool any = true;
-            while (any) {
+            for (int pass = 0; any && pass < 8; pass++) {     // at most 3 passes move anything
                 any = false;
                 for (unsigned k = 0; k < 3; k++) {
                     const unsigned a = order[k], b = order[k + 1];
@@ -171,7 +173,7 @@ __device__ void build_profile(Shared& S, const Slot& W, int cap, int lo, int ns,
             }
         }
     }
-    __syncthreads();
+    GA_SYNC();
 }
 
 // scorepp.cpp:83-95 with all four terms (a count of 0 ends the reference's loop; its term is +-0 here, the zeros come last)
@@ -195,7 +197,7 @@ __device__ bool nw_small(Shared& S, int la, int lb, int* plen) {
     }
     for (int x = lane; x <= la; x += 64) S.p.tb[x * stride] = 0;
     for (int x = lane; x <= lb; x += 64) S.p.tb[x] = 0;
-    __syncthreads();
+    GA_SYNC();
     const float open_a0 = S.p.opena[0], open_b0 = S.p.openb[0];
     for (int r0 = 0; r0 < la; r0 += 64) {
         const int i = r0 + lane + 1;                    // this lane's row (1-based)
@@ -260,9 +262,9 @@ __device__ bool nw_small(Shared& S, int la, int lb, int* plen) {
                 if (i == la && j == lb) { S.p.result[0] = m; S.p.result[1] = D; S.p.result[2] = I; }
             }
         }
-        __syncthreads();
+        GA_SYNC();
     }
-    __syncthreads();
+    GA_SYNC();
     bool ok = true;
     if (lane == 0) {
         const float mab = S.p.result[0], dab = S.p.result[1], iab = S.p.result[2];
@@ -296,11 +298,12 @@ __device__ bool nw_small(Shared& S, int la, int lb, int* plen) {
         for (int x = 0; x < n / 2; x++) { const uint8_t tmp = rev[x]; rev[x] = rev[n - 1 - x]; rev[n - 1 - x] = tmp; }
         S.flag = ok ? n : -1;
     }
-    __syncthreads();
+    GA_SYNC();
     *plen = S.flag;
     return S.flag >= 0;
 }
 
+#define GA_STAGE(stage_) do { if (P.dbg && lane == 0) P.dbg[blockIdx.x * 2 + 1] = (stage_); } while (0)
 __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& job, int* out_cols) {
     const int lane = (int)__lane_id();
     const int n = job.n, cap = P.cap;
@@ -317,9 +320,10 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         W.hash[i] = h ^ (uint64_t)L;
     }
     if (wave_sum(bad)) return false;
-    __syncthreads();
+    GA_SYNC();
     auto seq_char = [&](int i, int x) -> uint8_t { uint8_t ch = P.chars[P.seq_off[job.first_seq + i] + x]; return c_letter[ch] >= 16 ? (uint8_t)'N' : ch; };
 
+    GA_STAGE(1);
     // ---- distinct strings: cls[i] = first sequence spelling the same string
     for (int i = lane; i < n; i += 64) {
         int rep = i;
@@ -332,7 +336,7 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         }
         W.cls[i] = rep;
     }
-    __syncthreads();
+    GA_SYNC();
     int u = 0;
     for (int i0 = 0; i0 < n; i0 += 64) {
         const int i = i0 + lane;
@@ -341,10 +345,11 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         if (is_rep) { const int r = u + __popcll(m & ((1ull << lane) - 1)); W.repidx[i] = r; W.replist[r] = i; }
         u += __popcll(m);
     }
-    __syncthreads();
+    GA_SYNC();
+    GA_STAGE(2);
     // ---- per distinct string: its distinct 6-mers with 8-bit (wrapping) multiplicities (fastdistnuc.cpp:82-90)
-    for (int x = lane * 16; x < kTable; x += 64 * 16) *(uint4*)&S.table[x] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    for (int x = lane; x < kTable; x += 64) W.table[x] = 0;
+    GA_SYNC();
     for (int a = 0; a < u; a++) {
         const int i = W.replist[a], L = W.len[i];
         int nt = 0;
@@ -354,7 +359,7 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
                 if (p >= 5) for (int x = p - 5; x <= p; x++) { uint8_t l = c_letter[seq_char(i, x)]; if (l >= 4) l = 4; t = t * 6 + l; }
                 S.codes[p] = (uint16_t)t;
             }
-            __syncthreads();
+            GA_SYNC();
             for (int p0 = 0; p0 < L; p0 += 64) {
                 const int p = p0 + lane;
                 bool emit = false; int cnt = 0;
@@ -371,29 +376,30 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
                 }
                 nt += __popcll(m);
             }
-            __syncthreads();
+            GA_SYNC();
         }
         if (lane == 0) W.ntup[a] = nt;
     }
-    __syncthreads();
+    GA_SYNC();
     for (int a = 0; a < u; a++) {
         const int na = W.ntup[a];
-        for (int t = lane; t < na; t += 64) S.table[W.tcode[(size_t)a * kMaxCols + t]] = W.tcnt[(size_t)a * kMaxCols + t];
-        __syncthreads();
+        for (int t = lane; t < na; t += 64) W.table[W.tcode[(size_t)a * kMaxCols + t]] = W.tcnt[(size_t)a * kMaxCols + t];
+        GA_SYNC();
         for (int b = 0; b <= a; b++) {
             const int nb = W.ntup[b];
             int sum = 0;
             for (int t = lane; t < nb; t += 64) {
-                const uint8_t c1 = S.table[W.tcode[(size_t)b * kMaxCols + t]], c2 = W.tcnt[(size_t)b * kMaxCols + t];
+                const uint8_t c1 = W.table[W.tcode[(size_t)b * kMaxCols + t]], c2 = W.tcnt[(size_t)b * kMaxCols + t];
                 sum += c1 < c2 ? c1 : c2;
             }
             sum = wave_sum(sum);
             if (lane == 0) { W.ucommon[(size_t)a * u + b] = (uint16_t)sum; W.ucommon[(size_t)b * u + a] = (uint16_t)sum; }
         }
-        __syncthreads();
-        for (int t = lane; t < na; t += 64) S.table[W.tcode[(size_t)a * kMaxCols + t]] = 0;
-        __syncthreads();
+        GA_SYNC();
+        for (int t = lane; t < na; t += 64) W.table[W.tcode[(size_t)a * kMaxCols + t]] = 0;
+        GA_SYNC();
     }
+    GA_STAGE(3);
     // ---- distances (fastdistnuc.cpp:236-262)
     for (int i = 1; i < n; i++) {
         const int ci = W.repidx[W.cls[i]];
@@ -410,8 +416,9 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         }
     }
     if (lane == 0) W.dist[(size_t)n * (n - 1) / 2] = 0.0f;
-    __syncthreads();
+    GA_SYNC();
 
+    GA_STAGE(4);
     // ---- UPGMB (upgma2.cpp:133-355): 0.1 * average + 0.9 * minimum linkage, stale row minima kept
     const unsigned un = (unsigned)n;
     for (unsigned x = lane; x < un; x += 64) {
@@ -423,7 +430,7 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         }
         S.t.mind[x] = best; S.t.nearest[x] = arg; S.t.node[x] = x;
     }
-    __syncthreads();
+    GA_SYNC();
     for (unsigned k = 0; k + 1 < un; k++) {
         float best = kBigDist; unsigned lmin = kNone;
         for (unsigned j = lane; j < un; j += 64) {
@@ -445,7 +452,7 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
             if (nd < new_min) { new_min = nd; new_nearest = j; }
         }
         wave_argmin(new_min, new_nearest);
-        __syncthreads();
+        GA_SYNC();
         if (lane == 0) {
             const float dlr = W.dist[tri(lmin, rmin)];
             const float h = dlr / 2;
@@ -459,9 +466,10 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
             W.height[k] = h;
             S.t.node[lmin] = v; S.t.nearest[lmin] = new_nearest; S.t.mind[lmin] = new_min; S.t.node[rmin] = kNone;
         }
-        __syncthreads();
+        GA_SYNC();
     }
     const unsigned root = 2 * un - 2, nodes = 2 * un - 1;
+    GA_STAGE(5);
     // ---- ClustalW weights (clwwt.cpp:65-163)
     if (lane == 0) {
         for (unsigned v = 0; v < nodes; v++) W.under[v] = v < un ? 1 : W.under[W.left[v]] + W.under[W.right[v]];
@@ -469,25 +477,30 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         for (unsigned v = root; v >= un; v--) { W.lo[W.left[v]] = W.lo[v]; W.lo[W.right[v]] = W.lo[v] + (int32_t)W.under[W.left[v]]; }
         for (unsigned l = 0; l < un; l++) W.perm[W.lo[l]] = (int32_t)l;
     }
-    __syncthreads();
+    GA_SYNC();
     if (n == 2) { if (lane < 2) W.weight[lane] = 0.5f; }
     else {
         for (unsigned v = lane; v < nodes; v += 64) W.strength[v] = v == root ? 0.0 : W.to_parent[v] / (double)W.under[v];
-        __syncthreads();
+        GA_SYNC();
+        int broken = 0;
         for (unsigned l = lane; l < un; l += 64) {
             double sum = 0;
-            for (unsigned v = l; v != root; v = W.parent[v]) sum += W.strength[v];
+            unsigned steps = 0;
+            for (unsigned v = l; v != root && steps <= nodes; v = W.parent[v], steps++) { if (v >= nodes) { steps = nodes + 1; break; } sum += W.strength[v]; }
+            if (steps > nodes) broken = 1;
             if (sum < 0.0001) sum = 1.0;
             W.weight[l] = (float)sum;
         }
-        __syncthreads();
+        if (wave_sum(broken)) return false;        // not a tree: cannot happen, and must not spin if it does
+        GA_SYNC();
         float total = 0.0;
         for (unsigned l = 0; l < un; l++) total += W.weight[l];
         if (total == 0.0) return false;
-        __syncthreads();
+        GA_SYNC();
         for (unsigned l = lane; l < un; l += 64) W.weight[l] /= total;
     }
-    __syncthreads();
+    GA_SYNC();
+    GA_STAGE(6);
     // ---- leaves: one-row alignments
     for (int p = 0; p < n; p++) {
         const int i = W.perm[p], L = W.len[i];
@@ -495,7 +508,8 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         for (int x = lane; x < L; x += 64) row[x] = seq_char(i, x);
         if (lane == 0) { W.cur[p] = 0; W.ncols[i] = L; }
     }
-    __syncthreads();
+    GA_SYNC();
+    GA_STAGE(7);
     // ---- progressive alignment (progressivealign.cpp:16-82): children are created before their parent, so ascending
     // node order computes every alignment after its two inputs (the reference's left-first post-order does the same
     // merges in another order)
@@ -504,10 +518,13 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         const int loa = W.lo[a], nsa = (int)W.under[a], la = W.ncols[a];
         const int lob = W.lo[b], nsb = (int)W.under[b], lb = W.ncols[b];
         if (la <= 0 || lb <= 0 || la > kMaxCols || lb > kMaxCols) return false;
+        GA_STAGE(100 + (int)(v - un) * 10);
         build_profile(S, W, cap, loa, nsa, la, true);
         build_profile(S, W, cap, lob, nsb, lb, false);
         int plen = 0;
+        GA_STAGE(101 + (int)(v - un) * 10);
         if (!nw_small(S, la, lb, &plen)) return false;
+        GA_STAGE(102 + (int)(v - un) * 10);
         if (plen > cap || plen > kMaxCols) return false;
         // aligngivenpath.cpp:124-255: a column of A, of B, or of both
         if (lane == 0) {
@@ -519,7 +536,7 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
             }
             S.flag = (ok && ca == la && cb == lb) ? 1 : 0;
         }
-        __syncthreads();
+        GA_SYNC();
         if (!S.flag) return false;
         for (int s = 0; s < nsa + nsb; s++) {
             const bool in_a = s < nsa;
@@ -529,10 +546,10 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
             uint8_t* dst = W.rows + ((size_t)p * 2 + (curb ^ 1)) * (size_t)cap;
             for (int c = lane; c < plen; c += 64) { const int m = in_a ? S.p.mapa[c] : S.p.mapb[c]; dst[c] = m >= 0 ? src[m] : (uint8_t)'-'; }
         }
-        __syncthreads();
+        GA_SYNC();
         for (int s = lane; s < nsa + nsb; s += 64) { const int p = s < nsa ? loa + s : lob + (s - nsa); W.cur[p] ^= 1; }
         if (lane == 0) W.ncols[v] = plen;
-        __syncthreads();
+        GA_SYNC();
     }
     const int nc = W.ncols[root];
     if (nc > job.max_cols) return false;
@@ -567,13 +584,14 @@ __device__ Slot carve(uint8_t* base, int nmax, int cap) {
     W.perm = (int32_t*)take(4 * n);
     W.cur = take(n);
     W.rows = take(2 * n * (size_t)cap);
+    W.table = take(kTable);
     return W;
 }
 size_t slot_bytes(int nmax, int cap) {
     const size_t n = (size_t)nmax;
     auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
     return r(4 * (n * (n - 1) / 2 + 1)) + r(2 * n * n) + r(2 * n * kMaxCols) + r(n * kMaxCols) + r(4 * n) + r(8 * n) + 4 * r(4 * n) + 3 * r(8 * n) + r(16 * n) +
-           r(4 * n) + r(8 * n) + r(16 * n) + r(4 * n) + 2 * r(8 * n) + r(4 * n) + r(n) + r(2 * n * (size_t)cap) + 256;
+           r(4 * n) + r(8 * n) + r(16 * n) + r(4 * n) + 2 * r(8 * n) + r(4 * n) + r(n) + r(2 * n * (size_t)cap) + r(kTable) + 256;
 }
 
 __global__ __launch_bounds__(64) void gap_align_kernel(Params P) {
@@ -581,24 +599,42 @@ __global__ __launch_bounds__(64) void gap_align_kernel(Params P) {
     const Slot W = carve(P.ws + (size_t)blockIdx.x * (size_t)P.ws_stride, P.nmax, P.cap);
     for (;;) {
         if (threadIdx.x == 0) S.flag = (int32_t)atomicAdd(P.next, 1ull);
-        __syncthreads();
+        GA_SYNC();
         const int64_t j = S.flag;
-        __syncthreads();
+        GA_SYNC();
         if (j >= P.njobs) break;
         const Job job = P.jobs[j];
+        if (P.dbg && threadIdx.x == 0) { P.dbg[blockIdx.x * 2] = (int32_t)j; P.dbg[blockIdx.x * 2 + 1] = 0; }
         int cols = -1;
         if (!align_job(S, W, P, job, &cols)) cols = -1;
-        __syncthreads();
+        GA_SYNC();
         if (threadIdx.x == 0) P.out_cols[j] = cols;
+        if (P.dbg && threadIdx.x == 0) P.dbg[blockIdx.x * 2 + 1] = -1;
     }
 }
 
 thread_local std::string g_err;
+int32_t* g_dbg = nullptr; int64_t g_dbg_slots = 0;
+int32_t* g_dbg_dev = nullptr;      // PM_GAP_DEBUG=2: the markers live in device memory (cheap to write), peeked through a copy on another stream
 int fail(int code, const std::string& m) { g_err = m; return code; }
 bool g_tables_ready = false;
 }  // namespace
 
 extern "C" const char* pm_gap_last_error(void) { return g_err.c_str(); }
+// PM_GAP_DEBUG=1: (job, stage) of every slot of the running launch, readable from another thread
+extern "C" int64_t pm_gap_debug_peek(int32_t* out, int64_t cap) {
+    int64_t n = 0;
+    if (g_dbg_dev) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return -1;
+        n = std::min<int64_t>(cap, 2 * g_dbg_slots);
+        if (hipMemcpyAsync(out, g_dbg_dev, 4 * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) n = -2;
+        (void)hipStreamDestroy(st);
+        return n;
+    }
+    for (int64_t i = 0; g_dbg && i < 2 * g_dbg_slots && i < cap; i++) out[n++] = g_dbg[i];
+    return n;
+}
 
 extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
                                   const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols) {
@@ -666,7 +702,16 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
     GA_CHECK(hipMemcpyAsync(d_off, seq_off, 8 * (size_t)(seq + 1), hipMemcpyHostToDevice, stream));
     GA_CHECK(hipMemcpyAsync(d_chars, chars, (size_t)total_chars, hipMemcpyHostToDevice, stream));
     GA_CHECK(hipMemsetAsync(d_next, 0, 8, stream));
-    Params P{d_jobs, (int64_t)jobs.size(), d_off, d_chars, d_out, d_cols, d_next, d_ws, (int64_t)stride, nmax, cap};
+    int32_t* dbg = nullptr;
+    if (getenv("PM_GAP_DEBUG") && atoi(getenv("PM_GAP_DEBUG")) == 2) {
+        if (g_dbg_dev) (void)hipFree(g_dbg_dev);
+        g_dbg_dev = nullptr;
+        if (hipMalloc((void**)&g_dbg_dev, 8 * (size_t)slots) == hipSuccess) { g_dbg_slots = slots; (void)hipMemsetAsync(g_dbg_dev, 0xff, 8 * (size_t)slots, stream); dbg = g_dbg_dev; }
+    } else if (getenv("PM_GAP_DEBUG")) {
+        if (!g_dbg || g_dbg_slots < slots) { if (g_dbg) (void)hipHostFree(g_dbg); g_dbg = nullptr; if (hipHostMalloc((void**)&g_dbg, 8 * (size_t)slots, hipHostMallocMapped) == hipSuccess) g_dbg_slots = slots; }
+        if (g_dbg) { memset(g_dbg, 0xff, 8 * (size_t)slots); (void)hipHostGetDevicePointer((void**)&dbg, g_dbg, 0); }
+    }
+    Params P{d_jobs, (int64_t)jobs.size(), d_off, d_chars, d_out, d_cols, d_next, d_ws, (int64_t)stride, nmax, cap, dbg};
     hipLaunchKernelGGL(gap_align_kernel, dim3((unsigned)slots), dim3(64), 0, stream, P);
     GA_CHECK(hipGetLastError());
     std::vector<int32_t> got(jobs.size());
