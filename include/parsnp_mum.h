@@ -49,6 +49,16 @@ typedef int (*pm_allreduce_min_i32_fn)(void* ctx, int32_t* buf, int64_t count);
 typedef int (*pm_allgather_fn)(void* ctx, const void* send, int64_t send_bytes, void* recv /* world * send_bytes */);
 int pm_session_create_sharded(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens,
                               int rank, int world, pm_allreduce_min_i32_fn allreduce_min, pm_allgather_fn allgather, void* ctx);
+/* The same sharded run with the two exchanges ON THE DEVICE: the library owns an RCCL communicator (one rank per process
+ * and GPU, xGMI inside a node) and runs all-reduce(min) on Master.EP in place and the all-gather of the candidate columns
+ * on its own stream, between its kernels -- no host staging, no callback.  Rank 0 obtains an id with pm_rccl_unique_id
+ * and hands its 128 bytes to the other ranks by whatever channel launched them (a file, MPI, torch.distributed's store);
+ * every rank then calls pm_session_create_rccl with its rank.  RCCL is loaded on demand from PARSNP_RCCL_LIB or
+ * /opt/rocm/lib/librccl.so.1; a one-rank communicator (world = 1) is legal and runs the same exchange code. */
+#define PM_RCCL_ID_BYTES 128
+int pm_rccl_unique_id(uint8_t* id /* PM_RCCL_ID_BYTES */);
+int pm_session_create_rccl(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens,
+                           int rank, int world, const uint8_t* id /* PM_RCCL_ID_BYTES */);
 void pm_session_destroy(pm_session* s);
 int pm_session_genomes(const pm_session* s);
 

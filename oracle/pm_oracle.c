@@ -109,4 +109,9 @@ int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const 
     return PM_OK;
 }
 const char* pm_gap_last_error(void) { return ""; }
+/* RCCL sessions exist in the HIP library only */
+int pm_rccl_unique_id(uint8_t* id) { (void)id; return PM_EINVAL; }
+int pm_session_create_rccl(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens, int rank, int world, const uint8_t* id) {
+    (void)out; (void)device; (void)n_genomes; (void)seqs; (void)lens; (void)rank; (void)world; (void)id; return PM_EINVAL;
+}
 int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) { (void)s; (void)names; (void)ms; if (count) *count = 0; return PM_OK; }

@@ -44,6 +44,11 @@ class Lib:
         if rc != 0:
             raise PmError("%s (code %d)" % (self.L.pm_last_error().decode(), rc))
 
+    def rccl_unique_id(self) -> bytes:
+        ident = (C.c_uint8 * 128)()
+        self._check(self.L.pm_rccl_unique_id(ident))
+        return bytes(ident)
+
     def find_events(self, ref: bytes, query: bytes, min_len: int, strand: int = 0):
         cap = len(query) + 16
         j = np.zeros(cap, np.int64); l = np.zeros(cap, np.int64); ln = np.zeros(cap, np.int32); rp = np.zeros(cap, np.int32)
@@ -58,14 +63,22 @@ class Lib:
 class Session:
     """genomes resident on the device; genome 0 is the reference"""
 
-    def __init__(self, lib: Lib, seqs, device=-1):
+    def __init__(self, lib: Lib, seqs, device=-1, rccl=None):
+        """rccl = (rank, world, id bytes): a sharded session whose exchanges run over the engine's own RCCL communicator
+        (pm_session_create_rccl); `Lib.rccl_unique_id()` makes the id on rank 0"""
         self.lib = lib
         self.n = len(seqs)
         self._seqs = [bytes(s) for s in seqs]
         arr = (C.c_char_p * self.n)(*self._seqs)
         lens = (C.c_int64 * self.n)(*[len(s) for s in self._seqs])
         h = C.c_void_p()
-        lib._check(lib.L.pm_session_create(C.byref(h), device, self.n, arr, lens))
+        if rccl is not None:
+            rank, world, ident = rccl
+            lib.L.pm_session_create_rccl.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                                     C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+            lib._check(lib.L.pm_session_create_rccl(C.byref(h), device, self.n, arr, lens, rank, world, (C.c_uint8 * 128).from_buffer_copy(ident)))
+        else:
+            lib._check(lib.L.pm_session_create(C.byref(h), device, self.n, arr, lens))
         self.h = h
 
     def close(self):

@@ -53,6 +53,39 @@ int pm_session_create_sharded(pm_session** out, int device, int n_genomes, const
     c.rank = rank; c.world = world; c.allreduce_min_i32 = allreduce_min; c.allgather = allgather; c.ctx = ctx;
     return session_create(out, device, n_genomes, seqs, lens, &c);
 }
+#if defined(PM_HAVE_RCCL)
+int pm_rccl_unique_id(uint8_t* id128) {
+    if (!id128) return fail(PM_EINVAL, "bad argument");
+    Rccl& R = Rccl::get();
+    if (!R.ok()) return fail(PM_ENODEV, R.err);
+    ncclUniqueId id;
+    ncclResult_t r = R.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(PM_EHIP, std::string("ncclGetUniqueId: ") + R.GetErrorString(r));
+    memcpy(id128, &id, sizeof id);
+    return PM_OK;
+}
+int pm_session_create_rccl(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens, int rank, int world,
+                           const uint8_t* id128) {
+    if (!out || n_genomes < 1 || !seqs || !lens || !id128 || world < 1 || rank < 0 || rank >= world) return fail(PM_EINVAL, "bad argument");
+    try {
+        std::unique_ptr<pm_session> s(new pm_session);
+        std::string err;
+        s->backend.reset(pm_backend_open(device, &err));
+        if (!s->backend) return fail(PM_ENODEV, err);
+        if (!s->backend->comm_init(rank, world, id128)) return fail(PM_EHIP, s->backend->error());
+        s->engine.reset(new pm::Engine<PmBackend>(*s->backend));
+        pm::Collectives c;
+        c.rank = rank; c.world = world; c.device = true;
+        s->engine->set_shard(c);
+        int rc = s->engine->load_genomes(n_genomes, seqs, lens);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        *out = s.release();
+        return PM_OK;
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
+}
+#endif
 void pm_session_destroy(pm_session* s) { delete s; }
 int pm_session_genomes(const pm_session* s) { return s ? s->engine->ngen : 0; }
 

@@ -74,6 +74,9 @@ struct Collectives {
     int (*allreduce_min_i32)(void* ctx, int32_t* buf, int64_t count) = nullptr;
     int (*allgather)(void* ctx, const void* send, int64_t send_bytes, void* recv) = nullptr;   // recv: world * send_bytes
     void* ctx = nullptr;
+    // device collectives (pm_session_create_rccl): the backend owns an RCCL communicator and the exchanges run on device
+    // buffers on the engine's stream; the callbacks above are not used then
+    bool device = false;
 };
 
 inline int bits_for(uint64_t v) { int b = 1; while (b < 64 && (v >> b)) b++; return b; }
@@ -267,7 +270,7 @@ public:
         ensure(d_slots, (size_t)tsize); ensure(d_filter, (size_t)fwords);
         be.memset(d_filter.p, 0, sizeof(uint32_t) * (size_t)fwords);
         ensure(d_next, (size_t)std::max<int64_t>(npos, 1)); ensure(d_rep, (size_t)std::max<int64_t>(npos, 1));
-        ensure(d_epm, (size_t)std::max<int64_t>(npos, 1));
+        ensure(d_epm, (size_t)std::max<int64_t>(npos, 1) + 1);     // + the verdict word of a sharded run
         be.memset(d_slots.p, 0xff, sizeof(uint64_t) * (size_t)tsize);
         be.memset(d_counter.p, 0, 8 * ncounter);
         be.mark("index");
@@ -319,7 +322,7 @@ public:
         last_events = (int64_t)nev;
         // a rank of a sharded run that ran out of budget must not leave the others waiting in the collectives: the
         // verdict travels with the first exchange (below) and every rank returns the error together
-        const bool sharded = coll.world > 1;
+        const bool sharded = coll.world > 1 || coll.device;      // (a one-rank RCCL session still runs the exchanges: that is how a 1-GPU box tests them)
         if ((errbits & kErrWork) && !sharded) { error = "per-thread work budget exceeded (degenerate repeat structure in a region)"; return -5; }
 
         ensure(d_evkey2, std::max<size_t>(nev, 1)); ensure(d_evval2, std::max<size_t>(nev, 1));
@@ -359,7 +362,7 @@ public:
                 std::vector<int64_t> send(per, 0), recv(per * (size_t)coll.world);
                 for (int g = g_first; g < g_last; g++) send[(size_t)(g - g_first)] = mumi_covered[(size_t)(g - 1)];
                 send[per - 1] = errbits;
-                if (coll.allgather(coll.ctx, send.data(), (int64_t)(8 * send.size()), recv.data())) { error = "all-gather of MUMi coverage failed"; return -4; }
+                if (allgather_host(send.data(), (int64_t)(8 * send.size()), recv.data())) { error = "all-gather of MUMi coverage failed"; return -4; }
                 for (int r = 0; r < coll.world; r++) {
                     int a, b; shard_range(ngen, r, coll.world, &a, &b);
                     for (int g = a; g < b; g++) mumi_covered[(size_t)(g - 1)] = recv[(size_t)r * per + (size_t)(g - a)];
@@ -378,14 +381,20 @@ public:
         be.memset(d_coarse.p, 0, 4 * (size_t)std::max<int64_t>(centries, 1));
         be.launch("coarse_fill", (int64_t)nev, CoarseFill{skey, (int64_t)nev, lbits, d_lo.p, d_R.p, d_cbase.p, nq, d_coarse.p});
         be.launch_wave("master_ep", nchunks, MasterEP{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last});
-        if (sharded) {   // exchange 1: Master.EP = min over the ranks' genome blocks; the last word carries the error verdict
+        int32_t verdict = 0;
+        if (sharded && coll.device) {   // exchange 1 on the device: RCCL all-reduce(min) of Master.EP in place, + the error verdict word
+            be.mark("exchange_ep");
+            be.fill32(d_epm.p + npos, (errbits & kErrWork) ? -1 : 0);
+            if (be.allreduce_min_i32_dev(d_epm.p, npos + 1)) { error = "RCCL all-reduce of Master.EP failed: " + be.error(); return -4; }
+            be.d2h_async(&verdict, d_epm.p + npos, 4);       // read with the candidate count below
+        } else if (sharded) {   // exchange 1: Master.EP = min over the ranks' genome blocks; the last word carries the error verdict
             be.mark("exchange_ep");
             std::vector<int32_t> h((size_t)npos + 1);
             if (npos) be.d2h(h.data(), d_epm.p, 4 * (size_t)npos);
             h[(size_t)npos] = (errbits & kErrWork) ? -1 : 0;
             if (coll.allreduce_min_i32(coll.ctx, h.data(), npos + 1)) { error = "all-reduce of Master.EP failed"; return -4; }
-            if (h[(size_t)npos] < 0) { error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
-            if (npos) be.h2d(d_epm.p, h.data(), 4 * (size_t)npos);
+            verdict = h[(size_t)npos];
+            if (verdict >= 0 && npos) be.h2d(d_epm.p, h.data(), 4 * (size_t)npos);
         }
         be.mark("candidates");
         const int64_t nwv = (npos + 63) / 64;
@@ -395,6 +404,7 @@ public:
         be.exclusive_scan(d_wcount.p, d_woff.p, (size_t)nwv + 1);
         int64_t ncand_i = 0;
         be.d2h(&ncand_i, d_woff.p + nwv, 8);                                   // round trip 2: candidate count
+        if (verdict < 0) { error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
         const uint64_t ncand = (uint64_t)ncand_i;
         last_candidates = (int64_t)ncand;
         if (ncand == 0) { be.mark(nullptr); collect_timing(); return 0; }
@@ -412,23 +422,31 @@ public:
             be.launch("state_at_candidate", (int64_t)ncand * nq, StateAtCandidate{d_R.p, scand, ngen, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_at.p, d_cbase.p, d_coarse.p});
             be.mark("exchange_states");
             const size_t nqz = (size_t)nq, cz = (size_t)ncand;
-            std::vector<GenomeAtK> all(cz * nqz);
-            be.d2h(all.data(), d_at.p, sizeof(GenomeAtK) * all.size());
             int widest = 0;
             for (int r = 0; r < coll.world; r++) { int a, b; shard_range(ngen, r, coll.world, &a, &b); widest = std::max(widest, b - a); }
+            widest = std::max(widest, 1);
             const size_t blk = cz * (size_t)widest;
-            std::vector<GenomeAtK> send(std::max<size_t>(blk, 1)), recv(std::max<size_t>(blk, 1) * (size_t)coll.world);
-            const size_t mine = (size_t)(g_last - g_first);
-            for (size_t c = 0; c < cz; c++)
-                for (size_t x = 0; x < mine; x++) send[c * (size_t)widest + x] = all[c * nqz + (size_t)(g_first - 1) + x];
-            if (coll.allgather(coll.ctx, send.data(), (int64_t)(sizeof(GenomeAtK) * send.size()), recv.data())) { error = "all-gather of candidate states failed"; return -4; }
-            for (int r = 0; r < coll.world; r++) {
-                int a, b; shard_range(ngen, r, coll.world, &a, &b);
-                const GenomeAtK* src = recv.data() + (size_t)r * send.size();
+            if (coll.device) {      // pack this rank's columns, RCCL all-gather on the engine's stream, spread the blocks: nothing leaves the device
+                ensure(d_xsend, blk); ensure(d_xrecv, blk * (size_t)coll.world);
+                be.launch("pack_states", (int64_t)blk, PackStates{d_at.p, nq, g_first - 1, g_last - g_first, widest, d_xsend.p});
+                if (be.allgather_dev(d_xsend.p, (int64_t)(sizeof(GenomeAtK) * blk), d_xrecv.p)) { error = "RCCL all-gather of candidate states failed: " + be.error(); return -4; }
+                be.launch("unpack_states", (int64_t)(cz * nqz), UnpackStates{d_xrecv.p, nq, coll.world, widest, (int64_t)ncand, d_at.p});
+            } else {
+                std::vector<GenomeAtK> all(cz * nqz);
+                be.d2h(all.data(), d_at.p, sizeof(GenomeAtK) * all.size());
+                std::vector<GenomeAtK> send(blk), recv(blk * (size_t)coll.world);
+                const size_t mine = (size_t)(g_last - g_first);
                 for (size_t c = 0; c < cz; c++)
-                    for (int x = 0; x < b - a; x++) all[c * nqz + (size_t)(a - 1 + x)] = src[c * (size_t)widest + (size_t)x];
+                    for (size_t x = 0; x < mine; x++) send[c * (size_t)widest + x] = all[c * nqz + (size_t)(g_first - 1) + x];
+                if (coll.allgather(coll.ctx, send.data(), (int64_t)(sizeof(GenomeAtK) * send.size()), recv.data())) { error = "all-gather of candidate states failed"; return -4; }
+                for (int r = 0; r < coll.world; r++) {
+                    int a, b; shard_range(ngen, r, coll.world, &a, &b);
+                    const GenomeAtK* src = recv.data() + (size_t)r * send.size();
+                    for (size_t c = 0; c < cz; c++)
+                        for (int x = 0; x < b - a; x++) all[c * nqz + (size_t)(a - 1 + x)] = src[c * (size_t)widest + (size_t)x];
+                }
+                be.h2d(d_at.p, all.data(), sizeof(GenomeAtK) * all.size());
             }
-            be.h2d(d_at.p, all.data(), sizeof(GenomeAtK) * all.size());
             be.mark("fold");
             at = d_at.p;
         }
@@ -488,6 +506,16 @@ public:
         return 0;
     }
 
+    // small host-side all-gather (calcmumi's per-genome results): through device staging when the collectives are RCCL
+    int allgather_host(const void* send, int64_t bytes, void* recv) {
+        if (!coll.device) return coll.allgather(coll.ctx, send, bytes, recv);
+        ensure(d_hsend, (size_t)bytes); ensure(d_hrecv, (size_t)bytes * (size_t)coll.world);
+        be.h2d(d_hsend.p, send, (size_t)bytes);
+        if (be.allgather_dev(d_hsend.p, bytes, d_hrecv.p)) return 1;
+        be.d2h(recv, d_hrecv.p, (size_t)bytes * (size_t)coll.world);
+        return 0;
+    }
+
     // parity hook output (valid after run(..., want_events = true))
     std::vector<uint64_t> ev_key_h, ev_val_h;
     std::vector<int32_t> rep_h;
@@ -540,6 +568,7 @@ private:
     Buf<uint64_t> d_wmask; Buf<int64_t> d_wcount, d_woff;
     Buf<int64_t> d_okcnt, d_okpos, d_cbase; Buf<int32_t> d_coarse; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;
     Buf<uint32_t> d_cflags; Buf<int32_t> d_bmax, d_bmin;
+    Buf<GenomeAtK> d_xsend, d_xrecv; Buf<uint8_t> d_hsend, d_hrecv;
 };
 
 }  // namespace pm

@@ -4,7 +4,9 @@
 // Phase timing uses HIP events recorded on that stream (pm_last_timing).
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types only: the library is loaded on demand (see Rccl below), never linked
 #include <rocprim/rocprim.hpp>
 
 #include <map>
@@ -28,8 +30,41 @@ __global__ __launch_bounds__(64) void pm_wave_kernel(F f, int64_t n) {
     if (w < n) f.wave(w);
 }
 
+// RCCL, loaded by absolute path when a sharded session asks for device collectives.  Not a link-time dependency: (1) a
+// single-GPU run never maps the 570 MB library; (2) a process that also holds PyTorch has torch's own bundled librccl.so.1
+// loaded -- bound to torch's private HIP runtime -- and a NEEDED entry with that soname would resolve to it; dlopen of the
+// system file by path gives this library its own copy, bound to the HIP runtime the engine's streams belong to.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    static Rccl& get() {
+        static Rccl r;
+        if (r.lib || !r.err.empty()) return r;
+        const char* path = getenv("PARSNP_RCCL_LIB");
+        if (!path || !*path) path = "/opt/rocm/lib/librccl.so.1";
+        r.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) { r.err = std::string("cannot load RCCL (") + path + "): " + dlerror(); return r; }
+        auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.err.empty()) r.err = std::string("RCCL symbol missing: ") + n; return p; };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        return r;
+    }
+    bool ok() const { return lib && err.empty(); }
+};
+
 struct HipBackend {
     hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;          // device collectives of a sharded session (pm_session_create_rccl)
     std::string err;
     void* tmp = nullptr;
     size_t tmp_cap = 0;
@@ -49,7 +84,32 @@ struct HipBackend {
         for (auto e : pool) (void)hipEventDestroy(e);
         if (tmp) (void)hipFree(tmp);
         if (stage_p) (void)hipHostFree(stage_p);
+        if (comm) (void)Rccl::get().CommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
+    }
+    bool nccl_check(ncclResult_t r, const char* what) {
+        if (r == ncclSuccess) return true;
+        if (err.empty()) err = std::string(what) + ": " + Rccl::get().GetErrorString(r);
+        return false;
+    }
+    // one communicator per session, ranks = the processes of the sharded run (one per GPU), over xGMI inside a node
+    bool comm_init(int rank, int world, const uint8_t* id128) {
+        Rccl& R = Rccl::get();
+        if (!R.ok()) { if (err.empty()) err = R.err; return false; }
+        ncclUniqueId id;
+        static_assert(sizeof(ncclUniqueId) == 128, "PM_RCCL_ID_BYTES");
+        memcpy(&id, id128, sizeof id);
+        return nccl_check(R.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+    }
+    void fill32(int32_t* p, int32_t v) { check(hipMemsetD32Async((hipDeviceptr_t)p, v, 1, stream), "hipMemsetD32Async"); }
+    // in place on a device buffer, on the engine's stream (stream-ordered with the kernels around it: no host round trip)
+    int allreduce_min_i32_dev(int32_t* d, int64_t count) {
+        if (!comm) { if (err.empty()) err = "no RCCL communicator"; return 1; }
+        return nccl_check(Rccl::get().AllReduce(d, d, (size_t)count, ncclInt32, ncclMin, comm, stream), "ncclAllReduce(min)") ? 0 : 1;
+    }
+    int allgather_dev(const void* send, int64_t bytes, void* recv) {
+        if (!comm) { if (err.empty()) err = "no RCCL communicator"; return 1; }
+        return nccl_check(Rccl::get().AllGather(send, recv, (size_t)bytes, ncclUint8, comm, stream), "ncclAllGather") ? 0 : 1;
     }
     void* alloc(size_t n) { void* p = nullptr; if (!check(hipMalloc(&p, n ? n : 1), "hipMalloc")) return nullptr; return p; }
     void free(void* p) { check(hipFree(p), "hipFree"); }
@@ -166,4 +226,5 @@ static PmBackend* pm_backend_open(int device, std::string* err) {
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; delete b; return nullptr; }
     return b;
 }
+#define PM_HAVE_RCCL 1
 #include "abi_glue.h"

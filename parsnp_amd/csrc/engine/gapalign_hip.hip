@@ -77,7 +77,7 @@ struct Slot {
     int32_t* lo;            // [2n] first row of a node's alignment
     int32_t* ncols;         // [2n]
     int32_t* perm;          // [n] row -> sequence
-    uint8_t* cur;           // [n] which of a row's two buffers is current
+    float* total;           // [2n] sequential float sum of the weights of a node's rows, in row order
     uint8_t* rows;          // [n][2][cap]
     uint8_t* table;         // [46656] 6-mer counts of one string (fastdistnuc.cpp:82), all zero between uses
 };
@@ -117,15 +117,16 @@ struct __align__(16) Shared {
         float result[3];
     } p;
     uint16_t codes[kMaxCols];
+    float wrow[kMaxSeqs];      // weight of the sequence in row p (rows = leaves in the order of the root alignment)
+    uint8_t cur[kMaxSeqs];     // which of row p's two buffers is current
     int32_t flag;
 };
 
 // ---- profile of the alignment held by rows [lo, lo+ns) (nc columns) -> either the A arrays or the B arrays
-__device__ void build_profile(Shared& S, const Slot& W, int cap, int lo, int ns, int nc, bool as_a) {
+__device__ void build_profile(Shared& S, const Slot& W, int cap, int lo, int ns, int nc, float total, bool as_a) {
     const int lane = (int)__lane_id();
-    // msa2.cpp:418-431 + msa.cpp:369-381: this alignment's weights, rescaled to sum 1 (sequential float sum, MSA order)
-    float total = 0;
-    for (int s = 0; s < ns; s++) total += W.weight[W.perm[lo + s]];
+    // msa2.cpp:418-431 + msa.cpp:369-381: this alignment's weights, rescaled to sum 1.  `total` is the sequential float sum
+    // of the weights in MSA order, kept per node: a merged alignment's rows are A's then B's, so its sum continues A's.
     const float f = total != 0 ? 1.0f / total : 1.0f;
     const bool scale = total != 0;
     for (int c0 = 0; c0 < nc; c0 += 64) {
@@ -134,9 +135,9 @@ __device__ void build_profile(Shared& S, const Slot& W, int cap, int lo, int ns,
             float cnt[4] = {0, 0, 0, 0}, start = 0, end = 0;
             for (int s = 0; s < ns; s++) {
                 const int p = lo + s;
-                float ws = W.weight[W.perm[p]];
+                float ws = S.wrow[p];
                 if (scale) ws *= f;
-                const uint8_t* row = W.rows + ((size_t)p * 2 + W.cur[p]) * (size_t)cap;
+                const uint8_t* row = W.rows + ((size_t)p * 2 + S.cur[p]) * (size_t)cap;
                 const uint8_t ch = row[c];
                 if (is_gap(ch)) {
                     if (c == 0 || !is_gap(row[c - 1])) start += ws;
@@ -506,7 +507,7 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         const int i = W.perm[p], L = W.len[i];
         uint8_t* row = W.rows + ((size_t)p * 2) * (size_t)cap;
         for (int x = lane; x < L; x += 64) row[x] = seq_char(i, x);
-        if (lane == 0) { W.cur[p] = 0; W.ncols[i] = L; }
+        if (lane == 0) { S.cur[p] = 0; S.wrow[p] = W.weight[i]; W.ncols[i] = L; W.total[i] = 0.0f + W.weight[i]; }
     }
     GA_SYNC();
     GA_STAGE(7);
@@ -519,8 +520,8 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         const int lob = W.lo[b], nsb = (int)W.under[b], lb = W.ncols[b];
         if (la <= 0 || lb <= 0 || la > kMaxCols || lb > kMaxCols) return false;
         GA_STAGE(100 + (int)(v - un) * 10);
-        build_profile(S, W, cap, loa, nsa, la, true);
-        build_profile(S, W, cap, lob, nsb, lb, false);
+        build_profile(S, W, cap, loa, nsa, la, W.total[a], true);
+        build_profile(S, W, cap, lob, nsb, lb, W.total[b], false);
         int plen = 0;
         GA_STAGE(101 + (int)(v - un) * 10);
         if (!nw_small(S, la, lb, &plen)) return false;
@@ -541,20 +542,25 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         for (int s = 0; s < nsa + nsb; s++) {
             const bool in_a = s < nsa;
             const int p = in_a ? loa + s : lob + (s - nsa);
-            const uint8_t curb = W.cur[p];
+            const uint8_t curb = S.cur[p];
             const uint8_t* src = W.rows + ((size_t)p * 2 + curb) * (size_t)cap;
             uint8_t* dst = W.rows + ((size_t)p * 2 + (curb ^ 1)) * (size_t)cap;
             for (int c = lane; c < plen; c += 64) { const int m = in_a ? S.p.mapa[c] : S.p.mapb[c]; dst[c] = m >= 0 ? src[m] : (uint8_t)'-'; }
         }
         GA_SYNC();
-        for (int s = lane; s < nsa + nsb; s += 64) { const int p = s < nsa ? loa + s : lob + (s - nsa); W.cur[p] ^= 1; }
-        if (lane == 0) W.ncols[v] = plen;
+        for (int s = lane; s < nsa + nsb; s += 64) { const int p = s < nsa ? loa + s : lob + (s - nsa); S.cur[p] ^= 1; }
+        if (lane == 0) {
+            W.ncols[v] = plen;
+            float t = W.total[a];                    // the merged alignment's rows: A's, then B's
+            for (int x = 0; x < nsb; x++) t += S.wrow[lob + x];
+            W.total[v] = t;
+        }
         GA_SYNC();
     }
     const int nc = W.ncols[root];
     if (nc > job.max_cols) return false;
     for (int p = 0; p < n; p++) {
-        const uint8_t* src = W.rows + ((size_t)p * 2 + W.cur[p]) * (size_t)cap;
+        const uint8_t* src = W.rows + ((size_t)p * 2 + S.cur[p]) * (size_t)cap;
         uint8_t* dst = P.out_rows + job.row_off + (int64_t)W.perm[p] * job.max_cols;
         for (int c = lane; c < nc; c += 64) dst[c] = src[c];
     }
@@ -582,7 +588,7 @@ __device__ Slot carve(uint8_t* base, int nmax, int cap) {
     W.weight = (float*)take(4 * n);
     W.lo = (int32_t*)take(8 * n); W.ncols = (int32_t*)take(8 * n);
     W.perm = (int32_t*)take(4 * n);
-    W.cur = take(n);
+    W.total = (float*)take(8 * n);
     W.rows = take(2 * n * (size_t)cap);
     W.table = take(kTable);
     return W;
@@ -591,7 +597,7 @@ size_t slot_bytes(int nmax, int cap) {
     const size_t n = (size_t)nmax;
     auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
     return r(4 * (n * (n - 1) / 2 + 1)) + r(2 * n * n) + r(2 * n * kMaxCols) + r(n * kMaxCols) + r(4 * n) + r(8 * n) + 4 * r(4 * n) + 3 * r(8 * n) + r(16 * n) +
-           r(4 * n) + r(8 * n) + r(16 * n) + r(4 * n) + 2 * r(8 * n) + r(4 * n) + r(n) + r(2 * n * (size_t)cap) + r(kTable) + 256;
+           r(4 * n) + r(8 * n) + r(16 * n) + r(4 * n) + 2 * r(8 * n) + r(4 * n) + r(8 * n) + r(2 * n * (size_t)cap) + r(kTable) + 256;
 }
 
 __global__ __launch_bounds__(64) void gap_align_kernel(Params P) {

@@ -1223,6 +1223,28 @@ struct StateAtCandidate {
         out[tid] = state_at(R[r], r, k, g, nq, key, val, lo, st, rep, lbits, cbase, coarse);
     }
 };
+// Sharded run with device collectives (RCCL): the (EP,UP,SP) columns of this rank's genome block, packed [candidate][widest]
+// for the all-gather, and the gathered blocks of all ranks spread back into the [candidate][genome] table.
+// tid = (candidate, x): x-th genome of the block.  Block r of `world` covers query genomes [q r / world, q (r+1) / world).
+struct PackStates {
+    const GenomeAtK* at; int32_t nq; int32_t g0; int32_t mine; int32_t widest; GenomeAtK* send;     // g0: first query genome (0-based) of this rank
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = tid / widest; const int x = (int)(tid % widest);
+        send[tid] = x < mine ? at[c * nq + g0 + x] : GenomeAtK{0, 0, 0, 0, 0, 0};
+    }
+};
+struct UnpackStates {
+    const GenomeAtK* recv; int32_t nq; int32_t world; int32_t widest; int64_t ncand; GenomeAtK* at;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = tid / nq; const int g = (int)(tid % nq);
+        int r = (int)(((int64_t)(g + 1) * world - 1) / nq);           // the block that holds query genome g
+        while (r > 0 && (int)((int64_t)nq * r / world) > g) r--;
+        while (r + 1 < world && (int)((int64_t)nq * (r + 1) / world) <= g) r++;
+        const int first = (int)((int64_t)nq * r / world);
+        at[tid] = recv[(int64_t)r * ncand * widest + c * widest + (g - first)];
+    }
+};
+
 // One wavefront per candidate, lanes over the query genomes.  Intersect_UM's (UP=max, EP=min) fold and Merge_Master's
 // strand choice run genome after genome in ini order (mum.c:162-163, :92-123; ties -> reverse):
 //     fe = min(em, epf), re = min(em, epr);  forward iff fe > re;  em = max(fe, re) = min(em, max(epf, epr));  um = max(um, up of the chosen strand)

@@ -31,6 +31,17 @@ int pc_open_sharded(const char* ini_path, int rank, int world, pm_allreduce_min_
     *out = r;
     return 0;
 }
+// the same with the engine's own RCCL communicator (device-resident exchanges): id = the 128 bytes rank 0 got from pc_rccl_id
+int pc_rccl_id(uint8_t* id) { return pm_rccl_unique_id(id); }
+int pc_open_rccl(const char* ini_path, int rank, int world, const uint8_t* id, pc_run** out) {
+    pc_run* r = new pc_run;
+    r->run.shard.rank = rank; r->run.shard.world = world; r->run.shard.rccl = true;
+    memcpy(r->run.shard.rccl_id, id, PM_RCCL_ID_BYTES);
+    int rc = r->run.open(ini_path);
+    if (rc) { delete r; return rc; }
+    *out = r;
+    return 0;
+}
 // calcmumi on an opened run: writes <outdir>/all.mumi (rank 0 of a sharded run should be the only one to call pc_write)
 int pc_mumi(pc_run* r) { return r->run.mumi(); }
 // one pass of phases A-D; returns a JSON report (valid until the next call on this handle)

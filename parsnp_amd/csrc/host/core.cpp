@@ -93,7 +93,9 @@ int CoreRun::open(const std::string& ini_path) {
     std::vector<const uint8_t*> ptr(genomes.size());
     std::vector<int64_t> len(genomes.size());
     for (size_t i = 0; i < genomes.size(); i++) { ptr[i] = (const uint8_t*)genomes[i].seq.data(); len[i] = (int64_t)genomes[i].seq.size(); }
-    int rc = shard.world > 1
+    int rc = shard.rccl
+                 ? pm_session_create_rccl(&session, -1, (int)genomes.size(), ptr.data(), len.data(), shard.rank, shard.world, shard.rccl_id)
+             : shard.world > 1
                  ? pm_session_create_sharded(&session, -1, (int)genomes.size(), ptr.data(), len.data(), shard.rank, shard.world,
                                              shard.allreduce_min, shard.allgather, shard.ctx)
                  : pm_session_create(&session, -1, (int)genomes.size(), ptr.data(), len.data());

@@ -27,6 +27,9 @@ struct ShardSpec {
     pm_allreduce_min_i32_fn allreduce_min = nullptr;
     pm_allgather_fn allgather = nullptr;
     void* ctx = nullptr;
+    // device collectives: the engine's own RCCL communicator (pm_session_create_rccl) instead of the two callbacks
+    bool rccl = false;
+    uint8_t rccl_id[PM_RCCL_ID_BYTES] = {0};
 };
 
 class CoreRun {

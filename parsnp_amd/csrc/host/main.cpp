@@ -46,6 +46,34 @@ int main(int argc, char* argv[]) {
     time_t tstart, start, end;
     time(&tstart);
     CoreRun run;
+    // Sharded --no-partition run, one parsnp_core process per GPU: PARSNP_SHARD_WORLD ranks are started by
+    // any launcher with PARSNP_SHARD_RANK = 0 .. world-1 (and PARSNP_DEVICE, default = the rank); the engines exchange over
+    // their own RCCL communicator, whose id rank 0 publishes in PARSNP_RCCL_ID_FILE.  Rank 0 writes the outputs.
+    if (const char* w = getenv("PARSNP_SHARD_WORLD")) {
+        const int world = atoi(w), rank = getenv("PARSNP_SHARD_RANK") ? atoi(getenv("PARSNP_SHARD_RANK")) : 0;
+        if (world < 1 || rank < 0 || rank >= world) { std::cerr << "parsnp_core: bad PARSNP_SHARD_RANK / PARSNP_SHARD_WORLD" << std::endl; exit(1); }
+        if (!getenv("PARSNP_DEVICE")) setenv("PARSNP_DEVICE", std::to_string(rank).c_str(), 1);
+        const char* idf = getenv("PARSNP_RCCL_ID_FILE");
+        if (!idf || !*idf) { std::cerr << "parsnp_core: a sharded run needs PARSNP_RCCL_ID_FILE (a path every rank can read)" << std::endl; exit(1); }
+        run.shard.rank = rank; run.shard.world = world; run.shard.rccl = true;
+        if (rank == 0) {
+            if (pm_rccl_unique_id(run.shard.rccl_id) != PM_OK) { std::cerr << "parsnp_core: " << pm_last_error() << std::endl; exit(3); }
+            const std::string tmp = std::string(idf) + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(run.shard.rccl_id, 1, PM_RCCL_ID_BYTES, f) != PM_RCCL_ID_BYTES || fclose(f) || rename(tmp.c_str(), idf)) {
+                std::cerr << "parsnp_core: cannot write " << idf << std::endl; exit(1);
+            }
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 1200 && !got; tries++) {       // up to two minutes: rank 0 may still be starting
+                FILE* f = fopen(idf, "rb");
+                if (f) { got = fread(run.shard.rccl_id, 1, PM_RCCL_ID_BYTES, f) == PM_RCCL_ID_BYTES; fclose(f); }
+                if (!got) { struct timespec ts = {0, 100000000}; nanosleep(&ts, nullptr); }
+            }
+            if (!got) { std::cerr << "parsnp_core: no RCCL id in " << idf << std::endl; exit(1); }
+        }
+    }
+    const bool writer = run.shard.rank == 0;
     int rc = run.open(argv[1]);
     if (rc) exit(rc);
     if (run.prm.calc_mumi) {          // main() :3188-3209: distances only, no alignment
@@ -53,8 +81,9 @@ int main(int argc, char* argv[]) {
         std::cerr << "Calculating mumi distances.." << std::endl;
         exit(run.mumi());
     }
-    std::ofstream mfile((run.prm.outdir + "/parsnpAligner.log").c_str());
+    std::ofstream mfile((writer ? run.prm.outdir + "/parsnpAligner.log" : std::string("/dev/null")).c_str());
     StepReport rep = run.step();
+    if (!writer) exit(0);          // every rank computed the same alignment; rank 0 writes it
     if (!rep.mums_found) {
         mfile << "NO MUMS FOUND" << std::endl;
         mfile.close();

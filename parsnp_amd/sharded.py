@@ -22,12 +22,31 @@ AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 
 class ShardedRun:
-    def __init__(self, ini_path, dist, device=None, lib_path=None):
+    def __init__(self, ini_path, dist, device=None, lib_path=None, rccl=False):
+        """rccl=True: the engine's own RCCL communicator carries both exchanges on device buffers (pm_session_create_rccl);
+        torch.distributed only hands rank 0's communicator id to the other ranks.  rccl=False: the exchanges go through
+        the two callbacks below on host buffers (gloo in the CPU tests, or ranks that share a GPU)."""
         import torch
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.dev = device   # torch device for the collectives ("cuda:N" with nccl, "cpu" with gloo)
         L = self.L = C.CDLL(lib_path or CORE_LIB)
+        L.pc_step.argtypes = [C.c_void_p]; L.pc_step.restype = C.c_char_p
+        L.pc_write.argtypes = [C.c_void_p]; L.pc_mumi.argtypes = [C.c_void_p]; L.pc_close.argtypes = [C.c_void_p]
+        if rccl:
+            ident = (C.c_uint8 * 128)()
+            if self.rank == 0 and L.pc_rccl_id(ident):
+                raise RuntimeError("cannot create an RCCL communicator id")
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)          # 128 bytes through the launcher's channel
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            h = C.c_void_p()
+            L.pc_open_rccl.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_void_p)]
+            rc = L.pc_open_rccl(ini_path.encode(), self.rank, self.world, ident, C.byref(h))
+            if rc:
+                raise RuntimeError("parsnp_core could not start (exit code %d)" % rc)
+            self.h = h
+            return
         L.pc_open_sharded.argtypes = [C.c_char_p, C.c_int, C.c_int, AR, AG, C.c_void_p, C.POINTER(C.c_void_p)]
         L.pc_step.argtypes = [C.c_void_p]; L.pc_step.restype = C.c_char_p
         L.pc_write.argtypes = [C.c_void_p]; L.pc_mumi.argtypes = [C.c_void_p]; L.pc_close.argtypes = [C.c_void_p]
@@ -86,10 +105,18 @@ def main(argv=None):
         sys.exit("usage: python -m torch.distributed.run ... -m parsnp_amd.sharded <file.ini>")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if torch.cuda.is_available() and torch.cuda.device_count() >= world:
-        torch.cuda.set_device(local)
+    rccl = False
+    if torch.cuda.is_available() and torch.cuda.device_count() >= world and os.environ.get("PARSNP_SHARD_COLLECTIVES", "rccl") == "rccl":
+        # one GPU per rank: the engine's own RCCL communicator (device buffers, xGMI); torch.distributed is only the
+        # launcher's rendezvous here (gloo), so the process holds ONE RCCL -- the engine's
         os.environ["PARSNP_DEVICE"] = str(local)   # the engine links the system HIP runtime, not torch's
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo")
+        dev = "cpu"
+        rccl = True
+    elif torch.cuda.is_available() and torch.cuda.device_count() >= world:
+        torch.cuda.set_device(local)
+        os.environ["PARSNP_DEVICE"] = str(local)
+        dist.init_process_group("nccl")            # PARSNP_SHARD_COLLECTIVES=torch: host-staged exchanges through torch's RCCL
         dev = "cuda:%d" % local
     else:
         if torch.cuda.is_available():
@@ -97,7 +124,7 @@ def main(argv=None):
         dist.init_process_group("gloo")
         dev = "cpu"
     lib = os.environ.get("PARSNP_CORE_LIB")   # tests point this at their CPU build
-    run = ShardedRun(argv[0], dist, dev, lib)
+    run = ShardedRun(argv[0], dist, dev, lib, rccl=rccl)
     calcmumi = any(l.strip().lower() == "calcmumi=1" for l in open(argv[0]))
     if calcmumi:
         rc = run.mumi()

@@ -53,6 +53,13 @@ def pmc(d):
     return out
 
 
+def lib_sha():
+    """sha256 of the libparsnp_hip.so the passes ran on: bench.py quotes the traffic only for this binary"""
+    import hashlib
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parsnp_amd", "lib", "libparsnp_hip.so")
+    return hashlib.sha256(open(p, "rb").read()).hexdigest() if os.path.exists(p) else None
+
+
 def main():
     out = sys.argv[1]
     summ = os.path.join(out, "summary")
@@ -116,7 +123,8 @@ def main():
              "correction": "none (scattered-probe pattern; see calibration.json: gather kernels count 64 B per lane)",
              "rocprof_avg_launch_ms": ((st_se.get("total_ms", 0) + st_sp.get("total_ms", 0)) / calls) if calls else None,
              "rocprof_calls": calls,
-             "rocprof_seed_extend_avg_ms": st_se.get("avg_ms"), "rocprof_small_pair_events_avg_ms": st_sp.get("avg_ms")}
+             "rocprof_seed_extend_avg_ms": st_se.get("avg_ms"), "rocprof_small_pair_events_avg_ms": st_sp.get("avg_ms"),
+             "so_sha256": lib_sha()}
         json.dump(t, open(os.path.join(summ, "traffic_seed_extend.json"), "w"), indent=1)
     print(json.dumps({"stats": {k: v for k, v in stats.items() if v["total_ms"] > 1}, "calibration": cal, "seed_extend": per.get("SeedExtend"), "small_pair_events": per.get("SmallPairEvents")}, indent=1))
 

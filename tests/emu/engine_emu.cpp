@@ -20,6 +20,9 @@ struct HostBackend {
     void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void d2h_async(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void sync() {}
+    void fill32(int32_t* p, int32_t v) { *p = v; }
+    int allreduce_min_i32_dev(int32_t*, int64_t) { return 1; }      // no device collectives in the emulation
+    int allgather_dev(const void*, int64_t, void*) { return 1; }
     std::vector<char> stage;
     void* staging(size_t n) { if (stage.size() < n) stage.resize(n); return stage.data(); }
     void h2d_staged(void* d, const void* s, size_t n) { memcpy(d, s, n); }
@@ -49,3 +52,5 @@ extern "C" int pm_gap_align_batch(int, int64_t n_jobs, const int32_t*, const int
     return PM_OK;
 }
 extern "C" const char* pm_gap_last_error(void) { return ""; }
+extern "C" int pm_rccl_unique_id(uint8_t*) { return PM_EINVAL; }
+extern "C" int pm_session_create_rccl(pm_session**, int, int, const uint8_t* const*, const int64_t*, int, int, const uint8_t*) { return PM_EINVAL; }

@@ -314,3 +314,60 @@ def test_sharded_run_on_gpu(libs, tmp_path, name, world):
     assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["signature"]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
+
+
+def test_rccl_session_one_rank(libs):
+    """the device-collective path (the engine's own RCCL communicator: all-reduce(min) of Master.EP in place, pack /
+    all-gather / unpack of the candidate columns, all on the engine's stream) on a ONE-rank communicator -- what a box with
+    a single GPU can run of it: same candidates as the plain session, for whole genomes, batches and calcmumi"""
+    H, O = libs
+    ident = H.rccl_unique_id()
+    assert len(ident) == 128 and any(ident)
+    rng = np.random.default_rng(41)
+    for it in range(12):
+        ref, qs = adversarial_case(rng, 10, int(rng.choice([90, 4000])), int(rng.integers(1, 6)))
+        minsize = int(rng.integers(2, 12))
+        with Session(H, [ref] + qs) as plain, Session(H, [ref] + qs, rccl=(0, 1, H.rccl_unique_id())) as sharded:
+            assert T.same(plain.whole(minsize), sharded.whole(minsize)), (it, minsize)
+            assert plain.mumi_coverage() == sharded.mumi_coverage()
+            names = [n for n, _ in sharded.last_timing()]
+    ref = random_seq(rng, 60000)
+    qs = [mutate(rng, ref, sub=0.02, indel=0.002) for _ in range(5)]
+    with Session(H, [ref] + qs) as plain, Session(H, [ref] + qs, rccl=(0, 1, ident)) as sharded:
+        a, b = plain.whole(17), sharded.whole(17)
+        assert len(a[0]) > 100 and T.same(a, b)
+        assert "exchange_ep" in [n for n, _ in sharded.last_timing()] and "exchange_states" in [n for n, _ in sharded.last_timing()]
+
+
+@pytest.mark.parametrize("name", ["pop6x200k", "rearr6x300k"])
+def test_parsnp_core_sharded_binary_one_rank(libs, tmp_path, name):
+    """parsnp_core started as rank 0 of a 1-rank sharded run (PARSNP_SHARD_WORLD / PARSNP_RCCL_ID_FILE): the id file
+    hand-over, the RCCL session and the exchanges inside the drop-in binary; bytes as the reference's"""
+    r, gs = synth.make(name)
+    rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
+    env = dict(os.environ, PARSNP_SHARD_WORLD="1", PARSNP_SHARD_RANK="0", PARSNP_RCCL_ID_FILE=str(tmp_path / "rccl.id"))
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=4)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    assert os.path.getsize(str(tmp_path / "rccl.id")) == 128
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
+
+
+def test_sharded_run_rccl_two_gpus(libs, tmp_path):
+    """two ranks, one GPU each, exchanges over the engine's RCCL communicator (xGMI): runs wherever two GPUs are visible"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the build pool hands out single-GPU boxes; the driver's 8-GPU node runs it)")
+    import subprocess, sys
+    name = "poprearr10x400k"
+    rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    ini = os.path.join(out, "parsnpAligner.ini")
+    open(ini, "w").write(driver.ini_text(rp, qs, out, threads=4, **kw))
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", "-m", "parsnp_amd.sharded", ini], cwd=out, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
