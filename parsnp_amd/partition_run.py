@@ -5,8 +5,8 @@ rank, rank+world, ...; partitions never talk to each other while they run (no da
 per-partition reference intervals of the LCBs are all-gathered (objects; RCCL/gloo) so that every rank holds the
 intersection the reference's partition.py starts its merge from (partition.py:35-61, 539-583).
 
-The XMFA trimming / SPOA re-alignment of the merge itself (partition.py:100-433) is outside this project's scope
-(parity for it is unpinned because partition.py cannot be imported here)."""
+Rank 0 then merges the partitions' XMFA files into <outdir>/parsnp.xmfa (parsnp_amd.partition_merge: interval
+intersection, trimming, block merge -- partition.py:539-736; parity of that part is unpinned, see its docstring)."""
 import math
 import os
 import re
@@ -55,7 +55,7 @@ def intersect(interval_lists):
     return cur or []
 
 
-def run_partitioned(core_bin, ref, finalfiles, outdir, min_partition_size, rank=0, world=1, dist=None, local_rank=None, **ini_kw):
+def run_partitioned(core_bin, ref, finalfiles, outdir, min_partition_size, rank=0, world=1, dist=None, local_rank=None, merge=True, **ini_kw):
     """-> dict(partitions=[...], intersection=[...]) on every rank.  `dist`: an initialised torch.distributed module (or
     None for a single process)."""
     chunks = plan_partitions(finalfiles, min_partition_size)
@@ -76,4 +76,9 @@ def run_partitioned(core_bin, ref, finalfiles, outdir, min_partition_size, rank=
     else:
         parts = mine
     good = [p for p in parts if p["ok"]]   # failed partitions are dropped, the rest merged (parsnp:1594-1599)
-    return dict(partitions=parts, intersection=intersect([p["intervals"] for p in good]) if good else [])
+    merged = None
+    if merge and rank == 0 and good:
+        from . import partition_merge
+        merged = partition_merge.merge_partitions([os.path.join(p["dir"], "parsnpAligner.xmfa") for p in good], os.path.join(outdir, "parsnp.xmfa"))
+        merged = dict(clusters=merged["clusters"], sequences=merged["sequences"], xmfa=os.path.join(outdir, "parsnp.xmfa"))
+    return dict(partitions=parts, intersection=intersect([p["intervals"] for p in good]) if good else [], merged=merged)
