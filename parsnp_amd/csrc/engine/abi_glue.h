@@ -100,6 +100,7 @@ int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, 
         s->timing = s->engine->timing;
         // wall clock of the whole call on the host (uploads, launches, waits, result assembly) next to the device phases
         s->timing.push_back(pm::PhaseTime{"call_wall", std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count()});
+        if (s->engine->budget_retries) s->timing.push_back(pm::PhaseTime{"budget_retries", (float)s->engine->budget_retries});   // a count, not a time
         *out = r.release();
         return PM_OK;
     } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");

@@ -149,8 +149,27 @@ public:
     // result download.  Everything else the device needs from the host (region table, prefix arrays, request rows) is
     // assembled in ONE page-locked block and sent by asynchronous copies on the engine's stream.
     std::vector<int64_t> mumi_covered;   // result of run(..., mumi = true): per query genome
+    // A batch whose repeat structure exhausts the per-thread work budget (a tandem repeat of period > 1 with thousands of
+    // copies inside ONE region: every copy's K-mer chain is walked by every sample that hits it) is run again with a
+    // budget 256 times larger -- slow, but the reference aligns such input too; only then PM_ELIMIT.  In a sharded run the
+    // verdict is common to all ranks (it travels with the first exchange), so every rank repeats the batch together.
     int run(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events = false,
             bool mumi = false) {
+        budget_exceeded = false;
+        int rc = run_once(nreg, starts, lens, minsize, out, want_events, mumi);
+        if (rc == -5 && budget_exceeded && work_budget < ((int64_t)1 << 40)) {
+            const int64_t keep = work_budget;
+            work_budget = keep << 8;
+            budget_retries++;
+            rc = run_once(nreg, starts, lens, minsize, out, want_events, mumi);
+            work_budget = keep;
+        }
+        return rc;
+    }
+    bool budget_exceeded = false;
+    long budget_retries = 0;
+    int run_once(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events,
+                 bool mumi) {
         timing.clear();
         const int nq = ngen - 1;
         out->nregions = nreg; out->nq = nq; out->total = 0;
@@ -323,7 +342,7 @@ public:
         // a rank of a sharded run that ran out of budget must not leave the others waiting in the collectives: the
         // verdict travels with the first exchange (below) and every rank returns the error together
         const bool sharded = coll.world > 1 || coll.device;      // (a one-rank RCCL session still runs the exchanges: that is how a 1-GPU box tests them)
-        if ((errbits & kErrWork) && !sharded) { error = "per-thread work budget exceeded (degenerate repeat structure in a region)"; return -5; }
+        if ((errbits & kErrWork) && !sharded) { budget_exceeded = true; error = "per-thread work budget exceeded (degenerate repeat structure in a region)"; return -5; }
 
         ensure(d_evkey2, std::max<size_t>(nev, 1)); ensure(d_evval2, std::max<size_t>(nev, 1));
         ensure(d_evkey3, std::max<size_t>(nev, 1)); ensure(d_evval3, std::max<size_t>(nev, 1));
@@ -368,7 +387,7 @@ public:
                     for (int g = a; g < b; g++) mumi_covered[(size_t)(g - 1)] = recv[(size_t)r * per + (size_t)(g - a)];
                     errbits |= (uint32_t)recv[(size_t)r * per + per - 1];
                 }
-                if (errbits & kErrWork) { error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
+                if (errbits & kErrWork) { budget_exceeded = true; error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
             }
             be.mark(nullptr);
             collect_timing();
@@ -404,7 +423,7 @@ public:
         be.exclusive_scan(d_wcount.p, d_woff.p, (size_t)nwv + 1);
         int64_t ncand_i = 0;
         be.d2h(&ncand_i, d_woff.p + nwv, 8);                                   // round trip 2: candidate count
-        if (verdict < 0) { error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
+        if (verdict < 0) { budget_exceeded = true; error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
         const uint64_t ncand = (uint64_t)ncand_i;
         last_candidates = (int64_t)ncand;
         if (ncand == 0) { be.mark(nullptr); collect_timing(); return 0; }
@@ -520,7 +539,7 @@ public:
     std::vector<uint64_t> ev_key_h, ev_val_h;
     std::vector<int32_t> rep_h;
     int ev_lbits = 0;
-    int64_t work_budget = 1 << 22;
+    int64_t work_budget = getenv("PM_WORK_BUDGET") ? atol(getenv("PM_WORK_BUDGET")) : (1 << 22);      // PM_WORK_BUDGET: test hook
     // shortest one-region candidate list that gets the device overlap test (the host's PARSNP_PARALLEL_MIN; PM_DIRTY_MIN: test hook)
     int64_t dirty_min = getenv("PM_DIRTY_MIN") ? atol(getenv("PM_DIRTY_MIN")) : 4096;
 

@@ -325,6 +325,10 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     stats.t_pack += now_s() - t0;
     pm_result* res = nullptr;
     int rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);
+    if (rc == PM_ELIMIT) {     // a size limit of the engine (include/parsnp_mum.h), not a malfunction: its own exit code
+        std::cerr << "parsnp_core: input exceeds a limit of the multi-MUM engine: " << pm_last_error() << std::endl;
+        exit(5);
+    }
     if (rc != PM_OK) fatal(std::string("multi-MUM engine failed: ") + pm_last_error());
     std::shared_ptr<pm_result> own(res, pm_result_free);
     const int64_t* off = pm_result_offsets(res);
@@ -1182,6 +1186,12 @@ bool Aligner::extend_generations() {
                     if (ok && mm.length > 0)
                         for (size_t j = 0; j < n; j++) touches |= layout[j].get(mm.start[j]) | layout[j].get(mm.end(j) - 1);
                     if (!ok || !settle(mm, touches, any_reverse)) { tl.irows.rewind(imark); tl.brows.rewind(bmark); continue; }
+                    // a reverse-strand member is flipped against the WHOLE genome length (TMum.cpp:33-35), so it can pass the
+                    // sequence check while lying outside this region's interval (inverted repeats): its marks could then meet
+                    // another cluster's and the order would show.  The in-order replay decides such a generation.
+                    if (any_reverse)
+                        for (size_t j = 0; j < n; j++)
+                            if (!mm.fwd[j] && ((long)mm.start[j] < r.start[j] - 1 || mm.end(j) > r.end[j] + 1)) cluster_trouble = 1;
                     for (size_t j = 0; j < n; j++) layout[j].set_range_atomic(mm.start[j], mm.end(j));
                     mm.slength = r.slength;
                     o.accepted.push_back(mm);

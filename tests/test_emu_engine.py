@@ -135,6 +135,23 @@ def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
 
 
+def test_work_budget_retry(libs, monkeypatch):
+    """a region whose repeat structure exhausts the per-thread work budget is run again with a larger one instead of
+    failing the run (engine_core.h: run); PM_WORK_BUDGET makes a 40-copy tandem repeat enough to trigger it"""
+    E, O = libs
+    rng = np.random.default_rng(77)
+    unit = b"ACGTTGCA"
+    ref = random_seq(rng, 300) + unit * 40 + random_seq(rng, 300)
+    qs = [mutate(rng, ref, sub=0.01), random_seq(rng, 50) + unit * 37 + random_seq(rng, 200)]
+    want = oracles.restatement_multi_mum(O, [ref] + qs, 9, 1)
+    monkeypatch.setenv("PM_WORK_BUDGET", "48")
+    with Session(E, [ref] + qs) as s:
+        got = s.whole(9)
+        retried = dict(s.last_timing()).get("budget_retries", 0)
+    assert same(want, got)
+    assert retried >= 1
+
+
 def mumi_cases(rng, count):
     for it in range(count):
         ref, qs = adversarial_case(rng, 20, int(rng.choice([60, 250])), int(rng.integers(1, 4)))

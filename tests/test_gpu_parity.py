@@ -371,3 +371,7 @@ def test_sharded_run_rccl_two_gpus(libs, tmp_path):
                         "--master-port", "29533", "-m", "parsnp_amd.sharded", ini], cwd=out, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
+
+
+def test_work_budget_retry(libs, monkeypatch):
+    T.test_work_budget_retry(libs, monkeypatch)
