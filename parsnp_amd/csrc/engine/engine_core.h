@@ -127,19 +127,16 @@ public:
         blk = (SeqBlock*)be.alloc((size_t)words * sizeof(SeqBlock));
         d_goff = (int64_t*)be.alloc(sizeof(int64_t) * 2 * (size_t)n);
         d_glen = (int64_t*)be.alloc(sizeof(int64_t) * (size_t)n);
-        uint8_t* stage = (uint8_t*)be.alloc((size_t)std::max<int64_t>(maxlen, 1));
-        if (!blk || !d_goff || !d_glen || !stage) { error = "device allocation failed (genomes)"; return -3; }
+        if (!blk || !d_goff || !d_glen) { error = "device allocation failed (genomes)"; return -3; }
         be.memset(blk, 0, (size_t)words * sizeof(SeqBlock));
         be.h2d(d_goff, goff.data(), sizeof(int64_t) * goff.size());
         be.h2d(d_glen, lens, sizeof(int64_t) * (size_t)n);
-        for (int g = 0; g < n; g++) {
-            if (lens[g] == 0 || !resident(g)) continue;
-            be.h2d(stage, seqs[g], (size_t)lens[g]);
-            for (int s = 0; s < 2; s++)
-                be.launch("pack", (lens[g] + 31) / 32, PackStrand{stage, lens[g], s, blk, goff[2 * (size_t)g + s] / 32});
-            be.sync();   // stage is reused
-        }
-        be.free(stage);
+        // ASCII genomes -> packed strands: a few host threads copy the genomes into page-locked staging slots, each slot's
+        // DMA and its two PackStrand launches run on the slot's own stream while the next genome is being staged
+        // (the genomes arrive in ordinary memory, from which a direct copy is staged by the runtime at ~6 GB/s)
+        std::vector<char> res((size_t)n, 0);
+        for (int g = 0; g < n; g++) res[(size_t)g] = resident(g) && lens[g] > 0;
+        if (!be.stage_genomes(n, seqs, lens, res, goff, blk, maxlen)) { error = "genome upload failed: " + be.error(); return -3; }
         P = Packed{blk, d_goff, d_glen};
         return 0;
     }

@@ -11,6 +11,7 @@
 
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine_core.h"
@@ -141,6 +142,58 @@ struct HipBackend {
         return stage_p;
     }
     void h2d_staged(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D (staged)"); }
+
+    // see Engine::load_genomes.  kThreads host threads, two staging slots each (page-locked host block + device block + stream)
+    bool stage_genomes(int n, const uint8_t* const* seqs, const int64_t* lens, const std::vector<char>& take, const std::vector<int64_t>& goff,
+                       pm::SeqBlock* blk, int64_t maxlen) {
+        int64_t total = 0;
+        for (int g = 0; g < n; g++) if (take[(size_t)g]) total += lens[g];
+        const int kThreads = total < (8 << 20) ? 1 : 4;      // a handful of short sequences: one thread, two slots
+        constexpr int kPer = 2;
+        int device = 0;
+        if (!check(hipGetDevice(&device), "hipGetDevice")) return false;
+        check(hipStreamSynchronize(stream), "sync");      // the memset of the packed buffer precedes the pack kernels
+        struct Slot { uint8_t* host = nullptr; uint8_t* dev = nullptr; hipStream_t st = nullptr; hipEvent_t done = nullptr; bool used = false; };
+        std::vector<Slot> slots((size_t)kThreads * kPer);
+        bool ok = true;
+        const size_t cap = (size_t)std::max<int64_t>(maxlen, 1);
+        for (auto& sl : slots)
+            ok = ok && hipHostMalloc((void**)&sl.host, cap, hipHostMallocDefault) == hipSuccess && hipMalloc((void**)&sl.dev, cap) == hipSuccess &&
+                 hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) == hipSuccess;
+        std::vector<int> failed((size_t)kThreads, 0);
+        if (ok) {
+            auto work = [&](int t) {
+                if (hipSetDevice(device) != hipSuccess) { failed[(size_t)t] = 1; return; }
+                int turn = 0;
+                for (int g = t; g < n; g += kThreads) {
+                    if (!take[(size_t)g]) continue;
+                    Slot& sl = slots[(size_t)t * kPer + (size_t)(turn++ % kPer)];
+                    if (sl.used && hipEventSynchronize(sl.done) != hipSuccess) { failed[(size_t)t] = 1; return; }
+                    memcpy(sl.host, seqs[g], (size_t)lens[g]);
+                    if (hipMemcpyAsync(sl.dev, sl.host, (size_t)lens[g], hipMemcpyHostToDevice, sl.st) != hipSuccess) { failed[(size_t)t] = 1; return; }
+                    const int64_t nblk = (lens[g] + 31) / 32;
+                    for (int s = 0; s < 2; s++)
+                        hipLaunchKernelGGL(pm_kernel<pm::PackStrand>, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, sl.st,
+                                           pm::PackStrand{sl.dev, lens[g], s, blk, goff[2 * (size_t)g + (size_t)s] / 32}, nblk);
+                    if (hipGetLastError() != hipSuccess || hipEventRecord(sl.done, sl.st) != hipSuccess) { failed[(size_t)t] = 1; return; }
+                    sl.used = true;
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < kThreads; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto& x : th) x.join();
+        }
+        for (auto& sl : slots) {
+            if (sl.st) { if (hipStreamSynchronize(sl.st) != hipSuccess) ok = false; (void)hipStreamDestroy(sl.st); }
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            if (sl.host) (void)hipHostFree(sl.host);
+            if (sl.dev) (void)hipFree(sl.dev);
+        }
+        for (int f : failed) if (f) ok = false;
+        if (!ok && err.empty()) err = "staging the genomes failed (allocation, copy or PackStrand launch)";
+        return ok;
+    }
 
     template <class F> void launch(const char* name, int64_t n, F f) {
         if (n <= 0) return;

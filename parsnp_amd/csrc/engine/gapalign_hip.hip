@@ -36,7 +36,7 @@
 namespace {
 
 constexpr int kMaxSeqs = 512;      // sequences per alignment on the device
-constexpr int kMaxCols = 160;      // columns of any intermediate alignment on the device
+constexpr int kMaxCols = 96;       // columns of any intermediate alignment on the device (LDS per wavefront ~25 KB: 6 alignments in flight per CU)
 constexpr int kTable = 46656;      // 6^6 (fastdistnuc.cpp:82)
 constexpr float kMinusInf = (float)-1e37;
 constexpr float kBigDist = (float)1e29;
@@ -692,7 +692,7 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
     }
     hipDeviceProp_t prop;
     GA_CHECK(hipGetDeviceProperties(&prop, device >= 0 ? device : 0));
-    const int64_t slots = std::min<int64_t>((int64_t)jobs.size(), (int64_t)prop.multiProcessorCount * 3);   // 3 workgroups of 50 KB LDS fit a CU
+    const int64_t slots = std::min<int64_t>((int64_t)jobs.size(), (int64_t)prop.multiProcessorCount * 6);   // 6 workgroups of ~25 KB LDS fit a CU
     const size_t stride = slot_bytes(nmax, cap);
     GA_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     auto dalloc = [&](size_t bytes, void** p) { hipError_t e = hipMalloc(p, bytes ? bytes : 1); if (e == hipSuccess) owned.push_back(*p); return e; };

@@ -7,11 +7,13 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <fcntl.h>
 #include <fstream>
 #include <future>
 #include <iomanip>
 #include <iostream>
 #include <sstream>
+#include <unistd.h>
 
 #include "aligner.h"
 #include "gapalign.h"
@@ -19,7 +21,6 @@
 namespace parsnp {
 
 namespace {
-std::string lower(std::string s) { std::transform(s.begin(), s.end(), s.begin(), ::tolower); return s; }
 std::string upper(std::string s) { std::transform(s.begin(), s.end(), s.begin(), ::toupper); return s; }
 std::string sub(const std::string& g, long pos, long len) {   // std::string::substr semantics incl. size_t wrap of len
     if (pos < 0 || (size_t)pos > g.size()) { std::cerr << "parsnp_core: substr out of range" << std::endl; exit(1); }
@@ -81,15 +82,36 @@ void build_rows(const Aligner& a, const Lcb& ct, const std::vector<std::pair<siz
         for (size_t i = 0; i < n; i++) (*rows)[i].reserve(guess);
     }
     const Mum& first = a.pool[(size_t)ct.mums[0]];
-    auto mum_text = [&](const Mum& m, size_t i) {
-        std::string t = sub(a.genomes[i].seq, m.start[i], m.length);
-        return lower(first.fwd[i] ? t : reverse_complement(t));
+    // a MUM's text, lower case, the reverse complement for a reverse member (= lower(reverse_complement(sub(...))), written
+    // straight into the row: 14 million of these per run at 200 x 5 Mb)
+    static const struct Tables { char low[256], rc[256]; Tables() {
+        for (int c = 0; c < 256; c++) { low[c] = (char)tolower(c); rc[c] = 'n'; }
+        rc[(unsigned char)'A'] = rc[(unsigned char)'a'] = 't'; rc[(unsigned char)'C'] = rc[(unsigned char)'c'] = 'g';
+        rc[(unsigned char)'G'] = rc[(unsigned char)'g'] = 'c'; rc[(unsigned char)'T'] = rc[(unsigned char)'t'] = 'a';
+        rc[(unsigned char)'U'] = rc[(unsigned char)'u'] = 't';
+        for (char c : {'\r', '\n', '\t', ' ', '>', '.'}) rc[(unsigned char)c] = 0;       // dropped by reversec (parsnp.cpp:1369-1380)
+    } } T;
+    auto append_mum = [&](std::string& dst, const Mum& m, size_t i) {
+        const std::string& g = a.genomes[i].seq;
+        const long pos = m.start[i];
+        if (pos < 0 || (size_t)pos > g.size()) { std::cerr << "parsnp_core: substr out of range" << std::endl; exit(1); }
+        const size_t len = std::min<size_t>((size_t)m.length, g.size() - (size_t)pos);     // substr clamps
+        const size_t at = dst.size();
+        if (first.fwd[i]) {
+            dst.resize(at + len);
+            const char* src = g.data() + pos; char* out = &dst[at];
+            for (size_t x = 0; x < len; x++) out[x] = T.low[(unsigned char)src[x]];
+        } else {
+            dst.reserve(at + len);
+            const char* src = g.data() + pos;
+            for (size_t x = len; x-- > 0;) { const char c = T.rc[(unsigned char)src[x]]; if (c) dst.push_back(c); }
+        }
     };
     Gap gp;
     size_t next_aligned = 0;
     for (size_t t = 0; t < ct.mums.size(); t++) {
         const Mum& m = a.pool[(size_t)ct.mums[t]];
-        for (size_t i = 0; i < n; i++) (*rows)[i] += mum_text(m, i);
+        for (size_t i = 0; i < n; i++) append_mum((*rows)[i], m, i);
         if (t + 1 == ct.mums.size()) break;
         if (next_aligned < aligned.size() && aligned[next_aligned].first == t) {
             const Gap& ag = aligned[next_aligned++].second;
@@ -157,9 +179,9 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     std::sort(jobs.begin(), jobs.end(), [](const Gap* x, const Gap* y) { return x->max_len > y->max_len; });
     const long nj = (long)jobs.size();
     // The gaps go to the device in ONE batch (pm_gap_align_batch: one wavefront per gap, include/parsnp_mum.h); the few the
-    // device does not take -- wider than its 160-column limit, or declined -- are aligned here by the host threads, the
+    // device does not take -- wider than its 96-column limit, or declined -- are aligned here by the host threads, the
     // widest ones while the device works on the rest.  PARSNP_HOST_GAPS=1: everything on the host (measurement / tests).
-    constexpr unsigned kDeviceCols = 160;
+    constexpr unsigned kDeviceCols = 96;
     static const bool host_gaps = getenv("PARSNP_HOST_GAPS") != nullptr;
     vector<char> on_device((size_t)nj, 0);
     vector<int32_t> d_nseq, d_maxcols, d_cols; vector<int64_t> d_seqoff{0}, d_rowoff; vector<uint8_t> d_chars, d_out;
@@ -238,8 +260,12 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     for (char c : notes) if (c) *gap_note = true;
     lap("rows");
 
+    // Pass 1, in LCB order: the overlap trim against the previous printed LCB (it shortens rows and shifts the starts).
+    // Pass 2, all threads: the records of every printed LCB, wrapped at 80 columns, into one buffer per LCB.
+    // Pass 3: the buffers go to their places in the file with positioned writes (1 GB at 200 x 5 Mb).
     int prev_end = 0;
-    string rec;
+    vector<Lcb> trimmed(a.lcbs.size());
+    vector<char> printed(a.lcbs.size(), 0);
     for (size_t z = 0; z < a.lcbs.size(); z++) {
         Lcb ct = a.lcbs[z];
         vector<string>& row = rows[z];
@@ -271,14 +297,22 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         }
         prev_end = lcb_end;
         if (!(row[0].size() > (size_t)(prm.c * 1))) continue;
+        trimmed[z] = ct; printed[z] = 1;
+    }
+    vector<string> text(a.lcbs.size());
+    const long nz = (long)a.lcbs.size();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (long zz = 0; zz < nz; zz++) {
+        const size_t z = (size_t)zz;
+        if (!printed[z]) continue;
+        const Lcb& ct = trimmed[z];
+        vector<string>& row = rows[z];
+        string& out = text[z];
+        size_t total = 4;
+        for (size_t i = 0; i < n; i++) total += row[i].size() + row[i].size() / 80 + 96;
+        out.reserve(total);
         char b[16];
         snprintf(b, sizeof b, "%d", (int)z + 1);
-        ofstream block;
-        if (prm.recomb_filter) {
-            string bdir = dir + "blocks/b" + b;
-            int rc = system(("mkdir -p " + bdir).c_str()); (void)rc;
-            block.open((bdir + "/seq.fna").c_str());
-        }
         const Mum& first = a.pool[(size_t)ct.mums.front()];
         const Mum& lastm = a.pool[(size_t)ct.mums.back()];
         for (size_t i = 0; i < n; i++) {
@@ -299,19 +333,43 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
             else if (hdr != "s1") offset = -1;
             if (!first.fwd[i]) hd << "- cluster" << b << " " << hdr << ":p" << (ct.start[i] - seqstart) + 1 + first.length + offset;
             else hd << "+ cluster" << b << " " << hdr << ":p" << (ct.start[i] - seqstart) + 1 + offset;
-            // one record, wrapped at 80 columns, assembled in memory and written at once (same bytes as line-by-line)
             const string& s = row[i];
-            rec.clear();
-            rec.reserve(hd.str().size() + s.size() + s.size() / 80 + 8);
-            rec += hd.str(); rec += '\n';
+            out += hd.str(); out += '\n';
             size_t k = 0;
             const size_t width = 80;
-            for (; k + width < s.size(); k += width) { rec.append(s, k, width); rec += '\n'; }
-            rec.append(s, k, string::npos); rec += '\n';
-            xmfa.write(rec.data(), (std::streamsize)rec.size());
-            if (prm.recomb_filter) block.write(rec.data(), (std::streamsize)rec.size());
+            for (; k + width < s.size(); k += width) { out.append(s, k, width); out += '\n'; }
+            out.append(s, k, string::npos); out += '\n';
         }
-        xmfa << "=\n";
+        if (prm.recomb_filter) {        // blocks/b<z+1>/seq.fna: the same records, without the terminator
+            string bdir = dir + "blocks/b" + b;
+            int rc = system(("mkdir -p " + bdir).c_str()); (void)rc;
+            ofstream block((bdir + "/seq.fna").c_str());
+            block.write(out.data(), (std::streamsize)out.size());
+        }
+        out += "=\n";
+        vector<string>().swap(row);
+    }
+    {
+        xmfa.flush();
+        long long at = (long long)xmfa.tellp();
+        xmfa.close();
+        vector<long long> where(a.lcbs.size(), 0);
+        for (size_t z = 0; z < a.lcbs.size(); z++) { where[z] = at; at += (long long)text[z].size(); }
+        const string path = dir + stem + ".xmfa";
+        const int fd = open(path.c_str(), O_WRONLY);
+        if (fd < 0 || ftruncate(fd, (off_t)at) != 0) { cerr << "parsnp_core: cannot write " << path << endl; exit(1); }
+        int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(| : bad)
+        for (long zz = 0; zz < nz; zz++) {
+            const string& t = text[(size_t)zz];
+            size_t done = 0;
+            while (done < t.size()) {
+                const ssize_t w = pwrite(fd, t.data() + done, t.size() - done, (off_t)(where[(size_t)zz] + (long long)done));
+                if (w <= 0) { bad = 1; break; }
+                done += (size_t)w;
+            }
+        }
+        if (close(fd) != 0 || bad) { cerr << "parsnp_core: error writing " << path << endl; exit(1); }
     }
 
     lap("xmfa records");

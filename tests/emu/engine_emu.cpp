@@ -27,6 +27,14 @@ struct HostBackend {
     void* staging(size_t n) { if (stage.size() < n) stage.resize(n); return stage.data(); }
     void h2d_staged(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     template <class F> void launch(const char*, int64_t n, F f) { for (int64_t i = 0; i < n; i++) f(i); }
+    bool stage_genomes(int n, const uint8_t* const* seqs, const int64_t* lens, const std::vector<char>& take, const std::vector<int64_t>& goff,
+                       pm::SeqBlock* blk, int64_t) {
+        for (int g = 0; g < n; g++)
+            if (take[(size_t)g])
+                for (int s = 0; s < 2; s++)
+                    launch("pack", (lens[g] + 31) / 32, pm::PackStrand{seqs[g], lens[g], s, blk, goff[2 * (size_t)g + (size_t)s] / 32});
+        return true;
+    }
     template <class F> void launch_wave(const char*, int64_t n, F f) { for (int64_t i = 0; i < n; i++) f.wave(i); }
     void exclusive_scan(const int64_t* in, int64_t* out, size_t n) { int64_t a = 0; for (size_t i = 0; i < n; i++) { int64_t v = in[i]; out[i] = a; a += v; } }
     void sort_pairs(uint64_t* ki, uint64_t* ko, uint64_t* vi, uint64_t* vo, size_t n, int) {

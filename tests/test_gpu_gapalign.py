@@ -17,7 +17,7 @@ from test_gapalign import aligner  # noqa: F401  (fixture: the host restatement)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEVICE_COLS = 160
+DEVICE_COLS = 96
 
 
 @pytest.fixture(scope="module")
@@ -62,7 +62,7 @@ def test_committed_vectors(device):
     got = device([blk["in"] for blk in data])
     done = 0
     for blk, rows in zip(data, got):
-        if rows is None:      # declined: only what is outside the limits (a sequence or an alignment wider than 160 columns)
+        if rows is None:      # declined: only what is outside the limits (a sequence or an alignment wider than 96 columns)
             assert not fits(blk["in"]) or max(len(r) for r in blk["out"]) > (max(len(s) for s in blk["in"]) * 3) // 2 + 16 or max(len(r) for r in blk["out"]) > DEVICE_COLS, blk["in"]
             continue
         assert rows == blk["out"], blk["in"]
@@ -105,9 +105,9 @@ def test_many_sequences_per_gap(device, aligner):  # noqa: F811
 
 
 def test_declines_and_limits(device):
-    got = device([["ACGT", "ACG"], ["A" * 161, "A" * 100], ["ACGT"] * 513, ["ACGTACGTAA", "TTTTTTTTTT"]], slack=None)
+    got = device([["ACGT", "ACG"], ["A" * 97, "A" * 60], ["ACGT"] * 513, ["ACGTACGTAA", "TTTTTTTTTT"]], slack=None)
     assert got[0] is not None and got[3] is not None
-    assert got[1] is None and got[2] is None          # wider than 160 columns / more than 512 sequences
+    assert got[1] is None and got[2] is None          # wider than 96 columns / more than 512 sequences
     # a row capacity smaller than the alignment: declined, not overrun
     tight = device([["ACGTACGTAA", "TTTTTTTTTTAC"]], slack=12)
     assert tight[0] is None or len(tight[0][0]) <= 12
