@@ -31,8 +31,10 @@ static int session_create(pm_session** out, int device, int n_genomes, const uin
     try {
         std::unique_ptr<pm_session> s(new pm_session);
         std::string err;
+        const auto t0 = std::chrono::steady_clock::now();
         s->backend.reset(pm_backend_open(device, &err));
         if (!s->backend) return fail(PM_ENODEV, err);
+        if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[upload] %-14s %.4f s\n", "runtime start", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         s->engine.reset(new pm::Engine<PmBackend>(*s->backend));
         if (coll) s->engine->set_shard(*coll);
         int rc = s->engine->load_genomes(n_genomes, seqs, lens);

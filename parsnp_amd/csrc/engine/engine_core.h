@@ -3,6 +3,7 @@
 // tests/emu/ instantiates it with a sequential host backend to check the logic without a GPU (tests only).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -107,6 +108,10 @@ public:
 
     // ---- genomes -> packed strands in device memory
     int load_genomes(int n, const uint8_t* const* seqs, const int64_t* lens) {
+        const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double tl = now();
+        auto lap = [&](const char* what) { if (dbg) { be.sync(); const double t = now(); fprintf(stderr, "[upload] %-14s %.4f s\n", what, t - tl); tl = t; } };
         ngen = n;
         glen_h.assign(lens, lens + n);
         shard_range(n, coll.rank, coll.world, &g_first, &g_last);
@@ -128,6 +133,7 @@ public:
         d_goff = (int64_t*)be.alloc(sizeof(int64_t) * 2 * (size_t)n);
         d_glen = (int64_t*)be.alloc(sizeof(int64_t) * (size_t)n);
         if (!blk || !d_goff || !d_glen) { error = "device allocation failed (genomes)"; return -3; }
+        lap("allocate");
         be.memset(blk, 0, (size_t)words * sizeof(SeqBlock));
         be.h2d(d_goff, goff.data(), sizeof(int64_t) * goff.size());
         be.h2d(d_glen, lens, sizeof(int64_t) * (size_t)n);
@@ -136,7 +142,9 @@ public:
         // (the genomes arrive in ordinary memory, from which a direct copy is staged by the runtime at ~6 GB/s)
         std::vector<char> res((size_t)n, 0);
         for (int g = 0; g < n; g++) res[(size_t)g] = resident(g) && lens[g] > 0;
+        lap("clear + tables");
         if (!be.stage_genomes(n, seqs, lens, res, goff, blk, maxlen)) { error = "genome upload failed: " + be.error(); return -3; }
+        lap("stage + pack");
         P = Packed{blk, d_goff, d_glen};
         return 0;
     }

@@ -90,7 +90,7 @@ def test_many_sequences_per_gap(device, aligner):  # noqa: F811
     rng = random.Random(5)
     blks = []
     for k in range(60):
-        L = rng.choice([2, 3, 5, 8, 13, 21, 40, 90])
+        L = rng.choice([2, 3, 5, 8, 13, 21, 40, 60])
         base = "".join(rng.choice("ACGT") for _ in range(L))
         alleles = [gapgen.mutate(rng, base, rng.choice([0.05, 0.2, 0.5])) for _ in range(rng.choice([2, 3, 5, 9]))]
         if k % 3 == 0:
