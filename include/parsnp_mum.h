@@ -32,6 +32,11 @@ const char* pm_last_error(void);
 /* "hip" for libparsnp_hip.so. (The test-only CPU provider under oracle/ answers "oracle".) */
 const char* pm_provider(void);
 
+/* Optional: start the HIP runtime of this process (device discovery, context, code objects -- ~0.15 s when nothing else has
+ * touched the GPU yet).  Thread-safe; meant to be called from a side thread while the caller is still reading its input,
+ * as parsnp_core does during FASTA ingest.  device < 0: PARSNP_DEVICE or the current device. */
+int pm_warmup(int device);
+
 /* Upload the n genomes once (genome 0 = reference).  Replaces the per-call substr()+reversec()+strcpy of
  * src/parsnp.cpp:1540-1561: regions are addressed by (start,len) into these resident copies.
  * device < 0 selects the current HIP device. */

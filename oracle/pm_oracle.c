@@ -109,6 +109,7 @@ int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const 
     return PM_OK;
 }
 const char* pm_gap_last_error(void) { return ""; }
+int pm_warmup(int device) { (void)device; return PM_OK; }
 /* RCCL sessions exist in the HIP library only */
 int pm_rccl_unique_id(uint8_t* id) { (void)id; return PM_EINVAL; }
 int pm_session_create_rccl(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens, int rank, int world, const uint8_t* id) {

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -627,6 +628,18 @@ bool g_tables_ready = false;
 }  // namespace
 
 extern "C" const char* pm_gap_last_error(void) { return g_err.c_str(); }
+// Start the HIP runtime (device discovery, context, code objects: ~0.15 s of a fresh process) -- callable from a side
+// thread while the caller still parses its FASTA files, so that pm_session_create finds it running.
+extern "C" int pm_warmup(int device) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(PM_ENODEV, "no HIP device available");
+    if (device < 0) { const char* e = getenv("PARSNP_DEVICE"); if (e && *e) device = atoi(e); }
+    if (device >= 0 && (device >= count || hipSetDevice(device) != hipSuccess)) return fail(PM_ENODEV, "cannot select the requested HIP device");
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return fail(PM_EHIP, "hipMalloc failed during warm-up");
+    (void)hipFree(p);
+    return PM_OK;
+}
 // PM_GAP_DEBUG=1: (job, stage) of every slot of the running launch, readable from another thread
 extern "C" int64_t pm_gap_debug_peek(int32_t* out, int64_t cap) {
     int64_t n = 0;
@@ -690,6 +703,10 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
         for (size_t i : order) { j2.push_back(jobs[i]); w2.push_back(which[i]); }
         jobs.swap(j2); which.swap(w2);
     }
+    const bool timers = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tl = now();
+    auto lap = [&](const char* what) { if (timers) { const double t = now(); fprintf(stderr, "[gap batch] %-12s %.4f s\n", what, t - tl); tl = t; } };
     hipDeviceProp_t prop;
     GA_CHECK(hipGetDeviceProperties(&prop, device >= 0 ? device : 0));
     const int64_t slots = std::min<int64_t>((int64_t)jobs.size(), (int64_t)prop.multiProcessorCount * 6);   // 6 workgroups of ~25 KB LDS fit a CU
@@ -708,6 +725,7 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
     GA_CHECK(hipMemcpyAsync(d_off, seq_off, 8 * (size_t)(seq + 1), hipMemcpyHostToDevice, stream));
     GA_CHECK(hipMemcpyAsync(d_chars, chars, (size_t)total_chars, hipMemcpyHostToDevice, stream));
     GA_CHECK(hipMemsetAsync(d_next, 0, 8, stream));
+    if (timers) { GA_CHECK(hipStreamSynchronize(stream)); lap("alloc + h2d"); }
     int32_t* dbg = nullptr;
     if (getenv("PM_GAP_DEBUG") && atoi(getenv("PM_GAP_DEBUG")) == 2) {
         if (g_dbg_dev) (void)hipFree(g_dbg_dev);
@@ -720,12 +738,15 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
     Params P{d_jobs, (int64_t)jobs.size(), d_off, d_chars, d_out, d_cols, d_next, d_ws, (int64_t)stride, nmax, cap, dbg};
     hipLaunchKernelGGL(gap_align_kernel, dim3((unsigned)slots), dim3(64), 0, stream, P);
     GA_CHECK(hipGetLastError());
+    if (timers) { GA_CHECK(hipStreamSynchronize(stream)); lap("kernel"); }
     std::vector<int32_t> got(jobs.size());
     GA_CHECK(hipMemcpyAsync(got.data(), d_cols, 4 * jobs.size(), hipMemcpyDeviceToHost, stream));
     GA_CHECK(hipMemcpyAsync(out_rows, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, stream));
     GA_CHECK(hipStreamSynchronize(stream));
+    lap("d2h");
     for (size_t i = 0; i < jobs.size(); i++) cols[which[i]] = got[i];
     release();
+    lap("release");
 #undef GA_CHECK
     return PM_OK;
 }
