@@ -509,7 +509,10 @@ public:
                 ensure(d_bmax, (size_t)nblocks * ngz); ensure(d_bmin, (size_t)nblocks * ngz);
                 be.launch_wave("dirty_extent", nblocks * groups, DirtyExtent{d_csp.p, d_clon.p, d_cflags.p, nok, ngen, d_bmax.p, d_bmin.p});
                 be.launch_wave("dirty_prefix", groups, DirtyPrefix{nblocks, ngen, d_bmax.p, d_bmin.p});
-                be.launch_wave("dirty_mark", nblocks * groups, DirtyMark{d_csp.p, d_clon.p, nok, ngen, d_bmax.p, d_bmin.p, d_cflags.p});
+                ensure(d_dirty, nokz);
+                be.memset(d_dirty.p, 0, 4 * nokz);
+                be.launch_wave("dirty_mark", nblocks * groups, DirtyMark{d_csp.p, d_clon.p, nok, ngen, d_bmax.p, d_bmin.p, d_cflags.p, d_dirty.p});
+                be.launch("dirty_merge", nok, DirtyMerge{d_dirty.p, d_cflags.p});
                 out->dirty_known = true;
             }
             be.mark("download");
@@ -591,7 +594,7 @@ private:
     Buf<uint64_t> d_cand; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
     Buf<uint64_t> d_wmask; Buf<int64_t> d_wcount, d_woff;
     Buf<int64_t> d_okcnt, d_okpos, d_cbase; Buf<int32_t> d_coarse; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;
-    Buf<uint32_t> d_cflags; Buf<int32_t> d_bmax, d_bmin;
+    Buf<uint32_t> d_cflags, d_dirty; Buf<int32_t> d_bmax, d_bmin;
     Buf<GenomeAtK> d_xsend, d_xrecv; Buf<uint8_t> d_hsend, d_hrecv;
 };
 

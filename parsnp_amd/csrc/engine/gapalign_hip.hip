@@ -620,6 +620,8 @@ __global__ __launch_bounds__(64) void gap_align_kernel(Params P) {
     }
 }
 
+__global__ void warmup_kernel(int* p) { if (threadIdx.x == 0) *p = 1; }
+
 thread_local std::string g_err;
 int32_t* g_dbg = nullptr; int64_t g_dbg_slots = 0;
 int32_t* g_dbg_dev = nullptr;      // PM_GAP_DEBUG=2: the markers live in device memory (cheap to write), peeked through a copy on another stream
@@ -635,8 +637,16 @@ extern "C" int pm_warmup(int device) {
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(PM_ENODEV, "no HIP device available");
     if (device < 0) { const char* e = getenv("PARSNP_DEVICE"); if (e && *e) device = atoi(e); }
     if (device >= 0 && (device >= count || hipSetDevice(device) != hipSuccess)) return fail(PM_ENODEV, "cannot select the requested HIP device");
+    // an allocation brings the context up; a stream with one kernel on it brings up a hardware queue and this library's
+    // code objects -- the parts of the start-up that a later pm_session_create would otherwise wait for
     void* p = nullptr;
     if (hipMalloc(&p, 256) != hipSuccess) return fail(PM_EHIP, "hipMalloc failed during warm-up");
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+        hipLaunchKernelGGL(warmup_kernel, dim3(1), dim3(64), 0, st, (int*)p);
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+    }
     (void)hipFree(p);
     return PM_OK;
 }

@@ -339,6 +339,9 @@ struct PackStrand {
 constexpr uint64_t kMulti = 1ull << 31;
 PM_HD int32_t slot_head(uint64_t s) { return (int32_t)(s & 0x7fffffffu); }
 
+// the two filter bits of a K-mer inside its filter word (the second from hash bits the word index does not use)
+PM_HD uint32_t filter_mask(uint64_t hv, uint32_t bit) { return (1u << (bit & 31)) | (1u << ((uint32_t)(hv >> 58) & 31)); }
+
 // tid = flat reference position over the batch.
 struct IndexInsert {
     Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;   // posbase[nregions+1]
@@ -354,9 +357,11 @@ struct IndexInsert {
         const uint64_t hv = hash_tag(tag);
         const uint64_t fp = hv & 0xffffffff00000000ull;
         uint32_t h = (uint32_t)hv & ri.tmask;
-        {   // presence filter: most query K-mers of a non-matching strand are rejected by one bit that lives in L2
+        {   // presence filter: most query K-mers of a non-matching strand are rejected by one word that lives in L2.  Two
+            // hashed bits of the SAME 32-bit word per K-mer (a blocked Bloom filter: still one load per probe): at 8 filter
+            // bits per reference position a foreign K-mer passes with 5 % instead of the 12 % of one bit
             const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
-            atomic_or32(&filter[ri.fbase + (bit >> 5)], 1u << (bit & 31));
+            atomic_or32(&filter[ri.fbase + (bit >> 5)], filter_mask(hv, bit));
         }
         for (;;) {
             uint64_t* slot = &slots[ri.tbase + h];
@@ -384,7 +389,7 @@ PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_
     uint32_t h = (uint32_t)hv & ri.tmask;
     const int64_t base = P.goff[0] + ri.ref_pos;
     const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
-    if (!((filter[ri.fbase + (bit >> 5)] >> (bit & 31)) & 1u)) return kEmpty;
+    { const uint32_t fm = filter_mask(hv, bit); if ((filter[ri.fbase + (bit >> 5)] & fm) != fm) return kEmpty; }
     for (;;) {
         const uint64_t seen = slots[ri.tbase + h];
         if (seen == kEmpty) return kEmpty;
@@ -400,7 +405,7 @@ PM_HD uint64_t index_probe(const RegionInfo& ri, const uint64_t* slots, const ui
     const uint64_t fp = hv & 0xffffffff00000000ull;
     uint32_t h = (uint32_t)hv & ri.tmask;
     const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
-    if (!((filter[ri.fbase + (bit >> 5)] >> (bit & 31)) & 1u)) return kEmpty;
+    { const uint32_t fm = filter_mask(hv, bit); if ((filter[ri.fbase + (bit >> 5)] & fm) != fm) return kEmpty; }
     for (;;) {
         const uint64_t seen = slots[ri.tbase + h];
         if (seen == kEmpty || (seen & 0xffffffff00000000ull) == fp) return seen;
@@ -1376,6 +1381,7 @@ struct DirtyExtent {
         const int j = g0 + (int)__lane_id();
         if (j >= ngen) return;
         int32_t mx = -1, mn = 0x7fffffff;
+#pragma unroll 8
         for (int64_t c = c0; c < c1; c++) {
             const int32_t a = start[c * ngen + j], l = lon[c];
             if (!row_marks(flags[c], l)) continue;
@@ -1418,26 +1424,32 @@ struct DirtyPrefix {
     }
 };
 struct DirtyMark {
-    const int32_t* start; const int32_t* lon; int64_t n; int32_t ngen; const int32_t* bmax; const int32_t* bmin; uint32_t* flags;
+    const int32_t* start; const int32_t* lon; int64_t n; int32_t ngen; const int32_t* bmax; const int32_t* bmin;
+    const uint32_t* flags; uint32_t* dirty;      // dirty[c] (zeroed): set when candidate c overlaps something earlier; flags is only read
     PM_HD void wave(int64_t w) const {
         const int64_t groups = (ngen + 63) / 64, blk = w / groups; const int g0 = (int)(w % groups) * 64;
         const int64_t c0 = blk * kDirtyBlock, c1 = c0 + kDirtyBlock < n ? c0 + kDirtyBlock : n;
 #if defined(__HIP_DEVICE_COMPILE__)
         const int j = g0 + (int)__lane_id();
         const bool act = j < ngen;
+        const int jj = act ? j : 0;
         int32_t mx = act ? bmax[blk * ngen + j] : -1, mn = act ? bmin[blk * ngen + j] : 0x7fffffff;
-        for (int64_t c = c0; c < c1; c++) {
-            const int32_t l = lon[c];
-            const uint32_t fl = flags[c];      // bits other than kRowDirty do not change during this kernel
-            if (!row_marks(fl, l)) continue;    // uniform over the wavefront
-            bool hit = false;
-            if (act) {
-                const int32_t a = start[c * ngen + j], b = a + l;
-                hit = !(a >= mx || b <= mn);
-                if (b > mx) mx = b;
-                if (a < mn) mn = a;
+        // eight candidates per round: their rows are in flight together (one wavefront per SIMD cannot hide a load per step)
+        for (int64_t cb = c0; cb < c1; cb += 8) {
+            int32_t a[8], l[8]; uint32_t fl[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int64_t c = cb + u < c1 ? cb + u : c1 - 1;
+                a[u] = start[c * ngen + jj]; l[u] = lon[c]; fl[u] = flags[c];
             }
-            if (__ballot(hit) && __lane_id() == 0) atomic_or32(&flags[c], kRowDirty);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (cb + u >= c1 || !row_marks(fl[u], l[u])) continue;      // uniform over the wavefront
+                const int32_t b = a[u] + l[u];
+                const bool hit = act && !(a[u] >= mx || b <= mn);
+                if (act) { if (b > mx) mx = b; if (a[u] < mn) mn = a[u]; }
+                if (__ballot(hit) && __lane_id() == 0) atomic_or32(&dirty[cb + u], kRowDirty);
+            }
         }
 #else
         for (int j = g0; j < g0 + 64 && j < ngen; j++) {
@@ -1446,13 +1458,18 @@ struct DirtyMark {
                 const int32_t l = lon[c];
                 if (!row_marks(flags[c], l)) continue;
                 const int32_t a = start[c * ngen + j], b = a + l;
-                if (!(a >= mx || b <= mn)) flags[c] |= kRowDirty;
+                if (!(a >= mx || b <= mn)) dirty[c] |= kRowDirty;
                 if (b > mx) mx = b;
                 if (a < mn) mn = a;
             }
         }
 #endif
     }
+};
+// tid = candidate
+struct DirtyMerge {
+    const uint32_t* dirty; uint32_t* flags;
+    PM_HD void operator()(int64_t c) const { if (dirty[c]) flags[c] |= kRowDirty; }
 };
 
 }  // namespace pm
