@@ -38,6 +38,18 @@ RANDOM_PEAK_GBS = 3400.0   # measured ceiling of scattered 64-byte requests (scr
 PROFILE_ROUND = "r02"   # profiles/<round>/traffic_seed_extend.json, calibration.json: the PMC passes of the shipped binary
 
 
+def engine_src_sha256():
+    """sha256 over the sources of the engine translation unit (scripts/profile_summary.py stamps the same)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.h", "engine_core.h", "engine_hip.hip", "abi_glue.h"):
+        p = os.path.join(ROOT, "parsnp_amd", "csrc", "engine", f)
+        if not os.path.exists(p):
+            return None
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
 def so_sha256():
     """sha256 of the HIP library this process runs: the PMC traffic figure is only quoted for the binary it was measured on"""
     import hashlib
@@ -304,11 +316,11 @@ def main():
                 # workload; see the file for provenance, the calibration and the correction applied.  Quoted only for the
                 # binary the passes ran on (sha256 of libparsnp_hip.so stamped into the file by scripts/profile_summary.py).
                 tj = json.load(open(tpath))
-                if tj.get("so_sha256") == so_sha256():
+                if tj.get("so_sha256") == so_sha256() or (tj.get("engine_src_sha256") and tj.get("engine_src_sha256") == engine_src_sha256()):
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this binary (profiles/%s)" % PROFILE_ROUND
                 else:
-                    traffic_note = "profiles/%s/traffic_seed_extend.json was measured on another build of libparsnp_hip.so: not quoted" % PROFILE_ROUND
+                    traffic_note = "profiles/%s/traffic_seed_extend.json was measured on another build of the engine: not quoted" % PROFILE_ROUND
             peak_random = RANDOM_PEAK_GBS
             if dom and launches:
                 launch_ms = kernels[dom] / launches

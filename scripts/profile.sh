@@ -3,19 +3,20 @@
 #   1. kernel trace + stats of the default bench command            -> gpurun_out/prof/stats
 #   2. PMC pass FETCH_SIZE, 3. PMC pass WRITE_SIZE (separate passes) -> gpurun_out/prof/{fetch,write}
 #   4. FETCH_SIZE / WRITE_SIZE calibration on known byte counts      -> gpurun_out/prof/calib   (scripts/hbm_calib.hip)
-# then scripts/profile_summary.py condenses them into gpurun_out/prof/summary/ (copied by hand into profiles/).
+# then scripts/profile_summary.py condenses them into gpurun_out/prof/summary/ (copied by hand into profiles/rNN/).
+# Every bench run is wrapped in `timeout`: a hung profiler run must not eat the GPU budget.
 set -x
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT/summary
 export TMPDIR=/tmp
 cd /tmp
-python $REPO/bench.py --steps 3 --warmup 1 > $OUT/summary/bench_plain.json 2> $OUT/bench_plain.err
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o ks -- python $REPO/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $OUT/summary/bench_under_rocprof.json 2> $OUT/stats.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o pf -- python $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/fetch.out 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o pw -- python $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/write.out 2> $OUT/write.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/calib -o cf -- $REPO/parsnp_amd/bin/hbm_calib > $OUT/summary/calib_bytes.json 2> $OUT/calib.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/calibw -o cw -- $REPO/parsnp_amd/bin/hbm_calib > /dev/null 2> $OUT/calibw.err
+timeout 300 python $REPO/bench.py --steps 3 --warmup 1 > $OUT/summary/bench_plain.json 2> $OUT/bench_plain.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o ks -- python $REPO/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $OUT/summary/bench_under_rocprof.json 2> $OUT/stats.err
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o pf -- python $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/fetch.out 2> $OUT/fetch.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o pw -- python $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/write.out 2> $OUT/write.err
+timeout 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/calib -o cf -- $REPO/parsnp_amd/bin/hbm_calib > $OUT/summary/calib_bytes.json 2> $OUT/calib.err
+timeout 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/calibw -o cw -- $REPO/parsnp_amd/bin/hbm_calib > /dev/null 2> $OUT/calibw.err
 cd $REPO
 find $OUT -name "*.csv" | head -40
 python scripts/profile_summary.py $OUT

@@ -60,6 +60,17 @@ def lib_sha():
     return hashlib.sha256(open(p, "rb").read()).hexdigest() if os.path.exists(p) else None
 
 
+def engine_src_sha():
+    """sha256 over the sources of the engine translation unit (the kernels the passes measured): unlike the library hash
+    it survives edits to the other translation unit of libparsnp_hip.so (the gap aligner)"""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parsnp_amd", "csrc", "engine")
+    h = hashlib.sha256()
+    for f in ("kernels.h", "engine_core.h", "engine_hip.hip", "abi_glue.h"):
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     out = sys.argv[1]
     summ = os.path.join(out, "summary")
@@ -124,7 +135,7 @@ def main():
              "rocprof_avg_launch_ms": ((st_se.get("total_ms", 0) + st_sp.get("total_ms", 0)) / calls) if calls else None,
              "rocprof_calls": calls,
              "rocprof_seed_extend_avg_ms": st_se.get("avg_ms"), "rocprof_small_pair_events_avg_ms": st_sp.get("avg_ms"),
-             "so_sha256": lib_sha()}
+             "so_sha256": lib_sha(), "engine_src_sha256": engine_src_sha()}
         json.dump(t, open(os.path.join(summ, "traffic_seed_extend.json"), "w"), indent=1)
     print(json.dumps({"stats": {k: v for k, v in stats.items() if v["total_ms"] > 1}, "calibration": cal, "seed_extend": per.get("SeedExtend"), "small_pair_events": per.get("SmallPairEvents")}, indent=1))
 
