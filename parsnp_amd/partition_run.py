@@ -81,4 +81,8 @@ def run_partitioned(core_bin, ref, finalfiles, outdir, min_partition_size, rank=
         from . import partition_merge
         merged = partition_merge.merge_partitions([os.path.join(p["dir"], "parsnpAligner.xmfa") for p in good], os.path.join(outdir, "parsnp.xmfa"))
         merged = dict(clusters=merged["clusters"], sequences=merged["sequences"], xmfa=os.path.join(outdir, "parsnp.xmfa"))
+    if merge and dist is not None and world > 1:      # every rank returns the same view
+        box = [merged]
+        dist.broadcast_object_list(box, src=0)
+        merged = box[0]
     return dict(partitions=parts, intersection=intersect([p["intervals"] for p in good]) if good else [], merged=merged)

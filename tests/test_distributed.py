@@ -73,6 +73,9 @@ def test_two_ranks_gloo(cpu_checkers, tmp_path):
            [[list(i) for i in p["intervals"]] for p in single["partitions"]] == [p["intervals"] for p in r0["partitions"]]
     assert [list(i) for i in single["intersection"]] == r0["intersection"]
     assert len(r0["intersection"]) >= 1
+    # rank 0 merged the four partitions into one XMFA: every genome once, the same clusters as the single-process merge
+    assert r0["merged"]["sequences"] == 13 and r0["merged"]["clusters"] == single["merged"]["clusters"] >= 1
+    assert xmfa_util.md5(r0["merged"]["xmfa"]) == xmfa_util.md5(single["merged"]["xmfa"])
     for a, b in zip(single["partitions"], r0["partitions"]):
         assert xmfa_util.md5(os.path.join(a["dir"], "parsnpAligner.xmfa")) == xmfa_util.md5(os.path.join(b["dir"], "parsnpAligner.xmfa"))
 
