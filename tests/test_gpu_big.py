@@ -54,8 +54,9 @@ def test_baseline_size_against_reference(scratch, name):
         assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
         x = os.path.join(out, "parsnpAligner.xmfa")
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"], mode
-        assert xmfa_util.mum_lcb_signature(x) == want["signature"], mode
-        assert xmfa_util.md5(x) == want["xmfa_md5"], mode
+        if xmfa_util.md5(x) != want["xmfa_md5"]:      # every byte; the MUM/LCB signature (a Python pass over a 1 GB file) only to say what differs
+            assert xmfa_util.mum_lcb_signature(x) == want["signature"], mode + ": MUM / LCB coordinates differ"
+            assert False, mode + ": same MUMs and LCBs, the gap columns differ"
         assert "NOTE" not in open(os.path.join(out, "parsnpAligner.log")).read()
         shutil.rmtree(out, ignore_errors=True)
     shutil.rmtree(os.path.join(scratch, name), ignore_errors=True)
