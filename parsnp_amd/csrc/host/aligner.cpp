@@ -147,6 +147,7 @@ void Aligner::wait_layout() {
 
 Aligner::~Aligner() {
     wait_layout();
+    finish_prejudge();
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double t = now_s();
     auto lap = [&](const char* what) { if (dbg) { double u = now_s(); fprintf(stderr, "[release] %-10s %.4f s\n", what, u - t); t = u; } };
@@ -1118,6 +1119,7 @@ bool Aligner::extend_generations() {
         bool trouble = false;
         if (gi == 0) {                           // the first pushed seed, before anything is sorted
             trouble = !fetch(gen, &gen_raw);     // ... but every seed's engine result in ONE call
+            finish_prejudge();                   // (the anchors' chaining verdicts were worked out beside that call)
             seeds_raw = gen_raw;
             now.push_back(gen.front()); now_raw.push_back(gen_raw.front());
             first = {0, 1};
@@ -1247,8 +1249,11 @@ bool Aligner::extend() {
     sweeps_ = 0; misses_since_sweep_ = 0;
     double tr = now_s();
     bool any;
+    static const bool no_prejudge = getenv("PARSNP_NO_PREJUDGE") != nullptr;      // test hook: every verdict inside chain()
+    if (!no_prejudge) start_prejudge();
     if (getenv("PARSNP_SEQUENTIAL_REPLAY") == nullptr) any = extend_generations();
-    else { if (speculation_) prefetch(regions); tr = now_s(); any = extend_pass(false); }
+    else { if (speculation_) prefetch(regions); finish_prejudge(); tr = now_s(); any = extend_pass(false); }
+    finish_prejudge();
     stats.t_replay = now_s() - tr - stats.t_sweep;
     remaining_ = nullptr;
     cache_.clear();
@@ -1322,8 +1327,61 @@ void Aligner::filter_mums(int rvalue) {
 
 // Greedy collinear chaining of the MUMs in reference order (setFinalClusters :2563-2719).  The float32 / double
 // mix of the gap-ratio test is the reference's.
+// the test of one MUM against the open chain (:2596-2700).  It reads the chain only through its last MUM: the chain
+// end IS that MUM's end, and every member has the strand flags of the first, so "back" decides alone.
+uint8_t Aligner::judge_pair(const Mum& nt, const Mum& back) const {
+    const int d = prm.d;
+    const float diag_diff = prm.diag_diff;
+    bool addmum = true;
+    float max_gap = 0;
+    float min_gap = d + 10;
+    const long blen = back.length;
+    for (size_t k = 0; k < n; k++) {
+        const long fgap = (long)nt.start[k] - ((long)back.start[k] + blen);   // forward: next start - chain end
+        const long rgap = (long)back.start[k] - nt.end(k);   // reverse: previous MUM start - next end
+        const bool f = nt.fwd[k] != 0;
+        if (f && fgap > max_gap) max_gap = fgap;
+        else if (!f && rgap > max_gap) max_gap = fgap;       // sic (:2608-2611)
+        if (f && fgap < min_gap) min_gap = fgap;
+        else if (!f && rgap < min_gap) min_gap = rgap;
+        if (nt.fwd[k] != back.fwd[k]) addmum = false;
+        else if (f && fgap < 0) addmum = false;
+        else if (!f && fgap >= 0) addmum = false;
+        else if (f && fgap > d) addmum = false;
+        else if (!f && rgap > d) addmum = false;
+        if (!addmum) break;
+    }
+    if (!addmum) return kClose;
+    if (min_gap == 0) min_gap = 1;
+    if (max_gap == 0) max_gap = 1;
+    if (diag_diff > 1.0) return max_gap - min_gap < diag_diff ? kJoin : kPass;   // kPass: neither joined nor closed (:2684-2692)
+    return min_gap / max_gap >= 1.0 - diag_diff ? kJoin : kClose;
+}
+
+// The verdict of a pair of MUMs depends on the two alone, and four out of five anchors still follow the same anchor in
+// the final MUM list (the recursion adds one MUM per six anchors).  So the anchors' consecutive pairs are judged while the
+// host would otherwise wait for the recursion's first engine call; chain() reuses a verdict whenever the predecessor of a
+// MUM is still the one it was judged against.  Reads `pool` and `mums` as the anchor search left them: finish_prejudge()
+// is called before anything is added to either.
+void Aligner::start_prejudge() {
+    static const size_t min_n = getenv("PARSNP_PREJUDGE_MIN") ? (size_t)atol(getenv("PARSNP_PREJUDGE_MIN")) : 4096;   // test hook
+    if (mums.size() < min_n || prm.cores < 2) return;
+    judged_pred_.assign(pool.size(), -1); judged_verdict_.assign(pool.size(), kClose);
+    prejudge_ = std::async(std::launch::async, [this] {
+        const long m = (long)mums.size();
+#pragma omp parallel for schedule(static) num_threads(prm.cores)
+        for (long x = 1; x < m; x++) {
+            const int cur = mums[(size_t)x], prev = mums[(size_t)x - 1];
+            judged_verdict_[(size_t)cur] = judge_pair(pool[(size_t)cur], pool[(size_t)prev]);
+            judged_pred_[(size_t)cur] = prev;
+        }
+    });
+}
+void Aligner::finish_prejudge() { if (prejudge_.valid()) prejudge_.get(); }
+
 void Aligner::chain() {
     double t0 = now_s();
+    finish_prejudge();
     lcbs.clear();
     unique_order = true;
     {
@@ -1342,43 +1400,14 @@ void Aligner::chain() {
         }
     }
     if (mums.empty()) return;
-    const int d = prm.d;
-    const float diag_diff = prm.diag_diff;
-    // the test of one MUM against the open chain (:2596-2700).  It reads the chain only through its last MUM: the chain
-    // end IS that MUM's end, and every member has the strand flags of the first, so "back" decides alone.
-    enum : uint8_t { JOIN = 0, CLOSE = 1, PASS = 2 };
-    auto judge = [&](const Mum& nt, const Mum& back) -> uint8_t {
-        bool addmum = true;
-        float max_gap = 0;
-        float min_gap = d + 10;
-        const long blen = back.length;
-        for (size_t k = 0; k < n; k++) {
-            const long fgap = (long)nt.start[k] - ((long)back.start[k] + blen);   // forward: next start - chain end
-            const long rgap = (long)back.start[k] - nt.end(k);   // reverse: previous MUM start - next end
-            const bool f = nt.fwd[k] != 0;
-            if (f && fgap > max_gap) max_gap = fgap;
-            else if (!f && rgap > max_gap) max_gap = fgap;       // sic (:2608-2611)
-            if (f && fgap < min_gap) min_gap = fgap;
-            else if (!f && rgap < min_gap) min_gap = rgap;
-            if (nt.fwd[k] != back.fwd[k]) addmum = false;
-            else if (f && fgap < 0) addmum = false;
-            else if (!f && fgap >= 0) addmum = false;
-            else if (f && fgap > d) addmum = false;
-            else if (!f && rgap > d) addmum = false;
-            if (!addmum) break;
-        }
-        if (!addmum) return CLOSE;
-        if (min_gap == 0) min_gap = 1;
-        if (max_gap == 0) max_gap = 1;
-        if (diag_diff > 1.0) return max_gap - min_gap < diag_diff ? JOIN : PASS;   // PASS: neither joined nor closed (:2684-2692)
-        return min_gap / max_gap >= 1.0 - diag_diff ? JOIN : CLOSE;
-    };
+    enum : uint8_t { JOIN = kJoin, CLOSE = kClose, PASS = kPass };
+    auto judge = [&](const Mum& nt, const Mum& back) -> uint8_t { return judge_pair(nt, back); };
     // almost always the chain's last MUM is the previous MUM of the list: those verdicts are independent, computed ahead
     const long m = (long)mums.size();
     // (a verdict depends on the two MUMs alone: the second chaining pass, after a few LCBs were dissolved, reuses the
     // verdicts of every MUM whose predecessor is still the same)
     std::vector<uint8_t> ahead((size_t)m, CLOSE);
-    if (judged_pred_.size() < pool.size()) { judged_pred_.assign(pool.size(), -1); judged_verdict_.assign(pool.size(), CLOSE); }
+    if (judged_pred_.size() < pool.size()) { judged_pred_.resize(pool.size(), -1); judged_verdict_.resize(pool.size(), CLOSE); }   // earlier verdicts (start_prejudge, the first pass) stay
     std::vector<long> lens((size_t)m);          // gathered here: the sequential pass below would miss the cache once per MUM
     lens[0] = pool[(size_t)mums[0]].length;
 #pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 4096)

@@ -272,9 +272,14 @@ public:
     Region new_region();
 
     void wait_layout();           // the layout bitmaps are set up in the background (constructor); find_anchors() awaits them
+    enum : uint8_t { kJoin = 0, kClose = 1, kPass = 2 };
+    uint8_t judge_pair(const Mum& nt, const Mum& back) const;     // chain()'s test of a MUM against the open chain's last MUM
+    void start_prejudge();        // the anchors' consecutive pairs, judged beside the recursion's first engine call
+    void finish_prejudge();
 
 private:
     std::vector<std::future<void>> layout_ready_;
+    std::future<void> prejudge_;
     std::vector<int> judged_pred_;            // chain(): predecessor against which a MUM was last judged, and the verdict
     std::vector<uint8_t> judged_verdict_;
     pm_session* session_;

@@ -229,7 +229,7 @@ def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant
     else:
         r, gs = synth.make(name)
         rp, qs = synth.write_set(str(tmp_path / "in"), r, gs); kw = {}
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_PREJUDGE_MIN="8")
     if variant == "host_overlap":
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":

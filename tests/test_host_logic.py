@@ -104,15 +104,15 @@ def test_in_order_replay_same_result(cpu_checkers, tmp_path, name, threads):
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"], tag
 
 
-@pytest.mark.parametrize("switch", ["PARSNP_ORDERED_FLAGGED", "PARSNP_CHAIN_TWICE", "PARSNP_SYNC_LAYOUT", "PARSNP_EXACT_OVERLAP"])
+@pytest.mark.parametrize("switch", ["PARSNP_ORDERED_FLAGGED", "PARSNP_CHAIN_TWICE", "PARSNP_SYNC_LAYOUT", "PARSNP_EXACT_OVERLAP", "PARSNP_NO_PREJUDGE"])
 @pytest.mark.parametrize("name", ["poprearr10x400k", "draft8x300k"])
 def test_plain_variants_of_the_host_shortcuts(cpu_checkers, tmp_path, name, switch):
     """every host shortcut has a switch that takes the plain route instead -- flagged candidates all in candidate order,
     the second chaining pass always run, the layout cleared before anything else, the overlap flags from scratch
-    bitmaps -- and the bytes must not change (the default route is pinned by the goldens in the other tests)"""
+    bitmaps, no chaining verdict worked out ahead of chain() -- and the bytes must not change (the default route is pinned by the goldens in the other tests)"""
     rp, qs, kw = harsh_inputs(name, str(tmp_path))
     out = str(tmp_path / "out")
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PARSNP_PREJUDGE_MIN="8")   # the shortcuts at work on small sets
     env[switch] = "1"
     rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, threads=4, **kw)
     assert rc == 0
