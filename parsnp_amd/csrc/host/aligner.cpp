@@ -1367,9 +1367,11 @@ void Aligner::start_prejudge() {
     static const size_t min_n = getenv("PARSNP_PREJUDGE_MIN") ? (size_t)atol(getenv("PARSNP_PREJUDGE_MIN")) : 4096;   // test hook
     if (mums.size() < min_n || prm.cores < 2) return;
     judged_pred_.assign(pool.size(), -1); judged_verdict_.assign(pool.size(), kClose);
-    prejudge_ = std::async(std::launch::async, [this] {
+    // a third of the threads: the engine call it runs beside stages 26 MB of request rows with threads of its own first
+    const int team = std::max(2, prm.cores / 3);
+    prejudge_ = std::async(std::launch::async, [this, team] {
         const long m = (long)mums.size();
-#pragma omp parallel for schedule(static) num_threads(prm.cores)
+#pragma omp parallel for schedule(static) num_threads(team)
         for (long x = 1; x < m; x++) {
             const int cur = mums[(size_t)x], prev = mums[(size_t)x - 1];
             judged_verdict_[(size_t)cur] = judge_pair(pool[(size_t)cur], pool[(size_t)prev]);
