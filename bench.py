@@ -175,6 +175,10 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0,
                     help="ini [LCB] cores: host threads for ingest, candidate validation, output (0 = 24, fewer when the CPUs this "
                          "container may use, shared by the ranks of the node, do not allow it)")
+    ap.add_argument("--mode", default="partition", choices=["partition", "sharded"],
+                    help="N > 1: 'partition' (default) = one independent partition per GPU, weak scaling, no data-path collective; "
+                         "'sharded' = ONE alignment (the workload's genomes) sharded over the GPUs, strong scaling, both exchanges of "
+                         "every engine call over the engine's own RCCL communicator (device buffers)")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
@@ -194,13 +198,18 @@ def main():
     os.environ["PARSNP_DEVICE"] = str(dev)
     dist = None
     tdev = "cuda"
+    sharded = args.mode == "sharded"
     if world > 1:
         import torch.distributed as dist
-        if torch.cuda.device_count() >= world:
+        if torch.cuda.device_count() >= world and not sharded:
             dist.init_process_group("nccl")   # RCCL, one rank per GPU
-        else:                                  # smoke test of this script on a box with fewer GPUs than ranks
+        else:
+            # smoke test of this script on a box with fewer GPUs than ranks; and the sharded mode, where torch.distributed is
+            # only the rendezvous that carries the engine's RCCL id (the process then holds ONE RCCL: the engine's)
             dist.init_process_group("gloo")
             tdev = "cpu"
+    if sharded and world > torch.cuda.device_count():
+        sys.exit("bench.py --mode sharded needs one GPU per rank (RCCL refuses two ranks on one device)")
 
     def barrier():
         if dist is not None:
@@ -228,7 +237,7 @@ def main():
     workdir = tempfile.mkdtemp(prefix="parsnp_bench_r%d_" % rank, dir=scratch)
     try:
         t0 = time.time()
-        rp, qs, n_ref, m_avg, kw = make_inputs(workdir, args.workload, args.genomes, rank)
+        rp, qs, n_ref, m_avg, kw = make_inputs(workdir, args.workload, args.genomes, 0 if sharded else rank)   # sharded: every rank the same genomes
         gen_s = time.time() - t0
         out = os.path.join(workdir, "out")
         os.makedirs(out, exist_ok=True)
@@ -239,7 +248,19 @@ def main():
         logf = os.open(os.path.join(out, "bench.log"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
         os.dup2(logf, 1); os.dup2(logf, 2)
         try:
-            run = CoreRun(ini)
+            if sharded:
+                from parsnp_amd.sharded import ShardedRun
+
+                class _Solo:      # the one-rank case needs no process group
+                    @staticmethod
+                    def get_rank(): return 0
+                    @staticmethod
+                    def get_world_size(): return 1
+                    @staticmethod
+                    def broadcast_object_list(box, src=0): return None
+                run = ShardedRun(ini, dist if dist is not None else _Solo, "cpu", None, rccl=True)
+            else:
+                run = CoreRun(ini)
             cold_step_s = None
             for w in range(args.warmup):
                 tc = time.perf_counter()
@@ -259,7 +280,7 @@ def main():
                 ts = time.perf_counter()
                 rep = run.step()
                 step_ms.append(round(1e3 * (time.perf_counter() - ts), 2))
-                if dist is not None:
+                if dist is not None and not sharded:
                     # partition mode's exchange step: every rank's LCB reference intervals are all-gathered (RCCL) and
                     # intersected -- the positions aligned in EVERY partition (partition.py:35-61, 539-583)
                     merged_bp = exchange_intervals(torch, dist, tdev, rep["lcb_ref_intervals"])
@@ -284,14 +305,14 @@ def main():
             elapsed = float(t.item())
             cb = torch.tensor([reports[-1]["core_bp"]], dtype=torch.float64, device=tdev)
             dist.all_reduce(cb, op=dist.ReduceOp.SUM)
-            core_bp_total = int(cb.item())
+            core_bp_total = int(cb.item()) if not sharded else reports[-1]["core_bp"]      # sharded: every rank holds the one alignment
         else:
             core_bp_total = reports[-1]["core_bp"]
 
         if rank == 0:
             rep = reports[-1]
             G = len(qs)
-            value = world * G * args.steps / elapsed
+            value = (1 if sharded else world) * G * args.steps / elapsed       # sharded: the G genomes are the whole job
             # dominant kernel: per-phase HIP-event times of every engine launch of the timed steps (anchor launch +
             # recursion launches), summed per step and averaged over the steps
             phases, totals = {}, {}
@@ -343,12 +364,12 @@ def main():
             line = {
                 "metric": "genomes/sec (MUM+LCB end-to-end)", "value": round(value, 4), "unit": "genomes/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
                 "config": {"workload": "%s: %d query genomes x %.2f Mb vs 1 reference (%s model, %s), --no-partition per GPU%s"
                            % (args.workload, G, n_ref / 1e6, dict(bact200="population").get(args.workload, "synthetic"),
                               ", ".join("%s=%s" % (k, v) for k, v in sorted(kw.items()) if k not in ("n", "n_genomes")),
-                              "" if world == 1 else "; one partition per rank, %d ranks" % world),
-                           "genomes_per_gpu": G, "genome_bp": n_ref, "host_threads": args.host_threads, "host_cpus_usable": usable_cpus(), "numa_node": numa_node, "parallelism": "partition-per-gpu x%d" % world},
+                              "" if world == 1 else ("; ONE alignment sharded over %d ranks" % world if sharded else "; one partition per rank, %d ranks" % world)),
+                           "genomes_per_gpu": G if not sharded else round(G / world, 2), "genome_bp": n_ref, "host_threads": args.host_threads, "host_cpus_usable": usable_cpus(), "numa_node": numa_node, "parallelism": ("sharded x%d (engine RCCL: all-reduce(min) + all-gather per engine call)" % world) if sharded else "partition-per-gpu x%d" % world},
                 "step_ms": step_ms,
                 "core_bp_aligned": core_bp_total,
                 "core_bp_in_every_partition": merged_bp,

@@ -291,6 +291,18 @@ def test_bench_two_ranks_smoke(libs, tmp_path):
     assert 0 < d["core_bp_in_every_partition"] <= d["core_bp_aligned"] // 2 + 1000
 
 
+def test_bench_sharded_mode_one_rank(libs):
+    """bench.py --mode sharded (one alignment over the GPUs, engine-owned RCCL) with the one rank a single-GPU box allows"""
+    import subprocess, sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "sharded", "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "pop6x200k", "--cpu-sample", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and "sharded" in d["config"]["parallelism"]
+    assert d["mums"] > 2000 and "exchange_ep" in d["engine_ms"] and "exchange_states" in d["engine_ms"]
+
+
 @pytest.mark.parametrize("name,world", [("poprearr10x400k", 2), ("bact8", 4)])
 def test_sharded_run_on_gpu(libs, tmp_path, name, world):
     """SURVEY 8e-2 with the HIP engine: `world` ranks, each with its block of the query genomes resident (on this 1-GPU
