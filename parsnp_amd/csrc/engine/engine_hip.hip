@@ -226,12 +226,7 @@ struct HipBackend {
         need_tmp(bytes);
         check(rocprim::radix_sort_pairs(tmp, bytes, ki, ko, vi, vo, n, 0, (unsigned)bits, stream), "radix_sort_pairs");
     }
-    void sort_keys(uint64_t* ki, uint64_t* ko, size_t n, int bits) {
-        size_t bytes = 0;
-        check(rocprim::radix_sort_keys(nullptr, bytes, ki, ko, n, 0, (unsigned)bits, stream), "sort size");
-        need_tmp(bytes);
-        check(rocprim::radix_sort_keys(tmp, bytes, ki, ko, n, 0, (unsigned)bits, stream), "radix_sort_keys");
-    }
+
     // phase timing: mark(name) opens a phase, mark(nullptr) closes the last one
     void mark(const char* name) {
         hipEvent_t e;

@@ -43,7 +43,6 @@ struct HostBackend {
         std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ki[a] < ki[b]; });
         for (size_t i = 0; i < n; i++) { ko[i] = ki[idx[i]]; vo[i] = vi[idx[i]]; }
     }
-    void sort_keys(uint64_t* ki, uint64_t* ko, size_t n, int) { memcpy(ko, ki, 8 * n); std::sort(ko, ko + n); }
     void mark(const char*) {}
     std::vector<pm::PhaseTime> collect() { return {}; }
     bool ok() const { return true; }
