@@ -111,7 +111,7 @@ def test_events(libs):
 def test_end_to_end_with_emulated_engine(emu, tmp_path):
     r, gs = synth.make("viral50")
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
-    test_host_logic.check(emu[1], "viral50", rp, qs, str(tmp_path / "out"), True)
+    test_host_logic.check(emu[1], "viral50", rp, qs, str(tmp_path / "out"))
 
 
 @pytest.mark.parametrize("name", ["rearr6x300k", "pop6x200k"])

@@ -14,7 +14,7 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 E2E = json.load(open(os.path.join(G, "e2e.json")))
 
 
-def check(core, name, rp, qs, out, exact_xmfa=True, env=None):
+def check(core, name, rp, qs, out, env=None):
     rc, _ = driver.run_core(core, rp, qs, out, env=env)
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
     x = os.path.join(out, "parsnpAligner.xmfa")
@@ -28,14 +28,14 @@ def check(core, name, rp, qs, out, exact_xmfa=True, env=None):
 
 def test_mers(cpu_checkers, tmp_path):
     ref, qs = mers(base=str(tmp_path))
-    check(cpu_checkers, "mers", ref, qs, str(tmp_path / "out"), exact_xmfa=False)
+    check(cpu_checkers, "mers", ref, qs, str(tmp_path / "out"))
 
 
-@pytest.mark.parametrize("name,exact", [("viral50", True), ("pop6x200k", False), ("rearr6x300k", True)])
-def test_synthetic(cpu_checkers, tmp_path, name, exact):
+@pytest.mark.parametrize("name", ["viral50", "pop6x200k", "rearr6x300k"])
+def test_synthetic(cpu_checkers, tmp_path, name):
     r, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
-    check(cpu_checkers, name, rp, qs, str(tmp_path / "out"), exact)
+    check(cpu_checkers, name, rp, qs, str(tmp_path / "out"))
 
 
 @pytest.mark.parametrize("name", ["pop6x200k", "rearr6x300k", "poprearr10x400k"])
@@ -87,7 +87,7 @@ def test_no_speculation_same_result(cpu_checkers, tmp_path):
     r, gs = synth.make("pop6x200k")
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
     env = dict(os.environ, PARSNP_NO_SPECULATION="1")
-    check(cpu_checkers, "pop6x200k", rp, qs, str(tmp_path / "out"), False, env=env)
+    check(cpu_checkers, "pop6x200k", rp, qs, str(tmp_path / "out"), env=env)
 
 
 @pytest.mark.parametrize("name,threads", [("pop6x200k", 1), ("pop6x200k", 6), ("messy", 3), ("draft8x300k", 4), ("pchunk", 2)])
