@@ -480,6 +480,7 @@ bool Aligner::settle(Mum& m, bool touches, bool any_reverse) const {
 // Candidate -> MUM, in candidate order (parsnp.cpp:1717-1841).
 void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted) {
     wait_layout();
+    anchors_ordered_ = false;      // only validate_parallel, for a list accepted into an empty layout, can say otherwise
     const size_t ncand = raw.count;
     const int threads = prm.cores > 1 ? prm.cores : 1;
     static const size_t par_min = getenv("PARSNP_PARALLEL_MIN") ? (size_t)atol(getenv("PARSNP_PARALLEL_MIN")) : 4096;   // test hook
@@ -602,15 +603,26 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         if (settle(cand[(size_t)c], false, (st & 4) != 0)) state[(size_t)c] |= 16;
     }
     lap("settle");
-#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    // (the same pass notes whether the accepted clean candidates of a genome come one after the other: anchors_ordered_)
+    int disorder = 0;
+#pragma omp parallel for schedule(static, 1) num_threads(threads) reduction(| : disorder)
     for (int t = 0; t < nstripes; t++) {
         const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
+        std::vector<long> last_l(j1 - j0 + 16, 0);      // end of the previous accepted candidate, per genome of the stripe
+        long* last = last_l.data() + 8 - j0;
+        long bad = 0;
         for (size_t c = 0; c < ncand; c++) {
             __builtin_prefetch(srow + (c + 24) * n + j0); __builtin_prefetch(srow + (c + 24) * n + j1 - 1);
             if ((state[c] & 24) == 16)
                 { const int32_t* st = cand[c].start; const long lon = cand[c].length;     // accepted: inside the genome, length >= 5
-                  for (size_t j = j0; j < j1; j++) layout[j].set_range_inside(st[j], (long)st[j] + lon); }
+                  for (size_t j = j0; j < j1; j++) {
+                      const long a = st[j], b = a + lon;
+                      bad |= a - last[j];               // negative (sign bit) when this one starts before the previous one ends
+                      last[j] = b;
+                      layout[j].set_range_inside(a, b);
+                  } }
         }
+        disorder |= bad < 0 ? 1 : 0;
     }
     lap("mark");
     // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them
@@ -693,11 +705,29 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         }
         if (!acc) continue;
         m.slength = r.slength;
+        m.dirty = (st & 8) != 0;
         pool.push_back(m);
         accepted->push_back((int)pool.size() - 1);
         stats.parallel_dirty += (st & 8) ? 1 : 0;
     }
     stats.parallel_candidates += (long)ncand;
+    // order of the whole accepted list per genome = order of the clean ones (above) + every accepted flagged candidate
+    // between its list neighbours (it may have been trimmed: its row holds the final coordinates)
+    if (layout_empty && !disorder) {
+        bool ordered = true;
+        const size_t na = accepted->size();
+        for (size_t x = 0; x < na && ordered; x++) {
+            const Mum& m = pool[(size_t)(*accepted)[x]];
+            if (!m.dirty) continue;
+            for (int side = 0; side < 2 && ordered; side++) {
+                if ((side == 0 && x == 0) || (side == 1 && x + 1 == na)) continue;
+                const Mum& a = side == 0 ? pool[(size_t)(*accepted)[x - 1]] : m;
+                const Mum& b = side == 0 ? m : pool[(size_t)(*accepted)[x + 1]];
+                for (size_t j = 0; j < n; j++) if ((long)b.start[j] < a.end(j)) { ordered = false; break; }
+            }
+        }
+        anchors_ordered_ = ordered;
+    } else anchors_ordered_ = false;
     lap("sequential");
 }
 
@@ -773,6 +803,49 @@ bool Aligner::find_anchors() {
             if (kept && (!std::equal(f.start, f.start + n, got.start) || !std::equal(f.end, f.end + n, got.end) || f.slength != got.slength || f.llength != got.llength))
                 fatal("seed region differs from the full bitmap walk");
         };
+        // Anchors in list order in every genome (validate_parallel checked it): the marked base next to an anchor is its list
+        // neighbour's first / last base, so both regions follow from three rows -- no bitmap is read.  The walks they
+        // replace: determineRegion :1216-1231 (left: previous marked base, region starts one after it, at 1 at the genome
+        // start) and :1254-1268 (right: from one base after the MUM's end to the base before the next marked one or the
+        // sentinel at the genome end).
+        auto from_rows = [&](long i, bool left, Region* out) -> bool {
+            const Mum& m = pool[(size_t)found[(size_t)i]];
+            const Mum* other = left ? (i > 0 ? &pool[(size_t)found[(size_t)i - 1]] : nullptr) : (i + 1 < nf ? &pool[(size_t)found[(size_t)i + 1]] : nullptr);
+            long s = 500000000, l = 0;
+            for (size_t j = 0; j < n; j++) {
+                long a, b;
+                if (left) {
+                    a = other ? other->end(j) : 1;            // prev_set = the neighbour's last base e-1 -> start e; none: p = 0 -> start 1
+                    b = (long)m.start[j] - 1;
+                } else {
+                    const long nxt = m.end(j) + 1, size = gsize_[j];
+                    long p = nxt;                              // nxt >= size: the walk does not start
+                    if (nxt < size) p = other ? std::max<long>((long)other->start[j], nxt) : size;
+                    a = nxt; b = p - 1;
+                }
+                const long len = b - a;
+                if (len <= q) return false;
+                out->start[j] = a; out->end[j] = b; out->length[j] = len;
+                if (len < s) s = len;
+                if (len > l) l = len;
+            }
+            out->slength = s; out->llength = l;
+            return true;
+        };
+        static const bool no_rows_path = getenv("PARSNP_WALK_NEIGHBOURS") != nullptr;      // test hook: always the bitmap walks
+        if (anchors_ordered_ && !no_rows_path) {
+            for (long i = i0; i < i1; i++) {
+                const Mum& m = pool[(size_t)found[(size_t)i]];
+                Region& rR = rS[0];
+                const bool l_kept = from_rows(i, true, &lS);
+                if (check_derived) checked(m, true, l_kept, lS);
+                if (l_kept) keep(lS, &lRs[(size_t)i]);
+                const bool r_kept = from_rows(i, false, &rR);
+                if (check_derived) checked(m, false, r_kept, rR);
+                if (r_kept) keep(rR, &rRs[(size_t)i]);
+            }
+            continue;
+        }
         for (long i = i0; i < i1; i++) {
             const Mum& m = pool[(size_t)found[(size_t)i]];
             Region& pr = rS[(i - i0 + 1) & 1];       // right neighbour of the previous anchor of this run (valid when have_pr)
@@ -803,6 +876,7 @@ bool Aligner::find_anchors() {
         }
     }
     stats.t_neighbour += now_s() - tn;
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[anchors] seed regions %s %.4f s\n", anchors_ordered_ ? "from rows" : "by bitmap walks", now_s() - tn);
     for (size_t i = 0; i < found.size(); i++) {
         const Region& lR = lRs[i];
         if (lR.start && (i == 0 || !rRs[i - 1].start || !lR.same_as(rRs[i - 1], n))) regions.push_back(lR);

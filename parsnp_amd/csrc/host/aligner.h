@@ -179,6 +179,7 @@ struct Mum {
     long slength = 0;
     int32_t* start = nullptr;
     uint8_t* fwd = nullptr;
+    bool dirty = false;      // (anchor validation) overlapped an earlier candidate and went through the ordered pass
     long end(size_t j) const { return (long)start[j] + length; }
 };
 
@@ -280,6 +281,10 @@ public:
 private:
     std::vector<std::future<void>> layout_ready_;
     std::future<void> prejudge_;
+    // set by validate_parallel for the list it accepted into an EMPTY layout (the anchor call): in every genome the accepted
+    // MUMs lie in list order, one after the other without overlap -- then the marked base next to a MUM is its list
+    // neighbour's, and find_anchors() derives the seed regions from the rows instead of walking bitmaps
+    bool anchors_ordered_ = false;
     std::vector<int> judged_pred_;            // chain(): predecessor against which a MUM was last judged, and the verdict
     std::vector<uint8_t> judged_verdict_;
     pm_session* session_;

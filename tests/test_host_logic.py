@@ -120,16 +120,24 @@ def test_plain_variants_of_the_host_shortcuts(cpu_checkers, tmp_path, name, swit
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 
 
+@pytest.mark.parametrize("route", ["walks", "rows"])
 @pytest.mark.parametrize("name", ["pop6x200k", "poprearr10x400k", "messy", "draft8x300k"])
-def test_derived_left_neighbours_equal_the_walk(cpu_checkers, tmp_path, name):
+def test_derived_left_neighbours_equal_the_walk(cpu_checkers, tmp_path, name, route):
     """the seed regions left of an anchor are derived from the walk right of the previous anchor where that walk ended
-    at this anchor in every genome; PARSNP_CHECK_NEIGHBOURS=1 repeats every derived region with the bitmap walk of
-    determineRegion (parsnp.cpp:1199-1290) and aborts on a difference"""
+    at this anchor in every genome ("walks"); where the threaded validation found the accepted anchors in list order in
+    every genome, both regions of every anchor are derived from the rows of its list neighbours without reading a
+    bitmap ("rows": PARSNP_PARALLEL_MIN sends the small sets through that validation).  PARSNP_CHECK_NEIGHBOURS=1 repeats
+    every derived region with the bitmap walk of determineRegion (parsnp.cpp:1199-1290) and aborts on a difference"""
     rp, qs, kw = harsh_inputs(name, str(tmp_path))
     out = str(tmp_path / "out")
-    rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=dict(os.environ, PARSNP_CHECK_NEIGHBOURS="1"), threads=3, **kw)
-    assert rc == 0
+    env = dict(os.environ, PARSNP_CHECK_NEIGHBOURS="1")
+    if route == "rows":
+        env.update(PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PARSNP_DEBUG_TIMERS="1")
+    rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, threads=3, **kw)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
+    if route == "rows" and name == "pop6x200k":     # a collinear set: the row route must actually have been taken
+        assert "seed regions from rows" in open(os.path.join(out, "parsnp-aligner.err")).read()
 
 
 @pytest.mark.parametrize("name", ["pop6x200k", "poprearr10x400k"])
