@@ -312,7 +312,7 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     std::vector<int32_t> mins(reqs.size());
     double alg = 0;
     const long nreq = (long)reqs.size();
-#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) reduction(+ : alg) if (nreq > 256)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(prm.cores > 0 ? prm.cores : 1) reduction(+ : alg) if (nreq > 256)
     for (long i = 0; i < nreq; i++) {
         const Request& q = reqs[(size_t)i];
         memcpy(&starts[(size_t)i * n], q.start, n * 8);
@@ -530,7 +530,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     static const bool force_exact = getenv("PARSNP_EXACT_OVERLAP") != nullptr;   // test hook: always the bitmap test
     static const bool host_overlap = getenv("PARSNP_HOST_OVERLAP") != nullptr;   // test hook: the cheap test on the host although the device ran it
     const bool device_dirty = device_rows && raw.dirty_known && layout_empty && !host_overlap;
-#pragma omp parallel for schedule(static) num_threads(threads)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
     for (long c = 0; c < nc; c++) {
         Mum& m = cand[(size_t)c];
         m.start = srow + (size_t)c * n; m.fwd = frow + (size_t)c * n;
@@ -552,7 +552,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // are rearranged enough for it to flag too many, the exact test with scratch bitmaps decides instead.
     const int nstripes = threads;
     if (!device_dirty) {
-#pragma omp parallel for schedule(static, 1) num_threads(threads)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
         for (int t = 0; t < nstripes; t++) {
             const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
             std::vector<long> maxend_l(j1 - j0 + 16, -1), minstart_l(j1 - j0 + 16, (long)1 << 62);   // per stripe: no cache line shared with a neighbour
@@ -581,7 +581,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         for (size_t c = 0; c < ncand; c++) state[c] &= (uint8_t)~8;
         std::vector<Bitmap>& scratch = memory_->scratch;
         scratch.resize(n);
-#pragma omp parallel for schedule(static, 1) num_threads(threads)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
         for (int t = 0; t < nstripes; t++) {
             const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
             for (size_t j = j0; j < j1; j++) scratch[j].init_zero_lazy((size_t)gsize_[j] + 1);
@@ -596,7 +596,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     }
     lap("overlap");
     // clean candidates: settle in parallel (no trimming possible), then mark genome by genome
-#pragma omp parallel for schedule(static) num_threads(threads)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
     for (long c = 0; c < nc; c++) {
         const uint8_t st = state[(size_t)c];
         if ((st & 3) != 3 || (st & 8)) continue;
@@ -605,7 +605,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     lap("settle");
     // (the same pass notes whether the accepted clean candidates of a genome come one after the other: anchors_ordered_)
     int disorder = 0;
-#pragma omp parallel for schedule(static, 1) num_threads(threads) reduction(| : disorder)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(| : disorder)
     for (int t = 0; t < nstripes; t++) {
         const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
         std::vector<long> last_l(j1 - j0 + 16, 0);      // end of the previous accepted candidate, per genome of the stripe
@@ -641,7 +641,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     static const size_t free_min = getenv("PARSNP_FREE_MIN") ? (size_t)atol(getenv("PARSNP_FREE_MIN")) : 32;   // test hook
     if (nord >= free_min && !no_free) {
         std::fill(tangled.begin(), tangled.end(), 0);
-#pragma omp parallel for schedule(static, 1) num_threads(threads)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
         for (int t = 0; t < nstripes; t++) {
             const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
             std::vector<std::pair<long, uint32_t>> iv(nord);
@@ -775,11 +775,13 @@ bool Aligner::find_anchors() {
     const int nthreads = prm.cores > 0 ? prm.cores : 1;
     const long q = prm.q;
     while ((int)memory_->per_thread.size() < nthreads) memory_->per_thread.emplace_back(new AlignerMemory::PerThread);
-    std::vector<double> t_begin((size_t)nthreads, 0), t_end((size_t)nthreads, 0);     // PARSNP_DEBUG_TIMERS: when each thread ran its share
-#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
-    for (int t = 0; t < nthreads; t++) {
-        struct Span { double* b; double* e; Span(double* b_, double* e_) : b(b_), e(e_) { *b = now_s(); } ~Span() { *e = now_s(); } } span(&t_begin[(size_t)t], &t_end[(size_t)t]);
-        const long i0 = nf * t / nthreads, i1 = nf * (t + 1) / nthreads;
+    // runs of 1024 anchors handed out dynamically: with more threads than the container's CPU quota some thread regularly
+    // starts milliseconds late, and a fixed share per thread makes everybody wait for it
+    const long kRun = 1024;
+    const int nruns = (int)((nf + kRun - 1) / kRun);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int t = 0; t < nruns; t++) {
+        const long i0 = (long)t * kRun, i1 = std::min(nf, i0 + kRun);
         std::vector<long> buf(9 * n);
         auto scratch = [&](int k) { Region r; r.start = &buf[(size_t)k * 3 * n]; r.end = r.start + n; r.length = r.end + n; return r; };
         Region lS = scratch(0), rS[2] = {scratch(1), scratch(2)};
@@ -787,7 +789,7 @@ bool Aligner::find_anchors() {
             if (s.slength <= q) return;
             // rows from this thread's own arena: 8 000 kept regions through ONE arena behind a critical section cost 3 ms of
             // lock hand-overs between 48 threads (measured), the copies themselves nothing
-            AlignerMemory::PerThread& tl = *memory_->per_thread[(size_t)t];
+            AlignerMemory::PerThread& tl = *memory_->per_thread[(size_t)omp_get_thread_num()];
             Region r;
             r.start = tl.rows.alloc(n); r.end = tl.rows.alloc(n); r.length = tl.rows.alloc(n);
             memcpy(r.start, s.start, n * sizeof(long)); memcpy(r.end, s.end, n * sizeof(long)); memcpy(r.length, s.length, n * sizeof(long));
@@ -881,12 +883,7 @@ bool Aligner::find_anchors() {
         }
     }
     stats.t_neighbour += now_s() - tn;
-    if (getenv("PARSNP_DEBUG_TIMERS")) {
-        double first = 1e300, last_start = 0, longest = 0;
-        for (int t = 0; t < nthreads; t++) { first = std::min(first, t_begin[(size_t)t]); last_start = std::max(last_start, t_begin[(size_t)t]); longest = std::max(longest, t_end[(size_t)t] - t_begin[(size_t)t]); }
-        fprintf(stderr, "[anchors] seed regions %s %.4f s (first thread started after %.4f s, the last after %.4f s; longest share %.4f s)\n",
-                anchors_ordered_ ? "from rows" : "by bitmap walks", now_s() - tn, first - tn, last_start - tn, longest);
-    }
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[anchors] seed regions %s %.4f s\n", anchors_ordered_ ? "from rows" : "by bitmap walks", now_s() - tn);
     for (size_t i = 0; i < found.size(); i++) {
         const Region& lR = lRs[i];
         if (lR.start && (i == 0 || !rRs[i - 1].start || !lR.same_as(rRs[i - 1], n))) regions.push_back(lR);
@@ -1154,7 +1151,7 @@ bool Aligner::extend_generations() {
     auto plain_requests = [&](const std::vector<Region>& rs, const std::vector<int>* skip, std::vector<Request>* out) {
         const long m = (long)rs.size();
         std::vector<uint8_t> ok((size_t)m, 1);
-#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 256)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 256)
         for (long i = 0; i < m; i++) if (!skip || (*skip)[(size_t)i] < 0) ok[(size_t)i] = plain_shape(rs[(size_t)i]) ? 1 : 0;
         out->assign((size_t)m, Request{nullptr, nullptr, 0, 0, 0});
         for (long i = 0; i < m; i++) {
@@ -1355,7 +1352,7 @@ void Aligner::filter_mums(int rvalue) {
     {
         std::vector<Handle> h(mums.size());
         const long nh = (long)mums.size();        // one cache miss per MUM (its row): spread over the threads
-#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
         for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{pool[(size_t)mums[(size_t)i]].start[0], mums[(size_t)i]};
         // the list is the anchors followed by the MUMs of the recursion, each in reference order: two increasing runs.
         // With all keys different there is one sorted order and a merge finds it; with equal keys the order std::sort
@@ -1455,7 +1452,7 @@ void Aligner::start_prejudge() {
     const int team = std::max(2, prm.cores / 3);
     prejudge_ = std::async(std::launch::async, [this, team] {
         const long m = (long)mums.size();
-#pragma omp parallel for schedule(static) num_threads(team)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(team)
         for (long x = 1; x < m; x++) {
             const int cur = mums[(size_t)x], prev = mums[(size_t)x - 1];
             judged_verdict_[(size_t)cur] = judge_pair(pool[(size_t)cur], pool[(size_t)prev]);
@@ -1473,7 +1470,7 @@ void Aligner::chain() {
     {
         std::vector<Handle> h(mums.size());
         const long nh = (long)mums.size();        // one cache miss per MUM (its row): spread over the threads
-#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
         for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{pool[(size_t)mums[(size_t)i]].start[0], mums[(size_t)i]};
         // strictly increasing keys (the list as filter_mums left it) have one sorted order: nothing to do.  With ties
         // the order std::sort leaves is the reference's, so it runs.
@@ -1496,7 +1493,7 @@ void Aligner::chain() {
     if (judged_pred_.size() < pool.size()) { judged_pred_.resize(pool.size(), -1); judged_verdict_.resize(pool.size(), CLOSE); }   // earlier verdicts (start_prejudge, the first pass) stay
     std::vector<long> lens((size_t)m);          // gathered here: the sequential pass below would miss the cache once per MUM
     lens[0] = pool[(size_t)mums[0]].length;
-#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 4096)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 4096)
     for (long x = 1; x < m; x++) {
         const int cur = mums[(size_t)x], prev = mums[(size_t)x - 1];
         lens[(size_t)x] = pool[(size_t)cur].length;
