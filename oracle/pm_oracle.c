@@ -101,6 +101,7 @@ int32_t* pm_result_start(pm_result* r) { (void)r; return 0; }
 uint8_t* pm_result_strand(pm_result* r) { (void)r; return 0; }
 const uint32_t* pm_result_flags(const pm_result* r) { (void)r; return 0; }
 int pm_result_dirty_known(const pm_result* r) { (void)r; return 0; }
+int64_t pm_result_wait_rows(pm_result* r, int64_t upto) { (void)upto; return r ? pm_result_total(r) : 0; }
 /* the device gap aligner belongs to the HIP library; this checker declines every job, so the host aligner runs */
 int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
                        const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols) {

@@ -13,6 +13,7 @@ struct pm_session {
     std::unique_ptr<PmBackend> backend;
     std::unique_ptr<pm::Engine<PmBackend>> engine;
     std::vector<pm::PhaseTime> timing;
+    float call_wall_ms = 0;
 };
 struct pm_result { pm::BatchResult r; };
 
@@ -99,10 +100,8 @@ int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, 
         int rc = s->engine->run(n_regions, starts, lens, minsize, &r->r);
         if (rc) return fail(rc, s->engine->error);
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
-        s->timing = s->engine->timing;
         // wall clock of the whole call on the host (uploads, launches, waits, result assembly) next to the device phases
-        s->timing.push_back(pm::PhaseTime{"call_wall", std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count()});
-        if (s->engine->budget_retries) s->timing.push_back(pm::PhaseTime{"budget_retries", (float)s->engine->budget_retries});   // a count, not a time
+        s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
         *out = r.release();
         return PM_OK;
     } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
@@ -121,6 +120,7 @@ int32_t* pm_result_start(pm_result* r) { return r->r.start(); }
 uint8_t* pm_result_strand(pm_result* r) { return r->r.strand(); }
 const uint32_t* pm_result_flags(const pm_result* r) { return r->r.flags(); }
 int pm_result_dirty_known(const pm_result* r) { return r->r.dirty_known ? 1 : 0; }
+int64_t pm_result_wait_rows(pm_result* r, int64_t upto) { return r ? r->r.wait_rows(upto) : 0; }
 
 int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int strand,
                    int64_t cap, int64_t* count, int64_t* ev_j, int64_t* ev_l, int32_t* ev_len, int32_t* ev_rep) {
@@ -166,8 +166,13 @@ int pm_mumi_coverage(pm_session* s, const int64_t* starts, const int64_t* lens, 
     } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
 }
 
-int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) {
-    if (!s || !count) return PM_EINVAL;
+int pm_last_timing(const pm_session* cs, int* count, const char** names, float* ms) {
+    if (!cs || !count) return PM_EINVAL;
+    pm_session* s = const_cast<pm_session*>(cs);
+    s->engine->finish_pending();        // the phase times of a call whose rows were still arriving exist only now
+    s->timing = s->engine->timing;
+    if (s->call_wall_ms > 0) s->timing.push_back(pm::PhaseTime{"call_wall", s->call_wall_ms});
+    if (s->engine->budget_retries) s->timing.push_back(pm::PhaseTime{"budget_retries", (float)s->engine->budget_retries});   // a count, not a time
     int capn = *count, n = 0;
     for (const auto& t : s->timing) { if (n < capn) { names[n] = t.name; ms[n] = t.ms; } n++; }
     *count = n < capn ? n : capn;

@@ -3,6 +3,7 @@
 // tests/emu/ instantiates it with a sequential host backend to check the logic without a GPU (tests only).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -47,6 +48,24 @@ struct BatchResult {
     // a session in MUM-row mode (pm_session_rows) fills these instead of sp / fwd:
     HostPool::Block startb, strandb, flagsb; // int32 start[total*(nq+1)], uint8 strand[total*(nq+1)], uint32 flags[total]
     bool rows = false, dirty_known = false;  // dirty_known: the kRowDirty bits were computed (one-region batch with a long list)
+    // A long row table (the anchor call) is still arriving when the call returns: its copy is cut into slices, each followed
+    // by an event, and the caller waits slice by slice (pm_result_wait_rows) while it already works on what is there.
+    struct InFlight {
+        std::vector<int64_t> upto;                 // candidates [0, upto[s]) have arrived once events[s] has
+        std::vector<void*> events;
+        void (*wait_event)(void*) = nullptr;
+        std::atomic<bool> finished{false};         // set by the engine once the stream has drained (events are recycled then)
+    };
+    std::shared_ptr<InFlight> inflight;
+    int64_t wait_rows(int64_t want) {              // -> number of candidates whose rows are there (>= want; want < 0: all)
+        if (!inflight || inflight->finished.load(std::memory_order_acquire)) return total;
+        if (want < 0 || want > total) want = total;
+        for (size_t s = 0; s < inflight->upto.size(); s++) {
+            inflight->wait_event(inflight->events[s]);
+            if (inflight->upto[s] >= want) return inflight->upto[s];
+        }
+        return total;
+    }
     std::shared_ptr<HostPool> pool;
     int32_t* start() const { return (int32_t*)startb.p; }
     uint8_t* strand() const { return (uint8_t*)strandb.p; }
@@ -160,6 +179,7 @@ public:
     // verdict is common to all ranks (it travels with the first exchange), so every rank repeats the batch together.
     int run(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events = false,
             bool mumi = false) {
+        finish_pending();
         budget_exceeded = false;
         int rc = run_once(nreg, starts, lens, minsize, out, want_events, mumi);
         if (rc == -5 && budget_exceeded && work_budget < ((int64_t)1 << 40)) {
@@ -490,6 +510,8 @@ public:
         std::vector<int32_t> reg_h(nokz);
         out->kb = pool->take(4 * nokz); out->lonb = pool->take(4 * nokz);
         out->rows = want_rows; out->dirty_known = false;
+        bool sliced = false;
+        static const bool no_slices = getenv("PM_NO_ROW_SLICES") != nullptr;       // measurement / test hook: wait for the whole table
         if (!want_rows) {
             ensure(d_csp, std::max<size_t>(nokz * nqz2, 1)); ensure(d_cfwd, std::max<size_t>(nokz * nqz2, 1));
             be.launch("compact_sp", (int64_t)ncand * nq,
@@ -517,21 +539,59 @@ public:
             }
             be.mark("download");
             out->startb = pool->take(4 * nokz * ngz); out->strandb = pool->take(nokz * ngz); out->flagsb = pool->take(4 * nokz);
-            be.d2h_async(out->startb.p, d_csp.p, 4 * nokz * ngz);
-            be.d2h_async(out->strandb.p, d_cfwd.p, nokz * ngz);
             be.d2h_async(out->flagsb.p, d_cflags.p, 4 * nokz);
+            sliced = nreg == 1 && nok >= slice_min && !no_slices;
+            if (!sliced) {
+                be.d2h_async(out->startb.p, d_csp.p, 4 * nokz * ngz);
+                be.d2h_async(out->strandb.p, d_cfwd.p, nokz * ngz);
+            }
         }
         be.d2h_async(reg_h.data(), d_creg.p, 4 * nokz);
         be.d2h_async(out->kb.p, d_ck.p, 4 * nokz);
         be.d2h_async(out->lonb.p, d_clon.p, 4 * nokz);
-        be.mark(nullptr);
-        be.sync();                                                             // round trip 4: the results
+        if (sliced) {
+            // the per-candidate arrays first (the caller's first pass needs only those), then the rows in slices
+            void* small = be.event_record();
+            auto fl = std::make_shared<BatchResult::InFlight>();
+            fl->wait_event = &B::event_wait;
+            constexpr int kSlicesOut = 6;
+            for (int x = 0; x < kSlicesOut; x++) {
+                const size_t c0 = nokz * (size_t)x / kSlicesOut, c1 = nokz * (size_t)(x + 1) / kSlicesOut;
+                if (c1 == c0) continue;
+                be.d2h_async((int32_t*)out->startb.p + c0 * ngz, d_csp.p + c0 * ngz, 4 * (c1 - c0) * ngz);
+                be.d2h_async((uint8_t*)out->strandb.p + c0 * ngz, d_cfwd.p + c0 * ngz, (c1 - c0) * ngz);
+                fl->events.push_back(be.event_record());
+                fl->upto.push_back((int64_t)c1);
+            }
+            be.mark(nullptr);
+            B::event_wait(small);
+            be.event_release(small);
+            out->inflight = fl;
+            pending = fl;
+        } else {
+            be.mark(nullptr);
+            be.sync();                                                         // round trip 4: the results
+        }
         for (size_t w = 0; w < nokz; w++) out->off[(size_t)reg_h[w] + 1]++;
         for (int64_t r = 0; r < nreg; r++) out->off[(size_t)r + 1] += out->off[(size_t)r];
         out->total = out->off[(size_t)nreg];
-        collect_timing();
+        if (!sliced) collect_timing();
         return 0;
     }
+
+    // the row table of the last call may still be on its way (BatchResult::InFlight): drain the stream, hand the events
+    // back, read the phase times.  Called before the next batch, by pm_last_timing and on release.
+    void finish_pending() {
+        if (!pending) return;
+        be.sync();
+        pending->finished.store(true, std::memory_order_release);
+        for (void* e : pending->events) be.event_release(e);
+        pending->events.clear();
+        pending.reset();
+        collect_timing();
+    }
+    std::shared_ptr<BatchResult::InFlight> pending;
+    int64_t slice_min = getenv("PM_SLICE_MIN") ? atol(getenv("PM_SLICE_MIN")) : 8192;     // shortest row table delivered in slices (PM_SLICE_MIN: test hook)
 
     // small host-side all-gather (calcmumi's per-genome results): through device staging when the collectives are RCCL
     int allgather_host(const void* send, int64_t bytes, void* recv) {
@@ -552,6 +612,7 @@ public:
     int64_t dirty_min = getenv("PM_DIRTY_MIN") ? atol(getenv("PM_DIRTY_MIN")) : 4096;
 
     void release() {
+        finish_pending();
         for (BufBase* b : all_bufs) { if (b->raw) be.free(b->raw); b->raw = nullptr; b->cap = 0; }
         if (blk) be.free(blk);
         if (d_goff) be.free(d_goff);

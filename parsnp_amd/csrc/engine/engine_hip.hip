@@ -129,6 +129,16 @@ struct HipBackend {
     void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); check(hipStreamSynchronize(stream), "sync"); }
     void d2h_async(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); }
     void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+    // an event on the engine's stream that any host thread may wait for (the slices of a row table in flight)
+    void* event_record() {
+        hipEvent_t e = nullptr;
+        if (!pool.empty()) { e = pool.back(); pool.pop_back(); }
+        else if (!check(hipEventCreate(&e), "hipEventCreate")) return nullptr;
+        check(hipEventRecord(e, stream), "hipEventRecord");
+        return (void*)e;
+    }
+    static void event_wait(void* e) { if (e) (void)hipEventSynchronize((hipEvent_t)e); }
+    void event_release(void* e) { if (e) pool.push_back((hipEvent_t)e); }
     // page-locked block for the request rows of a call (kept, grown on demand); h2d_staged queues the DMA without waiting:
     // the block is not written again before the call's last synchronisation
     void* stage_p = nullptr; size_t stage_cap = 0;

@@ -294,10 +294,24 @@ void Aligner::chunk_requests(const Region& r, int minsize, std::vector<Request>*
     }
 }
 
+void Aligner::collect_engine_timing() {
+    timing_deferred_ = false;
+    int cnt = 64; const char* names[64]; float ms[64];
+    if (pm_last_timing(session_, &cnt, names, ms) != PM_OK) return;
+    if (timing_first_call_) stats.anchor_ms.clear();
+    for (int i = 0; i < cnt; i++) {
+        if (timing_first_call_) stats.anchor_ms.emplace_back(names[i], ms[i]);
+        bool merged = false;
+        for (auto& kv : stats.engine_ms) if (kv.first == names[i]) { kv.second += ms[i]; merged = true; }
+        if (!merged) stats.engine_ms.emplace_back(names[i], ms[i]);
+    }
+}
+
 void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out, bool rows) {
     out->clear();
     out->resize(reqs.size());
     if (reqs.empty()) return;
+    flush_engine_timing();
     double t0 = now_s();
     // results as MUM rows built on the device where the provider can (the HIP engine) and every request is its region
     static const bool no_rows = getenv("PARSNP_NO_DEVICE_ROWS") != nullptr;      // test hook: the host builds the rows from sp / fwd
@@ -347,24 +361,19 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
         Raw& r = (*out)[i];
         size_t a = (size_t)off[i], b = (size_t)off[i + 1];
         r.k = k + a; r.lon = lon + a;
-        if (rows) { r.start = rstart + a * n; r.strand = rstrand + a * n; r.flags = rflags + a; r.dirty_known = dirty_known; }
+        if (rows) { r.start = rstart + a * n; r.strand = rstrand + a * n; r.flags = rflags + a; r.dirty_known = dirty_known; r.row0 = a; }
         else { r.sp = sp + a * q; r.fwd = fw + a * q; }
         r.count = b - a;
         r.owner = own;
     }
     stats.t_unpack += now_s() - tu;
-    {
-        int cnt = 64; const char* names[64]; float ms[64];
-        if (pm_last_timing(session_, &cnt, names, ms) == PM_OK) {
-            if (stats.finder_calls == 0) stats.anchor_ms.clear();
-            for (int i = 0; i < cnt; i++) {
-                if (stats.finder_calls == 0) stats.anchor_ms.emplace_back(names[i], ms[i]);
-                bool merged = false;
-                for (auto& kv : stats.engine_ms) if (kv.first == names[i]) { kv.second += ms[i]; merged = true; }
-                if (!merged) stats.engine_ms.emplace_back(names[i], ms[i]);
-            }
-        }
-    }
+    // the device phase times: now, unless the rows of this result are still arriving (asking would wait for them) -- then
+    // before the next engine call or when the step's statistics are read
+    timing_first_call_ = stats.finder_calls == 0;
+    if (rows && pm_result_wait_rows(res, 0) < pm_result_total(res)) {
+        timing_deferred_ = true;
+        for (Raw& r : *out) r.in_flight = true;
+    } else collect_engine_timing();
     stats.finder_calls++;
     stats.finder_regions += (long)reqs.size();
     stats.finder_s += now_s() - t0;
@@ -485,6 +494,7 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
     const int threads = prm.cores > 1 ? prm.cores : 1;
     static const size_t par_min = getenv("PARSNP_PARALLEL_MIN") ? (size_t)atol(getenv("PARSNP_PARALLEL_MIN")) : 4096;   // test hook
     if (ncand >= par_min && threads > 1 && !layout[0].logging()) { validate_parallel(r, q, raw, accepted, threads); return; }
+    if (raw.in_flight) pm_result_wait_rows(raw.owner.get(), -1);      // the serial loop below reads any row
     const double tser = now_s();
     struct Rep { double t0; size_t n; ~Rep() { if (n > 1000 && getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[validate serial] %zu candidates %.4f s\n", n, now_s() - t0); } } rep_{tser, ncand};
     for (size_t c = 0; c < ncand; c++) {
@@ -520,6 +530,13 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // rows: built on the device where the engine delivers them (the candidates' rows ARE the result blocks then: nothing
     // is copied, trim() works on them in place and the result is kept alive), else from (sp, fwd) here
     const bool device_rows = raw.start != nullptr;
+    // rows still arriving from the device: a pass over the candidates asks for them as it gets there (pm_result_wait_rows
+    // answers with how far the table has come, so a thread asks once per slice)
+    auto rows_until = [&](size_t c_end) -> size_t {
+        if (!raw.in_flight) return ncand;
+        const int64_t got = pm_result_wait_rows(raw.owner.get(), (int64_t)(raw.row0 + c_end));
+        return got <= (int64_t)raw.row0 ? 0 : std::min(ncand, (size_t)got - raw.row0);
+    };
     int32_t* srow = device_rows ? raw.start : irows_.alloc(ncand * n);
     uint8_t* frow = device_rows ? raw.strand : brows_.alloc(ncand * n);
     if (device_rows) kept_results_.push_back(raw.owner);
@@ -551,6 +568,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // treating a clean candidate as dirty is harmless (it takes the ordered path and sees the same marks); where genomes
     // are rearranged enough for it to flag too many, the exact test with scratch bitmaps decides instead.
     const int nstripes = threads;
+    if (!device_dirty) (void)rows_until(ncand);      // the host's own overlap test walks every row
     if (!device_dirty) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
         for (int t = 0; t < nstripes; t++) {
@@ -596,11 +614,18 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     }
     lap("overlap");
     // clean candidates: settle in parallel (no trimming possible), then mark genome by genome
-#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
-    for (long c = 0; c < nc; c++) {
-        const uint8_t st = state[(size_t)c];
-        if ((st & 3) != 3 || (st & 8)) continue;
-        if (settle(cand[(size_t)c], false, (st & 4) != 0)) state[(size_t)c] |= 16;
+    {
+        const long kRun = 1024, nruns = (nc + kRun - 1) / kRun;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+        for (long rr = 0; rr < nruns; rr++) {
+            const long c0 = rr * kRun, c1 = std::min(nc, c0 + kRun);
+            (void)rows_until((size_t)c1);
+            for (long c = c0; c < c1; c++) {
+                const uint8_t st = state[(size_t)c];
+                if ((st & 3) != 3 || (st & 8)) continue;
+                if (settle(cand[(size_t)c], false, (st & 4) != 0)) state[(size_t)c] |= 16;
+            }
+        }
     }
     lap("settle");
     // (the same pass notes whether the accepted clean candidates of a genome come one after the other: anchors_ordered_)
@@ -611,7 +636,9 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         std::vector<long> last_l(j1 - j0 + 16, 0);      // end of the previous accepted candidate, per genome of the stripe
         long* last = last_l.data() + 8 - j0;
         long bad = 0;
+        size_t have = 0;
         for (size_t c = 0; c < ncand; c++) {
+            if (c >= have) have = rows_until(c + 1);
             __builtin_prefetch(srow + (c + 24) * n + j0); __builtin_prefetch(srow + (c + 24) * n + j1 - 1);
             if ((state[c] & 24) == 16)
                 { const int32_t* st = cand[c].start; const long lon = cand[c].length;     // accepted: inside the genome, length >= 5
@@ -625,6 +652,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         disorder |= bad < 0 ? 1 : 0;
     }
     lap("mark");
+    (void)rows_until(ncand);      // everything below reads any row
     // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them
     pool.reserve(pool.size() + ncand);
     accepted->reserve(accepted->size() + ncand);
@@ -1091,7 +1119,7 @@ bool Aligner::disjoint_clusters(const std::vector<Region>& w, std::vector<size_t
             }
             iv[(size_t)c] = std::make_pair(lo, hi);
         }
-        std::sort(iv.begin(), iv.end());
+        if (!std::is_sorted(iv.begin(), iv.end())) std::sort(iv.begin(), iv.end());      // a collinear genome holds them in reference order already
         for (long c = 0; c + 1 < nc; c++)
             if (iv[(size_t)c + 1].first <= iv[(size_t)c].second + 1) { bad = 1; break; }   // touching counts too
     }

@@ -207,6 +207,8 @@ struct Raw {
     // MUM-row mode of the engine (pm_session_rows): rows of n entries per candidate built on the device, and their flags
     int32_t* start = nullptr; uint8_t* strand = nullptr; const uint32_t* flags = nullptr;
     bool dirty_known = false;
+    bool in_flight = false;      // the rows may still be arriving: pm_result_wait_rows(owner, candidates needed) before reading them
+    size_t row0 = 0;             // this list's first candidate in the result (pm_result_wait_rows counts from the result's start)
     size_t count = 0;
     std::shared_ptr<pm_result> owner;
 };
@@ -273,6 +275,7 @@ public:
     Region new_region();
 
     void wait_layout();           // the layout bitmaps are set up in the background (constructor); find_anchors() awaits them
+    void flush_engine_timing() { if (timing_deferred_) collect_engine_timing(); }   // before `stats` is read
     enum : uint8_t { kJoin = 0, kClose = 1, kPass = 2 };
     uint8_t judge_pair(const Mum& nt, const Mum& back) const;     // chain()'s test of a MUM against the open chain's last MUM
     void start_prejudge();        // the anchors' consecutive pairs, judged beside the recursion's first engine call
@@ -299,6 +302,9 @@ private:
     void chunk_requests(const Region& r, int minsize, std::vector<Request>* out);   // the p-chunk loop, :1519-1547
     void run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out, bool rows = false);   // rows: every request is its region (plain)
     bool rows_mode_ = false, rows_supported_ = true;
+    bool timing_first_call_ = false;
+    bool timing_deferred_ = false;     // the phase times of the last engine call are read later (its rows were still arriving)
+    void collect_engine_timing();
     std::vector<std::shared_ptr<pm_result>> kept_results_;   // results whose row blocks hold the rows of accepted MUMs
     // cache of raw results keyed by request coordinates (results are a pure function of them); entries own a copy of
     // the coordinates and are compared in full on a hash hit

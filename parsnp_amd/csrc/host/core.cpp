@@ -198,6 +198,7 @@ StepReport CoreRun::step() {
         printf("        LCBs created, elapsed time: %.0lf seconds\n\n", difftime(end, start));
     }
     r.path_s = now_s() - t0;
+    a.flush_engine_timing();
     const Stats& s = a.stats;
     r.anchor_s = s.anchor_s; r.extend_s = s.extend_s; r.filter_s = s.filter_s; r.lcb_s = s.lcb_s; r.finder_s = s.finder_s;
     r.alg_bytes = s.alg_bytes; r.finder_calls = s.finder_calls; r.finder_regions = s.finder_regions; r.regions_processed = s.regions_processed;

@@ -20,6 +20,9 @@ struct HostBackend {
     void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void d2h_async(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void sync() {}
+    void* event_record() { return nullptr; }
+    static void event_wait(void*) {}
+    void event_release(void*) {}
     void fill32(int32_t* p, int32_t v) { *p = v; }
     int allreduce_min_i32_dev(int32_t*, int64_t) { return 1; }      // no device collectives in the emulation
     int allgather_dev(const void*, int64_t, void*) { return 1; }

@@ -220,7 +220,7 @@ def test_parsnp_core_replay_modes_threaded(libs, tmp_path, name, mode):
 
 
 @pytest.mark.parametrize("name", ["rearr6x300k", "poprearr10x400k", "pop20x1m"])
-@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows"])
+@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows", "rows_in_one_piece"])
 def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant):
     """the MUM rows and the cheap overlap flags come from the device (CompactCandidates, DirtyExtent/Prefix/Mark) and feed
     the threaded anchor validation in place; switching either back to the host must not change a byte"""
@@ -229,11 +229,13 @@ def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant
     else:
         r, gs = synth.make(name)
         rp, qs = synth.write_set(str(tmp_path / "in"), r, gs); kw = {}
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_PREJUDGE_MIN="8")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_PREJUDGE_MIN="8", PM_SLICE_MIN="8")
     if variant == "host_overlap":
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":
         env["PARSNP_NO_DEVICE_ROWS"] = "1"
+    if variant == "rows_in_one_piece":      # the other variants receive the row table in slices while they work (PM_SLICE_MIN)
+        env["PM_NO_ROW_SLICES"] = "1"
     out = str(tmp_path / "out")
     rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=8, **kw)
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
