@@ -119,8 +119,9 @@ int32_t* pm_result_start(pm_result* r);
 uint8_t* pm_result_strand(pm_result* r);
 const uint32_t* pm_result_flags(const pm_result* r);
 int pm_result_dirty_known(const pm_result* r);
-/* The row table of a long one-region result (the anchor call: 60 MB at 200 x 5 Mb) is still arriving when
- * pm_multi_mum_batch returns: k, lon and flags are complete, start / strand come in slices of candidates.  Before reading
+/* With PM_ROW_SLICES=1 in the environment the row table of a long one-region result (the anchor call: 60 MB at 200 x 5 Mb)
+ * is still arriving when pm_multi_mum_batch returns: k, lon and flags are complete, start / strand come in slices of
+ * candidates (overlap needs page-locked result blocks, PARSNP_PINNED=1; off by default: see engine_core.h for the numbers).  Before reading
  * the rows of candidates [0, upto) call pm_result_wait_rows(r, upto); it returns how many candidates' rows are there
  * (>= upto; upto < 0: all of them).  Callable from several threads; immediate for results that are complete. */
 int64_t pm_result_wait_rows(pm_result* r, int64_t upto);

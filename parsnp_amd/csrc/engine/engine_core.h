@@ -511,7 +511,11 @@ public:
         out->kb = pool->take(4 * nokz); out->lonb = pool->take(4 * nokz);
         out->rows = want_rows; out->dirty_known = false;
         bool sliced = false;
-        static const bool no_slices = getenv("PM_NO_ROW_SLICES") != nullptr;       // measurement / test hook: wait for the whole table
+        // Off by default -- measured on 200 x 5 Mb: into ordinary host memory the copies block the caller anyway (no overlap,
+        // 29.9 ms per step against 29.2 in one piece); into page-locked blocks (PARSNP_PINNED=1) the call does return 1.0 ms
+        // earlier, but the host's passes over page-locked rows are slower by more than that (29.6 against 30.3 in one piece,
+        // both behind the 29.2 of ordinary memory).  PM_ROW_SLICES=1 turns it on.
+        static const bool no_slices = getenv("PM_ROW_SLICES") == nullptr || atoi(getenv("PM_ROW_SLICES")) == 0;
         if (!want_rows) {
             ensure(d_csp, std::max<size_t>(nokz * nqz2, 1)); ensure(d_cfwd, std::max<size_t>(nokz * nqz2, 1));
             be.launch("compact_sp", (int64_t)ncand * nq,

@@ -122,7 +122,7 @@ def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
     the overlap test / the row construction back to the host: same bytes either way."""
     r, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PM_SLICE_MIN="8")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PM_SLICE_MIN="8", PM_ROW_SLICES="1")
     if variant == "host_overlap":
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":

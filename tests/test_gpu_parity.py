@@ -229,13 +229,13 @@ def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant
     else:
         r, gs = synth.make(name)
         rp, qs = synth.write_set(str(tmp_path / "in"), r, gs); kw = {}
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_PREJUDGE_MIN="8", PM_SLICE_MIN="8")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_PREJUDGE_MIN="8", PM_SLICE_MIN="8", PM_ROW_SLICES="1")
     if variant == "host_overlap":
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":
         env["PARSNP_NO_DEVICE_ROWS"] = "1"
-    if variant == "rows_in_one_piece":      # the other variants receive the row table in slices while they work (PM_SLICE_MIN)
-        env["PM_NO_ROW_SLICES"] = "1"
+    if variant == "rows_in_one_piece":      # the other variants receive the row table in slices while they work (PM_ROW_SLICES, PM_SLICE_MIN)
+        env["PM_ROW_SLICES"] = "0"
     out = str(tmp_path / "out")
     rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=8, **kw)
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
