@@ -653,9 +653,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     }
     lap("mark");
     (void)rows_until(ncand);      // everything below reads any row
-    // the rest, sequentially in candidate order; ids and pool order as the sequential loop assigns them
-    pool.reserve(pool.size() + ncand);
-    accepted->reserve(accepted->size() + ncand);
+    // the rest: ids and pool order as the sequential loop assigns them
     std::vector<uint32_t> ordered;        // the flagged candidates, in candidate order
     for (size_t c = 0; c < ncand; c++) if ((state[c] & 11) == 11) ordered.push_back((uint32_t)c);
     // Two flagged candidates whose ranges meet in no genome read and write different bits: they commute.  A flagged
@@ -711,33 +709,63 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         for (size_t j = 0; j < n; j++) { layout[j].prefetch(w.start[j]); layout[j].prefetch(w.end(j) - 1); }
     };
     warm(0); warm(1);
-    size_t onext = 0, oi = 0;
-    for (size_t c = 0; c < ncand; c++) {
-        const uint8_t st = state[c];
-        if (!(st & 1)) continue;
-        Mum& m = cand[c];
-        m.id = next_id_++;
-        bool acc = (st & 16) != 0;
-        if ((st & 2) && (st & 8)) {
-            const size_t o = oi++;                 // position in `ordered`
-            if (!tangled[o]) acc = settled[o] != 0;
-            else {
-                warm(++onext + 1);
-                bool touches = false;
-                if (m.length > 0)
-                    for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end(j) - 1);
-                acc = settle(m, touches, (st & 4) != 0);
-                if (acc) for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end(j));
-                stats.parallel_tangled++;
-            }
+    // (1) the tangled ones, in candidate order: the only part in which the order shows (everything else is marked already)
+    {
+        size_t onext = 0;
+        for (size_t o = 0; o < nord; o++) {
+            if (!tangled[o]) continue;
+            const size_t c = ordered[o];
+            Mum& m = cand[c];
+            warm(++onext + 1);
+            bool touches = false;
+            if (m.length > 0)
+                for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end(j) - 1);
+            const bool acc = settle(m, touches, (state[c] & 4) != 0);
+            if (acc) for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end(j));
+            settled[o] = acc ? 1 : 0;
+            stats.parallel_tangled++;
         }
-        if (!acc) continue;
-        m.slength = r.slength;
-        m.dirty = (st & 8) != 0;
-        pool.push_back(m);
-        accepted->push_back((int)pool.size() - 1);
-        stats.parallel_dirty += (st & 8) ? 1 : 0;
     }
+    // (2) ids and pool places as the sequential loop would assign them: every constructed candidate takes the next id, every
+    // accepted one the next place -- one pass over the state bytes -- then (3) the MUM records are written by all threads
+    constexpr uint32_t kNoPlace = 0xffffffffu;
+    std::vector<uint32_t> place(ncand, kNoPlace), idrank(ncand, 0);
+    size_t nacc = 0; long nid = 0, ndirty = 0;
+    {
+        size_t oi = 0;
+        for (size_t c = 0; c < ncand; c++) {
+            const uint8_t st = state[c];
+            if (!(st & 1)) continue;
+            idrank[c] = (uint32_t)nid++;
+            bool acc = (st & 16) != 0;
+            if ((st & 2) && (st & 8)) acc = settled[oi++] != 0;
+            if (!acc) continue;
+            place[c] = (uint32_t)nacc++;
+            ndirty += (st & 8) ? 1 : 0;
+        }
+    }
+    const size_t pool0 = pool.size(), acc0 = accepted->size();
+    const long id0 = next_id_;
+    pool.resize(pool0 + nacc);
+    accepted->resize(acc0 + nacc);
+    {
+        Mum* const pout = pool.data() + pool0;
+        int* const aout = accepted->data() + acc0;
+        const long slen = r.slength;
+#pragma omp parallel for schedule(dynamic, 2048) num_threads(threads)
+        for (long c = 0; c < nc; c++) {
+            const uint32_t at = place[(size_t)c];
+            if (at == kNoPlace) continue;
+            Mum m = cand[(size_t)c];
+            m.id = id0 + (long)idrank[(size_t)c];
+            m.slength = slen;
+            m.dirty = (state[(size_t)c] & 8) != 0;
+            pout[at] = m;
+            aout[at] = (int)(pool0 + at);
+        }
+    }
+    next_id_ += nid;
+    stats.parallel_dirty += ndirty;
     stats.parallel_candidates += (long)ncand;
     // order of the whole accepted list per genome = order of the clean ones (above) + every accepted flagged candidate
     // between its list neighbours (it may have been trimmed: its row holds the final coordinates)
@@ -783,7 +811,12 @@ bool Aligner::find_anchors() {
     std::vector<int> found;
     std::cerr << std::endl << "        Constructing device index of the reference...\n";
     std::cerr << "        Performing initial search for exact matches in the sequences...\n";
+    const bool dbg_a = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    double ta = now_s();
+    auto lap_a = [&](const char* what) { if (dbg_a) { const double t = now_s(); fprintf(stderr, "[anchors] %-18s %.4f s\n", what, t - ta); ta = t; } };
+    lap_a("set-up");
     region_mums(whole, true, &found, false);
+    lap_a("search + validation");
     wait_layout();
     mums = found;
     m0 = (long)found.size();
@@ -911,13 +944,14 @@ bool Aligner::find_anchors() {
         }
     }
     stats.t_neighbour += now_s() - tn;
-    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[anchors] seed regions %s %.4f s\n", anchors_ordered_ ? "from rows" : "by bitmap walks", now_s() - tn);
+    lap_a(anchors_ordered_ ? "seeds from rows" : "seeds by walks");
     for (size_t i = 0; i < found.size(); i++) {
         const Region& lR = lRs[i];
         if (lR.start && (i == 0 || !rRs[i - 1].start || !lR.same_as(rRs[i - 1], n))) regions.push_back(lR);
         const Region& rR = rRs[i];
         if (rR.start && (!lR.start || !rR.same_as(lR, n))) regions.push_back(rR);
     }
+    lap_a("region list");
     stats.anchor_s = now_s() - t0;
     return m0 != 0;
 }

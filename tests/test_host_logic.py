@@ -137,7 +137,7 @@ def test_derived_left_neighbours_equal_the_walk(cpu_checkers, tmp_path, name, ro
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     if route == "rows" and name == "pop6x200k":     # a collinear set: the row route must actually have been taken
-        assert "seed regions from rows" in open(os.path.join(out, "parsnp-aligner.err")).read()
+        assert "seeds from rows" in open(os.path.join(out, "parsnp-aligner.err")).read()
 
 
 @pytest.mark.parametrize("name", ["pop6x200k", "poprearr10x400k"])
