@@ -79,7 +79,6 @@ struct Slot {
     int32_t* ncols;         // [2n]
     int32_t* perm;          // [n] row -> sequence
     float* total;           // [2n] sequential float sum of the weights of a node's rows, in row order
-    uint8_t* rows;          // [n][2][cap]
     uint8_t* table;         // [46656] 6-mer counts of one string (fastdistnuc.cpp:82), all zero between uses
 };
 
@@ -87,7 +86,9 @@ struct Params {
     const Job* jobs; int64_t njobs; const int64_t* seq_off; const uint8_t* chars;
     uint8_t* out_rows; int32_t* out_cols; unsigned long long* next; uint8_t* ws; int64_t ws_stride; int32_t nmax, cap;
     volatile int32_t* dbg;     // PM_GAP_DEBUG: per slot (job, stage) in host memory the host can read while the kernel runs
+    unsigned long long* prof;  // PM_GAP_DEBUG=3: shader clocks per stage, summed over the jobs
 };
+constexpr int kProfStages = 16;
 
 // every lane's outstanding loads / stores (global and LDS) have completed before any lane goes on: the lanes of the one
 // wavefront of a workgroup talk to each other through global workspace and LDS
@@ -105,26 +106,34 @@ __device__ inline void wave_argmin(float& v, unsigned& i) {
     }
 }
 
-// LDS of the one wavefront of a workgroup, used phase after phase
+// LDS of the one wavefront of a workgroup, used phase after phase (the alignment rows themselves -- n rows of `cap`
+// bytes, row p = leaf p in the order of the root alignment -- follow it as dynamic LDS: every profile is a sequential
+// sum over its rows, 20 000 row visits for 201 sequences, and from global memory each visit is a round trip)
 struct __align__(16) Shared {
-    struct { float mind[kMaxSeqs]; unsigned nearest[kMaxSeqs]; unsigned node[kMaxSeqs]; } t;      // tree
+  union {           // the guide tree is finished (and synchronised on) before the first profile is built
+    struct { float mind[kMaxSeqs]; unsigned nearest[kMaxSeqs]; unsigned node[kMaxSeqs]; float height[kMaxSeqs]; } t;      // tree
     struct {
             float fa[4][kMaxCols]; uint8_t orda[kMaxCols]; float opena[kMaxCols], closea[kMaxCols];   // profile A: sorted counts, their letters
             float sb[4][kMaxCols]; float openb[kMaxCols], closeb[kMaxCols];                           // profile B: scores per letter
             float bD[kMaxCols + 2], bM[kMaxCols + 2], bN[kMaxCols + 2]; uint8_t bX[kMaxCols + 2];     // row handed from one 64-row stripe to the next
-            uint8_t tb[(kMaxCols + 1) * (kMaxCols + 1)];
             uint8_t path[2 * kMaxCols + 2];
             int16_t mapa[2 * kMaxCols + 2], mapb[2 * kMaxCols + 2];
         float result[3];
     } p;
+  };
+    uint8_t letter[256];       // alpha.cpp:125-166 (c_letter, copied: a table in constant memory costs a trip to memory per lane)
+    float total_i[kMaxSeqs];   // per internal node: sequential float sum of the weights of its rows, in row order
+    uint8_t ncols_i[kMaxSeqs]; // per internal node: columns of its alignment
+    uint8_t rowlen[kMaxSeqs];  // length of the sequence in row p
     uint16_t codes[kMaxCols];
     float wrow[kMaxSeqs];      // weight of the sequence in row p (rows = leaves in the order of the root alignment)
-    uint8_t cur[kMaxSeqs];     // which of row p's two buffers is current
     int32_t flag;
 };
 
 // ---- profile of the alignment held by rows [lo, lo+ns) (nc columns) -> either the A arrays or the B arrays
-__device__ void build_profile(Shared& S, const Slot& W, int cap, int lo, int ns, int nc, float total, bool as_a) {
+// R: the rows in LDS.  A column's sums run over the rows one after the other (float: the order is part of the result);
+// eight rows are fetched at a time so that the adds do not wait for one LDS access each.
+__device__ void build_profile(Shared& S, const uint8_t* R, int cap, int lo, int ns, int nc, float total, bool as_a) {
     const int lane = (int)__lane_id();
     // msa2.cpp:418-431 + msa.cpp:369-381: this alignment's weights, rescaled to sum 1.  `total` is the sequential float sum
     // of the weights in MSA order, kept per node: a merged alignment's rows are A's then B's, so its sum continues A's.
@@ -134,21 +143,35 @@ __device__ void build_profile(Shared& S, const Slot& W, int cap, int lo, int ns,
         const int c = c0 + lane;
         if (c < nc) {
             float cnt[4] = {0, 0, 0, 0}, start = 0, end = 0;
-            for (int s = 0; s < ns; s++) {
-                const int p = lo + s;
-                float ws = S.wrow[p];
+            const bool first_col = c == 0, last_col = c + 1 == nc;
+            const uint8_t* col = R + (size_t)lo * (size_t)cap + c;
+            auto fold = [&](uint8_t ch, uint8_t before, uint8_t after, float ws) {
                 if (scale) ws *= f;
-                const uint8_t* row = W.rows + ((size_t)p * 2 + S.cur[p]) * (size_t)cap;
-                const uint8_t ch = row[c];
                 if (is_gap(ch)) {
-                    if (c == 0 || !is_gap(row[c - 1])) start += ws;
-                    if (c + 1 == nc || !is_gap(row[c + 1])) end += ws;
-                    continue;
+                    if (first_col || !is_gap(before)) start += ws;
+                    if (last_col || !is_gap(after)) end += ws;
+                    return;
                 }
-                const uint8_t l = c_letter[ch];
+                const uint8_t l = S.letter[ch];
                 if (l < 4) cnt[l] += ws;
                 else if (l == 14) { cnt[2] += ws / 2; cnt[0] += ws / 2; }
                 else { const float q = ws / 20; cnt[0] += q; cnt[1] += q; cnt[2] += q; cnt[3] += q; }
+            };
+            int s0 = 0;
+            for (; s0 + 8 <= ns; s0 += 8) {
+                uint8_t ch[8], pv[8], nx[8]; float w[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint8_t* q = col + (size_t)(s0 + k) * (size_t)cap;
+                    ch[k] = q[0]; pv[k] = first_col ? (uint8_t)'A' : q[-1]; nx[k] = last_col ? (uint8_t)'A' : q[1];
+                    w[k] = S.wrow[lo + s0 + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) fold(ch[k], pv[k], nx[k], w[k]);
+            }
+            for (; s0 < ns; s0++) {
+                const uint8_t* q = col + (size_t)s0 * (size_t)cap;
+                fold(q[0], first_col ? (uint8_t)'A' : q[-1], last_col ? (uint8_t)'A' : q[1], S.wrow[lo + s0]);
             }
             unsigned order[4] = {0, 1, 2, 3};       // profilefrommsa.cpp:180-204: bubble sort, strict <
             bool any = true;
@@ -189,7 +212,7 @@ __device__ inline float match_ab(const Shared& S, const float f[4], uint8_t ord,
 }
 
 // nwsmall.cpp:447-620 + bittraceback.cpp:130-209 -> S.p.path[0..*plen) in forward order; false = the reference gives up
-__device__ bool nw_small(Shared& S, int la, int lb, int* plen) {
+__device__ bool nw_small(Shared& S, uint8_t* TB, int la, int lb, int* plen, bool prof, unsigned long long& prof_sweep, unsigned long long& prof_t0) {
     const int lane = (int)__lane_id();
     const float e = kGapExtend;
     const int stride = lb + 1;
@@ -197,8 +220,8 @@ __device__ bool nw_small(Shared& S, int la, int lb, int* plen) {
         S.p.opena[0] = 0.0f * -1.0f; if (la > 1) S.p.closea[la - 1] = 0.0f * -1.0f;
         S.p.openb[0] = 0.0f * -1.0f; if (lb > 1) S.p.closeb[lb - 1] = 0.0f * -1.0f;
     }
-    for (int x = lane; x <= la; x += 64) S.p.tb[x * stride] = 0;
-    for (int x = lane; x <= lb; x += 64) S.p.tb[x] = 0;
+    for (int x = lane; x <= la; x += 64) TB[x * stride] = 0;
+    for (int x = lane; x <= lb; x += 64) TB[x] = 0;
     GA_SYNC();
     const float open_a0 = S.p.opena[0], open_b0 = S.p.openb[0];
     for (int r0 = 0; r0 < la; r0 += 64) {
@@ -250,7 +273,7 @@ __device__ bool nw_small(Shared& S, int la, int lb, int* plen) {
                 const float mi = (j == 1 ? kMinusInf : lastM) + S.p.openb[j - 1];
                 const bool open_i = mi >= iij;
                 const float I = open_i ? mi : iij;
-                S.p.tb[i * stride + j] = (uint8_t)(xm | (from_m ? kMD : 0) | (open_i ? kMI : 0));
+                TB[i * stride + j] = (uint8_t)(xm | (from_m ? kMD : 0) | (open_i ? kMI : 0));
                 if (i < la && j < lb) {
                     const float dm = D + close_a, im = I + S.p.closeb[j - 1], mm = m;
                     const bool pm = mm >= dm && mm >= im;
@@ -267,6 +290,7 @@ __device__ bool nw_small(Shared& S, int la, int lb, int* plen) {
         GA_SYNC();
     }
     GA_SYNC();
+    if (prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof_sweep += t_ - prof_t0; prof_t0 = t_; }
     bool ok = true;
     if (lane == 0) {
         const float mab = S.p.result[0], dab = S.p.result[1], iab = S.p.result[2];
@@ -278,7 +302,7 @@ __device__ bool nw_small(Shared& S, int la, int lb, int* plen) {
         for (;;) {
             if (n >= 2 * kMaxCols + 2) { ok = false; break; }
             rev[n++] = (uint8_t)type;
-            const uint8_t bits = S.p.tb[a * stride + b];
+            const uint8_t bits = TB[a * stride + b];
             char next;
             if (type == 'M') {
                 const uint8_t x = bits & kXM;
@@ -306,9 +330,14 @@ __device__ bool nw_small(Shared& S, int la, int lb, int* plen) {
 }
 
 #define GA_STAGE(stage_) do { if (P.dbg && lane == 0) P.dbg[blockIdx.x * 2 + 1] = (stage_); } while (0)
-__device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& job, int* out_cols) {
+// PM_GAP_DEBUG=3: the shader clock spent since the previous mark goes to stage k_
+// (kept in registers and added to the launch's totals once per job: a shared counter per mark would be what is measured)
+#define GA_CLOCK(k_) do { if (P.prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof_acc[(k_)] += t_ - prof_t0; prof_t0 = t_; } } while (0)
+__device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, const Params& P, const Job& job, int* out_cols) {
     const int lane = (int)__lane_id();
     const int n = job.n, cap = P.cap;
+    unsigned long long prof_acc[kProfStages] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_t0 = P.prof ? (unsigned long long)clock64() : 0;
     if (n < 2 || n > kMaxSeqs) return false;
     // ---- sequences: lengths, FixAlpha (seq.cpp:331-344) happens when the rows are filled
     int bad = 0;
@@ -318,14 +347,14 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         W.len[i] = L;
         if (L <= 0 || L > cap || L > kMaxCols) bad = 1;
         uint64_t h = 1469598103934665603ull;
-        for (int x = 0; x < L; x++) { uint8_t ch = P.chars[a + x]; if (c_letter[ch] >= 16) ch = 'N'; h = (h ^ ch) * 1099511628211ull; }
+        for (int x = 0; x < L; x++) { uint8_t ch = P.chars[a + x]; if (S.letter[ch] >= 16) ch = 'N'; h = (h ^ ch) * 1099511628211ull; }
         W.hash[i] = h ^ (uint64_t)L;
     }
     if (wave_sum(bad)) return false;
     GA_SYNC();
-    auto seq_char = [&](int i, int x) -> uint8_t { uint8_t ch = P.chars[P.seq_off[job.first_seq + i] + x]; return c_letter[ch] >= 16 ? (uint8_t)'N' : ch; };
+    auto seq_char = [&](int i, int x) -> uint8_t { uint8_t ch = P.chars[P.seq_off[job.first_seq + i] + x]; return S.letter[ch] >= 16 ? (uint8_t)'N' : ch; };
 
-    GA_STAGE(1);
+    GA_STAGE(1); GA_CLOCK(0);
     // ---- distinct strings: cls[i] = first sequence spelling the same string
     for (int i = lane; i < n; i += 64) {
         int rep = i;
@@ -348,17 +377,16 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         u += __popcll(m);
     }
     GA_SYNC();
-    GA_STAGE(2);
+    GA_STAGE(2); GA_CLOCK(1);
     // ---- per distinct string: its distinct 6-mers with 8-bit (wrapping) multiplicities (fastdistnuc.cpp:82-90)
-    for (int x = lane; x < kTable; x += 64) W.table[x] = 0;
-    GA_SYNC();
+    // (the count table is all zero here: the kernel clears it once per slot, and every use below clears what it set)
     for (int a = 0; a < u; a++) {
         const int i = W.replist[a], L = W.len[i];
         int nt = 0;
         if (L >= 6) {
             for (int p = lane; p < L; p += 64) {
                 uint32_t t = 0;
-                if (p >= 5) for (int x = p - 5; x <= p; x++) { uint8_t l = c_letter[seq_char(i, x)]; if (l >= 4) l = 4; t = t * 6 + l; }
+                if (p >= 5) for (int x = p - 5; x <= p; x++) { uint8_t l = S.letter[seq_char(i, x)]; if (l >= 4) l = 4; t = t * 6 + l; }
                 S.codes[p] = (uint16_t)t;
             }
             GA_SYNC();
@@ -401,7 +429,7 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         for (int t = lane; t < na; t += 64) W.table[W.tcode[(size_t)a * kMaxCols + t]] = 0;
         GA_SYNC();
     }
-    GA_STAGE(3);
+    GA_STAGE(3); GA_CLOCK(2);
     // ---- distances (fastdistnuc.cpp:236-262)
     for (int i = 1; i < n; i++) {
         const int ci = W.repidx[W.cls[i]];
@@ -420,11 +448,12 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
     if (lane == 0) W.dist[(size_t)n * (n - 1) / 2] = 0.0f;
     GA_SYNC();
 
-    GA_STAGE(4);
+    GA_STAGE(4); GA_CLOCK(3);
     // ---- UPGMB (upgma2.cpp:133-355): 0.1 * average + 0.9 * minimum linkage, stale row minima kept
     const unsigned un = (unsigned)n;
     for (unsigned x = lane; x < un; x += 64) {
         float best = kBigDist; unsigned arg = kNone;
+#pragma unroll 8
         for (unsigned j = 0; j < un; j++) {
             if (j == x) continue;
             const float d = W.dist[tri(x, j)];
@@ -433,6 +462,7 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         S.t.mind[x] = best; S.t.nearest[x] = arg; S.t.node[x] = x;
     }
     GA_SYNC();
+    GA_CLOCK(4);
     for (unsigned k = 0; k + 1 < un; k++) {
         float best = kBigDist; unsigned lmin = kNone;
         for (unsigned j = lane; j < un; j += 64) {
@@ -443,35 +473,44 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         if (lmin == kNone) return false;
         const unsigned rmin = S.t.nearest[lmin];
         if (rmin == kNone || rmin >= un) return false;
+        // the distances of this step are requested together (two per cluster and lane, plus the pair's own): one round
+        // trip to the workspace per merge instead of one per 64 clusters
+        constexpr int kRounds = kMaxSeqs / 64;
+        float dl[kRounds], dr[kRounds];
+        const float dlr = W.dist[tri(lmin, rmin)];
+#pragma unroll
+        for (int r = 0; r < kRounds; r++) {
+            const unsigned j = (unsigned)r * 64 + (unsigned)lane;
+            dl[r] = 0; dr[r] = 0;
+            if (j < un && j != lmin && j != rmin && S.t.node[j] != kNone) { dl[r] = W.dist[tri(lmin, j)]; dr[r] = W.dist[tri(rmin, j)]; }
+        }
         float new_min = kBigDist; unsigned new_nearest = kNone;
-        for (unsigned j = lane; j < un; j += 64) {
-            if (j == lmin || j == rmin || S.t.node[j] == kNone) continue;
-            const unsigned vl = tri(lmin, j), vr = tri(rmin, j);
-            const float dl = W.dist[vl], dr = W.dist[vr];
-            const float nd = kSueff * ((dl + dr) / 2) + (1 - kSueff) * (dl < dr ? dl : dr);
+#pragma unroll
+        for (int r = 0; r < kRounds; r++) {
+            const unsigned j = (unsigned)r * 64 + (unsigned)lane;
+            if (j >= un || j == lmin || j == rmin || S.t.node[j] == kNone) continue;
+            const float nd = kSueff * ((dl[r] + dr[r]) / 2) + (1 - kSueff) * (dl[r] < dr[r] ? dl[r] : dr[r]);
             if (S.t.nearest[j] == rmin) S.t.nearest[j] = lmin;
-            W.dist[vl] = nd;
+            W.dist[tri(lmin, j)] = nd;
             if (nd < new_min) { new_min = nd; new_nearest = j; }
         }
         wave_argmin(new_min, new_nearest);
-        GA_SYNC();
         if (lane == 0) {
-            const float dlr = W.dist[tri(lmin, rmin)];
             const float h = dlr / 2;
             const unsigned ul = S.t.node[lmin], ur = S.t.node[rmin];
-            const float hl = ul < un ? 0 : W.height[ul - un];
-            const float hr = ur < un ? 0 : W.height[ur - un];
+            const float hl = ul < un ? 0 : S.t.height[ul - un];
+            const float hr = ur < un ? 0 : S.t.height[ur - un];
             const unsigned v = un + k;
             W.left[v] = ul; W.right[v] = ur;
             W.parent[ul] = v; W.parent[ur] = v;
             W.to_parent[ul] = (double)(h - hl); W.to_parent[ur] = (double)(h - hr);
-            W.height[k] = h;
+            S.t.height[k] = h;
             S.t.node[lmin] = v; S.t.nearest[lmin] = new_nearest; S.t.mind[lmin] = new_min; S.t.node[rmin] = kNone;
         }
         GA_SYNC();
     }
     const unsigned root = 2 * un - 2, nodes = 2 * un - 1;
-    GA_STAGE(5);
+    GA_STAGE(5); GA_CLOCK(5);
     // ---- ClustalW weights (clwwt.cpp:65-163)
     if (lane == 0) {
         for (unsigned v = 0; v < nodes; v++) W.under[v] = v < un ? 1 : W.under[W.left[v]] + W.under[W.right[v]];
@@ -502,31 +541,46 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         for (unsigned l = lane; l < un; l += 64) W.weight[l] /= total;
     }
     GA_SYNC();
-    GA_STAGE(6);
-    // ---- leaves: one-row alignments
-    for (int p = 0; p < n; p++) {
+    GA_STAGE(6); GA_CLOCK(6);
+    // ---- leaves: one-row alignments (row p of the LDS block = leaf p of the root alignment's order; a lane per row)
+    for (int p = lane; p < n; p += 64) {
         const int i = W.perm[p], L = W.len[i];
-        uint8_t* row = W.rows + ((size_t)p * 2) * (size_t)cap;
-        for (int x = lane; x < L; x += 64) row[x] = seq_char(i, x);
-        if (lane == 0) { S.cur[p] = 0; S.wrow[p] = W.weight[i]; W.ncols[i] = L; W.total[i] = 0.0f + W.weight[i]; }
+        uint8_t* row = R + (size_t)p * (size_t)cap;
+        const int64_t a0 = P.seq_off[job.first_seq + i];
+        for (int x = 0; x < L; x++) { const uint8_t ch = P.chars[a0 + x]; row[x] = S.letter[ch] >= 16 ? (uint8_t)'N' : ch; }
+        S.wrow[p] = W.weight[i]; S.rowlen[p] = (uint8_t)L;
     }
     GA_SYNC();
-    GA_STAGE(7);
+    GA_STAGE(7); GA_CLOCK(7);
     // ---- progressive alignment (progressivealign.cpp:16-82): children are created before their parent, so ascending
     // node order computes every alignment after its two inputs (the reference's left-first post-order does the same
     // merges in another order)
-    for (unsigned v = un; v < nodes; v++) {
-        const unsigned a = W.left[v], b = W.right[v];
-        const int loa = W.lo[a], nsa = (int)W.under[a], la = W.ncols[a];
-        const int lob = W.lo[b], nsb = (int)W.under[b], lb = W.ncols[b];
+    // (a node's inputs -- first row and number of rows of each child -- are fixed by now: 64 nodes' worth are fetched at a
+    // time, a lane each, and handed round; what a node produces -- columns, weight total -- stays in LDS)
+    for (unsigned v0 = un; v0 < nodes; v0 += 64) {
+      unsigned my_a = 0, my_b = 0; int my_loa = 0, my_nsa = 0, my_lob = 0, my_nsb = 0;
+      if (v0 + (unsigned)lane < nodes) {
+          my_a = W.left[v0 + lane]; my_b = W.right[v0 + lane];
+          my_loa = W.lo[my_a]; my_nsa = (int)W.under[my_a]; my_lob = W.lo[my_b]; my_nsb = (int)W.under[my_b];
+      }
+      const unsigned vend = v0 + 64 < nodes ? v0 + 64 : nodes;
+      for (unsigned v = v0; v < vend; v++) {
+        const int k = (int)(v - v0);
+        const unsigned a = (unsigned)__shfl((int)my_a, k, 64), b = (unsigned)__shfl((int)my_b, k, 64);
+        const int loa = __shfl(my_loa, k, 64), nsa = __shfl(my_nsa, k, 64), lob = __shfl(my_lob, k, 64), nsb = __shfl(my_nsb, k, 64);
+        const int la = a < un ? (int)S.rowlen[loa] : (int)S.ncols_i[a - un];
+        const int lb = b < un ? (int)S.rowlen[lob] : (int)S.ncols_i[b - un];
+        const float total_a = a < un ? 0.0f + S.wrow[loa] : S.total_i[a - un];
+        const float total_b = b < un ? 0.0f + S.wrow[lob] : S.total_i[b - un];
         if (la <= 0 || lb <= 0 || la > kMaxCols || lb > kMaxCols) return false;
         GA_STAGE(100 + (int)(v - un) * 10);
-        build_profile(S, W, cap, loa, nsa, la, W.total[a], true);
-        build_profile(S, W, cap, lob, nsb, lb, W.total[b], false);
+        GA_CLOCK(8);
+        build_profile(S, R, cap, loa, nsa, la, total_a, true);
+        build_profile(S, R, cap, lob, nsb, lb, total_b, false);
         int plen = 0;
-        GA_STAGE(101 + (int)(v - un) * 10);
-        if (!nw_small(S, la, lb, &plen)) return false;
-        GA_STAGE(102 + (int)(v - un) * 10);
+        GA_STAGE(101 + (int)(v - un) * 10); GA_CLOCK(13);
+        if (!nw_small(S, TB, la, lb, &plen, P.prof != nullptr, prof_acc[9], prof_t0)) return false;
+        GA_STAGE(102 + (int)(v - un) * 10); GA_CLOCK(10);
         if (plen > cap || plen > kMaxCols) return false;
         // aligngivenpath.cpp:124-255: a column of A, of B, or of both
         if (lane == 0) {
@@ -540,32 +594,60 @@ __device__ bool align_job(Shared& S, const Slot& W, const Params& P, const Job& 
         }
         GA_SYNC();
         if (!S.flag) return false;
-        for (int s = 0; s < nsa + nsb; s++) {
-            const bool in_a = s < nsa;
-            const int p = in_a ? loa + s : lob + (s - nsa);
-            const uint8_t curb = S.cur[p];
-            const uint8_t* src = W.rows + ((size_t)p * 2 + curb) * (size_t)cap;
-            uint8_t* dst = W.rows + ((size_t)p * 2 + (curb ^ 1)) * (size_t)cap;
-            for (int c = lane; c < plen; c += 64) { const int m = in_a ? S.p.mapa[c] : S.p.mapb[c]; dst[c] = m >= 0 ? src[m] : (uint8_t)'-'; }
+        // rows re-spelled in place through the column maps.  An input with no column inserted keeps its rows as they are
+        // (the map is the identity): when one sequence joins a large alignment, that is usually the large one.  Every lane
+        // reads its (at most two) characters of a row before any lane writes: one wavefront, LDS operations in program order.
+        static_assert(kMaxCols <= 128, "two columns per lane");
+        {
+            const int c1 = lane, c2 = lane + 64;
+            const int ma1 = c1 < plen ? S.p.mapa[c1] : -1, ma2 = c2 < plen ? S.p.mapa[c2] : -1;
+            const int mb1 = c1 < plen ? S.p.mapb[c1] : -1, mb2 = c2 < plen ? S.p.mapb[c2] : -1;
+            auto respell = [&](int p0, int np, int m1, int m2) {
+                int s0 = 0;
+                for (; s0 + 4 <= np; s0 += 4) {
+                    uint8_t v1[4], v2[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint8_t* row = R + (size_t)(p0 + s0 + k) * (size_t)cap;
+                        v1[k] = m1 >= 0 ? row[m1] : (uint8_t)'-'; v2[k] = m2 >= 0 ? row[m2] : (uint8_t)'-';
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint8_t* row = R + (size_t)(p0 + s0 + k) * (size_t)cap;
+                        if (c1 < plen) row[c1] = v1[k];
+                        if (c2 < plen) row[c2] = v2[k];
+                    }
+                }
+                for (; s0 < np; s0++) {
+                    uint8_t* row = R + (size_t)(p0 + s0) * (size_t)cap;
+                    const uint8_t v1 = m1 >= 0 ? row[m1] : (uint8_t)'-', v2 = m2 >= 0 ? row[m2] : (uint8_t)'-';
+                    if (c1 < plen) row[c1] = v1;
+                    if (c2 < plen) row[c2] = v2;
+                }
+            };
+            if (plen != la) respell(loa, nsa, ma1, ma2);
+            if (plen != lb) respell(lob, nsb, mb1, mb2);
         }
-        GA_SYNC();
-        for (int s = lane; s < nsa + nsb; s += 64) { const int p = s < nsa ? loa + s : lob + (s - nsa); S.cur[p] ^= 1; }
         if (lane == 0) {
-            W.ncols[v] = plen;
-            float t = W.total[a];                    // the merged alignment's rows: A's, then B's
+            S.ncols_i[v - un] = (uint8_t)plen;
+            float t = total_a;                       // the merged alignment's rows: A's, then B's
             for (int x = 0; x < nsb; x++) t += S.wrow[lob + x];
-            W.total[v] = t;
+            S.total_i[v - un] = t;
         }
         GA_SYNC();
+        GA_CLOCK(11);
+      }
     }
-    const int nc = W.ncols[root];
+    const int nc = n >= 2 ? (int)S.ncols_i[root - un] : 0;
     if (nc > job.max_cols) return false;
-    for (int p = 0; p < n; p++) {
-        const uint8_t* src = W.rows + ((size_t)p * 2 + S.cur[p]) * (size_t)cap;
+    for (int p = lane; p < n; p += 64) {              // a lane per row: its place in the output comes from one load
+        const uint8_t* src = R + (size_t)p * (size_t)cap;
         uint8_t* dst = P.out_rows + job.row_off + (int64_t)W.perm[p] * job.max_cols;
-        for (int c = lane; c < nc; c += 64) dst[c] = src[c];
+        for (int c = 0; c < nc; c++) dst[c] = src[c];
     }
     *out_cols = nc;
+    GA_CLOCK(12);
+    if (P.prof && lane == 0) for (int k = 0; k < kProfStages; k++) if (prof_acc[k]) atomicAdd(&P.prof[k], prof_acc[k]);
     return true;
 }
 
@@ -590,7 +672,6 @@ __device__ Slot carve(uint8_t* base, int nmax, int cap) {
     W.lo = (int32_t*)take(8 * n); W.ncols = (int32_t*)take(8 * n);
     W.perm = (int32_t*)take(4 * n);
     W.total = (float*)take(8 * n);
-    W.rows = take(2 * n * (size_t)cap);
     W.table = take(kTable);
     return W;
 }
@@ -598,12 +679,17 @@ size_t slot_bytes(int nmax, int cap) {
     const size_t n = (size_t)nmax;
     auto r = [](size_t b) { return (b + 15) & ~(size_t)15; };
     return r(4 * (n * (n - 1) / 2 + 1)) + r(2 * n * n) + r(2 * n * kMaxCols) + r(n * kMaxCols) + r(4 * n) + r(8 * n) + 4 * r(4 * n) + 3 * r(8 * n) + r(16 * n) +
-           r(4 * n) + r(8 * n) + r(16 * n) + r(4 * n) + 2 * r(8 * n) + r(4 * n) + r(8 * n) + r(2 * n * (size_t)cap) + r(kTable) + 256;
+           r(4 * n) + r(8 * n) + r(16 * n) + r(4 * n) + 2 * r(8 * n) + r(4 * n) + r(8 * n) + r(kTable) + 256;
 }
 
 __global__ __launch_bounds__(64) void gap_align_kernel(Params P) {
     __shared__ Shared S;
+    extern __shared__ __align__(16) uint8_t rows_lds[];      // nmax rows of cap bytes, then the (cap+1)^2 trace-back bytes of one pairwise DP
+    uint8_t* const tb_lds = rows_lds + ((((size_t)P.nmax * (size_t)P.cap) + 15) & ~(size_t)15);
+    for (int x = (int)threadIdx.x; x < 256; x += 64) S.letter[x] = c_letter[x];
     const Slot W = carve(P.ws + (size_t)blockIdx.x * (size_t)P.ws_stride, P.nmax, P.cap);
+    for (int x = (int)threadIdx.x; x < kTable; x += 64) W.table[x] = 0;
+    GA_SYNC();
     for (;;) {
         if (threadIdx.x == 0) S.flag = (int32_t)atomicAdd(P.next, 1ull);
         GA_SYNC();
@@ -613,7 +699,7 @@ __global__ __launch_bounds__(64) void gap_align_kernel(Params P) {
         const Job job = P.jobs[j];
         if (P.dbg && threadIdx.x == 0) { P.dbg[blockIdx.x * 2] = (int32_t)j; P.dbg[blockIdx.x * 2 + 1] = 0; }
         int cols = -1;
-        if (!align_job(S, W, P, job, &cols)) cols = -1;
+        if (!align_job(S, rows_lds, tb_lds, W, P, job, &cols)) cols = -1;
         GA_SYNC();
         if (threadIdx.x == 0) P.out_cols[j] = cols;
         if (P.dbg && threadIdx.x == 0) P.dbg[blockIdx.x * 2 + 1] = -1;
@@ -719,7 +805,13 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
     auto lap = [&](const char* what) { if (timers) { const double t = now(); fprintf(stderr, "[gap batch] %-12s %.4f s\n", what, t - tl); tl = t; } };
     hipDeviceProp_t prop;
     GA_CHECK(hipGetDeviceProperties(&prop, device >= 0 ? device : 0));
-    const int64_t slots = std::min<int64_t>((int64_t)jobs.size(), (int64_t)prop.multiProcessorCount * 6);   // 6 workgroups of ~25 KB LDS fit a CU
+    // LDS of a workgroup: the fixed block plus the alignment rows of the widest job; as many workgroups per CU as fit in 160 KB
+    const size_t rows_lds = ((((size_t)nmax * (size_t)cap) + 15) & ~(size_t)15) + ((((size_t)cap + 1) * ((size_t)cap + 1) + 15) & ~(size_t)15);
+    const size_t lds = sizeof(Shared) + rows_lds;
+    if (lds > 160 * 1024 - 1024) { release(); return fail(PM_ELIMIT, "gap alignment rows do not fit the LDS"); }
+    if (lds > 64 * 1024) GA_CHECK(hipFuncSetAttribute((const void*)gap_align_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 256)));
+    const int64_t slots = std::min<int64_t>((int64_t)jobs.size(), (int64_t)prop.multiProcessorCount * per_cu);
     const size_t stride = slot_bytes(nmax, cap);
     GA_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     auto dalloc = [&](size_t bytes, void** p) { hipError_t e = hipMalloc(p, bytes ? bytes : 1); if (e == hipSuccess) owned.push_back(*p); return e; };
@@ -745,8 +837,14 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
         if (!g_dbg || g_dbg_slots < slots) { if (g_dbg) (void)hipHostFree(g_dbg); g_dbg = nullptr; if (hipHostMalloc((void**)&g_dbg, 8 * (size_t)slots, hipHostMallocMapped) == hipSuccess) g_dbg_slots = slots; }
         if (g_dbg) { memset(g_dbg, 0xff, 8 * (size_t)slots); (void)hipHostGetDevicePointer((void**)&dbg, g_dbg, 0); }
     }
-    Params P{d_jobs, (int64_t)jobs.size(), d_off, d_chars, d_out, d_cols, d_next, d_ws, (int64_t)stride, nmax, cap, dbg};
-    hipLaunchKernelGGL(gap_align_kernel, dim3((unsigned)slots), dim3(64), 0, stream, P);
+    unsigned long long* d_prof = nullptr;
+    if (getenv("PM_GAP_DEBUG") && atoi(getenv("PM_GAP_DEBUG")) == 3) {
+        GA_CHECK(dalloc(8 * kProfStages, (void**)&d_prof));
+        GA_CHECK(hipMemsetAsync(d_prof, 0, 8 * kProfStages, stream));
+    }
+    Params P{d_jobs, (int64_t)jobs.size(), d_off, d_chars, d_out, d_cols, d_next, d_ws, (int64_t)stride, nmax, cap, dbg, d_prof};
+    if (timers) fprintf(stderr, "[gap batch] %zu jobs, widest %d sequences x %d columns: %zu B of LDS per wavefront, %d per CU, %lld slots\n", jobs.size(), nmax, cap, lds, per_cu, (long long)slots);
+    hipLaunchKernelGGL(gap_align_kernel, dim3((unsigned)slots), dim3(64), rows_lds, stream, P);
     GA_CHECK(hipGetLastError());
     if (timers) { GA_CHECK(hipStreamSynchronize(stream)); lap("kernel"); }
     std::vector<int32_t> got(jobs.size());
@@ -754,6 +852,16 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
     GA_CHECK(hipMemcpyAsync(out_rows, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, stream));
     GA_CHECK(hipStreamSynchronize(stream));
     lap("d2h");
+    if (d_prof) {
+        unsigned long long prof[kProfStages];
+        GA_CHECK(hipMemcpy(prof, d_prof, sizeof prof, hipMemcpyDeviceToHost));
+        static const char* const names[kProfStages] = {"lengths + hashes", "distinct strings", "6-mers + common counts", "distances", "tree: row minima", "tree: merges", "weights",
+                                                       "leaves", "node set-up", "pairwise DP: init + sweep", "DP: trace-back", "path maps + rows + totals", "output", "profiles", "", ""};
+        unsigned long long sum = 0;
+        for (int k = 0; k < kProfStages; k++) sum += prof[k];
+        for (int k = 0; k < kProfStages; k++)
+            if (prof[k]) fprintf(stderr, "[gap stages] %-24s %6.2f %%  %12.0f clocks per job\n", names[k], 100.0 * (double)prof[k] / (double)sum, (double)prof[k] / (double)jobs.size());
+    }
     for (size_t i = 0; i < jobs.size(); i++) cols[which[i]] = got[i];
     release();
     lap("release");

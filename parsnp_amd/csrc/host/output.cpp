@@ -7,12 +7,14 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fcntl.h>
 #include <fstream>
 #include <future>
 #include <iomanip>
 #include <iostream>
 #include <sstream>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include "aligner.h"
@@ -157,53 +159,201 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     }
     xmfa << "#IntervalCount " << printable << endl;
 
-    // rows of every printable LCB (the reference does this under OpenMP over the LCBs; rows are independent)
-    vector<vector<string>> rows(a.lcbs.size());
-    vector<char> notes(a.lcbs.size(), 0);
+    // Every printable LCB is laid out first (which gaps are aligned, how many columns each contributes), the aligned
+    // gaps of ALL LCBs go to the device in one batch, and then every record is generated straight into its place in the
+    // file: with the column counts known, the size of every record -- and so the file offset of every row -- is known
+    // before a single base is formatted, and the threads stream the rows (MUM text from the genomes, gap rows from the
+    // aligner's output) through small buffers and positioned writes.  Nothing of the 1 GB text (200 x 5 Mb) is held in
+    // memory.  An LCB the stream cannot print as it stands -- one that overlaps the previous printed LCB on the reference
+    // (the trim of :928-952 works on the finished rows), or whose coordinates would make std::string::substr clamp or
+    // wrap -- is built as strings, the way the reference does it ("slow" below); so is everything with recombfilter
+    // (blocks/b<k>/seq.fna wants the records twice) or PARSNP_PLAIN_OUTPUT=1 (test hook: both ways give the same file).
     const long nl = (long)a.lcbs.size();
     const int threads = prm.cores > 0 ? prm.cores : 1;
-    vector<vector<pair<size_t, Gap>>> gaps(a.lcbs.size());
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     auto clock_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tl = clock_s();
     auto lap = [&](const char* what) { if (dbg) { double t = clock_s(); fprintf(stderr, "[output] %-14s %.4f s\n", what, t - tl); tl = t; } };
     auto printable_lcb = [&](const Lcb& ct) { return ct.type == 1 && !ct.mums.empty() && prm.do_align != 0; };
-#pragma omp parallel for schedule(dynamic) num_threads(threads)
-    for (long z = 0; z < nl; z++)
-        if (printable_lcb(a.lcbs[(size_t)z])) gaps_to_align(a, a.lcbs[(size_t)z], &gaps[(size_t)z]);
-    lap("gap strings");
-    vector<Gap*> jobs;
-    for (auto& g : gaps) for (auto& tg : g) jobs.push_back(&tg.second);
+    static const bool plain_output = getenv("PARSNP_PLAIN_OUTPUT") != nullptr;
+    const bool all_slow = plain_output || prm.recomb_filter;
+
+    // ---- layout of every LCB
+    struct Plan {
+        bool regular = false;              // the stream can print it (unless it turns out to need the overlap trim)
+        std::vector<int32_t> gmax;         // per gap: longest gap string
+        std::vector<int32_t> gjob;         // per gap: index into `jobs` when the gap is aligned, else -1
+        std::vector<int32_t> gcols;        // per gap: columns in the rows
+        long cols = 0;                     // row length
+    };
+    vector<Plan> plan((size_t)nl);
+    auto gap_length = [&](const Mum& first, const Mum& m, const Mum& nx, size_t i, bool* clean) -> long {
+        const long gs = (long)a.genomes[i].seq.size();
+        if (!first.fwd[i]) {
+            const long pos = nx.end(i), len = m.start[i] - nx.end(i);
+            if (pos < 0 || pos > gs) { *clean = false; return 0; }
+            if (len < 1) return 0;
+            if (pos + len > gs) *clean = false;
+            return len;
+        }
+        const long pos = m.end(i), len = nx.start[i] - m.end(i);
+        if (pos < 0 || pos > gs || len < 0 || pos + len > gs) { *clean = false; return 0; }
+        return len;
+    };
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+    for (long z = 0; z < nl; z++) {
+        const Lcb& ct = a.lcbs[(size_t)z];
+        if (!printable_lcb(ct)) continue;
+        Plan& pl = plan[(size_t)z];
+        const size_t T = ct.mums.size();
+        pl.gmax.assign(T - 1, 0); pl.gjob.assign(T - 1, -1); pl.gcols.assign(T - 1, 0);
+        const Mum& first = a.pool[(size_t)ct.mums[0]];
+        bool clean = true;
+        for (size_t t = 0; t < T; t++) {
+            const Mum& m = a.pool[(size_t)ct.mums[t]];
+            for (size_t i = 0; i < n; i++) {
+                const long pos = m.start[i];
+                if (pos < 0 || m.length < 0 || pos + m.length > (long)a.genomes[i].seq.size()) clean = false;
+            }
+            if (t + 1 == T) break;
+            const Mum& nx = a.pool[(size_t)ct.mums[t + 1]];
+            long mx = 0, mn = 1000000;
+            for (size_t i = 0; i < n; i++) { const long l = gap_length(first, m, nx, i, &clean); mx = std::max(mx, l); mn = std::min(mn, l); }
+            pl.gmax[t] = (int32_t)mx;
+            // reference: MUSCLE(maxiters=1) over the n gap strings (:848-861); a single genome is never aligned (:809-826)
+            if (mx > 1 && mn > 0 && n > 1) pl.gjob[t] = 0;      // (numbered below)
+        }
+        pl.regular = clean;
+    }
+    // ---- the gaps that are aligned
+    struct Job { size_t z, t; unsigned max_len; long dev = -1; Gap host; bool on_host = false, failed = false; };
+    vector<Job> jobs;
+    for (long z = 0; z < nl; z++) {
+        Plan& pl = plan[(size_t)z];
+        if (!pl.regular) continue;                               // (an irregular LCB aligns its own gaps, below)
+        for (size_t t = 0; t < pl.gjob.size(); t++)
+            if (pl.gjob[t] == 0) { Job j; j.z = (size_t)z; j.t = t; j.max_len = (unsigned)pl.gmax[t]; jobs.push_back(std::move(j)); }
+            else pl.gjob[t] = -1;
+    }
     // longest first: the cost of one alignment grows with the square of the gap length, and a long one started last
     // would leave every other thread idle
-    std::sort(jobs.begin(), jobs.end(), [](const Gap* x, const Gap* y) { return x->max_len > y->max_len; });
+    std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) { return x.max_len > y.max_len; });
     const long nj = (long)jobs.size();
+    for (long x = 0; x < nj; x++) plan[jobs[(size_t)x].z].gjob[jobs[(size_t)x].t] = (int32_t)x;
+    static const struct Up { char up[256], rcu[256]; Up() {
+        for (int c = 0; c < 256; c++) {
+            up[c] = (char)toupper(c);
+            switch (toupper(c)) {                                 // = upper(reverse_complement()), ingest.cpp / parsnp.cpp:1294-1393
+                case 'A': rcu[c] = 'T'; break; case 'C': rcu[c] = 'G'; break; case 'G': rcu[c] = 'C'; break;
+                case 'T': rcu[c] = 'A'; break; case 'U': rcu[c] = 'T'; break;
+                case '\r': case '\n': case '\t': case ' ': case '>': case '.': rcu[c] = 0; break;
+                default: rcu[c] = 'N'; break;
+            }
+        }
+    } } U;
+    // the gap string of genome i between MUM t and t+1 of a regular LCB (upper case; reverse complement on a reverse LCB row)
+    auto gap_text = [&](const Lcb& ct, size_t t, size_t i, char* dst) -> size_t {
+        const Mum& first = a.pool[(size_t)ct.mums[0]];
+        const Mum& m = a.pool[(size_t)ct.mums[t]];
+        const Mum& nx = a.pool[(size_t)ct.mums[t + 1]];
+        const char* g = a.genomes[i].seq.data();
+        if (first.fwd[i]) {
+            const long pos = m.end(i), len = nx.start[i] - pos;
+            for (long x = 0; x < len; x++) dst[x] = U.up[(unsigned char)g[pos + x]];
+            return (size_t)len;
+        }
+        const long pos = nx.end(i), len = m.start[i] - pos;
+        size_t w = 0;
+        for (long x = len; x-- > 0;) { const char c = U.rcu[(unsigned char)g[pos + x]]; if (c) dst[w++] = c; }
+        return w;
+    };
     // The gaps go to the device in ONE batch (pm_gap_align_batch: one wavefront per gap, include/parsnp_mum.h); the few the
     // device does not take -- wider than its 96-column limit, or declined -- are aligned here by the host threads, the
     // widest ones while the device works on the rest.  PARSNP_HOST_GAPS=1: everything on the host (measurement / tests).
     constexpr unsigned kDeviceCols = 96;
     static const bool host_gaps = getenv("PARSNP_HOST_GAPS") != nullptr;
-    vector<char> on_device((size_t)nj, 0);
-    vector<int32_t> d_nseq, d_maxcols, d_cols; vector<int64_t> d_seqoff{0}, d_rowoff; vector<uint8_t> d_chars, d_out;
+    vector<int32_t> d_nseq, d_maxcols, d_cols; vector<int64_t> d_seqoff, d_rowoff; vector<uint8_t> d_chars, d_out;
     vector<long> d_job;
-    if (!host_gaps) {
+    if (!host_gaps && n <= 512) {
         int64_t out_bytes = 0;
         for (long x = 0; x < nj; x++) {
-            const Gap& gp = *jobs[(size_t)x];
-            if (gp.max_len > kDeviceCols || gp.seq.size() > 512) continue;
-            on_device[(size_t)x] = 1; d_job.push_back(x);
-            const int32_t cap = (int32_t)std::min<unsigned>(kDeviceCols, gp.max_len + gp.max_len / 2 + 16);
-            d_nseq.push_back((int32_t)gp.seq.size()); d_maxcols.push_back(cap); d_rowoff.push_back(out_bytes);
-            out_bytes += (int64_t)gp.seq.size() * cap;
-            for (const string& q : gp.seq) { d_chars.insert(d_chars.end(), q.begin(), q.end()); d_seqoff.push_back((int64_t)d_chars.size()); }
+            Job& j = jobs[(size_t)x];
+            if (j.max_len > kDeviceCols) continue;
+            j.dev = (long)d_job.size(); d_job.push_back(x);
+            const int32_t cap = (int32_t)std::min<unsigned>(kDeviceCols, j.max_len + j.max_len / 2 + 16);
+            d_nseq.push_back((int32_t)n); d_maxcols.push_back(cap); d_rowoff.push_back(out_bytes);
+            out_bytes += (int64_t)n * cap;
         }
-        d_out.resize((size_t)out_bytes); d_cols.assign(d_job.size(), -1);
+        const long nd = (long)d_job.size();
+        // the strings, job after job: lengths first (one offset per sequence), then the text by all threads
+        d_seqoff.assign((size_t)nd * n + 1, 0);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads)
+        for (long y = 0; y < nd; y++) {
+            const Job& j = jobs[(size_t)d_job[(size_t)y]];
+            const Lcb& ct = a.lcbs[j.z];
+            const Mum& first = a.pool[(size_t)ct.mums[0]];
+            const Mum& m = a.pool[(size_t)ct.mums[j.t]];
+            const Mum& nx = a.pool[(size_t)ct.mums[j.t + 1]];
+            bool clean = true;
+            for (size_t i = 0; i < n; i++) d_seqoff[(size_t)y * n + i + 1] = gap_length(first, m, nx, i, &clean);
+        }
+        for (size_t k = 1; k < d_seqoff.size(); k++) d_seqoff[k] += d_seqoff[k - 1];
+        d_chars.resize((size_t)d_seqoff.back() + 1);
+        int short_rows = 0;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(| : short_rows)
+        for (long y = 0; y < nd; y++) {
+            const Job& j = jobs[(size_t)d_job[(size_t)y]];
+            for (size_t i = 0; i < n; i++) {
+                const size_t at = (size_t)d_seqoff[(size_t)y * n + i], want = (size_t)(d_seqoff[(size_t)y * n + i + 1] - d_seqoff[(size_t)y * n + i]);
+                if (gap_text(a.lcbs[j.z], j.t, i, (char*)d_chars.data() + at) != want) short_rows = 1;
+            }
+        }
+        if (short_rows) { cerr << "parsnp_core: a genome holds a character its reverse complement drops" << endl; exit(1); }
+        d_out.resize((size_t)out_bytes); d_cols.assign((size_t)nd, -1);
+    }
+    lap("gap strings");
+    // The file's blocks are reserved while the gaps are being aligned (an estimate of its size: aligned gaps at their row
+    // capacity), and the records are later stored through a shared mapping: positioned writes to ONE file queue up behind
+    // its inode lock whatever the number of threads (2 GB/s here), page faults on a mapping do not.  A file system that
+    // cannot reserve (or PARSNP_OUTPUT_PWRITE=1, test hook) gets the positioned writes.
+    xmfa.flush();
+    const long long text_at = (long long)xmfa.tellp();
+    xmfa.close();
+    const string xmfa_path = dir + stem + ".xmfa";
+    const int fd = open(xmfa_path.c_str(), O_RDWR);
+    if (fd < 0) { cerr << "parsnp_core: cannot write " << xmfa_path << endl; exit(1); }
+    static const bool force_pwrite = getenv("PARSNP_OUTPUT_PWRITE") != nullptr;
+    long long reserved = 0;
+    std::future<bool> reserve_done;
+    if (!force_pwrite && !all_slow) {
+        long long est = text_at;
+        for (long z = 0; z < nl; z++) {
+            const Plan& pl = plan[(size_t)z];
+            if (!pl.regular) continue;
+            const Lcb& ct = a.lcbs[(size_t)z];
+            long long cols = 0;
+            for (size_t t = 0; t < ct.mums.size(); t++) {
+                cols += a.pool[(size_t)ct.mums[t]].length;
+                if (t + 1 < ct.mums.size()) cols += pl.gjob[t] >= 0 && jobs[(size_t)pl.gjob[t]].dev >= 0 ? d_maxcols[(size_t)jobs[(size_t)pl.gjob[t]].dev] : pl.gmax[t];
+            }
+            est += (long long)n * (cols + cols / 80 + 2 + 64) + 2;
+        }
+        reserved = est;
+        reserve_done = std::async(std::launch::async, [fd, est, dbg, clock_s] {
+            const double t0 = clock_s();
+            const bool ok = fallocate(fd, 0, 0, (off_t)est) == 0;
+            if (dbg) fprintf(stderr, "[output] reserve %lld MB: %s, %.4f s\n", est >> 20, ok ? "ok" : "not supported", clock_s() - t0);
+            return ok;
+        });
     }
     std::future<int> device_done;
     if (!d_job.empty())
         device_done = std::async(std::launch::async, [&] {
-            return pm_gap_align_batch(-1, (int64_t)d_job.size(), d_nseq.data(), d_seqoff.data(), d_chars.data(), d_maxcols.data(), d_rowoff.data(),
-                                      d_out.data(), (int64_t)d_out.size(), d_cols.data());
+            const double t0 = clock_s();
+            const int rc = pm_gap_align_batch(-1, (int64_t)d_job.size(), d_nseq.data(), d_seqoff.data(), d_chars.data(), d_maxcols.data(), d_rowoff.data(),
+                                              d_out.data(), (int64_t)d_out.size(), d_cols.data());
+            if (dbg) fprintf(stderr, "[output] gaps: device   %.4f s\n", clock_s() - t0);
+            return rc;
         });
     vector<double> jt(dbg ? (size_t)nj : 0);
     auto host_align = [&](const vector<long>& which) {
@@ -211,31 +361,24 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
         for (long y = 0; y < nw; y++) {
             const long x = which[(size_t)y];
-            Gap& gp = *jobs[(size_t)x];
+            Job& j = jobs[(size_t)x];
             const double t0 = dbg ? clock_s() : 0;
-            gp.failed = !gap_align(gp.seq, &gp.aligned);
+            gap_between(a, a.lcbs[j.z], j.t, &j.host);
+            j.on_host = true;
+            j.failed = !gap_align(j.host.seq, &j.host.aligned);
+            if (!j.failed)                       // (rows of one alignment have one length; anything else is not printable here)
+                for (const string& r : j.host.aligned) if (r.size() != j.host.aligned[0].size()) { cerr << "parsnp_core: ragged gap alignment" << endl; exit(1); }
             if (dbg) jt[(size_t)x] = clock_s() - t0;
         }
     };
     vector<long> rest;
-    for (long x = 0; x < nj; x++) if (!on_device[(size_t)x]) rest.push_back(x);
+    for (long x = 0; x < nj; x++) if (jobs[(size_t)x].dev < 0) rest.push_back(x);
     host_align(rest);
     long declined = 0;
     if (!d_job.empty()) {
         if (device_done.get() != PM_OK) { cerr << "parsnp_core: gap alignment on the device failed: " << pm_gap_last_error() << endl; exit(1); }
-        lap("gaps: device");
         rest.clear();
-        const long nd = (long)d_job.size();
-#pragma omp parallel for schedule(static) num_threads(threads)
-        for (long y = 0; y < nd; y++) {
-            if (d_cols[(size_t)y] < 0) continue;
-            Gap& gp = *jobs[(size_t)d_job[(size_t)y]];
-            gp.aligned.resize(gp.seq.size());
-            const char* base = (const char*)d_out.data() + d_rowoff[(size_t)y];
-            for (size_t i = 0; i < gp.seq.size(); i++) gp.aligned[i].assign(base + i * (size_t)d_maxcols[(size_t)y], (size_t)d_cols[(size_t)y]);
-            gp.failed = false;
-        }
-        for (long y = 0; y < nd; y++) if (d_cols[(size_t)y] < 0) rest.push_back(d_job[(size_t)y]);
+        for (size_t y = 0; y < d_job.size(); y++) if (d_cols[y] < 0) rest.push_back(d_job[y]);
         declined = (long)rest.size();
         host_align(rest);
     }
@@ -243,37 +386,92 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         double sum = 0, mx = 0; long arg = 0;
         for (long x = 0; x < nj; x++) { sum += jt[(size_t)x]; if (jt[(size_t)x] > mx) { mx = jt[(size_t)x]; arg = x; } }
         fprintf(stderr, "[output] %ld gap alignments: %zu on the device (%ld declined), %.3f s of host work, longest %.3f s (gap of %u columns)\n",
-                nj, d_job.size(), declined, sum, mx, jobs[(size_t)arg]->max_len);
+                nj, d_job.size(), declined, sum, mx, jobs[(size_t)arg].max_len);
     }
     lap("gap alignment");
-#pragma omp parallel for schedule(dynamic) num_threads(threads)
+    // row i of an aligned gap: pointer + length (nullptr: the alignment failed, the gap is padded instead)
+    auto aligned_row = [&](const Job& j, size_t i, size_t* len) -> const char* {
+        if (j.on_host) { if (j.failed) return nullptr; *len = j.host.aligned[i].size(); return j.host.aligned[i].data(); }
+        const size_t y = (size_t)j.dev;
+        *len = (size_t)d_cols[y];
+        return (const char*)d_out.data() + d_rowoff[y] + (int64_t)i * d_maxcols[y];
+    };
+    vector<char> notes((size_t)nl, 0);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
     for (long z = 0; z < nl; z++) {
+        Plan& pl = plan[(size_t)z];
+        if (!pl.regular) continue;
         const Lcb& ct = a.lcbs[(size_t)z];
-        rows[(size_t)z].assign(n, "");
-        if (printable_lcb(ct)) {
-            bool note = false;
-            build_rows(a, ct, gaps[(size_t)z], &rows[(size_t)z], &note);
-            notes[(size_t)z] = note;
-            vector<pair<size_t, Gap>>().swap(gaps[(size_t)z]);
+        long cols = 0;
+        for (size_t t = 0; t < ct.mums.size(); t++) {
+            cols += a.pool[(size_t)ct.mums[t]].length;
+            if (t + 1 == ct.mums.size()) break;
+            int32_t gc = pl.gmax[t];
+            if (pl.gjob[t] >= 0) {
+                size_t len = 0;
+                if (aligned_row(jobs[(size_t)pl.gjob[t]], 0, &len)) gc = (int32_t)len; else notes[(size_t)z] = 1;
+            }
+            pl.gcols[t] = gc; cols += gc;
         }
+        pl.cols = cols;
     }
-    for (char c : notes) if (c) *gap_note = true;
-    lap("rows");
+    // ---- the slow way for one LCB: its rows as strings (build_rows), from the same gap alignments
+    vector<vector<string>> rows((size_t)nl);
+    auto slow_rows = [&](size_t z) {
+        const Lcb& ct = a.lcbs[z];
+        const Plan& pl = plan[z];
+        vector<pair<size_t, Gap>> aligned;
+        if (!pl.regular) {                                   // its gaps were not in the batch
+            gaps_to_align(a, ct, &aligned);
+            for (auto& tg : aligned) tg.second.failed = !gap_align(tg.second.seq, &tg.second.aligned);
+        } else {
+            for (size_t t = 0; t < pl.gjob.size(); t++) {
+                if (pl.gjob[t] < 0) continue;
+                const Job& j = jobs[(size_t)pl.gjob[t]];
+                aligned.emplace_back(t, Gap());
+                Gap& gp = aligned.back().second;
+                gap_between(a, ct, t, &gp);
+                gp.aligned.resize(n);
+                for (size_t i = 0; i < n; i++) { size_t len = 0; const char* r = aligned_row(j, i, &len); if (!r) { gp.failed = true; break; } gp.aligned[i].assign(r, len); }
+            }
+        }
+        bool note = false;
+        build_rows(a, ct, aligned, &rows[z], &note);
+        if (note) notes[z] = 1;
+    };
+    vector<char> slow((size_t)nl, 0);
+    for (long z = 0; z < nl; z++) if (printable_lcb(a.lcbs[(size_t)z]) && (all_slow || !plan[(size_t)z].regular)) slow[(size_t)z] = 1;
+    {
+        vector<long> which;
+        for (long z = 0; z < nl; z++) if (slow[(size_t)z]) which.push_back(z);
+        const long nw = (long)which.size();
+#pragma omp parallel for schedule(dynamic) num_threads(threads)
+        for (long y = 0; y < nw; y++) slow_rows((size_t)which[(size_t)y]);
+    }
+    lap("layout");
 
     // Pass 1, in LCB order: the overlap trim against the previous printed LCB (it shortens rows and shifts the starts).
-    // Pass 2, all threads: the records of every printed LCB, wrapped at 80 columns, into one buffer per LCB.
-    // Pass 3: the buffers go to their places in the file with positioned writes (1 GB at 200 x 5 Mb).
+    // Pass 2, all threads: headers and sizes of the records of every printed LCB, hence their places in the file.
+    // Pass 3, all threads: the records, wrapped at 80 columns, written where they belong (1 GB at 200 x 5 Mb).
     int prev_end = 0;
-    vector<Lcb> trimmed(a.lcbs.size());
-    vector<char> printed(a.lcbs.size(), 0);
-    for (size_t z = 0; z < a.lcbs.size(); z++) {
-        Lcb ct = a.lcbs[z];
+    vector<Lcb> trimmed((size_t)nl);
+    vector<char> printed((size_t)nl, 0);
+    for (size_t z = 0; z < (size_t)nl; z++) {
+        const Lcb& c0 = a.lcbs[z];
+        if (!printable_lcb(c0)) continue;
+        const int lcb_start = (int)c0.start[0] + 1, lcb_end = (int)c0.end[0];
+        if (!slow[z]) {
+            if (!(plan[z].cols > (long)(prm.c * 1))) continue;
+            static const long mix = getenv("PARSNP_OUTPUT_MIX") ? atol(getenv("PARSNP_OUTPUT_MIX")) : 0;   // test hook: every mix-th LCB takes the late string route
+            if (std::max(0, prev_end - lcb_start) == 0 && !(mix > 0 && z % (size_t)mix == 0)) { prev_end = lcb_end; trimmed[z] = c0; printed[z] = 1; continue; }
+            slow_rows(z); slow[z] = 1;                       // it has to be trimmed: as strings
+        }
+        Lcb ct = c0;
         vector<string>& row = rows[z];
-        if (!(ct.type == 1 && !ct.mums.empty() && prm.do_align != 0 && row[0].size() > (size_t)(prm.c * 1))) continue;
+        if (!(row[0].size() > (size_t)(prm.c * 1))) continue;
         // trim the overlap with the previous printed LCB on the reference (:928-952, quirks kept: the column scan
         // never advances, and the start shift counts the non-gap columns of the whole reference row -- for genomes
         // after the first through the already shortened row 0, whose buffer still holds the old tail)
-        int lcb_start = (int)ct.start[0] + 1, lcb_end = (int)ct.end[0];
         int overlap = std::max(0, prev_end - lcb_start);
         if (overlap > 0) {
             if (row[0].empty() || row[0][0] == '-') { cerr << "parsnp_core: overlap trim would not terminate in the reference" << endl; exit(1); }
@@ -299,77 +497,209 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         if (!(row[0].size() > (size_t)(prm.c * 1))) continue;
         trimmed[z] = ct; printed[z] = 1;
     }
-    vector<string> text(a.lcbs.size());
-    const long nz = (long)a.lcbs.size();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-    for (long zz = 0; zz < nz; zz++) {
-        const size_t z = (size_t)zz;
-        if (!printed[z]) continue;
+    for (char c : notes) if (c) *gap_note = true;
+    if (dbg) {
+        long ns = 0, np = 0, nt = 0;
+        for (size_t z = 0; z < (size_t)nl; z++) { np += printed[z]; ns += printed[z] && slow[z]; nt += printed[z] && trimmed[z].start != a.lcbs[z].start; }
+        fprintf(stderr, "[output] %ld LCBs printed: %ld streamed, %ld as strings (%ld trimmed against their predecessor)\n", np, np - ns, ns, nt);
+    }
+    // headers of LCB z, one per genome, each ending in '\n' (:980-1049)
+    auto headers = [&](size_t z, string* out, vector<uint32_t>* ends) {
         const Lcb& ct = trimmed[z];
-        vector<string>& row = rows[z];
-        string& out = text[z];
-        size_t total = 4;
-        for (size_t i = 0; i < n; i++) total += row[i].size() + row[i].size() / 80 + 96;
-        out.reserve(total);
-        char b[16];
-        snprintf(b, sizeof b, "%d", (int)z + 1);
         const Mum& first = a.pool[(size_t)ct.mums.front()];
         const Mum& lastm = a.pool[(size_t)ct.mums.back()];
+        out->clear(); ends->clear();
+        char b[160];
         for (size_t i = 0; i < n; i++) {
-            std::ostringstream hd;
-            if (first.fwd[i]) hd << "> " << i + 1 << ":" << ct.start[i] + 1 << "-" << ct.end[i] << " ";
-            else hd << "> " << i + 1 << ":" << lastm.start[i] + 1 << "-" << first.end(i) << " ";
             // contig label and offset: last pos2hdr entry at or before the LCB start (:994-1037)
             // (the reference scans the map in key order; the entry it ends on is the last key <= start)
-            string hdr;
+            const string* hdr = nullptr;
             int seqstart = 0;
             {
                 const auto& p2h = a.genomes[i].pos2hdr;
                 auto it = p2h.upper_bound((int)ct.start[i]);
-                if (it != p2h.begin()) { --it; hdr = it->second; seqstart = it->first; }
+                if (it != p2h.begin()) { --it; hdr = &it->second; seqstart = it->first; }
             }
+            static const string s1 = "s1";
             int offset = 0;
-            if (hdr == "") { hdr = "s1"; offset = -1; }
-            else if (hdr != "s1") offset = -1;
-            if (!first.fwd[i]) hd << "- cluster" << b << " " << hdr << ":p" << (ct.start[i] - seqstart) + 1 + first.length + offset;
-            else hd << "+ cluster" << b << " " << hdr << ":p" << (ct.start[i] - seqstart) + 1 + offset;
+            if (!hdr || *hdr == "") { hdr = &s1; offset = -1; }
+            else if (*hdr != "s1") offset = -1;
+            int w;
+            if (first.fwd[i]) w = snprintf(b, sizeof b, "> %zu:%ld-%ld + cluster%d ", i + 1, (long)ct.start[i] + 1, (long)ct.end[i], (int)z + 1);
+            else w = snprintf(b, sizeof b, "> %zu:%ld-%ld - cluster%d ", i + 1, (long)lastm.start[i] + 1, (long)first.end(i), (int)z + 1);
+            out->append(b, (size_t)w);
+            out->append(*hdr);
+            if (first.fwd[i]) w = snprintf(b, sizeof b, ":p%ld\n", (long)(ct.start[i] - seqstart) + 1 + offset);
+            else w = snprintf(b, sizeof b, ":p%ld\n", (long)(ct.start[i] - seqstart) + 1 + first.length + offset);
+            out->append(b, (size_t)w);
+            ends->push_back((uint32_t)out->size());
+        }
+    };
+    auto wrapped = [](long long s) -> long long { return s + (s == 0 ? 1 : (s + 79) / 80); };     // s columns + their line ends
+    vector<string> text((size_t)nl);                 // slow LCBs: the whole record text
+    vector<string> heads((size_t)nl);                // streamed LCBs: the headers
+    vector<vector<uint32_t>> head_end((size_t)nl);
+    vector<long long> bytes((size_t)nl, 0);
+    const long nz = nl;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (long zz = 0; zz < nz; zz++) {
+        const size_t z = (size_t)zz;
+        if (!printed[z]) continue;
+        headers(z, &heads[z], &head_end[z]);
+        if (!slow[z]) { bytes[z] = (long long)heads[z].size() + (long long)n * wrapped(plan[z].cols) + 2; continue; }
+        vector<string>& row = rows[z];
+        string& out = text[z];
+        size_t total = 4 + heads[z].size();
+        for (size_t i = 0; i < n; i++) total += row[i].size() + row[i].size() / 80 + 2;
+        out.reserve(total);
+        for (size_t i = 0; i < n; i++) {
             const string& s = row[i];
-            out += hd.str(); out += '\n';
+            out.append(heads[z], i ? head_end[z][i - 1] : 0, head_end[z][i] - (i ? head_end[z][i - 1] : 0));
             size_t k = 0;
             const size_t width = 80;
             for (; k + width < s.size(); k += width) { out.append(s, k, width); out += '\n'; }
             out.append(s, k, string::npos); out += '\n';
         }
         if (prm.recomb_filter) {        // blocks/b<z+1>/seq.fna: the same records, without the terminator
-            string bdir = dir + "blocks/b" + b;
+            string bdir = dir + "blocks/b" + std::to_string((int)z + 1);
             int rc = system(("mkdir -p " + bdir).c_str()); (void)rc;
             ofstream block((bdir + "/seq.fna").c_str());
             block.write(out.data(), (std::streamsize)out.size());
         }
         out += "=\n";
+        bytes[z] = (long long)out.size();
         vector<string>().swap(row);
     }
+    lap("headers");
     {
-        xmfa.flush();
-        long long at = (long long)xmfa.tellp();
-        xmfa.close();
-        vector<long long> where(a.lcbs.size(), 0);
-        for (size_t z = 0; z < a.lcbs.size(); z++) { where[z] = at; at += (long long)text[z].size(); }
-        const string path = dir + stem + ".xmfa";
-        const int fd = open(path.c_str(), O_WRONLY);
-        if (fd < 0 || ftruncate(fd, (off_t)at) != 0) { cerr << "parsnp_core: cannot write " << path << endl; exit(1); }
-        int bad = 0;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(| : bad)
-        for (long zz = 0; zz < nz; zz++) {
-            const string& t = text[(size_t)zz];
-            size_t done = 0;
-            while (done < t.size()) {
-                const ssize_t w = pwrite(fd, t.data() + done, t.size() - done, (off_t)(where[(size_t)zz] + (long long)done));
-                if (w <= 0) { bad = 1; break; }
-                done += (size_t)w;
+        long long at = text_at;
+        vector<long long> where((size_t)nl, 0);
+        for (size_t z = 0; z < (size_t)nl; z++) { where[z] = at; at += bytes[z]; }
+        const string& path = xmfa_path;
+        char* map = nullptr;
+        if (reserve_done.valid() && reserve_done.get()) {
+            if (at > reserved && fallocate(fd, 0, (off_t)reserved, (off_t)(at - reserved)) != 0) { cerr << "parsnp_core: cannot write " << path << endl; exit(1); }
+            if (at > 0) {
+                void* m = mmap(nullptr, (size_t)at, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                if (m != MAP_FAILED) map = (char*)m;
             }
         }
-        if (close(fd) != 0 || bad) { cerr << "parsnp_core: error writing " << path << endl; exit(1); }
+        if (ftruncate(fd, (off_t)at) != 0) { cerr << "parsnp_core: cannot write " << path << endl; exit(1); }
+        if (dbg) fprintf(stderr, "[output] %lld MB through %s\n", at >> 20, map ? "a shared mapping" : "positioned writes");
+        // work items: a slow LCB's text, or a run of rows of a streamed LCB (about 1 MB of file each; the rows of one LCB
+        // have one size, so every row's place follows from its number)
+        struct Item { size_t z; size_t i0, i1; };
+        vector<Item> items;
+        for (size_t z = 0; z < (size_t)nl; z++) {
+            if (!printed[z]) continue;
+            if (slow[z]) { items.push_back(Item{z, 0, 0}); continue; }
+            const long long rowb = wrapped(plan[z].cols) + 48;
+            const size_t per = (size_t)std::max<long long>(1, ((long long)1 << 20) / rowb);
+            for (size_t i0 = 0; i0 < n; i0 += per) items.push_back(Item{z, i0, std::min(n, i0 + per)});
+        }
+        static const struct Low { char low[256], rc[256]; Low() {
+            for (int c = 0; c < 256; c++) { low[c] = (char)tolower(c); rc[c] = (char)tolower((unsigned char)U.rcu[c]); }
+        } } Lw;
+        int bad = 0;
+        const long ni = (long)items.size();
+#pragma omp parallel num_threads(threads) reduction(| : bad)
+        {
+            // a thread's buffer: filled with wrapped text, written out with positioned writes whenever it is nearly full
+            constexpr size_t kBuf = (size_t)1 << 18, kPiece = 4096;
+            vector<char> buf(kBuf + 2 * kPiece);
+            size_t w = 0; long long off = 0; int col = 0; long long produced = 0;
+            auto flush = [&] {
+                size_t done = 0;
+                if (map) { memcpy(map + off, buf.data(), w); done = w; }
+                while (done < w) {
+                    const ssize_t k = pwrite(fd, buf.data() + done, w - done, (off_t)(off + (long long)done));
+                    if (k <= 0) { bad = 1; break; }
+                    done += (size_t)k;
+                }
+                off += (long long)w; w = 0;
+            };
+            // `len` sequence characters src[0..len) through `table`, forwards or backwards, with a line end before every 81st
+            auto put = [&](const char* src, size_t len, const char* table, bool backwards) {
+                produced += (long long)len;
+                size_t x = 0;
+                while (x < len) {
+                    if (w >= kBuf) flush();
+                    size_t piece = std::min(len - x, kPiece);
+                    while (piece) {
+                        if (col == 80) { buf[w++] = '\n'; col = 0; }
+                        const size_t k = std::min(piece, (size_t)(80 - col));
+                        if (!table) memcpy(&buf[w], src + x, k);
+                        else if (!backwards) for (size_t y = 0; y < k; y++) buf[w + y] = table[(unsigned char)src[x + y]];
+                        else for (size_t y = 0; y < k; y++) { const char c = table[(unsigned char)src[len - 1 - (x + y)]]; buf[w + y] = c; if (!c) bad = 2; }
+                        w += k; x += k; col += (int)k; piece -= k;
+                    }
+                }
+            };
+            auto fill = [&](char c, size_t len) {
+                produced += (long long)len;
+                while (len) {
+                    if (w >= kBuf) flush();
+                    if (col == 80) { buf[w++] = '\n'; col = 0; }
+                    const size_t k = std::min(std::min(len, (size_t)(80 - col)), kPiece);
+                    memset(&buf[w], c, k); w += k; col += (int)k; len -= k;
+                }
+            };
+            vector<char> gbuf;
+#pragma omp for schedule(dynamic, 1)
+            for (long it = 0; it < ni; it++) {
+                const Item& item = items[(size_t)it];
+                const size_t z = item.z;
+                if (slow[z]) {
+                    const string& t = text[z];
+                    size_t done = 0;
+                    if (map) { memcpy(map + where[z], t.data(), t.size()); done = t.size(); }
+                    while (done < t.size()) {
+                        const ssize_t k = pwrite(fd, t.data() + done, t.size() - done, (off_t)(where[z] + (long long)done));
+                        if (k <= 0) { bad = 1; break; }
+                        done += (size_t)k;
+                    }
+                    continue;
+                }
+                const Lcb& ct = a.lcbs[z];
+                const Plan& pl = plan[z];
+                const Mum& first = a.pool[(size_t)ct.mums[0]];
+                const long long rowb = wrapped(pl.cols);
+                const size_t T = ct.mums.size();
+                w = 0; col = 0;
+                off = where[z] + (long long)(item.i0 ? head_end[z][item.i0 - 1] : 0) + (long long)item.i0 * rowb;
+                for (size_t i = item.i0; i < item.i1; i++) {
+                    const uint32_t h0 = i ? head_end[z][i - 1] : 0, h1 = head_end[z][i];
+                    if (w + (h1 - h0) >= kBuf) flush();
+                    memcpy(&buf[w], heads[z].data() + h0, h1 - h0); w += h1 - h0;
+                    col = 0; produced = 0;
+                    const char* g = a.genomes[i].seq.data();
+                    const bool fw = first.fwd[i] != 0;
+                    for (size_t t = 0; t < T; t++) {
+                        const Mum& m = a.pool[(size_t)ct.mums[t]];
+                        // a MUM's text, lower case, the reverse complement for a reverse member
+                        put(g + m.start[i], (size_t)m.length, fw ? Lw.low : Lw.rc, !fw);
+                        if (t + 1 == T) break;
+                        const long gc = pl.gcols[t];
+                        size_t len = 0;
+                        const char* r = pl.gjob[t] >= 0 ? aligned_row(jobs[(size_t)pl.gjob[t]], i, &len) : nullptr;
+                        if (r) { put(r, len, nullptr, false); continue; }
+                        if (gc == 0) continue;
+                        if (gbuf.size() < (size_t)gc + 8) gbuf.resize((size_t)gc + 8);
+                        len = gap_text(ct, t, i, gbuf.data());          // left-justified, '-' padded
+                        put(gbuf.data(), len, nullptr, false);
+                        fill('-', (size_t)gc - len);
+                    }
+                    buf[w++] = '\n';
+                    if (produced != pl.cols) bad = 2;                     // (a dropped character: cannot happen with ingest()'s alphabet)
+                }
+                if (item.i1 == n) { buf[w++] = '='; buf[w++] = '\n'; }
+                flush();
+                const long long end = where[z] + (long long)head_end[z][item.i1 - 1] + (long long)item.i1 * rowb + (item.i1 == n ? 2 : 0);
+                if (off != end) bad = 2;
+            }
+        }
+        if (map && munmap(map, (size_t)at) != 0) bad = 1;
+        if (close(fd) != 0 || bad) { cerr << "parsnp_core: error writing " << path << (bad == 2 ? " (record sizes)" : "") << endl; exit(1); }
     }
 
     lap("xmfa records");

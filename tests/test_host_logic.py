@@ -169,6 +169,37 @@ def test_threaded_validation_same_result(cpu_checkers, tmp_path, name, par_min):
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 
 
+@pytest.mark.parametrize("plain", [False, True, "mix", "pwrite"])
+@pytest.mark.parametrize("name", ["mers", "rearr6x300k", "poprearr10x400k", "messy", "draft8x300k"])
+def test_streamed_and_plain_records_agree(cpu_checkers, tmp_path, name, plain):
+    """the XMFA records are streamed into their places in the file from the MUM table and the gap alignments (sizes
+    first); an LCB that has to be trimmed against its predecessor, and everything under PARSNP_PLAIN_OUTPUT=1, is built
+    as strings the way the reference does it (parsnp.cpp:663-1071).  Both routes, several threads: the golden bytes."""
+    if name == "mers":
+        rp, qs = mers(base=str(tmp_path)); kw = {}
+    else:
+        rp, qs, kw = harsh_inputs(name, str(tmp_path))
+    out = str(tmp_path / "out")
+    env = dict(os.environ, PARSNP_DEBUG_TIMERS="1")
+    if plain == "mix":
+        env["PARSNP_OUTPUT_MIX"] = "3"     # every third LCB is turned into strings late, as one that needs the trim is
+    elif plain == "pwrite":
+        env["PARSNP_OUTPUT_PWRITE"] = "1"  # positioned writes instead of the shared mapping (a file system that cannot reserve)
+    elif plain:
+        env["PARSNP_PLAIN_OUTPUT"] = "1"
+    rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, threads=3, **kw)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
+    import re
+    m = re.search(r"\[output\] (\d+) LCBs printed: (\d+) streamed, (\d+) as strings", open(os.path.join(out, "parsnp-aligner.err")).read())
+    assert m and int(m.group(1)) > 0
+    assert (int(m.group(2)) == 0) if plain is True else (int(m.group(2)) > 0)
+    if plain == "mix":
+        assert int(m.group(3)) > 0
+    err = open(os.path.join(out, "parsnp-aligner.err")).read()
+    assert ("through positioned writes" in err) if plain in (True, "pwrite") else ("through a shared mapping" in err)
+
+
 MUMI = json.load(open(os.path.join(G, "mumi.json")))
 
 
