@@ -149,8 +149,9 @@ int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t 
  *   max_cols[j], row_off[j]    row capacity of job j and where its rows go: sequence i of job j is written to
  *                              out_rows[row_off[j] + i*max_cols[j] ..], cols[j] columns of it
  *   cols[j] = -1               the device declined the job (more than 512 sequences, an intermediate alignment wider than
- *                              96 columns or than max_cols[j], an empty sequence, or a case in which MUSCLE itself quits):
- *                              the caller aligns it on the host
+ *                              96 columns or than max_cols[j], an empty sequence, a lower-case letter or a 'U' -- its rows
+ *                              are kept as one code byte per column, which round-trips upper-case DNA without 'U' -- or a
+ *                              case in which MUSCLE itself quits): the caller aligns it on the host
  * device < 0: PARSNP_DEVICE or the current device.  Returns PM_OK or a PM_E* code (pm_gap_last_error()). */
 int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
                        const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols);

@@ -95,6 +95,13 @@ constexpr int kProfStages = 16;
 #define GA_SYNC() do { __builtin_amdgcn_s_waitcnt(0); __threadfence_block(); __syncthreads(); } while (0)
 __device__ inline unsigned tri(unsigned a, unsigned b) { return a >= b ? b + (a * (a - 1)) / 2 : a + (b * (b - 1)) / 2; }
 __device__ inline bool is_gap(uint8_t c) { return c == '-' || c == '.'; }
+// A row in LDS holds one byte per column: MUSCLE's letter code (alpha.cpp:125-166: 0..3 = ACGT, 4..15 wildcards in the
+// order MRWSYKVHDBXN), kRowGap for '-', and two flags a profile needs of a gap column: the row's gap starts here / ends
+// here (profilefrommsa.cpp:262-331 asks the neighbouring columns).  Upper-case input without 'U' round-trips through it;
+// anything else is declined.
+constexpr uint8_t kRowGap = 16, kRowCode = 0x1f, kRowStart = 0x40, kRowEnd = 0x80;
+__device__ inline bool row_gap(uint8_t b) { return (b & kRowCode) == kRowGap; }
+__device__ inline uint8_t row_char(uint8_t b) { const uint8_t c = b & kRowCode; return c == kRowGap ? (uint8_t)'-' : (uint8_t)"ACGTMRWSYKVHDBXN"[c]; }
 
 __device__ inline int wave_sum(int x) { for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64); return x; }
 // arg-min over (value, index): strictly smaller value wins, equal values -> the lower index (a sequential scan that
@@ -116,9 +123,10 @@ struct __align__(16) Shared {
             float fa[4][kMaxCols]; uint8_t orda[kMaxCols]; float opena[kMaxCols], closea[kMaxCols];   // profile A: sorted counts, their letters
             float sb[4][kMaxCols]; float openb[kMaxCols], closeb[kMaxCols];                           // profile B: scores per letter
             float bD[kMaxCols + 2], bM[kMaxCols + 2], bN[kMaxCols + 2]; uint8_t bX[kMaxCols + 2];     // row handed from one 64-row stripe to the next
-            uint8_t path[2 * kMaxCols + 2];
+            uint8_t path[2 * kMaxCols + 2], rev[2 * kMaxCols + 2];
             int16_t mapa[2 * kMaxCols + 2], mapb[2 * kMaxCols + 2];
         float result[3];
+        float acc[6][kMaxCols];      // a column's six sums (four letters, gap opened here, gap closed here) before they are gathered
     } p;
   };
     uint8_t letter[256];       // alpha.cpp:125-166 (c_letter, copied: a table in constant memory costs a trip to memory per lane)
@@ -131,48 +139,53 @@ struct __align__(16) Shared {
 };
 
 // ---- profile of the alignment held by rows [lo, lo+ns) (nc columns) -> either the A arrays or the B arrays
-// R: the rows in LDS.  A column's sums run over the rows one after the other (float: the order is part of the result);
-// eight rows are fetched at a time so that the adds do not wait for one LDS access each.
+// R: the rows in LDS.  Each of a column's six sums runs over the rows one after the other (float: the order is part of the
+// result) and the sums do not meet, so each gets a lane of its own: one masked compare and one add per row, eight rows
+// fetched at a time.  A row that does not touch a sum adds +0, which changes nothing (the sums are never negative).
+// kWild: some sequence of the job holds a wildcard (N, ...); without one the per-row test for it is not compiled in.
+template <bool kWild>
 __device__ void build_profile(Shared& S, const uint8_t* R, int cap, int lo, int ns, int nc, float total, bool as_a) {
     const int lane = (int)__lane_id();
     // msa2.cpp:418-431 + msa.cpp:369-381: this alignment's weights, rescaled to sum 1.  `total` is the sequential float sum
     // of the weights in MSA order, kept per node: a merged alignment's rows are A's then B's, so its sum continues A's.
     const float f = total != 0 ? 1.0f / total : 1.0f;
     const bool scale = total != 0;
+    const int items = nc * 6;
+    for (int i0 = 0; i0 < items; i0 += 64) {
+        const int item = i0 + lane;
+        const bool on = item < items;
+        const int c = on ? item / 6 : 0, kind = on ? item - c * 6 : 0;
+        const uint32_t cmask = kind < 4 ? (uint32_t)kRowCode : (kind == 4 ? (uint32_t)kRowStart : (uint32_t)kRowEnd);
+        const uint32_t cval = kind < 4 ? (uint32_t)kind : cmask;
+        const uint8_t* col = R + (size_t)lo * (size_t)cap + c;
+        float acc = 0;
+        auto fold = [&](uint32_t b, float ws) {
+            if (scale) ws *= f;
+            float add = (b & cmask) == cval ? ws : 0.0f;
+            if (kWild) {
+                const uint32_t code = b & kRowCode;
+                if (code >= 4 && code < kRowGap && kind < 4)        // a wildcard: 'X' is half G half A, the others a twentieth of each
+                    add = code == 14 ? ((kind == 2 || kind == 0) ? ws / 2 : 0.0f) : ws / 20;
+            }
+            acc += add;
+        };
+        int s0 = 0;
+        for (; s0 + 8 <= ns; s0 += 8) {
+            uint32_t b[8]; float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { b[k] = col[(size_t)(s0 + k) * (size_t)cap]; w[k] = S.wrow[lo + s0 + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) fold(b[k], w[k]);
+        }
+        for (; s0 < ns; s0++) fold(col[(size_t)s0 * (size_t)cap], S.wrow[lo + s0]);
+        if (on) S.p.acc[kind][c] = acc;
+    }
+    GA_SYNC();
     for (int c0 = 0; c0 < nc; c0 += 64) {
         const int c = c0 + lane;
         if (c < nc) {
-            float cnt[4] = {0, 0, 0, 0}, start = 0, end = 0;
-            const bool first_col = c == 0, last_col = c + 1 == nc;
-            const uint8_t* col = R + (size_t)lo * (size_t)cap + c;
-            auto fold = [&](uint8_t ch, uint8_t before, uint8_t after, float ws) {
-                if (scale) ws *= f;
-                if (is_gap(ch)) {
-                    if (first_col || !is_gap(before)) start += ws;
-                    if (last_col || !is_gap(after)) end += ws;
-                    return;
-                }
-                const uint8_t l = S.letter[ch];
-                if (l < 4) cnt[l] += ws;
-                else if (l == 14) { cnt[2] += ws / 2; cnt[0] += ws / 2; }
-                else { const float q = ws / 20; cnt[0] += q; cnt[1] += q; cnt[2] += q; cnt[3] += q; }
-            };
-            int s0 = 0;
-            for (; s0 + 8 <= ns; s0 += 8) {
-                uint8_t ch[8], pv[8], nx[8]; float w[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const uint8_t* q = col + (size_t)(s0 + k) * (size_t)cap;
-                    ch[k] = q[0]; pv[k] = first_col ? (uint8_t)'A' : q[-1]; nx[k] = last_col ? (uint8_t)'A' : q[1];
-                    w[k] = S.wrow[lo + s0 + k];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) fold(ch[k], pv[k], nx[k], w[k]);
-            }
-            for (; s0 < ns; s0++) {
-                const uint8_t* q = col + (size_t)s0 * (size_t)cap;
-                fold(q[0], first_col ? (uint8_t)'A' : q[-1], last_col ? (uint8_t)'A' : q[1], S.wrow[lo + s0]);
-            }
+            float cnt[4] = {S.p.acc[0][c], S.p.acc[1][c], S.p.acc[2][c], S.p.acc[3][c]};
+            const float start = S.p.acc[4][c], end = S.p.acc[5][c];
             unsigned order[4] = {0, 1, 2, 3};       // profilefrommsa.cpp:180-204: bubble sort, strict <
             bool any = true;
             for (int pass = 0; any && pass < 8; pass++) {     // at most 3 passes move anything
@@ -240,12 +253,20 @@ __device__ bool nw_small(Shared& S, uint8_t* TB, int la, int lb, int* plen, bool
         float lastD = kMinusInf, lastM = kMinusInf, lastI = kMinusInf;   // D[i][j-1]: unused; M[i][j-1]; I[i][j-1]
         float q1 = 0, q2 = 0; uint8_t x1 = 0, x2 = 0;                     // M[i+1][j+1] produced one / two steps ago
         float outD = kMinusInf, outM = kMinusInf;                         // D[i][j], M[i][j] of the last step (for the lane below)
+        const float closea0 = S.p.closea[0];
         for (int t = 0; t < rows_here + lb - 1; t++) {
+            const int j = t - lane + 1;
+            const bool act = row_ok && j >= 1 && j <= lb;
+            // everything this step reads from the profiles depends on (i, j) alone, not on the cells before it: asked for
+            // first (indices clamped for the lanes that sit out), so that these reads and the exchange with the lane above
+            // are in flight together -- one wait per step for a wavefront that has the SIMD nearly to itself
+            const int jc = j < 1 ? 1 : (j > lb ? lb : j);
+            const float ob = S.p.openb[jc - 1], cb = S.p.closeb[jc - 1], cb2 = S.p.closeb[jc >= 2 ? jc - 2 : 0];
+            const float mc = match_ab(S, fr, ordr, jc - 1);                       // this cell's own match score (column 1 and row 1 start from it)
+            const float mn = match_ab(S, fn, ordn, jc < lb ? jc : lb - 1);        // the match score of the cell below and to the right
             // what the lane above produced: at its last step (up) and two steps ago (diagonal)
             float upD = __shfl_up(outD, 1, 64), upM = __shfl_up(outM, 1, 64), dgM = __shfl_up(q2, 1, 64);
             uint8_t dgX = (uint8_t)__shfl_up((int)x2, 1, 64);
-            const int j = t - lane + 1;
-            const bool act = row_ok && j >= 1 && j <= lb;
             if (lane == 0 && act) {
                 if (r0 == 0) { upD = kMinusInf; upM = kMinusInf; }        // row 0: M[0][j] = D[0][j] = -inf for j >= 1
                 else { upD = S.p.bD[j]; upM = S.p.bM[j]; dgM = S.p.bN[j]; dgX = S.p.bX[j]; }
@@ -255,13 +276,13 @@ __device__ bool nw_small(Shared& S, uint8_t* TB, int la, int lb, int* plen, bool
                 float m; uint8_t xm;
                 if (j == 1) {
                     if (i == la) {
-                        if (la > 1) m = match_ab(S, fr, ordr, 0) + (la - 2) * e + open_a0 + close_am2;
-                        else m = match_ab(S, fr, ordr, 0) + open_a0 + S.p.closea[0];
+                        if (la > 1) m = mc + (la - 2) * e + open_a0 + close_am2;
+                        else m = mc + open_a0 + closea0;
                         xm = kDM;
-                    } else if (i == 1) { m = match_ab(S, fr, ordr, 0); xm = kMM; }
-                    else { m = match_ab(S, fr, ordr, 0) + open_a0 + (i - 2) * e + close_am2; xm = kDM; }
+                    } else if (i == 1) { m = mc; xm = kMM; }
+                    else { m = mc + open_a0 + (i - 2) * e + close_am2; xm = kDM; }
                 } else if (i == 1) {
-                    m = match_ab(S, fr, ordr, j - 1) + open_b0 + (j - 2) * e + S.p.closeb[j - 2]; xm = kIM;
+                    m = mc + open_b0 + (j - 2) * e + cb2; xm = kIM;
                 } else { m = dgM; xm = dgX; }
                 // REC_D
                 const float dd = upD + e, md = upM + open_a;
@@ -270,15 +291,15 @@ __device__ bool nw_small(Shared& S, uint8_t* TB, int la, int lb, int* plen, bool
                 // REC_I
                 float iij = j == 1 ? kMinusInf : lastI;
                 iij += e;
-                const float mi = (j == 1 ? kMinusInf : lastM) + S.p.openb[j - 1];
+                const float mi = (j == 1 ? kMinusInf : lastM) + ob;
                 const bool open_i = mi >= iij;
                 const float I = open_i ? mi : iij;
                 TB[i * stride + j] = (uint8_t)(xm | (from_m ? kMD : 0) | (open_i ? kMI : 0));
                 if (i < la && j < lb) {
-                    const float dm = D + close_a, im = I + S.p.closeb[j - 1], mm = m;
+                    const float dm = D + close_a, im = I + cb, mm = m;
                     const bool pm = mm >= dm && mm >= im;
                     const bool pd = !pm && dm >= mm && dm >= im;
-                    float nx = match_ab(S, fn, ordn, j);
+                    float nx = mn;
                     nx += pm ? mm : (pd ? dm : im);
                     q1 = nx; x1 = pm ? kMM : (pd ? kDM : kIM);
                 }
@@ -294,39 +315,31 @@ __device__ bool nw_small(Shared& S, uint8_t* TB, int la, int lb, int* plen, bool
     bool ok = true;
     if (lane == 0) {
         const float mab = S.p.result[0], dab = S.p.result[1], iab = S.p.result[2];
-        float score = mab; char type = 'M';
-        if (dab > score) { score = dab; type = 'D'; }
-        if (iab > score) { score = iab; type = 'I'; }
+        float score = mab; int type = 0;                  // 0 'M', 1 'D', 2 'I': the codes of the trace-back bits (kMM, kDM, kIM)
+        if (dab > score) { score = dab; type = 1; }
+        if (iab > score) { score = iab; type = 2; }
         int a = la, b = lb, n = 0;
-        uint8_t* rev = S.p.path;
-        for (;;) {
+        uint8_t* rev = S.p.rev;        // end to start, as the trace-back meets the cells
+        for (;;) {                     // one dependent LDS read per cell: the rest is selects, not branches
             if (n >= 2 * kMaxCols + 2) { ok = false; break; }
-            rev[n++] = (uint8_t)type;
-            const uint8_t bits = TB[a * stride + b];
-            char next;
-            if (type == 'M') {
-                const uint8_t x = bits & kXM;
-                if (x == kMM) next = 'M'; else if (x == kDM) next = 'D'; else if (x == kIM) next = 'I'; else { ok = false; break; }
-                if (a == 0 || b == 0) { ok = false; break; }
-                --a; --b;
-            } else if (type == 'D') {
-                next = (bits & kMD) ? 'M' : 'D';
-                if (a == 0) { ok = false; break; }
-                --a;
-            } else {
-                next = (bits & kMI) ? 'M' : 'I';
-                if (b == 0) { ok = false; break; }
-                --b;
-            }
+            rev[n++] = type == 0 ? (uint8_t)'M' : (type == 1 ? (uint8_t)'D' : (uint8_t)'I');
+            const uint32_t bits = TB[a * stride + b];
+            const uint32_t x = bits & kXM;
+            const int next = type == 0 ? (int)x : (type == 1 ? ((bits & kMD) ? 0 : 1) : ((bits & kMI) ? 0 : 2));
+            const int need_a = type != 2, need_b = type != 1;
+            if ((type == 0 && x == 3) || (need_a && a == 0) || (need_b && b == 0)) { ok = false; break; }
+            a -= need_a; b -= need_b;
             if (a == 0 && b == 0) break;
             type = next;
         }
-        for (int x = 0; x < n / 2; x++) { const uint8_t tmp = rev[x]; rev[x] = rev[n - 1 - x]; rev[n - 1 - x] = tmp; }
         S.flag = ok ? n : -1;
     }
     GA_SYNC();
-    *plen = S.flag;
-    return S.flag >= 0;
+    const int n = S.flag;
+    for (int x = lane; x < n; x += 64) S.p.path[x] = S.p.rev[n - 1 - x];
+    GA_SYNC();
+    *plen = n;
+    return n >= 0;
 }
 
 #define GA_STAGE(stage_) do { if (P.dbg && lane == 0) P.dbg[blockIdx.x * 2 + 1] = (stage_); } while (0)
@@ -340,17 +353,24 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
     unsigned long long prof_t0 = P.prof ? (unsigned long long)clock64() : 0;
     if (n < 2 || n > kMaxSeqs) return false;
     // ---- sequences: lengths, FixAlpha (seq.cpp:331-344) happens when the rows are filled
-    int bad = 0;
+    int bad = 0, wild = 0;
     for (int i = lane; i < n; i += 64) {
         const int64_t a = P.seq_off[job.first_seq + i], b = P.seq_off[job.first_seq + i + 1];
         const int L = (int)(b - a);
         W.len[i] = L;
         if (L <= 0 || L > cap || L > kMaxCols) bad = 1;
         uint64_t h = 1469598103934665603ull;
-        for (int x = 0; x < L; x++) { uint8_t ch = P.chars[a + x]; if (S.letter[ch] >= 16) ch = 'N'; h = (h ^ ch) * 1099511628211ull; }
+        for (int x = 0; x < L; x++) {
+            uint8_t ch = P.chars[a + x];
+            if (S.letter[ch] >= 16) ch = 'N';
+            else if (ch >= 'a' || ch == 'U') bad = 1;
+            if (S.letter[ch] >= 4) wild = 1;            // the row coding holds upper-case letters without 'U' (the caller's host path takes the rest)
+            h = (h ^ ch) * 1099511628211ull;
+        }
         W.hash[i] = h ^ (uint64_t)L;
     }
     if (wave_sum(bad)) return false;
+    const bool any_wild = wave_sum(wild) != 0;
     GA_SYNC();
     auto seq_char = [&](int i, int x) -> uint8_t { uint8_t ch = P.chars[P.seq_off[job.first_seq + i] + x]; return S.letter[ch] >= 16 ? (uint8_t)'N' : ch; };
 
@@ -547,7 +567,8 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
         const int i = W.perm[p], L = W.len[i];
         uint8_t* row = R + (size_t)p * (size_t)cap;
         const int64_t a0 = P.seq_off[job.first_seq + i];
-        for (int x = 0; x < L; x++) { const uint8_t ch = P.chars[a0 + x]; row[x] = S.letter[ch] >= 16 ? (uint8_t)'N' : ch; }
+        for (int x = 0; x < L; x++) { const uint8_t l = S.letter[P.chars[a0 + x]]; row[x] = l >= 16 ? (uint8_t)15 : l; }      // FixAlpha (seq.cpp:331-344): anything else is an 'N'
+
         S.wrow[p] = W.weight[i]; S.rowlen[p] = (uint8_t)L;
     }
     GA_SYNC();
@@ -575,25 +596,31 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
         if (la <= 0 || lb <= 0 || la > kMaxCols || lb > kMaxCols) return false;
         GA_STAGE(100 + (int)(v - un) * 10);
         GA_CLOCK(8);
-        build_profile(S, R, cap, loa, nsa, la, total_a, true);
-        build_profile(S, R, cap, lob, nsb, lb, total_b, false);
+        if (any_wild) { build_profile<true>(S, R, cap, loa, nsa, la, total_a, true); build_profile<true>(S, R, cap, lob, nsb, lb, total_b, false); }
+        else { build_profile<false>(S, R, cap, loa, nsa, la, total_a, true); build_profile<false>(S, R, cap, lob, nsb, lb, total_b, false); }
         int plen = 0;
         GA_STAGE(101 + (int)(v - un) * 10); GA_CLOCK(13);
         if (!nw_small(S, TB, la, lb, &plen, P.prof != nullptr, prof_acc[9], prof_t0)) return false;
         GA_STAGE(102 + (int)(v - un) * 10); GA_CLOCK(10);
         if (plen > cap || plen > kMaxCols) return false;
         // aligngivenpath.cpp:124-255: a column of A, of B, or of both
-        if (lane == 0) {
-            int ca = 0, cb = 0; bool ok = true;
-            for (int c = 0; c < plen; c++) {
-                const uint8_t t = S.p.path[c];
-                if (t != 'I') { if (ca >= la) ok = false; S.p.mapa[c] = (int16_t)ca; ca++; } else S.p.mapa[c] = -1;
-                if (t != 'D') { if (cb >= lb) ok = false; S.p.mapb[c] = (int16_t)cb; cb++; } else S.p.mapb[c] = -1;
+        // (a column's place in A / in B = the number of A / B columns before it: counted with ballots)
+        {
+            int ca = 0, cb = 0;
+            for (int c0 = 0; c0 < plen; c0 += 64) {
+                const int c = c0 + lane;
+                const uint8_t t = c < plen ? S.p.path[c] : (uint8_t)0;
+                const bool in_a = c < plen && t != 'I', in_b = c < plen && t != 'D';
+                const unsigned long long ma = __ballot(in_a), mb = __ballot(in_b), below = (1ull << lane) - 1;
+                if (c < plen) {
+                    S.p.mapa[c] = in_a ? (int16_t)(ca + __popcll(ma & below)) : (int16_t)-1;
+                    S.p.mapb[c] = in_b ? (int16_t)(cb + __popcll(mb & below)) : (int16_t)-1;
+                }
+                ca += __popcll(ma); cb += __popcll(mb);
             }
-            S.flag = (ok && ca == la && cb == lb) ? 1 : 0;
+            GA_SYNC();
+            if (ca != la || cb != lb) return false;
         }
-        GA_SYNC();
-        if (!S.flag) return false;
         // rows re-spelled in place through the column maps.  An input with no column inserted keeps its rows as they are
         // (the map is the identity): when one sequence joins a large alignment, that is usually the large one.  Every lane
         // reads its (at most two) characters of a row before any lane writes: one wavefront, LDS operations in program order.
@@ -603,26 +630,35 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
             const int ma1 = c1 < plen ? S.p.mapa[c1] : -1, ma2 = c2 < plen ? S.p.mapa[c2] : -1;
             const int mb1 = c1 < plen ? S.p.mapb[c1] : -1, mb2 = c2 < plen ? S.p.mapb[c2] : -1;
             auto respell = [&](int p0, int np, int m1, int m2) {
-                int s0 = 0;
-                for (; s0 + 4 <= np; s0 += 4) {
-                    uint8_t v1[4], v2[4];
+                // four rows at a time: their new codes, written; then, for the gap columns, the codes next to them (now in
+                // place) say whether the row's gap starts / ends here (the flags a profile reads, see kRowStart)
+                for (int s0 = 0; s0 < np; s0 += 4) {
+                    uint8_t v1[4], v2[4], l1[4], r1[4], l2[4], r2[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const uint8_t* row = R + (size_t)(p0 + s0 + k) * (size_t)cap;
-                        v1[k] = m1 >= 0 ? row[m1] : (uint8_t)'-'; v2[k] = m2 >= 0 ? row[m2] : (uint8_t)'-';
+                        const uint8_t* row = R + (size_t)(p0 + (s0 + k < np ? s0 + k : np - 1)) * (size_t)cap;
+                        v1[k] = m1 >= 0 ? (uint8_t)(row[m1] & kRowCode) : kRowGap; v2[k] = m2 >= 0 ? (uint8_t)(row[m2] & kRowCode) : kRowGap;
                     }
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
+                        if (s0 + k >= np) continue;
                         uint8_t* row = R + (size_t)(p0 + s0 + k) * (size_t)cap;
                         if (c1 < plen) row[c1] = v1[k];
                         if (c2 < plen) row[c2] = v2[k];
                     }
-                }
-                for (; s0 < np; s0++) {
-                    uint8_t* row = R + (size_t)(p0 + s0) * (size_t)cap;
-                    const uint8_t v1 = m1 >= 0 ? row[m1] : (uint8_t)'-', v2 = m2 >= 0 ? row[m2] : (uint8_t)'-';
-                    if (c1 < plen) row[c1] = v1;
-                    if (c2 < plen) row[c2] = v2;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint8_t* row = R + (size_t)(p0 + (s0 + k < np ? s0 + k : np - 1)) * (size_t)cap;
+                        l1[k] = c1 > 0 && c1 < plen ? row[c1 - 1] : (uint8_t)0; r1[k] = c1 + 1 < plen ? row[c1 + 1] : (uint8_t)0;
+                        l2[k] = c2 < plen ? row[c2 - 1] : (uint8_t)0; r2[k] = c2 + 1 < plen ? row[c2 + 1] : (uint8_t)0;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (s0 + k >= np) continue;
+                        uint8_t* row = R + (size_t)(p0 + s0 + k) * (size_t)cap;
+                        if (c1 < plen && v1[k] == kRowGap) row[c1] = (uint8_t)(kRowGap | (row_gap(l1[k]) ? 0 : kRowStart) | (row_gap(r1[k]) ? 0 : kRowEnd));
+                        if (c2 < plen && v2[k] == kRowGap) row[c2] = (uint8_t)(kRowGap | (row_gap(l2[k]) ? 0 : kRowStart) | (row_gap(r2[k]) ? 0 : kRowEnd));
+                    }
                 }
             };
             if (plen != la) respell(loa, nsa, ma1, ma2);
@@ -643,7 +679,7 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
     for (int p = lane; p < n; p += 64) {              // a lane per row: its place in the output comes from one load
         const uint8_t* src = R + (size_t)p * (size_t)cap;
         uint8_t* dst = P.out_rows + job.row_off + (int64_t)W.perm[p] * job.max_cols;
-        for (int c = 0; c < nc; c++) dst[c] = src[c];
+        for (int c = 0; c < nc; c++) dst[c] = row_char(src[c]);
     }
     *out_cols = nc;
     GA_CLOCK(12);

@@ -54,7 +54,9 @@ def device():
 
 
 def fits(block):
-    return len(block) >= 2 and all(0 < len(s) <= DEVICE_COLS for s in block)
+    # the device's documented limits (include/parsnp_mum.h): widths, and an alphabet its one-byte row coding round-trips --
+    # upper-case letters without 'U' (parsnp's ingest emits ACGTN only); the caller's host path takes everything else
+    return len(block) >= 2 and all(0 < len(s) <= DEVICE_COLS for s in block) and not any(ch.islower() or ch == "U" for s in block for ch in s)
 
 
 def test_committed_vectors(device):
