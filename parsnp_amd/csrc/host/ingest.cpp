@@ -98,21 +98,45 @@ bool ingest(const std::string& path, bool is_ref, bool reverse, int d, Genome* g
     s.resize(data.size() > pos ? data.size() - pos : 0);      // a byte appends at most one base; contig padding grows it below
     size_t w = 0;
     const unsigned char* in = (const unsigned char*)data.data();
+    // Sequence bytes between two header lines go through a loop without branches: the byte's emission is stored and the
+    // write index moves on if it was one; what a byte is (for the base counts) comes out of a histogram of the raw bytes
+    // afterwards.  (Four histograms: consecutive bytes are often equal, and one counter would wait for its own store.)
+    uint32_t hist[4][256];
+    memset(hist, 0, sizeof hist);
+    auto flush_hist = [&] {
+        for (int ch = 0; ch < 256; ch++) { count[cls[ch]] += (long long)hist[0][ch] + hist[1][ch] + hist[2][ch] + hist[3][ch]; }
+        memset(hist, 0, sizeof hist);
+    };
     while (pos < data.size() && !failed) {
-        const unsigned char ch = in[pos++];
-        const unsigned char e = emit[ch];
-        if (e) { s[w++] = (char)e; count[cls[ch]]++; continue; }
-        if (cls[ch] != HEADER) continue;
+        const void* hit = memchr(in + pos, '>', data.size() - pos);
+        const size_t stop = hit ? (size_t)((const unsigned char*)hit - in) : data.size();
+        char* out = &s[0];
+        size_t x = pos;
+        for (; x + 4 <= stop; x += 4) {
+            const unsigned char c0 = in[x], c1 = in[x + 1], c2 = in[x + 2], c3 = in[x + 3];
+            hist[0][c0]++; hist[1][c1]++; hist[2][c2]++; hist[3][c3]++;
+            const unsigned char e0 = emit[c0], e1 = emit[c1], e2 = emit[c2], e3 = emit[c3];
+            out[w] = (char)e0; w += e0 != 0;
+            out[w] = (char)e1; w += e1 != 0;
+            out[w] = (char)e2; w += e2 != 0;
+            out[w] = (char)e3; w += e3 != 0;
+        }
+        for (; x < stop; x++) { const unsigned char c = in[x]; hist[0][c]++; const unsigned char e = emit[c]; out[w] = (char)e; w += e != 0; }
+        pos = stop;
+        if (!hit) break;
+        pos++;                                                 // the '>' itself: a header line follows
         read_line(nullptr);
+        flush_hist();
         if (!is_ref) {                                         // :3114-3118
             const size_t pad = (size_t)(d + 10);
-            if (s.size() < w + pad + (data.size() - pos)) s.resize(w + pad + (data.size() - pos));
+            if (s.size() < w + pad + (data.size() - pos) + 1) s.resize(w + pad + (data.size() - pos) + 1);
             memset(&s[w], 'N', pad); w += pad;
             count[BASE_N] += d + 10; padding += d + 10;
         }
         seqcount++;
         g->pos2hdr[(int)(count[BASE_N] + count[BASE_C] + count[BASE_T] + count[BASE_U] + count[BASE_A] + count[BASE_G])] = "s" + std::to_string(seqcount);
     }
+    flush_hist();
     s.resize(w);
     const long long a = count[BASE_A], c = count[BASE_C], gg = count[BASE_G], t = count[BASE_T] + count[BASE_U], nn = count[BASE_N];
     if (reverse) std::reverse(s.begin(), s.end());

@@ -1,4 +1,6 @@
-timeout 240 python -m pytest tests/test_gpu_gapalign.py -x -q 2>&1 | tail -3
-timeout 300 python -m pytest tests/test_gpu_big.py -x -q -k "bact200" 2>&1 | tail -3
-PM_GAP_DEBUG=3 PARSNP_BENCH_LOG=gpurun_out/bench_laps.log PARSNP_DEBUG_TIMERS=1 timeout 200 python bench.py --steps 3 --warmup 1 --cpu-sample 0 2>/dev/null > gpurun_out/bench_out.json
-grep -E "^\[gap" gpurun_out/bench_laps.log | tail -22
+for t in 4 8 12; do
+PM_STAGE_THREADS=$t PARSNP_BENCH_LOG=gpurun_out/bench_laps_$t.log PARSNP_DEBUG_TIMERS=1 timeout 200 python bench.py --steps 3 --warmup 1 --cpu-sample 0 2>/dev/null > gpurun_out/bench_out_$t.json
+grep -E "^\[upload\] stage" gpurun_out/bench_laps_$t.log
+python -c "
+import json; d=json.loads(open('gpurun_out/bench_out_$t.json').read().strip().splitlines()[-1]); print($t, d['ms_per_step'], 'ingest %.3f upload %.3f output %.3f' % (d['split_s']['ingest'], d['split_s']['upload'], d['split_s']['output']), d['cold'])"
+done
