@@ -137,7 +137,28 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
         }));
     if (getenv("PARSNP_SYNC_LAYOUT")) wait_layout();    // measurement switch: clear before anything else, as a plain constructor would
 }
+// The marks validate_parallel put off: genome by genome (a task owns its genomes' bitmaps: plain stores), the candidates in
+// list order.  Started by whoever gets there first -- extend_generations right before the recursion's first engine call,
+// whose wait they fill -- or by wait_layout().
+void Aligner::mark_stripe(size_t j0, size_t j1) {
+    const size_t ncand = deferred_.state.size();
+    const int32_t* srow = deferred_.rows;
+    for (size_t c = 0; c < ncand; c++) {
+        __builtin_prefetch(srow + (c + 24) * n + j0); __builtin_prefetch(srow + (c + 24) * n + j1 - 1);
+        if ((deferred_.state[c] & 24) != 16) continue;
+        const int32_t* st = srow + c * n; const long lon = deferred_.length[c];
+        for (size_t j = j0; j < j1; j++) layout[j].set_range_inside(st[j], st[j] + lon);
+    }
+}
+void Aligner::start_deferred_marks() {
+    if (!deferred_.pending) return;
+    deferred_.pending = false;
+    const size_t tasks = std::min<size_t>(n, (size_t)std::max(1, prm.cores));
+    for (size_t t = 0; t < tasks; t++)
+        layout_ready_.push_back(std::async(std::launch::async, [this, t, tasks] { mark_stripe(n * t / tasks, n * (t + 1) / tasks); }));
+}
 void Aligner::wait_layout() {
+    start_deferred_marks();
     if (layout_ready_.empty()) return;
     const double t = now_s();
     for (auto& f : layout_ready_) f.get();
@@ -629,9 +650,86 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     }
     lap("settle");
     // (the same pass notes whether the accepted clean candidates of a genome come one after the other: anchors_ordered_)
+    //
+    // Into an empty layout (the anchor call) the marks can wait: nothing reads them before the recursion's first list is
+    // validated -- except the flagged candidates below, which look at the bits of their OWN intervals.  If the accepted
+    // clean candidates lie in list order in every genome (a pass over the rows, candidate by candidate: contiguous reads)
+    // the ones that meet a flagged candidate's interval are found by bisection and marked now; the other 12 million
+    // intervals (200 x 5 Mb: 3.6 ms of all cores) are marked by background tasks that extend_generations() starts right
+    // before the recursion's first engine call, whose wait they fill.  PARSNP_MARK_FIRST=1 (test hook): never put off.
+    static const bool mark_first = getenv("PARSNP_MARK_FIRST") != nullptr;
     int disorder = 0;
+    bool put_off = false;
+    if (layout_empty && !mark_first && threads > 1) {
+        (void)rows_until(ncand);
+        const long kRun = 1024, nruns = (nc + kRun - 1) / kRun;
+        std::vector<long> first_acc((size_t)nruns, -1), last_acc((size_t)nruns, -1);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(| : disorder)
-    for (int t = 0; t < nstripes; t++) {
+        for (long rr = 0; rr < nruns; rr++) {
+            long prev = -1;
+            const long c1 = std::min(nc, (rr + 1) * kRun);
+            for (long c = rr * kRun; c < c1; c++) {
+                if ((state[(size_t)c] & 24) != 16) continue;
+                if (prev < 0) first_acc[(size_t)rr] = c;
+                else {
+                    const int32_t* a = srow + (size_t)prev * n; const int32_t* b = srow + (size_t)c * n;
+                    const long lp = cand[(size_t)prev].length;
+                    long bad = 0;
+                    for (size_t j = 0; j < n; j++) bad |= (long)b[j] - ((long)a[j] + lp);      // sign bit: starts before the previous one ends
+                    disorder |= bad < 0 ? 1 : 0;
+                }
+                prev = c;
+            }
+            last_acc[(size_t)rr] = prev;
+        }
+        long prev = -1;
+        for (long rr = 0; rr < nruns && !disorder; rr++) {
+            if (first_acc[(size_t)rr] < 0) continue;
+            if (prev >= 0) {
+                const int32_t* a = srow + (size_t)prev * n; const int32_t* b = srow + (size_t)first_acc[(size_t)rr] * n;
+                const long lp = cand[(size_t)prev].length;
+                for (size_t j = 0; j < n; j++) if ((long)b[j] < (long)a[j] + lp) { disorder = 1; break; }
+            }
+            prev = last_acc[(size_t)rr];
+        }
+        if (!disorder) {
+            put_off = true;
+            std::vector<uint32_t> acc_idx;
+            acc_idx.reserve(ncand);
+            for (size_t c = 0; c < ncand; c++) if ((state[c] & 24) == 16) acc_idx.push_back((uint32_t)c);
+            std::vector<uint32_t> flagged_now;
+            for (size_t c = 0; c < ncand; c++) if ((state[c] & 11) == 11) flagged_now.push_back((uint32_t)c);
+            const long nfl = (long)flagged_now.size();
+            const size_t nacc = acc_idx.size();
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+            for (long o = 0; o < nfl; o++) {
+                const Mum& f = cand[flagged_now[(size_t)o]];
+                if (f.length <= 0) continue;
+                for (size_t j = 0; j < n; j++) {
+                    const long s = f.start[j], e = s + f.length;
+                    size_t lo = 0, hi = nacc;                 // the first accepted clean candidate that ends after s (ends rise with the list)
+                    while (lo < hi) {
+                        const size_t mid = (lo + hi) / 2; const uint32_t c = acc_idx[mid];
+                        if ((long)srow[(size_t)c * n + j] + cand[c].length > s) hi = mid; else lo = mid + 1;
+                    }
+                    for (size_t k = lo; k < nacc; k++) {
+                        const uint32_t c = acc_idx[k];
+                        const long a = srow[(size_t)c * n + j];
+                        if (a >= e) break;
+                        layout[j].set_range_atomic(a, a + cand[c].length);
+                    }
+                }
+            }
+            deferred_.rows = srow;
+            deferred_.length.resize(ncand);
+            for (size_t c = 0; c < ncand; c++) deferred_.length[c] = (int32_t)cand[c].length;
+            deferred_.state = state;
+            deferred_.pending = true;
+        }
+    }
+    disorder = 0;      // (put off: none; else the marking pass below finds it out itself)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(| : disorder) if (!put_off)
+    for (int t = 0; t < (put_off ? 0 : nstripes); t++) {
         const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
         std::vector<long> last_l(j1 - j0 + 16, 0);      // end of the previous accepted candidate, per genome of the stripe
         long* last = last_l.data() + 8 - j0;
@@ -784,6 +882,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         }
         anchors_ordered_ = ordered;
     } else anchors_ordered_ = false;
+    if (dbg && put_off) fprintf(stderr, "[validate_parallel] marks of the clean candidates put off\n");
     lap("sequential");
 }
 
@@ -817,7 +916,8 @@ bool Aligner::find_anchors() {
     lap_a("set-up");
     region_mums(whole, true, &found, false);
     lap_a("search + validation");
-    wait_layout();
+    // (marks that validate_parallel put off stay put off while the seed regions come from the rows: only walks read them)
+    if (!anchors_ordered_ || getenv("PARSNP_WALK_NEIGHBOURS") || getenv("PARSNP_CHECK_NEIGHBOURS")) wait_layout();
     mums = found;
     m0 = (long)found.size();
     // seed regions: left and right neighbour of every anchor, longer than q in every genome (:2150-2172).  The layout
@@ -965,6 +1065,7 @@ bool Aligner::find_anchors() {
 // std::sort's tie order becomes observable; from then on the literal vector + std::sort + adjacent-dedup of the
 // reference runs on exactly the array the reference would hold, until the keys are unique again.
 bool Aligner::extend_pass(bool speculative, bool sorted_start) {
+    wait_layout();
     std::vector<Region> rpool = std::move(regions);
     regions.clear();
     std::map<long, int> uniq;            // key -> rpool index       (fast mode)
@@ -1176,6 +1277,7 @@ bool Aligner::extend_generations() {
     std::vector<int> seeds_raw;                   // engine results of the seeds, for the restart
     std::function<void()> before_restart = [] {};
     auto restart_in_order = [&]() {
+        wait_layout();
         before_restart();
         pool.resize(pool0);
         mums = mums0;
@@ -1261,6 +1363,7 @@ bool Aligner::extend_generations() {
         std::vector<size_t> first;               // clusters of `now`
         bool trouble = false;
         if (gi == 0) {                           // the first pushed seed, before anything is sorted
+            start_deferred_marks();              // the anchors' put-off marks: set while this thread waits for the device
             trouble = !fetch(gen, &gen_raw);     // ... but every seed's engine result in ONE call
             finish_prejudge();                   // (the anchors' chaining verdicts were worked out beside that call)
             seeds_raw = gen_raw;
@@ -1298,6 +1401,7 @@ bool Aligner::extend_generations() {
         const long nclusters = (long)first.size() - 1;
         std::vector<Out> out((size_t)m);
         int cluster_trouble = 0;
+        wait_layout();
         double tv = now_s();
 #pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(| : cluster_trouble)
         for (long cl = 0; cl < nclusters; cl++) {
@@ -1410,6 +1514,7 @@ bool Aligner::extend() {
 // filterRandom1 (:327-425): a MUM no longer than rvalue survives only if it is collinear (0..5000 bases, no marked
 // base in between) with its successor -- and, when it has one, its predecessor -- in every genome.
 void Aligner::filter_mums(int rvalue) {
+    wait_layout();
     double t0 = now_s();
     {
         std::vector<Handle> h(mums.size());

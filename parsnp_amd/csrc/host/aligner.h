@@ -275,6 +275,7 @@ public:
     Region new_region();
 
     void wait_layout();           // the layout bitmaps are set up in the background (constructor); find_anchors() awaits them
+    void start_deferred_marks();  // (no-op unless validate_parallel put marks off)
     void flush_engine_timing() { if (timing_deferred_) collect_engine_timing(); }   // before `stats` is read
     enum : uint8_t { kJoin = 0, kClose = 1, kPass = 2 };
     uint8_t judge_pair(const Mum& nt, const Mum& back) const;     // chain()'s test of a MUM against the open chain's last MUM
@@ -283,6 +284,10 @@ public:
 
 private:
     std::vector<std::future<void>> layout_ready_;
+    // marks of the anchors' clean candidates that were put off (validate_parallel): start_deferred_marks() sets them in the
+    // background, wait_layout() starts them if nobody has and joins -- every reader of the layout goes through it
+    struct DeferredMarks { const int32_t* rows = nullptr; std::vector<int32_t> length; std::vector<uint8_t> state; bool pending = false; } deferred_;
+    void mark_stripe(size_t j0, size_t j1);     // the put-off marks of genomes [j0, j1)
     std::future<void> prejudge_;
     // set by validate_parallel for the list it accepted into an EMPTY layout (the anchor call): in every genome the accepted
     // MUMs lie in list order, one after the other without overlap -- then the marked base next to a MUM is its list

@@ -771,6 +771,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
 // coordinates are 0-based positions of the padded in-memory genome.
 void write_unaligned(Aligner& a) {
     using namespace std;
+    a.wait_layout();
     const size_t n = a.n;
     ofstream out((a.prm.outdir + "/parsnp.unalign").c_str());
     vector<long> lastpos(n, 0);
