@@ -107,6 +107,8 @@ void pm_result_free(pm_result* r);
  *                  PM_ROW_DIRTY    (only when pm_result_dirty_known) overlaps an earlier candidate of the list in some
  *                                  genome by the running-extent test of the anchor validation; computed for one-region
  *                                  batches with at least 4096 accepted candidates
+ *                  PM_ROW_EARLY    (with PM_ROW_DIRTY's condition) starts, in some genome, before the end of an earlier
+ *                                  candidate of the list: candidates WITHOUT it lie in list order in every genome
  * The window of genome j is the starts/lens row the caller passed, so the rows equal the reference's only for requests
  * whose rows ARE the region (one unclamped reference chunk); a caller with clamped or chunked rows keeps to sp / fwd.
  * The blocks are writable: the caller may trim the rows in place (Aligner::trim) and keep them as its MUM table. */
@@ -114,6 +116,7 @@ void pm_result_free(pm_result* r);
 #define PM_ROW_OUTSIDE 2u
 #define PM_ROW_REVERSE 4u
 #define PM_ROW_DIRTY 8u
+#define PM_ROW_EARLY 16u
 int pm_session_rows(pm_session* s, int enable);
 int32_t* pm_result_start(pm_result* r);
 uint8_t* pm_result_strand(pm_result* r);

@@ -1327,6 +1327,8 @@ constexpr uint32_t kRowBad = 1;        // a start position outside its region wi
 constexpr uint32_t kRowOutside = 2;    // the MUM would leave a genome (`notgood`)
 constexpr uint32_t kRowReverse = 4;    // some member is on the reverse strand
 constexpr uint32_t kRowDirty = 8;      // overlaps an earlier candidate of the list in some genome (cheap running-extent test)
+constexpr uint32_t kRowEarly = 16;     // starts, in some genome, before the end of an earlier candidate of the list (same running extents): no
+                                       // candidate without this bit lies out of list order -- the host's order test for free
 // tid = (candidate, genome column 0..ngen-1).  Writes the accepted candidates densely and AS MUM ROWS: per genome the
 // start on the genome's forward coordinates exactly as the TMum constructor derives it -- forward: window start + sp,
 // reverse: flipped against the WHOLE genome length (TMum.cpp:33-35) -- and the strand byte; column 0 is the reference.
@@ -1446,9 +1448,11 @@ struct DirtyMark {
             for (int u = 0; u < 8; u++) {
                 if (cb + u >= c1 || !row_marks(fl[u], l[u])) continue;      // uniform over the wavefront
                 const int32_t b = a[u] + l[u];
-                const bool hit = act && !(a[u] >= mx || b <= mn);
+                const bool early = act && !(a[u] >= mx);
+                const bool hit = early && !(b <= mn);
                 if (act) { if (b > mx) mx = b; if (a[u] < mn) mn = a[u]; }
-                if (__ballot(hit) && __lane_id() == 0) atomic_or32(&dirty[cb + u], kRowDirty);
+                const unsigned long long any_early = __ballot(early), any_hit = __ballot(hit);      // (both by the whole wavefront)
+                if (any_early && __lane_id() == 0) atomic_or32(&dirty[cb + u], kRowEarly | (any_hit ? kRowDirty : 0u));
             }
         }
 #else
@@ -1458,7 +1462,7 @@ struct DirtyMark {
                 const int32_t l = lon[c];
                 if (!row_marks(flags[c], l)) continue;
                 const int32_t a = start[c * ngen + j], b = a + l;
-                if (!(a >= mx || b <= mn)) dirty[c] |= kRowDirty;
+                if (!(a >= mx)) dirty[c] |= kRowEarly | (!(b <= mn) ? kRowDirty : 0u);
                 if (b > mx) mx = b;
                 if (a < mn) mn = a;
             }
@@ -1469,7 +1473,7 @@ struct DirtyMark {
 // tid = candidate
 struct DirtyMerge {
     const uint32_t* dirty; uint32_t* flags;
-    PM_HD void operator()(int64_t c) const { if (dirty[c]) flags[c] |= kRowDirty; }
+    PM_HD void operator()(int64_t c) const { if (dirty[c]) flags[c] |= dirty[c] & (kRowDirty | kRowEarly); }
 };
 
 }  // namespace pm

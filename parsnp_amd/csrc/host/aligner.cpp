@@ -1,6 +1,10 @@
 // aligner.cpp -- MUM validation, recursive extension and LCB formation on the host.
 // See aligner.h for the map onto the reference.  The match finding itself (csgmum) is NOT here: it is
 // requested through include/parsnp_mum.h in batches and runs on the GPU.
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include "aligner.h"
 
 #include <algorithm>
@@ -153,9 +157,16 @@ void Aligner::mark_stripe(size_t j0, size_t j1) {
 void Aligner::start_deferred_marks() {
     if (!deferred_.pending) return;
     deferred_.pending = false;
-    const size_t tasks = std::min<size_t>(n, (size_t)std::max(1, prm.cores));
+    static const long want = getenv("PARSNP_MARK_TASKS") ? atol(getenv("PARSNP_MARK_TASKS")) : 0;      // measurement knob
+    const size_t tasks = std::min<size_t>(n, (size_t)std::max<long>(1, want > 0 ? want : prm.cores));
     for (size_t t = 0; t < tasks; t++)
-        layout_ready_.push_back(std::async(std::launch::async, [this, t, tasks] { mark_stripe(n * t / tasks, n * (t + 1) / tasks); }));
+        layout_ready_.push_back(std::async(std::launch::async, [this, t, tasks] {
+            // background work: it yields to the threads that stage the engine call it runs beside, and takes the cores that
+            // call leaves idle while the device works
+            static const int nice_by = getenv("PARSNP_MARK_NICE") ? atoi(getenv("PARSNP_MARK_NICE")) : 10;
+            if (nice_by > 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nice_by);
+            mark_stripe(n * t / tasks, n * (t + 1) / tasks);
+        }));
 }
 void Aligner::wait_layout() {
     start_deferred_marks();
@@ -660,9 +671,18 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     static const bool mark_first = getenv("PARSNP_MARK_FIRST") != nullptr;
     int disorder = 0;
     bool put_off = false;
+    // (the order: from the device's PM_ROW_EARLY bits where it delivered the overlap flags -- no accepted clean candidate
+    // with the bit means in order; the bit is conservative, so a list it calls out of order takes the marking pass -- else
+    // from the rows, PARSNP_HOST_ORDER=1 forces that)
+    static const bool host_order = getenv("PARSNP_HOST_ORDER") != nullptr;
+    bool order_known = false;
+    if (layout_empty && !mark_first && threads > 1 && device_dirty && !host_order) {
+        for (size_t c = 0; c < ncand; c++) if ((state[c] & 24) == 16 && (raw.flags[c] & PM_ROW_EARLY)) { disorder = 1; break; }
+        order_known = true;
+    }
     if (layout_empty && !mark_first && threads > 1) {
         (void)rows_until(ncand);
-        const long kRun = 1024, nruns = (nc + kRun - 1) / kRun;
+        const long kRun = order_known ? nc + 1 : 1024, nruns = order_known ? 0 : (nc + kRun - 1) / kRun;
         std::vector<long> first_acc((size_t)nruns, -1), last_acc((size_t)nruns, -1);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(| : disorder)
         for (long rr = 0; rr < nruns; rr++) {
@@ -703,14 +723,32 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             const size_t nacc = acc_idx.size();
 #pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
             for (long o = 0; o < nfl; o++) {
-                const Mum& f = cand[flagged_now[(size_t)o]];
+                const uint32_t cf = flagged_now[(size_t)o];
+                const Mum& f = cand[cf];
                 if (f.length <= 0) continue;
+                // where the candidate itself sits in the accepted list: in most genomes what it meets are its list neighbours,
+                // so the search below gallops outwards from there (the same few rows for all genomes) before it bisects
+                const size_t here = (size_t)(std::lower_bound(acc_idx.begin(), acc_idx.end(), cf) - acc_idx.begin());
                 for (size_t j = 0; j < n; j++) {
                     const long s = f.start[j], e = s + f.length;
+                    auto ends_after = [&](size_t k) { const uint32_t c = acc_idx[k]; return (long)srow[(size_t)c * n + j] + cand[c].length > s; };
                     size_t lo = 0, hi = nacc;                 // the first accepted clean candidate that ends after s (ends rise with the list)
+                    if (here < nacc && ends_after(here)) {
+                        hi = here;
+                        for (size_t step = 1; hi > 0; step *= 2) {
+                            const size_t k = hi > step ? hi - step : 0;
+                            if (ends_after(k)) hi = k; else { lo = k + 1; break; }
+                        }
+                    } else if (here < nacc) {
+                        lo = here + 1;
+                        for (size_t step = 1; lo < nacc; step *= 2) {
+                            const size_t k = std::min(nacc - 1, lo + step - 1);
+                            if (!ends_after(k)) lo = k + 1; else { hi = k; break; }
+                        }
+                    }
                     while (lo < hi) {
-                        const size_t mid = (lo + hi) / 2; const uint32_t c = acc_idx[mid];
-                        if ((long)srow[(size_t)c * n + j] + cand[c].length > s) hi = mid; else lo = mid + 1;
+                        const size_t mid = (lo + hi) / 2;
+                        if (ends_after(mid)) hi = mid; else lo = mid + 1;
                     }
                     for (size_t k = lo; k < nacc; k++) {
                         const uint32_t c = acc_idx[k];
@@ -722,7 +760,8 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             }
             deferred_.rows = srow;
             deferred_.length.resize(ncand);
-            for (size_t c = 0; c < ncand; c++) deferred_.length[c] = (int32_t)cand[c].length;
+            if (device_rows) memcpy(deferred_.length.data(), raw.lon, ncand * sizeof(int32_t));
+            else for (size_t c = 0; c < ncand; c++) deferred_.length[c] = (int32_t)cand[c].length;
             deferred_.state = state;
             deferred_.pending = true;
         }
@@ -1004,6 +1043,9 @@ bool Aligner::find_anchors() {
         if (anchors_ordered_ && !no_rows_path) {
             for (long i = i0; i < i1; i++) {
                 const Mum& m = pool[(size_t)found[(size_t)i]];
+                // fourteen regions in fifteen are dropped at the first genome (one SNP between two anchors): the pass waits
+                // for the first line of a row it has not seen, so that line is asked for a few anchors ahead
+                if (i + 6 < nf) __builtin_prefetch(pool[(size_t)found[(size_t)i + 6]].start);
                 Region& rR = rS[0];
                 const bool l_kept = from_rows(i, true, &lS);
                 if (check_derived) checked(m, true, l_kept, lS);

@@ -220,10 +220,11 @@ def test_parsnp_core_replay_modes_threaded(libs, tmp_path, name, mode):
 
 
 @pytest.mark.parametrize("name", ["rearr6x300k", "poprearr10x400k", "pop20x1m"])
-@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows", "rows_in_one_piece"])
+@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows", "rows_in_one_piece", "host_order", "mark_first"])
 def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant):
-    """the MUM rows and the cheap overlap flags come from the device (CompactCandidates, DirtyExtent/Prefix/Mark) and feed
-    the threaded anchor validation in place; switching either back to the host must not change a byte"""
+    """the MUM rows, the cheap overlap flags and the list-order bits come from the device (CompactCandidates,
+    DirtyExtent/Prefix/Mark) and feed the threaded anchor validation in place; switching any of them back to the host, or
+    marking the layout before instead of after the flagged candidates, must not change a byte"""
     if name == "poprearr10x400k":
         rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
     else:
@@ -236,11 +237,19 @@ def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant
         env["PARSNP_NO_DEVICE_ROWS"] = "1"
     if variant == "rows_in_one_piece":      # the other variants receive the row table in slices while they work (PM_ROW_SLICES, PM_SLICE_MIN)
         env["PM_ROW_SLICES"] = "0"
+    if variant == "host_order":             # the list order from a pass over the rows instead of the device's PM_ROW_EARLY bits
+        env["PARSNP_HOST_ORDER"] = "1"
+    if variant == "mark_first":             # all marks before the flagged candidates (nothing put off)
+        env["PARSNP_MARK_FIRST"] = "1"
+    env["PARSNP_DEBUG_TIMERS"] = "1"
     out = str(tmp_path / "out")
     rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=8, **kw)
-    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    err = open(os.path.join(out, "parsnp-aligner.err")).read()
+    assert rc == 0, err[-2000:]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
+    if name == "pop20x1m":                  # a collinear set: the marks are put off unless told otherwise
+        assert ("put off" in err) == (variant != "mark_first")
 
 
 @pytest.mark.parametrize("name", ["mers", "messy", "pop6x200k_p"])
