@@ -273,6 +273,7 @@ def main():
             gc.disable()
             barrier()
             t0 = time.perf_counter()
+            cpu0 = sum(os.times()[:2])
             reports = []
             merged_bp = None
             step_ms = []
@@ -288,6 +289,7 @@ def main():
                 reports.append(rep)
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0
+            host_cores_busy = (sum(os.times()[:2]) - cpu0) / elapsed      # CPU seconds of this process (all threads) per second of the timed region
             gc.enable()
             barrier()
             t_out = time.time()
@@ -370,7 +372,7 @@ def main():
                               ", ".join("%s=%s" % (k, v) for k, v in sorted(kw.items()) if k not in ("n", "n_genomes")),
                               "" if world == 1 else ("; ONE alignment sharded over %d ranks" % world if sharded else "; one partition per rank, %d ranks" % world)),
                            "genomes_per_gpu": G if not sharded else round(G / world, 2), "genome_bp": n_ref, "host_threads": args.host_threads, "host_cpus_usable": usable_cpus(), "numa_node": numa_node, "parallelism": ("sharded x%d (engine RCCL: all-reduce(min) + all-gather per engine call)" % world) if sharded else "partition-per-gpu x%d" % world},
-                "step_ms": step_ms,
+                "step_ms": step_ms, "host_cores_busy": round(host_cores_busy, 2),
                 "core_bp_aligned": core_bp_total,
                 "core_bp_in_every_partition": merged_bp,
                 "mums": rep["mums"], "anchors": rep["anchors"], "lcbs": rep["lcbs"],
