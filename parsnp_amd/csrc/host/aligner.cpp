@@ -180,6 +180,7 @@ void Aligner::wait_layout() {
 }
 
 Aligner::~Aligner() {
+    deferred_.pending = false;      // marks nobody waited for are not set for the sake of it
     wait_layout();
     finish_prejudge();
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
