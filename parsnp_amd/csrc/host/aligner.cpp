@@ -685,7 +685,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     }
     if (layout_empty && !mark_first && threads > 1) {
         (void)rows_until(ncand);
-        const long kRun = order_known ? nc + 1 : 1024, nruns = order_known ? 0 : (nc + kRun - 1) / kRun;
+        const long kRun = 1024, nruns = order_known ? 0 : (nc + kRun - 1) / kRun;      // (no run: the device has said it)
         std::vector<long> first_acc((size_t)nruns, -1), last_acc((size_t)nruns, -1);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(| : disorder)
         for (long rr = 0; rr < nruns; rr++) {
