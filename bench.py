@@ -262,6 +262,10 @@ def main():
             else:
                 run = CoreRun(ini)
             cold_step_s = None
+            # the harness's own interpreter must not stall the passes it times: a full cyclic collection with torch imported
+            # costs ~40 ms and would otherwise fire inside the first (cold) pass or one of the few timed steps
+            gc.collect()
+            gc.disable()
             for w in range(args.warmup):
                 tc = time.perf_counter()
                 run.step()
