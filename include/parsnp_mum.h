@@ -158,6 +158,14 @@ int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t 
  * device < 0: PARSNP_DEVICE or the current device.  Returns PM_OK or a PM_E* code (pm_gap_last_error()). */
 int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
                        const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols);
+/* The same batch in n_groups groups of consecutive jobs (group g = jobs [group_end[g-1], group_end[g]), group_end[n_groups-1]
+ * = n_jobs): everything is uploaded once, the groups are aligned one after the other, and as soon as the rows and column
+ * counts of group g are in the caller's arrays `done(ctx, g)` is called from the calling thread -- the caller may use them
+ * while the later groups are still being aligned (the XMFA writer lays out and writes the records of the LCBs whose gaps
+ * are done).  On an error return the groups after the last one reported have not been reported.  done may be NULL. */
+int pm_gap_align_groups(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
+                        const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols,
+                        int n_groups, const int64_t* group_end, void (*done)(void* ctx, int group), void* ctx);
 const char* pm_gap_last_error(void);
 
 /* Device-side timing of the last pm_multi_mum_batch on this session (HIP events on the engine's stream):

@@ -109,6 +109,14 @@ int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const 
     for (int64_t j = 0; j < n_jobs; j++) cols[j] = -1;
     return PM_OK;
 }
+int pm_gap_align_groups(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
+                        const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols,
+                        int n_groups, const int64_t* group_end, void (*done)(void* ctx, int group), void* ctx) {
+    (void)device; (void)n_seqs; (void)seq_off; (void)chars; (void)max_cols; (void)row_off; (void)out_rows; (void)out_bytes; (void)group_end;
+    for (int64_t j = 0; j < n_jobs; j++) cols[j] = -1;
+    for (int g = 0; done && g < n_groups; g++) done(ctx, g);
+    return PM_OK;
+}
 const char* pm_gap_last_error(void) { return ""; }
 int pm_warmup(int device) { (void)device; return PM_OK; }
 /* RCCL sessions exist in the HIP library only */

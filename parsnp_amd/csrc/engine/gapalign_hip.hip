@@ -789,8 +789,19 @@ extern "C" int64_t pm_gap_debug_peek(int32_t* out, int64_t cap) {
 
 extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
                                   const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols) {
+    return pm_gap_align_groups(device, n_jobs, n_seqs, seq_off, chars, max_cols, row_off, out_rows, out_bytes, cols, 1, &n_jobs, nullptr, nullptr);
+}
+// The same batch in groups of consecutive jobs (group g = jobs [group_end[g-1], group_end[g])): everything is uploaded once,
+// the groups are aligned one after the other, and when the rows and column counts of a group are in the caller's memory
+// `done(ctx, g)` is called (from this thread) -- the caller can start using them while the later groups are still running.
+extern "C" int pm_gap_align_groups(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
+                                   const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols,
+                                   int n_groups, const int64_t* group_end, void (*done)(void* ctx, int group), void* ctx) {
     if (n_jobs < 0 || (n_jobs > 0 && (!n_seqs || !seq_off || !chars || !max_cols || !row_off || !out_rows || !cols))) return fail(PM_EINVAL, "bad argument");
-    if (n_jobs == 0) return PM_OK;
+    if (n_groups < 1 || !group_end || group_end[n_groups - 1] != n_jobs) return fail(PM_EINVAL, "bad job groups");
+    for (int g = 0; g < n_groups; g++) if (group_end[g] < (g ? group_end[g - 1] : 0)) return fail(PM_EINVAL, "bad job groups");
+    auto all_done = [&](int from) { if (done) for (int g = from; g < n_groups; g++) done(ctx, g); };
+    if (n_jobs == 0) { all_done(0); return PM_OK; }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return fail(PM_ENODEV, "no HIP device available; the gap aligner of this library has no CPU path");
     if (device < 0) { const char* e = getenv("PARSNP_DEVICE"); if (e && *e) device = atoi(e); }
@@ -812,27 +823,34 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
         g_tables_ready = true;
     }
     // jobs the device takes, longest first (the cost of one alignment grows with the square of its width)
-    std::vector<Job> jobs; std::vector<int64_t> which;
+    std::vector<Job> jobs; std::vector<int64_t> which; std::vector<int> group_of_job;
     int64_t seq = 0, total_chars = 0;
     int nmax = 2, cap = 1;
     std::vector<int> widest((size_t)n_jobs, 0);
+    int grp = 0;
     for (int64_t j = 0; j < n_jobs; j++) {
+        while (grp + 1 < n_groups && j >= group_end[grp]) grp++;
         cols[j] = -1;
         const int n = n_seqs[j];
         int w = 0; bool ok = n >= 2 && n <= kMaxSeqs && max_cols[j] >= 1;
         for (int i = 0; i < n && ok; i++) { const int64_t L = seq_off[seq + i + 1] - seq_off[seq + i]; if (L <= 0 || L > kMaxCols) ok = false; else w = std::max<int>(w, (int)L); }
         if (ok && row_off[j] + (int64_t)n * max_cols[j] > out_bytes) ok = false;
-        if (ok) { jobs.push_back(Job{seq, n, max_cols[j], row_off[j]}); which.push_back(j); widest[(size_t)j] = w; nmax = std::max(nmax, n); cap = std::max(cap, std::min<int>(max_cols[j], kMaxCols)); }
+        if (ok) { jobs.push_back(Job{seq, n, max_cols[j], row_off[j]}); which.push_back(j); group_of_job.push_back(grp); widest[(size_t)j] = w; nmax = std::max(nmax, n); cap = std::max(cap, std::min<int>(max_cols[j], kMaxCols)); }
         seq += n;
     }
     total_chars = seq_off[seq];
-    if (jobs.empty()) return PM_OK;
+    if (jobs.empty()) { all_done(0); return PM_OK; }
+    std::vector<size_t> first_of_group((size_t)n_groups + 1, 0);      // in the sorted job list
     {
         std::vector<size_t> order(jobs.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return widest[(size_t)which[a]] > widest[(size_t)which[b]]; });
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+            if (group_of_job[a] != group_of_job[b]) return group_of_job[a] < group_of_job[b];
+            return widest[(size_t)which[a]] > widest[(size_t)which[b]];
+        });
         std::vector<Job> j2; std::vector<int64_t> w2;
-        for (size_t i : order) { j2.push_back(jobs[i]); w2.push_back(which[i]); }
+        for (size_t i : order) { j2.push_back(jobs[i]); w2.push_back(which[i]); first_of_group[(size_t)group_of_job[i] + 1]++; }
+        for (int g = 0; g < n_groups; g++) first_of_group[(size_t)g + 1] += first_of_group[(size_t)g];
         jobs.swap(j2); which.swap(w2);
     }
     const bool timers = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
@@ -857,12 +875,12 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
     GA_CHECK(dalloc((size_t)total_chars, (void**)&d_chars));
     GA_CHECK(dalloc((size_t)out_bytes, (void**)&d_out));
     GA_CHECK(dalloc(4 * jobs.size(), (void**)&d_cols));
-    GA_CHECK(dalloc(8, (void**)&d_next));
+    GA_CHECK(dalloc(8 * (size_t)n_groups, (void**)&d_next));
     GA_CHECK(dalloc(stride * (size_t)slots, (void**)&d_ws));
     GA_CHECK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(Job) * jobs.size(), hipMemcpyHostToDevice, stream));
     GA_CHECK(hipMemcpyAsync(d_off, seq_off, 8 * (size_t)(seq + 1), hipMemcpyHostToDevice, stream));
     GA_CHECK(hipMemcpyAsync(d_chars, chars, (size_t)total_chars, hipMemcpyHostToDevice, stream));
-    GA_CHECK(hipMemsetAsync(d_next, 0, 8, stream));
+    GA_CHECK(hipMemsetAsync(d_next, 0, 8 * (size_t)n_groups, stream));
     if (timers) { GA_CHECK(hipStreamSynchronize(stream)); lap("alloc + h2d"); }
     int32_t* dbg = nullptr;
     if (getenv("PM_GAP_DEBUG") && atoi(getenv("PM_GAP_DEBUG")) == 2) {
@@ -878,16 +896,31 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
         GA_CHECK(dalloc(8 * kProfStages, (void**)&d_prof));
         GA_CHECK(hipMemsetAsync(d_prof, 0, 8 * kProfStages, stream));
     }
-    Params P{d_jobs, (int64_t)jobs.size(), d_off, d_chars, d_out, d_cols, d_next, d_ws, (int64_t)stride, nmax, cap, dbg, d_prof};
-    if (timers) fprintf(stderr, "[gap batch] %zu jobs, widest %d sequences x %d columns: %zu B of LDS per wavefront, %d per CU, %lld slots\n", jobs.size(), nmax, cap, lds, per_cu, (long long)slots);
-    hipLaunchKernelGGL(gap_align_kernel, dim3((unsigned)slots), dim3(64), rows_lds, stream, P);
-    GA_CHECK(hipGetLastError());
-    if (timers) { GA_CHECK(hipStreamSynchronize(stream)); lap("kernel"); }
+    if (timers) fprintf(stderr, "[gap batch] %zu jobs in %d group(s), widest %d sequences x %d columns: %zu B of LDS per wavefront, %d per CU, %lld slots\n", jobs.size(), n_groups, nmax, cap, lds, per_cu, (long long)slots);
     std::vector<int32_t> got(jobs.size());
-    GA_CHECK(hipMemcpyAsync(got.data(), d_cols, 4 * jobs.size(), hipMemcpyDeviceToHost, stream));
-    GA_CHECK(hipMemcpyAsync(out_rows, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, stream));
-    GA_CHECK(hipStreamSynchronize(stream));
-    lap("d2h");
+    int signalled = 0;                 // groups whose completion the caller has been told
+    for (int g = 0; g < n_groups; g++) {
+        const size_t j0 = first_of_group[(size_t)g], j1 = first_of_group[(size_t)g + 1];
+        if (j1 > j0) {
+            // a group's jobs: their own queue counter, their slice of the job and column arrays; workspace and slots shared
+            Params P{d_jobs + j0, (int64_t)(j1 - j0), d_off, d_chars, d_out, d_cols + j0, d_next + g, d_ws, (int64_t)stride, nmax, cap, dbg, d_prof};
+            const int64_t gslots = std::min<int64_t>((int64_t)(j1 - j0), slots);
+            hipLaunchKernelGGL(gap_align_kernel, dim3((unsigned)gslots), dim3(64), rows_lds, stream, P);
+            GA_CHECK(hipGetLastError());
+            // the rows of the group: the span of the output its jobs cover (a span may include rows of other groups: the
+            // device buffer holds their final bytes if they are done, and they are copied again when they are not)
+            int64_t lo = out_bytes, hi = 0;
+            for (size_t i = j0; i < j1; i++) { lo = std::min(lo, jobs[i].row_off); hi = std::max(hi, jobs[i].row_off + (int64_t)jobs[i].n * jobs[i].max_cols); }
+            GA_CHECK(hipMemcpyAsync(got.data() + j0, d_cols + j0, 4 * (j1 - j0), hipMemcpyDeviceToHost, stream));
+            if (hi > lo) GA_CHECK(hipMemcpyAsync(out_rows + lo, d_out + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, stream));
+            GA_CHECK(hipStreamSynchronize(stream));
+            for (size_t i = j0; i < j1; i++) cols[which[i]] = got[i];
+        }
+        if (timers) { char what[32]; snprintf(what, sizeof what, "group %d", g + 1); lap(what); }
+        if (done) done(ctx, g);
+        signalled = g + 1;
+    }
+    (void)signalled;
     if (d_prof) {
         unsigned long long prof[kProfStages];
         GA_CHECK(hipMemcpy(prof, d_prof, sizeof prof, hipMemcpyDeviceToHost));
@@ -898,7 +931,6 @@ extern "C" int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_s
         for (int k = 0; k < kProfStages; k++)
             if (prof[k]) fprintf(stderr, "[gap stages] %-24s %6.2f %%  %12.0f clocks per job\n", names[k], 100.0 * (double)prof[k] / (double)sum, (double)prof[k] / (double)jobs.size());
     }
-    for (size_t i = 0; i < jobs.size(); i++) cols[which[i]] = got[i];
     release();
     lap("release");
 #undef GA_CHECK

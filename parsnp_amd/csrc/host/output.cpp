@@ -226,7 +226,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         pl.regular = clean;
     }
     // ---- the gaps that are aligned
-    struct Job { size_t z, t; unsigned max_len; long dev = -1; Gap host; bool on_host = false, failed = false; };
+    struct Job { size_t z, t; unsigned max_len; long dev = -1; int grp = 0; Gap host; bool on_host = false, failed = false; };
     vector<Job> jobs;
     for (long z = 0; z < nl; z++) {
         Plan& pl = plan[(size_t)z];
@@ -272,44 +272,70 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     // widest ones while the device works on the rest.  PARSNP_HOST_GAPS=1: everything on the host (measurement / tests).
     constexpr unsigned kDeviceCols = 96;
     static const bool host_gaps = getenv("PARSNP_HOST_GAPS") != nullptr;
-    vector<int32_t> d_nseq, d_maxcols, d_cols; vector<int64_t> d_seqoff, d_rowoff; vector<uint8_t> d_chars, d_out;
-    vector<long> d_job;
+    // The LCBs are cut into a few groups of consecutive LCBs with about the same alignment work, one device batch each:
+    // the file offsets of a group's records only depend on the groups before it, so its records are written while the
+    // device aligns the gaps of the next group.  PARSNP_GAP_GROUPS (test hook) sets the number.
+    struct Group { size_t z0 = 0, z1 = 0, y0 = 0, y1 = 0; };      // its LCBs [z0, z1) and its device jobs [y0, y1)
+    struct Batch { vector<int32_t> nseq, maxcols, cols; vector<int64_t> seqoff, rowoff; vector<uint8_t> chars, out; vector<long> job; } B;
+    static const long want_groups = getenv("PARSNP_GAP_GROUPS") ? atol(getenv("PARSNP_GAP_GROUPS")) : 0;
+    const size_t ngroups = (size_t)std::max<long>(1, std::min<long>(16, want_groups > 0 ? want_groups : (nj >= 6000 && !all_slow ? 3 : 1)));
+    vector<Group> batch(ngroups);
+    {
+        vector<double> work((size_t)nl + 1, 0.0);            // alignment work before LCB z (a gap costs about its width squared)
+        for (long x = 0; x < nj; x++) work[jobs[(size_t)x].z + 1] += (double)(jobs[(size_t)x].max_len + 4) * (jobs[(size_t)x].max_len + 4);
+        for (long z = 0; z < nl; z++) work[(size_t)z + 1] += work[(size_t)z] + 1e-9;
+        size_t z = 0;
+        for (size_t g = 0; g < ngroups; g++) {
+            batch[g].z0 = z;
+            const double upto = work[(size_t)nl] * (double)(g + 1) / (double)ngroups;
+            while (z < (size_t)nl && (g + 1 == ngroups || work[z + 1] <= upto)) z++;
+            batch[g].z1 = z;
+        }
+        batch[ngroups - 1].z1 = (size_t)nl;
+    }
+    vector<int> group_of((size_t)nl, 0);
+    for (size_t g = 0; g < ngroups; g++) for (size_t z = batch[g].z0; z < batch[g].z1; z++) group_of[z] = (int)g;
+    for (long x = 0; x < nj; x++) jobs[(size_t)x].grp = group_of[jobs[(size_t)x].z];
     if (!host_gaps && n <= 512) {
         int64_t out_bytes = 0;
-        for (long x = 0; x < nj; x++) {
-            Job& j = jobs[(size_t)x];
-            if (j.max_len > kDeviceCols) continue;
-            j.dev = (long)d_job.size(); d_job.push_back(x);
-            const int32_t cap = (int32_t)std::min<unsigned>(kDeviceCols, j.max_len + j.max_len / 2 + 16);
-            d_nseq.push_back((int32_t)n); d_maxcols.push_back(cap); d_rowoff.push_back(out_bytes);
-            out_bytes += (int64_t)n * cap;
+        for (size_t g = 0; g < ngroups; g++) {               // group after group; the sorted order carries over: every group is longest first
+            batch[g].y0 = B.job.size();
+            for (long x = 0; x < nj; x++) {
+                Job& j = jobs[(size_t)x];
+                if (j.grp != (int)g || j.max_len > kDeviceCols) continue;
+                j.dev = (long)B.job.size(); B.job.push_back(x);
+                const int32_t cap = (int32_t)std::min<unsigned>(kDeviceCols, j.max_len + j.max_len / 2 + 16);
+                B.nseq.push_back((int32_t)n); B.maxcols.push_back(cap); B.rowoff.push_back(out_bytes);
+                out_bytes += (int64_t)n * cap;
+            }
+            batch[g].y1 = B.job.size();
         }
-        const long nd = (long)d_job.size();
+        int short_rows = 0;
+        const long nd = (long)B.job.size();
         // the strings, job after job: lengths first (one offset per sequence), then the text by all threads
-        d_seqoff.assign((size_t)nd * n + 1, 0);
+        B.seqoff.assign((size_t)nd * n + 1, 0);
 #pragma omp parallel for schedule(dynamic, 64) num_threads(threads)
         for (long y = 0; y < nd; y++) {
-            const Job& j = jobs[(size_t)d_job[(size_t)y]];
+            const Job& j = jobs[(size_t)B.job[(size_t)y]];
             const Lcb& ct = a.lcbs[j.z];
             const Mum& first = a.pool[(size_t)ct.mums[0]];
             const Mum& m = a.pool[(size_t)ct.mums[j.t]];
             const Mum& nx = a.pool[(size_t)ct.mums[j.t + 1]];
             bool clean = true;
-            for (size_t i = 0; i < n; i++) d_seqoff[(size_t)y * n + i + 1] = gap_length(first, m, nx, i, &clean);
+            for (size_t i = 0; i < n; i++) B.seqoff[(size_t)y * n + i + 1] = gap_length(first, m, nx, i, &clean);
         }
-        for (size_t k = 1; k < d_seqoff.size(); k++) d_seqoff[k] += d_seqoff[k - 1];
-        d_chars.resize((size_t)d_seqoff.back() + 1);
-        int short_rows = 0;
+        for (size_t k = 1; k < B.seqoff.size(); k++) B.seqoff[k] += B.seqoff[k - 1];
+        B.chars.resize((size_t)B.seqoff.back() + 1);
 #pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(| : short_rows)
         for (long y = 0; y < nd; y++) {
-            const Job& j = jobs[(size_t)d_job[(size_t)y]];
+            const Job& j = jobs[(size_t)B.job[(size_t)y]];
             for (size_t i = 0; i < n; i++) {
-                const size_t at = (size_t)d_seqoff[(size_t)y * n + i], want = (size_t)(d_seqoff[(size_t)y * n + i + 1] - d_seqoff[(size_t)y * n + i]);
-                if (gap_text(a.lcbs[j.z], j.t, i, (char*)d_chars.data() + at) != want) short_rows = 1;
+                const size_t at = (size_t)B.seqoff[(size_t)y * n + i], want = (size_t)(B.seqoff[(size_t)y * n + i + 1] - B.seqoff[(size_t)y * n + i]);
+                if (gap_text(a.lcbs[j.z], j.t, i, (char*)B.chars.data() + at) != want) short_rows = 1;
             }
         }
+        B.out.resize((size_t)out_bytes); B.cols.assign((size_t)nd, -1);
         if (short_rows) { cerr << "parsnp_core: a genome holds a character its reverse complement drops" << endl; exit(1); }
-        d_out.resize((size_t)out_bytes); d_cols.assign((size_t)nd, -1);
     }
     lap("gap strings");
     // The file's blocks are reserved while the gaps are being aligned (an estimate of its size: aligned gaps at their row
@@ -334,10 +360,11 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
             long long cols = 0;
             for (size_t t = 0; t < ct.mums.size(); t++) {
                 cols += a.pool[(size_t)ct.mums[t]].length;
-                if (t + 1 < ct.mums.size()) cols += pl.gjob[t] >= 0 && jobs[(size_t)pl.gjob[t]].dev >= 0 ? d_maxcols[(size_t)jobs[(size_t)pl.gjob[t]].dev] : pl.gmax[t];
+                if (t + 1 < ct.mums.size()) cols += pl.gjob[t] >= 0 && jobs[(size_t)pl.gjob[t]].dev >= 0 ? B.maxcols[(size_t)jobs[(size_t)pl.gjob[t]].dev] : pl.gmax[t];
             }
             est += (long long)n * (cols + cols / 80 + 2 + 64) + 2;
         }
+        if (getenv("PARSNP_RESERVE_TINY")) est = text_at + 4096;      // test hook: the mapping has to grow with every group
         reserved = est;
         reserve_done = std::async(std::launch::async, [fd, est, dbg, clock_s] {
             const double t0 = clock_s();
@@ -346,15 +373,26 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
             return ok;
         });
     }
-    std::future<int> device_done;
-    if (!d_job.empty())
-        device_done = std::async(std::launch::async, [&] {
+    // one side thread makes the ONE device call; the library reports every group as its rows arrive (pm_gap_align_groups),
+    // and the main thread takes them in that order
+    vector<std::promise<int>> batch_done(ngroups);
+    vector<std::future<int>> batch_ready;
+    for (auto& pr : batch_done) batch_ready.push_back(pr.get_future());
+    const size_t on_device = B.job.size();
+    struct Reported { vector<std::promise<int>>* done; size_t n = 0; } reported{&batch_done, 0};
+    std::future<void> device_side = std::async(std::launch::async, [&] {
+        int rc = PM_OK;
+        if (!B.job.empty()) {
+            vector<int64_t> group_end(ngroups);
+            for (size_t g = 0; g < ngroups; g++) group_end[g] = (int64_t)batch[g].y1;
             const double t0 = clock_s();
-            const int rc = pm_gap_align_batch(-1, (int64_t)d_job.size(), d_nseq.data(), d_seqoff.data(), d_chars.data(), d_maxcols.data(), d_rowoff.data(),
-                                              d_out.data(), (int64_t)d_out.size(), d_cols.data());
-            if (dbg) fprintf(stderr, "[output] gaps: device   %.4f s\n", clock_s() - t0);
-            return rc;
-        });
+            rc = pm_gap_align_groups(-1, (int64_t)B.job.size(), B.nseq.data(), B.seqoff.data(), B.chars.data(), B.maxcols.data(), B.rowoff.data(),
+                                     B.out.data(), (int64_t)B.out.size(), B.cols.data(), (int)ngroups, group_end.data(),
+                                     [](void* ctx, int) { Reported* r = (Reported*)ctx; (*r->done)[r->n++].set_value(PM_OK); }, &reported);
+            if (dbg) fprintf(stderr, "[output] gaps: device   %.4f s (%zu gaps in %zu groups)\n", clock_s() - t0, B.job.size(), ngroups);
+        }
+        while (reported.n < ngroups) batch_done[reported.n++].set_value(rc);      // (no device jobs, or a failure: the rest hears of it)
+    });
     vector<double> jt(dbg ? (size_t)nj : 0);
     auto host_align = [&](const vector<long>& which) {
         const long nw = (long)which.size();
@@ -375,30 +413,18 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     for (long x = 0; x < nj; x++) if (jobs[(size_t)x].dev < 0) rest.push_back(x);
     host_align(rest);
     long declined = 0;
-    if (!d_job.empty()) {
-        if (device_done.get() != PM_OK) { cerr << "parsnp_core: gap alignment on the device failed: " << pm_gap_last_error() << endl; exit(1); }
-        rest.clear();
-        for (size_t y = 0; y < d_job.size(); y++) if (d_cols[y] < 0) rest.push_back(d_job[y]);
-        declined = (long)rest.size();
-        host_align(rest);
-    }
-    if (dbg && nj) {
-        double sum = 0, mx = 0; long arg = 0;
-        for (long x = 0; x < nj; x++) { sum += jt[(size_t)x]; if (jt[(size_t)x] > mx) { mx = jt[(size_t)x]; arg = x; } }
-        fprintf(stderr, "[output] %ld gap alignments: %zu on the device (%ld declined), %.3f s of host work, longest %.3f s (gap of %u columns)\n",
-                nj, d_job.size(), declined, sum, mx, jobs[(size_t)arg].max_len);
-    }
-    lap("gap alignment");
+    lap("wide gaps: host");
     // row i of an aligned gap: pointer + length (nullptr: the alignment failed, the gap is padded instead)
     auto aligned_row = [&](const Job& j, size_t i, size_t* len) -> const char* {
         if (j.on_host) { if (j.failed) return nullptr; *len = j.host.aligned[i].size(); return j.host.aligned[i].data(); }
         const size_t y = (size_t)j.dev;
-        *len = (size_t)d_cols[y];
-        return (const char*)d_out.data() + d_rowoff[y] + (int64_t)i * d_maxcols[y];
+        *len = (size_t)B.cols[y];
+        return (const char*)B.out.data() + B.rowoff[y] + (int64_t)i * B.maxcols[y];
     };
     vector<char> notes((size_t)nl, 0);
+    auto stage_columns = [&](size_t gz0, size_t gz1) {
 #pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
-    for (long z = 0; z < nl; z++) {
+    for (long z = (long)gz0; z < (long)gz1; z++) {
         Plan& pl = plan[(size_t)z];
         if (!pl.regular) continue;
         const Lcb& ct = a.lcbs[(size_t)z];
@@ -415,6 +441,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         }
         pl.cols = cols;
     }
+    };
     // ---- the slow way for one LCB: its rows as strings (build_rows), from the same gap alignments
     vector<vector<string>> rows((size_t)nl);
     auto slow_rows = [&](size_t z) {
@@ -441,14 +468,13 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     };
     vector<char> slow((size_t)nl, 0);
     for (long z = 0; z < nl; z++) if (printable_lcb(a.lcbs[(size_t)z]) && (all_slow || !plan[(size_t)z].regular)) slow[(size_t)z] = 1;
-    {
+    auto stage_slow_rows = [&](size_t gz0, size_t gz1) {
         vector<long> which;
-        for (long z = 0; z < nl; z++) if (slow[(size_t)z]) which.push_back(z);
+        for (long z = (long)gz0; z < (long)gz1; z++) if (slow[(size_t)z]) which.push_back(z);
         const long nw = (long)which.size();
 #pragma omp parallel for schedule(dynamic) num_threads(threads)
         for (long y = 0; y < nw; y++) slow_rows((size_t)which[(size_t)y]);
-    }
-    lap("layout");
+    };
 
     // Pass 1, in LCB order: the overlap trim against the previous printed LCB (it shortens rows and shifts the starts).
     // Pass 2, all threads: headers and sizes of the records of every printed LCB, hence their places in the file.
@@ -456,7 +482,8 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     int prev_end = 0;
     vector<Lcb> trimmed((size_t)nl);
     vector<char> printed((size_t)nl, 0);
-    for (size_t z = 0; z < (size_t)nl; z++) {
+    auto stage_in_order = [&](size_t gz0, size_t gz1) {
+    for (size_t z = gz0; z < gz1; z++) {
         const Lcb& c0 = a.lcbs[z];
         if (!printable_lcb(c0)) continue;
         const int lcb_start = (int)c0.start[0] + 1, lcb_end = (int)c0.end[0];
@@ -497,12 +524,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         if (!(row[0].size() > (size_t)(prm.c * 1))) continue;
         trimmed[z] = ct; printed[z] = 1;
     }
-    for (char c : notes) if (c) *gap_note = true;
-    if (dbg) {
-        long ns = 0, np = 0, nt = 0;
-        for (size_t z = 0; z < (size_t)nl; z++) { np += printed[z]; ns += printed[z] && slow[z]; nt += printed[z] && trimmed[z].start != a.lcbs[z].start; }
-        fprintf(stderr, "[output] %ld LCBs printed: %ld streamed, %ld as strings (%ld trimmed against their predecessor)\n", np, np - ns, ns, nt);
-    }
+    };
     // headers of LCB z, one per genome, each ending in '\n' (:980-1049)
     auto headers = [&](size_t z, string* out, vector<uint32_t>* ends) {
         const Lcb& ct = trimmed[z];
@@ -540,9 +562,9 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     vector<string> heads((size_t)nl);                // streamed LCBs: the headers
     vector<vector<uint32_t>> head_end((size_t)nl);
     vector<long long> bytes((size_t)nl, 0);
-    const long nz = nl;
+    auto stage_sizes = [&](size_t gz0, size_t gz1) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-    for (long zz = 0; zz < nz; zz++) {
+    for (long zz = (long)gz0; zz < (long)gz1; zz++) {
         const size_t z = (size_t)zz;
         if (!printed[z]) continue;
         headers(z, &heads[z], &head_end[z]);
@@ -570,27 +592,41 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         bytes[z] = (long long)out.size();
         vector<string>().swap(row);
     }
-    lap("headers");
-    {
-        long long at = text_at;
-        vector<long long> where((size_t)nl, 0);
-        for (size_t z = 0; z < (size_t)nl; z++) { where[z] = at; at += bytes[z]; }
-        const string& path = xmfa_path;
-        char* map = nullptr;
-        if (reserve_done.valid() && reserve_done.get()) {
-            if (at > reserved && fallocate(fd, 0, (off_t)reserved, (off_t)(at - reserved)) != 0) { cerr << "parsnp_core: cannot write " << path << endl; exit(1); }
-            if (at > 0) {
-                void* m = mmap(nullptr, (size_t)at, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-                if (m != MAP_FAILED) map = (char*)m;
+    };
+    // the file: `at` = where the next group's records start; the mapping covers the reserved size and grows if a group
+    // needs more (only when gaps were aligned wider than the estimate allows for: host-aligned ones)
+    long long at = text_at;
+    vector<long long> where((size_t)nl, 0);
+    const string& path = xmfa_path;
+    char* map = nullptr; long long map_len = 0;
+    bool map_decided = false;
+    int bad = 0;
+    auto stage_write = [&](size_t gz0, size_t gz1) {
+        for (size_t z = gz0; z < gz1; z++) { where[z] = at; at += bytes[z]; }
+        if (!map_decided) {
+            map_decided = true;
+            if (reserve_done.valid() && reserve_done.get()) {
+                map_len = std::max(reserved, at);
+                if (map_len > reserved && fallocate(fd, 0, (off_t)reserved, (off_t)(map_len - reserved)) != 0) { cerr << "parsnp_core: cannot write " << path << endl; exit(1); }
+                if (map_len > 0) {
+                    void* m = mmap(nullptr, (size_t)map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                    if (m != MAP_FAILED) map = (char*)m;
+                }
             }
+            if (dbg) fprintf(stderr, "[output] records through %s\n", map ? "a shared mapping" : "positioned writes");
         }
-        if (ftruncate(fd, (off_t)at) != 0) { cerr << "parsnp_core: cannot write " << path << endl; exit(1); }
-        if (dbg) fprintf(stderr, "[output] %lld MB through %s\n", at >> 20, map ? "a shared mapping" : "positioned writes");
+        if (map && at > map_len) {
+            const long long grown = at + (at - map_len);
+            if (fallocate(fd, 0, (off_t)map_len, (off_t)(grown - map_len)) != 0) { cerr << "parsnp_core: cannot write " << path << endl; exit(1); }
+            void* m = mremap(map, (size_t)map_len, (size_t)grown, MREMAP_MAYMOVE);
+            if (m == MAP_FAILED) { cerr << "parsnp_core: cannot write " << path << endl; exit(1); }
+            map = (char*)m; map_len = grown;
+        }
         // work items: a slow LCB's text, or a run of rows of a streamed LCB (about 1 MB of file each; the rows of one LCB
         // have one size, so every row's place follows from its number)
         struct Item { size_t z; size_t i0, i1; };
         vector<Item> items;
-        for (size_t z = 0; z < (size_t)nl; z++) {
+        for (size_t z = gz0; z < gz1; z++) {
             if (!printed[z]) continue;
             if (slow[z]) { items.push_back(Item{z, 0, 0}); continue; }
             const long long rowb = wrapped(plan[z].cols) + 48;
@@ -600,7 +636,6 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         static const struct Low { char low[256], rc[256]; Low() {
             for (int c = 0; c < 256; c++) { low[c] = (char)tolower(c); rc[c] = (char)tolower((unsigned char)U.rcu[c]); }
         } } Lw;
-        int bad = 0;
         const long ni = (long)items.size();
 #pragma omp parallel num_threads(threads) reduction(| : bad)
         {
@@ -698,8 +733,37 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
                 if (off != end) bad = 2;
             }
         }
-        if (map && munmap(map, (size_t)at) != 0) bad = 1;
-        if (close(fd) != 0 || bad) { cerr << "parsnp_core: error writing " << path << (bad == 2 ? " (record sizes)" : "") << endl; exit(1); }
+        if (bad) { cerr << "parsnp_core: error writing " << path << (bad == 2 ? " (record sizes)" : "") << endl; exit(1); }
+    };
+    // ---- group after group: wait for its alignments, lay it out, write it
+    for (size_t g = 0; g < ngroups; g++) {
+        const Group& G = batch[g];
+        if (batch_ready[g].get() != PM_OK) { cerr << "parsnp_core: gap alignment on the device failed: " << pm_gap_last_error() << endl; exit(1); }
+        rest.clear();
+        for (size_t y = G.y0; y < G.y1; y++) if (B.cols[y] < 0) rest.push_back(B.job[y]);
+        declined += (long)rest.size();
+        host_align(rest);
+        stage_columns(G.z0, G.z1);
+        stage_slow_rows(G.z0, G.z1);
+        stage_in_order(G.z0, G.z1);
+        stage_sizes(G.z0, G.z1);
+        stage_write(G.z0, G.z1);
+        if (dbg) { char what[48]; snprintf(what, sizeof what, "group %zu written", g + 1); lap(what); }
+    }
+    device_side.get();
+    if (map && munmap(map, (size_t)map_len) != 0) bad = 1;
+    if (ftruncate(fd, (off_t)at) != 0 || close(fd) != 0 || bad) { cerr << "parsnp_core: error writing " << path << endl; exit(1); }
+    for (char c : notes) if (c) *gap_note = true;
+    if (dbg && nj) {
+        double sum = 0, mx = 0; long arg = 0;
+        for (long x = 0; x < nj; x++) { sum += jt[(size_t)x]; if (jt[(size_t)x] > mx) { mx = jt[(size_t)x]; arg = x; } }
+        fprintf(stderr, "[output] %ld gap alignments: %zu on the device (%ld declined), %.3f s of host work, longest %.3f s (gap of %u columns)\n",
+                nj, on_device, declined, sum, mx, jobs[(size_t)arg].max_len);
+    }
+    if (dbg) {
+        long ns = 0, np = 0, nt = 0;
+        for (size_t z = 0; z < (size_t)nl; z++) { np += printed[z]; ns += printed[z] && slow[z]; nt += printed[z] && trimmed[z].start != a.lcbs[z].start; }
+        fprintf(stderr, "[output] %ld LCBs printed: %ld streamed, %ld as strings (%ld trimmed against their predecessor); %lld MB in %zu group(s)\n", np, np - ns, ns, nt, at >> 20, ngroups);
     }
 
     lap("xmfa records");

@@ -61,6 +61,12 @@ extern "C" int pm_gap_align_batch(int, int64_t n_jobs, const int32_t*, const int
     for (int64_t j = 0; j < n_jobs; j++) cols[j] = -1;
     return PM_OK;
 }
+extern "C" int pm_gap_align_groups(int, int64_t n_jobs, const int32_t*, const int64_t*, const uint8_t*, const int32_t*, const int64_t*, uint8_t*, int64_t, int32_t* cols,
+                                   int n_groups, const int64_t*, void (*done)(void*, int), void* ctx) {
+    for (int64_t j = 0; j < n_jobs; j++) cols[j] = -1;
+    for (int g = 0; done && g < n_groups; g++) done(ctx, g);
+    return PM_OK;
+}
 extern "C" const char* pm_gap_last_error(void) { return ""; }
 extern "C" int pm_warmup(int) { return PM_OK; }
 extern "C" int pm_rccl_unique_id(uint8_t*) { return PM_EINVAL; }

@@ -169,7 +169,7 @@ def test_threaded_validation_same_result(cpu_checkers, tmp_path, name, par_min):
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 
 
-@pytest.mark.parametrize("plain", [False, True, "mix", "pwrite"])
+@pytest.mark.parametrize("plain", [False, True, "mix", "pwrite", "groups", "groups_pwrite", "groups_grow"])
 @pytest.mark.parametrize("name", ["mers", "rearr6x300k", "poprearr10x400k", "messy", "draft8x300k"])
 def test_streamed_and_plain_records_agree(cpu_checkers, tmp_path, name, plain):
     """the XMFA records are streamed into their places in the file from the MUM table and the gap alignments (sizes
@@ -185,6 +185,12 @@ def test_streamed_and_plain_records_agree(cpu_checkers, tmp_path, name, plain):
         env["PARSNP_OUTPUT_MIX"] = "3"     # every third LCB is turned into strings late, as one that needs the trim is
     elif plain == "pwrite":
         env["PARSNP_OUTPUT_PWRITE"] = "1"  # positioned writes instead of the shared mapping (a file system that cannot reserve)
+    elif plain in ("groups", "groups_pwrite", "groups_grow"):
+        env["PARSNP_GAP_GROUPS"] = "3"     # the LCBs in three groups, each laid out and written as soon as its gaps are aligned
+        if plain == "groups_pwrite":
+            env["PARSNP_OUTPUT_PWRITE"] = "1"
+        if plain == "groups_grow":
+            env["PARSNP_RESERVE_TINY"] = "1"   # too small a reservation: the mapping grows group by group
     elif plain:
         env["PARSNP_PLAIN_OUTPUT"] = "1"
     rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, threads=3, **kw)
@@ -197,7 +203,9 @@ def test_streamed_and_plain_records_agree(cpu_checkers, tmp_path, name, plain):
     if plain == "mix":
         assert int(m.group(3)) > 0
     err = open(os.path.join(out, "parsnp-aligner.err")).read()
-    assert ("through positioned writes" in err) if plain in (True, "pwrite") else ("through a shared mapping" in err)
+    assert ("through positioned writes" in err) if plain in (True, "pwrite", "groups_pwrite") else ("through a shared mapping" in err)
+    if plain in ("groups", "groups_pwrite", "groups_grow"):
+        assert "in 3 group(s)" in err
 
 
 @pytest.mark.parametrize("first", [False, True])
