@@ -122,3 +122,46 @@ def test_fresh_sets_against_reference(device):
     for blk, want, rows in zip(blks, gapgen.reference_align(blks), got):
         if rows is not None:
             assert rows == want, blk
+
+
+def test_groups_report_in_order_and_match_the_batch(device):
+    """pm_gap_align_groups: the same jobs in four groups of consecutive jobs -- one with no job the device takes -- give
+    the rows of the single batch, and `done` hears of every group, in order, with the group's rows already in place"""
+    blks = gapgen.blocks(41, 240, lengths=(1, 2, 3, 5, 8, 13, 30, 60))
+    blks[100:100] = [["A" * 97, "A" * 60]] * 3                      # a group made of declined jobs only
+    want = device(blks)
+    lib = C.CDLL(HIP_LIB)
+    lib.pm_gap_align_groups.restype = C.c_int
+    nseq = np.array([len(b) for b in blks], np.int32)
+    flat = [s.encode() for b in blks for s in b]
+    off = np.zeros(len(flat) + 1, np.int64)
+    off[1:] = np.cumsum([len(s) for s in flat])
+    chars = np.frombuffer(b"".join(flat), np.uint8).copy()
+    maxc = np.array([min(DEVICE_COLS, (max(len(s) for s in b) * 3) // 2 + 16) for b in blks], np.int32)
+    row_off = np.zeros(len(blks), np.int64)
+    row_off[1:] = np.cumsum(nseq[:-1].astype(np.int64) * maxc[:-1])
+    out = np.zeros(int((nseq.astype(np.int64) * maxc).sum()) + 1, np.uint8)
+    cols = np.full(len(blks), -7, np.int32)
+    group_end = np.array([100, 103, 180, len(blks)], np.int64)
+    seen = []
+
+    def rows_of(j):
+        if cols[j] < 0:
+            return None
+        base = int(row_off[j])
+        return [out[base + i * int(maxc[j]): base + i * int(maxc[j]) + int(cols[j])].tobytes().decode() for i in range(len(blks[j]))]
+
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+
+    def done(ctx, g):
+        lo = 0 if g == 0 else int(group_end[g - 1])
+        seen.append((g, [rows_of(j) for j in range(lo, int(group_end[g]))] == want[lo:int(group_end[g])]))
+
+    cb = CB(done)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))   # noqa: E731
+    rc = lib.pm_gap_align_groups(C.c_int(-1), C.c_int64(len(blks)), p(nseq, C.c_int32), p(off, C.c_int64), p(chars, C.c_uint8), p(maxc, C.c_int32),
+                                 p(row_off, C.c_int64), p(out, C.c_uint8), C.c_int64(len(out)), p(cols, C.c_int32), C.c_int(4), p(group_end, C.c_int64), cb, None)
+    assert rc == 0
+    assert seen == [(0, True), (1, True), (2, True), (3, True)]
+    assert [rows_of(j) for j in range(len(blks))] == want
+    assert all(w is None for w in want[100:103]) and sum(w is not None for w in want) > 200
