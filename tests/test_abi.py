@@ -72,3 +72,21 @@ def test_product_does_not_reference_the_oracle():
         txt = open(p, errors="ignore").read()
         assert not re.search(r'#include\s*"[^"]*(oracle|emu)', txt), p
         assert not re.search(r"(CDLL|dlopen|-l)\s*\(?[\"']?[^\n]*(pm_oracle|mum_oracle|pm_emu)", txt), p
+
+
+def test_gap_groups_argument_checks():
+    """pm_gap_align_groups before it touches a device: inconsistent group boundaries are PM_EINVAL; an empty batch reports
+    every group at once and succeeds"""
+    lib = ctypes.CDLL(HIP_LIB)
+    lib.pm_gap_align_groups.restype = ctypes.c_int
+    CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)
+    seen = []
+    cb = CB(lambda ctx, g: seen.append(g))
+    i32 = (ctypes.c_int32 * 4)()
+    i64 = (ctypes.c_int64 * 4)()
+    u8 = (ctypes.c_uint8 * 4)()
+    args = lambda n_jobs, ends: (ctypes.c_int(-1), ctypes.c_int64(n_jobs), i32, i64, u8, i32, i64, u8, ctypes.c_int64(4), i32,   # noqa: E731
+                                 ctypes.c_int(len(ends)), (ctypes.c_int64 * len(ends))(*ends), cb, None)
+    assert lib.pm_gap_align_groups(*args(2, [1, 3])) == -2 and seen == []           # the last boundary is not n_jobs (PM_EINVAL)
+    assert lib.pm_gap_align_groups(*args(2, [2, 1, 2])) == -2 and seen == []        # boundaries go backwards
+    assert lib.pm_gap_align_groups(*args(0, [0, 0, 0])) == 0 and seen == [0, 1, 2]  # nothing to align: every group reported
