@@ -1,5 +1,7 @@
-"""Merge of the per-partition alignments of partition mode into one parsnp.xmfa -- restatement of the reference driver's
-partition.py, without its Biopython / pyspoa dependencies:
+"""TEST INFRASTRUCTURE ONLY -- Python restatement of the reference driver's partition.py, function by
+function, without its Biopython / pyspoa dependencies.  The product's merge is native
+(parsnp_amd/csrc/host/partition_merge.cpp behind include/parsnp_merge.h); tests compare it with this file byte for byte
+and pin both against the hand-checked vectors of tests/golden/partition/.  Nothing under parsnp_amd/ imports this.
 
     interval_intersection, cut_overlaps         partition.py:35-61, :86-96
     chunk_intervals                             get_interval + get_chunked_intervals, :64-83, :507-536
@@ -8,14 +10,14 @@ partition.py, without its Biopython / pyspoa dependencies:
     combine_header_info, write_combined_header  :245-318
     merge_blocks / merge_xmfas                  :320-433, :683-736
 
-PARITY UNPINNED: partition.py cannot be imported in the build container (Bio, spoa absent), so these functions
-are pinned by code reading and by the properties tests/test_partition_merge.py checks (every trimmed partition has the
-same reference intervals; every record, gaps removed, spells its genome interval; the merged rows carry every partition's
-columns in reference order), not by the reference's output.  One deliberate difference: columns that are insertions
-relative to the reference are re-aligned by the reference with spoa.poa (:386); SPOA is a third-party library that is not
-here, so `align_insertions` is pluggable -- default: this project's gap aligner (the libMUSCLE restatement behind
-parsnp_core's XMFA writer) when libparsnp_core.so is built, else left-justified padding.  Reference-anchored columns,
-coordinates, headers and block order do not depend on it.
+PARITY UNPINNED against the reference's own output: partition.py cannot be imported in the build container (Bio, spoa
+absent, no network), so this restatement is pinned by code reading, by hand-checked vectors
+(tests/golden/partition/README.md says how each expected file was derived) and by the properties
+tests/test_partition_merge.py checks.  One deliberate difference: columns that are insertions relative to the reference
+are re-aligned by the reference with spoa.poa (:386); SPOA is a third-party library that is not here, so
+`align_insertions` is pluggable -- default: this project's gap aligner (the libMUSCLE restatement behind parsnp_core's
+XMFA writer), else left-justified padding.  Reference-anchored columns, coordinates, headers and block order do not
+depend on it.
 
 XMFA records are read as Bio.AlignIO's "mauve" parser presents them to partition.py: start = printed start - 1, end =
 printed end, strand +1/-1, name = the sequence index, id = the text after the strand ("clusterN sC:pP")."""
@@ -249,8 +251,8 @@ def _gap_aligner():
     if _GAP_LIB is None:
         _GAP_LIB = False
         try:
-            from .core_api import CORE_LIB
-            lib = ctypes.CDLL(os.environ.get("PARSNP_CORE_LIB") or CORE_LIB)
+            here = os.path.dirname(os.path.abspath(__file__))
+            lib = ctypes.CDLL(os.environ.get("PARSNP_GAP_LIB") or os.path.join(here, "..", "tests", "emu", "libgapalign.so"))
             lib.parsnp_gap_align.restype = ctypes.c_long
             lib.parsnp_gap_align.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_long]
             _GAP_LIB = lib

@@ -241,7 +241,7 @@ public:
                         gs += (size_t)(2 * ln[g] / div);
                         int64_t ns = (ln[g] >= K && nR >= K && g >= g_first && g < g_last) ? (ln[g] - K) / stride + 1 : 0;
                         if (small_pair(nR, ln[g]) && !no_small) ns = 0;
-                        units += 2 * ((ns + kUnitSamples - 1) / kUnitSamples);
+                        units += (ns + kUnitSamples - 1) / kUnitSamples;
                     }
                     guess_r[(size_t)r] = gs; units_r[(size_t)r] = units;
                     bad[(size_t)t] |= b;
@@ -347,8 +347,7 @@ public:
             be.mark("seed_extend");
             be.launch("seed_extend", nunits * 64,
                       SeedExtend{P, d_R.p, d_units.p, d_slots.p, d_filter.p, d_next.p, d_rep.p, d_repeated.p,
-                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err, work_budget,
-                                 getenv("PM_DEBUG_SEED") ? atoi(getenv("PM_DEBUG_SEED")) : 0});
+                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err, work_budget});
             if (!no_small)
                 be.launch("small_pair_events", npairs * 2,
                           SmallPairEvents{P, d_R.p, d_starts.p, d_lens.p, ngen, d_rep.p, d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, g_first, g_last});

@@ -190,10 +190,7 @@ struct RegionInfo {        // one per region of a batch
 };
 
 constexpr uint64_t kEmpty = ~0ull;
-#ifndef PM_UNIT
-#define PM_UNIT 64
-#endif
-constexpr int kUnitSamples = PM_UNIT;  // query samples per work unit (64 lanes x PM_UNIT/64): 64 keeps SeedExtend at 8 waves/SIMD
+constexpr int kUnitSamples = 64;       // query samples per work unit: one per lane
 constexpr int kSlices = 1024;          // the event buffer is appended through this many independent counters
 constexpr int kSliceStride = 8;        // uint64 words between two counters: one 64-byte line each
 
@@ -305,6 +302,37 @@ PM_HD uint64_t hash_tag(uint64_t t) {
     const uint32_t b = fmix32(a ^ lo ^ 0x68bc21ebu) + hi;
     return ((uint64_t)b << 32) | a;
 }
+// The index is keyed by CANONICAL K-mers: the smaller of a K-mer's tag and the tag of its reverse complement.  One probe
+// per sampled query K-mer then serves both strands of the query -- a hit whose reference K-mer equals the query K-mer is a
+// forward-strand seed, one that equals its reverse complement a reverse-strand seed (a palindromic K-mer is both) -- and the
+// reverse strand of a query is never streamed (it was 37 % of SeedExtend: nothing but filter probes that miss).
+PM_HD uint32_t brev32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x >> 8) & 0x00ff00ffu) | ((x & 0x00ff00ffu) << 8);
+    return (x >> 16) | (x << 16);
+#endif
+}
+// reverse complement of a K-mer tag, 1 <= K <= 16 (2K base bits | K mask bits << 32; an N stays an N, its base bits 0)
+PM_HD uint64_t rc_tag(uint64_t tag, int K) {
+    const uint32_t b = (uint32_t)tag, m = (uint32_t)(tag >> 32);
+    uint32_t rb = brev32(b);                                                   // base order reversed, the two bits of a base swapped
+    rb = ((rb >> 1) & 0x55555555u) | ((rb & 0x55555555u) << 1);                // ... and swapped back
+    rb = (~rb) >> (32 - 2 * K);                                                // complement (3 - code), the K bases moved down
+    uint32_t rm = 0;
+    if (m) {
+        rm = brev32(m) >> (32 - K);
+        uint32_t x = rm;                                                       // one mask bit -> the two bits of its base
+        x = (x | (x << 8)) & 0x00ff00ffu; x = (x | (x << 4)) & 0x0f0f0f0fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+        rb &= ~(x * 3u);
+    }
+    return (uint64_t)rb | ((uint64_t)rm << 32);
+}
+PM_HD uint64_t canonical_tag(uint64_t tag, int K) { const uint64_t rc = rc_tag(tag, K); return rc < tag ? rc : tag; }
 // largest r in [0, count) with base[r] <= x (base ascending, base[0] <= x)
 PM_HD int64_t upper_slot(const int64_t* base, int64_t count, int64_t x) {
     int64_t lo = 0, hi = count;
@@ -333,9 +361,9 @@ struct PackStrand {
 
 // ------------------------------------------------------------------------------------------ reference index
 // Replaces new_CSG/build_CSG/find_leaves (src/csgmum/csg.c:105-575): an open-addressing hash of the reference
-// substring's K-mers.  One 8-byte slot per distinct K-mer:  [63:32] fingerprint | [31] more-than-one-occurrence flag |
-// [30:0] head position; further occurrences hang off next[].  A fingerprint hit is confirmed against the K-mer at the
-// head position (the caller reads those reference bases anyway).
+// substring's CANONICAL K-mers.  One 8-byte slot per distinct canonical K-mer:  [63:32] fingerprint | [31]
+// more-than-one-occurrence flag | [30:0] head position; further occurrences (in either orientation) hang off next[].  A
+// fingerprint hit is confirmed against the K-mer at the head position (the caller reads those reference bases anyway).
 constexpr uint64_t kMulti = 1ull << 31;
 PM_HD int32_t slot_head(uint64_t s) { return (int32_t)(s & 0x7fffffffu); }
 
@@ -353,7 +381,7 @@ struct IndexInsert {
         next[tid] = -1;
         if (l + ri.K > ri.nR) return;
         const int64_t base = P.goff[0] + ri.ref_pos;
-        const uint64_t tag = kmer_tag(P, base + l, ri.K);
+        const uint64_t tag = canonical_tag(kmer_tag(P, base + l, ri.K), ri.K);
         const uint64_t hv = hash_tag(tag);
         const uint64_t fp = hv & 0xffffffff00000000ull;
         uint32_t h = (uint32_t)hv & ri.tmask;
@@ -370,7 +398,7 @@ struct IndexInsert {
                 seen = atomic_cas64(slot, kEmpty, fp | (uint64_t)l);
                 if (seen == kEmpty) return;                       // first occurrence of this K-mer
             }
-            if ((seen & 0xffffffff00000000ull) == fp && kmer_tag(P, base + slot_head(seen), ri.K) == tag) {
+            if ((seen & 0xffffffff00000000ull) == fp && canonical_tag(kmer_tag(P, base + slot_head(seen), ri.K), ri.K) == tag) {
                 for (;;) {                                          // push onto this K-mer's chain
                     next[tid] = slot_head(seen);
                     uint64_t prev = atomic_cas64(slot, seen, fp | kMulti | (uint64_t)l);
@@ -382,7 +410,7 @@ struct IndexInsert {
         }
     }
 };
-// -> slot value of the K-mer `tag` in region ri (confirmed against the reference K-mer at the head position), or kEmpty
+// -> slot value of the canonical K-mer `tag` in region ri (confirmed against the reference K-mer at the head position), or kEmpty
 PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_t* slots, const uint32_t* filter, uint64_t tag) {
     const uint64_t hv = hash_tag(tag);
     const uint64_t fp = hv & 0xffffffff00000000ull;
@@ -393,7 +421,7 @@ PM_HD uint64_t index_lookup(const Packed& P, const RegionInfo& ri, const uint64_
     for (;;) {
         const uint64_t seen = slots[ri.tbase + h];
         if (seen == kEmpty) return kEmpty;
-        if ((seen & 0xffffffff00000000ull) == fp && kmer_tag(P, base + slot_head(seen), ri.K) == tag) return seen;
+        if ((seen & 0xffffffff00000000ull) == fp && canonical_tag(kmer_tag(P, base + slot_head(seen), ri.K), ri.K) == tag) return seen;
         h = (h + 1) & ri.tmask;
     }
 }
@@ -432,21 +460,24 @@ struct RunLength {
 struct RepeatLength {
     Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;
     const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* run; int32_t* rep; uint32_t* repeated; uint32_t* err; int64_t budget;
-    // repeated: one bit per flat reference position, set when the K-mer starting there occurs elsewhere in R (rep' >= K);
-    // n/8 bytes, L2 resident -- SeedExtend's followers read it instead of probing the index
+    // repeated: one bit per flat reference position, set when the canonical K-mer starting there occurs elsewhere in R, in
+    // either orientation (its index chain has more than one entry); n/8 bytes, L2 resident -- SeedExtend's followers read
+    // it instead of probing the index
     PM_HD void operator()(int64_t tid) const {
         int64_t r = upper_slot(posbase, nregions, tid);
         const RegionInfo& ri = R[r];
         int32_t l = (int32_t)(tid - ri.posbase);
         int32_t best = 0;
+        bool shared = false;      // the canonical K-mer at l occurs elsewhere in R (in either orientation)
         if (l + ri.K <= ri.nR) {
             int64_t base = P.goff[0] + ri.ref_pos;
-            uint64_t tag = kmer_tag(P, base + l, ri.K);
+            uint64_t tag = canonical_tag(kmer_tag(P, base + l, ri.K), ri.K);
             uint64_t slot = index_lookup(P, ri, slots, filter, tag);
             if (slot != kEmpty && (slot & kMulti)) {
+                shared = true;
                 int64_t work = 0;
                 const int32_t r1 = run[tid];
-                const bool single = r1 >= ri.K;          // the K-mer is one symbol K times: so is every K-mer of its chain
+                const bool single = r1 >= ri.K;          // the K-mer is one symbol K times: its chain holds the runs of that symbol and of its complement
                 for (int32_t o = slot_head(slot); o >= 0; o = next[ri.posbase + o]) {
                     if (o == l) continue;
                     const int32_t cap = ri.nR - (l > o ? l : o);
@@ -454,12 +485,15 @@ struct RepeatLength {
                     if (single) {
                         // both suffixes begin with a run: different run lengths part where the shorter run ends
                         const int32_t r2 = run[ri.posbase + o];
-                        if (r1 != r2) { len = r1 < r2 ? r1 : r2; cost = 1; }
+                        if (lce_fwd(P, base + l, base + o, 1) == 0) { len = 0; cost = 1; }       // the complementary symbol
+                        else if (r1 != r2) { len = r1 < r2 ? r1 : r2; cost = 1; }
                         else { const int32_t more = lce_fwd(P, base + l + r1, base + o + r1, cap - r1); len = r1 + more; cost = 1 + (more >> 5); }
                         if (len > cap) len = cap;
                     } else {
-                        len = ri.K + lce_fwd(P, base + l + ri.K, base + o + ri.K, cap - ri.K);
+                        // from the K-mer's first base: an occurrence in the other orientation parts inside the K-mer and does not count
+                        len = lce_fwd(P, base + l, base + o, cap);
                         cost = 1 + (len >> 5);
+                        if (len < ri.K) len = 0;
                     }
                     if (len > best) best = len;
                     work += cost;
@@ -468,7 +502,7 @@ struct RepeatLength {
             }
         }
         rep[tid] = best;
-        if (best) atomic_or32(&repeated[tid >> 5], 1u << (tid & 31));
+        if (shared) atomic_or32(&repeated[tid >> 5], 1u << (tid & 31));
     }
 };
 
@@ -476,58 +510,57 @@ struct RepeatLength {
 // A (region, query piece) pair whose two sides both fit 128 bases -- practically all of the recursion's pairs -- is
 // compared diagonal by diagonal in registers (SmallPairEvents) instead of going through the K-mer index.
 PM_HD bool small_pair(int64_t nR, int64_t m) { return nR <= 128 && m <= 128; }
-// units of one (region, query genome) pair: 2 strands x ceil(samples / 256)
+// units of one (region, query genome) pair: ceil(samples / 64) -- the samples of the FORWARD strand of the query piece; a
+// seed of the reverse strand is found through the same probe (canonical K-mers)
 struct CountUnits {
     const RegionInfo* R; const int64_t* lens; int32_t ngen; int64_t* count;   // lens[r*ngen + g]
     int32_t g_first, g_last;   // query genomes [g_first, g_last) live on this GPU (all of them unless the run is sharded)
-    int no_small;              // debug: every pair through SeedExtend
+    int no_small;              // every pair through SeedExtend (calcmumi mode)
     PM_HD void operator()(int64_t pair) const {
         int64_t r = pair / (ngen - 1); int g = (int)(pair % (ngen - 1)) + 1;
         const RegionInfo& ri = R[r];
         int64_t m = lens[r * ngen + g];
         int64_t ns = (m >= ri.K && ri.nR >= ri.K && g >= g_first && g < g_last) ? (m - ri.K) / ri.stride + 1 : 0;
         if (small_pair(ri.nR, m) && !no_small) ns = 0;          // handled by SmallPairEvents, without index probes
-        count[pair] = 2 * ((ns + kUnitSamples - 1) / kUnitSamples);
+        count[pair] = (ns + kUnitSamples - 1) / kUnitSamples;
     }
 };
 // everything a SeedExtend wavefront needs to know about its unit, in one 32-byte record (one scalar load)
 struct alignas(32) UnitRec {
-    int64_t qbase;      // global base offset of the query piece on this unit's strand
+    int64_t qbase;      // global base offset of the query piece on the forward strand
+    int64_t qbase_r;    // ... and of the same piece, mirrored, on the stored reverse complement
     int32_t region;     // index into RegionInfo
     int32_t pair;       // region * (ngen-1) + (query genome - 1): the event key prefix
     int32_t m;          // length of the query piece
-    int32_t info;       // chunk << 1 | strand
-    int32_t pad_[2];
+    int32_t chunk;      // which 64 samples of the piece
 };
-// tid = work unit: which (pair, strand, chunk) it is (off[] = exclusive prefix of the per-pair unit counts)
+// tid = work unit: which (pair, chunk) it is (off[] = exclusive prefix of the per-pair unit counts)
 struct FillUnits {
     Packed P; const int64_t* starts; const int64_t* lens; int32_t ngen;
     const int64_t* off; const int64_t* count; int64_t npairs; UnitRec* units;
     PM_HD void operator()(int64_t tid) const {
         int64_t pair = upper_slot(off, npairs, tid);     // the last pair whose first unit is <= tid owns it
-        int64_t u = tid - off[pair], half = count[pair] / 2;
         const int64_t r = pair / (ngen - 1); const int g = (int)(pair % (ngen - 1)) + 1;
-        const int strand = u < half ? 0 : 1;
         const int64_t m = lens[r * ngen + g], qs = starts[r * ngen + g];
         UnitRec rec;
-        rec.qbase = strand ? P.goff[2 * g + 1] + (P.glen[g] - qs - m) : P.goff[2 * g] + qs;   // reverse strand: the piece, mirrored
+        rec.qbase = P.goff[2 * g] + qs;
+        rec.qbase_r = P.goff[2 * g + 1] + (P.glen[g] - qs - m);
         rec.region = (int32_t)r; rec.pair = (int32_t)pair; rec.m = (int32_t)m;
-        rec.info = (int32_t)(strand ? (((u - half) << 1) | 1) : (u << 1));
-        rec.pad_[0] = rec.pad_[1] = 0;
+        rec.chunk = (int32_t)(tid - off[pair]);
         units[tid] = rec;
     }
 };
 
 // ------------------------------------------------------------------------------------------ seed & extend
 // Replaces Find_UM (src/csgmum/mum.c:177-250): enumerates every R-unique maximal exact match of length >= minlen
-// between one query strand and the reference substring.  tid = unit*64 + lane; a lane takes samples
-// lane, lane+64, lane+128, lane+192 of its unit; sample s sits at query offset s*stride.  A match of length
-// >= minlen contains >= 1 whole sampled K-mer; it is reported from the first one only.
+// between BOTH strands of one query piece and the reference substring.  tid = unit*64 + lane; lane t takes sample
+// chunk*64 + t of the piece's forward strand; sample s sits at query offset s*stride.  A match of length >= minlen =
+// stride + K - 1 contains >= 1 whole sampled K-mer whichever strand it lies on; a forward match is reported from its
+// first sampled K-mer only, a reverse match from its last one (= the first in the reverse strand's own direction).
 struct SeedExtend {
     Packed P; const RegionInfo* R; const UnitRec* units;
     const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep; const uint32_t* repeated;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
-    int debug;   // PM_DEBUG_SEED experiments (profiling only; results are wrong when set): 1 no emit, 2 stop after lookup, 4 stop after left arm; 64 stop after the query K-mer, 128 stop after the right arm, 256 / 512 one strand only; 8 = every lane probes the index itself, 2048 = 32-base rounds in the right arm (same results)
     PM_HD void operator()(int64_t tid) const {
         int64_t unit = tid >> 6; int lane = (int)(tid & 63);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -536,10 +569,7 @@ struct SeedExtend {
         unit = (int64_t)__builtin_amdgcn_readfirstlane((int)unit);
 #endif
         const UnitRec rec = units[unit];
-        const int32_t pair = rec.pair, info = rec.info;
-        int strand = info & 1; int64_t chunk = info >> 1;
-        if ((debug & 256) && strand) return;     // profiling: forward-strand units only
-        if ((debug & 512) && !strand) return;    // profiling: reverse-strand units only
+        const int32_t pair = rec.pair;
         const RegionInfo& ri = R[rec.region];
         const int64_t m = rec.m;
         const int64_t qbase = rec.qbase;
@@ -553,17 +583,19 @@ struct SeedExtend {
         const uint64_t ev_cap = slice_cap;
         uint64_t* const key_out = ev_key + slice * slice_cap;
         uint64_t* const val_out = ev_val + slice * slice_cap;
-        // the first event of each of the thread's samples waits in registers and is written with ONE reservation per
-        // wavefront; a second event of the same sample (repeated K-mer) is rare and takes its own slot
-        constexpr int kPer = kUnitSamples / 64;
-        uint64_t bk[kPer], bv[kPer];
-        bool stop = false;
-#pragma unroll
-        for (int u = 0; u < kPer; u++) {
-            bk[u] = kEmpty; bv[u] = 0;
-            const int32_t sidx = (int32_t)chunk * kUnitSamples + u * 64 + lane;
+        // the first event of the lane's sample waits in registers and is written with ONE reservation per wavefront; a
+        // second event of the same sample (repeated or palindromic K-mer) is rare and takes its own slot
+        uint64_t bk = kEmpty, bv = 0;
+        auto emit = [&](int strand, int32_t l0, int64_t j0, int32_t len) {
+            const uint64_t ek = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
+            const uint64_t evv = ((uint64_t)j0 << 32) | (uint32_t)len;
+            if (bk == kEmpty) { bk = ek; bv = evv; }
+            else { const uint64_t at = atomic_add64(ev_count, 1); if (at < ev_cap) { key_out[at] = ek; val_out[at] = evv; } }
+        };
+        do {
+            const int32_t sidx = rec.chunk * kUnitSamples + lane;
             const int64_t j = (int64_t)sidx * ri.stride;
-            const bool valid = !stop && j + K <= m;
+            const bool valid = j + K <= m;
             // the four query blocks around the sample: the K-mer, the 32 bases before it and the 32 bases after it all come
             // out of them, and they are in flight while the index is probed
             const int64_t qp = qbase + j;
@@ -574,31 +606,32 @@ struct SeedExtend {
             const uint32_t kmask = K < 32 ? (uint32_t)((1ull << K) - 1) : ~0u;
             const Win qT = funnel(q1, q2, shq);
             const uint64_t tag = (qT.b & kbits) | ((uint64_t)(qT.m & kmask) << 32);
-            if (debug & 64) { if (tag == 12345) atomic_or32(err, 2u); continue; }
+            const uint64_t gat = rc_tag(tag, K);                 // the K-mer of the reverse strand that covers the same bases
+            const uint64_t ctag = gat < tag ? gat : tag;         // what the index knows both of them by
             // Index probes are the scarce resource (random 64-B requests at the fabric's request rate).  Consecutive lanes
-            // hold consecutive samples, and inside a match the K-mer of sample s+t sits t*stride bases after the K-mer of
-            // sample s.  So only every 8th lane (a leader) probes the index; a follower first looks where its leader's
-            // hit predicts its own K-mer: if the reference K-mer there equals its own and occurs nowhere else in R, that
-            // position is what the probe would have returned.  Otherwise it probes itself.
+            // hold consecutive samples, and inside a forward match the K-mer of sample s+t sits t*stride bases after the
+            // K-mer of sample s.  So only every 8th lane (a leader) probes the index; a follower first looks where its
+            // leader's hit predicts its own K-mer: if the reference K-mer there equals its own and its canonical form occurs
+            // nowhere else in R, that position is all the probe would have returned.  Otherwise it probes itself.
             uint64_t slot = kEmpty;
             const int sub = lane & 7;
-            const bool follow = ri.stride <= K && m >= 64 * (int64_t)ri.stride && !(debug & 8);   // short query pieces (recursion): one probe phase is faster
+            const bool follow = ri.stride <= K && m >= 64 * (int64_t)ri.stride;   // short query pieces (recursion): one probe phase is faster
             int32_t lead = -1;
             if (follow) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                if (valid && sub == 0) slot = index_probe(ri, slots, filter, tag);
+                if (valid && sub == 0) slot = index_probe(ri, slots, filter, ctag);
                 const int32_t mine = (sub == 0 && slot != kEmpty && !(slot & kMulti)) ? slot_head(slot) : -1;
                 lead = __shfl(mine, lane & ~7, 64);
 #else
                 // host emulation (one thread at a time): the leader's probe is recomputed by each of its followers
-                if (sub == 0) { if (valid) slot = index_probe(ri, slots, filter, tag); }
+                if (sub == 0) { if (valid) slot = index_probe(ri, slots, filter, ctag); }
                 else if (valid) {
-                    const uint64_t ls = index_probe(ri, slots, filter, kmer_tag(P, qbase + j - (int64_t)sub * ri.stride, K));
+                    const uint64_t ls = index_probe(ri, slots, filter, canonical_tag(kmer_tag(P, qbase + j - (int64_t)sub * ri.stride, K), K));
                     if (ls != kEmpty && !(ls & kMulti)) lead = slot_head(ls);
                 }
 #endif
             } else if (valid) {
-                slot = index_probe(ri, slots, filter, tag);
+                slot = index_probe(ri, slots, filter, ctag);
             }
             // the four reference blocks around the presumed position -- a follower's prediction, or the head of the probed
             // slot -- are fetched by all lanes in ONE round: confirmation of the K-mer, left arm and the first 32 bases of
@@ -606,6 +639,7 @@ struct SeedExtend {
             int32_t l = -1;
             int shr = 0;
             SeqBlock r0 = SeqBlock{0, 0, 0}, r1 = r0, r2 = r0, r3 = r0;
+            uint64_t rtag = 0;        // the reference K-mer at l
             bool multi = false;
             {
                 int32_t at = -1;
@@ -624,71 +658,84 @@ struct SeedExtend {
                     const uint32_t rw = is_pred ? repeated[fpos >> 5] : 0u;
                     r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
                     const Win rT = funnel(r1, r2, shr);
-                    ok = ((rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32)) == tag && !((rw >> (fpos & 31)) & 1u);
+                    rtag = (rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32);
+                    ok = is_pred ? (rtag == tag && !((rw >> (fpos & 31)) & 1u)) : (rtag == tag || rtag == gat);
                 }
                 if (ok) { l = at; multi = !is_pred && (slot & kMulti) != 0; }
                 else if (valid && (is_pred || (follow && sub != 0) || at >= 0)) {
                     // a follower without a confirmed prediction probes for itself; a probed slot whose K-mer differs
                     // (same 32-bit fingerprint, 2^-32) is settled by the confirmed lookup
-                    slot = (follow && sub != 0 && !(at >= 0 && !is_pred)) ? index_probe(ri, slots, filter, tag) : index_lookup(P, ri, slots, filter, tag);
+                    slot = (follow && sub != 0 && !(at >= 0 && !is_pred)) ? index_probe(ri, slots, filter, ctag) : index_lookup(P, ri, slots, filter, ctag);
                     if (slot != kEmpty) {
                         int32_t h2 = slot_head(slot);
                         int64_t rp = rbase + h2;
                         const SeqBlock* rb = P.blk + (rp >> 5) - 1;
                         r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
-                        const Win rT = funnel(r1, r2, shr);
-                        if (((rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32)) != tag) {
-                            slot = index_lookup(P, ri, slots, filter, tag);
+                        Win rT = funnel(r1, r2, shr);
+                        rtag = (rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32);
+                        if (rtag != tag && rtag != gat) {
+                            slot = index_lookup(P, ri, slots, filter, ctag);
                             h2 = slot == kEmpty ? -1 : slot_head(slot);
-                            if (h2 >= 0) { rp = rbase + h2; rb = P.blk + (rp >> 5) - 1; r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31); }
+                            if (h2 >= 0) {
+                                rp = rbase + h2; rb = P.blk + (rp >> 5) - 1; r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
+                                rT = funnel(r1, r2, shr);
+                                rtag = (rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32);
+                            }
                         }
                         l = h2;
                         multi = l >= 0 && (slot & kMulti) != 0;
                     }
                 }
             }
-            if (l < 0) continue;
-            if (debug & 2) { if (l == 123456789) atomic_or32(err, 2u); continue; }
+            if (l < 0) break;
             bool first_entry = true;
             for (; l >= 0; l = multi ? next[ri.posbase + l] : -1, first_entry = false) {
-                if (++work > budget) { atomic_or32(err, kErrWork); stop = true; break; }
-                // left: only `stride` bases matter -- a longer left arm means an earlier sample owns the match
-                int32_t lim = (int32_t)(j < l ? j : l);
-                if (lim > ri.stride) lim = ri.stride;
-                const bool in_regs = first_entry && ri.stride <= 32;     // both arms start inside the loaded blocks
-                int32_t left;
-                if (in_regs) { left = match_bwd(funnel(q0, q1, shq), funnel(r0, r1, shr)); if (left > lim) left = lim; }
-                else left = lce_bwd(P, qp, rbase + l, lim);
-                if (left >= ri.stride) continue;
-                if (debug & 4) { if (left == 12345) atomic_or32(err, 2u); continue; }
-                const int32_t rep_l0 = rep[ri.posbase + l - left];         // in flight while the right arm is compared
-                const int64_t mr = m - j - K; const int32_t rr = ri.nR - l - K;
-                const int32_t maxr = (int32_t)(mr < rr ? mr : rr);
-                int32_t right;
-                if (in_regs) {
-                    right = match_fwd(funnel3(q1, q2, q3, shq + K), funnel3(r1, r2, r3, shr + K));
-                    if (right >= 32 && maxr > 32) right = 32 + ((debug & 2048) ? lce_fwd(P, qp + K + 32, rbase + l + K + 32, maxr - 32) : lce_fwd64(P, qp + K + 32, rbase + l + K + 32, maxr - 32));
-                    if (right > maxr) right = maxr;
-                } else right = lce_fwd(P, qp + K, rbase + l + K, maxr);
-                int32_t len = left + K + right;
-                if (debug & 128) { if (len == 123456789) atomic_or32(err, 2u); continue; }
-                if (len < ri.minlen) continue;
-                int32_t l0 = l - left; int64_t j0 = j - left;
-                if (len <= rep_l0) continue;           // not unique in R
-                if (debug & 1) { if (len == 123456789) atomic_or32(err, 2u); continue; }
-                const uint64_t ek = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
-                const uint64_t evv = ((uint64_t)j0 << 32) | (uint32_t)len;
-                if (bk[u] == kEmpty) { bk[u] = ek; bv[u] = evv; }
-                else { uint64_t at = atomic_add64(ev_count, 1); if (at < ev_cap) { key_out[at] = ek; val_out[at] = evv; } }
+                if (++work > budget) { atomic_or32(err, kErrWork); break; }
+                // the entries of a chain share the canonical K-mer, not the orientation
+                if (!first_entry) rtag = kmer_tag(P, rbase + l, K);
+                if (rtag == tag) {
+                    // forward strand.  left: only `stride` bases matter -- a longer left arm means an earlier sample owns the match
+                    int32_t lim = (int32_t)(j < l ? j : l);
+                    if (lim > ri.stride) lim = ri.stride;
+                    const bool in_regs = first_entry && ri.stride <= 32;     // both arms start inside the loaded blocks
+                    int32_t left;
+                    if (in_regs) { left = match_bwd(funnel(q0, q1, shq), funnel(r0, r1, shr)); if (left > lim) left = lim; }
+                    else left = lce_bwd(P, qp, rbase + l, lim);
+                    if (left < ri.stride) {
+                        const int32_t rep_l0 = rep[ri.posbase + l - left];         // in flight while the right arm is compared
+                        const int64_t mr = m - j - K; const int32_t rr = ri.nR - l - K;
+                        const int32_t maxr = (int32_t)(mr < rr ? mr : rr);
+                        int32_t right;
+                        if (in_regs) {
+                            right = match_fwd(funnel3(q1, q2, q3, shq + K), funnel3(r1, r2, r3, shr + K));
+                            if (right >= 32 && maxr > 32) right = 32 + lce_fwd64(P, qp + K + 32, rbase + l + K + 32, maxr - 32);
+                            if (right > maxr) right = maxr;
+                        } else right = lce_fwd(P, qp + K, rbase + l + K, maxr);
+                        const int32_t len = left + K + right;
+                        if (len >= ri.minlen && len > rep_l0) emit(0, l - left, j - left, len);      // len <= rep': not unique in R
+                    }
+                }
+                if (rtag == gat) {
+                    // reverse strand: the same bases are the K-mer at jr of the mirrored piece; its left arm runs where this
+                    // strand's right arm would (inversions and spurious hits only: arms straight from memory)
+                    const int64_t jr = m - K - j;
+                    const int64_t qpr = rec.qbase_r + jr;
+                    int32_t lim = (int32_t)(jr < l ? jr : l);
+                    if (lim > ri.stride) lim = ri.stride;
+                    const int32_t left = lce_bwd(P, qpr, rbase + l, lim);
+                    if (left < ri.stride) {
+                        const int32_t rep_l0 = rep[ri.posbase + l - left];
+                        const int32_t rr = ri.nR - l - K;
+                        const int32_t maxr = (int32_t)(j < rr ? j : rr);               // m - jr - K = j bases follow the K-mer on the mirrored piece
+                        const int32_t right = lce_fwd(P, qpr + K, rbase + l + K, maxr);
+                        const int32_t len = left + K + right;
+                        if (len >= ri.minlen && len > rep_l0) emit(1, l - left, jr - left, len);
+                    }
+                }
             }
-        }
-        uint32_t nb = 0;
-#pragma unroll
-        for (int u = 0; u < kPer; u++) nb += bk[u] != kEmpty;
-        uint64_t at = kPer == 1 ? wave_reserve01(ev_count, nb != 0) : wave_reserve(ev_count, nb);
-#pragma unroll
-        for (int u = 0; u < kPer; u++)
-            if (bk[u] != kEmpty) { if (at < ev_cap) { key_out[at] = bk[u]; val_out[at] = bv[u]; } at++; }
+        } while (false);
+        const uint64_t at = wave_reserve01(ev_count, bk != kEmpty);
+        if (bk != kEmpty && at < ev_cap) { key_out[at] = bk; val_out[at] = bv; }
     }
 };
 

@@ -1,15 +1,25 @@
-"""Partition merge (parsnp_amd/partition_merge.py = the reference driver's partition.py:35-61, 86-216, 245-433, 539-736
-without Biopython / pyspoa).  partition.py cannot be imported here, so parity with it is UNPINNED; what is checked:
-hand-worked vectors for the interval arithmetic and the trimming, and end to end -- three partitions of a seeded set run
-through the host binary (CPU checker provider) -- the properties the merge must have whatever aligns the insertion columns:
-every trimmed partition has the same reference pieces, every record spells its genome interval, the merged file holds every
-genome once with rows of equal length."""
+"""Partition merge: the product's native merge (parsnp_amd/csrc/host/partition_merge.cpp behind include/parsnp_merge.h) and
+the Python restatement of the reference driver's partition.py (oracle/partition_oracle.py = partition.py:35-61, 86-216,
+245-433, 507-736 without Biopython / pyspoa; test infrastructure).  partition.py cannot be imported here (Bio, spoa absent),
+so parity with the reference's own output stays UNPINNED; what is checked:
+  * hand-worked vectors for the interval arithmetic, the trimming and the block merge (restatement), and the hand-checked
+    files of tests/golden/partition/ (both implementations, byte for byte; README.md there derives every expected line);
+  * native == restatement byte for byte (trimmed files and merged file) on partitions of seeded sets run through the host
+    binary (CPU checker provider);
+  * the properties the merge must have whatever aligns the insertion columns: every trimmed partition has the same
+    reference pieces, every record spells its genome interval, the merged file holds every genome once with rows of equal
+    length."""
+import filecmp
 import os
+import shutil
+import sys
 
 import pytest
 
-from parsnp_amd import partition_merge as pmg
-from parsnp_amd import partition_run, synth
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import partition_oracle as pmg  # noqa: E402
+from parsnp_amd import merge as native_merge  # noqa: E402
+from parsnp_amd import partition_run, synth  # noqa: E402
 
 COMP = bytes.maketrans(b"ACGTN", b"TGCAN")
 
@@ -69,9 +79,17 @@ def spelled(genome: bytes, r):
 def test_three_partitions_end_to_end(cpu_checkers, tmp_path):
     ref, gs = synth.make("pop6x200k")
     rp, qs = synth.write_set(str(tmp_path / "in"), ref, gs)
-    res = partition_run.run_partitioned(cpu_checkers, rp, qs, str(tmp_path / "out"), 2)
+    res = partition_run.run_partitioned(cpu_checkers, rp, qs, str(tmp_path / "out"), 2, keep_trimmed=True)
     assert [p["queries"] for p in res["partitions"]] == [2, 2, 2] and all(p["ok"] for p in res["partitions"])
     m = res["merged"]
+    # the native merge (what run_partitioned called) against the restatement: trimmed files and merged file, byte for byte
+    xs = [os.path.join(p["dir"], "parsnpAligner.xmfa") for p in res["partitions"]]
+    for x in xs:
+        shutil.move(x + ".trimmed", x + ".trimmed.native")
+    om = pmg.merge_partitions(xs, str(tmp_path / "oracle.xmfa"))
+    assert (om["clusters"], om["sequences"]) == (m["clusters"], m["sequences"])
+    assert all(filecmp.cmp(x + ".trimmed", x + ".trimmed.native", shallow=False) for x in xs)
+    assert filecmp.cmp(str(tmp_path / "oracle.xmfa"), m["xmfa"], shallow=False)
     assert m["sequences"] == 7 and m["clusters"] > 20
     genomes = {"ref.fna": ref}
     genomes.update({os.path.basename(q): g for q, g in zip(qs, gs)})
