@@ -94,3 +94,14 @@ def consistency(path, genomes):
                     stats["bad_sequence"] += 1
         block = []
     return stats
+
+
+def native_consistency(path, genome_dir, merged=False, threads=16, intervals=None):
+    """the same counts from oracle/_ref/xmfa_check (tests/emu/xmfa_check.cpp) -- for XMFA files of GB size.  genome_dir holds
+    the FASTA files the header's ##SequenceFile entries name.  merged: a partition merge (see xmfa_check.cpp)."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "xmfa_check")
+    cmd = [exe] + (["--merged"] if merged else []) + (["--intervals", intervals] if intervals else []) + [path, genome_dir, str(threads)]
+    return json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True).stdout)
