@@ -9,7 +9,10 @@ One "step" = one pass of the hot path over one batch of synthetic genomes (refer
 sequences are already resident in HBM (ingest, upload and XMFA writing are outside the timed region and reported
 separately).  N > 1: partition mode's natural split -- every rank owns one partition (the shared reference + its own
 G query genomes) on its own GPU, no data-path collective; value = genomes of all ranks / max-over-ranks time
-("scaling": "weak").
+("scaling": "weak") -- and, in the same line under `sharded_strong`, the SAME G genomes as one alignment sharded over the
+N GPUs (strong scaling: all-reduce(min) + all-gather per engine call over the engine's RCCL communicator), measured by a
+child process per rank.  `n_ranks_seen_by_rccl` and `per_rank` (host threads budgeted from the container's CPU quota,
+cores kept busy, ms per step of every rank) say what the numbers were measured on.
 
 The JSON line also carries
   roofline      dominant kernel (SeedExtend), timed live with HIP events on the engine's stream over every engine launch of
@@ -35,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 RANDOM_PEAK_GBS = 3400.0   # measured ceiling of scattered 64-byte requests (scripts/hbm_calib.hip gather kernels, profiles/r01/calibration.json: 54 G requests/s): what an index probe can reach
-PROFILE_ROUND = "r02"   # profiles/<round>/traffic_seed_extend.json, calibration.json: the PMC passes of the shipped binary
+PROFILE_ROUND = "r03"   # profiles/<round>/traffic_seed_extend.json, calibration.json: the PMC passes of the shipped binary
 
 
 def engine_src_sha256():
@@ -167,18 +170,21 @@ def exchange_intervals(torch, dist, tdev, intervals):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)      # ~5 s of timed region at 200 x 5 Mb: long enough for an outside GPU-activity sampler to see
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="bact200")
     ap.add_argument("--genomes", type=int, default=0, help="override the number of query genomes per partition")
     ap.add_argument("--cpu-sample", type=int, default=2, help="query genomes in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--host-threads", type=int, default=0,
                     help="ini [LCB] cores: host threads for ingest, candidate validation, output (0 = 24, fewer when the CPUs this "
                          "container may use, shared by the ranks of the node, do not allow it)")
-    ap.add_argument("--mode", default="partition", choices=["partition", "sharded"],
-                    help="N > 1: 'partition' (default) = one independent partition per GPU, weak scaling, no data-path collective; "
-                         "'sharded' = ONE alignment (the workload's genomes) sharded over the GPUs, strong scaling, both exchanges of "
-                         "every engine call over the engine's own RCCL communicator (device buffers)")
+    ap.add_argument("--mode", default="both", choices=["both", "partition", "sharded"],
+                    help="N > 1: 'partition' = one independent partition per GPU, weak scaling, no data-path collective (the headline "
+                         "value); 'sharded' = ONE alignment (the workload's genomes) sharded over the GPUs, strong scaling, both exchanges "
+                         "of every engine call over the engine's own RCCL communicator (device buffers); 'both' (default) = the partition "
+                         "measurement as the line's value and, for N > 1, the sharded measurement of the same workload beside it "
+                         "(`sharded_strong`, run by one child process per rank so that it cannot take the headline down with it)")
+    ap.add_argument("--inputs", default="", help="directory with ref.fna + g*.fna to use instead of generating the workload (the sharded child of --mode both)")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
@@ -199,6 +205,7 @@ def main():
     dist = None
     tdev = "cuda"
     sharded = args.mode == "sharded"
+    both = args.mode == "both" and world > 1
     if world > 1:
         import torch.distributed as dist
         if torch.cuda.device_count() >= world and not sharded:
@@ -237,7 +244,14 @@ def main():
     workdir = tempfile.mkdtemp(prefix="parsnp_bench_r%d_" % rank, dir=scratch)
     try:
         t0 = time.time()
-        rp, qs, n_ref, m_avg, kw = make_inputs(workdir, args.workload, args.genomes, 0 if sharded else rank)   # sharded: every rank the same genomes
+        if args.inputs:      # files some other process generated (same workload, same seeds)
+            import glob
+            rp, qs = os.path.join(args.inputs, "ref.fna"), sorted(glob.glob(os.path.join(args.inputs, "g*.fna")))
+            size = lambda f: sum(len(l) - 1 for l in open(f, "rb") if not l.startswith(b">"))      # noqa: E731
+            n_ref, m_avg = size(rp), sum(size(q) for q in qs[:4]) / max(1, len(qs[:4]))
+            kw = dict(__import__("parsnp_amd.synth", fromlist=["CONFIGS"]).CONFIGS[args.workload][1])
+        else:
+            rp, qs, n_ref, m_avg, kw = make_inputs(workdir, args.workload, args.genomes, 0 if sharded else rank)   # sharded: every rank the same genomes
         gen_s = time.time() - t0
         out = os.path.join(workdir, "out")
         os.makedirs(out, exist_ok=True)
@@ -300,11 +314,49 @@ def main():
             if rank == 0:
                 run.write()          # XMFA + log of one partition: outside the timed region, reported as split_s.output
             output_s = time.time() - t_out
+            # how many ranks RCCL itself counts: the engine's communicator (sharded), torch's (partition mode's interval exchange)
+            if sharded:
+                run.L.pc_rccl_ranks.argtypes = [__import__("ctypes").c_void_p]
+                rccl_ranks = int(run.L.pc_rccl_ranks(run.h))
+            else:
+                rccl_ranks = dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else (1 if dist is None else 0)
             run.close()
         finally:
             os.dup2(so, 1); os.dup2(se, 2)
             if os.environ.get("PARSNP_BENCH_LOG") and rank == 0:     # keep the host's chatter (PARSNP_DEBUG_TIMERS laps)
                 shutil.copyfile(os.path.join(out, "bench.log"), os.environ["PARSNP_BENCH_LOG"])
+        per_rank = [{"rank": rank, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "host_threads": args.host_threads, "host_cores_busy": round(host_cores_busy, 2)}]
+        sharded_strong = None
+        if dist is not None:
+            box = [None] * world
+            dist.all_gather_object(box, per_rank[0])
+            per_rank = box
+        if both:
+            # the same workload as ONE alignment sharded over the ranks (strong scaling): a child process per rank -- its own HIP
+            # context and the engine's own RCCL, rendezvous one port up -- on rank 0's genome files; a failure or a hang of that
+            # never-before-exercised path costs this key, not the line
+            box = [os.path.join(workdir, "in") if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if torch.cuda.device_count() >= world:
+                env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23), PARSNP_RCCL_TIMEOUT="120")
+                cmd = [sys.executable, os.path.abspath(__file__), "--mode", "sharded", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                       "--workload", args.workload, "--cpu-sample", "0", "--inputs", box[0], "--host-threads", str(args.host_threads)]
+                try:
+                    pr = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+                    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                    if rank == 0:
+                        if pr.returncode == 0 and lines:
+                            cj = json.loads(lines[-1])
+                            sharded_strong = {k: cj.get(k) for k in ("value", "unit", "ms_per_step", "scaling", "n_gpus", "steps", "n_ranks_seen_by_rccl", "per_rank", "step_ms",
+                                                                     "engine_ms", "split_s", "mums", "lcbs", "core_bp_aligned")}
+                            sharded_strong["config"] = cj.get("config", {}).get("parallelism")
+                        else:
+                            sharded_strong = {"error": "child exit code %d: %s" % (pr.returncode, pr.stderr[-400:])}
+                except subprocess.TimeoutExpired:
+                    sharded_strong = {"error": "the sharded child did not finish within 900 s"}
+            else:
+                sharded_strong = {"skipped": "needs one GPU per rank (%d ranks, %d GPUs visible)" % (world, torch.cuda.device_count())}
+            dist.barrier()
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -327,46 +379,65 @@ def main():
                     phases[k] = phases.get(k, 0.0) + v / len(reports)
                 for k, v in r["engine_ms"].items():
                     totals[k] = totals.get(k, 0.0) + v / len(reports)
-            kernels = {k: v for k, v in totals.items() if k not in ("setup", "download", "units", "call_wall")}
+            counts = ("budget_retries", "events")          # counts that travel in the timing list, not times
+            kernels = {k: v for k, v in totals.items() if k not in ("setup", "download", "units", "call_wall") + counts}
             dom = max(kernels, key=kernels.get) if kernels else None
             launches = sum(r["finder_calls"] for r in reports) / len(reports)          # engine launches per step
-            alg_step = sum(r["alg_bytes"] for r in reports) / len(reports)             # SURVEY 8d bytes of all of them
-            b_alg = m_avg / 4 + 16 * m_avg + 16 * n_ref          # bytes per query genome of the anchor launch (SURVEY 8d)
+            survey_step = sum(r["alg_bytes"] for r in reports) / len(reports)          # SURVEY 8d bytes of all of them
+            # what THIS engine's event search must move per step: (m + n)/2 per (region, query genome) -- the query piece and the
+            # reference window once, 16 B per 32 bases -- + one 64-B index request per sampled K-mer (pairs that fit 128 bases use
+            # no index) + 16 B per event it appends; summed by the host over every pair it sends (Stats::alg_bytes_kernel)
+            events_step = totals.get("events", 0.0)
+            alg_step = sum(r.get("alg_bytes_kernel", 0) for r in reports) / len(reports) + 16.0 * events_step
+            b_alg = m_avg / 4 + 16 * m_avg + 16 * n_ref          # SURVEY 8d: bytes per query genome of the anchor launch
+            anchor_stride = max(1, int(reports[-1].get("anchor_minsize", 25)) - 16 + 1)     # sampling step of the anchor launch (K = 16)
             roof = None
             traffic = None
-            traffic_note = "no PMC pass on file for this binary: frac is the model ratio"
-            peak_random = None
+            traffic_raw = None
+            traffic_note = "no PMC pass on file for this binary"
             pdir = os.path.join(ROOT, "profiles", PROFILE_ROUND)
             tpath = os.path.join(pdir, "traffic_seed_extend.json")
             if dom == "seed_extend" and args.workload == "bact200" and G == 200 and os.path.exists(tpath):
-                # HBM bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) on this exact
+                # fabric-side bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) on this exact
                 # workload; see the file for provenance, the calibration and the correction applied.  Quoted only for the
                 # binary the passes ran on (sha256 of libparsnp_hip.so stamped into the file by scripts/profile_summary.py).
                 tj = json.load(open(tpath))
                 if tj.get("so_sha256") == so_sha256() or (tj.get("engine_src_sha256") and tj.get("engine_src_sha256") == engine_src_sha256()):
                     traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this binary (profiles/%s)" % PROFILE_ROUND
+                    traffic_raw = tj.get("raw")
+                    traffic_note = tj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this binary (profiles/%s)" % PROFILE_ROUND)
                 else:
                     traffic_note = "profiles/%s/traffic_seed_extend.json was measured on another build of the engine: not quoted" % PROFILE_ROUND
-            peak_random = RANDOM_PEAK_GBS
             if dom and launches:
                 launch_ms = kernels[dom] / launches
-                model_gbs = alg_step / (kernels[dom] * 1e-3) / 1e9
-                # headline = bytes that crossed the HBM interface (PMC) / launch time; the model ratio (SURVEY 8d's algorithmic
-                # bytes / time) is kept beside it: it says how fast the kernel is relative to streaming the model's bytes,
-                # not how much of the 8 TB/s it moves
-                hbm_gbs = traffic / (launch_ms * 1e-3) / 1e9 if traffic else None
-                roof = {"bound": "hbm", "kernel": "seed_extend (SeedExtend + SmallPairEvents)" if dom == "seed_extend" else dom,
-                        "achieved": round(hbm_gbs if hbm_gbs is not None else model_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round((hbm_gbs if hbm_gbs is not None else model_gbs) / HBM_PEAK_GBS, 5),
-                        "frac_basis": "pmc_traffic" if hbm_gbs is not None else "model_bytes",
-                        "traffic": traffic, "traffic_note": traffic_note,
-                        "model_achieved": round(model_gbs, 2), "frac_model": round(model_gbs / HBM_PEAK_GBS, 5),
-                        "peak_random": peak_random, "frac_of_peak_random": round(hbm_gbs / peak_random, 5) if (hbm_gbs and peak_random) else None,
-                        "launch_ms": round(launch_ms, 4),
-                        "launches_per_step": launches, "alg_bytes_per_launch": int(alg_step / launches),
-                        "anchor_launch": {"launch_ms": round(phases.get(dom, 0.0), 4), "alg_bytes": int(b_alg * G),
-                                          "model_achieved": round(b_alg * G / (phases[dom] * 1e-3) / 1e9, 2) if phases.get(dom) else None}}
+                alg_gbs = alg_step / (kernels[dom] * 1e-3) / 1e9
+                survey_gbs = survey_step / (kernels[dom] * 1e-3) / 1e9
+                traffic_gbs = traffic / (launch_ms * 1e-3) / 1e9 if traffic else None
+                # achieved = algorithmic bytes of this engine's event search per launch / its HIP-event time, against the 8 TB/s HBM
+                # peak (the contract's roofline).  The kernel does not live under that roof: its requests are scattered 64-B index
+                # and sequence reads whose ceiling is the fabric's request rate (54 G requests/s = 3.4 TB/s, scripts/hbm_calib.hip),
+                # most of them served by the 256 MB Infinity Cache -- `limiter` says so, `traffic` is what the counters saw.
+                roof = {"bound": "hbm",
+                        "limiter": "request rate of scattered 64-B reads (index slots, presence filter, sequence blocks at hashed positions: 54 G requests/s "
+                                   "= 3.4 TB/s measured ceiling), then instruction issue under divergence; not byte bandwidth -- the index (67 MB), the filter "
+                                   "(8 MB) and the reference (2.5 MB) sit in the 256 MB Infinity Cache",
+                        "kernel": "seed_extend (SeedExtend + SmallPairEvents)" if dom == "seed_extend" else dom,
+                        "achieved": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 5),
+                        "frac_basis": "algorithmic bytes of this engine per launch / HIP-event time of the launch",
+                        "alg_model": "(m + n)/2 per (region, query genome) + 64 B per sampled K-mer (none for pairs that fit 128 bases) + 16 B per event",
+                        "alg_bytes_per_launch": int(alg_step / launches), "events_per_step": int(events_step),
+                        "alg_query_stream_bytes_per_launch": int(sum(r.get("alg_bytes_query", 0) for r in reports) / len(reports) / launches),
+                        "launch_ms": round(launch_ms, 4), "launches_per_step": launches,
+                        "traffic": traffic, "traffic_raw": traffic_raw, "traffic_note": traffic_note,
+                        "traffic_includes_infinity_cache_hits": True,
+                        "traffic_rate": round(traffic_gbs, 2) if traffic_gbs else None,
+                        "peak_random": RANDOM_PEAK_GBS, "frac_of_peak_random": round(traffic_gbs / RANDOM_PEAK_GBS, 5) if traffic_gbs else None,
+                        "survey_8d": {"model": "m/4 + 16 m + 16 n per (region, query genome): one 8-byte probe and 16 bytes of state per query SUFFIX -- "
+                                               "this engine samples every (minsize-15)th K-mer instead, so it moves a fraction of these bytes",
+                                      "bytes_per_launch": int(survey_step / launches), "achieved": round(survey_gbs, 2), "frac": round(survey_gbs / HBM_PEAK_GBS, 5)},
+                        "anchor_launch": {"launch_ms": round(phases.get(dom, 0.0), 4), "survey_8d_bytes": int(b_alg * G),
+                                          "alg_bytes": int(G * ((m_avg + n_ref) / 2 + 64 * ((m_avg - 16) // max(1, anchor_stride) + 1)) + 16 * phases.get("events", 0.0)),
+                                          "achieved": round((G * ((m_avg + n_ref) / 2 + 64 * ((m_avg - 16) // max(1, anchor_stride) + 1)) + 16 * phases.get("events", 0.0)) / (phases[dom] * 1e-3) / 1e9, 2) if phases.get(dom) else None}}
             line = {
                 "metric": "genomes/sec (MUM+LCB end-to-end)", "value": round(value, 4), "unit": "genomes/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -376,7 +447,9 @@ def main():
                               ", ".join("%s=%s" % (k, v) for k, v in sorted(kw.items()) if k not in ("n", "n_genomes")),
                               "" if world == 1 else ("; ONE alignment sharded over %d ranks" % world if sharded else "; one partition per rank, %d ranks" % world)),
                            "genomes_per_gpu": G if not sharded else round(G / world, 2), "genome_bp": n_ref, "host_threads": args.host_threads, "host_cpus_usable": usable_cpus(), "numa_node": numa_node, "parallelism": ("sharded x%d (engine RCCL: all-reduce(min) + all-gather per engine call)" % world) if sharded else "partition-per-gpu x%d" % world},
-                "step_ms": step_ms, "host_cores_busy": round(host_cores_busy, 2),
+                "n_ranks_seen_by_rccl": rccl_ranks, "per_rank": per_rank,
+                "sharded_strong": sharded_strong,
+                "step_ms": step_ms[:40], "host_cores_busy": round(host_cores_busy, 2),
                 "core_bp_aligned": core_bp_total,
                 "core_bp_in_every_partition": merged_bp,
                 "mums": rep["mums"], "anchors": rep["anchors"], "lcbs": rep["lcbs"],

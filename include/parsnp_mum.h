@@ -64,6 +64,8 @@ int pm_session_create_sharded(pm_session** out, int device, int n_genomes, const
 int pm_rccl_unique_id(uint8_t* id /* PM_RCCL_ID_BYTES */);
 int pm_session_create_rccl(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens,
                            int rank, int world, const uint8_t* id /* PM_RCCL_ID_BYTES */);
+/* number of ranks of the session's RCCL communicator as RCCL reports it (ncclCommCount); 0 for a session without one */
+int pm_session_rccl_ranks(const pm_session* s);
 void pm_session_destroy(pm_session* s);
 int pm_session_genomes(const pm_session* s);
 
@@ -162,7 +164,11 @@ int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const 
  * = n_jobs): everything is uploaded once, the groups are aligned one after the other, and as soon as the rows and column
  * counts of group g are in the caller's arrays `done(ctx, g)` is called from the calling thread -- the caller may use them
  * while the later groups are still being aligned (the XMFA writer lays out and writes the records of the LCBs whose gaps
- * are done).  On an error return the groups after the last one reported have not been reported.  done may be NULL. */
+ * are done).  On an error return the groups after the last one reported have not been reported.  done may be NULL.
+ * The rows of a group come back in ONE copy of the span of out_rows that its accepted jobs cover: the row areas of the
+ * groups must not interleave (row_off ascending with the job number, as the batch form lays them out), and the rows of a
+ * declined job (cols[j] = -1) that lie inside such a span hold unspecified bytes afterwards.
+ * pm_gap_last_error(): the message of the last failed call of this process, from any thread. */
 int pm_gap_align_groups(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
                         const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols,
                         int n_groups, const int64_t* group_end, void (*done)(void* ctx, int group), void* ctx);

@@ -121,6 +121,7 @@ const char* pm_gap_last_error(void) { return ""; }
 int pm_warmup(int device) { (void)device; return PM_OK; }
 /* RCCL sessions exist in the HIP library only */
 int pm_rccl_unique_id(uint8_t* id) { (void)id; return PM_EINVAL; }
+int pm_session_rccl_ranks(const pm_session* s) { (void)s; return 0; }
 int pm_session_create_rccl(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens, int rank, int world, const uint8_t* id) {
     (void)out; (void)device; (void)n_genomes; (void)seqs; (void)lens; (void)rank; (void)world; (void)id; return PM_EINVAL;
 }

@@ -88,6 +88,7 @@ int pm_session_create_rccl(pm_session** out, int device, int n_genomes, const ui
     } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
     } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
 }
+int pm_session_rccl_ranks(const pm_session* s) { return s ? s->backend->comm_ranks() : 0; }
 #endif
 void pm_session_destroy(pm_session* s) { delete s; }
 int pm_session_genomes(const pm_session* s) { return s ? s->engine->ngen : 0; }
@@ -173,6 +174,7 @@ int pm_last_timing(const pm_session* cs, int* count, const char** names, float* 
     s->timing = s->engine->timing;
     if (s->call_wall_ms > 0) s->timing.push_back(pm::PhaseTime{"call_wall", s->call_wall_ms});
     if (s->engine->budget_retries) s->timing.push_back(pm::PhaseTime{"budget_retries", (float)s->engine->budget_retries});   // a count, not a time
+    s->timing.push_back(pm::PhaseTime{"events", (float)s->engine->last_events});      // a count too: R-unique maximal matches the event search appended (16 B each)
     int capn = *count, n = 0;
     for (const auto& t : s->timing) { if (n < capn) { names[n] = t.name; ms[n] = t.ms; } n++; }
     *count = n < capn ? n : capn;

@@ -5,10 +5,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types only: the library is loaded on demand (see Rccl below), never linked
 #include <rocprim/rocprim.hpp>
 
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <string>
 #include <thread>
@@ -42,6 +45,7 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
     static Rccl& get() {
@@ -57,6 +61,7 @@ struct Rccl {
         r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
         return r;
     }
@@ -100,8 +105,25 @@ struct HipBackend {
         ncclUniqueId id;
         static_assert(sizeof(ncclUniqueId) == 128, "PM_RCCL_ID_BYTES");
         memcpy(&id, id128, sizeof id);
-        return nccl_check(R.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+        // ranks that hold different ids (a stale id file, a rank of another launch) wait for each other forever inside
+        // ncclCommInitRank: a watchdog ends the process with a message instead (PARSNP_RCCL_TIMEOUT seconds, default 180; 0 = none)
+        const int limit = getenv("PARSNP_RCCL_TIMEOUT") ? atoi(getenv("PARSNP_RCCL_TIMEOUT")) : 180;
+        std::atomic<bool> done{false};
+        std::thread dog;
+        if (limit > 0)
+            dog = std::thread([&done, limit, rank, world] {
+                for (int t = 0; t < limit * 10 && !done.load(); t++) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                if (!done.load()) {
+                    fprintf(stderr, "parsnp engine: rank %d of %d: the RCCL communicator did not come up within %d s (ranks with different ids? a rank that never started?)\n", rank, world, limit);
+                    _exit(4);
+                }
+            });
+        const ncclResult_t r = R.CommInitRank(&comm, world, id, rank);
+        done.store(true);
+        if (dog.joinable()) dog.join();
+        return nccl_check(r, "ncclCommInitRank");
     }
+    int comm_ranks() { int n = 0; if (comm && Rccl::get().CommCount(comm, &n) == ncclSuccess) return n; return 0; }      // what RCCL itself says
     void fill32(int32_t* p, int32_t v) { check(hipMemsetD32Async((hipDeviceptr_t)p, v, 1, stream), "hipMemsetD32Async"); }
     // in place on a device buffer, on the engine's stream (stream-ordered with the kernels around it: no host round trip)
     int allreduce_min_i32_dev(int32_t* d, int64_t count) {

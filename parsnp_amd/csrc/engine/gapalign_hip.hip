@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -744,14 +745,22 @@ __global__ __launch_bounds__(64) void gap_align_kernel(Params P) {
 
 __global__ void warmup_kernel(int* p) { if (threadIdx.x == 0) *p = 1; }
 
-thread_local std::string g_err;
+// the last error, process wide: the XMFA writer makes the call on a side thread and asks for the message on another.
+// pm_gap_last_error() hands out a copy that stays valid until the calling thread asks again.
+std::mutex g_err_mu;
+std::string g_err;
 int32_t* g_dbg = nullptr; int64_t g_dbg_slots = 0;
 int32_t* g_dbg_dev = nullptr;      // PM_GAP_DEBUG=2: the markers live in device memory (cheap to write), peeked through a copy on another stream
-int fail(int code, const std::string& m) { g_err = m; return code; }
-bool g_tables_ready = false;
+int fail(int code, const std::string& m) { std::lock_guard<std::mutex> lk(g_err_mu); g_err = m; return code; }
+std::once_flag g_tables_once;
 }  // namespace
 
-extern "C" const char* pm_gap_last_error(void) { return g_err.c_str(); }
+extern "C" const char* pm_gap_last_error(void) {
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    copy = g_err;
+    return copy.c_str();
+}
 // Start the HIP runtime (device discovery, context, code objects: ~0.15 s of a fresh process) -- callable from a side
 // thread while the caller still parses its FASTA files, so that pm_session_create finds it running.
 extern "C" int pm_warmup(int device) {
@@ -810,17 +819,20 @@ extern "C" int pm_gap_align_groups(int device, int64_t n_jobs, const int32_t* n_
     std::vector<void*> owned;
     hipStream_t stream = nullptr;
     auto release = [&]() { for (void* p : owned) (void)hipFree(p); owned.clear(); if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; } };
-    if (!g_tables_ready) {
-        uint8_t letter[256];
-        memset(letter, 255, sizeof letter);
-        const char* res = "ACGT";
-        for (int i = 0; i < 4; i++) { letter[(uint8_t)res[i]] = (uint8_t)i; letter[(uint8_t)(res[i] + 32)] = (uint8_t)i; }
-        letter[(uint8_t)'U'] = letter[(uint8_t)'u'] = 3;
-        const char* wild = "MRWSYKVHDBXN";
-        for (int i = 0; i < 12; i++) { letter[(uint8_t)wild[i]] = (uint8_t)(4 + i); letter[(uint8_t)(wild[i] + 32)] = (uint8_t)(4 + i); }
-        letter[(uint8_t)'-'] = letter[(uint8_t)'.'] = 16;
-        GA_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_letter), letter, 256));
-        g_tables_ready = true;
+    {
+        hipError_t table_err = hipSuccess;
+        std::call_once(g_tables_once, [&] {
+            uint8_t letter[256];
+            memset(letter, 255, sizeof letter);
+            const char* res = "ACGT";
+            for (int i = 0; i < 4; i++) { letter[(uint8_t)res[i]] = (uint8_t)i; letter[(uint8_t)(res[i] + 32)] = (uint8_t)i; }
+            letter[(uint8_t)'U'] = letter[(uint8_t)'u'] = 3;
+            const char* wild = "MRWSYKVHDBXN";
+            for (int i = 0; i < 12; i++) { letter[(uint8_t)wild[i]] = (uint8_t)(4 + i); letter[(uint8_t)(wild[i] + 32)] = (uint8_t)(4 + i); }
+            letter[(uint8_t)'-'] = letter[(uint8_t)'.'] = 16;
+            table_err = hipMemcpyToSymbol(HIP_SYMBOL(c_letter), letter, 256);
+        });
+        GA_CHECK(table_err);
     }
     // jobs the device takes, longest first (the cost of one alignment grows with the square of its width)
     std::vector<Job> jobs; std::vector<int64_t> which; std::vector<int> group_of_job;
@@ -858,7 +870,8 @@ extern "C" int pm_gap_align_groups(int device, int64_t n_jobs, const int32_t* n_
     double tl = now();
     auto lap = [&](const char* what) { if (timers) { const double t = now(); fprintf(stderr, "[gap batch] %-12s %.4f s\n", what, t - tl); tl = t; } };
     hipDeviceProp_t prop;
-    GA_CHECK(hipGetDeviceProperties(&prop, device >= 0 ? device : 0));
+    if (device < 0) GA_CHECK(hipGetDevice(&device));      // the current device of this thread
+    GA_CHECK(hipGetDeviceProperties(&prop, device));
     // LDS of a workgroup: the fixed block plus the alignment rows of the widest job; as many workgroups per CU as fit in 160 KB
     const size_t rows_lds = ((((size_t)nmax * (size_t)cap) + 15) & ~(size_t)15) + ((((size_t)cap + 1) * ((size_t)cap + 1) + 15) & ~(size_t)15);
     const size_t lds = sizeof(Shared) + rows_lds;

@@ -359,19 +359,32 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     std::vector<int64_t>& starts = memory_->batch_starts; std::vector<int64_t>& lens = memory_->batch_lens;
     if (starts.size() < reqs.size() * n) { starts.resize(reqs.size() * n); lens.resize(reqs.size() * n); }
     std::vector<int32_t> mins(reqs.size());
-    double alg = 0;
+    double alg = 0, algk = 0, algq = 0;
     const long nreq = (long)reqs.size();
-#pragma omp parallel for schedule(dynamic, 64) num_threads(prm.cores > 0 ? prm.cores : 1) reduction(+ : alg) if (nreq > 256)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(prm.cores > 0 ? prm.cores : 1) reduction(+ : alg, algk, algq) if (nreq > 256)
     for (long i = 0; i < nreq; i++) {
         const Request& q = reqs[(size_t)i];
         memcpy(&starts[(size_t)i * n], q.start, n * 8);
         memcpy(&lens[(size_t)i * n], q.len, n * 8);
         mins[(size_t)i] = q.minsize;
-        double a = 0;
-        for (size_t g = 1; g < n; g++) a += (double)q.len[g] * 16.25 + 16.0 * (double)q.len[0];
-        alg += a;
+        // SURVEY 8d's model (one 8-byte index probe and 16 bytes of state per query suffix), and what the event search of THIS
+        // engine has to move per (region, query genome): the query piece once (16 B per 32 bases; the reverse strand is not
+        // streamed), the reference window once, and one 64-byte index request per sampled K-mer unless both sides fit 128
+        // bases (SmallPairEvents: no index).  Events (16 B each) are added by the caller from the engine's count.
+        const long minlen = q.minsize < 1 ? 1 : q.minsize, K = minlen < 16 ? minlen : 16, stride = minlen - K + 1;
+        double a = 0, k = 0, qb = 0;
+        for (size_t g = 1; g < n; g++) {
+            const double m = (double)q.len[g], nr = (double)q.len[0];
+            a += m * 16.25 + 16.0 * nr;
+            k += 0.5 * m + 0.5 * nr;
+            qb += 0.5 * m;
+            if (!(q.len[g] <= 128 && q.len[0] <= 128) && q.len[g] >= K && q.len[0] >= K) k += 64.0 * (double)((q.len[g] - K) / stride + 1);
+        }
+        alg += a; algk += k; algq += qb;
     }
     stats.alg_bytes += alg;
+    stats.alg_bytes_kernel += algk;
+    stats.alg_bytes_query += algq;
     stats.t_pack += now_s() - t0;
     pm_result* res = nullptr;
     int rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);

@@ -217,6 +217,8 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     double anchor_s = 0, extend_s = 0, filter_s = 0, lcb_s = 0, finder_s = 0;
     double t_pack = 0;      // request rows -> the flat arrays of the C ABI
     double alg_bytes = 0;   // sum over the regions sent to the engine of (m/4 + 16 m + 16 n) per query genome
+    double alg_bytes_query = 0;    // ... of which the query pieces (m/2): the one coalesced stream that reaches the fabric
+    double alg_bytes_kernel = 0;   // the same sum of what THIS engine's event search must move: (m + n)/2 + 64 B per sampled K-mer (run_batch)
     long finder_calls = 0, finder_regions = 0, regions_processed = 0, cache_hits = 0, cache_misses = 0, spec_rounds = 0;
     // device-side phase times (HIP events, pm_last_timing): summed over every engine call of the step, and of the
     // anchor call alone (the one launch that sees whole genomes)

@@ -42,6 +42,7 @@ int pc_open_rccl(const char* ini_path, int rank, int world, const uint8_t* id, p
     *out = r;
     return 0;
 }
+int pc_rccl_ranks(pc_run* r) { return pm_session_rccl_ranks(r->run.session); }
 // calcmumi on an opened run: writes <outdir>/all.mumi (rank 0 of a sharded run should be the only one to call pc_write)
 int pc_mumi(pc_run* r) { return r->run.mumi(); }
 // one pass of phases A-D; returns a JSON report (valid until the next call on this handle)
@@ -52,8 +53,8 @@ const char* pc_step(pc_run* r) {
     o.precision(9);
     o << "{\"provider\": \"" << pm_provider() << "\", \"queries\": " << r->run.qfiles << ", \"setup_s\": " << s.setup_s << ", \"path_s\": " << s.path_s << ", \"anchor_s\": " << s.anchor_s
       << ", \"extend_s\": " << s.extend_s << ", \"filter_s\": " << s.filter_s << ", \"lcb_s\": " << s.lcb_s << ", \"finder_s\": " << s.finder_s
-      << ", \"ingest_s\": " << r->run.ingest_s << ", \"upload_s\": " << r->run.upload_s << ", \"anchors\": " << s.anchors << ", \"mums\": " << s.mums
-      << ", \"lcbs\": " << s.lcbs << ", \"core_bp\": " << s.core_bp << ", \"alg_bytes\": " << (long long)s.alg_bytes << ", \"finder_calls\": " << s.finder_calls << ", \"finder_regions\": "
+      << ", \"ingest_s\": " << r->run.ingest_s << ", \"upload_s\": " << r->run.upload_s << ", \"anchors\": " << s.anchors << ", \"anchor_minsize\": " << (long)r->run.align->l << ", \"mums\": " << s.mums
+      << ", \"lcbs\": " << s.lcbs << ", \"core_bp\": " << s.core_bp << ", \"alg_bytes\": " << (long long)s.alg_bytes << ", \"alg_bytes_kernel\": " << (long long)s.alg_bytes_kernel << ", \"alg_bytes_query\": " << (long long)s.alg_bytes_query << ", \"finder_calls\": " << s.finder_calls << ", \"finder_regions\": "
       << s.finder_regions << ", \"regions_processed\": " << s.regions_processed << ", \"cache_hits\": " << s.cache_hits << ", \"cache_misses\": "
       << s.cache_misses << ", \"spec_rounds\": " << s.spec_rounds << ", \"mums_found\": " << (s.mums_found ? "true" : "false")
       << ", \"host_split_s\": {\"validate\": " << s.host.t_validate << ", \"neighbour\": " << s.host.t_neighbour << ", \"key\": " << s.host.t_key

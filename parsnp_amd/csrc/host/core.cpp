@@ -201,7 +201,7 @@ StepReport CoreRun::step() {
     a.flush_engine_timing();
     const Stats& s = a.stats;
     r.anchor_s = s.anchor_s; r.extend_s = s.extend_s; r.filter_s = s.filter_s; r.lcb_s = s.lcb_s; r.finder_s = s.finder_s;
-    r.alg_bytes = s.alg_bytes; r.finder_calls = s.finder_calls; r.finder_regions = s.finder_regions; r.regions_processed = s.regions_processed;
+    r.alg_bytes = s.alg_bytes; r.alg_bytes_kernel = s.alg_bytes_kernel; r.alg_bytes_query = s.alg_bytes_query; r.finder_calls = s.finder_calls; r.finder_regions = s.finder_regions; r.regions_processed = s.regions_processed;
     r.cache_hits = s.cache_hits; r.cache_misses = s.cache_misses; r.spec_rounds = s.spec_rounds;
     r.engine_ms = s.engine_ms; r.anchor_ms = s.anchor_ms; r.host = s;
     r.anchors = a.m0; r.mums = (long)a.mums.size(); r.lcbs = (long)a.lcbs.size();

@@ -13,7 +13,7 @@ namespace parsnp {
 struct StepReport {
     double setup_s = 0;   // per-run host state: layout bitmaps, arenas (and release of the previous step's)
     double path_s = 0, anchor_s = 0, extend_s = 0, filter_s = 0, lcb_s = 0, finder_s = 0;
-    double alg_bytes = 0;
+    double alg_bytes = 0, alg_bytes_kernel = 0, alg_bytes_query = 0;
     long finder_calls = 0, finder_regions = 0, regions_processed = 0, cache_hits = 0, cache_misses = 0, spec_rounds = 0;
     long anchors = 0, mums = 0, lcbs = 0, core_bp = 0;
     bool mums_found = false;

@@ -8,6 +8,9 @@
 #include <ctime>
 #include <fstream>
 #include <iostream>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "core.h"
 #include "minlen.h"
@@ -56,21 +59,41 @@ int main(int argc, char* argv[]) {
         const char* idf = getenv("PARSNP_RCCL_ID_FILE");
         if (!idf || !*idf) { std::cerr << "parsnp_core: a sharded run needs PARSNP_RCCL_ID_FILE (a path every rank can read)" << std::endl; exit(1); }
         run.shard.rank = rank; run.shard.world = world; run.shard.rccl = true;
+        // The id file is PARSNP_RCCL_ID_BYTES of communicator id followed by the launch's nonce (PARSNP_SHARD_NONCE: any
+        // string the launcher gives to all ranks of ONE launch).  Rank 0 removes what a previous run may have left before it
+        // creates its id, publishes id + nonce by rename, and removes the file again at exit; the other ranks accept a file
+        // only if it carries their nonce -- or, without a nonce, if it is not older than their own start (a stale id would
+        // leave the ranks waiting for each other inside ncclCommInitRank until the engine's watchdog ends them).
+        const std::string nonce = getenv("PARSNP_SHARD_NONCE") ? getenv("PARSNP_SHARD_NONCE") : "";
         if (rank == 0) {
+            unlink(idf);
             if (pm_rccl_unique_id(run.shard.rccl_id) != PM_OK) { std::cerr << "parsnp_core: " << pm_last_error() << std::endl; exit(3); }
             const std::string tmp = std::string(idf) + ".tmp";
             FILE* f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(run.shard.rccl_id, 1, PM_RCCL_ID_BYTES, f) != PM_RCCL_ID_BYTES || fclose(f) || rename(tmp.c_str(), idf)) {
+            if (!f || fwrite(run.shard.rccl_id, 1, PM_RCCL_ID_BYTES, f) != PM_RCCL_ID_BYTES || fwrite(nonce.data(), 1, nonce.size(), f) != nonce.size() || fclose(f) ||
+                rename(tmp.c_str(), idf)) {
                 std::cerr << "parsnp_core: cannot write " << idf << std::endl; exit(1);
             }
+            static std::string id_file_to_remove;
+            id_file_to_remove = idf;
+            atexit([] { unlink(id_file_to_remove.c_str()); });
         } else {
             bool got = false;
+            const time_t started = time(nullptr);
             for (int tries = 0; tries < 1200 && !got; tries++) {       // up to two minutes: rank 0 may still be starting
                 FILE* f = fopen(idf, "rb");
-                if (f) { got = fread(run.shard.rccl_id, 1, PM_RCCL_ID_BYTES, f) == PM_RCCL_ID_BYTES; fclose(f); }
+                if (f) {
+                    char extra[256];
+                    struct stat st;
+                    const bool whole = fread(run.shard.rccl_id, 1, PM_RCCL_ID_BYTES, f) == PM_RCCL_ID_BYTES;
+                    const size_t ne = whole ? fread(extra, 1, sizeof extra, f) : 0;
+                    const bool fresh = !nonce.empty() ? std::string(extra, ne) == nonce : (fstat(fileno(f), &st) == 0 && st.st_mtime + 60 >= started);
+                    got = whole && fresh;
+                    fclose(f);
+                }
                 if (!got) { struct timespec ts = {0, 100000000}; nanosleep(&ts, nullptr); }
             }
-            if (!got) { std::cerr << "parsnp_core: no RCCL id in " << idf << std::endl; exit(1); }
+            if (!got) { std::cerr << "parsnp_core: no RCCL id of this launch in " << idf << " (PARSNP_SHARD_NONCE must be the same for all ranks)" << std::endl; exit(1); }
         }
     }
     const bool writer = run.shard.rank == 0;

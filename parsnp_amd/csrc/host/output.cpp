@@ -413,6 +413,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     for (long x = 0; x < nj; x++) if (jobs[(size_t)x].dev < 0) rest.push_back(x);
     host_align(rest);
     long declined = 0;
+    bool device_gaps_failed = false;
     lap("wide gaps: host");
     // row i of an aligned gap: pointer + length (nullptr: the alignment failed, the gap is padded instead)
     auto aligned_row = [&](const Job& j, size_t i, size_t* len) -> const char* {
@@ -738,7 +739,14 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     // ---- group after group: wait for its alignments, lay it out, write it
     for (size_t g = 0; g < ngroups; g++) {
         const Group& G = batch[g];
-        if (batch_ready[g].get() != PM_OK) { cerr << "parsnp_core: gap alignment on the device failed: " << pm_gap_last_error() << endl; exit(1); }
+        if (batch_ready[g].get() != PM_OK) {
+            // the alignment itself is complete by now; a device that cannot take the gaps (out of memory for the workspace, a
+            // part that refuses the LDS request, a stream error) only costs time: every job of the group counts as declined
+            // and goes through the host aligner, which produces the same rows
+            if (!device_gaps_failed) cerr << "parsnp_core: gap alignment on the device failed (" << pm_gap_last_error() << "): aligning the gaps on the host" << endl;
+            device_gaps_failed = true;
+            for (size_t y = G.y0; y < G.y1; y++) B.cols[y] = -1;
+        }
         rest.clear();
         for (size_t y = G.y0; y < G.y1; y++) if (B.cols[y] < 0) rest.push_back(B.job[y]);
         declined += (long)rest.size();

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -31,7 +32,9 @@
 #include <string>
 #include <vector>
 
-#include <omp.h>
+#include <atomic>
+#include <chrono>
+#include <thread>
 
 #include "gapalign.h"
 
@@ -39,6 +42,19 @@ namespace parsnp {
 namespace {
 
 typedef std::pair<long, long> Interval;
+
+// n independent items over `threads` plain threads, handed out one at a time (no OpenMP here: this code also runs inside
+// Python processes, where spinning OpenMP workers of several libraries fight over a container's CPU quota)
+template <class F> void parallel_items(long n, int threads, F fn) {
+    if (n <= 0) return;
+    const int nt = (int)std::max<long>(1, std::min<long>(threads, n));
+    if (nt == 1) { for (long i = 0; i < n; i++) fn(i); return; }
+    std::atomic<long> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++) pool.emplace_back([&] { for (long i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto& th : pool) th.join();
+}
+double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Mapped {
     const char* p = nullptr; size_t n = 0; int fd = -1;
@@ -419,45 +435,48 @@ struct MergeStats { long clusters = 0, sequences = 0, intervals = 0, ref_bases =
 MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::string& out_path, long min_interval_size, int threads, bool keep_trimmed) {
     if (xmfas.empty()) throw std::runtime_error("no partition to merge");
     if (threads < 1) threads = 1;
+    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    double tl = wall_s();
+    auto lap = [&](const char* what) { if (dbg) { const double t = wall_s(); fprintf(stderr, "[merge] %-12s %.3f s\n", what, t - tl); tl = t; } };
     std::vector<Part> parts(xmfas.size());
     std::vector<std::string> errors(xmfas.size());
     const long np = (long)parts.size();
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-    for (long p = 0; p < np; p++) {
+    parallel_items(np, threads, [&](long p) {
         try { read_xmfa(xmfas[(size_t)p], &parts[(size_t)p].x); } catch (const std::exception& e) { errors[(size_t)p] = e.what(); }
-    }
+    });
     for (long p = 0; p < np; p++) if (!errors[(size_t)p].empty()) throw std::runtime_error(xmfas[(size_t)p] + ": " + errors[(size_t)p]);
+    lap("read");
     std::vector<IntervalMap> per_chunk;
     for (const Part& pt : parts) per_chunk.push_back(chunk_intervals(pt.x));
     const IntervalMap inter = intersected_intervals(per_chunk, min_interval_size);
     MergeStats st;
     for (auto& kv : inter) { st.intervals += (long)kv.second.size(); for (const Interval& iv : kv.second) st.ref_bases += iv.second - iv.first; }
+    lap("intervals");
     // trim every partition (blocks in file order; a block may give several pieces)
     for (long p = 0; p < np; p++) {
         Part& pt = parts[(size_t)p];
         const long nb = (long)pt.x.blocks.size();
         std::vector<std::vector<TBlock>> per_block((size_t)nb);
-        std::string err;
-#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
-        for (long b = 0; b < nb; b++) {
-            try { trim_lcb(pt.x.blocks[(size_t)b], inter, 1, &per_block[(size_t)b]); }
-            catch (const std::exception& e) {
-#pragma omp critical
-                err = e.what();
+        std::vector<std::string> errs((size_t)threads + 1);
+        const long chunk = 16, nchunks = (nb + chunk - 1) / chunk;
+        parallel_items(nchunks, threads, [&](long c) {
+            for (long b = c * chunk; b < std::min(nb, (c + 1) * chunk); b++) {
+                try { trim_lcb(pt.x.blocks[(size_t)b], inter, 1, &per_block[(size_t)b]); }
+                catch (const std::exception& e) { errs[(size_t)(c % (threads + 1))] = e.what(); }
             }
-        }
-        if (!err.empty()) throw std::runtime_error(pt.x.path + ": " + err);
+        });
+        for (const std::string& e : errs) if (!e.empty()) throw std::runtime_error(pt.x.path + ": " + e);
         for (auto& v : per_block) for (TBlock& tb : v) pt.trimmed.push_back(std::move(tb));
     }
     for (const Part& pt : parts)
         if (pt.trimmed.size() != parts[0].trimmed.size()) throw std::runtime_error("One of the partitions has a different number of clusters after trimming...");   // partition.py:644-646
     const size_t nclusters = parts[0].trimmed.size();
+    lap("trim");
     if (keep_trimmed) {
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-        for (long p = 0; p < np; p++) {
+        parallel_items(np, threads, [&](long p) {
             const Part& pt = parts[(size_t)p];
             FILE* f = fopen((pt.x.path + ".trimmed").c_str(), "w");
-            if (!f) continue;
+            if (!f) return;
             fputs(pt.x.header_text.c_str(), f);
             std::string text, seq;
             for (size_t c = 0; c < pt.trimmed.size(); c++) {
@@ -472,8 +491,9 @@ MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::str
                 fwrite(text.data(), 1, text.size(), f);
             }
             fclose(f);
-        }
+        });
     }
+    if (keep_trimmed) lap("write trimmed");
     // combined header (combine_header_info, :245-292): a (file, header) pair seen before -- the reference, present in
     // every partition -- is not added again; such a sequence of a later partition has no new index
     std::vector<SeqEntry> order;
@@ -499,22 +519,17 @@ MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::str
     }
     // clusters: merged by all threads a batch at a time, written in order
     const size_t batch = (size_t)threads * 4;
-    std::string err;
     for (size_t c0 = 0; c0 < nclusters; c0 += batch) {
         const size_t c1 = std::min(nclusters, c0 + batch);
-        std::vector<std::string> text(c1 - c0);
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-        for (long c = (long)c0; c < (long)c1; c++) {
-            try { merge_cluster(parts, (size_t)c, &text[(size_t)c - c0]); }
-            catch (const std::exception& e) {
-#pragma omp critical
-                err = e.what();
-            }
-        }
-        if (!err.empty()) { close(fd); throw std::runtime_error(err); }
+        std::vector<std::string> text(c1 - c0), errs(c1 - c0);
+        parallel_items((long)(c1 - c0), threads, [&](long k) {
+            try { merge_cluster(parts, c0 + (size_t)k, &text[(size_t)k]); } catch (const std::exception& e) { errs[(size_t)k] = e.what(); }
+        });
+        for (const std::string& e : errs) if (!e.empty()) { close(fd); throw std::runtime_error(e); }
         for (const std::string& t : text) write_all(fd, t);
     }
     close(fd);
+    lap("merge + write");
     return st;
 }
 

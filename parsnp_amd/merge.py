@@ -28,8 +28,15 @@ def _load():
 def merge_partitions(partition_xmfas, out_path, min_interval_size=10, threads=None, keep_trimmed=False):
     """-> dict(clusters=, sequences=, ref_bases=); raises RuntimeError with the library's message on failure"""
     lib = _load()
-    if threads is None:
-        threads = max(1, min(32, len(os.sched_getaffinity(0))))
+    if threads is None:      # the CPUs this process may really use: affinity mask, capped by the container's CPU quota
+        threads = len(os.sched_getaffinity(0))
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if quota != "max":
+                threads = min(threads, int(int(quota) / int(period)))
+        except (OSError, ValueError):
+            pass
+        threads = max(1, min(16, threads))
     arr = (C.c_char_p * len(partition_xmfas))(*[p.encode() for p in partition_xmfas])
     clusters, sequences, bases = C.c_long(0), C.c_long(0), C.c_long(0)
     err = C.create_string_buffer(1024)

@@ -125,13 +125,26 @@ def main():
         write = se["write_bytes"] + (sp["write_bytes"] if sp and sp["write_bytes"] else 0)
         st_se, st_sp = stats.get("SeedExtend", {}), stats.get("SmallPairEvents", {})
         calls = st_se.get("calls")
-        # SeedExtend's loads are scattered 8-16 B probes (hash slots, next[], 16-B sequence blocks).  If the gather
-        # calibration shows 64 counted bytes per scattered lane (one minimum-size fabric request each), the counter is exact
-        # for this pattern and is used as it is; the 2x correction of the guide applies to wide coalesced streams only.
+        # The counters sit on the fabric side of the L2 (TCC_EA0_RDREQ x 64 B): Infinity-Cache hits are INCLUDED, so this is
+        # fabric traffic, an upper bound of the HBM bytes.  Calibration (calibration.json): scattered 8-16 B probes count 64 B per
+        # lane -- exact for the index / filter / next[] / sequence-block requests -- while a wide coalesced stream is tallied at
+        # half its bytes (the guide's gfx950 factor, reproduced by calib_stream16).  The one coalesced stream of this kernel that
+        # reaches the fabric is the query pieces (m/2 per pair; the reference windows hit the L2), so the missing half of that
+        # stream is added back: corrected = FETCH_SIZE + 0.5 x query-stream bytes + WRITE_SIZE.
+        qstream = None
+        try:
+            bj = [l for l in open(os.path.join(summ, "bench_plain.json")).read().splitlines() if l.startswith("{")][-1]
+            qstream = json.loads(bj)["roofline"].get("alg_query_stream_bytes_per_launch")
+        except Exception as e:   # noqa: BLE001
+            print("no bench line for the stream correction:", e)
+        corr = 0.5 * qstream if qstream else 0.0
         t = {"kernel": "seed_extend = SeedExtend + SmallPairEvents", "workload": "bact200, the event search of every engine call of one bench step (anchor + recursion)",
              "dispatches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
-             "hbm_bytes_per_launch": (fetch + write) / n,
-             "correction": "none (scattered-probe pattern; see calibration.json: gather kernels count 64 B per lane)",
+             "raw": {"FETCH_SIZE": fetch / n, "WRITE_SIZE": write / n},
+             "query_stream_bytes_per_launch": qstream,
+             "hbm_bytes_per_launch": (fetch + write) / n + corr,
+             "correction": "FETCH_SIZE + 0.5 x query-stream bytes (coalesced 16 B/lane streams are tallied at half, calibration.json calib_stream16) + WRITE_SIZE; scattered probes count 64 B per lane and are taken as they are",
+             "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this binary; fabric-side counters: Infinity-Cache hits included (upper bound of HBM bytes); coalesced query stream corrected x2",
              "rocprof_avg_launch_ms": ((st_se.get("total_ms", 0) + st_sp.get("total_ms", 0)) / calls) if calls else None,
              "rocprof_calls": calls,
              "rocprof_seed_extend_avg_ms": st_se.get("avg_ms"), "rocprof_small_pair_events_avg_ms": st_sp.get("avg_ms"),

@@ -70,4 +70,5 @@ extern "C" int pm_gap_align_groups(int, int64_t n_jobs, const int32_t*, const in
 extern "C" const char* pm_gap_last_error(void) { return ""; }
 extern "C" int pm_warmup(int) { return PM_OK; }
 extern "C" int pm_rccl_unique_id(uint8_t*) { return PM_EINVAL; }
+extern "C" int pm_session_rccl_ranks(const pm_session*) { return 0; }
 extern "C" int pm_session_create_rccl(pm_session**, int, int, const uint8_t* const*, const int64_t*, int, int, const uint8_t*) { return PM_EINVAL; }

@@ -70,98 +70,24 @@ def _big_scratch(need_gb):
 
 
 def test_config4_all_partitions_and_merge():
-    """BASELINE config 4 in full on the one GPU there is: 2000 x 5 Mb in the reference driver's Random(42) order, cut into
-    8 partitions of 250 (parsnp:1553-1564), every partition through parsnp_core (24 host threads) one after the other,
-    then the native merge (include/parsnp_merge.h).  Checked: partition 0 against the REFERENCE binary's golden (whole-XMFA
-    md5 + log counters); every partition's XMFA self-consistent (251 rows per block, MUM columns, every record spells its
-    genome interval); every trimmed partition holds the same reference intervals; the merged parsnp.xmfa holds all 2001
-    sequences in every block, every record spells its genome interval, and its reference bases are the intersection's."""
-    import time
-    from parsnp_amd import partition_run
+    """BASELINE config 4 in full on the one GPU there is (flows.config4_flow: 2000 x 5 Mb in the reference driver's
+    Random(42) order, 8 partitions of 250 through parsnp_core one after the other, the native merge); partition 0 against the
+    REFERENCE binary's golden (whole-XMFA md5 + log counters)."""
+    import flows
     d = _big_scratch(60)
     try:
-        t0 = time.time()
         model, kw = synth.CONFIGS["bact2000"]
-        ref, gs = synth.population(**kw)
-        rp, qs = synth.write_set(os.path.join(d, "in"), ref, gs)
-        del gs
-        t1 = time.time()
-        res = partition_run.run_partitioned(CORE_BIN, rp, driver.driver_order(qs), os.path.join(d, "out"), 250, keep_trimmed=True, threads=24)
-        t2 = time.time()
-        parts = res["partitions"]
-        assert len(parts) == 8 and all(p["ok"] and p["queries"] == 250 for p in parts), [(p["index"], p["rc"]) for p in parts]
-        if "bact2000_p0" in BIG:      # the driver's first chunk = the golden's partition 0
-            x0 = os.path.join(parts[0]["dir"], "parsnpAligner.xmfa")
-            assert xmfa_util.log_counters(os.path.join(parts[0]["dir"], "parsnpAligner.log")) == BIG["bact2000_p0"]["log"]
-            assert xmfa_util.md5(x0) == BIG["bact2000_p0"]["xmfa_md5"]
-        pieces = None
-        for p in parts:
-            x = os.path.join(p["dir"], "parsnpAligner.xmfa")
-            st = xmfa_util.native_consistency(x, os.path.join(d, "in"), threads=16)
-            assert st["bad_length"] == 0 and st["bad_mum_column"] == 0 and st["bad_sequence"] == 0 and st["missing_genomes"] == 0, (p["index"], st)
-            assert st["min_rows"] == 251 and st["max_rows"] == 251 and st["lcbs"] > 500, st
-            iv = x + ".trimmed.iv"
-            tr = xmfa_util.native_consistency(x + ".trimmed", os.path.join(d, "in"), threads=16, intervals=iv)
-            assert tr["bad_length"] == 0 and tr["bad_sequence"] == 0 and tr["shifted"] == 0, (p["index"], tr)
-            mine = open(iv).read()
-            assert pieces is None or mine == pieces, "partition %d: trimmed reference intervals differ" % p["index"]
-            pieces = mine
-            os.remove(x + ".trimmed")
-        t3 = time.time()
-        m = res["merged"]
-        assert m["sequences"] == 2001 and m["clusters"] == len(pieces.splitlines()) > 500
-        ms = xmfa_util.native_consistency(m["xmfa"], os.path.join(d, "in"), merged=True, threads=16)
-        assert ms["lcbs"] == m["clusters"] and ms["min_rows"] == 2001 and ms["max_rows"] == 2001 and ms["sequences"] == 2001, ms
-        assert ms["bad_length"] == 0 and ms["bad_mum_column"] == 0 and ms["bad_sequence"] == 0 and ms["shifted"] == 0 and ms["missing_genomes"] == 0, ms
-        assert ms["ref_bases"] == m["ref_bases"] == tr["ref_bases"]
-        assert m["ref_bases"] > 0.8 * len(ref)
-        print("config 4: generate %.1f s, 8 partitions + merge %.1f s, partition checks %.1f s, merged check %.1f s; %d clusters, %d reference bases, merged XMFA %.1f GB"
-              % (t1 - t0, t2 - t1, t3 - t2, time.time() - t3, m["clusters"], m["ref_bases"], os.path.getsize(m["xmfa"]) / 1e9))
+        flows.config4_flow(CORE_BIN, d, kw, 250, 8, threads=24, golden=BIG.get("bact2000_p0"), min_lcbs=500)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
 def test_config5_full_500_genomes():
-    """BASELINE config 5 in full: 500 x 5 Mb, 5 % segregating sites, 10 % of every genome rearranged, --no-partition on one
-    GPU (24 host threads): XMFA self-consistency (501 rows per block, MUM columns, every record spells its genome interval,
-    reverse-strand records present), run-to-run determinism, and the same bytes from the sharded form of the run -- 4 ranks,
-    each with its block of 125 query genomes resident, here sharing the one GPU and exchanging over gloo."""
-    import subprocess, sys, time
+    """BASELINE config 5 in full (flows.config5_flow: 500 x 5 Mb, 5 % segregating sites, 10 % of every genome rearranged,
+    --no-partition on one GPU, then the same run sharded over 4 ranks that share the GPU and exchange over gloo)."""
+    import flows
     d = _big_scratch(30)
     try:
-        t0 = time.time()
-        ref, gs = synth.make("rearr500")
-        rp, qs = synth.write_set(os.path.join(d, "in"), ref, gs)
-        del gs
-        t1 = time.time()
-        sums, walls = [], []
-        for rep in range(2):
-            out = os.path.join(d, "out%d" % rep)
-            t = time.time()
-            rc, _ = driver.run_core(CORE_BIN, rp, qs, out, threads=24, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
-            walls.append(time.time() - t)
-            assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
-            sums.append(xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")))
-            assert "NOTE" not in open(os.path.join(out, "parsnpAligner.log")).read()
-        assert sums[0] == sums[1]
-        t2 = time.time()
-        st = xmfa_util.native_consistency(os.path.join(d, "out0", "parsnpAligner.xmfa"), os.path.join(d, "in"), threads=16)
-        assert st["lcbs"] > 5000 and st["min_rows"] == 501 and st["max_rows"] == 501, st
-        assert st["bad_length"] == 0 and st["bad_mum_column"] == 0 and st["bad_sequence"] == 0 and st["missing_genomes"] == 0, st
-        assert st["reverse"] > 1000, st
-        t3 = time.time()
-        shutil.rmtree(os.path.join(d, "out1"), ignore_errors=True)
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        out = os.path.join(d, "sharded")
-        os.makedirs(out)
-        ini = os.path.join(out, "run.ini")
-        open(ini, "w").write(driver.ini_text(rp, qs, out, threads=6))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "29591",
-               "-m", "parsnp_amd.sharded", ini]
-        p = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=root, OMP_WAIT_POLICY="passive"), cwd=out, timeout=1500)
-        assert p.returncode == 0, p.stderr[-3000:]
-        assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == sums[0]
-        assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == xmfa_util.log_counters(os.path.join(d, "out0", "parsnpAligner.log"))
-        print("config 5: generate %.1f s, whole process %.1f / %.1f s, check %.1f s, sharded x4 on one GPU %.1f s; %s" % (t1 - t0, walls[0], walls[1], t3 - t2, time.time() - t3, st))
+        flows.config5_flow(CORE_BIN, d, "rearr500", {}, threads=24, ranks=4, min_lcbs=5000, min_reverse=1000)
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -368,11 +368,12 @@ def test_parsnp_core_sharded_binary_one_rank(libs, tmp_path, name):
     hand-over, the RCCL session and the exchanges inside the drop-in binary; bytes as the reference's"""
     r, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
-    env = dict(os.environ, PARSNP_SHARD_WORLD="1", PARSNP_SHARD_RANK="0", PARSNP_RCCL_ID_FILE=str(tmp_path / "rccl.id"))
+    open(str(tmp_path / "rccl.id"), "wb").write(b"\x07" * 128 + b"a previous launch")      # a stale id file must not survive rank 0's start
+    env = dict(os.environ, PARSNP_SHARD_WORLD="1", PARSNP_SHARD_RANK="0", PARSNP_RCCL_ID_FILE=str(tmp_path / "rccl.id"), PARSNP_SHARD_NONCE="launch-%s" % name)
     out = str(tmp_path / "out")
     rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=4)
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
-    assert os.path.getsize(str(tmp_path / "rccl.id")) == 128
+    assert not os.path.exists(str(tmp_path / "rccl.id"))      # rank 0 removes its id file at exit
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 

@@ -71,6 +71,34 @@ def test_merge_blocks_columns_and_insertions():
     assert merged[0].seq == "ACG-T--AC" and merged[1].seq == "ACGGT--AC" and merged[2].seq == "ACG-TTTAC"
 
 
+def test_hand_derived_fixture(tmp_path):
+    """tests/golden/partition: two tiny partitions whose expected trimmed and merged files were written out by hand
+    (README.md there); the native merge and the restatement must both reproduce them byte for byte"""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "partition")
+    for impl in ("native", "restatement"):
+        d = tmp_path / impl
+        d.mkdir()
+        xs = [str(d / n) for n in ("p1.xmfa", "p2.xmfa")]
+        for x in xs:
+            shutil.copy(os.path.join(gold, os.path.basename(x)), x)
+        out = str(d / "parsnp.xmfa")
+        if impl == "native":
+            m = native_merge.merge_partitions(xs, out, keep_trimmed=True, threads=2)
+            assert (m["clusters"], m["sequences"], m["ref_bases"]) == (3, 4, 48)
+        else:
+            m = pmg.merge_partitions(xs, out)
+            assert (m["clusters"], m["sequences"]) == (3, 4) and m["intervals"] == {1: [[6, 31], [35, 45], [48, 61]]}
+        for got, want in ((out, "parsnp.xmfa"), (xs[0] + ".trimmed", "p1.xmfa.trimmed"), (xs[1] + ".trimmed", "p2.xmfa.trimmed")):
+            assert open(got).read() == open(os.path.join(gold, "expected", want)).read(), (impl, want)
+    # malformed input and disagreeing partitions are errors, not crashes
+    bad = str(tmp_path / "bad.xmfa")
+    open(bad, "w").write("#FormatVersion Mauve\n> 1:1-4 + nocluster\nACGT\n=\n")
+    with pytest.raises(RuntimeError):
+        native_merge.merge_partitions([bad], str(tmp_path / "o.xmfa"))
+    with pytest.raises(RuntimeError):
+        native_merge.merge_partitions([str(tmp_path / "missing.xmfa")], str(tmp_path / "o.xmfa"))
+
+
 def spelled(genome: bytes, r):
     s = genome[r.start:r.end]
     return (s.translate(COMP)[::-1] if r.strand == -1 else s).decode()

@@ -96,12 +96,25 @@ def consistency(path, genomes):
     return stats
 
 
-def native_consistency(path, genome_dir, merged=False, threads=16, intervals=None):
+def usable_threads(cap=16):
+    """threads a test may start: the affinity mask capped by the container's CPU quota (cgroup cpu.max) and by `cap`"""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cap, n))
+
+
+def native_consistency(path, genome_dir, merged=False, threads=None, intervals=None):
     """the same counts from oracle/_ref/xmfa_check (tests/emu/xmfa_check.cpp) -- for XMFA files of GB size.  genome_dir holds
     the FASTA files the header's ##SequenceFile entries name.  merged: a partition merge (see xmfa_check.cpp)."""
     import json
     import os
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "xmfa_check")
-    cmd = [exe] + (["--merged"] if merged else []) + (["--intervals", intervals] if intervals else []) + [path, genome_dir, str(threads)]
-    return json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True).stdout)
+    cmd = [exe] + (["--merged"] if merged else []) + (["--intervals", intervals] if intervals else []) + [path, genome_dir, str(threads or usable_threads())]
+    return json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True, env=dict(os.environ, OMP_WAIT_POLICY="passive")).stdout)
