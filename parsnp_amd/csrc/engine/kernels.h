@@ -191,6 +191,10 @@ struct RegionInfo {        // one per region of a batch
 
 constexpr uint64_t kEmpty = ~0ull;
 constexpr int kUnitSamples = 64;       // query samples per work unit: one per lane
+#ifndef PM_LEAD
+#define PM_LEAD 8
+#endif
+constexpr int kLead = PM_LEAD;         // SeedExtend: one lane in kLead (a leader) probes the index, the others follow its hit
 constexpr int kSlices = 1024;          // the event buffer is appended through this many independent counters
 constexpr int kSliceStride = 8;        // uint64 words between two counters: one 64-byte line each
 
@@ -610,26 +614,44 @@ struct SeedExtend {
             const uint64_t ctag = gat < tag ? gat : tag;         // what the index knows both of them by
             // Index probes are the scarce resource (random 64-B requests at the fabric's request rate).  Consecutive lanes
             // hold consecutive samples, and inside a forward match the K-mer of sample s+t sits t*stride bases after the
-            // K-mer of sample s.  So only every 8th lane (a leader) probes the index; a follower first looks where its
+            // K-mer of sample s.  So only every kLead-th lane (a leader) probes the index; a follower first looks where its
             // leader's hit predicts its own K-mer: if the reference K-mer there equals its own and its canonical form occurs
             // nowhere else in R, that position is all the probe would have returned.  Otherwise it probes itself.
             uint64_t slot = kEmpty;
-            const int sub = lane & 7;
+            const int sub = lane & (kLead - 1);
             const bool follow = ri.stride <= K && m >= 64 * (int64_t)ri.stride;   // short query pieces (recursion): one probe phase is faster
-            int32_t lead = -1;
+            int32_t lead = -1;      // where a leader's hit says this lane's K-mer lies, or -1
             if (follow) {
+                // the lane's own leader, else -- that leader's K-mer crosses a difference in one sample out of seven at 1 %
+                // divergence, and its seven followers would all have to probe -- the leader of the group before or after
+                const int g0 = lane & ~(kLead - 1);
 #if defined(__HIP_DEVICE_COMPILE__)
                 if (valid && sub == 0) slot = index_probe(ri, slots, filter, ctag);
                 const int32_t mine = (sub == 0 && slot != kEmpty && !(slot & kMulti)) ? slot_head(slot) : -1;
-                lead = __shfl(mine, lane & ~7, 64);
+                const int32_t own = __shfl(mine, g0, 64);
+                int32_t before = __shfl(mine, (g0 + 64 - kLead) & 63, 64), after = __shfl(mine, (g0 + kLead) & 63, 64);
+                if (g0 == 0) before = -1;
+                if (g0 == 64 - kLead) after = -1;
 #else
-                // host emulation (one thread at a time): the leader's probe is recomputed by each of its followers
+                // host emulation (one thread at a time): the leaders' probes are recomputed by each follower
+                int32_t own = -1, before = -1, after = -1;
                 if (sub == 0) { if (valid) slot = index_probe(ri, slots, filter, ctag); }
                 else if (valid) {
-                    const uint64_t ls = index_probe(ri, slots, filter, canonical_tag(kmer_tag(P, qbase + j - (int64_t)sub * ri.stride, K), K));
-                    if (ls != kEmpty && !(ls & kMulti)) lead = slot_head(ls);
+                    auto probe_at = [&](int64_t jj) -> int32_t {
+                        if (jj < 0 || jj + K > m) return -1;
+                        const uint64_t ls = index_probe(ri, slots, filter, canonical_tag(kmer_tag(P, qbase + jj, K), K));
+                        return (ls != kEmpty && !(ls & kMulti)) ? slot_head(ls) : -1;
+                    };
+                    own = probe_at(j - (int64_t)sub * ri.stride);
+                    if (own < 0 && g0 > 0) before = probe_at(j - (int64_t)(kLead + sub) * ri.stride);
+                    if (own < 0 && before < 0 && g0 < 64 - kLead) after = probe_at(j + (int64_t)(kLead - sub) * ri.stride);
                 }
 #endif
+                if (sub != 0) {
+                    if (own >= 0) lead = own + sub * ri.stride;
+                    else if (before >= 0) lead = before + (kLead + sub) * ri.stride;
+                    else if (after >= (kLead - sub) * ri.stride) lead = after - (kLead - sub) * ri.stride;
+                }
             } else if (valid) {
                 slot = index_probe(ri, slots, filter, ctag);
             }
@@ -646,8 +668,7 @@ struct SeedExtend {
                 bool is_pred = false;
                 if (valid) {
                     if (follow && sub != 0) {
-                        const int32_t cand = lead >= 0 ? lead + sub * ri.stride : -1;
-                        if (cand >= 0 && cand + K <= ri.nR) { at = cand; is_pred = true; }
+                        if (lead >= 0 && lead + K <= ri.nR) { at = lead; is_pred = true; }
                     } else if (slot != kEmpty) at = slot_head(slot);
                 }
                 bool ok = false;

@@ -1,7 +1,10 @@
 #!/bin/bash
-# SeedExtend variants (PM_DEBUG_SEED bits 8 and 2048 keep the results): kernel time per step and of the anchor launch
-for d in "$@"; do
-  PM_DEBUG_SEED=$d python bench.py --steps 3 --warmup 1 --cpu-sample 0 2>/dev/null | python -c "
+# SeedExtend with other leader spacings (make -C parsnp_amd/csrc exp): kernel time per step and of the anchor launch.
+# Measurement helper: the variant libraries are substituted with LD_PRELOAD, the shipped binary is not touched.
+for v in "" lead4 lead16; do
+  pre=""; [ -n "$v" ] && pre="$(pwd)/parsnp_amd/lib/exp/libparsnp_hip_$v.so"
+  LD_PRELOAD=$pre python bench.py --steps 10 --warmup 3 --cpu-sample 0 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('variant $d', d['value'], 'seed_extend/step', d['engine_ms']['seed_extend'], 'anchor', d['anchor_launch_ms']['seed_extend'], 'mums', d['mums'], 'lcbs', d['lcbs'])"
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('variant=${v:-shipped}', 'ms_per_step', d['ms_per_step'], 'seed_extend/step', d['engine_ms']['seed_extend'], 'anchor launch', d['anchor_launch_ms']['seed_extend'], 'anchors', d['anchors'], 'mums', d['mums'])"
 done

@@ -82,7 +82,10 @@ int main(int argc, char** argv) {
         const char* le = nl ? nl : end;
         if (*p == '>') {
             Rec r; char strand = '+'; int idx = 0; long a = 0, b = 0;
-            if (sscanf(p, "> %d:%ld-%ld %c", &idx, &a, &b, &strand) != 4) { fprintf(stderr, "malformed record header at byte %zu\n", (size_t)(p - p0)); return 2; }
+            char hdr[256];      // (sscanf on the mapping itself would measure the rest of the file with strlen for every record)
+            const size_t hl = std::min<size_t>((size_t)(le - p), sizeof hdr - 1);
+            memcpy(hdr, p, hl); hdr[hl] = 0;
+            if (sscanf(hdr, "> %d:%ld-%ld %c", &idx, &a, &b, &strand) != 4) { fprintf(stderr, "malformed record header at byte %zu\n", (size_t)(p - p0)); return 2; }
             r.idx = idx; r.a = a; r.b = b; r.strand = strand;
             const char* s = nl ? nl + 1 : end;
             const char* q = s;
