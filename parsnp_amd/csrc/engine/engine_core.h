@@ -322,8 +322,8 @@ public:
         be.mark("repeat");
         ensure(d_run, (size_t)std::max<int64_t>(npos, 1));
         be.launch("run_length", npos, RunLength{P, d_R.p, nreg, d_posbase.p, d_run.p});
-        ensure(d_repeated, (size_t)(npos / 32 + 1));
-        be.memset(d_repeated.p, 0, 4 * (size_t)(npos / 32 + 1));
+        ensure(d_repeated, (size_t)(npos / 32 + 2));       // (SeedExtend reads the word after a position's own)
+        be.memset(d_repeated.p, 0, 4 * (size_t)(npos / 32 + 2));
         be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_filter.p, d_next.p, d_run.p, d_rep.p, d_repeated.p, d_err, work_budget});
 
         // -- work units (pairs that fit 128 bases on both sides go to SmallPairEvents instead)

@@ -26,6 +26,14 @@ __global__ __launch_bounds__(256) void pm_kernel(F f, int64_t n) {
     int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (tid < n) f(tid);
 }
+#if defined(PM_SEED_WAVES)
+// measurement builds only (make exp): SeedExtend compiled for a given number of wavefronts per SIMD (registers spill instead)
+template <>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM_SEED_WAVES, 8))) void pm_kernel<pm::SeedExtend>(pm::SeedExtend f, int64_t n) {
+    int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tid < n) f(tid);
+}
+#endif
 
 // one wavefront per work item: 64-thread workgroups, f.wave(item) with the lanes cooperating (shuffles, LDS)
 template <class F>

@@ -190,7 +190,11 @@ struct RegionInfo {        // one per region of a batch
 };
 
 constexpr uint64_t kEmpty = ~0ull;
-constexpr int kUnitSamples = 64;       // query samples per work unit: one per lane
+#ifndef PM_PER
+#define PM_PER 2
+#endif
+constexpr int kPer = PM_PER;           // SeedExtend: adjacent query samples per lane (they share the lane's sequence windows)
+constexpr int kUnitSamples = 64 * kPer;   // query samples per work unit
 #ifndef PM_LEAD
 #define PM_LEAD 8
 #endif
@@ -239,6 +243,23 @@ PM_HD int match_bwd(const Win& a, const Win& b) {      // equal bases from the l
     const uint64_t d = (x | (x >> 1)) & 0x5555555555555555ull;
     int c = d ? (clz64(d) >> 1) : 32;
     if (mx) { const int cm = clz32(mx); if (cm < c) c = cm; }
+    return c;
+}
+// differences of two 32-base windows: bit 2t of x / bit t of m set = base t differs (an N only equals an N)
+struct Diff { uint64_t x; uint32_t m; };
+PM_HD Diff diff_of(const Win& a, const Win& b) { const uint64_t x = a.b ^ b.b; return Diff{(x | (x >> 1)) & 0x5555555555555555ull, a.m ^ b.m}; }
+PM_HD int eq_up(const Diff& d, int t) {        // equal bases from base t (0..32) upwards, at most 32 - t
+    if (t >= 32) return 0;
+    const uint64_t x = d.x >> (2 * t); const uint32_t mm = d.m >> t;
+    int c = x ? (ctz64(x) >> 1) : 32 - t;
+    if (mm) { const int cm = ctz32(mm); if (cm < c) c = cm; }
+    return c;
+}
+PM_HD int eq_down(const Diff& d, int t) {      // equal bases from base t - 1 (t = 0..32) downwards, at most t
+    if (t <= 0) return 0;
+    const uint64_t x = d.x << (64 - 2 * t); const uint32_t mm = d.m << (32 - t);
+    int c = x ? (clz64(x) >> 1) : t;
+    if (mm) { const int cm = clz32(mm); if (cm < c) c = cm; }
     return c;
 }
 // number of equal bases going right from (a, b), at most maxlen
@@ -536,7 +557,7 @@ struct alignas(32) UnitRec {
     int32_t region;     // index into RegionInfo
     int32_t pair;       // region * (ngen-1) + (query genome - 1): the event key prefix
     int32_t m;          // length of the query piece
-    int32_t chunk;      // which 64 samples of the piece
+    int32_t chunk;      // which kUnitSamples samples of the piece
 };
 // tid = work unit: which (pair, chunk) it is (off[] = exclusive prefix of the per-pair unit counts)
 struct FillUnits {
@@ -557,10 +578,17 @@ struct FillUnits {
 
 // ------------------------------------------------------------------------------------------ seed & extend
 // Replaces Find_UM (src/csgmum/mum.c:177-250): enumerates every R-unique maximal exact match of length >= minlen
-// between BOTH strands of one query piece and the reference substring.  tid = unit*64 + lane; lane t takes sample
-// chunk*64 + t of the piece's forward strand; sample s sits at query offset s*stride.  A match of length >= minlen =
-// stride + K - 1 contains >= 1 whole sampled K-mer whichever strand it lies on; a forward match is reported from its
-// first sampled K-mer only, a reverse match from its last one (= the first in the reverse strand's own direction).
+// between BOTH strands of one query piece and the reference substring.  tid = unit*64 + lane; lane t takes the kPer
+// ADJACENT samples (chunk*64 + t)*kPer .. +kPer-1 of the piece's forward strand; sample s sits at query offset s*stride.
+// A match of length >= minlen = stride + K - 1 contains >= 1 whole sampled K-mer whichever strand it lies on; a forward
+// match is reported from its first sampled K-mer only, a reverse match from its last one (= the first in the reverse
+// strand's own direction).
+//
+// The launch is bound by the LATENCY of its chain of dependent memory round trips (unit record, query blocks, index
+// probe, reference blocks, arms, append) at the hardware's 8 wavefronts per SIMD -- not by bytes and, since one probe
+// serves 2 * kLead * kPer K-mers, no longer by the request rate.  Adjacent samples are stride <= 16 bases apart, so the
+// 128-base windows a lane loads around its first sample (query and reference) hold its other samples as well: kPer
+// samples per lane means 1/kPer as many wavefronts walking that chain for the same work.
 struct SeedExtend {
     Packed P; const RegionInfo* R; const UnitRec* units;
     const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep; const uint32_t* repeated;
@@ -579,6 +607,7 @@ struct SeedExtend {
         const int64_t qbase = rec.qbase;
         const int64_t rbase = P.goff[0] + ri.ref_pos;
         const int K = ri.K;
+        const int32_t stride = ri.stride;
         int64_t work = 0;
         // events are appended to one of kSlices sub-buffers (all four wavefronts of a workgroup use the same one): a
         // single counter serialises the ~10^6 wavefront reservations of a recursion batch
@@ -587,176 +616,247 @@ struct SeedExtend {
         const uint64_t ev_cap = slice_cap;
         uint64_t* const key_out = ev_key + slice * slice_cap;
         uint64_t* const val_out = ev_val + slice * slice_cap;
-        // the first event of the lane's sample waits in registers and is written with ONE reservation per wavefront; a
-        // second event of the same sample (repeated or palindromic K-mer) is rare and takes its own slot
-        uint64_t bk = kEmpty, bv = 0;
+        // the first kPer events of the lane wait in registers and are written with ONE reservation per wavefront; more
+        // (repeated or palindromic K-mers) are rare and take their own slots
+        uint64_t bk[kPer], bv[kPer];
+        int nb = 0;
+#pragma unroll
+        for (int u = 0; u < kPer; u++) { bk[u] = kEmpty; bv[u] = 0; }
         auto emit = [&](int strand, int32_t l0, int64_t j0, int32_t len) {
             const uint64_t ek = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
             const uint64_t evv = ((uint64_t)j0 << 32) | (uint32_t)len;
-            if (bk == kEmpty) { bk = ek; bv = evv; }
+            bool kept = false;
+#pragma unroll
+            for (int u = 0; u < kPer; u++) if (!kept && nb == u) { bk[u] = ek; bv[u] = evv; kept = true; }
+            if (kept) nb++;
             else { const uint64_t at = atomic_add64(ev_count, 1); if (at < ev_cap) { key_out[at] = ek; val_out[at] = evv; } }
         };
-        do {
-            const int32_t sidx = rec.chunk * kUnitSamples + lane;
-            const int64_t j = (int64_t)sidx * ri.stride;
-            const bool valid = j + K <= m;
-            // the four query blocks around the sample: the K-mer, the 32 bases before it and the 32 bases after it all come
-            // out of them, and they are in flight while the index is probed
-            const int64_t qp = qbase + j;
-            const int shq = (int)(qp & 31);
-            SeqBlock q0 = SeqBlock{0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
-            if (valid) { const SeqBlock* qb = P.blk + (qp >> 5) - 1; q0 = qb[0]; q1 = qb[1]; q2 = qb[2]; q3 = qb[3]; }
-            const uint64_t kbits = K < 32 ? (1ull << (2 * K)) - 1 : ~0ull;
-            const uint32_t kmask = K < 32 ? (uint32_t)((1ull << K) - 1) : ~0u;
-            const Win qT = funnel(q1, q2, shq);
-            const uint64_t tag = (qT.b & kbits) | ((uint64_t)(qT.m & kmask) << 32);
-            const uint64_t gat = rc_tag(tag, K);                 // the K-mer of the reverse strand that covers the same bases
-            const uint64_t ctag = gat < tag ? gat : tag;         // what the index knows both of them by
-            // Index probes are the scarce resource (random 64-B requests at the fabric's request rate).  Consecutive lanes
-            // hold consecutive samples, and inside a forward match the K-mer of sample s+t sits t*stride bases after the
-            // K-mer of sample s.  So only every kLead-th lane (a leader) probes the index; a follower first looks where its
-            // leader's hit predicts its own K-mer: if the reference K-mer there equals its own and its canonical form occurs
-            // nowhere else in R, that position is all the probe would have returned.  Otherwise it probes itself.
-            uint64_t slot = kEmpty;
-            const int sub = lane & (kLead - 1);
-            const bool follow = ri.stride <= K && m >= 64 * (int64_t)ri.stride;   // short query pieces (recursion): one probe phase is faster
-            int32_t lead = -1;      // where a leader's hit says this lane's K-mer lies, or -1
-            if (follow) {
-                // the lane's own leader, else -- that leader's K-mer crosses a difference in one sample out of seven at 1 %
-                // divergence, and its seven followers would all have to probe -- the leader of the group before or after
-                const int g0 = lane & ~(kLead - 1);
+        const uint64_t kbits = K < 32 ? (1ull << (2 * K)) - 1 : ~0ull;
+        const uint32_t kmask = K < 32 ? (uint32_t)((1ull << K) - 1) : ~0u;
+        auto tag_of = [&](const Win& w) { return (w.b & kbits) | ((uint64_t)(w.m & kmask) << 32); };
+        // a seed on the reverse strand: the sampled bases are the K-mer at jr = m - K - j of the mirrored piece, whose left arm
+        // runs where the forward strand's right arm would (inversions and spurious hits only: arms straight from memory)
+        auto reverse_seed = [&](int64_t j, int32_t l) {
+            const int64_t jr = m - K - j;
+            const int64_t qpr = rec.qbase_r + jr;
+            int32_t lim = (int32_t)(jr < l ? jr : l);
+            if (lim > stride) lim = stride;
+            const int32_t left = lce_bwd(P, qpr, rbase + l, lim);
+            if (left >= stride) return;
+            const int32_t rep_l0 = rep[ri.posbase + l - left];
+            const int32_t rr = ri.nR - l - K;
+            const int32_t maxr = (int32_t)(j < rr ? j : rr);               // m - jr - K = j bases follow the K-mer on the mirrored piece
+            const int32_t right = lce_fwd(P, qpr + K, rbase + l + K, maxr);
+            const int32_t len = left + K + right;
+            if (len >= ri.minlen && len > rep_l0) emit(1, l - left, jr - left, len);
+        };
+        // a seed on the forward strand with both arms from memory
+        auto forward_seed = [&](int64_t j, int32_t l) {
+            int32_t lim = (int32_t)(j < l ? j : l);
+            if (lim > stride) lim = stride;
+            const int32_t left = lce_bwd(P, qbase + j, rbase + l, lim);     // only `stride` bases matter: a longer left arm means an earlier sample owns the match
+            if (left >= stride) return;
+            const int32_t rep_l0 = rep[ri.posbase + l - left];
+            const int64_t mr = m - j - K; const int32_t rr = ri.nR - l - K;
+            const int32_t maxr = (int32_t)(mr < rr ? mr : rr);
+            const int32_t right = lce_fwd64(P, qbase + j + K, rbase + l + K, maxr);
+            const int32_t len = left + K + right;
+            if (len >= ri.minlen && len > rep_l0) emit(0, l - left, j - left, len);      // len <= rep': not unique in R
+        };
+        // every reference position of a slot's chain against one sample: the entries share the canonical K-mer, not the orientation
+        auto walk = [&](int64_t j, uint64_t tag, uint64_t gat, uint64_t slot, int32_t skip) {
+            const bool multi = (slot & kMulti) != 0;
+            for (int32_t l = slot_head(slot); l >= 0; l = multi ? next[ri.posbase + l] : -1) {
+                if (++work > budget) { atomic_or32(err, kErrWork); return; }
+                if (l == skip) continue;                    // (already handled from the registers)
+                const uint64_t rt = kmer_tag(P, rbase + l, K);
+                if (rt == tag) forward_seed(j, l);
+                if (rt == gat) reverse_seed(j, l);
+            }
+        };
+        // a sample without a usable prediction asks the index itself
+        auto probe_sample = [&](int64_t j, uint64_t tag, uint64_t gat) {
+            const uint64_t ctag = gat < tag ? gat : tag;
+            uint64_t slot = index_probe(ri, slots, filter, ctag);
+            if (slot == kEmpty) return;
+            const uint64_t rt = kmer_tag(P, rbase + slot_head(slot), K);
+            if (rt != tag && rt != gat) {                   // another K-mer with the same 32-bit fingerprint (2^-32): the confirmed lookup
+                slot = index_lookup(P, ri, slots, filter, ctag);
+                if (slot == kEmpty) return;
+            }
+            walk(j, tag, gat, slot, -1);
+        };
+
+        const int32_t s0 = (rec.chunk * 64 + lane) * kPer;
+        const int64_t j0 = (int64_t)s0 * stride;
+        // Adjacent samples are `stride` bases apart.  With (kPer - 1) * stride + K <= 32 all K-mers of the lane start inside
+        // ONE 32-base window -- window 1 of the 96 bases [j0 - 32, j0 + 64) that four 16-byte blocks hold
+        const bool regs = (kPer - 1) * stride + K <= 32;
+        const int64_t qp0 = qbase + j0;
+        const int shq = (int)(qp0 & 31);
+        Win qw0 = Win{0, 0}, qw1 = qw0, qw2 = qw0;
+        if (j0 + K <= m && regs) {
+            const SeqBlock* qb = P.blk + (qp0 >> 5) - 1;
+            const SeqBlock q0 = qb[0], q1 = qb[1], q2 = qb[2], q3 = qb[3];
+            qw0 = funnel(q0, q1, shq); qw1 = funnel(q1, q2, shq); qw2 = funnel(q2, q3, shq);
+        }
+        bool valid[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; u++) valid[u] = j0 + (int64_t)u * stride + K <= m;
+        auto tag_at = [&](int u) -> uint64_t {      // the u-th K-mer of the lane
+            if (!regs) return kmer_tag(P, qp0 + (int64_t)u * stride, K);
+            const int off = u * stride;
+            return ((qw1.b >> (2 * off)) & kbits) | ((uint64_t)((qw1.m >> off) & kmask) << 32);
+        };
+        // Index probes are scarce (random requests at the fabric's request rate, two dependent round trips).  Consecutive
+        // lanes hold consecutive samples, and inside a forward match the K-mer of sample s+t sits t*stride bases after the
+        // K-mer of sample s.  So only every kLead-th lane (a leader) probes the index, for its first sample; every other sample
+        // first looks where a leader's hit predicts its K-mer -- the lane's own leader, else the leader of the group before
+        // or after (a leader's K-mer crosses a difference in one sample out of seven at 1 % divergence).  If the reference
+        // K-mer there equals its own and its canonical form occurs nowhere else in R, that position is all a probe would have
+        // returned.  Otherwise the sample probes for itself.
+        const int sub = lane & (kLead - 1);
+        const bool follow = regs && stride <= K && m >= (int64_t)kUnitSamples * stride;   // short query pieces (recursion): every sample probes
+        uint64_t slot = kEmpty;      // the leader's probe of its first sample
+        int32_t base = -1;           // predicted reference position of the lane's FIRST sample
+        bool own_probe = false;      // ... which is the head of this lane's own slot
+        if (follow) {
+            const int g0 = lane & ~(kLead - 1);
 #if defined(__HIP_DEVICE_COMPILE__)
-                if (valid && sub == 0) slot = index_probe(ri, slots, filter, ctag);
-                const int32_t mine = (sub == 0 && slot != kEmpty && !(slot & kMulti)) ? slot_head(slot) : -1;
-                const int32_t own = __shfl(mine, g0, 64);
-                int32_t before = __shfl(mine, (g0 + 64 - kLead) & 63, 64), after = __shfl(mine, (g0 + kLead) & 63, 64);
-                if (g0 == 0) before = -1;
-                if (g0 == 64 - kLead) after = -1;
+            if (valid[0] && sub == 0) slot = index_probe(ri, slots, filter, canonical_tag(tag_at(0), K));
+            const int32_t mine = (sub == 0 && slot != kEmpty && !(slot & kMulti)) ? slot_head(slot) : -1;
+            const int32_t own = __shfl(mine, g0, 64);
+            int32_t before = __shfl(mine, (g0 + 64 - kLead) & 63, 64), after = __shfl(mine, (g0 + kLead) & 63, 64);
+            if (g0 == 0) before = -1;
+            if (g0 == 64 - kLead) after = -1;
 #else
-                // host emulation (one thread at a time): the leaders' probes are recomputed by each follower
-                int32_t own = -1, before = -1, after = -1;
-                if (sub == 0) { if (valid) slot = index_probe(ri, slots, filter, ctag); }
-                else if (valid) {
-                    auto probe_at = [&](int64_t jj) -> int32_t {
-                        if (jj < 0 || jj + K > m) return -1;
-                        const uint64_t ls = index_probe(ri, slots, filter, canonical_tag(kmer_tag(P, qbase + jj, K), K));
-                        return (ls != kEmpty && !(ls & kMulti)) ? slot_head(ls) : -1;
-                    };
-                    own = probe_at(j - (int64_t)sub * ri.stride);
-                    if (own < 0 && g0 > 0) before = probe_at(j - (int64_t)(kLead + sub) * ri.stride);
-                    if (own < 0 && before < 0 && g0 < 64 - kLead) after = probe_at(j + (int64_t)(kLead - sub) * ri.stride);
-                }
+            // host emulation (one thread at a time): the leaders' probes are recomputed by each lane
+            auto probe_at = [&](int64_t jj) -> int32_t {
+                if (jj < 0 || jj + K > m) return -1;
+                const uint64_t ls = index_probe(ri, slots, filter, canonical_tag(kmer_tag(P, qbase + jj, K), K));
+                return (ls != kEmpty && !(ls & kMulti)) ? slot_head(ls) : -1;
+            };
+            if (valid[0] && sub == 0) slot = index_probe(ri, slots, filter, canonical_tag(tag_at(0), K));
+            const int32_t own = sub == 0 ? ((slot != kEmpty && !(slot & kMulti)) ? slot_head(slot) : -1) : probe_at(j0 - (int64_t)sub * kPer * stride);
+            int32_t before = -1, after = -1;
+            if (own < 0 && g0 > 0) before = probe_at(j0 - (int64_t)(kLead + sub) * kPer * stride);
+            if (own < 0 && before < 0 && g0 < 64 - kLead) after = probe_at(j0 + (int64_t)(kLead - sub) * kPer * stride);
 #endif
-                if (sub != 0) {
-                    if (own >= 0) lead = own + sub * ri.stride;
-                    else if (before >= 0) lead = before + (kLead + sub) * ri.stride;
-                    else if (after >= (kLead - sub) * ri.stride) lead = after - (kLead - sub) * ri.stride;
-                }
-            } else if (valid) {
-                slot = index_probe(ri, slots, filter, ctag);
+            if (own >= 0) { base = own + sub * kPer * stride; own_probe = sub == 0; }
+            else if (before >= 0) base = before + (kLead + sub) * kPer * stride;
+            else if (after >= (kLead - sub) * kPer * stride) base = after - (kLead - sub) * kPer * stride;
+        }
+        // Sample u is looked for at base + u*stride: the 96 reference bases [base - 32, base + 64) are fetched by all lanes
+        // in ONE round and compared with the query's base by base (three 32-base difference words).  Everything the windows
+        // can say -- is the K-mer there, how far the match runs to the left, where the first difference to the right lies --
+        // is read off those words for all the lane's samples at once, so that the eight blocks are dead before the rare,
+        // divergent rest (probes, long arms, chains) begins: the kernel's registers decide how many wavefronts hide each
+        // other's memory latency.
+        enum : uint8_t { kNone = 0, kProbe = 1, kFwd = 2, kRev = 4 };      // what to do with a sample after the window phase
+        uint8_t todo[kPer]; int32_t left[kPer], right[kPer];
+        {
+            bool any_fast = false;
+            bool fast[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; u++) {
+                fast[u] = follow && valid[u] && base >= 0 && base + u * stride + K <= ri.nR;
+                if (u == 0 && sub == 0 && follow) fast[0] = fast[0] && own_probe;      // a leader's first sample: its own probe says where (or that there is nothing)
+                any_fast = any_fast || fast[u];
             }
-            // the four reference blocks around the presumed position -- a follower's prediction, or the head of the probed
-            // slot -- are fetched by all lanes in ONE round: confirmation of the K-mer, left arm and the first 32 bases of
-            // the right arm come out of them
-            int32_t l = -1;
-            int shr = 0;
-            SeqBlock r0 = SeqBlock{0, 0, 0}, r1 = r0, r2 = r0, r3 = r0;
-            uint64_t rtag = 0;        // the reference K-mer at l
-            bool multi = false;
-            {
-                int32_t at = -1;
-                bool is_pred = false;
-                if (valid) {
-                    if (follow && sub != 0) {
-                        if (lead >= 0 && lead + K <= ri.nR) { at = lead; is_pred = true; }
-                    } else if (slot != kEmpty) at = slot_head(slot);
-                }
-                bool ok = false;
-                if (at >= 0) {
-                    const int64_t rp = rbase + at;
-                    const SeqBlock* rb = P.blk + (rp >> 5) - 1;
-                    const int64_t fpos = ri.posbase + at;
-                    const uint32_t rw = is_pred ? repeated[fpos >> 5] : 0u;
-                    r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
-                    const Win rT = funnel(r1, r2, shr);
-                    rtag = (rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32);
-                    ok = is_pred ? (rtag == tag && !((rw >> (fpos & 31)) & 1u)) : (rtag == tag || rtag == gat);
-                }
-                if (ok) { l = at; multi = !is_pred && (slot & kMulti) != 0; }
-                else if (valid && (is_pred || (follow && sub != 0) || at >= 0)) {
-                    // a follower without a confirmed prediction probes for itself; a probed slot whose K-mer differs
-                    // (same 32-bit fingerprint, 2^-32) is settled by the confirmed lookup
-                    slot = (follow && sub != 0 && !(at >= 0 && !is_pred)) ? index_probe(ri, slots, filter, ctag) : index_lookup(P, ri, slots, filter, ctag);
-                    if (slot != kEmpty) {
-                        int32_t h2 = slot_head(slot);
-                        int64_t rp = rbase + h2;
-                        const SeqBlock* rb = P.blk + (rp >> 5) - 1;
-                        r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
-                        Win rT = funnel(r1, r2, shr);
-                        rtag = (rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32);
-                        if (rtag != tag && rtag != gat) {
-                            slot = index_lookup(P, ri, slots, filter, ctag);
-                            h2 = slot == kEmpty ? -1 : slot_head(slot);
-                            if (h2 >= 0) {
-                                rp = rbase + h2; rb = P.blk + (rp >> 5) - 1; r0 = rb[0]; r1 = rb[1]; r2 = rb[2]; r3 = rb[3]; shr = (int)(rp & 31);
-                                rT = funnel(r1, r2, shr);
-                                rtag = (rT.b & kbits) | ((uint64_t)(rT.m & kmask) << 32);
-                            }
+            Diff d0 = Diff{0, 0}, d1 = d0, d2 = d0;
+            Win rw1 = Win{0, 0};
+            uint64_t rwords = 0;
+            const int64_t fpos0 = ri.posbase + (base >= 0 ? base : 0);
+            if (any_fast) {
+                const int64_t rp = rbase + base;
+                const SeqBlock* rb = P.blk + (rp >> 5) - 1;
+                const uint32_t rep0 = repeated[fpos0 >> 5], rep1 = repeated[(fpos0 >> 5) + 1];      // (one more word than positions exists)
+                const SeqBlock r0 = rb[0], r1 = rb[1], r2 = rb[2], r3 = rb[3];
+                const int shr = (int)(rp & 31);
+                rw1 = funnel(r1, r2, shr);
+                d0 = diff_of(qw0, funnel(r0, r1, shr)); d1 = diff_of(qw1, rw1); d2 = diff_of(qw2, funnel(r2, r3, shr));
+                rwords = (uint64_t)rep0 | ((uint64_t)rep1 << 32);
+            }
+            bool fwd_here = false;       // the previous sample of this lane was confirmed as a forward seed on this diagonal
+#pragma unroll
+            for (int u = 0; u < kPer; u++) {
+                todo[u] = kNone; left[u] = 0; right[u] = 0;
+                if (!valid[u]) { fwd_here = false; continue; }
+                if (follow && u == 0 && sub == 0 && !own_probe) { todo[0] = kProbe; fwd_here = false; continue; }      // (handled from `slot` below)
+                if (!fast[u]) { todo[u] = kProbe; fwd_here = false; continue; }
+                const int off = u * stride;
+                const bool same = ((d1.x >> (2 * off)) & kbits) == 0 && ((d1.m >> off) & kmask) == 0;      // the reference K-mer there is the sample's
+                const bool predicted = !(u == 0 && own_probe);
+                const bool shared = ((rwords >> (((fpos0 & 31) + off) & 63)) & 1u) != 0;      // its canonical form occurs elsewhere in R
+                const uint64_t tg = tag_at(u);
+                const uint64_t gat = rc_tag(tg, K);               // the K-mer of the reverse strand that covers the same bases
+                bool rev = same && gat == tg;                      // a palindrome seeds both strands
+                if (!same && !predicted) rev = (((rw1.b >> (2 * off)) & kbits) | ((uint64_t)((rw1.m >> off) & kmask) << 32)) == gat;   // the probe found the K-mer on the other strand
+                if (predicted ? !(same && !shared) : !(same || rev)) { todo[u] = kProbe; fwd_here = false; continue; }
+                // forward seed: after a confirmed forward seed of the same lane on the same diagonal the `stride` bases before
+                // this K-mer lie inside that K-mer (stride <= K) -- the match belongs to the earlier sample
+                if (same) {
+                    if (!fwd_here) {
+                        int lf = eq_down(d1, off);
+                        if (lf == off) lf += eq_down(d0, 32);
+                        // only `stride` bases matter -- a longer left arm means an earlier sample owns the match -- and the arm
+                        // ends where the query piece or the reference substring begins
+                        const int64_t ju = j0 + off; const int32_t lu = base + off;
+                        const int32_t lim = (int32_t)(ju < lu ? ju : lu);
+                        if (lf > lim) lf = lim;
+                        left[u] = lf;
+                        if (lf < stride) {
+                            const int t = off + K;
+                            int rt = eq_up(d1, t);
+                            if (rt == 32 - t) rt += eq_up(d2, 0);
+                            right[u] = rt;                          // = 64 - t: equal as far as the windows reach
+                            todo[u] |= kFwd;
                         }
-                        l = h2;
-                        multi = l >= 0 && (slot & kMulti) != 0;
                     }
-                }
+                    fwd_here = true;
+                } else fwd_here = false;
+                if (rev) todo[u] |= kRev;
             }
-            if (l < 0) break;
-            bool first_entry = true;
-            for (; l >= 0; l = multi ? next[ri.posbase + l] : -1, first_entry = false) {
-                if (++work > budget) { atomic_or32(err, kErrWork); break; }
-                // the entries of a chain share the canonical K-mer, not the orientation
-                if (!first_entry) rtag = kmer_tag(P, rbase + l, K);
-                if (rtag == tag) {
-                    // forward strand.  left: only `stride` bases matter -- a longer left arm means an earlier sample owns the match
-                    int32_t lim = (int32_t)(j < l ? j : l);
-                    if (lim > ri.stride) lim = ri.stride;
-                    const bool in_regs = first_entry && ri.stride <= 32;     // both arms start inside the loaded blocks
-                    int32_t left;
-                    if (in_regs) { left = match_bwd(funnel(q0, q1, shq), funnel(r0, r1, shr)); if (left > lim) left = lim; }
-                    else left = lce_bwd(P, qp, rbase + l, lim);
-                    if (left < ri.stride) {
-                        const int32_t rep_l0 = rep[ri.posbase + l - left];         // in flight while the right arm is compared
-                        const int64_t mr = m - j - K; const int32_t rr = ri.nR - l - K;
-                        const int32_t maxr = (int32_t)(mr < rr ? mr : rr);
-                        int32_t right;
-                        if (in_regs) {
-                            right = match_fwd(funnel3(q1, q2, q3, shq + K), funnel3(r1, r2, r3, shr + K));
-                            if (right >= 32 && maxr > 32) right = 32 + lce_fwd64(P, qp + K + 32, rbase + l + K + 32, maxr - 32);
-                            if (right > maxr) right = maxr;
-                        } else right = lce_fwd(P, qp + K, rbase + l + K, maxr);
-                        const int32_t len = left + K + right;
-                        if (len >= ri.minlen && len > rep_l0) emit(0, l - left, j - left, len);      // len <= rep': not unique in R
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; u++) {
+            if (todo[u] == kNone) continue;
+            const int64_t j = j0 + (int64_t)u * stride;
+            if (++work > budget) { atomic_or32(err, kErrWork); break; }
+            if (todo[u] & kProbe) {
+                const uint64_t tg = tag_at(u);
+                const uint64_t gat = rc_tag(tg, K);
+                if (follow && u == 0 && sub == 0) {
+                    // a leader's first sample whose probe did not give one unrepeated, confirmed position: nothing in the
+                    // index, a chain, or another K-mer with the same fingerprint
+                    if (slot != kEmpty) {
+                        const uint64_t rt = kmer_tag(P, rbase + slot_head(slot), K);
+                        uint64_t sl = slot;
+                        if (rt != tg && rt != gat) sl = index_lookup(P, ri, slots, filter, gat < tg ? gat : tg);
+                        if (sl != kEmpty) walk(j, tg, gat, sl, -1);
                     }
-                }
-                if (rtag == gat) {
-                    // reverse strand: the same bases are the K-mer at jr of the mirrored piece; its left arm runs where this
-                    // strand's right arm would (inversions and spurious hits only: arms straight from memory)
-                    const int64_t jr = m - K - j;
-                    const int64_t qpr = rec.qbase_r + jr;
-                    int32_t lim = (int32_t)(jr < l ? jr : l);
-                    if (lim > ri.stride) lim = ri.stride;
-                    const int32_t left = lce_bwd(P, qpr, rbase + l, lim);
-                    if (left < ri.stride) {
-                        const int32_t rep_l0 = rep[ri.posbase + l - left];
-                        const int32_t rr = ri.nR - l - K;
-                        const int32_t maxr = (int32_t)(j < rr ? j : rr);               // m - jr - K = j bases follow the K-mer on the mirrored piece
-                        const int32_t right = lce_fwd(P, qpr + K, rbase + l + K, maxr);
-                        const int32_t len = left + K + right;
-                        if (len >= ri.minlen && len > rep_l0) emit(1, l - left, jr - left, len);
-                    }
-                }
+                } else probe_sample(j, tg, gat);
+                continue;
             }
-        } while (false);
-        const uint64_t at = wave_reserve01(ev_count, bk != kEmpty);
-        if (bk != kEmpty && at < ev_cap) { key_out[at] = bk; val_out[at] = bv; }
+            const int32_t l = base + u * stride;
+            if (todo[u] & kFwd) {
+                const int32_t lf = left[u];
+                const int32_t rep_l0 = rep[ri.posbase + l - lf];          // in flight while the right arm is compared
+                const int64_t mr = m - j - K; const int32_t rr = ri.nR - l - K;
+                const int32_t maxr = (int32_t)(mr < rr ? mr : rr);
+                const int32_t reach = 64 - u * stride - K;                // bases after the K-mer that the windows hold
+                int32_t rt = right[u];
+                if (rt >= reach && maxr > reach) rt = reach + lce_fwd64(P, qbase + j + K + reach, rbase + l + K + reach, maxr - reach);
+                if (rt > maxr) rt = maxr;
+                const int32_t len = lf + K + rt;
+                if (len >= ri.minlen && len > rep_l0) emit(0, l - lf, j - lf, len);      // len <= rep': not unique in R
+            }
+            if (todo[u] & kRev) reverse_seed(j, l);
+        }
+        uint64_t at = kPer == 1 ? wave_reserve01(ev_count, nb != 0) : wave_reserve(ev_count, (uint32_t)nb);
+#pragma unroll
+        for (int u = 0; u < kPer; u++)
+            if (u < nb) { if (at < ev_cap) { key_out[at] = bk[u]; val_out[at] = bv[u]; } at++; }
     }
 };
 

@@ -1,7 +1,7 @@
 #!/bin/bash
-# SeedExtend with other leader spacings (make -C parsnp_amd/csrc exp): kernel time per step and of the anchor launch.
+# SeedExtend with other compile-time choices (make -C parsnp_amd/csrc exp: samples per lane, wavefronts per SIMD, leader spacing): kernel time per step and of the anchor launch.
 # Measurement helper: the variant libraries are substituted with LD_PRELOAD, the shipped binary is not touched.
-for v in "" lead4 lead16; do
+for v in "" per1 per2w7 per2w8 lead16; do
   pre=""; [ -n "$v" ] && pre="$(pwd)/parsnp_amd/lib/exp/libparsnp_hip_$v.so"
   LD_PRELOAD=$pre python bench.py --steps 10 --warmup 3 --cpu-sample 0 2>/dev/null | python -c "
 import json,sys
