@@ -124,6 +124,22 @@ int32_t* pm_result_start(pm_result* r);
 uint8_t* pm_result_strand(pm_result* r);
 const uint32_t* pm_result_flags(const pm_result* r);
 int pm_result_dirty_known(const pm_result* r);
+
+/* Requests derived on the device.  The rows of a ONE-region result in row mode (the anchor call) stay resident as the
+ * session's "anchor table"; pm_result_table_id() names it (0: this result left no table).  The recursion's seed regions
+ * are gaps between two anchors that follow each other in every genome, so the caller may describe region r by 16 bytes --
+ * the two rows (candidate indices of that result) and the side -- instead of 2 x 8 bytes per genome:
+ *   side 0, left of `next`  (determineRegion src/parsnp.cpp:1216-1231): start = end(prev) [prev < 0: 1], end = start(next) - 1
+ *   side 1, right of `prev` (:1254-1268): start = end(prev) + 1, end = max(start(next), start) - 1 [next < 0: the genome's end]
+ *   request = (start, end - start) in every genome, end(x) = start(x) + length(x).
+ * A region that is not such a gap (a row the caller has trimmed since, a child region) sets explicit_row >= 0 and travels in
+ * ex_starts / ex_lens [n_explicit][n_genomes].  ref_start / ref_len [n_regions]: the reference column of every region (the
+ * host sizes the index from it).  The result is that of pm_multi_mum_batch on the same rows.  PM_EINVAL when table_id is not
+ * the resident table (a later one-region call replaced it). */
+typedef struct { int32_t prev, next, side, explicit_row; } pm_gap_ref;
+int pm_multi_mum_batch_gaps(pm_session* s, int64_t table_id, int64_t n_regions, const pm_gap_ref* gaps, const int64_t* ref_start, const int64_t* ref_len,
+                            const int32_t* minsize, int64_t n_explicit, const int64_t* ex_starts, const int64_t* ex_lens, pm_result** out);
+int64_t pm_result_table_id(const pm_result* r);
 /* With PM_ROW_SLICES=1 in the environment the row table of a long one-region result (the anchor call: 60 MB at 200 x 5 Mb)
  * is still arriving when pm_multi_mum_batch returns: k, lon and flags are complete, start / strand come in slices of
  * candidates (overlap needs page-locked result blocks, PARSNP_PINNED=1; off by default: see engine_core.h for the numbers).  Before reading

@@ -108,6 +108,26 @@ int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, 
     } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
     } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
 }
+int pm_multi_mum_batch_gaps(pm_session* s, int64_t table_id, int64_t n_regions, const pm_gap_ref* gaps, const int64_t* ref_start, const int64_t* ref_len,
+                            const int32_t* minsize, int64_t n_explicit, const int64_t* ex_starts, const int64_t* ex_lens, pm_result** out) {
+    if (!s || !out || n_regions < 1 || !gaps || !ref_start || !ref_len || !minsize || n_explicit < 0) return fail(PM_EINVAL, "bad argument");
+    static_assert(sizeof(pm_gap_ref) == sizeof(pm::GapRef), "pm_gap_ref layout");
+    try {
+        std::unique_ptr<pm_result> r(new pm_result);
+        const auto w0 = std::chrono::steady_clock::now();
+        pm::Engine<PmBackend>::GapBatch gb;
+        gb.table_id = table_id; gb.gaps = (const pm::GapRef*)gaps; gb.ref_start = ref_start; gb.ref_len = ref_len;
+        gb.n_explicit = n_explicit; gb.ex_starts = ex_starts; gb.ex_lens = ex_lens;
+        int rc = s->engine->run(n_regions, nullptr, nullptr, minsize, &r->r, false, false, &gb);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        *out = r.release();
+        return PM_OK;
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
+}
+int64_t pm_result_table_id(const pm_result* r) { return r ? r->r.table_id : 0; }
 int64_t pm_result_regions(const pm_result* r) { return r->r.nregions; }
 int64_t pm_result_total(const pm_result* r) { return r->r.total; }
 const int64_t* pm_result_offsets(const pm_result* r) { return r->r.off.data(); }

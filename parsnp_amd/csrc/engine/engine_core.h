@@ -48,6 +48,7 @@ struct BatchResult {
     // a session in MUM-row mode (pm_session_rows) fills these instead of sp / fwd:
     HostPool::Block startb, strandb, flagsb; // int32 start[total*(nq+1)], uint8 strand[total*(nq+1)], uint32 flags[total]
     bool rows = false, dirty_known = false;  // dirty_known: the kRowDirty bits were computed (one-region batch with a long list)
+    int64_t table_id = 0;                    // != 0: the rows of this result stay on the device as the session's anchor table (run_gaps)
     // A long row table (the anchor call) is still arriving when the call returns: its copy is cut into slices, each followed
     // by an event, and the caller waits slice by slice (pm_result_wait_rows) while it already works on what is there.
     struct InFlight {
@@ -177,24 +178,33 @@ public:
     // copies inside ONE region: every copy's K-mer chain is walked by every sample that hits it) is run again with a
     // budget 256 times larger -- slow, but the reference aligns such input too; only then PM_ELIMIT.  In a sharded run the
     // verdict is common to all ranks (it travels with the first exchange), so every rank repeats the batch together.
+    // Requests given as gaps of the anchor table (kernels.h: GapRef / ExpandGaps) + explicit rows for the rest.
+    struct GapBatch {
+        int64_t table_id = 0;
+        const GapRef* gaps = nullptr;                         // [nreg]
+        const int64_t* ref_start = nullptr; const int64_t* ref_len = nullptr;   // [nreg]: the reference column of every region (sizes the index)
+        int64_t n_explicit = 0; const int64_t* ex_starts = nullptr; const int64_t* ex_lens = nullptr;   // [n_explicit][ngen]
+    };
     int run(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events = false,
-            bool mumi = false) {
+            bool mumi = false, const GapBatch* gb = nullptr) {
         finish_pending();
         budget_exceeded = false;
-        int rc = run_once(nreg, starts, lens, minsize, out, want_events, mumi);
+        if (gb && (gb->table_id == 0 || gb->table_id != anchor_table_id)) { error = "the anchor table of these gap requests is no longer resident"; return -2; }
+        int rc = run_once(nreg, starts, lens, minsize, out, want_events, mumi, gb);
         if (rc == -5 && budget_exceeded && work_budget < ((int64_t)1 << 40)) {
             const int64_t keep = work_budget;
             work_budget = keep << 8;
             budget_retries++;
-            rc = run_once(nreg, starts, lens, minsize, out, want_events, mumi);
+            rc = run_once(nreg, starts, lens, minsize, out, want_events, mumi, gb);
             work_budget = keep;
         }
         return rc;
     }
+    int64_t anchor_table_id = 0, anchor_table_rows = 0;      // the resident anchor table: rows of the last one-region call in row mode
     bool budget_exceeded = false;
     long budget_retries = 0;
     int run_once(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events,
-                 bool mumi) {
+                 bool mumi, const GapBatch* gb = nullptr) {
         timing.clear();
         const int nq = ngen - 1;
         out->nregions = nreg; out->nq = nq; out->total = 0;
@@ -206,10 +216,12 @@ public:
         const int no_small = (mumi || getenv("PM_NO_SMALL_PAIRS")) ? 1 : 0;   // PM_NO_SMALL_PAIRS=1: measurement
 
         // -- host: the page-locked parameter block  [ RegionInfo x nreg | posbase | cbase | starts rows | lens rows ]
+        // (gap requests: the rows part holds only the explicit rows, followed by the GapRef table)
         const size_t nrow = (size_t)nreg * (size_t)ngen;
         const size_t regz = (size_t)nreg;
         const size_t bytes_R = sizeof(RegionInfo) * regz, bytes_pre = 8 * (regz + 1);
-        uint8_t* block = (uint8_t*)be.staging(bytes_R + 2 * bytes_pre + 16 * nrow + 64);
+        const size_t nrow_staged = gb ? (size_t)gb->n_explicit * (size_t)ngen : nrow;
+        uint8_t* block = (uint8_t*)be.staging(bytes_R + 2 * bytes_pre + 16 * nrow_staged + (gb ? sizeof(GapRef) * regz : 0) + 64);
         if (!block) { error = "cannot allocate the request staging block"; return -3; }
         RegionInfo* R = (RegionInfo*)block;
         int64_t* posbase = (int64_t*)(block + bytes_R);
@@ -217,7 +229,24 @@ public:
         int64_t* stage = cbase + regz + 1;
         std::vector<size_t> guess_r(regz, 0);
         std::vector<int64_t> units_r(regz, 0);
-        {
+        if (gb) {
+            if (gb->n_explicit < 0 || (gb->n_explicit > 0 && (!gb->ex_starts || !gb->ex_lens))) { error = "bad explicit rows"; return -2; }
+            for (int64_t r = 0; r < nreg; r++) {
+                const GapRef& g = gb->gaps[r];
+                if (g.explicit_row >= gb->n_explicit || (g.explicit_row < 0 && (g.prev >= anchor_table_rows || g.next >= anchor_table_rows || (g.prev < 0 && g.next < 0) || g.side < 0 || g.side > 1)))
+                    { error = "gap request outside the anchor table"; return -2; }
+                if (gb->ref_start[r] < 0 || gb->ref_len[r] < 0 || gb->ref_start[r] + gb->ref_len[r] > glen_h[0]) { error = "region outside its genome"; return -2; }
+                if (gb->ref_len[r] >= (1ll << 31)) { error = "region longer than 2^31"; return -5; }
+            }
+            for (int64_t x = 0; x < gb->n_explicit; x++)
+                for (int g = 0; g < ngen; g++) {
+                    const int64_t st = gb->ex_starts[x * ngen + g], ln = gb->ex_lens[x * ngen + g];
+                    if (st < 0 || ln < 0 || st + ln > glen_h[(size_t)g]) { error = "region outside its genome"; return -2; }
+                    if (ln >= (1ll << 31)) { error = "region longer than 2^31"; return -5; }
+                }
+            if (nrow_staged) { memcpy(stage, gb->ex_starts, 8 * nrow_staged); memcpy(stage + nrow_staged, gb->ex_lens, 8 * nrow_staged); }
+            memcpy(stage + 2 * nrow_staged, gb->gaps, sizeof(GapRef) * regz);
+        } else {
             // the request rows (2 x 8 bytes per region and genome: 26 MB for a recursion batch of 8 000 regions x 201) are
             // checked and copied by a few threads; the same pass counts the SeedExtend work units of every region (what
             // CountUnits computes on the device) so that the grid size needs no read-back
@@ -267,8 +296,8 @@ public:
         cbase[0] = 0;
         for (int64_t r = 0; r < nreg; r++) {
             RegionInfo& ri = R[(size_t)r];
-            ri.ref_pos = starts[r * ngen];
-            ri.nR = (int32_t)lens[r * ngen];
+            ri.ref_pos = gb ? gb->ref_start[r] : starts[r * ngen];
+            ri.nR = (int32_t)(gb ? gb->ref_len[r] : lens[r * ngen]);
             ri.minsize = minsize[r];
             ri.minlen = minsize[r] < 1 ? 1 : minsize[r];
             ri.K = ri.minlen < 16 ? ri.minlen : 16;
@@ -303,8 +332,15 @@ public:
         be.h2d_staged(d_R.p, R, bytes_R);
         be.h2d_staged(d_posbase.p, posbase, bytes_pre);
         be.h2d_staged(d_cbase.p, cbase, bytes_pre);
-        be.h2d_staged(d_starts.p, stage, sizeof(int64_t) * nrow);
-        be.h2d_staged(d_lens.p, stage + nrow, sizeof(int64_t) * nrow);
+        if (!gb) {
+            be.h2d_staged(d_starts.p, stage, sizeof(int64_t) * nrow);
+            be.h2d_staged(d_lens.p, stage + nrow, sizeof(int64_t) * nrow);
+        } else {
+            ensure(d_exstarts, std::max<size_t>(nrow_staged, 1)); ensure(d_exlens, std::max<size_t>(nrow_staged, 1)); ensure(d_gaps, regz);
+            if (nrow_staged) { be.h2d_staged(d_exstarts.p, stage, 8 * nrow_staged); be.h2d_staged(d_exlens.p, stage + nrow_staged, 8 * nrow_staged); }
+            be.h2d_staged(d_gaps.p, stage + 2 * nrow_staged, sizeof(GapRef) * regz);
+            be.launch("expand_gaps", (int64_t)nrow, ExpandGaps{d_gaps.p, ngen, d_anchor_start.p, d_anchor_lon.p, d_glen, d_exstarts.p, d_exlens.p, d_starts.p, d_lens.p});
+        }
         // event counters: kSlices counters one 64-byte line apart, then the error word of the batch (read back together)
         const size_t ncounter = (size_t)kSlices * kSliceStride + 8;
         ensure(d_counter, ncounter);
@@ -332,6 +368,11 @@ public:
         be.launch("count_units", npairs, CountUnits{d_R.p, d_lens.p, ngen, d_ucount.p, g_first, g_last, no_small});
         be.memset(d_ucount.p + npairs, 0, 8);
         be.exclusive_scan(d_ucount.p, d_uoff.p, (size_t)npairs + 1);
+        if (gb) {      // the host never saw the rows: the unit count comes back from the device (8 bytes)
+            be.d2h(&nunits, d_uoff.p + npairs, 8);
+            if (nunits >= (1ll << 31)) { error = "too many work units in one batch"; return -5; }
+            ev_guess += (size_t)nunits * 16;
+        }
         ensure(d_units, (size_t)std::max<int64_t>(nunits, 1));
         be.launch("fill_units", nunits, FillUnits{P, d_starts.p, d_lens.p, ngen, d_uoff.p, d_ucount.p, npairs, d_units.p});
 
@@ -540,6 +581,13 @@ public:
                 be.launch("dirty_merge", nok, DirtyMerge{d_dirty.p, d_cflags.p});
                 out->dirty_known = true;
             }
+            if (nreg == 1 && !gb && nok >= dirty_min) {      // a long list of one region (the anchor call): its rows stay on the device as the session's anchor table (run(..., gb))
+                ensure(d_anchor_start, std::max<size_t>(nokz * ngz, 1)); ensure(d_anchor_lon, std::max<size_t>(nokz, 1));
+                be.d2d(d_anchor_start.p, d_csp.p, 4 * nokz * ngz);
+                be.d2d(d_anchor_lon.p, d_clon.p, 4 * nokz);
+                anchor_table_rows = nok;
+                out->table_id = anchor_table_id = ++table_counter;
+            }
             be.mark("download");
             out->startb = pool->take(4 * nokz * ngz); out->strandb = pool->take(nokz * ngz); out->flagsb = pool->take(4 * nokz);
             be.d2h_async(out->flagsb.p, d_cflags.p, 4 * nokz);
@@ -660,6 +708,8 @@ private:
     Buf<int64_t> d_okcnt, d_okpos, d_cbase; Buf<int32_t> d_coarse; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;
     Buf<uint32_t> d_cflags, d_dirty; Buf<int32_t> d_bmax, d_bmin;
     Buf<GenomeAtK> d_xsend, d_xrecv; Buf<uint8_t> d_hsend, d_hrecv;
+    Buf<int32_t> d_anchor_start, d_anchor_lon; Buf<GapRef> d_gaps; Buf<int64_t> d_exstarts, d_exlens;
+    int64_t table_counter = 0;
 };
 
 }  // namespace pm

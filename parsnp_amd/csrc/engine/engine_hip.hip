@@ -181,6 +181,7 @@ struct HipBackend {
         }
         return stage_p;
     }
+    void d2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream), "hipMemcpy D2D"); }
     void h2d_staged(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D (staged)"); }
 
     // see Engine::load_genomes.  kThreads host threads, two staging slots each (page-locked host block + device block + stream)

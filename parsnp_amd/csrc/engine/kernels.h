@@ -559,6 +559,39 @@ struct alignas(32) UnitRec {
     int32_t m;          // length of the query piece
     int32_t chunk;      // which kUnitSamples samples of the piece
 };
+// ------------------------------------------------------------------------------------------ requests derived on the device
+// A request of the recursion is, almost always, the gap between two anchors that lie next to each other in every genome:
+// its rows follow from the two anchors' rows, which the device still holds from the anchor call (the "anchor table").  The
+// host then sends 16 bytes per region instead of 2 x 8 bytes per region AND genome (26 MB for the 8 000 regions of a
+// 200-genome run); regions it cannot derive that way travel as explicit rows and are scattered into place.
+//   side 0, the region LEFT of anchor `next`  (determineRegion src/parsnp.cpp:1216-1231 when the previous marked base is the
+//           last base of anchor `prev`):   start = end(prev) [prev < 0: 1],          end = start(next) - 1
+//   side 1, the region RIGHT of anchor `prev` (:1254-1268 when the next marked base is the first base of anchor `next`):
+//           start = end(prev) + 1,  end = max(start(next), start) - 1   [next < 0: the genome's end; start at or past it: start - 1]
+//   length = end - start; the request is (start, length) -- exactly what Aligner::find_anchors derives from the same rows.
+struct GapRef { int32_t prev, next; int32_t side; int32_t explicit_row; };      // explicit_row >= 0: row of the explicit arrays instead
+// tid = (region, genome)
+struct ExpandGaps {
+    const GapRef* gaps; int32_t ngen; const int32_t* astart; const int32_t* alon; const int64_t* glen;
+    const int64_t* ex_starts; const int64_t* ex_lens; int64_t* starts; int64_t* lens;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t r = tid / ngen; const int j = (int)(tid % ngen);
+        const GapRef g = gaps[r];
+        if (g.explicit_row >= 0) { starts[tid] = ex_starts[(int64_t)g.explicit_row * ngen + j]; lens[tid] = ex_lens[(int64_t)g.explicit_row * ngen + j]; return; }
+        const int64_t end_prev = g.prev >= 0 ? (int64_t)astart[(int64_t)g.prev * ngen + j] + alon[g.prev] : 0;
+        const int64_t start_next = g.next >= 0 ? (int64_t)astart[(int64_t)g.next * ngen + j] : 0;
+        int64_t a, b;
+        if (g.side == 0) { a = g.prev >= 0 ? end_prev : 1; b = start_next - 1; }
+        else {
+            const int64_t nxt = end_prev + 1, size = glen[j];
+            int64_t p = nxt;
+            if (nxt < size) p = g.next >= 0 ? (start_next > nxt ? start_next : nxt) : size;
+            a = nxt; b = p - 1;
+        }
+        starts[tid] = a; lens[tid] = b - a;
+    }
+};
+
 // tid = work unit: which (pair, chunk) it is (off[] = exclusive prefix of the per-pair unit counts)
 struct FillUnits {
     Packed P; const int64_t* starts; const int64_t* lens; int32_t ngen;

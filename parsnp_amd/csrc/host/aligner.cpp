@@ -361,11 +361,29 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     std::vector<int32_t> mins(reqs.size());
     double alg = 0, algk = 0, algq = 0;
     const long nreq = (long)reqs.size();
+    // Regions that are gaps between two rows of the engine's resident anchor table go as 16 bytes each (pm_multi_mum_batch_gaps)
+    // instead of 16 bytes per GENOME: the engine derives their rows from the table.  Worth it for a batch of many such regions
+    // (the recursion's seeds); the rows of the others travel as before, packed at the front of the flat arrays.
+    static const bool no_gaps = getenv("PARSNP_NO_GAP_REQUESTS") != nullptr;      // test hook: every row travels
+    long derived = 0;
+    if (rows && anchor_table_ != 0 && !no_gaps) for (const Request& q : reqs) derived += q.plain && q.gap_side >= 0;
+    const bool use_gaps = derived >= 64 && derived * 2 >= nreq;
+    std::vector<pm_gap_ref> gaps; std::vector<int64_t> ref_start, ref_len; std::vector<int32_t> explicit_at;
+    int64_t n_explicit = 0;
+    if (use_gaps) {
+        gaps.resize(reqs.size()); ref_start.resize(reqs.size()); ref_len.resize(reqs.size()); explicit_at.assign(reqs.size(), -1);
+        for (size_t i = 0; i < reqs.size(); i++) {
+            const Request& q = reqs[i];
+            ref_start[i] = q.start[0]; ref_len[i] = q.len[0];
+            if (q.plain && q.gap_side >= 0) gaps[i] = pm_gap_ref{q.gap_prev, q.gap_next, q.gap_side, -1};
+            else { explicit_at[i] = (int32_t)n_explicit; gaps[i] = pm_gap_ref{-1, -1, 0, (int32_t)n_explicit++}; }
+        }
+    }
 #pragma omp parallel for schedule(dynamic, 64) num_threads(prm.cores > 0 ? prm.cores : 1) reduction(+ : alg, algk, algq) if (nreq > 256)
     for (long i = 0; i < nreq; i++) {
         const Request& q = reqs[(size_t)i];
-        memcpy(&starts[(size_t)i * n], q.start, n * 8);
-        memcpy(&lens[(size_t)i * n], q.len, n * 8);
+        if (!use_gaps) { memcpy(&starts[(size_t)i * n], q.start, n * 8); memcpy(&lens[(size_t)i * n], q.len, n * 8); }
+        else if (explicit_at[(size_t)i] >= 0) { memcpy(&starts[(size_t)explicit_at[(size_t)i] * n], q.start, n * 8); memcpy(&lens[(size_t)explicit_at[(size_t)i] * n], q.len, n * 8); }
         mins[(size_t)i] = q.minsize;
         // SURVEY 8d's model (one 8-byte index probe and 16 bytes of state per query suffix), and what the event search of THIS
         // engine has to move per (region, query genome): the query piece once (16 B per 32 bases; the reverse strand is not
@@ -387,7 +405,17 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     stats.alg_bytes_query += algq;
     stats.t_pack += now_s() - t0;
     pm_result* res = nullptr;
-    int rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);
+    int rc;
+    if (use_gaps) {
+        rc = pm_multi_mum_batch_gaps(session_, anchor_table_, (int64_t)reqs.size(), gaps.data(), ref_start.data(), ref_len.data(), mins.data(),
+                                     n_explicit, starts.data(), lens.data(), &res);
+        if (rc == PM_EINVAL) {      // the engine holds another table by now (a later long one-region call): the rows travel
+            anchor_table_ = 0;
+            run_batch(reqs, out, rows);
+            return;
+        }
+        stats.gap_requests += (long)reqs.size() - (long)n_explicit;
+    } else rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);
     if (rc == PM_ELIMIT) {     // a size limit of the engine (include/parsnp_mum.h), not a malfunction: its own exit code
         std::cerr << "parsnp_core: input exceeds a limit of the multi-MUM engine: " << pm_last_error() << std::endl;
         exit(5);
@@ -899,6 +927,10 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     }
     const size_t pool0 = pool.size(), acc0 = accepted->size();
     const long id0 = next_id_;
+    // where the engine keeps this list's rows resident (its anchor table), the MUMs remember their row: the seed regions
+    // between two untouched rows can then be requested by reference (run_batch)
+    const int64_t table = device_rows ? pm_result_table_id(raw.owner.get()) : 0;
+    if (table) anchor_table_ = table;
     pool.resize(pool0 + nacc);
     accepted->resize(acc0 + nacc);
     {
@@ -910,6 +942,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             const uint32_t at = place[(size_t)c];
             if (at == kNoPlace) continue;
             Mum m = cand[(size_t)c];
+            m.row = table ? (int32_t)(raw.row0 + (size_t)c) : -1;
             m.id = id0 + (long)idrank[(size_t)c];
             m.slength = slen;
             m.dirty = (state[(size_t)c] & 8) != 0;
@@ -1010,6 +1043,7 @@ bool Aligner::find_anchors() {
             r.start = tl.rows.alloc(n); r.end = tl.rows.alloc(n); r.length = tl.rows.alloc(n);
             memcpy(r.start, s.start, n * sizeof(long)); memcpy(r.end, s.end, n * sizeof(long)); memcpy(r.length, s.length, n * sizeof(long));
             r.slength = s.slength; r.llength = s.llength;
+            r.gap_prev = s.gap_prev; r.gap_next = s.gap_next; r.gap_side = s.gap_side;
             *out = r;
         };
         // what is known about the right neighbour of the previous anchor of this run: its rows (kept), or a genome in
@@ -1053,6 +1087,13 @@ bool Aligner::find_anchors() {
                 if (len > l) l = len;
             }
             out->slength = s; out->llength = l;
+            // both rows as the engine holds them (a candidate that took the ordered pass may have been trimmed here)?
+            out->gap_side = -1;
+            if (anchor_table_ != 0 && m.row >= 0 && !m.dirty && (!other || (other->row >= 0 && !other->dirty))) {
+                out->gap_side = left ? 0 : 1;
+                out->gap_prev = left ? (other ? other->row : -1) : m.row;
+                out->gap_next = left ? m.row : (other ? other->row : -1);
+            }
             return true;
         };
         static const bool no_rows_path = getenv("PARSNP_WALK_NEIGHBOURS") != nullptr;      // test hook: always the bitmap walks
@@ -1365,7 +1406,7 @@ bool Aligner::extend_generations() {
     };
     auto plain_request = [&](const Region& r, Request* q) {
         if (!plain_shape(r)) return false;
-        *q = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0, true};
+        *q = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0, true, r.gap_prev, r.gap_next, r.gap_side};
         return true;
     };
     // the same for a list: the row checks (8 000 regions x 201 genomes per generation) by all threads, the minimum
@@ -1380,7 +1421,7 @@ bool Aligner::extend_generations() {
             if (skip && (*skip)[(size_t)i] >= 0) continue;
             if (!ok[(size_t)i]) return false;
             const Region& r = rs[(size_t)i];
-            (*out)[(size_t)i] = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0, true};
+            (*out)[(size_t)i] = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0, true, r.gap_prev, r.gap_next, r.gap_side};
         }
         return true;
     };

@@ -180,6 +180,7 @@ struct Mum {
     int32_t* start = nullptr;
     uint8_t* fwd = nullptr;
     bool dirty = false;      // (anchor validation) overlapped an earlier candidate and went through the ordered pass
+    int32_t row = -1;        // its row in the engine's resident anchor table (pm_result_table_id), where the engine keeps one
     long end(size_t j) const { return (long)start[j] + length; }
 };
 
@@ -188,6 +189,9 @@ struct Region {          // rows of n entries in Aligner's arenas; immutable onc
     long* end = nullptr;
     long* length = nullptr;
     long slength = 0, llength = 0;
+    // the region is the gap between rows gap_prev / gap_next of the engine's anchor table, on side gap_side (include/parsnp_mum.h:
+    // pm_gap_ref): the engine can derive its rows itself.  gap_side < 0: not such a gap, the rows travel.
+    int32_t gap_prev = -1, gap_next = -1; int8_t gap_side = -1;
     bool same_as(const Region& o, size_t n) const;   // TRegion operator== (LCR.cpp:48-58)
 };
 
@@ -219,6 +223,7 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     double alg_bytes = 0;   // sum over the regions sent to the engine of (m/4 + 16 m + 16 n) per query genome
     double alg_bytes_query = 0;    // ... of which the query pieces (m/2): the one coalesced stream that reaches the fabric
     double alg_bytes_kernel = 0;   // the same sum of what THIS engine's event search must move: (m + n)/2 + 64 B per sampled K-mer (run_batch)
+    long gap_requests = 0;  // regions whose rows the engine derived from its anchor table (pm_multi_mum_batch_gaps)
     long finder_calls = 0, finder_regions = 0, regions_processed = 0, cache_hits = 0, cache_misses = 0, spec_rounds = 0;
     // device-side phase times (HIP events, pm_last_timing): summed over every engine call of the step, and of the
     // anchor call alone (the one launch that sees whole genomes)
@@ -305,10 +310,14 @@ private:
     // --- finder plumbing -------------------------------------------------------------------------------------
     // one engine request = one reference chunk of one region; rows of n entries (the region's own rows when the
     // region is a single unclamped chunk, else rows in req_rows_)
-    struct Request { const long* start; const long* len; int32_t minsize; long ref_ini; uint64_t hash; bool plain = false; };   // plain: the rows are the region's own (one unclamped chunk)
+    struct Request {
+        const long* start; const long* len; int32_t minsize; long ref_ini; uint64_t hash; bool plain = false;   // plain: the rows are the region's own (one unclamped chunk)
+        int32_t gap_prev = -1, gap_next = -1; int8_t gap_side = -1;      // (plain requests) the region's place in the anchor table, see Region
+    };
     void chunk_requests(const Region& r, int minsize, std::vector<Request>* out);   // the p-chunk loop, :1519-1547
     void run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out, bool rows = false);   // rows: every request is its region (plain)
     bool rows_mode_ = false, rows_supported_ = true;
+    int64_t anchor_table_ = 0;         // id of the engine's resident anchor table that Mum::row / Region::gap_* refer to (0: none)
     bool timing_first_call_ = false;
     bool timing_deferred_ = false;     // the phase times of the last engine call are read later (its rows were still arriving)
     void collect_engine_timing();

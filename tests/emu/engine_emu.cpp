@@ -19,6 +19,7 @@ struct HostBackend {
     void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void d2h_async(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+    void d2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void sync() {}
     void* event_record() { return nullptr; }
     static void event_wait(void*) {}

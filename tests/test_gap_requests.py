@@ -1,0 +1,49 @@
+"""Requests derived on the device (include/parsnp_mum.h: pm_multi_mum_batch_gaps): the recursion's seed regions are sent as
+references into the engine's resident anchor table -- 16 bytes per region -- instead of 16 bytes per region and genome.  On the
+CPU the engine's functors run sequentially (tests/emu); the run must use the path (gap_requests > 0), give the bytes of the
+run in which every row travels, and both must be the reference binary's golden."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import xmfa_util
+from parsnp_amd import driver, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+E2E = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e.json")))
+
+_CHILD = """
+import sys, json
+sys.path.insert(0, %r)
+from parsnp_amd.core_api import CoreRun
+r = CoreRun(sys.argv[1], sys.argv[2])
+rep = r.step(); r.write(); r.close()
+print(json.dumps({k: rep[k] for k in ("gap_requests", "finder_calls", "finder_regions", "anchors", "mums", "lcbs")}))
+""" % ROOT
+
+
+@pytest.mark.parametrize("name", ["pop6x200k", "rearr6x300k"])
+def test_gap_requests_same_bytes(emu, tmp_path, name):
+    core_lib = os.path.join(os.path.dirname(emu[0]), "libparsnp_core_emu.so")
+    ref, gs = synth.make(name)
+    rp, qs = synth.write_set(str(tmp_path / "in"), ref, gs)
+    got = {}
+    for tag, env in (("gaps", {}), ("rows", {"PARSNP_NO_GAP_REQUESTS": "1"})):
+        out = str(tmp_path / tag)
+        os.makedirs(out)
+        ini = os.path.join(out, "run.ini")
+        open(ini, "w").write(driver.ini_text(rp, qs, out, threads=4))
+        # (small sets: the thresholds of the long-list routes are lowered so that the anchor list takes them)
+        e = dict(os.environ, PM_DIRTY_MIN="16", PARSNP_PARALLEL_MIN="16", **env)
+        p = subprocess.run([sys.executable, "-c", _CHILD, ini, core_lib], capture_output=True, text=True, env=e, cwd=out, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got[tag] = (json.loads(p.stdout.strip().splitlines()[-1]), xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")),
+                    xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")))
+    assert got["rows"][0]["gap_requests"] == 0
+    if name == "pop6x200k":      # collinear: the seeds lie between anchors that follow each other in every genome
+        assert got["gaps"][0]["gap_requests"] > 100
+    assert got["gaps"][1] == got["rows"][1] == E2E[name]["xmfa_md5"]
+    assert got["gaps"][2] == got["rows"][2] == E2E[name]["log"]
