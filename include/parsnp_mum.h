@@ -140,12 +140,13 @@ typedef struct { int32_t prev, next, side, explicit_row; } pm_gap_ref;
 int pm_multi_mum_batch_gaps(pm_session* s, int64_t table_id, int64_t n_regions, const pm_gap_ref* gaps, const int64_t* ref_start, const int64_t* ref_len,
                             const int32_t* minsize, int64_t n_explicit, const int64_t* ex_starts, const int64_t* ex_lens, pm_result** out);
 int64_t pm_result_table_id(const pm_result* r);
-/* With PM_ROW_SLICES=1 in the environment the row table of a long one-region result (the anchor call: 60 MB at 200 x 5 Mb)
- * is still arriving when pm_multi_mum_batch returns: k, lon and flags are complete, start / strand come in slices of
- * candidates (overlap needs page-locked result blocks, PARSNP_PINNED=1; off by default: see engine_core.h for the numbers).  Before reading
- * the rows of candidates [0, upto) call pm_result_wait_rows(r, upto); it returns how many candidates' rows are there
- * (>= upto; upto < 0: all of them).  Callable from several threads; immediate for results that are complete. */
-int64_t pm_result_wait_rows(pm_result* r, int64_t upto);
+/* Tunables of a session (tests lower the thresholds of the long-list routes so that small inputs take them):
+ *   "work_budget"  per-thread step budget of the index walks (default 2^22; a batch that exhausts it is repeated once with
+ *                  256 times as much, then PM_ELIMIT)
+ *   "dirty_min"    shortest one-region candidate list that gets the overlap / order flags and stays resident as the anchor
+ *                  table (default 4096)
+ * PM_EINVAL for an unknown key or a value out of range. */
+int pm_session_tune(pm_session* s, const char* key, int64_t value);
 
 /* calcmumi mode (Aligner::setMumi, src/parsnp.cpp:1869-2115): every query genome ALONE against the reference chunk
  * starts[0],lens[0] (query g: starts[g],lens[g]).  covered[g-1] = number of reference positions covered by the

@@ -107,7 +107,7 @@ int pm_multi_mum_batch_gaps(pm_session* s, int64_t table_id, int64_t n_regions, 
     (void)s; (void)table_id; (void)n_regions; (void)gaps; (void)ref_start; (void)ref_len; (void)minsize; (void)n_explicit; (void)ex_starts; (void)ex_lens; (void)out;
     return PM_EINVAL;
 }
-int64_t pm_result_wait_rows(pm_result* r, int64_t upto) { (void)upto; return r ? pm_result_total(r) : 0; }
+int pm_session_tune(pm_session* s, const char* key, int64_t value) { (void)s; (void)key; (void)value; return PM_OK; }      /* nothing to tune here */
 /* the device gap aligner belongs to the HIP library; this checker declines every job, so the host aligner runs */
 int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,
                        const int32_t* max_cols, const int64_t* row_off, uint8_t* out_rows, int64_t out_bytes, int32_t* cols) {

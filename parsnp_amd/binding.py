@@ -86,6 +86,11 @@ class Session:
             self.lib.L.pm_session_destroy(self.h)
             self.h = None
 
+    def tune(self, key: str, value: int):
+        """pm_session_tune: "work_budget", "dirty_min" (include/parsnp_mum.h)"""
+        self.lib.L.pm_session_tune.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        self.lib._check(self.lib.L.pm_session_tune(self.h, key.encode(), value))
+
     def __enter__(self):
         return self
 

@@ -136,12 +136,15 @@ const int32_t* pm_result_lon(const pm_result* r) { return r->r.lon(); }
 const int32_t* pm_result_sp(const pm_result* r) { return r->r.sp(); }
 const uint8_t* pm_result_fwd(const pm_result* r) { return r->r.fwd(); }
 void pm_result_free(pm_result* r) { delete r; }
+int pm_session_tune(pm_session* s, const char* key, int64_t value) {
+    if (!s || !key) return fail(PM_EINVAL, "bad argument");
+    return s->engine->tune(key, value) ? PM_OK : fail(PM_EINVAL, std::string("unknown tunable or bad value: ") + key);
+}
 int pm_session_rows(pm_session* s, int enable) { if (!s) return fail(PM_EINVAL, "bad argument"); s->engine->want_rows = enable != 0; return PM_OK; }
 int32_t* pm_result_start(pm_result* r) { return r->r.start(); }
 uint8_t* pm_result_strand(pm_result* r) { return r->r.strand(); }
 const uint32_t* pm_result_flags(const pm_result* r) { return r->r.flags(); }
 int pm_result_dirty_known(const pm_result* r) { return r->r.dirty_known ? 1 : 0; }
-int64_t pm_result_wait_rows(pm_result* r, int64_t upto) { return r ? r->r.wait_rows(upto) : 0; }
 
 int pm_find_events(const uint8_t* ref, int64_t n, const uint8_t* query, int64_t m, int32_t min_len, int strand,
                    int64_t cap, int64_t* count, int64_t* ev_j, int64_t* ev_l, int32_t* ev_len, int32_t* ev_rep) {
@@ -190,7 +193,6 @@ int pm_mumi_coverage(pm_session* s, const int64_t* starts, const int64_t* lens, 
 int pm_last_timing(const pm_session* cs, int* count, const char** names, float* ms) {
     if (!cs || !count) return PM_EINVAL;
     pm_session* s = const_cast<pm_session*>(cs);
-    s->engine->finish_pending();        // the phase times of a call whose rows were still arriving exist only now
     s->timing = s->engine->timing;
     if (s->call_wall_ms > 0) s->timing.push_back(pm::PhaseTime{"call_wall", s->call_wall_ms});
     if (s->engine->budget_retries) s->timing.push_back(pm::PhaseTime{"budget_retries", (float)s->engine->budget_retries});   // a count, not a time

@@ -19,7 +19,7 @@
 
 namespace pm {
 
-// Host buffers the results are downloaded into (ordinary memory; pinned with PARSNP_PINNED=1).  They are recycled: a result gives its
+// Host buffers the results are downloaded into (ordinary memory).  They are recycled: a result gives its
 // blocks back when it is freed, the next batch of the same shape takes them, so the steady state allocates nothing and
 // touches no fresh pages.  Shared by the session and every result it handed out (a result may outlive the session).
 struct HostPool {
@@ -49,24 +49,6 @@ struct BatchResult {
     HostPool::Block startb, strandb, flagsb; // int32 start[total*(nq+1)], uint8 strand[total*(nq+1)], uint32 flags[total]
     bool rows = false, dirty_known = false;  // dirty_known: the kRowDirty bits were computed (one-region batch with a long list)
     int64_t table_id = 0;                    // != 0: the rows of this result stay on the device as the session's anchor table (run_gaps)
-    // A long row table (the anchor call) is still arriving when the call returns: its copy is cut into slices, each followed
-    // by an event, and the caller waits slice by slice (pm_result_wait_rows) while it already works on what is there.
-    struct InFlight {
-        std::vector<int64_t> upto;                 // candidates [0, upto[s]) have arrived once events[s] has
-        std::vector<void*> events;
-        void (*wait_event)(void*) = nullptr;
-        std::atomic<bool> finished{false};         // set by the engine once the stream has drained (events are recycled then)
-    };
-    std::shared_ptr<InFlight> inflight;
-    int64_t wait_rows(int64_t want) {              // -> number of candidates whose rows are there (>= want; want < 0: all)
-        if (!inflight || inflight->finished.load(std::memory_order_acquire)) return total;
-        if (want < 0 || want > total) want = total;
-        for (size_t s = 0; s < inflight->upto.size(); s++) {
-            inflight->wait_event(inflight->events[s]);
-            if (inflight->upto[s] >= want) return inflight->upto[s];
-        }
-        return total;
-    }
     std::shared_ptr<HostPool> pool;
     int32_t* start() const { return (int32_t*)startb.p; }
     uint8_t* strand() const { return (uint8_t*)strandb.p; }
@@ -187,7 +169,6 @@ public:
     };
     int run(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events = false,
             bool mumi = false, const GapBatch* gb = nullptr) {
-        finish_pending();
         budget_exceeded = false;
         if (gb && (gb->table_id == 0 || gb->table_id != anchor_table_id)) { error = "the anchor table of these gap requests is no longer resident"; return -2; }
         int rc = run_once(nreg, starts, lens, minsize, out, want_events, mumi, gb);
@@ -213,7 +194,7 @@ public:
         out->pool = pool;
         if (nreg == 0) return 0;
         if (nq < 1) { error = "need at least one query genome"; return -2; }
-        const int no_small = (mumi || getenv("PM_NO_SMALL_PAIRS")) ? 1 : 0;   // PM_NO_SMALL_PAIRS=1: measurement
+        const int no_small = mumi ? 1 : 0;
 
         // -- host: the page-locked parameter block  [ RegionInfo x nreg | posbase | cbase | starts rows | lens rows ]
         // (gap requests: the rows part holds only the explicit rows, followed by the GapRef table)
@@ -550,12 +531,6 @@ public:
         std::vector<int32_t> reg_h(nokz);
         out->kb = pool->take(4 * nokz); out->lonb = pool->take(4 * nokz);
         out->rows = want_rows; out->dirty_known = false;
-        bool sliced = false;
-        // Off by default -- measured on 200 x 5 Mb: into ordinary host memory the copies block the caller anyway (no overlap,
-        // 29.9 ms per step against 29.2 in one piece); into page-locked blocks (PARSNP_PINNED=1) the call does return 1.0 ms
-        // earlier, but the host's passes over page-locked rows are slower by more than that (29.6 against 30.3 in one piece,
-        // both behind the 29.2 of ordinary memory).  PM_ROW_SLICES=1 turns it on.
-        static const bool no_slices = getenv("PM_ROW_SLICES") == nullptr || atoi(getenv("PM_ROW_SLICES")) == 0;
         if (!want_rows) {
             ensure(d_csp, std::max<size_t>(nokz * nqz2, 1)); ensure(d_cfwd, std::max<size_t>(nokz * nqz2, 1));
             be.launch("compact_sp", (int64_t)ncand * nq,
@@ -591,58 +566,20 @@ public:
             be.mark("download");
             out->startb = pool->take(4 * nokz * ngz); out->strandb = pool->take(nokz * ngz); out->flagsb = pool->take(4 * nokz);
             be.d2h_async(out->flagsb.p, d_cflags.p, 4 * nokz);
-            sliced = nreg == 1 && nok >= slice_min && !no_slices;
-            if (!sliced) {
-                be.d2h_async(out->startb.p, d_csp.p, 4 * nokz * ngz);
-                be.d2h_async(out->strandb.p, d_cfwd.p, nokz * ngz);
-            }
+            be.d2h_async(out->startb.p, d_csp.p, 4 * nokz * ngz);
+            be.d2h_async(out->strandb.p, d_cfwd.p, nokz * ngz);
         }
         be.d2h_async(reg_h.data(), d_creg.p, 4 * nokz);
         be.d2h_async(out->kb.p, d_ck.p, 4 * nokz);
         be.d2h_async(out->lonb.p, d_clon.p, 4 * nokz);
-        if (sliced) {
-            // the per-candidate arrays first (the caller's first pass needs only those), then the rows in slices
-            void* small = be.event_record();
-            auto fl = std::make_shared<BatchResult::InFlight>();
-            fl->wait_event = &B::event_wait;
-            constexpr int kSlicesOut = 6;
-            for (int x = 0; x < kSlicesOut; x++) {
-                const size_t c0 = nokz * (size_t)x / kSlicesOut, c1 = nokz * (size_t)(x + 1) / kSlicesOut;
-                if (c1 == c0) continue;
-                be.d2h_async((int32_t*)out->startb.p + c0 * ngz, d_csp.p + c0 * ngz, 4 * (c1 - c0) * ngz);
-                be.d2h_async((uint8_t*)out->strandb.p + c0 * ngz, d_cfwd.p + c0 * ngz, (c1 - c0) * ngz);
-                fl->events.push_back(be.event_record());
-                fl->upto.push_back((int64_t)c1);
-            }
-            be.mark(nullptr);
-            B::event_wait(small);
-            be.event_release(small);
-            out->inflight = fl;
-            pending = fl;
-        } else {
-            be.mark(nullptr);
-            be.sync();                                                         // round trip 4: the results
-        }
+        be.mark(nullptr);
+        be.sync();                                                         // round trip 4: the results
         for (size_t w = 0; w < nokz; w++) out->off[(size_t)reg_h[w] + 1]++;
         for (int64_t r = 0; r < nreg; r++) out->off[(size_t)r + 1] += out->off[(size_t)r];
         out->total = out->off[(size_t)nreg];
-        if (!sliced) collect_timing();
+        collect_timing();
         return 0;
     }
-
-    // the row table of the last call may still be on its way (BatchResult::InFlight): drain the stream, hand the events
-    // back, read the phase times.  Called before the next batch, by pm_last_timing and on release.
-    void finish_pending() {
-        if (!pending) return;
-        be.sync();
-        pending->finished.store(true, std::memory_order_release);
-        for (void* e : pending->events) be.event_release(e);
-        pending->events.clear();
-        pending.reset();
-        collect_timing();
-    }
-    std::shared_ptr<BatchResult::InFlight> pending;
-    int64_t slice_min = getenv("PM_SLICE_MIN") ? atol(getenv("PM_SLICE_MIN")) : 8192;     // shortest row table delivered in slices (PM_SLICE_MIN: test hook)
 
     // small host-side all-gather (calcmumi's per-genome results): through device staging when the collectives are RCCL
     int allgather_host(const void* send, int64_t bytes, void* recv) {
@@ -658,12 +595,17 @@ public:
     std::vector<uint64_t> ev_key_h, ev_val_h;
     std::vector<int32_t> rep_h;
     int ev_lbits = 0;
-    int64_t work_budget = getenv("PM_WORK_BUDGET") ? atol(getenv("PM_WORK_BUDGET")) : (1 << 22);      // PM_WORK_BUDGET: test hook
-    // shortest one-region candidate list that gets the device overlap test (the host's PARSNP_PARALLEL_MIN; PM_DIRTY_MIN: test hook)
-    int64_t dirty_min = getenv("PM_DIRTY_MIN") ? atol(getenv("PM_DIRTY_MIN")) : 4096;
+    // tunables of a session (pm_session_tune): per-thread work budget of the index walks; shortest one-region candidate list
+    // that gets the device overlap test and stays resident as the anchor table (the host's threshold for its long-list routes)
+    int64_t work_budget = 1 << 22;
+    int64_t dirty_min = 4096;
+    bool tune(const std::string& key, int64_t value) {
+        if (key == "work_budget" && value > 0) { work_budget = value; return true; }
+        if (key == "dirty_min" && value >= 0) { dirty_min = value; return true; }
+        return false;
+    }
 
     void release() {
-        finish_pending();
         for (BufBase* b : all_bufs) { if (b->raw) be.free(b->raw); b->raw = nullptr; b->cap = 0; }
         if (blk) be.free(blk);
         if (d_goff) be.free(d_goff);

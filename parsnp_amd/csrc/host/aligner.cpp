@@ -6,6 +6,7 @@
 #include <unistd.h>
 
 #include "aligner.h"
+#include "hooks.h"
 
 #include <algorithm>
 #include <chrono>
@@ -139,7 +140,6 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
         layout_ready_.push_back(std::async(std::launch::async, [this, k, parts] {
             for (size_t i = n * k / parts; i < n * (k + 1) / parts; i++) layout[i].init(genomes[i].seq.size() + 1);
         }));
-    if (getenv("PARSNP_SYNC_LAYOUT")) wait_layout();    // measurement switch: clear before anything else, as a plain constructor would
 }
 // The marks validate_parallel put off: genome by genome (a task owns its genomes' bitmaps: plain stores), the candidates in
 // list order.  Started by whoever gets there first -- extend_generations right before the recursion's first engine call,
@@ -157,16 +157,14 @@ void Aligner::mark_stripe(size_t j0, size_t j1) {
 void Aligner::start_deferred_marks() {
     if (!deferred_.pending) return;
     deferred_.pending = false;
-    static const long want = getenv("PARSNP_MARK_TASKS") ? atol(getenv("PARSNP_MARK_TASKS")) : 0;      // measurement knob
     // (half as many tasks as host threads: measured steadier than one per thread -- 27.6-28.1 against 28.5-28.7 ms mean over
     // 40 steps -- the call they run beside has staging threads of its own, and the container's CPU quota is finite)
-    const size_t tasks = std::min<size_t>(n, (size_t)std::max<long>(1, want > 0 ? want : (prm.cores + 1) / 2));
+    const size_t tasks = std::min<size_t>(n, (size_t)std::max<long>(1, (prm.cores + 1) / 2));
     for (size_t t = 0; t < tasks; t++)
         layout_ready_.push_back(std::async(std::launch::async, [this, t, tasks] {
             // background work: it yields to the threads that stage the engine call it runs beside, and takes the cores that
             // call leaves idle while the device works
-            static const int nice_by = getenv("PARSNP_MARK_NICE") ? atoi(getenv("PARSNP_MARK_NICE")) : 10;
-            if (nice_by > 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), nice_by);
+            (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
             mark_stripe(n * t / tasks, n * (t + 1) / tasks);
         }));
 }
@@ -330,7 +328,6 @@ void Aligner::chunk_requests(const Region& r, int minsize, std::vector<Request>*
 }
 
 void Aligner::collect_engine_timing() {
-    timing_deferred_ = false;
     int cnt = 64; const char* names[64]; float ms[64];
     if (pm_last_timing(session_, &cnt, names, ms) != PM_OK) return;
     if (timing_first_call_) stats.anchor_ms.clear();
@@ -346,10 +343,9 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     out->clear();
     out->resize(reqs.size());
     if (reqs.empty()) return;
-    flush_engine_timing();
     double t0 = now_s();
     // results as MUM rows built on the device where the provider can (the HIP engine) and every request is its region
-    static const bool no_rows = getenv("PARSNP_NO_DEVICE_ROWS") != nullptr;      // test hook: the host builds the rows from sp / fwd
+    static const bool no_rows = test_hook("PARSNP_NO_DEVICE_ROWS") != nullptr;      // test hook: the host builds the rows from sp / fwd
     rows = rows && rows_supported_ && !no_rows;
     if (rows != rows_mode_) {
         if (pm_session_rows(session_, rows ? 1 : 0) == PM_OK) rows_mode_ = rows;
@@ -364,7 +360,7 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     // Regions that are gaps between two rows of the engine's resident anchor table go as 16 bytes each (pm_multi_mum_batch_gaps)
     // instead of 16 bytes per GENOME: the engine derives their rows from the table.  Worth it for a batch of many such regions
     // (the recursion's seeds); the rows of the others travel as before, packed at the front of the flat arrays.
-    static const bool no_gaps = getenv("PARSNP_NO_GAP_REQUESTS") != nullptr;      // test hook: every row travels
+    static const bool no_gaps = test_hook("PARSNP_NO_GAP_REQUESTS") != nullptr;      // test hook: every row travels
     long derived = 0;
     if (rows && anchor_table_ != 0 && !no_gaps) for (const Request& q : reqs) derived += q.plain && q.gap_side >= 0;
     const bool use_gaps = derived >= 64 && derived * 2 >= nreq;
@@ -443,13 +439,8 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
         r.owner = own;
     }
     stats.t_unpack += now_s() - tu;
-    // the device phase times: now, unless the rows of this result are still arriving (asking would wait for them) -- then
-    // before the next engine call or when the step's statistics are read
     timing_first_call_ = stats.finder_calls == 0;
-    if (rows && pm_result_wait_rows(res, 0) < pm_result_total(res)) {
-        timing_deferred_ = true;
-        for (Raw& r : *out) r.in_flight = true;
-    } else collect_engine_timing();
+    collect_engine_timing();      // the device phase times of this call
     stats.finder_calls++;
     stats.finder_regions += (long)reqs.size();
     stats.finder_s += now_s() - t0;
@@ -568,9 +559,8 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
     anchors_ordered_ = false;      // only validate_parallel, for a list accepted into an empty layout, can say otherwise
     const size_t ncand = raw.count;
     const int threads = prm.cores > 1 ? prm.cores : 1;
-    static const size_t par_min = getenv("PARSNP_PARALLEL_MIN") ? (size_t)atol(getenv("PARSNP_PARALLEL_MIN")) : 4096;   // test hook
+    static const size_t par_min = test_hook("PARSNP_PARALLEL_MIN") ? (size_t)atol(test_hook("PARSNP_PARALLEL_MIN")) : 4096;   // test hook
     if (ncand >= par_min && threads > 1 && !layout[0].logging()) { validate_parallel(r, q, raw, accepted, threads); return; }
-    if (raw.in_flight) pm_result_wait_rows(raw.owner.get(), -1);      // the serial loop below reads any row
     const double tser = now_s();
     struct Rep { double t0; size_t n; ~Rep() { if (n > 1000 && getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[validate serial] %zu candidates %.4f s\n", n, now_s() - t0); } } rep_{tser, ncand};
     for (size_t c = 0; c < ncand; c++) {
@@ -606,13 +596,6 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // rows: built on the device where the engine delivers them (the candidates' rows ARE the result blocks then: nothing
     // is copied, trim() works on them in place and the result is kept alive), else from (sp, fwd) here
     const bool device_rows = raw.start != nullptr;
-    // rows still arriving from the device: a pass over the candidates asks for them as it gets there (pm_result_wait_rows
-    // answers with how far the table has come, so a thread asks once per slice)
-    auto rows_until = [&](size_t c_end) -> size_t {
-        if (!raw.in_flight) return ncand;
-        const int64_t got = pm_result_wait_rows(raw.owner.get(), (int64_t)(raw.row0 + c_end));
-        return got <= (int64_t)raw.row0 ? 0 : std::min(ncand, (size_t)got - raw.row0);
-    };
     int32_t* srow = device_rows ? raw.start : irows_.alloc(ncand * n);
     uint8_t* frow = device_rows ? raw.strand : brows_.alloc(ncand * n);
     if (device_rows) kept_results_.push_back(raw.owner);
@@ -620,8 +603,8 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     std::vector<uint8_t> state(ncand, 0);   // bit0 constructed, bit1 ok, bit2 any_reverse, bit3 dirty, bit4 accepted
     const long nc = (long)ncand;
     const bool layout_empty = pool.empty();      // nothing accepted yet: the layout holds no mark (the anchor call)
-    static const bool force_exact = getenv("PARSNP_EXACT_OVERLAP") != nullptr;   // test hook: always the bitmap test
-    static const bool host_overlap = getenv("PARSNP_HOST_OVERLAP") != nullptr;   // test hook: the cheap test on the host although the device ran it
+    static const bool force_exact = test_hook("PARSNP_EXACT_OVERLAP") != nullptr;   // test hook: always the bitmap test
+    static const bool host_overlap = test_hook("PARSNP_HOST_OVERLAP") != nullptr;   // test hook: the cheap test on the host although the device ran it
     const bool device_dirty = device_rows && raw.dirty_known && layout_empty && !host_overlap;
 #pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
     for (long c = 0; c < nc; c++) {
@@ -644,7 +627,6 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // treating a clean candidate as dirty is harmless (it takes the ordered path and sees the same marks); where genomes
     // are rearranged enough for it to flag too many, the exact test with scratch bitmaps decides instead.
     const int nstripes = threads;
-    if (!device_dirty) (void)rows_until(ncand);      // the host's own overlap test walks every row
     if (!device_dirty) {
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
         for (int t = 0; t < nstripes; t++) {
@@ -695,7 +677,6 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
         for (long rr = 0; rr < nruns; rr++) {
             const long c0 = rr * kRun, c1 = std::min(nc, c0 + kRun);
-            (void)rows_until((size_t)c1);
             for (long c = c0; c < c1; c++) {
                 const uint8_t st = state[(size_t)c];
                 if ((st & 3) != 3 || (st & 8)) continue;
@@ -712,20 +693,19 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // the ones that meet a flagged candidate's interval are found by bisection and marked now; the other 12 million
     // intervals (200 x 5 Mb: 3.6 ms of all cores) are marked by background tasks that extend_generations() starts right
     // before the recursion's first engine call, whose wait they fill.  PARSNP_MARK_FIRST=1 (test hook): never put off.
-    static const bool mark_first = getenv("PARSNP_MARK_FIRST") != nullptr;
+    static const bool mark_first = test_hook("PARSNP_MARK_FIRST") != nullptr;
     int disorder = 0;
     bool put_off = false;
     // (the order: from the device's PM_ROW_EARLY bits where it delivered the overlap flags -- no accepted clean candidate
     // with the bit means in order; the bit is conservative, so a list it calls out of order takes the marking pass -- else
     // from the rows, PARSNP_HOST_ORDER=1 forces that)
-    static const bool host_order = getenv("PARSNP_HOST_ORDER") != nullptr;
+    static const bool host_order = test_hook("PARSNP_HOST_ORDER") != nullptr;
     bool order_known = false;
     if (layout_empty && !mark_first && threads > 1 && device_dirty && !host_order) {
         for (size_t c = 0; c < ncand; c++) if ((state[c] & 24) == 16 && (raw.flags[c] & PM_ROW_EARLY)) { disorder = 1; break; }
         order_known = true;
     }
     if (layout_empty && !mark_first && threads > 1) {
-        (void)rows_until(ncand);
         const long kRun = 1024, nruns = order_known ? 0 : (nc + kRun - 1) / kRun;      // (no run: the device has said it)
         std::vector<long> first_acc((size_t)nruns, -1), last_acc((size_t)nruns, -1);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(| : disorder)
@@ -817,9 +797,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         std::vector<long> last_l(j1 - j0 + 16, 0);      // end of the previous accepted candidate, per genome of the stripe
         long* last = last_l.data() + 8 - j0;
         long bad = 0;
-        size_t have = 0;
         for (size_t c = 0; c < ncand; c++) {
-            if (c >= have) have = rows_until(c + 1);
             __builtin_prefetch(srow + (c + 24) * n + j0); __builtin_prefetch(srow + (c + 24) * n + j1 - 1);
             if ((state[c] & 24) == 16)
                 { const int32_t* st = cand[c].start; const long lon = cand[c].length;     // accepted: inside the genome, length >= 5
@@ -833,7 +811,6 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         disorder |= bad < 0 ? 1 : 0;
     }
     lap("mark");
-    (void)rows_until(ncand);      // everything below reads any row
     // the rest: ids and pool order as the sequential loop assigns them
     std::vector<uint32_t> ordered;        // the flagged candidates, in candidate order
     for (size_t c = 0; c < ncand; c++) if ((state[c] & 11) == 11) ordered.push_back((uint32_t)c);
@@ -844,8 +821,8 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // holder of that maximum are tangled (every member of an overlapping pair is caught as one or the other).
     const size_t nord = ordered.size();
     std::vector<uint8_t> tangled(nord, 1), settled(nord, 0);
-    static const bool no_free = getenv("PARSNP_ORDERED_FLAGGED") != nullptr;     // test hook: everything flagged stays ordered
-    static const size_t free_min = getenv("PARSNP_FREE_MIN") ? (size_t)atol(getenv("PARSNP_FREE_MIN")) : 32;   // test hook
+    static const bool no_free = test_hook("PARSNP_ORDERED_FLAGGED") != nullptr;     // test hook: everything flagged stays ordered
+    static const size_t free_min = test_hook("PARSNP_FREE_MIN") ? (size_t)atol(test_hook("PARSNP_FREE_MIN")) : 32;   // test hook
     if (nord >= free_min && !no_free) {
         std::fill(tangled.begin(), tangled.end(), 0);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
@@ -1005,7 +982,7 @@ bool Aligner::find_anchors() {
     region_mums(whole, true, &found, false);
     lap_a("search + validation");
     // (marks that validate_parallel put off stay put off while the seed regions come from the rows: only walks read them)
-    if (!anchors_ordered_ || getenv("PARSNP_WALK_NEIGHBOURS") || getenv("PARSNP_CHECK_NEIGHBOURS")) wait_layout();
+    if (!anchors_ordered_ || test_hook("PARSNP_WALK_NEIGHBOURS") || test_hook("PARSNP_CHECK_NEIGHBOURS")) wait_layout();
     mums = found;
     m0 = (long)found.size();
     // seed regions: left and right neighbour of every anchor, longer than q in every genome (:2150-2172).  The layout
@@ -1016,7 +993,7 @@ bool Aligner::find_anchors() {
     // scratch and kept -- copied into the arena -- only for those.
     std::vector<Region> lRs(found.size()), rRs(found.size());   // start == nullptr: dropped
     const long nf = (long)found.size();
-    static const bool check_derived = getenv("PARSNP_CHECK_NEIGHBOURS") != nullptr;
+    static const bool check_derived = test_hook("PARSNP_CHECK_NEIGHBOURS") != nullptr;
     // left neighbour: where the walk to the right of the previous anchor ended exactly at this anchor in every genome,
     // the walk back from this anchor crosses the same unmarked bases and stops at the previous anchor's last base
     // (prev_set :1216-1231), or one base later when the base after it is marked: no second walk over the bitmap.
@@ -1096,7 +1073,7 @@ bool Aligner::find_anchors() {
             }
             return true;
         };
-        static const bool no_rows_path = getenv("PARSNP_WALK_NEIGHBOURS") != nullptr;      // test hook: always the bitmap walks
+        static const bool no_rows_path = test_hook("PARSNP_WALK_NEIGHBOURS") != nullptr;      // test hook: always the bitmap walks
         if (anchors_ordered_ && !no_rows_path) {
             for (long i = i0; i < i1; i++) {
                 const Mum& m = pool[(size_t)found[(size_t)i]];
@@ -1178,7 +1155,7 @@ bool Aligner::extend_pass(bool speculative, bool sorted_start) {
     size_t head = 0;
     std::vector<int> found;
     std::vector<Handle> kids;
-    const bool force_literal = getenv("PARSNP_FORCE_LITERAL_WORKLIST") != nullptr;   // debug: always the reference's vector + std::sort
+    const bool force_literal = test_hook("PARSNP_FORCE_LITERAL_WORKLIST") != nullptr;   // debug: always the reference's vector + std::sort
     remaining_ = [&](std::vector<Region>* out) {   // what is still on the work list, in order
         if (literal) for (size_t x = head; x < work.size(); x++) out->push_back(rpool[(size_t)work[x].idx]);
         else for (const auto& kv : uniq) out->push_back(rpool[(size_t)kv.second]);
@@ -1591,13 +1568,13 @@ bool Aligner::extend_generations() {
 // that is not cached, a speculative sweep over everything still on the work list predicts and batches the rest.
 bool Aligner::extend() {
     double t0 = now_s();
-    speculation_ = getenv("PARSNP_NO_SPECULATION") == nullptr;
+    speculation_ = test_hook("PARSNP_NO_SPECULATION") == nullptr;
     sweeps_ = 0; misses_since_sweep_ = 0;
     double tr = now_s();
     bool any;
-    static const bool no_prejudge = getenv("PARSNP_NO_PREJUDGE") != nullptr;      // test hook: every verdict inside chain()
+    static const bool no_prejudge = test_hook("PARSNP_NO_PREJUDGE") != nullptr;      // test hook: every verdict inside chain()
     if (!no_prejudge) start_prejudge();
-    if (getenv("PARSNP_SEQUENTIAL_REPLAY") == nullptr) any = extend_generations();
+    if (test_hook("PARSNP_SEQUENTIAL_REPLAY") == nullptr) any = extend_generations();
     else { if (speculation_) prefetch(regions); finish_prejudge(); tr = now_s(); any = extend_pass(false); }
     finish_prejudge();
     stats.t_replay = now_s() - tr - stats.t_sweep;
@@ -1711,7 +1688,7 @@ uint8_t Aligner::judge_pair(const Mum& nt, const Mum& back) const {
 // MUM is still the one it was judged against.  Reads `pool` and `mums` as the anchor search left them: finish_prejudge()
 // is called before anything is added to either.
 void Aligner::start_prejudge() {
-    static const size_t min_n = getenv("PARSNP_PREJUDGE_MIN") ? (size_t)atol(getenv("PARSNP_PREJUDGE_MIN")) : 4096;   // test hook
+    static const size_t min_n = test_hook("PARSNP_PREJUDGE_MIN") ? (size_t)atol(test_hook("PARSNP_PREJUDGE_MIN")) : 4096;   // test hook
     if (mums.size() < min_n || prm.cores < 2) return;
     judged_pred_.assign(pool.size(), -1); judged_verdict_.assign(pool.size(), kClose);
     // a third of the threads: the engine call it runs beside stages 26 MB of request rows with threads of its own first

@@ -211,8 +211,7 @@ struct Raw {
     // MUM-row mode of the engine (pm_session_rows): rows of n entries per candidate built on the device, and their flags
     int32_t* start = nullptr; uint8_t* strand = nullptr; const uint32_t* flags = nullptr;
     bool dirty_known = false;
-    bool in_flight = false;      // the rows may still be arriving: pm_result_wait_rows(owner, candidates needed) before reading them
-    size_t row0 = 0;             // this list's first candidate in the result (pm_result_wait_rows counts from the result's start)
+    size_t row0 = 0;             // this list's first candidate in the result
     size_t count = 0;
     std::shared_ptr<pm_result> owner;
 };
@@ -283,7 +282,6 @@ public:
 
     void wait_layout();           // the layout bitmaps are set up in the background (constructor); find_anchors() awaits them
     void start_deferred_marks();  // (no-op unless validate_parallel put marks off)
-    void flush_engine_timing() { if (timing_deferred_) collect_engine_timing(); }   // before `stats` is read
     enum : uint8_t { kJoin = 0, kClose = 1, kPass = 2 };
     uint8_t judge_pair(const Mum& nt, const Mum& back) const;     // chain()'s test of a MUM against the open chain's last MUM
     void start_prejudge();        // the anchors' consecutive pairs, judged beside the recursion's first engine call
@@ -319,7 +317,6 @@ private:
     bool rows_mode_ = false, rows_supported_ = true;
     int64_t anchor_table_ = 0;         // id of the engine's resident anchor table that Mum::row / Region::gap_* refer to (0: none)
     bool timing_first_call_ = false;
-    bool timing_deferred_ = false;     // the phase times of the last engine call are read later (its rows were still arriving)
     void collect_engine_timing();
     std::vector<std::shared_ptr<pm_result>> kept_results_;   // results whose row blocks hold the rows of accepted MUMs
     // cache of raw results keyed by request coordinates (results are a pure function of them); entries own a copy of

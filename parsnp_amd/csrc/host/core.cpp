@@ -1,4 +1,5 @@
 #include "core.h"
+#include "hooks.h"
 
 #include <chrono>
 #include <cstdio>
@@ -107,6 +108,9 @@ int CoreRun::open(const std::string& ini_path) {
         std::cerr << "parsnp_core: cannot start the multi-MUM engine (" << pm_provider() << "): " << pm_last_error() << std::endl;
         return 3;
     }
+    // (test builds: the engine's thresholds of the long-list routes, lowered so that small inputs take them)
+    if (const char* v = test_hook("PM_DIRTY_MIN")) (void)pm_session_tune(session, "dirty_min", atol(v));
+    if (const char* v = test_hook("PM_WORK_BUDGET")) (void)pm_session_tune(session, "work_budget", atol(v));
     upload_s = now_s() - t1;
     return 0;
 }
@@ -189,7 +193,7 @@ StepReport CoreRun::step() {
         // the reference chains again (:3261-3268).  With no LCB dissolved and no two MUMs sharing a reference start the
         // MUM list and its sorted order are unchanged, and the second pass would rebuild exactly the list at hand
         // (chain order = order of the first MUMs on the reference = the order sort_lcbs left).
-        bool same = a.filtered_lcbs == dissolved && a.unique_order && !getenv("PARSNP_CHAIN_TWICE");
+        bool same = a.filtered_lcbs == dissolved && a.unique_order && !test_hook("PARSNP_CHAIN_TWICE");
         for (size_t i = 1; i < a.lcbs.size() && same; i++) same = a.lcbs[i - 1].start[0] < a.lcbs[i].start[0];
         if (!same) { a.chain(); lap("chain"); }
         a.fill_between(); lap("fill_between");
@@ -198,7 +202,6 @@ StepReport CoreRun::step() {
         printf("        LCBs created, elapsed time: %.0lf seconds\n\n", difftime(end, start));
     }
     r.path_s = now_s() - t0;
-    a.flush_engine_timing();
     const Stats& s = a.stats;
     r.anchor_s = s.anchor_s; r.extend_s = s.extend_s; r.filter_s = s.filter_s; r.lcb_s = s.lcb_s; r.finder_s = s.finder_s;
     r.alg_bytes = s.alg_bytes; r.alg_bytes_kernel = s.alg_bytes_kernel; r.alg_bytes_query = s.alg_bytes_query; r.finder_calls = s.finder_calls; r.finder_regions = s.finder_regions; r.regions_processed = s.regions_processed;

@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include "aligner.h"
+#include "hooks.h"
 #include "gapalign.h"
 
 namespace parsnp {
@@ -175,7 +176,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     double tl = clock_s();
     auto lap = [&](const char* what) { if (dbg) { double t = clock_s(); fprintf(stderr, "[output] %-14s %.4f s\n", what, t - tl); tl = t; } };
     auto printable_lcb = [&](const Lcb& ct) { return ct.type == 1 && !ct.mums.empty() && prm.do_align != 0; };
-    static const bool plain_output = getenv("PARSNP_PLAIN_OUTPUT") != nullptr;
+    static const bool plain_output = test_hook("PARSNP_PLAIN_OUTPUT") != nullptr;
     const bool all_slow = plain_output || prm.recomb_filter;
 
     // ---- layout of every LCB
@@ -271,13 +272,13 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     // device does not take -- wider than its 96-column limit, or declined -- are aligned here by the host threads, the
     // widest ones while the device works on the rest.  PARSNP_HOST_GAPS=1: everything on the host (measurement / tests).
     constexpr unsigned kDeviceCols = 96;
-    static const bool host_gaps = getenv("PARSNP_HOST_GAPS") != nullptr;
+    static const bool host_gaps = test_hook("PARSNP_HOST_GAPS") != nullptr;
     // The LCBs are cut into a few groups of consecutive LCBs with about the same alignment work, one device batch each:
     // the file offsets of a group's records only depend on the groups before it, so its records are written while the
     // device aligns the gaps of the next group.  PARSNP_GAP_GROUPS (test hook) sets the number.
     struct Group { size_t z0 = 0, z1 = 0, y0 = 0, y1 = 0; };      // its LCBs [z0, z1) and its device jobs [y0, y1)
     struct Batch { vector<int32_t> nseq, maxcols, cols; vector<int64_t> seqoff, rowoff; vector<uint8_t> chars, out; vector<long> job; } B;
-    static const long want_groups = getenv("PARSNP_GAP_GROUPS") ? atol(getenv("PARSNP_GAP_GROUPS")) : 0;
+    static const long want_groups = test_hook("PARSNP_GAP_GROUPS") ? atol(test_hook("PARSNP_GAP_GROUPS")) : 0;
     const size_t ngroups = (size_t)std::max<long>(1, std::min<long>(16, want_groups > 0 ? want_groups : (nj >= 6000 && !all_slow ? 3 : 1)));
     vector<Group> batch(ngroups);
     {
@@ -348,7 +349,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
     const string xmfa_path = dir + stem + ".xmfa";
     const int fd = open(xmfa_path.c_str(), O_RDWR);
     if (fd < 0) { cerr << "parsnp_core: cannot write " << xmfa_path << endl; exit(1); }
-    static const bool force_pwrite = getenv("PARSNP_OUTPUT_PWRITE") != nullptr;
+    static const bool force_pwrite = test_hook("PARSNP_OUTPUT_PWRITE") != nullptr;
     long long reserved = 0;
     std::future<bool> reserve_done;
     if (!force_pwrite && !all_slow) {
@@ -364,7 +365,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
             }
             est += (long long)n * (cols + cols / 80 + 2 + 64) + 2;
         }
-        if (getenv("PARSNP_RESERVE_TINY")) est = text_at + 4096;      // test hook: the mapping has to grow with every group
+        if (test_hook("PARSNP_RESERVE_TINY")) est = text_at + 4096;      // test hook: the mapping has to grow with every group
         reserved = est;
         reserve_done = std::async(std::launch::async, [fd, est, dbg, clock_s] {
             const double t0 = clock_s();
@@ -490,7 +491,7 @@ void write_output(Aligner& a, const std::string& stem, bool* gap_note) {
         const int lcb_start = (int)c0.start[0] + 1, lcb_end = (int)c0.end[0];
         if (!slow[z]) {
             if (!(plan[z].cols > (long)(prm.c * 1))) continue;
-            static const long mix = getenv("PARSNP_OUTPUT_MIX") ? atol(getenv("PARSNP_OUTPUT_MIX")) : 0;   // test hook: every mix-th LCB takes the late string route
+            static const long mix = test_hook("PARSNP_OUTPUT_MIX") ? atol(test_hook("PARSNP_OUTPUT_MIX")) : 0;   // test hook: every mix-th LCB takes the late string route
             if (std::max(0, prev_end - lcb_start) == 0 && !(mix > 0 && z % (size_t)mix == 0)) { prev_end = lcb_end; trimmed[z] = c0; printed[z] = 1; continue; }
             slow_rows(z); slow[z] = 1;                       // it has to be trimmed: as strings
         }

@@ -7,3 +7,4 @@ BIN_DIR = os.path.join(PKG, "bin")
 LIB_DIR = os.path.join(PKG, "lib")
 CORE_BIN = os.path.join(BIN_DIR, "parsnp_core")
 HIP_LIB = os.path.join(LIB_DIR, "libparsnp_hip.so")
+CORE_HOOKS_BIN = os.path.join(BIN_DIR, "parsnp_core_hooks")   # the same sources with the test hooks compiled in (csrc/host/hooks.h)

@@ -4,7 +4,7 @@ oracle/_ref/parsnp_core_ref): seeds beyond those of tests/test_fuzz_vs_reference
 taken host routes forced (parallel validation of short lists, free/tangled split of the flagged candidates) and every
 derived or early-exit seed region re-done with the full bitmap walk.
     python scripts/fuzz_campaign.py [first_small last_small [n_big]]      (default 24 160 14: ~15 min)
-PARSNP_FUZZ_CORE=hip runs the PRODUCT binary (parsnp_amd/bin/parsnp_core, on the GPU box) instead of the CPU checker, with
+PARSNP_FUZZ_CORE=hip runs the PRODUCT's sources with the test hooks compiled in (parsnp_amd/bin/parsnp_core_hooks, on the GPU box) instead of the CPU checker, with
 the device-side shortcuts forced onto the small sets as well (MUM rows + overlap flags from the device, prejudged chaining
 verdicts; the inter-MUM gaps go through the device aligner anyway)."""
 import os
@@ -22,7 +22,7 @@ import test_fuzz_vs_reference as F  # noqa: E402
 core = os.path.join(ROOT, "oracle", "_ref", "parsnp_core_oracle")
 os.environ.update(PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_NEIGHBOURS="1")
 if os.environ.get("PARSNP_FUZZ_CORE") == "hip":
-    core = os.path.join(ROOT, "parsnp_amd", "bin", "parsnp_core")
+    core = os.path.join(ROOT, "parsnp_amd", "bin", "parsnp_core_hooks")      # the product's sources with the test hooks compiled in
     os.environ.update(PM_DIRTY_MIN="2", PARSNP_PREJUDGE_MIN="2")
 first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (24, 160)
 n_big = int(sys.argv[3]) if len(sys.argv) > 3 else 14

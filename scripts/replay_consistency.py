@@ -23,7 +23,7 @@ sums = []
 for tag, extra in (("generations", {}), ("generations", {}), ("generations", {}), ("in_order", {"PARSNP_SEQUENTIAL_REPLAY": "1"})):
     out = os.path.join(base, "out")
     env = dict(os.environ, PARSNP_DEBUG_TIMERS="1", **extra)
-    rc, _ = driver.run_core(os.path.abspath(CORE_BIN), rp, qs, out, env=env, threads=threads)
+    rc, _ = driver.run_core(os.path.abspath(CORE_BIN) + ("_hooks" if extra else ""), rp, qs, out, env=env, threads=threads)
     h = hashlib.md5()
     with open(os.path.join(out, "parsnpAligner.xmfa"), "rb") as f:
         for blk in iter(lambda: f.read(1 << 24), b""):

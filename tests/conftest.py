@@ -45,11 +45,11 @@ def emu():
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-DPM_CHUNK=5", src, "-o", EMU_LIB], check=True)
     hsrc = [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".cpp") and f not in ("capi.cpp", "merge_main.cpp")]
     if not _newer(EMU_CORE, hsrc + [os.path.join(host, f) for f in os.listdir(host)] + [EMU_LIB]):
-        subprocess.run(["g++", "-O3", "-mavx2", "-std=c++17", "-fopenmp", "-w"] + hsrc + ["-L" + os.path.dirname(EMU_LIB), "-lpm_emu",
+        subprocess.run(["g++", "-O3", "-mavx2", "-std=c++17", "-fopenmp", "-w", "-DPARSNP_TEST_HOOKS"] + hsrc + ["-L" + os.path.dirname(EMU_LIB), "-lpm_emu",
                         "-Wl,-rpath,$ORIGIN", "-o", EMU_CORE], check=True)
     core_lib = os.path.join(ROOT, "tests", "emu", "libparsnp_core_emu.so")
     lsrc = [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".cpp") and f not in ("main.cpp", "merge_main.cpp")]
     if not _newer(core_lib, lsrc + [os.path.join(host, f) for f in os.listdir(host)] + [EMU_LIB]):
-        subprocess.run(["g++", "-O3", "-mavx2", "-std=c++17", "-fopenmp", "-fPIC", "-shared", "-w"] + lsrc +
+        subprocess.run(["g++", "-O3", "-mavx2", "-std=c++17", "-fopenmp", "-fPIC", "-shared", "-w", "-DPARSNP_TEST_HOOKS"] + lsrc +
                        ["-L" + os.path.dirname(EMU_LIB), "-lpm_emu", "-Wl,-rpath,$ORIGIN", "-o", core_lib], check=True)
     return EMU_LIB, EMU_CORE

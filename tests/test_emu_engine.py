@@ -122,7 +122,7 @@ def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
     the overlap test / the row construction back to the host: same bytes either way."""
     r, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PM_SLICE_MIN="8", PM_ROW_SLICES="1")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8")
     if variant == "host_overlap":
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":
@@ -145,15 +145,15 @@ def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
 
 def test_work_budget_retry(libs, monkeypatch):
     """a region whose repeat structure exhausts the per-thread work budget is run again with a larger one instead of
-    failing the run (engine_core.h: run); PM_WORK_BUDGET makes a 40-copy tandem repeat enough to trigger it"""
+    failing the run (engine_core.h: run); a budget of 48 steps (pm_session_tune) makes a 40-copy tandem repeat enough to trigger it"""
     E, O = libs
     rng = np.random.default_rng(77)
     unit = b"ACGTTGCA"
     ref = random_seq(rng, 300) + unit * 40 + random_seq(rng, 300)
     qs = [mutate(rng, ref, sub=0.01), random_seq(rng, 50) + unit * 37 + random_seq(rng, 200)]
     want = oracles.restatement_multi_mum(O, [ref] + qs, 9, 1)
-    monkeypatch.setenv("PM_WORK_BUDGET", "48")
     with Session(E, [ref] + qs) as s:
+        s.tune("work_budget", 48)
         got = s.whole(9)
         retried = dict(s.last_timing()).get("budget_retries", 0)
     assert same(want, got)

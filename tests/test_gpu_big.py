@@ -13,7 +13,7 @@ import pytest
 
 import xmfa_util
 from parsnp_amd import driver, synth
-from parsnp_amd.paths import CORE_BIN
+from parsnp_amd.paths import CORE_BIN, CORE_HOOKS_BIN
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +50,8 @@ def test_baseline_size_against_reference(scratch, name):
         if mode == "in_order":
             env["PARSNP_SEQUENTIAL_REPLAY"] = "1"
         out = os.path.join(scratch, name, "out_" + mode)
-        rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=24)
+        # (the in-order replay is a test hook: forced through the product's sources built with csrc/host/hooks.h's switches)
+        rc, _ = driver.run_core(CORE_HOOKS_BIN if mode == "in_order" else CORE_BIN, rp, qs, out, env=env, threads=24)
         assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
         x = os.path.join(out, "parsnpAligner.xmfa")
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"], mode

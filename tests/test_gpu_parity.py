@@ -13,7 +13,7 @@ import test_host_logic
 import xmfa_util
 from parsnp_amd import driver, synth
 from parsnp_amd.binding import Lib, Session
-from parsnp_amd.paths import CORE_BIN, HIP_LIB
+from parsnp_amd.paths import CORE_BIN, CORE_HOOKS_BIN, HIP_LIB
 from seqgen import adversarial_case, mutate, random_seq
 from test_golden import G, mers, read_fasta
 
@@ -213,37 +213,39 @@ def test_parsnp_core_replay_modes_threaded(libs, tmp_path, name, mode):
     if mode == "in_order":
         env["PARSNP_SEQUENTIAL_REPLAY"] = "1"
     out = str(tmp_path / "out")
-    rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=8, **kw)
+    rc, _ = driver.run_core(CORE_HOOKS_BIN if mode == "in_order" else CORE_BIN, rp, qs, out, env=env, threads=8, **kw)
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 
 
 @pytest.mark.parametrize("name", ["rearr6x300k", "poprearr10x400k", "pop20x1m"])
-@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows", "rows_in_one_piece", "host_order", "mark_first"])
+@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows", "all_rows_travel", "host_order", "mark_first"])
 def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant):
     """the MUM rows, the cheap overlap flags and the list-order bits come from the device (CompactCandidates,
-    DirtyExtent/Prefix/Mark) and feed the threaded anchor validation in place; switching any of them back to the host, or
-    marking the layout before instead of after the flagged candidates, must not change a byte"""
+    DirtyExtent/Prefix/Mark) and feed the threaded anchor validation in place, and the recursion's seed regions are derived on
+    the device from the resident anchor table; switching any of them back to the host, or marking the layout before instead of
+    after the flagged candidates, must not change a byte.  (parsnp_core_hooks = the product's sources with the test hooks of
+    csrc/host/hooks.h compiled in; the shipped binary ignores these switches.)"""
     if name == "poprearr10x400k":
         rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
     else:
         r, gs = synth.make(name)
         rp, qs = synth.write_set(str(tmp_path / "in"), r, gs); kw = {}
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_PREJUDGE_MIN="8", PM_SLICE_MIN="8", PM_ROW_SLICES="1")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_PREJUDGE_MIN="8")
     if variant == "host_overlap":
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":
         env["PARSNP_NO_DEVICE_ROWS"] = "1"
-    if variant == "rows_in_one_piece":      # the other variants receive the row table in slices while they work (PM_ROW_SLICES, PM_SLICE_MIN)
-        env["PM_ROW_SLICES"] = "0"
+    if variant == "all_rows_travel":        # the other variants send the seed regions as references into the resident anchor table
+        env["PARSNP_NO_GAP_REQUESTS"] = "1"
     if variant == "host_order":             # the list order from a pass over the rows instead of the device's PM_ROW_EARLY bits
         env["PARSNP_HOST_ORDER"] = "1"
     if variant == "mark_first":             # all marks before the flagged candidates (nothing put off)
         env["PARSNP_MARK_FIRST"] = "1"
     env["PARSNP_DEBUG_TIMERS"] = "1"
     out = str(tmp_path / "out")
-    rc, _ = driver.run_core(CORE_BIN, rp, qs, out, env=env, threads=8, **kw)
+    rc, _ = driver.run_core(CORE_HOOKS_BIN, rp, qs, out, env=env, threads=8, **kw)
     err = open(os.path.join(out, "parsnp-aligner.err")).read()
     assert rc == 0, err[-2000:]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
