@@ -86,17 +86,9 @@ struct Slot {
 struct Params {
     const Job* jobs; int64_t njobs; const int64_t* seq_off; const uint8_t* chars;
     uint8_t* out_rows; int32_t* out_cols; unsigned long long* next; uint8_t* ws; int64_t ws_stride; int32_t nmax, cap;
-    // instrumented builds only (-DPM_GAP_DEBUG_BUILD, scripts/gap_probe.py), null otherwise:
     volatile int32_t* dbg;     // PM_GAP_DEBUG: per slot (job, stage) in host memory the host can read while the kernel runs
     unsigned long long* prof;  // PM_GAP_DEBUG=3: shader clocks per stage, summed over the jobs
 };
-// The stage markers and stage clocks (how a hang of the first version was localised; where DESIGN 6's stage shares come
-// from) are compiled into instrumented builds only; the shipped kernel carries neither the branches nor the 16 counters.
-#if defined(PM_GAP_DEBUG_BUILD)
-constexpr bool kGapDebug = true;
-#else
-constexpr bool kGapDebug = false;
-#endif
 constexpr int kProfStages = 16;
 
 // every lane's outstanding loads / stores (global and LDS) have completed before any lane goes on: the lanes of the one
@@ -320,7 +312,7 @@ __device__ bool nw_small(Shared& S, uint8_t* TB, int la, int lb, int* plen, bool
         GA_SYNC();
     }
     GA_SYNC();
-    if (kGapDebug && prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof_sweep += t_ - prof_t0; prof_t0 = t_; }
+    if (prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof_sweep += t_ - prof_t0; prof_t0 = t_; }
     bool ok = true;
     if (lane == 0) {
         const float mab = S.p.result[0], dab = S.p.result[1], iab = S.p.result[2];
@@ -351,15 +343,15 @@ __device__ bool nw_small(Shared& S, uint8_t* TB, int la, int lb, int* plen, bool
     return n >= 0;
 }
 
-#define GA_STAGE(stage_) do { if (kGapDebug && P.dbg && lane == 0) P.dbg[blockIdx.x * 2 + 1] = (stage_); } while (0)
+#define GA_STAGE(stage_) do { if (P.dbg && lane == 0) P.dbg[blockIdx.x * 2 + 1] = (stage_); } while (0)
 // PM_GAP_DEBUG=3: the shader clock spent since the previous mark goes to stage k_
 // (kept in registers and added to the launch's totals once per job: a shared counter per mark would be what is measured)
-#define GA_CLOCK(k_) do { if (kGapDebug && P.prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof_acc[(k_)] += t_ - prof_t0; prof_t0 = t_; } } while (0)
+#define GA_CLOCK(k_) do { if (P.prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof_acc[(k_)] += t_ - prof_t0; prof_t0 = t_; } } while (0)
 __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, const Params& P, const Job& job, int* out_cols) {
     const int lane = (int)__lane_id();
     const int n = job.n, cap = P.cap;
     unsigned long long prof_acc[kProfStages] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long prof_t0 = (kGapDebug && P.prof) ? (unsigned long long)clock64() : 0;
+    unsigned long long prof_t0 = P.prof ? (unsigned long long)clock64() : 0;
     if (n < 2 || n > kMaxSeqs) return false;
     // ---- sequences: lengths, FixAlpha (seq.cpp:331-344) happens when the rows are filled
     int bad = 0, wild = 0;
@@ -609,7 +601,7 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
         else { build_profile<false>(S, R, cap, loa, nsa, la, total_a, true); build_profile<false>(S, R, cap, lob, nsb, lb, total_b, false); }
         int plen = 0;
         GA_STAGE(101 + (int)(v - un) * 10); GA_CLOCK(13);
-        if (!nw_small(S, TB, la, lb, &plen, kGapDebug && P.prof != nullptr, prof_acc[9], prof_t0)) return false;
+        if (!nw_small(S, TB, la, lb, &plen, P.prof != nullptr, prof_acc[9], prof_t0)) return false;
         GA_STAGE(102 + (int)(v - un) * 10); GA_CLOCK(10);
         if (plen > cap || plen > kMaxCols) return false;
         // aligngivenpath.cpp:124-255: a column of A, of B, or of both
@@ -692,7 +684,7 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
     }
     *out_cols = nc;
     GA_CLOCK(12);
-    if (kGapDebug && P.prof && lane == 0) for (int k = 0; k < kProfStages; k++) if (prof_acc[k]) atomicAdd(&P.prof[k], prof_acc[k]);
+    if (P.prof && lane == 0) for (int k = 0; k < kProfStages; k++) if (prof_acc[k]) atomicAdd(&P.prof[k], prof_acc[k]);
     return true;
 }
 
@@ -742,12 +734,12 @@ __global__ __launch_bounds__(64) void gap_align_kernel(Params P) {
         GA_SYNC();
         if (j >= P.njobs) break;
         const Job job = P.jobs[j];
-        if (kGapDebug && P.dbg && threadIdx.x == 0) { P.dbg[blockIdx.x * 2] = (int32_t)j; P.dbg[blockIdx.x * 2 + 1] = 0; }
+        if (P.dbg && threadIdx.x == 0) { P.dbg[blockIdx.x * 2] = (int32_t)j; P.dbg[blockIdx.x * 2 + 1] = 0; }
         int cols = -1;
         if (!align_job(S, rows_lds, tb_lds, W, P, job, &cols)) cols = -1;
         GA_SYNC();
         if (threadIdx.x == 0) P.out_cols[j] = cols;
-        if (kGapDebug && P.dbg && threadIdx.x == 0) P.dbg[blockIdx.x * 2 + 1] = -1;
+        if (P.dbg && threadIdx.x == 0) P.dbg[blockIdx.x * 2 + 1] = -1;
     }
 }
 
@@ -904,17 +896,16 @@ extern "C" int pm_gap_align_groups(int device, int64_t n_jobs, const int32_t* n_
     GA_CHECK(hipMemsetAsync(d_next, 0, 8 * (size_t)n_groups, stream));
     if (timers) { GA_CHECK(hipStreamSynchronize(stream)); lap("alloc + h2d"); }
     int32_t* dbg = nullptr;
-    const char* const dbg_env = kGapDebug ? getenv("PM_GAP_DEBUG") : nullptr;
-    if (dbg_env && atoi(dbg_env) == 2) {
+    if (getenv("PM_GAP_DEBUG") && atoi(getenv("PM_GAP_DEBUG")) == 2) {
         if (g_dbg_dev) (void)hipFree(g_dbg_dev);
         g_dbg_dev = nullptr;
         if (hipMalloc((void**)&g_dbg_dev, 8 * (size_t)slots) == hipSuccess) { g_dbg_slots = slots; (void)hipMemsetAsync(g_dbg_dev, 0xff, 8 * (size_t)slots, stream); dbg = g_dbg_dev; }
-    } else if (dbg_env) {
+    } else if (getenv("PM_GAP_DEBUG")) {
         if (!g_dbg || g_dbg_slots < slots) { if (g_dbg) (void)hipHostFree(g_dbg); g_dbg = nullptr; if (hipHostMalloc((void**)&g_dbg, 8 * (size_t)slots, hipHostMallocMapped) == hipSuccess) g_dbg_slots = slots; }
         if (g_dbg) { memset(g_dbg, 0xff, 8 * (size_t)slots); (void)hipHostGetDevicePointer((void**)&dbg, g_dbg, 0); }
     }
     unsigned long long* d_prof = nullptr;
-    if (dbg_env && atoi(dbg_env) == 3) {
+    if (getenv("PM_GAP_DEBUG") && atoi(getenv("PM_GAP_DEBUG")) == 3) {
         GA_CHECK(dalloc(8 * kProfStages, (void**)&d_prof));
         GA_CHECK(hipMemsetAsync(d_prof, 0, 8 * kProfStages, stream));
     }

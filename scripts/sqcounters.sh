@@ -4,9 +4,8 @@
 REPO=$(pwd); OUT=$REPO/gpurun_out/sq; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
 B="python $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0"
-timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_LDS --kernel-trace -d $OUT/a -o a -- $B > $OUT/a.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/b -o b -- $B > $OUT/b.log 2>&1
-timeout 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum --kernel-trace -d $OUT/c -o c -- $B > $OUT/c.log 2>&1
+timeout 90 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_LDS --kernel-trace -d $OUT/a -o a -- $B > $OUT/a.log 2>&1
+timeout 90 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/b -o b -- $B > $OUT/b.log 2>&1
 cd $REPO
 python - <<'PY'
 import sqlite3, glob
