@@ -188,9 +188,16 @@ def main():
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
-    # OpenMP workers sleep instead of spinning between the short parallel host phases: the GPU boxes cap the CPU time of
-    # the container (cgroup quota), and spinning threads burn it (measured: "active" costs 50 % of the throughput)
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    # OpenMP workers between the short parallel host phases (~20 per step): the GPU boxes cap the CPU time of the container
+    # (cgroup quota), and workers that spin without bound burn it (measured in round 1: "active" cost 50 % of the throughput);
+    # workers that sleep at once cost a futex wake-up per phase.  A short bounded spin (20 000 iterations, ~10 us) before
+    # sleeping is the measured best when one rank has the quota to itself (200 x 5 Mb, 24 threads: 25.2 ms per step against
+    # 26.4 passive, 11 instead of 8 cores busy); ranks that share a node's quota sleep at once.
+    if int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) == 1 and usable_cpus() >= 12:
+        os.environ.setdefault("OMP_WAIT_POLICY", "active")
+        os.environ.setdefault("GOMP_SPINCOUNT", "20000")
+    else:
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -379,7 +386,7 @@ def main():
                     phases[k] = phases.get(k, 0.0) + v / len(reports)
                 for k, v in r["engine_ms"].items():
                     totals[k] = totals.get(k, 0.0) + v / len(reports)
-            counts = ("budget_retries", "events")          # counts that travel in the timing list, not times
+            counts = ("budget_retries", "events", "rest_samples")          # counts that travel in the timing list, not times
             kernels = {k: v for k, v in totals.items() if k not in ("setup", "download", "units", "call_wall") + counts}
             dom = max(kernels, key=kernels.get) if kernels else None
             launches = sum(r["finder_calls"] for r in reports) / len(reports)          # engine launches per step

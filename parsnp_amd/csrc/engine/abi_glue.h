@@ -196,6 +196,7 @@ int pm_last_timing(const pm_session* cs, int* count, const char** names, float* 
     s->timing = s->engine->timing;
     if (s->call_wall_ms > 0) s->timing.push_back(pm::PhaseTime{"call_wall", s->call_wall_ms});
     if (s->engine->budget_retries) s->timing.push_back(pm::PhaseTime{"budget_retries", (float)s->engine->budget_retries});   // a count, not a time
+    s->timing.push_back(pm::PhaseTime{"rest_samples", (float)s->engine->last_rest});      // samples SeedExtend handed to SeedRest
     s->timing.push_back(pm::PhaseTime{"events", (float)s->engine->last_events});      // a count too: R-unique maximal matches the event search appended (16 B each)
     int capn = *count, n = 0;
     for (const auto& t : s->timing) { if (n < capn) { names[n] = t.name; ms[n] = t.ms; } n++; }

@@ -622,10 +622,21 @@ struct FillUnits {
 // serves 2 * kLead * kPer K-mers, no longer by the request rate.  Adjacent samples are stride <= 16 bases apart, so the
 // 128-base windows a lane loads around its first sample (query and reference) hold its other samples as well: kPer
 // samples per lane means 1/kPer as many wavefronts walking that chain for the same work.
+//
+// What SeedExtend itself does is the part all lanes share: windows, tags, the leaders' probes, confirmation at the
+// predicted positions, and the arms of a confirmed forward seed.  The rest is rare per sample but not per wavefront -- a
+// sample whose K-mer crosses a difference asks the index itself (15 % of the samples at 1 % divergence; one in twenty
+// passes the presence filter), a chain of repeated K-mers wants walking, a seed lies on the reverse strand -- and a
+// wavefront of 128 samples almost always holds one such lane, for which all 64 used to execute ~600 instructions of slot
+// walks and memory arms.  Those samples are now QUEUED (16 bytes each, one reservation per wavefront) and worked off by
+// SeedRest, one lane per queued sample in full wavefronts.
+struct RestItem { int32_t unit; int32_t sample; int32_t l; int32_t pad; };      // l >= 0: a reverse-strand seed confirmed at reference position l; l < 0: probe the index
+constexpr uint32_t kErrQueue = 4u;     // (error word) the queue of SeedRest overflowed: the launch is repeated with a larger one
 struct SeedExtend {
     Packed P; const RegionInfo* R; const UnitRec* units;
     const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep; const uint32_t* repeated;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
+    RestItem* queue; uint64_t* queue_count; uint64_t queue_cap;      // samples handed to SeedRest
     PM_HD void operator()(int64_t tid) const {
         int64_t unit = tid >> 6; int lane = (int)(tid & 63);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -641,7 +652,6 @@ struct SeedExtend {
         const int64_t rbase = P.goff[0] + ri.ref_pos;
         const int K = ri.K;
         const int32_t stride = ri.stride;
-        int64_t work = 0;
         // events are appended to one of kSlices sub-buffers (all four wavefronts of a workgroup use the same one): a
         // single counter serialises the ~10^6 wavefront reservations of a recursion batch
         const uint64_t slice = (uint64_t)((unit >> 2) & (kSlices - 1));
@@ -667,59 +677,6 @@ struct SeedExtend {
         const uint64_t kbits = K < 32 ? (1ull << (2 * K)) - 1 : ~0ull;
         const uint32_t kmask = K < 32 ? (uint32_t)((1ull << K) - 1) : ~0u;
         auto tag_of = [&](const Win& w) { return (w.b & kbits) | ((uint64_t)(w.m & kmask) << 32); };
-        // a seed on the reverse strand: the sampled bases are the K-mer at jr = m - K - j of the mirrored piece, whose left arm
-        // runs where the forward strand's right arm would (inversions and spurious hits only: arms straight from memory)
-        auto reverse_seed = [&](int64_t j, int32_t l) {
-            const int64_t jr = m - K - j;
-            const int64_t qpr = rec.qbase_r + jr;
-            int32_t lim = (int32_t)(jr < l ? jr : l);
-            if (lim > stride) lim = stride;
-            const int32_t left = lce_bwd(P, qpr, rbase + l, lim);
-            if (left >= stride) return;
-            const int32_t rep_l0 = rep[ri.posbase + l - left];
-            const int32_t rr = ri.nR - l - K;
-            const int32_t maxr = (int32_t)(j < rr ? j : rr);               // m - jr - K = j bases follow the K-mer on the mirrored piece
-            const int32_t right = lce_fwd(P, qpr + K, rbase + l + K, maxr);
-            const int32_t len = left + K + right;
-            if (len >= ri.minlen && len > rep_l0) emit(1, l - left, jr - left, len);
-        };
-        // a seed on the forward strand with both arms from memory
-        auto forward_seed = [&](int64_t j, int32_t l) {
-            int32_t lim = (int32_t)(j < l ? j : l);
-            if (lim > stride) lim = stride;
-            const int32_t left = lce_bwd(P, qbase + j, rbase + l, lim);     // only `stride` bases matter: a longer left arm means an earlier sample owns the match
-            if (left >= stride) return;
-            const int32_t rep_l0 = rep[ri.posbase + l - left];
-            const int64_t mr = m - j - K; const int32_t rr = ri.nR - l - K;
-            const int32_t maxr = (int32_t)(mr < rr ? mr : rr);
-            const int32_t right = lce_fwd64(P, qbase + j + K, rbase + l + K, maxr);
-            const int32_t len = left + K + right;
-            if (len >= ri.minlen && len > rep_l0) emit(0, l - left, j - left, len);      // len <= rep': not unique in R
-        };
-        // every reference position of a slot's chain against one sample: the entries share the canonical K-mer, not the orientation
-        auto walk = [&](int64_t j, uint64_t tag, uint64_t gat, uint64_t slot, int32_t skip) {
-            const bool multi = (slot & kMulti) != 0;
-            for (int32_t l = slot_head(slot); l >= 0; l = multi ? next[ri.posbase + l] : -1) {
-                if (++work > budget) { atomic_or32(err, kErrWork); return; }
-                if (l == skip) continue;                    // (already handled from the registers)
-                const uint64_t rt = kmer_tag(P, rbase + l, K);
-                if (rt == tag) forward_seed(j, l);
-                if (rt == gat) reverse_seed(j, l);
-            }
-        };
-        // a sample without a usable prediction asks the index itself
-        auto probe_sample = [&](int64_t j, uint64_t tag, uint64_t gat) {
-            const uint64_t ctag = gat < tag ? gat : tag;
-            uint64_t slot = index_probe(ri, slots, filter, ctag);
-            if (slot == kEmpty) return;
-            const uint64_t rt = kmer_tag(P, rbase + slot_head(slot), K);
-            if (rt != tag && rt != gat) {                   // another K-mer with the same 32-bit fingerprint (2^-32): the confirmed lookup
-                slot = index_lookup(P, ri, slots, filter, ctag);
-                if (slot == kEmpty) return;
-            }
-            walk(j, tag, gat, slot, -1);
-        };
-
         const int32_t s0 = (rec.chunk * 64 + lane) * kPer;
         const int64_t j0 = (int64_t)s0 * stride;
         // Adjacent samples are `stride` bases apart.  With (kPer - 1) * stride + K <= 32 all K-mers of the lane start inside
@@ -851,24 +808,34 @@ struct SeedExtend {
                 if (rev) todo[u] |= kRev;
             }
         }
+        // the samples for SeedRest: at most one item per sample
+        int32_t qs[kPer], ql[kPer];
+        int nqueued = 0;
+        auto hand_over = [&](int32_t sample, int32_t l) {
+            bool kept = false;
+#pragma unroll
+            for (int u = 0; u < kPer; u++) if (!kept && nqueued == u) { qs[u] = sample; ql[u] = l; kept = true; }
+            nqueued++;
+        };
+#pragma unroll
+        for (int u = 0; u < kPer; u++) { qs[u] = 0; ql[u] = -1; }
 #pragma unroll
         for (int u = 0; u < kPer; u++) {
             if (todo[u] == kNone) continue;
             const int64_t j = j0 + (int64_t)u * stride;
-            if (++work > budget) { atomic_or32(err, kErrWork); break; }
             if (todo[u] & kProbe) {
-                const uint64_t tg = tag_at(u);
-                const uint64_t gat = rc_tag(tg, K);
-                if (follow && u == 0 && sub == 0) {
-                    // a leader's first sample whose probe did not give one unrepeated, confirmed position: nothing in the
-                    // index, a chain, or another K-mer with the same fingerprint
-                    if (slot != kEmpty) {
-                        const uint64_t rt = kmer_tag(P, rbase + slot_head(slot), K);
-                        uint64_t sl = slot;
-                        if (rt != tg && rt != gat) sl = index_lookup(P, ri, slots, filter, gat < tg ? gat : tg);
-                        if (sl != kEmpty) walk(j, tg, gat, sl, -1);
-                    }
-                } else probe_sample(j, tg, gat);
+                // a leader's first sample whose probe did not give one unrepeated, confirmed position holds a slot (a chain, the
+                // other strand, another K-mer with the same fingerprint) or nothing; any other sample asks the presence filter --
+                // a K-mer it does not know is not in the index -- and only what passes goes on to the slot table
+                bool go;
+                if (follow && u == 0 && sub == 0) go = slot != kEmpty;
+                else {
+                    const uint64_t hv = hash_tag(canonical_tag(tag_at(u), K));
+                    const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
+                    const uint32_t fm = filter_mask(hv, bit);
+                    go = (filter[ri.fbase + (bit >> 5)] & fm) == fm;
+                }
+                if (go) hand_over(s0 + u, -1);
                 continue;
             }
             const int32_t l = base + u * stride;
@@ -884,12 +851,118 @@ struct SeedExtend {
                 const int32_t len = lf + K + rt;
                 if (len >= ri.minlen && len > rep_l0) emit(0, l - lf, j - lf, len);      // len <= rep': not unique in R
             }
-            if (todo[u] & kRev) reverse_seed(j, l);
+            if (todo[u] & kRev) hand_over(s0 + u, l);
+        }
+        {
+            uint64_t qat = wave_reserve(queue_count, (uint32_t)nqueued);
+#pragma unroll
+            for (int u = 0; u < kPer; u++)
+                if (u < nqueued) {
+                    if (qat < queue_cap) queue[qat] = RestItem{(int32_t)unit, qs[u], ql[u], 0};
+                    else atomic_or32(err, kErrQueue);
+                    qat++;
+                }
         }
         uint64_t at = kPer == 1 ? wave_reserve01(ev_count, nb != 0) : wave_reserve(ev_count, (uint32_t)nb);
 #pragma unroll
         for (int u = 0; u < kPer; u++)
             if (u < nb) { if (at < ev_cap) { key_out[at] = bk[u]; val_out[at] = bv[u]; } at++; }
+    }
+};
+
+// tid = queued sample (kernels.h: RestItem).  Everything here comes straight from memory: the K-mer, the slot walk, both arms.
+struct SeedRest {
+    Packed P; const RegionInfo* R; const UnitRec* units; const RestItem* queue; const uint64_t* queue_count; uint64_t queue_cap;
+    const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep;
+    uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
+    PM_HD void operator()(int64_t tid) const {
+        const uint64_t nq = *queue_count < queue_cap ? *queue_count : queue_cap;
+        const bool live = (uint64_t)tid < nq;
+        const RestItem it = live ? queue[tid] : RestItem{0, 0, -1, 0};
+        const UnitRec rec = units[it.unit];
+        const int32_t pair = rec.pair;
+        const RegionInfo& ri = R[rec.region];
+        const int64_t m = rec.m;
+        const int64_t qbase = rec.qbase;
+        const int64_t rbase = P.goff[0] + ri.ref_pos;
+        const int K = ri.K;
+        const int32_t stride = ri.stride;
+        int64_t work = 0;
+        const uint64_t slice = (uint64_t)((tid >> 8) & (kSlices - 1));      // one sub-buffer per workgroup
+        uint64_t* ev_count = ev_counters + slice * kSliceStride;
+        const uint64_t ev_cap = slice_cap;
+        uint64_t* const key_out = ev_key + slice * slice_cap;
+        uint64_t* const val_out = ev_val + slice * slice_cap;
+        uint64_t bk = kEmpty, bv = 0;      // the lane's first event waits for the wavefront's one reservation
+        auto emit = [&](int strand, int32_t l0, int64_t j0, int32_t len) {
+            const uint64_t ek = ((((uint64_t)pair << lbits) | (uint64_t)l0) << 1) | (uint64_t)strand;
+            const uint64_t evv = ((uint64_t)j0 << 32) | (uint32_t)len;
+            if (bk == kEmpty) { bk = ek; bv = evv; }
+            else { const uint64_t at = atomic_add64(ev_count, 1); if (at < ev_cap) { key_out[at] = ek; val_out[at] = evv; } }
+        };
+        // a seed on the reverse strand: the sampled bases are the K-mer at jr = m - K - j of the mirrored piece, whose left arm
+        // runs where the forward strand's right arm would (inversions and spurious hits only: arms straight from memory)
+        auto reverse_seed = [&](int64_t j, int32_t l) {
+            const int64_t jr = m - K - j;
+            const int64_t qpr = rec.qbase_r + jr;
+            int32_t lim = (int32_t)(jr < l ? jr : l);
+            if (lim > stride) lim = stride;
+            const int32_t left = lce_bwd(P, qpr, rbase + l, lim);
+            if (left >= stride) return;
+            const int32_t rep_l0 = rep[ri.posbase + l - left];
+            const int32_t rr = ri.nR - l - K;
+            const int32_t maxr = (int32_t)(j < rr ? j : rr);               // m - jr - K = j bases follow the K-mer on the mirrored piece
+            const int32_t right = lce_fwd(P, qpr + K, rbase + l + K, maxr);
+            const int32_t len = left + K + right;
+            if (len >= ri.minlen && len > rep_l0) emit(1, l - left, jr - left, len);
+        };
+        // a seed on the forward strand with both arms from memory
+        auto forward_seed = [&](int64_t j, int32_t l) {
+            int32_t lim = (int32_t)(j < l ? j : l);
+            if (lim > stride) lim = stride;
+            const int32_t left = lce_bwd(P, qbase + j, rbase + l, lim);     // only `stride` bases matter: a longer left arm means an earlier sample owns the match
+            if (left >= stride) return;
+            const int32_t rep_l0 = rep[ri.posbase + l - left];
+            const int64_t mr = m - j - K; const int32_t rr = ri.nR - l - K;
+            const int32_t maxr = (int32_t)(mr < rr ? mr : rr);
+            const int32_t right = lce_fwd64(P, qbase + j + K, rbase + l + K, maxr);
+            const int32_t len = left + K + right;
+            if (len >= ri.minlen && len > rep_l0) emit(0, l - left, j - left, len);      // len <= rep': not unique in R
+        };
+        // every reference position of a slot's chain against one sample: the entries share the canonical K-mer, not the orientation
+        auto walk = [&](int64_t j, uint64_t tag, uint64_t gat, uint64_t slot, int32_t skip) {
+            const bool multi = (slot & kMulti) != 0;
+            for (int32_t l = slot_head(slot); l >= 0; l = multi ? next[ri.posbase + l] : -1) {
+                if (++work > budget) { atomic_or32(err, kErrWork); return; }
+                if (l == skip) continue;                    // (already handled from the registers)
+                const uint64_t rt = kmer_tag(P, rbase + l, K);
+                if (rt == tag) forward_seed(j, l);
+                if (rt == gat) reverse_seed(j, l);
+            }
+        };
+        // a sample without a usable prediction asks the index itself
+        auto probe_sample = [&](int64_t j, uint64_t tag, uint64_t gat) {
+            const uint64_t ctag = gat < tag ? gat : tag;
+            uint64_t slot = index_probe(ri, slots, filter, ctag);
+            if (slot == kEmpty) return;
+            const uint64_t rt = kmer_tag(P, rbase + slot_head(slot), K);
+            if (rt != tag && rt != gat) {                   // another K-mer with the same 32-bit fingerprint (2^-32): the confirmed lookup
+                slot = index_lookup(P, ri, slots, filter, ctag);
+                if (slot == kEmpty) return;
+            }
+            walk(j, tag, gat, slot, -1);
+        };
+
+        if (live) {
+            const int64_t j = (int64_t)it.sample * stride;
+            if (it.l >= 0) reverse_seed(j, it.l);
+            else {
+                const uint64_t tg = kmer_tag(P, qbase + j, K);
+                probe_sample(j, tg, rc_tag(tg, K));
+            }
+        }
+        const uint64_t at = wave_reserve01(ev_count, bk != kEmpty);
+        if (bk != kEmpty && at < ev_cap) { key_out[at] = bk; val_out[at] = bv; }
     }
 };
 
