@@ -363,41 +363,46 @@ public:
         size_t slice_cap = (std::min<size_t>(std::max<size_t>(ev_cap_hint, ev_guess), (size_t)1 << 31) + kSlices - 1) / kSlices + 64;
         std::vector<uint64_t> counts(ncounter);
         uint32_t errbits = 0;
-        // samples that SeedExtend hands to SeedRest: a queue sized from what earlier calls needed, repeated with the exact size
-        // if it overflows (the counter keeps counting past the capacity)
-        uint64_t* d_qcount = d_counter.p + (size_t)kSlices * kSliceStride + 1;
-        size_t queue_cap = std::max<size_t>(std::max<size_t>(rest_cap_hint, (size_t)nunits * kUnitSamples / 64), 1 << 16);
+        // samples that SeedExtend hands to SeedRest: kSlices sub-queues sized from what earlier calls needed (first guess: one
+        // sample in sixteen), repeated with the exact size if one overflows (the counters keep counting past the capacity)
+        ensure(d_qcount, (size_t)kSlices * kSliceStride);
+        size_t queue_cap = std::max<size_t>(std::max<size_t>(rest_cap_hint[nreg == 1], (size_t)nunits * kUnitSamples / 16 / kSlices), 64) + 64;      // (anchor-shaped and recursion-shaped calls alternate)
         uint64_t nrest = 0;
         uint32_t sticky = 0;
+        std::vector<uint64_t> qcounts((size_t)kSlices * kSliceStride);
         for (bool again = false;; again = true) {
-            ensure(d_evkey, slice_cap * kSlices); ensure(d_evval, slice_cap * kSlices); ensure(d_rest, queue_cap);
-            if (again) be.memset(d_counter.p, 0, 8 * ((size_t)kSlices * kSliceStride + 2));      // event counters, error word, queue counter
+            ensure(d_evkey, slice_cap * kSlices); ensure(d_evval, slice_cap * kSlices); ensure(d_rest, queue_cap * kSlices);
+            if (again) be.memset(d_counter.p, 0, 8 * ((size_t)kSlices * kSliceStride + 1));      // event counters and error word
+            be.memset(d_qcount.p, 0, 8 * (size_t)kSlices * kSliceStride);
             be.mark("seed_extend");
             be.launch("seed_extend", nunits * 64,
                       SeedExtend{P, d_R.p, d_units.p, d_slots.p, d_filter.p, d_next.p, d_rep.p, d_repeated.p,
-                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err, work_budget, d_rest.p, d_qcount, (uint64_t)queue_cap});
-            if (nunits > 0)      // one lane per queued sample; lanes past the count leave at once (the count stays on the device)
-                be.launch("seed_rest", (int64_t)queue_cap,
-                          SeedRest{P, d_R.p, d_units.p, d_rest.p, d_qcount, (uint64_t)queue_cap, d_slots.p, d_filter.p, d_next.p, d_rep.p,
+                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err, work_budget, d_rest.p, d_qcount.p, (uint64_t)queue_cap});
+            if (nunits > 0)      // one lane per queued sample; lanes past a sub-queue's count leave at once (the counts stay on the device)
+                be.launch("seed_rest", (int64_t)(queue_cap * kSlices),
+                          SeedRest{P, d_R.p, d_units.p, d_rest.p, d_qcount.p, (uint64_t)queue_cap, d_slots.p, d_filter.p, d_next.p, d_rep.p,
                                    d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err, work_budget});
             if (!no_small)
                 be.launch("small_pair_events", npairs * 2,
                           SmallPairEvents{P, d_R.p, d_starts.p, d_lens.p, ngen, d_rep.p, d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, g_first, g_last});
             be.mark("sort");
             be.launch_wave("slice_offsets", 1, SliceOffsets{d_counter.p, d_sliceoff.p});
-            be.d2h(counts.data(), d_counter.p, 8 * counts.size());            // round trip 1: event counts + error word + queue length
-            uint64_t worst = 0;
-            nev = 0;
-            for (int sl = 0; sl < kSlices; sl++) { const uint64_t c = counts[(size_t)sl * kSliceStride]; nev += c; worst = std::max(worst, c); }
+            be.d2h_async(qcounts.data(), d_qcount.p, 8 * qcounts.size());
+            be.d2h(counts.data(), d_counter.p, 8 * counts.size());            // round trip 1: event counts + error word (+ the queues' lengths)
+            uint64_t worst = 0, qworst = 0;
+            nev = 0; nrest = 0;
+            for (int sl = 0; sl < kSlices; sl++) {
+                const uint64_t c = counts[(size_t)sl * kSliceStride]; nev += c; worst = std::max(worst, c);
+                const uint64_t q = qcounts[(size_t)sl * kSliceStride]; nrest += q; qworst = std::max(qworst, q);
+            }
             errbits = (uint32_t)counts[(size_t)kSlices * kSliceStride];
-            nrest = counts[(size_t)kSlices * kSliceStride + 1];
-            if (worst <= slice_cap && nrest <= queue_cap) break;
+            if (worst <= slice_cap && qworst <= queue_cap) break;
             if (worst > slice_cap) slice_cap = (size_t)(worst + worst / 8 + 64);
-            if (nrest > queue_cap) queue_cap = (size_t)(nrest + nrest / 8 + 64);
+            if (qworst > queue_cap) queue_cap = (size_t)(qworst + qworst / 8 + 64);
             sticky |= errbits & kErrWork;      // (RepeatLength's verdict: the word is cleared with the counters)
         }
         errbits |= sticky;
-        rest_cap_hint = (size_t)(nrest + nrest / 4);
+        rest_cap_hint[nreg == 1] = queue_cap;
         last_rest = (int64_t)nrest;
         ev_cap_hint = (size_t)(nev + nev / 4);
         last_events = (int64_t)nev;
@@ -655,7 +660,7 @@ private:
     SeqBlock* blk = nullptr; int64_t* d_goff = nullptr; int64_t* d_glen = nullptr;
     int64_t total_words = 0;
     Packed P{};
-    size_t ev_cap_hint = 0, cand_cap_hint = 0, rest_cap_hint = 0;
+    size_t ev_cap_hint = 0, cand_cap_hint = 0, rest_cap_hint[2] = {0, 0};
     Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase;
     Buf<uint64_t> d_slots; Buf<uint32_t> d_filter, d_repeated; Buf<int32_t> d_next, d_rep, d_run, d_epm;
     Buf<int64_t> d_ucount, d_uoff; Buf<UnitRec> d_units;
@@ -666,7 +671,7 @@ private:
     Buf<int64_t> d_okcnt, d_okpos, d_cbase; Buf<int32_t> d_coarse; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;
     Buf<uint32_t> d_cflags, d_dirty; Buf<int32_t> d_bmax, d_bmin;
     Buf<GenomeAtK> d_xsend, d_xrecv; Buf<uint8_t> d_hsend, d_hrecv;
-    Buf<RestItem> d_rest;
+    Buf<RestItem> d_rest; Buf<uint64_t> d_qcount;
     Buf<int32_t> d_anchor_start, d_anchor_lon; Buf<GapRef> d_gaps; Buf<int64_t> d_exstarts, d_exlens;
     int64_t table_counter = 0;
 };

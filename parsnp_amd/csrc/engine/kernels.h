@@ -631,12 +631,11 @@ struct FillUnits {
 // walks and memory arms.  Those samples are now QUEUED (16 bytes each, one reservation per wavefront) and worked off by
 // SeedRest, one lane per queued sample in full wavefronts.
 struct RestItem { int32_t unit; int32_t sample; int32_t l; int32_t pad; };      // l >= 0: a reverse-strand seed confirmed at reference position l; l < 0: probe the index
-constexpr uint32_t kErrQueue = 4u;     // (error word) the queue of SeedRest overflowed: the launch is repeated with a larger one
 struct SeedExtend {
     Packed P; const RegionInfo* R; const UnitRec* units;
     const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep; const uint32_t* repeated;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
-    RestItem* queue; uint64_t* queue_count; uint64_t queue_cap;      // samples handed to SeedRest
+    RestItem* queue; uint64_t* queue_count; uint64_t queue_cap;      // samples handed to SeedRest: kSlices sub-queues of queue_cap items
     PM_HD void operator()(int64_t tid) const {
         int64_t unit = tid >> 6; int lane = (int)(tid & 63);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -854,12 +853,13 @@ struct SeedExtend {
             if (todo[u] & kRev) hand_over(s0 + u, l);
         }
         {
-            uint64_t qat = wave_reserve(queue_count, (uint32_t)nqueued);
+            // (a sub-queue per workgroup, as for the events: one counter for the launch's ~10^6 wavefronts is a 20 ms queue)
+            uint64_t qat = wave_reserve(queue_count + slice * kSliceStride, (uint32_t)nqueued);
+            RestItem* const sub = queue + slice * queue_cap;
 #pragma unroll
             for (int u = 0; u < kPer; u++)
                 if (u < nqueued) {
-                    if (qat < queue_cap) queue[qat] = RestItem{(int32_t)unit, qs[u], ql[u], 0};
-                    else atomic_or32(err, kErrQueue);
+                    if (qat < queue_cap) sub[qat] = RestItem{(int32_t)unit, qs[u], ql[u], 0};
                     qat++;
                 }
         }
@@ -872,12 +872,14 @@ struct SeedExtend {
 
 // tid = queued sample (kernels.h: RestItem).  Everything here comes straight from memory: the K-mer, the slot walk, both arms.
 struct SeedRest {
+    // the queue: kSlices sub-queues of queue_cap items, each with its own counter (one 64-byte line apart, like the event buffers)
     Packed P; const RegionInfo* R; const UnitRec* units; const RestItem* queue; const uint64_t* queue_count; uint64_t queue_cap;
     const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
     PM_HD void operator()(int64_t tid) const {
-        const uint64_t nq = *queue_count < queue_cap ? *queue_count : queue_cap;
-        const bool live = (uint64_t)tid < nq;
+        const uint64_t sub = (uint64_t)tid / queue_cap, idx = (uint64_t)tid % queue_cap;
+        const uint64_t have = queue_count[sub * kSliceStride];
+        const bool live = idx < (have < queue_cap ? have : queue_cap);
         const RestItem it = live ? queue[tid] : RestItem{0, 0, -1, 0};
         const UnitRec rec = units[it.unit];
         const int32_t pair = rec.pair;
