@@ -428,7 +428,7 @@ def main():
                         "limiter": "request rate of scattered 64-B reads (index slots, presence filter, sequence blocks at hashed positions: 54 G requests/s "
                                    "= 3.4 TB/s measured ceiling), then instruction issue under divergence; not byte bandwidth -- the index (67 MB), the filter "
                                    "(8 MB) and the reference (2.5 MB) sit in the 256 MB Infinity Cache",
-                        "kernel": "seed_extend (SeedExtend + SmallPairEvents)" if dom == "seed_extend" else dom,
+                        "kernel": "seed_extend (SeedExtend + SeedRest + SmallPairEvents)" if dom == "seed_extend" else dom,
                         "achieved": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 5),
                         "frac_basis": "algorithmic bytes of this engine per launch / HIP-event time of the launch",
                         "alg_model": "(m + n)/2 per (region, query genome) + 64 B per sampled K-mer (none for pairs that fit 128 bases) + 16 B per event",

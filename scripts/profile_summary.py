@@ -118,12 +118,12 @@ def main():
     json.dump(cal, open(os.path.join(summ, "calibration.json"), "w"), indent=1)
     # the event search of one engine call = SeedExtend (index-seeded samples) + SmallPairEvents (pairs that fit 128 bases,
     # compared in registers): bench.py times them together as the `seed_extend` phase, so they are summed here too
-    se, sp = per.get("SeedExtend"), per.get("SmallPairEvents")
+    se, sp, sr = per.get("SeedExtend"), per.get("SmallPairEvents"), per.get("SeedRest")
     if se and se["fetch_bytes"] is not None and se["write_bytes"] is not None:
         n = se["dispatches"]
-        fetch = se["fetch_bytes"] + (sp["fetch_bytes"] if sp and sp["fetch_bytes"] else 0)
-        write = se["write_bytes"] + (sp["write_bytes"] if sp and sp["write_bytes"] else 0)
-        st_se, st_sp = stats.get("SeedExtend", {}), stats.get("SmallPairEvents", {})
+        fetch = se["fetch_bytes"] + sum(x["fetch_bytes"] for x in (sp, sr) if x and x["fetch_bytes"])
+        write = se["write_bytes"] + sum(x["write_bytes"] for x in (sp, sr) if x and x["write_bytes"])
+        st_se, st_sp, st_sr = stats.get("SeedExtend", {}), stats.get("SmallPairEvents", {}), stats.get("SeedRest", {})
         calls = st_se.get("calls")
         # The counters sit on the fabric side of the L2 (TCC_EA0_RDREQ x 64 B): Infinity-Cache hits are INCLUDED, so this is
         # fabric traffic, an upper bound of the HBM bytes.  Calibration (calibration.json): scattered 8-16 B probes count 64 B per
@@ -138,16 +138,17 @@ def main():
         except Exception as e:   # noqa: BLE001
             print("no bench line for the stream correction:", e)
         corr = 0.5 * qstream if qstream else 0.0
-        t = {"kernel": "seed_extend = SeedExtend + SmallPairEvents", "workload": "bact200, the event search of every engine call of one bench step (anchor + recursion)",
+        t = {"kernel": "seed_extend = SeedExtend + SeedRest + SmallPairEvents", "workload": "bact200, the event search of every engine call of one bench step (anchor + recursion)",
              "dispatches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
              "raw": {"FETCH_SIZE": fetch / n, "WRITE_SIZE": write / n},
              "query_stream_bytes_per_launch": qstream,
              "hbm_bytes_per_launch": (fetch + write) / n + corr,
              "correction": "FETCH_SIZE + 0.5 x query-stream bytes (coalesced 16 B/lane streams are tallied at half, calibration.json calib_stream16) + WRITE_SIZE; scattered probes count 64 B per lane and are taken as they are",
              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this binary; fabric-side counters: Infinity-Cache hits included (upper bound of HBM bytes); coalesced query stream corrected x2",
-             "rocprof_avg_launch_ms": ((st_se.get("total_ms", 0) + st_sp.get("total_ms", 0)) / calls) if calls else None,
+             "rocprof_avg_launch_ms": ((st_se.get("total_ms", 0) + st_sp.get("total_ms", 0) + st_sr.get("total_ms", 0)) / calls) if calls else None,
              "rocprof_calls": calls,
-             "rocprof_seed_extend_avg_ms": st_se.get("avg_ms"), "rocprof_small_pair_events_avg_ms": st_sp.get("avg_ms"),
+             "rocprof_seed_extend_avg_ms": st_se.get("avg_ms"), "rocprof_seed_extend_max_ms": st_se.get("max_ms"), "rocprof_seed_rest_avg_ms": st_sr.get("avg_ms"), "rocprof_seed_rest_max_ms": st_sr.get("max_ms"),
+             "rocprof_small_pair_events_avg_ms": st_sp.get("avg_ms"),
              "so_sha256": lib_sha(), "engine_src_sha256": engine_src_sha()}
         json.dump(t, open(os.path.join(summ, "traffic_seed_extend.json"), "w"), indent=1)
     print(json.dumps({"stats": {k: v for k, v in stats.items() if v["total_ms"] > 1}, "calibration": cal, "seed_extend": per.get("SeedExtend"), "small_pair_events": per.get("SmallPairEvents")}, indent=1))
