@@ -212,7 +212,8 @@ def main():
     dist = None
     tdev = "cuda"
     sharded = args.mode == "sharded"
-    both = args.mode == "both" and world > 1
+    # (PARSNP_BENCH_CHILD_TEST=1: exercise the child-process plumbing of `both` with the one rank a single-GPU box allows)
+    both = args.mode == "both" and (world > 1 or os.environ.get("PARSNP_BENCH_CHILD_TEST") == "1")
     if world > 1:
         import torch.distributed as dist
         if torch.cuda.device_count() >= world and not sharded:
@@ -343,7 +344,8 @@ def main():
             # context and the engine's own RCCL, rendezvous one port up -- on rank 0's genome files; a failure or a hang of that
             # never-before-exercised path costs this key, not the line
             box = [os.path.join(workdir, "in") if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
+            if dist is not None:
+                dist.broadcast_object_list(box, src=0)
             if torch.cuda.device_count() >= world:
                 env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23), PARSNP_RCCL_TIMEOUT="120")
                 cmd = [sys.executable, os.path.abspath(__file__), "--mode", "sharded", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
@@ -363,7 +365,8 @@ def main():
                     sharded_strong = {"error": "the sharded child did not finish within 900 s"}
             else:
                 sharded_strong = {"skipped": "needs one GPU per rank (%d ranks, %d GPUs visible)" % (world, torch.cuda.device_count())}
-            dist.barrier()
+            if dist is not None:
+                dist.barrier()
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -316,6 +316,23 @@ def test_bench_sharded_mode_one_rank(libs):
     assert d["mums"] > 2000 and "exchange_ep" in d["engine_ms"] and "exchange_states" in d["engine_ms"]
 
 
+def test_bench_both_scalings_child_process(libs):
+    """bench.py's default mode for N > 1 reports the sharded (strong-scaling) measurement of the same workload beside the
+    partition-per-GPU headline, measured by a child process per rank on rank 0's genome files.  With one GPU the plumbing is
+    exercised with one rank (PARSNP_BENCH_CHILD_TEST): the child's line comes back under `sharded_strong`, RCCL counts 1 rank"""
+    import subprocess, sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "pop6x200k", "--cpu-sample", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, PARSNP_BENCH_CHILD_TEST="1"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "weak" and d["n_gpus"] == 1 and d["n_ranks_seen_by_rccl"] == 1 and len(d["per_rank"]) == 1
+    ss = d["sharded_strong"]
+    assert ss and "error" not in ss and "skipped" not in ss, ss
+    assert ss["scaling"] == "strong" and ss["n_ranks_seen_by_rccl"] == 1 and ss["mums"] == d["mums"] and ss["lcbs"] == d["lcbs"]
+    assert "exchange_ep" in ss["engine_ms"] and "sharded" in ss["config"]
+
+
 @pytest.mark.parametrize("name,world", [("poprearr10x400k", 2), ("bact8", 4)])
 def test_sharded_run_on_gpu(libs, tmp_path, name, world):
     """SURVEY 8e-2 with the HIP engine: `world` ranks, each with its block of the query genomes resident (on this 1-GPU
@@ -401,3 +418,23 @@ def test_sharded_run_rccl_two_gpus(libs, tmp_path):
 
 def test_work_budget_retry(libs, monkeypatch):
     T.test_work_budget_retry(libs, monkeypatch)
+
+
+def test_bench_two_gpus_both_scalings(libs):
+    """two ranks, one GPU each: bench.py's one line carries the partition-per-GPU (weak) figure with torch's RCCL seeing both
+    ranks AND the sharded (strong) figure of the same workload measured over the engine's own RCCL communicator by the child
+    processes; runs wherever two GPUs are visible (the build pool hands out single-GPU boxes)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the build pool hands out single-GPU boxes; the driver's 8-GPU node runs it)")
+    import subprocess, sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "pop20x1m", "--cpu-sample", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["n_ranks_seen_by_rccl"] == 2 and len(d["per_rank"]) == 2
+    ss = d["sharded_strong"]
+    assert ss and "error" not in ss and "skipped" not in ss, ss
+    assert ss["scaling"] == "strong" and ss["n_gpus"] == 2 and ss["n_ranks_seen_by_rccl"] == 2
