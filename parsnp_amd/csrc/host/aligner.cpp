@@ -151,7 +151,7 @@ void Aligner::mark_stripe(size_t j0, size_t j1) {
         __builtin_prefetch(srow + (c + 24) * n + j0); __builtin_prefetch(srow + (c + 24) * n + j1 - 1);
         if ((deferred_.state[c] & 24) != 16) continue;
         const int32_t* st = srow + c * n; const long lon = deferred_.length[c];
-        for (size_t j = j0; j < j1; j++) layout[j].set_range_inside_atomic(st[j], st[j] + lon);
+        for (size_t j = j0; j < j1; j++) layout[j].set_range_inside(st[j], st[j] + lon);
     }
 }
 void Aligner::start_deferred_marks() {
@@ -381,20 +381,15 @@ void Aligner::start_speculation(int64_t table) {
         for (size_t i = 1; i < tab.size(); i++) tab[i] = (int32_t)min_length(false, (long)i);
         tab[0] = tab[1];      // (a region of length 0 is never kept: q >= 0)
     }
-    const double t_asked = now_s();
-    spec_ = std::async(std::launch::async, [this, table, &tab, t_asked]() -> pm_result* {
+    spec_ = std::async(std::launch::async, [this, table, &tab]() -> pm_result* {
         pm_result* res = nullptr;
-        const double t0 = now_s();
         const int rc = pm_multi_mum_batch_spec(session_, table, (int32_t)prm.q, (int64_t)prm.p, tab.data(), (int64_t)tab.size(), &res);
-        if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[speculation] helper thread started %.4f s after it was asked for, engine call %.4f s\n", t0 - t_asked, now_s() - t0);
         return rc == PM_OK ? res : nullptr;      // (a refusal only means that nothing was computed ahead)
     });
 }
 void Aligner::take_speculation() {
     if (!spec_.valid()) return;
-    const double tw = now_s();
     pm_result* res = spec_.get();
-    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[speculation] waited %.4f s for the batch computed ahead\n", now_s() - tw);
     if (!res) return;
     const size_t nreg = (size_t)pm_result_regions(res);
     const pm_gap_ref* refs = pm_result_spec_refs(res);
@@ -841,9 +836,6 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             else for (size_t c = 0; c < ncand; c++) deferred_.length[c] = (int32_t)cand[c].length;
             deferred_.state = state;
             deferred_.pending = true;
-            // ... and they start now (atomic word updates: the flagged candidates below mark bits of the same bitmaps); they
-            // fill the cores that the rest of the validation, the seed regions and the first generation leave idle
-            start_deferred_marks();
         }
     }
     disorder = 0;      // (put off: none; else the marking pass below finds it out itself)
@@ -935,7 +927,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             if (m.length > 0)
                 for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end(j) - 1);
             const bool acc = settle(m, touches, (state[c] & 4) != 0);
-            if (acc) for (size_t j = 0; j < n; j++) layout[j].set_range_atomic(m.start[j], m.end(j));      // (the put-off marks may be at work on these words)
+            if (acc) for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end(j));
             settled[o] = acc ? 1 : 0;
             stats.parallel_tangled++;
         }
@@ -1458,9 +1450,7 @@ bool Aligner::extend_generations() {
         }
         return true;
     };
-    // one engine call for the regions without a result (first_only: only rs[0] is needed now -- the first seed, which the
-    // reference processes before it sorts its list; what the engine has not computed ahead joins the next generation's call)
-    auto fetch = [&](const std::vector<Region>& rs, std::vector<int>* raw_of, bool first_only = false) {
+    auto fetch = [&](const std::vector<Region>& rs, std::vector<int>* raw_of) {      // one engine call for the regions without a result
         std::vector<Request> want, all; std::vector<size_t> who;
         if (!plain_requests(rs, raw_of, &all)) return false;
         take_speculation();      // what the engine computed ahead, beside the validation of the anchors
@@ -1474,7 +1464,6 @@ bool Aligner::extend_generations() {
                     continue;
                 }
             }
-            if (first_only && i > 0 && !spec_key_.empty()) continue;
             want.push_back(all[i]); who.push_back(i);
         }
         if (want.empty()) return true;
@@ -1507,8 +1496,8 @@ bool Aligner::extend_generations() {
         std::vector<size_t> first;               // clusters of `now`
         bool trouble = false;
         if (gi == 0) {                           // the first pushed seed, before anything is sorted
-            start_deferred_marks();              // (the anchors' put-off marks, if validate_parallel has not started them)
-            trouble = !fetch(gen, &gen_raw, true);     // every seed's engine result: computed ahead, or in ONE call
+            start_deferred_marks();              // the anchors' put-off marks: set while this thread waits for the device
+            trouble = !fetch(gen, &gen_raw);     // ... but every seed's engine result in ONE call
             finish_prejudge();                   // (the anchors' chaining verdicts were worked out beside that call)
             seeds_raw = gen_raw;
             now.push_back(gen.front()); now_raw.push_back(gen_raw.front());

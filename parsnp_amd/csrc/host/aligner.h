@@ -95,16 +95,6 @@ public:
         for (size_t i = wa + 1; i < wb; i++) w[i] = ~0ull;
         w[wb] |= last;
     }
-    // the same while other threads mark other ranges of this bitmap (atomic OR on the two words a neighbour may share)
-    void set_range_inside_atomic(long a, long b) {
-        uint64_t* w = w_.data();
-        const size_t wa = (size_t)a >> 6, wb = (size_t)(b - 1) >> 6;
-        const uint64_t first = ~0ull << (a & 63), last = ~0ull >> (63 - ((b - 1) & 63));
-        if (wa == wb) { __atomic_fetch_or(&w[wa], first & last, __ATOMIC_RELAXED); return; }
-        __atomic_fetch_or(&w[wa], first, __ATOMIC_RELAXED);
-        for (size_t i = wa + 1; i < wb; i++) __atomic_store_n(&w[i], ~0ull, __ATOMIC_RELAXED);
-        __atomic_fetch_or(&w[wb], last, __ATOMIC_RELAXED);
-    }
     void set_range_atomic(long a, long b);   // [a,b) := 1 with atomic word updates: threads marking neighbouring ranges may share a word
     void clear_range(long a, long b);   // [a,b) := 0
     long next_set(long from) const;     // smallest i >= from with bit set; the sentinel guarantees one for from <= n
