@@ -78,8 +78,6 @@ struct Rccl {
 
 struct HipBackend {
     hipStream_t stream = nullptr;
-    int device = 0;                     // the GPU of this session: a per-thread setting of the runtime, see bind_thread()
-    void bind_thread() { (void)hipSetDevice(device); }
     ncclComm_t comm = nullptr;          // device collectives of a sharded session (pm_session_create_rccl)
     std::string err;
     void* tmp = nullptr;
@@ -309,7 +307,6 @@ static PmBackend* pm_backend_open(int device, std::string* err) {
         if (device >= count || hipSetDevice(device) != hipSuccess) { *err = "cannot select the requested HIP device"; return nullptr; }
     }
     HipBackend* b = new HipBackend;
-    (void)hipGetDevice(&b->device);
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; delete b; return nullptr; }
     return b;
 }

@@ -21,7 +21,6 @@ struct HostBackend {
     void d2h_async(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void d2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void sync() {}
-    void bind_thread() {}
     void* event_record() { return nullptr; }
     static void event_wait(void*) {}
     void event_release(void*) {}
