@@ -140,6 +140,20 @@ typedef struct { int32_t prev, next, side, explicit_row; } pm_gap_ref;
 int pm_multi_mum_batch_gaps(pm_session* s, int64_t table_id, int64_t n_regions, const pm_gap_ref* gaps, const int64_t* ref_start, const int64_t* ref_len,
                             const int32_t* minsize, int64_t n_explicit, const int64_t* ex_starts, const int64_t* ex_lens, pm_result** out);
 int64_t pm_result_table_id(const pm_result* r);
+/* The layout after the anchor call.  The reference keeps one bit per base of every genome, set under every accepted MUM
+ * (mumlayout, src/parsnp.cpp:3181-3186; marked :1836-1839; read by trim :1399-1477, determineRegion :1199-1290,
+ * filterRandom1 :327-425, setInterClusterRegions :2389-2460).  The rows of the anchors are still resident (the anchor table),
+ * so the bitmaps are built on the device and arrive as ONE block: genome j has nbits[j] bits (the caller's choice: its length
+ * + 1, the last bit being the sentinel a scan to the right stops at -- set by this call) in 64-bit words
+ * [off[j], off[j+1]), off[0] = 0, off[j+1] = off[j] + (nbits[j] + 63) / 64 + 1; bit i = bit (i & 63) of word i >> 6.
+ *   accept[c] != 0   row c of the table is marked as it stands: [start, start + length) in every genome
+ *   extra_start [n_extra][n_genomes], extra_len [n_extra]: rows marked besides (the ones the caller trimmed)
+ * *image: page-locked memory of the session, written by a copy that runs beside the calls made next; pm_layout_wait()
+ * returns when it is complete.  The caller may then write to it; the next pm_layout_image of the session rewrites it, and
+ * pm_session_destroy releases it.  PM_EINVAL when table_id is not the resident table or n_rows not its length. */
+int pm_layout_image(pm_session* s, int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t n_rows,
+                    const int32_t* extra_start, const int32_t* extra_len, int64_t n_extra, uint64_t** image);
+int pm_layout_wait(pm_session* s);
 /* Tunables of a session (tests lower the thresholds of the long-list routes so that small inputs take them):
  *   "work_budget"  per-thread step budget of the index walks (default 2^22; a batch that exhausts it is repeated once with
  *                  256 times as much, then PM_ELIMIT)

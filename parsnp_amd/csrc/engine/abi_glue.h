@@ -136,6 +136,22 @@ const int32_t* pm_result_lon(const pm_result* r) { return r->r.lon(); }
 const int32_t* pm_result_sp(const pm_result* r) { return r->r.sp(); }
 const uint8_t* pm_result_fwd(const pm_result* r) { return r->r.fwd(); }
 void pm_result_free(pm_result* r) { delete r; }
+int pm_layout_image(pm_session* s, int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t n_rows,
+                    const int32_t* extra_start, const int32_t* extra_len, int64_t n_extra, uint64_t** image) {
+    if (!s || !nbits || !accept || !image || n_rows < 0 || n_extra < 0) return fail(PM_EINVAL, "bad argument");
+    try {
+        int rc = s->engine->layout_image(table_id, nbits, accept, n_rows, extra_start, extra_len, n_extra, image);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        return PM_OK;
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
+}
+int pm_layout_wait(pm_session* s) {
+    if (!s) return fail(PM_EINVAL, "bad argument");
+    s->engine->layout_wait();
+    return s->backend->ok() ? PM_OK : fail(PM_EHIP, s->backend->error());
+}
 int pm_session_tune(pm_session* s, const char* key, int64_t value) {
     if (!s || !key) return fail(PM_EINVAL, "bad argument");
     return s->engine->tune(key, value) ? PM_OK : fail(PM_EINVAL, std::string("unknown tunable or bad value: ") + key);

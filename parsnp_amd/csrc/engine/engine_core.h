@@ -602,6 +602,57 @@ public:
         return 0;
     }
 
+    // ---- the layout after the anchor call, built from the resident anchor table (kernels.h: LayoutMark; pm_layout_image)
+    // accept[c] != 0: row c of the table is marked as it stands; rows the host changed (trimmed) come as extra rows.  The
+    // image is copied to a page-locked block of the session on a second stream, beside whatever is queued next; the caller
+    // reads it after layout_wait().  The block is rewritten by the next call: the previous copy is awaited first.
+    int layout_image(int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t nrows, const int32_t* xstart, const int32_t* xlon, int64_t nx,
+                     uint64_t** image) {
+        if (table_id == 0 || table_id != anchor_table_id) { error = "the anchor table of this layout is no longer resident"; return -2; }
+        if (nrows != anchor_table_rows || !nbits || !accept || nx < 0 || (nx > 0 && (!xstart || !xlon))) { error = "bad layout request"; return -2; }
+        const size_t ngz = (size_t)ngen, nxz = (size_t)nx, nrz = (size_t)nrows;
+        std::vector<int64_t> off(ngz + 1, 0);
+        for (size_t j = 0; j < ngz; j++) {
+            if (nbits[j] < 0 || nbits[j] > glen_h[j] + 64) { error = "layout size does not fit its genome"; return -2; }
+            off[j + 1] = off[j] + (nbits[j] + 63) / 64 + 1;
+        }
+        const size_t words = (size_t)off[ngz];
+        be.side_wait();
+        if (words > image_words) {
+            if (image_h) be.pinned_free(image_h);
+            image_h = (uint64_t*)be.pinned_alloc(8 * words);
+            image_words = image_h ? words : 0;
+            if (!image_h) { error = "cannot allocate the page-locked layout block"; return -3; }
+        }
+        // parameters: [ word_off | nbits | extra lengths | extra rows | accept ] in a page-locked block of their own (the
+        // request block of run() is rewritten by the next call, which may be queued before these copies have run)
+        const size_t bytes = 8 * (ngz + 1) + 8 * ngz + 4 * nxz + 4 * nxz * ngz + nrz + 64;
+        if (bytes > image_stage_cap) {
+            if (image_stage) be.pinned_free(image_stage);
+            image_stage = (uint8_t*)be.pinned_alloc(bytes + bytes / 4);
+            image_stage_cap = image_stage ? bytes + bytes / 4 : 0;
+            if (!image_stage) { error = "cannot allocate the layout staging block"; return -3; }
+        }
+        int64_t* s_off = (int64_t*)image_stage; int64_t* s_bits = s_off + ngz + 1;
+        int32_t* s_xlon = (int32_t*)(s_bits + ngz); int32_t* s_xstart = s_xlon + nxz; uint8_t* s_acc = (uint8_t*)(s_xstart + nxz * ngz);
+        memcpy(s_off, off.data(), 8 * (ngz + 1)); memcpy(s_bits, nbits, 8 * ngz);
+        if (nxz) { memcpy(s_xlon, xlon, 4 * nxz); memcpy(s_xstart, xstart, 4 * nxz * ngz); }
+        memcpy(s_acc, accept, nrz);
+        ensure(d_image, words); ensure(d_imgoff, ngz + 1); ensure(d_imgbits, ngz); ensure(d_accept, std::max<size_t>(nrz, 1));
+        ensure(d_xstart, std::max<size_t>(nxz * ngz, 1)); ensure(d_xlon, std::max<size_t>(nxz, 1));
+        be.h2d_staged(d_imgoff.p, s_off, 8 * (ngz + 1)); be.h2d_staged(d_imgbits.p, s_bits, 8 * ngz);
+        be.h2d_staged(d_accept.p, s_acc, nrz);
+        if (nxz) { be.h2d_staged(d_xlon.p, s_xlon, 4 * nxz); be.h2d_staged(d_xstart.p, s_xstart, 4 * nxz * ngz); }
+        be.memset(d_image.p, 0, 8 * words);
+        be.launch("layout_sentinel", (int64_t)ngen, LayoutSentinel{d_imgoff.p, d_imgbits.p, d_image.p});
+        be.launch("layout_mark", nrows * ngen, LayoutMark{d_anchor_start.p, d_anchor_lon.p, d_accept.p, ngen, d_imgoff.p, d_imgbits.p, d_image.p});
+        be.launch("layout_mark", nx * ngen, LayoutMark{d_xstart.p, d_xlon.p, nullptr, ngen, d_imgoff.p, d_imgbits.p, d_image.p});
+        be.d2h_side(image_h, d_image.p, 8 * words);
+        *image = image_h;
+        return 0;
+    }
+    void layout_wait() { be.side_wait(); }
+
     // small host-side all-gather (calcmumi's per-genome results): through device staging when the collectives are RCCL
     int allgather_host(const void* send, int64_t bytes, void* recv) {
         if (!coll.device) return coll.allgather(coll.ctx, send, bytes, recv);
@@ -628,6 +679,10 @@ public:
 
     void release() {
         for (BufBase* b : all_bufs) { if (b->raw) be.free(b->raw); b->raw = nullptr; b->cap = 0; }
+        be.side_wait();
+        if (image_h) be.pinned_free(image_h);
+        if (image_stage) be.pinned_free(image_stage);
+        image_h = nullptr; image_stage = nullptr; image_words = 0; image_stage_cap = 0;
         if (blk) be.free(blk);
         if (d_goff) be.free(d_goff);
         if (d_glen) be.free(d_glen);
@@ -674,6 +729,9 @@ private:
     Buf<RestItem> d_rest; Buf<uint64_t> d_qcount;
     Buf<int32_t> d_anchor_start, d_anchor_lon; Buf<GapRef> d_gaps; Buf<int64_t> d_exstarts, d_exlens;
     int64_t table_counter = 0;
+    Buf<uint64_t> d_image; Buf<int64_t> d_imgoff, d_imgbits; Buf<uint8_t> d_accept; Buf<int32_t> d_xstart, d_xlon;
+    uint64_t* image_h = nullptr; size_t image_words = 0;      // page-locked: the layout image as the host reads it
+    uint8_t* image_stage = nullptr; size_t image_stage_cap = 0;
 };
 
 }  // namespace pm

@@ -132,6 +132,13 @@ PM_HD void atomic_or32(uint32_t* p, uint32_t v) {
     *p |= v;
 #endif
 }
+PM_HD void atomic_or64(uint64_t* p, uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicOr((unsigned long long*)p, (unsigned long long)v);
+#else
+    *p |= v;
+#endif
+}
 
 // ------------------------------------------------------------------------------------------ wavefront steps
 // The kernels below are launched one WAVEFRONT per work item (64-thread workgroups, `wave(w)` instead of
@@ -589,6 +596,40 @@ struct ExpandGaps {
             a = nxt; b = p - 1;
         }
         starts[tid] = a; lens[tid] = b - a;
+    }
+};
+
+// ------------------------------------------------------------------------------------------ layout image
+// The reference keeps one bit per base of every genome, set under every accepted MUM (mumlayout, src/parsnp.cpp:3181-3186;
+// marked :1836-1839).  After the anchor call that is 12 million ranges at 200 x 5 Mb -- rows the device still holds as the
+// anchor table.  The bitmaps are built here (zeroed, the rows' ranges set with atomic ORs, one sentinel bit past the end of
+// every genome) and sent to the host as one block, instead of being cleared and marked range by range by the host's cores.
+// Words are 64 bits, bit i of a genome = bit (i & 63) of its word i >> 6; genome j occupies words [word_off[j], word_off[j+1]).
+// tid = (row, genome); accept == nullptr: every row
+struct LayoutMark {
+    const int32_t* start; const int32_t* lon; const uint8_t* accept; int32_t ngen; const int64_t* word_off; const int64_t* nbits; uint64_t* image;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = tid / ngen; const int j = (int)(tid % ngen);
+        if (accept && !accept[c]) return;
+        int64_t a = start[tid], b = a + lon[c];
+        if (a < 0) a = 0;
+        if (b > nbits[j]) b = nbits[j];
+        uint64_t* w = image + word_off[j];
+        while (a < b) {
+            const int lo = (int)(a & 63);
+            const int64_t span = (64 - lo) < (b - a) ? (64 - lo) : (b - a);
+            const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
+            atomic_or64(&w[a >> 6], mask);
+            a += span;
+        }
+    }
+};
+// tid = genome: the bit past the last base (what a scan to the right stops at)
+struct LayoutSentinel {
+    const int64_t* word_off; const int64_t* nbits; uint64_t* image;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t nb = nbits[tid];
+        if (nb > 0) atomic_or64(&image[word_off[tid] + ((nb - 1) >> 6)], 1ull << ((nb - 1) & 63));
     }
 };
 

@@ -38,8 +38,8 @@ inline bool operator<(const Handle& a, const Handle& b) { return a.key < b.key; 
 void Bitmap::init(size_t nbits) {
     nbits_ = nbits;
     const size_t words = (nbits + 63) / 64 + 1;
-    if (w_.size() == words) std::fill(w_.begin(), w_.end(), 0);   // a recycled bitmap keeps its pages
-    else { decltype(w_)().swap(w_); w_.resize(words); }          // fresh zero pages, untouched until used
+    if (words_ == words) std::fill(w_, w_ + words_, 0);           // a recycled bitmap keeps its pages (attached words: cleared in place)
+    else fresh(words);                                            // fresh zero pages, untouched until used
     logging_ = false; log_.clear();
     if (nbits) w_[(nbits - 1) >> 6] |= 1ull << ((nbits - 1) & 63);
 }
@@ -64,6 +64,18 @@ void Bitmap::set_range_atomic(long a, long b) {
         const long span = std::min<long>(64 - lo, b - a);
         const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
         __atomic_fetch_or(&w_[wi], mask, __ATOMIC_RELAXED);
+        a += span;
+    }
+}
+void Bitmap::clear_range_atomic(long a, long b) {
+    if (a < 0) a = 0;
+    if (b > (long)nbits_) b = (long)nbits_;
+    while (a < b) {
+        const size_t wi = (size_t)a >> 6;
+        const int lo = (int)(a & 63);
+        const long span = std::min<long>(64 - lo, b - a);
+        const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
+        __atomic_fetch_and(&w_[wi], ~mask, __ATOMIC_RELAXED);
         a += span;
     }
 }
@@ -135,6 +147,16 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
     // the layout (validate, or the end of find_anchors) awaits it.
     // (a few threads, not one: one core clears ~10 GB/s and would still be at it when the 11 ms anchor call returns;
     // not all: pages first touched by the worker threads can end up away from the thread that does most of the walking)
+    // ... unless the previous run left the other set of bitmaps all zero (it went on with the engine's layout image)
+    if (memory_->spare_zero && memory_->spare.size() == n) {
+        bool fits = true;
+        for (size_t i = 0; i < n && fits; i++) fits = memory_->spare[i].bits() == genomes[i].seq.size() + 1;
+        memory_->spare_zero = false;
+        if (fits && test_hook("PARSNP_CHECK_ZERO"))      // test hook: the set the previous run handed back holds the sentinels and nothing else
+            for (size_t i = 0; i < n; i++)
+                if (memory_->spare[i].count_set() != 1 || !memory_->spare[i].get((long)genomes[i].seq.size())) fatal("the spare layout is not empty");
+        if (fits) { std::swap(memory_->layout, memory_->spare); return; }
+    }
     const size_t parts = std::min<size_t>(4, std::max<size_t>(1, n / 8));
     for (size_t k = 0; k < parts; k++)
         layout_ready_.push_back(std::async(std::launch::async, [this, k, parts] {
@@ -170,11 +192,19 @@ void Aligner::start_deferred_marks() {
 }
 void Aligner::wait_layout() {
     start_deferred_marks();
-    if (layout_ready_.empty()) return;
+    if (layout_ready_.empty()) { await_image(); return; }
     const double t = now_s();
     for (auto& f : layout_ready_) f.get();
     layout_ready_.clear();
     if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[setup] waited %.4f s for the layout to be cleared\n", now_s() - t);
+    await_image();
+}
+void Aligner::await_image() {
+    if (!image_pending_) return;
+    image_pending_ = false;
+    const double t = now_s();
+    if (pm_layout_wait(session_) != PM_OK) fatal(std::string("the layout image did not arrive: ") + pm_last_error());
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[setup] waited %.4f s for the layout image\n", now_s() - t);
 }
 
 Aligner::~Aligner() {
@@ -400,6 +430,9 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     stats.alg_bytes_kernel += algk;
     stats.alg_bytes_query += algq;
     stats.t_pack += now_s() - t0;
+    const bool dbg_b = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    if (dbg_b) fprintf(stderr, "[run_batch] %zu requests packed %.4f s\n", reqs.size(), now_s() - t0);
+    const double tcall = now_s();
     pm_result* res = nullptr;
     int rc;
     if (use_gaps) {
@@ -417,6 +450,7 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
         exit(5);
     }
     if (rc != PM_OK) fatal(std::string("multi-MUM engine failed: ") + pm_last_error());
+    if (dbg_b) fprintf(stderr, "[run_batch] engine call %.4f s\n", now_s() - tcall);
     std::shared_ptr<pm_result> own(res, pm_result_free);
     const int64_t* off = pm_result_offsets(res);
     const int32_t* k = pm_result_k(res);
@@ -592,7 +626,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     const size_t ncand = raw.count;
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double tp = now_s();
-    auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[validate_parallel] %-10s %.4f s\n", what, t - tp); tp = t; } };
+    auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[validate_parallel] %-10s %.4f s (cpu %.4f)\n", what, t - tp, cpu_lap_s()); tp = t; } };
     // rows: built on the device where the engine delivers them (the candidates' rows ARE the result blocks then: nothing
     // is copied, trim() works on them in place and the result is kept alive), else from (sp, fwd) here
     const bool device_rows = raw.start != nullptr;
@@ -606,6 +640,14 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     static const bool force_exact = test_hook("PARSNP_EXACT_OVERLAP") != nullptr;   // test hook: always the bitmap test
     static const bool host_overlap = test_hook("PARSNP_HOST_OVERLAP") != nullptr;   // test hook: the cheap test on the host although the device ran it
     const bool device_dirty = device_rows && raw.dirty_known && layout_empty && !host_overlap;
+    // Where the engine keeps this list's rows resident it can deliver the layout they leave as an image (pm_layout_image, at
+    // the end of this function): the bitmaps this call works on then only ever hold the marks the flagged candidates need,
+    // which are noted and taken back.  PARSNP_HOST_MARKS=1 (test hook): the host's cores mark, as without an anchor table.
+    static const bool host_marks = test_hook("PARSNP_HOST_MARKS") != nullptr;
+    const int64_t image_table = (device_rows && layout_empty && session_ && raw.row0 == 0 && !host_marks) ? pm_result_table_id(raw.owner.get()) : 0;
+    struct Span { int32_t j, a, len; };
+    std::vector<std::vector<Span>> marked_now(image_table ? (size_t)threads : 0);
+    for (auto& v : marked_now) v.reserve(ncand / 16 + 4096);
 #pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
     for (long c = 0; c < nc; c++) {
         Mum& m = cand[(size_t)c];
@@ -779,6 +821,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
                         const long a = srow[(size_t)c * n + j];
                         if (a >= e) break;
                         layout[j].set_range_atomic(a, a + cand[c].length);
+                        if (image_table) marked_now[(size_t)omp_get_thread_num()].push_back(Span{(int32_t)j, (int32_t)a, (int32_t)cand[c].length});
                     }
                 }
             }
@@ -949,6 +992,53 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     } else anchors_ordered_ = false;
     if (dbg && put_off) fprintf(stderr, "[validate_parallel] marks of the clean candidates put off\n");
     lap("sequential");
+    // The put-off marks, and everything else of the layout this list leaves: as an image from the device.  The accepted clean
+    // candidates are rows of its anchor table; the accepted flagged ones travel with the coordinates trim() left them.  The
+    // run goes on with bitmaps attached to the image (every reader awaits it: wait_layout); the set used so far gets its few
+    // marks taken back in the background and waits, all zero, for the next run.
+    if (put_off && image_table) {
+        std::vector<uint8_t> acc(ncand);
+        for (size_t c = 0; c < ncand; c++) acc[c] = (state[c] & 24) == 16;
+        auto extra_start = std::make_shared<std::vector<int32_t>>();
+        auto extra_len = std::make_shared<std::vector<int32_t>>();
+        for (size_t c = 0; c < ncand; c++)
+            if ((state[c] & 8) && place[c] != kNoPlace) {
+                extra_len->push_back((int32_t)cand[c].length);
+                extra_start->insert(extra_start->end(), cand[c].start, cand[c].start + n);
+            }
+        std::vector<int64_t> nbits(n);
+        for (size_t j = 0; j < n; j++) nbits[j] = (int64_t)gsize_[j] + 1;
+        uint64_t* image = nullptr;
+        const int rc = pm_layout_image(session_, image_table, nbits.data(), acc.data(), (int64_t)ncand, extra_start->data(), extra_len->data(),
+                                       (int64_t)extra_len->size(), &image);
+        if (rc == PM_OK) {
+            std::vector<Bitmap>& other = memory_->spare;
+            other.resize(n);
+            size_t off = 0;
+            for (size_t j = 0; j < n; j++) {
+                const size_t words = ((size_t)nbits[j] + 63) / 64 + 1;
+                other[j].attach(image + off, words, (size_t)nbits[j]);
+                off += words;
+            }
+            std::swap(memory_->layout, memory_->spare);       // `layout` is the image from here on
+            deferred_.pending = false;
+            image_pending_ = true;
+            memory_->spare_zero = true;                       // (once the tasks below are through: the next run starts after wait_layout)
+            auto logs = std::make_shared<std::vector<std::vector<Span>>>(std::move(marked_now));
+            std::vector<Bitmap>* zero = &memory_->spare;
+            const size_t nn = n, tasks = 4;
+            for (size_t t = 0; t < tasks; t++)
+                layout_ready_.push_back(std::async(std::launch::async, [zero, logs, extra_start, extra_len, nn, t, tasks] {
+                    for (size_t k = t; k < logs->size(); k += tasks)
+                        for (const Span& sp : (*logs)[k]) (*zero)[(size_t)sp.j].clear_range_atomic(sp.a, (long)sp.a + sp.len);
+                    const size_t nx = extra_len->size();
+                    for (size_t k = nx * t / tasks; k < nx * (t + 1) / tasks; k++)
+                        for (size_t j = 0; j < nn; j++) (*zero)[j].clear_range_atomic((*extra_start)[k * nn + j], (long)(*extra_start)[k * nn + j] + (*extra_len)[k]);
+                }));
+            stats.layout_images++;
+        } else if (dbg) fprintf(stderr, "[validate_parallel] no layout image (%s): the host marks\n", pm_last_error());
+        lap("image");
+    }
 }
 
 // Overlap trimming against already marked bases: from the left, then from the right, genome by genome; every trim
@@ -977,7 +1067,7 @@ bool Aligner::find_anchors() {
     std::cerr << "        Performing initial search for exact matches in the sequences...\n";
     const bool dbg_a = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double ta = now_s();
-    auto lap_a = [&](const char* what) { if (dbg_a) { const double t = now_s(); fprintf(stderr, "[anchors] %-18s %.4f s\n", what, t - ta); ta = t; } };
+    auto lap_a = [&](const char* what) { if (dbg_a) { const double t = now_s(); fprintf(stderr, "[anchors] %-18s %.4f s (cpu %.4f)\n", what, t - ta, cpu_lap_s()); ta = t; } };
     lap_a("set-up");
     region_mums(whole, true, &found, false);
     lap_a("search + validation");
@@ -1404,15 +1494,19 @@ bool Aligner::extend_generations() {
     };
     auto fetch = [&](const std::vector<Region>& rs, std::vector<int>* raw_of) {      // one engine call for the regions without a result
         std::vector<Request> want, all; std::vector<size_t> who;
+        const double tf = now_s();
         if (!plain_requests(rs, raw_of, &all)) return false;
         for (size_t i = 0; i < rs.size(); i++) {
             if ((*raw_of)[i] >= 0) continue;
             want.push_back(all[i]); who.push_back(i);
         }
         if (want.empty()) return true;
+        const double tr = now_s();
         std::vector<Raw> got;
         run_batch(want, &got, true);
+        const double tb = now_s();
         for (size_t k = 0; k < who.size(); k++) { (*raw_of)[who[k]] = (int)raws.size(); raws.push_back(std::move(got[k])); }
+        if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[fetch] requests %.4f s, batch %.4f s, filing %.4f s\n", tr - tf, tb - tr, now_s() - tb);
         return true;
     };
     auto file_into_cache = [&](const std::vector<Region>& rs, const std::vector<int>& raw_of) {
@@ -1432,7 +1526,7 @@ bool Aligner::extend_generations() {
     int gi = 0;                                  // 0: the first seed alone; 1: the other seeds + its children; 2..: children
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double tl = now_s();
-    auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[generation %d] %-12s %.4f s\n", gi, what, t - tl); tl = t; } };
+    auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[generation %d] %-12s %.4f s (cpu %.4f)\n", gi, what, t - tl, cpu_lap_s()); tl = t; } };
     while (!gen.empty()) {
         std::vector<Region> now;
         std::vector<int> now_raw;
@@ -1457,12 +1551,15 @@ bool Aligner::extend_generations() {
                 }
                 now.push_back(r); now_raw.push_back(gen_raw[(size_t)h[i].idx]);
             }
+            lap("sort");
             if (!trouble) trouble = !disjoint_clusters(now, &first);
+            lap("clusters");
             if (!trouble) trouble = !fetch(now, &now_raw);       // children: one more call (usually nothing to fetch)
         }
         lap("sort+fetch");
         std::vector<Request> req;
         if (!trouble && !plain_requests(now, nullptr, &req)) trouble = true;
+        lap("requests");
         if (trouble) {
             stats.generation_handover = gi;
             file_into_cache(gen, gen_raw);
@@ -1620,6 +1717,7 @@ void Aligner::filter_mums(int rvalue) {
         if (!merged && cut < h.size()) std::sort(h.begin(), h.end());
         for (size_t i = 0; i < mums.size(); i++) mums[i] = h[i].idx;
     }
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[filter_mums] order %.4f s\n", now_s() - t0);
     long numums = (long)mums.size();
     for (long x = 0; x < numums - 1; x++) {
         const Mum& mt = pool[(size_t)mums[(size_t)x]];
@@ -1647,6 +1745,7 @@ void Aligner::filter_mums(int rvalue) {
         }
     }
     stats.filter_s += now_s() - t0;
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[filter_mums] all %.4f s\n", now_s() - t0);
 }
 
 // Greedy collinear chaining of the MUMs in reference order (setFinalClusters :2563-2719).  The float32 / double
@@ -1744,6 +1843,7 @@ void Aligner::chain() {
         ahead[(size_t)x] = judged_verdict_[(size_t)cur];
     }
 
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[chain] order + verdicts %.4f s\n", now_s() - t0);
     auto open_chain = [&](int idx) { Lcb c; c.type = 1; c.mums.push_back(idx); c.length = pool[(size_t)idx].length; return c; };
     auto close_chain = [&](Lcb& c) {      // start of the first MUM, end of the last (Cluster(TMum) LCB.cpp:21-28 + the joins)
         const Mum& f = pool[(size_t)c.mums.front()];

@@ -18,6 +18,7 @@
 //   Aligner::fill_between      setInterClusterRegions                 :2389-2460
 //   write_output               writeOutput                            :505-1191
 #pragma once
+#include <ctime>
 #include <cstdint>
 #include <algorithm>
 #include <functional>
@@ -31,6 +32,17 @@
 #include "../../../include/parsnp_mum.h"
 
 namespace parsnp {
+
+// CPU seconds of the whole process since the previous call (PARSNP_DEBUG_TIMERS laps: wall time beside the work of all threads)
+inline double cpu_lap_s() {
+    static double last = 0;
+    timespec ts;
+    clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+    const double t = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, d = t - last;
+    last = t;
+    return d;
+}
+
 
 struct Params {
     int c = 0, d = 0, q = 0, p = 0, do_align = 0, cores = 2, random = 0;
@@ -56,9 +68,26 @@ public:
     void init_zero_lazy(size_t nbits) {   // scratch: no sentinel; storage (and its mapped pages) is kept when the size repeats
         const size_t words = (nbits + 63) / 64 + 1;
         nbits_ = nbits;
-        if (w_.size() == words) std::fill(w_.begin(), w_.end(), 0); else { decltype(w_)().swap(w_); w_.resize(words); }
+        if (words_ == words) std::fill(w_, w_ + words_, 0); else fresh(words);
     }
-    void release() { decltype(w_)().swap(w_); nbits_ = 0; }
+    void release() { fresh(0); nbits_ = 0; }
+    // a bitmap whose words live elsewhere (the layout image the engine delivers, pm_layout_image): not cleared, not owned
+    void attach(uint64_t* words, size_t nwords, size_t nbits_with_sentinel) {
+        decltype(own_)().swap(own_);
+        w_ = words; words_ = nwords; nbits_ = nbits_with_sentinel;
+        logging_ = false; log_.clear();
+    }
+    bool attached() const { return w_ && own_.empty(); }
+    size_t count_set() const { size_t c = 0; for (size_t i = 0; i < words_; i++) c += (size_t)__builtin_popcountll(w_[i]); return c; }
+    Bitmap() = default;
+    Bitmap(Bitmap&& o) noexcept { *this = std::move(o); }
+    Bitmap& operator=(Bitmap&& o) noexcept {
+        own_ = std::move(o.own_); w_ = o.w_; words_ = o.words_; nbits_ = o.nbits_; logging_ = o.logging_; log_ = std::move(o.log_);
+        o.w_ = nullptr; o.words_ = 0; o.nbits_ = 0;
+        return *this;
+    }
+    Bitmap(const Bitmap&) = delete;
+    Bitmap& operator=(const Bitmap&) = delete;
     bool test_and_set(long a, long b) {    // [a,b) := 1; was any of it marked?  (scratch use: no undo log)
         if (a < 0) a = 0;
         if (b > (long)nbits_) b = (long)nbits_;
@@ -87,7 +116,7 @@ public:
     void set_range_slow(long a, long b);
     // [a,b) := 1 for a range known to lie inside the bitmap, no undo log active (the bulk marking of validate_parallel)
     void set_range_inside(long a, long b) {
-        uint64_t* w = w_.data();
+        uint64_t* w = w_;
         const size_t wa = (size_t)a >> 6, wb = (size_t)(b - 1) >> 6;
         const uint64_t first = ~0ull << (a & 63), last = ~0ull >> (63 - ((b - 1) & 63));
         if (wa == wb) { w[wa] |= first & last; return; }
@@ -96,6 +125,7 @@ public:
         w[wb] |= last;
     }
     void set_range_atomic(long a, long b);   // [a,b) := 1 with atomic word updates: threads marking neighbouring ranges may share a word
+    void clear_range_atomic(long a, long b); // [a,b) := 0, likewise (no undo log)
     void clear_range(long a, long b);   // [a,b) := 0
     long next_set(long from) const;     // smallest i >= from with bit set; the sentinel guarantees one for from <= n
     long prev_set(long from) const;     // largest i <= from with bit set, or -1
@@ -129,7 +159,10 @@ private:
         template <class U> bool operator==(const ZeroAlloc<U>&) const { return true; }
         template <class U> bool operator!=(const ZeroAlloc<U>&) const { return false; }
     };
-    std::vector<uint64_t, ZeroAlloc<uint64_t>> w_;
+    std::vector<uint64_t, ZeroAlloc<uint64_t>> own_;
+    uint64_t* w_ = nullptr;       // own_.data(), or the attached words
+    size_t words_ = 0;
+    void fresh(size_t words) { decltype(own_)().swap(own_); own_.resize(words); w_ = words ? own_.data() : nullptr; words_ = words; }
     size_t nbits_ = 0;
     bool logging_ = false;
     std::vector<std::pair<size_t, uint64_t>> log_;
@@ -223,6 +256,7 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     double alg_bytes_query = 0;    // ... of which the query pieces (m/2): the one coalesced stream that reaches the fabric
     double alg_bytes_kernel = 0;   // the same sum of what THIS engine's event search must move: (m + n)/2 + 64 B per sampled K-mer (run_batch)
     long gap_requests = 0;  // regions whose rows the engine derived from its anchor table (pm_multi_mum_batch_gaps)
+    long layout_images = 0; // layouts delivered by the engine as an image (pm_layout_image) instead of marked by the host
     long finder_calls = 0, finder_regions = 0, regions_processed = 0, cache_hits = 0, cache_misses = 0, spec_rounds = 0;
     // device-side phase times (HIP events, pm_last_timing): summed over every engine call of the step, and of the
     // anchor call alone (the one launch that sees whole genomes)
@@ -240,6 +274,11 @@ struct AlignerMemory {
     Arena<int32_t> irows;                    // MUM start rows
     Arena<uint8_t> brows;                    // MUM strand rows
     std::vector<Bitmap> layout;              // the run's mumlayout: storage kept mapped across runs, cleared per run
+    // the other set of the pair.  When the engine delivers the layout of the anchors as an image (pm_layout_image) the run
+    // continues on bitmaps attached to that image, and the set it started on -- a few thousand marks of the flagged candidates,
+    // taken back -- is all zero again: the next run starts on it without clearing 125 MB (spare_zero)
+    std::vector<Bitmap> spare;
+    bool spare_zero = false;
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
     std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
     struct PerThread { Arena<long> rows; Arena<int32_t> irows; Arena<uint8_t> brows; std::vector<long> scratch; };
@@ -282,6 +321,7 @@ public:
 
     void wait_layout();           // the layout bitmaps are set up in the background (constructor); find_anchors() awaits them
     void start_deferred_marks();  // (no-op unless validate_parallel put marks off)
+    void await_image();           // (no-op unless the layout is an image in flight)
     enum : uint8_t { kJoin = 0, kClose = 1, kPass = 2 };
     uint8_t judge_pair(const Mum& nt, const Mum& back) const;     // chain()'s test of a MUM against the open chain's last MUM
     void start_prejudge();        // the anchors' consecutive pairs, judged beside the recursion's first engine call
@@ -298,6 +338,7 @@ private:
     // MUMs lie in list order, one after the other without overlap -- then the marked base next to a MUM is its list
     // neighbour's, and find_anchors() derives the seed regions from the rows instead of walking bitmaps
     bool anchors_ordered_ = false;
+    bool image_pending_ = false;              // the layout is an image in flight (pm_layout_image): wait_layout() awaits it
     std::vector<int> judged_pred_;            // chain(): predecessor against which a MUM was last judged, and the verdict
     std::vector<uint8_t> judged_verdict_;
     pm_session* session_;

@@ -186,7 +186,7 @@ StepReport CoreRun::step() {
         std::cerr << "Creating and verifying final LCBs..." << std::endl;
         const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
         double tl = now_s();
-        auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[lcb] %-12s %.4f s\n", what, t - tl); tl = t; } };
+        auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[lcb] %-12s %.4f s (cpu %.4f)\n", what, t - tl, cpu_lap_s()); tl = t; } };
         a.chain(); lap("chain");
         const long dissolved = a.filtered_lcbs;
         a.filter_lcbs(); lap("filter_lcbs");
