@@ -608,6 +608,7 @@ public:
     // reads it after layout_wait().  The block is rewritten by the next call: the previous copy is awaited first.
     int layout_image(int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t nrows, const int32_t* xstart, const int32_t* xlon, int64_t nx,
                      uint64_t** image) {
+        be.bind();
         if (table_id == 0 || table_id != anchor_table_id) { error = "the anchor table of this layout is no longer resident"; return -2; }
         if (nrows != anchor_table_rows || !nbits || !accept || nx < 0 || (nx > 0 && (!xstart || !xlon))) { error = "bad layout request"; return -2; }
         const size_t ngz = (size_t)ngen, nxz = (size_t)nx, nrz = (size_t)nrows;

@@ -78,6 +78,8 @@ struct Rccl {
 
 struct HipBackend {
     hipStream_t stream = nullptr;
+    int device = 0;                     // the session's GPU; bind() makes it the calling thread's (a call may come from a helper thread)
+    void bind() { check(hipSetDevice(device), "hipSetDevice"); }
     ncclComm_t comm = nullptr;          // device collectives of a sharded session (pm_session_create_rccl)
     std::string err;
     void* tmp = nullptr;
@@ -327,6 +329,7 @@ static PmBackend* pm_backend_open(int device, std::string* err) {
         if (device >= count || hipSetDevice(device) != hipSuccess) { *err = "cannot select the requested HIP device"; return nullptr; }
     }
     HipBackend* b = new HipBackend;
+    (void)hipGetDevice(&b->device);
     if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { *err = "hipStreamCreate failed"; delete b; return nullptr; }
     return b;
 }

@@ -136,6 +136,8 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
       n(g.size()), prm(p), genomes(g), layout(memory_->layout), session_(session), rows_(memory_->rows), irows_(memory_->irows), brows_(memory_->brows), cache_rows_(memory_->cache_rows),
       req_rows_(memory_->req_rows) {
     layout.resize(n);
+    pool.swap(memory_->pool_store);      // the previous run's MUM records: capacity (and mapped pages) kept, see ~Aligner
+    pool.clear();
     gsize_.resize(n);
     for (size_t i = 0; i < n; i++) {
         if (genomes[i].seq.size() > (size_t)INT32_MAX - 64) fatal("genome longer than 2^31 bases: " + genomes[i].path);   // Mum rows are int32
@@ -215,7 +217,7 @@ Aligner::~Aligner() {
     double t = now_s();
     auto lap = [&](const char* what) { if (dbg) { double u = now_s(); fprintf(stderr, "[release] %-10s %.4f s\n", what, u - t); t = u; } };
     cache_.clear(); lap("cache");
-    std::vector<Mum>().swap(pool); lap("pool");
+    pool.clear(); pool.swap(memory_->pool_store); lap("pool");
     std::vector<Lcb>().swap(lcbs); lap("lcbs");
     own_memory_.reset(); lap("arenas");
 }
@@ -633,7 +635,8 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     int32_t* srow = device_rows ? raw.start : irows_.alloc(ncand * n);
     uint8_t* frow = device_rows ? raw.strand : brows_.alloc(ncand * n);
     if (device_rows) kept_results_.push_back(raw.owner);
-    std::vector<Mum> cand(ncand);
+    std::vector<Mum>& cand = memory_->candidates;      // (the run's memory: 3 MB of records per anchor call, not faulted in again)
+    cand.clear(); cand.resize(ncand);
     std::vector<uint8_t> state(ncand, 0);   // bit0 constructed, bit1 ok, bit2 any_reverse, bit3 dirty, bit4 accepted
     const long nc = (long)ncand;
     const bool layout_empty = pool.empty();      // nothing accepted yet: the layout holds no mark (the anchor call)
@@ -795,6 +798,11 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
                 // where the candidate itself sits in the accepted list: in most genomes what it meets are its list neighbours,
                 // so the search below gallops outwards from there (the same few rows for all genomes) before it bisects
                 const size_t here = (size_t)(std::lower_bound(acc_idx.begin(), acc_idx.end(), cf) - acc_idx.begin());
+                // (their rows, whole: the searches of all genomes end among them, each in a different line of the same rows)
+                for (size_t k = here > 2 ? here - 2 : 0; k < std::min(nacc, here + 3); k++) {
+                    const char* row = (const char*)(srow + (size_t)acc_idx[k] * n);
+                    for (size_t b = 0; b < n * sizeof(int32_t); b += 64) __builtin_prefetch(row + b);
+                }
                 for (size_t j = 0; j < n; j++) {
                     const long s = f.start[j], e = s + f.length;
                     auto ends_after = [&](size_t k) { const uint32_t c = acc_idx[k]; return (long)srow[(size_t)c * n + j] + cand[c].length > s; };
@@ -927,6 +935,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             stats.parallel_tangled++;
         }
     }
+    lap("tangled");
     // (2) ids and pool places as the sequential loop would assign them: every constructed candidate takes the next id, every
     // accepted one the next place -- one pass over the state bytes -- then (3) the MUM records are written by all threads
     constexpr uint32_t kNoPlace = 0xffffffffu;
@@ -945,6 +954,31 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             ndirty += (st & 8) ? 1 : 0;
         }
     }
+    lap("places");
+    // The put-off marks, and everything else of the layout this list leaves, come as an image from the device: the accepted
+    // clean candidates are rows of its anchor table; the accepted flagged ones travel with the coordinates trim() left them.
+    // Asked for by a helper while this thread writes the MUM records (the engine is not used by anybody else meanwhile).
+    struct ImageAsk { int rc = PM_EINVAL; uint64_t* image = nullptr; std::string error; std::shared_ptr<std::vector<int32_t>> extra_start, extra_len; std::vector<int64_t> nbits; };
+    std::future<ImageAsk> image_ask;
+    if (put_off && image_table)
+        image_ask = std::async(std::launch::async, [&, this] {
+            ImageAsk a;
+            std::vector<uint8_t> acc(ncand);
+            for (size_t c = 0; c < ncand; c++) acc[c] = (state[c] & 24) == 16;
+            a.extra_start = std::make_shared<std::vector<int32_t>>();
+            a.extra_len = std::make_shared<std::vector<int32_t>>();
+            for (size_t c = 0; c < ncand; c++)
+                if ((state[c] & 8) && place[c] != kNoPlace) {
+                    a.extra_len->push_back((int32_t)cand[c].length);
+                    a.extra_start->insert(a.extra_start->end(), cand[c].start, cand[c].start + n);
+                }
+            a.nbits.resize(n);
+            for (size_t j = 0; j < n; j++) a.nbits[j] = (int64_t)gsize_[j] + 1;
+            a.rc = pm_layout_image(session_, image_table, a.nbits.data(), acc.data(), (int64_t)ncand, a.extra_start->data(), a.extra_len->data(),
+                                   (int64_t)a.extra_len->size(), &a.image);
+            if (a.rc != PM_OK) a.error = pm_last_error();
+            return a;
+        });
     const size_t pool0 = pool.size(), acc0 = accepted->size();
     const long id0 = next_id_;
     // where the engine keeps this list's rows resident (its anchor table), the MUMs remember their row: the seed regions
@@ -970,54 +1004,41 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             aout[at] = (int)(pool0 + at);
         }
     }
+    lap("records");
     next_id_ += nid;
     stats.parallel_dirty += ndirty;
     stats.parallel_candidates += (long)ncand;
     // order of the whole accepted list per genome = order of the clean ones (above) + every accepted flagged candidate
     // between its list neighbours (it may have been trimmed: its row holds the final coordinates)
     if (layout_empty && !disorder) {
-        bool ordered = true;
-        const size_t na = accepted->size();
-        for (size_t x = 0; x < na && ordered; x++) {
-            const Mum& m = pool[(size_t)(*accepted)[x]];
-            if (!m.dirty) continue;
-            for (int side = 0; side < 2 && ordered; side++) {
+        int unordered = 0;
+        const long na = (long)accepted->size();
+#pragma omp parallel for schedule(dynamic, 2048) num_threads(threads) reduction(| : unordered)
+        for (long x = 0; x < na; x++) {
+            const Mum& m = pool[(size_t)(*accepted)[(size_t)x]];
+            if (!m.dirty || unordered) continue;
+            for (int side = 0; side < 2; side++) {
                 if ((side == 0 && x == 0) || (side == 1 && x + 1 == na)) continue;
-                const Mum& a = side == 0 ? pool[(size_t)(*accepted)[x - 1]] : m;
-                const Mum& b = side == 0 ? m : pool[(size_t)(*accepted)[x + 1]];
-                for (size_t j = 0; j < n; j++) if ((long)b.start[j] < a.end(j)) { ordered = false; break; }
+                const Mum& a = side == 0 ? pool[(size_t)(*accepted)[(size_t)x - 1]] : m;
+                const Mum& b = side == 0 ? m : pool[(size_t)(*accepted)[(size_t)x + 1]];
+                for (size_t j = 0; j < n; j++) if ((long)b.start[j] < a.end(j)) { unordered = 1; break; }
             }
         }
-        anchors_ordered_ = ordered;
+        anchors_ordered_ = !unordered;
     } else anchors_ordered_ = false;
     if (dbg && put_off) fprintf(stderr, "[validate_parallel] marks of the clean candidates put off\n");
     lap("sequential");
-    // The put-off marks, and everything else of the layout this list leaves: as an image from the device.  The accepted clean
-    // candidates are rows of its anchor table; the accepted flagged ones travel with the coordinates trim() left them.  The
-    // run goes on with bitmaps attached to the image (every reader awaits it: wait_layout); the set used so far gets its few
+    // The run goes on with bitmaps attached to the image (every reader awaits it: wait_layout); the set used so far gets its few
     // marks taken back in the background and waits, all zero, for the next run.
-    if (put_off && image_table) {
-        std::vector<uint8_t> acc(ncand);
-        for (size_t c = 0; c < ncand; c++) acc[c] = (state[c] & 24) == 16;
-        auto extra_start = std::make_shared<std::vector<int32_t>>();
-        auto extra_len = std::make_shared<std::vector<int32_t>>();
-        for (size_t c = 0; c < ncand; c++)
-            if ((state[c] & 8) && place[c] != kNoPlace) {
-                extra_len->push_back((int32_t)cand[c].length);
-                extra_start->insert(extra_start->end(), cand[c].start, cand[c].start + n);
-            }
-        std::vector<int64_t> nbits(n);
-        for (size_t j = 0; j < n; j++) nbits[j] = (int64_t)gsize_[j] + 1;
-        uint64_t* image = nullptr;
-        const int rc = pm_layout_image(session_, image_table, nbits.data(), acc.data(), (int64_t)ncand, extra_start->data(), extra_len->data(),
-                                       (int64_t)extra_len->size(), &image);
-        if (rc == PM_OK) {
+    if (image_ask.valid()) {
+        ImageAsk a = image_ask.get();
+        if (a.rc == PM_OK) {
             std::vector<Bitmap>& other = memory_->spare;
             other.resize(n);
             size_t off = 0;
             for (size_t j = 0; j < n; j++) {
-                const size_t words = ((size_t)nbits[j] + 63) / 64 + 1;
-                other[j].attach(image + off, words, (size_t)nbits[j]);
+                const size_t words = ((size_t)a.nbits[j] + 63) / 64 + 1;
+                other[j].attach(a.image + off, words, (size_t)a.nbits[j]);
                 off += words;
             }
             std::swap(memory_->layout, memory_->spare);       // `layout` is the image from here on
@@ -1026,6 +1047,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             memory_->spare_zero = true;                       // (once the tasks below are through: the next run starts after wait_layout)
             auto logs = std::make_shared<std::vector<std::vector<Span>>>(std::move(marked_now));
             std::vector<Bitmap>* zero = &memory_->spare;
+            auto extra_start = a.extra_start; auto extra_len = a.extra_len;
             const size_t nn = n, tasks = 4;
             for (size_t t = 0; t < tasks; t++)
                 layout_ready_.push_back(std::async(std::launch::async, [zero, logs, extra_start, extra_len, nn, t, tasks] {
@@ -1036,7 +1058,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
                         for (size_t j = 0; j < nn; j++) (*zero)[j].clear_range_atomic((*extra_start)[k * nn + j], (long)(*extra_start)[k * nn + j] + (*extra_len)[k]);
                 }));
             stats.layout_images++;
-        } else if (dbg) fprintf(stderr, "[validate_parallel] no layout image (%s): the host marks\n", pm_last_error());
+        } else if (dbg) fprintf(stderr, "[validate_parallel] no layout image (%s): the host marks\n", a.error.c_str());
         lap("image");
     }
 }
@@ -1407,10 +1429,44 @@ bool Aligner::disjoint_clusters(const std::vector<Region>& w, std::vector<size_t
     first->push_back(m);
     const long nc = (long)first->size() - 1;
     if (nc < 2) return true;
+    // Collinear genomes hold the clusters in reference order: then "pairwise disjoint" is "every cluster starts after its
+    // predecessor ends" -- a pass over the regions' rows, cluster by cluster (contiguous reads).  A genome in which that
+    // fails for some pair may still hold them disjoint in another order: those genomes take the sort below.
+    std::vector<uint8_t> unsure(n, 0);
+    {
+        const int threads = prm.cores > 0 ? prm.cores : 1;
+        const long kBlock = 128, nblocks = (nc + kBlock - 1) / kBlock;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+        for (long bl = 0; bl < nblocks; bl++) {
+            const long c0 = bl * kBlock, c1 = std::min(nc, c0 + kBlock);
+            std::vector<long> lo(n), hi(n), prev(n);
+            auto extent = [&](long c, long* plo, long* phi) {
+                const size_t f = (*first)[(size_t)c], l = (*first)[(size_t)c + 1];
+                memcpy(plo, w[f].start, n * sizeof(long)); memcpy(phi, w[f].end, n * sizeof(long));
+                for (size_t i = f + 1; i < l; i++) {
+                    const long* st = w[i].start; const long* en = w[i].end;
+                    for (size_t g = 0; g < n; g++) { if (st[g] < plo[g]) plo[g] = st[g]; if (en[g] > phi[g]) phi[g] = en[g]; }
+                }
+            };
+            if (c0 > 0) extent(c0 - 1, lo.data(), prev.data());
+            for (long c = c0; c < c1; c++) {
+                extent(c, lo.data(), hi.data());
+                if (c > 0)
+                    for (size_t g = 1; g < n; g++)
+                        if (lo[g] <= prev[g] + 1) __atomic_store_n(&unsure[g], (uint8_t)1, __ATOMIC_RELAXED);      // touching counts too
+                prev.swap(hi);
+            }
+        }
+    }
+    std::vector<long> todo;
+    for (size_t g = 1; g < n; g++) if (unsure[g]) todo.push_back((long)g);
+    if (todo.empty()) return true;
     int bad = 0;
+    const long ntodo = (long)todo.size();
 #pragma omp parallel for schedule(dynamic, 4) num_threads(prm.cores > 0 ? prm.cores : 1) reduction(| : bad)
-    for (long g = 1; g < (long)n; g++) {
+    for (long t = 0; t < ntodo; t++) {
         if (bad) continue;
+        const long g = todo[(size_t)t];
         std::vector<std::pair<long, long>> iv((size_t)nc);
         for (long c = 0; c < nc; c++) {
             long lo = w[(*first)[(size_t)c]].start[g], hi = w[(*first)[(size_t)c]].end[g];
@@ -1694,27 +1750,51 @@ void Aligner::filter_mums(int rvalue) {
         const long nh = (long)mums.size();        // one cache miss per MUM (its row): spread over the threads
 #pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
         for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{pool[(size_t)mums[(size_t)i]].start[0], mums[(size_t)i]};
-        // the list is the anchors followed by the MUMs of the recursion, each in reference order: two increasing runs.
-        // With all keys different there is one sorted order and a merge finds it; with equal keys the order std::sort
-        // leaves is the reference's (sort( mums ) :338), so it runs on the list as it stands.
-        size_t cut = 1;
-        while (cut < h.size() && h[cut - 1].key < h[cut].key) cut++;
-        bool merged = cut < h.size();
-        for (size_t i = cut + 1; i < h.size() && merged; i++) merged = h[i - 1].key < h[i].key;
-        if (merged) {
-            std::vector<Handle> out(h.size());
-            size_t a = 0, b = cut, o = 0;
-            while (a < cut && b < h.size()) {
-                if (h[a].key == h[b].key) { merged = false; break; }
-                out[o++] = h[a].key < h[b].key ? h[a++] : h[b++];
+        if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[filter_mums] keys %.4f s\n", now_s() - t0);
+        // the list is the anchors followed by the MUMs of the recursion, generation by generation, each in reference order:
+        // a few increasing runs, one of them (the anchors) much longer than the rest.  With all keys different there is one
+        // sorted order, and merging finds it: the short runs into one list, that list into the long run by block copies
+        // (a binary search per element of the short list).  With equal keys the order std::sort leaves is the reference's
+        // (sort( mums ) :338), so it runs on the list as it stands.
+        std::vector<size_t> runs{0};
+        for (size_t i = 1; i < h.size(); i++) if (!(h[i - 1].key < h[i].key)) runs.push_back(i);
+        runs.push_back(h.size());
+        const size_t nruns = runs.size() - 1;
+        bool merged = nruns <= 1;
+        if (nruns >= 2 && nruns <= 64) {
+            size_t big = 0;
+            for (size_t r = 1; r < nruns; r++) if (runs[r + 1] - runs[r] > runs[big + 1] - runs[big]) big = r;
+            merged = true;
+            std::vector<Handle> small, tmp;
+            for (size_t r = 0; r < nruns && merged; r++) {
+                if (r == big) continue;
+                tmp.clear();
+                tmp.reserve(small.size() + runs[r + 1] - runs[r]);
+                size_t a = 0, b = runs[r];
+                while (a < small.size() && b < runs[r + 1]) {
+                    if (small[a].key == h[b].key) { merged = false; break; }
+                    tmp.push_back(small[a].key < h[b].key ? small[a++] : h[b++]);
+                }
+                while (a < small.size()) tmp.push_back(small[a++]);
+                while (b < runs[r + 1]) tmp.push_back(h[b++]);
+                small.swap(tmp);
             }
             if (merged) {
-                while (a < cut) out[o++] = h[a++];
-                while (b < h.size()) out[o++] = h[b++];
-                h.swap(out);
+                std::vector<Handle> out(h.size());
+                const Handle* B = h.data() + runs[big]; const Handle* const Bend = h.data() + runs[big + 1];
+                size_t o = 0;
+                for (size_t x = 0; x < small.size() && merged; x++) {
+                    const Handle* at = std::lower_bound(B, Bend, small[x]);
+                    if (at != Bend && at->key == small[x].key) { merged = false; break; }
+                    std::copy(B, at, out.begin() + (long)o);
+                    o += (size_t)(at - B);
+                    out[o++] = small[x];
+                    B = at;
+                }
+                if (merged) { std::copy(B, Bend, out.begin() + (long)o); h.swap(out); }
             }
         }
-        if (!merged && cut < h.size()) std::sort(h.begin(), h.end());
+        if (!merged) std::sort(h.begin(), h.end());
         for (size_t i = 0; i < mums.size(); i++) mums[i] = h[i].idx;
     }
     if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[filter_mums] order %.4f s\n", now_s() - t0);

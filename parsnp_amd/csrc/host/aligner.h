@@ -281,6 +281,7 @@ struct AlignerMemory {
     bool spare_zero = false;
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
     std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
+    std::vector<Mum> pool_store, candidates;         // storage of Aligner::pool / validate_parallel's candidate records between runs
     struct PerThread { Arena<long> rows; Arena<int32_t> irows; Arena<uint8_t> brows; std::vector<long> scratch; };
     std::vector<std::unique_ptr<PerThread>> per_thread;   // rows written by the threads of the generation-parallel replay
     void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); brows.reset(); for (auto& t : per_thread) { t->rows.reset(); t->irows.reset(); t->brows.reset(); } }

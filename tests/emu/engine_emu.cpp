@@ -22,6 +22,7 @@ struct HostBackend {
     void d2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void d2h_side(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void side_wait() {}
+    void bind() {}
     void* pinned_alloc(size_t n) { return malloc(n ? n : 1); }
     void pinned_free(void* p) { ::free(p); }
     void sync() {}
