@@ -154,6 +154,19 @@ int64_t pm_result_table_id(const pm_result* r);
 int pm_layout_image(pm_session* s, int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t n_rows,
                     const int32_t* extra_start, const int32_t* extra_len, int64_t n_extra, uint64_t** image);
 int pm_layout_wait(pm_session* s);
+/* The seed regions of the resident anchor table, worked out ON THE DEVICE and searched in one batch -- callable from a
+ * helper thread right after the anchor call, so that the batch runs beside the caller's validation of the anchors: for every
+ * two neighbouring rows that carry no verdict or overlap / order flag and are at least 5 long (rows the caller is certain to
+ * accept untouched), the left region of the second and the right region of the first (formulas above), kept when longer than
+ * q in every genome (src/parsnp.cpp:2158-2170) and at most ref_len_limit long on the reference (one chunk of the p-loop,
+ * :1519-1547); minimum length of a region = minsize_by_length[its shortest length] (regions whose shortest length is >=
+ * table_len are left to the caller).  pm_result_spec_refs / _minsize [pm_result_regions]: which gap each region of the
+ * result is and what it was searched with; the per-region results are those of pm_multi_mum_batch on the same rows.  A
+ * session is still single-threaded: no other call on it until this one has returned. */
+int pm_multi_mum_batch_spec(pm_session* s, int64_t table_id, int32_t q, int64_t ref_len_limit, const int32_t* minsize_by_length, int64_t table_len,
+                            pm_result** out);
+const pm_gap_ref* pm_result_spec_refs(const pm_result* r);
+const int32_t* pm_result_spec_minsize(const pm_result* r);
 /* Tunables of a session (tests lower the thresholds of the long-list routes so that small inputs take them):
  *   "work_budget"  per-thread step budget of the index walks (default 2^22; a batch that exhausts it is repeated once with
  *                  256 times as much, then PM_ELIMIT)

@@ -101,7 +101,13 @@ int32_t* pm_result_start(pm_result* r) { (void)r; return 0; }
 uint8_t* pm_result_strand(pm_result* r) { (void)r; return 0; }
 const uint32_t* pm_result_flags(const pm_result* r) { (void)r; return 0; }
 int pm_result_dirty_known(const pm_result* r) { (void)r; return 0; }
-int64_t pm_result_table_id(const pm_result* r) { (void)r; return 0; }       /* this provider keeps no anchor table */
+int64_t pm_result_table_id(const pm_result* r) { (void)r; return 0; }
+int pm_multi_mum_batch_spec(pm_session* s, int64_t table_id, int32_t q, int64_t ref_len_limit, const int32_t* minsize_by_length, int64_t table_len, pm_result** out) {
+    (void)s; (void)table_id; (void)q; (void)ref_len_limit; (void)minsize_by_length; (void)table_len; (void)out;
+    return PM_EINVAL;
+}
+const pm_gap_ref* pm_result_spec_refs(const pm_result* r) { (void)r; return 0; }
+const int32_t* pm_result_spec_minsize(const pm_result* r) { (void)r; return 0; }       /* this provider keeps no anchor table */
 int pm_multi_mum_batch_gaps(pm_session* s, int64_t table_id, int64_t n_regions, const pm_gap_ref* gaps, const int64_t* ref_start, const int64_t* ref_len,
                             const int32_t* minsize, int64_t n_explicit, const int64_t* ex_starts, const int64_t* ex_lens, pm_result** out) {
     (void)s; (void)table_id; (void)n_regions; (void)gaps; (void)ref_start; (void)ref_len; (void)minsize; (void)n_explicit; (void)ex_starts; (void)ex_lens; (void)out;

@@ -127,6 +127,23 @@ int pm_multi_mum_batch_gaps(pm_session* s, int64_t table_id, int64_t n_regions, 
     } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
     } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
 }
+int pm_multi_mum_batch_spec(pm_session* s, int64_t table_id, int32_t q, int64_t ref_len_limit, const int32_t* minsize_by_length, int64_t table_len, pm_result** out) {
+    if (!s || !out || !minsize_by_length || table_len < 1) return fail(PM_EINVAL, "bad argument");
+    try {
+        std::unique_ptr<pm_result> r(new pm_result);
+        const auto w0 = std::chrono::steady_clock::now();
+        s->backend->bind_thread();          // (the call may come from a helper thread: the device is a per-thread setting)
+        int rc = s->engine->run_spec(table_id, q, ref_len_limit, minsize_by_length, table_len, &r->r);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        *out = r.release();
+        return PM_OK;
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
+}
+const pm_gap_ref* pm_result_spec_refs(const pm_result* r) { return r ? (const pm_gap_ref*)r->r.spec_refs.data() : nullptr; }
+const int32_t* pm_result_spec_minsize(const pm_result* r) { return r ? r->r.spec_minsize.data() : nullptr; }
 int64_t pm_result_table_id(const pm_result* r) { return r ? r->r.table_id : 0; }
 int64_t pm_result_regions(const pm_result* r) { return r->r.nregions; }
 int64_t pm_result_total(const pm_result* r) { return r->r.total; }

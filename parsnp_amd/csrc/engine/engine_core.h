@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -27,7 +28,9 @@ struct HostPool {
     void (*free_fn)(void*) = nullptr;
     struct Block { void* p = nullptr; size_t cap = 0; };
     std::vector<Block> idle;
+    std::mutex mu;      // results are freed by whichever thread holds them while another thread's call takes blocks
     Block take(size_t n) {
+        std::lock_guard<std::mutex> lk(mu);
         size_t best = idle.size();
         for (size_t i = 0; i < idle.size(); i++)
             if (idle[i].cap >= n && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
@@ -36,7 +39,7 @@ struct HostPool {
         if (!b.p) throw std::bad_alloc();
         return b;
     }
-    void give(Block b) { if (b.p) idle.push_back(b); }
+    void give(Block b) { std::lock_guard<std::mutex> lk(mu); if (b.p) idle.push_back(b); }
     ~HostPool() { for (auto& b : idle) free_fn(b.p); }
 };
 
@@ -49,6 +52,8 @@ struct BatchResult {
     HostPool::Block startb, strandb, flagsb; // int32 start[total*(nq+1)], uint8 strand[total*(nq+1)], uint32 flags[total]
     bool rows = false, dirty_known = false;  // dirty_known: the kRowDirty bits were computed (one-region batch with a long list)
     int64_t table_id = 0;                    // != 0: the rows of this result stay on the device as the session's anchor table (run_gaps)
+    std::vector<GapRef> spec_refs;           // run_spec: which gap of the anchor table each region of this result is ...
+    std::vector<int32_t> spec_minsize;       // ... and the minimum length it was searched with
     std::shared_ptr<HostPool> pool;
     int32_t* start() const { return (int32_t*)startb.p; }
     uint8_t* strand() const { return (uint8_t*)strandb.p; }
@@ -182,6 +187,37 @@ public:
         return rc;
     }
     int64_t anchor_table_id = 0, anchor_table_rows = 0;      // the resident anchor table: rows of the last one-region call in row mode
+    // The seed regions of the resident anchor table worked out on the device (GapSeeds) and searched in one batch: what the
+    // host will ask for once it has validated the anchors, computed beside that validation (include/parsnp_mum.h:
+    // pm_multi_mum_batch_spec).  out->spec_refs says which gap each region of the result is.
+    int run_spec(int64_t table_id, int32_t q, int64_t ref_len_limit, const int32_t* minsize_by_length, int64_t table_len, BatchResult* out) {
+        if (table_id == 0 || table_id != anchor_table_id) { error = "the anchor table of this speculation is no longer resident"; return -2; }
+        if (!minsize_by_length || table_len < 1) { error = "bad minimum-length table"; return -2; }
+        const int64_t rows = anchor_table_rows;
+        const size_t cap = 2 * (size_t)(rows + 1);
+        ensure(d_spec, cap); ensure(d_speccount, 1); ensure(d_mintable, (size_t)table_len);
+        be.memset(d_speccount.p, 0, 8);
+        be.h2d(d_mintable.p, minsize_by_length, 4 * (size_t)table_len);
+        be.launch_wave("gap_seeds", rows + 1, GapSeeds{d_anchor_start.p, d_anchor_lon.p, d_anchor_flags.p, rows, ngen, d_glen, q, ref_len_limit, d_mintable.p, table_len,
+                                                       d_spec.p, d_speccount.p, (uint64_t)cap});
+        uint64_t n = 0;
+        be.d2h(&n, d_speccount.p, 8);
+        if (n > cap) n = cap;
+        std::vector<SpecRegion> sr((size_t)n);
+        if (n) be.d2h(sr.data(), d_spec.p, sizeof(SpecRegion) * (size_t)n);
+        // (the wavefronts append in any order: sorted, so that a run is reproducible event for event)
+        std::sort(sr.begin(), sr.end(), [](const SpecRegion& x, const SpecRegion& y) {
+            if (x.ref.next != y.ref.next) return (uint32_t)x.ref.next < (uint32_t)y.ref.next;      // (-1 = the end: last)
+            if (x.ref.prev != y.ref.prev) return x.ref.prev < y.ref.prev;
+            return x.ref.side < y.ref.side; });
+        std::vector<GapRef> refs((size_t)n); std::vector<int64_t> rs((size_t)n), rl((size_t)n); std::vector<int32_t> ms((size_t)n);
+        for (size_t i = 0; i < (size_t)n; i++) { refs[i] = sr[i].ref; rs[i] = sr[i].ref_start; rl[i] = sr[i].ref_len; ms[i] = sr[i].minsize; }
+        GapBatch gb;
+        gb.table_id = table_id; gb.gaps = refs.data(); gb.ref_start = rs.data(); gb.ref_len = rl.data();
+        const int rc = run((int64_t)n, nullptr, nullptr, ms.data(), out, false, false, &gb);
+        out->spec_refs.swap(refs); out->spec_minsize.swap(ms);
+        return rc;
+    }
     bool budget_exceeded = false;
     long budget_retries = 0;
     int run_once(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events,
@@ -578,9 +614,10 @@ public:
                 out->dirty_known = true;
             }
             if (nreg == 1 && !gb && nok >= dirty_min) {      // a long list of one region (the anchor call): its rows stay on the device as the session's anchor table (run(..., gb))
-                ensure(d_anchor_start, std::max<size_t>(nokz * ngz, 1)); ensure(d_anchor_lon, std::max<size_t>(nokz, 1));
+                ensure(d_anchor_start, std::max<size_t>(nokz * ngz, 1)); ensure(d_anchor_lon, std::max<size_t>(nokz, 1)); ensure(d_anchor_flags, std::max<size_t>(nokz, 1));
                 be.d2d(d_anchor_start.p, d_csp.p, 4 * nokz * ngz);
                 be.d2d(d_anchor_lon.p, d_clon.p, 4 * nokz);
+                be.d2d(d_anchor_flags.p, d_cflags.p, 4 * nokz);
                 anchor_table_rows = nok;
                 out->table_id = anchor_table_id = ++table_counter;
             }
@@ -728,7 +765,8 @@ private:
     Buf<uint32_t> d_cflags, d_dirty; Buf<int32_t> d_bmax, d_bmin;
     Buf<GenomeAtK> d_xsend, d_xrecv; Buf<uint8_t> d_hsend, d_hrecv;
     Buf<RestItem> d_rest; Buf<uint64_t> d_qcount;
-    Buf<int32_t> d_anchor_start, d_anchor_lon; Buf<GapRef> d_gaps; Buf<int64_t> d_exstarts, d_exlens;
+    Buf<int32_t> d_anchor_start, d_anchor_lon; Buf<uint32_t> d_anchor_flags; Buf<GapRef> d_gaps; Buf<int64_t> d_exstarts, d_exlens;
+    Buf<SpecRegion> d_spec; Buf<uint64_t> d_speccount; Buf<int32_t> d_mintable;
     int64_t table_counter = 0;
     Buf<uint64_t> d_image; Buf<int64_t> d_imgoff, d_imgbits; Buf<uint8_t> d_accept; Buf<int32_t> d_xstart, d_xlon;
     uint64_t* image_h = nullptr; size_t image_words = 0;      // page-locked: the layout image as the host reads it

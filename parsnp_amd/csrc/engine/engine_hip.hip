@@ -80,6 +80,7 @@ struct HipBackend {
     hipStream_t stream = nullptr;
     int device = 0;                     // the session's GPU; bind() makes it the calling thread's (a call may come from a helper thread)
     void bind() { check(hipSetDevice(device), "hipSetDevice"); }
+    void bind_thread() { bind(); }
     ncclComm_t comm = nullptr;          // device collectives of a sharded session (pm_session_create_rccl)
     std::string err;
     void* tmp = nullptr;

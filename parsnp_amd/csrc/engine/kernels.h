@@ -632,6 +632,70 @@ struct LayoutSentinel {
         if (nb > 0) atomic_or64(&image[word_off[tid] + ((nb - 1) >> 6)], 1ull << ((nb - 1) & 63));
     }
 };
+// The seed regions themselves, worked out on the device right after the anchor call -- while the host still receives and
+// validates the anchors -- so that the recursion's first batch can be computed SPECULATIVELY beside the host's work: for
+// every two neighbouring rows of the anchor table that the host is certain to accept untouched (no verdict or overlap / order
+// flag, length >= 5: what Aligner::validate_parallel calls clean and settles without looking), the left region of the second
+// and the right region of the first as find_anchors derives them from the same rows (formulas: ExpandGaps), kept when longer
+// than q in every genome (src/parsnp.cpp:2158-2170) and short enough on the reference for one chunk (:1519-1547).
+// One wavefront per pair of neighbours (w-1, w); lanes over the genomes.
+struct SpecRegion { GapRef ref; int64_t ref_start, ref_len; int32_t minsize, slength; };
+struct GapSeeds {
+    const int32_t* astart; const int32_t* alon; const uint32_t* aflags; int64_t nrows; int32_t ngen; const int64_t* glen;
+    int32_t q; int64_t ref_len_limit; const int32_t* minsize_by_length; int64_t table_len;
+    SpecRegion* out; uint64_t* out_count; uint64_t out_cap;
+    PM_HD void wave(int64_t w) const {
+        const int64_t a = w - 1, b = w < nrows ? w : -1;
+        const uint32_t kNotClean = 1u | 2u | 4u | 8u | 16u;      // kRowBad | kRowOutside | kRowReverse | kRowDirty | kRowEarly
+        if (a >= 0 && ((aflags[a] & kNotClean) || alon[a] < 5)) return;
+        if (b >= 0 && ((aflags[b] & kNotClean) || alon[b] < 5)) return;
+        if (a < 0 && b < 0) return;
+        for (int side = 0; side < 2; side++) {
+            if (side == 0 ? b < 0 : a < 0) continue;
+            int64_t smin = (int64_t)1 << 40, rstart = 0, rlen = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int lane = (int)__lane_id();
+            for (int j0 = 0; j0 < ngen; j0 += 64) {
+                const int j = j0 + lane;
+                int64_t len = (int64_t)1 << 40, st = 0;
+                if (j < ngen) {
+#else
+            {
+                for (int j = 0; j < ngen; j++) {
+                    int64_t len, st;
+#endif
+                    const int64_t end_a = a >= 0 ? (int64_t)astart[a * ngen + j] + alon[a] : 0;
+                    const int64_t start_b = b >= 0 ? (int64_t)astart[b * ngen + j] : 0;
+                    if (side == 0) { st = a >= 0 ? end_a : 1; len = start_b - 1 - st; }
+                    else {
+                        const int64_t nxt = end_a + 1, size = glen[j];
+                        int64_t p = nxt;
+                        if (nxt < size) p = b >= 0 ? (start_b > nxt ? start_b : nxt) : size;
+                        st = nxt; len = p - 1 - nxt;
+                    }
+                    if (j == 0) { rstart = st; rlen = len; }
+#if defined(__HIP_DEVICE_COMPILE__)
+                }
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const int64_t o = ((int64_t)__shfl_xor((int)(len >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)len, d, 64);
+                    if (o < len) len = o;
+                }
+                if (len < smin) smin = len;
+            }
+            rstart = ((int64_t)__shfl((int)(rstart >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)rstart, 0, 64);
+            rlen = ((int64_t)__shfl((int)(rlen >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)rlen, 0, 64);
+            if (lane != 0) continue;
+#else
+                    if (len < smin) smin = len;
+                }
+            }
+#endif
+            if (smin <= q || smin >= table_len || rlen <= 0 || rlen > ref_len_limit) continue;
+            const uint64_t at = atomic_add64(out_count, 1);
+            if (at < out_cap) out[at] = SpecRegion{GapRef{(int32_t)a, (int32_t)b, side, -1}, rstart, rlen, minsize_by_length[smin], (int32_t)smin};
+        }
+    }
+};
 
 // tid = work unit: which (pair, chunk) it is (off[] = exclusive prefix of the per-pair unit counts)
 struct FillUnits {

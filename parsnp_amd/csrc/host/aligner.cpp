@@ -210,6 +210,7 @@ void Aligner::await_image() {
 }
 
 Aligner::~Aligner() {
+    if (spec_.valid()) { pm_result* r = spec_.get(); if (r) pm_result_free(r); }      // (a speculation nobody took)
     deferred_.pending = false;      // marks nobody waited for are not set for the sake of it
     wait_layout();
     finish_prejudge();
@@ -371,10 +372,75 @@ void Aligner::collect_engine_timing() {
     }
 }
 
+// the per-region views into one engine result (nothing is copied; the views keep the result alive)
+void Aligner::unpack_result(pm_result* res, size_t nregions, bool rows, std::vector<Raw>* out) {
+    std::shared_ptr<pm_result> own(res, pm_result_free);
+    out->clear();
+    out->resize(nregions);
+    const int64_t* off = pm_result_offsets(res);
+    const int32_t* k = pm_result_k(res);
+    const int32_t* lon = pm_result_lon(res);
+    const int32_t* sp = pm_result_sp(res);
+    const uint8_t* fw = pm_result_fwd(res);
+    int32_t* rstart = rows ? pm_result_start(res) : nullptr;
+    uint8_t* rstrand = rows ? pm_result_strand(res) : nullptr;
+    const uint32_t* rflags = rows ? pm_result_flags(res) : nullptr;
+    const bool dirty_known = rows && pm_result_dirty_known(res) != 0;
+    const size_t q = n - 1;
+    for (size_t i = 0; i < nregions; i++) {
+        Raw& r = (*out)[i];
+        size_t a = (size_t)off[i], b = (size_t)off[i + 1];
+        r.k = k + a; r.lon = lon + a;
+        if (rows) { r.start = rstart + a * n; r.strand = rstrand + a * n; r.flags = rflags + a; r.dirty_known = dirty_known; r.row0 = a; }
+        else { r.sp = sp + a * q; r.fwd = fw + a * q; }
+        r.count = b - a;
+        r.owner = own;
+    }
+}
+
+// The recursion's first batch, computed beside the validation of the anchors (include/parsnp_mum.h:
+// pm_multi_mum_batch_spec): right after the anchor call a helper thread asks the engine for the seed regions between
+// anchors it is certain to see accepted untouched -- the device works them out from its resident anchor table and searches
+// them while this thread receives, validates and marks the anchors (~4 ms in which the device would idle).
+// take_speculation() joins; extend_generations() then finds almost every seed region's result waiting (looked up by the
+// two rows and the side) and sends only the rest.  Same bytes either way: a region's result is a pure function of its rows.
+void Aligner::start_speculation(int64_t table) {
+    static const bool off = test_hook("PARSNP_NO_SPECULATIVE_SEEDS") != nullptr;      // test hook: every seed region is requested after the validation
+    if (off || table == 0 || prm.cores < 2 || sharded_) return;
+    std::vector<int32_t>& tab = memory_->mum_minsize;
+    if (tab.empty()) {      // minimum length by shortest region length (the `mums` expression), once per run of the process
+        tab.resize(2048);
+        for (size_t i = 1; i < tab.size(); i++) tab[i] = (int32_t)min_length(false, (long)i);
+        tab[0] = tab[1];      // (a region of length 0 is never kept: q >= 0)
+    }
+    spec_ = std::async(std::launch::async, [this, table, &tab]() -> pm_result* {
+        pm_result* res = nullptr;
+        const int rc = pm_multi_mum_batch_spec(session_, table, (int32_t)prm.q, (int64_t)prm.p, tab.data(), (int64_t)tab.size(), &res);
+        return rc == PM_OK ? res : nullptr;      // (a refusal only means that nothing was computed ahead)
+    });
+}
+void Aligner::take_speculation() {
+    if (!spec_.valid()) return;
+    pm_result* res = spec_.get();
+    if (!res) return;
+    const size_t nreg = (size_t)pm_result_regions(res);
+    const pm_gap_ref* refs = pm_result_spec_refs(res);
+    const int32_t* ms = pm_result_spec_minsize(res);
+    spec_key_.clear(); spec_min_.assign(ms, ms + nreg);
+    for (size_t i = 0; i < nreg; i++) spec_key_.emplace(gap_key(refs[i].prev, refs[i].next, refs[i].side), (int)i);
+    unpack_result(res, nreg, true, &spec_raw_);
+    timing_first_call_ = false;
+    collect_engine_timing();
+    stats.finder_calls++;
+    stats.finder_regions += (long)nreg;
+    stats.spec_regions += (long)nreg;
+}
+
 void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out, bool rows) {
     out->clear();
     out->resize(reqs.size());
     if (reqs.empty()) return;
+    take_speculation();      // (a session is single-threaded: the batch the helper thread asked for has to be in first)
     double t0 = now_s();
     // results as MUM rows built on the device where the provider can (the HIP engine) and every request is its region
     static const bool no_rows = test_hook("PARSNP_NO_DEVICE_ROWS") != nullptr;      // test hook: the host builds the rows from sp / fwd
@@ -453,27 +519,8 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     }
     if (rc != PM_OK) fatal(std::string("multi-MUM engine failed: ") + pm_last_error());
     if (dbg_b) fprintf(stderr, "[run_batch] engine call %.4f s\n", now_s() - tcall);
-    std::shared_ptr<pm_result> own(res, pm_result_free);
-    const int64_t* off = pm_result_offsets(res);
-    const int32_t* k = pm_result_k(res);
-    const int32_t* lon = pm_result_lon(res);
-    const int32_t* sp = pm_result_sp(res);
-    const uint8_t* fw = pm_result_fwd(res);
-    int32_t* rstart = rows ? pm_result_start(res) : nullptr;
-    uint8_t* rstrand = rows ? pm_result_strand(res) : nullptr;
-    const uint32_t* rflags = rows ? pm_result_flags(res) : nullptr;
-    const bool dirty_known = rows && pm_result_dirty_known(res) != 0;
-    const size_t q = n - 1;
     double tu = now_s();
-    for (size_t i = 0; i < reqs.size(); i++) {
-        Raw& r = (*out)[i];
-        size_t a = (size_t)off[i], b = (size_t)off[i + 1];
-        r.k = k + a; r.lon = lon + a;
-        if (rows) { r.start = rstart + a * n; r.strand = rstrand + a * n; r.flags = rflags + a; r.dirty_known = dirty_known; r.row0 = a; }
-        else { r.sp = sp + a * q; r.fwd = fw + a * q; }
-        r.count = b - a;
-        r.owner = own;
-    }
+    unpack_result(res, reqs.size(), rows, out);
     stats.t_unpack += now_s() - tu;
     timing_first_call_ = stats.finder_calls == 0;
     collect_engine_timing();      // the device phase times of this call
@@ -508,6 +555,7 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
             std::vector<Request> one{q};
             std::vector<Raw> raw;
             run_batch(one, &raw, q.plain);
+            if (anchors && raw[0].start) start_speculation(pm_result_table_id(raw[0].owner.get()));
             if (!e) e = cache_put(q, false);
             e->raw = std::move(raw[0]); e->pending = false;
         } else if (!speculative) {
@@ -1552,8 +1600,17 @@ bool Aligner::extend_generations() {
         std::vector<Request> want, all; std::vector<size_t> who;
         const double tf = now_s();
         if (!plain_requests(rs, raw_of, &all)) return false;
+        take_speculation();      // what the engine computed ahead, beside the validation of the anchors
         for (size_t i = 0; i < rs.size(); i++) {
             if ((*raw_of)[i] >= 0) continue;
+            if (!spec_key_.empty() && rs[i].gap_side >= 0) {
+                auto it = spec_key_.find(gap_key(rs[i].gap_prev, rs[i].gap_next, rs[i].gap_side));
+                if (it != spec_key_.end() && spec_min_[(size_t)it->second] == all[i].minsize) {
+                    (*raw_of)[i] = (int)raws.size(); raws.push_back(spec_raw_[(size_t)it->second]);
+                    stats.spec_hits++;
+                    continue;
+                }
+            }
             want.push_back(all[i]); who.push_back(i);
         }
         if (want.empty()) return true;

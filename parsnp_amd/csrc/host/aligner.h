@@ -257,6 +257,7 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     double alg_bytes_kernel = 0;   // the same sum of what THIS engine's event search must move: (m + n)/2 + 64 B per sampled K-mer (run_batch)
     long gap_requests = 0;  // regions whose rows the engine derived from its anchor table (pm_multi_mum_batch_gaps)
     long layout_images = 0; // layouts delivered by the engine as an image (pm_layout_image) instead of marked by the host
+    long spec_regions = 0, spec_hits = 0;   // seed regions the engine computed ahead (pm_multi_mum_batch_spec), and how many of them the recursion asked for
     long finder_calls = 0, finder_regions = 0, regions_processed = 0, cache_hits = 0, cache_misses = 0, spec_rounds = 0;
     // device-side phase times (HIP events, pm_last_timing): summed over every engine call of the step, and of the
     // anchor call alone (the one launch that sees whole genomes)
@@ -282,6 +283,7 @@ struct AlignerMemory {
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
     std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
     std::vector<Mum> pool_store, candidates;         // storage of Aligner::pool / validate_parallel's candidate records between runs
+    std::vector<int32_t> mum_minsize;                // minimum MUM length by shortest region length (start_speculation)
     struct PerThread { Arena<long> rows; Arena<int32_t> irows; Arena<uint8_t> brows; std::vector<long> scratch; };
     std::vector<std::unique_ptr<PerThread>> per_thread;   // rows written by the threads of the generation-parallel replay
     void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); brows.reset(); for (auto& t : per_thread) { t->rows.reset(); t->irows.reset(); t->brows.reset(); } }
@@ -307,6 +309,7 @@ public:
     int random = 0;
     float anchor_time = 0, coarsen_time = 0, random_time = 0, clusters_time = 0, iclusters_time = 0;
     Stats stats;
+    bool sharded_ = false;       // (set by the owner) a rank of a sharded run: every rank makes the same engine calls in the same order, no helper thread
 
     bool find_anchors();       // returns m0 != 0
     bool extend();             // returns !mums.empty()
@@ -356,6 +359,15 @@ private:
     };
     void chunk_requests(const Region& r, int minsize, std::vector<Request>* out);   // the p-chunk loop, :1519-1547
     void run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out, bool rows = false);   // rows: every request is its region (plain)
+    void unpack_result(pm_result* res, size_t nregions, bool rows, std::vector<Raw>* out);
+    // the recursion's first batch computed beside the anchors' validation (aligner.cpp: start_speculation)
+    void start_speculation(int64_t table);
+    void take_speculation();
+    static uint64_t gap_key(int32_t prev, int32_t next, int side) { return ((uint64_t)(uint32_t)prev << 33) | ((uint64_t)(uint32_t)next << 1) | (uint64_t)(side & 1); }
+    std::future<pm_result*> spec_;
+    std::unordered_map<uint64_t, int> spec_key_;
+    std::vector<int32_t> spec_min_;
+    std::vector<Raw> spec_raw_;
     bool rows_mode_ = false, rows_supported_ = true;
     int64_t anchor_table_ = 0;         // id of the engine's resident anchor table that Mum::row / Region::gap_* refer to (0: none)
     bool timing_first_call_ = false;

@@ -153,6 +153,7 @@ StepReport CoreRun::step() {
     const double tm = now_s();
     memory.reset();
     align.reset(new Aligner(genomes, prm, session, &memory));
+    align->sharded_ = shard.world > 1 || shard.rccl;
     r.setup_s = now_s() - ts;
     if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[setup] release of the previous run %.4f s, new state %.4f s\n", tm - ts, now_s() - tm);
     Aligner& a = *align;

@@ -26,6 +26,7 @@ struct HostBackend {
     void* pinned_alloc(size_t n) { return malloc(n ? n : 1); }
     void pinned_free(void* p) { ::free(p); }
     void sync() {}
+    void bind_thread() {}
     void* event_record() { return nullptr; }
     static void event_wait(void*) {}
     void event_release(void*) {}

@@ -1,7 +1,9 @@
-"""Requests derived on the device (include/parsnp_mum.h: pm_multi_mum_batch_gaps): the recursion's seed regions are sent as
-references into the engine's resident anchor table -- 16 bytes per region -- instead of 16 bytes per region and genome.  On the
-CPU the engine's functors run sequentially (tests/emu); the run must use the path (gap_requests > 0), give the bytes of the
-run in which every row travels, and both must be the reference binary's golden."""
+"""Requests derived on the device (include/parsnp_mum.h): the recursion's seed regions are worked out by the engine itself from
+its resident anchor table and searched beside the host's validation of the anchors (pm_multi_mum_batch_spec, a helper thread),
+or -- with that switched off -- sent as references into the table, 16 bytes per region instead of 16 bytes per region and
+genome (pm_multi_mum_batch_gaps).  On the CPU the engine's functors run sequentially (tests/emu); the runs must use the
+paths (spec_hits / gap_requests > 0), give the bytes of the run in which every row travels after the validation, and all
+must be the reference binary's golden."""
 import json
 import os
 import subprocess
@@ -21,7 +23,7 @@ sys.path.insert(0, %r)
 from parsnp_amd.core_api import CoreRun
 r = CoreRun(sys.argv[1], sys.argv[2])
 rep = r.step(); r.write(); r.close()
-print(json.dumps({k: rep[k] for k in ("gap_requests", "layout_images", "finder_calls", "finder_regions", "anchors", "mums", "lcbs")}))
+print(json.dumps({k: rep[k] for k in ("gap_requests", "layout_images", "spec_regions", "spec_hits", "finder_calls", "finder_regions", "anchors", "mums", "lcbs")}))
 """ % ROOT
 
 # the same with the step run three times before the output is written: the runs after the first start on the bitmaps the
@@ -35,7 +37,7 @@ def test_gap_requests_same_bytes(emu, tmp_path, name):
     ref, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), ref, gs)
     got = {}
-    for tag, env in (("gaps", {}), ("rows", {"PARSNP_NO_GAP_REQUESTS": "1"})):
+    for tag, env in (("spec", {}), ("gaps", {"PARSNP_NO_SPECULATIVE_SEEDS": "1"}), ("rows", {"PARSNP_NO_SPECULATIVE_SEEDS": "1", "PARSNP_NO_GAP_REQUESTS": "1"})):
         out = str(tmp_path / tag)
         os.makedirs(out)
         ini = os.path.join(out, "run.ini")
@@ -46,11 +48,14 @@ def test_gap_requests_same_bytes(emu, tmp_path, name):
         assert p.returncode == 0, p.stderr[-2000:]
         got[tag] = (json.loads(p.stdout.strip().splitlines()[-1]), xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")),
                     xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")))
-    assert got["rows"][0]["gap_requests"] == 0
+    assert got["rows"][0]["gap_requests"] == 0 and got["rows"][0]["spec_regions"] == 0 and got["gaps"][0]["spec_regions"] == 0
     if name == "pop6x200k":      # collinear: the seeds lie between anchors that follow each other in every genome
         assert got["gaps"][0]["gap_requests"] > 100
-    assert got["gaps"][1] == got["rows"][1] == E2E[name]["xmfa_md5"]
-    assert got["gaps"][2] == got["rows"][2] == E2E[name]["log"]
+        assert got["spec"][0]["spec_hits"] > 100 and got["spec"][0]["spec_hits"] == got["spec"][0]["spec_regions"]
+    else:                        # rearranged: the host walks its bitmaps; what the engine computed ahead is not asked for
+        assert got["spec"][0]["spec_regions"] > 0
+    assert got["spec"][1] == got["gaps"][1] == got["rows"][1] == E2E[name]["xmfa_md5"]
+    assert got["spec"][2] == got["gaps"][2] == got["rows"][2] == E2E[name]["log"]
 
 
 # The layout after the anchor call as an image built on the device (include/parsnp_mum.h: pm_layout_image) against the host

@@ -220,11 +220,11 @@ def test_parsnp_core_replay_modes_threaded(libs, tmp_path, name, mode):
 
 
 @pytest.mark.parametrize("name", ["rearr6x300k", "poprearr10x400k", "pop20x1m"])
-@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows", "all_rows_travel", "host_order", "mark_first"])
+@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows", "seeds_by_reference", "all_rows_travel", "host_order", "mark_first"])
 def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant):
     """the MUM rows, the cheap overlap flags and the list-order bits come from the device (CompactCandidates,
     DirtyExtent/Prefix/Mark) and feed the threaded anchor validation in place, and the recursion's seed regions are derived on
-    the device from the resident anchor table; switching any of them back to the host, or marking the layout before instead of
+    the device from the resident anchor table and searched beside the validation of the anchors; switching any of them back to the host, or marking the layout before instead of
     after the flagged candidates, must not change a byte.  (parsnp_core_hooks = the product's sources with the test hooks of
     csrc/host/hooks.h compiled in; the shipped binary ignores these switches.)"""
     if name == "poprearr10x400k":
@@ -237,8 +237,10 @@ def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":
         env["PARSNP_NO_DEVICE_ROWS"] = "1"
-    if variant == "all_rows_travel":        # the other variants send the seed regions as references into the resident anchor table
-        env["PARSNP_NO_GAP_REQUESTS"] = "1"
+    if variant == "seeds_by_reference":     # no batch computed ahead beside the validation: the seed regions go as references into the anchor table
+        env["PARSNP_NO_SPECULATIVE_SEEDS"] = "1"
+    if variant == "all_rows_travel":        # ... nor that: every row of every seed region travels
+        env["PARSNP_NO_SPECULATIVE_SEEDS"] = "1"; env["PARSNP_NO_GAP_REQUESTS"] = "1"
     if variant == "host_order":             # the list order from a pass over the rows instead of the device's PM_ROW_EARLY bits
         env["PARSNP_HOST_ORDER"] = "1"
     if variant == "mark_first":             # all marks before the flagged candidates (nothing put off)
