@@ -836,8 +836,13 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             for (size_t c = 0; c < ncand; c++) if ((state[c] & 24) == 16) acc_idx.push_back((uint32_t)c);
             std::vector<uint32_t> flagged_now;
             for (size_t c = 0; c < ncand; c++) if ((state[c] & 11) == 11) flagged_now.push_back((uint32_t)c);
+            lap("lists");
             const long nfl = (long)flagged_now.size();
             const size_t nacc = acc_idx.size();
+            // lengths of the clean candidates (never trimmed): the engine's compact array where there is one, not the 48-byte records
+            std::vector<int32_t> len_store;
+            if (!device_rows) { len_store.resize(ncand); for (size_t c = 0; c < ncand; c++) len_store[c] = (int32_t)cand[c].length; }
+            const int32_t* const len_of = device_rows ? raw.lon : len_store.data();
 #pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
             for (long o = 0; o < nfl; o++) {
                 const uint32_t cf = flagged_now[(size_t)o];
@@ -853,7 +858,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
                 }
                 for (size_t j = 0; j < n; j++) {
                     const long s = f.start[j], e = s + f.length;
-                    auto ends_after = [&](size_t k) { const uint32_t c = acc_idx[k]; return (long)srow[(size_t)c * n + j] + cand[c].length > s; };
+                    auto ends_after = [&](size_t k) { const uint32_t c = acc_idx[k]; return (long)srow[(size_t)c * n + j] + len_of[c] > s; };
                     size_t lo = 0, hi = nacc;                 // the first accepted clean candidate that ends after s (ends rise with the list)
                     if (here < nacc && ends_after(here)) {
                         hi = here;
@@ -876,11 +881,12 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
                         const uint32_t c = acc_idx[k];
                         const long a = srow[(size_t)c * n + j];
                         if (a >= e) break;
-                        layout[j].set_range_atomic(a, a + cand[c].length);
-                        if (image_table) marked_now[(size_t)omp_get_thread_num()].push_back(Span{(int32_t)j, (int32_t)a, (int32_t)cand[c].length});
+                        layout[j].set_range_atomic(a, a + len_of[c]);
+                        if (image_table) marked_now[(size_t)omp_get_thread_num()].push_back(Span{(int32_t)j, (int32_t)a, (int32_t)len_of[c]});
                     }
                 }
             }
+            lap("neighbours");
             deferred_.rows = srow;
             deferred_.length.resize(ncand);
             if (device_rows) memcpy(deferred_.length.data(), raw.lon, ncand * sizeof(int32_t));
@@ -1011,6 +1017,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     if (put_off && image_table)
         image_ask = std::async(std::launch::async, [&, this] {
             ImageAsk a;
+            if (spec_.valid()) spec_.wait();      // (a session is single-threaded: the batch computed ahead has to be back first)
             std::vector<uint8_t> acc(ncand);
             for (size_t c = 0; c < ncand; c++) acc[c] = (state[c] & 24) == 16;
             a.extra_start = std::make_shared<std::vector<int32_t>>();
@@ -1035,6 +1042,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     if (table) anchor_table_ = table;
     pool.resize(pool0 + nacc);
     accepted->resize(acc0 + nacc);
+    lap("resize");
     {
         Mum* const pout = pool.data() + pool0;
         int* const aout = accepted->data() + acc0;
