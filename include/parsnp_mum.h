@@ -156,8 +156,9 @@ int pm_layout_image(pm_session* s, int64_t table_id, const int64_t* nbits, const
 int pm_layout_wait(pm_session* s);
 /* The seed regions of the resident anchor table, worked out ON THE DEVICE and searched in one batch -- callable from a
  * helper thread right after the anchor call, so that the batch runs beside the caller's validation of the anchors: for every
- * two neighbouring rows that carry no verdict or overlap / order flag and are at least 5 long (rows the caller is certain to
- * accept untouched), the left region of the second and the right region of the first (formulas above), kept when longer than
+ * two neighbouring rows that are inside their genomes and at least 5 long (rows the caller will accept as they stand, unless
+ * its own checks of a reverse member or of an overlap with an earlier row say otherwise -- the regions next to such a row are
+ * then a guess the caller does not look at), the left region of the second and the right region of the first (formulas above), kept when longer than
  * q in every genome (src/parsnp.cpp:2158-2170) and at most ref_len_limit long on the reference (one chunk of the p-loop,
  * :1519-1547); minimum length of a region = minsize_by_length[its shortest length] (regions whose shortest length is >=
  * table_len are left to the caller).  pm_result_spec_refs / _minsize [pm_result_regions]: which gap each region of the

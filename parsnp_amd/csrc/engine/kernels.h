@@ -646,7 +646,10 @@ struct GapSeeds {
     SpecRegion* out; uint64_t* out_count; uint64_t out_cap;
     PM_HD void wave(int64_t w) const {
         const int64_t a = w - 1, b = w < nrows ? w : -1;
-        const uint32_t kNotClean = 1u | 2u | 4u | 8u | 16u;      // kRowBad | kRowOutside | kRowReverse | kRowDirty | kRowEarly
+        // (a row with a reverse member, or one that overlaps an earlier row, may still be refused or trimmed by the host: the
+        // regions next to it are a guess then -- the host asks for a region by the two rows it lies between and only where it
+        // left both untouched, so a wrong guess is work nobody looks at, not a wrong answer)
+        const uint32_t kNotClean = 1u | 2u;      // kRowBad | kRowOutside
         if (a >= 0 && ((aflags[a] & kNotClean) || alon[a] < 5)) return;
         if (b >= 0 && ((aflags[b] & kNotClean) || alon[b] < 5)) return;
         if (a < 0 && b < 0) return;

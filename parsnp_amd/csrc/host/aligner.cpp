@@ -404,7 +404,7 @@ void Aligner::unpack_result(pm_result* res, size_t nregions, bool rows, std::vec
 // them while this thread receives, validates and marks the anchors (~4 ms in which the device would idle).
 // take_speculation() joins; extend_generations() then finds almost every seed region's result waiting (looked up by the
 // two rows and the side) and sends only the rest.  Same bytes either way: a region's result is a pure function of its rows.
-void Aligner::start_speculation(int64_t table) {
+void Aligner::start_speculation(int64_t table, int64_t rows) {
     static const bool off = test_hook("PARSNP_NO_SPECULATIVE_SEEDS") != nullptr;      // test hook: every seed region is requested after the validation
     if (off || table == 0 || prm.cores < 2 || sharded_) return;
     std::vector<int32_t>& tab = memory_->mum_minsize;
@@ -413,6 +413,7 @@ void Aligner::start_speculation(int64_t table) {
         for (size_t i = 1; i < tab.size(); i++) tab[i] = (int32_t)min_length(false, (long)i);
         tab[0] = tab[1];      // (a region of length 0 is never kept: q >= 0)
     }
+    spec_rows_ = rows;
     spec_ = std::async(std::launch::async, [this, table, &tab]() -> pm_result* {
         pm_result* res = nullptr;
         const int rc = pm_multi_mum_batch_spec(session_, table, (int32_t)prm.q, (int64_t)prm.p, tab.data(), (int64_t)tab.size(), &res);
@@ -426,8 +427,15 @@ void Aligner::take_speculation() {
     const size_t nreg = (size_t)pm_result_regions(res);
     const pm_gap_ref* refs = pm_result_spec_refs(res);
     const int32_t* ms = pm_result_spec_minsize(res);
-    spec_key_.clear(); spec_min_.assign(ms, ms + nreg);
-    for (size_t i = 0; i < nreg; i++) spec_key_.emplace(gap_key(refs[i].prev, refs[i].next, refs[i].side), (int)i);
+    // looked up by the row a region lies next to: the left region of row `next`, the right region of row `prev` (the other row
+    // is checked at the lookup)
+    spec_min_.assign(ms, ms + nreg);
+    spec_refs_.assign(refs, refs + nreg);
+    spec_at_.assign(2 * (size_t)(spec_rows_ + 1), -1);
+    for (size_t i = 0; i < nreg; i++) {
+        const int64_t row = refs[i].side == 0 ? refs[i].next : refs[i].prev;
+        if (row >= 0 && row < spec_rows_) spec_at_[2 * (size_t)row + (size_t)(refs[i].side & 1)] = (int32_t)i;
+    }
     unpack_result(res, nreg, true, &spec_raw_);
     timing_first_call_ = false;
     collect_engine_timing();
@@ -555,7 +563,7 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
             std::vector<Request> one{q};
             std::vector<Raw> raw;
             run_batch(one, &raw, q.plain);
-            if (anchors && raw[0].start) start_speculation(pm_result_table_id(raw[0].owner.get()));
+            if (anchors && raw[0].start) start_speculation(pm_result_table_id(raw[0].owner.get()), (int64_t)raw[0].count);
             if (!e) e = cache_put(q, false);
             e->raw = std::move(raw[0]); e->pending = false;
         } else if (!speculative) {
@@ -1056,6 +1064,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             m.id = id0 + (long)idrank[(size_t)c];
             m.slength = slen;
             m.dirty = (state[(size_t)c] & 8) != 0;
+            m.touched = m.dirty && (!device_rows || m.length != (long)raw.lon[(size_t)c]);      // (every trim shortens the MUM)
             pout[at] = m;
             aout[at] = (int)(pool0 + at);
         }
@@ -1234,7 +1243,7 @@ bool Aligner::find_anchors() {
             out->slength = s; out->llength = l;
             // both rows as the engine holds them (a candidate that took the ordered pass may have been trimmed here)?
             out->gap_side = -1;
-            if (anchor_table_ != 0 && m.row >= 0 && !m.dirty && (!other || (other->row >= 0 && !other->dirty))) {
+            if (anchor_table_ != 0 && m.row >= 0 && !m.touched && (!other || (other->row >= 0 && !other->touched))) {
                 out->gap_side = left ? 0 : 1;
                 out->gap_prev = left ? (other ? other->row : -1) : m.row;
                 out->gap_next = left ? m.row : (other ? other->row : -1);
@@ -1611,10 +1620,11 @@ bool Aligner::extend_generations() {
         take_speculation();      // what the engine computed ahead, beside the validation of the anchors
         for (size_t i = 0; i < rs.size(); i++) {
             if ((*raw_of)[i] >= 0) continue;
-            if (!spec_key_.empty() && rs[i].gap_side >= 0) {
-                auto it = spec_key_.find(gap_key(rs[i].gap_prev, rs[i].gap_next, rs[i].gap_side));
-                if (it != spec_key_.end() && spec_min_[(size_t)it->second] == all[i].minsize) {
-                    (*raw_of)[i] = (int)raws.size(); raws.push_back(spec_raw_[(size_t)it->second]);
+            if (!spec_at_.empty() && rs[i].gap_side >= 0) {
+                const int64_t row = rs[i].gap_side == 0 ? rs[i].gap_next : rs[i].gap_prev;
+                const int32_t at = row >= 0 && row < spec_rows_ ? spec_at_[2 * (size_t)row + (size_t)rs[i].gap_side] : -1;
+                if (at >= 0 && spec_refs_[(size_t)at].prev == rs[i].gap_prev && spec_refs_[(size_t)at].next == rs[i].gap_next && spec_min_[(size_t)at] == all[i].minsize) {
+                    (*raw_of)[i] = (int)raws.size(); raws.push_back(spec_raw_[(size_t)at]);
                     stats.spec_hits++;
                     continue;
                 }

@@ -213,6 +213,7 @@ struct Mum {
     int32_t* start = nullptr;
     uint8_t* fwd = nullptr;
     bool dirty = false;      // (anchor validation) overlapped an earlier candidate and went through the ordered pass
+    bool touched = false;    // ... and was trimmed there: its row is no longer the one the engine holds
     int32_t row = -1;        // its row in the engine's resident anchor table (pm_result_table_id), where the engine keeps one
     long end(size_t j) const { return (long)start[j] + length; }
 };
@@ -361,11 +362,12 @@ private:
     void run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out, bool rows = false);   // rows: every request is its region (plain)
     void unpack_result(pm_result* res, size_t nregions, bool rows, std::vector<Raw>* out);
     // the recursion's first batch computed beside the anchors' validation (aligner.cpp: start_speculation)
-    void start_speculation(int64_t table);
+    void start_speculation(int64_t table, int64_t rows);
     void take_speculation();
-    static uint64_t gap_key(int32_t prev, int32_t next, int side) { return ((uint64_t)(uint32_t)prev << 33) | ((uint64_t)(uint32_t)next << 1) | (uint64_t)(side & 1); }
     std::future<pm_result*> spec_;
-    std::unordered_map<uint64_t, int> spec_key_;
+    std::vector<int32_t> spec_at_;            // [2 * row + side]: the region of the batch computed ahead that lies left (0) / right (1) of that row, or -1
+    std::vector<pm_gap_ref> spec_refs_;
+    int64_t spec_rows_ = 0;                   // rows of the anchor table the batch was derived from
     std::vector<int32_t> spec_min_;
     std::vector<Raw> spec_raw_;
     bool rows_mode_ = false, rows_supported_ = true;

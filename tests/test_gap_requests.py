@@ -51,7 +51,8 @@ def test_gap_requests_same_bytes(emu, tmp_path, name):
     assert got["rows"][0]["gap_requests"] == 0 and got["rows"][0]["spec_regions"] == 0 and got["gaps"][0]["spec_regions"] == 0
     if name == "pop6x200k":      # collinear: the seeds lie between anchors that follow each other in every genome
         assert got["gaps"][0]["gap_requests"] > 100
-        assert got["spec"][0]["spec_hits"] > 100 and got["spec"][0]["spec_hits"] == got["spec"][0]["spec_regions"]
+        # (the engine also guesses the regions next to rows the host may still refuse or trim: a few of those are never asked for)
+        assert got["spec"][0]["spec_hits"] > 100 and 0 <= got["spec"][0]["spec_regions"] - got["spec"][0]["spec_hits"] <= 8
     else:                        # rearranged: the host walks its bitmaps; what the engine computed ahead is not asked for
         assert got["spec"][0]["spec_regions"] > 0
     assert got["spec"][1] == got["gaps"][1] == got["rows"][1] == E2E[name]["xmfa_md5"]
