@@ -179,6 +179,7 @@ void Aligner::mark_stripe(size_t j0, size_t j1) {
     }
 }
 void Aligner::start_deferred_marks() {
+    settle_image_ask();
     if (!deferred_.pending) return;
     deferred_.pending = false;
     // (half as many tasks as host threads: measured steadier than one per thread -- 27.6-28.1 against 28.5-28.7 ms mean over
@@ -191,6 +192,44 @@ void Aligner::start_deferred_marks() {
             (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
             mark_stripe(n * t / tasks, n * (t + 1) / tasks);
         }));
+}
+// The answer to validate_parallel's request for the layout image.  With it the run goes on with bitmaps attached to the image
+// (every reader awaits the copy: await_image); the set used so far gets its few marks taken back in the background and waits,
+// all zero, for the next run.  Without it the put-off marks are the host's business, as before.
+void Aligner::settle_image_ask() {
+    if (!image_ask_.valid()) return;
+    const double t = now_s();
+    image_ask_.get();
+    std::shared_ptr<ImageAsk> a = image_ask_data_;
+    image_ask_data_.reset();
+    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    if (a->rc != PM_OK) { if (dbg) fprintf(stderr, "[layout] no image (%s): the host marks\n", a->error.c_str()); return; }
+    std::vector<Bitmap>& other = memory_->spare;
+    other.resize(n);
+    size_t off = 0;
+    for (size_t j = 0; j < n; j++) {
+        const size_t words = ((size_t)a->nbits[j] + 63) / 64 + 1;
+        other[j].attach(a->image + off, words, (size_t)a->nbits[j]);
+        off += words;
+    }
+    std::swap(memory_->layout, memory_->spare);       // `layout` is the image from here on
+    deferred_.pending = false;
+    image_pending_ = true;
+    memory_->spare_zero = true;                       // (once the tasks below are through: wait_layout joins them)
+    std::vector<Bitmap>* zero = &memory_->spare;
+    const size_t nn = n, tasks = 4;
+    for (size_t t = 0; t < tasks; t++)
+        layout_ready_.push_back(std::async(std::launch::async, [zero, a, nn, t, tasks] {
+            for (size_t k = t; k < a->marked_now.size(); k += tasks) {
+                const std::vector<int32_t>& v = a->marked_now[k];
+                for (size_t x = 0; x + 2 < v.size(); x += 3) (*zero)[(size_t)v[x]].clear_range_atomic(v[x + 1], (long)v[x + 1] + v[x + 2]);
+            }
+            const size_t nx = a->extra_len.size();
+            for (size_t k = nx * t / tasks; k < nx * (t + 1) / tasks; k++)
+                for (size_t j = 0; j < nn; j++) (*zero)[j].clear_range_atomic(a->extra_start[k * nn + j], (long)a->extra_start[k * nn + j] + a->extra_len[k]);
+        }));
+    stats.layout_images++;
+    if (dbg) fprintf(stderr, "[layout] image taken over %.4f s\n", now_s() - t);
 }
 void Aligner::wait_layout() {
     start_deferred_marks();
@@ -210,6 +249,7 @@ void Aligner::await_image() {
 }
 
 Aligner::~Aligner() {
+    settle_image_ask();             // (an image request nobody took the answer of: the bitmaps must end up in their roles)
     if (spec_.valid()) { pm_result* r = spec_.get(); if (r) pm_result_free(r); }      // (a speculation nobody took)
     deferred_.pending = false;      // marks nobody waited for are not set for the sake of it
     wait_layout();
@@ -409,8 +449,14 @@ void Aligner::start_speculation(int64_t table, int64_t rows) {
     if (off || table == 0 || prm.cores < 2 || sharded_) return;
     std::vector<int32_t>& tab = memory_->mum_minsize;
     if (tab.empty()) {      // minimum length by shortest region length (the `mums` expression), once per run of the process
-        tab.resize(2048);
-        for (size_t i = 1; i < tab.size(); i++) tab[i] = (int32_t)min_length(false, (long)i);
+        // (up to 64 k bases: one seed region in sixty at 200 x 5 Mb is longer than 2 k in every genome, and a region the
+        // table does not cover costs a call of its own)
+        tab.resize(65536);
+        tab[1] = (int32_t)min_length(false, 1);      // (refuses an expression that cannot be evaluated)
+        const long nt = (long)tab.size();
+        const std::string& e = prm.mums;
+#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1)
+        for (long i = 2; i < nt; i++) { int v = 0; (void)min_mum_length(e, i, &v); tab[(size_t)i] = (int32_t)v; }
         tab[0] = tab[1];      // (a region of length 0 is never kept: q >= 0)
     }
     spec_rows_ = rows;
@@ -421,6 +467,7 @@ void Aligner::start_speculation(int64_t table, int64_t rows) {
     });
 }
 void Aligner::take_speculation() {
+    settle_image_ask();      // (its helper waits on the same future)
     if (!spec_.valid()) return;
     pm_result* res = spec_.get();
     if (!res) return;
@@ -1020,28 +1067,33 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // The put-off marks, and everything else of the layout this list leaves, come as an image from the device: the accepted
     // clean candidates are rows of its anchor table; the accepted flagged ones travel with the coordinates trim() left them.
     // Asked for by a helper while this thread writes the MUM records (the engine is not used by anybody else meanwhile).
-    struct ImageAsk { int rc = PM_EINVAL; uint64_t* image = nullptr; std::string error; std::shared_ptr<std::vector<int32_t>> extra_start, extra_len; std::vector<int64_t> nbits; };
-    std::future<ImageAsk> image_ask;
-    if (put_off && image_table)
-        image_ask = std::async(std::launch::async, [&, this] {
-            ImageAsk a;
-            if (spec_.valid()) spec_.wait();      // (a session is single-threaded: the batch computed ahead has to be back first)
-            std::vector<uint8_t> acc(ncand);
-            for (size_t c = 0; c < ncand; c++) acc[c] = (state[c] & 24) == 16;
-            a.extra_start = std::make_shared<std::vector<int32_t>>();
-            a.extra_len = std::make_shared<std::vector<int32_t>>();
-            for (size_t c = 0; c < ncand; c++)
-                if ((state[c] & 8) && place[c] != kNoPlace) {
-                    a.extra_len->push_back((int32_t)cand[c].length);
-                    a.extra_start->insert(a.extra_start->end(), cand[c].start, cand[c].start + n);
-                }
-            a.nbits.resize(n);
-            for (size_t j = 0; j < n; j++) a.nbits[j] = (int64_t)gsize_[j] + 1;
-            a.rc = pm_layout_image(session_, image_table, a.nbits.data(), acc.data(), (int64_t)ncand, a.extra_start->data(), a.extra_len->data(),
-                                   (int64_t)a.extra_len->size(), &a.image);
-            if (a.rc != PM_OK) a.error = pm_last_error();
-            return a;
+    // The engine is asked by a helper thread -- after the batch computed ahead is back, a session takes one call at a time --
+    // and the answer is taken by whoever first needs the layout (settle_image_ask, from wait_layout / start_deferred_marks).
+    if (put_off && image_table) {
+        auto ask = std::make_shared<ImageAsk>();
+        ask->accept.resize(ncand);
+        for (size_t c = 0; c < ncand; c++) ask->accept[c] = (state[c] & 24) == 16;
+        for (size_t c = 0; c < ncand; c++)
+            if ((state[c] & 8) && place[c] != kNoPlace) {
+                ask->extra_len.push_back((int32_t)cand[c].length);
+                ask->extra_start.insert(ask->extra_start.end(), cand[c].start, cand[c].start + n);
+            }
+        ask->nbits.resize(n);
+        for (size_t j = 0; j < n; j++) ask->nbits[j] = (int64_t)gsize_[j] + 1;
+        ask->marked_now.resize(marked_now.size());
+        for (size_t t = 0; t < marked_now.size(); t++) {
+            ask->marked_now[t].reserve(3 * marked_now[t].size());
+            for (const Span& sp : marked_now[t]) { ask->marked_now[t].push_back(sp.j); ask->marked_now[t].push_back(sp.a); ask->marked_now[t].push_back(sp.len); }
+        }
+        image_ask_data_ = ask;
+        const int64_t table_id = image_table;
+        image_ask_ = std::async(std::launch::async, [this, ask, table_id] {
+            if (spec_.valid()) spec_.wait();
+            ask->rc = pm_layout_image(session_, table_id, ask->nbits.data(), ask->accept.data(), (int64_t)ask->accept.size(), ask->extra_start.data(),
+                                      ask->extra_len.data(), (int64_t)ask->extra_len.size(), &ask->image);
+            if (ask->rc != PM_OK) ask->error = pm_last_error();
         });
+    }
     const size_t pool0 = pool.size(), acc0 = accepted->size();
     const long id0 = next_id_;
     // where the engine keeps this list's rows resident (its anchor table), the MUMs remember their row: the seed regions
@@ -1093,39 +1145,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     } else anchors_ordered_ = false;
     if (dbg && put_off) fprintf(stderr, "[validate_parallel] marks of the clean candidates put off\n");
     lap("sequential");
-    // The run goes on with bitmaps attached to the image (every reader awaits it: wait_layout); the set used so far gets its few
-    // marks taken back in the background and waits, all zero, for the next run.
-    if (image_ask.valid()) {
-        ImageAsk a = image_ask.get();
-        if (a.rc == PM_OK) {
-            std::vector<Bitmap>& other = memory_->spare;
-            other.resize(n);
-            size_t off = 0;
-            for (size_t j = 0; j < n; j++) {
-                const size_t words = ((size_t)a.nbits[j] + 63) / 64 + 1;
-                other[j].attach(a.image + off, words, (size_t)a.nbits[j]);
-                off += words;
-            }
-            std::swap(memory_->layout, memory_->spare);       // `layout` is the image from here on
-            deferred_.pending = false;
-            image_pending_ = true;
-            memory_->spare_zero = true;                       // (once the tasks below are through: the next run starts after wait_layout)
-            auto logs = std::make_shared<std::vector<std::vector<Span>>>(std::move(marked_now));
-            std::vector<Bitmap>* zero = &memory_->spare;
-            auto extra_start = a.extra_start; auto extra_len = a.extra_len;
-            const size_t nn = n, tasks = 4;
-            for (size_t t = 0; t < tasks; t++)
-                layout_ready_.push_back(std::async(std::launch::async, [zero, logs, extra_start, extra_len, nn, t, tasks] {
-                    for (size_t k = t; k < logs->size(); k += tasks)
-                        for (const Span& sp : (*logs)[k]) (*zero)[(size_t)sp.j].clear_range_atomic(sp.a, (long)sp.a + sp.len);
-                    const size_t nx = extra_len->size();
-                    for (size_t k = nx * t / tasks; k < nx * (t + 1) / tasks; k++)
-                        for (size_t j = 0; j < nn; j++) (*zero)[j].clear_range_atomic((*extra_start)[k * nn + j], (long)(*extra_start)[k * nn + j] + (*extra_len)[k]);
-                }));
-            stats.layout_images++;
-        } else if (dbg) fprintf(stderr, "[validate_parallel] no layout image (%s): the host marks\n", a.error.c_str());
-        lap("image");
-    }
+    lap("image ask");
 }
 
 // Overlap trimming against already marked bases: from the left, then from the right, genome by genome; every trim

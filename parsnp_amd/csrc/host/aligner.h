@@ -344,6 +344,15 @@ private:
     // neighbour's, and find_anchors() derives the seed regions from the rows instead of walking bitmaps
     bool anchors_ordered_ = false;
     bool image_pending_ = false;              // the layout is an image in flight (pm_layout_image): wait_layout() awaits it
+    // validate_parallel's request for that image, made by a helper thread; settle_image_ask() takes the answer
+    struct ImageAsk {
+        int rc = PM_EINVAL; uint64_t* image = nullptr; std::string error;
+        std::vector<uint8_t> accept; std::vector<int32_t> extra_start, extra_len; std::vector<int64_t> nbits;
+        std::vector<std::vector<int32_t>> marked_now;      // (genome, start, length) of every mark the flagged candidates needed, per thread
+    };
+    std::shared_ptr<ImageAsk> image_ask_data_;
+    std::future<void> image_ask_;
+    void settle_image_ask();
     std::vector<int> judged_pred_;            // chain(): predecessor against which a MUM was last judged, and the verdict
     std::vector<uint8_t> judged_verdict_;
     pm_session* session_;
