@@ -220,10 +220,8 @@ void Aligner::settle_image_ask() {
     const size_t nn = n, tasks = 4;
     for (size_t t = 0; t < tasks; t++)
         layout_ready_.push_back(std::async(std::launch::async, [zero, a, nn, t, tasks] {
-            for (size_t k = t; k < a->marked_now.size(); k += tasks) {
-                const std::vector<int32_t>& v = a->marked_now[k];
-                for (size_t x = 0; x + 2 < v.size(); x += 3) (*zero)[(size_t)v[x]].clear_range_atomic(v[x + 1], (long)v[x + 1] + v[x + 2]);
-            }
+            for (size_t k = t; k < a->marked_now.size(); k += tasks)
+                for (const MarkSpan& sp : a->marked_now[k]) (*zero)[(size_t)sp.j].clear_range_atomic(sp.a, (long)sp.a + sp.len);
             const size_t nx = a->extra_len.size();
             for (size_t k = nx * t / tasks; k < nx * (t + 1) / tasks; k++)
                 for (size_t j = 0; j < nn; j++) (*zero)[j].clear_range_atomic(a->extra_start[k * nn + j], (long)a->extra_start[k * nn + j] + a->extra_len[k]);
@@ -449,9 +447,7 @@ void Aligner::start_speculation(int64_t table, int64_t rows) {
     if (off || table == 0 || prm.cores < 2 || sharded_) return;
     std::vector<int32_t>& tab = memory_->mum_minsize;
     if (tab.empty()) {      // minimum length by shortest region length (the `mums` expression), once per run of the process
-        // (up to 64 k bases: one seed region in sixty at 200 x 5 Mb is longer than 2 k in every genome, and a region the
-        // table does not cover costs a call of its own)
-        tab.resize(65536);
+        tab.resize(8192);
         tab[1] = (int32_t)min_length(false, 1);      // (refuses an expression that cannot be evaluated)
         const long nt = (long)tab.size();
         const std::string& e = prm.mums;
@@ -751,7 +747,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // which are noted and taken back.  PARSNP_HOST_MARKS=1 (test hook): the host's cores mark, as without an anchor table.
     static const bool host_marks = test_hook("PARSNP_HOST_MARKS") != nullptr;
     const int64_t image_table = (device_rows && layout_empty && session_ && raw.row0 == 0 && !host_marks) ? pm_result_table_id(raw.owner.get()) : 0;
-    struct Span { int32_t j, a, len; };
+    typedef MarkSpan Span;
     std::vector<std::vector<Span>> marked_now(image_table ? (size_t)threads : 0);
     for (auto& v : marked_now) v.reserve(ncand / 16 + 4096);
 #pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
@@ -1080,11 +1076,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             }
         ask->nbits.resize(n);
         for (size_t j = 0; j < n; j++) ask->nbits[j] = (int64_t)gsize_[j] + 1;
-        ask->marked_now.resize(marked_now.size());
-        for (size_t t = 0; t < marked_now.size(); t++) {
-            ask->marked_now[t].reserve(3 * marked_now[t].size());
-            for (const Span& sp : marked_now[t]) { ask->marked_now[t].push_back(sp.j); ask->marked_now[t].push_back(sp.a); ask->marked_now[t].push_back(sp.len); }
-        }
+        ask->marked_now = std::move(marked_now);
         image_ask_data_ = ask;
         const int64_t table_id = image_table;
         image_ask_ = std::async(std::launch::async, [this, ask, table_id] {
@@ -1584,6 +1576,7 @@ bool Aligner::extend_generations() {
     std::vector<int> seeds_raw;                   // engine results of the seeds, for the restart
     std::function<void()> before_restart = [] {};
     auto restart_in_order = [&]() {
+        finish_prejudge();
         wait_layout();
         before_restart();
         pool.resize(pool0);
@@ -1686,7 +1679,6 @@ bool Aligner::extend_generations() {
         if (gi == 0) {                           // the first pushed seed, before anything is sorted
             start_deferred_marks();              // the anchors' put-off marks: set while this thread waits for the device
             trouble = !fetch(gen, &gen_raw);     // ... but every seed's engine result in ONE call
-            finish_prejudge();                   // (the anchors' chaining verdicts were worked out beside that call)
             seeds_raw = gen_raw;
             now.push_back(gen.front()); now_raw.push_back(gen_raw.front());
             first = {0, 1};
@@ -1712,6 +1704,7 @@ bool Aligner::extend_generations() {
         if (!trouble && !plain_requests(now, nullptr, &req)) trouble = true;
         lap("requests");
         if (trouble) {
+            finish_prejudge();
             stats.generation_handover = gi;
             file_into_cache(gen, gen_raw);
             if (gi == 0) { regions = std::move(gen); if (speculation_) prefetch(regions); return extend_pass(false); }
@@ -1800,6 +1793,12 @@ bool Aligner::extend_generations() {
         stats.t_validate += now_s() - tv;
         lap("validate");
         stats.generations++; stats.generation_regions += m;
+        {   // the anchors' chaining verdicts are still being worked out from `pool` and `mums` (start_prejudge): joined here only
+            // if the new MUMs would make either vector move
+            size_t more = 0;
+            for (long x = 0; x < m; x++) more += out[(size_t)x].accepted.size();
+            if (pool.size() + more > pool.capacity() || mums.size() + more > mums.capacity()) finish_prejudge();
+        }
         for (long x = 0; x < m; x++) {           // commit in list order
             for (Mum& mm : out[(size_t)x].accepted) { mm.id = next_id_++; pool.push_back(mm); mums.push_back((int)pool.size() - 1); }
             for (Region& k : out[(size_t)x].kids) { gen.push_back(k); gen_raw.push_back(-1); }
@@ -1959,16 +1958,19 @@ uint8_t Aligner::judge_pair(const Mum& nt, const Mum& back) const {
 // The verdict of a pair of MUMs depends on the two alone, and four out of five anchors still follow the same anchor in
 // the final MUM list (the recursion adds one MUM per six anchors).  So the anchors' consecutive pairs are judged while the
 // host would otherwise wait for the recursion's first engine call; chain() reuses a verdict whenever the predecessor of a
-// MUM is still the one it was judged against.  Reads `pool` and `mums` as the anchor search left them: finish_prejudge()
-// is called before anything is added to either.
+// MUM is still the one it was judged against.  Reads the anchors' part of `pool` and `mums`: the generations may append to both
+// meanwhile (room is reserved here), and finish_prejudge() is called before either would move or is reordered.
 void Aligner::start_prejudge() {
     static const size_t min_n = test_hook("PARSNP_PREJUDGE_MIN") ? (size_t)atol(test_hook("PARSNP_PREJUDGE_MIN")) : 4096;   // test hook
     if (mums.size() < min_n || prm.cores < 2) return;
     judged_pred_.assign(pool.size(), -1); judged_verdict_.assign(pool.size(), kClose);
+    // (room for the recursion's MUMs -- one per six anchors at 200 x 5 Mb -- so that the generations can add theirs while the
+    // verdicts are still being worked out: see the commit step of extend_generations)
+    pool.reserve(pool.size() + pool.size() / 2 + 1024); mums.reserve(mums.size() + mums.size() / 2 + 1024);
     // a third of the threads: the engine call it runs beside stages 26 MB of request rows with threads of its own first
     const int team = std::max(2, prm.cores / 3);
-    prejudge_ = std::async(std::launch::async, [this, team] {
-        const long m = (long)mums.size();
+    const long m = (long)mums.size();      // (the list as it stands: the generations append to it meanwhile)
+    prejudge_ = std::async(std::launch::async, [this, team, m] {
 #pragma omp parallel for schedule(dynamic, 1024) num_threads(team)
         for (long x = 1; x < m; x++) {
             const int cur = mums[(size_t)x], prev = mums[(size_t)x - 1];

@@ -345,10 +345,11 @@ private:
     bool anchors_ordered_ = false;
     bool image_pending_ = false;              // the layout is an image in flight (pm_layout_image): wait_layout() awaits it
     // validate_parallel's request for that image, made by a helper thread; settle_image_ask() takes the answer
+    struct MarkSpan { int32_t j, a, len; };               // genome, start, length
     struct ImageAsk {
         int rc = PM_EINVAL; uint64_t* image = nullptr; std::string error;
         std::vector<uint8_t> accept; std::vector<int32_t> extra_start, extra_len; std::vector<int64_t> nbits;
-        std::vector<std::vector<int32_t>> marked_now;      // (genome, start, length) of every mark the flagged candidates needed, per thread
+        std::vector<std::vector<MarkSpan>> marked_now;     // every mark the flagged candidates needed, per thread
     };
     std::shared_ptr<ImageAsk> image_ask_data_;
     std::future<void> image_ask_;
