@@ -146,7 +146,11 @@ int64_t pm_result_table_id(const pm_result* r);
  * so the bitmaps are built on the device and arrive as ONE block: genome j has nbits[j] bits (the caller's choice: its length
  * + 1, the last bit being the sentinel a scan to the right stops at -- set by this call) in 64-bit words
  * [off[j], off[j+1]), off[0] = 0, off[j+1] = off[j] + (nbits[j] + 63) / 64 + 1; bit i = bit (i & 63) of word i >> 6.
- *   accept[c] != 0   row c of the table is marked as it stands: [start, start + length) in every genome
+ *   accept[c] != 0   row c of the table is marked as it stands: [start, start + length) in every genome.  accept == NULL:
+ *                    the engine's own choice, made when the table was -- the rows without PM_ROW_BAD / _OUTSIDE / _DIRTY that
+ *                    are at least 5 long and forward on the reference (what the caller accepts without looking, short of its
+ *                    check of reverse-strand members): the image can then be asked for BEFORE the caller has validated
+ *                    anything, and it puts right what it decides otherwise in the image itself
  *   extra_start [n_extra][n_genomes], extra_len [n_extra]: rows marked besides (the ones the caller trimmed)
  * *image: page-locked memory of the session, written by a copy that runs beside the calls made next; pm_layout_wait()
  * returns when it is complete.  The caller may then write to it; the next pm_layout_image of the session rewrites it, and

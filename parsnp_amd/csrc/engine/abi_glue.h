@@ -155,7 +155,7 @@ const uint8_t* pm_result_fwd(const pm_result* r) { return r->r.fwd(); }
 void pm_result_free(pm_result* r) { delete r; }
 int pm_layout_image(pm_session* s, int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t n_rows,
                     const int32_t* extra_start, const int32_t* extra_len, int64_t n_extra, uint64_t** image) {
-    if (!s || !nbits || !accept || !image || n_rows < 0 || n_extra < 0) return fail(PM_EINVAL, "bad argument");
+    if (!s || !nbits || !image || n_rows < 0 || n_extra < 0) return fail(PM_EINVAL, "bad argument");
     try {
         int rc = s->engine->layout_image(table_id, nbits, accept, n_rows, extra_start, extra_len, n_extra, image);
         if (rc) return fail(rc, s->engine->error);

@@ -618,6 +618,8 @@ public:
                 be.d2d(d_anchor_start.p, d_csp.p, 4 * nokz * ngz);
                 be.d2d(d_anchor_lon.p, d_clon.p, 4 * nokz);
                 be.d2d(d_anchor_flags.p, d_cflags.p, 4 * nokz);
+                ensure(d_anchor_accept, std::max<size_t>(nokz, 1));      // (the overlap flags are in: same condition above)
+                be.launch("anchor_accept", nok, AnchorAccept{d_cflags.p, d_clon.p, d_cfwd.p, ngen, d_anchor_accept.p});
                 anchor_table_rows = nok;
                 out->table_id = anchor_table_id = ++table_counter;
             }
@@ -640,14 +642,15 @@ public:
     }
 
     // ---- the layout after the anchor call, built from the resident anchor table (kernels.h: LayoutMark; pm_layout_image)
-    // accept[c] != 0: row c of the table is marked as it stands; rows the host changed (trimmed) come as extra rows.  The
+    // accept[c] != 0: row c of the table is marked as it stands (accept == nullptr: the rows AnchorAccept chose when the table
+    // was made); rows the host changed (trimmed) come as extra rows.  The
     // image is copied to a page-locked block of the session on a second stream, beside whatever is queued next; the caller
     // reads it after layout_wait().  The block is rewritten by the next call: the previous copy is awaited first.
     int layout_image(int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t nrows, const int32_t* xstart, const int32_t* xlon, int64_t nx,
                      uint64_t** image) {
         be.bind();
         if (table_id == 0 || table_id != anchor_table_id) { error = "the anchor table of this layout is no longer resident"; return -2; }
-        if (nrows != anchor_table_rows || !nbits || !accept || nx < 0 || (nx > 0 && (!xstart || !xlon))) { error = "bad layout request"; return -2; }
+        if (nrows != anchor_table_rows || !nbits || nx < 0 || (nx > 0 && (!xstart || !xlon))) { error = "bad layout request"; return -2; }
         const size_t ngz = (size_t)ngen, nxz = (size_t)nx, nrz = (size_t)nrows;
         std::vector<int64_t> off(ngz + 1, 0);
         for (size_t j = 0; j < ngz; j++) {
@@ -675,21 +678,21 @@ public:
         int32_t* s_xlon = (int32_t*)(s_bits + ngz); int32_t* s_xstart = s_xlon + nxz; uint8_t* s_acc = (uint8_t*)(s_xstart + nxz * ngz);
         memcpy(s_off, off.data(), 8 * (ngz + 1)); memcpy(s_bits, nbits, 8 * ngz);
         if (nxz) { memcpy(s_xlon, xlon, 4 * nxz); memcpy(s_xstart, xstart, 4 * nxz * ngz); }
-        memcpy(s_acc, accept, nrz);
+        if (accept) memcpy(s_acc, accept, nrz);
         ensure(d_image, words); ensure(d_imgoff, ngz + 1); ensure(d_imgbits, ngz); ensure(d_accept, std::max<size_t>(nrz, 1));
         ensure(d_xstart, std::max<size_t>(nxz * ngz, 1)); ensure(d_xlon, std::max<size_t>(nxz, 1));
         be.h2d_staged(d_imgoff.p, s_off, 8 * (ngz + 1)); be.h2d_staged(d_imgbits.p, s_bits, 8 * ngz);
-        be.h2d_staged(d_accept.p, s_acc, nrz);
+        if (accept) be.h2d_staged(d_accept.p, s_acc, nrz);
         if (nxz) { be.h2d_staged(d_xlon.p, s_xlon, 4 * nxz); be.h2d_staged(d_xstart.p, s_xstart, 4 * nxz * ngz); }
         be.memset(d_image.p, 0, 8 * words);
         be.launch("layout_sentinel", (int64_t)ngen, LayoutSentinel{d_imgoff.p, d_imgbits.p, d_image.p});
-        be.launch("layout_mark", nrows * ngen, LayoutMark{d_anchor_start.p, d_anchor_lon.p, d_accept.p, ngen, d_imgoff.p, d_imgbits.p, d_image.p});
+        be.launch("layout_mark", nrows * ngen, LayoutMark{d_anchor_start.p, d_anchor_lon.p, accept ? d_accept.p : d_anchor_accept.p, ngen, d_imgoff.p, d_imgbits.p, d_image.p});
         be.launch("layout_mark", nx * ngen, LayoutMark{d_xstart.p, d_xlon.p, nullptr, ngen, d_imgoff.p, d_imgbits.p, d_image.p});
         be.d2h_side(image_h, d_image.p, 8 * words);
         *image = image_h;
         return 0;
     }
-    void layout_wait() { be.side_wait(); }
+    void layout_wait() { be.bind(); be.side_wait(); }      // (may be called by a helper thread while another call is running)
 
     // small host-side all-gather (calcmumi's per-genome results): through device staging when the collectives are RCCL
     int allgather_host(const void* send, int64_t bytes, void* recv) {
@@ -765,7 +768,7 @@ private:
     Buf<uint32_t> d_cflags, d_dirty; Buf<int32_t> d_bmax, d_bmin;
     Buf<GenomeAtK> d_xsend, d_xrecv; Buf<uint8_t> d_hsend, d_hrecv;
     Buf<RestItem> d_rest; Buf<uint64_t> d_qcount;
-    Buf<int32_t> d_anchor_start, d_anchor_lon; Buf<uint32_t> d_anchor_flags; Buf<GapRef> d_gaps; Buf<int64_t> d_exstarts, d_exlens;
+    Buf<int32_t> d_anchor_start, d_anchor_lon; Buf<uint32_t> d_anchor_flags; Buf<uint8_t> d_anchor_accept; Buf<GapRef> d_gaps; Buf<int64_t> d_exstarts, d_exlens;
     Buf<SpecRegion> d_spec; Buf<uint64_t> d_speccount; Buf<int32_t> d_mintable;
     int64_t table_counter = 0;
     Buf<uint64_t> d_image; Buf<int64_t> d_imgoff, d_imgbits; Buf<uint8_t> d_accept; Buf<int32_t> d_xstart, d_xlon;

@@ -624,6 +624,16 @@ struct LayoutMark {
         }
     }
 };
+// tid = row of the anchor table: will the host accept it as it stands?  What Aligner::validate_parallel calls a clean candidate
+// that settles (src/parsnp.cpp:1781-1833 with nothing to trim): inside its genomes, no overlap with an earlier row, at least 5
+// long, forward on the reference.  (The host may still refuse a row whose reverse-strand members do not spell the reverse
+// complement, :1791-1825: it takes such a row's marks out of the image itself.)
+struct AnchorAccept {
+    const uint32_t* flags; const int32_t* lon; const uint8_t* strand; int32_t ngen; uint8_t* accept;
+    PM_HD void operator()(int64_t c) const {
+        accept[c] = (uint8_t)(!(flags[c] & (1u | 2u | 8u)) && lon[c] >= 5 && strand[c * ngen] != 0);      // kRowBad | kRowOutside | kRowDirty
+    }
+};
 // tid = genome: the bit past the last base (what a scan to the right stops at)
 struct LayoutSentinel {
     const int64_t* word_off; const int64_t* nbits; uint64_t* image;

@@ -193,17 +193,9 @@ void Aligner::start_deferred_marks() {
             mark_stripe(n * t / tasks, n * (t + 1) / tasks);
         }));
 }
-// The answer to validate_parallel's request for the layout image.  With it the run goes on with bitmaps attached to the image
-// (every reader awaits the copy: await_image); the set used so far gets its few marks taken back in the background and waits,
-// all zero, for the next run.  Without it the put-off marks are the host's business, as before.
-void Aligner::settle_image_ask() {
-    if (!image_ask_.valid()) return;
-    const double t = now_s();
-    image_ask_.get();
-    std::shared_ptr<ImageAsk> a = image_ask_data_;
-    image_ask_data_.reset();
-    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
-    if (a->rc != PM_OK) { if (dbg) fprintf(stderr, "[layout] no image (%s): the host marks\n", a->error.c_str()); return; }
+// The run goes on with bitmaps attached to the engine's image; the set used so far gets its few marks (those the flagged
+// candidates needed) taken back in the background and waits, all zero, for the next run.
+void Aligner::adopt_image(std::shared_ptr<ImageAsk> a) {
     std::vector<Bitmap>& other = memory_->spare;
     other.resize(n);
     size_t off = 0;
@@ -217,7 +209,7 @@ void Aligner::settle_image_ask() {
     image_pending_ = true;
     memory_->spare_zero = true;                       // (once the tasks below are through: wait_layout joins them)
     std::vector<Bitmap>* zero = &memory_->spare;
-    const size_t nn = n, tasks = 4;
+    const size_t nn = n, tasks = 2;
     for (size_t t = 0; t < tasks; t++)
         layout_ready_.push_back(std::async(std::launch::async, [zero, a, nn, t, tasks] {
             for (size_t k = t; k < a->marked_now.size(); k += tasks)
@@ -226,6 +218,19 @@ void Aligner::settle_image_ask() {
             for (size_t k = nx * t / tasks; k < nx * (t + 1) / tasks; k++)
                 for (size_t j = 0; j < nn; j++) (*zero)[j].clear_range_atomic(a->extra_start[k * nn + j], (long)a->extra_start[k * nn + j] + a->extra_len[k]);
         }));
+}
+// The answer to validate_parallel's request for the layout image.  With it the run goes on with bitmaps attached to the image
+// (every reader awaits the copy: await_image); the set used so far gets its few marks taken back in the background and waits,
+// all zero, for the next run.  Without it the put-off marks are the host's business, as before.
+void Aligner::settle_image_ask() {
+    if (!image_ask_.valid()) return;
+    const double t = now_s();
+    image_ask_.get();
+    std::shared_ptr<ImageAsk> a = image_ask_data_;
+    image_ask_data_.reset();
+    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    if (a->rc != PM_OK) { if (dbg) fprintf(stderr, "[layout] no image (%s): the host marks\n", a->error.c_str()); return; }
+    adopt_image(a);
     stats.layout_images++;
     if (dbg) fprintf(stderr, "[layout] image taken over %.4f s\n", now_s() - t);
 }
@@ -239,11 +244,30 @@ void Aligner::wait_layout() {
     await_image();
 }
 void Aligner::await_image() {
+    if (image_fix_) {      // (an image asked for ahead: its task, joined by now, awaited the copy and put the host's decisions in)
+        if (image_fix_->rc != PM_OK) fatal("the layout image did not arrive: " + image_fix_->error);
+        image_fix_.reset();
+    }
     if (!image_pending_) return;
     image_pending_ = false;
     const double t = now_s();
     if (pm_layout_wait(session_) != PM_OK) fatal(std::string("the layout image did not arrive: ") + pm_last_error());
     if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[setup] waited %.4f s for the layout image\n", now_s() - t);
+}
+// The layout image asked for BEFORE the anchors are validated (pm_layout_image with the engine's own choice of rows): the copy
+// then runs beside the validation instead of after it.  Only where validate_parallel will take the engine's overlap flags as
+// they are -- then its clean candidates are the engine's choice, short of the reverse-strand check.
+void Aligner::ask_early_image(const Raw& raw) {
+    early_image_ = nullptr;
+    static const bool off = test_hook("PARSNP_HOST_MARKS") || test_hook("PARSNP_HOST_OVERLAP") || test_hook("PARSNP_MARK_FIRST") || test_hook("PARSNP_LATE_IMAGE");
+    static const size_t par_min = test_hook("PARSNP_PARALLEL_MIN") ? (size_t)atol(test_hook("PARSNP_PARALLEL_MIN")) : 4096;
+    if (off || !session_ || !pool.empty() || !raw.start || !raw.dirty_known || raw.row0 != 0 || prm.cores < 2 || raw.count < par_min || layout[0].logging()) return;
+    const int64_t table = pm_result_table_id(raw.owner.get());
+    if (!table) return;
+    early_nbits_.resize(n);
+    for (size_t j = 0; j < n; j++) early_nbits_[j] = (int64_t)gsize_[j] + 1;
+    uint64_t* image = nullptr;
+    if (pm_layout_image(session_, table, early_nbits_.data(), nullptr, (int64_t)raw.count, nullptr, nullptr, 0, &image) == PM_OK) early_image_ = image;
 }
 
 Aligner::~Aligner() {
@@ -606,6 +630,7 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
             std::vector<Request> one{q};
             std::vector<Raw> raw;
             run_batch(one, &raw, q.plain);
+            if (anchors && raw[0].start) ask_early_image(raw[0]);      // (before the helper thread's call: a session takes one call at a time)
             if (anchors && raw[0].start) start_speculation(pm_result_table_id(raw[0].owner.get()), (int64_t)raw[0].count);
             if (!e) e = cache_put(q, false);
             e->raw = std::move(raw[0]); e->pending = false;
@@ -1065,7 +1090,41 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // Asked for by a helper while this thread writes the MUM records (the engine is not used by anybody else meanwhile).
     // The engine is asked by a helper thread -- after the batch computed ahead is back, a session takes one call at a time --
     // and the answer is taken by whoever first needs the layout (settle_image_ask, from wait_layout / start_deferred_marks).
-    if (put_off && image_table) {
+    uint64_t* const early = early_image_;
+    early_image_ = nullptr;      // (an image asked for ahead that this list cannot use -- not put off -- is simply never looked at)
+    if (put_off && early && device_dirty) {
+        auto fix = std::make_shared<ImageAsk>();
+        fix->image = early; fix->nbits = early_nbits_; fix->rc = PM_OK;
+        for (size_t c = 0; c < ncand; c++) {
+            const uint8_t st = state[c];
+            if ((st & 8) && place[c] != kNoPlace) {      // accepted after the ordered pass: marked here, with the coordinates trim() left
+                fix->extra_len.push_back((int32_t)cand[c].length);
+                fix->extra_start.insert(fix->extra_start.end(), cand[c].start, cand[c].start + n);
+            } else if ((st & 11) == 3 && !(st & 16) && raw.lon[c] >= 5 && frow[c * n] != 0) {      // the engine's choice, refused by settle(): unmarked here
+                fix->clear_len.push_back(raw.lon[c]);
+                fix->clear_start.insert(fix->clear_start.end(), cand[c].start, cand[c].start + n);
+            }
+        }
+        fix->marked_now = std::move(marked_now);
+        adopt_image(fix);
+        // (the copy has been running since before the validation: a task awaits it and puts right what the host decided
+        // otherwise, well before the first reader asks -- wait_layout joins it)
+        image_pending_ = false;
+        std::vector<Bitmap>* img = &memory_->layout;
+        pm_session* ses = session_;
+        const size_t nn = n;
+        layout_ready_.push_back(std::async(std::launch::async, [img, fix, ses, nn] {
+            if (pm_layout_wait(ses) != PM_OK) { fix->rc = PM_EHIP; fix->error = pm_last_error(); return; }
+            // rows the engine marked and the host refused (a reverse-strand member that does not spell the reverse complement)
+            // overlap nothing accepted before them, and what was accepted later where they lie is among the rows set next
+            for (size_t k = 0; k < fix->clear_len.size(); k++)
+                for (size_t j = 0; j < nn; j++) (*img)[j].clear_range_atomic(fix->clear_start[k * nn + j], (long)fix->clear_start[k * nn + j] + fix->clear_len[k]);
+            for (size_t k = 0; k < fix->extra_len.size(); k++)
+                for (size_t j = 0; j < nn; j++) (*img)[j].set_range_atomic(fix->extra_start[k * nn + j], (long)fix->extra_start[k * nn + j] + fix->extra_len[k]);
+        }));
+        image_fix_ = fix;      // (wait_layout looks at its verdict)
+        stats.layout_images++;
+    } else if (put_off && image_table) {
         auto ask = std::make_shared<ImageAsk>();
         ask->accept.resize(ncand);
         for (size_t c = 0; c < ncand; c++) ask->accept[c] = (state[c] & 24) == 16;

@@ -349,11 +349,17 @@ private:
     struct ImageAsk {
         int rc = PM_EINVAL; uint64_t* image = nullptr; std::string error;
         std::vector<uint8_t> accept; std::vector<int32_t> extra_start, extra_len; std::vector<int64_t> nbits;
+        std::vector<int32_t> clear_start, clear_len;       // (an image asked for ahead) rows the engine marked and the host refused
         std::vector<std::vector<MarkSpan>> marked_now;     // every mark the flagged candidates needed, per thread
     };
     std::shared_ptr<ImageAsk> image_ask_data_;
     std::future<void> image_ask_;
     void settle_image_ask();
+    void adopt_image(std::shared_ptr<ImageAsk> a);
+    void ask_early_image(const Raw& raw);
+    uint64_t* early_image_ = nullptr;        // the image asked for before the validation of the anchors (ask_early_image)
+    std::vector<int64_t> early_nbits_;
+    std::shared_ptr<ImageAsk> image_fix_;    // ... and what await_image() has to put right in it
     std::vector<int> judged_pred_;            // chain(): predecessor against which a MUM was last judged, and the verdict
     std::vector<uint8_t> judged_verdict_;
     pm_session* session_;

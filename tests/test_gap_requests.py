@@ -68,7 +68,10 @@ def test_layout_image_same_bytes(emu, tmp_path, name):
     ref, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), ref, gs)
     got = {}
-    for tag, env, child in (("image", {}, _CHILD), ("host", {"PARSNP_HOST_MARKS": "1"}, _CHILD), ("image3", {}, _CHILD_REPEAT), ("host3", {"PARSNP_HOST_MARKS": "1"}, _CHILD_REPEAT)):
+    # image: asked for before the validation, the engine choosing the rows, the host putting right what it decides otherwise;
+    # late: asked for after it (PARSNP_LATE_IMAGE=1: the route of a list whose overlap flags the host works out itself)
+    for tag, env, child in (("image", {}, _CHILD), ("late", {"PARSNP_LATE_IMAGE": "1"}, _CHILD), ("host", {"PARSNP_HOST_MARKS": "1"}, _CHILD),
+                            ("image3", {}, _CHILD_REPEAT), ("late3", {"PARSNP_LATE_IMAGE": "1"}, _CHILD_REPEAT), ("host3", {"PARSNP_HOST_MARKS": "1"}, _CHILD_REPEAT)):
         out = str(tmp_path / tag)
         os.makedirs(out)
         ini = os.path.join(out, "run.ini")
@@ -81,6 +84,7 @@ def test_layout_image_same_bytes(emu, tmp_path, name):
     assert got["host"][0]["layout_images"] == 0 and got["host3"][0]["layout_images"] == 0
     if name == "pop6x200k":      # collinear: the accepted anchors lie in list order, the marks are put off -- and come as an image
         assert got["image"][0]["layout_images"] == 1 and got["image3"][0]["layout_images"] == 1
+        assert got["late"][0]["layout_images"] == 1 and got["late3"][0]["layout_images"] == 1
     for tag in got:
         assert got[tag][1] == E2E[name]["xmfa_md5"], tag
         assert got[tag][2] == E2E[name]["log"], tag
