@@ -414,6 +414,8 @@ def main():
                 tj = json.load(open(tpath))
                 if tj.get("so_sha256") == so_sha256() or (tj.get("engine_src_sha256") and tj.get("engine_src_sha256") == engine_src_sha256()):
                     traffic = tj.get("hbm_bytes_per_launch")
+                    if tj.get("hbm_bytes_per_step") and launches:      # (per step on file: divided by THIS run's engine calls per step)
+                        traffic = tj["hbm_bytes_per_step"] / launches
                     traffic_raw = tj.get("raw")
                     traffic_note = tj.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this binary (profiles/%s)" % PROFILE_ROUND)
                 else:

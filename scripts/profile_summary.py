@@ -131,17 +131,27 @@ def main():
         # half its bytes (the guide's gfx950 factor, reproduced by calib_stream16).  The one coalesced stream of this kernel that
         # reaches the fabric is the query pieces (m/2 per pair; the reference windows hit the L2), so the missing half of that
         # stream is added back: corrected = FETCH_SIZE + 0.5 x query-stream bytes + WRITE_SIZE.
+        # (everything per bench STEP first: the passes profile one step, and a step is several engine calls -- anchor, the
+        # batch computed ahead, the leftover regions -- not all of which launch SeedExtend; bench.py divides by its own count)
         qstream = None
+        bench_launches = None
         try:
             bj = [l for l in open(os.path.join(summ, "bench_plain.json")).read().splitlines() if l.startswith("{")][-1]
-            qstream = json.loads(bj)["roofline"].get("alg_query_stream_bytes_per_launch")
+            rl = json.loads(bj)["roofline"]
+            bench_launches = rl.get("launches_per_step")
+            qstream = rl.get("alg_query_stream_bytes_per_launch") * bench_launches
         except Exception as e:   # noqa: BLE001
             print("no bench line for the stream correction:", e)
         corr = 0.5 * qstream if qstream else 0.0
+        n_se = n
+        n = bench_launches or n
+        corr = corr / n
         t = {"kernel": "seed_extend = SeedExtend + SeedRest + SmallPairEvents", "workload": "bact200, the event search of every engine call of one bench step (anchor + recursion)",
              "dispatches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
              "raw": {"FETCH_SIZE": fetch / n, "WRITE_SIZE": write / n},
-             "query_stream_bytes_per_launch": qstream,
+             "seed_extend_dispatches_per_step": n_se, "launches_per_step": n,
+             "hbm_bytes_per_step": fetch + write + corr * n,
+             "query_stream_bytes_per_launch": (qstream / n) if qstream else None,
              "hbm_bytes_per_launch": (fetch + write) / n + corr,
              "correction": "FETCH_SIZE + 0.5 x query-stream bytes (coalesced 16 B/lane streams are tallied at half, calibration.json calib_stream16) + WRITE_SIZE; scattered probes count 64 B per lane and are taken as they are",
              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this binary; fabric-side counters: Infinity-Cache hits included (upper bound of HBM bytes); coalesced query stream corrected x2",
