@@ -261,7 +261,9 @@ void Aligner::ask_early_image(const Raw& raw) {
     early_image_ = nullptr;
     static const bool off = test_hook("PARSNP_HOST_MARKS") || test_hook("PARSNP_HOST_OVERLAP") || test_hook("PARSNP_MARK_FIRST") || test_hook("PARSNP_LATE_IMAGE");
     static const size_t par_min = test_hook("PARSNP_PARALLEL_MIN") ? (size_t)atol(test_hook("PARSNP_PARALLEL_MIN")) : 4096;
-    if (off || !session_ || !pool.empty() || !raw.start || !raw.dirty_known || raw.row0 != 0 || prm.cores < 2 || raw.count < par_min || layout[0].logging()) return;
+    if (off || !session_ || !pool.empty() || !raw.start || !raw.dirty_known || raw.row0 != 0 || prm.cores < 2 || raw.count < par_min) return;
+    wait_layout();      // (the bitmaps of this run are set up in the background: done long ago, joined here)
+    if (layout[0].logging() || layout[0].attached()) return;
     const int64_t table = pm_result_table_id(raw.owner.get());
     if (!table) return;
     early_nbits_.resize(n);
@@ -771,7 +773,9 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // the end of this function): the bitmaps this call works on then only ever hold the marks the flagged candidates need,
     // which are noted and taken back.  PARSNP_HOST_MARKS=1 (test hook): the host's cores mark, as without an anchor table.
     static const bool host_marks = test_hook("PARSNP_HOST_MARKS") != nullptr;
-    const int64_t image_table = (device_rows && layout_empty && session_ && raw.row0 == 0 && !host_marks) ? pm_result_table_id(raw.owner.get()) : 0;
+    // (never while this run works on bitmaps that ARE the engine's block -- a run that started on the image of the previous one
+    // because the other set could not be reused: the two sets must not end up on the same words)
+    const int64_t image_table = (device_rows && layout_empty && session_ && raw.row0 == 0 && !host_marks && !layout[0].attached()) ? pm_result_table_id(raw.owner.get()) : 0;
     typedef MarkSpan Span;
     std::vector<std::vector<Span>> marked_now(image_table ? (size_t)threads : 0);
     for (auto& v : marked_now) v.reserve(ncand / 16 + 4096);
@@ -1092,7 +1096,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     // and the answer is taken by whoever first needs the layout (settle_image_ask, from wait_layout / start_deferred_marks).
     uint64_t* const early = early_image_;
     early_image_ = nullptr;      // (an image asked for ahead that this list cannot use -- not put off -- is simply never looked at)
-    if (put_off && early && device_dirty) {
+    if (put_off && early && device_dirty && image_table) {
         auto fix = std::make_shared<ImageAsk>();
         fix->image = early; fix->nbits = early_nbits_; fix->rc = PM_OK;
         for (size_t c = 0; c < ncand; c++) {
