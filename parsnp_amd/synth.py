@@ -190,6 +190,8 @@ CONFIGS = {
     "pop20x1m": ("population", dict(seed=7, n=1_000_000, n_genomes=20, div=0.02, indel_frac=0.05)),
     "pop6x200k": ("population", dict(seed=9, n=200_000, n_genomes=6, div=0.02, indel_frac=0.05)),
     "rearr6x300k": ("rearranged", dict(seed=11, n=300_000, n_genomes=6, div=0.004, frac=0.15)),
+    # divergent, indel-rich population: one anchor candidate in forty overlaps an earlier one (the flagged / tangled routes of the validation)
+    "pop12x400k": ("population", dict(seed=21, n=400_000, n_genomes=12, div=0.03, indel_frac=0.10)),
     "rearr500": ("pop_rearranged", dict(seed=13, n=5_000_000, n_genomes=500, div=0.05, frac=0.10)),
     "rearr50": ("pop_rearranged", dict(seed=13, n=5_000_000, n_genomes=50, div=0.05, frac=0.10)),   # = the first 50 genomes of rearr500
     "bact2000": ("population", dict(seed=6, n=5_000_000, n_genomes=2000, div=0.02, indel_frac=0.05)),

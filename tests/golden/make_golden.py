@@ -6,7 +6,7 @@ oracle/Makefile).  Run in the build container only:  python tests/golden/make_go
   mers_anchor.npz   G2  candidate list + Master arrays of the MERS anchor pass (47 genomes)
   mumi.json         G4  all.mumi (calcmumi=1) of the reference binary on MERS, the messy multi-contig set and a p-limited set
   e2e.json          G3  XMFA md5, MUM/LCB signature md5 and log counters of the reference binary on
-                        MERS, viral50, pop6x200k, rearr6x300k, pop20x1m (21 x 1 Mb), bact8 (9 x 5 Mb) (inputs: tests/golden/mers_virus.tar.xz / parsnp_amd.synth seeds)
+                        MERS, viral50, pop6x200k, rearr6x300k, pop12x400k, pop20x1m (21 x 1 Mb), bact8 (9 x 5 Mb) (inputs: tests/golden/mers_virus.tar.xz / parsnp_amd.synth seeds)
 """
 import glob
 import json
@@ -68,7 +68,7 @@ def e2e_goldens(tmp, mref, mqs, only=None, e2e=None):
         return make
     # file names matter (##SequenceFile): MERS under its own names, synthetic sets as ref.fna / g%04d.fna
     run("mers", lambda: (mref, mqs))
-    for name in ("viral50", "pop6x200k", "rearr6x300k", "pop20x1m", "bact8", "poprearr10x400k"):   # bact8 takes ~80 s
+    for name in ("viral50", "pop6x200k", "rearr6x300k", "pop12x400k", "pop20x1m", "bact8", "poprearr10x400k"):   # bact8 takes ~80 s
         run(name, synthetic(name))
     run("messy", lambda: synth.messy_set(os.path.join(tmp, "messy")))
     run("pchunk", synthetic("pop6x200k", "pchunk"), partpos=66660)      # 3 reference chunks + the <50 bp tail rule (src/parsnp.cpp:1527-1538)

@@ -31,7 +31,7 @@ print(json.dumps({k: rep[k] for k in ("gap_requests", "layout_images", "spec_reg
 _CHILD_REPEAT = _CHILD.replace("rep = r.step(); r.write()", "r.step(); r.step(); rep = r.step(); r.write()")
 
 
-@pytest.mark.parametrize("name", ["pop6x200k", "rearr6x300k"])
+@pytest.mark.parametrize("name", ["pop6x200k", "rearr6x300k", "pop12x400k"])
 def test_gap_requests_same_bytes(emu, tmp_path, name):
     core_lib = os.path.join(os.path.dirname(emu[0]), "libparsnp_core_emu.so")
     ref, gs = synth.make(name)
@@ -49,10 +49,10 @@ def test_gap_requests_same_bytes(emu, tmp_path, name):
         got[tag] = (json.loads(p.stdout.strip().splitlines()[-1]), xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")),
                     xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")))
     assert got["rows"][0]["gap_requests"] == 0 and got["rows"][0]["spec_regions"] == 0 and got["gaps"][0]["spec_regions"] == 0
-    if name == "pop6x200k":      # collinear: the seeds lie between anchors that follow each other in every genome
+    if name != "rearr6x300k":    # collinear: the seeds lie between anchors that follow each other in every genome
         assert got["gaps"][0]["gap_requests"] > 100
         # (the engine also guesses the regions next to rows the host may still refuse or trim: a few of those are never asked for)
-        assert got["spec"][0]["spec_hits"] > 100 and 0 <= got["spec"][0]["spec_regions"] - got["spec"][0]["spec_hits"] <= 8
+        assert got["spec"][0]["spec_hits"] > 100 and 0 <= got["spec"][0]["spec_regions"] - got["spec"][0]["spec_hits"] <= 32
     else:                        # rearranged: the host walks its bitmaps; what the engine computed ahead is not asked for
         assert got["spec"][0]["spec_regions"] > 0
     assert got["spec"][1] == got["gaps"][1] == got["rows"][1] == E2E[name]["xmfa_md5"]
@@ -62,7 +62,7 @@ def test_gap_requests_same_bytes(emu, tmp_path, name):
 # The layout after the anchor call as an image built on the device (include/parsnp_mum.h: pm_layout_image) against the host
 # marking its own bitmaps (PARSNP_HOST_MARKS=1): same bytes, also when the step is repeated in one process (the bitmaps of
 # the previous run are reused: all zero after an image run, cleared after a host run).
-@pytest.mark.parametrize("name", ["pop6x200k", "rearr6x300k"])
+@pytest.mark.parametrize("name", ["pop6x200k", "rearr6x300k", "pop12x400k"])      # pop12x400k: 166 flagged candidates, 6 of them tangled
 def test_layout_image_same_bytes(emu, tmp_path, name):
     core_lib = os.path.join(os.path.dirname(emu[0]), "libparsnp_core_emu.so")
     ref, gs = synth.make(name)
@@ -82,7 +82,7 @@ def test_layout_image_same_bytes(emu, tmp_path, name):
         got[tag] = (json.loads(p.stdout.strip().splitlines()[-1]), xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")),
                     xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")))
     assert got["host"][0]["layout_images"] == 0 and got["host3"][0]["layout_images"] == 0
-    if name == "pop6x200k":      # collinear: the accepted anchors lie in list order, the marks are put off -- and come as an image
+    if name != "rearr6x300k":    # collinear: the accepted anchors lie in list order, the marks are put off -- and come as an image
         assert got["image"][0]["layout_images"] == 1 and got["image3"][0]["layout_images"] == 1
         assert got["late"][0]["layout_images"] == 1 and got["late3"][0]["layout_images"] == 1
     for tag in got:
