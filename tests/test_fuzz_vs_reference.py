@@ -88,6 +88,23 @@ def test_fuzz_host_logic(cpu_checkers, tmp_path, seed):
     side_by_side(cpu_checkers, seed, tmp_path)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_anchor_table_routes(emu, tmp_path, monkeypatch, seed):
+    """the same side by side for the host code over the kernel emulation, threaded, with the thresholds of the long-list routes
+    lowered so that these small sets take what needs the engine's resident anchor table: requests by reference, the recursion's
+    first batch computed ahead, the layout image (asked for before the validation, its corrections) -- scripts/fuzz_campaign.py
+    with PARSNP_FUZZ_CORE=emu is the long form (684 sets in round 3)"""
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_PREJUDGE_MIN="2", PARSNP_CHECK_ZERO="1").items():
+        monkeypatch.setenv(k, v)
+    ref, gs, kw, contigs = random_case(seed)
+    if kw.get("threads", 1) < 2:
+        kw["threads"] = 3
+    rp, qs = write(str(tmp_path / "in"), ref, gs, contigs, seed)
+    a = run(REFBIN, rp, qs, str(tmp_path / "ref"), kw)
+    b = run(emu[1], rp, qs, str(tmp_path / "mine"), kw)
+    assert a == b, (seed, kw, contigs)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(60))
 def test_fuzz_on_gpu(tmp_path, seed):
