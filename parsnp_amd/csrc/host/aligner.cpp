@@ -632,8 +632,24 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
             std::vector<Request> one{q};
             std::vector<Raw> raw;
             run_batch(one, &raw, q.plain);
-            if (anchors && raw[0].start) ask_early_image(raw[0]);      // (before the helper thread's call: a session takes one call at a time)
-            if (anchors && raw[0].start) start_speculation(pm_result_table_id(raw[0].owner.get()), (int64_t)raw[0].count);
+            // Both bets on what the validation will find are only placed on a list whose acceptable rows lie in list order in
+            // every genome (no PM_ROW_EARLY among them: the same bits validate_parallel reads the order from).  Out of order
+            // -- rearranged genomes -- the marks are not put off and the seed regions come from bitmap walks, not from pairs of
+            // rows: the image would be thrown away and no region of the batch asked for.
+            // (likewise where the running-extent test flags more than one row in eight: validate_parallel then drops the flags
+            // for the exact test -- the sign of rearranged genomes)
+            bool in_order = true;
+            if (anchors && raw[0].start && raw[0].dirty_known) {
+                size_t overlapping = 0;
+                for (size_t c = 0; c < raw[0].count && in_order; c++) {
+                    const uint32_t f = raw[0].flags[c];
+                    overlapping += !(f & PM_ROW_BAD) && (f & PM_ROW_DIRTY);
+                    in_order = !((f & PM_ROW_EARLY) && !(f & (PM_ROW_BAD | PM_ROW_OUTSIDE | PM_ROW_DIRTY)) && raw[0].lon[c] >= 5);
+                }
+                if (overlapping * 8 > raw[0].count) in_order = false;
+            }
+            if (anchors && raw[0].start && in_order) ask_early_image(raw[0]);      // (before the helper thread's call: a session takes one call at a time)
+            if (anchors && raw[0].start && in_order) start_speculation(pm_result_table_id(raw[0].owner.get()), (int64_t)raw[0].count);
             if (!e) e = cache_put(q, false);
             e->raw = std::move(raw[0]); e->pending = false;
         } else if (!speculative) {
