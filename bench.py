@@ -462,6 +462,11 @@ def main():
                 "n_ranks_seen_by_rccl": rccl_ranks, "per_rank": per_rank,
                 "sharded_strong": sharded_strong,
                 "step_ms": step_ms[:40], "host_cores_busy": round(host_cores_busy, 2),
+                # what the engine moved over the host link per step (pm_session_traffic: every copy it issued), and which route the
+                # steps took (resident: MUM rows, layout and regions stayed on the device, parsnp_amd/csrc/host/resident.cpp)
+                "pcie_bytes_per_step": {"h2d": int(sum(r.get("h2d_bytes", 0) for r in reports) / len(reports)),
+                                        "d2h": int(sum(r.get("d2h_bytes", 0) for r in reports) / len(reports))},
+                "resident_route": {"steps": sum(int(r.get("resident", 0)) for r in reports), "left_and_repeated_on_the_host_route": sum(int(r.get("resident_retry", 0)) for r in reports)},
                 "core_bp_aligned": core_bp_total,
                 "core_bp_in_every_partition": merged_bp,
                 "mums": rep["mums"], "anchors": rep["anchors"], "lcbs": rep["lcbs"],

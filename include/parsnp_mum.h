@@ -24,6 +24,7 @@ extern "C" {
 #define PM_ENOMEM (-3)   /* host or device allocation failed */
 #define PM_EHIP (-4)     /* a HIP call or kernel failed */
 #define PM_ELIMIT (-5)   /* a size limit of the engine was exceeded (see pm_limits) */
+#define PM_EAGAIN (-6)   /* the resident route (pm_store_*) does not apply to this input: the caller takes the host route */
 
 typedef struct pm_session pm_session; /* genomes resident in HBM (2-bit + N-mask, both strands) */
 typedef struct pm_result pm_result;   /* output of one batch call, owned by the library until pm_result_free */
@@ -177,8 +178,81 @@ const int32_t* pm_result_spec_minsize(const pm_result* r);
  *                  256 times as much, then PM_ELIMIT)
  *   "dirty_min"    shortest one-region candidate list that gets the overlap / order flags and stays resident as the anchor
  *                  table (default 4096)
+ *   "flagged_div"  pm_store_settle answers PM_EAGAIN when more than one row in flagged_div of the anchor table overlaps an
+ *                  earlier one (default 8, the host route's own threshold for its exact overlap test)
  * PM_EINVAL for an unknown key or a value out of range. */
 int pm_session_tune(pm_session* s, const char* key, int64_t value);
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * The RESIDENT route.  What Aligner does with a candidate list after csgmum produced it -- validation and trimming (second half
+ * of setMums1, src/parsnp.cpp:1713-1841; Aligner::trim :1399-1477), the neighbour regions (determineRegion :1199-1290), the
+ * generations of the work list (doWork :173-317), the pairwise test of the LCB chaining (setFinalClusters :2596-2700) and the
+ * inter-LCB fillers (setInterClusterRegions :2389-2460) -- on rows that never leave the device.  One entry point per reference
+ * function; the order-dependent list logic (work-list order, ties, the chain walk) stays with the caller, which receives a few
+ * bytes per MUM instead of its rows.
+ *
+ * pm_session_rows(s, 2) switches the session to resident mode: the rows of a long one-region result (the anchor call: the
+ * condition of the anchor table, above) stay on the device as rows [0, A) of the session's MUM STORE -- pm_result_start /
+ * _strand of such a result are NULL, pm_result_store_base() is 0 -- and every pm_store_search appends its candidates.  A store
+ * row has, besides the row the search delivered (never rewritten), `shift` (bases trimmed on the left: TMum::trimleft moves the
+ * start in EVERY genome), `len` (current length) and a state.  The layout (mumlayout, :3181-3186) is an image in device memory.
+ * The REGION STORE holds the request rows of seed and child regions.  A later anchor call of the session starts all three over.
+ * Every function returns PM_OK, PM_EAGAIN (the caller falls back to the host route: pm_store_rows(raw) gives it the rows it
+ * did not receive) or an error; a session is single-threaded. */
+#define PM_ST_BUILT 1u      /* the reference constructs a TMum for the candidate (no PM_ROW_BAD) */
+#define PM_ST_OK 2u         /* inside every genome (no PM_ROW_OUTSIDE) */
+#define PM_ST_FLAGGED 4u    /* (anchor list) overlapped an earlier row: settled against the marks of the others */
+#define PM_ST_TANGLED 8u    /* ... and another flagged row: settled in list order */
+#define PM_ST_ACCEPTED 16u  /* a MUM of the run: marked in the layout */
+typedef struct { int32_t start0, len, shift; uint32_t state_flags; } pm_row_info;   /* start on the reference (trim applied), length, left trim, state | PM_ROW_* << 8 */
+typedef struct { int64_t key, ref_start, ref_len; int32_t slength, parent; } pm_region_info;   /* push order, reference column, shortest length, store row of the MUM it lies next to */
+int64_t pm_result_store_base(const pm_result* r);      /* first store row of a result whose rows stayed resident, else -1 */
+/* setMums1, second half, for the anchor table `table_id` into an EMPTY layout (:1781-1841): rows that overlap nothing earlier
+ * are settled and marked at once; the flagged ones (PM_ROW_DIRTY) are trimmed against those marks (Aligner::trim) -- side by
+ * side where they meet no other flagged row, in list order where they do.  rows[c] for every row of the table.  PM_EAGAIN when
+ * more than one row in eight is flagged (rearranged genomes: the exact overlap test of the host route decides). */
+int pm_store_settle(pm_session* s, int64_t table_id, pm_row_info* rows);
+int pm_store_info(pm_session* s, int64_t first, int64_t count, pm_row_info* out);
+/* setInitialClusters' seed regions (:2150-2172): determineRegion on both sides of every accepted anchor (anchors[]: their store
+ * rows in list order), kept when longer than q in every genome.  The kept regions are regions [0, *n_regions) of the region
+ * store; pm_store_new_regions / _ids list them in the reference's push order. */
+int pm_store_seeds(pm_session* s, int64_t table_id, const int32_t* anchors, int64_t n_anchors, int32_t q, int64_t* n_regions);
+const pm_region_info* pm_store_new_regions(const pm_session* s);   /* of the last pm_store_seeds / pm_store_validate, valid until the next */
+const int32_t* pm_store_new_region_ids(const pm_session* s);
+int pm_store_regions_equal(pm_session* s, const int32_t* a, const int32_t* b, int64_t n, uint8_t* same);   /* TRegion operator== (LCR.cpp:48-58) */
+/* pm_multi_mum_batch on the rows of the listed regions; the candidates of region i become store rows
+ * [*first_row + offsets[i], *first_row + offsets[i + 1]) (offsets[n + 1]). */
+int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsize, int64_t n, int64_t* first_row, int64_t* offsets);
+/* One generation of doWork (:173-317).  The caller lists the waiting regions in the reference's order (reference start), with the
+ * store rows of their candidates, cut into clusters (cluster c = regions [cluster_first[c], cluster_first[c + 1])) that it has
+ * found pairwise disjoint in every genome; the clusters are validated side by side, each in order: candidates settled against
+ * the layout and marked (setMums1 second half), the neighbour regions of every new MUM longer than q appended to the region
+ * store (:215-254; pm_store_new_regions lists them parent by parent, in push order; one equal to a region still waiting in its
+ * cluster is dropped as the work list would, :294-306).  *trouble != 0: the reference's order would show (bit 0: a child sorts
+ * before a region still waiting in its cluster; bit 1: a reverse-strand member outside its region) -- the caller must discard
+ * the run and take the host route. */
+int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions,
+                      const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children);
+/* The test of setFinalClusters (:2596-2700) of MUM cur[i] against the open chain's last MUM back[i]: verdict[i] = 0 every
+ * genome's gap lies in [0, d] (min_gap / max_gap: what the ratio test :2693 reads), 1 the chain closes, 2 a reverse-strand
+ * member (the strand rules of :2604-2625 depend on the genome order): the caller judges the pair from its rows. */
+int pm_store_judge(pm_session* s, const int32_t* cur, const int32_t* back, int64_t n, int32_t d, int32_t* min_gap, int32_t* max_gap, uint8_t* verdict);
+int pm_store_unmark(pm_session* s, const int32_t* rows, int64_t n);      /* the MUMs leave the layout (:415-418, :460-466) */
+/* setInterClusterRegions (:2389-2460) for consecutive LCBs (last MUM of one, first MUM of the next): add[i] = 1 a filler is made
+ * -- its rows, [n_genomes] each, follow one another in pm_store_fill_starts / _ends --, 0 none, 2 the reference's bookkeeping
+ * would overrun (:2419-2433). */
+int pm_store_fill(pm_session* s, const int32_t* last_of, const int32_t* first_of_next, int64_t n, uint8_t* add);
+const int64_t* pm_store_fill_starts(const pm_session* s);
+const int64_t* pm_store_fill_ends(const pm_session* s);
+/* Rows for the host (the XMFA writer after the LCBs are final; a caller falling back to the host route): start[i * n_genomes + j]
+ * with the trim applied (raw != 0: as the search delivered it), strand byte.  rows == NULL: store rows [first, first + n). */
+int pm_store_rows(pm_session* s, const int32_t* rows, int64_t first, int64_t n, int raw, int32_t* start, uint8_t* strand);
+/* the layout image: genome j = words [word_off[j], word_off[j + 1]) (word_off[n_genomes + 1] filled in), n_j + 1 bits, returns the
+ * number of words; pm_store_layout copies it out */
+int64_t pm_store_layout_words(pm_session* s, int64_t* word_off);
+int pm_store_layout(pm_session* s, uint64_t* out, int64_t words);
+/* bytes this session has moved over the host link so far (every copy the engine issued, both directions) */
+int pm_session_traffic(const pm_session* s, uint64_t* h2d_bytes, uint64_t* d2h_bytes);
 
 /* calcmumi mode (Aligner::setMumi, src/parsnp.cpp:1869-2115): every query genome ALONE against the reference chunk
  * starts[0],lens[0] (query g: starts[g],lens[g]).  covered[g-1] = number of reference positions covered by the

@@ -145,3 +145,25 @@ int pm_session_create_rccl(pm_session** out, int device, int n_genomes, const ui
     (void)out; (void)device; (void)n_genomes; (void)seqs; (void)lens; (void)rank; (void)world; (void)id; return PM_EINVAL;
 }
 int pm_last_timing(const pm_session* s, int* count, const char** names, float* ms) { (void)s; (void)names; (void)ms; if (count) *count = 0; return PM_OK; }
+
+/* the resident route (pm_store_*) is the HIP engine's: this provider has no MUM store, its callers take the host route */
+int64_t pm_result_store_base(const pm_result* r) { (void)r; return -1; }
+int pm_store_settle(pm_session* s, int64_t table_id, pm_row_info* rows) { (void)s; (void)table_id; (void)rows; return PM_EINVAL; }
+int pm_store_info(pm_session* s, int64_t first, int64_t count, pm_row_info* out) { (void)s; (void)first; (void)count; (void)out; return PM_EINVAL; }
+int pm_store_seeds(pm_session* s, int64_t table_id, const int32_t* anchors, int64_t n_anchors, int32_t q, int64_t* n_regions) { (void)s; (void)table_id; (void)anchors; (void)n_anchors; (void)q; (void)n_regions; return PM_EINVAL; }
+const pm_region_info* pm_store_new_regions(const pm_session* s) { (void)s; return 0; }
+const int32_t* pm_store_new_region_ids(const pm_session* s) { (void)s; return 0; }
+int pm_store_regions_equal(pm_session* s, const int32_t* a, const int32_t* b, int64_t n, uint8_t* same) { (void)s; (void)a; (void)b; (void)n; (void)same; return PM_EINVAL; }
+int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsize, int64_t n, int64_t* first_row, int64_t* offsets) { (void)s; (void)regions; (void)minsize; (void)n; (void)first_row; (void)offsets; return PM_EINVAL; }
+int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions, const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children) {
+    (void)s; (void)regions; (void)row_first; (void)row_count; (void)n_regions; (void)cluster_first; (void)n_clusters; (void)q; (void)trouble; (void)n_children; return PM_EINVAL;
+}
+int pm_store_judge(pm_session* s, const int32_t* cur, const int32_t* back, int64_t n, int32_t d, int32_t* min_gap, int32_t* max_gap, uint8_t* verdict) { (void)s; (void)cur; (void)back; (void)n; (void)d; (void)min_gap; (void)max_gap; (void)verdict; return PM_EINVAL; }
+int pm_store_unmark(pm_session* s, const int32_t* rows, int64_t n) { (void)s; (void)rows; (void)n; return PM_EINVAL; }
+int pm_store_fill(pm_session* s, const int32_t* last_of, const int32_t* first_of_next, int64_t n, uint8_t* add) { (void)s; (void)last_of; (void)first_of_next; (void)n; (void)add; return PM_EINVAL; }
+const int64_t* pm_store_fill_starts(const pm_session* s) { (void)s; return 0; }
+const int64_t* pm_store_fill_ends(const pm_session* s) { (void)s; return 0; }
+int pm_store_rows(pm_session* s, const int32_t* rows, int64_t first, int64_t n, int raw, int32_t* start, uint8_t* strand) { (void)s; (void)rows; (void)first; (void)n; (void)raw; (void)start; (void)strand; return PM_EINVAL; }
+int64_t pm_store_layout_words(pm_session* s, int64_t* word_off) { (void)s; (void)word_off; return 0; }
+int pm_store_layout(pm_session* s, uint64_t* out, int64_t words) { (void)s; (void)out; (void)words; return PM_EINVAL; }
+int pm_session_traffic(const pm_session* s, uint64_t* h2d_bytes, uint64_t* d2h_bytes) { (void)s; if (h2d_bytes) *h2d_bytes = 0; if (d2h_bytes) *d2h_bytes = 0; return PM_OK; }

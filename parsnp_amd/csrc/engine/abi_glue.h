@@ -14,6 +14,8 @@ struct pm_session {
     std::unique_ptr<pm::Engine<PmBackend>> engine;
     std::vector<pm::PhaseTime> timing;
     float call_wall_ms = 0;
+    std::vector<pm::RegInfo> new_regions; std::vector<int32_t> new_region_ids;      // pm_store_seeds / pm_store_validate
+    std::vector<int64_t> fill_starts, fill_ends;                                    // pm_store_fill
 };
 struct pm_result { pm::BatchResult r; };
 
@@ -173,7 +175,108 @@ int pm_session_tune(pm_session* s, const char* key, int64_t value) {
     if (!s || !key) return fail(PM_EINVAL, "bad argument");
     return s->engine->tune(key, value) ? PM_OK : fail(PM_EINVAL, std::string("unknown tunable or bad value: ") + key);
 }
-int pm_session_rows(pm_session* s, int enable) { if (!s) return fail(PM_EINVAL, "bad argument"); s->engine->want_rows = enable != 0; return PM_OK; }
+int pm_session_rows(pm_session* s, int enable) {
+    if (!s || enable < 0 || enable > 2) return fail(PM_EINVAL, "bad argument");
+    if (enable == 2 && (s->engine->coll.world > 1 || s->engine->coll.device)) return fail(PM_EINVAL, "a sharded session has no resident mode");
+    s->engine->want_rows = enable != 0; s->engine->resident = enable == 2;
+    return PM_OK;
+}
+int64_t pm_result_store_base(const pm_result* r) { return r ? r->r.store_base : -1; }
+
+// the resident route: one engine method per entry point (engine_core.h)
+#define PM_STORE_CALL(expr)                                                                                                             \
+    try {                                                                                                                               \
+        const auto w0 = std::chrono::steady_clock::now();                                                                               \
+        const int rc = (expr);                                                                                                          \
+        if (rc) return fail(rc, s->engine->error);                                                                                      \
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());                                                               \
+        s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();                      \
+        return PM_OK;                                                                                                                   \
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");                                                 \
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
+static_assert(sizeof(pm_row_info) == sizeof(pm::RowInfo) && sizeof(pm_region_info) == sizeof(pm::RegInfo), "resident-route records");
+static_assert(PM_EAGAIN == pm::Engine<PmBackend>::kAgain, "PM_EAGAIN");
+int pm_store_settle(pm_session* s, int64_t table_id, pm_row_info* rows) {
+    if (!s || !rows) return fail(PM_EINVAL, "bad argument");
+    PM_STORE_CALL(s->engine->store_settle(table_id, (pm::RowInfo*)rows))
+}
+int pm_store_info(pm_session* s, int64_t first, int64_t count, pm_row_info* out) {
+    if (!s || (count > 0 && !out)) return fail(PM_EINVAL, "bad argument");
+    PM_STORE_CALL(s->engine->store_info(first, count, (pm::RowInfo*)out))
+}
+int pm_store_seeds(pm_session* s, int64_t table_id, const int32_t* anchors, int64_t n_anchors, int32_t q, int64_t* n_regions) {
+    if (!s || n_anchors < 0 || (n_anchors > 0 && !anchors) || !n_regions) return fail(PM_EINVAL, "bad argument");
+    *n_regions = 0;
+    try {
+        const int rc = s->engine->store_seeds(table_id, anchors, n_anchors, q, &s->new_regions, &s->new_region_ids);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        *n_regions = (int64_t)s->new_regions.size();
+        return PM_OK;
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
+}
+const pm_region_info* pm_store_new_regions(const pm_session* s) { return s ? (const pm_region_info*)s->new_regions.data() : nullptr; }
+const int32_t* pm_store_new_region_ids(const pm_session* s) { return s ? s->new_region_ids.data() : nullptr; }
+int pm_store_regions_equal(pm_session* s, const int32_t* a, const int32_t* b, int64_t n, uint8_t* same) {
+    if (!s || n < 0 || (n > 0 && (!a || !b || !same))) return fail(PM_EINVAL, "bad argument");
+    PM_STORE_CALL(s->engine->store_regions_equal(a, b, n, same))
+}
+int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsize, int64_t n, int64_t* first_row, int64_t* offsets) {
+    if (!s || n < 0 || (n > 0 && (!regions || !minsize)) || !first_row || !offsets) return fail(PM_EINVAL, "bad argument");
+    PM_STORE_CALL(s->engine->store_search(regions, minsize, n, first_row, offsets))
+}
+int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions,
+                      const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children) {
+    if (!s || n_regions < 0 || n_clusters < 0 || (n_regions > 0 && (!regions || !row_first || !row_count || !cluster_first)) || !trouble || !n_children) return fail(PM_EINVAL, "bad argument");
+    *n_children = 0;
+    try {
+        const auto w0 = std::chrono::steady_clock::now();
+        const int rc = s->engine->store_validate(regions, row_first, row_count, n_regions, cluster_first, n_clusters, q, trouble, &s->new_regions, &s->new_region_ids);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        *n_children = (int64_t)s->new_regions.size();
+        return PM_OK;
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
+}
+int pm_store_judge(pm_session* s, const int32_t* cur, const int32_t* back, int64_t n, int32_t d, int32_t* min_gap, int32_t* max_gap, uint8_t* verdict) {
+    if (!s || n < 0 || (n > 0 && (!cur || !back || !min_gap || !max_gap || !verdict))) return fail(PM_EINVAL, "bad argument");
+    PM_STORE_CALL(s->engine->store_judge(cur, back, n, d, min_gap, max_gap, verdict))
+}
+int pm_store_unmark(pm_session* s, const int32_t* rows, int64_t n) {
+    if (!s || n < 0 || (n > 0 && !rows)) return fail(PM_EINVAL, "bad argument");
+    PM_STORE_CALL(s->engine->store_unmark(rows, n))
+}
+int pm_store_fill(pm_session* s, const int32_t* last_of, const int32_t* first_of_next, int64_t n, uint8_t* add) {
+    if (!s || n < 0 || (n > 0 && (!last_of || !first_of_next || !add))) return fail(PM_EINVAL, "bad argument");
+    PM_STORE_CALL(s->engine->store_fill(last_of, first_of_next, n, add, &s->fill_starts, &s->fill_ends))
+}
+const int64_t* pm_store_fill_starts(const pm_session* s) { return s ? s->fill_starts.data() : nullptr; }
+const int64_t* pm_store_fill_ends(const pm_session* s) { return s ? s->fill_ends.data() : nullptr; }
+int pm_store_rows(pm_session* s, const int32_t* rows, int64_t first, int64_t n, int raw, int32_t* start, uint8_t* strand) {
+    if (!s || n < 0 || (n > 0 && (!start || !strand))) return fail(PM_EINVAL, "bad argument");
+    PM_STORE_CALL(s->engine->store_rows(rows, first, n, raw != 0, start, strand))
+}
+int64_t pm_store_layout_words(pm_session* s, int64_t* word_off) {
+    if (!s) return 0;
+    try {
+        const int64_t w = (int64_t)s->engine->layout_geometry();
+        if (word_off) for (size_t j = 0; j < s->engine->lay_off_h.size(); j++) word_off[j] = s->engine->lay_off_h[j];
+        return w;
+    } catch (...) { return 0; }
+}
+int pm_store_layout(pm_session* s, uint64_t* out, int64_t words) {
+    if (!s || !out) return fail(PM_EINVAL, "bad argument");
+    PM_STORE_CALL(s->engine->store_layout(out, words))
+}
+int pm_session_traffic(const pm_session* s, uint64_t* h2d_bytes, uint64_t* d2h_bytes) {
+    if (!s) return PM_EINVAL;
+    if (h2d_bytes) *h2d_bytes = s->backend->bytes_h2d;
+    if (d2h_bytes) *d2h_bytes = s->backend->bytes_d2h;
+    return PM_OK;
+}
 int32_t* pm_result_start(pm_result* r) { return r->r.start(); }
 uint8_t* pm_result_strand(pm_result* r) { return r->r.strand(); }
 const uint32_t* pm_result_flags(const pm_result* r) { return r->r.flags(); }
@@ -230,6 +333,11 @@ int pm_last_timing(const pm_session* cs, int* count, const char** names, float* 
     if (s->call_wall_ms > 0) s->timing.push_back(pm::PhaseTime{"call_wall", s->call_wall_ms});
     if (s->engine->budget_retries) s->timing.push_back(pm::PhaseTime{"budget_retries", (float)s->engine->budget_retries});   // a count, not a time
     s->timing.push_back(pm::PhaseTime{"rest_samples", (float)s->engine->last_rest});      // samples SeedExtend handed to SeedRest
+    if (s->engine->last_alg[0] > 0) {      // a search of store regions: its algorithmic bytes (counts as well; the caller never held the rows)
+        s->timing.push_back(pm::PhaseTime{"alg_survey", (float)s->engine->last_alg[0]});
+        s->timing.push_back(pm::PhaseTime{"alg_kernel", (float)s->engine->last_alg[1]});
+        s->timing.push_back(pm::PhaseTime{"alg_query", (float)s->engine->last_alg[2]});
+    }
     s->timing.push_back(pm::PhaseTime{"events", (float)s->engine->last_events});      // a count too: R-unique maximal matches the event search appended (16 B each)
     int capn = *count, n = 0;
     for (const auto& t : s->timing) { if (n < capn) { names[n] = t.name; ms[n] = t.ms; } n++; }

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "store_kernels.h"
 
 namespace pm {
 
@@ -52,6 +53,7 @@ struct BatchResult {
     HostPool::Block startb, strandb, flagsb; // int32 start[total*(nq+1)], uint8 strand[total*(nq+1)], uint32 flags[total]
     bool rows = false, dirty_known = false;  // dirty_known: the kRowDirty bits were computed (one-region batch with a long list)
     int64_t table_id = 0;                    // != 0: the rows of this result stay on the device as the session's anchor table (run_gaps)
+    int64_t store_base = -1;                 // resident mode: the result's rows are rows [store_base, store_base + total) of the session's MUM store (no start / strand blocks)
     std::vector<GapRef> spec_refs;           // run_spec: which gap of the anchor table each region of this result is ...
     std::vector<int32_t> spec_minsize;       // ... and the minimum length it was searched with
     std::shared_ptr<HostPool> pool;
@@ -99,6 +101,8 @@ public:
     std::string error;
     std::vector<PhaseTime> timing;
     int64_t last_events = 0, last_candidates = 0, last_rest = 0;
+    double last_alg[3] = {0, 0, 0};      // last search of store regions: SURVEY 8d bytes, this engine's bytes, query-stream bytes (AlgBytes)
+    uint64_t alg_raw[3] = {0, 0, 0};
 
     int ngen = 0;
     bool want_rows = false;           // pm_session_rows: results as MUM rows (start, strand, flags) instead of (sp, fwd)
@@ -171,11 +175,12 @@ public:
         const GapRef* gaps = nullptr;                         // [nreg]
         const int64_t* ref_start = nullptr; const int64_t* ref_len = nullptr;   // [nreg]: the reference column of every region (sizes the index)
         int64_t n_explicit = 0; const int64_t* ex_starts = nullptr; const int64_t* ex_lens = nullptr;   // [n_explicit][ngen]
+        const int32_t* store_ids = nullptr;                   // [nreg]: the regions are rows of the session's region store (resident route): gaps / explicit rows unused
     };
     int run(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events = false,
             bool mumi = false, const GapBatch* gb = nullptr) {
         budget_exceeded = false;
-        if (gb && (gb->table_id == 0 || gb->table_id != anchor_table_id)) { error = "the anchor table of these gap requests is no longer resident"; return -2; }
+        if (gb && !gb->store_ids && (gb->table_id == 0 || gb->table_id != anchor_table_id)) { error = "the anchor table of these gap requests is no longer resident"; return -2; }
         int rc = run_once(nreg, starts, lens, minsize, out, want_events, mumi, gb);
         if (rc == -5 && budget_exceeded && work_budget < ((int64_t)1 << 40)) {
             const int64_t keep = work_budget;
@@ -237,7 +242,8 @@ public:
         const size_t nrow = (size_t)nreg * (size_t)ngen;
         const size_t regz = (size_t)nreg;
         const size_t bytes_R = sizeof(RegionInfo) * regz, bytes_pre = 8 * (regz + 1);
-        const size_t nrow_staged = gb ? (size_t)gb->n_explicit * (size_t)ngen : nrow;
+        const bool from_store = gb && gb->store_ids;
+        const size_t nrow_staged = gb ? (from_store ? 0 : (size_t)gb->n_explicit * (size_t)ngen) : nrow;
         uint8_t* block = (uint8_t*)be.staging(bytes_R + 2 * bytes_pre + 16 * nrow_staged + (gb ? sizeof(GapRef) * regz : 0) + 64);
         if (!block) { error = "cannot allocate the request staging block"; return -3; }
         RegionInfo* R = (RegionInfo*)block;
@@ -246,7 +252,15 @@ public:
         int64_t* stage = cbase + regz + 1;
         std::vector<size_t> guess_r(regz, 0);
         std::vector<int64_t> units_r(regz, 0);
-        if (gb) {
+        if (from_store) {
+            for (int64_t r = 0; r < nreg; r++) {
+                if (gb->store_ids[r] < 0 || gb->store_ids[r] >= rg_count) { error = "region outside the region store"; return -2; }
+                if (gb->ref_start[r] < 0 || gb->ref_len[r] < 0 || gb->ref_start[r] + gb->ref_len[r] > glen_h[0]) { error = "region outside its genome"; return -2; }
+                if (gb->ref_len[r] >= (1ll << 31)) { error = "region longer than 2^31"; return -5; }
+            }
+            static_assert(sizeof(GapRef) >= sizeof(int32_t), "staging room");
+            memcpy(stage, gb->store_ids, sizeof(int32_t) * regz);
+        } else if (gb) {
             if (gb->n_explicit < 0 || (gb->n_explicit > 0 && (!gb->ex_starts || !gb->ex_lens))) { error = "bad explicit rows"; return -2; }
             for (int64_t r = 0; r < nreg; r++) {
                 const GapRef& g = gb->gaps[r];
@@ -352,6 +366,10 @@ public:
         if (!gb) {
             be.h2d_staged(d_starts.p, stage, sizeof(int64_t) * nrow);
             be.h2d_staged(d_lens.p, stage + nrow, sizeof(int64_t) * nrow);
+        } else if (from_store) {
+            ensure(d_list, regz);
+            be.h2d_staged(d_list.p, stage, sizeof(int32_t) * regz);
+            be.launch("gather_regions", (int64_t)nrow, GatherRegions{d_list.p, ngen, d_rg_start.p, d_rg_len.p, d_starts.p, d_lens.p});
         } else {
             ensure(d_exstarts, std::max<size_t>(nrow_staged, 1)); ensure(d_exlens, std::max<size_t>(nrow_staged, 1)); ensure(d_gaps, regz);
             if (nrow_staged) { be.h2d_staged(d_exstarts.p, stage, 8 * nrow_staged); be.h2d_staged(d_exlens.p, stage + nrow_staged, 8 * nrow_staged); }
@@ -370,6 +388,15 @@ public:
         ensure(d_epm, (size_t)std::max<int64_t>(npos, 1) + 1);     // + the verdict word of a sharded run
         be.memset(d_slots.p, 0xff, sizeof(uint64_t) * (size_t)tsize);
         be.memset(d_counter.p, 0, 8 * ncounter);
+        // rows the device derived itself (gaps of the anchor table, rows of the region store) were never seen by the host: the
+        // same checks the explicit rows get above, raised through the batch's error word
+        if (gb) be.launch("check_rows", (int64_t)nrow, CheckRows{d_R.p, d_starts.p, d_lens.p, ngen, d_glen, d_err});
+        last_alg[0] = last_alg[1] = last_alg[2] = 0;
+        if (from_store) {      // the algorithmic bytes of a search whose rows the host never saw (read back with the event counters)
+            ensure(d_alg, 4);
+            be.memset(d_alg.p, 0, 32);
+            be.launch_wave("alg_bytes", (nreg * nq + 63) / 64, AlgBytes{d_R.p, d_lens.p, ngen, nreg * nq, d_alg.p});
+        }
         be.mark("index");
         be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p, d_filter.p});
         be.mark("repeat");
@@ -424,6 +451,7 @@ public:
             be.mark("sort");
             be.launch_wave("slice_offsets", 1, SliceOffsets{d_counter.p, d_sliceoff.p});
             be.d2h_async(qcounts.data(), d_qcount.p, 8 * qcounts.size());
+            if (from_store) be.d2h_async(alg_raw, d_alg.p, 24);
             be.d2h(counts.data(), d_counter.p, 8 * counts.size());            // round trip 1: event counts + error word (+ the queues' lengths)
             uint64_t worst = 0, qworst = 0;
             nev = 0; nrest = 0;
@@ -435,9 +463,11 @@ public:
             if (worst <= slice_cap && qworst <= queue_cap) break;
             if (worst > slice_cap) slice_cap = (size_t)(worst + worst / 8 + 64);
             if (qworst > queue_cap) queue_cap = (size_t)(qworst + qworst / 8 + 64);
-            sticky |= errbits & kErrWork;      // (RepeatLength's verdict: the word is cleared with the counters)
+            sticky |= errbits & (kErrWork | kErrRows);      // (RepeatLength's and CheckRows' verdicts: the word is cleared with the counters)
         }
         errbits |= sticky;
+        if (from_store) { last_alg[0] = (double)alg_raw[0] / 4.0; last_alg[1] = (double)alg_raw[1] / 2.0; last_alg[2] = (double)alg_raw[2] / 2.0; }
+        if (errbits & kErrRows) { error = "region outside its genome"; return -2; }
         rest_cap_hint[nreg == 1] = queue_cap;
         last_rest = (int64_t)nrest;
         ev_cap_hint = (size_t)(nev + nev / 4);
@@ -529,7 +559,7 @@ public:
         if (verdict < 0) { budget_exceeded = true; error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
         const uint64_t ncand = (uint64_t)ncand_i;
         last_candidates = (int64_t)ncand;
-        if (ncand == 0) { be.mark(nullptr); collect_timing(); return 0; }
+        if (ncand == 0) { if (resident && from_store) out->store_base = ms_count; be.mark(nullptr); collect_timing(); return 0; }
         ensure(d_cand, (size_t)ncand);
         be.launch("cand_write", nwv * 64, CandWrite{d_R.p, nreg, d_posbase.p, d_wmask.p, d_woff.p, d_cand.p, ncand});
         const uint64_t* scand = d_cand.p;        // in (region, k) order by construction
@@ -613,21 +643,39 @@ public:
                 be.launch("dirty_merge", nok, DirtyMerge{d_dirty.p, d_cflags.p});
                 out->dirty_known = true;
             }
-            if (nreg == 1 && !gb && nok >= dirty_min) {      // a long list of one region (the anchor call): its rows stay on the device as the session's anchor table (run(..., gb))
-                ensure(d_anchor_start, std::max<size_t>(nokz * ngz, 1)); ensure(d_anchor_lon, std::max<size_t>(nokz, 1)); ensure(d_anchor_flags, std::max<size_t>(nokz, 1));
-                be.d2d(d_anchor_start.p, d_csp.p, 4 * nokz * ngz);
-                be.d2d(d_anchor_lon.p, d_clon.p, 4 * nokz);
-                be.d2d(d_anchor_flags.p, d_cflags.p, 4 * nokz);
-                ensure(d_anchor_accept, std::max<size_t>(nokz, 1));      // (the overlap flags are in: same condition above)
-                be.launch("anchor_accept", nok, AnchorAccept{d_cflags.p, d_clon.p, d_cfwd.p, ngen, d_anchor_accept.p});
-                anchor_table_rows = nok;
-                out->table_id = anchor_table_id = ++table_counter;
+            // Resident mode (pm_session_rows(s, 2)): the rows of the anchor call, and of every search of regions of the region store,
+            // stay on the device as rows of the MUM store -- the host receives the per-row scalars only (flags, k, length)
+            const bool anchor_call = nreg == 1 && !gb && nok >= dirty_min;
+            const bool keep_rows = resident && (anchor_call || from_store);
+            if (anchor_call || keep_rows) {      // (the anchor call: its rows are the session's anchor table = rows [0, A) of the store)
+                if (anchor_call) { ms_count = 0; rg_count = 0; layout_rows = -1; }
+                const size_t base = (size_t)ms_count, upto = base + nokz;
+                ensure_keep(d_anchor_start, std::max<size_t>(upto * ngz, 1), base * ngz); ensure_keep(d_ms_strand, std::max<size_t>(upto * ngz, 1), base * ngz);
+                ensure_keep(d_anchor_lon, std::max<size_t>(upto, 1), base); ensure_keep(d_anchor_flags, std::max<size_t>(upto, 1), base);
+                ensure_keep(d_ms_shift, std::max<size_t>(upto, 1), base); ensure_keep(d_ms_len, std::max<size_t>(upto, 1), base); ensure_keep(d_ms_state, std::max<size_t>(upto, 1), base);
+                be.d2d(d_anchor_start.p + base * ngz, d_csp.p, 4 * nokz * ngz);
+                be.d2d(d_ms_strand.p + base * ngz, d_cfwd.p, nokz * ngz);
+                be.d2d(d_anchor_lon.p + base, d_clon.p, 4 * nokz);
+                be.d2d(d_anchor_flags.p + base, d_cflags.p, 4 * nokz);
+                be.d2d(d_ms_len.p + base, d_clon.p, 4 * nokz);
+                if (nokz) { be.memset(d_ms_shift.p + base, 0, 4 * nokz); be.memset(d_ms_state.p + base, 0, nokz); }
+                out->store_base = (int64_t)base;
+                ms_count = (int64_t)upto;
+                if (anchor_call) {
+                    ensure(d_anchor_accept, std::max<size_t>(nokz, 1));      // (the overlap flags are in: same condition above)
+                    be.launch("anchor_accept", nok, AnchorAccept{d_cflags.p, d_clon.p, d_cfwd.p, ngen, d_anchor_accept.p});
+                    anchor_table_rows = nok;
+                    out->table_id = anchor_table_id = ++table_counter;
+                }
             }
             be.mark("download");
-            out->startb = pool->take(4 * nokz * ngz); out->strandb = pool->take(nokz * ngz); out->flagsb = pool->take(4 * nokz);
+            out->flagsb = pool->take(4 * nokz);
             be.d2h_async(out->flagsb.p, d_cflags.p, 4 * nokz);
-            be.d2h_async(out->startb.p, d_csp.p, 4 * nokz * ngz);
-            be.d2h_async(out->strandb.p, d_cfwd.p, nokz * ngz);
+            if (!keep_rows) {
+                out->startb = pool->take(4 * nokz * ngz); out->strandb = pool->take(nokz * ngz);
+                be.d2h_async(out->startb.p, d_csp.p, 4 * nokz * ngz);
+                be.d2h_async(out->strandb.p, d_cfwd.p, nokz * ngz);
+            }
         }
         be.d2h_async(reg_h.data(), d_creg.p, 4 * nokz);
         be.d2h_async(out->kb.p, d_ck.p, 4 * nokz);
@@ -637,6 +685,7 @@ public:
         for (size_t w = 0; w < nokz; w++) out->off[(size_t)reg_h[w] + 1]++;
         for (int64_t r = 0; r < nreg; r++) out->off[(size_t)r + 1] += out->off[(size_t)r];
         out->total = out->off[(size_t)nreg];
+        if (out->table_id && out->store_base == 0) anchor_flags_h.assign(out->flags(), out->flags() + nokz);      // (settle() lists the flagged rows from it)
         collect_timing();
         return 0;
     }
@@ -694,6 +743,293 @@ public:
     }
     void layout_wait() { be.bind(); be.side_wait(); }      // (may be called by a helper thread while another call is running)
 
+
+    // =====================================================================================================================
+    // The resident route (store_kernels.h; include/parsnp_mum.h: pm_store_*): what the reference does with the candidate lists
+    // AFTER csgmum produced them, on rows that never leave the device.  Every method is one call of the C ABI.
+    // =====================================================================================================================
+    bool resident = false;            // pm_session_rows(s, 2)
+    int64_t ms_count = 0;             // rows of the MUM store: [0, anchor_table_rows) = the anchor table, then every search of store regions
+    int64_t rg_count = 0;             // regions of the region store
+    std::vector<RegInfo> rg_info_h;   // host mirror of what the device said about each region (by region id)
+    std::vector<uint32_t> anchor_flags_h;
+    static constexpr int kAgain = -6; // PM_EAGAIN: the resident route does not apply; the caller takes the host route
+
+    void begin_store_call() { timing.clear(); last_events = last_rest = 0; last_alg[0] = last_alg[1] = last_alg[2] = 0; }      // (counts of the last search travel with pm_last_timing)
+    Store store_view() { return Store{d_anchor_start.p, d_ms_strand.p, d_anchor_lon.p, d_anchor_flags.p, d_ms_shift.p, d_ms_len.p, d_ms_state.p, ngen}; }
+    Layout layout_view(uint64_t* image) { return Layout{image, d_lay_off.p, d_lay_bits.p}; }
+    // geometry of the layout image: genome j has glen[j] + 1 bits (the last one the sentinel, src/parsnp.cpp:3184-3185)
+    size_t layout_geometry() {
+        const size_t ngz = (size_t)ngen;
+        if (lay_words == 0) {
+            std::vector<int64_t> off(ngz + 1, 0), bits(ngz);
+            for (size_t j = 0; j < ngz; j++) { bits[j] = glen_h[j] + 1; off[j + 1] = off[j] + (bits[j] + 63) / 64 + 1; }
+            ensure(d_lay_off, ngz + 1); ensure(d_lay_bits, ngz);
+            be.h2d(d_lay_off.p, off.data(), 8 * (ngz + 1)); be.h2d(d_lay_bits.p, bits.data(), 8 * ngz);
+            lay_words = (size_t)off[ngz];
+            lay_off_h = off;
+        }
+        return lay_words;
+    }
+    int need_resident(int64_t table_id) {
+        if (!resident) { error = "the session is not in resident mode"; return -2; }
+        if (table_id == 0 || table_id != anchor_table_id) { error = "the anchor table of this request is no longer resident"; return -2; }
+        return 0;
+    }
+    // Second half of setMums1 (src/parsnp.cpp:1713-1841) for the resident anchor list, into an EMPTY layout: rows that overlap
+    // nothing earlier are settled at once and marked; the flagged ones against those marks -- all at once where they meet no
+    // other flagged row, in list order where they do.  out[c] for every row of the table.
+    int store_settle(int64_t table_id, RowInfo* out) {
+        if (int rc = need_resident(table_id)) return rc;
+        begin_store_call();
+        const int64_t rows = anchor_table_rows;
+        std::vector<int32_t> fl;
+        for (int64_t c = 0; c < rows; c++) { const uint32_t f = anchor_flags_h[(size_t)c]; if (!(f & (kRowBad | kRowOutside)) && (f & kRowDirty)) fl.push_back((int32_t)c); }
+        if (fl.size() * (size_t)flagged_div > (size_t)rows) { error = "too many rows of the list overlap an earlier one (rearranged genomes): the host route decides"; return kAgain; }
+        const size_t words = layout_geometry();
+        ensure(d_image, words);
+        be.mark("settle");
+        be.memset(d_image.p, 0, 8 * words);
+        be.launch("layout_sentinel", (int64_t)ngen, LayoutSentinel{d_lay_off.p, d_lay_bits.p, d_image.p});
+        const Store S = store_view();
+        const Layout L = layout_view(d_image.p);
+        be.launch_wave("settle_clean", rows, SettleClean{S, P});
+        be.launch("store_mark", rows * ngen, StoreMark{S, L, 0, (uint8_t)(kStAccepted | kStFlagged), kStAccepted});
+        if (!fl.empty()) {
+            ensure(d_once, words); ensure(d_twice, words); ensure(d_list, fl.size());
+            be.memset(d_once.p, 0, 8 * words); be.memset(d_twice.p, 0, 8 * words);
+            be.h2d(d_list.p, fl.data(), 4 * fl.size());
+            be.launch("collide_mark", (int64_t)fl.size() * ngen, CollideMark{S, d_list.p, layout_view(d_once.p), d_twice.p});
+            be.launch_wave("collide_test", (int64_t)fl.size(), CollideTest{S, d_list.p, layout_view(d_twice.p)});
+            be.launch_wave("settle_flagged", (int64_t)fl.size(), SettleFlagged{S, L, P, d_list.p});
+            be.launch_wave("settle_tangled", 1, SettleTangled{S, L, P, d_list.p, (int64_t)fl.size()});
+        }
+        layout_rows = rows;
+        const int rc = store_info(0, rows, out);
+        return rc;
+    }
+    // per-row scalars of store rows [first, first + count)
+    int store_info(int64_t first, int64_t count, RowInfo* out) {
+        if (!resident || first < 0 || count < 0 || first + count > ms_count) { error = "rows outside the MUM store"; return -2; }
+        if (count == 0) return 0;
+        ensure(d_rowinfo, (size_t)count);
+        be.launch("store_info", count, StoreInfoOut{store_view(), first, d_rowinfo.p});
+        be.mark(nullptr);
+        be.d2h(out, d_rowinfo.p, sizeof(RowInfo) * (size_t)count);
+        collect_timing_more();
+        return 0;
+    }
+    // the regions the device appended since `first`, as the host wants them: sorted by key, dropped ones left out
+    void take_regions(int64_t first, int64_t upto, std::vector<RegInfo>* infos, std::vector<int32_t>* ids) {
+        const size_t m = (size_t)(upto - first);
+        std::vector<RegInfo> raw(m);
+        if (m) be.d2h(raw.data(), d_rg_info.p + first, sizeof(RegInfo) * m);
+        if (rg_info_h.size() < (size_t)upto) rg_info_h.resize((size_t)upto);
+        std::vector<int32_t> order;
+        for (size_t i = 0; i < m; i++) { rg_info_h[(size_t)first + i] = raw[i]; if (raw[i].key >= 0) order.push_back((int32_t)i); }
+        std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return raw[(size_t)x].key < raw[(size_t)y].key; });
+        infos->clear(); ids->clear();
+        for (int32_t i : order) { infos->push_back(raw[(size_t)i]); ids->push_back((int32_t)(first + i)); }
+    }
+    // setInitialClusters' seed regions (src/parsnp.cpp:2150-2172): both neighbour regions of every accepted anchor (acc: their rows,
+    // in list order) by walks over the image, kept when longer than q in every genome; in the reference's push order
+    int store_seeds(int64_t table_id, const int32_t* acc, int64_t nacc, int32_t q, std::vector<RegInfo>* infos, std::vector<int32_t>* ids) {
+        if (int rc = need_resident(table_id)) return rc;
+        if (layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
+        for (int64_t i = 0; i < nacc; i++) if (acc[i] < 0 || acc[i] >= anchor_table_rows) { error = "anchor outside the table"; return -2; }
+        rg_count = 0;
+        infos->clear(); ids->clear();
+        begin_store_call();
+        if (nacc == 0) return 0;
+        ensure(d_list, (size_t)nacc); ensure(d_rg_count, 2);
+        be.h2d(d_list.p, acc, 4 * (size_t)nacc);
+        be.mark("seeds");
+        size_t cap = std::max<size_t>(rg_cap_hint, (size_t)nacc / 4 + 1024);
+        for (;;) {
+            ensure(d_rg_start, cap * (size_t)ngen); ensure(d_rg_len, cap * (size_t)ngen); ensure(d_rg_info, cap);
+            be.memset(d_rg_count.p, 0, 16);
+            be.launch_wave("seed_walk", nacc, SeedWalk{store_view(), layout_view(d_image.p), P, d_list.p, q, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap});
+            uint64_t got = 0;
+            be.d2h(&got, d_rg_count.p, 8);
+            if (got <= cap) { rg_count = (int64_t)got; break; }
+            cap = (size_t)got + (size_t)got / 8 + 64;
+        }
+        rg_cap_hint = (size_t)rg_count + (size_t)rg_count / 4;
+        be.mark(nullptr);
+        take_regions(0, rg_count, infos, ids);
+        collect_timing_more();
+        return 0;
+    }
+    // are regions a[i] and b[i] the same in every genome (TRegion operator==)?
+    int store_regions_equal(const int32_t* a, const int32_t* b, int64_t n, uint8_t* same) {
+        if (!resident) { error = "the session is not in resident mode"; return -2; }
+        for (int64_t i = 0; i < n; i++) if (a[i] < 0 || a[i] >= rg_count || b[i] < 0 || b[i] >= rg_count) { error = "region outside the region store"; return -2; }
+        if (n == 0) return 0;
+        ensure(d_list, (size_t)n); ensure(d_list2, (size_t)n); ensure(d_small8, (size_t)n);
+        be.h2d(d_list.p, a, 4 * (size_t)n); be.h2d(d_list2.p, b, 4 * (size_t)n);
+        be.launch_wave("regions_equal", n, RegionsEqual{d_list.p, d_list2.p, ngen, d_rg_start.p, d_rg_len.p, d_small8.p});
+        be.d2h(same, d_small8.p, (size_t)n);
+        return 0;
+    }
+    // the multi-MUM search of regions of the store (pm_multi_mum_batch on their rows); the candidates become rows
+    // [*first_row + off[i], *first_row + off[i + 1]) of the MUM store
+    int store_search(const int32_t* ids, const int32_t* minsize, int64_t n, int64_t* first_row, int64_t* off) {
+        if (!resident) { error = "the session is not in resident mode"; return -2; }
+        std::vector<int64_t> rs((size_t)n), rl((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            if (ids[i] < 0 || ids[i] >= rg_count) { error = "region outside the region store"; return -2; }
+            rs[(size_t)i] = rg_info_h[(size_t)ids[i]].ref_start; rl[(size_t)i] = rg_info_h[(size_t)ids[i]].ref_len;
+        }
+        *first_row = ms_count;
+        off[0] = 0;
+        if (n == 0) return 0;
+        GapBatch gb;
+        gb.store_ids = ids; gb.ref_start = rs.data(); gb.ref_len = rl.data();
+        BatchResult br;
+        const bool keep = want_rows;
+        want_rows = true;
+        const int rc = run(n, nullptr, nullptr, minsize, &br, false, false, &gb);
+        want_rows = keep;
+        if (rc) return rc;
+        *first_row = br.store_base >= 0 ? br.store_base : ms_count;
+        for (int64_t i = 0; i <= n; i++) off[i] = br.off[(size_t)i];
+        return 0;
+    }
+    // One generation of the recursion (doWork, src/parsnp.cpp:173-317) over clusters of waiting regions that the caller found
+    // pairwise disjoint in every genome: candidates settled against the image and marked, children appended to the region store.
+    int store_validate(const int32_t* regions, const int64_t* row0, const int32_t* cnt, int64_t nreg, const int64_t* cluster_first, int64_t ncl, int32_t q,
+                       uint32_t* trouble, std::vector<RegInfo>* kids, std::vector<int32_t>* kid_ids) {
+        if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
+        kids->clear(); kid_ids->clear(); *trouble = 0;
+        if (nreg == 0 || ncl == 0) return 0;
+        int64_t total = 0;
+        for (int64_t x = 0; x < nreg; x++) {
+            if (regions[x] < 0 || regions[x] >= rg_count || row0[x] < 0 || cnt[x] < 0 || row0[x] + cnt[x] > ms_count) { error = "bad generation list"; return -2; }
+            total += cnt[x];
+        }
+        if (cluster_first[0] != 0 || cluster_first[ncl] != nreg) { error = "bad cluster list"; return -2; }
+        begin_store_call();
+        const size_t cap = (size_t)rg_count + 2 * (size_t)total + 16;       // (every accepted candidate has two neighbour regions)
+        ensure_keep(d_rg_start, cap * (size_t)ngen, (size_t)rg_count * (size_t)ngen); ensure_keep(d_rg_len, cap * (size_t)ngen, (size_t)rg_count * (size_t)ngen);
+        ensure_keep(d_rg_info, cap, (size_t)rg_count);
+        const size_t bytes = 4 * (size_t)nreg + 8 * (size_t)nreg + 4 * (size_t)nreg + 8 * ((size_t)ncl + 1) + 64;
+        uint8_t* block = (uint8_t*)be.staging(bytes);
+        if (!block) { error = "cannot allocate the request staging block"; return -3; }
+        int64_t* s_row0 = (int64_t*)block; int64_t* s_first = s_row0 + nreg; int32_t* s_reg = (int32_t*)(s_first + ncl + 1); int32_t* s_cnt = s_reg + nreg;
+        memcpy(s_row0, row0, 8 * (size_t)nreg); memcpy(s_first, cluster_first, 8 * ((size_t)ncl + 1)); memcpy(s_reg, regions, 4 * (size_t)nreg); memcpy(s_cnt, cnt, 4 * (size_t)nreg);
+        ensure(d_v_row0, (size_t)nreg); ensure(d_v_first, (size_t)ncl + 1); ensure(d_list, (size_t)nreg); ensure(d_list2, (size_t)nreg); ensure(d_rg_count, 2);
+        be.h2d_staged(d_v_row0.p, s_row0, 8 * (size_t)nreg); be.h2d_staged(d_v_first.p, s_first, 8 * ((size_t)ncl + 1));
+        be.h2d_staged(d_list.p, s_reg, 4 * (size_t)nreg); be.h2d_staged(d_list2.p, s_cnt, 4 * (size_t)nreg);
+        uint64_t head[2] = {(uint64_t)rg_count, 0};       // [0] the region counter, [1] the trouble word
+        be.h2d(d_rg_count.p, head, 16);
+        be.mark("validate");
+        be.launch_wave("clusters_disjoint", ncl - 1, ClustersDisjoint{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, (uint32_t*)(d_rg_count.p + 1)});
+        be.launch_wave("cluster_validate", ncl,
+                       ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
+                                       d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1)});
+        be.mark(nullptr);
+        be.d2h(head, d_rg_count.p, 16);
+        *trouble = (uint32_t)head[1];
+        if (head[0] > cap) { error = "region store overflow"; return -4; }
+        const int64_t before = rg_count;
+        rg_count = (int64_t)head[0];
+        take_regions(before, rg_count, kids, kid_ids);
+        collect_timing_more();
+        return 0;
+    }
+    // chain()'s test of MUM cur[i] against the open chain's last MUM back[i] (setFinalClusters :2596-2700): verdict 0 = every
+    // genome's gap inside [0, d] (min_gap / max_gap for the caller's ratio test), 1 = the chain closes, 2 = a reverse member: from the rows
+    int store_judge(const int32_t* cur, const int32_t* back, int64_t n, int32_t d, int32_t* min_gap, int32_t* max_gap, uint8_t* verdict) {
+        if (!resident) { error = "the session is not in resident mode"; return -2; }
+        for (int64_t i = 0; i < n; i++) if (cur[i] < 0 || cur[i] >= ms_count || back[i] < 0 || back[i] >= ms_count) { error = "rows outside the MUM store"; return -2; }
+        if (n == 0) return 0;
+        begin_store_call();
+        ensure(d_list, (size_t)n); ensure(d_list2, (size_t)n); ensure(d_j_min, (size_t)n); ensure(d_j_max, (size_t)n); ensure(d_small8, (size_t)n);
+        int32_t* block = (int32_t*)be.staging(8 * (size_t)n);
+        if (!block) { error = "cannot allocate the request staging block"; return -3; }
+        memcpy(block, cur, 4 * (size_t)n); memcpy(block + n, back, 4 * (size_t)n);
+        be.h2d_staged(d_list.p, block, 4 * (size_t)n); be.h2d_staged(d_list2.p, block + n, 4 * (size_t)n);
+        be.mark("judge");
+        be.launch_wave("judge_pairs", n, JudgePairs{store_view(), d_list.p, d_list2.p, d, d_j_min.p, d_j_max.p, d_small8.p});
+        be.mark(nullptr);
+        be.d2h_async(min_gap, d_j_min.p, 4 * (size_t)n); be.d2h_async(max_gap, d_j_max.p, 4 * (size_t)n);
+        be.d2h(verdict, d_small8.p, (size_t)n);
+        collect_timing_more();
+        return 0;
+    }
+    // the listed MUMs leave the layout (filterRandom1 :415-418, filterRandomClustersSimple1 :460-466)
+    int store_unmark(const int32_t* rows, int64_t n) {
+        if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
+        for (int64_t i = 0; i < n; i++) if (rows[i] < 0 || rows[i] >= ms_count) { error = "rows outside the MUM store"; return -2; }
+        if (n == 0) return 0;
+        ensure(d_list, (size_t)n);
+        be.h2d(d_list.p, rows, 4 * (size_t)n);
+        be.launch("store_unmark", n * ngen, StoreUnmark{store_view(), layout_view(d_image.p), d_list.p});
+        return 0;
+    }
+    // setInterClusterRegions (:2389-2460) for consecutive LCBs given by (last MUM of one, first MUM of the next); rows of the
+    // fillers that are made, [n_made][ngen] each, in pair order
+    int store_fill(const int32_t* last_of, const int32_t* first_of_next, int64_t n, uint8_t* add, std::vector<int64_t>* starts, std::vector<int64_t>* ends) {
+        if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
+        for (int64_t i = 0; i < n; i++) if (last_of[i] < 0 || last_of[i] >= ms_count || first_of_next[i] < 0 || first_of_next[i] >= ms_count) { error = "rows outside the MUM store"; return -2; }
+        starts->clear(); ends->clear();
+        if (n == 0) return 0;
+        begin_store_call();
+        const size_t ngz = (size_t)ngen;
+        ensure(d_list, (size_t)n); ensure(d_list2, (size_t)n); ensure(d_small8, (size_t)n); ensure(d_f_start, (size_t)n * ngz); ensure(d_f_end, (size_t)n * ngz);
+        be.h2d(d_list.p, last_of, 4 * (size_t)n); be.h2d(d_list2.p, first_of_next, 4 * (size_t)n);
+        be.mark("fill");
+        be.launch_wave("fill_between", n, FillBetween{store_view(), layout_view(d_image.p), P, d_list.p, d_list2.p, d_small8.p, d_f_start.p, d_f_end.p});
+        be.mark(nullptr);
+        be.d2h(add, d_small8.p, (size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            if (add[i] != 1) continue;
+            const size_t at = starts->size();
+            starts->resize(at + ngz); ends->resize(at + ngz);
+            be.d2h_async(starts->data() + at, d_f_start.p + (size_t)i * ngz, 8 * ngz); be.d2h(ends->data() + at, d_f_end.p + (size_t)i * ngz, 8 * ngz);
+        }
+        collect_timing_more();
+        return 0;
+    }
+    // rows of the store for the host (the XMFA writer after phase D; a caller that falls back to the host route): start per genome
+    // with the trim applied (raw: as the search delivered them) + strand byte.  rows == nullptr: rows [first, first + n)
+    int store_rows(const int32_t* rows, int64_t first, int64_t n, bool raw, int32_t* out_start, uint8_t* out_strand) {
+        if (!resident) { error = "the session is not in resident mode"; return -2; }
+        if (n == 0) return 0;
+        const size_t ngz = (size_t)ngen;
+        if (!rows) {
+            if (first < 0 || first + n > ms_count) { error = "rows outside the MUM store"; return -2; }
+            if (raw) {      // contiguous and untouched: straight copies
+                be.d2h_async(out_start, d_anchor_start.p + (size_t)first * ngz, 4 * (size_t)n * ngz);
+                be.d2h(out_strand, d_ms_strand.p + (size_t)first * ngz, (size_t)n * ngz);
+                return 0;
+            }
+        } else for (int64_t i = 0; i < n; i++) if (rows[i] < 0 || rows[i] >= ms_count) { error = "rows outside the MUM store"; return -2; }
+        // in pieces: the gathered copy of a 60 000-row list is 60 MB of device memory otherwise
+        const int64_t piece = std::max<int64_t>(1, (int64_t)((32u << 20) / (5 * ngz)));
+        ensure(d_list, (size_t)std::min(n, piece)); ensure(d_o_start, (size_t)std::min(n, piece) * ngz); ensure(d_o_strand, (size_t)std::min(n, piece) * ngz);
+        std::vector<int32_t> seq;
+        for (int64_t at = 0; at < n; at += piece) {
+            const int64_t m = std::min(piece, n - at);
+            const int32_t* src = rows ? rows + at : nullptr;
+            if (!src) { seq.resize((size_t)m); for (int64_t i = 0; i < m; i++) seq[(size_t)i] = (int32_t)(first + at + i); src = seq.data(); }
+            be.h2d(d_list.p, src, 4 * (size_t)m);
+            be.launch("store_rows", m * ngen, StoreRowsOut{store_view(), d_list.p, d_o_start.p, d_o_strand.p, raw ? 1 : 0});
+            be.d2h_async(out_start + (size_t)at * ngz, d_o_start.p, 4 * (size_t)m * ngz);
+            be.d2h(out_strand + (size_t)at * ngz, d_o_strand.p, (size_t)m * ngz);
+        }
+        return 0;
+    }
+    // the layout as the host keeps it (write_unaligned reads it): one block, words of genome j at off[j]
+    int store_layout(uint64_t* out, int64_t words) {
+        if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
+        if ((size_t)words != layout_geometry()) { error = "layout size does not match"; return -2; }
+        be.d2h(out, d_image.p, 8 * (size_t)words);
+        return 0;
+    }
+    std::vector<int64_t> lay_off_h;
+    void collect_timing_more() { for (const PhaseTime& t : be.collect()) timing.push_back(t); }
+
     // small host-side all-gather (calcmumi's per-genome results): through device staging when the collectives are RCCL
     int allgather_host(const void* send, int64_t bytes, void* recv) {
         if (!coll.device) return coll.allgather(coll.ctx, send, bytes, recv);
@@ -712,7 +1048,9 @@ public:
     // that gets the device overlap test and stays resident as the anchor table (the host's threshold for its long-list routes)
     int64_t work_budget = 1 << 22;
     int64_t dirty_min = 4096;
+    int64_t flagged_div = 8;      // store_settle: PM_EAGAIN when more than one row in flagged_div overlaps an earlier one
     bool tune(const std::string& key, int64_t value) {
+        if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
         if (key == "work_budget" && value > 0) { work_budget = value; return true; }
         if (key == "dirty_min" && value >= 0) { dirty_min = value; return true; }
         return false;
@@ -751,6 +1089,17 @@ private:
         if (!b.raw) throw DeviceOutOfMemory{want * sizeof(T)};
         b.p = (T*)b.raw; b.cap = want;
     }
+    // the same, keeping the first `keep` elements (the stores grow while the run appends to them)
+    template <class T> void ensure_keep(Buf<T>& b, size_t n, size_t keep) {
+        if (n <= b.cap && b.p) return;
+        if (std::find(all_bufs.begin(), all_bufs.end(), (BufBase*)&b) == all_bufs.end()) all_bufs.push_back(&b);
+        const size_t want = n + n / 2 + 16;
+        void* raw = be.alloc(want * sizeof(T));
+        if (!raw) throw DeviceOutOfMemory{want * sizeof(T)};
+        if (b.p && keep) { be.d2d(raw, b.p, keep * sizeof(T)); be.sync(); }
+        if (b.raw) be.free(b.raw);
+        b.raw = raw; b.p = (T*)raw; b.cap = want;
+    }
     void collect_timing() { timing = be.collect(); }
 
     SeqBlock* blk = nullptr; int64_t* d_goff = nullptr; int64_t* d_glen = nullptr;
@@ -772,6 +1121,11 @@ private:
     Buf<SpecRegion> d_spec; Buf<uint64_t> d_speccount; Buf<int32_t> d_mintable;
     int64_t table_counter = 0;
     Buf<uint64_t> d_image; Buf<int64_t> d_imgoff, d_imgbits; Buf<uint8_t> d_accept; Buf<int32_t> d_xstart, d_xlon;
+    Buf<uint8_t> d_ms_strand, d_ms_state, d_small8, d_o_strand; Buf<int32_t> d_ms_shift, d_ms_len, d_list, d_list2, d_j_min, d_j_max, d_o_start;
+    Buf<int64_t> d_rg_start, d_rg_len, d_lay_off, d_lay_bits, d_v_row0, d_v_first, d_f_start, d_f_end; Buf<RegInfo> d_rg_info; Buf<uint64_t> d_rg_count, d_once, d_twice;
+    Buf<RowInfo> d_rowinfo; Buf<uint64_t> d_alg;
+    size_t lay_words = 0, rg_cap_hint = 0;
+    int64_t layout_rows = -1;       // >= 0: the image holds the layout of the current anchor table (store_settle ran)
     uint64_t* image_h = nullptr; size_t image_words = 0;      // page-locked: the layout image as the host reads it
     uint8_t* image_stage = nullptr; size_t image_stage_cap = 0;
 };

@@ -156,9 +156,11 @@ struct HipBackend {
     static void* host_alloc(size_t n) { return malloc(n ? n : 1); }
     static void host_free(void* p) { ::free(p); }
     void memset(void* p, int v, size_t n) { check(hipMemsetAsync(p, v, n, stream), "hipMemsetAsync"); }
-    void h2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync"); }
-    void d2h(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); check(hipStreamSynchronize(stream), "sync"); }
-    void d2h_async(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); }
+    // bytes moved over the host link by this session (pm_session_traffic): every copy below adds its size
+    std::atomic<uint64_t> bytes_h2d{0}, bytes_d2h{0};
+    void h2d(void* d, const void* s, size_t n) { bytes_h2d += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync"); }
+    void d2h(void* d, const void* s, size_t n) { bytes_d2h += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); check(hipStreamSynchronize(stream), "sync"); }
+    void d2h_async(void* d, const void* s, size_t n) { bytes_d2h += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); }
     void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
     // an event on the engine's stream that any host thread may wait for (the slices of a row table in flight)
     void* event_record() {
@@ -191,6 +193,7 @@ struct HipBackend {
             if (!check(hipStreamCreateWithFlags(&side, hipStreamNonBlocking), "hipStreamCreate(side)")) return;
             if (!check(hipEventCreateWithFlags(&side_go, hipEventDisableTiming), "hipEventCreate") || !check(hipEventCreateWithFlags(&side_done, hipEventDisableTiming), "hipEventCreate")) return;
         }
+        bytes_d2h += n;
         check(hipEventRecord(side_go, stream), "hipEventRecord");
         check(hipStreamWaitEvent(side, side_go, 0), "hipStreamWaitEvent");
         if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, side), "hipMemcpy D2H (side)");
@@ -200,7 +203,7 @@ struct HipBackend {
     void side_wait() { if (side_pending) { check(hipEventSynchronize(side_done), "hipEventSynchronize(side)"); side_pending = false; } }
     void* pinned_alloc(size_t n) { void* p = nullptr; if (!check(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault), "hipHostMalloc")) return nullptr; return p; }
     void pinned_free(void* p) { if (p) (void)hipHostFree(p); }
-    void h2d_staged(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D (staged)"); }
+    void h2d_staged(void* d, const void* s, size_t n) { bytes_h2d += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D (staged)"); }
 
     // see Engine::load_genomes.  kThreads host threads, two staging slots each (page-locked host block + device block + stream)
     bool stage_genomes(int n, const uint8_t* const* seqs, const int64_t* lens, const std::vector<char>& take, const std::vector<int64_t>& goff,
@@ -229,6 +232,7 @@ struct HipBackend {
                     Slot& sl = slots[(size_t)t * kPer + (size_t)(turn++ % kPer)];
                     if (sl.used && hipEventSynchronize(sl.done) != hipSuccess) { failed[(size_t)t] = 1; return; }
                     memcpy(sl.host, seqs[g], (size_t)lens[g]);
+                    bytes_h2d += (uint64_t)lens[g];
                     if (hipMemcpyAsync(sl.dev, sl.host, (size_t)lens[g], hipMemcpyHostToDevice, sl.st) != hipSuccess) { failed[(size_t)t] = 1; return; }
                     const int64_t nblk = (lens[g] + 31) / 32;
                     for (int s = 0; s < 2; s++)

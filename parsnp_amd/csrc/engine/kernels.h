@@ -211,6 +211,7 @@ constexpr int kSliceStride = 8;        // uint64 words between two counters: one
 
 // error bits raised by kernels
 constexpr uint32_t kErrWork = 1u;  // per-thread work budget exceeded (degenerate repeat structure)
+constexpr uint32_t kErrRows = 2u;  // a request row derived on the device lies outside its genome, or is not the region its reference column describes
 
 // 32 bases starting at global base position p: 2-bit plane and N-mask plane
 PM_HD void window(const SeqBlock* blk, int64_t p, uint64_t* bits, uint32_t* mask) {
@@ -596,6 +597,19 @@ struct ExpandGaps {
             a = nxt; b = p - 1;
         }
         starts[tid] = a; lens[tid] = b - a;
+    }
+};
+
+// tid = (region, genome): the request rows the device derived itself, checked as the host checks rows it is handed
+// (pm_multi_mum_batch: "region outside its genome"); the reference column must be the one the caller sized the index from
+struct CheckRows {
+    const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen; const int64_t* glen; uint32_t* err;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t r = tid / ngen; const int j = (int)(tid % ngen);
+        const int64_t st = starts[tid], ln = lens[tid];
+        bool bad = st < 0 || ln < 0 || st + ln > glen[j];
+        if (j == 0) bad = bad || st != R[r].ref_pos || ln != (int64_t)R[r].nR;
+        if (bad) atomic_or32(err, kErrRows);
     }
 };
 

@@ -1,0 +1,592 @@
+// store_kernels.h -- device code of the RESIDENT route: what the reference does with a candidate list AFTER csgmum has
+// produced it -- the second half of Aligner::setMums1 (validation, src/parsnp.cpp:1713-1841), Aligner::trim (:1399-1477),
+// determineRegion (:1199-1290), the work-list generations of doWork (:173-317), the pairwise test of setFinalClusters
+// (:2596-2700) and setInterClusterRegions (:2389-2460) -- as kernels over data that never leaves the device:
+//
+//   MUM store     the rows of every candidate list of the run (int32 start per genome + strand byte, as CompactCandidates
+//                 wrote them, never rewritten), plus three scalars per row that the validation owns: `shift` (bases trimmed on
+//                 the left: the start moves right in EVERY genome, TMum::trimleft), `len` (current length) and `state`.
+//                 Rows [0, A) are the anchor table of the anchor call; every later search appends its candidates.
+//   layout image  one bit per base of every genome + a sentinel (the reference's mumlayout, :3181-3186), 64-bit words,
+//                 genome after genome; marks are atomic ORs, reads are L2-coherent loads (a wavefront must see the marks of
+//                 the candidate it accepted a moment ago, and those were made by atomics that bypass its L1).
+//   region store  request rows (int64 start / length per genome) of the seed regions and of every child region.
+//
+// One WAVEFRONT per work item (row, cluster, pair of LCBs); the lanes take the genomes.  The bodies are written ONCE for both
+// executions: `lanes_for` hands lane t the genomes t, t + 64, ... on the device and runs all genomes in order in the host
+// emulation (tests/emu: one thread plays every lane), and the reductions (`wave_min_i32`, `wave_or_u32`, ...) combine the
+// lanes' partial values on the device and are the identity on the host, where the one thread has accumulated everything.
+// A variable that a `lanes_for` body assigns is therefore per lane on the device and shared on the host; it may only be
+// read after a reduction or a broadcast has made it uniform.
+#pragma once
+#include "kernels.h"
+
+namespace pm {
+
+// ------------------------------------------------------------------------------------------ lanes
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class F> __device__ inline void lanes_for(int from, int n, F f) {
+    for (int j = (from & ~63) + (int)__lane_id(); j < n; j += 64) if (j >= from) f(j);
+}
+__device__ inline int32_t wave_min_i32(int32_t x) { for (int d = 32; d >= 1; d >>= 1) { const int32_t y = __shfl_xor(x, d, 64); if (y < x) x = y; } return x; }
+__device__ inline int32_t wave_max_i32(int32_t x) { for (int d = 32; d >= 1; d >>= 1) { const int32_t y = __shfl_xor(x, d, 64); if (y > x) x = y; } return x; }
+__device__ inline uint32_t wave_or_u32(uint32_t x) { for (int d = 32; d >= 1; d >>= 1) x |= (uint32_t)__shfl_xor((int)x, d, 64); return x; }
+__device__ inline int32_t wave_bcast_i32(int32_t x, int lane) { return __shfl(x, lane, 64); }
+__device__ inline uint64_t wave_sum_u64(uint64_t x) {
+    for (int d = 32; d >= 1; d >>= 1) x += ((uint64_t)(uint32_t)__shfl_xor((int)(x >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)x, d, 64);
+    return x;
+}
+__device__ inline bool wave_leader() { return __lane_id() == 0; }
+// loads that see what atomics of this or another wavefront have written (agent scope: served by the L2)
+__device__ inline uint64_t load_coherent64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline int32_t load_coherent32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint8_t load_coherent8(const uint8_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void store_coherent32(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void store_coherent8(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint64_t atomic_fetch_or64(uint64_t* p, uint64_t v) { return (uint64_t)atomicOr((unsigned long long*)p, (unsigned long long)v); }
+__device__ inline void atomic_and64(uint64_t* p, uint64_t v) { atomicAnd((unsigned long long*)p, (unsigned long long)v); }
+#else
+template <class F> inline void lanes_for(int from, int n, F f) { for (int j = from; j < n; j++) f(j); }
+inline int32_t wave_min_i32(int32_t x) { return x; }
+inline int32_t wave_max_i32(int32_t x) { return x; }
+inline uint32_t wave_or_u32(uint32_t x) { return x; }
+inline int32_t wave_bcast_i32(int32_t x, int) { return x; }
+inline uint64_t wave_sum_u64(uint64_t x) { return x; }
+inline bool wave_leader() { return true; }
+inline uint64_t load_coherent64(const uint64_t* p) { return *p; }
+inline int32_t load_coherent32(const int32_t* p) { return *p; }
+inline uint8_t load_coherent8(const uint8_t* p) { return *p; }
+inline void store_coherent32(int32_t* p, int32_t v) { *p = v; }
+inline void store_coherent8(uint8_t* p, uint8_t v) { *p = v; }
+inline uint64_t atomic_fetch_or64(uint64_t* p, uint64_t v) { const uint64_t o = *p; *p = o | v; return o; }
+inline void atomic_and64(uint64_t* p, uint64_t v) { *p &= v; }
+#endif
+
+// ------------------------------------------------------------------------------------------ the stores
+// state of a store row (what Aligner::validate_parallel keeps per candidate)
+constexpr uint8_t kStBuilt = 1;      // the reference constructs a TMum for it (no kRowBad, :1723)
+constexpr uint8_t kStOk = 2;         // inside every genome (`ok`, no kRowOutside)
+constexpr uint8_t kStFlagged = 4;    // (anchor list) overlaps an earlier row of the list: settled against the marks of the others
+constexpr uint8_t kStTangled = 8;    // ... and overlaps another flagged row: settled in list order
+constexpr uint8_t kStAccepted = 16;  // a MUM of the run
+struct Store {
+    const int32_t* start; const uint8_t* strand; const int32_t* lon; const uint32_t* flags;
+    int32_t* shift; int32_t* len; uint8_t* state;
+    int32_t ngen;
+};
+struct Layout { uint64_t* image; const int64_t* word_off; const int64_t* nbits; };
+
+// consecutive marked bases at pos, pos + 1, ... of genome j, at most maxlen (pos >= 0; bases at or past nbits read as unmarked)
+PM_HD int32_t img_run_up(const Layout& L, int j, int64_t pos, int32_t maxlen) {
+    const uint64_t* w = L.image + L.word_off[j];
+    const int64_t nb = L.nbits[j];
+    int32_t n = 0;
+    while (n < maxlen) {
+        const int64_t p = pos + n;
+        if (p >= nb) break;
+        const uint64_t x = ~(load_coherent64(w + (p >> 6)) >> (p & 63));      // (the bits shifted in at the top read as unmarked)
+        const int avail = 64 - (int)(p & 63);
+        int c = x ? ctz64(x) : 64;
+        if (c > avail) c = avail;
+        n += c;
+        if (c < avail) break;
+    }
+    return n < maxlen ? n : maxlen;
+}
+// consecutive marked bases at pos, pos - 1, ..., at most maxlen
+PM_HD int32_t img_run_down(const Layout& L, int j, int64_t pos, int32_t maxlen) {
+    const uint64_t* w = L.image + L.word_off[j];
+    int32_t n = 0;
+    while (n < maxlen) {
+        const int64_t p = pos - n;
+        if (p < 0) break;
+        const uint64_t x = ~(load_coherent64(w + (p >> 6)) << (63 - (int)(p & 63)));
+        const int avail = (int)(p & 63) + 1;
+        int c = x ? clz64(x) : 64;
+        if (c > avail) c = avail;
+        n += c;
+        if (c < avail) break;
+    }
+    return n < maxlen ? n : maxlen;
+}
+// smallest marked position >= from (the sentinel guarantees one for from <= genome length), nbits when there is none
+PM_HD int64_t img_next_set(const Layout& L, int j, int64_t from) {
+    const uint64_t* w = L.image + L.word_off[j];
+    const int64_t nb = L.nbits[j];
+    if (from < 0) from = 0;
+    if (from >= nb) return nb;
+    int64_t wi = from >> 6;
+    uint64_t x = load_coherent64(w + wi) & (~0ull << (from & 63));
+    const int64_t nw = (nb + 63) / 64;
+    while (!x) { if (++wi >= nw) return nb; x = load_coherent64(w + wi); }
+    return wi * 64 + ctz64(x);
+}
+// largest marked position <= from, or -1
+PM_HD int64_t img_prev_set(const Layout& L, int j, int64_t from) {
+    const uint64_t* w = L.image + L.word_off[j];
+    const int64_t nb = L.nbits[j];
+    if (from < 0) return -1;
+    if (from >= nb) from = nb - 1;
+    int64_t wi = from >> 6;
+    const int hi = (int)(from & 63);
+    uint64_t x = load_coherent64(w + wi) & (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1));
+    while (!x) { if (wi == 0) return -1; x = load_coherent64(w + --wi); }
+    return wi * 64 + 63 - clz64(x);
+}
+PM_HD void img_set_range(const Layout& L, int j, int64_t a, int64_t b) {
+    if (a < 0) a = 0;
+    if (b > L.nbits[j]) b = L.nbits[j];
+    uint64_t* w = L.image + L.word_off[j];
+    while (a < b) {
+        const int lo = (int)(a & 63);
+        const int64_t span = (64 - lo) < (b - a) ? (64 - lo) : (b - a);
+        atomic_or64(&w[a >> 6], (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo);
+        a += span;
+    }
+}
+PM_HD void img_clear_range(const Layout& L, int j, int64_t a, int64_t b) {
+    if (a < 0) a = 0;
+    if (b > L.nbits[j]) b = L.nbits[j];
+    uint64_t* w = L.image + L.word_off[j];
+    while (a < b) {
+        const int lo = (int)(a & 63);
+        const int64_t span = (64 - lo) < (b - a) ? (64 - lo) : (b - a);
+        atomic_and64(&w[a >> 6], ~((span == 64 ? ~0ull : ((1ull << span) - 1)) << lo));
+        a += span;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ settle
+// The per-candidate block of setMums1 (src/parsnp.cpp:1781-1833) for store row c, by all lanes of the wavefront: the length
+// tests, Aligner::trim against the layout (:1399-1477; TMum::trimleft / trimright, TMum.cpp:104-148: every trim shortens the
+// MUM in ALL genomes) and the check that reverse-strand members spell the reverse complement of the reference member
+// (:1791-1825).  Returns whether the reference keeps the MUM; *pdl / *plen: bases trimmed on the left / final length.
+// Does NOT mark the layout.
+//
+// trim() walks the genomes in order: genome j gives up marked bases at its start (the start moves right everywhere), then at
+// its end, and genome j + 1 sees the MUM as genome j left it.  Almost no genome trims anything, so instead of one genome
+// after the other the lanes look at all remaining genomes under the current (shift, length), the FIRST genome that would
+// trim does so -- the ones before it see nothing marked, exactly what the loop would have found -- and the rest are looked
+// at again: one round per genome that trims.
+PM_HD bool settle_row(const Store& S, const Layout& L, const Packed& P, int64_t c, bool trim, int32_t* pdl, int32_t* plen) {
+    const int n = S.ngen;
+    const uint32_t f = S.flags[c];
+    int32_t dl = 0, len = S.lon[c];
+    *pdl = 0; *plen = len;
+    if ((f & (kRowBad | kRowOutside)) || len < 5) return false;
+    const int32_t* st = S.start + c * n;
+    int from = 0;
+    while (trim && len > 0) {
+        int32_t first = 0x7fffffff, tl = 0, tr = 0;
+        lanes_for(from, n, [&](int j) {
+            if (j >= first) return;
+            const int64_t s = (int64_t)st[j] + dl;
+            const int32_t l = img_run_up(L, j, s, len);
+            const int32_t r = l < len ? img_run_down(L, j, s + len - 1, len - l) : 0;
+            if ((l | r) != 0) { first = j; tl = l; tr = r; }
+        });
+        const int32_t F = wave_min_i32(first);
+        if (F == 0x7fffffff) break;
+        tl = wave_bcast_i32(tl, F & 63); tr = wave_bcast_i32(tr, F & 63);
+        dl += tl; len -= tl + tr; from = F + 1;
+    }
+    *pdl = dl; *plen = len;
+    if (len < 2 || n <= 1) return false;
+    if (!S.strand[c * n]) return false;
+    if (f & kRowReverse) {
+        // genome j's bases [l1, l1 + len) reverse-complemented = the stored reverse strand of j from glen - l1 - len on
+        uint32_t bad = 0;
+        const int64_t r0 = P.goff[0] + (int64_t)st[0] + dl;
+        lanes_for(0, n, [&](int j) {
+            if (S.strand[c * n + j]) return;
+            const int64_t l1 = (int64_t)st[j] + dl;
+            if (lce_fwd(P, P.goff[2 * j + 1] + (P.glen[j] - l1 - len), r0, len) != len) bad = 1;
+        });
+        if (wave_or_u32(bad)) return false;
+    }
+    return true;
+}
+
+// One wavefront per row of the anchor table: state bits from the engine's verdict flags, and the rows that overlap nothing
+// earlier (no kRowDirty) settled at once -- nothing they touch is marked before them, so there is nothing to trim
+// (Aligner::validate_parallel's clean candidates).
+struct SettleClean {
+    Store S; Packed P;
+    PM_HD void wave(int64_t c) const {
+        const uint32_t f = S.flags[c];
+        uint8_t st = 0;
+        if (!(f & kRowBad)) st = (uint8_t)(kStBuilt | ((f & kRowOutside) ? 0 : kStOk) | ((f & kRowDirty) ? kStFlagged : 0));
+        int32_t dl = 0, len = S.lon[c];
+        if ((st & (kStBuilt | kStOk | kStFlagged)) == (kStBuilt | kStOk)) {
+            Layout none{nullptr, nullptr, nullptr};
+            if (settle_row(S, none, P, c, false, &dl, &len)) st |= kStAccepted;
+            dl = 0; len = S.lon[c];
+        }
+        if (wave_leader()) { S.state[c] = st; S.shift[c] = 0; S.len[c] = len; }
+    }
+};
+// tid = (row - row0, genome): the ranges of the rows whose state satisfies (state & mask) == want, set in the image
+struct StoreMark {
+    Store S; Layout L; int64_t row0; uint8_t mask, want;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = row0 + tid / S.ngen; const int j = (int)(tid % S.ngen);
+        if ((S.state[c] & mask) != want) return;
+        const int64_t a = (int64_t)S.start[c * S.ngen + j] + S.shift[c];
+        img_set_range(L, j, a, a + S.len[c]);
+    }
+};
+// tid = (i, genome): the rows listed in rows[] taken out of the image (filterRandom1 :415-418, filterRandomClustersSimple1 :460-466)
+struct StoreUnmark {
+    Store S; Layout L; const int32_t* rows;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = rows[tid / S.ngen]; const int j = (int)(tid % S.ngen);
+        const int64_t a = (int64_t)S.start[c * S.ngen + j] + S.shift[c];
+        img_clear_range(L, j, a, a + S.len[c]);
+    }
+};
+
+// Which flagged rows overlap ANOTHER flagged row in some genome ("tangled": their outcome depends on the list order)?  Two
+// scratch images of the layout's shape: every flagged row ORs its ranges into `once`; bits that were there already are ORed
+// into `twice` -- the overlap itself, which both rows of an overlapping pair cover -- and a second pass looks for `twice` bits
+// under a row's own ranges.  tid = (flagged index, genome) / one wavefront per flagged row.
+struct CollideMark {
+    Store S; const int32_t* list; Layout once; uint64_t* twice;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = list[tid / S.ngen]; const int j = (int)(tid % S.ngen);
+        int64_t a = S.start[c * S.ngen + j], b = a + S.lon[c];
+        if (a < 0) a = 0;
+        if (b > once.nbits[j]) b = once.nbits[j];
+        const int64_t base = once.word_off[j];
+        while (a < b) {
+            const int lo = (int)(a & 63);
+            const int64_t span = (64 - lo) < (b - a) ? (64 - lo) : (b - a);
+            const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
+            const uint64_t old = atomic_fetch_or64(&once.image[base + (a >> 6)], mask);
+            if (old & mask) atomic_or64(&twice[base + (a >> 6)], old & mask);
+            a += span;
+        }
+    }
+};
+struct CollideTest {
+    Store S; const int32_t* list; Layout twice;
+    PM_HD void wave(int64_t i) const {
+        const int64_t c = list[i];
+        const int n = S.ngen;
+        uint32_t hit = 0;
+        lanes_for(0, n, [&](int j) {
+            int64_t a = S.start[c * n + j], b = a + S.lon[c];
+            if (a < 0) a = 0;
+            if (b > twice.nbits[j]) b = twice.nbits[j];
+            if (a < b && img_next_set(twice, j, a) < b) hit = 1;
+        });
+        if (wave_or_u32(hit) && wave_leader()) S.state[c] |= kStTangled;
+    }
+};
+// the flagged rows that meet no other flagged row: each against the marks of the clean rows, all at once (they commute)
+struct SettleFlagged {
+    Store S; Layout L; Packed P; const int32_t* list;
+    PM_HD void wave(int64_t i) const {
+        const int64_t c = list[i];
+        if (S.state[c] & kStTangled) return;
+        int32_t dl, len;
+        const bool acc = settle_row(S, L, P, c, true, &dl, &len);
+        if (acc) lanes_for(0, S.ngen, [&](int j) { const int64_t a = (int64_t)S.start[c * S.ngen + j] + dl; img_set_range(L, j, a, a + len); });
+        if (wave_leader()) { S.shift[c] = dl; S.len[c] = len; if (acc) S.state[c] |= kStAccepted; }
+    }
+};
+// ... and the tangled ones in list order, by ONE wavefront: each sees the marks of those before it (:1836-1839)
+struct SettleTangled {
+    Store S; Layout L; Packed P; const int32_t* list; int64_t count;
+    PM_HD void wave(int64_t) const {
+        for (int64_t i = 0; i < count; i++) {
+            const int64_t c = list[i];
+            if (!(S.state[c] & kStTangled)) continue;
+            int32_t dl, len;
+            const bool acc = settle_row(S, L, P, c, true, &dl, &len);
+            if (acc) lanes_for(0, S.ngen, [&](int j) { const int64_t a = (int64_t)S.start[c * S.ngen + j] + dl; img_set_range(L, j, a, a + len); });
+            if (wave_leader()) { S.shift[c] = dl; S.len[c] = len; if (acc) S.state[c] |= kStAccepted; }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ regions
+// determineRegion (src/parsnp.cpp:1199-1290) for one side of one MUM, genome j: the walk over the layout to the previous /
+// next marked base.  left: [p + 1, start - 1) with p the previous marked base (none: the region begins at 1, :1222-1226);
+// right: from one base after the MUM's end to the base before the next marked one (or the sentinel at the genome's end).
+// The request is (start, end - start) -- TRegion's length = end - start (LCR.cpp:29).
+PM_HD void region_side(const Store& S, const Layout& L, const Packed& P, int64_t c, int32_t dl, int32_t len, int side, int j, int64_t* a, int64_t* b) {
+    const int64_t s = (int64_t)S.start[c * S.ngen + j] + dl;
+    if (side == 0) {
+        int64_t p = img_prev_set(L, j, s - 1);
+        if (p < 0) p = 0;
+        *a = p + 1; *b = s - 1;
+    } else {
+        const int64_t nxt = s + len + 1, size = P.glen[j];
+        const int64_t p = nxt >= size ? nxt : img_next_set(L, j, nxt);
+        *a = nxt; *b = p - 1;
+    }
+}
+// what the host learns about a region of the store
+struct RegInfo {
+    int64_t key;            // order in which the reference would push it (the caller sorts by it); -1: dropped (equal to a region still waiting)
+    int64_t ref_start, ref_len;
+    int32_t slength;        // shortest length over the genomes (TRegion::slength: chooses the minimum MUM length)
+    int32_t parent;         // store row of the MUM it lies next to
+};
+// shortest region length over the genomes (and the reference column), by the whole wavefront
+PM_HD int32_t region_extent(const Store& S, const Layout& L, const Packed& P, int64_t c, int32_t dl, int32_t len, int side, int64_t* ref_start, int64_t* ref_len) {
+    int32_t smin = 0x7fffffff, r0a = 0, r0l = 0;
+    lanes_for(0, S.ngen, [&](int j) {
+        int64_t a, b;
+        region_side(S, L, P, c, dl, len, side, j, &a, &b);
+        const int32_t ln = (int32_t)(b - a);
+        if (ln < smin) smin = ln;
+        if (j == 0) { r0a = (int32_t)a; r0l = ln; }
+    });
+    smin = wave_min_i32(smin);
+    *ref_start = wave_bcast_i32(r0a, 0); *ref_len = wave_bcast_i32(r0l, 0);
+    return smin;
+}
+// One wavefront per accepted anchor (acc[i] = its row): both neighbour regions, kept when longer than q in every genome
+// (setInitialClusters :2150-2172); kept regions are appended to the region store, key = 2 i + side = the reference's push order.
+struct SeedWalk {
+    Store S; Layout L; Packed P; const int32_t* acc; int32_t q;
+    int64_t* rg_start; int64_t* rg_len; RegInfo* info; uint64_t* count; uint64_t cap;
+    PM_HD void wave(int64_t i) const {
+        const int64_t c = acc[i];
+        const int32_t dl = S.shift[c], len = S.len[c];
+        const int n = S.ngen;
+        for (int side = 0; side < 2; side++) {
+            int64_t rs, rl;
+            const int32_t smin = region_extent(S, L, P, c, dl, len, side, &rs, &rl);
+            if (smin <= q) continue;
+            int32_t slot = 0;
+            if (wave_leader()) slot = (int32_t)atomic_add64(count, 1);
+            slot = wave_bcast_i32(slot, 0);
+            if ((uint64_t)slot >= cap) continue;           // (the caller sees count > cap and repeats with room)
+            lanes_for(0, n, [&](int j) {
+                int64_t a, b;
+                region_side(S, L, P, c, dl, len, side, j, &a, &b);
+                rg_start[(int64_t)slot * n + j] = a; rg_len[(int64_t)slot * n + j] = b - a;
+            });
+            if (wave_leader()) info[slot] = RegInfo{2 * i + side, rs, rl, smin, (int32_t)c};
+        }
+    }
+};
+// The algorithmic bytes of a search whose request rows the host never saw (bench.py's roofline; Aligner::run_batch sums the same
+// over rows it holds): per (region, query genome) with piece length m and reference window n,
+//   out[0] += 4 x SURVEY 8d's m/4 + 16 m + 16 n,   out[1] += 2 x ((m + n)/2 + 64 B per sampled K-mer, none for pairs that fit 128 bases),   out[2] += 2 x m/2.
+// One wavefront per 64 pairs, one atomic per wavefront and counter.
+struct AlgBytes {
+    const RegionInfo* R; const int64_t* lens; int32_t ngen; int64_t npairs; uint64_t* out;
+    PM_HD void wave(int64_t w) const {
+        uint64_t a = 0, k = 0, q = 0;
+        lanes_for(0, 64, [&](int t) {
+            const int64_t pair = w * 64 + t;
+            if (pair >= npairs) return;
+            const int64_t r = pair / (ngen - 1); const int g = (int)(pair % (ngen - 1)) + 1;
+            const RegionInfo& ri = R[r];
+            const int64_t m = lens[r * ngen + g], n = ri.nR;
+            a += (uint64_t)(65 * m + 64 * n);
+            k += (uint64_t)(m + n);
+            if (!(m <= 128 && n <= 128) && m >= ri.K && n >= ri.K) k += 128ull * (uint64_t)((m - ri.K) / ri.stride + 1);
+            q += (uint64_t)m;
+        });
+        a = wave_sum_u64(a); k = wave_sum_u64(k); q = wave_sum_u64(q);
+        if (wave_leader()) { atomic_add64(out, a); atomic_add64(out + 1, k); atomic_add64(out + 2, q); }
+    }
+};
+// tid = (i, genome): request rows of the listed regions, in list order, where the search reads them
+struct GatherRegions {
+    const int32_t* ids; int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; int64_t* starts; int64_t* lens;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t r = ids[tid / ngen]; const int j = (int)(tid % ngen);
+        starts[tid] = rg_start[r * ngen + j]; lens[tid] = rg_len[r * ngen + j];
+    }
+};
+// one wavefront per pair of regions: equal in every genome (TRegion operator==, LCR.cpp:48-58)?
+struct RegionsEqual {
+    const int32_t* a; const int32_t* b; int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; uint8_t* same;
+    PM_HD void wave(int64_t i) const {
+        const int64_t x = a[i], y = b[i];
+        uint32_t diff = 0;
+        lanes_for(0, ngen, [&](int j) { if (rg_start[x * ngen + j] != rg_start[y * ngen + j] || rg_len[x * ngen + j] != rg_len[y * ngen + j]) diff = 1; });
+        diff = wave_or_u32(diff);
+        if (wave_leader()) same[i] = diff ? 0 : 1;
+    }
+};
+
+// ------------------------------------------------------------------------------------------ one generation of the recursion
+// doWork (src/parsnp.cpp:173-317) pops the region with the smallest reference start, validates its candidates in order
+// (setMums1, second half), pushes the neighbour regions of every new MUM that are longer than q (:215-254) and sorts.  The
+// caller has found the waiting regions to fall into clusters that are disjoint in EVERY genome (Aligner::extend_generations):
+// nothing found in one cluster can touch, trim or bound anything of another, so the clusters run side by side -- one
+// wavefront each, its regions in the reference's order -- and the children form the next generation.
+// What would make the order observable is reported, not decided here (`trouble`): a child that sorts before a region still
+// waiting in its cluster (bit 0), a reverse-strand member that passes the sequence check outside its region (bit 1), a
+// region with more candidates than the key holds (bit 2).
+// Are the clusters of a generation pairwise disjoint in EVERY genome (Aligner::disjoint_clusters)?  Collinear genomes hold them
+// in reference order: then it is "every cluster starts after its predecessor ends, with a base between" in every genome.  A
+// genome in which that fails for some pair is reported (trouble bit 3) -- the clusters may still be disjoint there in another
+// order, which the host route's exact test decides.  One wavefront per cluster (from the second on).
+struct ClustersDisjoint {
+    int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first; uint32_t* trouble;
+    PM_HD void wave(int64_t w) const {
+        const int64_t cl = w + 1;
+        const int64_t p0 = cluster_first[cl - 1], p1 = cluster_first[cl], c1 = cluster_first[cl + 1];
+        uint32_t bad = 0;
+        lanes_for(1, ngen, [&](int j) {
+            int64_t hi = -1, lo = (int64_t)1 << 62;
+            for (int64_t x = p0; x < p1; x++) { const int64_t r = now_region[x]; const int64_t e = rg_start[r * ngen + j] + rg_len[r * ngen + j]; if (e > hi) hi = e; }
+            for (int64_t x = p1; x < c1; x++) { const int64_t r = now_region[x]; const int64_t a = rg_start[r * ngen + j]; if (a < lo) lo = a; }
+            if (lo <= hi + 1) bad = 1;      // touching counts too
+        });
+        if (wave_or_u32(bad) && wave_leader()) atomic_or32(trouble, 8u);
+    }
+};
+struct ClusterValidate {
+    Store S; Layout L; Packed P;
+    int64_t* rg_start; int64_t* rg_len; RegInfo* info; uint64_t* rg_count; uint64_t rg_cap;
+    const int32_t* now_region; const int64_t* now_row0; const int32_t* now_cnt; const int64_t* cluster_first;
+    int32_t q; uint32_t* trouble;
+    PM_HD void wave(int64_t cl) const {
+        const int n = S.ngen;
+        int64_t pending_min = -1;
+        const int64_t x1 = cluster_first[cl + 1];
+        for (int64_t x = cluster_first[cl]; x < x1; x++) {
+            const int64_t rid = now_region[x];
+            const int64_t* rs = rg_start + rid * n; const int64_t* rl = rg_len + rid * n;
+            if (pending_min >= 0 && pending_min <= rs[0]) { if (wave_leader()) atomic_or32(trouble, 1u); return; }
+            const int64_t row0 = now_row0[x]; const int32_t cnt = now_cnt[x];
+            if (cnt >= (1 << 22)) { if (wave_leader()) atomic_or32(trouble, 4u); return; }
+            for (int64_t c = row0; c < row0 + cnt; c++) {
+                const uint32_t f = S.flags[c];
+                int32_t dl, len;
+                const bool acc = settle_row(S, L, P, c, true, &dl, &len);
+                if (acc && (f & kRowReverse)) {
+                    // a reverse member is flipped against the WHOLE genome (TMum.cpp:33-35): it can pass the sequence check while
+                    // lying outside this region's interval, and its marks could then meet another cluster's
+                    uint32_t out = 0;
+                    lanes_for(0, n, [&](int j) {
+                        if (S.strand[c * n + j]) return;
+                        const int64_t a = (int64_t)S.start[c * n + j] + dl;
+                        if (a < rs[j] - 1 || a + len > rs[j] + rl[j] + 1) out = 1;
+                    });
+                    if (wave_or_u32(out) && wave_leader()) atomic_or32(trouble, 2u);
+                }
+                if (acc) lanes_for(0, n, [&](int j) { const int64_t a = (int64_t)S.start[c * n + j] + dl; img_set_range(L, j, a, a + len); });
+                if (wave_leader()) {
+                    store_coherent32(&S.shift[c], dl); store_coherent32(&S.len[c], len);
+                    store_coherent8(&S.state[c], (uint8_t)(((f & kRowBad) ? 0 : kStBuilt) | ((f & (kRowBad | kRowOutside)) ? 0 : kStOk) | (acc ? kStAccepted : 0)));
+                }
+            }
+            // children: left of a new MUM, right of it, in candidate order (:215-254); one that equals a region still waiting in
+            // this cluster is dropped, as the work list drops a region equal to one it holds (:294-306)
+            int32_t seq = 0;
+            for (int64_t c = row0; c < row0 + cnt; c++) {
+                if (!(load_coherent8(&S.state[c]) & kStAccepted)) continue;
+                const int32_t dl = load_coherent32(&S.shift[c]), len = load_coherent32(&S.len[c]);
+                for (int side = 0; side < 2; side++) {
+                    int64_t ks, kl;
+                    const int32_t smin = region_extent(S, L, P, c, dl, len, side, &ks, &kl);
+                    if (smin <= q) continue;
+                    int32_t slot = 0;
+                    if (wave_leader()) slot = (int32_t)atomic_add64(rg_count, 1);
+                    slot = wave_bcast_i32(slot, 0);
+                    if ((uint64_t)slot >= rg_cap) continue;
+                    lanes_for(0, n, [&](int j) {
+                        int64_t a, b;
+                        region_side(S, L, P, c, dl, len, side, j, &a, &b);
+                        rg_start[(int64_t)slot * n + j] = a; rg_len[(int64_t)slot * n + j] = b - a;
+                    });
+                    bool dup = false;
+                    for (int64_t y = x + 1; y < x1 && !dup; y++) {
+                        const int64_t o = now_region[y];
+                        uint32_t diff = 0;
+                        lanes_for(0, n, [&](int j) {
+                            if (rg_start[(int64_t)slot * n + j] != rg_start[o * n + j] || rg_len[(int64_t)slot * n + j] != rg_len[o * n + j]) diff = 1;
+                        });
+                        dup = wave_or_u32(diff) == 0;
+                    }
+                    if (wave_leader()) info[slot] = RegInfo{dup ? -1 : ((x << 24) | (int64_t)seq), ks, kl, smin, (int32_t)c};
+                    seq++;
+                    if (!dup && (pending_min < 0 || ks < pending_min)) pending_min = ks;
+                }
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ chaining
+// The test of one MUM against the open chain's last MUM (setFinalClusters :2596-2700) for the pairs (cur[i], back[i]):
+// one wavefront per pair.  With every member of both on the forward strand -- all but inversions -- the test is a reduction:
+// every genome's gap (next start - chain end) inside [0, d], and the smallest and largest gap for the ratio test, which the
+// caller applies in the reference's float arithmetic.  A pair with a reverse member (the loop's strand rules and its
+// `max_gap = fgap` at :2608-2611 depend on the genome order) is handed back: verdict 2, the caller judges it from the rows.
+struct JudgePairs {
+    Store S; const int32_t* cur; const int32_t* back; int32_t d; int32_t* min_gap; int32_t* max_gap; uint8_t* verdict;
+    PM_HD void wave(int64_t i) const {
+        const int64_t a = cur[i], b = back[i];
+        const int n = S.ngen;
+        if ((S.flags[a] | S.flags[b]) & kRowReverse) { if (wave_leader()) verdict[i] = 2; return; }
+        const int64_t sa = S.shift[a], eb = (int64_t)S.shift[b] + S.len[b];
+        int32_t mn = 0x7fffffff, mx = -0x7fffffff;
+        uint32_t bad = 0;
+        lanes_for(0, n, [&](int j) {
+            const int64_t g = ((int64_t)S.start[a * n + j] + sa) - ((int64_t)S.start[b * n + j] + eb);
+            if (g < 0 || g > d) bad = 1;
+            const int32_t gi = g < -0x7fffffff ? -0x7fffffff : g > 0x7fffffff ? 0x7fffffff : (int32_t)g;
+            if (gi < mn) mn = gi;
+            if (gi > mx) mx = gi;
+        });
+        bad = wave_or_u32(bad); mn = wave_min_i32(mn); mx = wave_max_i32(mx);
+        if (wave_leader()) { verdict[i] = bad ? 1 : 0; min_gap[i] = mn; max_gap[i] = mx; }
+    }
+};
+// setInterClusterRegions (src/parsnp.cpp:2389-2460) for the pairs of consecutive LCBs (last MUM of the first, first MUM of
+// the next): where the two do not overlap in any genome, the filler from the end of the first to the next marked base.
+// add[i]: 1 = a filler is made (its rows in out_start / out_end), 0 = none, 2 = the reference's bookkeeping would overrun
+// (a genome whose scan does not run after one whose scan did, :2419-2433): the caller stops as the reference would.
+struct FillBetween {
+    Store S; Layout L; Packed P; const int32_t* last_of; const int32_t* first_of_next; uint8_t* add; int64_t* out_start; int64_t* out_end;
+    PM_HD void wave(int64_t i) const {
+        const int64_t ct = last_of[i], nx = first_of_next[i];
+        const int n = S.ngen;
+        const int64_t ce = (int64_t)S.shift[ct] + S.len[ct], ns = S.shift[nx];
+        uint32_t overlap = 0, small = 0;
+        int32_t first_scan = 0x7fffffff, last_noscan = -1;
+        lanes_for(0, n, [&](int j) {
+            const int64_t e = (int64_t)S.start[ct * n + j] + ce;
+            if (((int64_t)S.start[nx * n + j] + ns) - e <= 0) overlap = 1;
+            const int64_t stop = P.glen[j];
+            int64_t end;
+            if (e + 1 <= stop) { end = img_next_set(L, j, e + 1) - 1; if (j < first_scan) first_scan = j; }
+            else { end = stop - 1; if (j > last_noscan) last_noscan = j; }
+            out_start[i * n + j] = e; out_end[i * n + j] = end + 1;
+            if (end + 1 - e < 5) small = 1;
+        });
+        overlap = wave_or_u32(overlap); small = wave_or_u32(small);
+        first_scan = wave_min_i32(first_scan); last_noscan = wave_max_i32(last_noscan);
+        if (wave_leader()) add[i] = overlap ? 0 : (first_scan < last_noscan ? 2 : (small ? 0 : 1));
+    }
+};
+// tid = (i, genome): the listed rows as the host wants them -- start with the trim applied, strand byte
+struct StoreRowsOut {
+    Store S; const int32_t* rows; int32_t* out_start; uint8_t* out_strand; int raw;      // raw: as the search delivered them
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = rows[tid / S.ngen]; const int j = (int)(tid % S.ngen);
+        out_start[tid] = S.start[c * S.ngen + j] + (raw ? 0 : S.shift[c]);
+        out_strand[tid] = S.strand[c * S.ngen + j];
+    }
+};
+// tid = row - row0: per-row scalars for the host in one record
+struct RowInfo { int32_t start0, len, shift; uint32_t state_flags; };      // state_flags: state | flags << 8
+struct StoreInfoOut {
+    Store S; int64_t row0; RowInfo* out;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = row0 + tid;
+        out[tid] = RowInfo{S.start[c * S.ngen] + S.shift[c], S.len[c], S.shift[c], (uint32_t)S.state[c] | (S.flags[c] << 8)};
+    }
+};
+
+}  // namespace pm

@@ -149,7 +149,18 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
     // the layout (validate, or the end of find_anchors) awaits it.
     // (a few threads, not one: one core clears ~10 GB/s and would still be at it when the 11 ms anchor call returns;
     // not all: pages first touched by the worker threads can end up away from the thread that does most of the walking)
-    // ... unless the previous run left the other set of bitmaps all zero (it went on with the engine's layout image)
+    // ... unless the previous run never wrote to them (the resident route keeps the layout on the device) ...
+    if (memory_->layout_clean && layout.size() == n) {
+        bool fits = true;
+        for (size_t i = 0; i < n && fits; i++) fits = layout[i].bits() == genomes[i].seq.size() + 1 && !layout[i].attached();
+        memory_->layout_clean = false;
+        if (fits && test_hook("PARSNP_CHECK_ZERO"))
+            for (size_t i = 0; i < n; i++)
+                if (layout[i].count_set() != 1 || !layout[i].get((long)genomes[i].seq.size())) fatal("the layout of a resident run is not empty");
+        if (fits) return;
+    }
+    memory_->layout_clean = false;
+    // ... or left the other set of bitmaps all zero (it went on with the engine's layout image)
     if (memory_->spare_zero && memory_->spare.size() == n) {
         bool fits = true;
         for (size_t i = 0; i < n && fits; i++) fits = memory_->spare[i].bits() == genomes[i].seq.size() + 1;
@@ -278,6 +289,8 @@ Aligner::~Aligner() {
     deferred_.pending = false;      // marks nobody waited for are not set for the sake of it
     wait_layout();
     finish_prejudge();
+    // the resident route never writes to the host's bitmaps: the next run starts on them as they are
+    memory_->layout_clean = res_.active && !layout.empty() && !layout[0].attached();
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double t = now_s();
     auto lap = [&](const char* what) { if (dbg) { double u = now_s(); fprintf(stderr, "[release] %-10s %.4f s\n", what, u - t); t = u; } };
@@ -429,6 +442,10 @@ void Aligner::collect_engine_timing() {
     if (pm_last_timing(session_, &cnt, names, ms) != PM_OK) return;
     if (timing_first_call_) stats.anchor_ms.clear();
     for (int i = 0; i < cnt; i++) {
+        // (counts that travel in the timing list: the algorithmic bytes of a search whose rows only the engine held)
+        if (!strcmp(names[i], "alg_survey")) { stats.alg_bytes += ms[i]; continue; }
+        if (!strcmp(names[i], "alg_kernel")) { stats.alg_bytes_kernel += ms[i]; continue; }
+        if (!strcmp(names[i], "alg_query")) { stats.alg_bytes_query += ms[i]; continue; }
         if (timing_first_call_) stats.anchor_ms.emplace_back(names[i], ms[i]);
         bool merged = false;
         for (auto& kv : stats.engine_ms) if (kv.first == names[i]) { kv.second += ms[i]; merged = true; }
@@ -522,9 +539,13 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     // results as MUM rows built on the device where the provider can (the HIP engine) and every request is its region
     static const bool no_rows = test_hook("PARSNP_NO_DEVICE_ROWS") != nullptr;      // test hook: the host builds the rows from sp / fwd
     rows = rows && rows_supported_ && !no_rows;
-    if (rows != rows_mode_) {
-        if (pm_session_rows(session_, rows ? 1 : 0) == PM_OK) rows_mode_ = rows;
-        else { rows_supported_ = false; rows = rows_mode_ = false; }
+    {
+        int mode = rows ? (resident_try_ ? 2 : 1) : 0;
+        if (mode != rows_mode_) {
+            if (mode == 2 && pm_session_rows(session_, 2) != PM_OK) mode = 1;      // (a provider without a MUM store: the result carries its rows)
+            if (mode == 2 || pm_session_rows(session_, mode) == PM_OK) rows_mode_ = mode;
+            else { rows_supported_ = false; rows = false; rows_mode_ = 0; }
+        }
     }
     // the flat arrays of the C ABI live in the run's memory: 2 x 13 MB for the recursion batch, not faulted in per call
     std::vector<int64_t>& starts = memory_->batch_starts; std::vector<int64_t>& lens = memory_->batch_lens;
@@ -1247,6 +1268,14 @@ bool Aligner::find_anchors() {
     double ta = now_s();
     auto lap_a = [&](const char* what) { if (dbg_a) { const double t = now_s(); fprintf(stderr, "[anchors] %-18s %.4f s (cpu %.4f)\n", what, t - ta, cpu_lap_s()); ta = t; } };
     lap_a("set-up");
+    if (resident_anchors(whole, &found)) {      // the resident route (resident.cpp): validated on the device, the seed regions stay there
+        lap_a("resident anchors");
+        mums = found;
+        m0 = (long)found.size();
+        stats.resident = 1;
+        stats.anchor_s = now_s() - t0;
+        return m0 != 0;
+    }
     region_mums(whole, true, &found, false);
     lap_a("search + validation");
     // (marks that validate_parallel put off stay put off while the seed regions come from the rows: only walks read them)
@@ -1894,6 +1923,12 @@ bool Aligner::extend_generations() {
 // that is not cached, a speculative sweep over everything still on the work list predicts and batches the rest.
 bool Aligner::extend() {
     double t0 = now_s();
+    if (res_.active) {
+        const bool any = resident_extend();
+        if (getenv("PARSNP_DEBUG_TIMERS"))
+            fprintf(stderr, "[extend] resident route: %ld generations (%ld regions)%s%s\n", stats.generations, stats.generation_regions, res_.failed ? ", left: " : "", res_.failed ? res_.why.c_str() : "");
+        return any;
+    }
     speculation_ = test_hook("PARSNP_NO_SPECULATION") == nullptr;
     sweeps_ = 0; misses_since_sweep_ = 0;
     double tr = now_s();
@@ -1922,7 +1957,7 @@ void Aligner::filter_mums(int rvalue) {
         std::vector<Handle> h(mums.size());
         const long nh = (long)mums.size();        // one cache miss per MUM (its row): spread over the threads
 #pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
-        for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{pool[(size_t)mums[(size_t)i]].start[0], mums[(size_t)i]};
+        for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{key0(mums[(size_t)i]), mums[(size_t)i]};
         if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[filter_mums] keys %.4f s\n", now_s() - t0);
         // the list is the anchors followed by the MUMs of the recursion, generation by generation, each in reference order:
         // a few increasing runs, one of them (the anchors) much longer than the rest.  With all keys different there is one
@@ -1975,6 +2010,7 @@ void Aligner::filter_mums(int rvalue) {
     for (long x = 0; x < numums - 1; x++) {
         const Mum& mt = pool[(size_t)mums[(size_t)x]];
         if (mt.length > rvalue) continue;
+        if (res_.active) { res_.failed = true; res_.why = "a MUM short enough for filterRandom1"; return; }      // (the rows and the layout are the device's: host route)
         const Mum& nt = pool[(size_t)mums[(size_t)x + 1]];
         const Mum* prev = x > 0 ? &pool[(size_t)mums[(size_t)x - 1]] : nullptr;
         bool adjacent = true;
@@ -2069,7 +2105,7 @@ void Aligner::chain() {
         std::vector<Handle> h(mums.size());
         const long nh = (long)mums.size();        // one cache miss per MUM (its row): spread over the threads
 #pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
-        for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{pool[(size_t)mums[(size_t)i]].start[0], mums[(size_t)i]};
+        for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{key0(mums[(size_t)i]), mums[(size_t)i]};
         // strictly increasing keys (the list as filter_mums left it) have one sorted order: nothing to do.  With ties
         // the order std::sort leaves is the reference's, so it runs.
         bool increasing = true;
@@ -2082,7 +2118,8 @@ void Aligner::chain() {
     }
     if (mums.empty()) return;
     enum : uint8_t { JOIN = kJoin, CLOSE = kClose, PASS = kPass };
-    auto judge = [&](const Mum& nt, const Mum& back) -> uint8_t { return judge_pair(nt, back); };
+    auto judge = [&](int cur, int back) -> uint8_t { return res_.active ? resident_judge_rows(cur, back) : judge_pair(pool[(size_t)cur], pool[(size_t)back]); };
+    if (res_.active) resident_verdicts();      // (the pairs whose predecessor changed: one engine call)
     // almost always the chain's last MUM is the previous MUM of the list: those verdicts are independent, computed ahead
     const long m = (long)mums.size();
     // (a verdict depends on the two MUMs alone: the second chaining pass, after a few LCBs were dissolved, reuses the
@@ -2095,7 +2132,7 @@ void Aligner::chain() {
     for (long x = 1; x < m; x++) {
         const int cur = mums[(size_t)x], prev = mums[(size_t)x - 1];
         lens[(size_t)x] = pool[(size_t)cur].length;
-        if (judged_pred_[(size_t)cur] != prev) { judged_verdict_[(size_t)cur] = judge(pool[(size_t)cur], pool[(size_t)prev]); judged_pred_[(size_t)cur] = prev; }
+        if (judged_pred_[(size_t)cur] != prev) { judged_verdict_[(size_t)cur] = judge(cur, prev); judged_pred_[(size_t)cur] = prev; }
         ahead[(size_t)x] = judged_verdict_[(size_t)cur];
     }
 
@@ -2104,6 +2141,11 @@ void Aligner::chain() {
     auto close_chain = [&](Lcb& c) {      // start of the first MUM, end of the last (Cluster(TMum) LCB.cpp:21-28 + the joins)
         const Mum& f = pool[(size_t)c.mums.front()];
         const Mum& b = pool[(size_t)c.mums.back()];
+        if (res_.active) {      // the reference column now, the rows with materialize()
+            c.start.assign(1, key0(c.mums.front())); c.end.assign(1, key0(c.mums.back()) + b.length);
+            lcbs.push_back(c);
+            return;
+        }
         c.start.assign(f.start, f.start + n);
         c.end.resize(n);
         for (size_t k = 0; k < n; k++) c.end[k] = b.end(k);
@@ -2117,7 +2159,7 @@ void Aligner::chain() {
         if (!addmum) cluster = open_chain(mums[(size_t)x - 1]);
         addmum = true;
         const int back = cluster.mums.back();
-        const uint8_t v = back == mums[(size_t)x - 1] ? ahead[(size_t)x] : judge(pool[(size_t)mums[(size_t)x]], pool[(size_t)back]);
+        const uint8_t v = back == mums[(size_t)x - 1] ? ahead[(size_t)x] : judge(mums[(size_t)x], back);
         if (v == PASS) continue;
         if (v == JOIN) {
             cluster.length += nt_length;
@@ -2148,19 +2190,22 @@ void Aligner::filter_lcbs() {
     double t0 = now_s();
     sort_lcbs(lcbs);
     long count = (long)lcbs.size();
+    std::vector<int32_t> unmark;      // (resident route: the layout is the device's)
     for (long x = 0; x < count - 1; x++) {
         if (lcbs[(size_t)x].length > prm.c) continue;
         filtered_lcbs += 1;
         for (int idx : lcbs[(size_t)x].mums) {
             filtered += 1;
             const Mum& mt = pool[(size_t)idx];
-            for (size_t k = 0; k < n; k++) layout[k].clear_range(mt.start[k], mt.end(k));
+            if (res_.active) unmark.push_back(mt.row);
+            else for (size_t k = 0; k < n; k++) layout[k].clear_range(mt.start[k], mt.end(k));
             auto it = std::find(mums.begin(), mums.end(), idx);   // first MUM with that id
             if (it != mums.end()) mums.erase(it);
         }
         lcbs.erase(lcbs.begin() + x);
         x -= 1; count -= 1;
     }
+    if (!unmark.empty() && pm_store_unmark(session_, unmark.data(), (int64_t)unmark.size()) != PM_OK) fatal(std::string("cannot take dissolved LCBs out of the layout: ") + pm_last_error());
     stats.lcb_s += now_s() - t0;
 }
 
@@ -2169,6 +2214,7 @@ void Aligner::filter_lcbs() {
 void Aligner::fill_between() {
     double t0 = now_s();
     sort_lcbs(lcbs);
+    if (res_.active) { resident_fill_between(); stats.lcb_s += now_s() - t0; return; }
     // every pair of consecutive LCBs is looked at on its own (bitmap reads only): all threads, results kept in order
     const long npairs = (long)lcbs.size() - 1;
     std::vector<std::unique_ptr<Lcb>> made(npairs > 0 ? (size_t)npairs : 0);

@@ -265,6 +265,8 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
     long generations = 0, generation_regions = 0, generation_handover = -1;   // parallel generations, regions in them, generation at which the in-order replay took over (-1: never)
     long generation_restarts = 0;   // generation-parallel extension abandoned after its second generation (see extend_generations)
+    long resident = 0;              // 1: phases A-D ran on the resident route (resident.cpp: rows, layout and regions stayed on the device)
+    long resident_retry = 0;        // 1: the resident route was left (the reference's processing order would have shown) and the step ran again on the host route
     long tie_fallbacks = 0, literal_iterations = 0, parallel_candidates = 0, parallel_dirty = 0, parallel_tangled = 0;   // work-list ties between different regions (extend_pass)
     double t_validate = 0, t_neighbour = 0, t_key = 0, t_sweep = 0, t_replay = 0, t_sort = 0, t_unpack = 0;   // host split
 };
@@ -281,6 +283,7 @@ struct AlignerMemory {
     // taken back -- is all zero again: the next run starts on it without clearing 125 MB (spare_zero)
     std::vector<Bitmap> spare;
     bool spare_zero = false;
+    bool layout_clean = false;               // `layout` holds the sentinels and nothing else: the run that used it never wrote to it (the resident route)
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
     std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
     std::vector<Mum> pool_store, candidates;         // storage of Aligner::pool / validate_parallel's candidate records between runs
@@ -311,6 +314,13 @@ public:
     float anchor_time = 0, coarsen_time = 0, random_time = 0, clusters_time = 0, iclusters_time = 0;
     Stats stats;
     bool sharded_ = false;       // (set by the owner) a rank of a sharded run: every rank makes the same engine calls in the same order, no helper thread
+    // The resident route (resident.cpp): MUM rows, layout and regions stay on the device; the host keeps the list logic.
+    bool resident_allowed_ = true;                       // (set by the owner) false: the run that repeats a step the route was left in
+    bool resident_active() const { return res_.active; }
+    bool resident_failed() const { return res_.failed; }
+    const std::string& resident_why() const { return res_.why; }
+    void materialize();                                  // rows of the LCBs' MUMs (and the layout, for parsnp.unalign) for the writer; no-op on the host route
+    long key0(int idx) const { return res_.active ? (long)res_.start0[(size_t)idx] : (long)pool[(size_t)idx].start[0]; }      // reference start of a MUM
 
     bool find_anchors();       // returns m0 != 0
     bool extend();             // returns !mums.empty()
@@ -333,6 +343,22 @@ public:
     void finish_prejudge();
 
 private:
+    struct Resident {
+        bool active = false, failed = false, materialized = false;
+        std::string why;
+        int64_t table = 0;
+        std::vector<int32_t> start0;                                           // reference start of pool[i]
+        std::vector<pm_region_info> gen_info; std::vector<int32_t> gen_id;     // the seed regions, in push order
+        std::vector<int32_t> fallback_start; std::vector<uint8_t> fallback_strand;   // rows fetched for the host route
+        std::vector<uint64_t> image;                                           // the layout, fetched for parsnp.unalign
+    } res_;
+    bool resident_try_ = false;           // run_batch: ask for resident mode (the anchor call of the route)
+    bool layout_written_ = false;         // this run wrote to `layout`
+    bool resident_anchors(const Region& whole, std::vector<int>* found);
+    bool resident_extend();
+    void resident_verdicts();
+    uint8_t resident_judge_rows(int cur, int back);
+    void resident_fill_between();
     std::vector<std::future<void>> layout_ready_;
     // marks of the anchors' clean candidates that were put off (validate_parallel): start_deferred_marks() sets them in the
     // background, wait_layout() starts them if nobody has and joins -- every reader of the layout goes through it
@@ -386,7 +412,7 @@ private:
     int64_t spec_rows_ = 0;                   // rows of the anchor table the batch was derived from
     std::vector<int32_t> spec_min_;
     std::vector<Raw> spec_raw_;
-    bool rows_mode_ = false, rows_supported_ = true;
+    int rows_mode_ = -1; bool rows_supported_ = true;     // pm_session_rows: 0 (sp, fwd), 1 MUM rows, 2 resident; -1: as an earlier run of the session left it
     int64_t anchor_table_ = 0;         // id of the engine's resident anchor table that Mum::row / Region::gap_* refer to (0: none)
     bool timing_first_call_ = false;
     void collect_engine_timing();

@@ -111,6 +111,7 @@ int CoreRun::open(const std::string& ini_path) {
     // (test builds: the engine's thresholds of the long-list routes, lowered so that small inputs take them)
     if (const char* v = test_hook("PM_DIRTY_MIN")) (void)pm_session_tune(session, "dirty_min", atol(v));
     if (const char* v = test_hook("PM_WORK_BUDGET")) (void)pm_session_tune(session, "work_budget", atol(v));
+    if (const char* v = test_hook("PM_FLAGGED_DIV")) (void)pm_session_tune(session, "flagged_div", atol(v));
     upload_s = now_s() - t1;
     return 0;
 }
@@ -147,6 +148,26 @@ int CoreRun::mumi() {
 }
 
 StepReport CoreRun::step() {
+    uint64_t h0 = 0, d0 = 0, h1 = 0, d1 = 0;
+    (void)pm_session_traffic(session, &h0, &d0);
+    StepReport r = step_once(true);
+    const std::string why = align->resident_why();
+    if (align->resident_failed()) {
+        // the resident route was left: the reference's processing order would have shown in the result (resident.cpp).  The
+        // step runs again on the host route, from the anchor call.
+        if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[resident] route left (%s): the step runs again on the host route\n", align->resident_why().c_str());
+        const double lost = r.path_s;
+        r = step_once(false);
+        r.path_s += lost; r.host.resident_retry = 1;
+    }
+    (void)pm_session_traffic(session, &h1, &d1);
+    r.h2d_bytes = (double)(h1 - h0); r.d2h_bytes = (double)(d1 - d0);
+    if (const char* log = test_hook("PARSNP_RESIDENT_LOG"))      // test hook: which route every step took
+        if (FILE* f = fopen(log, "a")) { fprintf(f, "resident=%ld retry=%ld anchors=%ld mums=%ld why=%s\n", r.host.resident, r.host.resident_retry, r.anchors, r.mums, why.c_str()); fclose(f); }
+    return r;
+}
+
+StepReport CoreRun::step_once(bool resident) {
     StepReport r;
     const double ts = now_s();
     align.reset();
@@ -154,6 +175,7 @@ StepReport CoreRun::step() {
     memory.reset();
     align.reset(new Aligner(genomes, prm, session, &memory));
     align->sharded_ = shard.world > 1 || shard.rccl;
+    align->resident_allowed_ = resident;
     r.setup_s = now_s() - ts;
     if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[setup] release of the previous run %.4f s, new state %.4f s\n", tm - ts, now_s() - tm);
     Aligner& a = *align;
@@ -171,7 +193,7 @@ StepReport CoreRun::step() {
     }
     time(&end);
     r.mums_found = found;
-    if (found) {
+    if (found && !a.resident_failed()) {
         printf("        Finished recursive MUM search, elapsed time: %.0lf seconds\n\n", difftime(end, start));
         a.coarsen_time = (float)difftime(end, start);
         if (prm.random) {
@@ -182,6 +204,7 @@ StepReport CoreRun::step() {
             time(&end);
             printf("        Finished filtering spurious matches, elapsed time: %.0lf seconds\n\n", difftime(end, start));
             a.random_time = (float)difftime(end, start);
+            if (a.resident_failed()) { r.path_s = now_s() - t0; return r; }
         }
         time(&start);
         std::cerr << "Creating and verifying final LCBs..." << std::endl;
@@ -194,6 +217,7 @@ StepReport CoreRun::step() {
         // the reference chains again (:3261-3268).  With no LCB dissolved and no two MUMs sharing a reference start the
         // MUM list and its sorted order are unchanged, and the second pass would rebuild exactly the list at hand
         // (chain order = order of the first MUMs on the reference = the order sort_lcbs left).
+        if (a.resident_failed()) { r.path_s = now_s() - t0; return r; }
         bool same = a.filtered_lcbs == dissolved && a.unique_order && !test_hook("PARSNP_CHAIN_TWICE");
         for (size_t i = 1; i < a.lcbs.size() && same; i++) same = a.lcbs[i - 1].start[0] < a.lcbs[i].start[0];
         if (!same) { a.chain(); lap("chain"); }
@@ -215,6 +239,7 @@ StepReport CoreRun::step() {
 }
 
 void CoreRun::write(bool* gap_note) {
+    align->materialize();      // (resident route: the rows of the LCBs' MUMs come to the host now)
     write_output(*align, "parsnpAligner", gap_note);
     if (prm.unaligned) write_unaligned(*align);   // src/parsnp.cpp:3283-3287
 }

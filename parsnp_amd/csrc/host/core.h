@@ -17,6 +17,7 @@ struct StepReport {
     long finder_calls = 0, finder_regions = 0, regions_processed = 0, cache_hits = 0, cache_misses = 0, spec_rounds = 0;
     long anchors = 0, mums = 0, lcbs = 0, core_bp = 0;
     bool mums_found = false;
+    double h2d_bytes = 0, d2h_bytes = 0;   // what the engine moved over the host link during the step (pm_session_traffic)
     std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
     Stats host;
 };
@@ -44,6 +45,7 @@ public:
     int mumi();
     // phases A-D on a fresh Aligner over the resident genomes
     StepReport step();
+    StepReport step_once(bool resident);     // (resident: the resident route may be taken, resident.cpp)
     // XMFA + log of the last step (phase E)
     void write(bool* gap_note);
     Params prm;

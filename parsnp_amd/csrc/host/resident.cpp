@@ -1,0 +1,366 @@
+// resident.cpp -- the RESIDENT route of the host side: phases A-D with the MUM rows, the layout and the regions kept on the
+// device (include/parsnp_mum.h: pm_store_*).  What the engine does per MUM and genome there -- validation and trimming of the
+// candidates (second half of setMums1, src/parsnp.cpp:1713-1841, :1399-1477), the neighbour walks of determineRegion
+// (:1199-1290), the pairwise test of setFinalClusters (:2596-2700), setInterClusterRegions (:2389-2460) -- this file does not;
+// what stays here is the part of the reference whose ORDER is observable and which needs a few bytes per MUM only: the work
+// list of doWork (:173-317: sort by reference start, drop a region equal to its successor, ties), the order in which accepted
+// MUMs enter the list, the sort of filterRandom1 (:338), the chain walk (:2563-2719) and filterRandomClustersSimple1 (:433-497).
+//
+// The route is taken for a long anchor list (the engine keeps its rows: the anchor table) and left for the host route of
+// aligner.cpp -- by running the step again on a fresh Aligner (CoreRun::step) -- the moment the reference's processing order
+// would show: two different regions with one reference start, clusters of waiting regions that are not disjoint in every
+// genome, a child region sorting before a region still waiting in its cluster, a reverse-strand member outside its region
+// (Aligner::extend_generations hands over to the in-order replay at the same points).  Rows travel to the host once, after
+// phase D, for the XMFA writer (materialize()).
+#include "aligner.h"
+#include "hooks.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+namespace parsnp {
+
+namespace {
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+[[noreturn]] void fatal(const std::string& msg) {
+    std::cerr << "parsnp_core: " << msg << std::endl;
+    exit(1);
+}
+struct Handle { long key; int idx; };
+inline bool operator<(const Handle& a, const Handle& b) { return a.key < b.key; }
+void engine_error(const char* what, int rc) {
+    if (rc == PM_ELIMIT) {
+        std::cerr << "parsnp_core: input exceeds a limit of the multi-MUM engine: " << pm_last_error() << std::endl;
+        exit(5);
+    }
+    fatal(std::string(what) + ": " + pm_last_error());
+}
+}  // namespace
+
+// Phase A.  The anchor call in resident mode, the validation of its list on the device (pm_store_settle), the accepted anchors
+// as MUM records without rows, the seed regions (pm_store_seeds).  Returns true when the route is taken; false leaves the run
+// to find_anchors()'s host route with nothing changed -- the engine result, rows fetched, waits in the request cache.
+bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
+    static const bool off = test_hook("PARSNP_NO_RESIDENT") != nullptr;      // test hook: always the host route
+    if (off || !resident_allowed_ || !session_ || sharded_ || n < 2 || prm.anchors_only || prm.random >= 2 || !pool.empty()) { res_.why = "not applicable (switched off, sharded, anchors only or a MUM filter length >= 2)"; return false; }
+    const int minsize = min_length(true, whole.slength);
+    l = (float)minsize;
+    std::vector<Request> reqs;
+    chunk_requests(whole, minsize, &reqs);
+    if (reqs.size() != 1 || !reqs[0].plain) { res_.why = "chunked reference"; return false; }      // (p): the p-loop is the host route's
+    resident_try_ = true;
+    std::vector<Raw> raw;
+    run_batch(reqs, &raw, true);
+    resident_try_ = false;
+    Raw& a = raw[0];
+    const int64_t table = pm_result_table_id(a.owner.get());
+    const bool kept = table != 0 && pm_result_store_base(a.owner.get()) == 0;      // the rows stayed on the device
+    std::vector<pm_row_info> info;
+    int rc = PM_EAGAIN;
+    if (kept) {
+        info.resize(a.count);
+        const double ts = now_s();
+        rc = pm_store_settle(session_, table, info.data());
+        if (rc != PM_OK && rc != PM_EAGAIN) engine_error("validation of the anchors on the device failed", rc);
+        timing_first_call_ = false; collect_engine_timing();
+        stats.t_validate += now_s() - ts;
+    }
+    if (rc != PM_OK) {
+        // not this list (short: no anchor table; or too many rows overlapping earlier ones): the host route, from the same result
+        if (kept) {
+            res_.fallback_start.resize(a.count * n); res_.fallback_strand.resize(a.count * n);
+            if (pm_store_rows(session_, nullptr, 0, (int64_t)a.count, 1, res_.fallback_start.data(), res_.fallback_strand.data()) != PM_OK)
+                engine_error("cannot fetch the anchor rows", PM_EHIP);
+            a.start = res_.fallback_start.data(); a.strand = res_.fallback_strand.data();
+        }
+        CacheEntry* e = cache_put(reqs[0], false);
+        e->raw = std::move(a);
+        res_.why = kept ? "too many anchor candidates overlap earlier ones" : "short anchor list (no anchor table)";
+        return false;
+    }
+    // the accepted anchors, in list order (ids as the sequential loop assigns them: one per constructed candidate)
+    res_.active = true; res_.table = table;
+    kept_results_.push_back(a.owner);
+    pool.clear(); res_.start0.clear();
+    std::vector<int32_t> acc;
+    for (size_t c = 0; c < a.count; c++) {
+        const uint32_t st = info[c].state_flags & 0xffu;
+        if (st & PM_ST_BUILT) next_id_++;
+        if (!(st & PM_ST_ACCEPTED)) continue;
+        Mum m;
+        m.id = next_id_ - 1; m.length = info[c].len; m.slength = whole.slength; m.row = (int32_t)c;
+        m.dirty = (st & PM_ST_FLAGGED) != 0; m.touched = info[c].len != a.lon[c];
+        pool.push_back(m); res_.start0.push_back(info[c].start0);
+        found->push_back((int)pool.size() - 1);
+        acc.push_back((int32_t)c);
+        stats.parallel_dirty += m.dirty;
+        stats.parallel_tangled += (st & PM_ST_TANGLED) != 0;
+    }
+    stats.parallel_candidates += (long)a.count;
+    stats.regions_processed++;
+    // seed regions: both neighbours of every anchor, longer than q in every genome (:2150-2172)
+    const double tn = now_s();
+    int64_t nreg = 0;
+    rc = pm_store_seeds(session_, table, acc.data(), (int64_t)acc.size(), (int32_t)prm.q, &nreg);
+    if (rc != PM_OK) engine_error("seed regions on the device failed", rc);
+    collect_engine_timing();
+    const pm_region_info* ri = pm_store_new_regions(session_);
+    const int32_t* rid = pm_store_new_region_ids(session_);
+    // the reference pushes lR unless it equals the right region of the previous anchor, rR unless it equals lR (:2158-2170): equal
+    // regions have equal reference columns -- only then is the device asked
+    res_.gen_info.clear(); res_.gen_id.clear();
+    for (int64_t i = 0; i < nreg; i++) {
+        bool drop = false;
+        if (!res_.gen_info.empty()) {
+            const pm_region_info& p = res_.gen_info.back();
+            const bool neighbours = p.key == ri[i].key - 1;      // rR(i) right after lR(i), lR(i) right after rR(i-1) (key = 2 i + side)
+            if (neighbours && p.ref_start == ri[i].ref_start && p.ref_len == ri[i].ref_len && p.slength == ri[i].slength) {
+                uint8_t same = 0;
+                const int32_t x = res_.gen_id.back(), y = rid[i];
+                if (pm_store_regions_equal(session_, &x, &y, 1, &same) != PM_OK) engine_error("region comparison failed", PM_EHIP);
+                drop = same != 0;
+            }
+        }
+        if (drop) continue;
+        res_.gen_info.push_back(ri[i]); res_.gen_id.push_back(rid[i]);
+    }
+    stats.t_neighbour += now_s() - tn;
+    return true;
+}
+
+// Phase B: the generations of extend_generations() with the per-genome work on the device.
+bool Aligner::resident_extend() {
+    const double t0 = now_s();
+    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    std::vector<pm_region_info> gen = std::move(res_.gen_info);
+    std::vector<int32_t> gen_id = std::move(res_.gen_id);
+    // where the candidates of a region lie in the MUM store (-1: not searched yet), by region id
+    std::vector<int64_t> row0; std::vector<int32_t> cnt;
+    auto known = [&](int32_t id) { return (size_t)id < row0.size() && row0[(size_t)id] >= 0; };
+    std::vector<pm_row_info> info;
+    struct Batch { int64_t first, total; };
+    std::vector<Batch> batches;
+    auto search = [&](const std::vector<pm_region_info>& rs, const std::vector<int32_t>& ids) {      // one engine call for the regions without a result
+        std::vector<int32_t> want, mins;
+        for (size_t i = 0; i < ids.size(); i++) {
+            if (known(ids[i])) continue;
+            want.push_back(ids[i]); mins.push_back((int32_t)min_length(false, rs[i].slength));
+        }
+        if (want.empty()) return;
+        const double ts = now_s();
+        std::vector<int64_t> off(want.size() + 1);
+        int64_t first = 0;
+        const int rc = pm_store_search(session_, want.data(), mins.data(), (int64_t)want.size(), &first, off.data());
+        if (rc != PM_OK) engine_error("multi-MUM engine failed", rc);
+        for (size_t i = 0; i < want.size(); i++) {
+            const size_t id = (size_t)want[i];
+            if (row0.size() <= id) { row0.resize(id + 1, -1); cnt.resize(id + 1, 0); }
+            row0[id] = first + off[i]; cnt[id] = (int32_t)(off[i + 1] - off[i]);
+        }
+        batches.push_back(Batch{first, off[want.size()]});
+        timing_first_call_ = false;
+        collect_engine_timing();
+        stats.finder_calls++; stats.finder_regions += (long)want.size();
+        stats.finder_s += now_s() - ts;
+    };
+    int gi = 0;
+    double tl = now_s();
+    auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[resident generation %d] %-12s %.4f s\n", gi, what, t - tl); tl = t; } };
+    while (!gen.empty()) {
+        std::vector<pm_region_info> now; std::vector<int32_t> now_id;
+        std::vector<int64_t> first;
+        if (gi == 0) {                  // the first pushed seed, before anything is sorted (:194-195 precede :291-292); every seed's search in ONE call
+            search(gen, gen_id);
+            now.push_back(gen.front()); now_id.push_back(gen_id.front());
+            first = {0, 1};
+            gen.erase(gen.begin()); gen_id.erase(gen_id.begin());
+        } else {                        // sort by reference start, drop a region equal to its successor (:291-306)
+            std::vector<Handle> h(gen.size());
+            for (size_t i = 0; i < gen.size(); i++) h[i] = Handle{(long)gen[i].ref_start, (int)i};
+            std::sort(h.begin(), h.end());
+            for (size_t i = 0; i < h.size(); i++) {
+                const pm_region_info& r = gen[(size_t)h[i].idx];
+                if (!now.empty() && now.back().ref_start == r.ref_start) {
+                    uint8_t same = 0;
+                    if (now.back().ref_len == r.ref_len && now.back().slength == r.slength) {
+                        const int32_t x = now_id.back(), y = gen_id[(size_t)h[i].idx];
+                        if (pm_store_regions_equal(session_, &x, &y, 1, &same) != PM_OK) engine_error("region comparison failed", PM_EHIP);
+                    }
+                    if (same) continue;
+                    res_.failed = true; res_.why = "two different regions share a reference start";      // the unstable sort decides: host route
+                    return false;
+                }
+                now.push_back(r); now_id.push_back(gen_id[(size_t)h[i].idx]);
+            }
+            // clusters: maximal runs that overlap or touch on the reference (disjointness in the other genomes: the device)
+            long reach = -1;
+            for (size_t i = 0; i < now.size(); i++) {
+                if (i == 0 || now[i].ref_start > reach + 1) first.push_back((int64_t)i);
+                const long end = (long)(now[i].ref_start + now[i].ref_len);
+                if (end > reach) reach = end;
+            }
+            first.push_back((int64_t)now.size());
+            lap("sort");
+            search(now, now_id);
+            gen.clear(); gen_id.clear();
+        }
+        lap("search");
+        std::vector<int64_t> r0(now.size()); std::vector<int32_t> rc_(now.size());
+        for (size_t i = 0; i < now.size(); i++) { r0[i] = row0[(size_t)now_id[i]]; rc_[i] = cnt[(size_t)now_id[i]]; }
+        uint32_t trouble = 0; int64_t nkids = 0;
+        const double tv = now_s();
+        int rc = pm_store_validate(session_, now_id.data(), r0.data(), rc_.data(), (int64_t)now.size(), first.data(), (int64_t)first.size() - 1, (int32_t)prm.q, &trouble, &nkids);
+        if (rc != PM_OK) engine_error("validation of a generation on the device failed", rc);
+        collect_engine_timing();
+        if (trouble) {
+            res_.failed = true;
+            res_.why = (trouble & 8) ? "clusters of waiting regions overlap in some genome" : (trouble & 1) ? "a child region sorts before a region still waiting in its cluster"
+                     : (trouble & 2) ? "a reverse-strand member lies outside its region" : "a region with too many candidates";
+            stats.generation_handover = gi;
+            return false;
+        }
+        // children (the engine lists them parent by parent in push order) -> the next generation, after what is still waiting
+        const pm_region_info* ki = pm_store_new_regions(session_);
+        const int32_t* kid = pm_store_new_region_ids(session_);
+        for (int64_t i = 0; i < nkids; i++) { gen.push_back(ki[i]); gen_id.push_back(kid[i]); }
+        // the scalars of the candidates just decided: the ranges of the searches they came from
+        int64_t lo = INT64_MAX, hi = -1;
+        for (size_t i = 0; i < now.size(); i++) if (rc_[i] > 0) { lo = std::min(lo, r0[i]); hi = std::max(hi, r0[i] + rc_[i]); }
+        if (hi > lo) {
+            if (info.size() < (size_t)hi) info.resize((size_t)hi);
+            if (pm_store_info(session_, lo, hi - lo, info.data() + lo) != PM_OK) engine_error("cannot read the validation's verdicts", PM_EHIP);
+        }
+        stats.t_validate += now_s() - tv;
+        lap("validate");
+        // commit in list order (:215-254 push the MUMs of a region in candidate order)
+        for (size_t i = 0; i < now.size(); i++) {
+            for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) {
+                const uint32_t st = info[(size_t)c].state_flags & 0xffu;
+                if (st & PM_ST_BUILT) next_id_++;
+                if (!(st & PM_ST_ACCEPTED)) continue;
+                Mum m;
+                m.id = next_id_ - 1; m.length = info[(size_t)c].len; m.slength = now[i].slength; m.row = (int32_t)c;
+                pool.push_back(m); res_.start0.push_back(info[(size_t)c].start0);
+                mums.push_back((int)pool.size() - 1);
+            }
+            stats.regions_processed++; stats.cache_hits++;
+        }
+        stats.generations++; stats.generation_regions += (long)now.size();
+        lap("commit");
+        gi++;
+    }
+    stats.extend_s = now_s() - t0;
+    stats.t_replay = stats.extend_s;
+    return !mums.empty();
+}
+
+// setFinalClusters' test of MUM cur against the chain's last MUM, from rows fetched for the pair (a reverse-strand member,
+// or a chain whose last MUM is not the previous MUM of the list: rare)
+uint8_t Aligner::resident_judge_rows(int cur, int back) {
+    const int32_t rows[2] = {pool[(size_t)cur].row, pool[(size_t)back].row};
+    std::vector<int32_t> st(2 * n); std::vector<uint8_t> fw(2 * n);
+    if (pm_store_rows(session_, rows, 0, 2, 0, st.data(), fw.data()) != PM_OK) engine_error("cannot fetch MUM rows", PM_EHIP);
+    Mum a = pool[(size_t)cur], b = pool[(size_t)back];
+    a.start = st.data(); a.fwd = fw.data(); b.start = st.data() + n; b.fwd = fw.data() + n;
+    return judge_pair(a, b);
+}
+// verdicts of the consecutive pairs of the list whose predecessor changed since they were last judged
+void Aligner::resident_verdicts() {
+    const long m = (long)mums.size();
+    if (judged_pred_.size() < pool.size()) { judged_pred_.resize(pool.size(), -1); judged_verdict_.resize(pool.size(), kClose); }
+    std::vector<int32_t> cur, back; std::vector<int> who;
+    for (long x = 1; x < m; x++) {
+        const int c = mums[(size_t)x], p = mums[(size_t)x - 1];
+        if (judged_pred_[(size_t)c] == p) continue;
+        cur.push_back(pool[(size_t)c].row); back.push_back(pool[(size_t)p].row); who.push_back(c);
+        judged_pred_[(size_t)c] = p;
+    }
+    if (cur.empty()) return;
+    std::vector<int32_t> mn(cur.size()), mx(cur.size()); std::vector<uint8_t> v(cur.size());
+    const int rc = pm_store_judge(session_, cur.data(), back.data(), (int64_t)cur.size(), (int32_t)prm.d, mn.data(), mx.data(), v.data());
+    if (rc != PM_OK) engine_error("chaining verdicts on the device failed", rc);
+    collect_engine_timing();
+    const float diag_diff = prm.diag_diff;
+    for (size_t i = 0; i < who.size(); i++) {
+        uint8_t out;
+        if (v[i] == 2) out = resident_judge_rows(who[i], judged_pred_[(size_t)who[i]]);
+        else if (v[i] == 1) out = kClose;
+        else {
+            // every member forward and every gap in [0, d]: the loop of :2596-2700 leaves max_gap = the largest gap (from 0) and
+            // min_gap = the smallest (from d + 10); the ratio test in the reference's float / double mix
+            float max_gap = 0, min_gap = (float)(prm.d + 10);
+            if ((float)mx[i] > max_gap) max_gap = (float)mx[i];
+            if ((float)mn[i] < min_gap) min_gap = (float)mn[i];
+            if (min_gap == 0) min_gap = 1;
+            if (max_gap == 0) max_gap = 1;
+            if (diag_diff > 1.0) out = max_gap - min_gap < diag_diff ? kJoin : kPass;
+            else out = min_gap / max_gap >= 1.0 - diag_diff ? kJoin : kClose;
+        }
+        judged_verdict_[(size_t)who[i]] = out;
+    }
+}
+
+// setInterClusterRegions (:2389-2460) on the device; the fillers come back as rows
+void Aligner::resident_fill_between() {
+    const long npairs = (long)lcbs.size() - 1;
+    if (npairs <= 0) return;
+    std::vector<int32_t> last_of((size_t)npairs), first_next((size_t)npairs);
+    for (long x = 0; x < npairs; x++) {
+        last_of[(size_t)x] = pool[(size_t)lcbs[(size_t)x].mums.back()].row;
+        first_next[(size_t)x] = pool[(size_t)lcbs[(size_t)x + 1].mums.front()].row;
+    }
+    std::vector<uint8_t> add((size_t)npairs);
+    const int rc = pm_store_fill(session_, last_of.data(), first_next.data(), npairs, add.data());
+    if (rc != PM_OK) engine_error("inter-LCB regions on the device failed", rc);
+    collect_engine_timing();
+    const int64_t* fs = pm_store_fill_starts(session_); const int64_t* fe = pm_store_fill_ends(session_);
+    std::vector<Lcb> fillers;
+    size_t at = 0;
+    for (long x = 0; x < npairs; x++) {
+        if (add[(size_t)x] == 2) fatal("inter-cluster region bookkeeping would overrun in the reference");
+        if (add[(size_t)x] != 1) continue;
+        Lcb f;
+        f.type = 0; f.length = 2;
+        f.start.assign(fs + at, fs + at + n); f.end.assign(fe + at, fe + at + n);
+        at += n;
+        fillers.push_back(std::move(f));
+    }
+    lcbs.insert(lcbs.begin(), fillers.begin(), fillers.end());
+}
+
+// The rows the XMFA writer reads -- every MUM of an LCB, the LCBs' own start / end rows -- and, for parsnp.unalign, the
+// layout: fetched once, after phase D.
+void Aligner::materialize() {
+    if (!res_.active || res_.materialized) return;
+    res_.materialized = true;
+    const double t0 = now_s();
+    std::vector<int32_t> rows; std::vector<int> who;
+    std::vector<uint8_t> seen(pool.size(), 0);
+    for (const Lcb& c : lcbs)
+        for (int idx : c.mums) if (!seen[(size_t)idx]) { seen[(size_t)idx] = 1; rows.push_back(pool[(size_t)idx].row); who.push_back(idx); }
+    int32_t* st = irows_.alloc(rows.size() * n + 1); uint8_t* fw = brows_.alloc(rows.size() * n + 1);
+    if (!rows.empty() && pm_store_rows(session_, rows.data(), 0, (int64_t)rows.size(), 0, st, fw) != PM_OK) engine_error("cannot fetch the MUM rows", PM_EHIP);
+    for (size_t i = 0; i < who.size(); i++) { pool[(size_t)who[i]].start = st + i * n; pool[(size_t)who[i]].fwd = fw + i * n; }
+    for (Lcb& c : lcbs) {
+        if (c.type != 1 || c.mums.empty()) continue;
+        const Mum& f = pool[(size_t)c.mums.front()]; const Mum& b = pool[(size_t)c.mums.back()];
+        c.start.assign(f.start, f.start + n);
+        c.end.resize(n);
+        for (size_t k = 0; k < n; k++) c.end[k] = b.end(k);
+    }
+    if (prm.unaligned) {      // write_unaligned walks (and marks) the layout
+        wait_layout();
+        std::vector<int64_t> off(n + 1);
+        const int64_t words = pm_store_layout_words(session_, off.data());
+        res_.image.resize((size_t)words);
+        if (pm_store_layout(session_, res_.image.data(), words) != PM_OK) engine_error("cannot fetch the layout", PM_EHIP);
+        for (size_t j = 0; j < n; j++) layout[j].attach(res_.image.data() + off[j], (size_t)(off[j + 1] - off[j]), genomes[j].seq.size() + 1);
+    }
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[resident] rows of %zu MUMs fetched for the writer %.4f s\n", rows.size(), now_s() - t0);
+}
+
+}  // namespace parsnp

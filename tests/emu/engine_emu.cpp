@@ -16,11 +16,12 @@ struct HostBackend {
     static void* host_alloc(size_t n) { return malloc(n ? n : 1); }
     static void host_free(void* p) { ::free(p); }
     void memset(void* p, int v, size_t n) { ::memset(p, v, n); }
-    void h2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
-    void d2h(void* d, const void* s, size_t n) { memcpy(d, s, n); }
-    void d2h_async(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+    uint64_t bytes_h2d = 0, bytes_d2h = 0;      // what a device backend would have moved over the host link
+    void h2d(void* d, const void* s, size_t n) { bytes_h2d += n; memcpy(d, s, n); }
+    void d2h(void* d, const void* s, size_t n) { bytes_d2h += n; memcpy(d, s, n); }
+    void d2h_async(void* d, const void* s, size_t n) { bytes_d2h += n; memcpy(d, s, n); }
     void d2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
-    void d2h_side(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+    void d2h_side(void* d, const void* s, size_t n) { bytes_d2h += n; memcpy(d, s, n); }
     void side_wait() {}
     void bind() {}
     void* pinned_alloc(size_t n) { return malloc(n ? n : 1); }
@@ -35,7 +36,7 @@ struct HostBackend {
     int allgather_dev(const void*, int64_t, void*) { return 1; }
     std::vector<char> stage;
     void* staging(size_t n) { if (stage.size() < n) stage.resize(n); return stage.data(); }
-    void h2d_staged(void* d, const void* s, size_t n) { memcpy(d, s, n); }
+    void h2d_staged(void* d, const void* s, size_t n) { bytes_h2d += n; memcpy(d, s, n); }
     template <class F> void launch(const char*, int64_t n, F f) { for (int64_t i = 0; i < n; i++) f(i); }
     bool stage_genomes(int n, const uint8_t* const* seqs, const int64_t* lens, const std::vector<char>& take, const std::vector<int64_t>& goff,
                        pm::SeqBlock* blk, int64_t) {

@@ -122,7 +122,7 @@ def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
     the overlap test / the row construction back to the host: same bytes either way."""
     r, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_NO_RESIDENT="1")      # (the host route: the resident route has its own test below)
     if variant == "host_overlap":
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":
@@ -141,6 +141,29 @@ def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
     if name == "pop6x200k":                 # a collinear set: the marks are put off unless told otherwise
         assert ("put off" in err) == (variant != "mark_first")
+
+
+@pytest.mark.parametrize("name,flagged_div,expect", [("viral50", 8, "resident"), ("pop6x200k", 8, "resident"), ("pop12x400k", 8, "resident"), ("pop12x400k", 1, "resident"),
+                                                      ("rearr6x300k", 8, "host"), ("rearr6x300k", 1, "left"), ("messy", 8, "left"), ("pchunk", 8, "host")])
+def test_resident_route(emu, tmp_path, name, flagged_div, expect):
+    """The resident route (csrc/host/resident.cpp over include/parsnp_mum.h's pm_store_*: candidates validated and trimmed, regions
+    walked, generations validated, chaining verdicts and inter-LCB fillers computed on rows that stay with the engine) in the
+    kernel emulation: the reference's bytes where it is taken (collinear sets; pop12x400k has 166 flagged anchor candidates, 6 of
+    them tangled), where the engine declines the anchor list (rearranged: more than one row in eight overlaps an earlier one)
+    and where the route is left because the reference's processing order would show (the step is repeated on the host route).
+    flagged_div = 1 lets every anchor list onto the route, so that the trimming kernels see the rearranged set as well."""
+    rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
+    log = str(tmp_path / "route.log")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PM_FLAGGED_DIV=str(flagged_div), PARSNP_RESIDENT_LOG=log, PARSNP_CHECK_ZERO="1")
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(emu[1], rp, qs, out, env=env, threads=4, **kw)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    want = test_host_logic.E2E[name]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == want["xmfa_md5"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
+    route = open(log).read()
+    assert ("resident=1" in route) == (expect == "resident"), route
+    assert ("retry=1" in route) == (expect == "left"), route
 
 
 def test_work_budget_retry(libs, monkeypatch):

@@ -12,6 +12,8 @@ import xmfa_util
 from parsnp_amd import driver, synth
 from parsnp_amd.paths import CORE_BIN
 
+CORE_HOOKS_BIN = os.path.join(os.path.dirname(CORE_BIN), "parsnp_core_hooks")      # the product's sources with the test hooks compiled in
+
 REFBIN = os.path.join(oracles.REFDIR, "parsnp_core_ref")
 pytestmark = pytest.mark.skipif(not os.path.exists(REFBIN), reason="reference binary not built/shipped")
 
@@ -88,13 +90,14 @@ def test_fuzz_host_logic(cpu_checkers, tmp_path, seed):
     side_by_side(cpu_checkers, seed, tmp_path)
 
 
-@pytest.mark.parametrize("seed", range(16))
-def test_fuzz_anchor_table_routes(emu, tmp_path, monkeypatch, seed):
-    """the same side by side for the host code over the kernel emulation, threaded, with the thresholds of the long-list routes
-    lowered so that these small sets take what needs the engine's resident anchor table: requests by reference, the recursion's
-    first batch computed ahead, the layout image (asked for before the validation, its corrections) -- scripts/fuzz_campaign.py
-    with PARSNP_FUZZ_CORE=emu is the long form (684 sets in round 3)"""
-    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_PREJUDGE_MIN="2", PARSNP_CHECK_ZERO="1").items():
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_resident_route(emu, tmp_path, monkeypatch, seed):
+    """side by side with the reference binary for the RESIDENT route (resident.cpp / pm_store_*) in the kernel emulation: the
+    thresholds lowered so that these small sets take it, and -- every other seed -- every anchor list let onto it however many
+    of its rows overlap earlier ones (PM_FLAGGED_DIV=1: the trimming and the in-order settling of tangled rows at work on
+    rearranged genomes).  Where the reference's order would show the route is left and the step repeated on the host route:
+    the bytes must be the reference's either way."""
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_PREJUDGE_MIN="2", PARSNP_CHECK_ZERO="1", PM_FLAGGED_DIV="1" if seed % 2 else "8").items():
         monkeypatch.setenv(k, v)
     ref, gs, kw, contigs = random_case(seed)
     if kw.get("threads", 1) < 2:
@@ -103,6 +106,34 @@ def test_fuzz_anchor_table_routes(emu, tmp_path, monkeypatch, seed):
     a = run(REFBIN, rp, qs, str(tmp_path / "ref"), kw)
     b = run(emu[1], rp, qs, str(tmp_path / "mine"), kw)
     assert a == b, (seed, kw, contigs)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_anchor_table_routes(emu, tmp_path, monkeypatch, seed):
+    """the same side by side for the host code over the kernel emulation, threaded, with the thresholds of the long-list routes
+    lowered so that these small sets take what needs the engine's resident anchor table: requests by reference, the recursion's
+    first batch computed ahead, the layout image (asked for before the validation, its corrections) -- scripts/fuzz_campaign.py
+    with PARSNP_FUZZ_CORE=emu is the long form (684 sets in round 3)"""
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_PREJUDGE_MIN="2", PARSNP_CHECK_ZERO="1", PARSNP_NO_RESIDENT="1").items():
+        monkeypatch.setenv(k, v)
+    ref, gs, kw, contigs = random_case(seed)
+    if kw.get("threads", 1) < 2:
+        kw["threads"] = 3
+    rp, qs = write(str(tmp_path / "in"), ref, gs, contigs, seed)
+    a = run(REFBIN, rp, qs, str(tmp_path / "ref"), kw)
+    b = run(emu[1], rp, qs, str(tmp_path / "mine"), kw)
+    assert a == b, (seed, kw, contigs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_resident_route_on_gpu(tmp_path, monkeypatch, seed):
+    """the resident route's KERNELS (store_kernels.h: wave64 code the CPU suite only runs through its one-thread emulation) side
+    by side with the reference binary: the product's sources with the test hooks compiled in, thresholds lowered so that the
+    small sets take the route, every other seed with every anchor list let onto it (PM_FLAGGED_DIV=1)"""
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_PREJUDGE_MIN="2", PM_FLAGGED_DIV="1" if seed % 2 else "8").items():
+        monkeypatch.setenv(k, v)
+    side_by_side(CORE_HOOKS_BIN, seed, tmp_path, big=seed >= 32)
 
 
 @pytest.mark.gpu

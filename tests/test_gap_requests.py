@@ -43,7 +43,7 @@ def test_gap_requests_same_bytes(emu, tmp_path, name):
         ini = os.path.join(out, "run.ini")
         open(ini, "w").write(driver.ini_text(rp, qs, out, threads=4))
         # (small sets: the thresholds of the long-list routes are lowered so that the anchor list takes them)
-        e = dict(os.environ, PM_DIRTY_MIN="16", PARSNP_PARALLEL_MIN="16", **env)
+        e = dict(os.environ, PM_DIRTY_MIN="16", PARSNP_PARALLEL_MIN="16", PARSNP_NO_RESIDENT="1", **env)      # (routes of the HOST route)
         p = subprocess.run([sys.executable, "-c", _CHILD, ini, core_lib], capture_output=True, text=True, env=e, cwd=out, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         got[tag] = (json.loads(p.stdout.strip().splitlines()[-1]), xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")),
@@ -76,7 +76,7 @@ def test_layout_image_same_bytes(emu, tmp_path, name):
         os.makedirs(out)
         ini = os.path.join(out, "run.ini")
         open(ini, "w").write(driver.ini_text(rp, qs, out, threads=4))
-        e = dict(os.environ, PM_DIRTY_MIN="16", PARSNP_PARALLEL_MIN="16", PARSNP_CHECK_ZERO="1", **env)
+        e = dict(os.environ, PM_DIRTY_MIN="16", PARSNP_PARALLEL_MIN="16", PARSNP_CHECK_ZERO="1", PARSNP_NO_RESIDENT="1", **env)
         p = subprocess.run([sys.executable, "-c", child, ini, core_lib], capture_output=True, text=True, env=e, cwd=out, timeout=900)
         assert p.returncode == 0, p.stderr[-2000:]
         got[tag] = (json.loads(p.stdout.strip().splitlines()[-1]), xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")),

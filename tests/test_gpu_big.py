@@ -45,13 +45,23 @@ def test_baseline_size_against_reference(scratch, name):
     want = BIG[name]
     rp, qs = inputs(name, scratch)
     assert len(qs) == want["n_queries"]
-    for mode in ("generations", "in_order"):
+    # the shipped binary (the resident route where the anchor list allows it: configs 3 and 4), then the host route in both of
+    # its replay modes (test hooks: forced through the product's sources built with csrc/host/hooks.h's switches)
+    for mode in ("shipped", "generations", "in_order"):
         env = dict(os.environ, OMP_WAIT_POLICY="passive")
+        if mode != "shipped":
+            env["PARSNP_NO_RESIDENT"] = "1"
         if mode == "in_order":
             env["PARSNP_SEQUENTIAL_REPLAY"] = "1"
         out = os.path.join(scratch, name, "out_" + mode)
-        # (the in-order replay is a test hook: forced through the product's sources built with csrc/host/hooks.h's switches)
-        rc, _ = driver.run_core(CORE_HOOKS_BIN if mode == "in_order" else CORE_BIN, rp, qs, out, env=env, threads=24)
+        timing = os.path.join(scratch, name, "timing_" + mode + ".json")
+        rc, _ = driver.run_core(CORE_BIN if mode == "shipped" else CORE_HOOKS_BIN, rp, qs, out, env=env, threads=24, timing=timing)
+        if rc == 0:
+            tj = json.load(open(timing))
+            # collinear populations (configs 3, 4) stay on the resident route; the rearranged set is declined at the anchor list
+            assert tj["resident"] == (1 if (mode == "shipped" and name != "rearr50") else 0), (mode, tj)
+            if tj["resident"]:
+                assert tj["d2h_bytes"] < 20e6 and tj["resident_retry"] == 0, tj      # rows stay on the device until the writer asks
         assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
         x = os.path.join(out, "parsnpAligner.xmfa")
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"], mode

@@ -200,20 +200,24 @@ def test_parsnp_core_synthetic(libs, tmp_path, name):
     test_host_logic.check(CORE_BIN, name, rp, qs, str(tmp_path / "out"))
 
 
-@pytest.mark.parametrize("name,mode", [("pop20x1m", "generations"), ("pop20x1m", "in_order"), ("draft20x1m", "generations"), ("poprearr10x400k", "generations")])
+@pytest.mark.parametrize("name,mode", [("pop20x1m", "resident"), ("pop20x1m", "generations"), ("pop20x1m", "in_order"), ("draft20x1m", "resident"), ("draft20x1m", "generations"),
+                                       ("poprearr10x400k", "generations")])
 def test_parsnp_core_replay_modes_threaded(libs, tmp_path, name, mode):
-    """8 host threads: the generation-parallel replay of the recursion (clusters of regions validated concurrently, atomic
-    marks) and the forced in-order replay give the reference's bytes"""
+    """8 host threads: the resident route (the shipped binary's default for a long anchor list: generations validated on the
+    device), the host route's generation-parallel replay of the recursion (clusters of regions validated concurrently, atomic
+    marks) and its forced in-order replay give the reference's bytes"""
     if name == "pop20x1m":
         r, gs = synth.make(name)
         rp, qs = synth.write_set(str(tmp_path / "in"), r, gs); kw = {}
     else:
         rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
     env = dict(os.environ)
+    if mode != "resident":
+        env["PARSNP_NO_RESIDENT"] = "1"
     if mode == "in_order":
         env["PARSNP_SEQUENTIAL_REPLAY"] = "1"
     out = str(tmp_path / "out")
-    rc, _ = driver.run_core(CORE_HOOKS_BIN if mode == "in_order" else CORE_BIN, rp, qs, out, env=env, threads=8, **kw)
+    rc, _ = driver.run_core(CORE_BIN if mode == "resident" else CORE_HOOKS_BIN, rp, qs, out, env=env, threads=8, **kw)
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
@@ -232,7 +236,7 @@ def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant
     else:
         r, gs = synth.make(name)
         rp, qs = synth.write_set(str(tmp_path / "in"), r, gs); kw = {}
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_PREJUDGE_MIN="8")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_PREJUDGE_MIN="8", PARSNP_NO_RESIDENT="1")      # (routes of the HOST route)
     if variant == "host_overlap":
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":
@@ -254,6 +258,26 @@ def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
     if name == "pop20x1m":                  # a collinear set: the marks are put off unless told otherwise
         assert ("put off" in err) == (variant != "mark_first")
+
+
+@pytest.mark.parametrize("name,flagged_div,expect", [("viral50", 8, "resident"), ("pop6x200k", 8, "resident"), ("pop12x400k", 8, "resident"), ("pop12x400k", 1, "resident"), ("pop20x1m", 8, "resident"),
+                                                      ("bact8", 8, "resident"), ("rearr6x300k", 8, "host"), ("rearr6x300k", 1, "left"), ("poprearr10x400k", 1, "left"), ("messy", 8, "left"), ("pchunk", 8, "host")])
+def test_parsnp_core_resident_route(libs, tmp_path, name, flagged_div, expect):
+    """The resident route on the device (store_kernels.h through pm_store_*): the reference's bytes where it is taken, where the
+    engine declines the anchor list and where the route is left and the step repeated on the host route; thresholds lowered so
+    that the small sets take it (pop12x400k: 166 flagged anchor candidates, 6 tangled; flagged_div = 1 sends rearranged lists
+    through the trimming kernels too).  Three steps in one process: the stores start over with every anchor call."""
+    rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
+    log = str(tmp_path / "route.log")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PM_FLAGGED_DIV=str(flagged_div), PARSNP_RESIDENT_LOG=log, PARSNP_CHECK_ZERO="1")
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(CORE_HOOKS_BIN, rp, qs, out, env=env, threads=8, **kw)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
+    route = open(log).read()
+    assert ("resident=1" in route) == (expect == "resident"), route
+    assert ("retry=1" in route) == (expect == "left"), route
 
 
 @pytest.mark.parametrize("name", ["mers", "messy", "pop6x200k_p"])
