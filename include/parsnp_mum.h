@@ -42,10 +42,11 @@ int pm_warmup(int device);
  * src/parsnp.cpp:1540-1561: regions are addressed by (start,len) into these resident copies.
  * device < 0 selects the current HIP device. */
 int pm_session_create(pm_session** out, int device, int n_genomes, const uint8_t* const* seqs, const int64_t* lens);
-/* Sharded run over the GPUs of one node: rank r of `world` keeps the reference and a contiguous block of
- * the query genomes (block r of world equal blocks of genomes 1..n-1, in ini order) resident on its GPU; seqs[] of the
- * other genomes is not read.  Every rank makes the same sequence of pm_multi_mum_batch / pm_mumi_coverage calls with
- * the same arguments and receives the same results.  Per batch the engine exchanges
+/* Sharded run over the GPUs of one node: rank r of `world` SEARCHES a contiguous block of the query genomes
+ * (block r of world equal blocks of genomes 1..n-1, in ini order) against the reference; every rank keeps all genomes
+ * resident (one byte per base and strand -- memory is not what a 288 GB GPU runs out of -- so that the validation of the
+ * resident route can check any member of a MUM against its sequence).  Every rank makes the same sequence of calls with the
+ * same arguments and receives the same results.  Per batch the engine exchanges
  *   (1) Master.EP, reduced with min over the ranks           (allreduce_min, one int32 per reference position), and
  *   (2) the per-genome (EP,UP,SP) columns at the candidates  (allgather of equal-size blocks),
  * through the two callbacks (host buffers; 0 = success), which the embedding process implements with

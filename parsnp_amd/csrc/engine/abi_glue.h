@@ -177,7 +177,6 @@ int pm_session_tune(pm_session* s, const char* key, int64_t value) {
 }
 int pm_session_rows(pm_session* s, int enable) {
     if (!s || enable < 0 || enable > 2) return fail(PM_EINVAL, "bad argument");
-    if (enable == 2 && (s->engine->coll.world > 1 || s->engine->coll.device)) return fail(PM_EINVAL, "a sharded session has no resident mode");
     s->engine->want_rows = enable != 0; s->engine->resident = enable == 2;
     return PM_OK;
 }

@@ -126,7 +126,10 @@ public:
         ngen = n;
         glen_h.assign(lens, lens + n);
         shard_range(n, coll.rank, coll.world, &g_first, &g_last);
-        auto resident = [&](int g) { return g == 0 || (g >= g_first && g < g_last); };
+        // every rank of a sharded run keeps ALL genomes resident (one byte per base and strand: 57 000 5-Mb genomes fit one GPU):
+        // the SEARCH is what is sharded -- a rank streams the query genomes of its block only (CountUnits, SmallPairEvents,
+        // MasterEP) -- while the resident route's validation checks reverse-strand members of any genome against the sequence
+        auto resident = [&](int) { return true; };
         std::vector<int64_t> goff(2 * (size_t)n);
         int64_t words = 2;                       // leading guard (64 bases)
         int64_t maxlen = 0;
@@ -395,7 +398,7 @@ public:
         if (from_store) {      // the algorithmic bytes of a search whose rows the host never saw (read back with the event counters)
             ensure(d_alg, 4);
             be.memset(d_alg.p, 0, 32);
-            be.launch_wave("alg_bytes", (nreg * nq + 63) / 64, AlgBytes{d_R.p, d_lens.p, ngen, nreg * nq, d_alg.p});
+            be.launch_wave("alg_bytes", (nreg * nq + kAlgPairs - 1) / kAlgPairs, AlgBytes{d_R.p, d_lens.p, ngen, nreg * nq, d_alg.p});
         }
         be.mark("index");
         be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p, d_filter.p});
@@ -982,11 +985,20 @@ public:
         be.launch_wave("fill_between", n, FillBetween{store_view(), layout_view(d_image.p), P, d_list.p, d_list2.p, d_small8.p, d_f_start.p, d_f_end.p});
         be.mark(nullptr);
         be.d2h(add, d_small8.p, (size_t)n);
-        for (int64_t i = 0; i < n; i++) {
-            if (add[i] != 1) continue;
-            const size_t at = starts->size();
-            starts->resize(at + ngz); ends->resize(at + ngz);
-            be.d2h_async(starts->data() + at, d_f_start.p + (size_t)i * ngz, 8 * ngz); be.d2h(ends->data() + at, d_f_end.p + (size_t)i * ngz, 8 * ngz);
+        std::vector<int32_t> which;
+        for (int64_t i = 0; i < n; i++) if (add[i] == 1) which.push_back((int32_t)i);
+        if (!which.empty()) {      // the rows of the fillers, packed on the device: one copy
+            const size_t m = which.size();
+            ensure(d_list, m); ensure(d_f_pack, 2 * m * ngz);
+            be.h2d(d_list.p, which.data(), 4 * m);
+            be.launch("fill_gather", (int64_t)m * ngen, FillGather{d_list.p, ngen, d_f_start.p, d_f_end.p, d_f_pack.p});
+            std::vector<int64_t> pack(2 * m * ngz);
+            be.d2h(pack.data(), d_f_pack.p, 8 * pack.size());
+            starts->resize(m * ngz); ends->resize(m * ngz);
+            for (size_t k = 0; k < m; k++) {
+                memcpy(starts->data() + k * ngz, pack.data() + (2 * k) * ngz, 8 * ngz);
+                memcpy(ends->data() + k * ngz, pack.data() + (2 * k + 1) * ngz, 8 * ngz);
+            }
         }
         collect_timing_more();
         return 0;
@@ -1122,7 +1134,7 @@ private:
     int64_t table_counter = 0;
     Buf<uint64_t> d_image; Buf<int64_t> d_imgoff, d_imgbits; Buf<uint8_t> d_accept; Buf<int32_t> d_xstart, d_xlon;
     Buf<uint8_t> d_ms_strand, d_ms_state, d_small8, d_o_strand; Buf<int32_t> d_ms_shift, d_ms_len, d_list, d_list2, d_j_min, d_j_max, d_o_start;
-    Buf<int64_t> d_rg_start, d_rg_len, d_lay_off, d_lay_bits, d_v_row0, d_v_first, d_f_start, d_f_end; Buf<RegInfo> d_rg_info; Buf<uint64_t> d_rg_count, d_once, d_twice;
+    Buf<int64_t> d_rg_start, d_rg_len, d_lay_off, d_lay_bits, d_v_row0, d_v_first, d_f_start, d_f_end, d_f_pack; Buf<RegInfo> d_rg_info; Buf<uint64_t> d_rg_count, d_once, d_twice;
     Buf<RowInfo> d_rowinfo; Buf<uint64_t> d_alg;
     size_t lay_words = 0, rg_cap_hint = 0;
     int64_t layout_rows = -1;       // >= 0: the image holds the layout of the current anchor table (store_settle ran)

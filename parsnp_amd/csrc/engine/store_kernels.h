@@ -32,6 +32,7 @@ __device__ inline int32_t wave_min_i32(int32_t x) { for (int d = 32; d >= 1; d >
 __device__ inline int32_t wave_max_i32(int32_t x) { for (int d = 32; d >= 1; d >>= 1) { const int32_t y = __shfl_xor(x, d, 64); if (y > x) x = y; } return x; }
 __device__ inline uint32_t wave_or_u32(uint32_t x) { for (int d = 32; d >= 1; d >>= 1) x |= (uint32_t)__shfl_xor((int)x, d, 64); return x; }
 __device__ inline int32_t wave_bcast_i32(int32_t x, int lane) { return __shfl(x, lane, 64); }
+__device__ inline uint64_t wave_or_u64(uint64_t x) { return ((uint64_t)wave_or_u32((uint32_t)(x >> 32)) << 32) | wave_or_u32((uint32_t)x); }
 __device__ inline uint64_t wave_sum_u64(uint64_t x) {
     for (int d = 32; d >= 1; d >>= 1) x += ((uint64_t)(uint32_t)__shfl_xor((int)(x >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)x, d, 64);
     return x;
@@ -51,6 +52,7 @@ inline int32_t wave_min_i32(int32_t x) { return x; }
 inline int32_t wave_max_i32(int32_t x) { return x; }
 inline uint32_t wave_or_u32(uint32_t x) { return x; }
 inline int32_t wave_bcast_i32(int32_t x, int) { return x; }
+inline uint64_t wave_or_u64(uint64_t x) { return x; }
 inline uint64_t wave_sum_u64(uint64_t x) { return x; }
 inline bool wave_leader() { return true; }
 inline uint64_t load_coherent64(const uint64_t* p) { return *p; }
@@ -132,6 +134,19 @@ PM_HD int64_t img_prev_set(const Layout& L, int j, int64_t from) {
     uint64_t x = load_coherent64(w + wi) & (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1));
     while (!x) { if (wi == 0) return -1; x = load_coherent64(w + --wi); }
     return wi * 64 + 63 - clz64(x);
+}
+// any marked base in [a, b)?  (reads the words of the range only)
+PM_HD bool img_any(const Layout& L, int j, int64_t a, int64_t b) {
+    if (a < 0) a = 0;
+    if (b > L.nbits[j]) b = L.nbits[j];
+    const uint64_t* w = L.image + L.word_off[j];
+    while (a < b) {
+        const int lo = (int)(a & 63);
+        const int64_t span = (64 - lo) < (b - a) ? (64 - lo) : (b - a);
+        if (load_coherent64(w + (a >> 6)) & ((span == 64 ? ~0ull : ((1ull << span) - 1)) << lo)) return true;
+        a += span;
+    }
+    return false;
 }
 PM_HD void img_set_range(const Layout& L, int j, int64_t a, int64_t b) {
     if (a < 0) a = 0;
@@ -274,10 +289,8 @@ struct CollideTest {
         const int n = S.ngen;
         uint32_t hit = 0;
         lanes_for(0, n, [&](int j) {
-            int64_t a = S.start[c * n + j], b = a + S.lon[c];
-            if (a < 0) a = 0;
-            if (b > twice.nbits[j]) b = twice.nbits[j];
-            if (a < b && img_next_set(twice, j, a) < b) hit = 1;
+            const int64_t a = S.start[c * n + j];
+            if (img_any(twice, j, a, a + S.lon[c])) hit = 1;
         });
         if (wave_or_u32(hit) && wave_leader()) S.state[c] |= kStTangled;
     }
@@ -298,13 +311,20 @@ struct SettleFlagged {
 struct SettleTangled {
     Store S; Layout L; Packed P; const int32_t* list; int64_t count;
     PM_HD void wave(int64_t) const {
-        for (int64_t i = 0; i < count; i++) {
-            const int64_t c = list[i];
-            if (!(S.state[c] & kStTangled)) continue;
-            int32_t dl, len;
-            const bool acc = settle_row(S, L, P, c, true, &dl, &len);
-            if (acc) lanes_for(0, S.ngen, [&](int j) { const int64_t a = (int64_t)S.start[c * S.ngen + j] + dl; img_set_range(L, j, a, a + len); });
-            if (wave_leader()) { S.shift[c] = dl; S.len[c] = len; if (acc) S.state[c] |= kStAccepted; }
+        for (int64_t base = 0; base < count; base += 64) {
+            // which of the next 64 flagged rows are tangled: one load per lane instead of a dependent load per row
+            uint64_t mask = 0;
+            lanes_for(0, 64, [&](int t) { if (base + t < count && (S.state[list[base + t]] & kStTangled)) mask |= 1ull << t; });
+            mask = wave_or_u64(mask);
+            while (mask) {
+                const int t = ctz64(mask);
+                mask &= mask - 1;
+                const int64_t c = list[base + t];
+                int32_t dl, len;
+                const bool acc = settle_row(S, L, P, c, true, &dl, &len);
+                if (acc) lanes_for(0, S.ngen, [&](int j) { const int64_t a = (int64_t)S.start[c * S.ngen + j] + dl; img_set_range(L, j, a, a + len); });
+                if (wave_leader()) { S.shift[c] = dl; S.len[c] = len; if (acc) S.state[c] |= kStAccepted; }
+            }
         }
     }
 };
@@ -376,13 +396,14 @@ struct SeedWalk {
 // The algorithmic bytes of a search whose request rows the host never saw (bench.py's roofline; Aligner::run_batch sums the same
 // over rows it holds): per (region, query genome) with piece length m and reference window n,
 //   out[0] += 4 x SURVEY 8d's m/4 + 16 m + 16 n,   out[1] += 2 x ((m + n)/2 + 64 B per sampled K-mer, none for pairs that fit 128 bases),   out[2] += 2 x m/2.
-// One wavefront per 64 pairs, one atomic per wavefront and counter.
+// One wavefront per kAlgPairs pairs, one atomic per wavefront and counter (three hot addresses: few wavefronts).
+constexpr int kAlgPairs = 4096;
 struct AlgBytes {
     const RegionInfo* R; const int64_t* lens; int32_t ngen; int64_t npairs; uint64_t* out;
     PM_HD void wave(int64_t w) const {
         uint64_t a = 0, k = 0, q = 0;
-        lanes_for(0, 64, [&](int t) {
-            const int64_t pair = w * 64 + t;
+        lanes_for(0, kAlgPairs, [&](int t) {
+            const int64_t pair = w * kAlgPairs + t;
             if (pair >= npairs) return;
             const int64_t r = pair / (ngen - 1); const int g = (int)(pair % (ngen - 1)) + 1;
             const RegionInfo& ri = R[r];
@@ -568,6 +589,15 @@ struct FillBetween {
         overlap = wave_or_u32(overlap); small = wave_or_u32(small);
         first_scan = wave_min_i32(first_scan); last_noscan = wave_max_i32(last_noscan);
         if (wave_leader()) add[i] = overlap ? 0 : (first_scan < last_noscan ? 2 : (small ? 0 : 1));
+    }
+};
+// tid = (k, genome): the rows of the fillers that are made (which[k] = their pair), packed for one copy to the host
+struct FillGather {
+    const int32_t* which; int32_t ngen; const int64_t* in_start; const int64_t* in_end; int64_t* out;      // out: [n_made][2][ngen]
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t k = tid / ngen; const int j = (int)(tid % ngen);
+        const int64_t i = which[k];
+        out[(2 * k) * ngen + j] = in_start[i * ngen + j]; out[(2 * k + 1) * ngen + j] = in_end[i * ngen + j];
     }
 };
 // tid = (i, genome): the listed rows as the host wants them -- start with the trim applied, strand byte

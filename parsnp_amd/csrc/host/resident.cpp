@@ -46,7 +46,7 @@ void engine_error(const char* what, int rc) {
 // to find_anchors()'s host route with nothing changed -- the engine result, rows fetched, waits in the request cache.
 bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
     static const bool off = test_hook("PARSNP_NO_RESIDENT") != nullptr;      // test hook: always the host route
-    if (off || !resident_allowed_ || !session_ || sharded_ || n < 2 || prm.anchors_only || prm.random >= 2 || !pool.empty()) { res_.why = "not applicable (switched off, sharded, anchors only or a MUM filter length >= 2)"; return false; }
+    if (off || !resident_allowed_ || !session_ || n < 2 || prm.anchors_only || prm.random >= 2 || !pool.empty()) { res_.why = "not applicable (switched off, anchors only or a MUM filter length >= 2)"; return false; }
     const int minsize = min_length(true, whole.slength);
     l = (float)minsize;
     std::vector<Request> reqs;

@@ -106,11 +106,15 @@ def test_bench_interval_exchange_two_ranks(tmp_path):
     assert p.returncode == 0, p.stderr[-3000:]
 
 
-@pytest.mark.parametrize("name,world", [("pop6x200k", 2), ("poprearr10x400k", 3), ("mumi", 2)])
-def test_sharded_run_gloo(emu, tmp_path, name, world):
+@pytest.mark.parametrize("name,world,route", [("pop6x200k", 2, "host"), ("pop6x200k", 2, "resident"), ("pop12x400k", 3, "resident"), ("poprearr10x400k", 3, "host"),
+                                              ("poprearr10x400k", 2, "resident_all_lists"), ("mumi", 2, "host")])
+def test_sharded_run_gloo(emu, tmp_path, name, world, route):
     """query genomes sharded over ranks, Master.EP all-reduced (min), candidate columns all-gathered.
     The engine here is the host-emulated kernel code (tests/emu) and the collectives run on gloo; the result must be
-    the single-process result (= the reference binary's golden)."""
+    the single-process result (= the reference binary's golden).  route "resident": thresholds lowered so that the small sets
+    take the resident route (every rank validates the same candidate rows on its own device: no host work to replicate and
+    no further exchange); "resident_all_lists" sends the rearranged set's anchor list through it as well, and the ranks leave
+    the route together."""
     import json
     import test_host_logic as H
     import xmfa_util
@@ -123,6 +127,9 @@ def test_sharded_run_gloo(emu, tmp_path, name, world):
     ini = os.path.join(out, "run.ini")
     open(ini, "w").write(driver.ini_text(rp, qs, out, calcmumi=1 if mumi else 0, **kw))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PARSNP_CORE_LIB=core_lib, PYTHONPATH=ROOT)
+    log = str(tmp_path / "route.log")
+    if route != "host":
+        env.update(PM_DIRTY_MIN="8", PARSNP_PARALLEL_MIN="8", PARSNP_RESIDENT_LOG=log, PM_FLAGGED_DIV="1" if route == "resident_all_lists" else "8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
            "--master-port", "29571", "-m", "parsnp_amd.sharded", ini]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=out, timeout=900)
@@ -134,3 +141,6 @@ def test_sharded_run_gloo(emu, tmp_path, name, world):
         assert xmfa_util.mum_lcb_signature(os.path.join(out, "parsnpAligner.xmfa")) == H.E2E[name]["signature"]
         assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == H.E2E[name]["xmfa_md5"]
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == H.E2E[name]["log"]
+        if route != "host":      # every rank took (or left) the route
+            lines = open(log).read().split("\n")[:-1]
+            assert len(lines) == world and all(("resident=1" if route == "resident" else "retry=1") in ln for ln in lines), lines
