@@ -389,7 +389,7 @@ def main():
                     phases[k] = phases.get(k, 0.0) + v / len(reports)
                 for k, v in r["engine_ms"].items():
                     totals[k] = totals.get(k, 0.0) + v / len(reports)
-            counts = ("budget_retries", "events", "rest_samples")          # counts that travel in the timing list, not times
+            counts = ("budget_retries", "events", "rest_samples", "n_positions", "n_candidates", "n_accepted")          # counts that travel in the timing list, not times
             kernels = {k: v for k, v in totals.items() if k not in ("setup", "download", "units", "call_wall") + counts}
             dom = max(kernels, key=kernels.get) if kernels else None
             launches = sum(r["finder_calls"] for r in reports) / len(reports)          # engine launches per step
@@ -450,6 +450,30 @@ def main():
                         "anchor_launch": {"launch_ms": round(phases.get(dom, 0.0), 4), "survey_8d_bytes": int(b_alg * G),
                                           "alg_bytes": int(G * ((m_avg + n_ref) / 2 + 64 * ((m_avg - 16) // max(1, anchor_stride) + 1)) + 16 * phases.get("events", 0.0)),
                                           "achieved": round((G * ((m_avg + n_ref) / 2 + 64 * ((m_avg - 16) // max(1, anchor_stride) + 1)) + 16 * phases.get("events", 0.0)) / (phases[dom] * 1e-3) / 1e9, 2) if phases.get(dom) else None}}
+            # the device phases of a step against the byte roofline, largest first: algorithmic bytes per step (models in DESIGN.md 3,
+            # from the counts the engine reports: events, reference positions, candidates, accepted MUM rows) / HIP-event time of
+            # the phase on the engine's stream; reproducible from profiles/<round>/kernel_stats.csv (the kernels of a phase are named)
+            ev, npos, ncand, nacc = totals.get("events", 0.0), totals.get("n_positions", 0.0), totals.get("n_candidates", 0.0), totals.get("n_accepted", 0.0)
+            ngen = G + 1
+            models = {
+                "seed_extend": ("SeedExtend + SeedRest + SmallPairEvents", alg_step, "(m + n)/2 per (region, query genome) + 64 B per sampled K-mer + 16 B per event"),
+                "sort": ("SliceOffsets + CompactEvents + rocPRIM radix sort (onesweep)", 64.0 * ev, "gather 32 B + one read and one write of the 16-byte record per event (a radix sort of 32-bit keys makes 4 such passes)"),
+                "scan": ("PairBounds + ChunkReduce + ChunkScan", 48.0 * ev, "16 B read + 32 B of running state written per event"),
+                "master_ep": ("CoarseFill + MasterEP", 12.0 * ev + 4.0 * npos, "12 B per event + 4 B per reference position"),
+                "fold": ("FoldCandidates", 69.0 * ncand * G, "per (candidate, query genome): 28 B running state + 2 x (16 B winner + 4 B repeat length) in, 5 B out"),
+                "compact": ("CompactCandidates + Dirty* + store append", (5.0 * ncand * G) + 3 * 5.0 * nacc * ngen, "5 B in per (candidate, genome); 5 B per (accepted row, genome) out, once more read by the overlap flags and once copied into the MUM store"),
+                "settle": ("SettleClean + StoreMark + Collide* + SettleFlagged / Tangled", 20.0 * reports[-1]["anchors"] * ngen + 3 * (n_ref + 1) * ngen / 8.0, "4 B row entry + two 8-byte words per (anchor, genome) + three images of 1 bit per base cleared"),
+                "index": ("IndexInsert", 24.0 * npos, "8 B slot + 16 B sequence window per reference position"),
+            }
+            ktable = []
+            for k, (names, nbytes, model) in models.items():
+                ms = totals.get(k, 0.0)
+                if ms > 0:
+                    ktable.append({"phase": k, "kernels": names, "alg_bytes_per_step": int(nbytes), "ms_per_step": round(ms, 4), "achieved_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                                   "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "model": model})
+            ktable.sort(key=lambda r: -r["ms_per_step"])
+            if roof is not None:
+                roof["kernels"] = ktable
             line = {
                 "metric": "genomes/sec (MUM+LCB end-to-end)", "value": round(value, 4), "unit": "genomes/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),

@@ -110,7 +110,7 @@ void pm_result_free(pm_result* r);
  *                  PM_ROW_REVERSE  some member is on the reverse strand
  *                  PM_ROW_DIRTY    (only when pm_result_dirty_known) overlaps an earlier candidate of the list in some
  *                                  genome by the running-extent test of the anchor validation; computed for one-region
- *                                  batches with at least 4096 accepted candidates
+ *                                  batches with at least "dirty_min" (4096) accepted candidates
  *                  PM_ROW_EARLY    (with PM_ROW_DIRTY's condition) starts, in some genome, before the end of an earlier
  *                                  candidate of the list: candidates WITHOUT it lie in list order in every genome
  * The window of genome j is the starts/lens row the caller passed, so the rows equal the reference's only for requests
@@ -127,58 +127,14 @@ uint8_t* pm_result_strand(pm_result* r);
 const uint32_t* pm_result_flags(const pm_result* r);
 int pm_result_dirty_known(const pm_result* r);
 
-/* Requests derived on the device.  The rows of a ONE-region result in row mode (the anchor call) stay resident as the
- * session's "anchor table"; pm_result_table_id() names it (0: this result left no table).  The recursion's seed regions
- * are gaps between two anchors that follow each other in every genome, so the caller may describe region r by 16 bytes --
- * the two rows (candidate indices of that result) and the side -- instead of 2 x 8 bytes per genome:
- *   side 0, left of `next`  (determineRegion src/parsnp.cpp:1216-1231): start = end(prev) [prev < 0: 1], end = start(next) - 1
- *   side 1, right of `prev` (:1254-1268): start = end(prev) + 1, end = max(start(next), start) - 1 [next < 0: the genome's end]
- *   request = (start, end - start) in every genome, end(x) = start(x) + length(x).
- * A region that is not such a gap (a row the caller has trimmed since, a child region) sets explicit_row >= 0 and travels in
- * ex_starts / ex_lens [n_explicit][n_genomes].  ref_start / ref_len [n_regions]: the reference column of every region (the
- * host sizes the index from it).  The result is that of pm_multi_mum_batch on the same rows.  PM_EINVAL when table_id is not
- * the resident table (a later one-region call replaced it). */
-typedef struct { int32_t prev, next, side, explicit_row; } pm_gap_ref;
-int pm_multi_mum_batch_gaps(pm_session* s, int64_t table_id, int64_t n_regions, const pm_gap_ref* gaps, const int64_t* ref_start, const int64_t* ref_len,
-                            const int32_t* minsize, int64_t n_explicit, const int64_t* ex_starts, const int64_t* ex_lens, pm_result** out);
+/* The rows of a long ONE-region result in row mode (the anchor call: at least "dirty_min" candidates) stay on the device as the
+ * session's ANCHOR TABLE; pm_result_table_id() names it (0: this result left no table).  The resident route below works on it. */
 int64_t pm_result_table_id(const pm_result* r);
-/* The layout after the anchor call.  The reference keeps one bit per base of every genome, set under every accepted MUM
- * (mumlayout, src/parsnp.cpp:3181-3186; marked :1836-1839; read by trim :1399-1477, determineRegion :1199-1290,
- * filterRandom1 :327-425, setInterClusterRegions :2389-2460).  The rows of the anchors are still resident (the anchor table),
- * so the bitmaps are built on the device and arrive as ONE block: genome j has nbits[j] bits (the caller's choice: its length
- * + 1, the last bit being the sentinel a scan to the right stops at -- set by this call) in 64-bit words
- * [off[j], off[j+1]), off[0] = 0, off[j+1] = off[j] + (nbits[j] + 63) / 64 + 1; bit i = bit (i & 63) of word i >> 6.
- *   accept[c] != 0   row c of the table is marked as it stands: [start, start + length) in every genome.  accept == NULL:
- *                    the engine's own choice, made when the table was -- the rows without PM_ROW_BAD / _OUTSIDE / _DIRTY that
- *                    are at least 5 long and forward on the reference (what the caller accepts without looking, short of its
- *                    check of reverse-strand members): the image can then be asked for BEFORE the caller has validated
- *                    anything, and it puts right what it decides otherwise in the image itself
- *   extra_start [n_extra][n_genomes], extra_len [n_extra]: rows marked besides (the ones the caller trimmed)
- * *image: page-locked memory of the session, written by a copy that runs beside the calls made next; pm_layout_wait()
- * returns when it is complete.  The caller may then write to it; the next pm_layout_image of the session rewrites it, and
- * pm_session_destroy releases it.  PM_EINVAL when table_id is not the resident table or n_rows not its length. */
-int pm_layout_image(pm_session* s, int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t n_rows,
-                    const int32_t* extra_start, const int32_t* extra_len, int64_t n_extra, uint64_t** image);
-int pm_layout_wait(pm_session* s);
-/* The seed regions of the resident anchor table, worked out ON THE DEVICE and searched in one batch -- callable from a
- * helper thread right after the anchor call, so that the batch runs beside the caller's validation of the anchors: for every
- * two neighbouring rows that are inside their genomes and at least 5 long (rows the caller will accept as they stand, unless
- * its own checks of a reverse member or of an overlap with an earlier row say otherwise -- the regions next to such a row are
- * then a guess the caller does not look at), the left region of the second and the right region of the first (formulas above), kept when longer than
- * q in every genome (src/parsnp.cpp:2158-2170) and at most ref_len_limit long on the reference (one chunk of the p-loop,
- * :1519-1547); minimum length of a region = minsize_by_length[its shortest length] (regions whose shortest length is >=
- * table_len are left to the caller).  pm_result_spec_refs / _minsize [pm_result_regions]: which gap each region of the
- * result is and what it was searched with; the per-region results are those of pm_multi_mum_batch on the same rows.  A
- * session is still single-threaded: no other call on it until this one has returned. */
-int pm_multi_mum_batch_spec(pm_session* s, int64_t table_id, int32_t q, int64_t ref_len_limit, const int32_t* minsize_by_length, int64_t table_len,
-                            pm_result** out);
-const pm_gap_ref* pm_result_spec_refs(const pm_result* r);
-const int32_t* pm_result_spec_minsize(const pm_result* r);
 /* Tunables of a session (tests lower the thresholds of the long-list routes so that small inputs take them):
  *   "work_budget"  per-thread step budget of the index walks (default 2^22; a batch that exhausts it is repeated once with
  *                  256 times as much, then PM_ELIMIT)
- *   "dirty_min"    shortest one-region candidate list that gets the overlap / order flags and stays resident as the anchor
- *                  table (default 4096)
+ *   "dirty_min"    shortest one-region candidate list that gets the overlap / order flags and stays on the device as the
+ *                  anchor table (default 4096)
  *   "flagged_div"  pm_store_settle answers PM_EAGAIN when more than one row in flagged_div of the anchor table overlaps an
  *                  earlier one (default 8, the host route's own threshold for its exact overlap test)
  * PM_EINVAL for an unknown key or a value out of range. */

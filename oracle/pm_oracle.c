@@ -102,24 +102,6 @@ uint8_t* pm_result_strand(pm_result* r) { (void)r; return 0; }
 const uint32_t* pm_result_flags(const pm_result* r) { (void)r; return 0; }
 int pm_result_dirty_known(const pm_result* r) { (void)r; return 0; }
 int64_t pm_result_table_id(const pm_result* r) { (void)r; return 0; }
-int pm_multi_mum_batch_spec(pm_session* s, int64_t table_id, int32_t q, int64_t ref_len_limit, const int32_t* minsize_by_length, int64_t table_len, pm_result** out) {
-    (void)s; (void)table_id; (void)q; (void)ref_len_limit; (void)minsize_by_length; (void)table_len; (void)out;
-    return PM_EINVAL;
-}
-const pm_gap_ref* pm_result_spec_refs(const pm_result* r) { (void)r; return 0; }
-const int32_t* pm_result_spec_minsize(const pm_result* r) { (void)r; return 0; }       /* this provider keeps no anchor table */
-int pm_multi_mum_batch_gaps(pm_session* s, int64_t table_id, int64_t n_regions, const pm_gap_ref* gaps, const int64_t* ref_start, const int64_t* ref_len,
-                            const int32_t* minsize, int64_t n_explicit, const int64_t* ex_starts, const int64_t* ex_lens, pm_result** out) {
-    (void)s; (void)table_id; (void)n_regions; (void)gaps; (void)ref_start; (void)ref_len; (void)minsize; (void)n_explicit; (void)ex_starts; (void)ex_lens; (void)out;
-    return PM_EINVAL;
-}
-/* no anchor table, so no layout image either: the host marks its bitmaps itself */
-int pm_layout_image(pm_session* s, int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t n_rows,
-                    const int32_t* extra_start, const int32_t* extra_len, int64_t n_extra, uint64_t** image) {
-    (void)s; (void)table_id; (void)nbits; (void)accept; (void)n_rows; (void)extra_start; (void)extra_len; (void)n_extra; (void)image;
-    return PM_EINVAL;
-}
-int pm_layout_wait(pm_session* s) { (void)s; return PM_OK; }
 int pm_session_tune(pm_session* s, const char* key, int64_t value) { (void)s; (void)key; (void)value; return PM_OK; }      /* nothing to tune here */
 /* the device gap aligner belongs to the HIP library; this checker declines every job, so the host aligner runs */
 int pm_gap_align_batch(int device, int64_t n_jobs, const int32_t* n_seqs, const int64_t* seq_off, const uint8_t* chars,

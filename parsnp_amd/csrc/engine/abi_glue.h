@@ -110,42 +110,6 @@ int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, 
     } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
     } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
 }
-int pm_multi_mum_batch_gaps(pm_session* s, int64_t table_id, int64_t n_regions, const pm_gap_ref* gaps, const int64_t* ref_start, const int64_t* ref_len,
-                            const int32_t* minsize, int64_t n_explicit, const int64_t* ex_starts, const int64_t* ex_lens, pm_result** out) {
-    if (!s || !out || n_regions < 1 || !gaps || !ref_start || !ref_len || !minsize || n_explicit < 0) return fail(PM_EINVAL, "bad argument");
-    static_assert(sizeof(pm_gap_ref) == sizeof(pm::GapRef), "pm_gap_ref layout");
-    try {
-        std::unique_ptr<pm_result> r(new pm_result);
-        const auto w0 = std::chrono::steady_clock::now();
-        pm::Engine<PmBackend>::GapBatch gb;
-        gb.table_id = table_id; gb.gaps = (const pm::GapRef*)gaps; gb.ref_start = ref_start; gb.ref_len = ref_len;
-        gb.n_explicit = n_explicit; gb.ex_starts = ex_starts; gb.ex_lens = ex_lens;
-        int rc = s->engine->run(n_regions, nullptr, nullptr, minsize, &r->r, false, false, &gb);
-        if (rc) return fail(rc, s->engine->error);
-        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
-        s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
-        *out = r.release();
-        return PM_OK;
-    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
-    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
-}
-int pm_multi_mum_batch_spec(pm_session* s, int64_t table_id, int32_t q, int64_t ref_len_limit, const int32_t* minsize_by_length, int64_t table_len, pm_result** out) {
-    if (!s || !out || !minsize_by_length || table_len < 1) return fail(PM_EINVAL, "bad argument");
-    try {
-        std::unique_ptr<pm_result> r(new pm_result);
-        const auto w0 = std::chrono::steady_clock::now();
-        s->backend->bind_thread();          // (the call may come from a helper thread: the device is a per-thread setting)
-        int rc = s->engine->run_spec(table_id, q, ref_len_limit, minsize_by_length, table_len, &r->r);
-        if (rc) return fail(rc, s->engine->error);
-        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
-        s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
-        *out = r.release();
-        return PM_OK;
-    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
-    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
-}
-const pm_gap_ref* pm_result_spec_refs(const pm_result* r) { return r ? (const pm_gap_ref*)r->r.spec_refs.data() : nullptr; }
-const int32_t* pm_result_spec_minsize(const pm_result* r) { return r ? r->r.spec_minsize.data() : nullptr; }
 int64_t pm_result_table_id(const pm_result* r) { return r ? r->r.table_id : 0; }
 int64_t pm_result_regions(const pm_result* r) { return r->r.nregions; }
 int64_t pm_result_total(const pm_result* r) { return r->r.total; }
@@ -155,22 +119,6 @@ const int32_t* pm_result_lon(const pm_result* r) { return r->r.lon(); }
 const int32_t* pm_result_sp(const pm_result* r) { return r->r.sp(); }
 const uint8_t* pm_result_fwd(const pm_result* r) { return r->r.fwd(); }
 void pm_result_free(pm_result* r) { delete r; }
-int pm_layout_image(pm_session* s, int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t n_rows,
-                    const int32_t* extra_start, const int32_t* extra_len, int64_t n_extra, uint64_t** image) {
-    if (!s || !nbits || !image || n_rows < 0 || n_extra < 0) return fail(PM_EINVAL, "bad argument");
-    try {
-        int rc = s->engine->layout_image(table_id, nbits, accept, n_rows, extra_start, extra_len, n_extra, image);
-        if (rc) return fail(rc, s->engine->error);
-        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
-        return PM_OK;
-    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
-    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
-}
-int pm_layout_wait(pm_session* s) {
-    if (!s) return fail(PM_EINVAL, "bad argument");
-    s->engine->layout_wait();
-    return s->backend->ok() ? PM_OK : fail(PM_EHIP, s->backend->error());
-}
 int pm_session_tune(pm_session* s, const char* key, int64_t value) {
     if (!s || !key) return fail(PM_EINVAL, "bad argument");
     return s->engine->tune(key, value) ? PM_OK : fail(PM_EINVAL, std::string("unknown tunable or bad value: ") + key);
@@ -337,6 +285,9 @@ int pm_last_timing(const pm_session* cs, int* count, const char** names, float* 
         s->timing.push_back(pm::PhaseTime{"alg_kernel", (float)s->engine->last_alg[1]});
         s->timing.push_back(pm::PhaseTime{"alg_query", (float)s->engine->last_alg[2]});
     }
+    s->timing.push_back(pm::PhaseTime{"n_positions", (float)s->engine->last_positions});      // counts as well: reference positions of the batch, candidates Master.EP selected, candidates the fold accepted
+    s->timing.push_back(pm::PhaseTime{"n_candidates", (float)s->engine->last_candidates});
+    s->timing.push_back(pm::PhaseTime{"n_accepted", (float)s->engine->last_accepted});
     s->timing.push_back(pm::PhaseTime{"events", (float)s->engine->last_events});      // a count too: R-unique maximal matches the event search appended (16 B each)
     int capn = *count, n = 0;
     for (const auto& t : s->timing) { if (n < capn) { names[n] = t.name; ms[n] = t.ms; } n++; }

@@ -52,10 +52,8 @@ struct BatchResult {
     // a session in MUM-row mode (pm_session_rows) fills these instead of sp / fwd:
     HostPool::Block startb, strandb, flagsb; // int32 start[total*(nq+1)], uint8 strand[total*(nq+1)], uint32 flags[total]
     bool rows = false, dirty_known = false;  // dirty_known: the kRowDirty bits were computed (one-region batch with a long list)
-    int64_t table_id = 0;                    // != 0: the rows of this result stay on the device as the session's anchor table (run_gaps)
+    int64_t table_id = 0;                    // != 0: the rows of this result stay on the device as the session's anchor table = rows [0, A) of the MUM store
     int64_t store_base = -1;                 // resident mode: the result's rows are rows [store_base, store_base + total) of the session's MUM store (no start / strand blocks)
-    std::vector<GapRef> spec_refs;           // run_spec: which gap of the anchor table each region of this result is ...
-    std::vector<int32_t> spec_minsize;       // ... and the minimum length it was searched with
     std::shared_ptr<HostPool> pool;
     int32_t* start() const { return (int32_t*)startb.p; }
     uint8_t* strand() const { return (uint8_t*)strandb.p; }
@@ -100,7 +98,7 @@ public:
 
     std::string error;
     std::vector<PhaseTime> timing;
-    int64_t last_events = 0, last_candidates = 0, last_rest = 0;
+    int64_t last_events = 0, last_candidates = 0, last_rest = 0, last_positions = 0, last_accepted = 0;
     double last_alg[3] = {0, 0, 0};      // last search of store regions: SURVEY 8d bytes, this engine's bytes, query-stream bytes (AlgBytes)
     uint64_t alg_raw[3] = {0, 0, 0};
 
@@ -172,18 +170,14 @@ public:
     // copies inside ONE region: every copy's K-mer chain is walked by every sample that hits it) is run again with a
     // budget 256 times larger -- slow, but the reference aligns such input too; only then PM_ELIMIT.  In a sharded run the
     // verdict is common to all ranks (it travels with the first exchange), so every rank repeats the batch together.
-    // Requests given as gaps of the anchor table (kernels.h: GapRef / ExpandGaps) + explicit rows for the rest.
+    // Requests whose rows are regions of the session's region store (resident route): the host holds their reference columns only.
     struct GapBatch {
-        int64_t table_id = 0;
-        const GapRef* gaps = nullptr;                         // [nreg]
         const int64_t* ref_start = nullptr; const int64_t* ref_len = nullptr;   // [nreg]: the reference column of every region (sizes the index)
-        int64_t n_explicit = 0; const int64_t* ex_starts = nullptr; const int64_t* ex_lens = nullptr;   // [n_explicit][ngen]
-        const int32_t* store_ids = nullptr;                   // [nreg]: the regions are rows of the session's region store (resident route): gaps / explicit rows unused
+        const int32_t* store_ids = nullptr;                                      // [nreg]: the regions
     };
     int run(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events = false,
             bool mumi = false, const GapBatch* gb = nullptr) {
         budget_exceeded = false;
-        if (gb && !gb->store_ids && (gb->table_id == 0 || gb->table_id != anchor_table_id)) { error = "the anchor table of these gap requests is no longer resident"; return -2; }
         int rc = run_once(nreg, starts, lens, minsize, out, want_events, mumi, gb);
         if (rc == -5 && budget_exceeded && work_budget < ((int64_t)1 << 40)) {
             const int64_t keep = work_budget;
@@ -194,38 +188,7 @@ public:
         }
         return rc;
     }
-    int64_t anchor_table_id = 0, anchor_table_rows = 0;      // the resident anchor table: rows of the last one-region call in row mode
-    // The seed regions of the resident anchor table worked out on the device (GapSeeds) and searched in one batch: what the
-    // host will ask for once it has validated the anchors, computed beside that validation (include/parsnp_mum.h:
-    // pm_multi_mum_batch_spec).  out->spec_refs says which gap each region of the result is.
-    int run_spec(int64_t table_id, int32_t q, int64_t ref_len_limit, const int32_t* minsize_by_length, int64_t table_len, BatchResult* out) {
-        if (table_id == 0 || table_id != anchor_table_id) { error = "the anchor table of this speculation is no longer resident"; return -2; }
-        if (!minsize_by_length || table_len < 1) { error = "bad minimum-length table"; return -2; }
-        const int64_t rows = anchor_table_rows;
-        const size_t cap = 2 * (size_t)(rows + 1);
-        ensure(d_spec, cap); ensure(d_speccount, 1); ensure(d_mintable, (size_t)table_len);
-        be.memset(d_speccount.p, 0, 8);
-        be.h2d(d_mintable.p, minsize_by_length, 4 * (size_t)table_len);
-        be.launch_wave("gap_seeds", rows + 1, GapSeeds{d_anchor_start.p, d_anchor_lon.p, d_anchor_flags.p, rows, ngen, d_glen, q, ref_len_limit, d_mintable.p, table_len,
-                                                       d_spec.p, d_speccount.p, (uint64_t)cap});
-        uint64_t n = 0;
-        be.d2h(&n, d_speccount.p, 8);
-        if (n > cap) n = cap;
-        std::vector<SpecRegion> sr((size_t)n);
-        if (n) be.d2h(sr.data(), d_spec.p, sizeof(SpecRegion) * (size_t)n);
-        // (the wavefronts append in any order: sorted, so that a run is reproducible event for event)
-        std::sort(sr.begin(), sr.end(), [](const SpecRegion& x, const SpecRegion& y) {
-            if (x.ref.next != y.ref.next) return (uint32_t)x.ref.next < (uint32_t)y.ref.next;      // (-1 = the end: last)
-            if (x.ref.prev != y.ref.prev) return x.ref.prev < y.ref.prev;
-            return x.ref.side < y.ref.side; });
-        std::vector<GapRef> refs((size_t)n); std::vector<int64_t> rs((size_t)n), rl((size_t)n); std::vector<int32_t> ms((size_t)n);
-        for (size_t i = 0; i < (size_t)n; i++) { refs[i] = sr[i].ref; rs[i] = sr[i].ref_start; rl[i] = sr[i].ref_len; ms[i] = sr[i].minsize; }
-        GapBatch gb;
-        gb.table_id = table_id; gb.gaps = refs.data(); gb.ref_start = rs.data(); gb.ref_len = rl.data();
-        const int rc = run((int64_t)n, nullptr, nullptr, ms.data(), out, false, false, &gb);
-        out->spec_refs.swap(refs); out->spec_minsize.swap(ms);
-        return rc;
-    }
+    int64_t anchor_table_id = 0, anchor_table_rows = 0;      // the anchor table: rows of the last long one-region call in row mode = rows [0, A) of the MUM store
     bool budget_exceeded = false;
     long budget_retries = 0;
     int run_once(int64_t nreg, const int64_t* starts, const int64_t* lens, const int32_t* minsize, BatchResult* out, bool want_events,
@@ -241,13 +204,14 @@ public:
         const int no_small = mumi ? 1 : 0;
 
         // -- host: the page-locked parameter block  [ RegionInfo x nreg | posbase | cbase | starts rows | lens rows ]
-        // (gap requests: the rows part holds only the explicit rows, followed by the GapRef table)
+        // (regions of the region store: the rows part holds their ids only)
         const size_t nrow = (size_t)nreg * (size_t)ngen;
         const size_t regz = (size_t)nreg;
         const size_t bytes_R = sizeof(RegionInfo) * regz, bytes_pre = 8 * (regz + 1);
         const bool from_store = gb && gb->store_ids;
-        const size_t nrow_staged = gb ? (from_store ? 0 : (size_t)gb->n_explicit * (size_t)ngen) : nrow;
-        uint8_t* block = (uint8_t*)be.staging(bytes_R + 2 * bytes_pre + 16 * nrow_staged + (gb ? sizeof(GapRef) * regz : 0) + 64);
+        if (gb && !from_store) { error = "bad region list"; return -2; }
+        const size_t nrow_staged = gb ? 0 : nrow;
+        uint8_t* block = (uint8_t*)be.staging(bytes_R + 2 * bytes_pre + 16 * nrow_staged + (gb ? 4 * regz : 0) + 64);
         if (!block) { error = "cannot allocate the request staging block"; return -3; }
         RegionInfo* R = (RegionInfo*)block;
         int64_t* posbase = (int64_t*)(block + bytes_R);
@@ -261,25 +225,7 @@ public:
                 if (gb->ref_start[r] < 0 || gb->ref_len[r] < 0 || gb->ref_start[r] + gb->ref_len[r] > glen_h[0]) { error = "region outside its genome"; return -2; }
                 if (gb->ref_len[r] >= (1ll << 31)) { error = "region longer than 2^31"; return -5; }
             }
-            static_assert(sizeof(GapRef) >= sizeof(int32_t), "staging room");
             memcpy(stage, gb->store_ids, sizeof(int32_t) * regz);
-        } else if (gb) {
-            if (gb->n_explicit < 0 || (gb->n_explicit > 0 && (!gb->ex_starts || !gb->ex_lens))) { error = "bad explicit rows"; return -2; }
-            for (int64_t r = 0; r < nreg; r++) {
-                const GapRef& g = gb->gaps[r];
-                if (g.explicit_row >= gb->n_explicit || (g.explicit_row < 0 && (g.prev >= anchor_table_rows || g.next >= anchor_table_rows || (g.prev < 0 && g.next < 0) || g.side < 0 || g.side > 1)))
-                    { error = "gap request outside the anchor table"; return -2; }
-                if (gb->ref_start[r] < 0 || gb->ref_len[r] < 0 || gb->ref_start[r] + gb->ref_len[r] > glen_h[0]) { error = "region outside its genome"; return -2; }
-                if (gb->ref_len[r] >= (1ll << 31)) { error = "region longer than 2^31"; return -5; }
-            }
-            for (int64_t x = 0; x < gb->n_explicit; x++)
-                for (int g = 0; g < ngen; g++) {
-                    const int64_t st = gb->ex_starts[x * ngen + g], ln = gb->ex_lens[x * ngen + g];
-                    if (st < 0 || ln < 0 || st + ln > glen_h[(size_t)g]) { error = "region outside its genome"; return -2; }
-                    if (ln >= (1ll << 31)) { error = "region longer than 2^31"; return -5; }
-                }
-            if (nrow_staged) { memcpy(stage, gb->ex_starts, 8 * nrow_staged); memcpy(stage + nrow_staged, gb->ex_lens, 8 * nrow_staged); }
-            memcpy(stage + 2 * nrow_staged, gb->gaps, sizeof(GapRef) * regz);
         } else {
             // the request rows (2 x 8 bytes per region and genome: 26 MB for a recursion batch of 8 000 regions x 201) are
             // checked and copied by a few threads; the same pass counts the SeedExtend work units of every region (what
@@ -350,6 +296,7 @@ public:
             nunits += units_r[(size_t)r];
         }
         posbase[regz] = npos;
+        last_positions = npos; last_candidates = 0; last_accepted = 0;
         const int64_t npairs = nreg * nq;
         const int64_t nchunks = cbase[regz] - nreg;                  // 256-position chunks of the batch
         const int64_t centries = cbase[regz] * nq;
@@ -373,11 +320,6 @@ public:
             ensure(d_list, regz);
             be.h2d_staged(d_list.p, stage, sizeof(int32_t) * regz);
             be.launch("gather_regions", (int64_t)nrow, GatherRegions{d_list.p, ngen, d_rg_start.p, d_rg_len.p, d_starts.p, d_lens.p});
-        } else {
-            ensure(d_exstarts, std::max<size_t>(nrow_staged, 1)); ensure(d_exlens, std::max<size_t>(nrow_staged, 1)); ensure(d_gaps, regz);
-            if (nrow_staged) { be.h2d_staged(d_exstarts.p, stage, 8 * nrow_staged); be.h2d_staged(d_exlens.p, stage + nrow_staged, 8 * nrow_staged); }
-            be.h2d_staged(d_gaps.p, stage + 2 * nrow_staged, sizeof(GapRef) * regz);
-            be.launch("expand_gaps", (int64_t)nrow, ExpandGaps{d_gaps.p, ngen, d_anchor_start.p, d_anchor_lon.p, d_glen, d_exstarts.p, d_exlens.p, d_starts.p, d_lens.p});
         }
         // event counters: kSlices counters one 64-byte line apart, then the error word of the batch (read back together)
         const size_t ncounter = (size_t)kSlices * kSliceStride + 8;
@@ -617,6 +559,7 @@ public:
         int64_t nok = 0;
         be.d2h(&nok, d_okpos.p + ncand, 8);                                    // round trip 3: accepted count
         const size_t nokz = (size_t)nok, nqz2 = (size_t)nq, ngz = (size_t)ngen;
+        last_accepted = nok;
         ensure(d_creg, std::max<size_t>(nokz, 1)); ensure(d_ck, std::max<size_t>(nokz, 1)); ensure(d_clon, std::max<size_t>(nokz, 1));
         std::vector<int32_t> reg_h(nokz);
         out->kb = pool->take(4 * nokz); out->lonb = pool->take(4 * nokz);
@@ -665,8 +608,6 @@ public:
                 out->store_base = (int64_t)base;
                 ms_count = (int64_t)upto;
                 if (anchor_call) {
-                    ensure(d_anchor_accept, std::max<size_t>(nokz, 1));      // (the overlap flags are in: same condition above)
-                    be.launch("anchor_accept", nok, AnchorAccept{d_cflags.p, d_clon.p, d_cfwd.p, ngen, d_anchor_accept.p});
                     anchor_table_rows = nok;
                     out->table_id = anchor_table_id = ++table_counter;
                 }
@@ -693,59 +634,6 @@ public:
         return 0;
     }
 
-    // ---- the layout after the anchor call, built from the resident anchor table (kernels.h: LayoutMark; pm_layout_image)
-    // accept[c] != 0: row c of the table is marked as it stands (accept == nullptr: the rows AnchorAccept chose when the table
-    // was made); rows the host changed (trimmed) come as extra rows.  The
-    // image is copied to a page-locked block of the session on a second stream, beside whatever is queued next; the caller
-    // reads it after layout_wait().  The block is rewritten by the next call: the previous copy is awaited first.
-    int layout_image(int64_t table_id, const int64_t* nbits, const uint8_t* accept, int64_t nrows, const int32_t* xstart, const int32_t* xlon, int64_t nx,
-                     uint64_t** image) {
-        be.bind();
-        if (table_id == 0 || table_id != anchor_table_id) { error = "the anchor table of this layout is no longer resident"; return -2; }
-        if (nrows != anchor_table_rows || !nbits || nx < 0 || (nx > 0 && (!xstart || !xlon))) { error = "bad layout request"; return -2; }
-        const size_t ngz = (size_t)ngen, nxz = (size_t)nx, nrz = (size_t)nrows;
-        std::vector<int64_t> off(ngz + 1, 0);
-        for (size_t j = 0; j < ngz; j++) {
-            if (nbits[j] < 0 || nbits[j] > glen_h[j] + 64) { error = "layout size does not fit its genome"; return -2; }
-            off[j + 1] = off[j] + (nbits[j] + 63) / 64 + 1;
-        }
-        const size_t words = (size_t)off[ngz];
-        be.side_wait();
-        if (words > image_words) {
-            if (image_h) be.pinned_free(image_h);
-            image_h = (uint64_t*)be.pinned_alloc(8 * words);
-            image_words = image_h ? words : 0;
-            if (!image_h) { error = "cannot allocate the page-locked layout block"; return -3; }
-        }
-        // parameters: [ word_off | nbits | extra lengths | extra rows | accept ] in a page-locked block of their own (the
-        // request block of run() is rewritten by the next call, which may be queued before these copies have run)
-        const size_t bytes = 8 * (ngz + 1) + 8 * ngz + 4 * nxz + 4 * nxz * ngz + nrz + 64;
-        if (bytes > image_stage_cap) {
-            if (image_stage) be.pinned_free(image_stage);
-            image_stage = (uint8_t*)be.pinned_alloc(bytes + bytes / 4);
-            image_stage_cap = image_stage ? bytes + bytes / 4 : 0;
-            if (!image_stage) { error = "cannot allocate the layout staging block"; return -3; }
-        }
-        int64_t* s_off = (int64_t*)image_stage; int64_t* s_bits = s_off + ngz + 1;
-        int32_t* s_xlon = (int32_t*)(s_bits + ngz); int32_t* s_xstart = s_xlon + nxz; uint8_t* s_acc = (uint8_t*)(s_xstart + nxz * ngz);
-        memcpy(s_off, off.data(), 8 * (ngz + 1)); memcpy(s_bits, nbits, 8 * ngz);
-        if (nxz) { memcpy(s_xlon, xlon, 4 * nxz); memcpy(s_xstart, xstart, 4 * nxz * ngz); }
-        if (accept) memcpy(s_acc, accept, nrz);
-        ensure(d_image, words); ensure(d_imgoff, ngz + 1); ensure(d_imgbits, ngz); ensure(d_accept, std::max<size_t>(nrz, 1));
-        ensure(d_xstart, std::max<size_t>(nxz * ngz, 1)); ensure(d_xlon, std::max<size_t>(nxz, 1));
-        be.h2d_staged(d_imgoff.p, s_off, 8 * (ngz + 1)); be.h2d_staged(d_imgbits.p, s_bits, 8 * ngz);
-        if (accept) be.h2d_staged(d_accept.p, s_acc, nrz);
-        if (nxz) { be.h2d_staged(d_xlon.p, s_xlon, 4 * nxz); be.h2d_staged(d_xstart.p, s_xstart, 4 * nxz * ngz); }
-        be.memset(d_image.p, 0, 8 * words);
-        be.launch("layout_sentinel", (int64_t)ngen, LayoutSentinel{d_imgoff.p, d_imgbits.p, d_image.p});
-        be.launch("layout_mark", nrows * ngen, LayoutMark{d_anchor_start.p, d_anchor_lon.p, accept ? d_accept.p : d_anchor_accept.p, ngen, d_imgoff.p, d_imgbits.p, d_image.p});
-        be.launch("layout_mark", nx * ngen, LayoutMark{d_xstart.p, d_xlon.p, nullptr, ngen, d_imgoff.p, d_imgbits.p, d_image.p});
-        be.d2h_side(image_h, d_image.p, 8 * words);
-        *image = image_h;
-        return 0;
-    }
-    void layout_wait() { be.bind(); be.side_wait(); }      // (may be called by a helper thread while another call is running)
-
 
     // =====================================================================================================================
     // The resident route (store_kernels.h; include/parsnp_mum.h: pm_store_*): what the reference does with the candidate lists
@@ -758,7 +646,7 @@ public:
     std::vector<uint32_t> anchor_flags_h;
     static constexpr int kAgain = -6; // PM_EAGAIN: the resident route does not apply; the caller takes the host route
 
-    void begin_store_call() { timing.clear(); last_events = last_rest = 0; last_alg[0] = last_alg[1] = last_alg[2] = 0; }      // (counts of the last search travel with pm_last_timing)
+    void begin_store_call() { timing.clear(); last_events = last_rest = last_positions = last_candidates = last_accepted = 0; last_alg[0] = last_alg[1] = last_alg[2] = 0; }      // (counts of the last search travel with pm_last_timing)
     Store store_view() { return Store{d_anchor_start.p, d_ms_strand.p, d_anchor_lon.p, d_anchor_flags.p, d_ms_shift.p, d_ms_len.p, d_ms_state.p, ngen}; }
     Layout layout_view(uint64_t* image) { return Layout{image, d_lay_off.p, d_lay_bits.p}; }
     // geometry of the layout image: genome j has glen[j] + 1 bits (the last one the sentinel, src/parsnp.cpp:3184-3185)
@@ -1070,10 +958,6 @@ public:
 
     void release() {
         for (BufBase* b : all_bufs) { if (b->raw) be.free(b->raw); b->raw = nullptr; b->cap = 0; }
-        be.side_wait();
-        if (image_h) be.pinned_free(image_h);
-        if (image_stage) be.pinned_free(image_stage);
-        image_h = nullptr; image_stage = nullptr; image_words = 0; image_stage_cap = 0;
         if (blk) be.free(blk);
         if (d_goff) be.free(d_goff);
         if (d_glen) be.free(d_glen);
@@ -1129,17 +1013,14 @@ private:
     Buf<uint32_t> d_cflags, d_dirty; Buf<int32_t> d_bmax, d_bmin;
     Buf<GenomeAtK> d_xsend, d_xrecv; Buf<uint8_t> d_hsend, d_hrecv;
     Buf<RestItem> d_rest; Buf<uint64_t> d_qcount;
-    Buf<int32_t> d_anchor_start, d_anchor_lon; Buf<uint32_t> d_anchor_flags; Buf<uint8_t> d_anchor_accept; Buf<GapRef> d_gaps; Buf<int64_t> d_exstarts, d_exlens;
-    Buf<SpecRegion> d_spec; Buf<uint64_t> d_speccount; Buf<int32_t> d_mintable;
+    Buf<int32_t> d_anchor_start, d_anchor_lon; Buf<uint32_t> d_anchor_flags;      // the MUM store's rows as the searches delivered them
     int64_t table_counter = 0;
-    Buf<uint64_t> d_image; Buf<int64_t> d_imgoff, d_imgbits; Buf<uint8_t> d_accept; Buf<int32_t> d_xstart, d_xlon;
+    Buf<uint64_t> d_image;
     Buf<uint8_t> d_ms_strand, d_ms_state, d_small8, d_o_strand; Buf<int32_t> d_ms_shift, d_ms_len, d_list, d_list2, d_j_min, d_j_max, d_o_start;
     Buf<int64_t> d_rg_start, d_rg_len, d_lay_off, d_lay_bits, d_v_row0, d_v_first, d_f_start, d_f_end, d_f_pack; Buf<RegInfo> d_rg_info; Buf<uint64_t> d_rg_count, d_once, d_twice;
     Buf<RowInfo> d_rowinfo; Buf<uint64_t> d_alg;
     size_t lay_words = 0, rg_cap_hint = 0;
     int64_t layout_rows = -1;       // >= 0: the image holds the layout of the current anchor table (store_settle ran)
-    uint64_t* image_h = nullptr; size_t image_words = 0;      // page-locked: the layout image as the host reads it
-    uint8_t* image_stage = nullptr; size_t image_stage_cap = 0;
 };
 
 }  // namespace pm

@@ -102,9 +102,6 @@ struct HipBackend {
         if (tmp) (void)hipFree(tmp);
         if (stage_p) (void)hipHostFree(stage_p);
         if (comm) (void)Rccl::get().CommDestroy(comm);
-        if (side_go) (void)hipEventDestroy(side_go);
-        if (side_done) (void)hipEventDestroy(side_done);
-        if (side) (void)hipStreamDestroy(side);
         if (stream) (void)hipStreamDestroy(stream);
     }
     bool nccl_check(ncclResult_t r, const char* what) {
@@ -185,22 +182,6 @@ struct HipBackend {
         return stage_p;
     }
     void d2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream), "hipMemcpy D2D"); }
-    // a large download that nobody waits for at once (the layout image): on a second stream, after what the engine's stream
-    // holds so far, beside what it is given next; side_wait() blocks until the last one has landed
-    hipStream_t side = nullptr; hipEvent_t side_go = nullptr, side_done = nullptr; bool side_pending = false;
-    void d2h_side(void* d, const void* s, size_t n) {
-        if (!side) {
-            if (!check(hipStreamCreateWithFlags(&side, hipStreamNonBlocking), "hipStreamCreate(side)")) return;
-            if (!check(hipEventCreateWithFlags(&side_go, hipEventDisableTiming), "hipEventCreate") || !check(hipEventCreateWithFlags(&side_done, hipEventDisableTiming), "hipEventCreate")) return;
-        }
-        bytes_d2h += n;
-        check(hipEventRecord(side_go, stream), "hipEventRecord");
-        check(hipStreamWaitEvent(side, side_go, 0), "hipStreamWaitEvent");
-        if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, side), "hipMemcpy D2H (side)");
-        check(hipEventRecord(side_done, side), "hipEventRecord");
-        side_pending = true;
-    }
-    void side_wait() { if (side_pending) { check(hipEventSynchronize(side_done), "hipEventSynchronize(side)"); side_pending = false; } }
     void* pinned_alloc(size_t n) { void* p = nullptr; if (!check(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault), "hipHostMalloc")) return nullptr; return p; }
     void pinned_free(void* p) { if (p) (void)hipHostFree(p); }
     void h2d_staged(void* d, const void* s, size_t n) { bytes_h2d += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D (staged)"); }

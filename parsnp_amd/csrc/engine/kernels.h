@@ -567,41 +567,10 @@ struct alignas(32) UnitRec {
     int32_t m;          // length of the query piece
     int32_t chunk;      // which kUnitSamples samples of the piece
 };
-// ------------------------------------------------------------------------------------------ requests derived on the device
-// A request of the recursion is, almost always, the gap between two anchors that lie next to each other in every genome:
-// its rows follow from the two anchors' rows, which the device still holds from the anchor call (the "anchor table").  The
-// host then sends 16 bytes per region instead of 2 x 8 bytes per region AND genome (26 MB for the 8 000 regions of a
-// 200-genome run); regions it cannot derive that way travel as explicit rows and are scattered into place.
-//   side 0, the region LEFT of anchor `next`  (determineRegion src/parsnp.cpp:1216-1231 when the previous marked base is the
-//           last base of anchor `prev`):   start = end(prev) [prev < 0: 1],          end = start(next) - 1
-//   side 1, the region RIGHT of anchor `prev` (:1254-1268 when the next marked base is the first base of anchor `next`):
-//           start = end(prev) + 1,  end = max(start(next), start) - 1   [next < 0: the genome's end; start at or past it: start - 1]
-//   length = end - start; the request is (start, length) -- exactly what Aligner::find_anchors derives from the same rows.
-struct GapRef { int32_t prev, next; int32_t side; int32_t explicit_row; };      // explicit_row >= 0: row of the explicit arrays instead
-// tid = (region, genome)
-struct ExpandGaps {
-    const GapRef* gaps; int32_t ngen; const int32_t* astart; const int32_t* alon; const int64_t* glen;
-    const int64_t* ex_starts; const int64_t* ex_lens; int64_t* starts; int64_t* lens;
-    PM_HD void operator()(int64_t tid) const {
-        const int64_t r = tid / ngen; const int j = (int)(tid % ngen);
-        const GapRef g = gaps[r];
-        if (g.explicit_row >= 0) { starts[tid] = ex_starts[(int64_t)g.explicit_row * ngen + j]; lens[tid] = ex_lens[(int64_t)g.explicit_row * ngen + j]; return; }
-        const int64_t end_prev = g.prev >= 0 ? (int64_t)astart[(int64_t)g.prev * ngen + j] + alon[g.prev] : 0;
-        const int64_t start_next = g.next >= 0 ? (int64_t)astart[(int64_t)g.next * ngen + j] : 0;
-        int64_t a, b;
-        if (g.side == 0) { a = g.prev >= 0 ? end_prev : 1; b = start_next - 1; }
-        else {
-            const int64_t nxt = end_prev + 1, size = glen[j];
-            int64_t p = nxt;
-            if (nxt < size) p = g.next >= 0 ? (start_next > nxt ? start_next : nxt) : size;
-            a = nxt; b = p - 1;
-        }
-        starts[tid] = a; lens[tid] = b - a;
-    }
-};
-
-// tid = (region, genome): the request rows the device derived itself, checked as the host checks rows it is handed
-// (pm_multi_mum_batch: "region outside its genome"); the reference column must be the one the caller sized the index from
+// ------------------------------------------------------------------------------------------ request rows held by the device
+// tid = (region, genome): request rows the host never saw (regions of the region store, store_kernels.h), checked as the host
+// checks rows it is handed (pm_multi_mum_batch: "region outside its genome"); the reference column must be the one the caller
+// sized the index from
 struct CheckRows {
     const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen; const int64_t* glen; uint32_t* err;
     PM_HD void operator()(int64_t tid) const {
@@ -614,40 +583,9 @@ struct CheckRows {
 };
 
 // ------------------------------------------------------------------------------------------ layout image
-// The reference keeps one bit per base of every genome, set under every accepted MUM (mumlayout, src/parsnp.cpp:3181-3186;
-// marked :1836-1839).  After the anchor call that is 12 million ranges at 200 x 5 Mb -- rows the device still holds as the
-// anchor table.  The bitmaps are built here (zeroed, the rows' ranges set with atomic ORs, one sentinel bit past the end of
-// every genome) and sent to the host as one block, instead of being cleared and marked range by range by the host's cores.
-// Words are 64 bits, bit i of a genome = bit (i & 63) of its word i >> 6; genome j occupies words [word_off[j], word_off[j+1]).
-// tid = (row, genome); accept == nullptr: every row
-struct LayoutMark {
-    const int32_t* start; const int32_t* lon; const uint8_t* accept; int32_t ngen; const int64_t* word_off; const int64_t* nbits; uint64_t* image;
-    PM_HD void operator()(int64_t tid) const {
-        const int64_t c = tid / ngen; const int j = (int)(tid % ngen);
-        if (accept && !accept[c]) return;
-        int64_t a = start[tid], b = a + lon[c];
-        if (a < 0) a = 0;
-        if (b > nbits[j]) b = nbits[j];
-        uint64_t* w = image + word_off[j];
-        while (a < b) {
-            const int lo = (int)(a & 63);
-            const int64_t span = (64 - lo) < (b - a) ? (64 - lo) : (b - a);
-            const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
-            atomic_or64(&w[a >> 6], mask);
-            a += span;
-        }
-    }
-};
-// tid = row of the anchor table: will the host accept it as it stands?  What Aligner::validate_parallel calls a clean candidate
-// that settles (src/parsnp.cpp:1781-1833 with nothing to trim): inside its genomes, no overlap with an earlier row, at least 5
-// long, forward on the reference.  (The host may still refuse a row whose reverse-strand members do not spell the reverse
-// complement, :1791-1825: it takes such a row's marks out of the image itself.)
-struct AnchorAccept {
-    const uint32_t* flags; const int32_t* lon; const uint8_t* strand; int32_t ngen; uint8_t* accept;
-    PM_HD void operator()(int64_t c) const {
-        accept[c] = (uint8_t)(!(flags[c] & (1u | 2u | 8u)) && lon[c] >= 5 && strand[c * ngen] != 0);      // kRowBad | kRowOutside | kRowDirty
-    }
-};
+// The reference keeps one bit per base of every genome, set under every accepted MUM (mumlayout, src/parsnp.cpp:3181-3186; marked
+// :1836-1839): here an image in device memory (store_kernels.h), 64-bit words, bit i of a genome = bit (i & 63) of its word i >> 6;
+// genome j occupies words [word_off[j], word_off[j+1]).
 // tid = genome: the bit past the last base (what a scan to the right stops at)
 struct LayoutSentinel {
     const int64_t* word_off; const int64_t* nbits; uint64_t* image;
@@ -656,74 +594,6 @@ struct LayoutSentinel {
         if (nb > 0) atomic_or64(&image[word_off[tid] + ((nb - 1) >> 6)], 1ull << ((nb - 1) & 63));
     }
 };
-// The seed regions themselves, worked out on the device right after the anchor call -- while the host still receives and
-// validates the anchors -- so that the recursion's first batch can be computed SPECULATIVELY beside the host's work: for
-// every two neighbouring rows of the anchor table that the host is certain to accept untouched (no verdict or overlap / order
-// flag, length >= 5: what Aligner::validate_parallel calls clean and settles without looking), the left region of the second
-// and the right region of the first as find_anchors derives them from the same rows (formulas: ExpandGaps), kept when longer
-// than q in every genome (src/parsnp.cpp:2158-2170) and short enough on the reference for one chunk (:1519-1547).
-// One wavefront per pair of neighbours (w-1, w); lanes over the genomes.
-struct SpecRegion { GapRef ref; int64_t ref_start, ref_len; int32_t minsize, slength; };
-struct GapSeeds {
-    const int32_t* astart; const int32_t* alon; const uint32_t* aflags; int64_t nrows; int32_t ngen; const int64_t* glen;
-    int32_t q; int64_t ref_len_limit; const int32_t* minsize_by_length; int64_t table_len;
-    SpecRegion* out; uint64_t* out_count; uint64_t out_cap;
-    PM_HD void wave(int64_t w) const {
-        const int64_t a = w - 1, b = w < nrows ? w : -1;
-        // (a row with a reverse member, or one that overlaps an earlier row, may still be refused or trimmed by the host: the
-        // regions next to it are a guess then -- the host asks for a region by the two rows it lies between and only where it
-        // left both untouched, so a wrong guess is work nobody looks at, not a wrong answer)
-        const uint32_t kNotClean = 1u | 2u;      // kRowBad | kRowOutside
-        if (a >= 0 && ((aflags[a] & kNotClean) || alon[a] < 5)) return;
-        if (b >= 0 && ((aflags[b] & kNotClean) || alon[b] < 5)) return;
-        if (a < 0 && b < 0) return;
-        for (int side = 0; side < 2; side++) {
-            if (side == 0 ? b < 0 : a < 0) continue;
-            int64_t smin = (int64_t)1 << 40, rstart = 0, rlen = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-            const int lane = (int)__lane_id();
-            for (int j0 = 0; j0 < ngen; j0 += 64) {
-                const int j = j0 + lane;
-                int64_t len = (int64_t)1 << 40, st = 0;
-                if (j < ngen) {
-#else
-            {
-                for (int j = 0; j < ngen; j++) {
-                    int64_t len, st;
-#endif
-                    const int64_t end_a = a >= 0 ? (int64_t)astart[a * ngen + j] + alon[a] : 0;
-                    const int64_t start_b = b >= 0 ? (int64_t)astart[b * ngen + j] : 0;
-                    if (side == 0) { st = a >= 0 ? end_a : 1; len = start_b - 1 - st; }
-                    else {
-                        const int64_t nxt = end_a + 1, size = glen[j];
-                        int64_t p = nxt;
-                        if (nxt < size) p = b >= 0 ? (start_b > nxt ? start_b : nxt) : size;
-                        st = nxt; len = p - 1 - nxt;
-                    }
-                    if (j == 0) { rstart = st; rlen = len; }
-#if defined(__HIP_DEVICE_COMPILE__)
-                }
-                for (int d = 32; d >= 1; d >>= 1) {
-                    const int64_t o = ((int64_t)__shfl_xor((int)(len >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)len, d, 64);
-                    if (o < len) len = o;
-                }
-                if (len < smin) smin = len;
-            }
-            rstart = ((int64_t)__shfl((int)(rstart >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)rstart, 0, 64);
-            rlen = ((int64_t)__shfl((int)(rlen >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)rlen, 0, 64);
-            if (lane != 0) continue;
-#else
-                    if (len < smin) smin = len;
-                }
-            }
-#endif
-            if (smin <= q || smin >= table_len || rlen <= 0 || rlen > ref_len_limit) continue;
-            const uint64_t at = atomic_add64(out_count, 1);
-            if (at < out_cap) out[at] = SpecRegion{GapRef{(int32_t)a, (int32_t)b, side, -1}, rstart, rlen, minsize_by_length[smin], (int32_t)smin};
-        }
-    }
-};
-
 // tid = work unit: which (pair, chunk) it is (off[] = exclusive prefix of the per-pair unit counts)
 struct FillUnits {
     Packed P; const int64_t* starts; const int64_t* lens; int32_t ngen;

@@ -147,7 +147,7 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
     // each when they are first marked, and giving them back costs as much again: 78 vs 61 ms per step), so a repeated
     // run only has to clear them -- beside the anchor call, while the host has nothing else to do; the first reader of
     // the layout (validate, or the end of find_anchors) awaits it.
-    // (a few threads, not one: one core clears ~10 GB/s and would still be at it when the 11 ms anchor call returns;
+    // (a few threads, not one: one core clears ~10 GB/s and would still be at it when the anchor call returns;
     // not all: pages first touched by the worker threads can end up away from the thread that does most of the walking)
     // ... unless the previous run never wrote to them (the resident route keeps the layout on the device) ...
     if (memory_->layout_clean && layout.size() == n) {
@@ -160,135 +160,22 @@ Aligner::Aligner(std::vector<Genome>& g, const Params& p, pm_session* session, A
         if (fits) return;
     }
     memory_->layout_clean = false;
-    // ... or left the other set of bitmaps all zero (it went on with the engine's layout image)
-    if (memory_->spare_zero && memory_->spare.size() == n) {
-        bool fits = true;
-        for (size_t i = 0; i < n && fits; i++) fits = memory_->spare[i].bits() == genomes[i].seq.size() + 1;
-        memory_->spare_zero = false;
-        if (fits && test_hook("PARSNP_CHECK_ZERO"))      // test hook: the set the previous run handed back holds the sentinels and nothing else
-            for (size_t i = 0; i < n; i++)
-                if (memory_->spare[i].count_set() != 1 || !memory_->spare[i].get((long)genomes[i].seq.size())) fatal("the spare layout is not empty");
-        if (fits) { std::swap(memory_->layout, memory_->spare); return; }
-    }
     const size_t parts = std::min<size_t>(4, std::max<size_t>(1, n / 8));
     for (size_t k = 0; k < parts; k++)
         layout_ready_.push_back(std::async(std::launch::async, [this, k, parts] {
             for (size_t i = n * k / parts; i < n * (k + 1) / parts; i++) layout[i].init(genomes[i].seq.size() + 1);
         }));
 }
-// The marks validate_parallel put off: genome by genome (a task owns its genomes' bitmaps: plain stores), the candidates in
-// list order.  Started by whoever gets there first -- extend_generations right before the recursion's first engine call,
-// whose wait they fill -- or by wait_layout().
-void Aligner::mark_stripe(size_t j0, size_t j1) {
-    const size_t ncand = deferred_.state.size();
-    const int32_t* srow = deferred_.rows;
-    for (size_t c = 0; c < ncand; c++) {
-        __builtin_prefetch(srow + (c + 24) * n + j0); __builtin_prefetch(srow + (c + 24) * n + j1 - 1);
-        if ((deferred_.state[c] & 24) != 16) continue;
-        const int32_t* st = srow + c * n; const long lon = deferred_.length[c];
-        for (size_t j = j0; j < j1; j++) layout[j].set_range_inside(st[j], st[j] + lon);
-    }
-}
-void Aligner::start_deferred_marks() {
-    settle_image_ask();
-    if (!deferred_.pending) return;
-    deferred_.pending = false;
-    // (half as many tasks as host threads: measured steadier than one per thread -- 27.6-28.1 against 28.5-28.7 ms mean over
-    // 40 steps -- the call they run beside has staging threads of its own, and the container's CPU quota is finite)
-    const size_t tasks = std::min<size_t>(n, (size_t)std::max<long>(1, (prm.cores + 1) / 2));
-    for (size_t t = 0; t < tasks; t++)
-        layout_ready_.push_back(std::async(std::launch::async, [this, t, tasks] {
-            // background work: it yields to the threads that stage the engine call it runs beside, and takes the cores that
-            // call leaves idle while the device works
-            (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
-            mark_stripe(n * t / tasks, n * (t + 1) / tasks);
-        }));
-}
-// The run goes on with bitmaps attached to the engine's image; the set used so far gets its few marks (those the flagged
-// candidates needed) taken back in the background and waits, all zero, for the next run.
-void Aligner::adopt_image(std::shared_ptr<ImageAsk> a) {
-    std::vector<Bitmap>& other = memory_->spare;
-    other.resize(n);
-    size_t off = 0;
-    for (size_t j = 0; j < n; j++) {
-        const size_t words = ((size_t)a->nbits[j] + 63) / 64 + 1;
-        other[j].attach(a->image + off, words, (size_t)a->nbits[j]);
-        off += words;
-    }
-    std::swap(memory_->layout, memory_->spare);       // `layout` is the image from here on
-    deferred_.pending = false;
-    image_pending_ = true;
-    memory_->spare_zero = true;                       // (once the tasks below are through: wait_layout joins them)
-    std::vector<Bitmap>* zero = &memory_->spare;
-    const size_t nn = n, tasks = 2;
-    for (size_t t = 0; t < tasks; t++)
-        layout_ready_.push_back(std::async(std::launch::async, [zero, a, nn, t, tasks] {
-            for (size_t k = t; k < a->marked_now.size(); k += tasks)
-                for (const MarkSpan& sp : a->marked_now[k]) (*zero)[(size_t)sp.j].clear_range_atomic(sp.a, (long)sp.a + sp.len);
-            const size_t nx = a->extra_len.size();
-            for (size_t k = nx * t / tasks; k < nx * (t + 1) / tasks; k++)
-                for (size_t j = 0; j < nn; j++) (*zero)[j].clear_range_atomic(a->extra_start[k * nn + j], (long)a->extra_start[k * nn + j] + a->extra_len[k]);
-        }));
-}
-// The answer to validate_parallel's request for the layout image.  With it the run goes on with bitmaps attached to the image
-// (every reader awaits the copy: await_image); the set used so far gets its few marks taken back in the background and waits,
-// all zero, for the next run.  Without it the put-off marks are the host's business, as before.
-void Aligner::settle_image_ask() {
-    if (!image_ask_.valid()) return;
-    const double t = now_s();
-    image_ask_.get();
-    std::shared_ptr<ImageAsk> a = image_ask_data_;
-    image_ask_data_.reset();
-    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
-    if (a->rc != PM_OK) { if (dbg) fprintf(stderr, "[layout] no image (%s): the host marks\n", a->error.c_str()); return; }
-    adopt_image(a);
-    stats.layout_images++;
-    if (dbg) fprintf(stderr, "[layout] image taken over %.4f s\n", now_s() - t);
-}
 void Aligner::wait_layout() {
-    start_deferred_marks();
-    if (layout_ready_.empty()) { await_image(); return; }
+    if (layout_ready_.empty()) return;
     const double t = now_s();
     for (auto& f : layout_ready_) f.get();
     layout_ready_.clear();
     if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[setup] waited %.4f s for the layout to be cleared\n", now_s() - t);
-    await_image();
-}
-void Aligner::await_image() {
-    if (image_fix_) {      // (an image asked for ahead: its task, joined by now, awaited the copy and put the host's decisions in)
-        if (image_fix_->rc != PM_OK) fatal("the layout image did not arrive: " + image_fix_->error);
-        image_fix_.reset();
-    }
-    if (!image_pending_) return;
-    image_pending_ = false;
-    const double t = now_s();
-    if (pm_layout_wait(session_) != PM_OK) fatal(std::string("the layout image did not arrive: ") + pm_last_error());
-    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[setup] waited %.4f s for the layout image\n", now_s() - t);
-}
-// The layout image asked for BEFORE the anchors are validated (pm_layout_image with the engine's own choice of rows): the copy
-// then runs beside the validation instead of after it.  Only where validate_parallel will take the engine's overlap flags as
-// they are -- then its clean candidates are the engine's choice, short of the reverse-strand check.
-void Aligner::ask_early_image(const Raw& raw) {
-    early_image_ = nullptr;
-    static const bool off = test_hook("PARSNP_HOST_MARKS") || test_hook("PARSNP_HOST_OVERLAP") || test_hook("PARSNP_MARK_FIRST") || test_hook("PARSNP_LATE_IMAGE");
-    static const size_t par_min = test_hook("PARSNP_PARALLEL_MIN") ? (size_t)atol(test_hook("PARSNP_PARALLEL_MIN")) : 4096;
-    if (off || !session_ || !pool.empty() || !raw.start || !raw.dirty_known || raw.row0 != 0 || prm.cores < 2 || raw.count < par_min) return;
-    wait_layout();      // (the bitmaps of this run are set up in the background: done long ago, joined here)
-    if (layout[0].logging() || layout[0].attached()) return;
-    const int64_t table = pm_result_table_id(raw.owner.get());
-    if (!table) return;
-    early_nbits_.resize(n);
-    for (size_t j = 0; j < n; j++) early_nbits_[j] = (int64_t)gsize_[j] + 1;
-    uint64_t* image = nullptr;
-    if (pm_layout_image(session_, table, early_nbits_.data(), nullptr, (int64_t)raw.count, nullptr, nullptr, 0, &image) == PM_OK) early_image_ = image;
 }
 
 Aligner::~Aligner() {
-    settle_image_ask();             // (an image request nobody took the answer of: the bitmaps must end up in their roles)
-    if (spec_.valid()) { pm_result* r = spec_.get(); if (r) pm_result_free(r); }      // (a speculation nobody took)
-    deferred_.pending = false;      // marks nobody waited for are not set for the sake of it
     wait_layout();
-    finish_prejudge();
     // the resident route never writes to the host's bitmaps: the next run starts on them as they are
     memory_->layout_clean = res_.active && !layout.empty() && !layout[0].attached();
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
@@ -479,62 +366,10 @@ void Aligner::unpack_result(pm_result* res, size_t nregions, bool rows, std::vec
     }
 }
 
-// The recursion's first batch, computed beside the validation of the anchors (include/parsnp_mum.h:
-// pm_multi_mum_batch_spec): right after the anchor call a helper thread asks the engine for the seed regions between
-// anchors it is certain to see accepted untouched -- the device works them out from its resident anchor table and searches
-// them while this thread receives, validates and marks the anchors (~4 ms in which the device would idle).
-// take_speculation() joins; extend_generations() then finds almost every seed region's result waiting (looked up by the
-// two rows and the side) and sends only the rest.  Same bytes either way: a region's result is a pure function of its rows.
-void Aligner::start_speculation(int64_t table, int64_t rows) {
-    static const bool off = test_hook("PARSNP_NO_SPECULATIVE_SEEDS") != nullptr;      // test hook: every seed region is requested after the validation
-    if (off || table == 0 || prm.cores < 2 || sharded_) return;
-    std::vector<int32_t>& tab = memory_->mum_minsize;
-    if (tab.empty()) {      // minimum length by shortest region length (the `mums` expression), once per run of the process
-        tab.resize(8192);
-        tab[1] = (int32_t)min_length(false, 1);      // (refuses an expression that cannot be evaluated)
-        const long nt = (long)tab.size();
-        const std::string& e = prm.mums;
-#pragma omp parallel for schedule(static) num_threads(prm.cores > 0 ? prm.cores : 1)
-        for (long i = 2; i < nt; i++) { int v = 0; (void)min_mum_length(e, i, &v); tab[(size_t)i] = (int32_t)v; }
-        tab[0] = tab[1];      // (a region of length 0 is never kept: q >= 0)
-    }
-    spec_rows_ = rows;
-    spec_ = std::async(std::launch::async, [this, table, &tab]() -> pm_result* {
-        pm_result* res = nullptr;
-        const int rc = pm_multi_mum_batch_spec(session_, table, (int32_t)prm.q, (int64_t)prm.p, tab.data(), (int64_t)tab.size(), &res);
-        return rc == PM_OK ? res : nullptr;      // (a refusal only means that nothing was computed ahead)
-    });
-}
-void Aligner::take_speculation() {
-    settle_image_ask();      // (its helper waits on the same future)
-    if (!spec_.valid()) return;
-    pm_result* res = spec_.get();
-    if (!res) return;
-    const size_t nreg = (size_t)pm_result_regions(res);
-    const pm_gap_ref* refs = pm_result_spec_refs(res);
-    const int32_t* ms = pm_result_spec_minsize(res);
-    // looked up by the row a region lies next to: the left region of row `next`, the right region of row `prev` (the other row
-    // is checked at the lookup)
-    spec_min_.assign(ms, ms + nreg);
-    spec_refs_.assign(refs, refs + nreg);
-    spec_at_.assign(2 * (size_t)(spec_rows_ + 1), -1);
-    for (size_t i = 0; i < nreg; i++) {
-        const int64_t row = refs[i].side == 0 ? refs[i].next : refs[i].prev;
-        if (row >= 0 && row < spec_rows_) spec_at_[2 * (size_t)row + (size_t)(refs[i].side & 1)] = (int32_t)i;
-    }
-    unpack_result(res, nreg, true, &spec_raw_);
-    timing_first_call_ = false;
-    collect_engine_timing();
-    stats.finder_calls++;
-    stats.finder_regions += (long)nreg;
-    stats.spec_regions += (long)nreg;
-}
-
 void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out, bool rows) {
     out->clear();
     out->resize(reqs.size());
     if (reqs.empty()) return;
-    take_speculation();      // (a session is single-threaded: the batch the helper thread asked for has to be in first)
     double t0 = now_s();
     // results as MUM rows built on the device where the provider can (the HIP engine) and every request is its region
     static const bool no_rows = test_hook("PARSNP_NO_DEVICE_ROWS") != nullptr;      // test hook: the host builds the rows from sp / fwd
@@ -553,29 +388,10 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     std::vector<int32_t> mins(reqs.size());
     double alg = 0, algk = 0, algq = 0;
     const long nreq = (long)reqs.size();
-    // Regions that are gaps between two rows of the engine's resident anchor table go as 16 bytes each (pm_multi_mum_batch_gaps)
-    // instead of 16 bytes per GENOME: the engine derives their rows from the table.  Worth it for a batch of many such regions
-    // (the recursion's seeds); the rows of the others travel as before, packed at the front of the flat arrays.
-    static const bool no_gaps = test_hook("PARSNP_NO_GAP_REQUESTS") != nullptr;      // test hook: every row travels
-    long derived = 0;
-    if (rows && anchor_table_ != 0 && !no_gaps) for (const Request& q : reqs) derived += q.plain && q.gap_side >= 0;
-    const bool use_gaps = derived >= 64 && derived * 2 >= nreq;
-    std::vector<pm_gap_ref> gaps; std::vector<int64_t> ref_start, ref_len; std::vector<int32_t> explicit_at;
-    int64_t n_explicit = 0;
-    if (use_gaps) {
-        gaps.resize(reqs.size()); ref_start.resize(reqs.size()); ref_len.resize(reqs.size()); explicit_at.assign(reqs.size(), -1);
-        for (size_t i = 0; i < reqs.size(); i++) {
-            const Request& q = reqs[i];
-            ref_start[i] = q.start[0]; ref_len[i] = q.len[0];
-            if (q.plain && q.gap_side >= 0) gaps[i] = pm_gap_ref{q.gap_prev, q.gap_next, q.gap_side, -1};
-            else { explicit_at[i] = (int32_t)n_explicit; gaps[i] = pm_gap_ref{-1, -1, 0, (int32_t)n_explicit++}; }
-        }
-    }
 #pragma omp parallel for schedule(dynamic, 64) num_threads(prm.cores > 0 ? prm.cores : 1) reduction(+ : alg, algk, algq) if (nreq > 256)
     for (long i = 0; i < nreq; i++) {
         const Request& q = reqs[(size_t)i];
-        if (!use_gaps) { memcpy(&starts[(size_t)i * n], q.start, n * 8); memcpy(&lens[(size_t)i * n], q.len, n * 8); }
-        else if (explicit_at[(size_t)i] >= 0) { memcpy(&starts[(size_t)explicit_at[(size_t)i] * n], q.start, n * 8); memcpy(&lens[(size_t)explicit_at[(size_t)i] * n], q.len, n * 8); }
+        memcpy(&starts[(size_t)i * n], q.start, n * 8); memcpy(&lens[(size_t)i * n], q.len, n * 8);
         mins[(size_t)i] = q.minsize;
         // SURVEY 8d's model (one 8-byte index probe and 16 bytes of state per query suffix), and what the event search of THIS
         // engine has to move per (region, query genome): the query piece once (16 B per 32 bases; the reverse strand is not
@@ -600,17 +416,7 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     if (dbg_b) fprintf(stderr, "[run_batch] %zu requests packed %.4f s\n", reqs.size(), now_s() - t0);
     const double tcall = now_s();
     pm_result* res = nullptr;
-    int rc;
-    if (use_gaps) {
-        rc = pm_multi_mum_batch_gaps(session_, anchor_table_, (int64_t)reqs.size(), gaps.data(), ref_start.data(), ref_len.data(), mins.data(),
-                                     n_explicit, starts.data(), lens.data(), &res);
-        if (rc == PM_EINVAL) {      // the engine holds another table by now (a later long one-region call): the rows travel
-            anchor_table_ = 0;
-            run_batch(reqs, out, rows);
-            return;
-        }
-        stats.gap_requests += (long)reqs.size() - (long)n_explicit;
-    } else rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);
+    const int rc = pm_multi_mum_batch(session_, (int64_t)reqs.size(), starts.data(), lens.data(), mins.data(), &res);
     if (rc == PM_ELIMIT) {     // a size limit of the engine (include/parsnp_mum.h), not a malfunction: its own exit code
         std::cerr << "parsnp_core: input exceeds a limit of the multi-MUM engine: " << pm_last_error() << std::endl;
         exit(5);
@@ -653,24 +459,6 @@ void Aligner::region_mums(const Region& r, bool anchors, std::vector<int>* accep
             std::vector<Request> one{q};
             std::vector<Raw> raw;
             run_batch(one, &raw, q.plain);
-            // Both bets on what the validation will find are only placed on a list whose acceptable rows lie in list order in
-            // every genome (no PM_ROW_EARLY among them: the same bits validate_parallel reads the order from).  Out of order
-            // -- rearranged genomes -- the marks are not put off and the seed regions come from bitmap walks, not from pairs of
-            // rows: the image would be thrown away and no region of the batch asked for.
-            // (likewise where the running-extent test flags more than one row in eight: validate_parallel then drops the flags
-            // for the exact test -- the sign of rearranged genomes)
-            bool in_order = true;
-            if (anchors && raw[0].start && raw[0].dirty_known) {
-                size_t overlapping = 0;
-                for (size_t c = 0; c < raw[0].count && in_order; c++) {
-                    const uint32_t f = raw[0].flags[c];
-                    overlapping += !(f & PM_ROW_BAD) && (f & PM_ROW_DIRTY);
-                    in_order = !((f & PM_ROW_EARLY) && !(f & (PM_ROW_BAD | PM_ROW_OUTSIDE | PM_ROW_DIRTY)) && raw[0].lon[c] >= 5);
-                }
-                if (overlapping * 8 > raw[0].count) in_order = false;
-            }
-            if (anchors && raw[0].start && in_order) ask_early_image(raw[0]);      // (before the helper thread's call: a session takes one call at a time)
-            if (anchors && raw[0].start && in_order) start_speculation(pm_result_table_id(raw[0].owner.get()), (int64_t)raw[0].count);
             if (!e) e = cache_put(q, false);
             e->raw = std::move(raw[0]); e->pending = false;
         } else if (!speculative) {
@@ -806,16 +594,6 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
     static const bool force_exact = test_hook("PARSNP_EXACT_OVERLAP") != nullptr;   // test hook: always the bitmap test
     static const bool host_overlap = test_hook("PARSNP_HOST_OVERLAP") != nullptr;   // test hook: the cheap test on the host although the device ran it
     const bool device_dirty = device_rows && raw.dirty_known && layout_empty && !host_overlap;
-    // Where the engine keeps this list's rows resident it can deliver the layout they leave as an image (pm_layout_image, at
-    // the end of this function): the bitmaps this call works on then only ever hold the marks the flagged candidates need,
-    // which are noted and taken back.  PARSNP_HOST_MARKS=1 (test hook): the host's cores mark, as without an anchor table.
-    static const bool host_marks = test_hook("PARSNP_HOST_MARKS") != nullptr;
-    // (never while this run works on bitmaps that ARE the engine's block -- a run that started on the image of the previous one
-    // because the other set could not be reused: the two sets must not end up on the same words)
-    const int64_t image_table = (device_rows && layout_empty && session_ && raw.row0 == 0 && !host_marks && !layout[0].attached()) ? pm_result_table_id(raw.owner.get()) : 0;
-    typedef MarkSpan Span;
-    std::vector<std::vector<Span>> marked_now(image_table ? (size_t)threads : 0);
-    for (auto& v : marked_now) v.reserve(ncand / 16 + 4096);
 #pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
     for (long c = 0; c < nc; c++) {
         Mum& m = cand[(size_t)c];
@@ -895,126 +673,11 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         }
     }
     lap("settle");
-    // (the same pass notes whether the accepted clean candidates of a genome come one after the other: anchors_ordered_)
-    //
-    // Into an empty layout (the anchor call) the marks can wait: nothing reads them before the recursion's first list is
-    // validated -- except the flagged candidates below, which look at the bits of their OWN intervals.  If the accepted
-    // clean candidates lie in list order in every genome (a pass over the rows, candidate by candidate: contiguous reads)
-    // the ones that meet a flagged candidate's interval are found by bisection and marked now; the other 12 million
-    // intervals (200 x 5 Mb: 3.6 ms of all cores) are marked by background tasks that extend_generations() starts right
-    // before the recursion's first engine call, whose wait they fill.  PARSNP_MARK_FIRST=1 (test hook): never put off.
-    static const bool mark_first = test_hook("PARSNP_MARK_FIRST") != nullptr;
+    // the marks of the clean candidates, genome by genome; the same pass notes whether the accepted clean candidates of a
+    // genome come one after the other (anchors_ordered_)
     int disorder = 0;
-    bool put_off = false;
-    // (the order: from the device's PM_ROW_EARLY bits where it delivered the overlap flags -- no accepted clean candidate
-    // with the bit means in order; the bit is conservative, so a list it calls out of order takes the marking pass -- else
-    // from the rows, PARSNP_HOST_ORDER=1 forces that)
-    static const bool host_order = test_hook("PARSNP_HOST_ORDER") != nullptr;
-    bool order_known = false;
-    if (layout_empty && !mark_first && threads > 1 && device_dirty && !host_order) {
-        for (size_t c = 0; c < ncand; c++) if ((state[c] & 24) == 16 && (raw.flags[c] & PM_ROW_EARLY)) { disorder = 1; break; }
-        order_known = true;
-    }
-    if (layout_empty && !mark_first && threads > 1) {
-        const long kRun = 1024, nruns = order_known ? 0 : (nc + kRun - 1) / kRun;      // (no run: the device has said it)
-        std::vector<long> first_acc((size_t)nruns, -1), last_acc((size_t)nruns, -1);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(| : disorder)
-        for (long rr = 0; rr < nruns; rr++) {
-            long prev = -1;
-            const long c1 = std::min(nc, (rr + 1) * kRun);
-            for (long c = rr * kRun; c < c1; c++) {
-                if ((state[(size_t)c] & 24) != 16) continue;
-                if (prev < 0) first_acc[(size_t)rr] = c;
-                else {
-                    const int32_t* a = srow + (size_t)prev * n; const int32_t* b = srow + (size_t)c * n;
-                    const long lp = cand[(size_t)prev].length;
-                    long bad = 0;
-                    for (size_t j = 0; j < n; j++) bad |= (long)b[j] - ((long)a[j] + lp);      // sign bit: starts before the previous one ends
-                    disorder |= bad < 0 ? 1 : 0;
-                }
-                prev = c;
-            }
-            last_acc[(size_t)rr] = prev;
-        }
-        long prev = -1;
-        for (long rr = 0; rr < nruns && !disorder; rr++) {
-            if (first_acc[(size_t)rr] < 0) continue;
-            if (prev >= 0) {
-                const int32_t* a = srow + (size_t)prev * n; const int32_t* b = srow + (size_t)first_acc[(size_t)rr] * n;
-                const long lp = cand[(size_t)prev].length;
-                for (size_t j = 0; j < n; j++) if ((long)b[j] < (long)a[j] + lp) { disorder = 1; break; }
-            }
-            prev = last_acc[(size_t)rr];
-        }
-        if (!disorder) {
-            put_off = true;
-            std::vector<uint32_t> acc_idx;
-            acc_idx.reserve(ncand);
-            for (size_t c = 0; c < ncand; c++) if ((state[c] & 24) == 16) acc_idx.push_back((uint32_t)c);
-            std::vector<uint32_t> flagged_now;
-            for (size_t c = 0; c < ncand; c++) if ((state[c] & 11) == 11) flagged_now.push_back((uint32_t)c);
-            lap("lists");
-            const long nfl = (long)flagged_now.size();
-            const size_t nacc = acc_idx.size();
-            // lengths of the clean candidates (never trimmed): the engine's compact array where there is one, not the 48-byte records
-            std::vector<int32_t> len_store;
-            if (!device_rows) { len_store.resize(ncand); for (size_t c = 0; c < ncand; c++) len_store[c] = (int32_t)cand[c].length; }
-            const int32_t* const len_of = device_rows ? raw.lon : len_store.data();
-#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
-            for (long o = 0; o < nfl; o++) {
-                const uint32_t cf = flagged_now[(size_t)o];
-                const Mum& f = cand[cf];
-                if (f.length <= 0) continue;
-                // where the candidate itself sits in the accepted list: in most genomes what it meets are its list neighbours,
-                // so the search below gallops outwards from there (the same few rows for all genomes) before it bisects
-                const size_t here = (size_t)(std::lower_bound(acc_idx.begin(), acc_idx.end(), cf) - acc_idx.begin());
-                // (their rows, whole: the searches of all genomes end among them, each in a different line of the same rows)
-                for (size_t k = here > 2 ? here - 2 : 0; k < std::min(nacc, here + 3); k++) {
-                    const char* row = (const char*)(srow + (size_t)acc_idx[k] * n);
-                    for (size_t b = 0; b < n * sizeof(int32_t); b += 64) __builtin_prefetch(row + b);
-                }
-                for (size_t j = 0; j < n; j++) {
-                    const long s = f.start[j], e = s + f.length;
-                    auto ends_after = [&](size_t k) { const uint32_t c = acc_idx[k]; return (long)srow[(size_t)c * n + j] + len_of[c] > s; };
-                    size_t lo = 0, hi = nacc;                 // the first accepted clean candidate that ends after s (ends rise with the list)
-                    if (here < nacc && ends_after(here)) {
-                        hi = here;
-                        for (size_t step = 1; hi > 0; step *= 2) {
-                            const size_t k = hi > step ? hi - step : 0;
-                            if (ends_after(k)) hi = k; else { lo = k + 1; break; }
-                        }
-                    } else if (here < nacc) {
-                        lo = here + 1;
-                        for (size_t step = 1; lo < nacc; step *= 2) {
-                            const size_t k = std::min(nacc - 1, lo + step - 1);
-                            if (!ends_after(k)) lo = k + 1; else { hi = k; break; }
-                        }
-                    }
-                    while (lo < hi) {
-                        const size_t mid = (lo + hi) / 2;
-                        if (ends_after(mid)) hi = mid; else lo = mid + 1;
-                    }
-                    for (size_t k = lo; k < nacc; k++) {
-                        const uint32_t c = acc_idx[k];
-                        const long a = srow[(size_t)c * n + j];
-                        if (a >= e) break;
-                        layout[j].set_range_atomic(a, a + len_of[c]);
-                        if (image_table) marked_now[(size_t)omp_get_thread_num()].push_back(Span{(int32_t)j, (int32_t)a, (int32_t)len_of[c]});
-                    }
-                }
-            }
-            lap("neighbours");
-            deferred_.rows = srow;
-            deferred_.length.resize(ncand);
-            if (device_rows) memcpy(deferred_.length.data(), raw.lon, ncand * sizeof(int32_t));
-            else for (size_t c = 0; c < ncand; c++) deferred_.length[c] = (int32_t)cand[c].length;
-            deferred_.state = state;
-            deferred_.pending = true;
-        }
-    }
-    disorder = 0;      // (put off: none; else the marking pass below finds it out itself)
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(| : disorder) if (!put_off)
-    for (int t = 0; t < (put_off ? 0 : nstripes); t++) {
+    for (int t = 0; t < nstripes; t++) {
         const size_t j0 = n * (size_t)t / (size_t)nstripes, j1 = n * (size_t)(t + 1) / (size_t)nstripes;
         std::vector<long> last_l(j1 - j0 + 16, 0);      // end of the previous accepted candidate, per genome of the stripe
         long* last = last_l.data() + 8 - j0;
@@ -1126,72 +789,8 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         }
     }
     lap("places");
-    // The put-off marks, and everything else of the layout this list leaves, come as an image from the device: the accepted
-    // clean candidates are rows of its anchor table; the accepted flagged ones travel with the coordinates trim() left them.
-    // Asked for by a helper while this thread writes the MUM records (the engine is not used by anybody else meanwhile).
-    // The engine is asked by a helper thread -- after the batch computed ahead is back, a session takes one call at a time --
-    // and the answer is taken by whoever first needs the layout (settle_image_ask, from wait_layout / start_deferred_marks).
-    uint64_t* const early = early_image_;
-    early_image_ = nullptr;      // (an image asked for ahead that this list cannot use -- not put off -- is simply never looked at)
-    if (put_off && early && device_dirty && image_table) {
-        auto fix = std::make_shared<ImageAsk>();
-        fix->image = early; fix->nbits = early_nbits_; fix->rc = PM_OK;
-        for (size_t c = 0; c < ncand; c++) {
-            const uint8_t st = state[c];
-            if ((st & 8) && place[c] != kNoPlace) {      // accepted after the ordered pass: marked here, with the coordinates trim() left
-                fix->extra_len.push_back((int32_t)cand[c].length);
-                fix->extra_start.insert(fix->extra_start.end(), cand[c].start, cand[c].start + n);
-            } else if ((st & 11) == 3 && !(st & 16) && raw.lon[c] >= 5 && frow[c * n] != 0) {      // the engine's choice, refused by settle(): unmarked here
-                fix->clear_len.push_back(raw.lon[c]);
-                fix->clear_start.insert(fix->clear_start.end(), cand[c].start, cand[c].start + n);
-            }
-        }
-        fix->marked_now = std::move(marked_now);
-        adopt_image(fix);
-        // (the copy has been running since before the validation: a task awaits it and puts right what the host decided
-        // otherwise, well before the first reader asks -- wait_layout joins it)
-        image_pending_ = false;
-        std::vector<Bitmap>* img = &memory_->layout;
-        pm_session* ses = session_;
-        const size_t nn = n;
-        layout_ready_.push_back(std::async(std::launch::async, [img, fix, ses, nn] {
-            if (pm_layout_wait(ses) != PM_OK) { fix->rc = PM_EHIP; fix->error = pm_last_error(); return; }
-            // rows the engine marked and the host refused (a reverse-strand member that does not spell the reverse complement)
-            // overlap nothing accepted before them, and what was accepted later where they lie is among the rows set next
-            for (size_t k = 0; k < fix->clear_len.size(); k++)
-                for (size_t j = 0; j < nn; j++) (*img)[j].clear_range_atomic(fix->clear_start[k * nn + j], (long)fix->clear_start[k * nn + j] + fix->clear_len[k]);
-            for (size_t k = 0; k < fix->extra_len.size(); k++)
-                for (size_t j = 0; j < nn; j++) (*img)[j].set_range_atomic(fix->extra_start[k * nn + j], (long)fix->extra_start[k * nn + j] + fix->extra_len[k]);
-        }));
-        image_fix_ = fix;      // (wait_layout looks at its verdict)
-        stats.layout_images++;
-    } else if (put_off && image_table) {
-        auto ask = std::make_shared<ImageAsk>();
-        ask->accept.resize(ncand);
-        for (size_t c = 0; c < ncand; c++) ask->accept[c] = (state[c] & 24) == 16;
-        for (size_t c = 0; c < ncand; c++)
-            if ((state[c] & 8) && place[c] != kNoPlace) {
-                ask->extra_len.push_back((int32_t)cand[c].length);
-                ask->extra_start.insert(ask->extra_start.end(), cand[c].start, cand[c].start + n);
-            }
-        ask->nbits.resize(n);
-        for (size_t j = 0; j < n; j++) ask->nbits[j] = (int64_t)gsize_[j] + 1;
-        ask->marked_now = std::move(marked_now);
-        image_ask_data_ = ask;
-        const int64_t table_id = image_table;
-        image_ask_ = std::async(std::launch::async, [this, ask, table_id] {
-            if (spec_.valid()) spec_.wait();
-            ask->rc = pm_layout_image(session_, table_id, ask->nbits.data(), ask->accept.data(), (int64_t)ask->accept.size(), ask->extra_start.data(),
-                                      ask->extra_len.data(), (int64_t)ask->extra_len.size(), &ask->image);
-            if (ask->rc != PM_OK) ask->error = pm_last_error();
-        });
-    }
     const size_t pool0 = pool.size(), acc0 = accepted->size();
     const long id0 = next_id_;
-    // where the engine keeps this list's rows resident (its anchor table), the MUMs remember their row: the seed regions
-    // between two untouched rows can then be requested by reference (run_batch)
-    const int64_t table = device_rows ? pm_result_table_id(raw.owner.get()) : 0;
-    if (table) anchor_table_ = table;
     pool.resize(pool0 + nacc);
     accepted->resize(acc0 + nacc);
     lap("resize");
@@ -1204,7 +803,6 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
             const uint32_t at = place[(size_t)c];
             if (at == kNoPlace) continue;
             Mum m = cand[(size_t)c];
-            m.row = table ? (int32_t)(raw.row0 + (size_t)c) : -1;
             m.id = id0 + (long)idrank[(size_t)c];
             m.slength = slen;
             m.dirty = (state[(size_t)c] & 8) != 0;
@@ -1235,9 +833,7 @@ void Aligner::validate_parallel(const Region& r, const Request& q, const Raw& ra
         }
         anchors_ordered_ = !unordered;
     } else anchors_ordered_ = false;
-    if (dbg && put_off) fprintf(stderr, "[validate_parallel] marks of the clean candidates put off\n");
     lap("sequential");
-    lap("image ask");
 }
 
 // Overlap trimming against already marked bases: from the left, then from the right, genome by genome; every trim
@@ -1278,8 +874,7 @@ bool Aligner::find_anchors() {
     }
     region_mums(whole, true, &found, false);
     lap_a("search + validation");
-    // (marks that validate_parallel put off stay put off while the seed regions come from the rows: only walks read them)
-    if (!anchors_ordered_ || test_hook("PARSNP_WALK_NEIGHBOURS") || test_hook("PARSNP_CHECK_NEIGHBOURS")) wait_layout();
+    wait_layout();
     mums = found;
     m0 = (long)found.size();
     // seed regions: left and right neighbour of every anchor, longer than q in every genome (:2150-2172).  The layout
@@ -1317,7 +912,6 @@ bool Aligner::find_anchors() {
             r.start = tl.rows.alloc(n); r.end = tl.rows.alloc(n); r.length = tl.rows.alloc(n);
             memcpy(r.start, s.start, n * sizeof(long)); memcpy(r.end, s.end, n * sizeof(long)); memcpy(r.length, s.length, n * sizeof(long));
             r.slength = s.slength; r.llength = s.llength;
-            r.gap_prev = s.gap_prev; r.gap_next = s.gap_next; r.gap_side = s.gap_side;
             *out = r;
         };
         // what is known about the right neighbour of the previous anchor of this run: its rows (kept), or a genome in
@@ -1361,13 +955,6 @@ bool Aligner::find_anchors() {
                 if (len > l) l = len;
             }
             out->slength = s; out->llength = l;
-            // both rows as the engine holds them (a candidate that took the ordered pass may have been trimmed here)?
-            out->gap_side = -1;
-            if (anchor_table_ != 0 && m.row >= 0 && !m.touched && (!other || (other->row >= 0 && !other->touched))) {
-                out->gap_side = left ? 0 : 1;
-                out->gap_prev = left ? (other ? other->row : -1) : m.row;
-                out->gap_next = left ? m.row : (other ? other->row : -1);
-            }
             return true;
         };
         static const bool no_rows_path = test_hook("PARSNP_WALK_NEIGHBOURS") != nullptr;      // test hook: always the bitmap walks
@@ -1684,7 +1271,6 @@ bool Aligner::extend_generations() {
     std::vector<int> seeds_raw;                   // engine results of the seeds, for the restart
     std::function<void()> before_restart = [] {};
     auto restart_in_order = [&]() {
-        finish_prejudge();
         wait_layout();
         before_restart();
         pool.resize(pool0);
@@ -1715,7 +1301,7 @@ bool Aligner::extend_generations() {
     };
     auto plain_request = [&](const Region& r, Request* q) {
         if (!plain_shape(r)) return false;
-        *q = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0, true, r.gap_prev, r.gap_next, r.gap_side};
+        *q = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0, true};
         return true;
     };
     // the same for a list: the row checks (8 000 regions x 201 genomes per generation) by all threads, the minimum
@@ -1730,7 +1316,7 @@ bool Aligner::extend_generations() {
             if (skip && (*skip)[(size_t)i] >= 0) continue;
             if (!ok[(size_t)i]) return false;
             const Region& r = rs[(size_t)i];
-            (*out)[(size_t)i] = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0, true, r.gap_prev, r.gap_next, r.gap_side};
+            (*out)[(size_t)i] = Request{r.start, r.length, min_length(false, r.slength), r.start[0], 0, true};
         }
         return true;
     };
@@ -1738,18 +1324,8 @@ bool Aligner::extend_generations() {
         std::vector<Request> want, all; std::vector<size_t> who;
         const double tf = now_s();
         if (!plain_requests(rs, raw_of, &all)) return false;
-        take_speculation();      // what the engine computed ahead, beside the validation of the anchors
         for (size_t i = 0; i < rs.size(); i++) {
             if ((*raw_of)[i] >= 0) continue;
-            if (!spec_at_.empty() && rs[i].gap_side >= 0) {
-                const int64_t row = rs[i].gap_side == 0 ? rs[i].gap_next : rs[i].gap_prev;
-                const int32_t at = row >= 0 && row < spec_rows_ ? spec_at_[2 * (size_t)row + (size_t)rs[i].gap_side] : -1;
-                if (at >= 0 && spec_refs_[(size_t)at].prev == rs[i].gap_prev && spec_refs_[(size_t)at].next == rs[i].gap_next && spec_min_[(size_t)at] == all[i].minsize) {
-                    (*raw_of)[i] = (int)raws.size(); raws.push_back(spec_raw_[(size_t)at]);
-                    stats.spec_hits++;
-                    continue;
-                }
-            }
             want.push_back(all[i]); who.push_back(i);
         }
         if (want.empty()) return true;
@@ -1785,8 +1361,7 @@ bool Aligner::extend_generations() {
         std::vector<size_t> first;               // clusters of `now`
         bool trouble = false;
         if (gi == 0) {                           // the first pushed seed, before anything is sorted
-            start_deferred_marks();              // the anchors' put-off marks: set while this thread waits for the device
-            trouble = !fetch(gen, &gen_raw);     // ... but every seed's engine result in ONE call
+            trouble = !fetch(gen, &gen_raw);     // every seed's engine result in ONE call
             seeds_raw = gen_raw;
             now.push_back(gen.front()); now_raw.push_back(gen_raw.front());
             first = {0, 1};
@@ -1812,7 +1387,6 @@ bool Aligner::extend_generations() {
         if (!trouble && !plain_requests(now, nullptr, &req)) trouble = true;
         lap("requests");
         if (trouble) {
-            finish_prejudge();
             stats.generation_handover = gi;
             file_into_cache(gen, gen_raw);
             if (gi == 0) { regions = std::move(gen); if (speculation_) prefetch(regions); return extend_pass(false); }
@@ -1901,12 +1475,6 @@ bool Aligner::extend_generations() {
         stats.t_validate += now_s() - tv;
         lap("validate");
         stats.generations++; stats.generation_regions += m;
-        {   // the anchors' chaining verdicts are still being worked out from `pool` and `mums` (start_prejudge): joined here only
-            // if the new MUMs would make either vector move
-            size_t more = 0;
-            for (long x = 0; x < m; x++) more += out[(size_t)x].accepted.size();
-            if (pool.size() + more > pool.capacity() || mums.size() + more > mums.capacity()) finish_prejudge();
-        }
         for (long x = 0; x < m; x++) {           // commit in list order
             for (Mum& mm : out[(size_t)x].accepted) { mm.id = next_id_++; pool.push_back(mm); mums.push_back((int)pool.size() - 1); }
             for (Region& k : out[(size_t)x].kids) { gen.push_back(k); gen_raw.push_back(-1); }
@@ -1933,11 +1501,8 @@ bool Aligner::extend() {
     sweeps_ = 0; misses_since_sweep_ = 0;
     double tr = now_s();
     bool any;
-    static const bool no_prejudge = test_hook("PARSNP_NO_PREJUDGE") != nullptr;      // test hook: every verdict inside chain()
-    if (!no_prejudge) start_prejudge();
     if (test_hook("PARSNP_SEQUENTIAL_REPLAY") == nullptr) any = extend_generations();
-    else { if (speculation_) prefetch(regions); finish_prejudge(); tr = now_s(); any = extend_pass(false); }
-    finish_prejudge();
+    else { if (speculation_) prefetch(regions); tr = now_s(); any = extend_pass(false); }
     stats.t_replay = now_s() - tr - stats.t_sweep;
     remaining_ = nullptr;
     cache_.clear();
@@ -2070,35 +1635,8 @@ uint8_t Aligner::judge_pair(const Mum& nt, const Mum& back) const {
     return min_gap / max_gap >= 1.0 - diag_diff ? kJoin : kClose;
 }
 
-// The verdict of a pair of MUMs depends on the two alone, and four out of five anchors still follow the same anchor in
-// the final MUM list (the recursion adds one MUM per six anchors).  So the anchors' consecutive pairs are judged while the
-// host would otherwise wait for the recursion's first engine call; chain() reuses a verdict whenever the predecessor of a
-// MUM is still the one it was judged against.  Reads the anchors' part of `pool` and `mums`: the generations may append to both
-// meanwhile (room is reserved here), and finish_prejudge() is called before either would move or is reordered.
-void Aligner::start_prejudge() {
-    static const size_t min_n = test_hook("PARSNP_PREJUDGE_MIN") ? (size_t)atol(test_hook("PARSNP_PREJUDGE_MIN")) : 4096;   // test hook
-    if (mums.size() < min_n || prm.cores < 2) return;
-    judged_pred_.assign(pool.size(), -1); judged_verdict_.assign(pool.size(), kClose);
-    // (room for the recursion's MUMs -- one per six anchors at 200 x 5 Mb -- so that the generations can add theirs while the
-    // verdicts are still being worked out: see the commit step of extend_generations)
-    pool.reserve(pool.size() + pool.size() / 2 + 1024); mums.reserve(mums.size() + mums.size() / 2 + 1024);
-    // a third of the threads: the engine call it runs beside stages 26 MB of request rows with threads of its own first
-    const int team = std::max(2, prm.cores / 3);
-    const long m = (long)mums.size();      // (the list as it stands: the generations append to it meanwhile)
-    prejudge_ = std::async(std::launch::async, [this, team, m] {
-#pragma omp parallel for schedule(dynamic, 1024) num_threads(team)
-        for (long x = 1; x < m; x++) {
-            const int cur = mums[(size_t)x], prev = mums[(size_t)x - 1];
-            judged_verdict_[(size_t)cur] = judge_pair(pool[(size_t)cur], pool[(size_t)prev]);
-            judged_pred_[(size_t)cur] = prev;
-        }
-    });
-}
-void Aligner::finish_prejudge() { if (prejudge_.valid()) prejudge_.get(); }
-
 void Aligner::chain() {
     double t0 = now_s();
-    finish_prejudge();
     lcbs.clear();
     unique_order = true;
     {
@@ -2125,7 +1663,7 @@ void Aligner::chain() {
     // (a verdict depends on the two MUMs alone: the second chaining pass, after a few LCBs were dissolved, reuses the
     // verdicts of every MUM whose predecessor is still the same)
     std::vector<uint8_t> ahead((size_t)m, CLOSE);
-    if (judged_pred_.size() < pool.size()) { judged_pred_.resize(pool.size(), -1); judged_verdict_.resize(pool.size(), CLOSE); }   // earlier verdicts (start_prejudge, the first pass) stay
+    if (judged_pred_.size() < pool.size()) { judged_pred_.resize(pool.size(), -1); judged_verdict_.resize(pool.size(), CLOSE); }   // earlier verdicts (the first pass) stay
     std::vector<long> lens((size_t)m);          // gathered here: the sequential pass below would miss the cache once per MUM
     lens[0] = pool[(size_t)mums[0]].length;
 #pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 4096)

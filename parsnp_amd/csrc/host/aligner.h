@@ -213,8 +213,8 @@ struct Mum {
     int32_t* start = nullptr;
     uint8_t* fwd = nullptr;
     bool dirty = false;      // (anchor validation) overlapped an earlier candidate and went through the ordered pass
-    bool touched = false;    // ... and was trimmed there: its row is no longer the one the engine holds
-    int32_t row = -1;        // its row in the engine's resident anchor table (pm_result_table_id), where the engine keeps one
+    bool touched = false;    // ... and was trimmed there
+    int32_t row = -1;        // (resident route) its row in the engine's MUM store
     long end(size_t j) const { return (long)start[j] + length; }
 };
 
@@ -223,9 +223,6 @@ struct Region {          // rows of n entries in Aligner's arenas; immutable onc
     long* end = nullptr;
     long* length = nullptr;
     long slength = 0, llength = 0;
-    // the region is the gap between rows gap_prev / gap_next of the engine's anchor table, on side gap_side (include/parsnp_mum.h:
-    // pm_gap_ref): the engine can derive its rows itself.  gap_side < 0: not such a gap, the rows travel.
-    int32_t gap_prev = -1, gap_next = -1; int8_t gap_side = -1;
     bool same_as(const Region& o, size_t n) const;   // TRegion operator== (LCR.cpp:48-58)
 };
 
@@ -256,9 +253,6 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     double alg_bytes = 0;   // sum over the regions sent to the engine of (m/4 + 16 m + 16 n) per query genome
     double alg_bytes_query = 0;    // ... of which the query pieces (m/2): the one coalesced stream that reaches the fabric
     double alg_bytes_kernel = 0;   // the same sum of what THIS engine's event search must move: (m + n)/2 + 64 B per sampled K-mer (run_batch)
-    long gap_requests = 0;  // regions whose rows the engine derived from its anchor table (pm_multi_mum_batch_gaps)
-    long layout_images = 0; // layouts delivered by the engine as an image (pm_layout_image) instead of marked by the host
-    long spec_regions = 0, spec_hits = 0;   // seed regions the engine computed ahead (pm_multi_mum_batch_spec), and how many of them the recursion asked for
     long finder_calls = 0, finder_regions = 0, regions_processed = 0, cache_hits = 0, cache_misses = 0, spec_rounds = 0;
     // device-side phase times (HIP events, pm_last_timing): summed over every engine call of the step, and of the
     // anchor call alone (the one launch that sees whole genomes)
@@ -278,16 +272,10 @@ struct AlignerMemory {
     Arena<int32_t> irows;                    // MUM start rows
     Arena<uint8_t> brows;                    // MUM strand rows
     std::vector<Bitmap> layout;              // the run's mumlayout: storage kept mapped across runs, cleared per run
-    // the other set of the pair.  When the engine delivers the layout of the anchors as an image (pm_layout_image) the run
-    // continues on bitmaps attached to that image, and the set it started on -- a few thousand marks of the flagged candidates,
-    // taken back -- is all zero again: the next run starts on it without clearing 125 MB (spare_zero)
-    std::vector<Bitmap> spare;
-    bool spare_zero = false;
     bool layout_clean = false;               // `layout` holds the sentinels and nothing else: the run that used it never wrote to it (the resident route)
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
     std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
     std::vector<Mum> pool_store, candidates;         // storage of Aligner::pool / validate_parallel's candidate records between runs
-    std::vector<int32_t> mum_minsize;                // minimum MUM length by shortest region length (start_speculation)
     struct PerThread { Arena<long> rows; Arena<int32_t> irows; Arena<uint8_t> brows; std::vector<long> scratch; };
     std::vector<std::unique_ptr<PerThread>> per_thread;   // rows written by the threads of the generation-parallel replay
     void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); brows.reset(); for (auto& t : per_thread) { t->rows.reset(); t->irows.reset(); t->brows.reset(); } }
@@ -334,13 +322,9 @@ public:
     bool neighbour_if_longer(const Mum& m, bool left, long q, Region* out, long* short_j, long* short_len, long* short_stop) const;
     Region new_region();
 
-    void wait_layout();           // the layout bitmaps are set up in the background (constructor); find_anchors() awaits them
-    void start_deferred_marks();  // (no-op unless validate_parallel put marks off)
-    void await_image();           // (no-op unless the layout is an image in flight)
+    void wait_layout();           // the layout bitmaps are set up in the background (constructor); the first reader awaits them
     enum : uint8_t { kJoin = 0, kClose = 1, kPass = 2 };
     uint8_t judge_pair(const Mum& nt, const Mum& back) const;     // chain()'s test of a MUM against the open chain's last MUM
-    void start_prejudge();        // the anchors' consecutive pairs, judged beside the recursion's first engine call
-    void finish_prejudge();
 
 private:
     struct Resident {
@@ -360,32 +344,10 @@ private:
     uint8_t resident_judge_rows(int cur, int back);
     void resident_fill_between();
     std::vector<std::future<void>> layout_ready_;
-    // marks of the anchors' clean candidates that were put off (validate_parallel): start_deferred_marks() sets them in the
-    // background, wait_layout() starts them if nobody has and joins -- every reader of the layout goes through it
-    struct DeferredMarks { const int32_t* rows = nullptr; std::vector<int32_t> length; std::vector<uint8_t> state; bool pending = false; } deferred_;
-    void mark_stripe(size_t j0, size_t j1);     // the put-off marks of genomes [j0, j1)
-    std::future<void> prejudge_;
     // set by validate_parallel for the list it accepted into an EMPTY layout (the anchor call): in every genome the accepted
     // MUMs lie in list order, one after the other without overlap -- then the marked base next to a MUM is its list
     // neighbour's, and find_anchors() derives the seed regions from the rows instead of walking bitmaps
     bool anchors_ordered_ = false;
-    bool image_pending_ = false;              // the layout is an image in flight (pm_layout_image): wait_layout() awaits it
-    // validate_parallel's request for that image, made by a helper thread; settle_image_ask() takes the answer
-    struct MarkSpan { int32_t j, a, len; };               // genome, start, length
-    struct ImageAsk {
-        int rc = PM_EINVAL; uint64_t* image = nullptr; std::string error;
-        std::vector<uint8_t> accept; std::vector<int32_t> extra_start, extra_len; std::vector<int64_t> nbits;
-        std::vector<int32_t> clear_start, clear_len;       // (an image asked for ahead) rows the engine marked and the host refused
-        std::vector<std::vector<MarkSpan>> marked_now;     // every mark the flagged candidates needed, per thread
-    };
-    std::shared_ptr<ImageAsk> image_ask_data_;
-    std::future<void> image_ask_;
-    void settle_image_ask();
-    void adopt_image(std::shared_ptr<ImageAsk> a);
-    void ask_early_image(const Raw& raw);
-    uint64_t* early_image_ = nullptr;        // the image asked for before the validation of the anchors (ask_early_image)
-    std::vector<int64_t> early_nbits_;
-    std::shared_ptr<ImageAsk> image_fix_;    // ... and what await_image() has to put right in it
     std::vector<int> judged_pred_;            // chain(): predecessor against which a MUM was last judged, and the verdict
     std::vector<uint8_t> judged_verdict_;
     pm_session* session_;
@@ -398,22 +360,11 @@ private:
     // region is a single unclamped chunk, else rows in req_rows_)
     struct Request {
         const long* start; const long* len; int32_t minsize; long ref_ini; uint64_t hash; bool plain = false;   // plain: the rows are the region's own (one unclamped chunk)
-        int32_t gap_prev = -1, gap_next = -1; int8_t gap_side = -1;      // (plain requests) the region's place in the anchor table, see Region
     };
     void chunk_requests(const Region& r, int minsize, std::vector<Request>* out);   // the p-chunk loop, :1519-1547
     void run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out, bool rows = false);   // rows: every request is its region (plain)
     void unpack_result(pm_result* res, size_t nregions, bool rows, std::vector<Raw>* out);
-    // the recursion's first batch computed beside the anchors' validation (aligner.cpp: start_speculation)
-    void start_speculation(int64_t table, int64_t rows);
-    void take_speculation();
-    std::future<pm_result*> spec_;
-    std::vector<int32_t> spec_at_;            // [2 * row + side]: the region of the batch computed ahead that lies left (0) / right (1) of that row, or -1
-    std::vector<pm_gap_ref> spec_refs_;
-    int64_t spec_rows_ = 0;                   // rows of the anchor table the batch was derived from
-    std::vector<int32_t> spec_min_;
-    std::vector<Raw> spec_raw_;
     int rows_mode_ = -1; bool rows_supported_ = true;     // pm_session_rows: 0 (sp, fwd), 1 MUM rows, 2 resident; -1: as an earlier run of the session left it
-    int64_t anchor_table_ = 0;         // id of the engine's resident anchor table that Mum::row / Region::gap_* refer to (0: none)
     bool timing_first_call_ = false;
     void collect_engine_timing();
     std::vector<std::shared_ptr<pm_result>> kept_results_;   // results whose row blocks hold the rows of accepted MUMs

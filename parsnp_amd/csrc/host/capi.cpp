@@ -59,7 +59,7 @@ const char* pc_step(pc_run* r) {
       << s.cache_misses << ", \"spec_rounds\": " << s.spec_rounds << ", \"mums_found\": " << (s.mums_found ? "true" : "false")
       << ", \"host_split_s\": {\"validate\": " << s.host.t_validate << ", \"neighbour\": " << s.host.t_neighbour << ", \"key\": " << s.host.t_key
       << ", \"sweep\": " << s.host.t_sweep << ", \"replay\": " << s.host.t_replay << ", \"sort\": " << s.host.t_sort << ", \"unpack\": " << s.host.t_unpack << ", \"pack\": " << s.host.t_pack << "}"
-      << ", \"gap_requests\": " << s.host.gap_requests << ", \"layout_images\": " << s.host.layout_images << ", \"spec_regions\": " << s.host.spec_regions << ", \"spec_hits\": " << s.host.spec_hits << ", \"h2d_bytes\": " << (long long)s.h2d_bytes << ", \"d2h_bytes\": " << (long long)s.d2h_bytes << ", \"resident\": " << s.host.resident << ", \"resident_retry\": " << s.host.resident_retry << ", \"tie_fallbacks\": " << s.host.tie_fallbacks << ", \"literal_iterations\": " << s.host.literal_iterations;
+      << ", \"h2d_bytes\": " << (long long)s.h2d_bytes << ", \"d2h_bytes\": " << (long long)s.d2h_bytes << ", \"resident\": " << s.host.resident << ", \"resident_retry\": " << s.host.resident_retry << ", \"tie_fallbacks\": " << s.host.tie_fallbacks << ", \"literal_iterations\": " << s.host.literal_iterations;
     for (int which = 0; which < 2; which++) {
         o << ", \"" << (which ? "anchor_ms" : "engine_ms") << "\": {";
         const auto& v = which ? s.anchor_ms : s.engine_ms;

@@ -52,10 +52,14 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
     std::vector<Request> reqs;
     chunk_requests(whole, minsize, &reqs);
     if (reqs.size() != 1 || !reqs[0].plain) { res_.why = "chunked reference"; return false; }      // (p): the p-loop is the host route's
+    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    double tl = now_s();
+    auto lap = [&](const char* what) { if (dbg) { const double t = now_s(); fprintf(stderr, "[resident anchors] %-14s %.4f s\n", what, t - tl); tl = t; } };
     resident_try_ = true;
     std::vector<Raw> raw;
     run_batch(reqs, &raw, true);
     resident_try_ = false;
+    lap("search");
     Raw& a = raw[0];
     const int64_t table = pm_result_table_id(a.owner.get());
     const bool kept = table != 0 && pm_result_store_base(a.owner.get()) == 0;      // the rows stayed on the device
@@ -68,6 +72,7 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
         if (rc != PM_OK && rc != PM_EAGAIN) engine_error("validation of the anchors on the device failed", rc);
         timing_first_call_ = false; collect_engine_timing();
         stats.t_validate += now_s() - ts;
+        lap("settle");
     }
     if (rc != PM_OK) {
         // not this list (short: no anchor table; or too many rows overlapping earlier ones): the host route, from the same result
@@ -102,6 +107,7 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
     }
     stats.parallel_candidates += (long)a.count;
     stats.regions_processed++;
+    lap("records");
     // seed regions: both neighbours of every anchor, longer than q in every genome (:2150-2172)
     const double tn = now_s();
     int64_t nreg = 0;
@@ -129,6 +135,7 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
         res_.gen_info.push_back(ri[i]); res_.gen_id.push_back(rid[i]);
     }
     stats.t_neighbour += now_s() - tn;
+    lap("seeds");
     return true;
 }
 

@@ -25,12 +25,12 @@ core = os.path.join(ROOT, "oracle", "_ref", "parsnp_core_oracle")
 os.environ.update(PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_NEIGHBOURS="1")
 if os.environ.get("PARSNP_FUZZ_CORE") == "hip":
     core = os.path.join(ROOT, "parsnp_amd", "bin", "parsnp_core_hooks")      # the product's sources with the test hooks compiled in
-    os.environ.update(PM_DIRTY_MIN="2", PARSNP_PREJUDGE_MIN="2")
+    os.environ.update(PM_DIRTY_MIN="2")
 if os.environ.get("PARSNP_FUZZ_CORE") == "emu":
     # the host code over the kernel emulation (tests/emu/parsnp_core_emu, built by the test suite's `emu` fixture): the routes
     # that need the engine's anchor table -- requests by reference, the batch computed ahead, the layout image -- on the CPU
     core = os.path.join(ROOT, "tests", "emu", "parsnp_core_emu")
-    os.environ.update(PM_DIRTY_MIN="2", PARSNP_PREJUDGE_MIN="2", PARSNP_CHECK_ZERO="1")
+    os.environ.update(PM_DIRTY_MIN="2", PARSNP_CHECK_ZERO="1")
 first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (24, 160)
 n_big = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 bad = []

@@ -30,11 +30,11 @@ EOF
 bad=0
 for name in pop6x200k rearr6x300k; do
     want=$(python -c "import json; print(json.load(open('$REPO/tests/golden/e2e.json'))['$name']['xmfa_md5'])")
-    for route in "DEFAULT=1" "PARSNP_LATE_IMAGE=1" "PARSNP_HOST_MARKS=1" "PARSNP_NO_SPECULATIVE_SEEDS=1" "PARSNP_SEQUENTIAL_REPLAY=1"; do
+    for route in "DEFAULT=1" "PM_FLAGGED_DIV=1" "PARSNP_NO_RESIDENT=1" "PARSNP_NO_RESIDENT=1 PARSNP_SEQUENTIAL_REPLAY=1"; do
         for san in asan tsan; do
             cd $W/$name/out; rm -f parsnpAligner.xmfa
             extra=""; [ $san = tsan ] && extra="OMP_THREAD_LIMIT=1"
-            env $route $extra PM_DIRTY_MIN=16 PARSNP_PARALLEL_MIN=16 PARSNP_PREJUDGE_MIN=16 PARSNP_CHECK_ZERO=1 ASAN_OPTIONS=detect_leaks=0 TSAN_OPTIONS=halt_on_error=0 \
+            env $route $extra PM_DIRTY_MIN=16 PARSNP_PARALLEL_MIN=16 PARSNP_CHECK_ZERO=1 ASAN_OPTIONS=detect_leaks=0 TSAN_OPTIONS=halt_on_error=0 \
                 $W/steps_$san ../run.ini 3 > $W/log.txt 2>&1 || { echo "FAILED rc: $name $route $san"; bad=1; }
             n=$(grep -c "runtime error\|AddressSanitizer\|WARNING: ThreadSanitizer" $W/log.txt || true)
             got=$(md5sum parsnpAligner.xmfa | cut -d' ' -f1)

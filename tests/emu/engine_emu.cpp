@@ -21,8 +21,6 @@ struct HostBackend {
     void d2h(void* d, const void* s, size_t n) { bytes_d2h += n; memcpy(d, s, n); }
     void d2h_async(void* d, const void* s, size_t n) { bytes_d2h += n; memcpy(d, s, n); }
     void d2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
-    void d2h_side(void* d, const void* s, size_t n) { bytes_d2h += n; memcpy(d, s, n); }
-    void side_wait() {}
     void bind() {}
     void* pinned_alloc(size_t n) { return malloc(n ? n : 1); }
     void pinned_free(void* p) { ::free(p); }

@@ -17,7 +17,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < steps; i++) rep = run.step();
     bool note = false;
     run.write(&note);
-    fprintf(stderr, "steps_main: %d steps, %ld anchors, %ld MUMs, %ld LCBs, %ld layout image(s), %ld regions computed ahead (%ld asked for)\n", steps, rep.anchors, rep.mums, rep.lcbs,
-            rep.host.layout_images, rep.host.spec_regions, rep.host.spec_hits);
+    fprintf(stderr, "steps_main: %d steps, %ld anchors, %ld MUMs, %ld LCBs, resident route %ld (left and repeated on the host route: %ld)\n", steps, rep.anchors, rep.mums, rep.lcbs,
+            rep.host.resident, rep.host.resident_retry);
     return 0;
 }

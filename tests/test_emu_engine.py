@@ -115,11 +115,12 @@ def test_end_to_end_with_emulated_engine(emu, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["rearr6x300k", "pop6x200k"])
-@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows", "host_order", "mark_first"])
+@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows"])
 def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
-    """MUM rows (start, strand, flags) and the cheap overlap flags built by the engine (CompactCandidates, Dirty* kernels)
-    feed the threaded anchor validation; thresholds lowered so that the small sets take that route.  The variants switch
-    the overlap test / the row construction back to the host: same bytes either way."""
+    """the HOST route (what a step falls back to when the resident route does not apply): MUM rows (start, strand, flags) and the
+    cheap overlap flags built by the engine (CompactCandidates, Dirty* kernels) feed the threaded anchor validation; thresholds
+    lowered so that the small sets take that route.  The variants switch the overlap test / the row construction back to the
+    host: same bytes either way."""
     r, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
     env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_NO_RESIDENT="1")      # (the host route: the resident route has its own test below)
@@ -127,11 +128,6 @@ def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":
         env["PARSNP_NO_DEVICE_ROWS"] = "1"
-    if variant == "host_order":             # the list order from a pass over the rows instead of the engine's PM_ROW_EARLY bits
-        env["PARSNP_HOST_ORDER"] = "1"
-    if variant == "mark_first":             # all marks before the flagged candidates (nothing put off)
-        env["PARSNP_MARK_FIRST"] = "1"
-    env["PARSNP_DEBUG_TIMERS"] = "1"
     out = str(tmp_path / "out")
     rc, _ = driver.run_core(emu[1], rp, qs, out, env=env, threads=4)
     err = open(os.path.join(out, "parsnp-aligner.err")).read()
@@ -139,8 +135,6 @@ def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
     want = test_host_logic.E2E[name]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == want["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
-    if name == "pop6x200k":                 # a collinear set: the marks are put off unless told otherwise
-        assert ("put off" in err) == (variant != "mark_first")
 
 
 @pytest.mark.parametrize("name,flagged_div,expect", [("viral50", 8, "resident"), ("pop6x200k", 8, "resident"), ("pop12x400k", 8, "resident"), ("pop12x400k", 1, "resident"),

@@ -97,7 +97,7 @@ def test_fuzz_resident_route(emu, tmp_path, monkeypatch, seed):
     of its rows overlap earlier ones (PM_FLAGGED_DIV=1: the trimming and the in-order settling of tangled rows at work on
     rearranged genomes).  Where the reference's order would show the route is left and the step repeated on the host route:
     the bytes must be the reference's either way."""
-    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_PREJUDGE_MIN="2", PARSNP_CHECK_ZERO="1", PM_FLAGGED_DIV="1" if seed % 2 else "8").items():
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PM_FLAGGED_DIV="1" if seed % 2 else "8").items():
         monkeypatch.setenv(k, v)
     ref, gs, kw, contigs = random_case(seed)
     if kw.get("threads", 1) < 2:
@@ -109,12 +109,12 @@ def test_fuzz_resident_route(emu, tmp_path, monkeypatch, seed):
 
 
 @pytest.mark.parametrize("seed", range(16))
-def test_fuzz_anchor_table_routes(emu, tmp_path, monkeypatch, seed):
-    """the same side by side for the host code over the kernel emulation, threaded, with the thresholds of the long-list routes
-    lowered so that these small sets take what needs the engine's resident anchor table: requests by reference, the recursion's
-    first batch computed ahead, the layout image (asked for before the validation, its corrections) -- scripts/fuzz_campaign.py
-    with PARSNP_FUZZ_CORE=emu is the long form (684 sets in round 3)"""
-    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_PREJUDGE_MIN="2", PARSNP_CHECK_ZERO="1", PARSNP_NO_RESIDENT="1").items():
+def test_fuzz_host_route_over_device_rows(emu, tmp_path, monkeypatch, seed):
+    """the same side by side for the HOST route over the kernel emulation (PARSNP_NO_RESIDENT: what a step falls back to),
+    threaded, with the thresholds of its long-list paths lowered so that these small sets take them: MUM rows and overlap flags
+    from the engine, threaded validation, generation-parallel replay -- scripts/fuzz_campaign.py with PARSNP_FUZZ_CORE=emu is
+    the long form"""
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PARSNP_NO_RESIDENT="1").items():
         monkeypatch.setenv(k, v)
     ref, gs, kw, contigs = random_case(seed)
     if kw.get("threads", 1) < 2:
@@ -131,7 +131,7 @@ def test_fuzz_resident_route_on_gpu(tmp_path, monkeypatch, seed):
     """the resident route's KERNELS (store_kernels.h: wave64 code the CPU suite only runs through its one-thread emulation) side
     by side with the reference binary: the product's sources with the test hooks compiled in, thresholds lowered so that the
     small sets take the route, every other seed with every anchor list let onto it (PM_FLAGGED_DIV=1)"""
-    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_PREJUDGE_MIN="2", PM_FLAGGED_DIV="1" if seed % 2 else "8").items():
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PM_FLAGGED_DIV="1" if seed % 2 else "8").items():
         monkeypatch.setenv(k, v)
     side_by_side(CORE_HOOKS_BIN, seed, tmp_path, big=seed >= 32)
 

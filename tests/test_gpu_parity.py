@@ -224,31 +224,22 @@ def test_parsnp_core_replay_modes_threaded(libs, tmp_path, name, mode):
 
 
 @pytest.mark.parametrize("name", ["rearr6x300k", "poprearr10x400k", "pop20x1m"])
-@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows", "seeds_by_reference", "all_rows_travel", "host_order", "mark_first"])
+@pytest.mark.parametrize("variant", ["device_rows_and_flags", "host_overlap", "host_rows"])
 def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant):
-    """the MUM rows, the cheap overlap flags and the list-order bits come from the device (CompactCandidates,
-    DirtyExtent/Prefix/Mark) and feed the threaded anchor validation in place, and the recursion's seed regions are derived on
-    the device from the resident anchor table and searched beside the validation of the anchors; switching any of them back to the host, or marking the layout before instead of
-    after the flagged candidates, must not change a byte.  (parsnp_core_hooks = the product's sources with the test hooks of
-    csrc/host/hooks.h compiled in; the shipped binary ignores these switches.)"""
+    """the HOST route (what a step falls back to when the resident route does not apply): the MUM rows, the cheap overlap flags
+    and the list-order bits come from the device (CompactCandidates, DirtyExtent/Prefix/Mark) and feed the threaded anchor
+    validation in place; switching either back to the host must not change a byte.  (parsnp_core_hooks = the product's sources
+    with the test hooks of csrc/host/hooks.h compiled in; the shipped binary ignores these switches.)"""
     if name == "poprearr10x400k":
         rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
     else:
         r, gs = synth.make(name)
         rp, qs = synth.write_set(str(tmp_path / "in"), r, gs); kw = {}
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_PREJUDGE_MIN="8", PARSNP_NO_RESIDENT="1")      # (routes of the HOST route)
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_NO_RESIDENT="1")      # (routes of the HOST route)
     if variant == "host_overlap":
         env["PARSNP_HOST_OVERLAP"] = "1"
     if variant == "host_rows":
         env["PARSNP_NO_DEVICE_ROWS"] = "1"
-    if variant == "seeds_by_reference":     # no batch computed ahead beside the validation: the seed regions go as references into the anchor table
-        env["PARSNP_NO_SPECULATIVE_SEEDS"] = "1"
-    if variant == "all_rows_travel":        # ... nor that: every row of every seed region travels
-        env["PARSNP_NO_SPECULATIVE_SEEDS"] = "1"; env["PARSNP_NO_GAP_REQUESTS"] = "1"
-    if variant == "host_order":             # the list order from a pass over the rows instead of the device's PM_ROW_EARLY bits
-        env["PARSNP_HOST_ORDER"] = "1"
-    if variant == "mark_first":             # all marks before the flagged candidates (nothing put off)
-        env["PARSNP_MARK_FIRST"] = "1"
     env["PARSNP_DEBUG_TIMERS"] = "1"
     out = str(tmp_path / "out")
     rc, _ = driver.run_core(CORE_HOOKS_BIN, rp, qs, out, env=env, threads=8, **kw)
@@ -256,8 +247,6 @@ def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant
     assert rc == 0, err[-2000:]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
-    if name == "pop20x1m":                  # a collinear set: the marks are put off unless told otherwise
-        assert ("put off" in err) == (variant != "mark_first")
 
 
 @pytest.mark.parametrize("name,flagged_div,expect", [("viral50", 8, "resident"), ("pop6x200k", 8, "resident"), ("pop12x400k", 8, "resident"), ("pop12x400k", 1, "resident"), ("pop20x1m", 8, "resident"),

@@ -104,15 +104,15 @@ def test_in_order_replay_same_result(cpu_checkers, tmp_path, name, threads):
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"], tag
 
 
-@pytest.mark.parametrize("switch", ["PARSNP_ORDERED_FLAGGED", "PARSNP_CHAIN_TWICE", "PARSNP_SYNC_LAYOUT", "PARSNP_EXACT_OVERLAP", "PARSNP_NO_PREJUDGE"])
+@pytest.mark.parametrize("switch", ["PARSNP_ORDERED_FLAGGED", "PARSNP_CHAIN_TWICE", "PARSNP_EXACT_OVERLAP"])
 @pytest.mark.parametrize("name", ["poprearr10x400k", "draft8x300k"])
 def test_plain_variants_of_the_host_shortcuts(cpu_checkers, tmp_path, name, switch):
     """every host shortcut has a switch that takes the plain route instead -- flagged candidates all in candidate order,
-    the second chaining pass always run, the layout cleared before anything else, the overlap flags from scratch
-    bitmaps, no chaining verdict worked out ahead of chain() -- and the bytes must not change (the default route is pinned by the goldens in the other tests)"""
+    the second chaining pass always run, the overlap flags from scratch bitmaps -- and the bytes must not change (the default
+    route is pinned by the goldens in the other tests)"""
     rp, qs, kw = harsh_inputs(name, str(tmp_path))
     out = str(tmp_path / "out")
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PARSNP_PREJUDGE_MIN="8")   # the shortcuts at work on small sets
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2")   # the shortcuts at work on small sets
     env[switch] = "1"
     rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, threads=4, **kw)
     assert rc == 0
@@ -208,27 +208,18 @@ def test_streamed_and_plain_records_agree(cpu_checkers, tmp_path, name, plain):
         assert "in 3 group(s)" in err
 
 
-@pytest.mark.parametrize("first", [False, True])
 @pytest.mark.parametrize("name", ["pop6x200k", "poprearr10x400k", "messy", "pchunk", "draft8x300k"])
-def test_put_off_marks_same_result(cpu_checkers, tmp_path, name, first):
-    """into an empty layout the marks of the clean candidates are put off (set by background tasks beside the recursion's
-    first engine call) when the accepted clean candidates lie in list order in every genome; the flagged candidates, which
-    read the bits of their own intervals, get the marks they can meet by bisection first.  PARSNP_MARK_FIRST=1: the plain
-    order (all marks, then the flagged candidates).  Same bytes either way; a collinear set must take the put-off route."""
+def test_threaded_validation_of_short_lists(cpu_checkers, tmp_path, name):
+    """the threaded validation of a candidate list (clean candidates settled and marked by genome stripes, flagged ones against
+    those marks -- side by side where they meet no other flagged candidate, in list order where they do) on lists far shorter
+    than its production threshold: the reference's bytes"""
     rp, qs, kw = harsh_inputs(name, str(tmp_path))
     out = str(tmp_path / "out")
-    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PARSNP_DEBUG_TIMERS="1")
-    if first:
-        env["PARSNP_MARK_FIRST"] = "1"
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2")
     rc, _ = driver.run_core(cpu_checkers, rp, qs, out, env=env, threads=4, **kw)
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
-    err = open(os.path.join(out, "parsnp-aligner.err")).read()
-    if first:
-        assert "put off" not in err
-    elif name == "pop6x200k":
-        assert "put off" in err
 
 
 MUMI = json.load(open(os.path.join(G, "mumi.json")))
