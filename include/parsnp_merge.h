@@ -27,6 +27,12 @@ extern "C" {
 int parsnp_partition_merge(int n_xmfas, const char* const* xmfa_paths, const char* out_path, long min_interval_size, int threads,
                            int keep_trimmed, long* clusters, long* sequences, long* ref_bases, char* err, long err_cap);
 
+/* Where the last merge of this process could depend on the insertion aligner (the reference re-aligns runs of columns that are
+ * insertions relative to the reference with spoa.poa, partition.py:386; this library with the gap aligner of the XMFA writer):
+ * runs of such columns; those that collected bases from more than one sequence (a single sequence is its own alignment either
+ * way); those among them whose sequences are not all the same string; and the merged columns of the shared runs. */
+void parsnp_partition_merge_insertions(long* runs, long* shared, long* shared_diverse, long* shared_columns);
+
 #ifdef __cplusplus
 }
 #endif

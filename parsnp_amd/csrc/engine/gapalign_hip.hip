@@ -752,7 +752,10 @@ std::string g_err;
 int32_t* g_dbg = nullptr; int64_t g_dbg_slots = 0;
 int32_t* g_dbg_dev = nullptr;      // PM_GAP_DEBUG=2: the markers live in device memory (cheap to write), peeked through a copy on another stream
 int fail(int code, const std::string& m) { std::lock_guard<std::mutex> lk(g_err_mu); g_err = m; return code; }
-std::once_flag g_tables_once;
+// the letter table is uploaded once per device; the flag is set only after the upload succeeded (a failed call must not leave
+// later calls of the process aligning with an uninitialised table)
+std::mutex g_tables_mu;
+bool g_tables_ready[64] = {false};
 }  // namespace
 
 extern "C" const char* pm_gap_last_error(void) {
@@ -821,7 +824,10 @@ extern "C" int pm_gap_align_groups(int device, int64_t n_jobs, const int32_t* n_
     auto release = [&]() { for (void* p : owned) (void)hipFree(p); owned.clear(); if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; } };
     {
         hipError_t table_err = hipSuccess;
-        std::call_once(g_tables_once, [&] {
+        int cur_dev = 0;
+        (void)hipGetDevice(&cur_dev);
+        std::lock_guard<std::mutex> lk(g_tables_mu);
+        if (cur_dev < 0 || cur_dev >= 64 || !g_tables_ready[cur_dev]) {
             uint8_t letter[256];
             memset(letter, 255, sizeof letter);
             const char* res = "ACGT";
@@ -831,7 +837,8 @@ extern "C" int pm_gap_align_groups(int device, int64_t n_jobs, const int32_t* n_
             for (int i = 0; i < 12; i++) { letter[(uint8_t)wild[i]] = (uint8_t)(4 + i); letter[(uint8_t)(wild[i] + 32)] = (uint8_t)(4 + i); }
             letter[(uint8_t)'-'] = letter[(uint8_t)'.'] = 16;
             table_err = hipMemcpyToSymbol(HIP_SYMBOL(c_letter), letter, 256);
-        });
+            if (table_err == hipSuccess && cur_dev >= 0 && cur_dev < 64) g_tables_ready[cur_dev] = true;
+        }
         GA_CHECK(table_err);
     }
     // jobs the device takes, longest first (the cost of one alignment grows with the square of its width)

@@ -320,6 +320,14 @@ void record_header(int name, long start, long end, int strand, long cluster, lon
 
 struct Part { XFile x; std::vector<TBlock> trimmed; std::map<int, int> new_index; };
 
+// Where the merged alignment can depend on the insertion aligner (the reference re-aligns insertion runs with
+// spoa.poa, partition.py:386; here they go through the gap aligner of the XMFA writer): counted per merge.
+//   runs            runs of merged columns in which some partition's reference row holds a gap
+//   shared          ... that collected bases from MORE THAN ONE sequence (one sequence is its own alignment either way)
+//   shared_diverse  ... whose sequences are not all the same string (identical strings align column by column in any aligner)
+//   shared_columns  merged columns of the shared runs
+std::atomic<long> g_ins_runs{0}, g_ins_shared{0}, g_ins_shared_diverse{0}, g_ins_shared_columns{0};
+
 // merge_blocks, :320-433: the same trimmed cluster of every partition -> one block.  Columns in which every partition's
 // reference row holds a base are concatenated partition after partition (the reference row from the first); a run of
 // columns in which some reference row holds a gap is an insertion: its bases are collected per sequence and aligned
@@ -361,6 +369,13 @@ void merge_cluster(const std::vector<Part>& parts, size_t cluster, std::string* 
         size_t width = 0;
         if (!ok) { aligned = seqs; }
         for (const std::string& s : aligned) width = std::max(width, s.size());
+        g_ins_runs++;
+        if (seqs.size() > 1) {
+            g_ins_shared++; g_ins_shared_columns += (long)width;
+            bool same = true;
+            for (const std::string& s : seqs) same = same && s == seqs[0];
+            if (!same) g_ins_shared_diverse++;
+        }
         if (!ok) for (std::string& s : aligned) s.append(width - s.size(), '-');
         for (size_t k = 0; k < gap_order.size(); k++) rows[gap_order[k]].seq += aligned[k];
         for (size_t r = 0; r < rows.size(); r++) if (!in_gap_set[r]) rows[r].seq.append(width, '-');
@@ -428,13 +443,14 @@ void write_all(int fd, const std::string& s) {
 
 }  // namespace
 
-struct MergeStats { long clusters = 0, sequences = 0, intervals = 0, ref_bases = 0; };
+struct MergeStats { long clusters = 0, sequences = 0, intervals = 0, ref_bases = 0, ins_runs = 0, ins_shared = 0, ins_shared_diverse = 0, ins_shared_columns = 0; };
 
 // xmfas: the partitions' alignments (parsnp_core's XMFA of every good partition, in chunk-label order).  Writes the
 // merged alignment to out_path and, with keep_trimmed, <xmfa>.trimmed next to every input (trim_single_xmfa, :586-618).
 MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::string& out_path, long min_interval_size, int threads, bool keep_trimmed) {
     if (xmfas.empty()) throw std::runtime_error("no partition to merge");
     if (threads < 1) threads = 1;
+    g_ins_runs = 0; g_ins_shared = 0; g_ins_shared_diverse = 0; g_ins_shared_columns = 0;
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double tl = wall_s();
     auto lap = [&](const char* what) { if (dbg) { const double t = wall_s(); fprintf(stderr, "[merge] %-12s %.3f s\n", what, t - tl); tl = t; } };
@@ -457,12 +473,12 @@ MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::str
         Part& pt = parts[(size_t)p];
         const long nb = (long)pt.x.blocks.size();
         std::vector<std::vector<TBlock>> per_block((size_t)nb);
-        std::vector<std::string> errs((size_t)threads + 1);
+        std::vector<std::string> errs((size_t)nb);      // one slot per block: chunks run side by side
         const long chunk = 16, nchunks = (nb + chunk - 1) / chunk;
         parallel_items(nchunks, threads, [&](long c) {
             for (long b = c * chunk; b < std::min(nb, (c + 1) * chunk); b++) {
                 try { trim_lcb(pt.x.blocks[(size_t)b], inter, 1, &per_block[(size_t)b]); }
-                catch (const std::exception& e) { errs[(size_t)(c % (threads + 1))] = e.what(); }
+                catch (const std::exception& e) { errs[(size_t)b] = e.what(); }
             }
         });
         for (const std::string& e : errs) if (!e.empty()) throw std::runtime_error(pt.x.path + ": " + e);
@@ -473,10 +489,11 @@ MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::str
     const size_t nclusters = parts[0].trimmed.size();
     lap("trim");
     if (keep_trimmed) {
+        std::vector<std::string> werr((size_t)np);
         parallel_items(np, threads, [&](long p) {
             const Part& pt = parts[(size_t)p];
             FILE* f = fopen((pt.x.path + ".trimmed").c_str(), "w");
-            if (!f) return;
+            if (!f) { werr[(size_t)p] = "cannot write " + pt.x.path + ".trimmed"; return; }
             fputs(pt.x.header_text.c_str(), f);
             std::string text, seq;
             for (size_t c = 0; c < pt.trimmed.size(); c++) {
@@ -488,10 +505,11 @@ MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::str
                     wrap80(seq, &text);
                 }
                 text.append("=\n");
-                fwrite(text.data(), 1, text.size(), f);
+                if (fwrite(text.data(), 1, text.size(), f) != text.size()) { werr[(size_t)p] = "short write to " + pt.x.path + ".trimmed"; break; }
             }
-            fclose(f);
+            if (fclose(f) != 0 && werr[(size_t)p].empty()) werr[(size_t)p] = "cannot finish " + pt.x.path + ".trimmed";
         });
+        for (const std::string& e : werr) if (!e.empty()) throw std::runtime_error(e);
     }
     if (keep_trimmed) lap("write trimmed");
     // combined header (combine_header_info, :245-292): a (file, header) pair seen before -- the reference, present in
@@ -530,6 +548,7 @@ MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::str
     }
     close(fd);
     lap("merge + write");
+    st.ins_runs = g_ins_runs; st.ins_shared = g_ins_shared; st.ins_shared_diverse = g_ins_shared_diverse; st.ins_shared_columns = g_ins_shared_columns;
     return st;
 }
 
@@ -537,6 +556,13 @@ MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::str
 
 // C entry (include/parsnp_merge.h): what the reference driver does between "Computing intersection of all partition
 // LCBs..." and the end of merge_xmfas (parsnp:1601-1615).  Returns 0, or 1 with a message in err.
+static long g_last_ins[4] = {0, 0, 0, 0};
+extern "C" void parsnp_partition_merge_insertions(long* runs, long* shared, long* shared_diverse, long* shared_columns) {
+    if (runs) *runs = g_last_ins[0];
+    if (shared) *shared = g_last_ins[1];
+    if (shared_diverse) *shared_diverse = g_last_ins[2];
+    if (shared_columns) *shared_columns = g_last_ins[3];
+}
 extern "C" int parsnp_partition_merge(int n_xmfas, const char* const* xmfa_paths, const char* out_path, long min_interval_size, int threads,
                                       int keep_trimmed, long* clusters, long* sequences, long* ref_bases, char* err, long err_cap) {
     try {
@@ -546,6 +572,7 @@ extern "C" int parsnp_partition_merge(int n_xmfas, const char* const* xmfa_paths
         if (clusters) *clusters = st.clusters;
         if (sequences) *sequences = st.sequences;
         if (ref_bases) *ref_bases = st.ref_bases;
+        g_last_ins[0] = st.ins_runs; g_last_ins[1] = st.ins_shared; g_last_ins[2] = st.ins_shared_diverse; g_last_ins[3] = st.ins_shared_columns;
         return 0;
     } catch (const std::exception& e) {
         if (err && err_cap > 0) { strncpy(err, e.what(), (size_t)err_cap - 1); err[err_cap - 1] = 0; }

@@ -44,4 +44,8 @@ def merge_partitions(partition_xmfas, out_path, min_interval_size=10, threads=No
                                     C.byref(clusters), C.byref(sequences), C.byref(bases), err, len(err))
     if rc:
         raise RuntimeError("partition merge failed: " + err.value.decode(errors="replace"))
-    return dict(clusters=clusters.value, sequences=sequences.value, ref_bases=bases.value)
+    ins = [C.c_long(0) for _ in range(4)]
+    lib.parsnp_partition_merge_insertions(*[C.byref(x) for x in ins])
+    # insertions: where the merged file could depend on the insertion aligner (SPOA in the reference)
+    return dict(clusters=clusters.value, sequences=sequences.value, ref_bases=bases.value,
+                insertions=dict(runs=ins[0].value, shared=ins[1].value, shared_diverse=ins[2].value, shared_columns=ins[3].value))

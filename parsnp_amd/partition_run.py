@@ -81,7 +81,7 @@ def run_partitioned(core_bin, ref, finalfiles, outdir, min_partition_size, rank=
         from . import merge as native_merge
         merged = native_merge.merge_partitions([os.path.join(p["dir"], "parsnpAligner.xmfa") for p in good], os.path.join(outdir, "parsnp.xmfa"),
                                                keep_trimmed=keep_trimmed)
-        merged = dict(clusters=merged["clusters"], sequences=merged["sequences"], ref_bases=merged["ref_bases"], xmfa=os.path.join(outdir, "parsnp.xmfa"))
+        merged = dict(clusters=merged["clusters"], sequences=merged["sequences"], ref_bases=merged["ref_bases"], insertions=merged["insertions"], xmfa=os.path.join(outdir, "parsnp.xmfa"))
     if merge and dist is not None and world > 1:      # every rank returns the same view
         box = [merged]
         dist.broadcast_object_list(box, src=0)

@@ -49,6 +49,12 @@ def config4_flow(core_bin, d, population_kw, part_size, n_parts, threads, golden
     assert len(parts) == n_parts and all(p["ok"] and p["queries"] == part_size for p in parts), [(p["index"], p["rc"]) for p in parts]
     m = res["merged"]
     say("config 4: partitions + merge %.1f s; %d clusters, %d sequences, %d reference bases" % (t2 - t1, m["clusters"], m["sequences"], m["ref_bases"]))
+    # where the merged file could depend on the insertion aligner (the reference: spoa.poa, partition.py:386): runs of
+    # insertion columns that collected bases from more than one sequence, and those whose sequences are not all one string
+    ins = m["insertions"]
+    say("config 4: insertion runs in the merge: %d, shared by several sequences: %d (%d merged columns), of those with differing sequences: %d"
+        % (ins["runs"], ins["shared"], ins["shared_columns"], ins["shared_diverse"]))
+    res["insertion_exposure"] = ins
     if golden:      # the driver's first chunk = the golden's partition 0
         x0 = os.path.join(parts[0]["dir"], "parsnpAligner.xmfa")
         assert xmfa_util.log_counters(os.path.join(parts[0]["dir"], "parsnpAligner.log")) == golden["log"]
