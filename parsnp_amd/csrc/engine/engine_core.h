@@ -573,40 +573,45 @@ public:
             be.d2h_async(out->spb.p, d_csp.p, 4 * nokz * nqz2);
             be.d2h_async(out->fwdb.p, d_cfwd.p, nokz * nqz2);
         } else {
-            ensure(d_csp, std::max<size_t>(nokz * ngz, 1)); ensure(d_cfwd, std::max<size_t>(nokz * ngz, 1)); ensure(d_cflags, std::max<size_t>(nokz, 1));
-            be.memset(d_cflags.p, 0, 4 * std::max<size_t>(nokz, 1));
-            be.launch("compact_candidates", (int64_t)ncand * ngen,
-                      CompactCandidates{scand, d_ok.p, d_okpos.p, ngen, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_starts.p, d_lens.p, d_glen,
-                                        d_creg.p, d_ck.p, d_clon.p, d_csp.p, d_cfwd.p, d_cflags.p});
-            if (nreg == 1 && nok >= dirty_min) {     // a long list of one region (the anchor call): the cheap overlap test on the device
-                const int64_t nblocks = (nok + kDirtyBlock - 1) / kDirtyBlock, groups = (ngen + 63) / 64;
-                ensure(d_bmax, (size_t)nblocks * ngz); ensure(d_bmin, (size_t)nblocks * ngz);
-                be.launch_wave("dirty_extent", nblocks * groups, DirtyExtent{d_csp.p, d_clon.p, d_cflags.p, nok, ngen, d_bmax.p, d_bmin.p});
-                be.launch_wave("dirty_prefix", groups, DirtyPrefix{nblocks, ngen, d_bmax.p, d_bmin.p});
-                ensure(d_dirty, nokz);
-                be.memset(d_dirty.p, 0, 4 * nokz);
-                be.launch_wave("dirty_mark", nblocks * groups, DirtyMark{d_csp.p, d_clon.p, nok, ngen, d_bmax.p, d_bmin.p, d_cflags.p, d_dirty.p});
-                be.launch("dirty_merge", nok, DirtyMerge{d_dirty.p, d_cflags.p});
-                out->dirty_known = true;
-            }
             // Resident mode (pm_session_rows(s, 2)): the rows of the anchor call, and of every search of regions of the region store,
-            // stay on the device as rows of the MUM store -- the host receives the per-row scalars only (flags, k, length)
+            // stay on the device as rows of the MUM store -- the host receives the per-row scalars only (flags, k, length).  The
+            // anchor call's rows are the session's anchor table (= rows [0, A) of the store) in either mode.  The compaction
+            // writes such rows straight into the store (a copy of the 60 MB anchor table is half a millisecond).
             const bool anchor_call = nreg == 1 && !gb && nok >= dirty_min;
             const bool keep_rows = resident && (anchor_call || from_store);
-            if (anchor_call || keep_rows) {      // (the anchor call: its rows are the session's anchor table = rows [0, A) of the store)
+            const bool to_store = anchor_call || keep_rows;
+            int32_t* p_start; uint8_t* p_strand; int32_t* p_lon; uint32_t* p_flags;
+            if (to_store) {
                 if (anchor_call) { ms_count = 0; rg_count = 0; layout_rows = -1; }
                 const size_t base = (size_t)ms_count, upto = base + nokz;
                 ensure_keep(d_anchor_start, std::max<size_t>(upto * ngz, 1), base * ngz); ensure_keep(d_ms_strand, std::max<size_t>(upto * ngz, 1), base * ngz);
                 ensure_keep(d_anchor_lon, std::max<size_t>(upto, 1), base); ensure_keep(d_anchor_flags, std::max<size_t>(upto, 1), base);
                 ensure_keep(d_ms_shift, std::max<size_t>(upto, 1), base); ensure_keep(d_ms_len, std::max<size_t>(upto, 1), base); ensure_keep(d_ms_state, std::max<size_t>(upto, 1), base);
-                be.d2d(d_anchor_start.p + base * ngz, d_csp.p, 4 * nokz * ngz);
-                be.d2d(d_ms_strand.p + base * ngz, d_cfwd.p, nokz * ngz);
-                be.d2d(d_anchor_lon.p + base, d_clon.p, 4 * nokz);
-                be.d2d(d_anchor_flags.p + base, d_cflags.p, 4 * nokz);
-                be.d2d(d_ms_len.p + base, d_clon.p, 4 * nokz);
-                if (nokz) { be.memset(d_ms_shift.p + base, 0, 4 * nokz); be.memset(d_ms_state.p + base, 0, nokz); }
+                p_start = d_anchor_start.p + base * ngz; p_strand = d_ms_strand.p + base * ngz; p_lon = d_anchor_lon.p + base; p_flags = d_anchor_flags.p + base;
                 out->store_base = (int64_t)base;
                 ms_count = (int64_t)upto;
+            } else {
+                ensure(d_csp, std::max<size_t>(nokz * ngz, 1)); ensure(d_cfwd, std::max<size_t>(nokz * ngz, 1)); ensure(d_cflags, std::max<size_t>(nokz, 1));
+                p_start = d_csp.p; p_strand = d_cfwd.p; p_lon = d_clon.p; p_flags = d_cflags.p;
+            }
+            if (nokz) be.memset(p_flags, 0, 4 * nokz);
+            be.launch("compact_candidates", (int64_t)ncand * ngen,
+                      CompactCandidates{scand, d_ok.p, d_okpos.p, ngen, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_starts.p, d_lens.p, d_glen,
+                                        d_creg.p, d_ck.p, p_lon, p_start, p_strand, p_flags});
+            if (nreg == 1 && nok >= dirty_min) {     // a long list of one region (the anchor call): the cheap overlap test on the device
+                const int64_t nblocks = (nok + kDirtyBlock - 1) / kDirtyBlock, groups = (ngen + 63) / 64;
+                ensure(d_bmax, (size_t)nblocks * ngz); ensure(d_bmin, (size_t)nblocks * ngz);
+                be.launch_wave("dirty_extent", nblocks * groups, DirtyExtent{p_start, p_lon, p_flags, nok, ngen, d_bmax.p, d_bmin.p});
+                be.launch_wave("dirty_prefix", groups, DirtyPrefix{nblocks, ngen, d_bmax.p, d_bmin.p});
+                ensure(d_dirty, nokz);
+                be.memset(d_dirty.p, 0, 4 * nokz);
+                be.launch_wave("dirty_mark", nblocks * groups, DirtyMark{p_start, p_lon, nok, ngen, d_bmax.p, d_bmin.p, p_flags, d_dirty.p});
+                be.launch("dirty_merge", nok, DirtyMerge{d_dirty.p, p_flags});
+                out->dirty_known = true;
+            }
+            if (to_store) {
+                be.d2d(d_ms_len.p + (ms_count - nok), p_lon, 4 * nokz);
+                if (nokz) { be.memset(d_ms_shift.p + (ms_count - nok), 0, 4 * nokz); be.memset(d_ms_state.p + (ms_count - nok), 0, nokz); }
                 if (anchor_call) {
                     anchor_table_rows = nok;
                     out->table_id = anchor_table_id = ++table_counter;
@@ -614,16 +619,17 @@ public:
             }
             be.mark("download");
             out->flagsb = pool->take(4 * nokz);
-            be.d2h_async(out->flagsb.p, d_cflags.p, 4 * nokz);
+            be.d2h_async(out->flagsb.p, p_flags, 4 * nokz);
             if (!keep_rows) {
                 out->startb = pool->take(4 * nokz * ngz); out->strandb = pool->take(nokz * ngz);
-                be.d2h_async(out->startb.p, d_csp.p, 4 * nokz * ngz);
-                be.d2h_async(out->strandb.p, d_cfwd.p, nokz * ngz);
+                be.d2h_async(out->startb.p, p_start, 4 * nokz * ngz);
+                be.d2h_async(out->strandb.p, p_strand, nokz * ngz);
             }
+            be.d2h_async(out->lonb.p, p_lon, 4 * nokz);
         }
+        if (!want_rows) be.d2h_async(out->lonb.p, d_clon.p, 4 * nokz);
         be.d2h_async(reg_h.data(), d_creg.p, 4 * nokz);
         be.d2h_async(out->kb.p, d_ck.p, 4 * nokz);
-        be.d2h_async(out->lonb.p, d_clon.p, 4 * nokz);
         be.mark(nullptr);
         be.sync();                                                         // round trip 4: the results
         for (size_t w = 0; w < nokz; w++) out->off[(size_t)reg_h[w] + 1]++;
@@ -648,7 +654,8 @@ public:
 
     void begin_store_call() { timing.clear(); last_events = last_rest = last_positions = last_candidates = last_accepted = 0; last_alg[0] = last_alg[1] = last_alg[2] = 0; }      // (counts of the last search travel with pm_last_timing)
     Store store_view() { return Store{d_anchor_start.p, d_ms_strand.p, d_anchor_lon.p, d_anchor_flags.p, d_ms_shift.p, d_ms_len.p, d_ms_state.p, ngen}; }
-    Layout layout_view(uint64_t* image) { return Layout{image, d_lay_off.p, d_lay_bits.p}; }
+    // coherent: the reader must see marks made while its kernel runs (a wavefront that validates candidates in order)
+    Layout layout_view(uint64_t* image, bool coherent = true) { return Layout{image, d_lay_off.p, d_lay_bits.p, coherent ? 1 : 0}; }
     // geometry of the layout image: genome j has glen[j] + 1 bits (the last one the sentinel, src/parsnp.cpp:3184-3185)
     size_t layout_geometry() {
         const size_t ngz = (size_t)ngen;
@@ -679,20 +686,27 @@ public:
         if (fl.size() * (size_t)flagged_div > (size_t)rows) { error = "too many rows of the list overlap an earlier one (rearranged genomes): the host route decides"; return kAgain; }
         const size_t words = layout_geometry();
         ensure(d_image, words);
+        // do the rows that can be accepted untrimmed lie in list order in every genome (none starts before the end of an earlier
+        // row: the engine's kRowEarly bit)?  Then their marks need no atomics (StoreMarkOrdered)
+        bool ordered = true;
+        for (int64_t c = 0; c < rows && ordered; c++) { const uint32_t f = anchor_flags_h[(size_t)c]; ordered = !((f & kRowEarly) && !(f & (kRowBad | kRowOutside | kRowDirty))); }
         be.mark("settle");
         be.memset(d_image.p, 0, 8 * words);
-        be.launch("layout_sentinel", (int64_t)ngen, LayoutSentinel{d_lay_off.p, d_lay_bits.p, d_image.p});
         const Store S = store_view();
         const Layout L = layout_view(d_image.p);
         be.launch_wave("settle_clean", rows, SettleClean{S, P});
-        be.launch("store_mark", rows * ngen, StoreMark{S, L, 0, (uint8_t)(kStAccepted | kStFlagged), kStAccepted});
+        if (ordered && !force_atomic_marks) be.launch_wave("store_mark_ordered", ((rows + kMarkRows - 1) / kMarkRows) * ((ngen + 63) / 64), StoreMarkOrdered{S, L, rows});
+        else be.launch("store_mark", rows * ngen, StoreMark{S, L, 0, (uint8_t)(kStAccepted | kStFlagged), kStAccepted});
+        be.launch("layout_sentinel", (int64_t)ngen, LayoutSentinel{d_lay_off.p, d_lay_bits.p, d_image.p});
         if (!fl.empty()) {
+            const uint64_t* before_once = d_once.p; const uint64_t* before_twice = d_twice.p;
             ensure(d_once, words); ensure(d_twice, words); ensure(d_list, fl.size());
-            be.memset(d_once.p, 0, 8 * words); be.memset(d_twice.p, 0, 8 * words);
+            if (d_once.p != before_once || d_twice.p != before_twice) { be.memset(d_once.p, 0, 8 * words); be.memset(d_twice.p, 0, 8 * words); }      // (kept all zero between calls: CollideClear)
             be.h2d(d_list.p, fl.data(), 4 * fl.size());
             be.launch("collide_mark", (int64_t)fl.size() * ngen, CollideMark{S, d_list.p, layout_view(d_once.p), d_twice.p});
-            be.launch_wave("collide_test", (int64_t)fl.size(), CollideTest{S, d_list.p, layout_view(d_twice.p)});
-            be.launch_wave("settle_flagged", (int64_t)fl.size(), SettleFlagged{S, L, P, d_list.p});
+            be.launch_wave("collide_test", (int64_t)fl.size(), CollideTest{S, d_list.p, layout_view(d_twice.p, false)});
+            be.launch("collide_clear", (int64_t)fl.size() * ngen, CollideClear{S, d_list.p, layout_view(d_once.p), d_twice.p});
+            be.launch_wave("settle_flagged", (int64_t)fl.size(), SettleFlagged{S, layout_view(d_image.p, false), P, d_list.p});
             be.launch_wave("settle_tangled", 1, SettleTangled{S, L, P, d_list.p, (int64_t)fl.size()});
         }
         layout_rows = rows;
@@ -739,7 +753,7 @@ public:
         for (;;) {
             ensure(d_rg_start, cap * (size_t)ngen); ensure(d_rg_len, cap * (size_t)ngen); ensure(d_rg_info, cap);
             be.memset(d_rg_count.p, 0, 16);
-            be.launch_wave("seed_walk", nacc, SeedWalk{store_view(), layout_view(d_image.p), P, d_list.p, q, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap});
+            be.launch_wave("seed_walk", nacc, SeedWalk{store_view(), layout_view(d_image.p, false), P, d_list.p, q, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap});
             uint64_t got = 0;
             be.d2h(&got, d_rg_count.p, 8);
             if (got <= cap) { rg_count = (int64_t)got; break; }
@@ -870,7 +884,7 @@ public:
         ensure(d_list, (size_t)n); ensure(d_list2, (size_t)n); ensure(d_small8, (size_t)n); ensure(d_f_start, (size_t)n * ngz); ensure(d_f_end, (size_t)n * ngz);
         be.h2d(d_list.p, last_of, 4 * (size_t)n); be.h2d(d_list2.p, first_of_next, 4 * (size_t)n);
         be.mark("fill");
-        be.launch_wave("fill_between", n, FillBetween{store_view(), layout_view(d_image.p), P, d_list.p, d_list2.p, d_small8.p, d_f_start.p, d_f_end.p});
+        be.launch_wave("fill_between", n, FillBetween{store_view(), layout_view(d_image.p, false), P, d_list.p, d_list2.p, d_small8.p, d_f_start.p, d_f_end.p});
         be.mark(nullptr);
         be.d2h(add, d_small8.p, (size_t)n);
         std::vector<int32_t> which;
@@ -949,8 +963,10 @@ public:
     int64_t work_budget = 1 << 22;
     int64_t dirty_min = 4096;
     int64_t flagged_div = 8;      // store_settle: PM_EAGAIN when more than one row in flagged_div overlaps an earlier one
+    bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
     bool tune(const std::string& key, int64_t value) {
         if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
+        if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
         if (key == "work_budget" && value > 0) { work_budget = value; return true; }
         if (key == "dirty_min" && value >= 0) { dirty_min = value; return true; }
         return false;

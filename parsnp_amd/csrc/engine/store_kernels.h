@@ -76,7 +76,11 @@ struct Store {
     int32_t* shift; int32_t* len; uint8_t* state;
     int32_t ngen;
 };
-struct Layout { uint64_t* image; const int64_t* word_off; const int64_t* nbits; };
+struct Layout {
+    uint64_t* image; const int64_t* word_off; const int64_t* nbits;
+    int coherent;      // != 0: reads see marks made during the running kernel (served by the L2); 0: the image does not change under the reader
+};
+PM_HD uint64_t img_ld(const Layout& L, const uint64_t* p) { return L.coherent ? load_coherent64(p) : *p; }
 
 // consecutive marked bases at pos, pos + 1, ... of genome j, at most maxlen (pos >= 0; bases at or past nbits read as unmarked)
 PM_HD int32_t img_run_up(const Layout& L, int j, int64_t pos, int32_t maxlen) {
@@ -86,7 +90,7 @@ PM_HD int32_t img_run_up(const Layout& L, int j, int64_t pos, int32_t maxlen) {
     while (n < maxlen) {
         const int64_t p = pos + n;
         if (p >= nb) break;
-        const uint64_t x = ~(load_coherent64(w + (p >> 6)) >> (p & 63));      // (the bits shifted in at the top read as unmarked)
+        const uint64_t x = ~(img_ld(L, w + (p >> 6)) >> (p & 63));      // (the bits shifted in at the top read as unmarked)
         const int avail = 64 - (int)(p & 63);
         int c = x ? ctz64(x) : 64;
         if (c > avail) c = avail;
@@ -102,7 +106,7 @@ PM_HD int32_t img_run_down(const Layout& L, int j, int64_t pos, int32_t maxlen) 
     while (n < maxlen) {
         const int64_t p = pos - n;
         if (p < 0) break;
-        const uint64_t x = ~(load_coherent64(w + (p >> 6)) << (63 - (int)(p & 63)));
+        const uint64_t x = ~(img_ld(L, w + (p >> 6)) << (63 - (int)(p & 63)));
         const int avail = (int)(p & 63) + 1;
         int c = x ? clz64(x) : 64;
         if (c > avail) c = avail;
@@ -118,9 +122,9 @@ PM_HD int64_t img_next_set(const Layout& L, int j, int64_t from) {
     if (from < 0) from = 0;
     if (from >= nb) return nb;
     int64_t wi = from >> 6;
-    uint64_t x = load_coherent64(w + wi) & (~0ull << (from & 63));
+    uint64_t x = img_ld(L, w + wi) & (~0ull << (from & 63));
     const int64_t nw = (nb + 63) / 64;
-    while (!x) { if (++wi >= nw) return nb; x = load_coherent64(w + wi); }
+    while (!x) { if (++wi >= nw) return nb; x = img_ld(L, w + wi); }
     return wi * 64 + ctz64(x);
 }
 // largest marked position <= from, or -1
@@ -131,8 +135,8 @@ PM_HD int64_t img_prev_set(const Layout& L, int j, int64_t from) {
     if (from >= nb) from = nb - 1;
     int64_t wi = from >> 6;
     const int hi = (int)(from & 63);
-    uint64_t x = load_coherent64(w + wi) & (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1));
-    while (!x) { if (wi == 0) return -1; x = load_coherent64(w + --wi); }
+    uint64_t x = img_ld(L, w + wi) & (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1));
+    while (!x) { if (wi == 0) return -1; x = img_ld(L, w + --wi); }
     return wi * 64 + 63 - clz64(x);
 }
 // any marked base in [a, b)?  (reads the words of the range only)
@@ -143,7 +147,7 @@ PM_HD bool img_any(const Layout& L, int j, int64_t a, int64_t b) {
     while (a < b) {
         const int lo = (int)(a & 63);
         const int64_t span = (64 - lo) < (b - a) ? (64 - lo) : (b - a);
-        if (load_coherent64(w + (a >> 6)) & ((span == 64 ? ~0ull : ((1ull << span) - 1)) << lo)) return true;
+        if (img_ld(L, w + (a >> 6)) & ((span == 64 ? ~0ull : ((1ull << span) - 1)) << lo)) return true;
         a += span;
     }
     return false;
@@ -233,7 +237,7 @@ struct SettleClean {
         if (!(f & kRowBad)) st = (uint8_t)(kStBuilt | ((f & kRowOutside) ? 0 : kStOk) | ((f & kRowDirty) ? kStFlagged : 0));
         int32_t dl = 0, len = S.lon[c];
         if ((st & (kStBuilt | kStOk | kStFlagged)) == (kStBuilt | kStOk)) {
-            Layout none{nullptr, nullptr, nullptr};
+            Layout none{nullptr, nullptr, nullptr, 0};
             if (settle_row(S, none, P, c, false, &dl, &len)) st |= kStAccepted;
             dl = 0; len = S.lon[c];
         }
@@ -248,6 +252,56 @@ struct StoreMark {
         if ((S.state[c] & mask) != want) return;
         const int64_t a = (int64_t)S.start[c * S.ngen + j] + S.shift[c];
         img_set_range(L, j, a, a + S.len[c]);
+    }
+};
+// The same marks for a list whose accepted clean rows lie in list order in every genome, one after the other without overlap
+// (no such row carries kRowEarly: the caller checks) -- every population sample.  12 million ranges of ~80 bases cost ~28 million
+// atomic ORs above (0.95 ms at 200 x 5 Mb); here a lane owns a genome and walks kMarkRows consecutive rows, gathering the bits
+// of the word it is in and writing each word ONCE when it moves on: plain stores, except the first and the last word of the
+// walk, which the neighbouring walks may share (atomic OR).  One wavefront per (block of rows, 64 genomes); the row entries of
+// a wavefront's lanes are adjacent (coalesced), eight rows in flight.  The sentinel bits are set after this kernel.
+constexpr int kMarkRows = 256;
+struct StoreMarkOrdered {
+    Store S; Layout L; int64_t rows;
+    PM_HD void wave(int64_t w) const {
+        const int n = S.ngen;
+        const int64_t groups = (n + 63) / 64, blk = w / groups;
+        const int g0 = (int)(w % groups) * 64;
+        const int64_t c0 = blk * kMarkRows, c1 = c0 + kMarkRows < rows ? c0 + kMarkRows : rows;
+        lanes_for(g0, g0 + 64 < n ? g0 + 64 : n, [&](int j) {
+            uint64_t* img = L.image + L.word_off[j];
+            const int64_t nb = L.nbits[j];
+            int64_t cur = -1; uint64_t bits = 0; bool first = true;
+            auto flush = [&](bool last) {
+                if (cur < 0) return;
+                if (first || last) atomic_or64(&img[cur], bits); else img[cur] = bits;
+                first = false;
+            };
+            for (int64_t cb = c0; cb < c1; cb += 8) {
+                int32_t a[8], l[8]; uint8_t st[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int64_t c = cb + u < c1 ? cb + u : c1 - 1;
+                    a[u] = S.start[c * n + j]; l[u] = S.len[c]; st[u] = S.state[c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (cb + u >= c1 || (st[u] & (kStAccepted | kStFlagged)) != kStAccepted) continue;
+                    int64_t x = a[u], e = x + l[u];
+                    if (x < 0) x = 0;
+                    if (e > nb) e = nb;
+                    while (x < e) {
+                        const int64_t wi = x >> 6;
+                        if (wi != cur) { flush(false); cur = wi; bits = 0; }
+                        const int lo = (int)(x & 63);
+                        const int64_t span = (64 - lo) < (e - x) ? (64 - lo) : (e - x);
+                        bits |= (span == 64 ? ~0ull : ((1ull << span) - 1)) << lo;
+                        x += span;
+                    }
+                }
+            }
+            flush(true);
+        });
     }
 };
 // tid = (i, genome): the rows listed in rows[] taken out of the image (filterRandom1 :415-418, filterRandomClustersSimple1 :460-466)
@@ -293,6 +347,19 @@ struct CollideTest {
             if (img_any(twice, j, a, a + S.lon[c])) hit = 1;
         });
         if (wave_or_u32(hit) && wave_leader()) S.state[c] |= kStTangled;
+    }
+};
+// tid = (flagged index, genome): the two scratch images back to all zero -- the words under the flagged rows' ranges are the
+// only ones that were written (clearing 2 x 126 MB per step for 850 rows' worth of bits costs 0.3 ms)
+struct CollideClear {
+    Store S; const int32_t* list; Layout once; uint64_t* twice;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t c = list[tid / S.ngen]; const int j = (int)(tid % S.ngen);
+        int64_t a = S.start[c * S.ngen + j], b = a + S.lon[c];
+        if (a < 0) a = 0;
+        if (b > once.nbits[j]) b = once.nbits[j];
+        const int64_t base = once.word_off[j];
+        for (int64_t w = a >> 6; a < b && w <= ((b - 1) >> 6); w++) { once.image[base + w] = 0; twice[base + w] = 0; }
     }
 };
 // the flagged rows that meet no other flagged row: each against the marks of the clean rows, all at once (they commute)

@@ -175,6 +175,7 @@ void Aligner::wait_layout() {
 }
 
 Aligner::~Aligner() {
+    if (res_.records.valid()) res_.records.get();      // (a resident run nobody extended: its helper writes to `pool`)
     wait_layout();
     // the resident route never writes to the host's bitmaps: the next run starts on them as they are
     memory_->layout_clean = res_.active && !layout.empty() && !layout[0].attached();
@@ -1521,7 +1522,8 @@ void Aligner::filter_mums(int rvalue) {
     {
         std::vector<Handle> h(mums.size());
         const long nh = (long)mums.size();        // one cache miss per MUM (its row): spread over the threads
-#pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
+        // (the resident route holds the keys in one array: no cache miss per MUM to spread over threads, and no worker to wake)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096 && !res_.active)
         for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{key0(mums[(size_t)i]), mums[(size_t)i]};
         if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[filter_mums] keys %.4f s\n", now_s() - t0);
         // the list is the anchors followed by the MUMs of the recursion, generation by generation, each in reference order:
@@ -1642,7 +1644,7 @@ void Aligner::chain() {
     {
         std::vector<Handle> h(mums.size());
         const long nh = (long)mums.size();        // one cache miss per MUM (its row): spread over the threads
-#pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (nh > 4096 && !res_.active)
         for (long i = 0; i < nh; i++) h[(size_t)i] = Handle{key0(mums[(size_t)i]), mums[(size_t)i]};
         // strictly increasing keys (the list as filter_mums left it) have one sorted order: nothing to do.  With ties
         // the order std::sort leaves is the reference's, so it runs.
@@ -1666,7 +1668,7 @@ void Aligner::chain() {
     if (judged_pred_.size() < pool.size()) { judged_pred_.resize(pool.size(), -1); judged_verdict_.resize(pool.size(), CLOSE); }   // earlier verdicts (the first pass) stay
     std::vector<long> lens((size_t)m);          // gathered here: the sequential pass below would miss the cache once per MUM
     lens[0] = pool[(size_t)mums[0]].length;
-#pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 4096)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(prm.cores > 0 ? prm.cores : 1) if (m > 4096 && !res_.active)
     for (long x = 1; x < m; x++) {
         const int cur = mums[(size_t)x], prev = mums[(size_t)x - 1];
         lens[(size_t)x] = pool[(size_t)cur].length;

@@ -335,6 +335,7 @@ private:
         std::vector<pm_region_info> gen_info; std::vector<int32_t> gen_id;     // the seed regions, in push order
         std::vector<int32_t> fallback_start; std::vector<uint8_t> fallback_strand;   // rows fetched for the host route
         std::vector<uint64_t> image;                                           // the layout, fetched for parsnp.unalign
+        std::future<void> records;                                             // the anchors' MUM records, written beside the seed regions' device work
     } res_;
     bool resident_try_ = false;           // run_batch: ask for resident mode (the anchor call of the route)
     bool layout_written_ = false;         // this run wrote to `layout`

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <iostream>
 
 namespace parsnp {
@@ -87,23 +88,42 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
         res_.why = kept ? "too many anchor candidates overlap earlier ones" : "short anchor list (no anchor table)";
         return false;
     }
-    // the accepted anchors, in list order (ids as the sequential loop assigns them: one per constructed candidate)
+    // the accepted anchors, in list order.  Their rows for the seed regions first -- the device goes on at once --, the MUM
+    // records (ids as the sequential loop assigns them: one per constructed candidate) beside it, on a helper thread that
+    // resident_extend() joins before the first MUM of the recursion is committed
     res_.active = true; res_.table = table;
     kept_results_.push_back(a.owner);
     pool.clear(); res_.start0.clear();
     std::vector<int32_t> acc;
-    for (size_t c = 0; c < a.count; c++) {
-        const uint32_t st = info[c].state_flags & 0xffu;
-        if (st & PM_ST_BUILT) next_id_++;
-        if (!(st & PM_ST_ACCEPTED)) continue;
-        Mum m;
-        m.id = next_id_ - 1; m.length = info[c].len; m.slength = whole.slength; m.row = (int32_t)c;
-        m.dirty = (st & PM_ST_FLAGGED) != 0; m.touched = info[c].len != a.lon[c];
-        pool.push_back(m); res_.start0.push_back(info[c].start0);
-        found->push_back((int)pool.size() - 1);
-        acc.push_back((int32_t)c);
-        stats.parallel_dirty += m.dirty;
-        stats.parallel_tangled += (st & PM_ST_TANGLED) != 0;
+    acc.reserve(a.count);
+    for (size_t c = 0; c < a.count; c++) if (info[c].state_flags & PM_ST_ACCEPTED) acc.push_back((int32_t)c);
+    const size_t nacc = acc.size();
+    found->resize(nacc);
+    for (size_t i = 0; i < nacc; i++) (*found)[i] = (int)i;
+    {
+        auto infos = std::make_shared<std::vector<pm_row_info>>(std::move(info));
+        std::shared_ptr<pm_result> keep = a.owner;
+        const int32_t* lon = a.lon;
+        const size_t count = a.count;
+        const long slen = whole.slength;
+        res_.records = std::async(std::launch::async, [this, infos, keep, lon, count, slen, nacc] {
+            pool.resize(nacc); res_.start0.resize(nacc);
+            size_t at = 0;
+            long dirty = 0, tangled = 0;
+            for (size_t c = 0; c < count; c++) {
+                const pm_row_info& r = (*infos)[c];
+                const uint32_t st = r.state_flags & 0xffu;
+                if (st & PM_ST_BUILT) next_id_++;
+                if (!(st & PM_ST_ACCEPTED)) continue;
+                Mum m;
+                m.id = next_id_ - 1; m.length = r.len; m.slength = slen; m.row = (int32_t)c;
+                m.dirty = (st & PM_ST_FLAGGED) != 0; m.touched = r.len != lon[c];
+                pool[at] = m; res_.start0[at] = r.start0;
+                at++;
+                dirty += m.dirty; tangled += (st & PM_ST_TANGLED) != 0;
+            }
+            stats.parallel_dirty += dirty; stats.parallel_tangled += tangled;
+        });
     }
     stats.parallel_candidates += (long)a.count;
     stats.regions_processed++;
@@ -142,6 +162,7 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
 // Phase B: the generations of extend_generations() with the per-genome work on the device.
 bool Aligner::resident_extend() {
     const double t0 = now_s();
+    struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.get(); } } join_records{res_.records};      // (the anchors' MUM records: joined on every way out)
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     std::vector<pm_region_info> gen = std::move(res_.gen_info);
     std::vector<int32_t> gen_id = std::move(res_.gen_id);
@@ -243,6 +264,7 @@ bool Aligner::resident_extend() {
         }
         stats.t_validate += now_s() - tv;
         lap("validate");
+        if (res_.records.valid()) res_.records.get();      // the anchors' records are in: the recursion's MUMs follow them in the pool
         // commit in list order (:215-254 push the MUMs of a region in candidate order)
         for (size_t i = 0; i < now.size(); i++) {
             for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) {

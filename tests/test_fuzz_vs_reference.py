@@ -97,7 +97,8 @@ def test_fuzz_resident_route(emu, tmp_path, monkeypatch, seed):
     of its rows overlap earlier ones (PM_FLAGGED_DIV=1: the trimming and the in-order settling of tangled rows at work on
     rearranged genomes).  Where the reference's order would show the route is left and the step repeated on the host route:
     the bytes must be the reference's either way."""
-    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PM_FLAGGED_DIV="1" if seed % 2 else "8").items():
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PM_FLAGGED_DIV="1" if seed % 2 else "8",
+                     PM_ATOMIC_MARKS="1" if seed % 4 == 0 else "0").items():      # (every fourth seed: the marks of an in-order list by atomic ORs as well)
         monkeypatch.setenv(k, v)
     ref, gs, kw, contigs = random_case(seed)
     if kw.get("threads", 1) < 2:
@@ -131,7 +132,7 @@ def test_fuzz_resident_route_on_gpu(tmp_path, monkeypatch, seed):
     """the resident route's KERNELS (store_kernels.h: wave64 code the CPU suite only runs through its one-thread emulation) side
     by side with the reference binary: the product's sources with the test hooks compiled in, thresholds lowered so that the
     small sets take the route, every other seed with every anchor list let onto it (PM_FLAGGED_DIV=1)"""
-    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PM_FLAGGED_DIV="1" if seed % 2 else "8").items():
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PM_FLAGGED_DIV="1" if seed % 2 else "8", PM_ATOMIC_MARKS="1" if seed % 4 == 0 else "0").items():
         monkeypatch.setenv(k, v)
     side_by_side(CORE_HOOKS_BIN, seed, tmp_path, big=seed >= 32)
 
