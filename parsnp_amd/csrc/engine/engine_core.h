@@ -238,7 +238,7 @@ public:
                     const int64_t* st = starts + r * ngen; const int64_t* ln = lens + r * ngen;
                     const int minlen = minsize[r] < 1 ? 1 : minsize[r];
                     const int div = std::max(8, minlen);
-                    const int K = minlen < 16 ? minlen : 16, stride = minlen - K + 1;
+                    const int K = minlen < kMaxK ? minlen : kMaxK, stride = minlen - K + 1;
                     const int64_t nR = ln[0];
                     size_t gs = 0;
                     int64_t units = 0;
@@ -280,7 +280,7 @@ public:
             ri.nR = (int32_t)(gb ? gb->ref_len[r] : lens[r * ngen]);
             ri.minsize = minsize[r];
             ri.minlen = minsize[r] < 1 ? 1 : minsize[r];
-            ri.K = ri.minlen < 16 ? ri.minlen : 16;
+            ri.K = ri.minlen < kMaxK ? ri.minlen : kMaxK;
             ri.stride = ri.minlen - ri.K + 1;
             int64_t slots = 16;
             while (2 * slots < 3 * (int64_t)ri.nR) slots <<= 1;   // load factor <= 2/3

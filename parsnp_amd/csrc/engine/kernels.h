@@ -111,6 +111,23 @@ PM_HD uint64_t wave_reserve01(uint64_t* counter, bool want) {
     uint64_t o = *counter; *counter = o + (want ? 1 : 0); return o;
 #endif
 }
+// the same for at most TWO slots per lane (SeedExtend's two samples): two ballots instead of a 6-step shuffle scan
+PM_HD uint64_t wave_reserve2(uint64_t* counter, uint32_t n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long m1 = __ballot(n >= 1), m2 = __ballot(n >= 2);
+    if ((m1 | m2) == 0) return 0;
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u)) +
+                            __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+    const int first = __ffsll((long long)m1) - 1;
+    unsigned long long base = 0;
+    if ((int)__lane_id() == first) base = atomicAdd((unsigned long long*)counter, (unsigned long long)(__popcll(m1) + __popcll(m2)));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, first);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), first);
+    return (((uint64_t)hi << 32) | lo) + before;
+#else
+    uint64_t o = *counter; *counter = o + n; return o;
+#endif
+}
 PM_HD void atomic_max32(int32_t* p, int32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicMax(p, v);
@@ -206,6 +223,10 @@ constexpr int kUnitSamples = 64 * kPer;   // query samples per work unit
 #define PM_LEAD 8
 #endif
 constexpr int kLead = PM_LEAD;         // SeedExtend: one lane in kLead (a leader) probes the index, the others follow its hit
+#ifndef PM_KMAX
+#define PM_KMAX 16
+#endif
+constexpr int kMaxK = PM_KMAX;         // longest seed: K = min(minsize, kMaxK), query sampling step minsize - K + 1 (a tag holds 16 bases)
 constexpr int kSlices = 1024;          // the event buffer is appended through this many independent counters
 constexpr int kSliceStride = 8;        // uint64 words between two counters: one 64-byte line each
 
@@ -699,6 +720,13 @@ struct SeedExtend {
             const int off = u * stride;
             return ((qw1.b >> (2 * off)) & kbits) | ((uint64_t)((qw1.m >> off) & kmask) << 32);
         };
+        // every sample's K-mer and the K-mer of the reverse strand over the same bases, ONCE: the leader's probe, the strand
+        // tests and the presence-filter checks below all want one or both (five reverse complements per lane otherwise, ~100
+        // of the kernel's 1 300 vector instructions per wavefront -- and the launch is bound by instruction issue)
+        uint64_t tgs[kPer], gts[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; u++) { tgs[u] = valid[u] ? tag_at(u) : 0; gts[u] = rc_tag(tgs[u], K); }
+        auto ctag_at = [&](int u) -> uint64_t { return gts[u] < tgs[u] ? gts[u] : tgs[u]; };
         // Index probes are scarce (random requests at the fabric's request rate, two dependent round trips).  Consecutive
         // lanes hold consecutive samples, and inside a forward match the K-mer of sample s+t sits t*stride bases after the
         // K-mer of sample s.  So only every kLead-th lane (a leader) probes the index, for its first sample; every other sample
@@ -714,7 +742,7 @@ struct SeedExtend {
         if (follow) {
             const int g0 = lane & ~(kLead - 1);
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (valid[0] && sub == 0) slot = index_probe(ri, slots, filter, canonical_tag(tag_at(0), K));
+            if (valid[0] && sub == 0) slot = index_probe(ri, slots, filter, ctag_at(0));
             const int32_t mine = (sub == 0 && slot != kEmpty && !(slot & kMulti)) ? slot_head(slot) : -1;
             const int32_t own = __shfl(mine, g0, 64);
             int32_t before = __shfl(mine, (g0 + 64 - kLead) & 63, 64), after = __shfl(mine, (g0 + kLead) & 63, 64);
@@ -727,7 +755,7 @@ struct SeedExtend {
                 const uint64_t ls = index_probe(ri, slots, filter, canonical_tag(kmer_tag(P, qbase + jj, K), K));
                 return (ls != kEmpty && !(ls & kMulti)) ? slot_head(ls) : -1;
             };
-            if (valid[0] && sub == 0) slot = index_probe(ri, slots, filter, canonical_tag(tag_at(0), K));
+            if (valid[0] && sub == 0) slot = index_probe(ri, slots, filter, ctag_at(0));
             const int32_t own = sub == 0 ? ((slot != kEmpty && !(slot & kMulti)) ? slot_head(slot) : -1) : probe_at(j0 - (int64_t)sub * kPer * stride);
             int32_t before = -1, after = -1;
             if (own < 0 && g0 > 0) before = probe_at(j0 - (int64_t)(kLead + sub) * kPer * stride);
@@ -779,8 +807,8 @@ struct SeedExtend {
                 const bool same = ((d1.x >> (2 * off)) & kbits) == 0 && ((d1.m >> off) & kmask) == 0;      // the reference K-mer there is the sample's
                 const bool predicted = !(u == 0 && own_probe);
                 const bool shared = ((rwords >> (((fpos0 & 31) + off) & 63)) & 1u) != 0;      // its canonical form occurs elsewhere in R
-                const uint64_t tg = tag_at(u);
-                const uint64_t gat = rc_tag(tg, K);               // the K-mer of the reverse strand that covers the same bases
+                const uint64_t tg = tgs[u];
+                const uint64_t gat = gts[u];                       // the K-mer of the reverse strand that covers the same bases
                 bool rev = same && gat == tg;                      // a palindrome seeds both strands
                 if (!same && !predicted) rev = (((rw1.b >> (2 * off)) & kbits) | ((uint64_t)((rw1.m >> off) & kmask) << 32)) == gat;   // the probe found the K-mer on the other strand
                 if (predicted ? !(same && !shared) : !(same || rev)) { todo[u] = kProbe; fwd_here = false; continue; }
@@ -831,7 +859,7 @@ struct SeedExtend {
                 bool go;
                 if (follow && u == 0 && sub == 0) go = slot != kEmpty;
                 else {
-                    const uint64_t hv = hash_tag(canonical_tag(tag_at(u), K));
+                    const uint64_t hv = hash_tag(ctag_at(u));
                     const uint32_t bit = (uint32_t)(hv >> 35) & ri.fmask;
                     const uint32_t fm = filter_mask(hv, bit);
                     go = (filter[ri.fbase + (bit >> 5)] & fm) == fm;
@@ -856,7 +884,7 @@ struct SeedExtend {
         }
         {
             // (a sub-queue per workgroup, as for the events: one counter for the launch's ~10^6 wavefronts is a 20 ms queue)
-            uint64_t qat = wave_reserve(queue_count + slice * kSliceStride, (uint32_t)nqueued);
+            uint64_t qat = kPer == 2 ? wave_reserve2(queue_count + slice * kSliceStride, (uint32_t)nqueued) : wave_reserve(queue_count + slice * kSliceStride, (uint32_t)nqueued);
             RestItem* const sub = queue + slice * queue_cap;
 #pragma unroll
             for (int u = 0; u < kPer; u++)
@@ -865,7 +893,7 @@ struct SeedExtend {
                     qat++;
                 }
         }
-        uint64_t at = kPer == 1 ? wave_reserve01(ev_count, nb != 0) : wave_reserve(ev_count, (uint32_t)nb);
+        uint64_t at = kPer == 1 ? wave_reserve01(ev_count, nb != 0) : kPer == 2 ? wave_reserve2(ev_count, (uint32_t)nb) : wave_reserve(ev_count, (uint32_t)nb);
 #pragma unroll
         for (int u = 0; u < kPer; u++)
             if (u < nb) { if (at < ev_cap) { key_out[at] = bk[u]; val_out[at] = bv[u]; } at++; }
@@ -1202,7 +1230,9 @@ struct ChunkReduce {
         for (; i < b; i++) {
             uint64_t k = key[i], v = val[i];
             int32_t l = (int32_t)((k >> 1) & lmask);
-            state_push(cur.s[k & 1], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
+            // (a strand chosen by an index would put `cur` into LDS: the compiler promotes a dynamically indexed private array)
+            if (k & 1) state_push(cur.s[1], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
+            else state_push(cur.s[0], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
         }
         summary[c] = cur;
     }
@@ -1232,7 +1262,9 @@ struct ChunkScan {
             uint64_t k = key[i], v = val[i];
             if ((k >> (lbits + 1)) != pair) { pair = k >> (lbits + 1); cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1}; }
             int32_t l = (int32_t)((k >> 1) & lmask);
-            state_push(cur.s[k & 1], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
+            // (a strand chosen by an index would put `cur` into LDS: the compiler promotes a dynamically indexed private array)
+            if (k & 1) state_push(cur.s[1], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
+            else state_push(cur.s[0], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
             st[i] = cur;
             emax[i] = cur.s[0].e1 > cur.s[1].e1 ? cur.s[0].e1 : cur.s[1].e1;
         }
