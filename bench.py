@@ -38,14 +38,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 RANDOM_PEAK_GBS = 3400.0   # measured ceiling of scattered 64-byte requests (scripts/hbm_calib.hip gather kernels, profiles/r01/calibration.json: 54 G requests/s): what an index probe can reach
-PROFILE_ROUND = "r03"   # profiles/<round>/traffic_seed_extend.json, calibration.json: the PMC passes of the shipped binary
+PROFILE_ROUND = "r04"   # profiles/<round>/traffic_seed_extend.json, calibration.json: the PMC passes of the shipped binary
 
 
 def engine_src_sha256():
     """sha256 over the sources of the engine translation unit (scripts/profile_summary.py stamps the same)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.h", "engine_core.h", "engine_hip.hip", "abi_glue.h"):
+    for f in ("kernels.h", "store_kernels.h", "engine_core.h", "engine_hip.hip", "abi_glue.h"):
         p = os.path.join(ROOT, "parsnp_amd", "csrc", "engine", f)
         if not os.path.exists(p):
             return None
@@ -185,6 +185,8 @@ def main():
                          "measurement as the line's value and, for N > 1, the sharded measurement of the same workload beside it "
                          "(`sharded_strong`, run by one child process per rank so that it cannot take the headline down with it)")
     ap.add_argument("--inputs", default="", help="directory with ref.fna + g*.fna to use instead of generating the workload (the sharded child of --mode both)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="a tunable of the engine session (pm_session_tune: group_small=0, ...) for before/after measurements; named in config.tune")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
@@ -283,6 +285,11 @@ def main():
                 run = ShardedRun(ini, dist if dist is not None else _Solo, "cpu", None, rccl=True)
             else:
                 run = CoreRun(ini)
+            for kv in args.tune:
+                key, _, val = kv.partition("=")
+                run.L.pc_tune.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_char_p, __import__("ctypes").c_longlong]
+                if run.L.pc_tune(run.h, key.encode(), int(val)) != 0:
+                    raise SystemExit("bench.py: --tune %s refused by the engine" % kv)
             cold_step_s = None
             # the harness's own interpreter must not stall the passes it times: a full cyclic collection with torch imported
             # costs ~40 ms and would otherwise fire inside the first (cold) pass or one of the few timed steps
@@ -389,7 +396,7 @@ def main():
                     phases[k] = phases.get(k, 0.0) + v / len(reports)
                 for k, v in r["engine_ms"].items():
                     totals[k] = totals.get(k, 0.0) + v / len(reports)
-            counts = ("budget_retries", "events", "rest_samples", "n_positions", "n_candidates", "n_accepted")          # counts that travel in the timing list, not times
+            counts = ("budget_retries", "events", "rest_samples", "n_positions", "n_candidates", "n_accepted", "n_grouped")          # counts that travel in the timing list, not times
             kernels = {k: v for k, v in totals.items() if k not in ("setup", "download", "units", "call_wall") + counts}
             dom = max(kernels, key=kernels.get) if kernels else None
             launches = sum(r["finder_calls"] for r in reports) / len(reports)          # engine launches per step
@@ -429,10 +436,13 @@ def main():
                 # peak (the contract's roofline).  The kernel does not live under that roof: its requests are scattered 64-B index
                 # and sequence reads whose ceiling is the fabric's request rate (54 G requests/s = 3.4 TB/s, scripts/hbm_calib.hip),
                 # most of them served by the 256 MB Infinity Cache -- `limiter` says so, `traffic` is what the counters saw.
-                roof = {"bound": "hbm",
-                        "limiter": "request rate of scattered 64-B reads (index slots, presence filter, sequence blocks at hashed positions: 54 G requests/s "
-                                   "= 3.4 TB/s measured ceiling), then instruction issue under divergence; not byte bandwidth -- the index (67 MB), the filter "
-                                   "(8 MB) and the reference (2.5 MB) sit in the 256 MB Infinity Cache",
+                roof = {"bound": "hbm",      # (the contract's two rooflines; what the kernel really waits for: `limiter`)
+                        "limiter": "vector-instruction issue: SeedExtend issues ~1 200 vector + 400 scalar instructions per 128-sample wavefront "
+                                   "(profiles/%s/sq_seed_extend.json, SQ counters of the shipped kernels) -- 0.78 M wavefronts x 1 200 at one wave64 "
+                                   "instruction per SIMD and 4 cycles is ~85 %% of the anchor launch; SeedRest (5.5 %% of the samples) waits on dependent "
+                                   "scattered reads (84 %% of its wave-cycles waiting), SmallPairEvents is register arithmetic.  Not byte bandwidth: the "
+                                   "index (67 MB), the filter (8 MB) and the reference (2.5 MB) sit in the 256 MB Infinity Cache, and the scattered "
+                                   "64-B requests peak at 54 G/s = 3.4 TB/s (scripts/hbm_calib.hip)" % PROFILE_ROUND,
                         "kernel": "seed_extend (SeedExtend + SeedRest + SmallPairEvents)" if dom == "seed_extend" else dom,
                         "achieved": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 5),
                         "frac_basis": "algorithmic bytes of this engine per launch / HIP-event time of the launch",
@@ -482,7 +492,7 @@ def main():
                            % (args.workload, G, n_ref / 1e6, dict(bact200="population").get(args.workload, "synthetic"),
                               ", ".join("%s=%s" % (k, v) for k, v in sorted(kw.items()) if k not in ("n", "n_genomes")),
                               "" if world == 1 else ("; ONE alignment sharded over %d ranks" % world if sharded else "; one partition per rank, %d ranks" % world)),
-                           "genomes_per_gpu": G if not sharded else round(G / world, 2), "genome_bp": n_ref, "host_threads": args.host_threads, "host_cpus_usable": usable_cpus(), "numa_node": numa_node, "parallelism": ("sharded x%d (engine RCCL: all-reduce(min) + all-gather per engine call)" % world) if sharded else "partition-per-gpu x%d" % world},
+                           "genomes_per_gpu": G if not sharded else round(G / world, 2), "genome_bp": n_ref, "host_threads": args.host_threads, "tune": args.tune or None, "host_cpus_usable": usable_cpus(), "numa_node": numa_node, "parallelism": ("sharded x%d (engine RCCL: all-reduce(min) + all-gather per engine call)" % world) if sharded else "partition-per-gpu x%d" % world},
                 "n_ranks_seen_by_rccl": rccl_ranks, "per_rank": per_rank,
                 "sharded_strong": sharded_strong,
                 "step_ms": step_ms[:40], "host_cores_busy": round(host_cores_busy, 2),

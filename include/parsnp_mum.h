@@ -138,6 +138,8 @@ int64_t pm_result_table_id(const pm_result* r);
  *   "flagged_div"  pm_store_settle answers PM_EAGAIN when more than one row in flagged_div of the anchor table overlaps an
  *                  earlier one (default 8, the host route's own threshold for its exact overlap test)
  *   "atomic_marks" != 0: pm_store_settle marks the layout with atomic ORs even where the list's order allows plain stores (tests)
+ *   "group_small"  0: the events of a recursion batch's small regions are found pair by pair and sorted with the others, instead of
+ *                  once per distinct query piece (default 1; both give the same events, tests compare the two)
  * PM_EINVAL for an unknown key or a value out of range. */
 int pm_session_tune(pm_session* s, const char* key, int64_t value);
 

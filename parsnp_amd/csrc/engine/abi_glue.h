@@ -288,6 +288,7 @@ int pm_last_timing(const pm_session* cs, int* count, const char** names, float* 
     s->timing.push_back(pm::PhaseTime{"n_positions", (float)s->engine->last_positions});      // counts as well: reference positions of the batch, candidates Master.EP selected, candidates the fold accepted
     s->timing.push_back(pm::PhaseTime{"n_candidates", (float)s->engine->last_candidates});
     s->timing.push_back(pm::PhaseTime{"n_accepted", (float)s->engine->last_accepted});
+    s->timing.push_back(pm::PhaseTime{"n_grouped", (float)s->engine->last_grouped});
     s->timing.push_back(pm::PhaseTime{"events", (float)s->engine->last_events});      // a count too: R-unique maximal matches the event search appended (16 B each)
     int capn = *count, n = 0;
     for (const auto& t : s->timing) { if (n < capn) { names[n] = t.name; ms[n] = t.ms; } n++; }

@@ -296,7 +296,7 @@ public:
             nunits += units_r[(size_t)r];
         }
         posbase[regz] = npos;
-        last_positions = npos; last_candidates = 0; last_accepted = 0;
+        last_positions = npos; last_candidates = 0; last_accepted = 0; last_grouped = 0;
         const int64_t npairs = nreg * nq;
         const int64_t nchunks = cbase[regz] - nreg;                  // 256-position chunks of the batch
         const int64_t centries = cbase[regz] * nq;
@@ -378,9 +378,22 @@ public:
         uint64_t nrest = 0;
         uint32_t sticky = 0;
         std::vector<uint64_t> qcounts((size_t)kSlices * kSliceStride);
+        // the small regions of a recursion batch: their events once per distinct piece, straight into the head of the final array
+        const bool grouping = group_small && !no_small && !want_events && nreg >= 2 && nq <= kGrpGenomes;
+        const size_t kGrpSlot = (size_t)kSlices * kSliceStride + 2;      // (d_counter: the block counter of the grouped events)
+        size_t grp_cap = grouping ? std::max<size_t>(grp_cap_hint, (size_t)npairs * 3) + 64 : 0;
+        uint64_t ngrp = 0;
+        if (grouping) { ensure(d_gflag, (size_t)nreg); ensure(d_glo, (size_t)npairs); }
         for (bool again = false;; again = true) {
             ensure(d_evkey, slice_cap * kSlices); ensure(d_evval, slice_cap * kSlices); ensure(d_rest, queue_cap * kSlices);
-            if (again) be.memset(d_counter.p, 0, 8 * ((size_t)kSlices * kSliceStride + 1));      // event counters and error word
+            if (again) be.memset(d_counter.p, 0, 8 * ncounter);      // event counters, error word, grouped events
+            if (grouping) {
+                ensure(d_evkey3, grp_cap + ev_cap_hint); ensure(d_evval3, grp_cap + ev_cap_hint);
+                be.mark("grouped_events");
+                be.launch_wave("grouped_pair_events", nreg,
+                               GroupedPairEvents{P, d_R.p, d_starts.p, d_lens.p, ngen, d_rep.p, d_evkey3.p, d_evval3.p, d_counter.p + kGrpSlot, (uint64_t)grp_cap, lbits,
+                                                 d_glo.p, g_first, g_last, d_gflag.p});
+            }
             be.memset(d_qcount.p, 0, 8 * (size_t)kSlices * kSliceStride);
             be.mark("seed_extend");
             be.launch("seed_extend", nunits * 64,
@@ -392,7 +405,7 @@ public:
                                    d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err, work_budget});
             if (!no_small)
                 be.launch("small_pair_events", npairs * 2,
-                          SmallPairEvents{P, d_R.p, d_starts.p, d_lens.p, ngen, d_rep.p, d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, g_first, g_last});
+                          SmallPairEvents{P, d_R.p, d_starts.p, d_lens.p, ngen, d_rep.p, d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, g_first, g_last, grouping ? d_gflag.p : nullptr});
             be.mark("sort");
             be.launch_wave("slice_offsets", 1, SliceOffsets{d_counter.p, d_sliceoff.p});
             be.d2h_async(qcounts.data(), d_qcount.p, 8 * qcounts.size());
@@ -405,7 +418,9 @@ public:
                 const uint64_t q = qcounts[(size_t)sl * kSliceStride]; nrest += q; qworst = std::max(qworst, q);
             }
             errbits = (uint32_t)counts[(size_t)kSlices * kSliceStride];
-            if (worst <= slice_cap && qworst <= queue_cap) break;
+            ngrp = grouping ? counts[kGrpSlot] : 0;
+            if (worst <= slice_cap && qworst <= queue_cap && ngrp <= grp_cap) break;
+            if (ngrp > grp_cap) grp_cap = (size_t)(ngrp + ngrp / 8 + 64);
             if (worst > slice_cap) slice_cap = (size_t)(worst + worst / 8 + 64);
             if (qworst > queue_cap) queue_cap = (size_t)(qworst + qworst / 8 + 64);
             sticky |= errbits & (kErrWork | kErrRows);      // (RepeatLength's and CheckRows' verdicts: the word is cleared with the counters)
@@ -416,23 +431,28 @@ public:
         rest_cap_hint[nreg == 1] = queue_cap;
         last_rest = (int64_t)nrest;
         ev_cap_hint = (size_t)(nev + nev / 4);
-        last_events = (int64_t)nev;
+        if (grouping) grp_cap_hint = (size_t)(ngrp + ngrp / 4);
+        last_events = (int64_t)(nev + ngrp);
+        last_grouped = (int64_t)ngrp;
         // a rank of a sharded run that ran out of budget must not leave the others waiting in the collectives: the
         // verdict travels with the first exchange (below) and every rank returns the error together
         const bool sharded = coll.world > 1 || coll.device;      // (a one-rank RCCL session still runs the exchanges: that is how a 1-GPU box tests them)
         if ((errbits & kErrWork) && !sharded) { budget_exceeded = true; error = "per-thread work budget exceeded (degenerate repeat structure in a region)"; return -5; }
 
         ensure(d_evkey2, std::max<size_t>(nev, 1)); ensure(d_evval2, std::max<size_t>(nev, 1));
-        ensure(d_evkey3, std::max<size_t>(nev, 1)); ensure(d_evval3, std::max<size_t>(nev, 1));
+        // the final array: [ grouped events, contiguous and ordered per pair | the other events, sorted by (pair, l, strand) ]
+        ensure_keep(d_evkey3, std::max<size_t>(ngrp + nev, 1), (size_t)ngrp); ensure_keep(d_evval3, std::max<size_t>(ngrp + nev, 1), (size_t)ngrp);
         const int keybits = bits_for((uint64_t)npairs) + lbits + 1;
         uint64_t *skey = d_evkey3.p, *sval = d_evval3.p;
         if (nev > 0) {
             be.launch("compact_events", (int64_t)nev, CompactEvents{d_evkey.p, d_evval.p, d_sliceoff.p, (uint64_t)slice_cap, d_evkey2.p, d_evval2.p});
-            be.sort_pairs(d_evkey2.p, d_evkey3.p, d_evval2.p, d_evval3.p, (size_t)nev, keybits);
+            be.sort_pairs(d_evkey2.p, d_evkey3.p + ngrp, d_evval2.p, d_evval3.p + ngrp, (size_t)nev, keybits);
         }
         be.mark("scan");
         ensure(d_lo, (size_t)npairs + 1);
-        be.launch("pair_bounds", npairs, PairBounds{skey, (int64_t)nev, lbits, npairs, d_lo.p});
+        nev += ngrp;
+        be.launch("pair_bounds", npairs, PairBounds{skey, (int64_t)nev, lbits, npairs, d_lo.p, (int64_t)ngrp});
+        if (grouping) be.launch("grouped_bounds", npairs, GroupedBounds{d_gflag.p, d_glo.p, nq, d_lo.p});
         ensure(d_state, std::max<size_t>(nev, 1)); ensure(d_emax, std::max<size_t>(nev, 1));
         const int64_t nscan = ((int64_t)nev + kChunk - 1) / kChunk;
         ensure(d_summary, (size_t)std::max<int64_t>(nscan, 1)); ensure(d_startshere, (size_t)std::max<int64_t>(nscan, 1));
@@ -652,7 +672,7 @@ public:
     std::vector<uint32_t> anchor_flags_h;
     static constexpr int kAgain = -6; // PM_EAGAIN: the resident route does not apply; the caller takes the host route
 
-    void begin_store_call() { timing.clear(); last_events = last_rest = last_positions = last_candidates = last_accepted = 0; last_alg[0] = last_alg[1] = last_alg[2] = 0; }      // (counts of the last search travel with pm_last_timing)
+    void begin_store_call() { timing.clear(); last_events = last_rest = last_positions = last_candidates = last_accepted = last_grouped = 0; last_alg[0] = last_alg[1] = last_alg[2] = 0; }      // (counts of the last search travel with pm_last_timing)
     Store store_view() { return Store{d_anchor_start.p, d_ms_strand.p, d_anchor_lon.p, d_anchor_flags.p, d_ms_shift.p, d_ms_len.p, d_ms_state.p, ngen}; }
     // coherent: the reader must see marks made while its kernel runs (a wavefront that validates candidates in order)
     Layout layout_view(uint64_t* image, bool coherent = true) { return Layout{image, d_lay_off.p, d_lay_bits.p, coherent ? 1 : 0}; }
@@ -963,10 +983,13 @@ public:
     int64_t work_budget = 1 << 22;
     int64_t dirty_min = 4096;
     int64_t flagged_div = 8;      // store_settle: PM_EAGAIN when more than one row in flagged_div overlaps an earlier one
+    bool group_small = true;      // the events of a recursion batch's small regions once per distinct piece (GroupedPairEvents)
+    int64_t last_grouped = 0;
     bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
     bool tune(const std::string& key, int64_t value) {
         if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
+        if (key == "group_small") { group_small = value != 0; return true; }
         if (key == "work_budget" && value > 0) { work_budget = value; return true; }
         if (key == "dirty_min" && value >= 0) { dirty_min = value; return true; }
         return false;
@@ -1017,7 +1040,8 @@ private:
     SeqBlock* blk = nullptr; int64_t* d_goff = nullptr; int64_t* d_glen = nullptr;
     int64_t total_words = 0;
     Packed P{};
-    size_t ev_cap_hint = 0, cand_cap_hint = 0, rest_cap_hint[2] = {0, 0};
+    size_t ev_cap_hint = 0, cand_cap_hint = 0, rest_cap_hint[2] = {0, 0}, grp_cap_hint = 0;
+    Buf<uint8_t> d_gflag; Buf<int64_t> d_glo;
     Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase;
     Buf<uint64_t> d_slots; Buf<uint32_t> d_filter, d_repeated; Buf<int32_t> d_next, d_rep, d_run, d_epm;
     Buf<int64_t> d_ucount, d_uoff; Buf<UnitRec> d_units;

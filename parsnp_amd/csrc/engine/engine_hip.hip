@@ -186,12 +186,14 @@ struct HipBackend {
     void pinned_free(void* p) { if (p) (void)hipHostFree(p); }
     void h2d_staged(void* d, const void* s, size_t n) { bytes_h2d += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D (staged)"); }
 
+    // copy threads of the genome upload: the staging copy into page-locked memory (~5 GB/s per thread) is what the upload waits for
+    static int upload_threads() { const char* e = getenv("PARSNP_UPLOAD_THREADS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? v : 4; }
     // see Engine::load_genomes.  kThreads host threads, two staging slots each (page-locked host block + device block + stream)
     bool stage_genomes(int n, const uint8_t* const* seqs, const int64_t* lens, const std::vector<char>& take, const std::vector<int64_t>& goff,
                        pm::SeqBlock* blk, int64_t maxlen) {
         int64_t total = 0;
         for (int g = 0; g < n; g++) if (take[(size_t)g]) total += lens[g];
-        const int kThreads = total < (8 << 20) ? 1 : 4;      // a handful of short sequences: one thread, two slots
+        const int kThreads = total < (8 << 20) ? 1 : upload_threads();      // a handful of short sequences: one thread, two slots
         constexpr int kPer = 2;
         int device = 0;
         if (!check(hipGetDevice(&device), "hipGetDevice")) return false;

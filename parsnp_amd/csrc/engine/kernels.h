@@ -1079,48 +1079,55 @@ struct W128 {
 // index: both sides sit in registers as bit planes, every diagonal is one shift + XOR, and a run of equal bases is a run
 // of ones.  tid = (pair, strand); one lane does all diagonals of its pair (a few thousand bit operations), so the 3 million
 // such pairs of a recursion batch are 50 000 wavefronts instead of 3 million nearly empty SeedExtend units.
+// every maximal exact match of length >= L between reference bases [rpos, rpos + nR) and query bases [qpos, qpos + m), both
+// sides at most W::kBits long: emit(l0, j0, len).  Both sides as three bit planes; a diagonal is one shift + XOR.
+// (first, step: this caller's share of the diagonals -- every step-th, from the first-th -- when several lanes split a pair)
+template <class W, class Emit>
+PM_HD void pair_diagonals(const Packed& P, int64_t rpos, int64_t qpos, int32_t nR, int32_t m, int32_t L, Emit emit, int32_t first = 0, int32_t step = 1) {
+    const W r0 = W::load(P.blk, rpos, 0), r1 = W::load(P.blk, rpos, 1), rn = W::load(P.blk, rpos, 2);
+    const W q0 = W::load(P.blk, qpos, 0), q1 = W::load(P.blk, qpos, 1), qn = W::load(P.blk, qpos, 2);
+    const W vr = W::ones(nR), vq = W::ones(m);
+    for (int32_t d = -(m - L) + first; d <= nR - L; d += step) {        // diagonal: reference position = query position + d
+        W eq;
+        if (d >= 0) eq = ~((r0.shr(d) ^ q0) | (r1.shr(d) ^ q1) | (rn.shr(d) ^ qn)) & vr.shr(d) & vq;      // bit t: query t, reference t + d
+        else eq = ~((r0 ^ q0.shr(-d)) | (r1 ^ q1.shr(-d)) | (rn ^ qn.shr(-d))) & vr & vq.shr(-d);         // bit t: reference t, query t - d
+        W x = eq;                                            // any run of at least L ones?
+        int k = 1;
+        while (2 * k <= L) { x = x & x.shr(k); k *= 2; }
+        if (L > k) x = x & x.shr(L - k);
+        if (!x.any()) continue;
+        while (eq.any()) {
+            const int s = eq.low();
+            const int len = eq.run_at(s);
+            if (len >= L) emit(d >= 0 ? s + d : s, d >= 0 ? s : s - d, len);      // (l0, j0, len)
+            eq = eq.clear_below(s + len);
+        }
+    }
+}
 struct SmallPairEvents {
     Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen;
     const int32_t* rep;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits;
     int32_t g_first, g_last;
+    const uint8_t* grouped;      // [region] != 0: the region's pairs are GroupedPairEvents' (store_kernels.h); nullptr: none
 
     template <class W, class Emit>
-    PM_HD void scan(int64_t rpos, int64_t qpos, int32_t nR, int32_t m, int32_t L, Emit emit) const {
-        const W r0 = W::load(P.blk, rpos, 0), r1 = W::load(P.blk, rpos, 1), rn = W::load(P.blk, rpos, 2);
-        const W q0 = W::load(P.blk, qpos, 0), q1 = W::load(P.blk, qpos, 1), qn = W::load(P.blk, qpos, 2);
-        const W vr = W::ones(nR), vq = W::ones(m);
-        for (int32_t d = -(m - L); d <= nR - L; d++) {        // diagonal: reference position = query position + d
-            W eq;
-            if (d >= 0) eq = ~((r0.shr(d) ^ q0) | (r1.shr(d) ^ q1) | (rn.shr(d) ^ qn)) & vr.shr(d) & vq;      // bit t: query t, reference t + d
-            else eq = ~((r0 ^ q0.shr(-d)) | (r1 ^ q1.shr(-d)) | (rn ^ qn.shr(-d))) & vr & vq.shr(-d);         // bit t: reference t, query t - d
-            W x = eq;                                            // any run of at least L ones?
-            int k = 1;
-            while (2 * k <= L) { x = x & x.shr(k); k *= 2; }
-            if (L > k) x = x & x.shr(L - k);
-            if (!x.any()) continue;
-            while (eq.any()) {
-                const int s = eq.low();
-                const int len = eq.run_at(s);
-                if (len >= L) emit(d >= 0 ? s + d : s, d >= 0 ? s : s - d, len);      // (l0, j0, len)
-                eq = eq.clear_below(s + len);
-            }
-        }
-    }
+    PM_HD void scan(int64_t rpos, int64_t qpos, int32_t nR, int32_t m, int32_t L, Emit emit) const { pair_diagonals<W>(P, rpos, qpos, nR, m, L, emit); }
 
     PM_HD void operator()(int64_t tid) const {
         const int64_t pair = tid >> 1; const int strand = (int)(tid & 1);
         const int32_t nq = ngen - 1;
         const int64_t r = pair / nq; const int g = (int)(pair % nq) + 1;
         const RegionInfo& ri = R[r];
-        const int64_t m = lens[r * ngen + g], qs = starts[r * ngen + g];
+        const bool mine = !(grouped && grouped[r]);       // (the lanes of a grouped region leave without touching its rows)
+        const int64_t m = mine ? lens[r * ngen + g] : 0, qs = mine ? starts[r * ngen + g] : 0;
         const int32_t nR = ri.nR, L = ri.minlen;
         const uint64_t slice = (uint64_t)((tid >> 8) & (kSlices - 1));      // one sub-buffer per workgroup, as in SeedExtend
         uint64_t* ev_count = ev_counters + slice * kSliceStride;
         uint64_t* const key_out = ev_key + slice * slice_cap;
         uint64_t* const val_out = ev_val + slice * slice_cap;
         uint64_t first_key = kEmpty, first_val = 0;
-        if (small_pair(nR, m) && m >= L && nR >= L && g >= g_first && g < g_last) {
+        if (mine && small_pair(nR, m) && m >= L && nR >= L && g >= g_first && g < g_last) {
             const int64_t qbase = strand ? P.goff[2 * g + 1] + (P.glen[g] - qs - m) : P.goff[2 * g] + qs;
             const int64_t rbase = P.goff[0] + ri.ref_pos;
             auto emit = [&](int32_t l0, int32_t j0, int32_t len) {
@@ -1171,9 +1178,10 @@ struct CompactEvents {
 // After sorting by (pair, l, strand): first event of every pair
 struct PairBounds {
     const uint64_t* key; int64_t nev; int lbits; int64_t npairs; int64_t* lo;   // lo[npairs+1]
+    int64_t base;      // the sorted events are key[base, nev) (before them: the grouped events, store_kernels.h)
     PM_HD void operator()(int64_t pair) const {
         uint64_t want = (uint64_t)pair << (lbits + 1);
-        int64_t a = 0, b = nev;
+        int64_t a = base, b = nev;
         while (a < b) { int64_t mid = (a + b) >> 1; if (key[mid] < want) a = mid + 1; else b = mid; }
         lo[pair] = a;
         if (pair == npairs - 1) lo[npairs] = nev;

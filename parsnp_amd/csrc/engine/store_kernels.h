@@ -38,6 +38,8 @@ __device__ inline uint64_t wave_sum_u64(uint64_t x) {
     return x;
 }
 __device__ inline bool wave_leader() { return __lane_id() == 0; }
+__device__ inline void wave_sync() { __syncthreads(); }      // (one wavefront per workgroup: orders its LDS traffic)
+#define PM_WAVE_SHARED __shared__
 // loads that see what atomics of this or another wavefront have written (agent scope: served by the L2)
 __device__ inline uint64_t load_coherent64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline int32_t load_coherent32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -55,6 +57,8 @@ inline int32_t wave_bcast_i32(int32_t x, int) { return x; }
 inline uint64_t wave_or_u64(uint64_t x) { return x; }
 inline uint64_t wave_sum_u64(uint64_t x) { return x; }
 inline bool wave_leader() { return true; }
+inline void wave_sync() {}
+#define PM_WAVE_SHARED
 inline uint64_t load_coherent64(const uint64_t* p) { return *p; }
 inline int32_t load_coherent32(const int32_t* p) { return *p; }
 inline uint8_t load_coherent8(const uint8_t* p) { return *p; }
@@ -502,6 +506,200 @@ struct RegionsEqual {
         diff = wave_or_u32(diff);
         if (wave_leader()) same[i] = diff ? 0 : 1;
     }
+};
+
+// ------------------------------------------------------------------------------------------ events of small regions, once per distinct piece
+// The recursion's regions are tiny (mean 46 bp at 200 x 5 Mb) and many: 8 000 regions x 200 genomes = 1.6 M (region, genome)
+// pairs, each scanned diagonal by diagonal by SmallPairEvents (0.7 ms of vector arithmetic) and their 3.7 M events gathered and
+// radix-sorted (0.33 ms).  But the genomes of a population carry a handful of DISTINCT strings between two anchors (2^k for k
+// segregating sites), and everything downstream only needs the events of a pair contiguous and in reference order, not a
+// globally sorted array.  So: one wavefront per region whose sides all fit 128 bases, lane t holding the genomes
+// [1 + t * per, 1 + (t + 1) * per) --
+//   1. round by round every lane loads one genome's piece (three bit planes, masked to its length) and looks it up among the
+//      distinct pieces seen so far (at most kGrpPieces, kept in LDS); the lanes whose piece is new elect one of them at a time,
+//      which joins the table, until every lane knows its piece's number;
+//   2. the distinct pieces are scanned once per strand (pair_diagonals), their events kept sorted by reference position in LDS;
+//   3. every lane copies the events of its genomes' pieces, keyed with their own pair, to one block of the grouped event
+//      array (the head of the array the sorted events of the other pairs are appended to): a pair's events are contiguous and
+//      ordered, and `glo[pair]` is where they start -- no gather, no sort.
+// A region with a side longer than 128 bases, more than kGrpPieces distinct pieces, or more than kGrpEvents events of one
+// (piece, strand) leaves its flag at 0 and writes nothing: SmallPairEvents, launched after this kernel, takes it.
+constexpr int kGrpEvents = 16;
+constexpr int kGrpPieces = 32;
+constexpr int kGrpGenomes = 1024;      // (the piece numbers of one region's genomes sit in LDS)
+PM_HD void lds_min32(int32_t* p, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
+PM_HD int32_t lds_add32(int32_t* p, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, v);
+#else
+    const int32_t o = *p; *p = o + v; return o;
+#endif
+}
+struct GroupedPairEvents {
+    Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen; const int32_t* rep;
+    uint64_t* ev_key; uint64_t* ev_val; uint64_t* block_count; uint64_t ev_cap; int lbits; int64_t* glo; int32_t g_first, g_last;
+    uint8_t* flag;      // [region] = 1: its events are in the grouped array (0: not a small region, or more pieces / events than fit)
+    PM_HD void wave(int64_t r) const {
+        const int32_t nq = ngen - 1;
+        const int per = (nq + 63) / 64;
+        const RegionInfo& ri = R[r];
+        const int32_t nR = ri.nR, L = ri.minlen;
+        const int64_t rbase = P.goff[0] + ri.ref_pos;
+        uint32_t big = nR > 128 ? 1u : 0u;      // every pair must fit 128 bases on both sides (small_pair)
+        lanes_for(1, ngen, [&](int g) { if (lens[r * ngen + g] > 128) big = 1; });
+        big = wave_or_u32(big);
+        if (big) { if (wave_leader()) flag[r] = 0; return; }
+        PM_WAVE_SHARED uint64_t sh_pl[64][6];         // the lanes' pieces of the running round
+        PM_WAVE_SHARED int32_t sh_m[64];              // ... their lengths (-1: no genome)
+        PM_WAVE_SHARED uint8_t sh_open[64];           // ... not numbered yet
+        PM_WAVE_SHARED uint64_t rp_pl[kGrpPieces][6]; // the distinct pieces
+        PM_WAVE_SHARED int32_t rp_m[kGrpPieces];
+        PM_WAVE_SHARED int32_t rp_g[kGrpPieces];      // a genome that holds the piece
+        PM_WAVE_SHARED uint8_t sh_piece[kGrpGenomes]; // genome -> number of its piece
+        PM_WAVE_SHARED uint32_t sh_ev[2 * kGrpPieces][kGrpEvents];
+        PM_WAVE_SHARED int32_t sh_cnt[2 * kGrpPieces];
+        PM_WAVE_SHARED int32_t sh_tot[64];
+        PM_WAVE_SHARED int32_t sh_elect;
+        PM_WAVE_SHARED int32_t sh_bad;
+        PM_WAVE_SHARED uint64_t sh_base;
+        if (wave_leader()) sh_bad = 0;
+        int npieces = 0;      // (the same in every lane)
+        // 1. number the pieces
+        for (int k = 0; k < per; k++) {
+            wave_sync();
+            lanes_for(0, 64, [&](int t) {
+                const int g = 1 + t * per + k;
+                int32_t m = -1;
+                if (g < ngen) {
+                    m = (int32_t)lens[r * ngen + g];
+                    const int64_t qpos = P.goff[2 * g] + starts[r * ngen + g];
+                    const W128 v = W128::ones(m);
+                    for (int pl = 0; pl < 3; pl++) { const W128 x = W128::load(P.blk, qpos, pl) & v; sh_pl[t][2 * pl] = x.lo; sh_pl[t][2 * pl + 1] = x.hi; }
+                }
+                sh_m[t] = m;
+                uint8_t open = m >= 0;
+                for (int i = 0; i < npieces && open; i++) {
+                    if (rp_m[i] != m) continue;
+                    bool same = true;
+                    for (int x = 0; x < 6 && same; x++) same = rp_pl[i][x] == sh_pl[t][x];
+                    if (same) { sh_piece[g - 1] = (uint8_t)i; open = 0; }
+                }
+                sh_open[t] = open;
+            });
+            for (;;) {      // the lanes with a piece that is not in the table: the lowest of them adds its own
+                wave_sync();
+                if (wave_leader()) sh_elect = 64;
+                wave_sync();
+                lanes_for(0, 64, [&](int t) { if (sh_open[t]) lds_min32(&sh_elect, t); });
+                wave_sync();
+                const int e = sh_elect;
+                if (e == 64) break;
+                if (npieces == kGrpPieces) { if (wave_leader()) sh_bad = 1; break; }
+                lanes_for(0, 64, [&](int t) {
+                    if (t != e) return;
+                    for (int x = 0; x < 6; x++) rp_pl[npieces][x] = sh_pl[t][x];
+                    rp_m[npieces] = sh_m[t]; rp_g[npieces] = 1 + t * per + k;
+                });
+                wave_sync();
+                lanes_for(0, 64, [&](int t) {
+                    if (!sh_open[t] || rp_m[npieces] != sh_m[t]) return;
+                    bool same = true;
+                    for (int x = 0; x < 6 && same; x++) same = rp_pl[npieces][x] == sh_pl[t][x];
+                    if (same) { sh_piece[t * per + k] = (uint8_t)npieces; sh_open[t] = 0; }
+                });
+                npieces++;
+            }
+            wave_sync();
+            if (sh_bad) break;
+        }
+        // 2. the events of every (piece, strand): the 64 lanes split the (piece, strand) tasks and, within a task, its diagonals
+        const int tasks = 2 * npieces;
+        int share = 1;
+        while (share * 2 * tasks <= 64) share *= 2;      // lanes per task
+        if (!sh_bad) {
+            lanes_for(0, tasks, [&](int wi) { sh_cnt[wi] = 0; });
+            wave_sync();
+            lanes_for(0, tasks * share, [&](int t) {
+                const int wi = t / share, sub = t % share;
+                const int g = rp_g[wi >> 1], strand = wi & 1;
+                const int32_t m = rp_m[wi >> 1];
+                if (m < L || nR < L) return;
+                const int64_t qs = starts[r * ngen + g];
+                const int64_t qbase = strand ? P.goff[2 * g + 1] + (P.glen[g] - qs - m) : P.goff[2 * g] + qs;
+                auto emit = [&](int32_t l0, int32_t j0, int32_t len) {
+                    if (len <= rep[ri.posbase + l0]) return;             // not unique in R
+                    const int32_t at = lds_add32(&sh_cnt[wi], 1);
+                    if (at < kGrpEvents) sh_ev[wi][at] = (uint32_t)l0 | ((uint32_t)j0 << 8) | ((uint32_t)len << 16);
+                };
+                if (nR <= 64 && m <= 64) pair_diagonals<W64>(P, rbase, qbase, nR, m, L, emit, sub, share);
+                else pair_diagonals<W128>(P, rbase, qbase, nR, m, L, emit, sub, share);
+            });
+            wave_sync();
+            lanes_for(0, tasks, [&](int wi) {      // in order of the reference position (a few entries: by insertion)
+                const int n = sh_cnt[wi];
+                if (n > kGrpEvents) { sh_bad = 1; return; }
+                for (int i = 1; i < n; i++) {
+                    const uint32_t e = sh_ev[wi][i];
+                    int at = i;
+                    while (at > 0 && (sh_ev[wi][at - 1] & 0xffu) > (e & 0xffu)) { sh_ev[wi][at] = sh_ev[wi][at - 1]; at--; }
+                    sh_ev[wi][at] = e;
+                }
+            });
+        }
+        wave_sync();
+        if (sh_bad) { if (wave_leader()) flag[r] = 0; return; }      // SmallPairEvents takes the region
+        // 3. the block: every lane's share, then the events of its genomes
+        lanes_for(0, 64, [&](int t) {
+            int c = 0;
+            for (int k = 0; k < per; k++) {
+                const int g = 1 + t * per + k;
+                if (g < ngen && g >= g_first && g < g_last) { const int i = sh_piece[g - 1]; c += sh_cnt[2 * i] + sh_cnt[2 * i + 1]; }
+            }
+            sh_tot[t] = c;
+        });
+        wave_sync();
+        if (wave_leader()) {
+            int total = 0;
+            for (int t = 0; t < 64; t++) { const int c = sh_tot[t]; sh_tot[t] = total; total += c; }
+            sh_base = total ? atomic_add64(block_count, (uint64_t)total) : 0;
+            flag[r] = 1;
+        }
+        wave_sync();
+        lanes_for(0, 64, [&](int t) {
+            uint64_t at0 = sh_base + (uint64_t)sh_tot[t];
+            for (int k = 0; k < per; k++) {
+                const int g = 1 + t * per + k;
+                if (g >= ngen) break;
+                const int64_t pair = r * nq + (g - 1);
+                glo[pair] = (int64_t)at0;
+                if (g < g_first || g >= g_last) continue;
+                const int i = sh_piece[g - 1];
+                const uint32_t* a = sh_ev[2 * i]; const uint32_t* b = sh_ev[2 * i + 1];
+                const int na = sh_cnt[2 * i], nb = sh_cnt[2 * i + 1], c = na + nb;
+                if (at0 + (uint64_t)c <= ev_cap) {
+                    int ia = 0, ib = 0;
+                    for (int x = 0; x < c; x++) {      // merged by (reference position, strand): the order of the sort key
+                        const bool fwd = ib >= nb || (ia < na && (a[ia] & 0xffu) <= (b[ib] & 0xffu));
+                        const uint32_t e = fwd ? a[ia++] : b[ib++];
+                        ev_key[at0 + x] = ((((uint64_t)pair << lbits) | (uint64_t)(e & 0xffu)) << 1) | (fwd ? 0ull : 1ull);
+                        ev_val[at0 + x] = ((uint64_t)((e >> 8) & 0xffu) << 32) | (uint64_t)(e >> 16);
+                    }
+                }
+                at0 += (uint64_t)c;
+            }
+        });
+    }
+};
+// tid = pair: the events of a flagged region's pair start at glo[pair] of the grouped array
+struct GroupedBounds {
+    const uint8_t* flag; const int64_t* glo; int32_t nq; int64_t* lo;
+    PM_HD void operator()(int64_t pair) const { if (flag[pair / nq]) lo[pair] = glo[pair]; }
 };
 
 // ------------------------------------------------------------------------------------------ one generation of the recursion

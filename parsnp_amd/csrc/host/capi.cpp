@@ -43,6 +43,8 @@ int pc_open_rccl(const char* ini_path, int rank, int world, const uint8_t* id, p
     return 0;
 }
 int pc_rccl_ranks(pc_run* r) { return pm_session_rccl_ranks(r->run.session); }
+// a tunable of the run's engine session (pm_session_tune, include/parsnp_mum.h): bench.py --tune, for before/after measurements
+int pc_tune(pc_run* r, const char* key, long long value) { return pm_session_tune(r->run.session, key, (int64_t)value); }
 // calcmumi on an opened run: writes <outdir>/all.mumi (rank 0 of a sharded run should be the only one to call pc_write)
 int pc_mumi(pc_run* r) { return r->run.mumi(); }
 // one pass of phases A-D; returns a JSON report (valid until the next call on this handle)

@@ -66,7 +66,7 @@ def engine_src_sha():
     import hashlib
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "parsnp_amd", "csrc", "engine")
     h = hashlib.sha256()
-    for f in ("kernels.h", "engine_core.h", "engine_hip.hip", "abi_glue.h"):
+    for f in ("kernels.h", "store_kernels.h", "engine_core.h", "engine_hip.hip", "abi_glue.h"):
         h.update(open(os.path.join(root, f), "rb").read())
     return h.hexdigest()
 

@@ -78,6 +78,59 @@ def test_batched_regions(libs):
     assert batch_case(rng, E, O, n_regions=12, glen=20000, nq=3, big_minsize=True) > 5
 
 
+def small_region_batch(rng, E, O, nq, n_regions, distinct, minsize_hi=10, low_complexity=False):
+    """a recursion-shaped batch: every region at most 128 bases in every genome, the genomes a population that carries
+    `distinct` versions of each stretch (+ a few private ones)"""
+    glen = 4000
+    ref = (random_seq(rng, 7) * (glen // 7 + 1))[:glen] if low_complexity else random_seq(rng, glen)
+    versions = [ref] + [mutate(rng, ref, sub=0.03, indel=0.0) for _ in range(distinct - 1)]      # (no indels: one window fits all)
+    qs = []
+    for g in range(nq):
+        q = bytearray(versions[int(rng.integers(0, distinct))])
+        if rng.random() < 0.1:
+            at = int(rng.integers(0, glen)); q[at:at + 1] = b"ACGT"[int(rng.integers(0, 4)):][:1]
+        if g % 5 == 4:
+            a = glen // 4; b = a + glen // 3
+            q = bytearray(bytes(q[:a]) + oracles.revcomp(bytes(q[a:b])) + bytes(q[b:]))
+        qs.append(bytes(q))
+    seqs = [ref] + qs
+    starts = np.zeros((n_regions, nq + 1), np.int64); lens = np.zeros_like(starts); mins = np.zeros(n_regions, np.int32)
+    for r in range(n_regions):
+        ln = int(rng.integers(0, 129)); st = int(rng.integers(0, glen - 140))
+        for g in range(nq + 1):
+            jitter = int(rng.integers(-3, 4)) if rng.random() < 0.2 else 0
+            lens[r, g] = max(0, min(128, ln + jitter)); starts[r, g] = st + (int(rng.integers(0, 4)) if rng.random() < 0.1 else 0)
+        mins[r] = int(rng.integers(2, minsize_hi))
+    got = {}
+    for grouped in (1, 0):
+        with Session(E, seqs) as s:
+            s.tune("group_small", grouped)
+            got[grouped] = s.multi_mum_batch(starts, lens, mins)
+            counts = dict(s.last_timing())
+        if not grouped or distinct <= 40:      # (more distinct pieces than the table holds: most regions are handed back, short ones may stay)
+            assert (counts.get("n_grouped", 0) > 0) == bool(grouped), counts
+    n = 0
+    for r in range(n_regions):
+        assert same(got[0][r], got[1][r]), (r, starts[r], lens[r], mins[r])
+        if r % 4 == 0:
+            sub = [seqs[g][starts[r, g]:starts[r, g] + lens[r, g]] for g in range(nq + 1)]
+            want = oracles.restatement_multi_mum(O, sub, int(mins[r]), 1)
+            assert same(want, got[1][r]), (r, starts[r], lens[r], mins[r])
+            n += len(want[0])
+    return n
+
+
+@pytest.mark.parametrize("nq,distinct,low", [(5, 2, False), (63, 4, False), (64, 3, False), (70, 6, False), (150, 5, False), (200, 80, False), (200, 28, False), (40, 3, True)])
+def test_small_regions_once_per_distinct_piece(libs, nq, distinct, low):
+    """GroupedPairEvents (store_kernels.h): the events of a batch's small regions computed once per distinct query piece and
+    laid out per pair without the sort -- the same multi-MUMs as pair by pair (group_small = 0) and as the restatement; with
+    more genomes than lanes, with more distinct pieces than the table holds (80 versions) and with more events per piece than
+    the lists hold (a 7-base tandem repeat), where a region is handed back to SmallPairEvents"""
+    E, O = libs
+    rng = np.random.default_rng(1000 + nq)
+    assert small_region_batch(rng, E, O, nq, 48 if nq < 100 else 24, distinct, low_complexity=low) >= (0 if low or distinct > 20 else 5)
+
+
 def test_long_minimum_lengths(libs):
     """minsize > 47 makes the sampling stride exceed one 32-base window (left arm continues from memory), and matches
     longer than the 64 prefetched bases continue from memory on the right"""

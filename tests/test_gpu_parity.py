@@ -68,6 +68,15 @@ def test_batched_regions(libs):
     assert T.batch_case(rng, H, O, n_regions=24, glen=40000, nq=4, big_minsize=True) > 10
 
 
+@pytest.mark.parametrize("nq,distinct,low", [(5, 2, False), (64, 3, False), (70, 6, False), (150, 5, False), (200, 80, False), (200, 28, False), (300, 9, False), (40, 3, True)])
+def test_small_regions_once_per_distinct_piece(libs, nq, distinct, low):
+    """GroupedPairEvents on the device (one wavefront per small region: pieces numbered through LDS, one diagonal scan per
+    distinct piece and strand, per-pair event blocks without the sort) against pair by pair and the restatement"""
+    H, O = libs
+    rng = np.random.default_rng(2000 + nq)
+    assert T.small_region_batch(rng, H, O, nq, 64 if nq < 100 else 32, distinct, low_complexity=low) >= (0 if low or distinct > 20 else 5)
+
+
 def test_empty_and_ragged(libs):
     H, O = libs
     seqs = [b"ACGTACGTTTGACCA", b"", b"ACGTACGTTTGACCA", b"N" * 40, b"TGGTCAAACGTACGT"]
