@@ -457,7 +457,7 @@ public:
         const int64_t nscan = ((int64_t)nev + kChunk - 1) / kChunk;
         ensure(d_summary, (size_t)std::max<int64_t>(nscan, 1)); ensure(d_startshere, (size_t)std::max<int64_t>(nscan, 1));
         be.launch("chunk_reduce", nscan, ChunkReduce{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p});
-        be.launch("chunk_scan", nscan, ChunkScan{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p, d_state.p, d_emax.p});
+        be.launch("chunk_scan", nscan, ChunkScan{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p, d_state.p, d_emax.p, d_R.p, nq, d_rep.p});
 
         if (want_events) {   // parity hook (pm_find_events): sorted events + rep'
             ev_key_h.resize((size_t)nev); ev_val_h.resize((size_t)nev); rep_h.resize((size_t)npos);
@@ -1046,7 +1046,7 @@ private:
     Buf<uint64_t> d_slots; Buf<uint32_t> d_filter, d_repeated; Buf<int32_t> d_next, d_rep, d_run, d_epm;
     Buf<int64_t> d_ucount, d_uoff; Buf<UnitRec> d_units;
     Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2, d_evkey3, d_evval3; Buf<int64_t> d_sliceoff;
-    Buf<int64_t> d_lo, d_cov; Buf<EventState> d_state, d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
+    Buf<int64_t> d_lo, d_cov; Buf<EventAtK> d_state; Buf<EventState> d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
     Buf<uint64_t> d_cand; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
     Buf<uint64_t> d_wmask; Buf<int64_t> d_wcount, d_woff;
     Buf<int64_t> d_okcnt, d_okpos, d_cbase; Buf<int32_t> d_coarse; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;

@@ -1189,6 +1189,11 @@ struct PairBounds {
 };
 struct StrandState { int32_t e1, e2, w; };
 struct EventState { StrandState s[2]; };
+// what the scan leaves per event for the readers (the fold, the MUMi coverage): per strand, over the pair's events up to this
+// one, EP = e1, UP = max(l_w + rep[l_w], e2) and SP - k = j_w - l_w of the winner -- resolved here, once per event, instead of
+// three dependent loads (winner's key, value, repeat length) per strand, candidate and genome in the fold.  e1 == 0: no event.
+struct StrandAtK { int32_t e1, up, spb; };
+struct EventAtK { StrandAtK s[2]; };
 #ifndef PM_CHUNK
 #define PM_CHUNK 128
 #endif
@@ -1252,12 +1257,15 @@ struct ChunkReduce {
 //   EP[k] = e1, UP[k] = max(l_w + rep[l_w], e2), SP[k] = j_w + (k - l_w).
 struct ChunkScan {
     const uint64_t* key; const uint64_t* val; int64_t nev; int lbits; const EventState* summary; const uint8_t* starts_here;
-    EventState* st; int32_t* emax;
+    EventAtK* st; int32_t* emax;
+    const RegionInfo* R; int32_t nq; const int32_t* rep;
     PM_HD void operator()(int64_t c) const {
         const uint64_t lmask = (1ull << lbits) - 1;
         int64_t a = c * kChunk, b = a + kChunk < nev ? a + kChunk : nev;
         EventState cur; cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1};
         uint64_t pair = key[a] >> (lbits + 1);
+        int64_t posbase = R[(int64_t)pair / nq].posbase;
+        int32_t up0 = 0, up1 = 0, spb0 = 0, spb1 = 0;      // of the strands' winners: l_w + rep[l_w] and j_w - l_w
         if (a > 0 && (key[a - 1] >> (lbits + 1)) == pair) {
             // the pair began in an earlier chunk: fold the summaries back to (and including) the chunk it starts in
             for (int64_t p = c - 1; p >= 0; p--) {
@@ -1265,16 +1273,31 @@ struct ChunkScan {
                 cur.s[1] = state_join(summary[p].s[1], cur.s[1], key, val, lmask);
                 if (starts_here[p]) break;
             }
+            if (cur.s[0].w >= 0) { const int32_t wl = (int32_t)((key[cur.s[0].w] >> 1) & lmask); up0 = wl + rep[posbase + wl]; spb0 = (int32_t)(val[cur.s[0].w] >> 32) - wl; }
+            if (cur.s[1].w >= 0) { const int32_t wl = (int32_t)((key[cur.s[1].w] >> 1) & lmask); up1 = wl + rep[posbase + wl]; spb1 = (int32_t)(val[cur.s[1].w] >> 32) - wl; }
         }
+        // (the repeat length of an event's own position is loaded with the event, one event ahead: a load that waited for the
+        // verdict of state_push would put a trip to memory into every step of this sequential loop)
+        uint64_t k = key[a], v = val[a];
+        int32_t rp = rep[posbase + (int32_t)((k >> 1) & lmask)];
         for (int64_t i = a; i < b; i++) {
-            uint64_t k = key[i], v = val[i];
+            uint64_t kn = 0, vn = 0; int32_t rpn = 0; int64_t posbase_n = posbase;
+            if (i + 1 < b) {
+                kn = key[i + 1]; vn = val[i + 1];
+                if ((kn >> (lbits + 1)) != (k >> (lbits + 1))) posbase_n = R[(int64_t)(kn >> (lbits + 1)) / nq].posbase;
+                rpn = rep[posbase_n + (int32_t)((kn >> 1) & lmask)];
+            }
             if ((k >> (lbits + 1)) != pair) { pair = k >> (lbits + 1); cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1}; }
-            int32_t l = (int32_t)((k >> 1) & lmask);
+            const int32_t l = (int32_t)((k >> 1) & lmask), j = (int32_t)(v >> 32);
             // (a strand chosen by an index would put `cur` into LDS: the compiler promotes a dynamically indexed private array)
-            if (k & 1) state_push(cur.s[1], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
-            else state_push(cur.s[0], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
-            st[i] = cur;
+            if (k & 1) { state_push(cur.s[1], key, val, lmask, i, l, j, l + (int32_t)(v & 0xffffffffu)); if (cur.s[1].w == (int32_t)i) { up1 = l + rp; spb1 = j - l; } }
+            else { state_push(cur.s[0], key, val, lmask, i, l, j, l + (int32_t)(v & 0xffffffffu)); if (cur.s[0].w == (int32_t)i) { up0 = l + rp; spb0 = j - l; } }
+            EventAtK o;
+            o.s[0] = cur.s[0].w < 0 ? StrandAtK{0, 0, 0} : StrandAtK{cur.s[0].e1, cur.s[0].e2 > up0 ? cur.s[0].e2 : up0, spb0};
+            o.s[1] = cur.s[1].w < 0 ? StrandAtK{0, 0, 0} : StrandAtK{cur.s[1].e1, cur.s[1].e2 > up1 ? cur.s[1].e2 : up1, spb1};
+            st[i] = o;
             emax[i] = cur.s[0].e1 > cur.s[1].e1 ? cur.s[0].e1 : cur.s[1].e1;
+            k = kn; v = vn; rp = rpn; posbase = posbase_n;
         }
     }
 };
@@ -1286,7 +1309,7 @@ struct ChunkScan {
 // the number of marked positions.  (UP,EP) only change where an event starts, so the scan runs over events.
 // tid = pair (region 0, query genome).
 struct MumiCoverage {
-    const RegionInfo* R; const uint64_t* key; const uint64_t* val; const int64_t* lo; const EventState* st; const int32_t* rep;
+    const RegionInfo* R; const uint64_t* key; const uint64_t* val; const int64_t* lo; const EventAtK* st; const int32_t* rep;
     int lbits; int32_t ngen; int64_t* covered;
     PM_HD void operator()(int64_t pair) const {
         const RegionInfo& ri = R[pair / (ngen - 1)];
@@ -1297,15 +1320,8 @@ struct MumiCoverage {
             int32_t l = (int32_t)((key[i] >> 1) & lmask);
             int32_t lnext = i + 1 < b ? (int32_t)((key[i + 1] >> 1) & lmask) : ri.nR;
             if (lnext == l) continue;                    // the state after the last event starting at l is the one at k = l
-            const EventState& s = st[i];
-            int32_t ep[2] = {0, 0}, up[2] = {0, 0};
-            for (int sd = 0; sd < 2; sd++) {
-                if (s.s[sd].w < 0) continue;
-                int32_t wl = (int32_t)((key[s.s[sd].w] >> 1) & lmask);
-                ep[sd] = s.s[sd].e1;
-                up[sd] = wl + rep[ri.posbase + wl];
-                if (s.s[sd].e2 > up[sd]) up[sd] = s.s[sd].e2;
-            }
+            const EventAtK& s = st[i];
+            const int32_t ep[2] = {s.s[0].e1, s.s[1].e1}, up[2] = {s.s[0].up, s.s[1].up};      // (no event on a strand: 0, 0)
             int c = ep[0] > ep[1] ? 0 : 1;               // Merge_Master: forward only if strictly better
             int32_t EP = ep[c], UP = up[c];
             if (!(EP > last_ep && UP < EP)) continue;
@@ -1510,7 +1526,7 @@ struct CandWrite {
 struct GenomeAtK { int32_t epf, upf, spf, epr, upr, spr; };
 // both strands of query genome g (0-based) at candidate (r, k): the propagated Pair[k] / SP[k] of Find_UM + Intersect_UM
 PM_HD GenomeAtK state_at(const RegionInfo& ri, int64_t r, int32_t k, int g, int32_t nq, const uint64_t* key, const uint64_t* val,
-                         const int64_t* lo, const EventState* st, const int32_t* rep, int lbits, const int64_t* cbase, const int32_t* coarse) {
+                         const int64_t* lo, const EventAtK* st, const int32_t* rep, int lbits, const int64_t* cbase, const int32_t* coarse) {
     const int64_t pair = r * nq + g;
     const int32_t* row = coarse + cbase[r] * nq + (int64_t)(k >> kCoarseShift) * nq;
     const int64_t first = lo[pair];
@@ -1519,17 +1535,9 @@ PM_HD GenomeAtK state_at(const RegionInfo& ri, int64_t r, int32_t k, int g, int3
     while (a < b) { const int64_t mid = (a + b) >> 1; if (key[mid] <= want) a = mid + 1; else b = mid; }
     GenomeAtK o{0, 0, 0, 0, 0, 0};
     if (a > first) {
-        const EventState s = st[a - 1];
-        const uint64_t lmask = (1ull << lbits) - 1;
-        for (int sd = 0; sd < 2; sd++) {
-            if (s.s[sd].w < 0) continue;
-            const uint64_t wk = key[s.s[sd].w], wv = val[s.s[sd].w];
-            const int32_t wl = (int32_t)((wk >> 1) & lmask), wj = (int32_t)(wv >> 32);
-            int32_t up = wl + rep[ri.posbase + wl];
-            if (s.s[sd].e2 > up) up = s.s[sd].e2;
-            if (sd == 0) { o.epf = s.s[0].e1; o.upf = up; o.spf = wj + (k - wl); }
-            else { o.epr = s.s[1].e1; o.upr = up; o.spr = wj + (k - wl); }
-        }
+        const EventAtK s = st[a - 1];
+        if (s.s[0].e1) { o.epf = s.s[0].e1; o.upf = s.s[0].up; o.spf = s.s[0].spb + k; }
+        if (s.s[1].e1) { o.epr = s.s[1].e1; o.upr = s.s[1].up; o.spr = s.s[1].spb + k; }
     }
     return o;
 }
@@ -1537,7 +1545,7 @@ PM_HD GenomeAtK state_at(const RegionInfo& ri, int64_t r, int32_t k, int g, int3
 // the fold); an unsharded run computes the states inside FoldCandidates.
 struct StateAtCandidate {
     const RegionInfo* R; const uint64_t* cand; int32_t ngen; const uint64_t* key; const uint64_t* val; const int64_t* lo;
-    const EventState* st; const int32_t* rep; int lbits; GenomeAtK* out;
+    const EventAtK* st; const int32_t* rep; int lbits; GenomeAtK* out;
     const int64_t* cbase; const int32_t* coarse;
     PM_HD void operator()(int64_t tid) const {
         const int32_t nq = ngen - 1;
@@ -1578,7 +1586,7 @@ struct UnpackStates {
 // the strand, as before; and out_ok / k / lon per candidate.
 struct FoldCandidates {
     const RegionInfo* R; const uint64_t* cand; int32_t ngen; const GenomeAtK* at;
-    const uint64_t* key; const uint64_t* val; const int64_t* lo; const EventState* st; const int32_t* rep; int lbits;
+    const uint64_t* key; const uint64_t* val; const int64_t* lo; const EventAtK* st; const int32_t* rep; int lbits;
     const int64_t* cbase; const int32_t* coarse;
     int32_t* out_k; int32_t* out_lon; int32_t* out_sp; uint8_t* out_fwd; uint8_t* out_ok;
     PM_HD void wave(int64_t c) const {
