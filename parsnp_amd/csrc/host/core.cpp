@@ -95,6 +95,7 @@ int CoreRun::open(const std::string& ini_path) {
     // genomes -> HBM (2-bit + N mask, both strands); the engine addresses regions by coordinates from here on
     const double t1 = now_s();
     (void)gpu_ready.get();      // a failure shows up again, with its message, in the session call below
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[upload] waited %.4f s for the GPU runtime (started beside the ingest, %.4f s ago)\n", now_s() - t1, now_s() - t0);
     std::vector<const uint8_t*> ptr(genomes.size());
     std::vector<int64_t> len(genomes.size());
     for (size_t i = 0; i < genomes.size(); i++) { ptr[i] = (const uint8_t*)genomes[i].seq.data(); len[i] = (int64_t)genomes[i].seq.size(); }
