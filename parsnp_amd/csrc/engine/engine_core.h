@@ -389,10 +389,11 @@ public:
             if (again) be.memset(d_counter.p, 0, 8 * ncounter);      // event counters, error word, grouped events
             if (grouping) {
                 ensure(d_evkey3, grp_cap + ev_cap_hint); ensure(d_evval3, grp_cap + ev_cap_hint);
+                ensure(d_state, grp_cap + ev_cap_hint); ensure(d_emax, grp_cap + ev_cap_hint);
                 be.mark("grouped_events");
                 be.launch_wave("grouped_pair_events", nreg,
                                GroupedPairEvents{P, d_R.p, d_starts.p, d_lens.p, ngen, d_rep.p, d_evkey3.p, d_evval3.p, d_counter.p + kGrpSlot, (uint64_t)grp_cap, lbits,
-                                                 d_glo.p, g_first, g_last, d_gflag.p});
+                                                 d_glo.p, g_first, g_last, d_gflag.p, d_state.p, d_emax.p, d_epm.p});
             }
             be.memset(d_qcount.p, 0, 8 * (size_t)kSlices * kSliceStride);
             be.mark("seed_extend");
@@ -453,11 +454,13 @@ public:
         nev += ngrp;
         be.launch("pair_bounds", npairs, PairBounds{skey, (int64_t)nev, lbits, npairs, d_lo.p, (int64_t)ngrp});
         if (grouping) be.launch("grouped_bounds", npairs, GroupedBounds{d_gflag.p, d_glo.p, nq, d_lo.p});
-        ensure(d_state, std::max<size_t>(nev, 1)); ensure(d_emax, std::max<size_t>(nev, 1));
-        const int64_t nscan = ((int64_t)nev + kChunk - 1) / kChunk;
+        // (the grouped events came with their states: the scan runs over the sorted part, its event numbers relative to it)
+        ensure_keep(d_state, std::max<size_t>(nev, 1), (size_t)ngrp); ensure_keep(d_emax, std::max<size_t>(nev, 1), (size_t)ngrp);
+        const int64_t nsorted = (int64_t)(nev - ngrp);
+        const int64_t nscan = (nsorted + kChunk - 1) / kChunk;
         ensure(d_summary, (size_t)std::max<int64_t>(nscan, 1)); ensure(d_startshere, (size_t)std::max<int64_t>(nscan, 1));
-        be.launch("chunk_reduce", nscan, ChunkReduce{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p});
-        be.launch("chunk_scan", nscan, ChunkScan{skey, sval, (int64_t)nev, lbits, d_summary.p, d_startshere.p, d_state.p, d_emax.p, d_R.p, nq, d_rep.p});
+        be.launch("chunk_reduce", nscan, ChunkReduce{skey + ngrp, sval + ngrp, nsorted, lbits, d_summary.p, d_startshere.p});
+        be.launch("chunk_scan", nscan, ChunkScan{skey + ngrp, sval + ngrp, nsorted, lbits, d_summary.p, d_startshere.p, d_state.p + ngrp, d_emax.p + ngrp, d_R.p, nq, d_rep.p});
 
         if (want_events) {   // parity hook (pm_find_events): sorted events + rep'
             ev_key_h.resize((size_t)nev); ev_val_h.resize((size_t)nev); rep_h.resize((size_t)npos);
@@ -497,7 +500,7 @@ public:
         ensure(d_coarse, (size_t)std::max<int64_t>(centries, 1));
         be.memset(d_coarse.p, 0, 4 * (size_t)std::max<int64_t>(centries, 1));
         be.launch("coarse_fill", (int64_t)nev, CoarseFill{skey, (int64_t)nev, lbits, d_lo.p, d_R.p, d_cbase.p, nq, d_coarse.p});
-        be.launch_wave("master_ep", nchunks, MasterEP{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last});
+        be.launch_wave("master_ep", nchunks, MasterEP{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, grouping ? d_gflag.p : nullptr});
         int32_t verdict = 0;
         if (sharded && coll.device) {   // exchange 1 on the device: RCCL all-reduce(min) of Master.EP in place, + the error verdict word
             be.mark("exchange_ep");

@@ -1387,9 +1387,11 @@ struct MasterEP {
     int32_t ngen; const uint64_t* key; const int64_t* lo; const int32_t* emax; int lbits; int32_t* epm;
     const int64_t* cbase; const int32_t* coarse;
     int32_t g_first, g_last;   // sharded run: the min over the other genomes arrives by all-reduce
+    const uint8_t* grouped;    // [region] != 0: GroupedPairEvents (store_kernels.h) has written the region's Master.EP; nullptr: none
     PM_HD void wave(int64_t w) const {
         const int32_t nq = ngen - 1;
         const int64_t r = region_of_chunk(cbase, nregions, w);
+        if (grouped && grouped[r]) return;
         const RegionInfo& ri = R[r];
         const int64_t b = w - (cbase[r] - r);
         const int32_t k0 = (int32_t)(b << kCoarseShift);

@@ -545,6 +545,8 @@ struct GroupedPairEvents {
     Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen; const int32_t* rep;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* block_count; uint64_t ev_cap; int lbits; int64_t* glo; int32_t g_first, g_last;
     uint8_t* flag;      // [region] = 1: its events are in the grouped array (0: not a small region, or more pieces / events than fit)
+    EventAtK* st; int32_t* emax;      // what ChunkScan would leave for these events (kernels.h), written with them
+    int32_t* epm;                     // Master.EP of the region's positions (MasterEP, kernels.h): min over the genomes of this rank
     PM_HD void wave(int64_t r) const {
         const int32_t nq = ngen - 1;
         const int per = (nq + 63) / 64;
@@ -564,11 +566,14 @@ struct GroupedPairEvents {
         PM_WAVE_SHARED uint8_t sh_piece[kGrpGenomes]; // genome -> number of its piece
         PM_WAVE_SHARED uint32_t sh_ev[2 * kGrpPieces][kGrpEvents];
         PM_WAVE_SHARED int32_t sh_cnt[2 * kGrpPieces];
+        PM_WAVE_SHARED uint32_t sh_st[2 * kGrpPieces][kGrpEvents];      // the strand's state after each of its events: e1 | up << 8 | (spb + 128) << 16
+        PM_WAVE_SHARED uint8_t sh_used[kGrpPieces];                      // a genome of this rank holds the piece
         PM_WAVE_SHARED int32_t sh_tot[64];
         PM_WAVE_SHARED int32_t sh_elect;
         PM_WAVE_SHARED int32_t sh_bad;
         PM_WAVE_SHARED uint64_t sh_base;
         if (wave_leader()) sh_bad = 0;
+        lanes_for(0, kGrpPieces, [&](int i) { sh_used[i] = 0; });
         int npieces = 0;      // (the same in every lane)
         // 1. number the pieces
         for (int k = 0; k < per; k++) {
@@ -654,16 +659,48 @@ struct GroupedPairEvents {
         }
         wave_sync();
         if (sh_bad) { if (wave_leader()) flag[r] = 0; return; }      // SmallPairEvents takes the region
+        // 2b. the running state of every (piece, strand) after each of its events, as state_push keeps it (kernels.h: furthest
+        // end e1 and its event w -- first in (l, j) order on equal ends -- and the second furthest end e2), resolved as ChunkScan
+        // leaves it: EP = e1, UP = max(l_w + rep'[l_w], e2), SP - k = j_w - l_w.  All of them at most 128: one word per event.
+        lanes_for(0, tasks, [&](int wi) {
+            const int n = sh_cnt[wi];
+            int32_t e1 = 0, e2 = 0, wl = 0, wj = 0, up = 0; bool have = false;
+            for (int i = 0; i < n; i++) {
+                const uint32_t e = sh_ev[wi][i];
+                const int32_t l = (int32_t)(e & 0xffu), j = (int32_t)((e >> 8) & 0xffu), end = l + (int32_t)(e >> 16);
+                const bool take = !have || end > e1 || (end == e1 && (l < wl || (l == wl && j < wj)));
+                if (take) { if (have && e1 > e2) e2 = e1; e1 = end; wl = l; wj = j; up = l + rep[ri.posbase + l]; have = true; }
+                else if (end > e2) e2 = end;
+                sh_st[wi][i] = (uint32_t)e1 | ((uint32_t)(e2 > up ? e2 : up) << 8) | ((uint32_t)(wj - wl + 128) << 16);
+            }
+        });
         // 3. the block: every lane's share, then the events of its genomes
         lanes_for(0, 64, [&](int t) {
             int c = 0;
             for (int k = 0; k < per; k++) {
                 const int g = 1 + t * per + k;
-                if (g < ngen && g >= g_first && g < g_last) { const int i = sh_piece[g - 1]; c += sh_cnt[2 * i] + sh_cnt[2 * i + 1]; }
+                if (g < ngen && g >= g_first && g < g_last) { const int i = sh_piece[g - 1]; c += sh_cnt[2 * i] + sh_cnt[2 * i + 1]; sh_used[i] = 1; }
             }
             sh_tot[t] = c;
         });
         wave_sync();
+        // Master.EP of the region (MasterEP's fold): a genome's EP at k = the furthest end over its events that start at or before
+        // k, 0 without one; the minimum over the genomes of this rank = over the pieces they hold
+        lanes_for(0, nR, [&](int k) {
+            int32_t ep = nR;
+            for (int i = 0; i < npieces; i++) {
+                if (!sh_used[i]) continue;
+                int32_t v = 0;
+                for (int sd = 0; sd < 2; sd++) {
+                    const int wi = 2 * i + sd, n = sh_cnt[wi];
+                    int32_t e = 0;
+                    for (int x = 0; x < n && (int32_t)(sh_ev[wi][x] & 0xffu) <= k; x++) e = (int32_t)(sh_st[wi][x] & 0xffu);
+                    if (e > v) v = e;
+                }
+                if (v < ep) ep = v;
+            }
+            epm[ri.posbase + k] = ep;
+        });
         if (wave_leader()) {
             int total = 0;
             for (int t = 0; t < 64; t++) { const int c = sh_tot[t]; sh_tot[t] = total; total += c; }
@@ -689,6 +726,12 @@ struct GroupedPairEvents {
                         const uint32_t e = fwd ? a[ia++] : b[ib++];
                         ev_key[at0 + x] = ((((uint64_t)pair << lbits) | (uint64_t)(e & 0xffu)) << 1) | (fwd ? 0ull : 1ull);
                         ev_val[at0 + x] = ((uint64_t)((e >> 8) & 0xffu) << 32) | (uint64_t)(e >> 16);
+                        const uint32_t sf = ia ? sh_st[2 * i][ia - 1] : 0, sr = ib ? sh_st[2 * i + 1][ib - 1] : 0;      // (e1 = 0: no event yet)
+                        EventAtK o;
+                        o.s[0] = sf ? StrandAtK{(int32_t)(sf & 0xffu), (int32_t)((sf >> 8) & 0xffu), (int32_t)(sf >> 16) - 128} : StrandAtK{0, 0, 0};
+                        o.s[1] = sr ? StrandAtK{(int32_t)(sr & 0xffu), (int32_t)((sr >> 8) & 0xffu), (int32_t)(sr >> 16) - 128} : StrandAtK{0, 0, 0};
+                        st[at0 + x] = o;
+                        emax[at0 + x] = o.s[0].e1 > o.s[1].e1 ? o.s[0].e1 : o.s[1].e1;
                     }
                 }
                 at0 += (uint64_t)c;
