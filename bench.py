@@ -468,7 +468,7 @@ def main():
             models = {
                 "seed_extend": ("SeedExtend + SeedRest + SmallPairEvents", alg_step, "(m + n)/2 per (region, query genome) + 64 B per sampled K-mer + 16 B per event"),
                 "sort": ("SliceOffsets + CompactEvents + rocPRIM radix sort (onesweep)", 64.0 * ev, "gather 32 B + one read and one write of the 16-byte record per event (a radix sort of 32-bit keys makes 4 such passes)"),
-                "scan": ("PairBounds + ChunkReduce + ChunkScan", 48.0 * ev, "16 B read + 32 B of running state written per event"),
+                "scan": ("PairBounds + WaveSummary + WaveScan", 60.0 * ev, "16 B read twice (summary pass, scan pass) + 28 B of resolved state written per event"),
                 "master_ep": ("CoarseFill + MasterEP", 12.0 * ev + 4.0 * npos, "12 B per event + 4 B per reference position"),
                 "fold": ("FoldCandidates", 69.0 * ncand * G, "per (candidate, query genome): 28 B running state + 2 x (16 B winner + 4 B repeat length) in, 5 B out"),
                 "compact": ("CompactCandidates + Dirty* + store append", (5.0 * ncand * G) + 3 * 5.0 * nacc * ngen, "5 B in per (candidate, genome); 5 B per (accepted row, genome) out, once more read by the overlap flags and once copied into the MUM store"),

@@ -457,10 +457,13 @@ public:
         // (the grouped events came with their states: the scan runs over the sorted part, its event numbers relative to it)
         ensure_keep(d_state, std::max<size_t>(nev, 1), (size_t)ngrp); ensure_keep(d_emax, std::max<size_t>(nev, 1), (size_t)ngrp);
         const int64_t nsorted = (int64_t)(nev - ngrp);
-        const int64_t nscan = (nsorted + kChunk - 1) / kChunk;
-        ensure(d_summary, (size_t)std::max<int64_t>(nscan, 1)); ensure(d_startshere, (size_t)std::max<int64_t>(nscan, 1));
-        be.launch("chunk_reduce", nscan, ChunkReduce{skey + ngrp, sval + ngrp, nsorted, lbits, d_summary.p, d_startshere.p});
-        be.launch("chunk_scan", nscan, ChunkScan{skey + ngrp, sval + ngrp, nsorted, lbits, d_summary.p, d_startshere.p, d_state.p + ngrp, d_emax.p + ngrp, d_R.p, nq, d_rep.p});
+        if (nsorted > 0) {
+            const int64_t nwaves = (nsorted + kWaveEvents - 1) / kWaveEvents;
+            ensure(d_wsummary, (size_t)nwaves);
+            const WaveScanCore core{skey + ngrp, sval + ngrp, nsorted, lbits, d_R.p, nq, d_rep.p};
+            be.launch_wave("wave_summary", nwaves, WaveSummary{core, d_wsummary.p});
+            be.launch_wave("wave_scan", nwaves, WaveScan{core, d_wsummary.p, d_lo.p, (int64_t)ngrp, d_state.p + ngrp, d_emax.p + ngrp});
+        }
 
         if (want_events) {   // parity hook (pm_find_events): sorted events + rep'
             ev_key_h.resize((size_t)nev); ev_val_h.resize((size_t)nev); rep_h.resize((size_t)npos);
@@ -1049,7 +1052,7 @@ private:
     Buf<uint64_t> d_slots; Buf<uint32_t> d_filter, d_repeated; Buf<int32_t> d_next, d_rep, d_run, d_epm;
     Buf<int64_t> d_ucount, d_uoff; Buf<UnitRec> d_units;
     Buf<uint64_t> d_counter, d_evkey, d_evval, d_evkey2, d_evval2, d_evkey3, d_evval3; Buf<int64_t> d_sliceoff;
-    Buf<int64_t> d_lo, d_cov; Buf<EventAtK> d_state; Buf<EventState> d_summary; Buf<int32_t> d_emax; Buf<uint8_t> d_startshere;
+    Buf<int64_t> d_lo, d_cov; Buf<EventAtK> d_state; Buf<PairState> d_wsummary; Buf<int32_t> d_emax;
     Buf<uint64_t> d_cand; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
     Buf<uint64_t> d_wmask; Buf<int64_t> d_wcount, d_woff;
     Buf<int64_t> d_okcnt, d_okpos, d_cbase; Buf<int32_t> d_coarse; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;

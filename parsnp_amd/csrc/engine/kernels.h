@@ -162,6 +162,7 @@ PM_HD void atomic_or64(uint64_t* p, uint64_t v) {
 // `operator()(tid)`); lanes cooperate through shuffles and LDS.  The host emulation (tests only) runs `wave(w)` as one
 // sequential loop that computes the same values.
 #if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline bool wave_leader_k() { return __lane_id() == 0; }
 __device__ inline int32_t wave_incl_sum(int32_t x) {
     const int lane = (int)__lane_id();
     for (int d = 1; d < 64; d <<= 1) { const int32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
@@ -188,6 +189,8 @@ __device__ inline uint32_t wave_all_or(uint32_t x) {
     for (int d = 32; d >= 1; d >>= 1) x |= (uint32_t)__shfl_xor((int)x, d, 64);
     return x;
 }
+#else
+inline bool wave_leader_k() { return true; }
 #endif
 
 // ------------------------------------------------------------------------------------------ shared structures
@@ -1187,118 +1190,142 @@ struct PairBounds {
         if (pair == npairs - 1) lo[npairs] = nev;
     }
 };
-struct StrandState { int32_t e1, e2, w; };
-struct EventState { StrandState s[2]; };
 // what the scan leaves per event for the readers (the fold, the MUMi coverage): per strand, over the pair's events up to this
 // one, EP = e1, UP = max(l_w + rep[l_w], e2) and SP - k = j_w - l_w of the winner -- resolved here, once per event, instead of
 // three dependent loads (winner's key, value, repeat length) per strand, candidate and genome in the fold.  e1 == 0: no event.
 struct StrandAtK { int32_t e1, up, spb; };
 struct EventAtK { StrandAtK s[2]; };
-#ifndef PM_CHUNK
-#define PM_CHUNK 128
+// ------------------------------------------------------------------------------------------ the scan, a wavefront at a time
+// Test_UM (mum.c:27-45) + the forward carry of Intersect_UM (mum.c:125-175) in closed form (SURVEY 3.3-3,-4): per strand, over a
+// pair's events with l <= k,
+//   e1 = furthest end, w = the event that reaches it (first in (l, j) order on equal ends), e2 = second furthest end;
+//   EP[k] = e1, UP[k] = max(l_w + rep'[l_w], e2), SP[k] = j_w + (k - l_w).
+// Adding an event to that state is an associative fold -- join(state, the state of the one event) -- so the running state of
+// every event is a SEGMENTED INCLUSIVE SCAN over the sorted events, segments = pairs: one lane per event, 64 consecutive events
+// per round (coalesced loads, 1.5 KB of states stored per instruction), six shuffle steps per round, the last lane's state
+// carried into the next round.  The state carries its winner's (l, j, rep') along, so the ties of equal reach are settled
+// without a load and the resolved record (EP, UP, SP - k) falls out of the registers.  A wavefront takes kWaveEvents consecutive
+// events; pass 1 leaves the state of every wavefront's trailing pair, pass 2 joins the summaries back to the wavefront its
+// first pair starts in (`lo`) and scans.  (Until round 4 a THREAD per 128 consecutive events: 64 lanes reading and writing 64
+// places 3 KB apart with every instruction, every step of a thread's loop a trip to memory, and a look back over up to 300
+// chunk summaries -- 0.55 ms for the anchor call's 7.7 M events against 0.28.)
+#ifndef PM_WAVE_EVENTS
+#define PM_WAVE_EVENTS 512
 #endif
-constexpr int kChunk = PM_CHUNK;   // events per scan thread
-
-// add event i to a strand state
-PM_HD void state_push(StrandState& s, const uint64_t* key, const uint64_t* val, uint64_t lmask, int64_t i, int32_t l, int32_t j, int32_t end) {
-    bool take = s.w < 0;
-    if (!take) {
-        if (end > s.e1) take = true;
-        else if (end == s.e1) {   // equal reach: the earlier (l, j) is the one Test_UM / Intersect_UM keep
-            uint64_t wk = key[s.w], wv = val[s.w];
-            int32_t wl = (int32_t)((wk >> 1) & lmask), wj = (int32_t)(wv >> 32);
-            take = l < wl || (l == wl && j < wj);
-        }
-    }
-    if (take) { if (s.w >= 0 && s.e1 > s.e2) s.e2 = s.e1; s.e1 = end; s.w = (int32_t)i; }
-    else if (end > s.e2) s.e2 = end;
-}
-// a (earlier events) followed by b (later events) of the same pair and strand
-PM_HD StrandState state_join(const StrandState& a, const StrandState& b, const uint64_t* key, const uint64_t* val, uint64_t lmask) {
-    if (a.w < 0) return b;
-    if (b.w < 0) return a;
-    bool a_wins = a.e1 > b.e1;
-    if (a.e1 == b.e1) {
-        uint64_t ak = key[a.w], bk = key[b.w];
-        int32_t al = (int32_t)((ak >> 1) & lmask), bl = (int32_t)((bk >> 1) & lmask);
-        a_wins = al < bl || (al == bl && (int32_t)(val[a.w] >> 32) <= (int32_t)(val[b.w] >> 32));
-    }
-    StrandState o;
-    if (a_wins) { o.e1 = a.e1; o.w = a.w; o.e2 = a.e2 > b.e1 ? a.e2 : b.e1; }
-    else { o.e1 = b.e1; o.w = b.w; o.e2 = b.e2 > a.e1 ? b.e2 : a.e1; }
+constexpr int kWaveEvents = PM_WAVE_EVENTS;
+struct WinState { int32_t e1, e2, wl, wj, wr; };        // furthest end (0: no event), second furthest, the winner's l, j and rep'[l]
+struct PairState { WinState s[2]; };
+PM_HD WinState win_join(const WinState& a, const WinState& b) {      // a: earlier events, b: later events of the same pair and strand
+    if (a.e1 == 0) return b;
+    if (b.e1 == 0) return a;
+    const bool a_wins = a.e1 > b.e1 || (a.e1 == b.e1 && (a.wl < b.wl || (a.wl == b.wl && a.wj <= b.wj)));      // equal reach: the earlier (l, j)
+    WinState o;
+    if (a_wins) { o = a; o.e2 = a.e2 > b.e1 ? a.e2 : b.e1; }
+    else { o = b; o.e2 = b.e2 > a.e1 ? b.e2 : a.e1; }
     return o;
 }
-// Pass 1, tid = chunk of kChunk consecutive sorted events: state of the chunk's TRAILING pair (events of the chunk
-// that belong to the same pair as its last event) and whether that pair starts inside the chunk.
-struct ChunkReduce {
-    const uint64_t* key; const uint64_t* val; int64_t nev; int lbits; EventState* summary; uint8_t* starts_here;
-    PM_HD void operator()(int64_t c) const {
+PM_HD PairState pair_join(const PairState& a, const PairState& b) { PairState o; o.s[0] = win_join(a.s[0], b.s[0]); o.s[1] = win_join(a.s[1], b.s[1]); return o; }
+PM_HD PairState pair_of_event(uint64_t k, uint64_t v, uint64_t lmask, int32_t rp) {
+    const int32_t l = (int32_t)((k >> 1) & lmask), j = (int32_t)(v >> 32);
+    PairState o; o.s[0] = WinState{0, 0, 0, 0, 0}; o.s[1] = o.s[0];
+    const WinState w{l + (int32_t)(v & 0xffffffffu), 0, l, j, rp};
+    if (k & 1) o.s[1] = w; else o.s[0] = w;
+    return o;
+}
+PM_HD EventAtK resolved(const PairState& p) {
+    EventAtK o;
+    for (int sd = 0; sd < 2; sd++) {
+        const WinState& w = p.s[sd];
+        const int32_t up = w.wl + w.wr;
+        o.s[sd] = w.e1 ? StrandAtK{w.e1, w.e2 > up ? w.e2 : up, w.wj - w.wl} : StrandAtK{0, 0, 0};
+    }
+    return o;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline WinState win_shfl_up(const WinState& x, int d) { return WinState{__shfl_up(x.e1, d, 64), __shfl_up(x.e2, d, 64), __shfl_up(x.wl, d, 64), __shfl_up(x.wj, d, 64), __shfl_up(x.wr, d, 64)}; }
+__device__ inline WinState win_bcast(const WinState& x, int lane) { return WinState{__shfl(x.e1, lane, 64), __shfl(x.e2, lane, 64), __shfl(x.wl, lane, 64), __shfl(x.wj, lane, 64), __shfl(x.wr, lane, 64)}; }
+// segmented inclusive scan over the lanes: `head` = this lane's event opens a pair; returns whether a pair opened at or before this lane
+__device__ inline bool pair_scan(PairState& x, bool head) {
+    const int lane = (int)__lane_id();
+    int h = head ? 1 : 0;
+    for (int d = 1; d < 64; d <<= 1) {
+        PairState y; y.s[0] = win_shfl_up(x.s[0], d); y.s[1] = win_shfl_up(x.s[1], d);
+        const int hy = __shfl_up(h, d, 64);
+        if (lane >= d && !h) { x = pair_join(y, x); h = hy; }
+    }
+    return h != 0;
+}
+#endif
+// what one wavefront does with its kWaveEvents events: `carry` = the state of its first pair before them (nothing if the
+// first event opens a pair); store = false: only the trailing pair's state comes back
+struct WaveScanCore {
+    const uint64_t* key; const uint64_t* val; int64_t nev; int lbits; const RegionInfo* R; int32_t nq; const int32_t* rep;
+    PM_HD PairState run(int64_t w, PairState carry, bool store, EventAtK* st, int32_t* emax, bool* opened) const {
         const uint64_t lmask = (1ull << lbits) - 1;
-        int64_t a = c * kChunk, b = a + kChunk < nev ? a + kChunk : nev;
-        uint64_t pair = key[b - 1] >> (lbits + 1);
-        EventState cur; cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1};
-        int64_t i = b - 1;
-        while (i > a && (key[i - 1] >> (lbits + 1)) == pair) i--;       // first event of the trailing pair inside the chunk
-        starts_here[c] = (i > a) || a == 0 || (key[a - 1] >> (lbits + 1)) != pair;
-        for (; i < b; i++) {
-            uint64_t k = key[i], v = val[i];
-            int32_t l = (int32_t)((k >> 1) & lmask);
-            // (a strand chosen by an index would put `cur` into LDS: the compiler promotes a dynamically indexed private array)
-            if (k & 1) state_push(cur.s[1], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
-            else state_push(cur.s[0], key, val, lmask, i, l, (int32_t)(v >> 32), l + (int32_t)(v & 0xffffffffu));
+        const int64_t a = w * kWaveEvents, b = a + kWaveEvents < nev ? a + kWaveEvents : nev;
+        bool any_head = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int lane = (int)__lane_id();
+        for (int64_t base = a; base < b; base += 64) {
+            const int64_t i = base + lane;
+            const bool in = i < b;
+            PairState x; x.s[0] = WinState{0, 0, 0, 0, 0}; x.s[1] = x.s[0];
+            bool head = false;
+            if (in) {
+                const uint64_t k = key[i], v = val[i];
+                const uint64_t pair = k >> (lbits + 1);
+                head = i == 0 || (key[i - 1] >> (lbits + 1)) != pair;
+                x = pair_of_event(k, v, lmask, store ? rep[R[(int64_t)pair / nq].posbase + (int32_t)((k >> 1) & lmask)] : 0);
+            }
+            const bool h = pair_scan(x, head);
+            if (!h) x = pair_join(carry, x);                       // no pair opened at or before this lane: the carried pair goes on
+            if (in && store) { st[i] = resolved(x); emax[i] = x.s[0].e1 > x.s[1].e1 ? x.s[0].e1 : x.s[1].e1; }
+            const int last = (int)((b - base < 64 ? b - base : 64) - 1);
+            carry.s[0] = win_bcast(x.s[0], last); carry.s[1] = win_bcast(x.s[1], last);
+            any_head = any_head || __ballot(head) != 0;
         }
-        summary[c] = cur;
+#else
+        for (int64_t i = a; i < b; i++) {
+            const uint64_t k = key[i], v = val[i];
+            const uint64_t pair = k >> (lbits + 1);
+            const bool head = i == 0 || (key[i - 1] >> (lbits + 1)) != pair;
+            const PairState x = pair_of_event(k, v, lmask, store ? rep[R[(int64_t)pair / nq].posbase + (int32_t)((k >> 1) & lmask)] : 0);
+            carry = head ? x : pair_join(carry, x);
+            any_head = any_head || head;
+            if (store) { st[i] = resolved(carry); emax[i] = carry.s[0].e1 > carry.s[1].e1 ? carry.s[0].e1 : carry.s[1].e1; }
+        }
+#endif
+        if (opened) *opened = any_head;
+        return carry;
     }
 };
-// Pass 2, tid = chunk: carry-in from the preceding chunks of the same pair (look back to the chunk the pair starts
-// in), then the running state after every event.  This is Test_UM (mum.c:27-45) + the forward carry of Intersect_UM
-// (mum.c:125-175) in closed form (SURVEY 3.3-3,-4): per strand, over the events with l <= k,
-//   e1 = furthest end, w = the event that reaches it (first in (l, j) order), e2 = second furthest end;
-//   EP[k] = e1, UP[k] = max(l_w + rep[l_w], e2), SP[k] = j_w + (k - l_w).
-struct ChunkScan {
-    const uint64_t* key; const uint64_t* val; int64_t nev; int lbits; const EventState* summary; const uint8_t* starts_here;
-    EventAtK* st; int32_t* emax;
-    const RegionInfo* R; int32_t nq; const int32_t* rep;
-    PM_HD void operator()(int64_t c) const {
-        const uint64_t lmask = (1ull << lbits) - 1;
-        int64_t a = c * kChunk, b = a + kChunk < nev ? a + kChunk : nev;
-        EventState cur; cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1};
-        uint64_t pair = key[a] >> (lbits + 1);
-        int64_t posbase = R[(int64_t)pair / nq].posbase;
-        int32_t up0 = 0, up1 = 0, spb0 = 0, spb1 = 0;      // of the strands' winners: l_w + rep[l_w] and j_w - l_w
-        if (a > 0 && (key[a - 1] >> (lbits + 1)) == pair) {
-            // the pair began in an earlier chunk: fold the summaries back to (and including) the chunk it starts in
-            for (int64_t p = c - 1; p >= 0; p--) {
-                cur.s[0] = state_join(summary[p].s[0], cur.s[0], key, val, lmask);
-                cur.s[1] = state_join(summary[p].s[1], cur.s[1], key, val, lmask);
-                if (starts_here[p]) break;
-            }
-            if (cur.s[0].w >= 0) { const int32_t wl = (int32_t)((key[cur.s[0].w] >> 1) & lmask); up0 = wl + rep[posbase + wl]; spb0 = (int32_t)(val[cur.s[0].w] >> 32) - wl; }
-            if (cur.s[1].w >= 0) { const int32_t wl = (int32_t)((key[cur.s[1].w] >> 1) & lmask); up1 = wl + rep[posbase + wl]; spb1 = (int32_t)(val[cur.s[1].w] >> 32) - wl; }
+// pass 1, one wavefront per kWaveEvents events: the state of its trailing pair over its own events
+struct WaveSummary {
+    WaveScanCore core; PairState* summary;
+    PM_HD void wave(int64_t w) const {
+        PairState none; none.s[0] = WinState{0, 0, 0, 0, 0}; none.s[1] = none.s[0];
+        PairState t = core.run(w, none, false, nullptr, nullptr, nullptr);
+        if (wave_leader_k()) {      // (pass 1 runs without the repeat lengths -- they decide nothing -- and fetches the two winners' at the end)
+            const int64_t b = (w + 1) * kWaveEvents < core.nev ? (w + 1) * kWaveEvents : core.nev;
+            const int64_t posbase = core.R[(int64_t)(core.key[b - 1] >> (core.lbits + 1)) / core.nq].posbase;
+            if (t.s[0].e1) t.s[0].wr = core.rep[posbase + t.s[0].wl];
+            if (t.s[1].e1) t.s[1].wr = core.rep[posbase + t.s[1].wl];
+            summary[w] = t;
         }
-        // (the repeat length of an event's own position is loaded with the event, one event ahead: a load that waited for the
-        // verdict of state_push would put a trip to memory into every step of this sequential loop)
-        uint64_t k = key[a], v = val[a];
-        int32_t rp = rep[posbase + (int32_t)((k >> 1) & lmask)];
-        for (int64_t i = a; i < b; i++) {
-            uint64_t kn = 0, vn = 0; int32_t rpn = 0; int64_t posbase_n = posbase;
-            if (i + 1 < b) {
-                kn = key[i + 1]; vn = val[i + 1];
-                if ((kn >> (lbits + 1)) != (k >> (lbits + 1))) posbase_n = R[(int64_t)(kn >> (lbits + 1)) / nq].posbase;
-                rpn = rep[posbase_n + (int32_t)((kn >> 1) & lmask)];
-            }
-            if ((k >> (lbits + 1)) != pair) { pair = k >> (lbits + 1); cur.s[0] = StrandState{0, 0, -1}; cur.s[1] = StrandState{0, 0, -1}; }
-            const int32_t l = (int32_t)((k >> 1) & lmask), j = (int32_t)(v >> 32);
-            // (a strand chosen by an index would put `cur` into LDS: the compiler promotes a dynamically indexed private array)
-            if (k & 1) { state_push(cur.s[1], key, val, lmask, i, l, j, l + (int32_t)(v & 0xffffffffu)); if (cur.s[1].w == (int32_t)i) { up1 = l + rp; spb1 = j - l; } }
-            else { state_push(cur.s[0], key, val, lmask, i, l, j, l + (int32_t)(v & 0xffffffffu)); if (cur.s[0].w == (int32_t)i) { up0 = l + rp; spb0 = j - l; } }
-            EventAtK o;
-            o.s[0] = cur.s[0].w < 0 ? StrandAtK{0, 0, 0} : StrandAtK{cur.s[0].e1, cur.s[0].e2 > up0 ? cur.s[0].e2 : up0, spb0};
-            o.s[1] = cur.s[1].w < 0 ? StrandAtK{0, 0, 0} : StrandAtK{cur.s[1].e1, cur.s[1].e2 > up1 ? cur.s[1].e2 : up1, spb1};
-            st[i] = o;
-            emax[i] = cur.s[0].e1 > cur.s[1].e1 ? cur.s[0].e1 : cur.s[1].e1;
-            k = kn; v = vn; rp = rpn; posbase = posbase_n;
+    }
+};
+// pass 2: the carried state of the wavefront's first pair from the summaries of the wavefronts since that pair began, then the scan
+struct WaveScan {
+    WaveScanCore core; const PairState* summary; const int64_t* lo; int64_t lo_base; EventAtK* st; int32_t* emax;
+    PM_HD void wave(int64_t w) const {
+        PairState carry; carry.s[0] = WinState{0, 0, 0, 0, 0}; carry.s[1] = carry.s[0];
+        const int64_t a = w * kWaveEvents;
+        const uint64_t pair = core.key[a] >> (core.lbits + 1);
+        if (a > 0 && (core.key[a - 1] >> (core.lbits + 1)) == pair) {
+            const int64_t s0 = (lo[pair] - lo_base) / kWaveEvents;      // (the same in every lane: a loop of scalar loads)
+            for (int64_t p = s0; p < w; p++) carry = pair_join(carry, summary[p]);
         }
+        (void)core.run(w, carry, true, st, emax, nullptr);
     }
 };
 

@@ -545,7 +545,7 @@ struct GroupedPairEvents {
     Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen; const int32_t* rep;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* block_count; uint64_t ev_cap; int lbits; int64_t* glo; int32_t g_first, g_last;
     uint8_t* flag;      // [region] = 1: its events are in the grouped array (0: not a small region, or more pieces / events than fit)
-    EventAtK* st; int32_t* emax;      // what ChunkScan would leave for these events (kernels.h), written with them
+    EventAtK* st; int32_t* emax;      // what WaveScan would leave for these events (kernels.h), written with them
     int32_t* epm;                     // Master.EP of the region's positions (MasterEP, kernels.h): min over the genomes of this rank
     PM_HD void wave(int64_t r) const {
         const int32_t nq = ngen - 1;
@@ -659,8 +659,8 @@ struct GroupedPairEvents {
         }
         wave_sync();
         if (sh_bad) { if (wave_leader()) flag[r] = 0; return; }      // SmallPairEvents takes the region
-        // 2b. the running state of every (piece, strand) after each of its events, as state_push keeps it (kernels.h: furthest
-        // end e1 and its event w -- first in (l, j) order on equal ends -- and the second furthest end e2), resolved as ChunkScan
+        // 2b. the running state of every (piece, strand) after each of its events, as win_join keeps it (kernels.h: furthest
+        // end e1 and its event w -- first in (l, j) order on equal ends -- and the second furthest end e2), resolved as WaveScan
         // leaves it: EP = e1, UP = max(l_w + rep'[l_w], e2), SP - k = j_w - l_w.  All of them at most 128: one word per event.
         lanes_for(0, tasks, [&](int wi) {
             const int n = sh_cnt[wi];

@@ -12,7 +12,7 @@ W=${1:-/tmp/parsnp_sanitize}
 mkdir -p $W
 cd $REPO
 HOST=$(ls parsnp_amd/csrc/host/*.cpp | grep -v "main.cpp\|capi.cpp")
-FLAGS="-O1 -g -fno-omit-frame-pointer -mavx2 -std=c++17 -fopenmp -w -DPARSNP_TEST_HOOKS -DPM_CHUNK=5"
+FLAGS="-O1 -g -fno-omit-frame-pointer -mavx2 -std=c++17 -fopenmp -w -DPARSNP_TEST_HOOKS -DPM_WAVE_EVENTS=5"
 g++ $FLAGS -fsanitize=address,undefined tests/emu/steps_main.cpp tests/emu/engine_emu.cpp $HOST -o $W/steps_asan &
 g++ $FLAGS -fsanitize=thread tests/emu/steps_main.cpp tests/emu/engine_emu.cpp $HOST -o $W/steps_tsan &
 wait

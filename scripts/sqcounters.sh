@@ -11,7 +11,7 @@ timeout 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ
 cd $REPO
 python - <<'PY'
 import sqlite3, glob, json, hashlib, os, re
-kernels = ["SeedExtend", "SeedRest", "SmallPairEvents", "MasterEP", "FoldCandidates", "ChunkScan", "IndexInsert"]
+kernels = ["SeedExtend", "SeedRest", "SmallPairEvents", "MasterEP", "FoldCandidates", "WaveScan", "GroupedPairEvents", "IndexInsert"]
 out = {"so_sha256": hashlib.sha256(open("parsnp_amd/lib/libparsnp_hip.so", "rb").read()).hexdigest(), "workload": "bench.py default (200 x 5 Mb), 2 steps + 1 warm-up",
        "note": "per kernel: counters of its dispatches; `anchor` = the dispatch records of the longest launch (the anchor call); a record = one XCD's sampled shader engine", "kernels": {}}
 for d in ("a", "b"):

@@ -42,7 +42,7 @@ def emu():
     deps = [src] + [os.path.join(eng, f) for f in os.listdir(eng)] + [os.path.join(ROOT, "include", "parsnp_mum.h")]
     if not _newer(EMU_LIB, deps):
         # a tiny scan chunk makes the cross-chunk look-back of the scan kernels run on small test inputs
-        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-DPM_CHUNK=5", src, "-o", EMU_LIB], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-w", "-DPM_WAVE_EVENTS=5", src, "-o", EMU_LIB], check=True)
     hsrc = [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".cpp") and f not in ("capi.cpp", "merge_main.cpp")]
     if not _newer(EMU_CORE, hsrc + [os.path.join(host, f) for f in os.listdir(host)] + [EMU_LIB]):
         subprocess.run(["g++", "-O3", "-mavx2", "-std=c++17", "-fopenmp", "-w", "-DPARSNP_TEST_HOOKS"] + hsrc + ["-L" + os.path.dirname(EMU_LIB), "-lpm_emu",
