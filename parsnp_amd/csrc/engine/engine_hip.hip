@@ -175,9 +175,24 @@ struct HipBackend {
     }
     // bytes moved over the host link by this session (pm_session_traffic): every copy below adds its size
     std::atomic<uint64_t> bytes_h2d{0}, bytes_d2h{0};
-    void h2d(void* d, const void* s, size_t n) { bytes_h2d += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync"); }
-    void d2h(void* d, const void* s, size_t n) { bytes_d2h += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); check(hipStreamSynchronize(stream), "sync"); }
-    void d2h_async(void* d, const void* s, size_t n) { bytes_d2h += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); }
+    // PARSNP_COPY_LOG=1: every copy over the host link with its size and the time the caller spent in it (stderr)
+    static bool copy_log() { static const bool on = getenv("PARSNP_COPY_LOG") != nullptr; return on; }
+    static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void h2d(void* d, const void* s, size_t n) {
+        const double t0 = copy_log() ? now_us() : 0;
+        bytes_h2d += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync");
+        if (copy_log()) fprintf(stderr, "[copy] h2d       %9zu B %8.1f us\n", n, now_us() - t0);
+    }
+    void d2h(void* d, const void* s, size_t n) {
+        const double t0 = copy_log() ? now_us() : 0;
+        bytes_d2h += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); check(hipStreamSynchronize(stream), "sync");
+        if (copy_log()) fprintf(stderr, "[copy] d2h       %9zu B %8.1f us (with the queued work before it)\n", n, now_us() - t0);
+    }
+    void d2h_async(void* d, const void* s, size_t n) {
+        const double t0 = copy_log() ? now_us() : 0;
+        bytes_d2h += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H");
+        if (copy_log()) fprintf(stderr, "[copy] d2h_async %9zu B %8.1f us\n", n, now_us() - t0);
+    }
     void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
     // an event on the engine's stream that any host thread may wait for (the slices of a row table in flight)
     void* event_record() {
@@ -204,7 +219,10 @@ struct HipBackend {
     void d2d(void* d, const void* s, size_t n) { if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, stream), "hipMemcpy D2D"); }
     void* pinned_alloc(size_t n) { void* p = nullptr; if (!check(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault), "hipHostMalloc")) return nullptr; return p; }
     void pinned_free(void* p) { if (p) (void)hipHostFree(p); }
-    void h2d_staged(void* d, const void* s, size_t n) { bytes_h2d += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D (staged)"); }
+    void h2d_staged(void* d, const void* s, size_t n) {
+        bytes_h2d += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D (staged)");
+        if (getenv("PARSNP_COPY_LOG")) fprintf(stderr, "[copy] h2d_staged %8zu B\n", n);
+    }
 
     // copy threads of the genome upload: the staging copy into page-locked memory (~5 GB/s per thread) is what the upload waits for
     static int upload_threads() { const char* e = getenv("PARSNP_UPLOAD_THREADS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? v : 4; }

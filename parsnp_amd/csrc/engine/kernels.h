@@ -1625,6 +1625,8 @@ struct FoldCandidates {
         int32_t em = ri.nR, um = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
         const int lane = (int)__lane_id();
+        // (fetching the states of 4 x 64 genomes stage by stage before folding the first was measured: 0.42 instead of 0.35 ms for
+        // the anchor call -- the launch is bound by its scattered requests, not by one wavefront's chain of them)
         for (int g0 = 0; g0 < nq; g0 += 64) {
             const int g = g0 + lane;
             const bool act = g < nq;
