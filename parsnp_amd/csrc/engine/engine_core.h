@@ -363,7 +363,20 @@ public:
             ev_guess += (size_t)nunits * 16;
         }
         ensure(d_units, (size_t)std::max<int64_t>(nunits, 1));
-        be.launch("fill_units", nunits, FillUnits{P, d_starts.p, d_lens.p, ngen, d_uoff.p, d_ucount.p, npairs, d_units.p});
+        // one region known to the host (the anchor call) on one GPU: the units chunk by chunk (FillUnits)
+        int64_t cmin = 0;
+        if (nreg == 1 && !gb && g_first <= 1 && g_last >= ngen && units_chunk_major) {
+            cmin = INT64_MAX;
+            const int32_t ms1 = std::max(minsize[0], 1); const int K1 = std::min(ms1, kMaxK); const int64_t stride1 = ms1 - K1 + 1;
+            for (int g = 1; g < ngen; g++) {
+                const int64_t m = lens[g];
+                int64_t ns = (m >= K1 && lens[0] >= K1) ? (m - K1) / stride1 + 1 : 0;
+                if (small_pair(lens[0], m) && !no_small) ns = 0;
+                cmin = std::min<int64_t>(cmin, (ns + kUnitSamples - 1) / kUnitSamples);
+            }
+            if (cmin == INT64_MAX) cmin = 0;
+        }
+        be.launch("fill_units", nunits, FillUnits{P, d_starts.p, d_lens.p, ngen, d_uoff.p, d_ucount.p, npairs, d_units.p, cmin});
 
         // -- events: kSlices append buffers (retry with larger ones on overflow), gathered, then sorted by (pair, l, strand)
         ensure(d_sliceoff, (size_t)kSlices + 1);
@@ -391,9 +404,9 @@ public:
                 ensure(d_evkey3, grp_cap + ev_cap_hint); ensure(d_evval3, grp_cap + ev_cap_hint);
                 ensure(d_state, grp_cap + ev_cap_hint); ensure(d_emax, grp_cap + ev_cap_hint);
                 be.mark("grouped_events");
-                be.launch_wave("grouped_pair_events", nreg,
+                be.launch_wave("grouped_pair_events", xcd_grid(nreg),
                                GroupedPairEvents{P, d_R.p, d_starts.p, d_lens.p, ngen, d_rep.p, d_evkey3.p, d_evval3.p, d_counter.p + kGrpSlot, (uint64_t)grp_cap, lbits,
-                                                 d_glo.p, g_first, g_last, d_gflag.p, d_state.p, d_emax.p, d_epm.p});
+                                                 d_glo.p, g_first, g_last, d_gflag.p, d_state.p, d_emax.p, d_epm.p, (int64_t)nreg});
             }
             be.memset(d_qcount.p, 0, 8 * (size_t)kSlices * kSliceStride);
             be.mark("seed_extend");
@@ -503,7 +516,7 @@ public:
         ensure(d_coarse, (size_t)std::max<int64_t>(centries, 1));
         be.memset(d_coarse.p, 0, 4 * (size_t)std::max<int64_t>(centries, 1));
         be.launch("coarse_fill", (int64_t)nev, CoarseFill{skey, (int64_t)nev, lbits, d_lo.p, d_R.p, d_cbase.p, nq, d_coarse.p});
-        be.launch_wave("master_ep", nchunks, MasterEP{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, grouping ? d_gflag.p : nullptr});
+        be.launch_wave("master_ep", xcd_grid(nchunks), MasterEP{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, grouping ? d_gflag.p : nullptr, nchunks});
         int32_t verdict = 0;
         if (sharded && coll.device) {   // exchange 1 on the device: RCCL all-reduce(min) of Master.EP in place, + the error verdict word
             be.mark("exchange_ep");
@@ -573,9 +586,9 @@ public:
             be.mark("fold");
             at = d_at.p;
         }
-        be.launch_wave("fold_candidates", (int64_t)ncand,
+        be.launch_wave("fold_candidates", xcd_grid((int64_t)ncand),
                        FoldCandidates{d_R.p, scand, ngen, at, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_cbase.p, d_coarse.p,
-                                      d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_ok.p});
+                                      d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_ok.p, (int64_t)ncand});
 
         // -- accepted candidates, compacted on the device and downloaded straight into the result's blocks
         be.mark("compact");
@@ -779,7 +792,7 @@ public:
         for (;;) {
             ensure(d_rg_start, cap * (size_t)ngen); ensure(d_rg_len, cap * (size_t)ngen); ensure(d_rg_info, cap);
             be.memset(d_rg_count.p, 0, 16);
-            be.launch_wave("seed_walk", nacc, SeedWalk{store_view(), layout_view(d_image.p, false), P, d_list.p, q, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap});
+            be.launch_wave("seed_walk", xcd_grid(nacc), SeedWalk{store_view(), layout_view(d_image.p, false), P, d_list.p, q, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap, (int64_t)nacc});
             uint64_t got = 0;
             be.d2h(&got, d_rg_count.p, 8);
             if (got <= cap) { rg_count = (int64_t)got; break; }
@@ -855,9 +868,9 @@ public:
         be.h2d(d_rg_count.p, head, 16);
         be.mark("validate");
         be.launch_wave("clusters_disjoint", ncl - 1, ClustersDisjoint{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, (uint32_t*)(d_rg_count.p + 1)});
-        be.launch_wave("cluster_validate", ncl,
+        be.launch_wave("cluster_validate", xcd_grid(ncl),
                        ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
-                                       d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1)});
+                                       d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), (int64_t)ncl});
         be.mark(nullptr);
         be.d2h(head, d_rg_count.p, 16);
         *trouble = (uint32_t)head[1];
@@ -989,6 +1002,7 @@ public:
     int64_t work_budget = 1 << 22;
     int64_t dirty_min = 4096;
     int64_t flagged_div = 8;      // store_settle: PM_EAGAIN when more than one row in flagged_div overlaps an earlier one
+    bool units_chunk_major = true;      // the anchor call's work units chunk by chunk (FillUnits) instead of genome by genome
     bool group_small = true;      // the events of a recursion batch's small regions once per distinct piece (GroupedPairEvents)
     int64_t last_grouped = 0;
     bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
@@ -996,6 +1010,7 @@ public:
         if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
         if (key == "group_small") { group_small = value != 0; return true; }
+        if (key == "units_chunk_major") { units_chunk_major = value != 0; return true; }
         if (key == "work_budget" && value > 0) { work_budget = value; return true; }
         if (key == "dirty_min" && value >= 0) { dirty_min = value; return true; }
         return false;

@@ -193,6 +193,13 @@ __device__ inline uint32_t wave_all_or(uint32_t x) {
 inline bool wave_leader_k() { return true; }
 #endif
 
+// Workgroups are handed to the 8 XCDs of the chip round robin by their number, and every XCD has its own L2.  Work items whose
+// NEIGHBOURS read the same cache lines are therefore numbered so that a contiguous eighth of them lands on one XCD: workgroup w
+// takes item (w mod 8) * ceil(n / 8) + w / 8 of a launch of xcd_grid(n) workgroups (the last ones may find nothing).
+constexpr int kXcds = 8;
+PM_HD int64_t xcd_grid(int64_t n) { return (n + kXcds - 1) / kXcds * kXcds; }
+PM_HD int64_t xcd_item(int64_t w, int64_t n) { return (w % kXcds) * ((n + kXcds - 1) / kXcds) + w / kXcds; }
+
 // ------------------------------------------------------------------------------------------ shared structures
 struct alignas(16) SeqBlock { uint64_t b2; uint32_t nm; uint32_t pad; };   // 32 bases
 struct Packed {            // the resident genomes
@@ -622,6 +629,10 @@ struct LayoutSentinel {
 struct FillUnits {
     Packed P; const int64_t* starts; const int64_t* lens; int32_t ngen;
     const int64_t* off; const int64_t* count; int64_t npairs; UnitRec* units;
+    int64_t cmin;      // > 0 (one region, every pair at least cmin units): the first cmin chunks of all pairs CHUNK by chunk -- the
+                       // wavefronts that run together then look at the same stretch of the reference in different genomes (its
+                       // windows, index slots and repeat lengths come from the L2 instead of once per genome from memory); the
+                       // ragged rest pair by pair behind them.  0: pair by pair.
     PM_HD void operator()(int64_t tid) const {
         int64_t pair = upper_slot(off, npairs, tid);     // the last pair whose first unit is <= tid owns it
         const int64_t r = pair / (ngen - 1); const int g = (int)(pair % (ngen - 1)) + 1;
@@ -630,8 +641,9 @@ struct FillUnits {
         rec.qbase = P.goff[2 * g] + qs;
         rec.qbase_r = P.goff[2 * g + 1] + (P.glen[g] - qs - m);
         rec.region = (int32_t)r; rec.pair = (int32_t)pair; rec.m = (int32_t)m;
-        rec.chunk = (int32_t)(tid - off[pair]);
-        units[tid] = rec;
+        const int64_t chunk = tid - off[pair];
+        rec.chunk = (int32_t)chunk;
+        units[chunk < cmin ? chunk * npairs + pair : cmin * npairs + (off[pair] - pair * cmin) + (chunk - cmin)] = rec;
     }
 };
 
@@ -1415,7 +1427,10 @@ struct MasterEP {
     const int64_t* cbase; const int32_t* coarse;
     int32_t g_first, g_last;   // sharded run: the min over the other genomes arrives by all-reduce
     const uint8_t* grouped;    // [region] != 0: GroupedPairEvents (store_kernels.h) has written the region's Master.EP; nullptr: none
-    PM_HD void wave(int64_t w) const {
+    int64_t nchunks;           // the launch is xcd_grid(nchunks) wavefronts: neighbouring chunks (the same lines of events) on one L2
+    PM_HD void wave(int64_t w0) const {
+        const int64_t w = xcd_item(w0, nchunks);
+        if (w >= nchunks) return;
         const int32_t nq = ngen - 1;
         const int64_t r = region_of_chunk(cbase, nregions, w);
         if (grouped && grouped[r]) return;
@@ -1618,7 +1633,11 @@ struct FoldCandidates {
     const uint64_t* key; const uint64_t* val; const int64_t* lo; const EventAtK* st; const int32_t* rep; int lbits;
     const int64_t* cbase; const int32_t* coarse;
     int32_t* out_k; int32_t* out_lon; int32_t* out_sp; uint8_t* out_fwd; uint8_t* out_ok;
-    PM_HD void wave(int64_t c) const {
+    int64_t ncand;      // the launch is xcd_grid(ncand) wavefronts
+    PM_HD void wave(int64_t w) const {
+        // neighbouring candidates read neighbouring events of every genome: they go to the SAME L2 (xcd_item)
+        const int64_t c = xcd_item(w, ncand);
+        if (c >= ncand) return;
         const int32_t nq = ngen - 1;
         const int64_t r = (int64_t)(cand[c] >> 32); const int32_t k = (int32_t)(cand[c] & 0xffffffffu);
         const RegionInfo& ri = R[r];

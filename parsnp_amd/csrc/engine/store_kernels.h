@@ -443,7 +443,10 @@ PM_HD int32_t region_extent(const Store& S, const Layout& L, const Packed& P, in
 struct SeedWalk {
     Store S; Layout L; Packed P; const int32_t* acc; int32_t q;
     int64_t* rg_start; int64_t* rg_len; RegInfo* info; uint64_t* count; uint64_t cap;
-    PM_HD void wave(int64_t i) const {
+    int64_t nacc;      // the launch is xcd_grid(nacc) wavefronts: neighbouring anchors walk the same words of the image
+    PM_HD void wave(int64_t w) const {
+        const int64_t i = xcd_item(w, nacc);
+        if (i >= nacc) return;
         const int64_t c = acc[i];
         const int32_t dl = S.shift[c], len = S.len[c];
         const int n = S.ngen;
@@ -547,7 +550,10 @@ struct GroupedPairEvents {
     uint8_t* flag;      // [region] = 1: its events are in the grouped array (0: not a small region, or more pieces / events than fit)
     EventAtK* st; int32_t* emax;      // what WaveScan would leave for these events (kernels.h), written with them
     int32_t* epm;                     // Master.EP of the region's positions (MasterEP, kernels.h): min over the genomes of this rank
-    PM_HD void wave(int64_t r) const {
+    int64_t nreg;                     // the launch is xcd_grid(nreg) wavefronts: neighbouring regions read the same lines of every genome
+    PM_HD void wave(int64_t w) const {
+        const int64_t r = xcd_item(w, nreg);
+        if (r >= nreg) return;
         const int32_t nq = ngen - 1;
         const int per = (nq + 63) / 64;
         const RegionInfo& ri = R[r];
@@ -778,7 +784,10 @@ struct ClusterValidate {
     int64_t* rg_start; int64_t* rg_len; RegInfo* info; uint64_t* rg_count; uint64_t rg_cap;
     const int32_t* now_region; const int64_t* now_row0; const int32_t* now_cnt; const int64_t* cluster_first;
     int32_t q; uint32_t* trouble;
-    PM_HD void wave(int64_t cl) const {
+    int64_t ncl;      // the launch is xcd_grid(ncl) wavefronts: neighbouring clusters read and mark neighbouring words of the image
+    PM_HD void wave(int64_t w) const {
+        const int64_t cl = xcd_item(w, ncl);
+        if (cl >= ncl) return;
         const int n = S.ngen;
         int64_t pending_min = -1;
         const int64_t x1 = cluster_first[cl + 1];
