@@ -363,20 +363,7 @@ public:
             ev_guess += (size_t)nunits * 16;
         }
         ensure(d_units, (size_t)std::max<int64_t>(nunits, 1));
-        // one region known to the host (the anchor call) on one GPU: the units chunk by chunk (FillUnits)
-        int64_t cmin = 0;
-        if (nreg == 1 && !gb && g_first <= 1 && g_last >= ngen && units_chunk_major) {
-            cmin = INT64_MAX;
-            const int32_t ms1 = std::max(minsize[0], 1); const int K1 = std::min(ms1, kMaxK); const int64_t stride1 = ms1 - K1 + 1;
-            for (int g = 1; g < ngen; g++) {
-                const int64_t m = lens[g];
-                int64_t ns = (m >= K1 && lens[0] >= K1) ? (m - K1) / stride1 + 1 : 0;
-                if (small_pair(lens[0], m) && !no_small) ns = 0;
-                cmin = std::min<int64_t>(cmin, (ns + kUnitSamples - 1) / kUnitSamples);
-            }
-            if (cmin == INT64_MAX) cmin = 0;
-        }
-        be.launch("fill_units", nunits, FillUnits{P, d_starts.p, d_lens.p, ngen, d_uoff.p, d_ucount.p, npairs, d_units.p, cmin});
+        be.launch("fill_units", nunits, FillUnits{P, d_starts.p, d_lens.p, ngen, d_uoff.p, d_ucount.p, npairs, d_units.p});
 
         // -- events: kSlices append buffers (retry with larger ones on overflow), gathered, then sorted by (pair, l, strand)
         ensure(d_sliceoff, (size_t)kSlices + 1);
@@ -1002,7 +989,6 @@ public:
     int64_t work_budget = 1 << 22;
     int64_t dirty_min = 4096;
     int64_t flagged_div = 8;      // store_settle: PM_EAGAIN when more than one row in flagged_div overlaps an earlier one
-    bool units_chunk_major = true;      // the anchor call's work units chunk by chunk (FillUnits) instead of genome by genome
     bool group_small = true;      // the events of a recursion batch's small regions once per distinct piece (GroupedPairEvents)
     int64_t last_grouped = 0;
     bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
@@ -1010,7 +996,6 @@ public:
         if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
         if (key == "group_small") { group_small = value != 0; return true; }
-        if (key == "units_chunk_major") { units_chunk_major = value != 0; return true; }
         if (key == "work_budget" && value > 0) { work_budget = value; return true; }
         if (key == "dirty_min" && value >= 0) { dirty_min = value; return true; }
         return false;
