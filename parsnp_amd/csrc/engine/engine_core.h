@@ -44,6 +44,7 @@ struct HostPool {
     ~HostPool() { for (auto& b : idle) free_fn(b.p); }
 };
 
+struct ClearJob { void* p; size_t bytes; int value; };      // backend clear_many: several clears in one launch
 struct BatchResult {
     int64_t nregions = 0, total = 0;
     int nq = 0;
@@ -328,18 +329,29 @@ public:
 
         // -- reference index + repeat lengths
         ensure(d_slots, (size_t)tsize); ensure(d_filter, (size_t)fwords);
-        be.memset(d_filter.p, 0, sizeof(uint32_t) * (size_t)fwords);
         ensure(d_next, (size_t)std::max<int64_t>(npos, 1)); ensure(d_rep, (size_t)std::max<int64_t>(npos, 1));
         ensure(d_epm, (size_t)std::max<int64_t>(npos, 1) + 1);     // + the verdict word of a sharded run
-        be.memset(d_slots.p, 0xff, sizeof(uint64_t) * (size_t)tsize);
-        be.memset(d_counter.p, 0, 8 * ncounter);
+        // everything the call clears before it starts, in one launch: presence filter, slots (0xff = empty), event counters + error
+        // word, the repeated-K-mer bits, the coarse index, the closing words of the two prefix scans, the byte counters
+        const int64_t nwv = (npos + 63) / 64;
+        const bool from_store_ = gb && gb->store_ids;
+        ensure(d_repeated, (size_t)(npos / 32 + 2));       // (SeedExtend reads the word after a position's own)
+        ensure(d_ucount, (size_t)npairs + 1); ensure(d_uoff, (size_t)npairs + 1);
+        ensure(d_coarse, (size_t)std::max<int64_t>(centries, 1));
+        ensure(d_wmask, (size_t)nwv + 1); ensure(d_wcount, (size_t)nwv + 1); ensure(d_woff, (size_t)nwv + 1);
+        if (from_store_) ensure(d_alg, 4);
+        {
+            const ClearJob jobs[] = {
+                {d_filter.p, sizeof(uint32_t) * (size_t)fwords, 0}, {d_slots.p, sizeof(uint64_t) * (size_t)tsize, 0xff}, {d_counter.p, 8 * ncounter, 0},
+                {d_repeated.p, 4 * (size_t)(npos / 32 + 2), 0}, {d_coarse.p, 4 * (size_t)std::max<int64_t>(centries, 1), 0},
+                {d_ucount.p + npairs, 8, 0}, {d_wcount.p + nwv, 8, 0}, {from_store_ ? d_alg.p : nullptr, from_store_ ? (size_t)32 : 0, 0}};
+            be.clear_many(jobs, (int)(sizeof jobs / sizeof jobs[0]));
+        }
         // rows the device derived itself (gaps of the anchor table, rows of the region store) were never seen by the host: the
         // same checks the explicit rows get above, raised through the batch's error word
         if (gb) be.launch("check_rows", (int64_t)nrow, CheckRows{d_R.p, d_starts.p, d_lens.p, ngen, d_glen, d_err});
         last_alg[0] = last_alg[1] = last_alg[2] = 0;
         if (from_store) {      // the algorithmic bytes of a search whose rows the host never saw (read back with the event counters)
-            ensure(d_alg, 4);
-            be.memset(d_alg.p, 0, 32);
             be.launch_wave("alg_bytes", (nreg * nq + kAlgPairs - 1) / kAlgPairs, AlgBytes{d_R.p, d_lens.p, ngen, nreg * nq, d_alg.p});
         }
         be.mark("index");
@@ -347,15 +359,11 @@ public:
         be.mark("repeat");
         ensure(d_run, (size_t)std::max<int64_t>(npos, 1));
         be.launch("run_length", npos, RunLength{P, d_R.p, nreg, d_posbase.p, d_run.p});
-        ensure(d_repeated, (size_t)(npos / 32 + 2));       // (SeedExtend reads the word after a position's own)
-        be.memset(d_repeated.p, 0, 4 * (size_t)(npos / 32 + 2));
         be.launch("repeat_length", npos, RepeatLength{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_filter.p, d_next.p, d_run.p, d_rep.p, d_repeated.p, d_err, work_budget});
 
         // -- work units (pairs that fit 128 bases on both sides go to SmallPairEvents instead)
         be.mark("units");
-        ensure(d_ucount, (size_t)npairs + 1); ensure(d_uoff, (size_t)npairs + 1);
         be.launch("count_units", npairs, CountUnits{d_R.p, d_lens.p, ngen, d_ucount.p, g_first, g_last, no_small});
-        be.memset(d_ucount.p + npairs, 0, 8);
         be.exclusive_scan(d_ucount.p, d_uoff.p, (size_t)npairs + 1);
         if (gb) {      // the host never saw the rows: the unit count comes back from the device (8 bytes)
             be.d2h(&nunits, d_uoff.p + npairs, 8);
@@ -500,8 +508,6 @@ public:
 
         // -- Master.EP, candidates
         be.mark("master_ep");
-        ensure(d_coarse, (size_t)std::max<int64_t>(centries, 1));
-        be.memset(d_coarse.p, 0, 4 * (size_t)std::max<int64_t>(centries, 1));
         be.launch("coarse_fill", (int64_t)nev, CoarseFill{skey, (int64_t)nev, lbits, d_lo.p, d_R.p, d_cbase.p, nq, d_coarse.p});
         be.launch_wave("master_ep", xcd_grid(nchunks), MasterEP{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, grouping ? d_gflag.p : nullptr, nchunks});
         int32_t verdict = 0;
@@ -520,10 +526,7 @@ public:
             if (verdict >= 0 && npos) be.h2d(d_epm.p, h.data(), 4 * (size_t)npos);
         }
         be.mark("candidates");
-        const int64_t nwv = (npos + 63) / 64;
-        ensure(d_wmask, (size_t)nwv + 1); ensure(d_wcount, (size_t)nwv + 1); ensure(d_woff, (size_t)nwv + 1);
         be.launch_wave("cand_mark", nwv, CandMark{d_R.p, nreg, d_posbase.p, npos, d_epm.p, d_wmask.p, d_wcount.p});
-        be.memset(d_wcount.p + nwv, 0, 8);
         be.exclusive_scan(d_wcount.p, d_woff.p, (size_t)nwv + 1);
         int64_t ncand_i = 0;
         be.d2h(&ncand_i, d_woff.p + nwv, 8);                                   // round trip 2: candidate count

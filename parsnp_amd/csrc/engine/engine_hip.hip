@@ -44,6 +44,27 @@ __global__ __launch_bounds__(256) void pm_fill16(uint4* p, uint4 v, int64_t n16)
     for (int k = 0; k < 16; k++, i += 256) if (i < n16) p[i] = v;
 }
 
+// the tables and counters a search clears before it starts, in ONE launch (a dozen hipMemsetAsync calls are a dozen 5 us kernels):
+// every workgroup takes 64 KB of one job
+struct FillJobs { enum { kMax = 12 }; void* p[kMax]; unsigned long long bytes[kMax]; unsigned int value[kMax]; unsigned int first_block[kMax + 1]; int n; };
+__global__ __launch_bounds__(256) void pm_fill_many(FillJobs jobs) {
+    int j = 0;
+    while (j + 1 < jobs.n && blockIdx.x >= jobs.first_block[j + 1]) j++;
+    const unsigned long long off = (unsigned long long)(blockIdx.x - jobs.first_block[j]) << 16;
+    const unsigned long long n = jobs.bytes[j];
+    unsigned char* base = (unsigned char*)jobs.p[j];
+    const unsigned int w = jobs.value[j];
+    if ((((uintptr_t)base) & 15) == 0) {
+        uint4* q = (uint4*)(base + off);
+        const unsigned long long n16 = (n > off ? (n - off < 65536 ? n - off : 65536) : 0) >> 4;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const unsigned long long i = (unsigned long long)k * 256 + threadIdx.x; if (i < n16) q[i] = make_uint4(w, w, w, w); }
+        for (unsigned long long i = off + (n16 << 4) + threadIdx.x; i < n && i < off + 65536; i += 256) base[i] = (unsigned char)w;      // (tail)
+    } else {
+        for (unsigned long long i = off + threadIdx.x; i < n && i < off + 65536; i += 256) base[i] = (unsigned char)w;
+    }
+}
+
 // one wavefront per work item: 64-thread workgroups, f.wave(item) with the lanes cooperating (shuffles, LDS)
 template <class F>
 __global__ __launch_bounds__(64) void pm_wave_kernel(F f, int64_t n) {
@@ -172,6 +193,23 @@ struct HipBackend {
             return;
         }
         check(hipMemsetAsync(p, v, n, stream), "hipMemsetAsync");
+    }
+    // several clears in one launch (engine_core.h: the tables and counters a search clears before it starts)
+    void clear_many(const pm::ClearJob* jobs, int n) {
+        FillJobs f; f.n = 0; unsigned int blocks = 0;
+        for (int i = 0; i < n; i++) {
+            if (!jobs[i].bytes) continue;
+            if (f.n == FillJobs::kMax) { launch_fill(f, blocks); f.n = 0; blocks = 0; }
+            f.p[f.n] = jobs[i].p; f.bytes[f.n] = jobs[i].bytes; f.value[f.n] = 0x01010101u * (unsigned int)(uint8_t)jobs[i].value; f.first_block[f.n] = blocks;
+            blocks += (unsigned int)((jobs[i].bytes + 65535) >> 16);
+            f.n++;
+        }
+        if (f.n) launch_fill(f, blocks);
+    }
+    void launch_fill(FillJobs& f, unsigned int blocks) {
+        f.first_block[f.n] = blocks;
+        hipLaunchKernelGGL(pm_fill_many, dim3(blocks), dim3(256), 0, stream, f);
+        check(hipGetLastError(), "pm_fill_many");
     }
     // bytes moved over the host link by this session (pm_session_traffic): every copy below adds its size
     std::atomic<uint64_t> bytes_h2d{0}, bytes_d2h{0};

@@ -16,6 +16,7 @@ struct HostBackend {
     static void* host_alloc(size_t n) { return malloc(n ? n : 1); }
     static void host_free(void* p) { ::free(p); }
     void memset(void* p, int v, size_t n) { ::memset(p, v, n); }
+    void clear_many(const pm::ClearJob* jobs, int n) { for (int i = 0; i < n; i++) if (jobs[i].bytes) ::memset(jobs[i].p, jobs[i].value, jobs[i].bytes); }
     uint64_t bytes_h2d = 0, bytes_d2h = 0;      // what a device backend would have moved over the host link
     void h2d(void* d, const void* s, size_t n) { bytes_h2d += n; memcpy(d, s, n); }
     void d2h(void* d, const void* s, size_t n) { bytes_d2h += n; memcpy(d, s, n); }
