@@ -623,7 +623,14 @@ public:
                 ensure(d_csp, std::max<size_t>(nokz * ngz, 1)); ensure(d_cfwd, std::max<size_t>(nokz * ngz, 1)); ensure(d_cflags, std::max<size_t>(nokz, 1));
                 p_start = d_csp.p; p_strand = d_cfwd.p; p_lon = d_clon.p; p_flags = d_cflags.p;
             }
-            if (nokz) be.memset(p_flags, 0, 4 * nokz);
+            const bool long_list = nreg == 1 && nok >= dirty_min;
+            if (long_list) ensure(d_dirty, nokz);
+            {      // the flags of the rows (OR-ed into), the cheap overlap test's marks, shift and state of the new store rows: one launch
+                const ClearJob jobs[] = {{p_flags, 4 * nokz, 0}, {long_list ? d_dirty.p : nullptr, long_list ? 4 * nokz : 0, 0},
+                                         {to_store ? d_ms_shift.p + (ms_count - nok) : nullptr, to_store ? 4 * nokz : 0, 0},
+                                         {to_store ? d_ms_state.p + (ms_count - nok) : nullptr, to_store ? nokz : 0, 0}};
+                be.clear_many(jobs, 4);
+            }
             be.launch("compact_candidates", (int64_t)ncand * ngen,
                       CompactCandidates{scand, d_ok.p, d_okpos.p, ngen, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_starts.p, d_lens.p, d_glen,
                                         d_creg.p, d_ck.p, p_lon, p_start, p_strand, p_flags});
@@ -632,15 +639,12 @@ public:
                 ensure(d_bmax, (size_t)nblocks * ngz); ensure(d_bmin, (size_t)nblocks * ngz);
                 be.launch_wave("dirty_extent", nblocks * groups, DirtyExtent{p_start, p_lon, p_flags, nok, ngen, d_bmax.p, d_bmin.p});
                 be.launch_wave("dirty_prefix", groups, DirtyPrefix{nblocks, ngen, d_bmax.p, d_bmin.p});
-                ensure(d_dirty, nokz);
-                be.memset(d_dirty.p, 0, 4 * nokz);
                 be.launch_wave("dirty_mark", nblocks * groups, DirtyMark{p_start, p_lon, nok, ngen, d_bmax.p, d_bmin.p, p_flags, d_dirty.p});
                 be.launch("dirty_merge", nok, DirtyMerge{d_dirty.p, p_flags});
                 out->dirty_known = true;
             }
             if (to_store) {
                 be.d2d(d_ms_len.p + (ms_count - nok), p_lon, 4 * nokz);
-                if (nokz) { be.memset(d_ms_shift.p + (ms_count - nok), 0, 4 * nokz); be.memset(d_ms_state.p + (ms_count - nok), 0, nokz); }
                 if (anchor_call) {
                     anchor_table_rows = nok;
                     out->table_id = anchor_table_id = ++table_counter;

@@ -131,6 +131,7 @@ struct HipBackend {
         for (auto e : pool) (void)hipEventDestroy(e);
         if (tmp) (void)hipFree(tmp);
         if (stage_p) (void)hipHostFree(stage_p);
+        if (ring) (void)hipHostFree(ring);
         if (comm) (void)Rccl::get().CommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -216,9 +217,26 @@ struct HipBackend {
     // PARSNP_COPY_LOG=1: every copy over the host link with its size and the time the caller spent in it (stderr)
     static bool copy_log() { static const bool on = getenv("PARSNP_COPY_LOG") != nullptr; return on; }
     static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    // Small uploads (row lists, counters: a few KB, ~10 per step) go through a page-locked ring and are queued without waiting: from
+    // ordinary memory the runtime stages the copy itself and the call returns only when it is done -- 15-25 us each on an idle
+    // stream.  The ring is reused from its start when full, after one wait for the stream.
+    uint8_t* ring = nullptr; size_t ring_at = 0; static constexpr size_t kRing = (size_t)4 << 20;
     void h2d(void* d, const void* s, size_t n) {
         const double t0 = copy_log() ? now_us() : 0;
-        bytes_h2d += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync");
+        bytes_h2d += n;
+        if (n && n <= kRing / 4) {
+            if (!ring && hipHostMalloc((void**)&ring, kRing, hipHostMallocDefault) != hipSuccess) ring = nullptr;
+            if (ring) {
+                const size_t need = (n + 63) & ~(size_t)63;
+                if (ring_at + need > kRing) { check(hipStreamSynchronize(stream), "sync"); ring_at = 0; }
+                memcpy(ring + ring_at, s, n);
+                check(hipMemcpyAsync(d, ring + ring_at, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D (ring)");
+                ring_at += need;
+                if (copy_log()) fprintf(stderr, "[copy] h2d (ring) %8zu B %8.1f us\n", n, now_us() - t0);
+                return;
+            }
+        }
+        if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync");
         if (copy_log()) fprintf(stderr, "[copy] h2d       %9zu B %8.1f us\n", n, now_us() - t0);
     }
     void d2h(void* d, const void* s, size_t n) {
