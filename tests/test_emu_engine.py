@@ -256,3 +256,16 @@ def check_mumi(E, O, count, seed):
 
 def test_mumi_coverage(libs):
     check_mumi(libs[0], libs[1], 300, 8)
+
+
+def test_scan_operator_and_xcd_numbering(tmp_path):
+    """tests/emu/scan_check.cpp against the product's kernels.h: the join of the wavefront scan is associative and a 64-lane
+    segmented scan with the kernel's update rule (rounds, carry of the last lane) gives every event the state of the sequential
+    rule (Test_UM + Intersect_UM's carry: furthest end, its first event in (l, j) order, second furthest end); xcd_item maps a
+    launch of xcd_grid(n) workgroups onto the n items exactly once each"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "scan_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-w", os.path.join(root, "tests", "emu", "scan_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
