@@ -8,10 +8,11 @@ recursive inter-anchor extension, LCB formation) on MI355X, on BASELINE.json's h
 One "step" = one pass of the hot path over one batch of synthetic genomes (reference + G queries) whose packed
 sequences are already resident in HBM (ingest, upload and XMFA writing are outside the timed region and reported
 separately).  N > 1: partition mode's natural split -- every rank owns one partition (the shared reference + its own
-G query genomes) on its own GPU, no data-path collective; value = genomes of all ranks / max-over-ranks time
-("scaling": "weak") -- and, in the same line under `sharded_strong`, the SAME G genomes as one alignment sharded over the
-N GPUs (strong scaling: all-reduce(min) + all-gather per engine call over the engine's RCCL communicator), measured by a
-child process per rank.  `n_ranks_seen_by_rccl` and `per_rank` (host threads budgeted from the container's CPU quota,
+G query genomes) on its own GPU, no data-path collective; value = genomes of all ranks / max-over-ranks time.  THE N > 1
+HEADLINE IS THEREFORE N x G GENOMES IN N ALIGNMENTS ("scaling": "weak", `total_genomes` = N x G) -- a larger job than the
+metric's one 200-genome alignment; that one job on N GPUs is the line's `sharded_strong`: the SAME G genomes as one
+alignment sharded over the N GPUs (strong scaling: all-reduce(min) + all-gather per engine call over the engine's RCCL
+communicator), measured by a child process per rank; DESIGN.md section 5 holds the predicted curve of both.  `n_ranks_seen_by_rccl` and `per_rank` (host threads budgeted from the container's CPU quota,
 cores kept busy, ms per step of every rank) say what the numbers were measured on.
 
 The JSON line also carries
@@ -38,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 RANDOM_PEAK_GBS = 3400.0   # measured ceiling of scattered 64-byte requests (scripts/hbm_calib.hip gather kernels, profiles/r01/calibration.json: 54 G requests/s): what an index probe can reach
-PROFILE_ROUND = "r04"   # profiles/<round>/traffic_seed_extend.json, calibration.json: the PMC passes of the shipped binary
+PROFILE_ROUND = "r05"   # profiles/<round>/traffic_seed_extend.json, calibration.json: the PMC passes of the shipped binary
 
 
 def engine_src_sha256():
@@ -58,6 +59,41 @@ def so_sha256():
     import hashlib
     from parsnp_amd.paths import HIP_LIB
     return hashlib.sha256(open(HIP_LIB, "rb").read()).hexdigest()
+
+
+def anchor_alg(G, m_avg, n_ref, stride, phases):
+    """byte model of the anchor launch's event search: G query genomes streamed once, the reference window once, a 64-B
+    index request per leader (8 B per sample), 64 B per sample SeedRest probes, 16 B per event"""
+    samples = (m_avg - 16) // max(1, stride) + 1
+    return G * (m_avg / 2 + 8 * samples) + n_ref / 2 + 64 * phases.get("rest_samples", 0.0) + 16 * phases.get("events", 0.0)
+
+
+def issue_fraction(pdir):
+    """share of the anchor dispatch's cycles in which SeedExtend's SIMDs issue vector instructions, from the SQ counters of THIS
+    build (scripts/sqcounters.sh) and the measured int32 issue rate of a gfx950 SIMD (scripts/valu_calib.hip); None without both"""
+    try:
+        sq = json.load(open(os.path.join(pdir, "sq_seed_extend.json")))
+        cal = json.load(open(os.path.join(pdir, "calibration.json")))
+    except (OSError, ValueError):
+        return None
+    if sq.get("so_sha256") != so_sha256() and sq.get("engine_src_sha256") != engine_src_sha256():
+        return None
+    ipc = (cal.get("valu") or {}).get("valu_int32_wave64_instructions_per_cycle_per_simd")
+    k = sq.get("kernels", {}).get("SeedExtend", {})
+    c = k.get("counters", {})
+    g = lambda n: c.get(n, {}).get("max_per_record", 0.0)      # noqa: E731 -- the records of the longest dispatch (the anchor launch)
+    n_disp = max(1, k.get("dispatch_ns", {}).get("n", 1))
+    per_dispatch = max(1, c.get("SQ_INSTS_VALU", {}).get("records", n_disp) // n_disp)      # counter records per dispatch (one per XCD and sampled shader engine)
+    if not ipc or not g("SQ_INSTS_VALU") or not g("GRBM_GUI_ACTIVE"):
+        return None
+    simds = 256 * 4
+    valu_total = g("SQ_INSTS_VALU") * per_dispatch
+    cycles = g("GRBM_GUI_ACTIVE")
+    return {"valu_instructions": int(valu_total), "dispatch_cycles": int(cycles), "simds": simds, "cycles_per_valu": round(1.0 / ipc, 3),
+            "valu_per_wave": int(g("SQ_INSTS_VALU") / max(1.0, g("SQ_WAVES"))),
+            "issue_frac": round(valu_total / simds / ipc / cycles, 4),
+            "wait_frac": round(g("SQ_WAIT_ANY") / max(1.0, g("SQ_WAVE_CYCLES")), 4),
+            "source": "profiles/%s/sq_seed_extend.json + calibration.json" % PROFILE_ROUND}
 
 
 def make_inputs(workdir, workload, genomes, rank):
@@ -187,6 +223,9 @@ def main():
     ap.add_argument("--inputs", default="", help="directory with ref.fna + g*.fna to use instead of generating the workload (the sharded child of --mode both)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="a tunable of the engine session (pm_session_tune: group_small=0, ...) for before/after measurements; named in config.tune")
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"],
+                    help="ms per step of BASELINE's other single-GPU configurations (viral50 = config 2, rearr500 = config 5) in the line's "
+                         "`other_configs`, each measured by a child run of this script; auto = on for the default workload at N = 1")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
 
@@ -325,6 +364,13 @@ def main():
             host_cores_busy = (sum(os.times()[:2]) - cpu0) / elapsed      # CPU seconds of this process (all threads) per second of the timed region
             gc.enable()
             barrier()
+            # the timed region ends with the MUM list, the LCBs and their counters on the host; the ROWS of the MUMs stay on the device
+            # until the writer asks (resident route).  What fetching them costs is measured here, once, and reported beside ms_per_step
+            materialize_ms = None
+            if rank == 0 and not sharded:
+                run.L.pc_materialize.argtypes = [__import__("ctypes").c_void_p]
+                run.L.pc_materialize.restype = __import__("ctypes").c_double
+                materialize_ms = round(float(run.L.pc_materialize(run.h)), 3)
             t_out = time.time()
             if rank == 0:
                 run.write()          # XMFA + log of one partition: outside the timed region, reported as split_s.output
@@ -334,7 +380,7 @@ def main():
                 run.L.pc_rccl_ranks.argtypes = [__import__("ctypes").c_void_p]
                 rccl_ranks = int(run.L.pc_rccl_ranks(run.h))
             else:
-                rccl_ranks = dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else (1 if dist is None else 0)
+                rccl_ranks = dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else (None if dist is None else 0)      # None: no communicator exists (N = 1)
             run.close()
         finally:
             os.dup2(so, 1); os.dup2(se, 2)
@@ -409,7 +455,8 @@ def main():
             # reference window once, 16 B per 32 bases -- + one 64-B index request per sampled K-mer (pairs that fit 128 bases use
             # no index) + 16 B per event it appends; summed by the host over every pair it sends (Stats::alg_bytes_kernel)
             events_step = totals.get("events", 0.0)
-            alg_step = sum(r.get("alg_bytes_kernel", 0) for r in reports) / len(reports) + 16.0 * events_step
+            rest_step = totals.get("rest_samples", 0.0)
+            alg_step = sum(r.get("alg_bytes_kernel", 0) for r in reports) / len(reports) + 64.0 * rest_step + 16.0 * events_step
             b_alg = m_avg / 4 + 16 * m_avg + 16 * n_ref          # bytes per query genome of the anchor launch
             anchor_stride = max(1, int(reports[-1].get("anchor_minsize", 25)) - 16 + 1)     # sampling step of the anchor launch (K = 16)
             roof = None
@@ -436,35 +483,48 @@ def main():
                 alg_gbs = alg_step / (kernels[dom] * 1e-3) / 1e9
                 survey_gbs = survey_step / (kernels[dom] * 1e-3) / 1e9
                 traffic_gbs = traffic / (launch_ms * 1e-3) / 1e9 if traffic else None
-                # achieved = algorithmic bytes of this engine's event search per launch / its HIP-event time, against the 8 TB/s HBM
-                # peak (the contract's roofline).  The kernel does not live under that roof: its requests are scattered 64-B index
-                # and sequence reads whose ceiling is the fabric's request rate (54 G requests/s = 3.4 TB/s, scripts/hbm_calib.hip),
-                # most of them served by the 256 MB Infinity Cache -- `limiter` says so, `traffic` is what the counters saw.
-                roof = {"bound": "hbm",      # (the contract's two rooflines; what the kernel really waits for: `limiter`)
-                        "limiter": "vector-instruction issue: SeedExtend issues 1 201 vector + 402 scalar instructions per 128-sample wavefront "
-                                   "(profiles/%s/sq_seed_extend.json, SQ counters of the shipped kernels) -- 0.78 M wavefronts x 1 201 at one wave64 "
-                                   "instruction per SIMD and 4 cycles is ~85 %% of the anchor launch; SeedRest (5.5 %% of the samples) waits on dependent "
-                                   "scattered reads (84 %% of its wave-cycles waiting), GroupedPairEvents / SmallPairEvents are register and LDS arithmetic.  "
-                                   "Not byte bandwidth: the counters see 2.0 GB per launch against 3.8 GB of algorithmic bytes; the index (67 MB), the "
-                                   "filter (8 MB) and the reference (2.5 MB) sit in the 256 MB Infinity Cache, and the scattered 64-B requests peak at "
-                                   "54 G/s = 3.4 TB/s (scripts/hbm_calib.hip)" % PROFILE_ROUND,
+                # frac: what the fabric counters saw per launch / the HIP-event time of the launch / 8 TB/s where a PMC pass of THIS
+                # build is on file -- an upper bound of the HBM fraction (Infinity-Cache hits are in it) -- else the byte model, which
+                # is built never to exceed the counters (round 4's charged an index request per sample: 1.9 x the counters).  The
+                # kernel does not live under the byte roof: `limiter` / `issue_frac` say what it waits for.
+                issue = issue_fraction(pdir)
+                if issue and issue.get("issue_frac") is not None:
+                    limiter = ("vector-instruction issue: the anchor dispatch of SeedExtend issues %d vector instructions per 128-sample wavefront "
+                               "(SQ counters of this build, profiles/%s/sq_seed_extend.json); at the measured %.2f cycles per wave64 int32 VALU instruction "
+                               "and SIMD (scripts/valu_calib.hip, profiles/%s/calibration.json) they occupy %.0f %% of the dispatch's cycles; %.0f %% of its "
+                               "wave-cycles are spent waiting.  SeedRest waits on dependent scattered reads; GroupedPairEvents / SmallPairEvents are "
+                               "register and LDS arithmetic." % (issue["valu_per_wave"], PROFILE_ROUND, issue["cycles_per_valu"], PROFILE_ROUND, 100 * issue["issue_frac"], 100 * issue.get("wait_frac", 0)))
+                else:
+                    limiter = ("vector-instruction issue (SQ counters of round 4: 1 201 vector + 402 scalar instructions per 128-sample wavefront of SeedExtend, 62 %% of its "
+                               "wave-cycles waiting); no SQ pass of this build on file, so no issue fraction is quoted")
+                frac_traffic = round(traffic_gbs / HBM_PEAK_GBS, 5) if traffic_gbs else None
+                roof = {"bound": "hbm",      # (the contract's two rooflines; what the kernel really waits for: `limiter`, `issue_frac`)
+                        "limiter": limiter,
+                        "issue_frac": issue.get("issue_frac") if issue else None, "issue": issue,
                         "kernel": "seed_extend (SeedExtend + SeedRest + GroupedPairEvents + SmallPairEvents)" if dom == "seed_extend" else dom,
-                        "achieved": round(alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_gbs / HBM_PEAK_GBS, 5),
-                        "frac_basis": "algorithmic bytes of this engine per launch / HIP-event time of the launch",
-                        "alg_model": "(m + n)/2 per (region, query genome) + 64 B per sampled K-mer (none for pairs that fit 128 bases) + 16 B per event",
-                        "alg_bytes_per_launch": int(alg_step / launches), "events_per_step": int(events_step),
+                        "achieved": round(traffic_gbs if traffic_gbs else alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": frac_traffic if frac_traffic is not None else round(alg_gbs / HBM_PEAK_GBS, 5),
+                        "frac_basis": ("fabric-side counter traffic of this build per launch (FETCH_SIZE + WRITE_SIZE, corrected; Infinity-Cache hits included: an upper bound of the HBM bytes) / HIP-event time of the launch"
+                                       if frac_traffic is not None else "byte model (no PMC pass of this build on file) / HIP-event time of the launch"),
+                        "alg_model": "per (region, query genome) m/2 + 8 B per sampled K-mer (a 64-B index request per leader = one sample in eight; none for pairs that fit 128 bases), "
+                                     "per region n/2, 64 B per sample SeedRest probes on its own, 16 B per event",
+                        "alg_achieved": round(alg_gbs, 2), "alg_frac": round(alg_gbs / HBM_PEAK_GBS, 5),
+                        "alg_bytes_per_launch": int(alg_step / launches), "events_per_step": int(events_step), "rest_samples_per_step": int(rest_step),
                         "alg_query_stream_bytes_per_launch": int(sum(r.get("alg_bytes_query", 0) for r in reports) / len(reports) / launches),
                         "launch_ms": round(launch_ms, 4), "launches_per_step": launches,
                         "traffic": traffic, "traffic_raw": traffic_raw, "traffic_note": traffic_note,
                         "traffic_includes_infinity_cache_hits": True,
                         "traffic_rate": round(traffic_gbs, 2) if traffic_gbs else None,
+                        "model_exceeds_traffic": (alg_step / launches > traffic) if traffic else None,
                         "peak_random": RANDOM_PEAK_GBS, "frac_of_peak_random": round(traffic_gbs / RANDOM_PEAK_GBS, 5) if traffic_gbs else None,
-                        "survey_8d": {"model": "m/4 + 16 m + 16 n per (region, query genome): one 8-byte probe and 16 bytes of state per query SUFFIX -- "
-                                               "this engine samples every (minsize-15)th K-mer instead, so it moves a fraction of these bytes",
+                        "survey_8d": {"not_a_bound": True,
+                                      "model": "m/4 + 16 m + 16 n per (region, query genome): one 8-byte probe and 16 bytes of state per query SUFFIX -- "
+                                               "this engine samples every (minsize-15)th K-mer and keeps no dense per-genome state, so it moves a fraction of these "
+                                               "bytes: the figure (a 'fraction' above 1) compares speeds, it bounds nothing",
                                       "bytes_per_launch": int(survey_step / launches), "achieved": round(survey_gbs, 2), "frac": round(survey_gbs / HBM_PEAK_GBS, 5)},
                         "anchor_launch": {"launch_ms": round(phases.get(dom, 0.0), 4), "survey_8d_bytes": int(b_alg * G),
-                                          "alg_bytes": int(G * ((m_avg + n_ref) / 2 + 64 * ((m_avg - 16) // max(1, anchor_stride) + 1)) + 16 * phases.get("events", 0.0)),
-                                          "achieved": round((G * ((m_avg + n_ref) / 2 + 64 * ((m_avg - 16) // max(1, anchor_stride) + 1)) + 16 * phases.get("events", 0.0)) / (phases[dom] * 1e-3) / 1e9, 2) if phases.get(dom) else None}}
+                                          "alg_bytes": int(anchor_alg(G, m_avg, n_ref, anchor_stride, phases)),
+                                          "achieved": round(anchor_alg(G, m_avg, n_ref, anchor_stride, phases) / (phases[dom] * 1e-3) / 1e9, 2) if phases.get(dom) else None}}
             # the device phases of a step against the byte roofline, largest first: algorithmic bytes per step (models in DESIGN.md 3,
             # from the counts the engine reports: events, reference positions, candidates, accepted MUM rows) / HIP-event time of
             # the phase on the engine's stream; reproducible from profiles/<round>/kernel_stats.csv (the kernels of a phase are named)
@@ -487,11 +547,39 @@ def main():
                     ktable.append({"phase": k, "kernels": names, "alg_bytes_per_step": int(nbytes), "ms_per_step": round(ms, 4), "achieved_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
                                    "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "model": model})
             ktable.sort(key=lambda r: -r["ms_per_step"])
+            # where the step's wall time is not device time: ms_per_step - the HIP-event phases of every engine call of a step
+            # (the list logic of the host, the round trips, the launches themselves)
+            kernel_ms = sum(v for k, v in totals.items() if k not in ("call_wall",) + counts)
+            ms_per_step = 1e3 * elapsed / args.steps
+            # BASELINE's other single-GPU configurations, a child run each (their own process: nothing of them is resident here)
+            other = None
+            want_other = args.other_configs == "on" or (args.other_configs == "auto" and args.workload == "bact200" and not args.genomes and world == 1 and not args.inputs)
+            if want_other:
+                other = {}
+                for wl, st in (("viral50", 20), ("rearr500", 3)):
+                    cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(st), "--warmup", "1", "--cpu-sample", "0", "--other-configs", "off",
+                           "--host-threads", str(args.host_threads)]
+                    try:
+                        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                        lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                        if pr.returncode == 0 and lines:
+                            cj = json.loads(lines[-1])
+                            other[wl] = {k: cj.get(k) for k in ("ms_per_step", "value", "steps", "host_cores_busy", "resident_route", "device_chain_steps", "mums", "lcbs", "anchors", "pcie_bytes_per_step", "host_ms_outside_kernels")}
+                            other[wl]["workload"] = cj.get("config", {}).get("workload")
+                        else:
+                            other[wl] = {"error": "child exit code %d: %s" % (pr.returncode, pr.stderr[-300:])}
+                    except subprocess.TimeoutExpired:
+                        other[wl] = {"error": "did not finish within 600 s"}
             if roof is not None:
                 roof["kernels"] = ktable
             line = {
                 "metric": "genomes/sec (MUM+LCB end-to-end)", "value": round(value, 4), "unit": "genomes/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+                "total_genomes": (1 if sharded else world) * G,      # N > 1, partition mode: N x G genomes in N alignments (weak scaling) -- not ONE job of G genomes on N GPUs, which is `sharded_strong`
+                "device_ms_per_step": round(kernel_ms, 3), "host_ms_outside_kernels": round(ms_per_step - kernel_ms, 3),
+                "materialize_ms": materialize_ms,      # (outside the timed region) the rows of the final MUM list fetched for the writer, once
+                "device_chain_steps": sum(int(r.get("device_chain", 0)) for r in reports),      # steps whose phases C-D came from the device in one call (pm_store_chain_*)
+                "other_configs": other,
                 "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
                 "config": {"workload": "%s: %d query genomes x %.2f Mb vs 1 reference (%s model, %s), --no-partition per GPU%s"
                            % (args.workload, G, n_ref / 1e6, dict(bact200="population").get(args.workload, "synthetic"),

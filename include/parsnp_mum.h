@@ -140,6 +140,11 @@ int64_t pm_result_table_id(const pm_result* r);
  *   "atomic_marks" != 0: pm_store_settle marks the layout with atomic ORs even where the list's order allows plain stores (tests)
  *   "group_small"  0: the events of a recursion batch's small regions are found pair by pair and sorted with the others, instead of
  *                  once per distinct query piece (default 1; both give the same events, tests compare the two)
+ *   "master_seg"   0: Master.EP by the round-4 kernel (every lane tests every staged event: MasterEP) instead of from the genomes'
+ *                  segments (MasterEPSeg; default 1; the same values, tests compare the two)
+ *   "chain_tie"    != 0: pm_store_chain_begin reports two MUMs with one reference start although there is none (tests: the
+ *                  caller's own list logic must give the same bytes)
+ *   "timing"       0: no HIP events around the phases of a call (pm_last_timing then reports counts only)
  * PM_EINVAL for an unknown key or a value out of range. */
 int pm_session_tune(pm_session* s, const char* key, int64_t value);
 
@@ -177,6 +182,9 @@ int pm_store_info(pm_session* s, int64_t first, int64_t count, pm_row_info* out)
  * rows in list order), kept when longer than q in every genome.  The kept regions are regions [0, *n_regions) of the region
  * store; pm_store_new_regions / _ids list them in the reference's push order. */
 int pm_store_seeds(pm_session* s, int64_t table_id, const int32_t* anchors, int64_t n_anchors, int32_t q, int64_t* n_regions);
+/* pm_store_settle and pm_store_seeds in one call, without the round trip between them: the accepted anchors are listed on the
+ * device and the kept regions arrive in the reference's push order (pm_store_new_regions / _ids).  PM_EAGAIN as pm_store_settle. */
+int pm_store_settle_seeds(pm_session* s, int64_t table_id, int32_t q, pm_row_info* rows, int64_t* n_regions);
 const pm_region_info* pm_store_new_regions(const pm_session* s);   /* of the last pm_store_seeds / pm_store_validate, valid until the next */
 const int32_t* pm_store_new_region_ids(const pm_session* s);
 int pm_store_regions_equal(pm_session* s, const int32_t* a, const int32_t* b, int64_t n, uint8_t* same);   /* TRegion operator== (LCR.cpp:48-58) */
@@ -188,11 +196,16 @@ int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsiz
  * found pairwise disjoint in every genome; the clusters are validated side by side, each in order: candidates settled against
  * the layout and marked (setMums1 second half), the neighbour regions of every new MUM longer than q appended to the region
  * store (:215-254; pm_store_new_regions lists them parent by parent, in push order; one equal to a region still waiting in its
- * cluster is dropped as the work list would, :294-306).  *trouble != 0: the reference's order would show (bit 0: a child sorts
- * before a region still waiting in its cluster; bit 1: a reverse-strand member outside its region) -- the caller must discard
- * the run and take the host route. */
+ * cluster is dropped as the work list would, :294-306).  *trouble != 0: the reference's order would show -- bit 0 (1): a child sorts
+ * before a region still waiting in its cluster; bit 1 (2): a reverse-strand member outside its region; bit 2 (4): a region with
+ * 2^22 candidates or more; bit 3 (8): the clusters are not disjoint in some genome.  The caller clusters on the reference only;
+ * disjointness in the query genomes is checked by the call itself (clusters in reference order must follow each other, with a
+ * base between, in every genome).  On trouble the caller must discard the run and take the host route.
+ * info_count > 0: the per-row scalars (pm_store_info) of store rows [info_first, info_first + info_count) -- the candidates
+ * just decided -- come back with the same round trip. */
 int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions,
-                      const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children);
+                      const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children,
+                      int64_t info_first, int64_t info_count, pm_row_info* info);
 /* The test of setFinalClusters (:2596-2700) of MUM cur[i] against the open chain's last MUM back[i]: verdict[i] = 0 every
  * genome's gap lies in [0, d] (min_gap / max_gap: what the ratio test :2693 reads), 1 the chain closes, 2 a reverse-strand
  * member (the strand rules of :2604-2625 depend on the genome order): the caller judges the pair from its rows. */
@@ -204,6 +217,21 @@ int pm_store_unmark(pm_session* s, const int32_t* rows, int64_t n);      /* the 
 int pm_store_fill(pm_session* s, const int32_t* last_of, const int32_t* first_of_next, int64_t n, uint8_t* add);
 const int64_t* pm_store_fill_starts(const pm_session* s);
 const int64_t* pm_store_fill_ends(const pm_session* s);
+/* Phases C-D in one queue of launches, for a run whose list logic is order-free -- all reference starts of the accepted MUMs
+ * differ, diag_diff <= 1 (the ratio test joins or closes, :2693), no MUM short enough for filterRandom1 (:338-425): the sort by
+ * reference start (:338, :2571), the chain walk of setFinalClusters (:2563-2719; the pairwise test of pm_store_judge, pairs with
+ * reverse-strand members included, with the ratio test applied on the device in the reference's float / double mix), the
+ * dissolving of LCBs no longer than c by filterRandomClustersSimple1 (:433-497; the last LCB is never examined, :447; their
+ * MUMs leave the layout), the second chaining pass (:3261-3268) and the fillers of setInterClusterRegions (:2389-2460; counted:
+ * a filler is never printed, it shifts the numbers of the LCBs behind it).  _begin queues the work and returns; _end waits
+ * for it: n_mums store rows in reference order (rows), a flag per MUM that begins an LCB (heads) -- both valid until the
+ * session's next chain call -- and the counters of the log.  trouble != 0: bit 0 two MUMs share a reference start (the
+ * reference's unstable sort decides: nothing on the device has changed, the caller runs pm_store_judge / _unmark / _fill with
+ * its own list logic); bit 1 the reference's filler bookkeeping would overrun (:2419-2433, pm_store_fill's add = 2).
+ * n_expected: the number of accepted store rows (the caller's MUM list); a mismatch is an error. */
+typedef struct { int64_t n_in, lcbs_first, lcbs_dissolved, mums_dissolved, n_mums, n_lcbs, n_fillers; uint64_t trouble; } pm_chain_info;
+int pm_store_chain_begin(pm_session* s, int64_t n_expected, int32_t d, float diag_diff, int64_t c);
+int pm_store_chain_end(pm_session* s, pm_chain_info* info, const int32_t** rows, const uint8_t** heads);
 /* Rows for the host (the XMFA writer after the LCBs are final; a caller falling back to the host route): start[i * n_genomes + j]
  * with the trim applied (raw != 0: as the search delivered it), strand byte.  rows == NULL: store rows [first, first + n). */
 int pm_store_rows(pm_session* s, const int32_t* rows, int64_t first, int64_t n, int raw, int32_t* start, uint8_t* strand);

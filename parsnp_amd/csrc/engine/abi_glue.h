@@ -163,6 +163,20 @@ int pm_store_seeds(pm_session* s, int64_t table_id, const int32_t* anchors, int6
     } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
     } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
 }
+int pm_store_settle_seeds(pm_session* s, int64_t table_id, int32_t q, pm_row_info* rows, int64_t* n_regions) {
+    if (!s || !rows || !n_regions) return fail(PM_EINVAL, "bad argument");
+    *n_regions = 0;
+    try {
+        const auto w0 = std::chrono::steady_clock::now();
+        const int rc = s->engine->store_settle_seeds(table_id, q, (pm::RowInfo*)rows, &s->new_regions, &s->new_region_ids);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        *n_regions = (int64_t)s->new_regions.size();
+        return PM_OK;
+    } catch (const std::bad_alloc&) { return fail(PM_ENOMEM, "host allocation failed");
+    } catch (const pm::Engine<PmBackend>::DeviceOutOfMemory& e) { return fail(PM_ENOMEM, "device allocation of " + std::to_string(e.bytes) + " bytes failed"); }
+}
 const pm_region_info* pm_store_new_regions(const pm_session* s) { return s ? (const pm_region_info*)s->new_regions.data() : nullptr; }
 const int32_t* pm_store_new_region_ids(const pm_session* s) { return s ? s->new_region_ids.data() : nullptr; }
 int pm_store_regions_equal(pm_session* s, const int32_t* a, const int32_t* b, int64_t n, uint8_t* same) {
@@ -174,12 +188,13 @@ int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsiz
     PM_STORE_CALL(s->engine->store_search(regions, minsize, n, first_row, offsets))
 }
 int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions,
-                      const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children) {
-    if (!s || n_regions < 0 || n_clusters < 0 || (n_regions > 0 && (!regions || !row_first || !row_count || !cluster_first)) || !trouble || !n_children) return fail(PM_EINVAL, "bad argument");
+                      const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children,
+                      int64_t info_first, int64_t info_count, pm_row_info* info) {
+    if (!s || n_regions < 0 || n_clusters < 0 || (n_regions > 0 && (!regions || !row_first || !row_count || !cluster_first)) || !trouble || !n_children || info_count < 0 || (info_count > 0 && !info)) return fail(PM_EINVAL, "bad argument");
     *n_children = 0;
     try {
         const auto w0 = std::chrono::steady_clock::now();
-        const int rc = s->engine->store_validate(regions, row_first, row_count, n_regions, cluster_first, n_clusters, q, trouble, &s->new_regions, &s->new_region_ids);
+        const int rc = s->engine->store_validate(regions, row_first, row_count, n_regions, cluster_first, n_clusters, q, trouble, &s->new_regions, &s->new_region_ids, info_first, info_count, (pm::RowInfo*)info);
         if (rc) return fail(rc, s->engine->error);
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
         s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
@@ -199,6 +214,15 @@ int pm_store_unmark(pm_session* s, const int32_t* rows, int64_t n) {
 int pm_store_fill(pm_session* s, const int32_t* last_of, const int32_t* first_of_next, int64_t n, uint8_t* add) {
     if (!s || n < 0 || (n > 0 && (!last_of || !first_of_next || !add))) return fail(PM_EINVAL, "bad argument");
     PM_STORE_CALL(s->engine->store_fill(last_of, first_of_next, n, add, &s->fill_starts, &s->fill_ends))
+}
+int pm_store_chain_begin(pm_session* s, int64_t n_expected, int32_t d, float diag_diff, int64_t c) {
+    if (!s) return fail(PM_EINVAL, "bad argument");
+    PM_STORE_CALL(s->engine->store_chain_begin(n_expected, d, diag_diff, c))
+}
+int pm_store_chain_end(pm_session* s, pm_chain_info* info, const int32_t** rows, const uint8_t** heads) {
+    if (!s || !info || !rows || !heads) return fail(PM_EINVAL, "bad argument");
+    static_assert(sizeof(pm_chain_info) == sizeof(pm::Engine<PmBackend>::ChainInfo), "pm_chain_info");
+    PM_STORE_CALL(s->engine->store_chain_end((pm::Engine<PmBackend>::ChainInfo*)info, rows, heads))
 }
 const int64_t* pm_store_fill_starts(const pm_session* s) { return s ? s->fill_starts.data() : nullptr; }
 const int64_t* pm_store_fill_ends(const pm_session* s) { return s ? s->fill_ends.data() : nullptr; }

@@ -509,7 +509,8 @@ public:
         // -- Master.EP, candidates
         be.mark("master_ep");
         be.launch("coarse_fill", (int64_t)nev, CoarseFill{skey, (int64_t)nev, lbits, d_lo.p, d_R.p, d_cbase.p, nq, d_coarse.p});
-        be.launch_wave("master_ep", xcd_grid(nchunks), MasterEP{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, grouping ? d_gflag.p : nullptr, nchunks});
+        if (master_seg) be.launch_wave("master_ep_seg", xcd_grid(nchunks), MasterEPSeg{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, grouping ? d_gflag.p : nullptr, nchunks});
+        else be.launch_wave("master_ep", xcd_grid(nchunks), MasterEP{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, grouping ? d_gflag.p : nullptr, nchunks});
         int32_t verdict = 0;
         if (sharded && coll.device) {   // exchange 1 on the device: RCCL all-reduce(min) of Master.EP in place, + the error verdict word
             be.mark("exchange_ep");
@@ -711,6 +712,11 @@ public:
     // nothing earlier are settled at once and marked; the flagged ones against those marks -- all at once where they meet no
     // other flagged row, in list order where they do.  out[c] for every row of the table.
     int store_settle(int64_t table_id, RowInfo* out) {
+        if (int rc = settle_launch(table_id)) return rc;
+        return store_info(0, anchor_table_rows, out);
+    }
+    // the launches of store_settle (nothing is waited for)
+    int settle_launch(int64_t table_id) {
         if (int rc = need_resident(table_id)) return rc;
         begin_store_call();
         const int64_t rows = anchor_table_rows;
@@ -743,8 +749,63 @@ public:
             be.launch_wave("settle_tangled", 1, SettleTangled{S, L, P, d_list.p, (int64_t)fl.size()});
         }
         layout_rows = rows;
-        const int rc = store_info(0, rows, out);
-        return rc;
+        return 0;
+    }
+    // store_settle and store_seeds in one call, without the round trip between them: the accepted anchors are listed on the device,
+    // the kept regions are placed in the reference's push order (SeedCount / SeedPlace), and the per-row scalars of the table travel
+    // with the regions' summaries.  infos / ids: as store_seeds leaves them.
+    int store_settle_seeds(int64_t table_id, int32_t q, RowInfo* out, std::vector<RegInfo>* infos, std::vector<int32_t>* ids) {
+        infos->clear(); ids->clear();
+        if (int rc = settle_launch(table_id)) return rc;
+        const int64_t rows = anchor_table_rows;
+        rg_count = 0;
+        if (rows == 0) return 0;
+        const Store S = store_view();
+        ensure(d_rowinfo, (size_t)rows);
+        be.launch("store_info", rows, StoreInfoOut{S, 0, d_rowinfo.p});
+        be.mark("seeds");
+        ensure(d_ch_flag, (size_t)rows + 1); ensure(d_ch_pos, (size_t)rows + 1); ensure(d_list, (size_t)rows);
+        ensure(d_sd_cnt, (size_t)rows + 1); ensure(d_sd_off, (size_t)rows + 1); ensure(d_sd_keep, (size_t)rows);
+        be.launch("chain_flag", rows + 1, ChainFlag{S, rows, d_ch_flag.p});
+        be.exclusive_scan(d_ch_flag.p, d_ch_pos.p, (size_t)rows + 1);
+        be.launch("anchor_list", rows, AnchorList{S, d_ch_pos.p, d_list.p});
+        const int64_t* nacc = d_ch_pos.p + rows;
+        const Layout L = layout_view(d_image.p, false);
+        be.memset(d_sd_cnt.p + rows, 0, 8);
+        be.launch_wave("seed_count", xcd_grid(rows), SeedCount{S, L, P, d_list.p, nacc, q, d_sd_cnt.p, d_sd_keep.p, rows});
+        be.exclusive_scan(d_sd_cnt.p, d_sd_off.p, (size_t)rows + 1);
+        size_t cap = std::max<size_t>(rg_cap_hint, (size_t)rows / 4 + 1024);
+        std::vector<RegInfo> raw;
+        for (bool again = false;; again = true) {
+            ensure(d_rg_start, cap * (size_t)ngen); ensure(d_rg_len, cap * (size_t)ngen); ensure(d_rg_info, cap);
+            be.launch_wave("seed_place", xcd_grid(rows), SeedPlace{S, L, P, d_list.p, nacc, d_sd_off.p, d_sd_keep.p, d_rg_start.p, d_rg_len.p, d_rg_info.p, (uint64_t)cap, rows});
+            be.mark(nullptr);
+            // the summaries travel with the count: as many as the last run had (a run with more fetches the rest)
+            const size_t guess = std::min(cap, rg_cap_hint);
+            raw.resize(guess);
+            if (guess) be.d2h_async(raw.data(), d_rg_info.p, sizeof(RegInfo) * guess);
+            if (!again) be.d2h_async(out, d_rowinfo.p, sizeof(RowInfo) * (size_t)rows);
+            int64_t got = 0;
+            be.d2h(&got, d_sd_off.p + rows, 8);
+            if ((size_t)got <= cap) {
+                rg_count = got;
+                raw.resize((size_t)got);
+                if ((size_t)got > guess) be.d2h(raw.data() + guess, d_rg_info.p + guess, sizeof(RegInfo) * ((size_t)got - guess));
+                break;
+            }
+            cap = (size_t)got + (size_t)got / 8 + 64;
+            be.mark("seeds");
+        }
+        rg_cap_hint = (size_t)rg_count + (size_t)rg_count / 4;
+        if (rg_info_h.size() < (size_t)rg_count) rg_info_h.resize((size_t)rg_count);
+        bool sorted = true;
+        for (int64_t i = 0; i < rg_count; i++) { rg_info_h[(size_t)i] = raw[(size_t)i]; if (i && raw[(size_t)i - 1].key >= raw[(size_t)i].key) sorted = false; }
+        if (!sorted) { error = "seed regions out of order"; return -4; }
+        infos->swap(raw);
+        ids->resize((size_t)rg_count);
+        for (int64_t i = 0; i < rg_count; i++) (*ids)[(size_t)i] = (int32_t)i;
+        collect_timing_more();
+        return 0;
     }
     // per-row scalars of store rows [first, first + count)
     int store_info(int64_t first, int64_t count, RowInfo* out) {
@@ -836,7 +897,7 @@ public:
     // One generation of the recursion (doWork, src/parsnp.cpp:173-317) over clusters of waiting regions that the caller found
     // pairwise disjoint in every genome: candidates settled against the image and marked, children appended to the region store.
     int store_validate(const int32_t* regions, const int64_t* row0, const int32_t* cnt, int64_t nreg, const int64_t* cluster_first, int64_t ncl, int32_t q,
-                       uint32_t* trouble, std::vector<RegInfo>* kids, std::vector<int32_t>* kid_ids) {
+                       uint32_t* trouble, std::vector<RegInfo>* kids, std::vector<int32_t>* kid_ids, int64_t info_first = 0, int64_t info_count = 0, RowInfo* info = nullptr) {
         if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
         kids->clear(); kid_ids->clear(); *trouble = 0;
         if (nreg == 0 || ncl == 0) return 0;
@@ -865,7 +926,13 @@ public:
         be.launch_wave("cluster_validate", xcd_grid(ncl),
                        ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
                                        d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), (int64_t)ncl});
+        if (info_count > 0) {      // the scalars of the candidates just decided, with the same round trip
+            if (info_first < 0 || info_first + info_count > ms_count) { error = "rows outside the MUM store"; return -2; }
+            ensure(d_rowinfo, (size_t)info_count);
+            be.launch("store_info", info_count, StoreInfoOut{store_view(), info_first, d_rowinfo.p});
+        }
         be.mark(nullptr);
+        if (info_count > 0) be.d2h_async(info, d_rowinfo.p, sizeof(RowInfo) * (size_t)info_count);
         be.d2h(head, d_rg_count.p, 16);
         *trouble = (uint32_t)head[1];
         if (head[0] > cap) { error = "region store overflow"; return -4; }
@@ -938,6 +1005,80 @@ public:
         collect_timing_more();
         return 0;
     }
+    // Phases C-D where their list logic is order-free (store_kernels.h, "phases C-D on the store"): the accepted rows sorted by
+    // reference start, chained, the short LCBs dissolved, chained again, the fillers counted -- one queue of launches, no round
+    // trip.  Two halves: begin() queues the work and the copies, end() waits for them; the caller may work in between.
+    // expect: the number of accepted rows (the caller's MUM list).
+    struct ChainInfo { int64_t n_in, lcbs_first, lcbs_dissolved, mums_dissolved, n_mums, n_lcbs, n_fillers; uint64_t trouble; };
+    int store_chain_begin(int64_t expect, int32_t d, float diag_diff, int64_t c) {
+        if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
+        if (expect <= 0 || expect > ms_count) { error = "bad MUM count"; return -2; }
+        if (chain_event) { be.event_wait(chain_event); be.event_release(chain_event); chain_event = nullptr; }
+        begin_store_call();
+        const size_t rows = (size_t)ms_count, cap = (size_t)expect;
+        ensure(d_ch_flag, rows + 1); ensure(d_ch_pos, rows + 1);
+        ensure(d_ch_key, cap); ensure(d_ch_val, cap); ensure(d_ch_skey, cap); ensure(d_ch_srow, cap); ensure(d_ch_key2, cap); ensure(d_ch_row2, cap);
+        ensure(d_ch_verdict, cap); ensure(d_ch_head, cap + 1); ensure(d_ch_hpos, cap + 1); ensure(d_ch_survive, cap + 1); ensure(d_ch_spos, cap + 1);
+        ensure(d_ch_lcblen, cap); ensure(d_ch_hdr, kChWords); ensure(d_ch_outrow, cap); ensure(d_ch_outhead, cap);
+        const size_t host_bytes = 8 * (size_t)kChWords + 4 * cap + cap;
+        if (host_bytes > chain_host_cap) {
+            if (chain_host) be.pinned_free(chain_host);
+            chain_host_cap = 0;
+            chain_host = (uint8_t*)be.pinned_alloc(host_bytes + host_bytes / 4 + 64);
+            if (!chain_host) { error = "cannot allocate the chain result block"; return -3; }
+            chain_host_cap = host_bytes + host_bytes / 4 + 64;
+        }
+        chain_cap = (int64_t)cap;
+        const Store S = store_view();
+        be.mark("chain");
+        {
+            const ClearJob jobs[] = {{d_ch_hdr.p, 8 * (size_t)kChWords, 0}, {d_ch_lcblen.p, 8 * cap, 0}};
+            be.clear_many(jobs, 2);
+        }
+        be.launch("chain_flag", (int64_t)rows + 1, ChainFlag{S, (int64_t)rows, d_ch_flag.p});
+        be.exclusive_scan(d_ch_flag.p, d_ch_pos.p, rows + 1);
+        be.launch("chain_keys", (int64_t)rows, ChainKeys{S, d_ch_pos.p, d_ch_key.p, d_ch_val.p, (int64_t)cap});
+        be.sort_pairs(d_ch_key.p, d_ch_skey.p, d_ch_val.p, d_ch_srow.p, cap, bits_for((uint64_t)glen_h[0]));
+        const int64_t* n1 = d_ch_pos.p + rows;
+        int64_t* hdr = d_ch_hdr.p;
+        uint64_t* trouble = (uint64_t*)(hdr + kChTrouble);
+        // first pass: verdicts, chains, their lengths, the dissolved ones out of the layout and out of the list
+        be.launch_wave("chain_judge", (int64_t)cap, ChainJudge{S, d_ch_skey.p, d_ch_srow.p, n1, d, diag_diff, d_ch_verdict.p, trouble, force_chain_tie ? 1 : 0});
+        be.launch("chain_heads", (int64_t)cap + 1, ChainHeads{d_ch_verdict.p, n1, d_ch_head.p});
+        be.exclusive_scan(d_ch_head.p, d_ch_hpos.p, cap + 1);
+        be.launch("chain_lcb_sum", (int64_t)cap, ChainLcbSum{S, d_ch_srow.p, n1, d_ch_hpos.p, d_ch_lcblen.p});
+        be.launch("chain_dissolve", (int64_t)cap + 1, ChainDissolve{n1, d_ch_hpos.p, d_ch_head.p, d_ch_lcblen.p, c, d_ch_survive.p, hdr});
+        be.launch_wave("chain_unmark", (int64_t)cap, ChainUnmark{S, layout_view(d_image.p), d_ch_srow.p, n1, d_ch_survive.p});
+        be.exclusive_scan(d_ch_survive.p, d_ch_spos.p, cap + 1);
+        be.launch("chain_compact", (int64_t)cap, ChainCompact{n1, d_ch_survive.p, d_ch_spos.p, d_ch_skey.p, d_ch_srow.p, d_ch_key2.p, d_ch_row2.p, hdr});
+        // second pass (the reference chains again after dissolving, :3261-3268), then the fillers between the final LCBs
+        const int64_t* n2 = hdr + kChN2;
+        be.launch_wave("chain_judge", (int64_t)cap, ChainJudge{S, d_ch_key2.p, d_ch_row2.p, n2, d, diag_diff, d_ch_verdict.p, trouble, 0});
+        be.launch("chain_heads", (int64_t)cap + 1, ChainHeads{d_ch_verdict.p, n2, d_ch_head.p});
+        be.exclusive_scan(d_ch_head.p, d_ch_hpos.p, cap + 1);
+        if (cap > 1) be.launch_wave("chain_fill", (int64_t)cap - 1, ChainFill{S, layout_view(d_image.p, false), P, d_ch_row2.p, n2, d_ch_head.p, hdr});
+        be.launch("chain_out", (int64_t)cap, ChainOut{d_ch_row2.p, n2, d_ch_head.p, d_ch_hpos.p, d_ch_outrow.p, d_ch_outhead.p, hdr});
+        be.mark(nullptr);
+        be.d2h_async(chain_host, hdr, 8 * (size_t)kChWords);
+        be.d2h_async(chain_host + 8 * (size_t)kChWords, d_ch_outrow.p, 4 * cap);
+        be.d2h_async(chain_host + 8 * (size_t)kChWords + 4 * cap, d_ch_outhead.p, cap);
+        chain_event = be.event_record();
+        chain_pending = true;
+        return 0;
+    }
+    int store_chain_end(ChainInfo* info, const int32_t** rows, const uint8_t** heads) {
+        if (!chain_pending) { error = "no chain call in flight"; return -2; }
+        chain_pending = false;
+        if (chain_event) { be.event_wait(chain_event); be.event_release(chain_event); chain_event = nullptr; }
+        else be.sync();
+        const int64_t* h = (const int64_t*)chain_host;
+        *info = ChainInfo{h[kChN1], h[kChLcb1], h[kChLcbDissolved], h[kChMumDissolved], h[kChN2], h[kChLcb2], h[kChFill], (uint64_t)h[kChTrouble]};
+        *rows = (const int32_t*)(chain_host + 8 * (size_t)kChWords);
+        *heads = chain_host + 8 * (size_t)kChWords + 4 * (size_t)chain_cap;
+        collect_timing_more();
+        if (info->n_in != chain_cap) { error = "the MUM list of the caller and the accepted rows of the store differ"; return -2; }
+        return 0;
+    }
     // rows of the store for the host (the XMFA writer after phase D; a caller that falls back to the host route): start per genome
     // with the trim applied (raw: as the search delivered them) + strand byte.  rows == nullptr: rows [first, first + n)
     int store_rows(const int32_t* rows, int64_t first, int64_t n, bool raw, int32_t* out_start, uint8_t* out_strand) {
@@ -999,9 +1140,15 @@ public:
     bool group_small = true;      // the events of a recursion batch's small regions once per distinct piece (GroupedPairEvents)
     int64_t last_grouped = 0;
     bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
+    bool master_seg = true;               // Master.EP from the genomes' segments (MasterEPSeg); false: every lane against every staged event (MasterEP)
+    bool force_chain_tie = false;         // (tests) store_chain_begin reports two MUMs with one reference start
+    bool phase_timing = true;             // HIP events around the phases of a call (pm_last_timing); off: the marks cost nothing
     bool tune(const std::string& key, int64_t value) {
         if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
+        if (key == "master_seg") { master_seg = value != 0; return true; }
+        if (key == "chain_tie") { force_chain_tie = value != 0; return true; }
+        if (key == "timing") { phase_timing = value != 0; be.timing_on = phase_timing; return true; }
         if (key == "group_small") { group_small = value != 0; return true; }
         if (key == "work_budget" && value > 0) { work_budget = value; return true; }
         if (key == "dirty_min" && value >= 0) { dirty_min = value; return true; }
@@ -1009,7 +1156,10 @@ public:
     }
 
     void release() {
+        if (chain_event) { be.event_wait(chain_event); be.event_release(chain_event); chain_event = nullptr; }
         for (BufBase* b : all_bufs) { if (b->raw) be.free(b->raw); b->raw = nullptr; b->cap = 0; }
+        if (chain_host) be.pinned_free(chain_host);
+        chain_host = nullptr; chain_host_cap = 0; chain_pending = false;
         if (blk) be.free(blk);
         if (d_goff) be.free(d_goff);
         if (d_glen) be.free(d_glen);
@@ -1072,6 +1222,12 @@ private:
     Buf<uint8_t> d_ms_strand, d_ms_state, d_small8, d_o_strand; Buf<int32_t> d_ms_shift, d_ms_len, d_list, d_list2, d_j_min, d_j_max, d_o_start;
     Buf<int64_t> d_rg_start, d_rg_len, d_lay_off, d_lay_bits, d_v_row0, d_v_first, d_f_start, d_f_end, d_f_pack; Buf<RegInfo> d_rg_info; Buf<uint64_t> d_rg_count, d_once, d_twice;
     Buf<RowInfo> d_rowinfo; Buf<uint64_t> d_alg;
+    Buf<int64_t> d_sd_cnt, d_sd_off; Buf<uint8_t> d_sd_keep;      // store_settle_seeds
+    // store_chain_begin / _end
+    Buf<int64_t> d_ch_flag, d_ch_pos, d_ch_head, d_ch_hpos, d_ch_survive, d_ch_spos, d_ch_hdr;
+    Buf<uint64_t> d_ch_key, d_ch_val, d_ch_skey, d_ch_srow, d_ch_key2, d_ch_row2, d_ch_lcblen;
+    Buf<uint8_t> d_ch_verdict, d_ch_outhead; Buf<int32_t> d_ch_outrow;
+    uint8_t* chain_host = nullptr; size_t chain_host_cap = 0; void* chain_event = nullptr; bool chain_pending = false; int64_t chain_cap = 0;
     size_t lay_words = 0, rg_cap_hint = 0;
     int64_t layout_rows = -1;       // >= 0: the image holds the layout of the current anchor table (store_settle ran)
 };

@@ -26,14 +26,6 @@ __global__ __launch_bounds__(256) void pm_kernel(F f, int64_t n) {
     int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (tid < n) f(tid);
 }
-#if defined(PM_SEED_WAVES)
-// measurement builds only (make exp): SeedExtend compiled for a given number of wavefronts per SIMD (registers spill instead)
-template <>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PM_SEED_WAVES, 8))) void pm_kernel<pm::SeedExtend>(pm::SeedExtend f, int64_t n) {
-    int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (tid < n) f(tid);
-}
-#endif
 
 // clearing of the large tables (64 MB of index slots, the 16 MB coarse table, the layout images): 16 bytes per lane and step,
 // every workgroup a contiguous stretch.  (hipMemsetAsync's fill kernel was measured at 0.43 TB/s on the slot table: 149 us.)
@@ -368,7 +360,9 @@ struct HipBackend {
     }
 
     // phase timing: mark(name) opens a phase, mark(nullptr) closes the last one
+    bool timing_on = true;      // pm_session_tune(s, "timing", 0): no events, collect() only waits for the stream
     void mark(const char* name) {
+        if (!timing_on) return;
         hipEvent_t e;
         if (!pool.empty()) { e = pool.back(); pool.pop_back(); }
         else if (!check(hipEventCreate(&e), "hipEventCreate")) return;

@@ -233,14 +233,9 @@ constexpr int kUnitSamples = 64 * kPer;   // query samples per work unit
 #define PM_LEAD 8
 #endif
 constexpr int kLead = PM_LEAD;         // SeedExtend: one lane in kLead (a leader) probes the index, the others follow its hit
-#ifndef PM_NEIGHBOURS
-#define PM_NEIGHBOURS 0
-#endif
-// ... and a lane whose first K-mer is not there tries one base to either side (SeedExtend's window phase).  MEASURED at 200 x 5 Mb
-// and left off: the samples handed to SeedRest drop from 5.48 M to 2.45 M and SeedRest from 0.50 to 0.29 ms, but SeedExtend --
-// bound by instruction issue -- pays 129 more vector instructions (883 -> 1 012 static) in nearly every wavefront: 1.78 -> 1.99 ms.
-// The same events either way (the GPU parity tests pass with it on).
-constexpr bool kNeighbourDiagonals = PM_NEIGHBOURS != 0;
+// (A lane whose first K-mer is not at the predicted position trying one base to either side in the windows it holds was measured
+// in round 4 and removed in round 5: SeedRest's queue halves, 0.50 -> 0.29 ms, but SeedExtend -- bound by instruction issue -- pays
+// 129 more vector instructions in nearly every wavefront, 1.78 -> 1.99 ms.  History: up to commit 682a045.)
 #ifndef PM_KMAX
 #define PM_KMAX 16
 #endif
@@ -794,7 +789,6 @@ struct SeedExtend {
         // other's memory latency.
         enum : uint8_t { kNone = 0, kProbe = 1, kFwd = 2, kRev = 4 };      // what to do with a sample after the window phase
         uint8_t todo[kPer]; int32_t left[kPer], right[kPer];
-        int cut = 0;      // 1: the lane's windows were shifted up by a base and end one base earlier
         {
             bool any_fast = false;
             bool fast[kPer];
@@ -819,35 +813,6 @@ struct SeedExtend {
                 rw1 = funnel(r1, r2, shr);
                 d0 = diff_of(qw0, rw0); d1 = diff_of(qw1, rw1); d2 = diff_of(qw2, rw2);
                 rwords = (uint64_t)rep0 | ((uint64_t)rep1 << 32);
-                // A single-base insertion or deletion between the leader and this lane puts the lane's K-mers ONE diagonal beside
-                // the predicted one -- what most of the samples handed to SeedRest were (5.5 % of all at 200 x 5 Mb).  The three
-                // reference windows in registers hold the neighbouring diagonals too: if the lane's first K-mer is not at the
-                // predicted position but is one base to either side, that position becomes the lane's prediction and the windows
-                // are shifted by a base.  (Any guess is as good as another: a predicted position only counts where the K-mer is
-                // there and occurs nowhere else in R.)  The base that a shift moves in at the far end is not in the registers: it
-                // counts as a difference -- 32 bases to the left nothing looks (only `stride` bases of a left arm matter); on the
-                // right the arm goes on from memory one base earlier (`cut`).
-                if (kNeighbourDiagonals && fast[0] && !own_probe && !((d1.x & kbits) == 0 && (d1.m & kmask) == 0)) {
-                    int delta = 0;
-                    if (base + 1 + K <= ri.nR && ((qw1.b ^ (rw1.b >> 2)) & kbits) == 0 && ((qw1.m ^ (rw1.m >> 1)) & kmask) == 0) delta = 1;
-                    else if (base >= 1 && rbit0 > 0 && ((qw1.b ^ ((rw1.b << 2) | (rw0.b >> 62))) & kbits) == 0 && ((qw1.m ^ ((rw1.m << 1) | (rw0.m >> 31))) & kmask) == 0) delta = -1;
-                    if (delta > 0) {
-                        const Win n0{(rw0.b >> 2) | (rw1.b << 62), (rw0.m >> 1) | (rw1.m << 31)}, n1{(rw1.b >> 2) | (rw2.b << 62), (rw1.m >> 1) | (rw2.m << 31)}, n2{rw2.b >> 2, rw2.m >> 1};
-                        d0 = diff_of(qw0, n0); d1 = diff_of(qw1, n1); d2 = diff_of(qw2, n2);
-                        d2.x |= 1ull << 62;
-                        rw1 = n1; cut = 1;
-                    } else if (delta < 0) {
-                        const Win n0{rw0.b << 2, rw0.m << 1}, n1{(rw1.b << 2) | (rw0.b >> 62), (rw1.m << 1) | (rw0.m >> 31)}, n2{(rw2.b << 2) | (rw1.b >> 62), (rw2.m << 1) | (rw1.m >> 31)};
-                        d0 = diff_of(qw0, n0); d1 = diff_of(qw1, n1); d2 = diff_of(qw2, n2);
-                        d0.x |= 1ull;
-                        rw1 = n1;
-                    }
-                    if (delta) {
-                        base += delta; rbit0 += delta;
-#pragma unroll
-                        for (int u = 1; u < kPer; u++) fast[u] = fast[u] && base + u * stride + K <= ri.nR;
-                    }
-                }
             }
             bool fwd_here = false;       // the previous sample of this lane was confirmed as a forward seed on this diagonal
 #pragma unroll
@@ -926,7 +891,7 @@ struct SeedExtend {
                 const int32_t rep_l0 = rep[ri.posbase + l - lf];          // in flight while the right arm is compared
                 const int64_t mr = m - j - K; const int32_t rr = ri.nR - l - K;
                 const int32_t maxr = (int32_t)(mr < rr ? mr : rr);
-                const int32_t reach = 64 - u * stride - K - cut;          // bases after the K-mer that the windows hold
+                const int32_t reach = 64 - u * stride - K;          // bases after the K-mer that the windows hold
                 int32_t rt = right[u];
                 if (rt >= reach && maxr > reach) rt = reach + lce_fwd64(P, qbase + j + K + reach, rbase + l + K + reach, maxr - reach);
                 if (rt > maxr) rt = maxr;

@@ -68,6 +68,96 @@ inline uint64_t atomic_fetch_or64(uint64_t* p, uint64_t v) { const uint64_t o = 
 inline void atomic_and64(uint64_t* p, uint64_t v) { *p &= v; }
 #endif
 
+// LDS atomics of the wavefront kernels (plain updates in the emulation, where one thread plays every lane)
+PM_HD void lds_min32(int32_t* p, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMin(p, v);
+#else
+    if (v < *p) *p = v;
+#endif
+}
+PM_HD int32_t lds_add32(int32_t* p, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(p, v);
+#else
+    const int32_t o = *p; *p = o + v; return o;
+#endif
+}
+// ------------------------------------------------------------------------------------------ Master.EP from segments
+// Master.EP of a chunk of 256 reference positions = the pointwise minimum over the query genomes of EP_g, and EP_g is a STEP
+// function: the furthest end over the genome's events that start at or before k (`emax` of the last such event), which only
+// rises with k.  MasterEP (kernels.h) lets every lane test every staged event of every genome against its four positions --
+// 6 500 vector instructions per chunk at 200 genomes, the events of a chunk being ~2 per genome.  Here the lanes take the GENOMES:
+// a genome's function is the list of its segments (value, end), and because the values of one genome never fall,
+//     EP_g[k] = min { value of s : s a segment of g that ends after k },
+// so the minimum over all genomes is the same expression over ALL segments: every segment drops its value at its last position
+// (an LDS atomicMin on a 256-entry array, ~3 per genome) and a suffix minimum over the array gives every position the smallest
+// value of the segments that end after it.  One body for the device and for the CPU suite's emulation (lanes_for / wave_sync).
+struct MasterEPSeg {
+    const RegionInfo* R; int64_t nregions;
+    int32_t ngen; const uint64_t* key; const int64_t* lo; const int32_t* emax; int lbits; int32_t* epm;
+    const int64_t* cbase; const int32_t* coarse;
+    int32_t g_first, g_last;   // sharded run: the min over the other genomes arrives by all-reduce
+    const uint8_t* grouped;    // [region] != 0: GroupedPairEvents has written the region's Master.EP; nullptr: none
+    int64_t nchunks;           // the launch is xcd_grid(nchunks) wavefronts: neighbouring chunks (the same lines of events) on one L2
+    PM_HD void wave(int64_t w0) const {
+        const int64_t w = xcd_item(w0, nchunks);
+        if (w >= nchunks) return;
+        const int32_t nq = ngen - 1;
+        const int64_t r = region_of_chunk(cbase, nregions, w);
+        if (grouped && grouped[r]) return;
+        const RegionInfo& ri = R[r];
+        const int64_t b = w - (cbase[r] - r);
+        const int32_t k0 = (int32_t)(b << kCoarseShift);
+        const uint64_t lmask = (1ull << lbits) - 1;
+        const int32_t* row = coarse + cbase[r] * nq + b * nq;
+        const int ga = g_first - 1, gb = g_last - 1;
+        PM_WAVE_SHARED int32_t A[kChunkPos];      // A[e]: the smallest value of a segment whose last position is e
+        PM_WAVE_SHARED int32_t part[2][64];
+        const int32_t top = ri.nR;
+        lanes_for(0, kChunkPos, [&](int e) { A[e] = top; });
+        wave_sync();
+        lanes_for(ga, gb, [&](int g) {
+            const int64_t first = lo[r * nq + g];
+            const int64_t a = first + row[g], e = first + row[nq + g];
+            int32_t v = a > first ? emax[a - 1] : 0;      // the genome's value where the chunk begins
+            for (int64_t i = a; i < e; i++) {
+                const int32_t l = (int32_t)((key[i] >> 1) & lmask) - k0;      // the segment before event i ends at l - 1
+                if (l >= 1) lds_min32(&A[l - 1], v);
+                v = emax[i];
+            }
+            lds_min32(&A[kChunkPos - 1], v);      // the last segment runs to the end of the chunk
+        });
+        wave_sync();
+        // suffix minimum: inside every lane's four entries, then over the lanes' minima (six doubling steps through LDS)
+        lanes_for(0, 64, [&](int t) {
+            int32_t m = A[4 * t + 3];
+            for (int u = 2; u >= 0; u--) { const int32_t x = A[4 * t + u]; if (x < m) m = x; A[4 * t + u] = m; }
+            part[0][t] = m;
+        });
+        wave_sync();
+        int cur = 0;
+        for (int d = 1; d < 64; d <<= 1) {
+            lanes_for(0, 64, [&](int t) {
+                int32_t x = part[cur][t];
+                if (t + d < 64) { const int32_t y = part[cur][t + d]; if (y < x) x = y; }
+                part[cur ^ 1][t] = x;
+            });
+            wave_sync();
+            cur ^= 1;
+        }
+        lanes_for(0, 64, [&](int t) {
+            const int32_t above = t < 63 ? part[cur][t + 1] : 0x7fffffff;
+            for (int u = 0; u < 4; u++) {
+                const int32_t k = k0 + 4 * t + u;
+                if (k >= ri.nR) break;
+                const int32_t x = A[4 * t + u];
+                epm[ri.posbase + k] = x < above ? x : above;
+            }
+        });
+    }
+};
+
 // ------------------------------------------------------------------------------------------ the stores
 // state of a store row (what Aligner::validate_parallel keeps per candidate)
 constexpr uint8_t kStBuilt = 1;      // the reference constructs a TMum for it (no kRowBad, :1723)
@@ -467,9 +557,62 @@ struct SeedWalk {
         }
     }
 };
+// The same seed regions without a host round trip between the validation of the anchor list and the walks, and in the
+// reference's PUSH ORDER without a sort: the accepted anchors are listed on the device (AnchorList, from an exclusive scan of
+// their flags), SeedCount walks both sides of every accepted anchor and notes which of them are kept, an exclusive scan of the
+// counts gives every anchor the slot of its first region, and SeedPlace walks the kept sides again (one side in fifteen at
+// 200 x 5 Mb) and writes their rows there.  The launches cover the table's rows (the number of accepted anchors is only known
+// to the device): wavefront w takes item xcd_item(w, rows) and leaves when that is past the accepted count.
+// tid = row of the anchor table: acc[pos] = row, for the accepted ones
+struct AnchorList {
+    Store S; const int64_t* pos; int32_t* acc;
+    PM_HD void operator()(int64_t c) const { if (S.state[c] & kStAccepted) acc[pos[c]] = (int32_t)c; }
+};
+struct SeedCount {
+    Store S; Layout L; Packed P; const int32_t* acc; const int64_t* nacc; int32_t q; int64_t* cnt; uint8_t* keep; int64_t rows;
+    PM_HD void wave(int64_t w) const {
+        const int64_t i = xcd_item(w, rows);
+        if (i >= rows) return;
+        if (i >= *nacc) { if (wave_leader()) { cnt[i] = 0; keep[i] = 0; } return; }
+        const int64_t c = acc[i];
+        const int32_t dl = S.shift[c], len = S.len[c];
+        uint8_t k = 0;
+        for (int side = 0; side < 2; side++) {
+            int64_t rs, rl;
+            if (region_extent(S, L, P, c, dl, len, side, &rs, &rl) > q) k |= (uint8_t)(1 << side);
+        }
+        if (wave_leader()) { cnt[i] = (k & 1) + (k >> 1); keep[i] = k; }
+    }
+};
+struct SeedPlace {
+    Store S; Layout L; Packed P; const int32_t* acc; const int64_t* nacc; const int64_t* off; const uint8_t* keep;
+    int64_t* rg_start; int64_t* rg_len; RegInfo* info; uint64_t cap; int64_t rows;
+    PM_HD void wave(int64_t w) const {
+        const int64_t i = xcd_item(w, rows);
+        if (i >= rows || i >= *nacc || !keep[i]) return;
+        const int64_t c = acc[i];
+        const int32_t dl = S.shift[c], len = S.len[c];
+        const int n = S.ngen;
+        int64_t slot = off[i];
+        for (int side = 0; side < 2; side++) {
+            if (!(keep[i] & (1 << side))) continue;
+            if ((uint64_t)slot >= cap) return;           // (the caller sees the total past the capacity and repeats with room)
+            int64_t rs, rl;
+            const int32_t smin = region_extent(S, L, P, c, dl, len, side, &rs, &rl);
+            lanes_for(0, n, [&](int j) {
+                int64_t a, b;
+                region_side(S, L, P, c, dl, len, side, j, &a, &b);
+                rg_start[slot * n + j] = a; rg_len[slot * n + j] = b - a;
+            });
+            if (wave_leader()) info[slot] = RegInfo{2 * i + side, rs, rl, smin, (int32_t)c};
+            slot++;
+        }
+    }
+};
 // The algorithmic bytes of a search whose request rows the host never saw (bench.py's roofline; Aligner::run_batch sums the same
 // over rows it holds): per (region, query genome) with piece length m and reference window n,
-//   out[0] += 4 x SURVEY 8d's m/4 + 16 m + 16 n,   out[1] += 2 x ((m + n)/2 + 64 B per sampled K-mer, none for pairs that fit 128 bases),   out[2] += 2 x m/2.
+//   out[0] += 4 x SURVEY 8d's m/4 + 16 m + 16 n,   out[1] += 2 x (m/2 + 8 B per sampled K-mer -- one 64-B index request per leader, none
+//   for pairs that fit 128 bases -- and n/2 once per region),   out[2] += 2 x m/2.
 // One wavefront per kAlgPairs pairs, one atomic per wavefront and counter (three hot addresses: few wavefronts).
 constexpr int kAlgPairs = 4096;
 struct AlgBytes {
@@ -483,8 +626,8 @@ struct AlgBytes {
             const RegionInfo& ri = R[r];
             const int64_t m = lens[r * ngen + g], n = ri.nR;
             a += (uint64_t)(65 * m + 64 * n);
-            k += (uint64_t)(m + n);
-            if (!(m <= 128 && n <= 128) && m >= ri.K && n >= ri.K) k += 128ull * (uint64_t)((m - ri.K) / ri.stride + 1);
+            k += (uint64_t)m + (g == 1 ? (uint64_t)n : 0ull);
+            if (!(m <= 128 && n <= 128) && m >= ri.K && n >= ri.K) k += 16ull * (uint64_t)((m - ri.K) / ri.stride + 1);
             q += (uint64_t)m;
         });
         a = wave_sum_u64(a); k = wave_sum_u64(k); q = wave_sum_u64(q);
@@ -530,20 +673,6 @@ struct RegionsEqual {
 constexpr int kGrpEvents = 16;
 constexpr int kGrpPieces = 32;
 constexpr int kGrpGenomes = 1024;      // (the piece numbers of one region's genomes sit in LDS)
-PM_HD void lds_min32(int32_t* p, int32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    atomicMin(p, v);
-#else
-    if (v < *p) *p = v;
-#endif
-}
-PM_HD int32_t lds_add32(int32_t* p, int32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return atomicAdd(p, v);
-#else
-    const int32_t o = *p; *p = o + v; return o;
-#endif
-}
 struct GroupedPairEvents {
     Packed P; const RegionInfo* R; const int64_t* starts; const int64_t* lens; int32_t ngen; const int32_t* rep;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* block_count; uint64_t ev_cap; int lbits; int64_t* glo; int32_t g_first, g_last;
@@ -908,6 +1037,184 @@ struct FillBetween {
         if (wave_leader()) add[i] = overlap ? 0 : (first_scan < last_noscan ? 2 : (small ? 0 : 1));
     }
 };
+// ------------------------------------------------------------------------------------------ phases C-D on the store
+// The list logic of filterRandom1's sort (:338), setFinalClusters (:2563-2719), filterRandomClustersSimple1 (:433-497), the second
+// setFinalClusters (:3261-3268) and setInterClusterRegions (:2389-2460) for the case in which it is ORDER-FREE: all reference
+// starts of the accepted MUMs differ (one sorted order; the unstable std::sort of the reference cannot show), the ratio test
+// has two outcomes (diag_diff <= 1: a MUM joins the open chain or closes it, so the chain's last MUM is always the list
+// predecessor and the chains are the maximal runs between "close" verdicts), every MUM is longer than the filter length.
+// Then the sorted list is a radix sort of (reference start, row), a chain boundary is a flag per consecutive pair, an LCB's
+// length a segmented sum, the dissolved LCBs (length <= c, never the last: :447) a flag per LCB, the second chaining pass the
+// same flags over the compacted list, and the fillers a test per consecutive pair of final LCBs.  The host receives the
+// sorted rows of the final MUM list, a head flag per MUM and seven counters; what is not order-free (a tie) is reported in the
+// trouble word and the caller runs its own list logic instead -- nothing on the device has changed by then.
+constexpr uint8_t kChJoin = 0, kChClose = 1;
+constexpr uint64_t kChainTie = 1, kChainOverrun = 2;
+// the header of a chain call (int64 words in device memory)
+enum { kChN1 = 0, kChLcb1, kChLcbDissolved, kChMumDissolved, kChN2, kChLcb2, kChFill, kChTrouble, kChWords };
+// tid = store row (one past the end: 0): accepted?
+struct ChainFlag {
+    Store S; int64_t rows; int64_t* flag;
+    PM_HD void operator()(int64_t c) const { flag[c] = c < rows && (S.state[c] & kStAccepted) ? 1 : 0; }
+};
+// tid = store row: the sort's input (reference start with the trim applied, row), compacted
+struct ChainKeys {
+    Store S; const int64_t* pos; uint64_t* key; uint64_t* val; int64_t cap;
+    PM_HD void operator()(int64_t c) const {
+        if (!(S.state[c] & kStAccepted) || pos[c] >= cap) return;      // (more accepted rows than the caller's list holds: the call fails on the count)
+        key[pos[c]] = (uint64_t)(uint32_t)(S.start[c * S.ngen] + S.shift[c]); val[pos[c]] = (uint64_t)c;
+    }
+};
+// One wavefront per list position x: the test of setFinalClusters (:2596-2700) of MUM row[x] against row[x - 1], to the verdict.
+// All-forward pairs are a reduction over the genomes (JudgePairs) and the ratio test of :2693 in the reference's float / double
+// mix; a pair with a reverse member is walked genome by genome by one lane (the strand rules of :2604-2625 and `max_gap = fgap`
+// at :2608-2611 depend on the genome order).  *count: the list's length (the launch covers its capacity).
+struct ChainJudge {
+    Store S; const uint64_t* key; const uint64_t* row; const int64_t* count; int32_t d; float diag_diff; uint8_t* verdict; uint64_t* trouble;
+    int force_tie;      // (tests) report a tie although there is none: the caller's own list logic takes over
+    PM_HD void wave(int64_t x) const {
+        if (x >= *count) return;
+        if (x == 0) { if (wave_leader()) { verdict[0] = kChClose; if (force_tie) atomic_or64(trouble, kChainTie); } return; }
+        const int64_t a = (int64_t)row[x], b = (int64_t)row[x - 1];
+        const int n = S.ngen;
+        if (key[x] == key[x - 1] && wave_leader()) atomic_or64(trouble, kChainTie);
+        const int64_t sa = S.shift[a], la = S.len[a], sb = S.shift[b], lb = S.len[b];
+        uint8_t out = kChClose;
+        if (!((S.flags[a] | S.flags[b]) & kRowReverse)) {
+            int32_t mn = 0x7fffffff, mx = -0x7fffffff;
+            uint32_t bad = 0;
+            lanes_for(0, n, [&](int j) {
+                const int64_t g = ((int64_t)S.start[a * n + j] + sa) - ((int64_t)S.start[b * n + j] + sb + lb);
+                if (g < 0 || g > d) bad = 1;
+                const int32_t gi = g < -0x7fffffff ? -0x7fffffff : g > 0x7fffffff ? 0x7fffffff : (int32_t)g;
+                if (gi < mn) mn = gi;
+                if (gi > mx) mx = gi;
+            });
+            bad = wave_or_u32(bad); mn = wave_min_i32(mn); mx = wave_max_i32(mx);
+            if (!bad) {
+                // every gap in [0, d]: the loop leaves max_gap = the largest gap (from 0) and min_gap = the smallest (from d + 10)
+                float max_gap = 0, min_gap = (float)(d + 10);
+                if ((float)mx > max_gap) max_gap = (float)mx;
+                if ((float)mn < min_gap) min_gap = (float)mn;
+                if (min_gap == 0) min_gap = 1;
+                if (max_gap == 0) max_gap = 1;
+                out = min_gap / max_gap >= 1.0 - diag_diff ? kChJoin : kChClose;
+            }
+        } else if (wave_leader()) {
+            bool addmum = true;
+            float max_gap = 0, min_gap = (float)(d + 10);
+            for (int k = 0; k < n; k++) {
+                const int64_t ns = (int64_t)S.start[a * n + k] + sa, bs = (int64_t)S.start[b * n + k] + sb;
+                const int64_t fgap = ns - (bs + lb);        // forward: next start - chain end
+                const int64_t rgap = bs - (ns + la);        // reverse: previous MUM start - next end
+                const bool f = S.strand[a * n + k] != 0;
+                if (f && fgap > max_gap) max_gap = (float)fgap;
+                else if (!f && rgap > max_gap) max_gap = (float)fgap;       // sic (:2608-2611)
+                if (f && fgap < min_gap) min_gap = (float)fgap;
+                else if (!f && rgap < min_gap) min_gap = (float)rgap;
+                if (S.strand[a * n + k] != S.strand[b * n + k]) addmum = false;
+                else if (f && fgap < 0) addmum = false;
+                else if (!f && fgap >= 0) addmum = false;
+                else if (f && fgap > d) addmum = false;
+                else if (!f && rgap > d) addmum = false;
+                if (!addmum) break;
+            }
+            if (addmum) {
+                if (min_gap == 0) min_gap = 1;
+                if (max_gap == 0) max_gap = 1;
+                out = min_gap / max_gap >= 1.0 - diag_diff ? kChJoin : kChClose;
+            }
+        }
+        if (wave_leader()) verdict[x] = out;
+    }
+};
+// tid = list position (capacity + 1 of them: the scan's closing word): does a chain begin here?
+struct ChainHeads {
+    const uint8_t* verdict; const int64_t* count; int64_t* head;
+    PM_HD void operator()(int64_t x) const { head[x] = x < *count && verdict[x] == kChClose ? 1 : 0; }
+};
+// tid = list position: the MUM's length into its LCB's sum (lcb = number of heads up to and including x, less one)
+struct ChainLcbSum {
+    Store S; const uint64_t* row; const int64_t* count; const int64_t* hpos; uint64_t* lcb_len;
+    PM_HD void operator()(int64_t x) const {
+        if (x >= *count) return;
+        atomic_add64(&lcb_len[hpos[x + 1] - 1], (uint64_t)(int64_t)S.len[(int64_t)row[x]]);
+    }
+};
+// tid = list position (capacity + 1): filterRandomClustersSimple1 (:433-497) -- an LCB whose MUM lengths sum to <= c is dissolved,
+// the last one is never examined (:447); survive[x] for the compaction, the two counters of the log
+struct ChainDissolve {
+    const int64_t* count; const int64_t* hpos; const int64_t* head; const uint64_t* lcb_len; int64_t c; int64_t* survive; int64_t* hdr;
+    PM_HD void operator()(int64_t x) const {
+        const int64_t n = *count;
+        if (x >= n) { survive[x] = 0; return; }
+        const int64_t nl = hpos[n], id = hpos[x + 1] - 1;
+        if (x == 0) { hdr[kChN1] = n; hdr[kChLcb1] = nl; }
+        const bool dis = hdr[kChTrouble] == 0 && id != nl - 1 && (int64_t)lcb_len[id] <= c;
+        survive[x] = dis ? 0 : 1;
+        if (dis) { atomic_add64((uint64_t*)&hdr[kChMumDissolved], 1); if (head[x]) atomic_add64((uint64_t*)&hdr[kChLcbDissolved], 1); }
+    }
+};
+// one wavefront per list position: a dissolved MUM leaves the layout (:460-466)
+struct ChainUnmark {
+    Store S; Layout L; const uint64_t* row; const int64_t* count; const int64_t* survive;
+    PM_HD void wave(int64_t x) const {
+        if (x >= *count || survive[x]) return;
+        const int64_t c = (int64_t)row[x];
+        const int64_t sh = S.shift[c], len = S.len[c];
+        lanes_for(0, S.ngen, [&](int j) { const int64_t a = (int64_t)S.start[c * S.ngen + j] + sh; img_clear_range(L, j, a, a + len); });
+    }
+};
+// tid = list position: the surviving MUMs, in order
+struct ChainCompact {
+    const int64_t* count; const int64_t* survive; const int64_t* spos; const uint64_t* key; const uint64_t* row; uint64_t* key2; uint64_t* row2; int64_t* hdr;
+    PM_HD void operator()(int64_t x) const {
+        const int64_t n = *count;
+        if (x == 0) hdr[kChN2] = spos[n];
+        if (x >= n || !survive[x]) return;
+        key2[spos[x]] = key[x]; row2[spos[x]] = row[x];
+    }
+};
+// One wavefront per list position of the final list: where an LCB begins (x >= 1), setInterClusterRegions (:2389-2460) for the
+// LCB that ends at x - 1 and the one that begins at x -- FillBetween without the rows, which nothing downstream reads (a
+// filler is never printed; it shifts the numbers of the LCBs behind it, :2452-2457).
+struct ChainFill {
+    Store S; Layout L; Packed P; const uint64_t* row; const int64_t* count; const int64_t* head; int64_t* hdr;
+    PM_HD void wave(int64_t w) const {
+        const int64_t x = w + 1;
+        if (x >= *count || !head[x]) return;
+        const int64_t ct = (int64_t)row[x - 1], nx = (int64_t)row[x];
+        const int n = S.ngen;
+        const int64_t ce = (int64_t)S.shift[ct] + S.len[ct], ns = S.shift[nx];
+        uint32_t overlap = 0, small = 0;
+        int32_t first_scan = 0x7fffffff, last_noscan = -1;
+        lanes_for(0, n, [&](int j) {
+            const int64_t e = (int64_t)S.start[ct * n + j] + ce;
+            if (((int64_t)S.start[nx * n + j] + ns) - e <= 0) overlap = 1;
+            const int64_t stop = P.glen[j];
+            int64_t end;
+            if (e + 1 <= stop) { end = img_next_set(L, j, e + 1) - 1; if (j < first_scan) first_scan = j; }
+            else { end = stop - 1; if (j > last_noscan) last_noscan = j; }
+            if (end + 1 - e < 5) small = 1;
+        });
+        overlap = wave_or_u32(overlap); small = wave_or_u32(small);
+        first_scan = wave_min_i32(first_scan); last_noscan = wave_max_i32(last_noscan);
+        if (!wave_leader() || overlap) return;
+        if (first_scan < last_noscan) atomic_or64((uint64_t*)&hdr[kChTrouble], kChainOverrun);
+        else if (!small) atomic_add64((uint64_t*)&hdr[kChFill], 1);
+    }
+};
+// tid = list position: what the host receives -- the store row and the head flag of every MUM of the final list
+struct ChainOut {
+    const uint64_t* row; const int64_t* count; const int64_t* head; const int64_t* hpos; int32_t* out_row; uint8_t* out_head; int64_t* hdr;
+    PM_HD void operator()(int64_t x) const {
+        const int64_t n = *count;
+        if (x == 0) hdr[kChLcb2] = hpos[n];
+        if (x >= n) return;
+        out_row[x] = (int32_t)row[x]; out_head[x] = (uint8_t)head[x];
+    }
+};
+
 // tid = (k, genome): the rows of the fillers that are made (which[k] = their pair), packed for one copy to the host
 struct FillGather {
     const int32_t* which; int32_t ngen; const int64_t* in_start; const int64_t* in_end; int64_t* out;      // out: [n_made][2][ngen]

@@ -179,6 +179,9 @@ Aligner::~Aligner() {
     wait_layout();
     // the resident route never writes to the host's bitmaps: the next run starts on them as they are
     memory_->layout_clean = res_.active && !layout.empty() && !layout[0].attached();
+    // bitmaps attached to this run's layout image (materialize(), parsnp.unalign) outlive the image in the shared AlignerMemory:
+    // released, so that the next run's init() takes fresh storage instead of clearing words that are gone
+    for (Bitmap& b : layout) if (b.attached()) b.release();
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double t = now_s();
     auto lap = [&](const char* what) { if (dbg) { double u = now_s(); fprintf(stderr, "[release] %-10s %.4f s\n", what, u - t); t = u; } };
@@ -395,18 +398,21 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
         memcpy(&starts[(size_t)i * n], q.start, n * 8); memcpy(&lens[(size_t)i * n], q.len, n * 8);
         mins[(size_t)i] = q.minsize;
         // SURVEY 8d's model (one 8-byte index probe and 16 bytes of state per query suffix), and what the event search of THIS
-        // engine has to move per (region, query genome): the query piece once (16 B per 32 bases; the reverse strand is not
-        // streamed), the reference window once, and one 64-byte index request per sampled K-mer unless both sides fit 128
-        // bases (SmallPairEvents: no index).  Events (16 B each) are added by the caller from the engine's count.
+        // engine has to move: per (region, query genome) the query piece once (16 B per 32 bases; the reverse strand is not
+        // streamed) and 8 B per sampled K-mer -- one 64-byte index request per LEADER, one sample in eight -- unless both sides
+        // fit 128 bases (no index), and per region the reference window once.  The samples SeedRest probes on their own (64 B
+        // each) and the events (16 B each) are added by the caller from the engine's counts.  (Until round 4 the model charged
+        // an index request per sample and the reference window per genome: 1.9 x what the fabric counters saw.)
         const long minlen = q.minsize < 1 ? 1 : q.minsize, K = minlen < 16 ? minlen : 16, stride = minlen - K + 1;
         double a = 0, k = 0, qb = 0;
         for (size_t g = 1; g < n; g++) {
             const double m = (double)q.len[g], nr = (double)q.len[0];
             a += m * 16.25 + 16.0 * nr;
-            k += 0.5 * m + 0.5 * nr;
+            k += 0.5 * m;
             qb += 0.5 * m;
-            if (!(q.len[g] <= 128 && q.len[0] <= 128) && q.len[g] >= K && q.len[0] >= K) k += 64.0 * (double)((q.len[g] - K) / stride + 1);
+            if (!(q.len[g] <= 128 && q.len[0] <= 128) && q.len[g] >= K && q.len[0] >= K) k += 8.0 * (double)((q.len[g] - K) / stride + 1);
         }
+        k += 0.5 * (double)q.len[0];
         alg += a; algk += k; algq += qb;
     }
     stats.alg_bytes += alg;

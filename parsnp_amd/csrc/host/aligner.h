@@ -260,6 +260,7 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     long generations = 0, generation_regions = 0, generation_handover = -1;   // parallel generations, regions in them, generation at which the in-order replay took over (-1: never)
     long generation_restarts = 0;   // generation-parallel extension abandoned after its second generation (see extend_generations)
     long resident = 0;              // 1: phases A-D ran on the resident route (resident.cpp: rows, layout and regions stayed on the device)
+    long device_chain = 0;          // 1: phases C-D (sort, chaining, LCB filter, fillers) came from the device in one call (pm_store_chain_*)
     long resident_retry = 0;        // 1: the resident route was left (the reference's processing order would have shown) and the step ran again on the host route
     long tie_fallbacks = 0, literal_iterations = 0, parallel_candidates = 0, parallel_dirty = 0, parallel_tangled = 0;   // work-list ties between different regions (extend_pass)
     double t_validate = 0, t_neighbour = 0, t_key = 0, t_sweep = 0, t_replay = 0, t_sort = 0, t_unpack = 0;   // host split
@@ -307,6 +308,7 @@ public:
     bool resident_active() const { return res_.active; }
     bool resident_failed() const { return res_.failed; }
     const std::string& resident_why() const { return res_.why; }
+    bool resident_chain();                               // phases C-D from the device (resident.cpp); false: the caller runs them
     void materialize();                                  // rows of the LCBs' MUMs (and the layout, for parsnp.unalign) for the writer; no-op on the host route
     long key0(int idx) const { return res_.active ? (long)res_.start0[(size_t)idx] : (long)pool[(size_t)idx].start[0]; }      // reference start of a MUM
 
@@ -336,11 +338,14 @@ private:
         std::vector<int32_t> fallback_start; std::vector<uint8_t> fallback_strand;   // rows fetched for the host route
         std::vector<uint64_t> image;                                           // the layout, fetched for parsnp.unalign
         std::future<void> records;                                             // the anchors' MUM records, written beside the seed regions' device work
+        bool chain_queued = false;                                             // pm_store_chain_begin is in flight (resident_chain() collects it)
+        std::string chain_why;                                                 // why phases C-D fell back to the host's list logic
     } res_;
     bool resident_try_ = false;           // run_batch: ask for resident mode (the anchor call of the route)
     bool layout_written_ = false;         // this run wrote to `layout`
     bool resident_anchors(const Region& whole, std::vector<int>* found);
     bool resident_extend();
+    void resident_chain_begin(size_t expect);
     void resident_verdicts();
     uint8_t resident_judge_rows(int cur, int back);
     void resident_fill_between();

@@ -1,5 +1,6 @@
 // capi.cpp -- in-process C API over CoreRun for bench.py and tests (libparsnp_core.so): open once (ingest +
 // upload), then step the timed path (phases A-D) any number of times on the resident genomes.
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -61,7 +62,7 @@ const char* pc_step(pc_run* r) {
       << s.cache_misses << ", \"spec_rounds\": " << s.spec_rounds << ", \"mums_found\": " << (s.mums_found ? "true" : "false")
       << ", \"host_split_s\": {\"validate\": " << s.host.t_validate << ", \"neighbour\": " << s.host.t_neighbour << ", \"key\": " << s.host.t_key
       << ", \"sweep\": " << s.host.t_sweep << ", \"replay\": " << s.host.t_replay << ", \"sort\": " << s.host.t_sort << ", \"unpack\": " << s.host.t_unpack << ", \"pack\": " << s.host.t_pack << "}"
-      << ", \"h2d_bytes\": " << (long long)s.h2d_bytes << ", \"d2h_bytes\": " << (long long)s.d2h_bytes << ", \"resident\": " << s.host.resident << ", \"resident_retry\": " << s.host.resident_retry << ", \"tie_fallbacks\": " << s.host.tie_fallbacks << ", \"literal_iterations\": " << s.host.literal_iterations;
+      << ", \"h2d_bytes\": " << (long long)s.h2d_bytes << ", \"d2h_bytes\": " << (long long)s.d2h_bytes << ", \"resident\": " << s.host.resident << ", \"resident_retry\": " << s.host.resident_retry << ", \"device_chain\": " << s.host.device_chain << ", \"tie_fallbacks\": " << s.host.tie_fallbacks << ", \"literal_iterations\": " << s.host.literal_iterations;
     for (int which = 0; which < 2; which++) {
         o << ", \"" << (which ? "anchor_ms" : "engine_ms") << "\": {";
         const auto& v = which ? s.anchor_ms : s.engine_ms;
@@ -80,6 +81,14 @@ const char* pc_step(pc_run* r) {
     o << "]}";
     r->json = o.str();
     return r->json.c_str();
+}
+// the rows of the final MUM list reach the host (resident route: they wait on the device until the writer asks, CoreRun::write);
+// returns the milliseconds it took, 0 when they were there already.  bench.py reports it beside ms_per_step (`materialize_ms`)
+double pc_materialize(pc_run* r) {
+    if (!r->last.mums_found || !r->run.align) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    r->run.align->materialize();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 int pc_write(pc_run* r) {
     if (!r->last.mums_found) return 1;

@@ -115,6 +115,8 @@ int CoreRun::open(const std::string& ini_path) {
     if (const char* v = test_hook("PM_FLAGGED_DIV")) (void)pm_session_tune(session, "flagged_div", atol(v));
     if (const char* v = test_hook("PM_ATOMIC_MARKS")) (void)pm_session_tune(session, "atomic_marks", atol(v));
     if (const char* v = test_hook("PM_GROUP_SMALL")) (void)pm_session_tune(session, "group_small", atol(v));
+    if (const char* v = test_hook("PM_MASTER_SEG")) (void)pm_session_tune(session, "master_seg", atol(v));
+    if (const char* v = test_hook("PM_CHAIN_TIE")) (void)pm_session_tune(session, "chain_tie", atol(v));
     upload_s = now_s() - t1;
     return 0;
 }
@@ -166,7 +168,7 @@ StepReport CoreRun::step() {
     (void)pm_session_traffic(session, &h1, &d1);
     r.h2d_bytes = (double)(h1 - h0); r.d2h_bytes = (double)(d1 - d0);
     if (const char* log = test_hook("PARSNP_RESIDENT_LOG"))      // test hook: which route every step took
-        if (FILE* f = fopen(log, "a")) { fprintf(f, "resident=%ld retry=%ld anchors=%ld mums=%ld why=%s\n", r.host.resident, r.host.resident_retry, r.anchors, r.mums, why.c_str()); fclose(f); }
+        if (FILE* f = fopen(log, "a")) { fprintf(f, "resident=%ld retry=%ld chain=%ld anchors=%ld mums=%ld why=%s\n", r.host.resident, r.host.resident_retry, r.host.device_chain, r.anchors, r.mums, why.c_str()); fclose(f); }
     return r;
 }
 
@@ -199,11 +201,13 @@ StepReport CoreRun::step_once(bool resident) {
     if (found && !a.resident_failed()) {
         printf("        Finished recursive MUM search, elapsed time: %.0lf seconds\n\n", difftime(end, start));
         a.coarsen_time = (float)difftime(end, start);
+        // (resident route, order-free list logic: phases C-D were queued on the device behind the last generation)
+        const bool from_device = a.resident_chain();
         if (prm.random) {
             std::cerr << "Filtering spurious matches..." << std::endl;
             time(&start);
             a.random = prm.random;
-            a.filter_mums(prm.random);
+            if (!from_device) a.filter_mums(prm.random);
             time(&end);
             printf("        Finished filtering spurious matches, elapsed time: %.0lf seconds\n\n", difftime(end, start));
             a.random_time = (float)difftime(end, start);
@@ -214,6 +218,7 @@ StepReport CoreRun::step_once(bool resident) {
         const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
         double tl = now_s();
         auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[lcb] %-12s %.4f s (cpu %.4f)\n", what, t - tl, cpu_lap_s()); tl = t; } };
+        if (!from_device) {
         a.chain(); lap("chain");
         const long dissolved = a.filtered_lcbs;
         a.filter_lcbs(); lap("filter_lcbs");
@@ -225,6 +230,7 @@ StepReport CoreRun::step_once(bool resident) {
         for (size_t i = 1; i < a.lcbs.size() && same; i++) same = a.lcbs[i - 1].start[0] < a.lcbs[i].start[0];
         if (!same) { a.chain(); lap("chain"); }
         a.fill_between(); lap("fill_between");
+        }
         time(&end);
         a.iclusters_time = (float)difftime(end, start);
         printf("        LCBs created, elapsed time: %.0lf seconds\n\n", difftime(end, start));

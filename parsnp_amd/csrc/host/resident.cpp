@@ -66,10 +66,14 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
     const bool kept = table != 0 && pm_result_store_base(a.owner.get()) == 0;      // the rows stayed on the device
     std::vector<pm_row_info> info;
     int rc = PM_EAGAIN;
+    static const bool fused = test_hook("PARSNP_SPLIT_SETTLE") == nullptr;
+    int64_t nreg = 0;
     if (kept) {
         info.resize(a.count);
         const double ts = now_s();
-        rc = pm_store_settle(session_, table, info.data());
+        // validation and seed regions in one call (one round trip); the test hook takes the two calls it replaces
+        if (fused) rc = pm_store_settle_seeds(session_, table, (int32_t)prm.q, info.data(), &nreg);
+        else rc = pm_store_settle(session_, table, info.data());
         if (rc != PM_OK && rc != PM_EAGAIN) engine_error("validation of the anchors on the device failed", rc);
         timing_first_call_ = false; collect_engine_timing();
         stats.t_validate += now_s() - ts;
@@ -130,10 +134,11 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
     lap("records");
     // seed regions: both neighbours of every anchor, longer than q in every genome (:2150-2172)
     const double tn = now_s();
-    int64_t nreg = 0;
-    rc = pm_store_seeds(session_, table, acc.data(), (int64_t)acc.size(), (int32_t)prm.q, &nreg);
-    if (rc != PM_OK) engine_error("seed regions on the device failed", rc);
-    collect_engine_timing();
+    if (!fused) {
+        rc = pm_store_seeds(session_, table, acc.data(), (int64_t)acc.size(), (int32_t)prm.q, &nreg);
+        if (rc != PM_OK) engine_error("seed regions on the device failed", rc);
+        collect_engine_timing();
+    }
     const pm_region_info* ri = pm_store_new_regions(session_);
     const int32_t* rid = pm_store_new_region_ids(session_);
     // the reference pushes lR unless it equals the right region of the previous anchor, rR unless it equals lR (:2158-2170): equal
@@ -241,7 +246,12 @@ bool Aligner::resident_extend() {
         for (size_t i = 0; i < now.size(); i++) { r0[i] = row0[(size_t)now_id[i]]; rc_[i] = cnt[(size_t)now_id[i]]; }
         uint32_t trouble = 0; int64_t nkids = 0;
         const double tv = now_s();
-        int rc = pm_store_validate(session_, now_id.data(), r0.data(), rc_.data(), (int64_t)now.size(), first.data(), (int64_t)first.size() - 1, (int32_t)prm.q, &trouble, &nkids);
+        // the scalars of the candidates about to be decided travel back with the call: the ranges of the searches they came from
+        int64_t lo = INT64_MAX, hi = -1;
+        for (size_t i = 0; i < now.size(); i++) if (rc_[i] > 0) { lo = std::min(lo, r0[i]); hi = std::max(hi, r0[i] + rc_[i]); }
+        if (hi > lo && info.size() < (size_t)hi) info.resize((size_t)hi);
+        int rc = pm_store_validate(session_, now_id.data(), r0.data(), rc_.data(), (int64_t)now.size(), first.data(), (int64_t)first.size() - 1, (int32_t)prm.q, &trouble, &nkids,
+                                   hi > lo ? lo : 0, hi > lo ? hi - lo : 0, hi > lo ? info.data() + lo : nullptr);
         if (rc != PM_OK) engine_error("validation of a generation on the device failed", rc);
         collect_engine_timing();
         if (trouble) {
@@ -255,15 +265,17 @@ bool Aligner::resident_extend() {
         const pm_region_info* ki = pm_store_new_regions(session_);
         const int32_t* kid = pm_store_new_region_ids(session_);
         for (int64_t i = 0; i < nkids; i++) { gen.push_back(ki[i]); gen_id.push_back(kid[i]); }
-        // the scalars of the candidates just decided: the ranges of the searches they came from
-        int64_t lo = INT64_MAX, hi = -1;
-        for (size_t i = 0; i < now.size(); i++) if (rc_[i] > 0) { lo = std::min(lo, r0[i]); hi = std::max(hi, r0[i] + rc_[i]); }
-        if (hi > lo) {
-            if (info.size() < (size_t)hi) info.resize((size_t)hi);
-            if (pm_store_info(session_, lo, hi - lo, info.data() + lo) != PM_OK) engine_error("cannot read the validation's verdicts", PM_EHIP);
-        }
         stats.t_validate += now_s() - tv;
         lap("validate");
+        if (gen.empty()) {
+            // the last generation: the accepted rows of the store are the run's MUM list.  Phases C-D are queued on the device now
+            // (resident_chain() collects them) and run beside the commit below
+            size_t more = 0;
+            for (size_t i = 0; i < now.size(); i++)
+                for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) more += (info[(size_t)c].state_flags & PM_ST_ACCEPTED) != 0;
+            resident_chain_begin(mums.size() + more);
+            lap("chain queued");
+        }
         if (res_.records.valid()) res_.records.get();      // the anchors' records are in: the recursion's MUMs follow them in the pool
         // commit in list order (:215-254 push the MUMs of a region in candidate order)
         for (size_t i = 0; i < now.size(); i++) {
@@ -282,9 +294,62 @@ bool Aligner::resident_extend() {
         lap("commit");
         gi++;
     }
+    if (!res_.chain_queued && !mums.empty()) resident_chain_begin(mums.size());      // (no seed region at all: the anchors are the list)
     stats.extend_s = now_s() - t0;
     stats.t_replay = stats.extend_s;
     return !mums.empty();
+}
+
+// Phases C-D on the device (pm_store_chain_begin / _end: the sort of filterRandom1 :338, setFinalClusters :2563-2719,
+// filterRandomClustersSimple1 :433-497, the second chaining pass :3261-3268, setInterClusterRegions :2389-2460) where their list
+// logic is order-free: diag_diff <= 1 (the ratio test joins or closes: the chain's last MUM is the list predecessor), a filter
+// length below every MUM's (accepted MUMs have >= 2 bases), and -- the device's own finding -- no two MUMs with one reference start.
+void Aligner::resident_chain_begin(size_t expect) {
+    static const bool off = test_hook("PARSNP_NO_DEVICE_CHAIN") != nullptr;      // test hook: the host's list logic over pm_store_judge / _unmark / _fill
+    res_.chain_queued = false;
+    if (off || expect == 0 || prm.random > 1 || !(prm.diag_diff <= 1.0f)) return;
+    const int rc = pm_store_chain_begin(session_, (int64_t)expect, (int32_t)prm.d, prm.diag_diff, (int64_t)prm.c);
+    if (rc != PM_OK) engine_error("phases C-D on the device failed", rc);
+    collect_engine_timing();
+    res_.chain_queued = true;
+}
+// returns true when mums, lcbs and the counters of the log are those of phases C-D; false: the caller runs filter_mums(), chain(),
+// filter_lcbs(), chain(), fill_between() (nothing on the device has changed)
+bool Aligner::resident_chain() {
+    if (!res_.active || !res_.chain_queued) return false;
+    res_.chain_queued = false;
+    const double t0 = now_s();
+    pm_chain_info ci; const int32_t* rows = nullptr; const uint8_t* heads = nullptr;
+    const int rc = pm_store_chain_end(session_, &ci, &rows, &heads);
+    if (rc != PM_OK) engine_error("phases C-D on the device failed", rc);
+    collect_engine_timing();
+    if (ci.n_in != (int64_t)mums.size()) fatal("the device's MUM list and the host's differ");
+    if (ci.trouble & 1) { res_.chain_why = "two MUMs share a reference start"; return false; }
+    if (ci.trouble & 2) fatal("inter-cluster region bookkeeping would overrun in the reference");
+    // store row -> MUM record
+    int32_t top = 0;
+    for (const Mum& m : pool) if (m.row > top) top = m.row;
+    std::vector<int32_t> of((size_t)top + 1, -1);
+    for (size_t i = 0; i < pool.size(); i++) of[(size_t)pool[i].row] = (int32_t)i;
+    mums.resize((size_t)ci.n_mums);
+    lcbs.clear();
+    lcbs.reserve((size_t)(ci.n_fillers + ci.n_lcbs));
+    for (int64_t f = 0; f < ci.n_fillers; f++) { Lcb c; c.type = 0; c.length = 2; lcbs.push_back(std::move(c)); }      // (their rows: nothing reads them)
+    for (int64_t x = 0; x < ci.n_mums; x++) {
+        if (rows[x] < 0 || rows[x] > top || of[(size_t)rows[x]] < 0) fatal("the device's MUM list names a row the host does not hold");
+        const int idx = of[(size_t)rows[x]];
+        mums[(size_t)x] = idx;
+        if (heads[x]) { Lcb c; c.type = 1; c.length = 0; c.start.assign(1, key0(idx)); lcbs.push_back(std::move(c)); }
+        Lcb& c = lcbs.back();
+        c.mums.push_back(idx); c.length += pool[(size_t)idx].length;
+        c.end.assign(1, key0(idx) + pool[(size_t)idx].length);
+    }
+    if ((int64_t)lcbs.size() != ci.n_fillers + ci.n_lcbs) fatal("the device's LCB count and its head flags differ");
+    filtered += ci.mums_dissolved; filtered_lcbs += ci.lcbs_dissolved;
+    unique_order = true;
+    stats.lcb_s += now_s() - t0;
+    stats.device_chain = 1;
+    return true;
 }
 
 // setFinalClusters' test of MUM cur against the chain's last MUM, from rows fetched for the pair (a reverse-strand member,

@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/prof_stats
 rm -rf $OUT; mkdir -p $OUT/summary
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o ks -- python $REPO/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $OUT/summary/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o ks -- python $REPO/bench.py --steps 3 --warmup 1 --cpu-sample 0 --other-configs off > $OUT/summary/bench_under_rocprof.json 2> $OUT/stats.err
 cd $REPO
 python scripts/profile_summary.py $OUT > /dev/null 2>&1
 rm -rf $OUT/stats

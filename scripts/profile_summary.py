@@ -92,6 +92,28 @@ def main():
             f.write(open(ks).read())
         for r in rows:
             stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6, "total_ms": float(r["TotalDurationNs"]) / 1e6}
+    # where the device waits for the host: the idle time between consecutive kernels of the traced run, by (kernel before, kernel
+    # after) -- what `host_ms_outside_kernels` of the bench line is made of
+    try:
+        tr = db_rows(os.path.join(out, "stats"), "select name, start, end from kernels order by start")
+        if tr:
+            gaps = {}
+            total_idle = 0.0
+            busy = sum(e - b for _, b, e in tr)
+            for (n0, b0, e0), (n1, b1, e1) in zip(tr, tr[1:]):
+                g = b1 - e0
+                if g > 5000:      # > 5 us: not back-to-back
+                    k = short(n0) + " -> " + short(n1)
+                    x = gaps.setdefault(k, {"count": 0, "total_us": 0.0, "max_us": 0.0})
+                    x["count"] += 1; x["total_us"] += g / 1e3; x["max_us"] = max(x["max_us"], g / 1e3)
+                    if g < 50e6:      # (the pauses between warm-up, steps and the writer are not part of a step)
+                        total_idle += g / 1e3
+            top = sorted(gaps.items(), key=lambda kv: -kv[1]["total_us"])[:40]
+            json.dump({"note": "idle time of the device between consecutive kernels of the traced bench run (warm-up + steps + one XMFA write), gaps > 5 us, by (kernel before -> kernel after); gaps >= 50 ms (between steps, around the writer) are listed but not summed",
+                       "kernel_busy_ms": busy / 1e6, "idle_ms_in_gaps_below_50ms": total_idle / 1e3, "gaps": [dict(pair=k, **v) for k, v in top]},
+                      open(os.path.join(summ, "idle_gaps.json"), "w"), indent=1)
+    except Exception as e:   # noqa: BLE001
+        print("no gap analysis:", e)
     fetch, write = pmc(os.path.join(out, "fetch")), pmc(os.path.join(out, "write"))
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB
     per = {}
@@ -115,6 +137,10 @@ def main():
                 cal[k]["counter_bytes_per_lane"] = per_launch / known["gather_lanes"]
             if k in cw:
                 cal[k]["write_size_bytes"] = cw[k]["sum"] * 1024 / cw[k]["dispatches"]
+    try:      # the int32 VALU issue rate of a SIMD (scripts/valu_calib.hip): what bench.py's `issue_frac` prices SQ_INSTS_VALU with
+        cal["valu"] = json.loads(open(os.path.join(summ, "valu_calib.json")).read().strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001
+        print("no VALU calibration:", e)
     json.dump(cal, open(os.path.join(summ, "calibration.json"), "w"), indent=1)
     # the event search of one engine call = SeedExtend (index-seeded samples) + SmallPairEvents (pairs that fit 128 bases,
     # compared in registers): bench.py times them together as the `seed_extend` phase, so they are summed here too

@@ -5,14 +5,19 @@
 # the sha256 of the library.   gpurun --timeout 600 -- 'bash scripts/sqcounters.sh'
 REPO=$(pwd); OUT=$REPO/gpurun_out/sq; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
-B="python $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0"
+B="python $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --other-configs off"
 timeout 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_LDS --kernel-trace -d $OUT/a -o a -- $B > $OUT/a.log 2>&1
 timeout 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/b -o b -- $B > $OUT/b.log 2>&1
 cd $REPO
 python - <<'PY'
 import sqlite3, glob, json, hashlib, os, re
 kernels = ["SeedExtend", "SeedRest", "SmallPairEvents", "MasterEP", "FoldCandidates", "WaveScan", "GroupedPairEvents", "IndexInsert"]
-out = {"so_sha256": hashlib.sha256(open("parsnp_amd/lib/libparsnp_hip.so", "rb").read()).hexdigest(), "workload": "bench.py default (200 x 5 Mb), 2 steps + 1 warm-up",
+def src_sha():
+    h = hashlib.sha256()
+    for f in ("kernels.h", "store_kernels.h", "engine_core.h", "engine_hip.hip", "abi_glue.h"):
+        h.update(open("parsnp_amd/csrc/engine/" + f, "rb").read())
+    return h.hexdigest()
+out = {"so_sha256": hashlib.sha256(open("parsnp_amd/lib/libparsnp_hip.so", "rb").read()).hexdigest(), "engine_src_sha256": src_sha(), "workload": "bench.py default (200 x 5 Mb), 2 steps + 1 warm-up",
        "note": "per kernel: counters of its dispatches; `anchor` = the dispatch records of the longest launch (the anchor call); a record = one XCD's sampled shader engine", "kernels": {}}
 for d in ("a", "b"):
     for db in glob.glob("gpurun_out/sq/%s/**/*_results.db" % d, recursive=True):

@@ -53,6 +53,7 @@ struct HostBackend {
         std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ki[a] < ki[b]; });
         for (size_t i = 0; i < n; i++) { ko[i] = ki[idx[i]]; vo[i] = vi[idx[i]]; }
     }
+    bool timing_on = true;
     void mark(const char*) {}
     std::vector<pm::PhaseTime> collect() { return {}; }
     bool ok() const { return true; }

@@ -38,6 +38,30 @@ def test_random_regions(libs):
     assert total > 500
 
 
+def test_master_ep_both_kernels(libs):
+    """Master.EP from the genomes' segments (MasterEPSeg, the shipped kernel: every other test here runs it) and by the round-4
+    kernel (tune master_seg = 0): the same candidates, against the restatement; regions longer than one 256-position chunk and more
+    genomes than a wavefront has lanes"""
+    E, O = libs
+    rng = np.random.default_rng(55)
+    total = 0
+    for it in range(60):
+        if it % 10 == 0:
+            ref = random_seq(rng, 1500)
+            qs = [mutate(rng, ref, sub=0.03, indel=0.004) for _ in range(70 if it % 20 == 0 else 5)]
+        else:
+            ref, qs = adversarial_case(rng, 10, 700, int(rng.integers(1, 5)))
+        minsize = int(rng.integers(4, 14))
+        want = oracles.restatement_multi_mum(O, [ref] + qs, minsize, 1)
+        for seg in (1, 0):
+            with Session(E, [ref] + qs) as s:
+                s.tune("master_seg", seg)
+                got = s.whole(minsize)
+            assert same(want, got), (it, seg, minsize)
+        total += len(want[0])
+    assert total > 200
+
+
 def batch_case(rng, E, O, n_regions=40, glen=3000, nq=4, big_minsize=False):
     ref = random_seq(rng, glen)
     qs = []
@@ -211,6 +235,55 @@ def test_resident_route(emu, tmp_path, name, flagged_div, expect):
     route = open(log).read()
     assert ("resident=1" in route) == (expect == "resident"), route
     assert ("retry=1" in route) == (expect == "left"), route
+
+
+@pytest.mark.parametrize("name", ["pop12x400k", "viral50"])
+@pytest.mark.parametrize("variant", ["host_list_logic", "reported_tie", "split_settle"])
+def test_resident_route_variants(emu, tmp_path, name, variant):
+    """the entry points the shipped route no longer calls, and its fall-backs: phases C-D by the host's list logic over
+    pm_store_judge / _unmark / _fill (PARSNP_NO_DEVICE_CHAIN: pm_store_chain_* switched off; PM_CHAIN_TIE: the device reports two
+    MUMs with one reference start and the caller takes over), pm_store_settle + pm_store_seeds as two calls -- the reference's bytes
+    each time, as from the one-call forms (test_resident_route)"""
+    rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
+    log = str(tmp_path / "route.log")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_RESIDENT_LOG=log, PARSNP_CHECK_ZERO="1")
+    env.update({"host_list_logic": {"PARSNP_NO_DEVICE_CHAIN": "1"}, "reported_tie": {"PM_CHAIN_TIE": "1"}, "split_settle": {"PARSNP_SPLIT_SETTLE": "1"}}[variant])
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(emu[1], rp, qs, out, env=env, threads=4, **kw)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    want = test_host_logic.E2E[name]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == want["xmfa_md5"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
+    route = open(log).read()
+    assert "resident=1" in route and ("chain=1" in route) == (variant == "split_settle"), route
+
+
+def test_unaligned_twice_on_the_resident_route(emu, tmp_path):
+    """step, write, step, write in ONE process with unaligned=1 on the resident route: the writer attaches the host's layout
+    bitmaps to the image it fetched, and the next step must not inherit them (they pointed into freed memory once)"""
+    import json
+    from parsnp_amd.core_api import CoreRun
+    rp, qs, kw = test_host_logic.harsh_inputs("pop6x200k", str(tmp_path))
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    ini = os.path.join(out, "parsnpAligner.ini")
+    open(ini, "w").write(driver.ini_text(rp, qs, out, unaligned=1, threads=2))
+    code = (
+        "import sys, hashlib, os; sys.path.insert(0, %r)\n"
+        "from parsnp_amd.core_api import CoreRun\n"
+        "r = CoreRun(%r, lib_path=%r)\n"
+        "res = []\n"
+        "for k in range(3):\n"
+        "    s = r.step(); assert s['resident'] == 1, s\n"
+        "    assert r.write() == 0\n"
+        "    res.append((s['mums'], s['lcbs'], hashlib.md5(open(os.path.join(%r, 'parsnpAligner.xmfa'), 'rb').read()).hexdigest(), hashlib.md5(open(os.path.join(%r, 'parsnp.unalign'), 'rb').read()).hexdigest()))\n"
+        "assert res[0] == res[1] == res[2], res\n"
+        "print(res[0][2])\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ini, os.path.join(os.path.dirname(emu[0]), "libparsnp_core_emu.so"), out, out))
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8")
+    import subprocess, sys
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=out)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-3000:]
+    assert p.stdout.strip().splitlines()[-1] == test_host_logic.E2E["pop6x200k"]["xmfa_md5"]
 
 
 def test_work_budget_retry(libs, monkeypatch):

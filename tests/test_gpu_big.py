@@ -62,6 +62,7 @@ def test_baseline_size_against_reference(scratch, name):
             assert tj["resident"] == (1 if (mode == "shipped" and name != "rearr50") else 0), (mode, tj)
             if tj["resident"]:
                 assert tj["d2h_bytes"] < 20e6 and tj["resident_retry"] == 0, tj      # rows stay on the device until the writer asks
+                assert tj["device_chain"] == 1, tj      # ... and phases C-D came from the device in one call (pm_store_chain_*)
         assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
         x = os.path.join(out, "parsnpAligner.xmfa")
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"], mode

@@ -278,6 +278,26 @@ def test_parsnp_core_resident_route(libs, tmp_path, name, flagged_div, expect):
     assert ("retry=1" in route) == (expect == "left"), route
 
 
+@pytest.mark.parametrize("name", ["pop12x400k", "pop20x1m"])
+@pytest.mark.parametrize("variant", ["one_call_forms", "host_list_logic", "reported_tie", "split_settle"])
+def test_parsnp_core_resident_route_variants(libs, tmp_path, name, variant):
+    """phases C-D from the device in one call (pm_store_chain_*: sort, chaining with the ratio test in the reference's float /
+    double mix, LCB filter, second pass, fillers) and validation + seed regions in one call (pm_store_settle_seeds), against the
+    forms they replaced -- the host's list logic over pm_store_judge / _unmark / _fill, the device reporting a tie and handing
+    over, pm_store_settle + pm_store_seeds as two calls: the reference's bytes each time"""
+    rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
+    log = str(tmp_path / "route.log")
+    env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_RESIDENT_LOG=log, PARSNP_CHECK_ZERO="1")
+    env.update({"one_call_forms": {}, "host_list_logic": {"PARSNP_NO_DEVICE_CHAIN": "1"}, "reported_tie": {"PM_CHAIN_TIE": "1"}, "split_settle": {"PARSNP_SPLIT_SETTLE": "1"}}[variant])
+    out = str(tmp_path / "out")
+    rc, _ = driver.run_core(CORE_HOOKS_BIN, rp, qs, out, env=env, threads=8, **kw)
+    assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
+    assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
+    assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
+    route = open(log).read()
+    assert "resident=1" in route and ("chain=1" in route) == (variant in ("one_call_forms", "split_settle")), route
+
+
 @pytest.mark.parametrize("name", ["mers", "messy", "pop6x200k_p"])
 def test_parsnp_core_calcmumi(libs, tmp_path, name):
     test_host_logic.check_mumi(CORE_BIN, name, str(tmp_path))
