@@ -142,6 +142,7 @@ int64_t pm_result_table_id(const pm_result* r);
  *                  once per distinct query piece (default 1; both give the same events, tests compare the two)
  *   "master_seg"   0: Master.EP by the round-4 kernel (every lane tests every staged event: MasterEP) instead of from the genomes'
  *                  segments (MasterEPSeg; default 1; the same values, tests compare the two)
+ *   "stage_gate"   != 0: the second stage of a two-stage pm_store_validate is never run (tests: the caller forms it again)
  *   "chain_tie"    != 0: pm_store_chain_begin reports two MUMs with one reference start although there is none (tests: the
  *                  caller's own list logic must give the same bytes)
  *   "timing"       0: no HIP events around the phases of a call (pm_last_timing then reports counts only)
@@ -202,10 +203,14 @@ int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsiz
  * disjointness in the query genomes is checked by the call itself (clusters in reference order must follow each other, with a
  * base between, in every genome).  On trouble the caller must discard the run and take the host route.
  * info_count > 0: the per-row scalars (pm_store_info) of store rows [info_first, info_first + info_count) -- the candidates
- * just decided -- come back with the same round trip. */
+ * just decided -- come back with the same round trip.
+ * stage_first > 0: TWO generations in one call.  Clusters [0, stage_first) are validated first (the first pushed seed, which the
+ * reference processes before its work list is ever sorted, :194-195 before :291-292); clusters [stage_first, n_clusters) -- the
+ * generation the caller formed on the assumption that the first stage pushes no child region -- are validated behind them if
+ * that held (*second_stage_ran = 1) and are left untouched if not (0: the caller forms the generation again, with the children). */
 int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions,
                       const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children,
-                      int64_t info_first, int64_t info_count, pm_row_info* info);
+                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran);
 /* The test of setFinalClusters (:2596-2700) of MUM cur[i] against the open chain's last MUM back[i]: verdict[i] = 0 every
  * genome's gap lies in [0, d] (min_gap / max_gap: what the ratio test :2693 reads), 1 the chain closes, 2 a reverse-strand
  * member (the strand rules of :2604-2625 depend on the genome order): the caller judges the pair from its rows. */

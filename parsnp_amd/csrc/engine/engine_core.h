@@ -897,7 +897,11 @@ public:
     // One generation of the recursion (doWork, src/parsnp.cpp:173-317) over clusters of waiting regions that the caller found
     // pairwise disjoint in every genome: candidates settled against the image and marked, children appended to the region store.
     int store_validate(const int32_t* regions, const int64_t* row0, const int32_t* cnt, int64_t nreg, const int64_t* cluster_first, int64_t ncl, int32_t q,
-                       uint32_t* trouble, std::vector<RegInfo>* kids, std::vector<int32_t>* kid_ids, int64_t info_first = 0, int64_t info_count = 0, RowInfo* info = nullptr) {
+                       uint32_t* trouble, std::vector<RegInfo>* kids, std::vector<int32_t>* kid_ids, int64_t info_first = 0, int64_t info_count = 0, RowInfo* info = nullptr,
+                       int64_t stage_first = 0, int32_t* second_stage_ran = nullptr) {
+        // stage_first > 0: clusters [0, stage_first) are a generation of their own (the first pushed seed, which the reference
+        // processes before anything is sorted); the rest -- the generation the caller formed on the assumption that the first leaves
+        // no child region -- runs behind it in the same call if that held, and is left untouched if not (*second_stage_ran = 0)
         if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
         kids->clear(); kid_ids->clear(); *trouble = 0;
         if (nreg == 0 || ncl == 0) return 0;
@@ -907,6 +911,7 @@ public:
             total += cnt[x];
         }
         if (cluster_first[0] != 0 || cluster_first[ncl] != nreg) { error = "bad cluster list"; return -2; }
+        if (stage_first < 0 || stage_first >= ncl) { error = "bad stage boundary"; return -2; }
         begin_store_call();
         const size_t cap = (size_t)rg_count + 2 * (size_t)total + 16;       // (every accepted candidate has two neighbour regions)
         ensure_keep(d_rg_start, cap * (size_t)ngen, (size_t)rg_count * (size_t)ngen); ensure_keep(d_rg_len, cap * (size_t)ngen, (size_t)rg_count * (size_t)ngen);
@@ -916,16 +921,23 @@ public:
         if (!block) { error = "cannot allocate the request staging block"; return -3; }
         int64_t* s_row0 = (int64_t*)block; int64_t* s_first = s_row0 + nreg; int32_t* s_reg = (int32_t*)(s_first + ncl + 1); int32_t* s_cnt = s_reg + nreg;
         memcpy(s_row0, row0, 8 * (size_t)nreg); memcpy(s_first, cluster_first, 8 * ((size_t)ncl + 1)); memcpy(s_reg, regions, 4 * (size_t)nreg); memcpy(s_cnt, cnt, 4 * (size_t)nreg);
-        ensure(d_v_row0, (size_t)nreg); ensure(d_v_first, (size_t)ncl + 1); ensure(d_list, (size_t)nreg); ensure(d_list2, (size_t)nreg); ensure(d_rg_count, 2);
+        ensure(d_v_row0, (size_t)nreg); ensure(d_v_first, (size_t)ncl + 1); ensure(d_list, (size_t)nreg); ensure(d_list2, (size_t)nreg); ensure(d_rg_count, 4);
         be.h2d_staged(d_v_row0.p, s_row0, 8 * (size_t)nreg); be.h2d_staged(d_v_first.p, s_first, 8 * ((size_t)ncl + 1));
         be.h2d_staged(d_list.p, s_reg, 4 * (size_t)nreg); be.h2d_staged(d_list2.p, s_cnt, 4 * (size_t)nreg);
-        uint64_t head[2] = {(uint64_t)rg_count, 0};       // [0] the region counter, [1] the trouble word
-        be.h2d(d_rg_count.p, head, 16);
+        uint64_t head[3] = {(uint64_t)rg_count, 0, 0};       // [0] the region counter, [1] the trouble word, [2] the gate of the second stage
+        be.h2d(d_rg_count.p, head, 24);
         be.mark("validate");
-        be.launch_wave("clusters_disjoint", ncl - 1, ClustersDisjoint{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, (uint32_t*)(d_rg_count.p + 1)});
-        be.launch_wave("cluster_validate", xcd_grid(ncl),
+        be.launch_wave("clusters_disjoint", ncl - 1, ClustersDisjoint{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, (uint32_t*)(d_rg_count.p + 1), stage_first});
+        const int64_t na = stage_first > 0 ? stage_first : ncl;
+        be.launch_wave("cluster_validate", xcd_grid(na),
                        ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
-                                       d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), (int64_t)ncl});
+                                       d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), na, 0, nullptr});
+        if (stage_first > 0) {
+            be.launch("stage_gate", 1, StageGate{d_rg_count.p, (uint64_t)rg_count, force_gate ? 1 : 0});
+            be.launch_wave("cluster_validate", xcd_grid(ncl - na),
+                           ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
+                                           d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), ncl - na, na, d_rg_count.p + 2});
+        }
         if (info_count > 0) {      // the scalars of the candidates just decided, with the same round trip
             if (info_first < 0 || info_first + info_count > ms_count) { error = "rows outside the MUM store"; return -2; }
             ensure(d_rowinfo, (size_t)info_count);
@@ -933,8 +945,9 @@ public:
         }
         be.mark(nullptr);
         if (info_count > 0) be.d2h_async(info, d_rowinfo.p, sizeof(RowInfo) * (size_t)info_count);
-        be.d2h(head, d_rg_count.p, 16);
+        be.d2h(head, d_rg_count.p, 24);
         *trouble = (uint32_t)head[1];
+        if (second_stage_ran) *second_stage_ran = stage_first > 0 && head[2] == 0 ? 1 : 0;
         if (head[0] > cap) { error = "region store overflow"; return -4; }
         const int64_t before = rg_count;
         rg_count = (int64_t)head[0];
@@ -1141,12 +1154,14 @@ public:
     int64_t last_grouped = 0;
     bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
     bool master_seg = true;               // Master.EP from the genomes' segments (MasterEPSeg); false: every lane against every staged event (MasterEP)
+    bool force_gate = false;              // (tests) the second stage of a two-stage store_validate never runs
     bool force_chain_tie = false;         // (tests) store_chain_begin reports two MUMs with one reference start
     bool phase_timing = true;             // HIP events around the phases of a call (pm_last_timing); off: the marks cost nothing
     bool tune(const std::string& key, int64_t value) {
         if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
         if (key == "master_seg") { master_seg = value != 0; return true; }
+        if (key == "stage_gate") { force_gate = value != 0; return true; }
         if (key == "chain_tie") { force_chain_tie = value != 0; return true; }
         if (key == "timing") { phase_timing = value != 0; be.timing_on = phase_timing; return true; }
         if (key == "group_small") { group_small = value != 0; return true; }

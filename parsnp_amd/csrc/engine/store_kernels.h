@@ -895,8 +895,10 @@ struct GroupedBounds {
 // order, which the host route's exact test decides.  One wavefront per cluster (from the second on).
 struct ClustersDisjoint {
     int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first; uint32_t* trouble;
+    int64_t stage_first;      // the first cluster of the call's second stage (0: one stage): it runs after its predecessor, not beside it
     PM_HD void wave(int64_t w) const {
         const int64_t cl = w + 1;
+        if (cl == stage_first) return;
         const int64_t p0 = cluster_first[cl - 1], p1 = cluster_first[cl], c1 = cluster_first[cl + 1];
         uint32_t bad = 0;
         lanes_for(1, ngen, [&](int j) {
@@ -914,9 +916,12 @@ struct ClusterValidate {
     const int32_t* now_region; const int64_t* now_row0; const int32_t* now_cnt; const int64_t* cluster_first;
     int32_t q; uint32_t* trouble;
     int64_t ncl;      // the launch is xcd_grid(ncl) wavefronts: neighbouring clusters read and mark neighbouring words of the image
+    int64_t cl0;      // ... for the clusters [cl0, cl0 + ncl) of the list
+    const uint64_t* gate;      // != nullptr: the second stage of a call -- it only runs if the first left *gate at 0 (StageGate)
     PM_HD void wave(int64_t w) const {
-        const int64_t cl = xcd_item(w, ncl);
-        if (cl >= ncl) return;
+        if (gate && *gate) return;
+        const int64_t cl = cl0 + xcd_item(w, ncl);
+        if (cl >= cl0 + ncl) return;
         const int n = S.ngen;
         int64_t pending_min = -1;
         const int64_t x1 = cluster_first[cl + 1];
@@ -982,6 +987,14 @@ struct ClusterValidate {
             }
         }
     }
+};
+
+// between the two stages of a validation call (one thread): did the first stage leave a child region or trouble behind?  Then the
+// second stage -- formed by the caller on the assumption that it would not -- must not run.  head: [0] region counter, [1] trouble
+// word, [2] the gate
+struct StageGate {
+    uint64_t* head; uint64_t regions_before; int force;      // force: (tests) close the gate whatever the first stage did
+    PM_HD void operator()(int64_t) const { head[2] = (force || head[0] != regions_before || (uint32_t)head[1] != 0) ? 1 : 0; }
 };
 
 // ------------------------------------------------------------------------------------------ chaining

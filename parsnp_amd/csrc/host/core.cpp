@@ -116,6 +116,7 @@ int CoreRun::open(const std::string& ini_path) {
     if (const char* v = test_hook("PM_ATOMIC_MARKS")) (void)pm_session_tune(session, "atomic_marks", atol(v));
     if (const char* v = test_hook("PM_GROUP_SMALL")) (void)pm_session_tune(session, "group_small", atol(v));
     if (const char* v = test_hook("PM_MASTER_SEG")) (void)pm_session_tune(session, "master_seg", atol(v));
+    if (const char* v = test_hook("PM_STAGE_GATE")) (void)pm_session_tune(session, "stage_gate", atol(v));
     if (const char* v = test_hook("PM_CHAIN_TIE")) (void)pm_session_tune(session, "chain_tie", atol(v));
     upload_s = now_s() - t1;
     return 0;

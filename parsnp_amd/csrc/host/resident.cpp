@@ -203,40 +203,57 @@ bool Aligner::resident_extend() {
     int gi = 0;
     double tl = now_s();
     auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[resident generation %d] %-12s %.4f s\n", gi, what, t - tl); tl = t; } };
+    // sort by reference start, drop a region equal to its successor (:291-306), cut into clusters: maximal runs that overlap or touch on
+    // the reference (disjointness in the other genomes: the device).  Appends to now / now_id / first; false: the route is left
+    auto sort_and_cluster = [&](const std::vector<pm_region_info>& in, const std::vector<int32_t>& in_id, std::vector<pm_region_info>* now, std::vector<int32_t>* now_id, std::vector<int64_t>* first) {
+        const size_t base = now->size();
+        std::vector<Handle> h(in.size());
+        for (size_t i = 0; i < in.size(); i++) h[i] = Handle{(long)in[i].ref_start, (int)i};
+        std::sort(h.begin(), h.end());
+        for (size_t i = 0; i < h.size(); i++) {
+            const pm_region_info& r = in[(size_t)h[i].idx];
+            if (now->size() > base && now->back().ref_start == r.ref_start) {
+                uint8_t same = 0;
+                if (now->back().ref_len == r.ref_len && now->back().slength == r.slength) {
+                    const int32_t x = now_id->back(), y = in_id[(size_t)h[i].idx];
+                    if (pm_store_regions_equal(session_, &x, &y, 1, &same) != PM_OK) engine_error("region comparison failed", PM_EHIP);
+                }
+                if (same) continue;
+                res_.failed = true; res_.why = "two different regions share a reference start";      // the unstable sort decides: host route
+                return false;
+            }
+            now->push_back(r); now_id->push_back(in_id[(size_t)h[i].idx]);
+        }
+        long reach = -1;
+        for (size_t i = base; i < now->size(); i++) {
+            if (i == base || (*now)[i].ref_start > reach + 1) first->push_back((int64_t)i);
+            const long end = (long)((*now)[i].ref_start + (*now)[i].ref_len);
+            if (end > reach) reach = end;
+        }
+        first->push_back((int64_t)now->size());
+        return true;
+    };
+    static const bool two_stages = test_hook("PARSNP_ONE_STAGE") == nullptr;      // test hook: every generation its own call
     while (!gen.empty()) {
         std::vector<pm_region_info> now; std::vector<int32_t> now_id;
         std::vector<int64_t> first;
+        int64_t stage_first = 0;                      // > 0: the call holds two generations (pm_store_validate)
+        std::vector<pm_region_info> rest; std::vector<int32_t> rest_id;
         if (gi == 0) {                  // the first pushed seed, before anything is sorted (:194-195 precede :291-292); every seed's search in ONE call
             search(gen, gen_id);
             now.push_back(gen.front()); now_id.push_back(gen_id.front());
-            first = {0, 1};
+            first = {0};
             gen.erase(gen.begin()); gen_id.erase(gen_id.begin());
-        } else {                        // sort by reference start, drop a region equal to its successor (:291-306)
-            std::vector<Handle> h(gen.size());
-            for (size_t i = 0; i < gen.size(); i++) h[i] = Handle{(long)gen[i].ref_start, (int)i};
-            std::sort(h.begin(), h.end());
-            for (size_t i = 0; i < h.size(); i++) {
-                const pm_region_info& r = gen[(size_t)h[i].idx];
-                if (!now.empty() && now.back().ref_start == r.ref_start) {
-                    uint8_t same = 0;
-                    if (now.back().ref_len == r.ref_len && now.back().slength == r.slength) {
-                        const int32_t x = now_id.back(), y = gen_id[(size_t)h[i].idx];
-                        if (pm_store_regions_equal(session_, &x, &y, 1, &same) != PM_OK) engine_error("region comparison failed", PM_EHIP);
-                    }
-                    if (same) continue;
-                    res_.failed = true; res_.why = "two different regions share a reference start";      // the unstable sort decides: host route
-                    return false;
-                }
-                now.push_back(r); now_id.push_back(gen_id[(size_t)h[i].idx]);
-            }
-            // clusters: maximal runs that overlap or touch on the reference (disjointness in the other genomes: the device)
-            long reach = -1;
-            for (size_t i = 0; i < now.size(); i++) {
-                if (i == 0 || now[i].ref_start > reach + 1) first.push_back((int64_t)i);
-                const long end = (long)(now[i].ref_start + now[i].ref_len);
-                if (end > reach) reach = end;
-            }
-            first.push_back((int64_t)now.size());
+            // ... and, in the same call, the generation that follows if the first seed pushes no child region (it almost never
+            // does): the remaining seeds, sorted.  The device leaves them alone if it does
+            if (two_stages && !gen.empty()) {
+                rest = gen; rest_id = gen_id;
+                if (!sort_and_cluster(gen, gen_id, &now, &now_id, &first)) return false;
+                stage_first = 1;
+                gen.clear(); gen_id.clear();
+            } else first.push_back(1);
+        } else {
+            if (!sort_and_cluster(gen, gen_id, &now, &now_id, &first)) return false;
             lap("sort");
             search(now, now_id);
             gen.clear(); gen_id.clear();
@@ -250,8 +267,9 @@ bool Aligner::resident_extend() {
         int64_t lo = INT64_MAX, hi = -1;
         for (size_t i = 0; i < now.size(); i++) if (rc_[i] > 0) { lo = std::min(lo, r0[i]); hi = std::max(hi, r0[i] + rc_[i]); }
         if (hi > lo && info.size() < (size_t)hi) info.resize((size_t)hi);
+        int32_t second_ran = 0;
         int rc = pm_store_validate(session_, now_id.data(), r0.data(), rc_.data(), (int64_t)now.size(), first.data(), (int64_t)first.size() - 1, (int32_t)prm.q, &trouble, &nkids,
-                                   hi > lo ? lo : 0, hi > lo ? hi - lo : 0, hi > lo ? info.data() + lo : nullptr);
+                                   hi > lo ? lo : 0, hi > lo ? hi - lo : 0, hi > lo ? info.data() + lo : nullptr, stage_first, &second_ran);
         if (rc != PM_OK) engine_error("validation of a generation on the device failed", rc);
         collect_engine_timing();
         if (trouble) {
@@ -264,6 +282,12 @@ bool Aligner::resident_extend() {
         // children (the engine lists them parent by parent in push order) -> the next generation, after what is still waiting
         const pm_region_info* ki = pm_store_new_regions(session_);
         const int32_t* kid = pm_store_new_region_ids(session_);
+        if (stage_first > 0 && !second_ran) {
+            // the first seed pushed children: only it was validated.  What waits is the other seeds, then the children (:215-254)
+            now.resize(1); now_id.resize(1); r0.resize(1); rc_.resize(1);
+            gen = std::move(rest); gen_id = std::move(rest_id);
+            stage_first = 0;
+        }
         for (int64_t i = 0; i < nkids; i++) { gen.push_back(ki[i]); gen_id.push_back(kid[i]); }
         stats.t_validate += now_s() - tv;
         lap("validate");
@@ -290,9 +314,9 @@ bool Aligner::resident_extend() {
             }
             stats.regions_processed++; stats.cache_hits++;
         }
-        stats.generations++; stats.generation_regions += (long)now.size();
+        stats.generations += stage_first > 0 ? 2 : 1; stats.generation_regions += (long)now.size();
         lap("commit");
-        gi++;
+        gi += stage_first > 0 ? 2 : 1;
     }
     if (!res_.chain_queued && !mums.empty()) resident_chain_begin(mums.size());      // (no seed region at all: the anchors are the list)
     stats.extend_s = now_s() - t0;
