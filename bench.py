@@ -495,7 +495,7 @@ def main():
                                "wave-cycles are spent waiting.  SeedRest waits on dependent scattered reads; GroupedPairEvents / SmallPairEvents are "
                                "register and LDS arithmetic." % (issue["valu_per_wave"], PROFILE_ROUND, issue["cycles_per_valu"], PROFILE_ROUND, 100 * issue["issue_frac"], 100 * issue.get("wait_frac", 0)))
                 else:
-                    limiter = ("vector-instruction issue (SQ counters of round 4: 1 201 vector + 402 scalar instructions per 128-sample wavefront of SeedExtend, 62 %% of its "
+                    limiter = ("vector-instruction issue (SQ counters of round 4: 1 201 vector + 402 scalar instructions per 128-sample wavefront of SeedExtend, 62 % of its "
                                "wave-cycles waiting); no SQ pass of this build on file, so no issue fraction is quoted")
                 frac_traffic = round(traffic_gbs / HBM_PEAK_GBS, 5) if traffic_gbs else None
                 roof = {"bound": "hbm",      # (the contract's two rooflines; what the kernel really waits for: `limiter`, `issue_frac`)

@@ -102,6 +102,7 @@ public:
     int64_t last_events = 0, last_candidates = 0, last_rest = 0, last_positions = 0, last_accepted = 0;
     double last_alg[3] = {0, 0, 0};      // last search of store regions: SURVEY 8d bytes, this engine's bytes, query-stream bytes (AlgBytes)
     uint64_t alg_raw[3] = {0, 0, 0};
+    uint64_t alg_sets[8 * kAlgSets] = {};
 
     int ngen = 0;
     bool want_rows = false;           // pm_session_rows: results as MUM rows (start, strand, flags) instead of (sp, fwd)
@@ -339,12 +340,12 @@ public:
         ensure(d_ucount, (size_t)npairs + 1); ensure(d_uoff, (size_t)npairs + 1);
         ensure(d_coarse, (size_t)std::max<int64_t>(centries, 1));
         ensure(d_wmask, (size_t)nwv + 1); ensure(d_wcount, (size_t)nwv + 1); ensure(d_woff, (size_t)nwv + 1);
-        if (from_store_) ensure(d_alg, 4);
+        if (from_store_) ensure(d_alg, 8 * (size_t)kAlgSets);
         {
             const ClearJob jobs[] = {
                 {d_filter.p, sizeof(uint32_t) * (size_t)fwords, 0}, {d_slots.p, sizeof(uint64_t) * (size_t)tsize, 0xff}, {d_counter.p, 8 * ncounter, 0},
                 {d_repeated.p, 4 * (size_t)(npos / 32 + 2), 0}, {d_coarse.p, 4 * (size_t)std::max<int64_t>(centries, 1), 0},
-                {d_ucount.p + npairs, 8, 0}, {d_wcount.p + nwv, 8, 0}, {from_store_ ? d_alg.p : nullptr, from_store_ ? (size_t)32 : 0, 0}};
+                {d_ucount.p + npairs, 8, 0}, {d_wcount.p + nwv, 8, 0}, {from_store_ ? d_alg.p : nullptr, from_store_ ? (size_t)64 * kAlgSets : 0, 0}};
             be.clear_many(jobs, (int)(sizeof jobs / sizeof jobs[0]));
         }
         // rows the device derived itself (gaps of the anchor table, rows of the region store) were never seen by the host: the
@@ -418,7 +419,7 @@ public:
             be.mark("sort");
             be.launch_wave("slice_offsets", 1, SliceOffsets{d_counter.p, d_sliceoff.p});
             be.d2h_async(qcounts.data(), d_qcount.p, 8 * qcounts.size());
-            if (from_store) be.d2h_async(alg_raw, d_alg.p, 24);
+            if (from_store) be.d2h_async(alg_sets, d_alg.p, sizeof alg_sets);
             be.d2h(counts.data(), d_counter.p, 8 * counts.size());            // round trip 1: event counts + error word (+ the queues' lengths)
             uint64_t worst = 0, qworst = 0;
             nev = 0; nrest = 0;
@@ -435,6 +436,10 @@ public:
             sticky |= errbits & (kErrWork | kErrRows);      // (RepeatLength's and CheckRows' verdicts: the word is cleared with the counters)
         }
         errbits |= sticky;
+        if (from_store) {
+            alg_raw[0] = alg_raw[1] = alg_raw[2] = 0;
+            for (int x = 0; x < kAlgSets; x++) for (int k = 0; k < 3; k++) alg_raw[k] += alg_sets[8 * x + k];
+        }
         if (from_store) { last_alg[0] = (double)alg_raw[0] / 4.0; last_alg[1] = (double)alg_raw[1] / 2.0; last_alg[2] = (double)alg_raw[2] / 2.0; }
         if (errbits & kErrRows) { error = "region outside its genome"; return -2; }
         rest_cap_hint[nreg == 1] = queue_cap;

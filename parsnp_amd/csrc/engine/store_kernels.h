@@ -613,8 +613,10 @@ struct SeedPlace {
 // over rows it holds): per (region, query genome) with piece length m and reference window n,
 //   out[0] += 4 x SURVEY 8d's m/4 + 16 m + 16 n,   out[1] += 2 x (m/2 + 8 B per sampled K-mer -- one 64-B index request per leader, none
 //   for pairs that fit 128 bases -- and n/2 once per region),   out[2] += 2 x m/2.
-// One wavefront per kAlgPairs pairs, one atomic per wavefront and counter (three hot addresses: few wavefronts).
-constexpr int kAlgPairs = 4096;
+// One wavefront per kAlgPairs pairs, one atomic per wavefront and counter on one of kAlgSets sets of counters, a 64-byte line
+// apart (the host adds the sets up): three hot addresses made this kernel 42 us of a step at 4 096 pairs per wavefront.
+constexpr int kAlgPairs = 256;
+constexpr int kAlgSets = 64;
 struct AlgBytes {
     const RegionInfo* R; const int64_t* lens; int32_t ngen; int64_t npairs; uint64_t* out;
     PM_HD void wave(int64_t w) const {
@@ -631,7 +633,8 @@ struct AlgBytes {
             q += (uint64_t)m;
         });
         a = wave_sum_u64(a); k = wave_sum_u64(k); q = wave_sum_u64(q);
-        if (wave_leader()) { atomic_add64(out, a); atomic_add64(out + 1, k); atomic_add64(out + 2, q); }
+        uint64_t* set = out + (size_t)(w & (kAlgSets - 1)) * 8;
+        if (wave_leader()) { atomic_add64(set, a); atomic_add64(set + 1, k); atomic_add64(set + 2, q); }
     }
 };
 // tid = (i, genome): request rows of the listed regions, in list order, where the search reads them

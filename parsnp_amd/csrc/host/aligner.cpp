@@ -175,7 +175,6 @@ void Aligner::wait_layout() {
 }
 
 Aligner::~Aligner() {
-    if (res_.records.valid()) res_.records.get();      // (a resident run nobody extended: its helper writes to `pool`)
     wait_layout();
     // the resident route never writes to the host's bitmaps: the next run starts on them as they are
     memory_->layout_clean = res_.active && !layout.empty() && !layout[0].attached();
@@ -253,6 +252,21 @@ Region Aligner::neighbour_region(const Mum& m, bool left) {
 }
 
 int Aligner::min_length(bool anchors, long slength) {
+    // a pure function of the ini's expression and the length: short lengths (the recursion's 8 000 regions per step) through a
+    // flat table that the runs of one process share
+    if (slength >= 0 && slength < (1 << 16)) {
+        std::vector<int>& flat = memory_->minlen_flat[anchors ? 1 : 0];
+        std::string& owner = memory_->minlen_expr[anchors ? 1 : 0];
+        const std::string& e = anchors ? prm.anchors : prm.mums;
+        if (flat.empty() || owner != e) { flat.assign(1 << 16, INT32_MIN); owner = e; }
+        int& v = flat[(size_t)slength];
+        if (v == INT32_MIN) {
+            int w = 0;
+            if (!min_mum_length(e, slength, &w)) fatal("cannot evaluate minimum MUM length expression '" + e + "'");
+            v = w;
+        }
+        return v;
+    }
     auto& memo = minlen_memo_[anchors ? 1 : 0];
     auto it = memo.find(slength);
     if (it != memo.end()) return it->second;

@@ -277,6 +277,7 @@ struct AlignerMemory {
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
     std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
     std::vector<Mum> pool_store, candidates;         // storage of Aligner::pool / validate_parallel's candidate records between runs
+    std::vector<int> minlen_flat[2]; std::string minlen_expr[2];   // Aligner::min_length for lengths below 2^16, by expression (mums, anchors)
     struct PerThread { Arena<long> rows; Arena<int32_t> irows; Arena<uint8_t> brows; std::vector<long> scratch; };
     std::vector<std::unique_ptr<PerThread>> per_thread;   // rows written by the threads of the generation-parallel replay
     void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); brows.reset(); for (auto& t : per_thread) { t->rows.reset(); t->irows.reset(); t->brows.reset(); } }
@@ -337,7 +338,8 @@ private:
         std::vector<pm_region_info> gen_info; std::vector<int32_t> gen_id;     // the seed regions, in push order
         std::vector<int32_t> fallback_start; std::vector<uint8_t> fallback_strand;   // rows fetched for the host route
         std::vector<uint64_t> image;                                           // the layout, fetched for parsnp.unalign
-        std::future<void> records;                                             // the anchors' MUM records, written beside the seed regions' device work
+        std::vector<pm_row_info> anchor_info; const int32_t* anchor_lon = nullptr; long anchor_slength = 0; size_t anchor_accepted = 0;   // what resident_records() writes the anchors' MUM records from
+        bool records_done = true;
         bool chain_queued = false;                                             // pm_store_chain_begin is in flight (resident_chain() collects it)
         std::string chain_why;                                                 // why phases C-D fell back to the host's list logic
     } res_;
@@ -346,6 +348,7 @@ private:
     bool resident_anchors(const Region& whole, std::vector<int>* found);
     bool resident_extend();
     void resident_chain_begin(size_t expect);
+    void resident_records();
     void resident_verdicts();
     uint8_t resident_judge_rows(int cur, int back);
     void resident_fill_between();

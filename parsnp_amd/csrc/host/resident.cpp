@@ -92,43 +92,23 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
         res_.why = kept ? "too many anchor candidates overlap earlier ones" : "short anchor list (no anchor table)";
         return false;
     }
-    // the accepted anchors, in list order.  Their rows for the seed regions first -- the device goes on at once --, the MUM
-    // records (ids as the sequential loop assigns them: one per constructed candidate) beside it, on a helper thread that
-    // resident_extend() joins before the first MUM of the recursion is committed
+    // the accepted anchors, in list order: counted now; their MUM records (ids as the sequential loop assigns them: one per
+    // constructed candidate) are written by resident_records() while the device works on phases C-D -- nothing on the way to the
+    // recursion's search waits for them (a helper thread wrote them until round 5: starting it cost more than it hid)
     res_.active = true; res_.table = table;
     kept_results_.push_back(a.owner);
     pool.clear(); res_.start0.clear();
     std::vector<int32_t> acc;
-    acc.reserve(a.count);
-    for (size_t c = 0; c < a.count; c++) if (info[c].state_flags & PM_ST_ACCEPTED) acc.push_back((int32_t)c);
-    const size_t nacc = acc.size();
+    size_t nacc = 0;
+    if (fused) { for (size_t c = 0; c < a.count; c++) nacc += (info[c].state_flags & PM_ST_ACCEPTED) != 0; }
+    else {
+        acc.reserve(a.count);
+        for (size_t c = 0; c < a.count; c++) if (info[c].state_flags & PM_ST_ACCEPTED) acc.push_back((int32_t)c);
+        nacc = acc.size();
+    }
     found->resize(nacc);
     for (size_t i = 0; i < nacc; i++) (*found)[i] = (int)i;
-    {
-        auto infos = std::make_shared<std::vector<pm_row_info>>(std::move(info));
-        std::shared_ptr<pm_result> keep = a.owner;
-        const int32_t* lon = a.lon;
-        const size_t count = a.count;
-        const long slen = whole.slength;
-        res_.records = std::async(std::launch::async, [this, infos, keep, lon, count, slen, nacc] {
-            pool.resize(nacc); res_.start0.resize(nacc);
-            size_t at = 0;
-            long dirty = 0, tangled = 0;
-            for (size_t c = 0; c < count; c++) {
-                const pm_row_info& r = (*infos)[c];
-                const uint32_t st = r.state_flags & 0xffu;
-                if (st & PM_ST_BUILT) next_id_++;
-                if (!(st & PM_ST_ACCEPTED)) continue;
-                Mum m;
-                m.id = next_id_ - 1; m.length = r.len; m.slength = slen; m.row = (int32_t)c;
-                m.dirty = (st & PM_ST_FLAGGED) != 0; m.touched = r.len != lon[c];
-                pool[at] = m; res_.start0[at] = r.start0;
-                at++;
-                dirty += m.dirty; tangled += (st & PM_ST_TANGLED) != 0;
-            }
-            stats.parallel_dirty += dirty; stats.parallel_tangled += tangled;
-        });
-    }
+    res_.anchor_info = std::move(info); res_.anchor_lon = a.lon; res_.anchor_slength = whole.slength; res_.anchor_accepted = nacc; res_.records_done = false;
     stats.parallel_candidates += (long)a.count;
     stats.regions_processed++;
     lap("records");
@@ -164,10 +144,34 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
     return true;
 }
 
+// the MUM records of the accepted anchors (no rows: those stay on the device), in list order, at the head of the pool
+void Aligner::resident_records() {
+    if (res_.records_done) return;
+    res_.records_done = true;
+    const size_t nacc = res_.anchor_accepted, count = res_.anchor_info.size();
+    pool.resize(nacc); res_.start0.resize(nacc);
+    size_t at = 0;
+    long dirty = 0, tangled = 0;
+    for (size_t c = 0; c < count; c++) {
+        const pm_row_info& r = res_.anchor_info[c];
+        const uint32_t st = r.state_flags & 0xffu;
+        if (st & PM_ST_BUILT) next_id_++;
+        if (!(st & PM_ST_ACCEPTED)) continue;
+        Mum m;
+        m.id = next_id_ - 1; m.length = r.len; m.slength = res_.anchor_slength; m.row = (int32_t)c;
+        m.dirty = (st & PM_ST_FLAGGED) != 0; m.touched = r.len != res_.anchor_lon[c];
+        pool[at] = m; res_.start0[at] = r.start0;
+        at++;
+        dirty += m.dirty; tangled += (st & PM_ST_TANGLED) != 0;
+    }
+    stats.parallel_dirty += dirty; stats.parallel_tangled += tangled;
+    std::vector<pm_row_info>().swap(res_.anchor_info);
+}
+
 // Phase B: the generations of extend_generations() with the per-genome work on the device.
 bool Aligner::resident_extend() {
     const double t0 = now_s();
-    struct Join { std::future<void>& f; ~Join() { if (f.valid()) f.get(); } } join_records{res_.records};      // (the anchors' MUM records: joined on every way out)
+    struct Records { Aligner* a; ~Records() { a->resident_records(); } } records_on_every_way_out{this};
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     std::vector<pm_region_info> gen = std::move(res_.gen_info);
     std::vector<int32_t> gen_id = std::move(res_.gen_id);
@@ -300,7 +304,7 @@ bool Aligner::resident_extend() {
             resident_chain_begin(mums.size() + more);
             lap("chain queued");
         }
-        if (res_.records.valid()) res_.records.get();      // the anchors' records are in: the recursion's MUMs follow them in the pool
+        resident_records();      // the anchors' records first: the recursion's MUMs follow them in the pool
         // commit in list order (:215-254 push the MUMs of a region in candidate order)
         for (size_t i = 0; i < now.size(); i++) {
             for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) {

@@ -1,9 +1,17 @@
 #!/bin/bash
-# the rocprofv3 passes on the final build, then the default bench line WITH the stamped traffic file in place
-mkdir -p gpurun_out/final
+# round 5: the profiler passes on the build at hand (kernel trace + stats, FETCH_SIZE / WRITE_SIZE passes, the HBM and VALU
+# calibrations, SQ counters), the summaries copied into profiles/r05/ so that the default bench line that follows can quote the
+# traffic and the issue fraction OF THIS BUILD; then the per-step floor (bench.py --genomes 25 ... 200).
+#   gpurun --timeout 1500 -- 'bash scripts/round_profile.sh'
+mkdir -p gpurun_out/final profiles/r05
 O=gpurun_out/final
 bash scripts/profile.sh > $O/profile.log 2>&1; ls gpurun_out/prof/summary
-cp gpurun_out/prof/summary/traffic_seed_extend.json gpurun_out/prof/summary/calibration.json profiles/r04/
+for f in traffic_seed_extend.json calibration.json kernel_stats.csv pmc_per_kernel.json idle_gaps.json calib_bytes.json valu_calib.json bench_plain.json bench_under_rocprof.json; do cp gpurun_out/prof/summary/$f profiles/r05/ 2>/dev/null; done
 bash scripts/sqcounters.sh > $O/sq.log 2>&1; tail -4 $O/sq.log | cut -c1-200
-timeout 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -1 $O/bench_default.json | python scripts/benchline.py | head -2
-timeout 300 python bench.py --steps 60 --warmup 5 --cpu-sample 0 --other-configs off --tune group_small=0 > $O/bench_group_small_0.json 2> /dev/null; tail -1 $O/bench_group_small_0.json | python scripts/benchline.py | head -1
+cp gpurun_out/sq/summary.json profiles/r05/sq_seed_extend.json
+timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -1 $O/bench_default.json | python scripts/benchline.py | head -2
+cp $O/bench_default.json profiles/r05/bench_default.json
+timeout 300 python bench.py --steps 60 --warmup 5 --cpu-sample 0 --other-configs off --tune master_seg=0 > $O/bench_master_seg_0.json 2> /dev/null; tail -1 $O/bench_master_seg_0.json | python scripts/benchline.py | head -1
+cp $O/bench_master_seg_0.json profiles/r05/
+bash scripts/floor.sh; cp gpurun_out/floor.json profiles/r05/floor.json
+mkdir -p gpurun_out/profiles_r05; cp profiles/r05/* gpurun_out/profiles_r05/
