@@ -1795,11 +1795,19 @@ struct DirtyPrefix {
 #endif
         for (int j = j0; j < j1; j++) {
             int32_t mx = -1, mn = 0x7fffffff;
-            for (int64_t b = 0; b < nblocks; b++) {
-                const int32_t x = bmax[b * ngen + j], y = bmin[b * ngen + j];
-                bmax[b * ngen + j] = mx; bmin[b * ngen + j] = mn;
-                if (x > mx) mx = x;
-                if (y < mn) mn = y;
+            // sixteen blocks per round: their extents are in flight together (four wavefronts cannot hide a load per block: 71 us
+            // for the 236 blocks of a 60 000-row list when every block waited for its own)
+            for (int64_t b0 = 0; b0 < nblocks; b0 += 16) {
+                int32_t x[16], y[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { const int64_t b = b0 + u < nblocks ? b0 + u : nblocks - 1; x[u] = bmax[b * ngen + j]; y[u] = bmin[b * ngen + j]; }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    if (b0 + u >= nblocks) continue;
+                    bmax[(b0 + u) * ngen + j] = mx; bmin[(b0 + u) * ngen + j] = mn;
+                    if (x[u] > mx) mx = x[u];
+                    if (y[u] < mn) mn = y[u];
+                }
             }
         }
     }
