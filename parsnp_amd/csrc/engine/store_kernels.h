@@ -269,7 +269,6 @@ PM_HD void img_clear_range(const Layout& L, int j, int64_t a, int64_t b) {
     }
 }
 
-constexpr int kSettlePre = 512;      // genomes whose image words settle_row fetches ahead (8 KB of LDS per wavefront); beyond: the plain walk
 // ------------------------------------------------------------------------------------------ settle
 // The per-candidate block of setMums1 (src/parsnp.cpp:1781-1833) for store row c, by all lanes of the wavefront: the length
 // tests, Aligner::trim against the layout (:1399-1477; TMum::trimleft / trimright, TMum.cpp:104-148: every trim shortens the
@@ -290,45 +289,13 @@ PM_HD bool settle_row(const Store& S, const Layout& L, const Packed& P, int64_t 
     if ((f & (kRowBad | kRowOutside)) || len < 5) return false;
     const int32_t* st = S.start + c * n;
     int from = 0;
-    // A lane looks at its genomes one after the other, and each look is two DEPENDENT image reads (the word under the first base, the
-    // word under the last): four genomes per lane at 200 genomes = eight L2 round trips in a row per round.  So the words under both
-    // ends of every genome's range are fetched first, all at once, into LDS (by genome), and the looks below take them from there; a
-    // run that crosses into a neighbouring word (rare: a MUM candidate covered by marks for more than a word) walks the image as before.
-    PM_WAVE_SHARED uint64_t pre_lo[kSettlePre]; PM_WAVE_SHARED uint64_t pre_hi[kSettlePre];
     while (trim && len > 0) {
         int32_t first = 0x7fffffff, tl = 0, tr = 0;
-        wave_sync();
-        lanes_for(from, n < kSettlePre ? n : kSettlePre, [&](int j) {
-            const int64_t s = (int64_t)st[j] + dl, e = s + len - 1, nb = L.nbits[j];
-            const uint64_t* w = L.image + L.word_off[j];
-            pre_lo[j] = (s >= 0 && s < nb) ? img_ld(L, w + (s >> 6)) : 0;
-            pre_hi[j] = (e >= 0 && e < nb) ? img_ld(L, w + (e >> 6)) : 0;
-        });
-        wave_sync();
         lanes_for(from, n, [&](int j) {
             if (j >= first) return;
             const int64_t s = (int64_t)st[j] + dl;
-            int32_t l, r;
-            if (j < kSettlePre && s >= 0 && s + len <= L.nbits[j]) {
-                // marked bases from s upwards, as far as the word under s tells; a run that fills the rest of that word goes on in the image
-                const int lo = (int)(s & 63), avail = 64 - lo;
-                const uint64_t x = ~(pre_lo[j] >> lo);
-                int cu = x ? ctz64(x) : 64;
-                if (cu > avail) cu = avail;
-                l = (cu < avail || cu >= len) ? (cu < len ? cu : len) : img_run_up(L, j, s, len);
-                if (l < len) {
-                    const int64_t e = s + len - 1;
-                    const int hi = (int)(e & 63), av = hi + 1;
-                    const uint64_t y = ~(pre_hi[j] << (63 - hi));
-                    int cd = y ? clz64(y) : 64;
-                    if (cd > av) cd = av;
-                    const int32_t room = len - l;
-                    r = (cd < av || cd >= room) ? (cd < room ? cd : room) : img_run_down(L, j, e, room);
-                } else r = 0;
-            } else {
-                l = img_run_up(L, j, s, len);
-                r = l < len ? img_run_down(L, j, s + len - 1, len - l) : 0;
-            }
+            const int32_t l = img_run_up(L, j, s, len);
+            const int32_t r = l < len ? img_run_down(L, j, s + len - 1, len - l) : 0;
             if ((l | r) != 0) { first = j; tl = l; tr = r; }
         });
         const int32_t F = wave_min_i32(first);
@@ -528,43 +495,15 @@ struct SettleTangled {
 // next marked base.  left: [p + 1, start - 1) with p the previous marked base (none: the region begins at 1, :1222-1226);
 // right: from one base after the MUM's end to the base before the next marked one (or the sentinel at the genome's end).
 // The request is (start, end - start) -- TRegion's length = end - start (LCR.cpp:29).
-// The walks of one MUM's two sides start from the image words under the base before its start and under the base after the one
-// past its end.  A lane walks its genomes one after the other, and every walk begins with a dependent read; region_prefetch
-// fetches those first words of ALL genomes at once into LDS (by genome), and a walk that finds its marked base there -- the
-// neighbouring MUM is usually less than a word away -- never goes to memory.
-struct ImgPre { uint64_t* lo; uint64_t* hi; };      // [kSettlePre] each; lo == nullptr: no prefetch
-PM_HD void region_prefetch(const Store& S, const Layout& L, int64_t c, int32_t dl, int32_t len, const ImgPre& pre) {
-    wave_sync();
-    lanes_for(0, S.ngen < kSettlePre ? S.ngen : kSettlePre, [&](int j) {
-        const int64_t s = (int64_t)S.start[c * S.ngen + j] + dl, nb = L.nbits[j];
-        const uint64_t* w = L.image + L.word_off[j];
-        const int64_t a = s - 1, b = s + len + 1;
-        pre.lo[j] = (a >= 0 && a < nb) ? img_ld(L, w + (a >> 6)) : 0;
-        pre.hi[j] = (b >= 0 && b < nb) ? img_ld(L, w + (b >> 6)) : 0;
-    });
-    wave_sync();
-}
-PM_HD void region_side(const Store& S, const Layout& L, const Packed& P, int64_t c, int32_t dl, int32_t len, int side, int j, int64_t* a, int64_t* b, const ImgPre* pre = nullptr) {
+PM_HD void region_side(const Store& S, const Layout& L, const Packed& P, int64_t c, int32_t dl, int32_t len, int side, int j, int64_t* a, int64_t* b) {
     const int64_t s = (int64_t)S.start[c * S.ngen + j] + dl;
-    const bool have = pre && pre->lo && j < kSettlePre;
     if (side == 0) {
-        int64_t p;
-        const int64_t from = s - 1;
-        if (have && from >= 0 && from < L.nbits[j]) {
-            const int hi = (int)(from & 63);
-            const uint64_t x = pre->lo[j] & (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1));
-            p = x ? (from >> 6) * 64 + 63 - clz64(x) : img_prev_set(L, j, (from >> 6) * 64 - 1);
-        } else p = img_prev_set(L, j, from);
+        int64_t p = img_prev_set(L, j, s - 1);
         if (p < 0) p = 0;
         *a = p + 1; *b = s - 1;
     } else {
         const int64_t nxt = s + len + 1, size = P.glen[j];
-        int64_t p;
-        if (nxt >= size) p = nxt;
-        else if (have && nxt >= 0 && nxt < L.nbits[j]) {
-            const uint64_t x = pre->hi[j] & (~0ull << (nxt & 63));
-            p = x ? (nxt >> 6) * 64 + ctz64(x) : img_next_set(L, j, ((nxt >> 6) + 1) * 64);
-        } else p = img_next_set(L, j, nxt);
+        const int64_t p = nxt >= size ? nxt : img_next_set(L, j, nxt);
         *a = nxt; *b = p - 1;
     }
 }
@@ -576,11 +515,11 @@ struct RegInfo {
     int32_t parent;         // store row of the MUM it lies next to
 };
 // shortest region length over the genomes (and the reference column), by the whole wavefront
-PM_HD int32_t region_extent(const Store& S, const Layout& L, const Packed& P, int64_t c, int32_t dl, int32_t len, int side, int64_t* ref_start, int64_t* ref_len, const ImgPre* pre = nullptr) {
+PM_HD int32_t region_extent(const Store& S, const Layout& L, const Packed& P, int64_t c, int32_t dl, int32_t len, int side, int64_t* ref_start, int64_t* ref_len) {
     int32_t smin = 0x7fffffff, r0a = 0, r0l = 0;
     lanes_for(0, S.ngen, [&](int j) {
         int64_t a, b;
-        region_side(S, L, P, c, dl, len, side, j, &a, &b, pre);
+        region_side(S, L, P, c, dl, len, side, j, &a, &b);
         const int32_t ln = (int32_t)(b - a);
         if (ln < smin) smin = ln;
         if (j == 0) { r0a = (int32_t)a; r0l = ln; }
@@ -637,13 +576,10 @@ struct SeedCount {
         if (i >= *nacc) { if (wave_leader()) { cnt[i] = 0; keep[i] = 0; } return; }
         const int64_t c = acc[i];
         const int32_t dl = S.shift[c], len = S.len[c];
-        PM_WAVE_SHARED uint64_t pre_lo[kSettlePre]; PM_WAVE_SHARED uint64_t pre_hi[kSettlePre];
-        const ImgPre pre{pre_lo, pre_hi};
-        region_prefetch(S, L, c, dl, len, pre);
         uint8_t k = 0;
         for (int side = 0; side < 2; side++) {
             int64_t rs, rl;
-            if (region_extent(S, L, P, c, dl, len, side, &rs, &rl, &pre) > q) k |= (uint8_t)(1 << side);
+            if (region_extent(S, L, P, c, dl, len, side, &rs, &rl) > q) k |= (uint8_t)(1 << side);
         }
         if (wave_leader()) { cnt[i] = (k & 1) + (k >> 1); keep[i] = k; }
     }
@@ -658,17 +594,14 @@ struct SeedPlace {
         const int32_t dl = S.shift[c], len = S.len[c];
         const int n = S.ngen;
         int64_t slot = off[i];
-        PM_WAVE_SHARED uint64_t pre_lo[kSettlePre]; PM_WAVE_SHARED uint64_t pre_hi[kSettlePre];
-        const ImgPre pre{pre_lo, pre_hi};
-        region_prefetch(S, L, c, dl, len, pre);
         for (int side = 0; side < 2; side++) {
             if (!(keep[i] & (1 << side))) continue;
             if ((uint64_t)slot >= cap) return;           // (the caller sees the total past the capacity and repeats with room)
             int64_t rs, rl;
-            const int32_t smin = region_extent(S, L, P, c, dl, len, side, &rs, &rl, &pre);
+            const int32_t smin = region_extent(S, L, P, c, dl, len, side, &rs, &rl);
             lanes_for(0, n, [&](int j) {
                 int64_t a, b;
-                region_side(S, L, P, c, dl, len, side, j, &a, &b, &pre);
+                region_side(S, L, P, c, dl, len, side, j, &a, &b);
                 rg_start[slot * n + j] = a; rg_len[slot * n + j] = b - a;
             });
             if (wave_leader()) info[slot] = RegInfo{2 * i + side, rs, rl, smin, (int32_t)c};
@@ -993,8 +926,6 @@ struct ClusterValidate {
         const int64_t cl = cl0 + xcd_item(w, ncl);
         if (cl >= cl0 + ncl) return;
         const int n = S.ngen;
-        PM_WAVE_SHARED uint64_t pre_lo[kSettlePre]; PM_WAVE_SHARED uint64_t pre_hi[kSettlePre];
-        const ImgPre pre{pre_lo, pre_hi};
         int64_t pending_min = -1;
         const int64_t x1 = cluster_first[cl + 1];
         for (int64_t x = cluster_first[cl]; x < x1; x++) {
@@ -1030,10 +961,9 @@ struct ClusterValidate {
             for (int64_t c = row0; c < row0 + cnt; c++) {
                 if (!(load_coherent8(&S.state[c]) & kStAccepted)) continue;
                 const int32_t dl = load_coherent32(&S.shift[c]), len = load_coherent32(&S.len[c]);
-                region_prefetch(S, L, c, dl, len, pre);
                 for (int side = 0; side < 2; side++) {
                     int64_t ks, kl;
-                    const int32_t smin = region_extent(S, L, P, c, dl, len, side, &ks, &kl, &pre);
+                    const int32_t smin = region_extent(S, L, P, c, dl, len, side, &ks, &kl);
                     if (smin <= q) continue;
                     int32_t slot = 0;
                     if (wave_leader()) slot = (int32_t)atomic_add64(rg_count, 1);
@@ -1041,7 +971,7 @@ struct ClusterValidate {
                     if ((uint64_t)slot >= rg_cap) continue;
                     lanes_for(0, n, [&](int j) {
                         int64_t a, b;
-                        region_side(S, L, P, c, dl, len, side, j, &a, &b, &pre);
+                        region_side(S, L, P, c, dl, len, side, j, &a, &b);
                         rg_start[(int64_t)slot * n + j] = a; rg_len[(int64_t)slot * n + j] = b - a;
                     });
                     bool dup = false;
