@@ -489,14 +489,17 @@ def main():
                 # kernel does not live under the byte roof: `limiter` / `issue_frac` say what it waits for.
                 issue = issue_fraction(pdir)
                 if issue and issue.get("issue_frac") is not None:
-                    limiter = ("vector-instruction issue: the anchor dispatch of SeedExtend issues %d vector instructions per 128-sample wavefront "
-                               "(SQ counters of this build, profiles/%s/sq_seed_extend.json); at the measured %.2f cycles per wave64 int32 VALU instruction "
-                               "and SIMD (scripts/valu_calib.hip, profiles/%s/calibration.json) they occupy %.0f %% of the dispatch's cycles; %.0f %% of its "
-                               "wave-cycles are spent waiting.  SeedRest waits on dependent scattered reads; GroupedPairEvents / SmallPairEvents are "
-                               "register and LDS arithmetic." % (issue["valu_per_wave"], PROFILE_ROUND, issue["cycles_per_valu"], PROFILE_ROUND, 100 * issue["issue_frac"], 100 * issue.get("wait_frac", 0)))
+                    limiter = ("a chain of dependent scattered reads under half-used issue slots, not byte bandwidth: the anchor dispatch of SeedExtend issues %d "
+                               "vector instructions per 128-sample wavefront (SQ counters of this build, profiles/%s/sq_seed_extend.json); at the measured %.2f cycles "
+                               "per wave64 int32 VALU instruction and SIMD (scripts/valu_calib.hip, profiles/%s/calibration.json; the guide's figure is 2) they occupy "
+                               "%.0f %% of the dispatch's cycles (`issue_frac`; round 4 assumed 4 cycles and called it 85 %%), while %.0f %% of the wave-cycles of its 8 "
+                               "wavefronts per SIMD are spent waiting -- unit record, query blocks, the leaders' filter word and slot, reference blocks, repeat length: "
+                               "five round trips in a row per wavefront, ~56 vector memory instructions of 64 scattered lanes each.  SeedRest waits on dependent scattered "
+                               "reads outright; GroupedPairEvents / SmallPairEvents are register and LDS arithmetic."
+                               % (issue["valu_per_wave"], PROFILE_ROUND, issue["cycles_per_valu"], PROFILE_ROUND, 100 * issue["issue_frac"], 100 * issue.get("wait_frac", 0)))
                 else:
-                    limiter = ("vector-instruction issue (SQ counters of round 4: 1 201 vector + 402 scalar instructions per 128-sample wavefront of SeedExtend, 62 % of its "
-                               "wave-cycles waiting); no SQ pass of this build on file, so no issue fraction is quoted")
+                    limiter = ("dependent scattered reads under half-used issue slots (SQ counters of round 4: 1 201 vector + 402 scalar instructions per 128-sample wavefront "
+                               "of SeedExtend, 62 % of its wave-cycles waiting); no SQ pass of this build on file, so no issue fraction is quoted")
                 frac_traffic = round(traffic_gbs / HBM_PEAK_GBS, 5) if traffic_gbs else None
                 roof = {"bound": "hbm",      # (the contract's two rooflines; what the kernel really waits for: `limiter`, `issue_frac`)
                         "limiter": limiter,
