@@ -1749,21 +1749,31 @@ static void sort_lcbs(std::vector<Lcb>& v) {
 void Aligner::filter_lcbs() {
     double t0 = now_s();
     sort_lcbs(lcbs);
-    long count = (long)lcbs.size();
+    const long count = (long)lcbs.size();
     std::vector<int32_t> unmark;      // (resident route: the layout is the device's)
-    for (long x = 0; x < count - 1; x++) {
+    // (the reference erases every dissolved MUM from the list and every dissolved LCB from its list one at a time, :460-470 -- quadratic
+    // on a rearranged set with 20 000 short LCBs; which ones go does not depend on the order, so: marked, then both lists swept once)
+    std::vector<char> dead_mum(pool.size(), 0), dead_lcb((size_t)count, 0);
+    bool any = false;
+    for (long x = 0; x < count - 1; x++) {      // the last LCB is never examined (:447)
         if (lcbs[(size_t)x].length > prm.c) continue;
         filtered_lcbs += 1;
+        dead_lcb[(size_t)x] = 1; any = true;
         for (int idx : lcbs[(size_t)x].mums) {
             filtered += 1;
             const Mum& mt = pool[(size_t)idx];
             if (res_.active) unmark.push_back(mt.row);
             else for (size_t k = 0; k < n; k++) layout[k].clear_range(mt.start[k], mt.end(k));
-            auto it = std::find(mums.begin(), mums.end(), idx);   // first MUM with that id
-            if (it != mums.end()) mums.erase(it);
+            dead_mum[(size_t)idx] = 1;
         }
-        lcbs.erase(lcbs.begin() + x);
-        x -= 1; count -= 1;
+    }
+    if (any) {
+        size_t w = 0;
+        for (size_t i = 0; i < mums.size(); i++) if (!dead_mum[(size_t)mums[i]]) mums[w++] = mums[i];
+        mums.resize(w);
+        w = 0;
+        for (size_t x = 0; x < (size_t)count; x++) if (!dead_lcb[x]) { if (w != x) lcbs[w] = std::move(lcbs[x]); w++; }
+        lcbs.resize(w);
     }
     if (!unmark.empty() && pm_store_unmark(session_, unmark.data(), (int64_t)unmark.size()) != PM_OK) fatal(std::string("cannot take dissolved LCBs out of the layout: ") + pm_last_error());
     stats.lcb_s += now_s() - t0;

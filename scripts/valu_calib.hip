@@ -4,7 +4,7 @@
 // v_fma_f32; this program measures v_add_u32 / v_and_b32 / v_lshlrev_b32, the mix of the seed kernels, as
 //   dependent chain   one accumulator, every instruction waits for the one before it (latency)
 //   independent       eight accumulators round robin (throughput of ONE wave)
-// at 1 ... 8 wavefronts per SIMD (blocks of 256 x w threads, one per CU; w = 8: two blocks of 1024 per CU), timed per wave with
+// at 1 ... 8 wavefronts per SIMD (one block of 256 x w threads per CU; above w = 4 two blocks of 128 x w), timed per wave with
 // s_memtime (tick = shader cycle) and over the launch with HIP events.  Prints one JSON object.
 //   hipcc --offload-arch=gfx950 -O3 scripts/valu_calib.hip -o parsnp_amd/bin/valu_calib && parsnp_amd/bin/valu_calib
 #include <hip/hip_runtime.h>
@@ -69,12 +69,14 @@ int main() {
     double best_rate = 0;
     for (int dep = 1; dep >= 0; dep--)
         for (int w = 1; w <= 8; w++) {
-            const int blocks = w == 8 ? 2 * cus : cus, threads = w == 8 ? 1024 : 256 * w;
+            // 4 w wavefronts per CU: one block of 256 w threads up to w = 4, two blocks of 128 w threads above (a block holds 1024 at most)
+            const int blocks = w > 4 ? 2 * cus : cus, threads = w > 4 ? 128 * w : 256 * w;
             float ms = 0;
             for (int rep = 0; rep < 3; rep++) {      // (the last repetition counts: clocks have settled)
                 CK(hipEventRecord(e0, 0));
                 if (dep) hipLaunchKernelGGL(chain<true>, dim3(blocks), dim3(threads), 0, 0, d_out, d_cyc, 3u, 0x7fffffffu);
                 else hipLaunchKernelGGL(chain<false>, dim3(blocks), dim3(threads), 0, 0, d_out, d_cyc, 3u, 0x7fffffffu);
+                CK(hipGetLastError());
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 CK(hipEventElapsedTime(&ms, e0, e1));
