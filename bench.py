@@ -400,11 +400,11 @@ def main():
             if dist is not None:
                 dist.broadcast_object_list(box, src=0)
             if torch.cuda.device_count() >= world:
-                env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23), PARSNP_RCCL_TIMEOUT="120")
+                env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23), PARSNP_RCCL_TIMEOUT="60")
                 cmd = [sys.executable, os.path.abspath(__file__), "--mode", "sharded", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
                        "--workload", args.workload, "--cpu-sample", "0", "--inputs", box[0], "--host-threads", str(args.host_threads)]
                 try:
-                    pr = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+                    pr = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)      # (a healthy child: ~40 s; the line must not wait 15 minutes for a hung one)
                     lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
                     if rank == 0:
                         if pr.returncode == 0 and lines:
@@ -415,7 +415,7 @@ def main():
                         else:
                             sharded_strong = {"error": "child exit code %d: %s" % (pr.returncode, pr.stderr[-400:])}
                 except subprocess.TimeoutExpired:
-                    sharded_strong = {"error": "the sharded child did not finish within 900 s"}
+                    sharded_strong = {"error": "the sharded child did not finish within 300 s"}
             else:
                 sharded_strong = {"skipped": "needs one GPU per rank (%d ranks, %d GPUs visible)" % (world, torch.cuda.device_count())}
             if dist is not None:

@@ -1699,16 +1699,11 @@ void Aligner::chain() {
     if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[chain] order + verdicts %.4f s\n", now_s() - t0);
     auto open_chain = [&](int idx) { Lcb c; c.type = 1; c.mums.push_back(idx); c.length = pool[(size_t)idx].length; return c; };
     auto close_chain = [&](Lcb& c) {      // start of the first MUM, end of the last (Cluster(TMum) LCB.cpp:21-28 + the joins)
-        const Mum& f = pool[(size_t)c.mums.front()];
+        // the reference column now; the rows of the other genomes when the list of LCBs is final (complete_lcbs() on the host route,
+        // materialize() on the resident one): the LCB filter and the second chaining pass read the reference column only, and on a
+        // rearranged set of 500 genomes the rows of 23 000 LCBs are 2 x 23 MB per pass
         const Mum& b = pool[(size_t)c.mums.back()];
-        if (res_.active) {      // the reference column now, the rows with materialize()
-            c.start.assign(1, key0(c.mums.front())); c.end.assign(1, key0(c.mums.back()) + b.length);
-            lcbs.push_back(c);
-            return;
-        }
-        c.start.assign(f.start, f.start + n);
-        c.end.resize(n);
-        for (size_t k = 0; k < n; k++) c.end[k] = b.end(k);
+        c.start.assign(1, key0(c.mums.front())); c.end.assign(1, key0(c.mums.back()) + b.length);
         lcbs.push_back(c);
     };
     Lcb cluster = open_chain(mums[0]);
@@ -1734,6 +1729,23 @@ void Aligner::chain() {
     stats.lcb_s += now_s() - t0;
 }
 
+// start / end rows of the LCBs (Cluster(TMum) LCB.cpp:21-28 + the joins: the start of the first MUM, the end of the last), for the
+// list as it stands; the host route's rows live with the MUMs
+void Aligner::complete_lcbs() {
+    if (res_.active) return;      // (resident route: the rows arrive with materialize())
+    const long nl = (long)lcbs.size();
+#pragma omp parallel for schedule(dynamic, 64) num_threads(prm.cores > 0 ? prm.cores : 1) if (nl > 256)
+    for (long x = 0; x < nl; x++) {
+        Lcb& c = lcbs[(size_t)x];
+        if (c.type != 1 || c.mums.empty() || c.start.size() == n) continue;
+        const Mum& f = pool[(size_t)c.mums.front()];
+        const Mum& b = pool[(size_t)c.mums.back()];
+        c.start.assign(f.start, f.start + n);
+        c.end.resize(n);
+        for (size_t k = 0; k < n; k++) c.end[k] = b.end(k);
+    }
+}
+
 static void sort_lcbs(std::vector<Lcb>& v) {
     std::vector<Handle> h(v.size());
     for (size_t i = 0; i < v.size(); i++) h[i] = Handle{v[i].start[0], (int)i};
@@ -1754,6 +1766,7 @@ void Aligner::filter_lcbs() {
     // (the reference erases every dissolved MUM from the list and every dissolved LCB from its list one at a time, :460-470 -- quadratic
     // on a rearranged set with 20 000 short LCBs; which ones go does not depend on the order, so: marked, then both lists swept once)
     std::vector<char> dead_mum(pool.size(), 0), dead_lcb((size_t)count, 0);
+    std::vector<int> gone;
     bool any = false;
     for (long x = 0; x < count - 1; x++) {      // the last LCB is never examined (:447)
         if (lcbs[(size_t)x].length > prm.c) continue;
@@ -1761,11 +1774,16 @@ void Aligner::filter_lcbs() {
         dead_lcb[(size_t)x] = 1; any = true;
         for (int idx : lcbs[(size_t)x].mums) {
             filtered += 1;
-            const Mum& mt = pool[(size_t)idx];
-            if (res_.active) unmark.push_back(mt.row);
-            else for (size_t k = 0; k < n; k++) layout[k].clear_range(mt.start[k], mt.end(k));
+            if (res_.active) unmark.push_back(pool[(size_t)idx].row);
+            else gone.push_back(idx);
             dead_mum[(size_t)idx] = 1;
         }
+    }
+    if (!gone.empty()) {      // out of the layout (:460-466): a genome per task (its bitmap is its own)
+        const long ng = (long)n;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(prm.cores > 0 ? prm.cores : 1) if (gone.size() * n > 100000)
+        for (long k = 0; k < ng; k++)
+            for (int idx : gone) { const Mum& mt = pool[(size_t)idx]; layout[(size_t)k].clear_range(mt.start[k], mt.end((size_t)k)); }
     }
     if (any) {
         size_t w = 0;
@@ -1785,6 +1803,7 @@ void Aligner::fill_between() {
     double t0 = now_s();
     sort_lcbs(lcbs);
     if (res_.active) { resident_fill_between(); stats.lcb_s += now_s() - t0; return; }
+    complete_lcbs();
     // every pair of consecutive LCBs is looked at on its own (bitmap reads only): all threads, results kept in order
     const long npairs = (long)lcbs.size() - 1;
     std::vector<std::unique_ptr<Lcb>> made(npairs > 0 ? (size_t)npairs : 0);

@@ -319,6 +319,7 @@ public:
     void chain();
     void filter_lcbs();
     void fill_between();
+    void complete_lcbs();      // the LCBs' start / end rows in every genome (host route; chain() leaves the reference column)
 
     Region neighbour_region(const Mum& m, bool left);
     void neighbour_into(const Mum& m, bool left, Region* out) const;   // rows of *out already allocated
