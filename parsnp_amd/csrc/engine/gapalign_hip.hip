@@ -345,20 +345,25 @@ __device__ bool nw_small(Shared& S, uint8_t* TB, int la, int lb, int* plen, bool
 
 // -DPM_GAP_NO_MARKERS: the kernel without its stage markers and stage clocks (what hung once in round 3, on that round's kernel;
 // measurement builds only: `make -C parsnp_amd/csrc nomark`, scripts/gap_nomark.sh)
-#if defined(PM_GAP_NO_MARKERS)
-constexpr bool kGapMarkers = false;
+#if defined(PM_GAP_NO_MARKERS) || defined(PM_GAP_NO_STAGES)
+constexpr bool kGapStages = false;      // the (job, stage) markers of PM_GAP_DEBUG=1|2
 #else
-constexpr bool kGapMarkers = true;
+constexpr bool kGapStages = true;
 #endif
-#define GA_STAGE(stage_) do { if (kGapMarkers && P.dbg && lane == 0) P.dbg[blockIdx.x * 2 + 1] = (stage_); } while (0)
+#if defined(PM_GAP_NO_MARKERS) || defined(PM_GAP_NO_CLOCKS)
+constexpr bool kGapClocks = false;      // the stage clocks of PM_GAP_DEBUG=3
+#else
+constexpr bool kGapClocks = true;
+#endif
+#define GA_STAGE(stage_) do { if (kGapStages && P.dbg && lane == 0) P.dbg[blockIdx.x * 2 + 1] = (stage_); } while (0)
 // PM_GAP_DEBUG=3: the shader clock spent since the previous mark goes to stage k_
 // (kept in registers and added to the launch's totals once per job: a shared counter per mark would be what is measured)
-#define GA_CLOCK(k_) do { if (kGapMarkers && P.prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof_acc[(k_)] += t_ - prof_t0; prof_t0 = t_; } } while (0)
+#define GA_CLOCK(k_) do { if (kGapClocks && P.prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof_acc[(k_)] += t_ - prof_t0; prof_t0 = t_; } } while (0)
 __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, const Params& P, const Job& job, int* out_cols) {
     const int lane = (int)__lane_id();
     const int n = job.n, cap = P.cap;
     unsigned long long prof_acc[kProfStages] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long prof_t0 = (kGapMarkers && P.prof) ? (unsigned long long)clock64() : 0;
+    unsigned long long prof_t0 = (kGapClocks && P.prof) ? (unsigned long long)clock64() : 0;
     if (n < 2 || n > kMaxSeqs) return false;
     // ---- sequences: lengths, FixAlpha (seq.cpp:331-344) happens when the rows are filled
     int bad = 0, wild = 0;
@@ -608,7 +613,7 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
         else { build_profile<false>(S, R, cap, loa, nsa, la, total_a, true); build_profile<false>(S, R, cap, lob, nsb, lb, total_b, false); }
         int plen = 0;
         GA_STAGE(101 + (int)(v - un) * 10); GA_CLOCK(13);
-        if (!nw_small(S, TB, la, lb, &plen, kGapMarkers && P.prof != nullptr, prof_acc[9], prof_t0)) return false;
+        if (!nw_small(S, TB, la, lb, &plen, kGapClocks && P.prof != nullptr, prof_acc[9], prof_t0)) return false;
         GA_STAGE(102 + (int)(v - un) * 10); GA_CLOCK(10);
         if (plen > cap || plen > kMaxCols) return false;
         // aligngivenpath.cpp:124-255: a column of A, of B, or of both
@@ -691,7 +696,7 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
     }
     *out_cols = nc;
     GA_CLOCK(12);
-    if (kGapMarkers && P.prof && lane == 0) for (int k = 0; k < kProfStages; k++) if (prof_acc[k]) atomicAdd(&P.prof[k], prof_acc[k]);
+    if (kGapClocks && P.prof && lane == 0) for (int k = 0; k < kProfStages; k++) if (prof_acc[k]) atomicAdd(&P.prof[k], prof_acc[k]);
     return true;
 }
 
@@ -741,12 +746,12 @@ __global__ __launch_bounds__(64) void gap_align_kernel(Params P) {
         GA_SYNC();
         if (j >= P.njobs) break;
         const Job job = P.jobs[j];
-        if (kGapMarkers && P.dbg && threadIdx.x == 0) { P.dbg[blockIdx.x * 2] = (int32_t)j; P.dbg[blockIdx.x * 2 + 1] = 0; }
+        if (kGapStages && P.dbg && threadIdx.x == 0) { P.dbg[blockIdx.x * 2] = (int32_t)j; P.dbg[blockIdx.x * 2 + 1] = 0; }
         int cols = -1;
         if (!align_job(S, rows_lds, tb_lds, W, P, job, &cols)) cols = -1;
         GA_SYNC();
         if (threadIdx.x == 0) P.out_cols[j] = cols;
-        if (kGapMarkers && P.dbg && threadIdx.x == 0) P.dbg[blockIdx.x * 2 + 1] = -1;
+        if (kGapStages && P.dbg && threadIdx.x == 0) P.dbg[blockIdx.x * 2 + 1] = -1;
     }
 }
 
