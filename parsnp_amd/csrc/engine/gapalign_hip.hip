@@ -104,7 +104,16 @@ constexpr uint8_t kRowGap = 16, kRowCode = 0x1f, kRowStart = 0x40, kRowEnd = 0x8
 __device__ inline bool row_gap(uint8_t b) { return (b & kRowCode) == kRowGap; }
 __device__ inline uint8_t row_char(uint8_t b) { const uint8_t c = b & kRowCode; return c == kRowGap ? (uint8_t)'-' : (uint8_t)"ACGTMRWSYKVHDBXN"[c]; }
 
-__device__ inline int wave_sum(int x) { for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64); return x; }
+// A value that every lane of the wavefront holds alike -- the job number, a length read from one address, the result of a reduction
+// -- said so: it moves to a scalar register, and the branches and loop bounds that depend on it become SCALAR branches.  Without this
+// the compiler must take every `return false` and every loop exit of a job for divergent (it cannot see that a butterfly sum or an
+// LDS word is the same in all lanes), structures the job loop as nested exec-mask loops in which "returned" lanes wait for the
+// others, and a build without the stage markers hung in that structure on the device (round 3, reproduced in round 5:
+// scripts/gap_nomark.sh; the markers' branches happened to break it up).  Uniform by construction; said so, it is also cheaper.
+__device__ inline int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ inline unsigned uni(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ inline float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ inline int wave_sum(int x) { for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64); return uni(x); }
 // arg-min over (value, index): strictly smaller value wins, equal values -> the lower index (a sequential scan that
 // replaces its best only on `<` keeps the first one it met)
 __device__ inline void wave_argmin(float& v, unsigned& i) {
@@ -112,6 +121,7 @@ __device__ inline void wave_argmin(float& v, unsigned& i) {
         const float ov = __shfl_xor(v, d, 64); const unsigned oi = (unsigned)__shfl_xor((int)i, d, 64);
         if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
     }
+    v = uni(v); i = uni(i);
 }
 
 // LDS of the one wavefront of a workgroup, used phase after phase (the alignment rows themselves -- n rows of `cap`
@@ -336,7 +346,7 @@ __device__ bool nw_small(Shared& S, uint8_t* TB, int la, int lb, int* plen, bool
         S.flag = ok ? n : -1;
     }
     GA_SYNC();
-    const int n = S.flag;
+    const int n = uni(S.flag);
     for (int x = lane; x < n; x += 64) S.p.path[x] = S.p.rev[n - 1 - x];
     GA_SYNC();
     *plen = n;
@@ -355,10 +365,27 @@ constexpr bool kGapClocks = false;      // the stage clocks of PM_GAP_DEBUG=3
 #else
 constexpr bool kGapClocks = true;
 #endif
-#define GA_STAGE(stage_) do { if (kGapStages && P.dbg && lane == 0) P.dbg[blockIdx.x * 2 + 1] = (stage_); } while (0)
+// (-DPM_GAP_STRIP_STAGE=s: ONE marker compiled out -- s = 1 ... 7 the stages, 100 the three markers of the merge loop, 900 the job
+// markers of the kernel's loop: which marker's absence the hang of the marker-free build needs, scripts/gap_nomark.sh)
+#if !defined(PM_GAP_STRIP_STAGE)
+#define PM_GAP_STRIP_STAGE (-1)
+#endif
+constexpr bool ga_stage_on(int s) { return kGapStages && !(PM_GAP_STRIP_STAGE == s || (PM_GAP_STRIP_STAGE == 100 && s >= 100 && s < 900)); }
+#define GA_STAGE(stage_) do { if (ga_stage_on(stage_) && P.dbg && lane == 0) P.dbg[blockIdx.x * 2 + 1] = (stage_); } while (0)
+#define GA_STAGE_DYN(stage_) do { if (P.dbg && lane == 0) P.dbg[blockIdx.x * 2 + 1] = (stage_); } while (0)
 // PM_GAP_DEBUG=3: the shader clock spent since the previous mark goes to stage k_
 // (kept in registers and added to the launch's totals once per job: a shared counter per mark would be what is measured)
 #define GA_CLOCK(k_) do { if (kGapClocks && P.prof) { const unsigned long long t_ = (unsigned long long)clock64(); prof_acc[(k_)] += t_ - prof_t0; prof_t0 = t_; } } while (0)
+// NOT inlined into the kernel's job loop, on purpose.  Inlined, hipcc (ROCm 7.2) structures the loop and this function's early
+// returns into an exec-mask loop whose exit mask is `threadIdx.x == 0` (the condition of the job fetch and of the result store around
+// the call): lane 0 leaves it, lanes 1-63 go round the job body again and never leave -- the kernel hangs on the first batch of more
+// than one job.  The (job, stage) markers of PM_GAP_DEBUG happened to break that structure up, which is why only a build WITHOUT them
+// hung (round 3; reproduced, bisected to the two job markers of the kernel's loop and read off the ISA in round 5: DESIGN.md 9-6,
+// scripts/gap_nomark.sh).  As a call the job is one node of the loop's control flow; -DPM_GAP_INLINE restores the old shape for the
+// regression check.  tests/test_gpu_gapalign.py::test_marker_free_build runs the marker-free build.
+#if !defined(PM_GAP_INLINE)
+__attribute__((noinline))
+#endif
 __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, const Params& P, const Job& job, int* out_cols) {
     const int lane = (int)__lane_id();
     const int n = job.n, cap = P.cap;
@@ -414,7 +441,7 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
     // ---- per distinct string: its distinct 6-mers with 8-bit (wrapping) multiplicities (fastdistnuc.cpp:82-90)
     // (the count table is all zero here: the kernel clears it once per slot, and every use below clears what it set)
     for (int a = 0; a < u; a++) {
-        const int i = W.replist[a], L = W.len[i];
+        const int i = uni(W.replist[a]), L = uni(W.len[i]);
         int nt = 0;
         if (L >= 6) {
             for (int p = lane; p < L; p += 64) {
@@ -445,11 +472,11 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
     }
     GA_SYNC();
     for (int a = 0; a < u; a++) {
-        const int na = W.ntup[a];
+        const int na = uni(W.ntup[a]);
         for (int t = lane; t < na; t += 64) W.table[W.tcode[(size_t)a * kMaxCols + t]] = W.tcnt[(size_t)a * kMaxCols + t];
         GA_SYNC();
         for (int b = 0; b <= a; b++) {
-            const int nb = W.ntup[b];
+            const int nb = uni(W.ntup[b]);
             int sum = 0;
             for (int t = lane; t < nb; t += 64) {
                 const uint8_t c1 = W.table[W.tcode[(size_t)b * kMaxCols + t]], c2 = W.tcnt[(size_t)b * kMaxCols + t];
@@ -504,7 +531,7 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
         }
         wave_argmin(best, lmin);
         if (lmin == kNone) return false;
-        const unsigned rmin = S.t.nearest[lmin];
+        const unsigned rmin = uni(S.t.nearest[lmin]);
         if (rmin == kNone || rmin >= un) return false;
         // the distances of this step are requested together (two per cluster and lane, plus the pair's own): one round
         // trip to the workspace per merge instead of one per 64 clusters
@@ -600,21 +627,21 @@ __device__ bool align_job(Shared& S, uint8_t* R, uint8_t* TB, const Slot& W, con
       const unsigned vend = v0 + 64 < nodes ? v0 + 64 : nodes;
       for (unsigned v = v0; v < vend; v++) {
         const int k = (int)(v - v0);
-        const unsigned a = (unsigned)__shfl((int)my_a, k, 64), b = (unsigned)__shfl((int)my_b, k, 64);
-        const int loa = __shfl(my_loa, k, 64), nsa = __shfl(my_nsa, k, 64), lob = __shfl(my_lob, k, 64), nsb = __shfl(my_nsb, k, 64);
-        const int la = a < un ? (int)S.rowlen[loa] : (int)S.ncols_i[a - un];
-        const int lb = b < un ? (int)S.rowlen[lob] : (int)S.ncols_i[b - un];
+        const unsigned a = uni((unsigned)__shfl((int)my_a, k, 64)), b = uni((unsigned)__shfl((int)my_b, k, 64));
+        const int loa = uni(__shfl(my_loa, k, 64)), nsa = uni(__shfl(my_nsa, k, 64)), lob = uni(__shfl(my_lob, k, 64)), nsb = uni(__shfl(my_nsb, k, 64));
+        const int la = uni(a < un ? (int)S.rowlen[loa] : (int)S.ncols_i[a - un]);
+        const int lb = uni(b < un ? (int)S.rowlen[lob] : (int)S.ncols_i[b - un]);
         const float total_a = a < un ? 0.0f + S.wrow[loa] : S.total_i[a - un];
         const float total_b = b < un ? 0.0f + S.wrow[lob] : S.total_i[b - un];
         if (la <= 0 || lb <= 0 || la > kMaxCols || lb > kMaxCols) return false;
-        GA_STAGE(100 + (int)(v - un) * 10);
+        if (ga_stage_on(100)) GA_STAGE_DYN(100 + (int)(v - un) * 10);
         GA_CLOCK(8);
         if (any_wild) { build_profile<true>(S, R, cap, loa, nsa, la, total_a, true); build_profile<true>(S, R, cap, lob, nsb, lb, total_b, false); }
         else { build_profile<false>(S, R, cap, loa, nsa, la, total_a, true); build_profile<false>(S, R, cap, lob, nsb, lb, total_b, false); }
         int plen = 0;
-        GA_STAGE(101 + (int)(v - un) * 10); GA_CLOCK(13);
+        if (ga_stage_on(100)) GA_STAGE_DYN(101 + (int)(v - un) * 10); GA_CLOCK(13);
         if (!nw_small(S, TB, la, lb, &plen, kGapClocks && P.prof != nullptr, prof_acc[9], prof_t0)) return false;
-        GA_STAGE(102 + (int)(v - un) * 10); GA_CLOCK(10);
+        if (ga_stage_on(100)) GA_STAGE_DYN(102 + (int)(v - un) * 10); GA_CLOCK(10);
         if (plen > cap || plen > kMaxCols) return false;
         // aligngivenpath.cpp:124-255: a column of A, of B, or of both
         // (a column's place in A / in B = the number of A / B columns before it: counted with ballots)
@@ -742,16 +769,16 @@ __global__ __launch_bounds__(64) void gap_align_kernel(Params P) {
     for (;;) {
         if (threadIdx.x == 0) S.flag = (int32_t)atomicAdd(P.next, 1ull);
         GA_SYNC();
-        const int64_t j = S.flag;
+        const int64_t j = uni(S.flag);
         GA_SYNC();
         if (j >= P.njobs) break;
         const Job job = P.jobs[j];
-        if (kGapStages && P.dbg && threadIdx.x == 0) { P.dbg[blockIdx.x * 2] = (int32_t)j; P.dbg[blockIdx.x * 2 + 1] = 0; }
+        if (ga_stage_on(900) && P.dbg && threadIdx.x == 0) { P.dbg[blockIdx.x * 2] = (int32_t)j; P.dbg[blockIdx.x * 2 + 1] = 0; }
         int cols = -1;
         if (!align_job(S, rows_lds, tb_lds, W, P, job, &cols)) cols = -1;
         GA_SYNC();
         if (threadIdx.x == 0) P.out_cols[j] = cols;
-        if (kGapStages && P.dbg && threadIdx.x == 0) P.dbg[blockIdx.x * 2 + 1] = -1;
+        if (ga_stage_on(900) && P.dbg && threadIdx.x == 0) P.dbg[blockIdx.x * 2 + 1] = -1;
     }
 }
 

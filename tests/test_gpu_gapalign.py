@@ -165,3 +165,23 @@ def test_groups_report_in_order_and_match_the_batch(device):
     assert seen == [(0, True), (1, True), (2, True), (3, True)]
     assert [rows_of(j) for j in range(len(blks))] == want
     assert all(w is None for w in want[100:103]) and sum(w is not None for w in want) > 200
+
+
+def test_marker_free_build():
+    """The gap kernel WITHOUT its (job, stage) markers and stage clocks (parsnp_amd/lib/exp/libparsnp_hip_no_MARKERS.so, built by
+    csrc/Makefile: -DPM_GAP_NO_MARKERS).  Until round 5 such a build hung on the device on the first batch of more than one job: with
+    align_job inlined into the kernel's job loop the compiler produced an exec-mask loop that only lane 0 ever left, and the markers'
+    branches happened to break it up (gapalign_hip.hip: align_job).  The committed vectors, fresh seeded sets and a
+    batch of many small jobs through that build, in a child process under a watchdog: a hang is a red test, not a stuck suite."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "parsnp_amd", "lib", "exp", "libparsnp_hip_no_MARKERS.so")
+    assert os.path.exists(lib), "the marker-free build is part of `make -C parsnp_amd/csrc` (python -c 'import __graft_entry__ as g; g.build()')"
+    env = dict(os.environ, PARSNP_HIP_LIB=lib)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k",
+                        "committed_vectors or fresh_sets_against_host or many_sequences or declines or groups_report"],
+                       capture_output=True, text=True, env=env, timeout=240, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-1000:]
+    # growing batches -- 50 small jobs was where the inlined shape hung --, every step under the probe's own 20-s watchdog
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gap_probe.py")], capture_output=True, text=True, env=env, timeout=200, cwd=ROOT)
+    assert q.returncode == 0 and "STUCK" not in q.stdout and "2000 x 201 alleles" in q.stdout, q.stdout[-1500:] + q.stderr[-1500:]
