@@ -224,7 +224,7 @@ def main():
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="a tunable of the engine session (pm_session_tune: group_small=0, ...) for before/after measurements; named in config.tune")
     ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"],
-                    help="ms per step of BASELINE's other single-GPU configurations (viral50 = config 2, rearr500 = config 5) in the line's "
+                    help="ms per step of BASELINE's other single-GPU configurations (viral50 = config 2, rearr500 = config 5) and of config 3 with ten inverted segments (bact200inv) in the line's "
                          "`other_configs`, each measured by a child run of this script; auto = on for the default workload at N = 1")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
@@ -559,7 +559,7 @@ def main():
             want_other = args.other_configs == "on" or (args.other_configs == "auto" and args.workload == "bact200" and not args.genomes and world == 1 and not args.inputs)
             if want_other:
                 other = {}
-                for wl, st in (("viral50", 20), ("rearr500", 3)):
+                for wl, st in (("viral50", 20), ("bact200inv", 20), ("rearr500", 3)):
                     cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", str(st), "--warmup", "1", "--cpu-sample", "0", "--other-configs", "off",
                            "--host-threads", str(args.host_threads)]
                     try:

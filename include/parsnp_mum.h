@@ -135,8 +135,10 @@ int64_t pm_result_table_id(const pm_result* r);
  *                  256 times as much, then PM_ELIMIT)
  *   "dirty_min"    shortest one-region candidate list that gets the overlap / order flags and stays on the device as the
  *                  anchor table (default 4096)
- *   "flagged_div"  pm_store_settle answers PM_EAGAIN when more than one row in flagged_div of the anchor table overlaps an
- *                  earlier one (default 8, the host route's own threshold for its exact overlap test)
+ *   "flagged_div"  pm_store_settle takes an anchor table of which at most one row in flagged_div is flagged (overlaps an earlier
+ *                  one by the cheap running-extent test: default 8) as it is; above three rows in four it answers PM_EAGAIN;
+ *                  in between it counts the TANGLED rows (flagged rows that overlap one another: settled in list order by one
+ *                  wavefront) and answers PM_EAGAIN with more than "tangled_max" of them (default 2048).  1: never PM_EAGAIN (tests)
  *   "atomic_marks" != 0: pm_store_settle marks the layout with atomic ORs even where the list's order allows plain stores (tests)
  *   "group_small"  0: the events of a recursion batch's small regions are found pair by pair and sorted with the others, instead of
  *                  once per distinct query piece (default 1; both give the same events, tests compare the two)
@@ -175,8 +177,9 @@ typedef struct { int64_t key, ref_start, ref_len; int32_t slength, parent; } pm_
 int64_t pm_result_store_base(const pm_result* r);      /* first store row of a result whose rows stayed resident, else -1 */
 /* setMums1, second half, for the anchor table `table_id` into an EMPTY layout (:1781-1841): rows that overlap nothing earlier
  * are settled and marked at once; the flagged ones (PM_ROW_DIRTY) are trimmed against those marks (Aligner::trim) -- side by
- * side where they meet no other flagged row, in list order where they do.  rows[c] for every row of the table.  PM_EAGAIN when
- * more than one row in eight is flagged (rearranged genomes: the exact overlap test of the host route decides). */
+ * side where they meet no other flagged row, in list order where they do.  rows[c] for every row of the table.  PM_EAGAIN for a
+ * heavily rearranged set (more than three rows in four flagged, or -- above one in eight -- more than 2048 tangled ones: the
+ * exact overlap test and the threads of the host route decide; a population with a few inversions is taken). */
 int pm_store_settle(pm_session* s, int64_t table_id, pm_row_info* rows);
 int pm_store_info(pm_session* s, int64_t first, int64_t count, pm_row_info* out);
 /* setInitialClusters' seed regions (:2150-2172): determineRegion on both sides of every accepted anchor (anchors[]: their store

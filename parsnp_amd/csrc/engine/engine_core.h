@@ -727,7 +727,15 @@ public:
         const int64_t rows = anchor_table_rows;
         std::vector<int32_t> fl;
         for (int64_t c = 0; c < rows; c++) { const uint32_t f = anchor_flags_h[(size_t)c]; if (!(f & (kRowBad | kRowOutside)) && (f & kRowDirty)) fl.push_back((int32_t)c); }
-        if (fl.size() * (size_t)flagged_div > (size_t)rows) { error = "too many rows of the list overlap an earlier one (rearranged genomes): the host route decides"; return kAgain; }
+        // The cheap running-extent test flags every row of an inverted or moved block, whether it overlaps anything or not: a
+        // population with a few inversions has a third of its rows flagged and a handful tangled, a set with 10 % of every one of its
+        // 50 genomes rearranged has all of them flagged and thousands tangled.  The flagged rows that meet no other flagged row cost a
+        // wavefront each, side by side; the TANGLED ones are what one wavefront settles in list order.  So: up to one row in
+        // flagged_div flagged -- every population sample -- the list is taken as it is; above three in four it is declined outright
+        // (the host route's exact overlap test and threads); in between, the tangled rows are counted once the collision test has run
+        // (one 8-byte read-back) and the list is declined if there are more than tangled_max.  flagged_div = 1: never declined (tests).
+        const bool many_flagged = flagged_div > 1 && fl.size() * (size_t)flagged_div > (size_t)rows;
+        if (many_flagged && fl.size() * 4 > (size_t)rows * 3) { error = "too many rows of the list overlap an earlier one (rearranged genomes): the host route decides"; return kAgain; }
         const size_t words = layout_geometry();
         ensure(d_image, words);
         // do the rows that can be accepted untrimmed lie in list order in every genome (none starts before the end of an earlier
@@ -750,6 +758,19 @@ public:
             be.launch("collide_mark", (int64_t)fl.size() * ngen, CollideMark{S, d_list.p, layout_view(d_once.p), d_twice.p});
             be.launch_wave("collide_test", (int64_t)fl.size(), CollideTest{S, d_list.p, layout_view(d_twice.p, false)});
             be.launch("collide_clear", (int64_t)fl.size() * ngen, CollideClear{S, d_list.p, layout_view(d_once.p), d_twice.p});
+            if (many_flagged) {
+                ensure(d_rg_count, 4);
+                be.memset(d_rg_count.p, 0, 8);
+                be.launch("count_tangled", (int64_t)fl.size(), CountTangled{S, d_list.p, d_rg_count.p});
+                uint64_t tangled = 0;
+                be.d2h(&tangled, d_rg_count.p, 8);
+                if ((int64_t)tangled > tangled_max) {
+                    be.mark(nullptr);
+                    collect_timing_more();
+                    error = "too many rows of the list overlap one another (rearranged genomes): the host route decides";
+                    return kAgain;
+                }
+            }
             be.launch_wave("settle_flagged", (int64_t)fl.size(), SettleFlagged{S, layout_view(d_image.p, false), P, d_list.p});
             be.launch_wave("settle_tangled", 1, SettleTangled{S, L, P, d_list.p, (int64_t)fl.size()});
         }
@@ -1154,7 +1175,8 @@ public:
     // that gets the device overlap test and stays resident as the anchor table (the host's threshold for its long-list routes)
     int64_t work_budget = 1 << 22;
     int64_t dirty_min = 4096;
-    int64_t flagged_div = 8;      // store_settle: PM_EAGAIN when more than one row in flagged_div overlaps an earlier one
+    int64_t flagged_div = 8;      // store_settle: above one flagged row in flagged_div the tangled rows are counted before the list is taken (1: never declined)
+    int64_t tangled_max = 2048;   // ... and the list declined (PM_EAGAIN) with more tangled rows than this (one wavefront settles them in list order, ~13 us each)
     bool group_small = true;      // the events of a recursion batch's small regions once per distinct piece (GroupedPairEvents)
     int64_t last_grouped = 0;
     bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
@@ -1164,6 +1186,7 @@ public:
     bool phase_timing = true;             // HIP events around the phases of a call (pm_last_timing); off: the marks cost nothing
     bool tune(const std::string& key, int64_t value) {
         if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
+        if (key == "tangled_max" && value >= 0) { tangled_max = value; return true; }
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
         if (key == "master_seg") { master_seg = value != 0; return true; }
         if (key == "stage_gate") { force_gate = value != 0; return true; }

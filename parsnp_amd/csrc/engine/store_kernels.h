@@ -443,6 +443,11 @@ struct CollideTest {
         if (wave_or_u32(hit) && wave_leader()) S.state[c] |= kStTangled;
     }
 };
+// tid = flagged index: how many of the flagged rows are tangled (store_settle's second look at a list with many flagged rows)
+struct CountTangled {
+    Store S; const int32_t* list; uint64_t* count;
+    PM_HD void operator()(int64_t i) const { if (S.state[list[i]] & kStTangled) atomic_add64(count, 1); }
+};
 // tid = (flagged index, genome): the two scratch images back to all zero -- the words under the flagged rows' ranges are the
 // only ones that were written (clearing 2 x 126 MB per step for 850 rows' worth of bits costs 0.3 ms)
 struct CollideClear {

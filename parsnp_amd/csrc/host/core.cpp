@@ -113,6 +113,7 @@ int CoreRun::open(const std::string& ini_path) {
     if (const char* v = test_hook("PM_DIRTY_MIN")) (void)pm_session_tune(session, "dirty_min", atol(v));
     if (const char* v = test_hook("PM_WORK_BUDGET")) (void)pm_session_tune(session, "work_budget", atol(v));
     if (const char* v = test_hook("PM_FLAGGED_DIV")) (void)pm_session_tune(session, "flagged_div", atol(v));
+    if (const char* v = test_hook("PM_TANGLED_MAX")) (void)pm_session_tune(session, "tangled_max", atol(v));
     if (const char* v = test_hook("PM_ATOMIC_MARKS")) (void)pm_session_tune(session, "atomic_marks", atol(v));
     if (const char* v = test_hook("PM_GROUP_SMALL")) (void)pm_session_tune(session, "group_small", atol(v));
     if (const char* v = test_hook("PM_MASTER_SEG")) (void)pm_session_tune(session, "master_seg", atol(v));

@@ -108,6 +108,21 @@ def pop_rearranged(seed, n, n_genomes, div, indel_frac=0.05, frac=0.10, block=20
     return ref, out
 
 
+def pop_inverted(seed, n, n_genomes, div, indel_frac=0.05, inv_every=20, inv_len=200_000, carry_seed=None):
+    """population model + ONE clean inversion of inv_len bases in every inv_every-th genome, each at its own place: what a bacterial
+    population looks like to the anchor validation -- collinear but for a few inverted segments, whose anchor candidates the cheap
+    running-extent test flags (they lie out of order in that genome) although hardly any of them overlaps anything."""
+    ref, gs = population(seed, n, n_genomes, div, indel_frac, carry_seed=carry_seed)
+    rng = np.random.default_rng(seed + 104729 if carry_seed is None else carry_seed + 104729)
+    out = []
+    for i, s in enumerate(gs):
+        if i % inv_every == inv_every - 1 and len(s) > 2 * inv_len:
+            a = int(rng.integers(0, len(s) - inv_len))
+            s = s[:a] + s[a:a + inv_len].translate(_COMP)[::-1] + s[a + inv_len:]
+        out.append(s)
+    return ref, out
+
+
 def write_multicontig(path, name, seq: bytes, cuts, width=80, crlf=False, lower=False):
     """FASTA with one record per contig (cuts = interior cut positions)"""
     nl = b"\r\n" if crlf else b"\n"
@@ -194,6 +209,9 @@ CONFIGS = {
     "pop12x400k": ("population", dict(seed=21, n=400_000, n_genomes=12, div=0.03, indel_frac=0.10)),
     "rearr500": ("pop_rearranged", dict(seed=13, n=5_000_000, n_genomes=500, div=0.05, frac=0.10)),
     "rearr50": ("pop_rearranged", dict(seed=13, n=5_000_000, n_genomes=50, div=0.05, frac=0.10)),   # = the first 50 genomes of rearr500
+    # config 3 with an inverted 200-kb segment in every 20th genome (10 of 200): a third of the anchor candidates flagged, a few tangled
+    "bact200inv": ("pop_inverted", dict(seed=5, n=5_000_000, n_genomes=200, div=0.02, indel_frac=0.05, inv_every=20, inv_len=200_000)),
+    "popinv12x400k": ("pop_inverted", dict(seed=31, n=400_000, n_genomes=12, div=0.02, indel_frac=0.05, inv_every=5, inv_len=30_000)),   # 2 of 12 genomes inverted: the reduced form, with a golden
     "bact2000": ("population", dict(seed=6, n=5_000_000, n_genomes=2000, div=0.02, indel_frac=0.05)),
     "poprearr10x400k": ("pop_rearranged", dict(seed=13, n=400_000, n_genomes=10, div=0.05, frac=0.10)),
 }
@@ -221,7 +239,7 @@ def make_partition(part=0, **override):
 def make(name, **override):
     model, kw = CONFIGS[name]
     kw = dict(kw, **override)
-    return {"population": population, "musclefree": musclefree, "rearranged": rearranged, "pop_rearranged": pop_rearranged}[model](**kw)
+    return {"population": population, "musclefree": musclefree, "rearranged": rearranged, "pop_rearranged": pop_rearranged, "pop_inverted": pop_inverted}[model](**kw)
 
 
 def messy_set(outdir, seed=23, n=150_000, n_genomes=6):

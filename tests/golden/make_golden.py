@@ -68,7 +68,7 @@ def e2e_goldens(tmp, mref, mqs, only=None, e2e=None):
         return make
     # file names matter (##SequenceFile): MERS under its own names, synthetic sets as ref.fna / g%04d.fna
     run("mers", lambda: (mref, mqs))
-    for name in ("viral50", "pop6x200k", "rearr6x300k", "pop12x400k", "pop20x1m", "bact8", "poprearr10x400k"):   # bact8 takes ~80 s
+    for name in ("viral50", "pop6x200k", "rearr6x300k", "pop12x400k", "pop20x1m", "bact8", "poprearr10x400k", "popinv12x400k"):   # bact8 takes ~80 s
         run(name, synthetic(name))
     run("messy", lambda: synth.messy_set(os.path.join(tmp, "messy")))
     run("pchunk", synthetic("pop6x200k", "pchunk"), partpos=66660)      # 3 reference chunks + the <50 bp tail rule (src/parsnp.cpp:1527-1538)

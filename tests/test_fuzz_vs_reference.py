@@ -109,6 +109,48 @@ def test_fuzz_resident_route(emu, tmp_path, monkeypatch, seed):
     assert a == b, (seed, kw, contigs)
 
 
+def inversion_case():
+    """a population with three clean inversions (20 kb in genome 2, 30 kb in genome 4, 5 kb in genome 5): the cheap running-extent
+    test flags every anchor candidate inside an inverted block (a third of the list), hardly any of them overlaps anything"""
+    ref, gs = synth.population(seed=77, n=150_000, n_genomes=6, div=0.01, indel_frac=0.0)
+    gs = [bytearray(g) for g in gs]
+    for k, (a, b) in ((1, (40000, 60000)), (3, (90000, 120000)), (4, (20000, 25000))):
+        gs[k][a:b] = oracles.revcomp(bytes(gs[k][a:b]))
+    return ref, [bytes(g) for g in gs]
+
+
+def inversions_on_the_resident_route(core, tmp_path, monkeypatch, variant):
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PARSNP_RESIDENT_LOG=str(tmp_path / "route.log")).items():
+        monkeypatch.setenv(k, v)
+    if variant == "tangled_limit":
+        monkeypatch.setenv("PM_TANGLED_MAX", "0")
+    ref, gs = inversion_case()
+    rp, qs = synth.write_set(str(tmp_path / "in"), ref, gs)
+    a = run(REFBIN, rp, qs, str(tmp_path / "ref"), dict(threads=3))
+    b = run(core, rp, qs, str(tmp_path / "mine"), dict(threads=3))
+    assert a == b
+    x = open(str(tmp_path / "mine" / "parsnpAligner.xmfa")).read()
+    assert sum(1 for l in x.splitlines() if l.startswith(">") and " - " in l) >= 3      # reverse-strand LCB records: the inversions are aligned
+    route = open(str(tmp_path / "route.log")).read()
+    if variant == "taken":      # more than one row in eight flagged, a handful tangled: taken; reverse pairs judged by ChainJudge's ordered loop
+        assert "resident=1" in route and "chain=1" in route and "retry=0" in route, route
+    else:                       # the tangled rows counted after the collision test, over the limit: declined there, the host route from the same result
+        assert "resident=0" in route and "overlap" in route, route
+
+
+@pytest.mark.parametrize("variant", ["taken", "tangled_limit"])
+def test_inversions_on_the_resident_route(emu, tmp_path, monkeypatch, variant):
+    """the anchor list of a population with a few inversions stays on the device (round 5: the list is declined by its TANGLED rows,
+    counted on the device, not by the rows the cheap test flags), reverse-strand members and all: the reference binary's bytes"""
+    inversions_on_the_resident_route(emu[1], tmp_path, monkeypatch, variant)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["taken", "tangled_limit"])
+def test_inversions_on_the_resident_route_on_gpu(tmp_path, monkeypatch, variant):
+    inversions_on_the_resident_route(CORE_HOOKS_BIN, tmp_path, monkeypatch, variant)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_host_route_over_device_rows(emu, tmp_path, monkeypatch, seed):
     """the same side by side for the HOST route over the kernel emulation (PARSNP_NO_RESIDENT: what a step falls back to),

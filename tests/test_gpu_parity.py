@@ -180,7 +180,7 @@ def test_properties_at_scale(libs):
     print("timing", timing)
 
 
-@pytest.mark.parametrize("name,genomes", [("bact200", 40), ("rearr500", 24)])
+@pytest.mark.parametrize("name,genomes", [("bact200", 40), ("rearr500", 24), ("bact200inv", 40)])
 def test_xmfa_consistency_at_scale(libs, tmp_path, name, genomes):
     """BASELINE-size genomes (5 Mb; config 3 shape and config 5 shape with fewer genomes), whole run with 8 host threads:
     size-independent properties of the XMFA -- rows of an LCB have one length, MUM columns are gap-free and identical in
@@ -188,7 +188,9 @@ def test_xmfa_consistency_at_scale(libs, tmp_path, name, genomes):
     run-to-run determinism."""
     model, kw = synth.CONFIGS[name]
     kw = dict(kw, n_genomes=genomes)
-    ref, gs = {"population": synth.population, "pop_rearranged": synth.pop_rearranged}[model](**kw)
+    if name == "bact200inv":
+        kw["inv_every"] = 8      # 5 of the 40 genomes carry their inversion
+    ref, gs = {"population": synth.population, "pop_rearranged": synth.pop_rearranged, "pop_inverted": synth.pop_inverted}[model](**kw)
     rp, qs = synth.write_set(str(tmp_path / "in"), ref, gs)
     sums = []
     for rep in range(2):
@@ -217,7 +219,7 @@ def test_parsnp_core_mers(libs, tmp_path):
     test_host_logic.check(CORE_BIN, "mers", ref, qs, str(tmp_path / "out"))
 
 
-@pytest.mark.parametrize("name", ["viral50", "pop6x200k", "rearr6x300k", "pop20x1m", "bact8"])
+@pytest.mark.parametrize("name", ["viral50", "pop6x200k", "rearr6x300k", "pop20x1m", "bact8", "popinv12x400k"])
 def test_parsnp_core_synthetic(libs, tmp_path, name):
     r, gs = synth.make(name)
     rp, qs = synth.write_set(str(tmp_path / "in"), r, gs)
@@ -273,7 +275,7 @@ def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
 
 
-@pytest.mark.parametrize("name,flagged_div,expect", [("viral50", 8, "resident"), ("pop6x200k", 8, "resident"), ("pop12x400k", 8, "resident"), ("pop12x400k", 1, "resident"), ("pop20x1m", 8, "resident"),
+@pytest.mark.parametrize("name,flagged_div,expect", [("viral50", 8, "resident"), ("pop6x200k", 8, "resident"), ("pop12x400k", 8, "resident"), ("pop12x400k", 1, "resident"), ("popinv12x400k", 8, "resident"), ("pop20x1m", 8, "resident"),
                                                       ("bact8", 8, "resident"), ("rearr6x300k", 8, "host"), ("rearr6x300k", 1, "left"), ("poprearr10x400k", 1, "left"), ("messy", 8, "left"), ("pchunk", 8, "host")])
 def test_parsnp_core_resident_route(libs, tmp_path, name, flagged_div, expect):
     """The resident route on the device (store_kernels.h through pm_store_*): the reference's bytes where it is taken, where the

@@ -38,7 +38,7 @@ def test_synthetic(cpu_checkers, tmp_path, name):
     check(cpu_checkers, name, rp, qs, str(tmp_path / "out"))
 
 
-@pytest.mark.parametrize("name", ["pop6x200k", "rearr6x300k", "poprearr10x400k"])
+@pytest.mark.parametrize("name", ["pop6x200k", "rearr6x300k", "poprearr10x400k", "popinv12x400k"])
 def test_xmfa_self_consistency(cpu_checkers, tmp_path, name):
     """the size-independent XMFA properties used at full size on the GPU (tests/xmfa_util.consistency), here on sets whose
     bytes are also pinned by goldens: equal row lengths, clean MUM columns, every record spells its genome interval"""
