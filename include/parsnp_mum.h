@@ -201,8 +201,10 @@ int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsiz
  * the layout and marked (setMums1 second half), the neighbour regions of every new MUM longer than q appended to the region
  * store (:215-254; pm_store_new_regions lists them parent by parent, in push order; one equal to a region still waiting in its
  * cluster is dropped as the work list would, :294-306).  *trouble != 0: the reference's order would show -- bit 0 (1): a child sorts
- * before a region still waiting in its cluster; bit 1 (2): a reverse-strand member outside its region; bit 2 (4): a region with
- * 2^22 candidates or more; bit 3 (8): the clusters are not disjoint in some genome.  The caller clusters on the reference only;
+ * before a region still waiting in its cluster; bit 1 (2): a reverse-strand member outside its region (TMum.cpp:33-35 flips it
+ * against the whole genome) was accepted there; bit 2 (4): a region with 2^22 candidates or more, or more candidates with a member
+ * outside their region (or one longer than 64 bases) than the engine notes for pm_store_order_check; bit 3 (8): the clusters are
+ * not disjoint in some genome.  The caller clusters on the reference only;
  * disjointness in the query genomes is checked by the call itself (clusters in reference order must follow each other, with a
  * base between, in every genome).  On trouble the caller must discard the run and take the host route.
  * info_count > 0: the per-row scalars (pm_store_info) of store rows [info_first, info_first + info_count) -- the candidates
@@ -210,10 +212,21 @@ int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsiz
  * stage_first > 0: TWO generations in one call.  Clusters [0, stage_first) are validated first (the first pushed seed, which the
  * reference processes before its work list is ever sorted, :194-195 before :291-292); clusters [stage_first, n_clusters) -- the
  * generation the caller formed on the assumption that the first stage pushes no child region -- are validated behind them if
- * that held (*second_stage_ran = 1) and are left untouched if not (0: the caller forms the generation again, with the children). */
+ * that held (*second_stage_ran = 1) and are left untouched if not (0: the caller forms the generation again, with the children).
+ * generation: the number of the (first) generation of the call, 0 = the first pushed seed alone; with the regions' reference
+ * starts it orders the regions as the reference's work list does (pm_store_order_check). */
 int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions,
                       const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children,
-                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran);
+                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran, int32_t generation);
+/* After the LAST generation.  A candidate with a reverse-strand member outside its region reads layout marks in another
+ * cluster's territory, and what is marked there when the reference looks depends on its order (doWork :173-317: the first pushed
+ * seed, then always the waiting region with the smallest reference start).  pm_store_validate notes every such candidate with
+ * the marks it saw; this call decides each of them again with the marks the reference's order had in place -- the anchors' and
+ * those of the recursion's MUMs whose region comes earlier in that order -- and reports *trouble != 0 when a verdict, a shift or
+ * a length differs from what the generations stored: the caller must discard the run and take the host route.
+ * pm_store_chain_begin runs the same check ahead of phases C-D (bit 2 of pm_chain_info.trouble): a caller that queues them
+ * does not call this. */
+int pm_store_order_check(pm_session* s, uint32_t* trouble);
 /* The test of setFinalClusters (:2596-2700) of MUM cur[i] against the open chain's last MUM back[i]: verdict[i] = 0 every
  * genome's gap lies in [0, d] (min_gap / max_gap: what the ratio test :2693 reads), 1 the chain closes, 2 a reverse-strand
  * member (the strand rules of :2604-2625 depend on the genome order): the caller judges the pair from its rows. */
@@ -235,7 +248,8 @@ const int64_t* pm_store_fill_ends(const pm_session* s);
  * for it: n_mums store rows in reference order (rows), a flag per MUM that begins an LCB (heads) -- both valid until the
  * session's next chain call -- and the counters of the log.  trouble != 0: bit 0 two MUMs share a reference start (the
  * reference's unstable sort decides: nothing on the device has changed, the caller runs pm_store_judge / _unmark / _fill with
- * its own list logic); bit 1 the reference's filler bookkeeping would overrun (:2419-2433, pm_store_fill's add = 2).
+ * its own list logic); bit 1 the reference's filler bookkeeping would overrun (:2419-2433, pm_store_fill's add = 2); bit 2 the
+ * order check (pm_store_order_check) failed: nothing has changed, the caller discards the run and takes the host route.
  * n_expected: the number of accepted store rows (the caller's MUM list); a mismatch is an error. */
 typedef struct { int64_t n_in, lcbs_first, lcbs_dissolved, mums_dissolved, n_mums, n_lcbs, n_fillers; uint64_t trouble; } pm_chain_info;
 int pm_store_chain_begin(pm_session* s, int64_t n_expected, int32_t d, float diag_diff, int64_t c);

@@ -189,12 +189,12 @@ int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsiz
 }
 int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions,
                       const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children,
-                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran) {
-    if (!s || n_regions < 0 || n_clusters < 0 || (n_regions > 0 && (!regions || !row_first || !row_count || !cluster_first)) || !trouble || !n_children || info_count < 0 || (info_count > 0 && !info)) return fail(PM_EINVAL, "bad argument");
+                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran, int32_t generation) {
+    if (!s || generation < 0 || n_regions < 0 || n_clusters < 0 || (n_regions > 0 && (!regions || !row_first || !row_count || !cluster_first)) || !trouble || !n_children || info_count < 0 || (info_count > 0 && !info)) return fail(PM_EINVAL, "bad argument");
     *n_children = 0;
     try {
         const auto w0 = std::chrono::steady_clock::now();
-        const int rc = s->engine->store_validate(regions, row_first, row_count, n_regions, cluster_first, n_clusters, q, trouble, &s->new_regions, &s->new_region_ids, info_first, info_count, (pm::RowInfo*)info, stage_first, second_stage_ran);
+        const int rc = s->engine->store_validate(regions, row_first, row_count, n_regions, cluster_first, n_clusters, q, trouble, &s->new_regions, &s->new_region_ids, info_first, info_count, (pm::RowInfo*)info, stage_first, second_stage_ran, generation);
         if (rc) return fail(rc, s->engine->error);
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
         s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
@@ -214,6 +214,17 @@ int pm_store_unmark(pm_session* s, const int32_t* rows, int64_t n) {
 int pm_store_fill(pm_session* s, const int32_t* last_of, const int32_t* first_of_next, int64_t n, uint8_t* add) {
     if (!s || n < 0 || (n > 0 && (!last_of || !first_of_next || !add))) return fail(PM_EINVAL, "bad argument");
     PM_STORE_CALL(s->engine->store_fill(last_of, first_of_next, n, add, &s->fill_starts, &s->fill_ends))
+}
+int pm_store_order_check(pm_session* s, uint32_t* trouble) {
+    if (!s || !trouble) return fail(PM_EINVAL, "bad argument");
+    try {
+        const auto w0 = std::chrono::steady_clock::now();
+        const int rc = s->engine->store_order_check(trouble);
+        if (rc) return fail(rc, s->engine->error);
+        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
+        s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        return PM_OK;
+    } catch (const std::exception& e) { return fail(PM_EHIP, e.what()); }
 }
 int pm_store_chain_begin(pm_session* s, int64_t n_expected, int32_t d, float diag_diff, int64_t c) {
     if (!s) return fail(PM_EINVAL, "bad argument");

@@ -743,6 +743,9 @@ public:
         bool ordered = true;
         for (int64_t c = 0; c < rows && ordered; c++) { const uint32_t f = anchor_flags_h[(size_t)c]; ordered = !((f & kRowEarly) && !(f & (kRowBad | kRowOutside | kRowDirty))); }
         be.mark("settle");
+        ensure(d_foreign_count, 2);
+        be.memset(d_foreign_count.p, 0, 16);      // (candidates noted for store_order_check: none yet)
+        ms_key_rows = 0;
         be.memset(d_image.p, 0, 8 * words);
         const Store S = store_view();
         const Layout L = layout_view(d_image.p);
@@ -924,7 +927,7 @@ public:
     // pairwise disjoint in every genome: candidates settled against the image and marked, children appended to the region store.
     int store_validate(const int32_t* regions, const int64_t* row0, const int32_t* cnt, int64_t nreg, const int64_t* cluster_first, int64_t ncl, int32_t q,
                        uint32_t* trouble, std::vector<RegInfo>* kids, std::vector<int32_t>* kid_ids, int64_t info_first = 0, int64_t info_count = 0, RowInfo* info = nullptr,
-                       int64_t stage_first = 0, int32_t* second_stage_ran = nullptr) {
+                       int64_t stage_first = 0, int32_t* second_stage_ran = nullptr, int32_t generation = 1) {
         // stage_first > 0: clusters [0, stage_first) are a generation of their own (the first pushed seed, which the reference
         // processes before anything is sorted); the rest -- the generation the caller formed on the assumption that the first leaves
         // no child region -- runs behind it in the same call if that held, and is left untouched if not (*second_stage_ran = 0)
@@ -955,14 +958,21 @@ public:
         be.mark("validate");
         be.launch_wave("clusters_disjoint", ncl - 1, ClustersDisjoint{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, (uint32_t*)(d_rg_count.p + 1), stage_first});
         const int64_t na = stage_first > 0 ? stage_first : ncl;
+        // candidates with a member outside their region are noted for store_order_check (store_kernels.h: ForeignRead); the counter is
+        // zeroed by settle_launch, once per anchor list
+        foreign_cap = std::min<size_t>((size_t)1 << 16, ((size_t)32 << 20) / (8 * (size_t)ngen));
+        ensure(d_foreign, foreign_cap); ensure(d_foreign_masks, foreign_cap * (size_t)ngen); ensure(d_foreign_count, 2);
+        ensure_keep(d_ms_key, (size_t)ms_count, (size_t)ms_key_rows); ms_key_rows = ms_count;
         be.launch_wave("cluster_validate", xcd_grid(na),
                        ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
-                                       d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), na, 0, nullptr});
+                                       d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), na, 0, nullptr,
+                                       d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation});
         if (stage_first > 0) {
             be.launch("stage_gate", 1, StageGate{d_rg_count.p, (uint64_t)rg_count, force_gate ? 1 : 0});
             be.launch_wave("cluster_validate", xcd_grid(ncl - na),
                            ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
-                                           d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), ncl - na, na, d_rg_count.p + 2});
+                                           d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), ncl - na, na, d_rg_count.p + 2,
+                                           d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation + 1});
         }
         if (info_count > 0) {      // the scalars of the candidates just decided, with the same round trip
             if (info_first < 0 || info_first + info_count > ms_count) { error = "rows outside the MUM store"; return -2; }
@@ -1049,6 +1059,30 @@ public:
     // trip.  Two halves: begin() queues the work and the copies, end() waits for them; the caller may work in between.
     // expect: the number of accepted rows (the caller's MUM list).
     struct ChainInfo { int64_t n_in, lcbs_first, lcbs_dissolved, mums_dissolved, n_mums, n_lcbs, n_fillers; uint64_t trouble; };
+    // After the last generation: every candidate that read marks outside its region, decided again the way the reference's order
+    // had them (store_kernels.h: ForeignResolve).  *trouble != 0: the order would show.  store_chain_begin runs the same check
+    // first (bit kChainOrder of pm_chain_info.trouble); this call is for a caller that does not queue phases C-D.
+    void order_check_launch(uint32_t* word, uint32_t bit) {
+        if (!d_foreign.p || !d_foreign_masks.p || !d_ms_key.p || foreign_cap == 0) return;      // (no generation ran)
+        be.launch_wave("foreign_resolve", (int64_t)foreign_cap,
+                       ForeignResolve{store_view(), layout_view(d_image.p, false), P, d_rg_start.p, d_rg_len.p, d_ms_key.p, d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap,
+                                      d_foreign_masks.p, layout_rows, ms_count, word, bit});
+    }
+    int store_order_check(uint32_t* trouble) {
+        if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
+        *trouble = 0;
+        begin_store_call();
+        ensure(d_rg_count, 4);
+        be.mark("validate");
+        be.memset(d_rg_count.p + 1, 0, 8);
+        order_check_launch((uint32_t*)(d_rg_count.p + 1), 1u);
+        be.mark(nullptr);
+        uint64_t word = 0;
+        be.d2h(&word, d_rg_count.p + 1, 8);
+        *trouble = (uint32_t)word;
+        collect_timing_more();
+        return 0;
+    }
     int store_chain_begin(int64_t expect, int32_t d, float diag_diff, int64_t c) {
         if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
         if (expect <= 0 || expect > ms_count) { error = "bad MUM count"; return -2; }
@@ -1074,6 +1108,7 @@ public:
             const ClearJob jobs[] = {{d_ch_hdr.p, 8 * (size_t)kChWords, 0}, {d_ch_lcblen.p, 8 * cap, 0}};
             be.clear_many(jobs, 2);
         }
+        order_check_launch((uint32_t*)(d_ch_hdr.p + kChTrouble), (uint32_t)kChainOrder);      // (before anything leaves the layout)
         be.launch("chain_flag", (int64_t)rows + 1, ChainFlag{S, (int64_t)rows, d_ch_flag.p});
         be.exclusive_scan(d_ch_flag.p, d_ch_pos.p, rows + 1);
         be.launch("chain_keys", (int64_t)rows, ChainKeys{S, d_ch_pos.p, d_ch_key.p, d_ch_val.p, (int64_t)cap});
@@ -1266,6 +1301,8 @@ private:
     Buf<int64_t> d_rg_start, d_rg_len, d_lay_off, d_lay_bits, d_v_row0, d_v_first, d_f_start, d_f_end, d_f_pack; Buf<RegInfo> d_rg_info; Buf<uint64_t> d_rg_count, d_once, d_twice;
     Buf<RowInfo> d_rowinfo; Buf<uint64_t> d_alg;
     Buf<int64_t> d_sd_cnt, d_sd_off; Buf<uint8_t> d_sd_keep;      // store_settle_seeds
+    Buf<ForeignRead> d_foreign; Buf<uint64_t> d_foreign_count, d_foreign_masks; Buf<int64_t> d_ms_key;       // store_validate / store_order_check: candidates with a member outside their region
+    size_t foreign_cap = 0; int64_t ms_key_rows = 0;
     // store_chain_begin / _end
     Buf<int64_t> d_ch_flag, d_ch_pos, d_ch_head, d_ch_hpos, d_ch_survive, d_ch_spos, d_ch_hdr;
     Buf<uint64_t> d_ch_key, d_ch_val, d_ch_skey, d_ch_srow, d_ch_key2, d_ch_row2, d_ch_lcblen;

@@ -918,6 +918,110 @@ struct ClustersDisjoint {
         if (wave_or_u32(bad) && wave_leader()) atomic_or32(trouble, 8u);
     }
 };
+// A reverse-strand member is flipped against the WHOLE genome (TMum.cpp:33-35): inside a sub-region it usually lands far outside
+// the region, and the validation of its candidate -- the trimming -- then READS layout bits in another cluster's territory.  What
+// is marked there at that moment depends on how far the other clusters have come: in the reference's sequential order
+// (doWork :173-317: the first pushed seed, then always the waiting region with the smallest reference start) it is the anchors
+// plus the MUMs of every region processed BEFORE this one; in a generation scheme it is whatever the other wavefronts happened to
+// have marked.  Almost always that decides nothing -- in a collinear population 3 % of the recursion's candidates carry such a
+// member and fail the sequence check whatever they read -- but not always (fuzz campaign of round 5, seed 7059: the reference trims
+// such a candidate to 2 bases and accepts it; a region 20 kb further on, which the reference processes later, had already marked
+// its MUM here and the candidate was trimmed away).  So:
+//   * ClusterValidate NOTES every such candidate (ForeignRead) with the marks it saw in EVERY genome's interval -- inside its
+//     region those are the reference's, cluster by cluster (the clusters are disjoint and an accepted member outside its region
+//     ends the route);
+//   * every row of the recursion carries the ORDER KEY of its region, (reference start, generation), -1 for the first seed:
+//     region Y is processed before region X exactly when key(Y) < key(X) -- a child starts at or after its parent, so everything
+//     that leads to Y has a smaller start than X too, and of two regions with one start the older generation went first (two
+//     of one generation: the route is left before this matters);
+//   * when the recursion is over, ForeignResolve decides every noted candidate AGAIN the way the reference's order had it: in the
+//     genomes of its outside members the marks are the anchors' plus those of the recursion's MUMs with a smaller key or of
+//     earlier candidates of the same region (found by a scan over the recursion's accepted rows), elsewhere the noted ones;
+//     Aligner::trim (:1399-1477) on these masks, then the sequence check.  A verdict, shift or length that differs from what the
+//     generation scheme stored means the order shows: the route is left.
+struct ForeignRead { int32_t row, region, row0, pad; int64_t key; };
+// marks of [a, a + len) of genome j, len <= 64: bit t = base a + t (bases outside the genome read as unmarked, as the runs do)
+PM_HD uint64_t img_bits64(const Layout& L, int j, int64_t a, int32_t len) {
+    const uint64_t* w = L.image + L.word_off[j];
+    const int64_t nb = L.nbits[j];
+    uint64_t m = 0;
+    int32_t t = a < 0 ? (int32_t)(-a) : 0;
+    while (t < len) {
+        const int64_t p = a + t;
+        if (p >= nb) break;
+        const int lo = (int)(p & 63);
+        int span = 64 - lo;
+        if (span > len - t) span = len - t;
+        const uint64_t x = (img_ld(L, w + (p >> 6)) >> lo) & (span == 64 ? ~0ull : ((1ull << span) - 1));
+        m |= x << t;
+        t += span;
+    }
+    return m;
+}
+PM_HD int64_t order_key(int64_t ref_start, int32_t generation) { return generation <= 0 ? -1 : ref_start * 4096 + (generation < 4095 ? generation : 4095); }
+struct ForeignResolve {
+    Store S; Layout L; Packed P;
+    const int64_t* rg_start; const int64_t* rg_len; const int64_t* key;
+    const ForeignRead* list; const uint64_t* count; uint64_t cap; const uint64_t* masks;
+    int64_t rows_first, rows_end;      // the recursion's rows of the store
+    uint32_t* trouble; uint32_t bit;
+    PM_HD void wave(int64_t i) const {
+        const uint64_t ne = *count < cap ? *count : cap;
+        if ((uint64_t)i >= ne) return;
+        const ForeignRead e = list[i];
+        const int n = S.ngen;
+        const int64_t c = e.row;
+        const int32_t* st = S.start + c * n;
+        const int32_t lon = S.lon[c];
+        const int64_t* rs = rg_start + (int64_t)e.region * n; const int64_t* rl = rg_len + (int64_t)e.region * n;
+        const uint64_t* M = masks + (uint64_t)i * (uint64_t)n;
+        int32_t dl = 0, len = lon;
+        for (int j = 0; j < n && len > 0; j++) {
+            uint64_t m = M[j];
+            const int64_t a = st[j];
+            if (!S.strand[c * n + j] && (a < rs[j] - 1 || a + lon > rs[j] + rl[j] + 1)) {
+                // an outside member: the marks the reference's order had here
+                uint64_t owned = 0, present = 0;
+                lanes_for(0, (int)(rows_end - rows_first), [&](int t) {
+                    const int64_t r = rows_first + t;
+                    if (!(S.state[r] & kStAccepted)) return;
+                    const int64_t ar = (int64_t)S.start[r * n + j] + S.shift[r];
+                    const int64_t lo = ar > a ? ar : a, hi = ar + S.len[r] < a + lon ? ar + S.len[r] : a + lon;
+                    if (lo >= hi) return;
+                    const uint64_t bits = ((hi - lo) == 64 ? ~0ull : ((1ull << (hi - lo)) - 1)) << (lo - a);
+                    owned |= bits;
+                    if (key[r] < e.key || (r >= e.row0 && r < c)) present |= bits;
+                });
+                owned = wave_or_u64(owned); present = wave_or_u64(present);
+                m = (img_bits64(L, j, a, lon) & ~owned) | present;
+            }
+            // genome j gives up the marked bases at its start, then at its end (TMum::trimleft / trimright: everywhere at once)
+            const uint64_t x = (m >> dl) & (len == 64 ? ~0ull : ((1ull << len) - 1));
+            int32_t l = ~x ? ctz64(~x) : 64;
+            if (l > len) l = len;
+            int32_t r = 0;
+            if (l < len) {
+                const uint64_t y = ~(x << (64 - len));      // (the last base of the window at bit 63)
+                r = y ? clz64(y) : 64;
+                if (r > len - l) r = len - l;
+            }
+            dl += l; len -= l + r;
+        }
+        bool acc = len >= 2 && n > 1 && S.strand[c * n] != 0;
+        if (acc) {
+            uint32_t bad = 0;
+            const int64_t r0 = P.goff[0] + (int64_t)st[0] + dl;
+            lanes_for(0, n, [&](int j) {
+                if (S.strand[c * n + j]) return;
+                const int64_t l1 = (int64_t)st[j] + dl;
+                if (lce_fwd(P, P.goff[2 * j + 1] + (P.glen[j] - l1 - len), r0, len) != len) bad = 1;
+            });
+            acc = wave_or_u32(bad) == 0;
+        }
+        const bool was = (S.state[c] & kStAccepted) != 0;
+        if ((acc != was || (acc && (dl != S.shift[c] || len != S.len[c]))) && wave_leader()) atomic_or32(trouble, bit);
+    }
+};
 struct ClusterValidate {
     Store S; Layout L; Packed P;
     int64_t* rg_start; int64_t* rg_len; RegInfo* info; uint64_t* rg_count; uint64_t rg_cap;
@@ -926,6 +1030,8 @@ struct ClusterValidate {
     int64_t ncl;      // the launch is xcd_grid(ncl) wavefronts: neighbouring clusters read and mark neighbouring words of the image
     int64_t cl0;      // ... for the clusters [cl0, cl0 + ncl) of the list
     const uint64_t* gate;      // != nullptr: the second stage of a call -- it only runs if the first left *gate at 0 (StageGate)
+    ForeignRead* foreign; uint64_t* foreign_count; uint64_t foreign_cap; uint64_t* foreign_masks;      // candidates with a member outside their region (ForeignResolve)
+    int64_t* row_key; int32_t generation;      // the order key of every row decided here (order_key)
     PM_HD void wave(int64_t w) const {
         if (gate && *gate) return;
         const int64_t cl = cl0 + xcd_item(w, ncl);
@@ -939,9 +1045,30 @@ struct ClusterValidate {
             if (pending_min >= 0 && pending_min <= rs[0]) { if (wave_leader()) atomic_or32(trouble, 1u); return; }
             const int64_t row0 = now_row0[x]; const int32_t cnt = now_cnt[x];
             if (cnt >= (1 << 22)) { if (wave_leader()) atomic_or32(trouble, 4u); return; }
+            const int64_t okey = order_key(rs[0], generation);
             for (int64_t c = row0; c < row0 + cnt; c++) {
                 const uint32_t f = S.flags[c];
                 int32_t dl, len;
+                if (wave_leader()) row_key[c] = okey;
+                if ((f & kRowReverse) && !(f & (kRowBad | kRowOutside)) && S.lon[c] >= 5) {
+                    const int32_t lon = S.lon[c];
+                    uint32_t outside = 0;
+                    lanes_for(0, n, [&](int j) {
+                        if (S.strand[c * n + j]) return;
+                        const int64_t a = S.start[c * n + j];
+                        if (a < rs[j] - 1 || a + lon > rs[j] + rl[j] + 1) outside = 1;
+                    });
+                    if (wave_or_u32(outside)) {      // noted for ForeignResolve, with what it sees now
+                        int32_t at = 0;
+                        if (wave_leader()) at = (int32_t)atomic_add64(foreign_count, 1);
+                        at = wave_bcast_i32(at, 0);
+                        if ((uint64_t)at >= foreign_cap || lon > 64) { if (wave_leader()) atomic_or32(trouble, 4u); }      // (the host route decides)
+                        else {
+                            if (wave_leader()) foreign[at] = ForeignRead{(int32_t)c, (int32_t)rid, (int32_t)row0, 0, okey};
+                            lanes_for(0, n, [&](int j) { foreign_masks[(uint64_t)at * (uint64_t)n + j] = img_bits64(L, j, S.start[c * n + j], lon); });
+                        }
+                    }
+                }
                 const bool acc = settle_row(S, L, P, c, true, &dl, &len);
                 if (acc && (f & kRowReverse)) {
                     // a reverse member is flipped against the WHOLE genome (TMum.cpp:33-35): it can pass the sequence check while
@@ -1070,7 +1197,7 @@ struct FillBetween {
 // sorted rows of the final MUM list, a head flag per MUM and seven counters; what is not order-free (a tie) is reported in the
 // trouble word and the caller runs its own list logic instead -- nothing on the device has changed by then.
 constexpr uint8_t kChJoin = 0, kChClose = 1;
-constexpr uint64_t kChainTie = 1, kChainOverrun = 2;
+constexpr uint64_t kChainTie = 1, kChainOverrun = 2, kChainOrder = 4;      // (kChainOrder: ForeignResolve, queued ahead of the chain kernels)
 // the header of a chain call (int64 words in device memory)
 enum { kChN1 = 0, kChLcb1, kChLcbDissolved, kChMumDissolved, kChN2, kChLcb2, kChFill, kChTrouble, kChWords };
 // tid = store row (one past the end: 0): accepted?

@@ -446,6 +446,16 @@ void Aligner::run_batch(const std::vector<Request>& reqs, std::vector<Raw>* out,
     if (dbg_b) fprintf(stderr, "[run_batch] engine call %.4f s\n", now_s() - tcall);
     double tu = now_s();
     unpack_result(res, reqs.size(), rows, out);
+    if (const char* dump = test_hook("PARSNP_DUMP_BATCH")) {      // test hook: every request's reference column and its candidates (k, length), for a diff of two providers
+        if (FILE* f = fopen(dump, "a")) {
+            for (size_t i = 0; i < reqs.size(); i++) {
+                fprintf(f, "R %ld %ld min %d n %zu:", reqs[i].start[0], reqs[i].len[0], (int)reqs[i].minsize, (*out)[i].count);
+                for (size_t c = 0; c < (*out)[i].count; c++) fprintf(f, " %d+%d", (*out)[i].k[c], (*out)[i].lon[c]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
     stats.t_unpack += now_s() - tu;
     timing_first_call_ = stats.finder_calls == 0;
     collect_engine_timing();      // the device phase times of this call
@@ -541,21 +551,22 @@ bool Aligner::settle(Mum& m, bool touches, bool any_reverse) const {
     if (touches) trim(m);   // trim() only acts when the first or last base of some genome is already marked
     if (m.length < 2 || n <= 1) return false;
     if (!m.fwd[0]) return false;
-    if (any_reverse) {
-        const std::string& g0 = genomes[0].seq;
-        for (size_t j = 0; j < n; j++) {
-            if (m.fwd[j]) continue;
-            const std::string& gj = genomes[j].seq;
-            long l1 = m.start[j], l2 = m.length;
-            if (l1 > (long)gj.size() || m.start[0] > (long)g0.size()) fatal("MUM outside genome");
-            long have = std::min<long>(l2, (long)gj.size() - l1), have0 = std::min<long>(l2, (long)g0.size() - m.start[0]);
-            if (have != have0) return false;
-            for (long x = 0; x < have; x++) {
-                char cj = gj[(size_t)(l1 + have - 1 - x)], want;
-                switch (cj) { case 'A': want = 'T'; break; case 'C': want = 'G'; break; case 'G': want = 'C'; break;
-                              case 'T': want = 'A'; break; default: want = 'N'; }
-                if (g0[(size_t)(m.start[0] + x)] != want) return false;
-            }
+    return !any_reverse || reverse_members_spell(m);
+}
+bool Aligner::reverse_members_spell(const Mum& m) const {
+    const std::string& g0 = genomes[0].seq;
+    for (size_t j = 0; j < n; j++) {
+        if (m.fwd[j]) continue;
+        const std::string& gj = genomes[j].seq;
+        long l1 = m.start[j], l2 = m.length;
+        if (l1 > (long)gj.size() || m.start[0] > (long)g0.size()) fatal("MUM outside genome");
+        long have = std::min<long>(l2, (long)gj.size() - l1), have0 = std::min<long>(l2, (long)g0.size() - m.start[0]);
+        if (have != have0) return false;
+        for (long x = 0; x < have; x++) {
+            char cj = gj[(size_t)(l1 + have - 1 - x)], want;
+            switch (cj) { case 'A': want = 'T'; break; case 'C': want = 'G'; break; case 'G': want = 'C'; break;
+                          case 'T': want = 'A'; break; default: want = 'N'; }
+            if (g0[(size_t)(m.start[0] + x)] != want) return false;
         }
     }
     return true;
@@ -582,7 +593,15 @@ void Aligner::validate(const Region& r, const Request& q, const Raw& raw, std::v
         bool touches = false;
         if (ok && m.length > 0)
             for (size_t j = 0; j < n; j++) touches |= layout[j].get(m.start[j]) | layout[j].get(m.end(j) - 1);
+        if (const char* dump = test_hook("PARSNP_DUMP_VALIDATION"))      // test hook: every candidate's rows as the host validates them
+            if (FILE* f = fopen(dump, "a")) {
+                fprintf(f, "host candidate of region %ld+%ld: len %ld ok %d touches %d rev %d rows", r.start[0], r.length[0], m.length, (int)ok, (int)touches, (int)any_reverse);
+                for (size_t j = 0; j < n; j++) fprintf(f, " %d%c", m.start[j], m.fwd[j] ? '+' : '-');
+                fprintf(f, "\n"); fclose(f);
+            }
         if (!ok || !settle(m, touches, any_reverse)) { irows_.rewind(imark); brows_.rewind(bmark); continue; }
+        if (const char* dump = test_hook("PARSNP_DUMP_VALIDATION"))
+            if (FILE* f = fopen(dump, "a")) { fprintf(f, "   accepted: start0 %d len %ld\n", m.start[0], m.length); fclose(f); }
         for (size_t j = 0; j < n; j++) layout[j].set_range(m.start[j], m.end(j));
         m.slength = r.slength;
         pool.push_back(m);
@@ -1372,6 +1391,12 @@ bool Aligner::extend_generations() {
     const int threads = prm.cores > 0 ? prm.cores : 1;
     while ((int)memory_->per_thread.size() < threads) memory_->per_thread.emplace_back(new AlignerMemory::PerThread);
     struct Out { std::vector<Mum> accepted; std::vector<Region> kids; };
+    // candidates with a reverse-strand member outside their region (see the validation loop), of every generation so far, and
+    // for every MUM of the recursion (pool[pool0 + i]) the order key of its region, the region and its place among the region's MUMs
+    std::vector<AlignerMemory::ForeignCase> foreign_cases;
+    std::vector<long> mum_key; std::vector<int> mum_uid, mum_rank;
+    int uid_base = 0;
+    for (auto& t : memory_->per_thread) t->foreign.clear();
     int gi = 0;                                  // 0: the first seed alone; 1: the other seeds + its children; 2..: children
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double tl = now_s();
@@ -1454,7 +1479,27 @@ bool Aligner::extend_generations() {
                     bool touches = false;
                     if (ok && mm.length > 0)
                         for (size_t j = 0; j < n; j++) touches |= layout[j].get(mm.start[j]) | layout[j].get(mm.end(j) - 1);
+                    // a reverse-strand member flipped far outside this region (TMum.cpp:33-35) makes the touch test and the trimming
+                    // READ layout bits in another cluster's territory, and what is marked there when the reference looks depends on
+                    // its order.  The candidate is noted with what it saw and decided again, in the reference's order, when the
+                    // recursion is over (engine/store_kernels.h: ForeignRead / ForeignResolve; fuzz seed 7059 of round 5)
+                    AlignerMemory::ForeignCase* noted = nullptr;
+                    if (ok && any_reverse && mm.length >= 5) {
+                        bool outside = false;
+                        for (size_t j = 0; j < n; j++) outside |= !mm.fwd[j] && ((long)mm.start[j] < r.start[j] - 1 || mm.end(j) > r.end[j] + 1);
+                        if (outside && mm.length > 64) cluster_trouble = 1;
+                        else if (outside) {
+                            tl.foreign.emplace_back();
+                            noted = &tl.foreign.back();
+                            noted->start.assign(mm.start, mm.start + n); noted->fwd.assign(mm.fwd, mm.fwd + n); noted->mask.resize(n);
+                            for (size_t j = 0; j < n; j++) noted->mask[j] = layout[j].bits64(mm.start[j], mm.length);
+                            noted->length = mm.length; noted->key = gi == 0 ? -1 : r.start[0] * 4096 + std::min(gi, 4095); noted->uid = uid_base + (int)x;
+                            noted->own_before = o.accepted.size(); noted->rstart = r.start; noted->rend = r.end;
+                            noted->accepted = false; noted->acc_start0 = 0; noted->acc_length = 0;
+                        }
+                    }
                     if (!ok || !settle(mm, touches, any_reverse)) { tl.irows.rewind(imark); tl.brows.rewind(bmark); continue; }
+                    if (noted) { noted->accepted = true; noted->acc_start0 = mm.start[0]; noted->acc_length = mm.length; }
                     // a reverse-strand member is flipped against the WHOLE genome length (TMum.cpp:33-35), so it can pass the
                     // sequence check while lying outside this region's interval (inverted repeats): its marks could then meet
                     // another cluster's and the order would show.  The in-order replay decides such a generation.
@@ -1492,18 +1537,70 @@ bool Aligner::extend_generations() {
                 }
             }
         }
+        for (auto& t : memory_->per_thread) { for (auto& f : t->foreign) foreign_cases.push_back(std::move(f)); t->foreign.clear(); }
         if (cluster_trouble) { stats.generation_handover = gi; return restart_in_order(); }
         stats.t_validate += now_s() - tv;
         lap("validate");
         stats.generations++; stats.generation_regions += m;
         for (long x = 0; x < m; x++) {           // commit in list order
-            for (Mum& mm : out[(size_t)x].accepted) { mm.id = next_id_++; pool.push_back(mm); mums.push_back((int)pool.size() - 1); }
+            int rank = 0;
+            for (Mum& mm : out[(size_t)x].accepted) {
+                mm.id = next_id_++; pool.push_back(mm); mums.push_back((int)pool.size() - 1);
+                mum_key.push_back(gi == 0 ? -1 : now[(size_t)x].start[0] * 4096 + std::min(gi, 4095)); mum_uid.push_back(uid_base + (int)x); mum_rank.push_back(rank++);
+            }
             for (Region& k : out[(size_t)x].kids) { gen.push_back(k); gen_raw.push_back(-1); }
             stats.regions_processed++; stats.cache_hits++;
         }
         lap("commit");
+        uid_base += (int)m;
         gi++;
     }
+    // The noted candidates again, with the marks the reference's order (the first seed, then always the waiting region with the
+    // smallest reference start) had in place in the genomes of their outside members: the anchors' and those of the recursion's
+    // MUMs from regions with a smaller (reference start, generation), or earlier in the same region.  A different verdict, shift
+    // or length: the order shows, the in-order replay decides the run.
+    const long ncases = (long)foreign_cases.size();
+    int differs = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(| : differs) if (ncases > 8)
+    for (long ci = 0; ci < ncases; ci++) {
+        const AlignerMemory::ForeignCase& e = foreign_cases[(size_t)ci];
+        long dl = 0, len = e.length;
+        for (size_t j = 0; j < n && len > 0; j++) {
+            uint64_t mk = e.mask[j];
+            const long a = e.start[j];
+            if (!e.fwd[j] && (a < e.rstart[j] - 1 || a + e.length > e.rend[j] + 1)) {
+                uint64_t owned = 0, present = 0;
+                for (size_t k = pool0; k < pool.size(); k++) {
+                    const long ar = pool[k].start[j], lo = std::max(ar, a), hi = std::min(ar + pool[k].length, a + e.length);
+                    if (lo >= hi) continue;
+                    const uint64_t bits = ((hi - lo) == 64 ? ~0ull : ((1ull << (hi - lo)) - 1)) << (lo - a);
+                    owned |= bits;
+                    const size_t i = k - pool0;
+                    if (mum_key[i] < e.key || (mum_uid[i] == e.uid && (size_t)mum_rank[i] < e.own_before)) present |= bits;
+                }
+                mk = (layout[j].bits64(a, e.length) & ~owned) | present;
+            }
+            const uint64_t x = (mk >> dl) & (len == 64 ? ~0ull : ((1ull << len) - 1));
+            long l = ~x ? __builtin_ctzll(~x) : 64;
+            if (l > len) l = len;
+            long rr = 0;
+            if (l < len) {
+                const uint64_t y = ~(x << (64 - len));
+                rr = y ? __builtin_clzll(y) : 64;
+                if (rr > len - l) rr = len - l;
+            }
+            dl += l; len -= l + rr;
+        }
+        bool acc = len >= 2 && n > 1 && e.fwd[0];
+        if (acc) {
+            std::vector<int32_t> st(e.start);
+            for (size_t j = 0; j < n; j++) st[j] += (int32_t)dl;
+            Mum t; t.start = st.data(); t.fwd = const_cast<uint8_t*>(e.fwd.data()); t.length = len;
+            acc = reverse_members_spell(t);
+        }
+        if (acc != e.accepted || (acc && (e.start[0] + dl != e.acc_start0 || len != e.acc_length))) differs = 1;
+    }
+    if (differs) { stats.generation_handover = gi; return restart_in_order(); }
     return !mums.empty();
 }
 

@@ -78,6 +78,18 @@ public:
         logging_ = false; log_.clear();
     }
     bool attached() const { return w_ && own_.empty(); }
+    uint64_t bits64(long a, long len) const {      // marks of [a, a + len), len <= 64: bit t = base a + t (outside the bitmap: unmarked)
+        uint64_t m = 0;
+        for (long t = a < 0 ? -a : 0; t < len; ) {
+            const long p = a + t;
+            if (p >= (long)nbits_) break;
+            const int lo = (int)(p & 63);
+            const long span = std::min<long>(64 - lo, len - t);
+            m |= ((w_[(size_t)p >> 6] >> lo) & (span == 64 ? ~0ull : ((1ull << span) - 1))) << t;
+            t += span;
+        }
+        return m;
+    }
     size_t count_set() const { size_t c = 0; for (size_t i = 0; i < words_; i++) c += (size_t)__builtin_popcountll(w_[i]); return c; }
     Bitmap() = default;
     Bitmap(Bitmap&& o) noexcept { *this = std::move(o); }
@@ -278,7 +290,14 @@ struct AlignerMemory {
     std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
     std::vector<Mum> pool_store, candidates;         // storage of Aligner::pool / validate_parallel's candidate records between runs
     std::vector<int> minlen_flat[2]; std::string minlen_expr[2];   // Aligner::min_length for lengths below 2^16, by expression (mums, anchors)
-    struct PerThread { Arena<long> rows; Arena<int32_t> irows; Arena<uint8_t> brows; std::vector<long> scratch; };
+    // extend_generations: a candidate with a reverse-strand member outside its region, with the marks it saw in every genome's
+    // interval and what was decided (engine/store_kernels.h: ForeignRead / ForeignResolve)
+    struct ForeignCase {
+        std::vector<int32_t> start; std::vector<uint8_t> fwd; std::vector<uint64_t> mask;
+        long length, key; int uid; size_t own_before; const long* rstart; const long* rend;
+        bool accepted; long acc_start0, acc_length;
+    };
+    struct PerThread { Arena<long> rows; Arena<int32_t> irows; Arena<uint8_t> brows; std::vector<long> scratch; std::vector<ForeignCase> foreign; };
     std::vector<std::unique_ptr<PerThread>> per_thread;   // rows written by the threads of the generation-parallel replay
     void reset() { rows.reset(); cache_rows.reset(); req_rows.reset(); irows.reset(); brows.reset(); for (auto& t : per_thread) { t->rows.reset(); t->irows.reset(); t->brows.reset(); } }
 };
@@ -310,6 +329,7 @@ public:
     bool resident_failed() const { return res_.failed; }
     const std::string& resident_why() const { return res_.why; }
     bool resident_chain();                               // phases C-D from the device (resident.cpp); false: the caller runs them
+    void materialize_keys() {}                           // (test hook: key0() of every MUM of the list is valid on both routes once the recursion has returned)
     void materialize();                                  // rows of the LCBs' MUMs (and the layout, for parsnp.unalign) for the writer; no-op on the host route
     long key0(int idx) const { return res_.active ? (long)res_.start0[(size_t)idx] : (long)pool[(size_t)idx].start[0]; }      // reference start of a MUM
 
@@ -397,6 +417,7 @@ private:
     void validate_parallel(const Region& r, const Request& q, const Raw& raw, std::vector<int>* accepted, int threads);
     bool candidate_rows(const Region& r, const Request& q, const Raw& raw, size_t c, Mum& m, bool* ok, bool* any_reverse) const;
     bool settle(Mum& m, bool touches, bool any_reverse) const;
+    bool reverse_members_spell(const Mum& m) const;      // the sequence check of settle() alone (:1791-1825)
     void trim(Mum& m) const;
     bool extend_pass(bool speculative, bool sorted_start = false);
     bool extend_generations();

@@ -200,11 +200,23 @@ StepReport CoreRun::step_once(bool resident) {
     }
     time(&end);
     r.mums_found = found;
+    if (const char* dump = test_hook("PARSNP_DUMP_MUMS")) {      // test hook: the MUM list after the recursion, (reference start, length) in list order
+        if (FILE* f = fopen(dump, "w")) {
+            if (a.resident_active()) a.materialize_keys();
+            for (int idx : a.mums) {
+                fprintf(f, "%ld %ld", a.key0(idx), a.pool[(size_t)idx].length);
+                if (a.pool[(size_t)idx].start) for (size_t j = 0; j < a.n; j++) fprintf(f, " %d%c", a.pool[(size_t)idx].start[j], a.pool[(size_t)idx].fwd[j] ? '+' : '-');
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
     if (found && !a.resident_failed()) {
-        printf("        Finished recursive MUM search, elapsed time: %.0lf seconds\n\n", difftime(end, start));
-        a.coarsen_time = (float)difftime(end, start);
         // (resident route, order-free list logic: phases C-D were queued on the device behind the last generation)
         const bool from_device = a.resident_chain();
+        if (a.resident_failed()) { r.path_s = now_s() - t0; return r; }      // (the order check queued ahead of phases C-D)
+        printf("        Finished recursive MUM search, elapsed time: %.0lf seconds\n\n", difftime(end, start));
+        a.coarsen_time = (float)difftime(end, start);
         if (prm.random) {
             std::cerr << "Filtering spurious matches..." << std::endl;
             time(&start);

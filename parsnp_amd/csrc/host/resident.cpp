@@ -168,6 +168,7 @@ void Aligner::resident_records() {
     std::vector<pm_row_info>().swap(res_.anchor_info);
 }
 
+static const char* const kOrderWhy = "a candidate with a reverse-strand member outside its region is decided differently by the reference's order";
 // Phase B: the generations of extend_generations() with the per-genome work on the device.
 bool Aligner::resident_extend() {
     const double t0 = now_s();
@@ -273,13 +274,14 @@ bool Aligner::resident_extend() {
         if (hi > lo && info.size() < (size_t)hi) info.resize((size_t)hi);
         int32_t second_ran = 0;
         int rc = pm_store_validate(session_, now_id.data(), r0.data(), rc_.data(), (int64_t)now.size(), first.data(), (int64_t)first.size() - 1, (int32_t)prm.q, &trouble, &nkids,
-                                   hi > lo ? lo : 0, hi > lo ? hi - lo : 0, hi > lo ? info.data() + lo : nullptr, stage_first, &second_ran);
+                                   hi > lo ? lo : 0, hi > lo ? hi - lo : 0, hi > lo ? info.data() + lo : nullptr, stage_first, &second_ran, (int32_t)gi);
         if (rc != PM_OK) engine_error("validation of a generation on the device failed", rc);
         collect_engine_timing();
         if (trouble) {
             res_.failed = true;
             res_.why = (trouble & 8) ? "clusters of waiting regions overlap in some genome" : (trouble & 1) ? "a child region sorts before a region still waiting in its cluster"
-                     : (trouble & 2) ? "a reverse-strand member lies outside its region" : "a region with too many candidates";
+                     : (trouble & 2) ? "a reverse-strand member outside its region was accepted"
+                     : "a region with too many candidates, or more candidates with a member outside their region than the engine notes";
             stats.generation_handover = gi;
             return false;
         }
@@ -307,6 +309,22 @@ bool Aligner::resident_extend() {
         resident_records();      // the anchors' records first: the recursion's MUMs follow them in the pool
         // commit in list order (:215-254 push the MUMs of a region in candidate order)
         for (size_t i = 0; i < now.size(); i++) {
+            if (const char* dump = test_hook("PARSNP_DUMP_VALIDATION"))      // test hook: what the device decided for every candidate of every region
+                if (FILE* f = fopen(dump, "a")) {
+                    fprintf(f, "region %ld+%ld (generation %d):", (long)now[i].ref_start, (long)now[i].ref_len, gi);
+                    for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) fprintf(f, " [%d len %d shift %d state %02x flags %x]", info[(size_t)c].start0, info[(size_t)c].len, info[(size_t)c].shift, info[(size_t)c].state_flags & 0xffu, info[(size_t)c].state_flags >> 8);
+                    fprintf(f, "\n");
+                    for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) {
+                        std::vector<int32_t> st(n); std::vector<uint8_t> fw(n);
+                        const int32_t row = (int32_t)c;
+                        if (pm_store_rows(session_, &row, 0, 1, 1, st.data(), fw.data()) == PM_OK) {
+                            fprintf(f, "   device candidate rows (raw)");
+                            for (size_t j = 0; j < n; j++) fprintf(f, " %d%c", st[j], fw[j] ? '+' : '-');
+                            fprintf(f, "\n");
+                        }
+                    }
+                    fclose(f);
+                }
             for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) {
                 const uint32_t st = info[(size_t)c].state_flags & 0xffu;
                 if (st & PM_ST_BUILT) next_id_++;
@@ -323,6 +341,13 @@ bool Aligner::resident_extend() {
         gi += stage_first > 0 ? 2 : 1;
     }
     if (!res_.chain_queued && !mums.empty()) resident_chain_begin(mums.size());      // (no seed region at all: the anchors are the list)
+    if (!res_.chain_queued && gi > 0) {
+        // candidates that read marks outside their region, decided again in the reference's order (a queued chain does this itself)
+        uint32_t trouble = 0;
+        if (pm_store_order_check(session_, &trouble) != PM_OK) engine_error("the order check on the device failed", PM_EHIP);
+        collect_engine_timing();
+        if (trouble) { res_.failed = true; res_.why = kOrderWhy; stats.generation_handover = gi; return false; }
+    }
     stats.extend_s = now_s() - t0;
     stats.t_replay = stats.extend_s;
     return !mums.empty();
@@ -352,6 +377,7 @@ bool Aligner::resident_chain() {
     if (rc != PM_OK) engine_error("phases C-D on the device failed", rc);
     collect_engine_timing();
     if (ci.n_in != (int64_t)mums.size()) fatal("the device's MUM list and the host's differ");
+    if (ci.trouble & 4) { res_.failed = true; res_.why = kOrderWhy; return false; }
     if (ci.trouble & 1) { res_.chain_why = "two MUMs share a reference start"; return false; }
     if (ci.trouble & 2) fatal("inter-cluster region bookkeeping would overrun in the reference");
     // store row -> MUM record

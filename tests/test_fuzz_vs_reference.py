@@ -151,6 +151,40 @@ def test_inversions_on_the_resident_route_on_gpu(tmp_path, monkeypatch, variant)
     inversions_on_the_resident_route(CORE_HOOKS_BIN, tmp_path, monkeypatch, variant)
 
 
+def order_case(core, tmp_path, monkeypatch, route):
+    """seed 7059 of round 5's campaign: a recursion candidate (7 bases, one reverse-strand member) whose flipped member lies 20 kb
+    outside its region, where another region's MUM gets marked.  The reference processes that other region LATER, trims the
+    candidate to 2 bases against the anchors alone and accepts it (201 MUMs found); a generation scheme that happens to have
+    marked the other MUM first trims it away (200).  Both routes now note such candidates and decide them again in the
+    reference's order (ForeignResolve / the end of extend_generations): the resident route is left, the host's generations hand
+    over to the in-order replay, and the log counts what the reference counts."""
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PARSNP_RESIDENT_LOG=str(tmp_path / "route.log")).items():
+        monkeypatch.setenv(k, v)
+    if route == "host":
+        monkeypatch.setenv("PARSNP_NO_RESIDENT", "1")
+    ref, gs, kw, contigs = random_case(7059, False)
+    kw["threads"] = 3
+    rp, qs = write(str(tmp_path / "in"), ref, gs, contigs, 7059)
+    a = run(REFBIN, rp, qs, str(tmp_path / "ref"), kw)
+    b = run(core, rp, qs, str(tmp_path / "mine"), kw)
+    assert a == b
+    assert any(l.startswith("Number of MUMs found") and l.split()[-1] == "201" for l in a[2]), a[2]
+    log = open(str(tmp_path / "route.log")).read()
+    if route == "resident":
+        assert "retry=1" in log and "decided differently by the reference's order" in log, log
+
+
+@pytest.mark.parametrize("route", ["resident", "host"])
+def test_order_of_reads_outside_a_region(emu, tmp_path, monkeypatch, route):
+    order_case(emu[1], tmp_path, monkeypatch, route)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["resident", "host"])
+def test_order_of_reads_outside_a_region_on_gpu(tmp_path, monkeypatch, route):
+    order_case(CORE_HOOKS_BIN, tmp_path, monkeypatch, route)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_host_route_over_device_rows(emu, tmp_path, monkeypatch, seed):
     """the same side by side for the HOST route over the kernel emulation (PARSNP_NO_RESIDENT: what a step falls back to),
