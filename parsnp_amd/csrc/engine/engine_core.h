@@ -745,8 +745,10 @@ public:
         be.mark("settle");
         ensure(d_foreign_count, 2);
         be.memset(d_foreign_count.p, 0, 16);      // (candidates noted for store_order_check: none yet)
-        ms_key_rows = 0;
+        ms_key_rows = 0; foreign_seen = 0;
         be.memset(d_image.p, 0, 8 * words);
+        ensure(d_recwords, words);
+        be.memset(d_recwords.p, 0, words);      // (where the recursion marks: ClusterValidate, for the order check)
         const Store S = store_view();
         const Layout L = layout_view(d_image.p);
         be.launch_wave("settle_clean", rows, SettleClean{S, P});
@@ -966,13 +968,13 @@ public:
         be.launch_wave("cluster_validate", xcd_grid(na),
                        ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
                                        d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), na, 0, nullptr,
-                                       d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation});
+                                       d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation, d_recwords.p});
         if (stage_first > 0) {
             be.launch("stage_gate", 1, StageGate{d_rg_count.p, (uint64_t)rg_count, force_gate ? 1 : 0});
             be.launch_wave("cluster_validate", xcd_grid(ncl - na),
                            ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
                                            d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), ncl - na, na, d_rg_count.p + 2,
-                                           d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation + 1});
+                                           d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation + 1, d_recwords.p});
         }
         if (info_count > 0) {      // the scalars of the candidates just decided, with the same round trip
             if (info_first < 0 || info_first + info_count > ms_count) { error = "rows outside the MUM store"; return -2; }
@@ -981,6 +983,7 @@ public:
         }
         be.mark(nullptr);
         if (info_count > 0) be.d2h_async(info, d_rowinfo.p, sizeof(RowInfo) * (size_t)info_count);
+        be.d2h_async(&foreign_seen, d_foreign_count.p, 8);
         be.d2h(head, d_rg_count.p, 24);
         *trouble = (uint32_t)head[1];
         if (second_stage_ran) *second_stage_ran = stage_first > 0 && head[2] == 0 ? 1 : 0;
@@ -1060,13 +1063,28 @@ public:
     // expect: the number of accepted rows (the caller's MUM list).
     struct ChainInfo { int64_t n_in, lcbs_first, lcbs_dissolved, mums_dissolved, n_mums, n_lcbs, n_fillers; uint64_t trouble; };
     // After the last generation: every candidate that read marks outside its region, decided again the way the reference's order
-    // had them (store_kernels.h: ForeignResolve).  *trouble != 0: the order would show.  store_chain_begin runs the same check
-    // first (bit kChainOrder of pm_chain_info.trouble); this call is for a caller that does not queue phases C-D.
+    // had them (store_kernels.h: ForeignRead and what follows it).  *trouble != 0: the order would show.  store_chain_begin runs
+    // the same check first (bit kChainOrder of pm_chain_info.trouble); store_order_check is for a caller that does not queue phases C-D.
     void order_check_launch(uint32_t* word, uint32_t bit) {
-        if (!d_foreign.p || !d_foreign_masks.p || !d_ms_key.p || foreign_cap == 0) return;      // (no generation ran)
-        be.launch_wave("foreign_resolve", (int64_t)foreign_cap,
-                       ForeignResolve{store_view(), layout_view(d_image.p, false), P, d_rg_start.p, d_rg_len.p, d_ms_key.p, d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap,
-                                      d_foreign_masks.p, layout_rows, ms_count, word, bit});
+        const int64_t cnt = (int64_t)std::min<uint64_t>(foreign_seen, (uint64_t)foreign_cap);
+        const int64_t rows = ms_count - layout_rows;
+        if (cnt <= 0 || rows <= 0) return;      // (nothing was noted)
+        ensure(d_hits, kHitCap); ensure(d_hit_count, 2); ensure(d_hit_owned, kHitCap * (size_t)ngen); ensure(d_hit_present, kHitCap * (size_t)ngen);
+        be.memset(d_hit_count.p, 0, 16);
+        const Store S = store_view();
+        const Layout L = layout_view(d_image.p, false);
+        be.launch_wave("foreign_bound", cnt, ForeignBound{S, L, P, d_rg_start.p, d_rg_len.p, d_foreign.p, cnt, d_foreign_masks.p, d_recwords.p, d_hits.p, d_hit_count.p, (uint64_t)kHitCap,
+                                                         d_hit_owned.p, d_hit_present.p, word, bit});
+        const int64_t chunks = (rows + kScanRows - 1) / kScanRows, waves = 8192;
+        be.launch_wave("foreign_scan", waves, ForeignScan{S, d_rg_start.p, d_rg_len.p, d_ms_key.p, d_foreign.p, d_hits.p, d_hit_count.p, (uint64_t)kHitCap, d_hit_owned.p, d_hit_present.p,
+                                                         layout_rows, ms_count, chunks, waves});
+        be.launch_wave("foreign_decide_hits", (int64_t)kHitCap, ForeignDecideHits{S, L, P, d_rg_start.p, d_rg_len.p, d_foreign.p, d_foreign_masks.p, d_hits.p, d_hit_count.p, (uint64_t)kHitCap,
+                                                                                 d_hit_owned.p, d_hit_present.p, word, bit});
+        if (getenv("PM_DEBUG_ORDER")) {      // (debugging aid: waits for the queue)
+            uint64_t nh = 0;
+            be.d2h(&nh, d_hit_count.p, 8);
+            fprintf(stderr, "[order check] %ld noted candidates, %ld left to the scan (launched for %ld), %ld recursion rows\n", (long)cnt, (long)nh, (long)kHitCap, (long)rows);
+        }
     }
     int store_order_check(uint32_t* trouble) {
         if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
@@ -1302,7 +1320,9 @@ private:
     Buf<RowInfo> d_rowinfo; Buf<uint64_t> d_alg;
     Buf<int64_t> d_sd_cnt, d_sd_off; Buf<uint8_t> d_sd_keep;      // store_settle_seeds
     Buf<ForeignRead> d_foreign; Buf<uint64_t> d_foreign_count, d_foreign_masks; Buf<int64_t> d_ms_key;       // store_validate / store_order_check: candidates with a member outside their region
-    size_t foreign_cap = 0; int64_t ms_key_rows = 0;
+    size_t foreign_cap = 0; int64_t ms_key_rows = 0; uint64_t foreign_seen = 0;      // foreign_seen: the device's counter as of the last validation call
+    static constexpr size_t kHitCap = 256;      // noted candidates that the bounds of ForeignBound do not decide
+    Buf<uint64_t> d_hit_count, d_hit_owned, d_hit_present; Buf<int32_t> d_hits; Buf<uint8_t> d_recwords;      // d_recwords: one byte per image word, set where the recursion has marked
     // store_chain_begin / _end
     Buf<int64_t> d_ch_flag, d_ch_pos, d_ch_head, d_ch_hpos, d_ch_survive, d_ch_spos, d_ch_hdr;
     Buf<uint64_t> d_ch_key, d_ch_val, d_ch_skey, d_ch_srow, d_ch_key2, d_ch_row2, d_ch_lcblen;

@@ -934,7 +934,7 @@ struct ClustersDisjoint {
 //     region Y is processed before region X exactly when key(Y) < key(X) -- a child starts at or after its parent, so everything
 //     that leads to Y has a smaller start than X too, and of two regions with one start the older generation went first (two
 //     of one generation: the route is left before this matters);
-//   * when the recursion is over, ForeignResolve decides every noted candidate AGAIN the way the reference's order had it: in the
+//   * when the recursion is over, the resolve (ForeignBound and the kernels around it) decides every noted candidate AGAIN the way the reference's order had it: in the
 //     genomes of its outside members the marks are the anchors' plus those of the recursion's MUMs with a smaller key or of
 //     earlier candidates of the same region (found by a scan over the recursion's accepted rows), elsewhere the noted ones;
 //     Aligner::trim (:1399-1477) on these masks, then the sequence check.  A verdict, shift or length that differs from what the
@@ -959,44 +959,55 @@ PM_HD uint64_t img_bits64(const Layout& L, int j, int64_t a, int32_t len) {
     return m;
 }
 PM_HD int64_t order_key(int64_t ref_start, int32_t generation) { return generation <= 0 ? -1 : ref_start * 4096 + (generation < 4095 ? generation : 4095); }
-struct ForeignResolve {
-    Store S; Layout L; Packed P;
-    const int64_t* rg_start; const int64_t* rg_len; const int64_t* key;
-    const ForeignRead* list; const uint64_t* count; uint64_t cap; const uint64_t* masks;
-    int64_t rows_first, rows_end;      // the recursion's rows of the store
-    uint32_t* trouble; uint32_t bit;
-    PM_HD void wave(int64_t i) const {
-        const uint64_t ne = *count < cap ? *count : cap;
-        if ((uint64_t)i >= ne) return;
-        const ForeignRead e = list[i];
-        const int n = S.ngen;
-        const int64_t c = e.row;
-        const int32_t* st = S.start + c * n;
-        const int32_t lon = S.lon[c];
-        const int64_t* rs = rg_start + (int64_t)e.region * n; const int64_t* rl = rg_len + (int64_t)e.region * n;
-        const uint64_t* M = masks + (uint64_t)i * (uint64_t)n;
-        int32_t dl = 0, len = lon;
-        for (int j = 0; j < n && len > 0; j++) {
-            uint64_t m = M[j];
-            const int64_t a = st[j];
-            if (!S.strand[c * n + j] && (a < rs[j] - 1 || a + lon > rs[j] + rl[j] + 1)) {
-                // an outside member: the marks the reference's order had here
-                uint64_t owned = 0, present = 0;
-                lanes_for(0, (int)(rows_end - rows_first), [&](int t) {
-                    const int64_t r = rows_first + t;
-                    if (!(S.state[r] & kStAccepted)) return;
-                    const int64_t ar = (int64_t)S.start[r * n + j] + S.shift[r];
-                    const int64_t lo = ar > a ? ar : a, hi = ar + S.len[r] < a + lon ? ar + S.len[r] : a + lon;
-                    if (lo >= hi) return;
-                    const uint64_t bits = ((hi - lo) == 64 ? ~0ull : ((1ull << (hi - lo)) - 1)) << (lo - a);
-                    owned |= bits;
-                    if (key[r] < e.key || (r >= e.row0 && r < c)) present |= bits;
-                });
-                owned = wave_or_u64(owned); present = wave_or_u64(present);
-                m = (img_bits64(L, j, a, lon) & ~owned) | present;
-            }
-            // genome j gives up the marked bases at its start, then at its end (TMum::trimleft / trimright: everywhere at once)
-            const uint64_t x = (m >> dl) & (len == 64 ? ~0ull : ((1ull << len) - 1));
+// The resolve as launches (engine_core.h: order_check_launch).  Which of the marks in an outside member's interval belong to the
+// recursion, and to which MUM, only a scan over the recursion's accepted rows can tell, and a candidate that is reverse in one
+// query genome of a population is reverse in all of them: 500 noted candidates x 200 genomes x 17 000 rows at 200 x 5 Mb.  So
+//   ClusterValidate  sets, for every MUM it accepts, one BYTE per word of the layout image that the MUM marks (`rec`, cleared
+//                  with the image): a coarse picture of the recursion's marks alone, written with plain stores;
+//   ForeignBound   per noted candidate, BOUNDS on what the reference's order saw in the genomes of its outside members: at
+//                  least the final marks outside the image words the recursion touched (those are anchors' marks, in place
+//                  before any region is processed), at most the final marks.  Trimming is monotone -- more marks, or a smaller
+//                  interval to start from, never leave more -- so the interval the reference kept lies between the two trimmed
+//                  with the bounds.  Both equal, or the larger one shorter than 2 bases (almost every candidate: its outside
+//                  members lie among anchors and are trimmed away whatever else is marked): decided on the spot.  The rest goes
+//                  onto a short hit list;
+//   ForeignScan    for the hits, the recursion's accepted rows against the candidate's intervals, all genomes side by side
+//                  (the rows stream through once per hit): the marks the recursion owns there, and which of them come from a
+//                  region that the reference's order processes earlier;
+//   ForeignDecideHits   the hits decided with exactly those.
+constexpr int kScanRows = 16;         // rows of the store per work item of ForeignScan
+// the image words of genome j (from word_off) that bases [a, b) touch get their byte
+PM_HD void rec_set(uint8_t* rec, int64_t word_off, int64_t nbits, int64_t a, int64_t b) {
+    if (a < 0) a = 0;
+    if (b > nbits) b = nbits;
+    if (a >= b) return;
+    for (int64_t w = a >> 6; w <= ((b - 1) >> 6); w++) rec[word_off + w] = 1;
+}
+// the bases of [a, a + len), len <= 64, that lie in an image word the recursion has marked: bit t = base a + t
+PM_HD uint64_t rec_bits64(const uint8_t* rec, int64_t word_off, int64_t nbits, int64_t a, int32_t len) {
+    uint64_t m = 0;
+    int32_t t = a < 0 ? (int32_t)(-a) : 0;
+    while (t < len) {
+        const int64_t p = a + t;
+        if (p >= nbits) break;
+        int32_t span = 64 - (int32_t)(p & 63);
+        if (span > len - t) span = len - t;
+        if (rec[word_off + (p >> 6)]) m |= (span == 64 ? ~0ull : ((1ull << span) - 1)) << t;
+        t += span;
+    }
+    return m;
+}
+// Aligner::trim (:1399-1477) of a candidate of `lon` bases on masks: mask(j) = the marks of genome j's interval, bit t = base t
+// of the candidate.  settle_row's rounds: the first genome that trims does so, the rest look again.
+template <class MaskOf> PM_HD void trim_on_masks(int n, int32_t lon, MaskOf mask, int32_t* pdl, int32_t* plen) {
+    int32_t dl = 0, len = lon;
+    int from = 0;
+    while (len > 0) {
+        int32_t first = 0x7fffffff, tl = 0, tr = 0;
+        lanes_for(from, n, [&](int j) {
+            if (j >= first) return;
+            const uint64_t x = (mask(j) >> dl) & (len == 64 ? ~0ull : ((1ull << len) - 1));
+            if (!x) return;
             int32_t l = ~x ? ctz64(~x) : 64;
             if (l > len) l = len;
             int32_t r = 0;
@@ -1005,21 +1016,134 @@ struct ForeignResolve {
                 r = y ? clz64(y) : 64;
                 if (r > len - l) r = len - l;
             }
-            dl += l; len -= l + r;
+            if ((l | r) != 0) { first = j; tl = l; tr = r; }
+        });
+        const int32_t F = wave_min_i32(first);
+        if (F == 0x7fffffff) break;
+        tl = wave_bcast_i32(tl, F & 63); tr = wave_bcast_i32(tr, F & 63);
+        dl += tl; len -= tl + tr; from = F + 1;
+    }
+    *pdl = dl; *plen = len;
+}
+// the rest of settle_row for the trimmed candidate, against what the generations stored: true = verdict, shift or length differ
+PM_HD bool verdict_differs(const Store& S, const Packed& P, int64_t c, int32_t dl, int32_t len) {
+    const int n = S.ngen;
+    const int32_t* st = S.start + c * n;
+    bool acc = len >= 2 && n > 1 && S.strand[c * n] != 0;
+    if (acc) {
+        uint32_t bad = 0;
+        const int64_t r0 = P.goff[0] + (int64_t)st[0] + dl;
+        lanes_for(0, n, [&](int j) {
+            if (S.strand[c * n + j]) return;
+            const int64_t l1 = (int64_t)st[j] + dl;
+            if (lce_fwd(P, P.goff[2 * j + 1] + (P.glen[j] - l1 - len), r0, len) != len) bad = 1;
+        });
+        acc = wave_or_u32(bad) == 0;
+    }
+    const bool was = (S.state[c] & kStAccepted) != 0;
+    return acc != was || (acc && (dl != S.shift[c] || len != S.len[c]));
+}
+PM_HD bool member_outside(const Store& S, int64_t c, int j, const int64_t* rs, const int64_t* rl) {
+    if (S.strand[c * S.ngen + j]) return false;
+    const int64_t a = S.start[c * S.ngen + j];
+    return a < rs[j] - 1 || a + S.lon[c] > rs[j] + rl[j] + 1;
+}
+// one wavefront per noted candidate
+struct ForeignBound {
+    Store S; Layout L; Packed P;
+    const int64_t* rg_start; const int64_t* rg_len;
+    const ForeignRead* list; int64_t count; const uint64_t* masks; const uint8_t* rec;
+    int32_t* hits; uint64_t* hit_count; uint64_t hit_cap; uint64_t* hit_owned; uint64_t* hit_present;
+    uint32_t* trouble; uint32_t bit;
+    PM_HD void wave(int64_t i) const {
+        if (i >= count) return;
+        const ForeignRead e = list[i];
+        const int n = S.ngen;
+        const int64_t c = e.row;
+        const int32_t lon = S.lon[c];
+        const int64_t* rs = rg_start + (int64_t)e.region * n; const int64_t* rl = rg_len + (int64_t)e.region * n;
+        const uint64_t* M = masks + (uint64_t)i * (uint64_t)n;
+        int32_t dl_lo, len_lo, dl_hi, len_hi;
+        trim_on_masks(n, lon, [&](int j) -> uint64_t {      // at least: the final marks outside the words the recursion touched
+            if (!member_outside(S, c, j, rs, rl)) return M[j];
+            const int64_t a = S.start[c * n + j];
+            return img_bits64(L, j, a, lon) & ~rec_bits64(rec, L.word_off[j], L.nbits[j], a, lon);
+        }, &dl_lo, &len_lo);
+        if (len_lo >= 2) {
+            trim_on_masks(n, lon, [&](int j) -> uint64_t {      // at most: the final marks
+                return member_outside(S, c, j, rs, rl) ? img_bits64(L, j, S.start[c * n + j], lon) : M[j];
+            }, &dl_hi, &len_hi);
+            if (dl_hi != dl_lo || len_hi != len_lo) {      // the order decides: onto the hit list
+                int32_t at = 0;
+                if (wave_leader()) at = (int32_t)atomic_add64(hit_count, 1);
+                at = wave_bcast_i32(at, 0);
+                if ((uint64_t)at >= hit_cap) { if (wave_leader()) atomic_or32(trouble, bit); return; }      // (more than the scan is launched for: the host route)
+                if (wave_leader()) hits[at] = (int32_t)i;
+                lanes_for(0, n, [&](int j) { hit_owned[(uint64_t)at * (uint64_t)n + j] = 0; hit_present[(uint64_t)at * (uint64_t)n + j] = 0; });
+                return;
+            }
         }
-        bool acc = len >= 2 && n > 1 && S.strand[c * n] != 0;
-        if (acc) {
-            uint32_t bad = 0;
-            const int64_t r0 = P.goff[0] + (int64_t)st[0] + dl;
+        if (verdict_differs(S, P, c, dl_lo, len_lo) && wave_leader()) atomic_or32(trouble, bit);
+    }
+};
+// Work item x = (hit x / chunks, chunk x % chunks of kScanRows recursion rows), the items dealt round robin to a fixed number
+// of wavefronts (the number of hits is only known on the device): every lane takes genomes, holds the candidate's interval there
+// and runs over the chunk's rows -- which of them overlap it (owned), which of those the reference's order had in place (present).
+struct ForeignScan {
+    Store S; const int64_t* rg_start; const int64_t* rg_len; const int64_t* key; const ForeignRead* list;
+    const int32_t* hits; const uint64_t* hit_count; uint64_t hit_cap; uint64_t* hit_owned; uint64_t* hit_present;
+    int64_t rows_first, rows_end, chunks, waves;
+    PM_HD void wave(int64_t w) const {
+        const uint64_t nh = *hit_count < hit_cap ? *hit_count : hit_cap;
+        const int n = S.ngen;
+        for (int64_t x = w; x < (int64_t)nh * chunks; x += waves) {
+            const int64_t slot = x / chunks, chunk = x % chunks;
+            const ForeignRead e = list[hits[slot]];
+            const int64_t c = e.row;
+            const int32_t lon = S.lon[c];
+            const int64_t* rs = rg_start + (int64_t)e.region * n; const int64_t* rl = rg_len + (int64_t)e.region * n;
+            const int64_t r_lo = rows_first + chunk * kScanRows, r_hi = r_lo + kScanRows < rows_end ? r_lo + kScanRows : rows_end;
             lanes_for(0, n, [&](int j) {
-                if (S.strand[c * n + j]) return;
-                const int64_t l1 = (int64_t)st[j] + dl;
-                if (lce_fwd(P, P.goff[2 * j + 1] + (P.glen[j] - l1 - len), r0, len) != len) bad = 1;
+                if (!member_outside(S, c, j, rs, rl)) return;
+                const int64_t a = S.start[c * n + j];
+                uint64_t owned = 0, present = 0;
+                for (int64_t r = r_lo; r < r_hi; r++) {
+                    if (!(S.state[r] & kStAccepted)) continue;
+                    const int64_t ar = (int64_t)S.start[r * n + j] + S.shift[r];
+                    const int64_t lo = ar > a ? ar : a, hi = ar + S.len[r] < a + lon ? ar + S.len[r] : a + lon;
+                    if (lo >= hi) continue;
+                    const uint64_t bits = ((hi - lo) == 64 ? ~0ull : ((1ull << (hi - lo)) - 1)) << (lo - a);
+                    owned |= bits;
+                    if (key[r] < e.key || (r >= e.row0 && r < c)) present |= bits;
+                }
+                if (owned) atomic_or64(&hit_owned[(uint64_t)slot * (uint64_t)n + j], owned);
+                if (present) atomic_or64(&hit_present[(uint64_t)slot * (uint64_t)n + j], present);
             });
-            acc = wave_or_u32(bad) == 0;
         }
-        const bool was = (S.state[c] & kStAccepted) != 0;
-        if ((acc != was || (acc && (dl != S.shift[c] || len != S.len[c]))) && wave_leader()) atomic_or32(trouble, bit);
+    }
+};
+struct ForeignDecideHits {
+    Store S; Layout L; Packed P;
+    const int64_t* rg_start; const int64_t* rg_len;
+    const ForeignRead* list; const uint64_t* masks; const int32_t* hits; const uint64_t* hit_count; uint64_t hit_cap;
+    const uint64_t* hit_owned; const uint64_t* hit_present;
+    uint32_t* trouble; uint32_t bit;
+    PM_HD void wave(int64_t slot) const {
+        const uint64_t nh = *hit_count < hit_cap ? *hit_count : hit_cap;
+        if ((uint64_t)slot >= nh) return;
+        const int32_t i = hits[slot];
+        const ForeignRead e = list[i];
+        const int n = S.ngen;
+        const int64_t c = e.row;
+        const int32_t lon = S.lon[c];
+        const int64_t* rs = rg_start + (int64_t)e.region * n; const int64_t* rl = rg_len + (int64_t)e.region * n;
+        const uint64_t* M = masks + (uint64_t)i * (uint64_t)n;
+        int32_t dl, len;
+        trim_on_masks(n, lon, [&](int j) -> uint64_t {      // the anchors' marks + the recursion's that were in place
+            if (!member_outside(S, c, j, rs, rl)) return M[j];
+            return (img_bits64(L, j, S.start[c * n + j], lon) & ~hit_owned[(uint64_t)slot * (uint64_t)n + j]) | hit_present[(uint64_t)slot * (uint64_t)n + j];
+        }, &dl, &len);
+        if (verdict_differs(S, P, c, dl, len) && wave_leader()) atomic_or32(trouble, bit);
     }
 };
 struct ClusterValidate {
@@ -1030,8 +1154,9 @@ struct ClusterValidate {
     int64_t ncl;      // the launch is xcd_grid(ncl) wavefronts: neighbouring clusters read and mark neighbouring words of the image
     int64_t cl0;      // ... for the clusters [cl0, cl0 + ncl) of the list
     const uint64_t* gate;      // != nullptr: the second stage of a call -- it only runs if the first left *gate at 0 (StageGate)
-    ForeignRead* foreign; uint64_t* foreign_count; uint64_t foreign_cap; uint64_t* foreign_masks;      // candidates with a member outside their region (ForeignResolve)
+    ForeignRead* foreign; uint64_t* foreign_count; uint64_t foreign_cap; uint64_t* foreign_masks;      // candidates with a member outside their region (ForeignBound)
     int64_t* row_key; int32_t generation;      // the order key of every row decided here (order_key)
+    uint8_t* rec;                              // one byte per image word: the recursion has marked there
     PM_HD void wave(int64_t w) const {
         if (gate && *gate) return;
         const int64_t cl = cl0 + xcd_item(w, ncl);
@@ -1058,7 +1183,7 @@ struct ClusterValidate {
                         const int64_t a = S.start[c * n + j];
                         if (a < rs[j] - 1 || a + lon > rs[j] + rl[j] + 1) outside = 1;
                     });
-                    if (wave_or_u32(outside)) {      // noted for ForeignResolve, with what it sees now
+                    if (wave_or_u32(outside)) {      // noted for the resolve, with what it sees now
                         int32_t at = 0;
                         if (wave_leader()) at = (int32_t)atomic_add64(foreign_count, 1);
                         at = wave_bcast_i32(at, 0);
@@ -1081,7 +1206,7 @@ struct ClusterValidate {
                     });
                     if (wave_or_u32(out) && wave_leader()) atomic_or32(trouble, 2u);
                 }
-                if (acc) lanes_for(0, n, [&](int j) { const int64_t a = (int64_t)S.start[c * n + j] + dl; img_set_range(L, j, a, a + len); });
+                if (acc) lanes_for(0, n, [&](int j) { const int64_t a = (int64_t)S.start[c * n + j] + dl; img_set_range(L, j, a, a + len); rec_set(rec, L.word_off[j], L.nbits[j], a, a + len); });
                 if (wave_leader()) {
                     store_coherent32(&S.shift[c], dl); store_coherent32(&S.len[c], len);
                     store_coherent8(&S.state[c], (uint8_t)(((f & kRowBad) ? 0 : kStBuilt) | ((f & (kRowBad | kRowOutside)) ? 0 : kStOk) | (acc ? kStAccepted : 0)));
@@ -1197,7 +1322,7 @@ struct FillBetween {
 // sorted rows of the final MUM list, a head flag per MUM and seven counters; what is not order-free (a tie) is reported in the
 // trouble word and the caller runs its own list logic instead -- nothing on the device has changed by then.
 constexpr uint8_t kChJoin = 0, kChClose = 1;
-constexpr uint64_t kChainTie = 1, kChainOverrun = 2, kChainOrder = 4;      // (kChainOrder: ForeignResolve, queued ahead of the chain kernels)
+constexpr uint64_t kChainTie = 1, kChainOverrun = 2, kChainOrder = 4;      // (kChainOrder: the order check, ForeignBound and the kernels around it, queued ahead of the chain kernels)
 // the header of a chain call (int64 words in device memory)
 enum { kChN1 = 0, kChLcb1, kChLcbDissolved, kChMumDissolved, kChN2, kChLcb2, kChFill, kChTrouble, kChWords };
 // tid = store row (one past the end: 0): accepted?

@@ -1482,7 +1482,7 @@ bool Aligner::extend_generations() {
                     // a reverse-strand member flipped far outside this region (TMum.cpp:33-35) makes the touch test and the trimming
                     // READ layout bits in another cluster's territory, and what is marked there when the reference looks depends on
                     // its order.  The candidate is noted with what it saw and decided again, in the reference's order, when the
-                    // recursion is over (engine/store_kernels.h: ForeignRead / ForeignResolve; fuzz seed 7059 of round 5)
+                    // recursion is over (engine/store_kernels.h: ForeignRead / ForeignBound; fuzz seed 7059 of round 5)
                     AlignerMemory::ForeignCase* noted = nullptr;
                     if (ok && any_reverse && mm.length >= 5) {
                         bool outside = false;

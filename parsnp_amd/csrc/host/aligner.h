@@ -291,7 +291,7 @@ struct AlignerMemory {
     std::vector<Mum> pool_store, candidates;         // storage of Aligner::pool / validate_parallel's candidate records between runs
     std::vector<int> minlen_flat[2]; std::string minlen_expr[2];   // Aligner::min_length for lengths below 2^16, by expression (mums, anchors)
     // extend_generations: a candidate with a reverse-strand member outside its region, with the marks it saw in every genome's
-    // interval and what was decided (engine/store_kernels.h: ForeignRead / ForeignResolve)
+    // interval and what was decided (engine/store_kernels.h: ForeignRead / ForeignBound)
     struct ForeignCase {
         std::vector<int32_t> start; std::vector<uint8_t> fwd; std::vector<uint64_t> mask;
         long length, key; int uid; size_t own_before; const long* rstart; const long* rend;

@@ -156,7 +156,7 @@ def order_case(core, tmp_path, monkeypatch, route):
     outside its region, where another region's MUM gets marked.  The reference processes that other region LATER, trims the
     candidate to 2 bases against the anchors alone and accepts it (201 MUMs found); a generation scheme that happens to have
     marked the other MUM first trims it away (200).  Both routes now note such candidates and decide them again in the
-    reference's order (ForeignResolve / the end of extend_generations): the resident route is left, the host's generations hand
+    reference's order (ForeignBound and the kernels around it / the end of extend_generations): the resident route is left, the host's generations hand
     over to the in-order replay, and the log counts what the reference counts."""
     for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PARSNP_RESIDENT_LOG=str(tmp_path / "route.log")).items():
         monkeypatch.setenv(k, v)
