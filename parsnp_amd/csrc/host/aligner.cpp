@@ -1395,6 +1395,8 @@ bool Aligner::extend_generations() {
     // for every MUM of the recursion (pool[pool0 + i]) the order key of its region, the region and its place among the region's MUMs
     std::vector<AlignerMemory::ForeignCase> foreign_cases;
     std::vector<long> mum_key; std::vector<int> mum_uid, mum_rank;
+    std::vector<std::vector<uint8_t>> rec_words(n);      // one byte per 64 bases of every genome: the recursion has marked there
+    for (size_t g = 0; g < n; g++) rec_words[g].assign(genomes[g].seq.size() / 64 + 2, 0);
     int uid_base = 0;
     for (auto& t : memory_->per_thread) t->foreign.clear();
     int gi = 0;                                  // 0: the first seed alone; 1: the other seeds + its children; 2..: children
@@ -1506,7 +1508,10 @@ bool Aligner::extend_generations() {
                     if (any_reverse)
                         for (size_t j = 0; j < n; j++)
                             if (!mm.fwd[j] && ((long)mm.start[j] < r.start[j] - 1 || mm.end(j) > r.end[j] + 1)) cluster_trouble = 1;
-                    for (size_t j = 0; j < n; j++) layout[j].set_range_atomic(mm.start[j], mm.end(j));
+                    for (size_t j = 0; j < n; j++) {
+                        layout[j].set_range_atomic(mm.start[j], mm.end(j));
+                        for (long w = (long)mm.start[j] >> 6; w <= (mm.end(j) - 1) >> 6; w++) rec_words[j][(size_t)w] = 1;
+                    }
                     mm.slength = r.slength;
                     o.accepted.push_back(mm);
                 }
@@ -1557,39 +1562,64 @@ bool Aligner::extend_generations() {
     }
     // The noted candidates again, with the marks the reference's order (the first seed, then always the waiting region with the
     // smallest reference start) had in place in the genomes of their outside members: the anchors' and those of the recursion's
-    // MUMs from regions with a smaller (reference start, generation), or earlier in the same region.  A different verdict, shift
-    // or length: the order shows, the in-order replay decides the run.
+    // MUMs from regions with a smaller (reference start, generation), or earlier in the same region.  As on the device
+    // (engine/store_kernels.h: ForeignBound): first with a lower and an upper bound of those marks -- the final marks outside /
+    // inside the 64-base words the recursion has touched; trimming is monotone, so equal results, or less than two bases left
+    // with the lower bound, settle the candidate -- and only for the others the exact marks, from a walk over the recursion's
+    // MUMs.  A different verdict, shift or length: the order shows, the in-order replay decides the run.
     const long ncases = (long)foreign_cases.size();
     int differs = 0;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(| : differs) if (ncases > 8)
     for (long ci = 0; ci < ncases; ci++) {
         const AlignerMemory::ForeignCase& e = foreign_cases[(size_t)ci];
-        long dl = 0, len = e.length;
-        for (size_t j = 0; j < n && len > 0; j++) {
-            uint64_t mk = e.mask[j];
+        auto outside = [&](size_t j) { return !e.fwd[j] && ((long)e.start[j] < e.rstart[j] - 1 || (long)e.start[j] + e.length > e.rend[j] + 1); };
+        auto rec_bits = [&](size_t j) {      // the bases of the member's interval that lie in a word the recursion has marked
+            uint64_t m = 0;
+            for (long t = 0; t < e.length; ) {
+                const long p = (long)e.start[j] + t, span = std::min<long>(64 - (p & 63), e.length - t);
+                if (rec_words[j][(size_t)p >> 6]) m |= (span == 64 ? ~0ull : ((1ull << span) - 1)) << t;
+                t += span;
+            }
+            return m;
+        };
+        auto exact = [&](size_t j) {         // the anchors' marks + the recursion's that the reference's order had in place
             const long a = e.start[j];
-            if (!e.fwd[j] && (a < e.rstart[j] - 1 || a + e.length > e.rend[j] + 1)) {
-                uint64_t owned = 0, present = 0;
-                for (size_t k = pool0; k < pool.size(); k++) {
-                    const long ar = pool[k].start[j], lo = std::max(ar, a), hi = std::min(ar + pool[k].length, a + e.length);
-                    if (lo >= hi) continue;
-                    const uint64_t bits = ((hi - lo) == 64 ? ~0ull : ((1ull << (hi - lo)) - 1)) << (lo - a);
-                    owned |= bits;
-                    const size_t i = k - pool0;
-                    if (mum_key[i] < e.key || (mum_uid[i] == e.uid && (size_t)mum_rank[i] < e.own_before)) present |= bits;
+            uint64_t owned = 0, present = 0;
+            for (size_t k = pool0; k < pool.size(); k++) {
+                const long ar = pool[k].start[j], lo = std::max(ar, a), hi = std::min(ar + pool[k].length, a + e.length);
+                if (lo >= hi) continue;
+                const uint64_t bits = ((hi - lo) == 64 ? ~0ull : ((1ull << (hi - lo)) - 1)) << (lo - a);
+                owned |= bits;
+                const size_t i = k - pool0;
+                if (mum_key[i] < e.key || (mum_uid[i] == e.uid && (size_t)mum_rank[i] < e.own_before)) present |= bits;
+            }
+            return (layout[j].bits64(a, e.length) & ~owned) | present;
+        };
+        auto trim_with = [&](int how, long* pdl, long* plen) {      // how: 0 lower bound, 1 upper bound, 2 exact
+            long dl = 0, len = e.length;
+            for (size_t j = 0; j < n && len > 0; j++) {
+                uint64_t mk = e.mask[j];
+                if (outside(j)) mk = how == 2 ? exact(j) : how == 1 ? layout[j].bits64(e.start[j], e.length) : (layout[j].bits64(e.start[j], e.length) & ~rec_bits(j));
+                const uint64_t x = (mk >> dl) & (len == 64 ? ~0ull : ((1ull << len) - 1));
+                if (!x) continue;
+                long l = ~x ? __builtin_ctzll(~x) : 64;
+                if (l > len) l = len;
+                long rr = 0;
+                if (l < len) {
+                    const uint64_t y = ~(x << (64 - len));
+                    rr = y ? __builtin_clzll(y) : 64;
+                    if (rr > len - l) rr = len - l;
                 }
-                mk = (layout[j].bits64(a, e.length) & ~owned) | present;
+                dl += l; len -= l + rr;
             }
-            const uint64_t x = (mk >> dl) & (len == 64 ? ~0ull : ((1ull << len) - 1));
-            long l = ~x ? __builtin_ctzll(~x) : 64;
-            if (l > len) l = len;
-            long rr = 0;
-            if (l < len) {
-                const uint64_t y = ~(x << (64 - len));
-                rr = y ? __builtin_clzll(y) : 64;
-                if (rr > len - l) rr = len - l;
-            }
-            dl += l; len -= l + rr;
+            *pdl = dl; *plen = len;
+        };
+        long dl, len;
+        trim_with(0, &dl, &len);
+        if (len >= 2) {
+            long dh, lh;
+            trim_with(1, &dh, &lh);
+            if (dh != dl || lh != len) trim_with(2, &dl, &len);
         }
         bool acc = len >= 2 && n > 1 && e.fwd[0];
         if (acc) {

@@ -329,7 +329,6 @@ public:
     bool resident_failed() const { return res_.failed; }
     const std::string& resident_why() const { return res_.why; }
     bool resident_chain();                               // phases C-D from the device (resident.cpp); false: the caller runs them
-    void materialize_keys() {}                           // (test hook: key0() of every MUM of the list is valid on both routes once the recursion has returned)
     void materialize();                                  // rows of the LCBs' MUMs (and the layout, for parsnp.unalign) for the writer; no-op on the host route
     long key0(int idx) const { return res_.active ? (long)res_.start0[(size_t)idx] : (long)pool[(size_t)idx].start[0]; }      // reference start of a MUM
 

@@ -202,7 +202,6 @@ StepReport CoreRun::step_once(bool resident) {
     r.mums_found = found;
     if (const char* dump = test_hook("PARSNP_DUMP_MUMS")) {      // test hook: the MUM list after the recursion, (reference start, length) in list order
         if (FILE* f = fopen(dump, "w")) {
-            if (a.resident_active()) a.materialize_keys();
             for (int idx : a.mums) {
                 fprintf(f, "%ld %ld", a.key0(idx), a.pool[(size_t)idx].length);
                 if (a.pool[(size_t)idx].start) for (size_t j = 0; j < a.n; j++) fprintf(f, " %d%c", a.pool[(size_t)idx].start[j], a.pool[(size_t)idx].fwd[j] ? '+' : '-');
