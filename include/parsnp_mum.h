@@ -145,6 +145,8 @@ int64_t pm_result_table_id(const pm_result* r);
  *   "master_seg"   0: Master.EP by the round-4 kernel (every lane tests every staged event: MasterEP) instead of from the genomes'
  *                  segments (MasterEPSeg; default 1; the same values, tests compare the two)
  *   "stage_gate"   != 0: the second stage of a two-stage pm_store_validate is never run (tests: the caller forms it again)
+ *   "cluster_unsure" != 0: pm_store_validate's collinear test of the clusters reports failure although they are in order (tests:
+ *                  the exact test -- extents ORed into a scratch image -- must find them disjoint and the same bytes result)
  *   "chain_tie"    != 0: pm_store_chain_begin reports two MUMs with one reference start although there is none (tests: the
  *                  caller's own list logic must give the same bytes)
  *   "timing"       0: no HIP events around the phases of a call (pm_last_timing then reports counts only)
@@ -205,8 +207,9 @@ int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsiz
  * against the whole genome) was accepted there; bit 2 (4): a region with 2^22 candidates or more, or more candidates with a member
  * outside their region (or one longer than 64 bases) than the engine notes for pm_store_order_check; bit 3 (8): the clusters are
  * not disjoint in some genome.  The caller clusters on the reference only;
- * disjointness in the query genomes is checked by the call itself (clusters in reference order must follow each other, with a
- * base between, in every genome).  On trouble the caller must discard the run and take the host route.
+ * disjointness in the query genomes is checked by the call itself (clusters in reference order follow each other, with a
+ * base between, in every genome -- or, where a genome holds them in another order, their extents are pairwise disjoint with a
+ * base between: nothing is validated before that is known).  On trouble the caller must discard the run and take the host route.
  * info_count > 0: the per-row scalars (pm_store_info) of store rows [info_first, info_first + info_count) -- the candidates
  * just decided -- come back with the same round trip.
  * stage_first > 0: TWO generations in one call.  Clusters [0, stage_first) are validated first (the first pushed seed, which the

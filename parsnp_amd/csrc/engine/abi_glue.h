@@ -324,6 +324,7 @@ int pm_last_timing(const pm_session* cs, int* count, const char** names, float* 
     s->timing.push_back(pm::PhaseTime{"n_candidates", (float)s->engine->last_candidates});
     s->timing.push_back(pm::PhaseTime{"n_accepted", (float)s->engine->last_accepted});
     s->timing.push_back(pm::PhaseTime{"n_grouped", (float)s->engine->last_grouped});
+    if (s->engine->exact_cluster_tests) { s->timing.push_back(pm::PhaseTime{"exact_cluster_tests", (float)s->engine->exact_cluster_tests}); s->engine->exact_cluster_tests = 0; }      // generations whose clusters only the exact test found disjoint (inversions)
     s->timing.push_back(pm::PhaseTime{"events", (float)s->engine->last_events});      // a count too: R-unique maximal matches the event search appended (16 B each)
     int capn = *count, n = 0;
     for (const auto& t : s->timing) { if (n < capn) { names[n] = t.name; ms[n] = t.ms; } n++; }

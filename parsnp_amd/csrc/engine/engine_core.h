@@ -929,7 +929,7 @@ public:
     // pairwise disjoint in every genome: candidates settled against the image and marked, children appended to the region store.
     int store_validate(const int32_t* regions, const int64_t* row0, const int32_t* cnt, int64_t nreg, const int64_t* cluster_first, int64_t ncl, int32_t q,
                        uint32_t* trouble, std::vector<RegInfo>* kids, std::vector<int32_t>* kid_ids, int64_t info_first = 0, int64_t info_count = 0, RowInfo* info = nullptr,
-                       int64_t stage_first = 0, int32_t* second_stage_ran = nullptr, int32_t generation = 1) {
+                       int64_t stage_first = 0, int32_t* second_stage_ran = nullptr, int32_t generation_no = 1) {
         // stage_first > 0: clusters [0, stage_first) are a generation of their own (the first pushed seed, which the reference
         // processes before anything is sorted); the rest -- the generation the caller formed on the assumption that the first leaves
         // no child region -- runs behind it in the same call if that held, and is left untouched if not (*second_stage_ran = 0)
@@ -955,36 +955,62 @@ public:
         ensure(d_v_row0, (size_t)nreg); ensure(d_v_first, (size_t)ncl + 1); ensure(d_list, (size_t)nreg); ensure(d_list2, (size_t)nreg); ensure(d_rg_count, 4);
         be.h2d_staged(d_v_row0.p, s_row0, 8 * (size_t)nreg); be.h2d_staged(d_v_first.p, s_first, 8 * ((size_t)ncl + 1));
         be.h2d_staged(d_list.p, s_reg, 4 * (size_t)nreg); be.h2d_staged(d_list2.p, s_cnt, 4 * (size_t)nreg);
-        uint64_t head[3] = {(uint64_t)rg_count, 0, 0};       // [0] the region counter, [1] the trouble word, [2] the gate of the second stage
-        be.h2d(d_rg_count.p, head, 24);
-        be.mark("validate");
-        be.launch_wave("clusters_disjoint", ncl - 1, ClustersDisjoint{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, (uint32_t*)(d_rg_count.p + 1), stage_first});
-        const int64_t na = stage_first > 0 ? stage_first : ncl;
         // candidates with a member outside their region are noted for store_order_check (store_kernels.h: ForeignRead); the counter is
         // zeroed by settle_launch, once per anchor list
         foreign_cap = std::min<size_t>((size_t)1 << 16, ((size_t)32 << 20) / (8 * (size_t)ngen));
         ensure(d_foreign, foreign_cap); ensure(d_foreign_masks, foreign_cap * (size_t)ngen); ensure(d_foreign_count, 2);
         ensure_keep(d_ms_key, (size_t)ms_count, (size_t)ms_key_rows); ms_key_rows = ms_count;
-        be.launch_wave("cluster_validate", xcd_grid(na),
-                       ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
-                                       d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), na, 0, nullptr,
-                                       d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation, d_recwords.p});
-        if (stage_first > 0) {
-            be.launch("stage_gate", 1, StageGate{d_rg_count.p, (uint64_t)rg_count, force_gate ? 1 : 0});
-            be.launch_wave("cluster_validate", xcd_grid(ncl - na),
-                           ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
-                                           d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), ncl - na, na, d_rg_count.p + 2,
-                                           d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation + 1, d_recwords.p});
-        }
-        if (info_count > 0) {      // the scalars of the candidates just decided, with the same round trip
+        const int64_t na = stage_first > 0 ? stage_first : ncl;
+        uint64_t head[4] = {(uint64_t)rg_count, 0, 0, 0};       // [0] the region counter, [1] the trouble word, [2] the gate of the second stage, [3] collinear test failed
+        if (info_count > 0) {      // the scalars of the candidates just decided come back with the same round trip
             if (info_first < 0 || info_first + info_count > ms_count) { error = "rows outside the MUM store"; return -2; }
             ensure(d_rowinfo, (size_t)info_count);
-            be.launch("store_info", info_count, StoreInfoOut{store_view(), info_first, d_rowinfo.p});
         }
-        be.mark(nullptr);
-        if (info_count > 0) be.d2h_async(info, d_rowinfo.p, sizeof(RowInfo) * (size_t)info_count);
-        be.d2h_async(&foreign_seen, d_foreign_count.p, 8);
-        be.d2h(head, d_rg_count.p, 24);
+        auto generation = [&](bool collinear_test) {      // the launches of the call and its one wait
+            be.h2d(d_rg_count.p, head, 32);
+            if (collinear_test) be.launch_wave("clusters_disjoint", ncl - 1, ClustersDisjoint{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, d_rg_count.p + 3, stage_first, force_unsure ? 1 : 0});
+            be.launch_wave("cluster_validate", xcd_grid(na),
+                           ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
+                                           d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), na, 0, nullptr, d_rg_count.p + 3,
+                                           d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation_no, d_recwords.p});
+            if (stage_first > 0) {
+                be.launch("stage_gate", 1, StageGate{d_rg_count.p, (uint64_t)rg_count, force_gate ? 1 : 0});
+                be.launch_wave("cluster_validate", xcd_grid(ncl - na),
+                               ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
+                                               d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), ncl - na, na, d_rg_count.p + 2, d_rg_count.p + 3,
+                                               d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation_no + 1, d_recwords.p});
+            }
+            if (info_count > 0) be.launch("store_info", info_count, StoreInfoOut{store_view(), info_first, d_rowinfo.p});
+            be.mark(nullptr);
+            if (info_count > 0) be.d2h_async(info, d_rowinfo.p, sizeof(RowInfo) * (size_t)info_count);
+            be.d2h_async(&foreign_seen, d_foreign_count.p, 8);
+            be.d2h(head, d_rg_count.p, 32);
+        };
+        be.mark("validate");
+        generation(true);
+        if (head[3] != 0) {
+            // some genome does not hold the clusters in reference order (an inversion): nothing has been validated (ClusterValidate
+            // saw the word).  The exact question, stage by stage -- are the clusters' extents pairwise disjoint with a base between?
+            const size_t words = layout_geometry();
+            const uint64_t* before = d_once.p;
+            ensure(d_once, words);
+            if (d_once.p != before) be.memset(d_once.p, 0, 8 * words);      // (kept all zero between calls)
+            head[0] = (uint64_t)rg_count; head[1] = head[2] = head[3] = 0;
+            be.mark("validate");
+            be.h2d(d_rg_count.p, head, 32);
+            for (int stage = 0; stage < (stage_first > 0 ? 2 : 1); stage++) {
+                const int64_t c0 = stage == 0 ? 0 : na, cn = stage == 0 ? na : ncl - na;
+                if (cn < 2) continue;
+                for (int mark = 1; mark >= 0; mark--)
+                    be.launch_wave("clusters_collide", cn, ClustersCollide{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), (uint32_t*)(d_rg_count.p + 1), c0, mark});
+            }
+            be.d2h(head, d_rg_count.p, 32);
+            if (!(head[1] & 8)) {      // disjoint: the generation, without the collinear test
+                exact_cluster_tests++;
+                head[0] = (uint64_t)rg_count; head[1] = head[2] = head[3] = 0;
+                generation(false);
+            } else be.mark(nullptr);
+        }
         *trouble = (uint32_t)head[1];
         if (second_stage_ran) *second_stage_ran = stage_first > 0 && head[2] == 0 ? 1 : 0;
         if (head[0] > cap) { error = "region store overflow"; return -4; }
@@ -1236,6 +1262,8 @@ public:
     bool master_seg = true;               // Master.EP from the genomes' segments (MasterEPSeg); false: every lane against every staged event (MasterEP)
     bool force_gate = false;              // (tests) the second stage of a two-stage store_validate never runs
     bool force_chain_tie = false;         // (tests) store_chain_begin reports two MUMs with one reference start
+    bool force_unsure = false;            // (tests) store_validate's collinear test of the clusters reports failure: the exact test decides
+    int64_t exact_cluster_tests = 0;      // generations validated after ClustersCollide found their clusters disjoint
     bool phase_timing = true;             // HIP events around the phases of a call (pm_last_timing); off: the marks cost nothing
     bool tune(const std::string& key, int64_t value) {
         if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
@@ -1244,6 +1272,7 @@ public:
         if (key == "master_seg") { master_seg = value != 0; return true; }
         if (key == "stage_gate") { force_gate = value != 0; return true; }
         if (key == "chain_tie") { force_chain_tie = value != 0; return true; }
+        if (key == "cluster_unsure") { force_unsure = value != 0; return true; }
         if (key == "timing") { phase_timing = value != 0; be.timing_on = phase_timing; return true; }
         if (key == "group_small") { group_small = value != 0; return true; }
         if (key == "work_budget" && value > 0) { work_budget = value; return true; }

@@ -898,14 +898,19 @@ struct GroupedBounds {
 // waiting in its cluster (bit 0), a reverse-strand member that passes the sequence check outside its region (bit 1), a
 // region with more candidates than the key holds (bit 2).
 // Are the clusters of a generation pairwise disjoint in EVERY genome (Aligner::disjoint_clusters)?  Collinear genomes hold them
-// in reference order: then it is "every cluster starts after its predecessor ends, with a base between" in every genome.  A
-// genome in which that fails for some pair is reported (trouble bit 3) -- the clusters may still be disjoint there in another
-// order, which the host route's exact test decides.  One wavefront per cluster (from the second on).
+// in reference order: then it is "every cluster starts after its predecessor ends, with a base between" in every genome
+// (ClustersDisjoint: one wavefront per cluster from the second on).  A genome in which that fails for some pair -- an inverted
+// block holds its clusters in the opposite order -- raises *unsure: nothing of the generation is validated (ClusterValidate looks
+// at the word), and the engine puts the exact question: ClustersCollide ORs every cluster's extent [lo, hi + 2) into a scratch
+// image (all zero between calls) and two clusters whose extents share a bit -- they overlap, touch, or have no base between --
+// are trouble bit 3; ClustersClear wipes the scratch image; then the generation is validated as usual.
 struct ClustersDisjoint {
-    int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first; uint32_t* trouble;
+    int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first; uint64_t* unsure;
     int64_t stage_first;      // the first cluster of the call's second stage (0: one stage): it runs after its predecessor, not beside it
+    int force;                // (tests) raise *unsure whatever the clusters look like
     PM_HD void wave(int64_t w) const {
         const int64_t cl = w + 1;
+        if (force) { if (wave_leader()) atomic_or64(unsure, 1ull); return; }
         if (cl == stage_first) return;
         const int64_t p0 = cluster_first[cl - 1], p1 = cluster_first[cl], c1 = cluster_first[cl + 1];
         uint32_t bad = 0;
@@ -915,7 +920,37 @@ struct ClustersDisjoint {
             for (int64_t x = p1; x < c1; x++) { const int64_t r = now_region[x]; const int64_t a = rg_start[r * ngen + j]; if (a < lo) lo = a; }
             if (lo <= hi + 1) bad = 1;      // touching counts too
         });
-        if (wave_or_u32(bad) && wave_leader()) atomic_or32(trouble, 8u);
+        if (wave_or_u32(bad) && wave_leader()) atomic_or64(unsure, 1ull);
+    }
+};
+// one wavefront per cluster of one stage of the call (clusters [cl0, cl0 + ncl)): mark = 1 the extents into the scratch image,
+// a bit found set is a collision; mark = 0 the words of the extents back to zero
+struct ClustersCollide {
+    int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first;
+    Layout scratch; uint32_t* trouble; int64_t cl0; int mark;
+    PM_HD void wave(int64_t w) const {
+        const int64_t cl = cl0 + w;
+        const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
+        uint32_t bad = 0;
+        lanes_for(1, ngen, [&](int j) {
+            int64_t hi = -1, lo = (int64_t)1 << 62;
+            for (int64_t x = p0; x < p1; x++) {
+                const int64_t r = now_region[x]; const int64_t a = rg_start[r * ngen + j], e = a + rg_len[r * ngen + j];
+                if (a < lo) lo = a;
+                if (e > hi) hi = e;
+            }
+            int64_t a = lo < 0 ? 0 : lo, b = hi + 2 > scratch.nbits[j] ? scratch.nbits[j] : hi + 2;
+            uint64_t* wd = scratch.image + scratch.word_off[j];
+            while (a < b) {
+                const int f = (int)(a & 63);
+                const int64_t span = (64 - f) < (b - a) ? (64 - f) : (b - a);
+                const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << f;
+                if (mark) { if (atomic_fetch_or64(&wd[a >> 6], mask) & mask) bad = 1; }
+                else wd[a >> 6] = 0;
+                a += span;
+            }
+        });
+        if (mark && wave_or_u32(bad) && wave_leader()) atomic_or32(trouble, 8u);
     }
 };
 // A reverse-strand member is flipped against the WHOLE genome (TMum.cpp:33-35): inside a sub-region it usually lands far outside
@@ -1154,11 +1189,12 @@ struct ClusterValidate {
     int64_t ncl;      // the launch is xcd_grid(ncl) wavefronts: neighbouring clusters read and mark neighbouring words of the image
     int64_t cl0;      // ... for the clusters [cl0, cl0 + ncl) of the list
     const uint64_t* gate;      // != nullptr: the second stage of a call -- it only runs if the first left *gate at 0 (StageGate)
+    const uint64_t* unsure;    // != nullptr: nothing runs while the collinear test of the clusters has not passed (ClustersDisjoint)
     ForeignRead* foreign; uint64_t* foreign_count; uint64_t foreign_cap; uint64_t* foreign_masks;      // candidates with a member outside their region (ForeignBound)
     int64_t* row_key; int32_t generation;      // the order key of every row decided here (order_key)
     uint8_t* rec;                              // one byte per image word: the recursion has marked there
     PM_HD void wave(int64_t w) const {
-        if (gate && *gate) return;
+        if ((gate && *gate) || (unsure && *unsure)) return;
         const int64_t cl = cl0 + xcd_item(w, ncl);
         if (cl >= cl0 + ncl) return;
         const int n = S.ngen;
@@ -1254,7 +1290,7 @@ struct ClusterValidate {
 // word, [2] the gate
 struct StageGate {
     uint64_t* head; uint64_t regions_before; int force;      // force: (tests) close the gate whatever the first stage did
-    PM_HD void operator()(int64_t) const { head[2] = (force || head[0] != regions_before || (uint32_t)head[1] != 0) ? 1 : 0; }
+    PM_HD void operator()(int64_t) const { head[2] = (force || head[0] != regions_before || (uint32_t)head[1] != 0 || head[3] != 0) ? 1 : 0; }
 };
 
 // ------------------------------------------------------------------------------------------ chaining

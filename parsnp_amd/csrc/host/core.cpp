@@ -118,6 +118,7 @@ int CoreRun::open(const std::string& ini_path) {
     if (const char* v = test_hook("PM_GROUP_SMALL")) (void)pm_session_tune(session, "group_small", atol(v));
     if (const char* v = test_hook("PM_MASTER_SEG")) (void)pm_session_tune(session, "master_seg", atol(v));
     if (const char* v = test_hook("PM_STAGE_GATE")) (void)pm_session_tune(session, "stage_gate", atol(v));
+    if (const char* v = test_hook("PM_CLUSTER_UNSURE")) (void)pm_session_tune(session, "cluster_unsure", atol(v));
     if (const char* v = test_hook("PM_CHAIN_TIE")) (void)pm_session_tune(session, "chain_tie", atol(v));
     upload_s = now_s() - t1;
     return 0;
@@ -170,7 +171,11 @@ StepReport CoreRun::step() {
     (void)pm_session_traffic(session, &h1, &d1);
     r.h2d_bytes = (double)(h1 - h0); r.d2h_bytes = (double)(d1 - d0);
     if (const char* log = test_hook("PARSNP_RESIDENT_LOG"))      // test hook: which route every step took
-        if (FILE* f = fopen(log, "a")) { fprintf(f, "resident=%ld retry=%ld chain=%ld anchors=%ld mums=%ld why=%s\n", r.host.resident, r.host.resident_retry, r.host.device_chain, r.anchors, r.mums, why.c_str()); fclose(f); }
+        if (FILE* f = fopen(log, "a")) {
+            double exact = 0;
+            for (const auto& kv : r.host.engine_ms) if (kv.first == "exact_cluster_tests") exact = kv.second;
+            fprintf(f, "resident=%ld retry=%ld chain=%ld exact=%ld anchors=%ld mums=%ld why=%s\n", r.host.resident, r.host.resident_retry, r.host.device_chain, (long)exact, r.anchors, r.mums, why.c_str()); fclose(f);
+        }
     return r;
 }
 

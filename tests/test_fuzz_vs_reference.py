@@ -151,6 +151,36 @@ def test_inversions_on_the_resident_route_on_gpu(tmp_path, monkeypatch, variant)
     inversions_on_the_resident_route(CORE_HOOKS_BIN, tmp_path, monkeypatch, variant)
 
 
+def clusters_in_another_order(core, tmp_path, monkeypatch):
+    """a population at 3 % divergence with two long inversions (30 kb of 150 kb in genome 2, 37 kb in genome 4): the recursion's
+    seed regions inside an inverted block form several clusters, and the inverted genome holds them in the OPPOSITE order.  The
+    collinear test of a generation's clusters (ClustersDisjoint) fails there; round 5's exact test (ClustersCollide: every cluster's
+    extent ORed into a scratch image, a bit found set = two clusters meet) finds them disjoint and the generation runs on the
+    device: the reference binary's bytes, the route kept"""
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PARSNP_RESIDENT_LOG=str(tmp_path / "route.log")).items():
+        monkeypatch.setenv(k, v)
+    n = 150_000
+    ref, gs = synth.population(seed=78, n=n, n_genomes=6, div=0.03, indel_frac=0.0)
+    gs = [bytearray(g) for g in gs]
+    for k, (a, b) in ((1, (n // 4, n // 4 + n // 5)), (3, (n // 2, n // 2 + n // 4))):
+        gs[k][a:b] = oracles.revcomp(bytes(gs[k][a:b]))
+    rp, qs = synth.write_set(str(tmp_path / "in"), ref, [bytes(g) for g in gs])
+    a = run(REFBIN, rp, qs, str(tmp_path / "ref"), dict(threads=3))
+    b = run(core, rp, qs, str(tmp_path / "mine"), dict(threads=3))
+    assert a == b
+    route = open(str(tmp_path / "route.log")).read()
+    assert "resident=1" in route and "retry=0" in route and "exact=0" not in route, route
+
+
+def test_clusters_in_another_order(emu, tmp_path, monkeypatch):
+    clusters_in_another_order(emu[1], tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_clusters_in_another_order_on_gpu(tmp_path, monkeypatch):
+    clusters_in_another_order(CORE_HOOKS_BIN, tmp_path, monkeypatch)
+
+
 def order_case(core, tmp_path, monkeypatch, route):
     """seed 7059 of round 5's campaign: a recursion candidate (7 bases, one reverse-strand member) whose flipped member lies 20 kb
     outside its region, where another region's MUM gets marked.  The reference processes that other region LATER, trims the
