@@ -30,7 +30,7 @@ EOF
 bad=0
 for name in pop6x200k rearr6x300k; do
     want=$(python -c "import json; print(json.load(open('$REPO/tests/golden/e2e.json'))['$name']['xmfa_md5'])")
-    for route in "DEFAULT=1" "PM_FLAGGED_DIV=1" "PARSNP_NO_DEVICE_CHAIN=1 PARSNP_SPLIT_SETTLE=1 PARSNP_ONE_STAGE=1" "PM_STAGE_GATE=1 PM_CHAIN_TIE=1" "PARSNP_NO_RESIDENT=1" "PARSNP_NO_RESIDENT=1 PARSNP_SEQUENTIAL_REPLAY=1"; do
+    for route in "DEFAULT=1" "PM_FLAGGED_DIV=1" "PARSNP_NO_DEVICE_CHAIN=1 PARSNP_SPLIT_SETTLE=1 PARSNP_ONE_STAGE=1" "PM_STAGE_GATE=1 PM_CHAIN_TIE=1" "PM_CLUSTER_UNSURE=1 PARSNP_NO_DEVICE_CHAIN=1" "PARSNP_NO_RESIDENT=1" "PARSNP_NO_RESIDENT=1 PARSNP_SEQUENTIAL_REPLAY=1"; do
         for san in asan tsan; do
             cd $W/$name/out; rm -f parsnpAligner.xmfa
             extra=""; [ $san = tsan ] && extra="OMP_THREAD_LIMIT=1"
