@@ -596,7 +596,8 @@ def main():
                 # steps took (resident: MUM rows, layout and regions stayed on the device, parsnp_amd/csrc/host/resident.cpp)
                 "pcie_bytes_per_step": {"h2d": int(sum(r.get("h2d_bytes", 0) for r in reports) / len(reports)),
                                         "d2h": int(sum(r.get("d2h_bytes", 0) for r in reports) / len(reports))},
-                "resident_route": {"steps": sum(int(r.get("resident", 0)) for r in reports), "left_and_repeated_on_the_host_route": sum(int(r.get("resident_retry", 0)) for r in reports)},
+                "resident_route": {"steps": sum(int(r.get("resident", 0)) for r in reports), "left_and_repeated_on_the_host_route": sum(int(r.get("resident_retry", 0)) for r in reports),
+                                   "why_not": next((r.get("resident_why") for r in reversed(reports) if r.get("resident_why")), None)},      # (the last step's reason when a step did not stay on the route)
                 "core_bp_aligned": core_bp_total,
                 "core_bp_in_every_partition": merged_bp,
                 "mums": rep["mums"], "anchors": rep["anchors"], "lcbs": rep["lcbs"],

@@ -63,6 +63,11 @@ const char* pc_step(pc_run* r) {
       << ", \"host_split_s\": {\"validate\": " << s.host.t_validate << ", \"neighbour\": " << s.host.t_neighbour << ", \"key\": " << s.host.t_key
       << ", \"sweep\": " << s.host.t_sweep << ", \"replay\": " << s.host.t_replay << ", \"sort\": " << s.host.t_sort << ", \"unpack\": " << s.host.t_unpack << ", \"pack\": " << s.host.t_pack << "}"
       << ", \"h2d_bytes\": " << (long long)s.h2d_bytes << ", \"d2h_bytes\": " << (long long)s.d2h_bytes << ", \"resident\": " << s.host.resident << ", \"resident_retry\": " << s.host.resident_retry << ", \"device_chain\": " << s.host.device_chain << ", \"tie_fallbacks\": " << s.host.tie_fallbacks << ", \"literal_iterations\": " << s.host.literal_iterations;
+    {
+        std::string why = s.resident_why;      // (plain words; quotes and backslashes would break the JSON)
+        for (char& ch : why) if (ch == '"' || ch == '\\' || (unsigned char)ch < 32) ch = ' ';
+        o << ", \"resident_why\": \"" << why << "\"";
+    }
     for (int which = 0; which < 2; which++) {
         o << ", \"" << (which ? "anchor_ms" : "engine_ms") << "\": {";
         const auto& v = which ? s.anchor_ms : s.engine_ms;

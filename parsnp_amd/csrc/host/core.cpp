@@ -170,6 +170,7 @@ StepReport CoreRun::step() {
     }
     (void)pm_session_traffic(session, &h1, &d1);
     r.h2d_bytes = (double)(h1 - h0); r.d2h_bytes = (double)(d1 - d0);
+    r.resident_why = why;
     if (const char* log = test_hook("PARSNP_RESIDENT_LOG"))      // test hook: which route every step took
         if (FILE* f = fopen(log, "a")) {
             double exact = 0;

@@ -19,6 +19,7 @@ struct StepReport {
     bool mums_found = false;
     double h2d_bytes = 0, d2h_bytes = 0;   // what the engine moved over the host link during the step (pm_session_traffic)
     std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
+    std::string resident_why;   // why the resident route was not taken or was left (empty: it was taken)
     Stats host;
 };
 
