@@ -147,6 +147,8 @@ int64_t pm_result_table_id(const pm_result* r);
  *   "stage_gate"   != 0: the second stage of a two-stage pm_store_validate is never run (tests: the caller forms it again)
  *   "cluster_unsure" != 0: pm_store_validate's collinear test of the clusters reports failure although they are in order (tests:
  *                  the exact test -- extents ORed into a scratch image -- must find them disjoint and the same bytes result)
+ *   "order_debug"  != 0: the order check (pm_store_order_check / pm_store_chain_begin) waits for its kernels and prints to stderr
+ *                  how many candidates it had noted and how many its bounds left to the scan
  *   "chain_tie"    != 0: pm_store_chain_begin reports two MUMs with one reference start although there is none (tests: the
  *                  caller's own list logic must give the same bytes)
  *   "timing"       0: no HIP events around the phases of a call (pm_last_timing then reports counts only)

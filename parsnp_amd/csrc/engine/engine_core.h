@@ -1106,7 +1106,7 @@ public:
                                                          layout_rows, ms_count, chunks, waves});
         be.launch_wave("foreign_decide_hits", (int64_t)kHitCap, ForeignDecideHits{S, L, P, d_rg_start.p, d_rg_len.p, d_foreign.p, d_foreign_masks.p, d_hits.p, d_hit_count.p, (uint64_t)kHitCap,
                                                                                  d_hit_owned.p, d_hit_present.p, word, bit});
-        if (getenv("PM_DEBUG_ORDER")) {      // (debugging aid: waits for the queue)
+        if (order_debug) {      // (pm_session_tune "order_debug": waits for the queue and says what the check had to do)
             uint64_t nh = 0;
             be.d2h(&nh, d_hit_count.p, 8);
             fprintf(stderr, "[order check] %ld noted candidates, %ld left to the scan (launched for %ld), %ld recursion rows\n", (long)cnt, (long)nh, (long)kHitCap, (long)rows);
@@ -1263,6 +1263,7 @@ public:
     bool force_gate = false;              // (tests) the second stage of a two-stage store_validate never runs
     bool force_chain_tie = false;         // (tests) store_chain_begin reports two MUMs with one reference start
     bool force_unsure = false;            // (tests) store_validate's collinear test of the clusters reports failure: the exact test decides
+    bool order_debug = false;             // the order check prints its counts (noted candidates, candidates left to the scan) to stderr
     int64_t exact_cluster_tests = 0;      // generations validated after ClustersCollide found their clusters disjoint
     bool phase_timing = true;             // HIP events around the phases of a call (pm_last_timing); off: the marks cost nothing
     bool tune(const std::string& key, int64_t value) {
@@ -1273,6 +1274,7 @@ public:
         if (key == "stage_gate") { force_gate = value != 0; return true; }
         if (key == "chain_tie") { force_chain_tie = value != 0; return true; }
         if (key == "cluster_unsure") { force_unsure = value != 0; return true; }
+        if (key == "order_debug") { order_debug = value != 0; return true; }
         if (key == "timing") { phase_timing = value != 0; be.timing_on = phase_timing; return true; }
         if (key == "group_small") { group_small = value != 0; return true; }
         if (key == "work_budget" && value > 0) { work_budget = value; return true; }

@@ -7,7 +7,7 @@ O=gpurun_out/r5
 timeout 600 python -m pytest tests/test_fuzz_vs_reference.py -m gpu -x -q -k "order_of_reads or resident_route_on_gpu or inversions" 2>&1 | tail -3
 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "resident_route or twins" 2>&1 | tail -3
 timeout 600 python -m pytest tests/test_gpu_big.py -m gpu -x -q -k "bact200" 2>&1 | tail -3
-PM_DEBUG_ORDER=1 timeout 200 python bench.py --steps 2 --warmup 1 --cpu-sample 0 --other-configs off 2>&1 >/dev/null | grep "order check" | tail -2
+PARSNP_BENCH_LOG=$O/order.log timeout 200 python bench.py --steps 2 --warmup 1 --cpu-sample 0 --other-configs off --tune order_debug=1 > /dev/null 2>&1; grep "order check" $O/order.log | tail -1
 timeout 300 python bench.py --steps 60 --warmup 5 --cpu-sample 0 --other-configs off > $O/bench_order.json 2> $O/bench_order.err; tail -1 $O/bench_order.json | python scripts/benchline.py | head -2
 bash scripts/profile_stats.sh > $O/stats.log 2>&1; python - <<'PY'
 import csv,re

@@ -20,4 +20,4 @@ PARSNP_DEBUG_TIMERS=1 timeout 400 python bench.py --workload rearr500 --steps 2 
 grep -E "^\[(anchors|extend|lcb|replay|sweep|generation 1\]|filter)" $O/rearr500_laps.err | tail -40 > gpurun_out/profiles_r05/rearr500_laps.txt; cp gpurun_out/profiles_r05/rearr500_laps.txt profiles/r05/
 # the product's sources with the hooks compiled in, side by side with the reference binary, final kernels
 PARSNP_FUZZ_CORE=hip timeout 600 python scripts/fuzz_campaign.py 6500 6580 4 > gpurun_out/profiles_r05/fuzz_hip_final.log 2>&1; tail -1 gpurun_out/profiles_r05/fuzz_hip_final.log
-PM_DEBUG_ORDER=1 timeout 200 python bench.py --steps 2 --warmup 1 --cpu-sample 0 --other-configs off > /dev/null 2> $O/order.err; grep "order check" $O/order.err | tail -1 | tee gpurun_out/profiles_r05/order_check_counts.txt
+PARSNP_BENCH_LOG=$O/order.log timeout 200 python bench.py --steps 2 --warmup 1 --cpu-sample 0 --other-configs off --tune order_debug=1 > /dev/null 2> $O/order.err; grep "order check" $O/order.log | tail -1 | tee gpurun_out/profiles_r05/order_check_counts.txt
