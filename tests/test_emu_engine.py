@@ -333,6 +333,19 @@ def test_mumi_coverage(libs):
     check_mumi(libs[0], libs[1], 300, 8)
 
 
+def test_order_check_pieces(tmp_path):
+    """tests/emu/order_check.cpp against the product's store_kernels.h: trimming on 64-bit masks (what the order check decides a noted
+    candidate with) leaves the (shift, length) that settle_row leaves on the image the masks were read from, and both equal a
+    genome-by-genome restatement of Aligner::trim; marks that nest give intervals that nest (the bounds of ForeignBound); the mask
+    readers against base-by-base loops; order_key orders by (reference start, generation)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "order_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-w", os.path.join(root, "tests", "emu", "order_check.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
 def test_scan_operator_and_xcd_numbering(tmp_path):
     """tests/emu/scan_check.cpp against the product's kernels.h: the join of the wavefront scan is associative and a 64-lane
     segmented scan with the kernel's update rule (rounds, carry of the last lane) gives every event the state of the sequential
