@@ -204,25 +204,32 @@ int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsiz
  * found pairwise disjoint in every genome; the clusters are validated side by side, each in order: candidates settled against
  * the layout and marked (setMums1 second half), the neighbour regions of every new MUM longer than q appended to the region
  * store (:215-254; pm_store_new_regions lists them parent by parent, in push order; one equal to a region still waiting in its
- * cluster is dropped as the work list would, :294-306).  *trouble != 0: the reference's order would show -- bit 0 (1): a child sorts
- * before a region still waiting in its cluster; bit 1 (2): a reverse-strand member outside its region (TMum.cpp:33-35 flips it
- * against the whole genome) was accepted there; bit 2 (4): a region with 2^22 candidates or more, or more candidates with a member
- * outside their region (or one longer than 64 bases) than the engine notes for pm_store_order_check; bit 3 (8): the clusters are
- * not disjoint in some genome.  The caller clusters on the reference only;
- * disjointness in the query genomes is checked by the call itself (clusters in reference order follow each other, with a
- * base between, in every genome -- or, where a genome holds them in another order, their extents are pairwise disjoint with a
- * base between: nothing is validated before that is known).  On trouble the caller must discard the run and take the host route.
+ * cluster is dropped as the work list would, :294-306).  The caller clusters on the reference only; what the other genomes do
+ * to the clusters is the call's business, and its answer is done[c] (n_clusters values): how many regions of cluster c were
+ * processed.  All of them where the cluster meets no EARLIER cluster in any genome (clusters in reference order follow each
+ * other with a base between in every genome -- or, where a genome holds them in another order, their extents are tested
+ * exactly); NONE where it does: the reference (doWork pops the smallest reference start, and children lie inside their parents)
+ * finishes the earlier cluster and everything it leads to first, so the cluster must wait -- the caller keeps its regions on
+ * the work list for the next generation, where the question is put again; the FIRST FEW where a child of a processed region
+ * sorts before (or ties with) the next waiting region of the cluster: the rest waits as well, the next generation sorts it
+ * with the children (:291-292).  Every call processes at least the first region of its first cluster.  done == NULL: a caller
+ * that cannot keep regions waiting -- either case is then reported as trouble (bits 3 / 0) instead.
+ * *trouble != 0: the reference's order would show and the caller must discard the run and take the host route -- bit 1 (2): a
+ * reverse-strand member outside its region (TMum.cpp:33-35 flips it against the whole genome) was accepted there; bit 2 (4): a
+ * region with 2^22 candidates or more, or more candidates with a member outside their region (or one longer than 64 bases) than
+ * the engine notes for pm_store_order_check; bits 0 (1) and 3 (8): only with done == NULL, see above.
  * info_count > 0: the per-row scalars (pm_store_info) of store rows [info_first, info_first + info_count) -- the candidates
  * just decided -- come back with the same round trip.
  * stage_first > 0: TWO generations in one call.  Clusters [0, stage_first) are validated first (the first pushed seed, which the
  * reference processes before its work list is ever sorted, :194-195 before :291-292); clusters [stage_first, n_clusters) -- the
  * generation the caller formed on the assumption that the first stage pushes no child region -- are validated behind them if
- * that held (*second_stage_ran = 1) and are left untouched if not (0: the caller forms the generation again, with the children).
+ * that held (*second_stage_ran = 1) and are left untouched if not (0: the caller forms the generation again, with the children;
+ * their done[] is 0).
  * generation: the number of the (first) generation of the call, 0 = the first pushed seed alone; with the regions' reference
  * starts it orders the regions as the reference's work list does (pm_store_order_check). */
 int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions,
                       const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children,
-                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran, int32_t generation);
+                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran, int32_t generation, int32_t* done);
 /* After the LAST generation.  A candidate with a reverse-strand member outside its region reads layout marks in another
  * cluster's territory, and what is marked there when the reference looks depends on its order (doWork :173-317: the first pushed
  * seed, then always the waiting region with the smallest reference start).  pm_store_validate notes every such candidate with

@@ -138,8 +138,8 @@ const int32_t* pm_store_new_region_ids(const pm_session* s) { (void)s; return 0;
 int pm_store_regions_equal(pm_session* s, const int32_t* a, const int32_t* b, int64_t n, uint8_t* same) { (void)s; (void)a; (void)b; (void)n; (void)same; return PM_EINVAL; }
 int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsize, int64_t n, int64_t* first_row, int64_t* offsets) { (void)s; (void)regions; (void)minsize; (void)n; (void)first_row; (void)offsets; return PM_EINVAL; }
 int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions, const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children,
-                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran, int32_t generation) {
-    (void)s; (void)generation; (void)stage_first; (void)second_stage_ran; (void)regions; (void)row_first; (void)row_count; (void)n_regions; (void)cluster_first; (void)n_clusters; (void)q; (void)trouble; (void)n_children; (void)info_first; (void)info_count; (void)info; return PM_EINVAL;
+                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran, int32_t generation, int32_t* done) {
+    (void)s; (void)generation; (void)done; (void)stage_first; (void)second_stage_ran; (void)regions; (void)row_first; (void)row_count; (void)n_regions; (void)cluster_first; (void)n_clusters; (void)q; (void)trouble; (void)n_children; (void)info_first; (void)info_count; (void)info; return PM_EINVAL;
 }
 int pm_store_settle_seeds(pm_session* s, int64_t table_id, int32_t q, pm_row_info* rows, int64_t* n_regions) { (void)s; (void)table_id; (void)q; (void)rows; (void)n_regions; return PM_EINVAL; }
 int pm_store_order_check(pm_session* s, uint32_t* trouble) { (void)s; (void)trouble; return PM_EINVAL; }

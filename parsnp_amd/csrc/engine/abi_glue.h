@@ -189,12 +189,12 @@ int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsiz
 }
 int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_first, const int32_t* row_count, int64_t n_regions,
                       const int64_t* cluster_first, int64_t n_clusters, int32_t q, uint32_t* trouble, int64_t* n_children,
-                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran, int32_t generation) {
+                      int64_t info_first, int64_t info_count, pm_row_info* info, int64_t stage_first, int32_t* second_stage_ran, int32_t generation, int32_t* done) {
     if (!s || generation < 0 || n_regions < 0 || n_clusters < 0 || (n_regions > 0 && (!regions || !row_first || !row_count || !cluster_first)) || !trouble || !n_children || info_count < 0 || (info_count > 0 && !info)) return fail(PM_EINVAL, "bad argument");
     *n_children = 0;
     try {
         const auto w0 = std::chrono::steady_clock::now();
-        const int rc = s->engine->store_validate(regions, row_first, row_count, n_regions, cluster_first, n_clusters, q, trouble, &s->new_regions, &s->new_region_ids, info_first, info_count, (pm::RowInfo*)info, stage_first, second_stage_ran, generation);
+        const int rc = s->engine->store_validate(regions, row_first, row_count, n_regions, cluster_first, n_clusters, q, trouble, &s->new_regions, &s->new_region_ids, info_first, info_count, (pm::RowInfo*)info, stage_first, second_stage_ran, generation, done);
         if (rc) return fail(rc, s->engine->error);
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
         s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
@@ -217,14 +217,7 @@ int pm_store_fill(pm_session* s, const int32_t* last_of, const int32_t* first_of
 }
 int pm_store_order_check(pm_session* s, uint32_t* trouble) {
     if (!s || !trouble) return fail(PM_EINVAL, "bad argument");
-    try {
-        const auto w0 = std::chrono::steady_clock::now();
-        const int rc = s->engine->store_order_check(trouble);
-        if (rc) return fail(rc, s->engine->error);
-        if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
-        s->call_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
-        return PM_OK;
-    } catch (const std::exception& e) { return fail(PM_EHIP, e.what()); }
+    PM_STORE_CALL(s->engine->store_order_check(trouble))
 }
 int pm_store_chain_begin(pm_session* s, int64_t n_expected, int32_t d, float diag_diff, int64_t c) {
     if (!s) return fail(PM_EINVAL, "bad argument");
@@ -324,7 +317,8 @@ int pm_last_timing(const pm_session* cs, int* count, const char** names, float* 
     s->timing.push_back(pm::PhaseTime{"n_candidates", (float)s->engine->last_candidates});
     s->timing.push_back(pm::PhaseTime{"n_accepted", (float)s->engine->last_accepted});
     s->timing.push_back(pm::PhaseTime{"n_grouped", (float)s->engine->last_grouped});
-    if (s->engine->exact_cluster_tests) { s->timing.push_back(pm::PhaseTime{"exact_cluster_tests", (float)s->engine->exact_cluster_tests}); s->engine->exact_cluster_tests = 0; }      // generations whose clusters only the exact test found disjoint (inversions)
+    if (s->engine->exact_cluster_tests) { s->timing.push_back(pm::PhaseTime{"exact_cluster_tests", (float)s->engine->exact_cluster_tests}); s->engine->exact_cluster_tests = 0; }      // generations validated with the exact test of their clusters (inversions)
+    if (s->engine->deferred_regions) { s->timing.push_back(pm::PhaseTime{"deferred_regions", (float)s->engine->deferred_regions}); s->engine->deferred_regions = 0; }      // regions a generation left waiting (their cluster met an earlier one, or a child sorted first)
     s->timing.push_back(pm::PhaseTime{"events", (float)s->engine->last_events});      // a count too: R-unique maximal matches the event search appended (16 B each)
     int capn = *count, n = 0;
     for (const auto& t : s->timing) { if (n < capn) { names[n] = t.name; ms[n] = t.ms; } n++; }

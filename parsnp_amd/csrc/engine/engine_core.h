@@ -729,13 +729,13 @@ public:
         for (int64_t c = 0; c < rows; c++) { const uint32_t f = anchor_flags_h[(size_t)c]; if (!(f & (kRowBad | kRowOutside)) && (f & kRowDirty)) fl.push_back((int32_t)c); }
         // The cheap running-extent test flags every row of an inverted or moved block, whether it overlaps anything or not: a
         // population with a few inversions has a third of its rows flagged and a handful tangled, a set with 10 % of every one of its
-        // 50 genomes rearranged has all of them flagged and thousands tangled.  The flagged rows that meet no other flagged row cost a
-        // wavefront each, side by side; the TANGLED ones are what one wavefront settles in list order.  So: up to one row in
-        // flagged_div flagged -- every population sample -- the list is taken as it is; above three in four it is declined outright
-        // (the host route's exact overlap test and threads); in between, the tangled rows are counted once the collision test has run
-        // (one 8-byte read-back) and the list is declined if there are more than tangled_max.  flagged_div = 1: never declined (tests).
+        // 500 genomes rearranged has all of them flagged and thousands tangled.  The flagged rows that meet no other flagged row cost a
+        // wavefront each, side by side; the TANGLED ones are settled in list order where they meet one another -- in rounds, every
+        // row as soon as the tangled rows before it that share a 64-base word with it are done (TangleOwner / TangleSettle), and what
+        // kTangleRounds rounds leave by one wavefront.  With more than one row in flagged_div flagged the tangled rows are counted
+        // first (one 8-byte read-back) and the list is declined above tangled_max of them (PM_EAGAIN: the host route's exact overlap
+        // test and threads).  flagged_div = 1: never declined (tests).
         const bool many_flagged = flagged_div > 1 && fl.size() * (size_t)flagged_div > (size_t)rows;
-        if (many_flagged && fl.size() * 4 > (size_t)rows * 3) { error = "too many rows of the list overlap an earlier one (rearranged genomes): the host route decides"; return kAgain; }
         const size_t words = layout_geometry();
         ensure(d_image, words);
         // do the rows that can be accepted untrimmed lie in list order in every genome (none starts before the end of an earlier
@@ -763,12 +763,15 @@ public:
             be.launch("collide_mark", (int64_t)fl.size() * ngen, CollideMark{S, d_list.p, layout_view(d_once.p), d_twice.p});
             be.launch_wave("collide_test", (int64_t)fl.size(), CollideTest{S, d_list.p, layout_view(d_twice.p, false)});
             be.launch("collide_clear", (int64_t)fl.size() * ngen, CollideClear{S, d_list.p, layout_view(d_once.p), d_twice.p});
+            ensure(d_t_rem, 2); ensure(d_t_done, fl.size());
+            {
+                const ClearJob jobs[] = {{d_t_rem.p, 16, 0}, {d_t_done.p, fl.size(), 0}};
+                be.clear_many(jobs, 2);
+            }
+            be.launch("count_tangled", (int64_t)fl.size(), CountTangled{S, d_list.p, d_t_rem.p});
             if (many_flagged) {
-                ensure(d_rg_count, 4);
-                be.memset(d_rg_count.p, 0, 8);
-                be.launch("count_tangled", (int64_t)fl.size(), CountTangled{S, d_list.p, d_rg_count.p});
                 uint64_t tangled = 0;
-                be.d2h(&tangled, d_rg_count.p, 8);
+                be.d2h(&tangled, d_t_rem.p, 8);
                 if ((int64_t)tangled > tangled_max) {
                     be.mark(nullptr);
                     collect_timing_more();
@@ -777,7 +780,17 @@ public:
                 }
             }
             be.launch_wave("settle_flagged", (int64_t)fl.size(), SettleFlagged{S, layout_view(d_image.p, false), P, d_list.p});
-            be.launch_wave("settle_tangled", 1, SettleTangled{S, L, P, d_list.p, (int64_t)fl.size()});
+            {
+                const int32_t* before = d_owner.p;
+                ensure(d_owner, words);
+                if (d_owner.p != before) be.memset(d_owner.p, 0, 4 * words);      // (kept all zero between calls)
+            }
+            for (int round = 0; round < (tangle_rounds ? kTangleRounds : 0); round++) {
+                be.launch_wave("tangle_owner", (int64_t)fl.size(), TangleOwner{S, d_list.p, d_lay_off.p, d_lay_bits.p, d_owner.p, d_t_done.p, d_t_rem.p});
+                be.launch_wave("tangle_settle", (int64_t)fl.size(), TangleSettle{S, layout_view(d_image.p, false), P, d_list.p, d_owner.p, d_t_done.p, d_t_rem.p});
+                be.launch_wave("tangle_clear", (int64_t)fl.size(), TangleClear{S, d_list.p, d_lay_off.p, d_lay_bits.p, d_owner.p, d_t_done.p});
+            }
+            be.launch_wave("settle_tangled", 1, SettleTangled{S, L, P, d_list.p, (int64_t)fl.size(), d_t_done.p, d_t_rem.p});
         }
         layout_rows = rows;
         return 0;
@@ -929,10 +942,14 @@ public:
     // pairwise disjoint in every genome: candidates settled against the image and marked, children appended to the region store.
     int store_validate(const int32_t* regions, const int64_t* row0, const int32_t* cnt, int64_t nreg, const int64_t* cluster_first, int64_t ncl, int32_t q,
                        uint32_t* trouble, std::vector<RegInfo>* kids, std::vector<int32_t>* kid_ids, int64_t info_first = 0, int64_t info_count = 0, RowInfo* info = nullptr,
-                       int64_t stage_first = 0, int32_t* second_stage_ran = nullptr, int32_t generation_no = 1) {
+                       int64_t stage_first = 0, int32_t* second_stage_ran = nullptr, int32_t generation_no = 1, int32_t* done = nullptr) {
         // stage_first > 0: clusters [0, stage_first) are a generation of their own (the first pushed seed, which the reference
         // processes before anything is sorted); the rest -- the generation the caller formed on the assumption that the first leaves
         // no child region -- runs behind it in the same call if that held, and is left untouched if not (*second_stage_ran = 0)
+        // done[cluster]: how many regions of the cluster were processed -- all of them, or fewer: none where the cluster meets an
+        // earlier one in some genome (it waits for that one and for everything it leads to), the first few where a child sorts
+        // before the next waiting region.  done == nullptr: a caller that cannot keep regions waiting; either case is trouble then
+        // (bits 3 / 0) and the run must be discarded
         if (!resident || layout_rows < 0) { error = "the anchor list has not been settled"; return -2; }
         kids->clear(); kid_ids->clear(); *trouble = 0;
         if (nreg == 0 || ncl == 0) return 0;
@@ -953,6 +970,7 @@ public:
         int64_t* s_row0 = (int64_t*)block; int64_t* s_first = s_row0 + nreg; int32_t* s_reg = (int32_t*)(s_first + ncl + 1); int32_t* s_cnt = s_reg + nreg;
         memcpy(s_row0, row0, 8 * (size_t)nreg); memcpy(s_first, cluster_first, 8 * ((size_t)ncl + 1)); memcpy(s_reg, regions, 4 * (size_t)nreg); memcpy(s_cnt, cnt, 4 * (size_t)nreg);
         ensure(d_v_row0, (size_t)nreg); ensure(d_v_first, (size_t)ncl + 1); ensure(d_list, (size_t)nreg); ensure(d_list2, (size_t)nreg); ensure(d_rg_count, 4);
+        ensure(d_v_done, (size_t)ncl); ensure(d_v_defer, (size_t)ncl); ensure(d_v_involved, (size_t)ncl);
         be.h2d_staged(d_v_row0.p, s_row0, 8 * (size_t)nreg); be.h2d_staged(d_v_first.p, s_first, 8 * ((size_t)ncl + 1));
         be.h2d_staged(d_list.p, s_reg, 4 * (size_t)nreg); be.h2d_staged(d_list2.p, s_cnt, 4 * (size_t)nreg);
         // candidates with a member outside their region are noted for store_order_check (store_kernels.h: ForeignRead); the counter is
@@ -966,53 +984,72 @@ public:
             if (info_first < 0 || info_first + info_count > ms_count) { error = "rows outside the MUM store"; return -2; }
             ensure(d_rowinfo, (size_t)info_count);
         }
-        auto generation = [&](bool collinear_test) {      // the launches of the call and its one wait
+        std::vector<int32_t> done_h((size_t)ncl, 0);
+        // the launches of the call and its one wait.  exact = false: the clusters are expected in reference order in every genome
+        // (ClustersDisjoint looks; if not, nothing runs).  exact = true: which clusters meet an earlier one is worked out first
+        // (ClusterExtents ... ClusterDefer, for the stage that runs clusters side by side) and those wait
+        auto generation = [&](bool exact) {
             be.h2d(d_rg_count.p, head, 32);
-            if (collinear_test) be.launch_wave("clusters_disjoint", ncl - 1, ClustersDisjoint{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, d_rg_count.p + 3, stage_first, force_unsure ? 1 : 0});
+            be.memset(d_v_done.p, 0, 4 * (size_t)ncl);
+            const uint8_t* defer = nullptr;
+            if (exact) {
+                be.memset(d_v_defer.p, 0, (size_t)ncl);
+                const int64_t c0 = stage_first > 0 ? na : 0, cn = ncl - c0;      // (the first stage of a two-stage call is one cluster)
+                if (cn >= 2) {
+                    const size_t words = layout_geometry();
+                    const uint64_t* b1 = d_once.p; const uint64_t* b2 = d_twice.p; const int32_t* b3 = d_owner.p;
+                    ensure(d_once, words); ensure(d_twice, words); ensure(d_owner, words);
+                    if (d_once.p != b1 || d_twice.p != b2) { be.memset(d_once.p, 0, 8 * words); be.memset(d_twice.p, 0, 8 * words); }      // (kept all zero between calls)
+                    if (d_owner.p != b3) be.memset(d_owner.p, 0, 4 * words);
+                    be.launch_wave("cluster_extents", cn, ClusterExtents{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_twice.p, d_owner.p, c0, 1});
+                    be.launch_wave("cluster_involved", cn, ClusterInvolved{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_twice.p, false), d_owner.p, d_v_involved.p, c0});
+                    be.launch_wave("cluster_defer", cn, ClusterDefer{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, d_lay_off.p, d_lay_bits.p, d_owner.p, d_v_involved.p, d_v_defer.p, c0});
+                    be.launch_wave("cluster_extents", cn, ClusterExtents{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_twice.p, d_owner.p, c0, 0});
+                }
+                defer = d_v_defer.p;
+                exact_cluster_tests++;
+            } else be.launch_wave("clusters_disjoint", ncl - 1, ClustersDisjoint{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, d_rg_count.p + 3, stage_first, force_unsure ? 1 : 0});
             be.launch_wave("cluster_validate", xcd_grid(na),
                            ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
                                            d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), na, 0, nullptr, d_rg_count.p + 3,
-                                           d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation_no, d_recwords.p});
+                                           d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation_no, d_recwords.p, defer, d_v_done.p});
             if (stage_first > 0) {
                 be.launch("stage_gate", 1, StageGate{d_rg_count.p, (uint64_t)rg_count, force_gate ? 1 : 0});
                 be.launch_wave("cluster_validate", xcd_grid(ncl - na),
                                ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
                                                d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), ncl - na, na, d_rg_count.p + 2, d_rg_count.p + 3,
-                                               d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation_no + 1, d_recwords.p});
+                                               d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation_no + 1, d_recwords.p, defer, d_v_done.p});
             }
             if (info_count > 0) be.launch("store_info", info_count, StoreInfoOut{store_view(), info_first, d_rowinfo.p});
             be.mark(nullptr);
             if (info_count > 0) be.d2h_async(info, d_rowinfo.p, sizeof(RowInfo) * (size_t)info_count);
             be.d2h_async(&foreign_seen, d_foreign_count.p, 8);
+            be.d2h_async(done_h.data(), d_v_done.p, 4 * (size_t)ncl);
             be.d2h(head, d_rg_count.p, 32);
         };
         be.mark("validate");
-        generation(true);
-        if (head[3] != 0) {
-            // some genome does not hold the clusters in reference order (an inversion): nothing has been validated (ClusterValidate
-            // saw the word).  The exact question, stage by stage -- are the clusters' extents pairwise disjoint with a base between?
-            const size_t words = layout_geometry();
-            const uint64_t* before = d_once.p;
-            ensure(d_once, words);
-            if (d_once.p != before) be.memset(d_once.p, 0, 8 * words);      // (kept all zero between calls)
+        // a session whose genomes have once held the clusters in another order (an inversion) asks the exact question at once:
+        // the collinear test would fail again, at the price of a round trip
+        generation(clusters_out_of_order);
+        if (head[3] != 0 && !clusters_out_of_order) {
+            // some genome does not hold the clusters in reference order: nothing has been validated (ClusterValidate saw the word)
+            clusters_out_of_order = true;
             head[0] = (uint64_t)rg_count; head[1] = head[2] = head[3] = 0;
             be.mark("validate");
-            be.h2d(d_rg_count.p, head, 32);
-            for (int stage = 0; stage < (stage_first > 0 ? 2 : 1); stage++) {
-                const int64_t c0 = stage == 0 ? 0 : na, cn = stage == 0 ? na : ncl - na;
-                if (cn < 2) continue;
-                for (int mark = 1; mark >= 0; mark--)
-                    be.launch_wave("clusters_collide", cn, ClustersCollide{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), (uint32_t*)(d_rg_count.p + 1), c0, mark});
-            }
-            be.d2h(head, d_rg_count.p, 32);
-            if (!(head[1] & 8)) {      // disjoint: the generation, without the collinear test
-                exact_cluster_tests++;
-                head[0] = (uint64_t)rg_count; head[1] = head[2] = head[3] = 0;
-                generation(false);
-            } else be.mark(nullptr);
+            generation(true);
         }
         *trouble = (uint32_t)head[1];
-        if (second_stage_ran) *second_stage_ran = stage_first > 0 && head[2] == 0 ? 1 : 0;
+        const bool ran2 = stage_first > 0 && head[2] == 0;
+        if (second_stage_ran) *second_stage_ran = ran2 ? 1 : 0;
+        for (int64_t cl = 0; cl < ncl; cl++) {
+            if (stage_first > 0 && cl >= na && !ran2) { done_h[(size_t)cl] = 0; continue; }
+            const int64_t size = cluster_first[cl + 1] - cluster_first[cl];
+            if (done_h[(size_t)cl] < size) {
+                deferred_regions += size - done_h[(size_t)cl];
+                if (!done && !*trouble) *trouble |= done_h[(size_t)cl] == 0 ? 8u : 1u;
+            }
+        }
+        if (done) memcpy(done, done_h.data(), 4 * (size_t)ncl);
         if (head[0] > cap) { error = "region store overflow"; return -4; }
         const int64_t before = rg_count;
         rg_count = (int64_t)head[0];
@@ -1255,7 +1292,8 @@ public:
     int64_t work_budget = 1 << 22;
     int64_t dirty_min = 4096;
     int64_t flagged_div = 8;      // store_settle: above one flagged row in flagged_div the tangled rows are counted before the list is taken (1: never declined)
-    int64_t tangled_max = 2048;   // ... and the list declined (PM_EAGAIN) with more tangled rows than this (one wavefront settles them in list order, ~13 us each)
+    int64_t tangled_max = 1 << 17;   // ... and the list declined (PM_EAGAIN) with more tangled rows than this
+    bool tangle_rounds = true;    // tangled rows settled in rounds (TangleOwner / TangleSettle) before the one wavefront that takes what is left; false: that wavefront takes them all (tests)
     bool group_small = true;      // the events of a recursion batch's small regions once per distinct piece (GroupedPairEvents)
     int64_t last_grouped = 0;
     bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
@@ -1264,11 +1302,14 @@ public:
     bool force_chain_tie = false;         // (tests) store_chain_begin reports two MUMs with one reference start
     bool force_unsure = false;            // (tests) store_validate's collinear test of the clusters reports failure: the exact test decides
     bool order_debug = false;             // the order check prints its counts (noted candidates, candidates left to the scan) to stderr
-    int64_t exact_cluster_tests = 0;      // generations validated after ClustersCollide found their clusters disjoint
+    int64_t exact_cluster_tests = 0;      // generations validated with the exact test of their clusters (ClusterExtents ... ClusterDefer)
+    int64_t deferred_regions = 0;         // regions a validation call left on the caller's work list (their cluster met an earlier one, or a child sorted first)
+    bool clusters_out_of_order = false;   // a generation of this session failed the collinear test of its clusters: the exact test is asked at once from then on
     bool phase_timing = true;             // HIP events around the phases of a call (pm_last_timing); off: the marks cost nothing
     bool tune(const std::string& key, int64_t value) {
         if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
         if (key == "tangled_max" && value >= 0) { tangled_max = value; return true; }
+        if (key == "tangle_rounds") { tangle_rounds = value != 0; return true; }
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
         if (key == "master_seg") { master_seg = value != 0; return true; }
         if (key == "stage_gate") { force_gate = value != 0; return true; }
@@ -1350,6 +1391,8 @@ private:
     Buf<int64_t> d_rg_start, d_rg_len, d_lay_off, d_lay_bits, d_v_row0, d_v_first, d_f_start, d_f_end, d_f_pack; Buf<RegInfo> d_rg_info; Buf<uint64_t> d_rg_count, d_once, d_twice;
     Buf<RowInfo> d_rowinfo; Buf<uint64_t> d_alg;
     Buf<int64_t> d_sd_cnt, d_sd_off; Buf<uint8_t> d_sd_keep;      // store_settle_seeds
+    Buf<uint64_t> d_t_rem; Buf<uint8_t> d_t_done;      // settle_launch: tangled rows left, settled flags per flagged row
+    Buf<int32_t> d_v_done, d_owner; Buf<uint8_t> d_v_defer, d_v_involved;      // store_validate: regions processed per cluster; the exact test of the clusters
     Buf<ForeignRead> d_foreign; Buf<uint64_t> d_foreign_count, d_foreign_masks; Buf<int64_t> d_ms_key;       // store_validate / store_order_check: candidates with a member outside their region
     size_t foreign_cap = 0; int64_t ms_key_rows = 0; uint64_t foreign_seen = 0;      // foreign_seen: the device's counter as of the last validation call
     static constexpr size_t kHitCap = 256;      // noted candidates that the bounds of ForeignBound do not decide

@@ -473,14 +473,84 @@ struct SettleFlagged {
         if (wave_leader()) { S.shift[c] = dl; S.len[c] = len; if (acc) S.state[c] |= kStAccepted; }
     }
 };
-// ... and the tangled ones in list order, by ONE wavefront: each sees the marks of those before it (:1836-1839)
+// ... and the tangled ones in LIST ORDER: each sees the marks of those before it (:1836-1839).  One wavefront working through them
+// one after the other (SettleTangled) is 13 us per row -- nothing for the 18 tangled rows of a population sample, 40 ms for the
+// 3 000 of a set with 10 % of every genome rearranged.  But list order only matters between rows that MEET: a tangled row may be
+// settled as soon as every earlier tangled row that shares a base with it has been.  Rounds of three launches, one wavefront per
+// flagged row, the lanes over the genomes:
+//   TangleOwner   every tangled row not settled yet writes its list index into every 64-base WORD of its ranges (`owner`: one
+//                 int32 per image word, kept all zero between calls; the smallest index wins, stored as 0x7fffffff - index);
+//   TangleSettle  a row that finds its own index in all of its words has no unsettled earlier row near it: settled and marked now.
+//                 The rows of one round share no word, so they neither read nor write one another's bits;
+//   TangleClear   the words written in this round back to zero.
+// A word is coarser than a base: two rows in one word that do not overlap are settled one round apart, never differently.  What
+// kTangleRounds rounds leave (chains of rows overlapping one another) SettleTangled finishes in list order.
+constexpr int kTangleRounds = 6;
+struct TangleOwner {
+    Store S; const int32_t* list; const int64_t* word_off; const int64_t* nbits; int32_t* owner; const uint8_t* t_done; const uint64_t* remaining;
+    PM_HD void wave(int64_t i) const {
+        if (*remaining == 0) return;
+        const int64_t c = list[i];
+        if (!(S.state[c] & kStTangled) || t_done[i]) return;
+        const int n = S.ngen;
+        const int32_t mine = 0x7fffffff - (int32_t)i;
+        lanes_for(0, n, [&](int j) {
+            int64_t a = S.start[c * n + j], b = a + S.lon[c];
+            if (a < 0) a = 0;
+            if (b > nbits[j]) b = nbits[j];
+            if (a >= b) return;
+            for (int64_t w = a >> 6; w <= ((b - 1) >> 6); w++) atomic_max32(&owner[word_off[j] + w], mine);
+        });
+    }
+};
+struct TangleSettle {
+    Store S; Layout L; Packed P; const int32_t* list; const int32_t* owner; uint8_t* t_done; uint64_t* remaining;
+    PM_HD void wave(int64_t i) const {
+        if (load_coherent64(remaining) == 0) return;
+        const int64_t c = list[i];
+        if (!(S.state[c] & kStTangled) || t_done[i]) return;
+        const int n = S.ngen;
+        const int32_t mine = 0x7fffffff - (int32_t)i;
+        uint32_t wait = 0;
+        lanes_for(0, n, [&](int j) {
+            int64_t a = S.start[c * n + j], b = a + S.lon[c];
+            if (a < 0) a = 0;
+            if (b > L.nbits[j]) b = L.nbits[j];
+            if (a >= b) return;
+            for (int64_t w = a >> 6; w <= ((b - 1) >> 6); w++) if (owner[L.word_off[j] + w] != mine) wait = 1;
+        });
+        if (wave_or_u32(wait)) return;
+        int32_t dl, len;
+        const bool acc = settle_row(S, L, P, c, true, &dl, &len);
+        if (acc) lanes_for(0, n, [&](int j) { const int64_t a = (int64_t)S.start[c * n + j] + dl; img_set_range(L, j, a, a + len); });
+        if (wave_leader()) { S.shift[c] = dl; S.len[c] = len; if (acc) S.state[c] |= kStAccepted; t_done[i] = 1; atomic_add64(remaining, ~0ull); }
+    }
+};
+struct TangleClear {
+    Store S; const int32_t* list; const int64_t* word_off; const int64_t* nbits; int32_t* owner; uint8_t* t_done;
+    PM_HD void wave(int64_t i) const {
+        const int64_t c = list[i];
+        if (!(S.state[c] & kStTangled) || t_done[i] == 2) return;
+        const int n = S.ngen;
+        lanes_for(0, n, [&](int j) {
+            int64_t a = S.start[c * n + j], b = a + S.lon[c];
+            if (a < 0) a = 0;
+            if (b > nbits[j]) b = nbits[j];
+            if (a >= b) return;
+            for (int64_t w = a >> 6; w <= ((b - 1) >> 6); w++) owner[word_off[j] + w] = 0;
+        });
+        if (wave_leader() && t_done[i] == 1) t_done[i] = 2;
+    }
+};
 struct SettleTangled {
     Store S; Layout L; Packed P; const int32_t* list; int64_t count;
+    const uint8_t* t_done; const uint64_t* remaining;      // != nullptr: the rounds before this launch have settled the rows with t_done[i] != 0, *remaining are left
     PM_HD void wave(int64_t) const {
+        if (remaining && *remaining == 0) return;
         for (int64_t base = 0; base < count; base += 64) {
             // which of the next 64 flagged rows are tangled: one load per lane instead of a dependent load per row
             uint64_t mask = 0;
-            lanes_for(0, 64, [&](int t) { if (base + t < count && (S.state[list[base + t]] & kStTangled)) mask |= 1ull << t; });
+            lanes_for(0, 64, [&](int t) { if (base + t < count && (S.state[list[base + t]] & kStTangled) && !(t_done && t_done[base + t])) mask |= 1ull << t; });
             mask = wave_or_u64(mask);
             while (mask) {
                 const int t = ctz64(mask);
@@ -894,16 +964,15 @@ struct GroupedBounds {
 // caller has found the waiting regions to fall into clusters that are disjoint in EVERY genome (Aligner::extend_generations):
 // nothing found in one cluster can touch, trim or bound anything of another, so the clusters run side by side -- one
 // wavefront each, its regions in the reference's order -- and the children form the next generation.
-// What would make the order observable is reported, not decided here (`trouble`): a child that sorts before a region still
-// waiting in its cluster (bit 0), a reverse-strand member that passes the sequence check outside its region (bit 1), a
-// region with more candidates than the key holds (bit 2).
+// What would make the order observable is reported, not decided here (`trouble`): a reverse-strand member that passes the
+// sequence check outside its region (bit 1), a region with more candidates than the key holds (bit 2).  A child that sorts before
+// a region still waiting in its cluster is no trouble since round 6: the cluster stops there (`done`), and what waits goes back to
+// the caller's work list together with the children -- the next generation sorts them as the reference's list would (:291-292).
 // Are the clusters of a generation pairwise disjoint in EVERY genome (Aligner::disjoint_clusters)?  Collinear genomes hold them
 // in reference order: then it is "every cluster starts after its predecessor ends, with a base between" in every genome
 // (ClustersDisjoint: one wavefront per cluster from the second on).  A genome in which that fails for some pair -- an inverted
 // block holds its clusters in the opposite order -- raises *unsure: nothing of the generation is validated (ClusterValidate looks
-// at the word), and the engine puts the exact question: ClustersCollide ORs every cluster's extent [lo, hi + 2) into a scratch
-// image (all zero between calls) and two clusters whose extents share a bit -- they overlap, touch, or have no base between --
-// are trouble bit 3; ClustersClear wipes the scratch image; then the generation is validated as usual.
+// at the word), and the engine puts the exact question, cluster by cluster (ClusterExtents and the kernels after it).
 struct ClustersDisjoint {
     int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first; uint64_t* unsure;
     int64_t stage_first;      // the first cluster of the call's second stage (0: one stage): it runs after its predecessor, not beside it
@@ -923,34 +992,95 @@ struct ClustersDisjoint {
         if (wave_or_u32(bad) && wave_leader()) atomic_or64(unsure, 1ull);
     }
 };
-// one wavefront per cluster of one stage of the call (clusters [cl0, cl0 + ncl)): mark = 1 the extents into the scratch image,
-// a bit found set is a collision; mark = 0 the words of the extents back to zero
-struct ClustersCollide {
+// Where some genome holds the clusters of a generation in another order, the exact question is put, and since round 6 its answer
+// is not "all or nothing" but a verdict PER CLUSTER.  The reference (doWork :173-317) always pops the waiting region with the
+// smallest reference start, and the children of a region lie inside it in every genome, so a cluster X that comes before a cluster
+// Y on the reference is finished -- with everything it leads to -- before Y begins.  If X and Y meet in some genome (the two
+// breakpoint regions of an inversion are the same gap of the inverted genome) Y must see X's marks: Y is DEFERRED, it stays on
+// the work list and runs in a later generation, when no cluster before it meets it any more.  A cluster that meets nothing
+// earlier runs now; the clusters that run together are pairwise disjoint, which is all ClusterValidate needs.
+//   ClusterExtents   one wavefront per cluster: its extent [lo, hi + 2) of every genome (they overlap, touch, or have no base
+//                    between = they share a bit) ORed into the scratch image `once`, bits that were there already into `twice`;
+//   ClusterInvolved  a `twice` bit under the own extent = the cluster meets another one; such a cluster writes its number into
+//                    every 64-base WORD of its extents (`owner`: one int32 per image word, the smallest number wins);
+//   ClusterDefer     an involved cluster that finds a smaller number than its own in a word of its extents is deferred.  (A word
+//                    is coarser than a bit: two involved clusters that share a word but no base defer the later one without
+//                    need -- a generation more, never a different result);
+//   ClusterExtents with mark = 0 wipes the words it wrote (the scratch arrays are kept all zero between calls).
+// owner[] holds 0x7fffffff - cluster so that zero means "nobody" and the smallest number is the largest value.
+PM_HD void cluster_extent(int32_t ngen, const int64_t* rg_start, const int64_t* rg_len, const int32_t* now_region, int64_t p0, int64_t p1, int j, int64_t nbits, int64_t* a, int64_t* b) {
+    int64_t hi = -1, lo = (int64_t)1 << 62;
+    for (int64_t x = p0; x < p1; x++) {
+        const int64_t r = now_region[x]; const int64_t s = rg_start[r * ngen + j], e = s + rg_len[r * ngen + j];
+        if (s < lo) lo = s;
+        if (e > hi) hi = e;
+    }
+    *a = lo < 0 ? 0 : lo; *b = hi + 2 > nbits ? nbits : hi + 2;
+}
+struct ClusterExtents {
     int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first;
-    Layout scratch; uint32_t* trouble; int64_t cl0; int mark;
+    Layout once; uint64_t* twice; int32_t* owner; int64_t cl0; int mark;
     PM_HD void wave(int64_t w) const {
         const int64_t cl = cl0 + w;
         const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
-        uint32_t bad = 0;
         lanes_for(1, ngen, [&](int j) {
-            int64_t hi = -1, lo = (int64_t)1 << 62;
-            for (int64_t x = p0; x < p1; x++) {
-                const int64_t r = now_region[x]; const int64_t a = rg_start[r * ngen + j], e = a + rg_len[r * ngen + j];
-                if (a < lo) lo = a;
-                if (e > hi) hi = e;
-            }
-            int64_t a = lo < 0 ? 0 : lo, b = hi + 2 > scratch.nbits[j] ? scratch.nbits[j] : hi + 2;
-            uint64_t* wd = scratch.image + scratch.word_off[j];
+            int64_t a, b;
+            cluster_extent(ngen, rg_start, rg_len, now_region, p0, p1, j, once.nbits[j], &a, &b);
+            const int64_t base = once.word_off[j];
             while (a < b) {
                 const int f = (int)(a & 63);
                 const int64_t span = (64 - f) < (b - a) ? (64 - f) : (b - a);
                 const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << f;
-                if (mark) { if (atomic_fetch_or64(&wd[a >> 6], mask) & mask) bad = 1; }
-                else wd[a >> 6] = 0;
+                if (mark) {
+                    const uint64_t old = atomic_fetch_or64(&once.image[base + (a >> 6)], mask);
+                    if (old & mask) atomic_or64(&twice[base + (a >> 6)], old & mask);
+                } else { once.image[base + (a >> 6)] = 0; twice[base + (a >> 6)] = 0; owner[base + (a >> 6)] = 0; }
                 a += span;
             }
         });
-        if (mark && wave_or_u32(bad) && wave_leader()) atomic_or32(trouble, 8u);
+    }
+};
+struct ClusterInvolved {
+    int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first;
+    Layout twice; int32_t* owner; uint8_t* involved; int64_t cl0;
+    PM_HD void wave(int64_t w) const {
+        const int64_t cl = cl0 + w;
+        const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
+        uint32_t hit = 0;
+        lanes_for(1, ngen, [&](int j) {
+            int64_t a, b;
+            cluster_extent(ngen, rg_start, rg_len, now_region, p0, p1, j, twice.nbits[j], &a, &b);
+            if (img_any(twice, j, a, b)) hit = 1;
+        });
+        hit = wave_or_u32(hit);
+        if (wave_leader()) involved[cl] = hit ? 1 : 0;
+        if (!hit) return;
+        const int32_t mine = 0x7fffffff - (int32_t)cl;
+        lanes_for(1, ngen, [&](int j) {
+            int64_t a, b;
+            cluster_extent(ngen, rg_start, rg_len, now_region, p0, p1, j, twice.nbits[j], &a, &b);
+            if (a >= b) return;
+            for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6); wd++) atomic_max32(&owner[twice.word_off[j] + wd], mine);
+        });
+    }
+};
+struct ClusterDefer {
+    int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first;
+    const int64_t* word_off; const int64_t* nbits; const int32_t* owner; const uint8_t* involved; uint8_t* defer; int64_t cl0;
+    PM_HD void wave(int64_t w) const {
+        const int64_t cl = cl0 + w;
+        if (!involved[cl]) { if (wave_leader()) defer[cl] = 0; return; }
+        const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
+        const int32_t mine = 0x7fffffff - (int32_t)cl;
+        uint32_t earlier = 0;
+        lanes_for(1, ngen, [&](int j) {
+            int64_t a, b;
+            cluster_extent(ngen, rg_start, rg_len, now_region, p0, p1, j, nbits[j], &a, &b);
+            if (a >= b) return;
+            for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6); wd++) if (owner[word_off[j] + wd] > mine) earlier = 1;
+        });
+        earlier = wave_or_u32(earlier);
+        if (wave_leader()) defer[cl] = earlier ? 1 : 0;
     }
 };
 // A reverse-strand member is flipped against the WHOLE genome (TMum.cpp:33-35): inside a sub-region it usually lands far outside
@@ -1193,17 +1323,23 @@ struct ClusterValidate {
     ForeignRead* foreign; uint64_t* foreign_count; uint64_t foreign_cap; uint64_t* foreign_masks;      // candidates with a member outside their region (ForeignBound)
     int64_t* row_key; int32_t generation;      // the order key of every row decided here (order_key)
     uint8_t* rec;                              // one byte per image word: the recursion has marked there
+    const uint8_t* defer;                      // != nullptr: [cluster] != 0 -- it meets an earlier cluster in some genome and waits (ClusterDefer)
+    int32_t* done;                             // [cluster]: how many of its regions were processed (the rest stay on the caller's work list)
     PM_HD void wave(int64_t w) const {
-        if ((gate && *gate) || (unsure && *unsure)) return;
+        if ((gate && *gate) || (unsure && *unsure && !defer)) return;      // (the collinear test failed and nobody has said which clusters may run)
         const int64_t cl = cl0 + xcd_item(w, ncl);
         if (cl >= cl0 + ncl) return;
+        if (defer && defer[cl]) return;      // (done[cl] stays 0)
         const int n = S.ngen;
         int64_t pending_min = -1;
-        const int64_t x1 = cluster_first[cl + 1];
-        for (int64_t x = cluster_first[cl]; x < x1; x++) {
+        const int64_t x0 = cluster_first[cl], x1 = cluster_first[cl + 1];
+        if (wave_leader()) done[cl] = (int32_t)(x1 - x0);
+        for (int64_t x = x0; x < x1; x++) {
             const int64_t rid = now_region[x];
             const int64_t* rs = rg_start + rid * n; const int64_t* rl = rg_len + rid * n;
-            if (pending_min >= 0 && pending_min <= rs[0]) { if (wave_leader()) atomic_or32(trouble, 1u); return; }
+            // a child of a region processed here sorts before this one (or ties with it): the reference would take the child first, and
+            // a child needs its search.  The cluster stops; what waits stays on the caller's work list, with the children (:291-292)
+            if (pending_min >= 0 && pending_min <= rs[0]) { if (wave_leader()) done[cl] = (int32_t)(x - x0); return; }
             const int64_t row0 = now_row0[x]; const int32_t cnt = now_cnt[x];
             if (cnt >= (1 << 22)) { if (wave_leader()) atomic_or32(trouble, 4u); return; }
             const int64_t okey = order_key(rs[0], generation);

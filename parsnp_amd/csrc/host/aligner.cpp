@@ -898,8 +898,10 @@ bool Aligner::find_anchors() {
     for (size_t i = 0; i < n; i++) { whole.start[i] = 0; whole.end[i] = (long)genomes[i].seq.size(); }
     finish_region(whole, n);
     std::vector<int> found;
-    std::cerr << std::endl << "        Constructing device index of the reference...\n";
-    std::cerr << "        Performing initial search for exact matches in the sequences...\n";
+    if (announce_) {
+        std::cerr << std::endl << "        Constructing device index of the reference...\n";
+        std::cerr << "        Performing initial search for exact matches in the sequences...\n";
+    }
     const bool dbg_a = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double ta = now_s();
     auto lap_a = [&](const char* what) { if (dbg_a) { const double t = now_s(); fprintf(stderr, "[anchors] %-18s %.4f s (cpu %.4f)\n", what, t - ta, cpu_lap_s()); ta = t; } };
@@ -1510,7 +1512,7 @@ bool Aligner::extend_generations() {
                             if (!mm.fwd[j] && ((long)mm.start[j] < r.start[j] - 1 || mm.end(j) > r.end[j] + 1)) cluster_trouble = 1;
                     for (size_t j = 0; j < n; j++) {
                         layout[j].set_range_atomic(mm.start[j], mm.end(j));
-                        for (long w = (long)mm.start[j] >> 6; w <= (mm.end(j) - 1) >> 6; w++) rec_words[j][(size_t)w] = 1;
+                        for (long w = (long)mm.start[j] >> 6; w <= (mm.end(j) - 1) >> 6; w++) __atomic_store_n(&rec_words[j][(size_t)w], (uint8_t)1, __ATOMIC_RELAXED);      // (every thread of the generation stores 1)
                     }
                     mm.slength = r.slength;
                     o.accepted.push_back(mm);

@@ -85,7 +85,7 @@ public:
             if (p >= (long)nbits_) break;
             const int lo = (int)(p & 63);
             const long span = std::min<long>(64 - lo, len - t);
-            m |= ((w_[(size_t)p >> 6] >> lo) & (span == 64 ? ~0ull : ((1ull << span) - 1))) << t;
+            m |= ((__atomic_load_n(&w_[(size_t)p >> 6], __ATOMIC_RELAXED) >> lo) & (span == 64 ? ~0ull : ((1ull << span) - 1))) << t;      // (other threads may be marking: set_range_atomic)
             t += span;
         }
         return m;
@@ -271,6 +271,8 @@ struct Stats {   // wall-clock split reported next to the reference's own phase 
     std::vector<std::pair<std::string, double>> engine_ms, anchor_ms;
     long generations = 0, generation_regions = 0, generation_handover = -1;   // parallel generations, regions in them, generation at which the in-order replay took over (-1: never)
     long generation_restarts = 0;   // generation-parallel extension abandoned after its second generation (see extend_generations)
+    long regions_deferred = 0;      // (resident route) regions a generation left on the work list: their cluster met an earlier one in some genome, or a child sorted first
+    long tie_runs = 0, tie_runs_open = 0;   // (resident route) runs of different regions with one reference start; ... of which more than one region had candidates (the route is left)
     long resident = 0;              // 1: phases A-D ran on the resident route (resident.cpp: rows, layout and regions stayed on the device)
     long device_chain = 0;          // 1: phases C-D (sort, chaining, LCB filter, fillers) came from the device in one call (pm_store_chain_*)
     long resident_retry = 0;        // 1: the resident route was left (the reference's processing order would have shown) and the step ran again on the host route
@@ -325,6 +327,7 @@ public:
     bool sharded_ = false;       // (set by the owner) a rank of a sharded run: every rank makes the same engine calls in the same order, no helper thread
     // The resident route (resident.cpp): MUM rows, layout and regions stay on the device; the host keeps the list logic.
     bool resident_allowed_ = true;                       // (set by the owner) false: the run that repeats a step the route was left in
+    bool announce_ = true;      // find_anchors prints its two progress lines (false: the step is being run again on the host route, they are out already)
     bool resident_active() const { return res_.active; }
     bool resident_failed() const { return res_.failed; }
     const std::string& resident_why() const { return res_.why; }

@@ -62,7 +62,8 @@ const char* pc_step(pc_run* r) {
       << s.cache_misses << ", \"spec_rounds\": " << s.spec_rounds << ", \"mums_found\": " << (s.mums_found ? "true" : "false")
       << ", \"host_split_s\": {\"validate\": " << s.host.t_validate << ", \"neighbour\": " << s.host.t_neighbour << ", \"key\": " << s.host.t_key
       << ", \"sweep\": " << s.host.t_sweep << ", \"replay\": " << s.host.t_replay << ", \"sort\": " << s.host.t_sort << ", \"unpack\": " << s.host.t_unpack << ", \"pack\": " << s.host.t_pack << "}"
-      << ", \"h2d_bytes\": " << (long long)s.h2d_bytes << ", \"d2h_bytes\": " << (long long)s.d2h_bytes << ", \"resident\": " << s.host.resident << ", \"resident_retry\": " << s.host.resident_retry << ", \"device_chain\": " << s.host.device_chain << ", \"tie_fallbacks\": " << s.host.tie_fallbacks << ", \"literal_iterations\": " << s.host.literal_iterations;
+      << ", \"h2d_bytes\": " << (long long)s.h2d_bytes << ", \"d2h_bytes\": " << (long long)s.d2h_bytes << ", \"resident\": " << s.host.resident << ", \"resident_retry\": " << s.host.resident_retry << ", \"device_chain\": " << s.host.device_chain << ", \"tie_fallbacks\": " << s.host.tie_fallbacks << ", \"literal_iterations\": " << s.host.literal_iterations
+      << ", \"generations\": " << s.host.generations << ", \"regions_deferred\": " << s.host.regions_deferred << ", \"tie_runs\": " << s.host.tie_runs << ", \"tie_runs_open\": " << s.host.tie_runs_open;
     {
         std::string why = s.resident_why;      // (plain words; quotes and backslashes would break the JSON)
         for (char& ch : why) if (ch == '"' || ch == '\\' || (unsigned char)ch < 32) ch = ' ';

@@ -158,12 +158,16 @@ int CoreRun::mumi() {
 StepReport CoreRun::step() {
     uint64_t h0 = 0, d0 = 0, h1 = 0, d1 = 0;
     (void)pm_session_traffic(session, &h0, &d0);
-    StepReport r = step_once(true);
-    const std::string why = align->resident_why();
-    if (align->resident_failed()) {
+    said_ = 0;
+    // an input that left the resident route once leaves it at the same point every time (the step is a function of the genomes and
+    // the parameters): later steps of the session go to the host route at once instead of paying for the attempt again
+    StepReport r = step_once(left_why_.empty());
+    std::string why = left_why_.empty() ? align->resident_why() : "left in an earlier step of this session (" + left_why_ + ")";
+    if (left_why_.empty() && align->resident_failed()) {
         // the resident route was left: the reference's processing order would have shown in the result (resident.cpp).  The
         // step runs again on the host route, from the anchor call.
         if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[resident] route left (%s): the step runs again on the host route\n", align->resident_why().c_str());
+        left_why_ = why;
         const double lost = r.path_s;
         r = step_once(false);
         r.path_s += lost; r.host.resident_retry = 1;
@@ -175,9 +179,17 @@ StepReport CoreRun::step() {
         if (FILE* f = fopen(log, "a")) {
             double exact = 0;
             for (const auto& kv : r.host.engine_ms) if (kv.first == "exact_cluster_tests") exact = kv.second;
-            fprintf(f, "resident=%ld retry=%ld chain=%ld exact=%ld anchors=%ld mums=%ld why=%s\n", r.host.resident, r.host.resident_retry, r.host.device_chain, (long)exact, r.anchors, r.mums, why.c_str()); fclose(f);
+            fprintf(f, "resident=%ld retry=%ld chain=%ld exact=%ld generations=%ld deferred=%ld ties=%ld anchors=%ld mums=%ld why=%s\n", r.host.resident, r.host.resident_retry, r.host.device_chain, (long)exact, r.host.generations, r.host.regions_deferred, r.host.tie_runs, r.anchors, r.mums, why.c_str()); fclose(f);
         }
     return r;
+}
+
+// the progress lines of a step (stderr / stdout, as the reference prints them): each ONCE per step, also when the step is run again
+// on the host route after the resident route was left
+bool CoreRun::say(int stage) {
+    if (stage <= said_) return false;
+    said_ = stage;
+    return true;
 }
 
 StepReport CoreRun::step_once(bool resident) {
@@ -194,14 +206,15 @@ StepReport CoreRun::step_once(bool resident) {
     Aligner& a = *align;
     time_t start, end;
     time(&start);
-    std::cerr << "Searching for initial MUM anchors..." << std::endl;
+    a.announce_ = say(1);
+    if (a.announce_) std::cerr << "Searching for initial MUM anchors..." << std::endl;
     const double t0 = now_s();
     bool found = a.find_anchors();
     time(&end);
     a.anchor_time = (float)difftime(end, start);
     time(&start);
     if (!prm.anchors_only) {
-        std::cerr << "Performing recursive MUM search between MUM anchors..." << std::endl;
+        if (say(2)) std::cerr << "Performing recursive MUM search between MUM anchors..." << std::endl;
         found = a.extend();
     }
     time(&end);
@@ -220,20 +233,20 @@ StepReport CoreRun::step_once(bool resident) {
         // (resident route, order-free list logic: phases C-D were queued on the device behind the last generation)
         const bool from_device = a.resident_chain();
         if (a.resident_failed()) { r.path_s = now_s() - t0; return r; }      // (the order check queued ahead of phases C-D)
-        printf("        Finished recursive MUM search, elapsed time: %.0lf seconds\n\n", difftime(end, start));
+        if (say(3)) printf("        Finished recursive MUM search, elapsed time: %.0lf seconds\n\n", difftime(end, start));
         a.coarsen_time = (float)difftime(end, start);
         if (prm.random) {
-            std::cerr << "Filtering spurious matches..." << std::endl;
+            if (say(4)) std::cerr << "Filtering spurious matches..." << std::endl;
             time(&start);
             a.random = prm.random;
             if (!from_device) a.filter_mums(prm.random);
             time(&end);
-            printf("        Finished filtering spurious matches, elapsed time: %.0lf seconds\n\n", difftime(end, start));
+            if (say(5)) printf("        Finished filtering spurious matches, elapsed time: %.0lf seconds\n\n", difftime(end, start));
             a.random_time = (float)difftime(end, start);
             if (a.resident_failed()) { r.path_s = now_s() - t0; return r; }
         }
         time(&start);
-        std::cerr << "Creating and verifying final LCBs..." << std::endl;
+        if (say(6)) std::cerr << "Creating and verifying final LCBs..." << std::endl;
         const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
         double tl = now_s();
         auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[lcb] %-12s %.4f s (cpu %.4f)\n", what, t - tl, cpu_lap_s()); tl = t; } };
@@ -252,7 +265,7 @@ StepReport CoreRun::step_once(bool resident) {
         }
         time(&end);
         a.iclusters_time = (float)difftime(end, start);
-        printf("        LCBs created, elapsed time: %.0lf seconds\n\n", difftime(end, start));
+        if (say(7)) printf("        LCBs created, elapsed time: %.0lf seconds\n\n", difftime(end, start));
     }
     r.path_s = now_s() - t0;
     const Stats& s = a.stats;

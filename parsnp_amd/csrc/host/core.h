@@ -56,6 +56,10 @@ public:
     AlignerMemory memory;                 // arenas kept across step() calls (declared before align: destroyed after it)
     std::unique_ptr<Aligner> align;
     pm_session* session = nullptr;
+private:
+    std::string left_why_;                // why a step of this session left the resident route (later steps take the host route at once)
+    int said_ = 0;                        // the last progress line of the running step that was printed
+    bool say(int stage);
 };
 
 }  // namespace parsnp

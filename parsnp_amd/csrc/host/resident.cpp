@@ -208,40 +208,69 @@ bool Aligner::resident_extend() {
     int gi = 0;
     double tl = now_s();
     auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[resident generation %d] %-12s %.4f s\n", gi, what, t - tl); tl = t; } };
-    // sort by reference start, drop a region equal to its successor (:291-306), cut into clusters: maximal runs that overlap or touch on
-    // the reference (disjointness in the other genomes: the device).  Appends to now / now_id / first; false: the route is left
-    auto sort_and_cluster = [&](const std::vector<pm_region_info>& in, const std::vector<int32_t>& in_id, std::vector<pm_region_info>* now, std::vector<int32_t>* now_id, std::vector<int64_t>* first) {
-        const size_t base = now->size();
+    // The work list of a generation (:291-306), in two steps around the search of its new regions.
+    // sort_unique: sorted by reference start, a region equal to another one with its reference start dropped.  Regions that share a
+    // reference start and DIFFER stay, next to each other -- inside an inverted block of some genome the right neighbour of one anchor
+    // and the left neighbour of the next are one gap of the reference and two different gaps of that genome -- and tie_runs says
+    // where; a run that also lost a duplicate is noted (the reference erases ADJACENT duplicates only, and its unstable sort decides
+    // what is adjacent).
+    struct TieRun { size_t first, count; bool lost_duplicate; };
+    auto sort_unique = [&](const std::vector<pm_region_info>& in, const std::vector<int32_t>& in_id, std::vector<pm_region_info>* out, std::vector<int32_t>* out_id, std::vector<TieRun>* ties) {
         std::vector<Handle> h(in.size());
         for (size_t i = 0; i < in.size(); i++) h[i] = Handle{(long)in[i].ref_start, (int)i};
         std::sort(h.begin(), h.end());
+        size_t run0 = out->size();
+        bool lost = false;
+        auto close_run = [&]() { if (out->size() - run0 > 1) ties->push_back(TieRun{run0, out->size() - run0, lost}); };
         for (size_t i = 0; i < h.size(); i++) {
             const pm_region_info& r = in[(size_t)h[i].idx];
-            if (now->size() > base && now->back().ref_start == r.ref_start) {
+            if (out->size() > run0 && (*out)[run0].ref_start != r.ref_start) { close_run(); run0 = out->size(); lost = false; }
+            bool dup = false;
+            for (size_t y = run0; y < out->size() && !dup; y++) {
+                if ((*out)[y].ref_len != r.ref_len || (*out)[y].slength != r.slength) continue;
                 uint8_t same = 0;
-                if (now->back().ref_len == r.ref_len && now->back().slength == r.slength) {
-                    const int32_t x = now_id->back(), y = in_id[(size_t)h[i].idx];
-                    if (pm_store_regions_equal(session_, &x, &y, 1, &same) != PM_OK) engine_error("region comparison failed", PM_EHIP);
-                }
-                if (same) continue;
-                res_.failed = true; res_.why = "two different regions share a reference start";      // the unstable sort decides: host route
+                const int32_t x = (*out_id)[y], z = in_id[(size_t)h[i].idx];
+                if (pm_store_regions_equal(session_, &x, &z, 1, &same) != PM_OK) engine_error("region comparison failed", PM_EHIP);
+                dup = same != 0;
+            }
+            if (dup) { lost = true; continue; }
+            out->push_back(r); out_id->push_back(in_id[(size_t)h[i].idx]);
+        }
+        close_run();
+    };
+    // settle_ties (after the search): regions with one reference start are processed in the order the reference's unstable sort
+    // leaves them in, which nothing here can know -- but a region WITHOUT candidates changes nothing when it is processed (no MUM,
+    // no mark, no child), so the order only shows where two regions of a run have candidates (or the run lost a duplicate of a region
+    // that has some: the reference may process that one twice).  Then the route is left; else the run is put in an order of ours.
+    auto settle_ties = [&](std::vector<pm_region_info>* list, std::vector<int32_t>* ids, const std::vector<TieRun>& ties) {
+        for (const TieRun& t : ties) {
+            size_t with = 0, at = t.first;
+            for (size_t y = t.first; y < t.first + t.count; y++) if (cnt[(size_t)(*ids)[y]] > 0) { with++; at = y; }
+            stats.tie_runs++;
+            if (with > 1 || (with == 1 && t.lost_duplicate)) {
+                stats.tie_runs_open++;
+                res_.failed = true; res_.why = "two different regions with candidates share a reference start";      // the unstable sort decides: host route
                 return false;
             }
-            now->push_back(r); now_id->push_back(in_id[(size_t)h[i].idx]);
+            if (with == 1 && at != t.first + t.count - 1) { std::swap((*list)[at], (*list)[t.first + t.count - 1]); std::swap((*ids)[at], (*ids)[t.first + t.count - 1]); }
         }
+        return true;
+    };
+    // clusters: maximal runs that overlap or touch on the reference (what the other genomes do to them: the device)
+    auto cluster = [&](const std::vector<pm_region_info>& list, size_t base, std::vector<int64_t>* first) {
         long reach = -1;
-        for (size_t i = base; i < now->size(); i++) {
-            if (i == base || (*now)[i].ref_start > reach + 1) first->push_back((int64_t)i);
-            const long end = (long)((*now)[i].ref_start + (*now)[i].ref_len);
+        for (size_t i = base; i < list.size(); i++) {
+            if (i == base || list[i].ref_start > reach + 1) first->push_back((int64_t)i);
+            const long end = (long)(list[i].ref_start + list[i].ref_len);
             if (end > reach) reach = end;
         }
-        first->push_back((int64_t)now->size());
-        return true;
+        first->push_back((int64_t)list.size());
     };
     static const bool two_stages = test_hook("PARSNP_ONE_STAGE") == nullptr;      // test hook: every generation its own call
     while (!gen.empty()) {
         std::vector<pm_region_info> now; std::vector<int32_t> now_id;
         std::vector<int64_t> first;
+        std::vector<TieRun> ties;
         int64_t stage_first = 0;                      // > 0: the call holds two generations (pm_store_validate)
         std::vector<pm_region_info> rest; std::vector<int32_t> rest_id;
         if (gi == 0) {                  // the first pushed seed, before anything is sorted (:194-195 precede :291-292); every seed's search in ONE call
@@ -253,14 +282,18 @@ bool Aligner::resident_extend() {
             // does): the remaining seeds, sorted.  The device leaves them alone if it does
             if (two_stages && !gen.empty()) {
                 rest = gen; rest_id = gen_id;
-                if (!sort_and_cluster(gen, gen_id, &now, &now_id, &first)) return false;
+                sort_unique(gen, gen_id, &now, &now_id, &ties);
+                if (!settle_ties(&now, &now_id, ties)) return false;
+                cluster(now, 1, &first);
                 stage_first = 1;
                 gen.clear(); gen_id.clear();
             } else first.push_back(1);
         } else {
-            if (!sort_and_cluster(gen, gen_id, &now, &now_id, &first)) return false;
+            sort_unique(gen, gen_id, &now, &now_id, &ties);
             lap("sort");
             search(now, now_id);
+            if (!settle_ties(&now, &now_id, ties)) return false;
+            cluster(now, 0, &first);
             gen.clear(); gen_id.clear();
         }
         lap("search");
@@ -273,14 +306,15 @@ bool Aligner::resident_extend() {
         for (size_t i = 0; i < now.size(); i++) if (rc_[i] > 0) { lo = std::min(lo, r0[i]); hi = std::max(hi, r0[i] + rc_[i]); }
         if (hi > lo && info.size() < (size_t)hi) info.resize((size_t)hi);
         int32_t second_ran = 0;
-        int rc = pm_store_validate(session_, now_id.data(), r0.data(), rc_.data(), (int64_t)now.size(), first.data(), (int64_t)first.size() - 1, (int32_t)prm.q, &trouble, &nkids,
-                                   hi > lo ? lo : 0, hi > lo ? hi - lo : 0, hi > lo ? info.data() + lo : nullptr, stage_first, &second_ran, (int32_t)gi);
+        const int64_t ncl = (int64_t)first.size() - 1;
+        std::vector<int32_t> done((size_t)ncl, 0);
+        int rc = pm_store_validate(session_, now_id.data(), r0.data(), rc_.data(), (int64_t)now.size(), first.data(), ncl, (int32_t)prm.q, &trouble, &nkids,
+                                   hi > lo ? lo : 0, hi > lo ? hi - lo : 0, hi > lo ? info.data() + lo : nullptr, stage_first, &second_ran, (int32_t)gi, done.data());
         if (rc != PM_OK) engine_error("validation of a generation on the device failed", rc);
         collect_engine_timing();
         if (trouble) {
             res_.failed = true;
-            res_.why = (trouble & 8) ? "clusters of waiting regions overlap in some genome" : (trouble & 1) ? "a child region sorts before a region still waiting in its cluster"
-                     : (trouble & 2) ? "a reverse-strand member outside its region was accepted"
+            res_.why = (trouble & 2) ? "a reverse-strand member outside its region was accepted"
                      : "a region with too many candidates, or more candidates with a member outside their region than the engine notes";
             stats.generation_handover = gi;
             return false;
@@ -290,10 +324,21 @@ bool Aligner::resident_extend() {
         const int32_t* kid = pm_store_new_region_ids(session_);
         if (stage_first > 0 && !second_ran) {
             // the first seed pushed children: only it was validated.  What waits is the other seeds, then the children (:215-254)
-            now.resize(1); now_id.resize(1); r0.resize(1); rc_.resize(1);
+            first.resize(2); first[1] = 1; done.resize(1);
             gen = std::move(rest); gen_id = std::move(rest_id);
             stage_first = 0;
         }
+        // which regions were processed: all of a cluster, none of it (it meets an earlier cluster in some genome and waits for that
+        // one), or its first few (a child sorts before the next one).  What was not stays on the work list
+        std::vector<uint8_t> ran(now.size(), 0);
+        long waiting = 0;
+        for (size_t cl = 0; cl + 1 < first.size(); cl++)
+            for (int64_t x = first[cl]; x < first[cl + 1]; x++) {
+                if (x - first[cl] < done[cl]) ran[(size_t)x] = 1;
+                else if (x < (int64_t)now.size()) { gen.push_back(now[(size_t)x]); gen_id.push_back(now_id[(size_t)x]); waiting++; }
+            }
+        if (!ran[0]) fatal("a generation on the device processed nothing");
+        stats.regions_deferred += waiting;
         for (int64_t i = 0; i < nkids; i++) { gen.push_back(ki[i]); gen_id.push_back(kid[i]); }
         stats.t_validate += now_s() - tv;
         lap("validate");
@@ -302,13 +347,16 @@ bool Aligner::resident_extend() {
             // (resident_chain() collects them) and run beside the commit below
             size_t more = 0;
             for (size_t i = 0; i < now.size(); i++)
-                for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) more += (info[(size_t)c].state_flags & PM_ST_ACCEPTED) != 0;
+                for (int64_t c = r0[i]; ran[i] && c < r0[i] + rc_[i]; c++) more += (info[(size_t)c].state_flags & PM_ST_ACCEPTED) != 0;
             resident_chain_begin(mums.size() + more);
             lap("chain queued");
         }
         resident_records();      // the anchors' records first: the recursion's MUMs follow them in the pool
         // commit in list order (:215-254 push the MUMs of a region in candidate order)
+        long processed = 0;
         for (size_t i = 0; i < now.size(); i++) {
+            if (!ran[i]) continue;
+            processed++;
             if (const char* dump = test_hook("PARSNP_DUMP_VALIDATION"))      // test hook: what the device decided for every candidate of every region
                 if (FILE* f = fopen(dump, "a")) {
                     fprintf(f, "region %ld+%ld (generation %d):", (long)now[i].ref_start, (long)now[i].ref_len, gi);
@@ -336,7 +384,7 @@ bool Aligner::resident_extend() {
             }
             stats.regions_processed++; stats.cache_hits++;
         }
-        stats.generations += stage_first > 0 ? 2 : 1; stats.generation_regions += (long)now.size();
+        stats.generations += stage_first > 0 ? 2 : 1; stats.generation_regions += processed;
         lap("commit");
         gi += stage_first > 0 ? 2 : 1;
     }
@@ -389,6 +437,7 @@ bool Aligner::resident_chain() {
     lcbs.clear();
     lcbs.reserve((size_t)(ci.n_fillers + ci.n_lcbs));
     for (int64_t f = 0; f < ci.n_fillers; f++) { Lcb c; c.type = 0; c.length = 2; lcbs.push_back(std::move(c)); }      // (their rows: nothing reads them)
+    if (ci.n_mums > ci.n_in || (ci.n_mums > 0 && !heads[0])) fatal("the device's MUM list does not begin with an LCB head, or is longer than the list it came from");
     for (int64_t x = 0; x < ci.n_mums; x++) {
         if (rows[x] < 0 || rows[x] > top || of[(size_t)rows[x]] < 0) fatal("the device's MUM list names a row the host does not hold");
         const int idx = of[(size_t)rows[x]];

@@ -215,7 +215,7 @@ def test_device_rows_and_overlap_flags(emu, tmp_path, name, variant):
 
 
 @pytest.mark.parametrize("name,flagged_div,expect", [("viral50", 8, "resident"), ("pop6x200k", 8, "resident"), ("pop12x400k", 8, "resident"), ("pop12x400k", 1, "resident"), ("popinv12x400k", 8, "resident"),
-                                                      ("rearr6x300k", 8, "host"), ("rearr6x300k", 1, "left"), ("messy", 8, "left"), ("pchunk", 8, "host")])
+                                                      ("rearr6x300k", 8, "resident"), ("rearr6x300k", 1, "resident"), ("messy", 8, "resident"), ("pchunk", 8, "host")])
 def test_resident_route(emu, tmp_path, name, flagged_div, expect):
     """The resident route (csrc/host/resident.cpp over include/parsnp_mum.h's pm_store_*: candidates validated and trimmed, regions
     walked, generations validated, chaining verdicts and inter-LCB fillers computed on rows that stay with the engine) in the

@@ -276,7 +276,7 @@ def test_parsnp_core_device_rows_and_overlap_flags(libs, tmp_path, name, variant
 
 
 @pytest.mark.parametrize("name,flagged_div,expect", [("viral50", 8, "resident"), ("pop6x200k", 8, "resident"), ("pop12x400k", 8, "resident"), ("pop12x400k", 1, "resident"), ("popinv12x400k", 8, "resident"), ("pop20x1m", 8, "resident"),
-                                                      ("bact8", 8, "resident"), ("rearr6x300k", 8, "host"), ("rearr6x300k", 1, "left"), ("poprearr10x400k", 1, "left"), ("messy", 8, "left"), ("pchunk", 8, "host")])
+                                                      ("bact8", 8, "resident"), ("rearr6x300k", 8, "resident"), ("rearr6x300k", 1, "resident"), ("poprearr10x400k", 1, "resident"), ("messy", 8, "resident"), ("pchunk", 8, "host")])
 def test_parsnp_core_resident_route(libs, tmp_path, name, flagged_div, expect):
     """The resident route on the device (store_kernels.h through pm_store_*): the reference's bytes where it is taken, where the
     engine declines the anchor list and where the route is left and the step repeated on the host route; thresholds lowered so
