@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 RANDOM_PEAK_GBS = 3400.0   # measured ceiling of scattered 64-byte requests (scripts/hbm_calib.hip gather kernels, profiles/r01/calibration.json: 54 G requests/s): what an index probe can reach
-PROFILE_ROUND = "r05"   # profiles/<round>/traffic_seed_extend.json, calibration.json: the PMC passes of the shipped binary
+PROFILE_ROUND = "r06"   # profiles/<round>/traffic_seed_extend.json, calibration.json: the PMC passes of the shipped binary
 
 
 def engine_src_sha256():
@@ -504,7 +504,7 @@ def main():
                 roof = {"bound": "hbm",      # (the contract's two rooflines; what the kernel really waits for: `limiter`, `issue_frac`)
                         "limiter": limiter,
                         "issue_frac": issue.get("issue_frac") if issue else None, "issue": issue,
-                        "kernel": "seed_extend (SeedExtend + SeedRest + GroupedPairEvents + SmallPairEvents)" if dom == "seed_extend" else dom,
+                        "kernel": "seed_extend (SeedExtend + SeedRest + GroupedPairEvents + SmallPairEvents: bytes and time both cover these four)" if dom == "seed_extend" else dom,
                         "achieved": round(traffic_gbs if traffic_gbs else alg_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": frac_traffic if frac_traffic is not None else round(alg_gbs / HBM_PEAK_GBS, 5),
                         "frac_basis": ("fabric-side counter traffic of this build per launch (FETCH_SIZE + WRITE_SIZE, corrected; Infinity-Cache hits included: an upper bound of the HBM bytes) / HIP-event time of the launch"
@@ -542,13 +542,37 @@ def main():
                 "compact": ("CompactCandidates + Dirty* + store append", (5.0 * ncand * G) + 3 * 5.0 * nacc * ngen, "5 B in per (candidate, genome); 5 B per (accepted row, genome) out, once more read by the overlap flags and once copied into the MUM store"),
                 "settle": ("SettleClean + StoreMark + Collide* + SettleFlagged / Tangled", 20.0 * reports[-1]["anchors"] * ngen + 3 * (n_ref + 1) * ngen / 8.0, "4 B row entry + two 8-byte words per (anchor, genome) + three images of 1 bit per base cleared"),
                 "index": ("IndexInsert", 24.0 * npos, "8 B slot + 16 B sequence window per reference position"),
+                "repeat": ("RunLength + RepeatLength", 28.0 * npos, "16 B sequence window + 8 B slot + 4 B out per reference position"),
+                "seeds": ("AnchorList + SeedCount + SeedPlace", 2 * 20.0 * reports[-1]["anchors"] * ngen, "per (anchor, genome) and side: 4 B row entry + two 8-byte image words"),
+                "validate": ("Clusters* + ClusterValidate", 20.0 * max(0, reports[-1]["mums"] - reports[-1]["anchors"]) * ngen * 3, "per (candidate, genome): 4 B row entry + two image words, ~3 candidates per accepted MUM"),
+                "chain": ("Foreign* + Chain*", 2 * 2 * 4.0 * reports[-1]["mums"] * ngen, "two passes over the MUM list, two rows of 4 B per genome per pair"),
             }
+            # ... and beside every model what the fabric counters saw for the phase's kernels in one step of THIS build
+            # (profiles/<round>/traffic_phases.json, scripts/profile_summary.py: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc
+            # passes, summed over the kernels of the phase; quoted only for the library it was measured on, on this workload)
+            phase_traffic, phase_traffic_note = {}, "no PMC pass of this build on file (profiles/%s/traffic_phases.json)" % PROFILE_ROUND
+            try:
+                pj = json.load(open(os.path.join(pdir, "traffic_phases.json")))
+                if args.workload == "bact200" and G == 200 and pj.get("so_sha256") == so_sha256():
+                    phase_traffic, phase_traffic_note = pj.get("phases", {}), pj.get("note")
+                elif pj.get("so_sha256") != so_sha256():
+                    phase_traffic_note = "profiles/%s/traffic_phases.json was measured on another build of the engine: not quoted" % PROFILE_ROUND
+            except (OSError, ValueError):
+                pass
             ktable = []
             for k, (names, nbytes, model) in models.items():
                 ms = totals.get(k, 0.0)
                 if ms > 0:
-                    ktable.append({"phase": k, "kernels": names, "alg_bytes_per_step": int(nbytes), "ms_per_step": round(ms, 4), "achieved_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
-                                   "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "model": model})
+                    row = {"phase": k, "kernels": names, "alg_bytes_per_step": int(nbytes), "ms_per_step": round(ms, 4), "achieved_GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                           "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "model": model}
+                    t = phase_traffic.get(k)
+                    if t:      # counters: raw = FETCH_SIZE + WRITE_SIZE; upper = 2 x FETCH_SIZE + WRITE_SIZE (coalesced 16 B/lane reads are tallied at half)
+                        row.update({"traffic_bytes_per_step": int(t["raw_bytes_per_step"]), "traffic_upper_bytes_per_step": int(t["upper_bytes_per_step"]),
+                                    "traffic_GBs": round(t["raw_bytes_per_step"] / (ms * 1e-3) / 1e9, 1), "traffic_frac": round(t["raw_bytes_per_step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "traffic_over_alg": round(t["raw_bytes_per_step"] / nbytes, 2) if nbytes else None, "traffic_kernels": t.get("kernels")})
+                    else:
+                        row["traffic_bytes_per_step"] = None
+                    ktable.append(row)
             ktable.sort(key=lambda r: -r["ms_per_step"])
             # where the step's wall time is not device time: ms_per_step - the HIP-event phases of every engine call of a step
             # (the list logic of the host, the round trips, the launches themselves)
@@ -575,6 +599,7 @@ def main():
                         other[wl] = {"error": "did not finish within 600 s"}
             if roof is not None:
                 roof["kernels"] = ktable
+                roof["kernels_traffic_note"] = phase_traffic_note
             line = {
                 "metric": "genomes/sec (MUM+LCB end-to-end)", "value": round(value, 4), "unit": "genomes/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -615,6 +640,7 @@ def main():
                 "regions": {"processed": rep["regions_processed"], "engine_calls": rep["finder_calls"], "cache_misses": rep["cache_misses"],
                             "speculative_rounds": rep["spec_rounds"]},
                 "roofline": roof,
+                "build": {"so_sha256": so_sha256(), "engine_src_sha256": engine_src_sha256()},      # what ran: profiles/<round>/*.json carry the same stamps
                 "cpu_baseline": cpu_baseline(workdir, rp, qs, args.cpu_sample) if (args.cpu_sample > 0 and world == 1) else None,
             }
             print(json.dumps(line))

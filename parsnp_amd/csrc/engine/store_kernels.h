@@ -999,8 +999,8 @@ struct ClustersDisjoint {
 // breakpoint regions of an inversion are the same gap of the inverted genome) Y must see X's marks: Y is DEFERRED, it stays on
 // the work list and runs in a later generation, when no cluster before it meets it any more.  A cluster that meets nothing
 // earlier runs now; the clusters that run together are pairwise disjoint, which is all ClusterValidate needs.
-//   ClusterExtents   one wavefront per cluster: its extent [lo, hi + 2) of every genome (they overlap, touch, or have no base
-//                    between = they share a bit) ORed into the scratch image `once`, bits that were there already into `twice`;
+//   ClusterExtents   one wavefront per cluster: what it touches in every genome (cluster_pieces: the union of its regions, each with two
+//                    bases of margin) ORed into the scratch image `once`, bits that were there already into `twice`;
 //   ClusterInvolved  a `twice` bit under the own extent = the cluster meets another one; such a cluster writes its number into
 //                    every 64-base WORD of its extents (`owner`: one int32 per image word, the smallest number wins);
 //   ClusterDefer     an involved cluster that finds a smaller number than its own in a word of its extents is deferred.  (A word
@@ -1008,14 +1008,39 @@ struct ClustersDisjoint {
 //                    need -- a generation more, never a different result);
 //   ClusterExtents with mark = 0 wipes the words it wrote (the scratch arrays are kept all zero between calls).
 // owner[] holds 0x7fffffff - cluster so that zero means "nobody" and the smallest number is the largest value.
-PM_HD void cluster_extent(int32_t ngen, const int64_t* rg_start, const int64_t* rg_len, const int32_t* now_region, int64_t p0, int64_t p1, int j, int64_t nbits, int64_t* a, int64_t* b) {
-    int64_t hi = -1, lo = (int64_t)1 << 62;
-    for (int64_t x = p0; x < p1; x++) {
-        const int64_t r = now_region[x]; const int64_t s = rg_start[r * ngen + j], e = s + rg_len[r * ngen + j];
-        if (s < lo) lo = s;
-        if (e > hi) hi = e;
+// What a cluster touches in genome j: the union of its regions' intervals [start, start + len + 2) (the + 2: clusters that touch, or have
+// no base between, meet as well).  Not the hull: where a genome is rearranged the regions of one cluster can lie megabases apart --
+// the seed region before an inverted block and the one behind it are neighbours on the reference -- and a hull would cover, and
+// collide with, everything between them.  The lane sorts the cluster's intervals in its genome and hands every maximal run of
+// overlapping ones to f(a, b) once, so that a cluster never meets ITSELF; a cluster of more than kPieces regions (dense repeats)
+// is taken by its hull.
+constexpr int kPieces = 8;
+template <class F> PM_HD void cluster_pieces(int32_t ngen, const int64_t* rg_start, const int64_t* rg_len, const int32_t* now_region, int64_t p0, int64_t p1, int j, int64_t nbits, F f) {
+    const int cnt = (int)(p1 - p0);
+    auto clip = [&](int64_t a, int64_t b) { if (a < 0) a = 0; if (b > nbits) b = nbits; if (a < b) f(a, b); };
+    if (cnt > kPieces) {
+        int64_t hi = -1, lo = (int64_t)1 << 62;
+        for (int64_t x = p0; x < p1; x++) {
+            const int64_t r = now_region[x]; const int64_t s = rg_start[r * ngen + j], e = s + rg_len[r * ngen + j];
+            if (s < lo) lo = s;
+            if (e > hi) hi = e;
+        }
+        clip(lo, hi + 2);
+        return;
     }
-    *a = lo < 0 ? 0 : lo; *b = hi + 2 > nbits ? nbits : hi + 2;
+    int64_t a[kPieces], b[kPieces];
+    for (int i = 0; i < cnt; i++) {      // insertion sort by start
+        const int64_t r = now_region[p0 + i]; const int64_t s = rg_start[r * ngen + j], e = s + rg_len[r * ngen + j] + 2;
+        int k = i;
+        while (k > 0 && a[k - 1] > s) { a[k] = a[k - 1]; b[k] = b[k - 1]; k--; }
+        a[k] = s; b[k] = e;
+    }
+    int64_t ca = a[0], cb = b[0];
+    for (int i = 1; i < cnt; i++) {
+        if (a[i] <= cb) { if (b[i] > cb) cb = b[i]; }
+        else { clip(ca, cb); ca = a[i]; cb = b[i]; }
+    }
+    clip(ca, cb);
 }
 struct ClusterExtents {
     int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first;
@@ -1024,19 +1049,19 @@ struct ClusterExtents {
         const int64_t cl = cl0 + w;
         const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
         lanes_for(1, ngen, [&](int j) {
-            int64_t a, b;
-            cluster_extent(ngen, rg_start, rg_len, now_region, p0, p1, j, once.nbits[j], &a, &b);
             const int64_t base = once.word_off[j];
-            while (a < b) {
-                const int f = (int)(a & 63);
-                const int64_t span = (64 - f) < (b - a) ? (64 - f) : (b - a);
-                const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << f;
-                if (mark) {
-                    const uint64_t old = atomic_fetch_or64(&once.image[base + (a >> 6)], mask);
-                    if (old & mask) atomic_or64(&twice[base + (a >> 6)], old & mask);
-                } else { once.image[base + (a >> 6)] = 0; twice[base + (a >> 6)] = 0; owner[base + (a >> 6)] = 0; }
-                a += span;
-            }
+            cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, once.nbits[j], [&](int64_t a, int64_t b) {
+                while (a < b) {
+                    const int f = (int)(a & 63);
+                    const int64_t span = (64 - f) < (b - a) ? (64 - f) : (b - a);
+                    const uint64_t mask = (span == 64 ? ~0ull : ((1ull << span) - 1)) << f;
+                    if (mark) {
+                        const uint64_t old = atomic_fetch_or64(&once.image[base + (a >> 6)], mask);
+                        if (old & mask) atomic_or64(&twice[base + (a >> 6)], old & mask);
+                    } else { once.image[base + (a >> 6)] = 0; twice[base + (a >> 6)] = 0; owner[base + (a >> 6)] = 0; }
+                    a += span;
+                }
+            });
         });
     }
 };
@@ -1048,19 +1073,16 @@ struct ClusterInvolved {
         const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
         uint32_t hit = 0;
         lanes_for(1, ngen, [&](int j) {
-            int64_t a, b;
-            cluster_extent(ngen, rg_start, rg_len, now_region, p0, p1, j, twice.nbits[j], &a, &b);
-            if (img_any(twice, j, a, b)) hit = 1;
+            cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, twice.nbits[j], [&](int64_t a, int64_t b) { if (!hit && img_any(twice, j, a, b)) hit = 1; });
         });
         hit = wave_or_u32(hit);
         if (wave_leader()) involved[cl] = hit ? 1 : 0;
         if (!hit) return;
         const int32_t mine = 0x7fffffff - (int32_t)cl;
         lanes_for(1, ngen, [&](int j) {
-            int64_t a, b;
-            cluster_extent(ngen, rg_start, rg_len, now_region, p0, p1, j, twice.nbits[j], &a, &b);
-            if (a >= b) return;
-            for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6); wd++) atomic_max32(&owner[twice.word_off[j] + wd], mine);
+            cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, twice.nbits[j], [&](int64_t a, int64_t b) {
+                for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6); wd++) atomic_max32(&owner[twice.word_off[j] + wd], mine);
+            });
         });
     }
 };
@@ -1074,10 +1096,9 @@ struct ClusterDefer {
         const int32_t mine = 0x7fffffff - (int32_t)cl;
         uint32_t earlier = 0;
         lanes_for(1, ngen, [&](int j) {
-            int64_t a, b;
-            cluster_extent(ngen, rg_start, rg_len, now_region, p0, p1, j, nbits[j], &a, &b);
-            if (a >= b) return;
-            for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6); wd++) if (owner[word_off[j] + wd] > mine) earlier = 1;
+            cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, nbits[j], [&](int64_t a, int64_t b) {
+                for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6) && !earlier; wd++) if (owner[word_off[j] + wd] > mine) earlier = 1;
+            });
         });
         earlier = wave_or_u32(earlier);
         if (wave_leader()) defer[cl] = earlier ? 1 : 0;

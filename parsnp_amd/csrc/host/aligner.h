@@ -358,6 +358,7 @@ private:
         std::string why;
         int64_t table = 0;
         std::vector<int32_t> start0;                                           // reference start of pool[i]
+        std::vector<int64_t> found_key;                                        // pool[i] of the recursion: where its REGION stands in the reference's processing order (reference start, generation; -1: the first pushed seed)
         std::vector<pm_region_info> gen_info; std::vector<int32_t> gen_id;     // the seed regions, in push order
         std::vector<int32_t> fallback_start; std::vector<uint8_t> fallback_strand;   // rows fetched for the host route
         std::vector<uint64_t> image;                                           // the layout, fetched for parsnp.unalign

@@ -97,7 +97,7 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
     // recursion's search waits for them (a helper thread wrote them until round 5: starting it cost more than it hid)
     res_.active = true; res_.table = table;
     kept_results_.push_back(a.owner);
-    pool.clear(); res_.start0.clear();
+    pool.clear(); res_.start0.clear(); res_.found_key.clear();
     std::vector<int32_t> acc;
     size_t nacc = 0;
     if (fused) { for (size_t c = 0; c < a.count; c++) nacc += (info[c].state_flags & PM_ST_ACCEPTED) != 0; }
@@ -380,6 +380,10 @@ bool Aligner::resident_extend() {
                 Mum m;
                 m.id = next_id_ - 1; m.length = info[(size_t)c].len; m.slength = now[i].slength; m.row = (int32_t)c;
                 pool.push_back(m); res_.start0.push_back(info[(size_t)c].start0);
+                // (generation of the region: the second stage of a two-stage call is one later; 0 = the first pushed seed, processed before anything is sorted)
+                const int g = gi + (stage_first > 0 && i >= (size_t)first[(size_t)stage_first] ? 1 : 0);
+                res_.found_key.resize(pool.size(), -1);
+                res_.found_key.back() = g <= 0 ? -1 : (int64_t)now[i].ref_start * 4096 + (g < 4095 ? g : 4095);
                 mums.push_back((int)pool.size() - 1);
             }
             stats.regions_processed++; stats.cache_hits++;
@@ -426,7 +430,21 @@ bool Aligner::resident_chain() {
     collect_engine_timing();
     if (ci.n_in != (int64_t)mums.size()) fatal("the device's MUM list and the host's differ");
     if (ci.trouble & 4) { res_.failed = true; res_.why = kOrderWhy; return false; }
-    if (ci.trouble & 1) { res_.chain_why = "two MUMs share a reference start"; return false; }
+    if (ci.trouble & 1) {
+        // sort( mums ) (:338, :2571) is unstable: what it does with two MUMs of one reference start depends on the list it is handed.
+        // The reference's list is the anchors followed by the recursion's MUMs as doWork found them -- region after region in ITS
+        // order (the first pushed seed, then always the waiting region with the smallest reference start: a parent before its
+        // children), candidate after candidate -- while this route found them generation by generation.  Put them in that order
+        // (a region's rows follow one another in the store), then the host's list logic does what the reference's does.
+        res_.found_key.resize(pool.size(), -1);
+        std::stable_sort(mums.begin() + (long)m0, mums.end(), [&](int a, int b) {
+            if (res_.found_key[(size_t)a] != res_.found_key[(size_t)b]) return res_.found_key[(size_t)a] < res_.found_key[(size_t)b];
+            return pool[(size_t)a].row < pool[(size_t)b].row;
+        });
+        res_.chain_why = "two MUMs share a reference start";
+        if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[resident] phases C-D by the host's list logic: %s\n", res_.chain_why.c_str());
+        return false;
+    }
     if (ci.trouble & 2) fatal("inter-cluster region bookkeeping would overrun in the reference");
     // store row -> MUM record
     int32_t top = 0;

@@ -19,8 +19,37 @@ def find(d, suffix):
 
 
 def short(name):
-    m = re.search(r"pm_kernel<pm::(\w+)>", name)
-    return m.group(1) if m else name.split("(")[0]
+    """pm_kernel<pm::X> and pm_wave_kernel<pm::X> -> X; the engine's own plain kernels and the library's by their function name"""
+    m = re.search(r"pm_(?:wave_)?kernel<pm::(\w+)>", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"(pm_fill16|pm_fill_many|gap_align_kernel)", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"rocprim::\w+::detail::(?:trampoline_kernel<rocprim::\w+::detail::wrapped_(\w+?)_config|(\w+?)<)", name)
+    if m:
+        return "rocprim_" + (m.group(1) or m.group(2))
+    name = name.split("(")[0].strip()
+    return name[5:] if name.startswith("void ") else name
+
+
+# the device phases of a bench step (bench.py: `roofline.kernels`) and the kernels they launch -- the fabric-side counter bytes of a
+# phase are the sums over these (traffic_phases.json); a rocPRIM kernel belongs to the phase that calls the primitive most
+PHASES = {
+    "seed_extend": ["SeedExtend", "SeedRest", "GroupedPairEvents", "SmallPairEvents"],
+    "sort": ["SliceOffsets", "CompactEvents", "EventBucket", "EventPlace", "EventOrder", "rocprim_radix_sort_onesweep", "rocprim_radix_sort_block_sort", "rocprim_merge_sort_block_merge", "rocprim_merge_sort_block_sort"],
+    "scan": ["PairBounds", "GroupedBounds", "WaveSummary", "WaveScan"],
+    "master_ep": ["CoarseFill", "MasterEPSeg", "MasterEP"],
+    "fold": ["FoldCandidates", "CandMark", "CandWrite"],
+    "compact": ["OkCount", "CompactCandidates", "CompactSp", "DirtyExtent", "DirtyPrefix", "DirtyMark", "DirtyMerge"],
+    "settle": ["SettleClean", "StoreMarkOrdered", "StoreMark", "LayoutSentinel", "CollideMark", "CollideTest", "CollideClear", "CountTangled", "SettleFlagged", "SettleTangled",
+               "TangleOwner", "TangleSettle", "TangleClear", "StoreInfoOut"],
+    "index": ["IndexInsert"],
+    "repeat": ["RunLength", "RepeatLength"],
+    "seeds": ["ChainFlag", "AnchorList", "SeedCount", "SeedPlace", "SeedWalk"],
+    "validate": ["ClustersDisjoint", "ClusterExtents", "ClusterInvolved", "ClusterDefer", "ClusterValidate", "StageGate"],
+    "chain": ["ForeignBound", "ForeignScan", "ForeignDecideHits", "ChainKeys", "ChainJudge", "ChainHeads", "ChainLcbSum", "ChainDissolve", "ChainUnmark", "ChainCompact", "ChainFill", "ChainOut"],
+}
 
 
 def db_rows(d, sql):
@@ -51,6 +80,16 @@ def pmc(d):
         e["dispatches"] += 1
         e["sum"] += float(row["Counter_Value"])
     return out
+
+
+def traced_steps(out):
+    """steps + warm-up of the bench run the --stats pass traced (its own JSON line)"""
+    try:
+        bj = [l for l in open(os.path.join(out, "summary", "bench_under_rocprof.json")).read().splitlines() if l.startswith("{")][-1]
+        d = json.loads(bj)
+        return int(d["steps"]) + int(d["warmup"])
+    except Exception:   # noqa: BLE001
+        return 4
 
 
 def lib_sha():
@@ -122,6 +161,22 @@ def main():
                   "fetch_bytes": fetch[k]["sum"] * 1024 if k in fetch else None,
                   "write_bytes": write[k]["sum"] * 1024 if k in write else None}
     json.dump(per, open(os.path.join(summ, "pmc_per_kernel.json"), "w"), indent=1)
+    # the same per device phase of a bench step (the PMC passes profile ONE step with no warm-up): what bench.py sets beside the byte
+    # model of every phase.  raw = FETCH_SIZE + WRITE_SIZE as counted; upper = 2 x FETCH_SIZE + WRITE_SIZE (if every read were a
+    # wide coalesced 16 B/lane stream, which the counter tallies at half: calibration.json) -- the truth lies between the two
+    ph = {}
+    for name, kernels in PHASES.items():
+        f = sum(per[k]["fetch_bytes"] or 0 for k in kernels if k in per)
+        w = sum(per[k]["write_bytes"] or 0 for k in kernels if k in per)
+        if f or w:
+            ph[name] = {"kernels": [k for k in kernels if k in per], "fetch_bytes_per_step": f, "write_bytes_per_step": w, "raw_bytes_per_step": f + w, "upper_bytes_per_step": 2 * f + w,
+                        "rocprof_ms_per_step": round(sum(stats[k]["total_ms"] for k in kernels if k in stats) / max(1, traced_steps(out)), 4)}
+    named = {k for ks_ in PHASES.values() for k in ks_}
+    json.dump({"note": "fabric-side counter bytes per device phase of ONE bench step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `bench.py --steps 1 --warmup 0`; Infinity-Cache hits included); "
+                       "raw = FETCH_SIZE + WRITE_SIZE, upper = 2 x FETCH_SIZE + WRITE_SIZE (wide coalesced reads are tallied at half: calibration.json); rocprof_ms_per_step from the --stats pass",
+               "so_sha256": lib_sha(), "engine_src_sha256": engine_src_sha(), "phases": ph,
+               "kernels_in_no_phase": {k: v for k, v in per.items() if k not in named and ((v["fetch_bytes"] or 0) + (v["write_bytes"] or 0)) > 1e6}},
+              open(os.path.join(summ, "traffic_phases.json"), "w"), indent=1)
     cal = {}
     known = {}
     try:
@@ -144,12 +199,13 @@ def main():
     json.dump(cal, open(os.path.join(summ, "calibration.json"), "w"), indent=1)
     # the event search of one engine call = SeedExtend (index-seeded samples) + SmallPairEvents (pairs that fit 128 bases,
     # compared in registers): bench.py times them together as the `seed_extend` phase, so they are summed here too
-    se, sp, sr = per.get("SeedExtend"), per.get("SmallPairEvents"), per.get("SeedRest")
+    se, sp, sr, gp = per.get("SeedExtend"), per.get("SmallPairEvents"), per.get("SeedRest"), per.get("GroupedPairEvents")
     if se and se["fetch_bytes"] is not None and se["write_bytes"] is not None:
         n = se["dispatches"]
-        fetch = se["fetch_bytes"] + sum(x["fetch_bytes"] for x in (sp, sr) if x and x["fetch_bytes"])
-        write = se["write_bytes"] + sum(x["write_bytes"] for x in (sp, sr) if x and x["write_bytes"])
-        st_se, st_sp, st_sr = stats.get("SeedExtend", {}), stats.get("SmallPairEvents", {}), stats.get("SeedRest", {})
+        # (GroupedPairEvents too: bench.py's `seed_extend` phase time holds it -- its `grouped_events` mark is added to the phase)
+        fetch = se["fetch_bytes"] + sum(x["fetch_bytes"] for x in (sp, sr, gp) if x and x["fetch_bytes"])
+        write = se["write_bytes"] + sum(x["write_bytes"] for x in (sp, sr, gp) if x and x["write_bytes"])
+        st_se, st_sp, st_sr, st_gp = stats.get("SeedExtend", {}), stats.get("SmallPairEvents", {}), stats.get("SeedRest", {}), stats.get("GroupedPairEvents", {})
         calls = st_se.get("calls")
         # The counters sit on the fabric side of the L2 (TCC_EA0_RDREQ x 64 B): Infinity-Cache hits are INCLUDED, so this is
         # fabric traffic, an upper bound of the HBM bytes.  Calibration (calibration.json): scattered 8-16 B probes count 64 B per
@@ -172,7 +228,7 @@ def main():
         n_se = n
         n = bench_launches or n
         corr = corr / n
-        t = {"kernel": "seed_extend = SeedExtend + SeedRest + SmallPairEvents", "workload": "bact200, the event search of every engine call of one bench step (anchor + recursion)",
+        t = {"kernel": "seed_extend = SeedExtend + SeedRest + GroupedPairEvents + SmallPairEvents", "workload": "bact200, the event search of every engine call of one bench step (anchor + recursion)",
              "dispatches": n, "fetch_bytes_per_launch": fetch / n, "write_bytes_per_launch": write / n,
              "raw": {"FETCH_SIZE": fetch / n, "WRITE_SIZE": write / n},
              "seed_extend_dispatches_per_step": n_se, "launches_per_step": n,
@@ -181,7 +237,8 @@ def main():
              "hbm_bytes_per_launch": (fetch + write) / n + corr,
              "correction": "FETCH_SIZE + 0.5 x query-stream bytes (coalesced 16 B/lane streams are tallied at half, calibration.json calib_stream16) + WRITE_SIZE; scattered probes count 64 B per lane and are taken as they are",
              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, this binary; fabric-side counters: Infinity-Cache hits included (upper bound of HBM bytes); coalesced query stream corrected x2",
-             "rocprof_avg_launch_ms": ((st_se.get("total_ms", 0) + st_sp.get("total_ms", 0) + st_sr.get("total_ms", 0)) / calls) if calls else None,
+             "rocprof_avg_launch_ms": ((st_se.get("total_ms", 0) + st_sp.get("total_ms", 0) + st_sr.get("total_ms", 0) + st_gp.get("total_ms", 0)) / calls) if calls else None,
+             "rocprof_grouped_pair_events_avg_ms": st_gp.get("avg_ms"),
              "rocprof_calls": calls,
              "rocprof_seed_extend_avg_ms": st_se.get("avg_ms"), "rocprof_seed_extend_max_ms": st_se.get("max_ms"), "rocprof_seed_rest_avg_ms": st_sr.get("avg_ms"), "rocprof_seed_rest_max_ms": st_sr.get("max_ms"),
              "rocprof_small_pair_events_avg_ms": st_sp.get("avg_ms"),

@@ -181,6 +181,60 @@ def test_clusters_in_another_order_on_gpu(tmp_path, monkeypatch):
     clusters_in_another_order(CORE_HOOKS_BIN, tmp_path, monkeypatch)
 
 
+def waiting_clusters(core, tmp_path, monkeypatch):
+    """a population with a 60 kb inversion in every third genome: the seed region before an inverted block and the one behind it are
+    neighbours in the inverted genome, so the two clusters they belong to on the reference MEET there, and the reference (which always
+    pops the region with the smallest reference start) finishes the first and everything it leads to before the second.  Until round
+    6 the route was left there; now the later cluster WAITS a generation (pm_store_validate's done[]: ClusterExtents / ClusterInvolved
+    / ClusterDefer) -- the reference binary's bytes, the route kept, a region deferred"""
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PARSNP_RESIDENT_LOG=str(tmp_path / "route.log")).items():
+        monkeypatch.setenv(k, v)
+    ref, gs = synth.pop_inverted(seed=43, n=400_000, n_genomes=12, div=0.02, indel_frac=0.05, inv_every=3, inv_len=60_000)
+    rp, qs = synth.write_set(str(tmp_path / "in"), ref, gs)
+    a = run(REFBIN, rp, qs, str(tmp_path / "ref"), dict(threads=3))
+    b = run(core, rp, qs, str(tmp_path / "mine"), dict(threads=3))
+    assert a == b
+    route = open(str(tmp_path / "route.log")).read()
+    assert "resident=1" in route and "retry=0" in route and "deferred=0" not in route, route
+
+
+def test_waiting_clusters(emu, tmp_path, monkeypatch):
+    waiting_clusters(emu[1], tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_waiting_clusters_on_gpu(tmp_path, monkeypatch):
+    waiting_clusters(CORE_HOOKS_BIN, tmp_path, monkeypatch)
+
+
+def tied_mums(core, tmp_path, monkeypatch):
+    """seed 8953 of round 6's campaign: two ACCEPTED MUMs with one reference start.  Aligner::trim walks the genomes once, in order: a
+    later genome shifts the second candidate by a base onto the first one's reference start after the reference's own turn has passed
+    (:1399-1477).  sort( mums ) (:338) is unstable, so what it does with the pair depends on the list it is handed -- the reference's is in
+    doWork's processing order, the resident route's in generation order.  The device's chain reports the tie; the host then puts the
+    recursion's MUMs into the reference's order (region by region by reference start and generation, row by row) before its own list
+    logic sorts them: the reference binary's bytes (23 MUMs filtered, not 24), the route kept"""
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PARSNP_RESIDENT_LOG=str(tmp_path / "route.log")).items():
+        monkeypatch.setenv(k, v)
+    ref, gs, kw, contigs = random_case(8953, False)
+    kw["threads"] = 3
+    rp, qs = write(str(tmp_path / "in"), ref, gs, contigs, 8953)
+    a = run(REFBIN, rp, qs, str(tmp_path / "ref"), kw)
+    b = run(core, rp, qs, str(tmp_path / "mine"), kw)
+    assert a == b
+    route = open(str(tmp_path / "route.log")).read()
+    assert "resident=1" in route and "retry=0" in route and "chain=0" in route, route      # (chain=0: the tie was reported, the host's list logic ran)
+
+
+def test_tied_mums_on_the_resident_route(emu, tmp_path, monkeypatch):
+    tied_mums(emu[1], tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_tied_mums_on_the_resident_route_on_gpu(tmp_path, monkeypatch):
+    tied_mums(CORE_HOOKS_BIN, tmp_path, monkeypatch)
+
+
 def order_case(core, tmp_path, monkeypatch, route):
     """seed 7059 of round 5's campaign: a recursion candidate (7 bases, one reverse-strand member) whose flipped member lies 20 kb
     outside its region, where another region's MUM gets marked.  The reference processes that other region LATER, trims the
