@@ -1199,6 +1199,7 @@ public:
         uint64_t* trouble = (uint64_t*)(hdr + kChTrouble);
         // first pass: verdicts, chains, their lengths, the dissolved ones out of the layout and out of the list
         be.launch_wave("chain_judge", (int64_t)cap, ChainJudge{S, d_ch_skey.p, d_ch_srow.p, n1, d, diag_diff, d_ch_verdict.p, trouble, force_chain_tie ? 1 : 0});
+        be.launch("chain_judge_reverse", (int64_t)cap, ChainJudgeReverse{S, d_ch_srow.p, n1, d, diag_diff, d_ch_verdict.p});
         be.launch("chain_heads", (int64_t)cap + 1, ChainHeads{d_ch_verdict.p, n1, d_ch_head.p});
         be.exclusive_scan(d_ch_head.p, d_ch_hpos.p, cap + 1);
         be.launch("chain_lcb_sum", (int64_t)cap, ChainLcbSum{S, d_ch_srow.p, n1, d_ch_hpos.p, d_ch_lcblen.p});
@@ -1209,6 +1210,7 @@ public:
         // second pass (the reference chains again after dissolving, :3261-3268), then the fillers between the final LCBs
         const int64_t* n2 = hdr + kChN2;
         be.launch_wave("chain_judge", (int64_t)cap, ChainJudge{S, d_ch_key2.p, d_ch_row2.p, n2, d, diag_diff, d_ch_verdict.p, trouble, 0});
+        be.launch("chain_judge_reverse", (int64_t)cap, ChainJudgeReverse{S, d_ch_row2.p, n2, d, diag_diff, d_ch_verdict.p});
         be.launch("chain_heads", (int64_t)cap + 1, ChainHeads{d_ch_verdict.p, n2, d_ch_head.p});
         be.exclusive_scan(d_ch_head.p, d_ch_hpos.p, cap + 1);
         if (cap > 1) be.launch_wave("chain_fill", (int64_t)cap - 1, ChainFill{S, layout_view(d_image.p, false), P, d_ch_row2.p, n2, d_ch_head.p, hdr});

@@ -1636,11 +1636,14 @@ struct FoldCandidates {
     const uint64_t* key; const uint64_t* val; const int64_t* lo; const EventAtK* st; const int32_t* rep; int lbits;
     const int64_t* cbase; const int32_t* coarse;
     int32_t* out_k; int32_t* out_lon; int32_t* out_sp; uint8_t* out_fwd; uint8_t* out_ok;
-    int64_t ncand;      // the launch is xcd_grid(ncand) wavefronts
+    int64_t ncand;      // the launch is xcd_grid(ncand) wavefronts; ncand: the candidate CAPACITY of the call ...
+    const int64_t* count;      // ... and the number there are (device memory: the call does not wait for it)
     PM_HD void wave(int64_t w) const {
         // neighbouring candidates read neighbouring events of every genome: they go to the SAME L2 (xcd_item)
-        const int64_t c = xcd_item(w, ncand);
-        if (c >= ncand) return;
+        const int64_t nc = *count < ncand ? *count : ncand;
+        if (w / kXcds >= (nc + kXcds - 1) / kXcds) return;      // (a launch over the capacity: past the live count's last round)
+        const int64_t c = xcd_item(w, nc);
+        if (c >= nc) return;
         const int32_t nq = ngen - 1;
         const int64_t r = (int64_t)(cand[c] >> 32); const int32_t k = (int32_t)(cand[c] & 0xffffffffu);
         const RegionInfo& ri = R[r];
@@ -1684,8 +1687,8 @@ struct FoldCandidates {
 
 // accepted candidates only, densely, in candidate order: what the host receives.  pos = exclusive prefix of ok.
 struct OkCount {
-    const uint8_t* ok; int64_t ncand; int64_t* cnt;     // cnt[ncand] = 0 closes the scan
-    PM_HD void operator()(int64_t c) const { cnt[c] = c < ncand ? (ok[c] ? 1 : 0) : 0; }
+    const uint8_t* ok; const int64_t* ncand; int64_t* cnt;     // launched over the capacity + 1: zeros past the live count close the scan
+    PM_HD void operator()(int64_t c) const { cnt[c] = c < *ncand ? (ok[c] ? 1 : 0) : 0; }
 };
 // tid = (candidate, query genome): the accepted candidates densely, as (sp, strand) per query genome (the documented
 // result of pm_multi_mum_batch; a session switched to MUM rows with pm_session_rows gets CompactCandidates instead)
@@ -1693,9 +1696,10 @@ struct CompactSp {
     const uint64_t* cand; const uint8_t* ok; const int64_t* pos; int32_t nq;
     const int32_t* k; const int32_t* lon; const int32_t* sp; const uint8_t* fwd;
     int32_t* out_region; int32_t* out_k; int32_t* out_lon; int32_t* out_sp; uint8_t* out_fwd;
+    const int64_t* ncand;
     PM_HD void operator()(int64_t tid) const {
         const int64_t c = tid / nq; const int g = (int)(tid % nq);
-        if (!ok[c]) return;
+        if (c >= *ncand || !ok[c]) return;
         const int64_t w = pos[c];
         out_sp[w * nq + g] = sp[tid]; out_fwd[w * nq + g] = fwd[tid];
         if (g == 0) { out_region[w] = (int32_t)(cand[c] >> 32); out_k[w] = k[c]; out_lon[w] = lon[c]; }
@@ -1717,9 +1721,10 @@ struct CompactCandidates {
     const int32_t* k; const int32_t* lon; const int32_t* sp; const uint8_t* fwd;
     const int64_t* starts; const int64_t* lens; const int64_t* glen;
     int32_t* out_region; int32_t* out_k; int32_t* out_lon; int32_t* out_start; uint8_t* out_strand; uint32_t* out_flags;   // out_flags zeroed
+    const int64_t* ncand;      // the live candidate count (the launch covers the capacity)
     PM_HD void operator()(int64_t tid) const {
         const int64_t c = tid / ngen; const int j = (int)(tid % ngen);
-        if (!ok[c]) return;
+        if (c >= *ncand || !ok[c]) return;
         const int64_t w = pos[c];
         const int64_t r = (int64_t)(cand[c] >> 32);
         const int64_t lo = lon[c];
@@ -1754,8 +1759,9 @@ struct CompactCandidates {
 constexpr int kDirtyBlock = 256;
 PM_HD bool row_marks(uint32_t flags, int32_t lon) { return !(flags & (kRowBad | kRowOutside)) && lon >= 5; }
 struct DirtyExtent {
-    const int32_t* start; const int32_t* lon; const uint32_t* flags; int64_t n; int32_t ngen; int32_t* bmax; int32_t* bmin;   // [block][ngen]
+    const int32_t* start; const int32_t* lon; const uint32_t* flags; const int64_t* n_live; int32_t ngen; int32_t* bmax; int32_t* bmin;   // [block][ngen]; *n_live: the rows there are (the launch covers the capacity)
     PM_HD void wave(int64_t w) const {
+        const int64_t n = *n_live;
         const int64_t groups = (ngen + 63) / 64, blk = w / groups; const int g0 = (int)(w % groups) * 64;
         const int64_t c0 = blk * kDirtyBlock, c1 = c0 + kDirtyBlock < n ? c0 + kDirtyBlock : n;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1813,9 +1819,10 @@ struct DirtyPrefix {
     }
 };
 struct DirtyMark {
-    const int32_t* start; const int32_t* lon; int64_t n; int32_t ngen; const int32_t* bmax; const int32_t* bmin;
+    const int32_t* start; const int32_t* lon; const int64_t* n_live; int32_t ngen; const int32_t* bmax; const int32_t* bmin;
     const uint32_t* flags; uint32_t* dirty;      // dirty[c] (zeroed): set when candidate c overlaps something earlier; flags is only read
     PM_HD void wave(int64_t w) const {
+        const int64_t n = *n_live;
         const int64_t groups = (ngen + 63) / 64, blk = w / groups; const int g0 = (int)(w % groups) * 64;
         const int64_t c0 = blk * kDirtyBlock, c1 = c0 + kDirtyBlock < n ? c0 + kDirtyBlock : n;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1859,8 +1866,8 @@ struct DirtyMark {
 };
 // tid = candidate
 struct DirtyMerge {
-    const uint32_t* dirty; uint32_t* flags;
-    PM_HD void operator()(int64_t c) const { if (dirty[c]) flags[c] |= dirty[c] & (kRowDirty | kRowEarly); }
+    const uint32_t* dirty; uint32_t* flags; const int64_t* n_live;
+    PM_HD void operator()(int64_t c) const { if (c < *n_live && dirty[c]) flags[c] |= dirty[c] & (kRowDirty | kRowEarly); }
 };
 
 }  // namespace pm

@@ -1533,8 +1533,8 @@ struct ChainKeys {
 };
 // One wavefront per list position x: the test of setFinalClusters (:2596-2700) of MUM row[x] against row[x - 1], to the verdict.
 // All-forward pairs are a reduction over the genomes (JudgePairs) and the ratio test of :2693 in the reference's float / double
-// mix; a pair with a reverse member is walked genome by genome by one lane (the strand rules of :2604-2625 and `max_gap = fgap`
-// at :2608-2611 depend on the genome order).  *count: the list's length (the launch covers its capacity).
+// mix; a pair with a reverse member is left to ChainJudgeReverse (the strand rules of :2604-2625 and `max_gap = fgap` at :2608-2611
+// depend on the genome order: one lane walks the genomes).  *count: the list's length (the launch covers its capacity).
 struct ChainJudge {
     Store S; const uint64_t* key; const uint64_t* row; const int64_t* count; int32_t d; float diag_diff; uint8_t* verdict; uint64_t* trouble;
     int force_tie;      // (tests) report a tie although there is none: the caller's own list logic takes over
@@ -1566,32 +1566,47 @@ struct ChainJudge {
                 if (max_gap == 0) max_gap = 1;
                 out = min_gap / max_gap >= 1.0 - diag_diff ? kChJoin : kChClose;
             }
-        } else if (wave_leader()) {
-            bool addmum = true;
-            float max_gap = 0, min_gap = (float)(d + 10);
-            for (int k = 0; k < n; k++) {
-                const int64_t ns = (int64_t)S.start[a * n + k] + sa, bs = (int64_t)S.start[b * n + k] + sb;
-                const int64_t fgap = ns - (bs + lb);        // forward: next start - chain end
-                const int64_t rgap = bs - (ns + la);        // reverse: previous MUM start - next end
-                const bool f = S.strand[a * n + k] != 0;
-                if (f && fgap > max_gap) max_gap = (float)fgap;
-                else if (!f && rgap > max_gap) max_gap = (float)fgap;       // sic (:2608-2611)
-                if (f && fgap < min_gap) min_gap = (float)fgap;
-                else if (!f && rgap < min_gap) min_gap = (float)rgap;
-                if (S.strand[a * n + k] != S.strand[b * n + k]) addmum = false;
-                else if (f && fgap < 0) addmum = false;
-                else if (!f && fgap >= 0) addmum = false;
-                else if (f && fgap > d) addmum = false;
-                else if (!f && rgap > d) addmum = false;
-                if (!addmum) break;
-            }
-            if (addmum) {
-                if (min_gap == 0) min_gap = 1;
-                if (max_gap == 0) max_gap = 1;
-                out = min_gap / max_gap >= 1.0 - diag_diff ? kChJoin : kChClose;
-            }
-        }
+        } else return;      // (a reverse member: ChainJudgeReverse)
         if (wave_leader()) verdict[x] = out;
+    }
+};
+// tid = list position x: the same test for a pair with a reverse-strand member, genome by genome -- the strand rules of :2604-2625 and
+// the `max_gap = fgap` of :2608-2611 make the loop's outcome depend on the order of the genomes, so ONE lane walks them; but the pairs
+// do not depend on one another, so every lane of the launch has a pair of its own (a lane of a wavefront per pair until round 6: 7 ms for
+// the 60 000 pairs of 500 rearranged genomes, and 63 lanes idle).  A lane streams its two rows, 64-byte lines of 16 genomes each.
+struct ChainJudgeReverse {
+    Store S; const uint64_t* row; const int64_t* count; int32_t d; float diag_diff; uint8_t* verdict;
+    PM_HD void operator()(int64_t x) const {
+        if (x < 1 || x >= *count) return;
+        const int64_t a = (int64_t)row[x], b = (int64_t)row[x - 1];
+        if (!((S.flags[a] | S.flags[b]) & kRowReverse)) return;
+        const int n = S.ngen;
+        const int64_t sa = S.shift[a], la = S.len[a], sb = S.shift[b], lb = S.len[b];
+        uint8_t out = kChClose;
+        bool addmum = true;
+        float max_gap = 0, min_gap = (float)(d + 10);
+        for (int k = 0; k < n; k++) {
+            const int64_t ns = (int64_t)S.start[a * n + k] + sa, bs = (int64_t)S.start[b * n + k] + sb;
+            const int64_t fgap = ns - (bs + lb);        // forward: next start - chain end
+            const int64_t rgap = bs - (ns + la);        // reverse: previous MUM start - next end
+            const bool f = S.strand[a * n + k] != 0;
+            if (f && fgap > max_gap) max_gap = (float)fgap;
+            else if (!f && rgap > max_gap) max_gap = (float)fgap;       // sic (:2608-2611)
+            if (f && fgap < min_gap) min_gap = (float)fgap;
+            else if (!f && rgap < min_gap) min_gap = (float)rgap;
+            if (S.strand[a * n + k] != S.strand[b * n + k]) addmum = false;
+            else if (f && fgap < 0) addmum = false;
+            else if (!f && fgap >= 0) addmum = false;
+            else if (f && fgap > d) addmum = false;
+            else if (!f && rgap > d) addmum = false;
+            if (!addmum) break;
+        }
+        if (addmum) {
+            if (min_gap == 0) min_gap = 1;
+            if (max_gap == 0) max_gap = 1;
+            out = min_gap / max_gap >= 1.0 - diag_diff ? kChJoin : kChClose;
+        }
+        verdict[x] = out;
     }
 };
 // tid = list position (capacity + 1 of them: the scan's closing word): does a chain begin here?

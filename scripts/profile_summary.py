@@ -48,7 +48,7 @@ PHASES = {
     "repeat": ["RunLength", "RepeatLength"],
     "seeds": ["ChainFlag", "AnchorList", "SeedCount", "SeedPlace", "SeedWalk"],
     "validate": ["ClustersDisjoint", "ClusterExtents", "ClusterInvolved", "ClusterDefer", "ClusterValidate", "StageGate"],
-    "chain": ["ForeignBound", "ForeignScan", "ForeignDecideHits", "ChainKeys", "ChainJudge", "ChainHeads", "ChainLcbSum", "ChainDissolve", "ChainUnmark", "ChainCompact", "ChainFill", "ChainOut"],
+    "chain": ["ForeignBound", "ForeignScan", "ForeignDecideHits", "ChainKeys", "ChainJudge", "ChainJudgeReverse", "ChainHeads", "ChainLcbSum", "ChainDissolve", "ChainUnmark", "ChainCompact", "ChainFill", "ChainOut"],
 }
 
 

@@ -20,3 +20,29 @@ if has rearr; then
   PARSNP_BENCH_LOG=$O/rearr_laps.log PARSNP_DEBUG_TIMERS=1 timeout 600 python bench.py --workload rearr500 --steps 1 --warmup 1 --cpu-sample 0 --other-configs off > /dev/null 2>&1
   grep -E "^\[(resident|anchors|extend|lcb)" $O/rearr_laps.log | tail -120 > $O/rearr_laps.txt
 fi
+if has prof; then      # per-kernel times of config 3 with inversions and of config 5 (rocprofv3 --kernel-trace --stats, a few steps each)
+  for wl in ${PROF_WL:-bact200inv rearr500}; do
+    P=$O/prof_$wl; rm -rf $P; mkdir -p $P
+    ( cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats -d $P -o ks -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 3 --warmup 1 --cpu-sample 0 --other-configs off > $P/bench.json 2> $P/err.log )
+    python - "$P" "$wl" <<'PY'
+import glob, sqlite3, sys, re, os
+P, wl = sys.argv[1], sys.argv[2]
+db = sorted(glob.glob(os.path.join(P, "**", "*_results.db"), recursive=True))
+rows = []
+if db:
+    c = sqlite3.connect(db[0])
+    tables = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+    t = "kernels" if "kernels" in tables else next((x for x in tables if x.startswith("kernels")), None)
+    rows = list(c.execute("select name, count(*), sum(duration), max(duration) from %s group by name order by sum(duration) desc" % t)) if t else []
+def short(n):
+    m = re.search(r"pm_(?:wave_)?kernel<pm::(\w+)>", n)
+    return m.group(1) if m else n.split("(")[0][-60:]
+with open(os.path.join(P, "..", "kernels_%s.txt" % wl), "w") as f:
+    f.write("# %s: bench.py --steps 3 --warmup 1 under rocprofv3 --kernel-trace (4 steps in all); ms per STEP, calls per step, longest dispatch ms\n" % wl)
+    for n, calls, tot, mx in rows[:45]:
+        f.write("%-34s %8.3f %7.1f %8.3f\n" % (short(n), tot / 4e6, calls / 4.0, mx / 1e6))
+print(open(os.path.join(P, "..", "kernels_%s.txt" % wl)).read()[:2500])
+PY
+    rm -rf $P
+  done
+fi

@@ -45,7 +45,7 @@ def test_baseline_size_against_reference(scratch, name):
     want = BIG[name]
     rp, qs = inputs(name, scratch)
     assert len(qs) == want["n_queries"]
-    # the shipped binary (the resident route where the anchor list allows it: configs 3 and 4), then the host route in both of
+    # the shipped binary (the resident route), then the host route in both of
     # its replay modes (test hooks: forced through the product's sources built with csrc/host/hooks.h's switches)
     for mode in ("shipped", "generations", "in_order"):
         env = dict(os.environ, OMP_WAIT_POLICY="passive")
@@ -58,11 +58,13 @@ def test_baseline_size_against_reference(scratch, name):
         rc, _ = driver.run_core(CORE_BIN if mode == "shipped" else CORE_HOOKS_BIN, rp, qs, out, env=env, threads=24, timing=timing)
         if rc == 0:
             tj = json.load(open(timing))
-            # collinear populations (configs 3, 4) stay on the resident route; the rearranged set is declined at the anchor list
-            assert tj["resident"] == (1 if (mode == "shipped" and name != "rearr50") else 0), (mode, tj)
+            # every configuration stays on the resident route -- since round 6 the rearranged set too: its anchor list is settled on
+            # the device (tangled rows in rounds) and clusters of waiting regions that meet in some genome wait for one another
+            assert tj["resident"] == (1 if mode == "shipped" else 0), (mode, tj)
             if tj["resident"]:
                 assert tj["d2h_bytes"] < 20e6 and tj["resident_retry"] == 0, tj      # rows stay on the device until the writer asks
-                assert tj["device_chain"] == 1, tj      # ... and phases C-D came from the device in one call (pm_store_chain_*)
+                if name != "rearr50":
+                    assert tj["device_chain"] == 1, tj      # ... and phases C-D came from the device in one call (pm_store_chain_*)
         assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
         x = os.path.join(out, "parsnpAligner.xmfa")
         assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"], mode
