@@ -366,13 +366,16 @@ public:
         be.mark("units");
         be.launch("count_units", npairs, CountUnits{d_R.p, d_lens.p, ngen, d_ucount.p, g_first, g_last, no_small});
         be.exclusive_scan(d_ucount.p, d_uoff.p, (size_t)npairs + 1);
-        if (gb) {      // the host never saw the rows: the unit count comes back from the device (8 bytes)
+        // the host never saw the rows of a store search: the unit count is the device's.  The call used to wait for it (8 bytes); now it
+        // launches over a CAPACITY from the last call of the shape, the kernels read the live count, and the count comes back with the
+        // event counters (a capacity that was too small repeats the event search, like a full event buffer)
+        bool units_known = !gb;
+        if (gb && !(fast_tail && units_hint[nreg == 1] > 0)) {
             be.d2h(&nunits, d_uoff.p + npairs, 8);
-            if (nunits >= (1ll << 31)) { error = "too many work units in one batch"; return -5; }
-            ev_guess += (size_t)nunits * 16;
-        }
-        ensure(d_units, (size_t)std::max<int64_t>(nunits, 1));
-        be.launch("fill_units", nunits, FillUnits{P, d_starts.p, d_lens.p, ngen, d_uoff.p, d_ucount.p, npairs, d_units.p});
+            units_known = true;
+        } else if (gb) nunits = units_hint[nreg == 1] + units_hint[nreg == 1] / 4 + 64;
+        if (nunits >= (1ll << 31)) { error = "too many work units in one batch"; return -5; }
+        if (gb) ev_guess += (size_t)nunits * 16;
 
         // -- events: kSlices append buffers (retry with larger ones on overflow), gathered, then sorted by (pair, l, strand)
         ensure(d_sliceoff, (size_t)kSlices + 1);
@@ -393,7 +396,10 @@ public:
         size_t grp_cap = grouping ? std::max<size_t>(grp_cap_hint, (size_t)npairs * 3) + 64 : 0;
         uint64_t ngrp = 0;
         if (grouping) { ensure(d_gflag, (size_t)nreg); ensure(d_glo, (size_t)npairs); }
+        int64_t nunits_live = nunits;
         for (bool again = false;; again = true) {
+            ensure(d_units, (size_t)std::max<int64_t>(nunits, 1));
+            be.launch("fill_units", nunits, FillUnits{P, d_starts.p, d_lens.p, ngen, d_uoff.p, d_ucount.p, npairs, d_units.p});
             ensure(d_evkey, slice_cap * kSlices); ensure(d_evval, slice_cap * kSlices); ensure(d_rest, queue_cap * kSlices);
             if (again) be.memset(d_counter.p, 0, 8 * ncounter);      // event counters, error word, grouped events
             if (grouping) {
@@ -408,7 +414,7 @@ public:
             be.mark("seed_extend");
             be.launch("seed_extend", nunits * 64,
                       SeedExtend{P, d_R.p, d_units.p, d_slots.p, d_filter.p, d_next.p, d_rep.p, d_repeated.p,
-                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err, work_budget, d_rest.p, d_qcount.p, (uint64_t)queue_cap});
+                                 d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, lbits, d_err, work_budget, d_rest.p, d_qcount.p, (uint64_t)queue_cap, d_uoff.p + npairs});
             if (nunits > 0)      // one lane per queued sample; lanes past a sub-queue's count leave at once (the counts stay on the device)
                 be.launch("seed_rest", (int64_t)(queue_cap * kSlices),
                           SeedRest{P, d_R.p, d_units.p, d_rest.p, d_qcount.p, (uint64_t)queue_cap, d_slots.p, d_filter.p, d_next.p, d_rep.p,
@@ -420,7 +426,18 @@ public:
             be.launch_wave("slice_offsets", 1, SliceOffsets{d_counter.p, d_sliceoff.p});
             be.d2h_async(qcounts.data(), d_qcount.p, 8 * qcounts.size());
             if (from_store) be.d2h_async(alg_sets, d_alg.p, sizeof alg_sets);
-            be.d2h(counts.data(), d_counter.p, 8 * counts.size());            // round trip 1: event counts + error word (+ the queues' lengths)
+            if (!units_known) be.d2h_async(&nunits_live, d_uoff.p + npairs, 8);
+            be.d2h(counts.data(), d_counter.p, 8 * counts.size());            // round trip 1: event counts + error word (+ the queues' lengths, + the unit count)
+            if (!units_known) {
+                units_known = true;
+                if (nunits_live >= (1ll << 31)) { error = "too many work units in one batch"; return -5; }
+                if (nunits_live > nunits) {      // more units than the capacity: the event search again, over all of them
+                    nunits = nunits_live;
+                    queue_cap = std::max<size_t>(queue_cap, (size_t)nunits * kUnitSamples / 16 / kSlices + 64);
+                    tail_repeats++;
+                    continue;
+                }
+            }
             uint64_t worst = 0, qworst = 0;
             nev = 0; nrest = 0;
             for (int sl = 0; sl < kSlices; sl++) {
@@ -443,6 +460,7 @@ public:
         if (from_store) { last_alg[0] = (double)alg_raw[0] / 4.0; last_alg[1] = (double)alg_raw[1] / 2.0; last_alg[2] = (double)alg_raw[2] / 2.0; }
         if (errbits & kErrRows) { error = "region outside its genome"; return -2; }
         rest_cap_hint[nreg == 1] = queue_cap;
+        if (gb) units_hint[nreg == 1] = std::max<int64_t>(nunits_live, 1);
         last_rest = (int64_t)nrest;
         ev_cap_hint = (size_t)(nev + nev / 4);
         if (grouping) grp_cap_hint = (size_t)(ngrp + ngrp / 4);
@@ -534,147 +552,182 @@ public:
         be.mark("candidates");
         be.launch_wave("cand_mark", nwv, CandMark{d_R.p, nreg, d_posbase.p, npos, d_epm.p, d_wmask.p, d_wcount.p});
         be.exclusive_scan(d_wcount.p, d_woff.p, (size_t)nwv + 1);
-        int64_t ncand_i = 0;
-        be.d2h(&ncand_i, d_woff.p + nwv, 8);                                   // round trip 2: candidate count
-        if (verdict < 0) { budget_exceeded = true; error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
-        const uint64_t ncand = (uint64_t)ncand_i;
-        last_candidates = (int64_t)ncand;
-        if (ncand == 0) { if (resident && from_store) out->store_base = ms_count; be.mark(nullptr); collect_timing(); return 0; }
-        ensure(d_cand, (size_t)ncand);
-        be.launch("cand_write", nwv * 64, CandWrite{d_R.p, nreg, d_posbase.p, d_wmask.p, d_woff.p, d_cand.p, ncand});
-        const uint64_t* scand = d_cand.p;        // in (region, k) order by construction
-
-        // -- per-candidate genome fold
-        be.mark("fold");
-        ensure(d_ok, (size_t)ncand); ensure(d_ok_k, (size_t)ncand); ensure(d_ok_lon, (size_t)ncand);
-        ensure(d_osp, (size_t)ncand * (size_t)nq); ensure(d_ofwd, (size_t)ncand * (size_t)nq);
-        const GenomeAtK* at = nullptr;
-        if (sharded) {   // exchange 2: every rank contributes the (EP,UP,SP) columns of its genome block
-            ensure(d_at, (size_t)ncand * (size_t)nq);
-            be.launch("state_at_candidate", (int64_t)ncand * nq, StateAtCandidate{d_R.p, scand, ngen, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_at.p, d_cbase.p, d_coarse.p});
-            be.mark("exchange_states");
-            const size_t nqz = (size_t)nq, cz = (size_t)ncand;
-            int widest = 0;
-            for (int r = 0; r < coll.world; r++) { int a, b; shard_range(ngen, r, coll.world, &a, &b); widest = std::max(widest, b - a); }
-            widest = std::max(widest, 1);
-            const size_t blk = cz * (size_t)widest;
-            if (coll.device) {      // pack this rank's columns, RCCL all-gather on the engine's stream, spread the blocks: nothing leaves the device
-                ensure(d_xsend, blk); ensure(d_xrecv, blk * (size_t)coll.world);
-                be.launch("pack_states", (int64_t)blk, PackStates{d_at.p, nq, g_first - 1, g_last - g_first, widest, d_xsend.p});
-                if (be.allgather_dev(d_xsend.p, (int64_t)(sizeof(GenomeAtK) * blk), d_xrecv.p)) { error = "RCCL all-gather of candidate states failed: " + be.error(); return -4; }
-                be.launch("unpack_states", (int64_t)(cz * nqz), UnpackStates{d_xrecv.p, nq, coll.world, widest, (int64_t)ncand, d_at.p});
-            } else {
-                std::vector<GenomeAtK> all(cz * nqz);
-                be.d2h(all.data(), d_at.p, sizeof(GenomeAtK) * all.size());
-                std::vector<GenomeAtK> send(blk), recv(blk * (size_t)coll.world);
-                const size_t mine = (size_t)(g_last - g_first);
-                for (size_t c = 0; c < cz; c++)
-                    for (size_t x = 0; x < mine; x++) send[c * (size_t)widest + x] = all[c * nqz + (size_t)(g_first - 1) + x];
-                if (coll.allgather(coll.ctx, send.data(), (int64_t)(sizeof(GenomeAtK) * send.size()), recv.data())) { error = "all-gather of candidate states failed"; return -4; }
-                for (int r = 0; r < coll.world; r++) {
-                    int a, b; shard_range(ngen, r, coll.world, &a, &b);
-                    const GenomeAtK* src = recv.data() + (size_t)r * send.size();
-                    for (size_t c = 0; c < cz; c++)
-                        for (int x = 0; x < b - a; x++) all[c * nqz + (size_t)(a - 1 + x)] = src[c * (size_t)widest + (size_t)x];
-                }
-                be.h2d(d_at.p, all.data(), sizeof(GenomeAtK) * all.size());
+        const int64_t* ncand_p = d_woff.p + nwv;      // the candidate count, where the device keeps it
+        // The rest of the call -- candidates listed, folded over the genomes, the accepted ones compacted into rows, the overlap flags
+        // of a long list -- used to wait twice for the device, for the candidate count and for the accepted count, because the
+        // launches and buffers were sized with them.  A call whose rows stay on the device (the resident route's anchor call and its
+        // store searches) no longer does: launches and buffers take CAPACITIES from what the last call of the same shape needed,
+        // every kernel reads the live count from device memory, and both counts come back with the results, in the call's one last
+        // wait.  A capacity that turns out too small (or an anchor list that turns out short) repeats the tail the exact way.
+        const int shape = nreg == 1 ? 1 : 0;
+        const bool anchor_guess = nreg == 1 && !gb && tail_hint[shape].nok >= dirty_min;
+        const bool may_skip_waits = !sharded && want_rows && resident && tail_hint[shape].ncand > 0 && (from_store || anchor_guess) && fast_tail;
+        for (int attempt = may_skip_waits ? 0 : 1;; attempt++) {
+            const bool exact = attempt > 0;
+            int64_t ncand_i = 0;
+            if (exact) be.d2h(&ncand_i, ncand_p, 8);                                   // round trip 2: candidate count
+            if (verdict < 0) { budget_exceeded = true; error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
+            if (exact) {
+                last_candidates = ncand_i;
+                if (ncand_i == 0) { tail_hint[shape] = TailHint{1, 0}; if (resident && from_store) out->store_base = ms_count; be.mark(nullptr); collect_timing(); return 0; }
             }
+            // capacity of the candidate list: the count itself when it is known
+            const uint64_t ncand = exact ? (uint64_t)ncand_i : (uint64_t)(tail_hint[shape].ncand + tail_hint[shape].ncand / 4 + 1024);
+            ensure(d_cand, (size_t)ncand);
+            be.launch("cand_write", nwv * 64, CandWrite{d_R.p, nreg, d_posbase.p, d_wmask.p, d_woff.p, d_cand.p, ncand});
+            const uint64_t* scand = d_cand.p;        // in (region, k) order by construction
+
+            // -- per-candidate genome fold
             be.mark("fold");
-            at = d_at.p;
-        }
-        be.launch_wave("fold_candidates", xcd_grid((int64_t)ncand),
-                       FoldCandidates{d_R.p, scand, ngen, at, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_cbase.p, d_coarse.p,
-                                      d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_ok.p, (int64_t)ncand});
-
-        // -- accepted candidates, compacted on the device and downloaded straight into the result's blocks
-        be.mark("compact");
-        ensure(d_okcnt, (size_t)ncand + 1); ensure(d_okpos, (size_t)ncand + 1);
-        be.launch("ok_count", (int64_t)ncand + 1, OkCount{d_ok.p, (int64_t)ncand, d_okcnt.p});
-        be.exclusive_scan(d_okcnt.p, d_okpos.p, (size_t)ncand + 1);
-        int64_t nok = 0;
-        be.d2h(&nok, d_okpos.p + ncand, 8);                                    // round trip 3: accepted count
-        const size_t nokz = (size_t)nok, nqz2 = (size_t)nq, ngz = (size_t)ngen;
-        last_accepted = nok;
-        ensure(d_creg, std::max<size_t>(nokz, 1)); ensure(d_ck, std::max<size_t>(nokz, 1)); ensure(d_clon, std::max<size_t>(nokz, 1));
-        std::vector<int32_t> reg_h(nokz);
-        out->kb = pool->take(4 * nokz); out->lonb = pool->take(4 * nokz);
-        out->rows = want_rows; out->dirty_known = false;
-        if (!want_rows) {
-            ensure(d_csp, std::max<size_t>(nokz * nqz2, 1)); ensure(d_cfwd, std::max<size_t>(nokz * nqz2, 1));
-            be.launch("compact_sp", (int64_t)ncand * nq,
-                      CompactSp{scand, d_ok.p, d_okpos.p, nq, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_creg.p, d_ck.p, d_clon.p, d_csp.p, d_cfwd.p});
-            be.mark("download");
-            out->spb = pool->take(4 * nokz * nqz2); out->fwdb = pool->take(nokz * nqz2);
-            be.d2h_async(out->spb.p, d_csp.p, 4 * nokz * nqz2);
-            be.d2h_async(out->fwdb.p, d_cfwd.p, nokz * nqz2);
-        } else {
-            // Resident mode (pm_session_rows(s, 2)): the rows of the anchor call, and of every search of regions of the region store,
-            // stay on the device as rows of the MUM store -- the host receives the per-row scalars only (flags, k, length).  The
-            // anchor call's rows are the session's anchor table (= rows [0, A) of the store) in either mode.  The compaction
-            // writes such rows straight into the store (a copy of the 60 MB anchor table is half a millisecond).
-            const bool anchor_call = nreg == 1 && !gb && nok >= dirty_min;
-            const bool keep_rows = resident && (anchor_call || from_store);
-            const bool to_store = anchor_call || keep_rows;
-            int32_t* p_start; uint8_t* p_strand; int32_t* p_lon; uint32_t* p_flags;
-            if (to_store) {
-                if (anchor_call) { ms_count = 0; rg_count = 0; layout_rows = -1; }
-                const size_t base = (size_t)ms_count, upto = base + nokz;
-                ensure_keep(d_anchor_start, std::max<size_t>(upto * ngz, 1), base * ngz); ensure_keep(d_ms_strand, std::max<size_t>(upto * ngz, 1), base * ngz);
-                ensure_keep(d_anchor_lon, std::max<size_t>(upto, 1), base); ensure_keep(d_anchor_flags, std::max<size_t>(upto, 1), base);
-                ensure_keep(d_ms_shift, std::max<size_t>(upto, 1), base); ensure_keep(d_ms_len, std::max<size_t>(upto, 1), base); ensure_keep(d_ms_state, std::max<size_t>(upto, 1), base);
-                p_start = d_anchor_start.p + base * ngz; p_strand = d_ms_strand.p + base * ngz; p_lon = d_anchor_lon.p + base; p_flags = d_anchor_flags.p + base;
-                out->store_base = (int64_t)base;
-                ms_count = (int64_t)upto;
-            } else {
-                ensure(d_csp, std::max<size_t>(nokz * ngz, 1)); ensure(d_cfwd, std::max<size_t>(nokz * ngz, 1)); ensure(d_cflags, std::max<size_t>(nokz, 1));
-                p_start = d_csp.p; p_strand = d_cfwd.p; p_lon = d_clon.p; p_flags = d_cflags.p;
-            }
-            const bool long_list = nreg == 1 && nok >= dirty_min;
-            if (long_list) ensure(d_dirty, nokz);
-            {      // the flags of the rows (OR-ed into), the cheap overlap test's marks, shift and state of the new store rows: one launch
-                const ClearJob jobs[] = {{p_flags, 4 * nokz, 0}, {long_list ? d_dirty.p : nullptr, long_list ? 4 * nokz : 0, 0},
-                                         {to_store ? d_ms_shift.p + (ms_count - nok) : nullptr, to_store ? 4 * nokz : 0, 0},
-                                         {to_store ? d_ms_state.p + (ms_count - nok) : nullptr, to_store ? nokz : 0, 0}};
-                be.clear_many(jobs, 4);
-            }
-            be.launch("compact_candidates", (int64_t)ncand * ngen,
-                      CompactCandidates{scand, d_ok.p, d_okpos.p, ngen, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_starts.p, d_lens.p, d_glen,
-                                        d_creg.p, d_ck.p, p_lon, p_start, p_strand, p_flags});
-            if (nreg == 1 && nok >= dirty_min) {     // a long list of one region (the anchor call): the cheap overlap test on the device
-                const int64_t nblocks = (nok + kDirtyBlock - 1) / kDirtyBlock, groups = (ngen + 63) / 64;
-                ensure(d_bmax, (size_t)nblocks * ngz); ensure(d_bmin, (size_t)nblocks * ngz);
-                be.launch_wave("dirty_extent", nblocks * groups, DirtyExtent{p_start, p_lon, p_flags, nok, ngen, d_bmax.p, d_bmin.p});
-                be.launch_wave("dirty_prefix", groups, DirtyPrefix{nblocks, ngen, d_bmax.p, d_bmin.p});
-                be.launch_wave("dirty_mark", nblocks * groups, DirtyMark{p_start, p_lon, nok, ngen, d_bmax.p, d_bmin.p, p_flags, d_dirty.p});
-                be.launch("dirty_merge", nok, DirtyMerge{d_dirty.p, p_flags});
-                out->dirty_known = true;
-            }
-            if (to_store) {
-                be.d2d(d_ms_len.p + (ms_count - nok), p_lon, 4 * nokz);
-                if (anchor_call) {
-                    anchor_table_rows = nok;
-                    out->table_id = anchor_table_id = ++table_counter;
+            ensure(d_ok, (size_t)ncand); ensure(d_ok_k, (size_t)ncand); ensure(d_ok_lon, (size_t)ncand);
+            ensure(d_osp, (size_t)ncand * (size_t)nq); ensure(d_ofwd, (size_t)ncand * (size_t)nq);
+            const GenomeAtK* at = nullptr;
+            if (sharded) {   // exchange 2: every rank contributes the (EP,UP,SP) columns of its genome block
+                ensure(d_at, (size_t)ncand * (size_t)nq);
+                be.launch("state_at_candidate", (int64_t)ncand * nq, StateAtCandidate{d_R.p, scand, ngen, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_at.p, d_cbase.p, d_coarse.p});
+                be.mark("exchange_states");
+                const size_t nqz = (size_t)nq, cz = (size_t)ncand;
+                int widest = 0;
+                for (int r = 0; r < coll.world; r++) { int a, b; shard_range(ngen, r, coll.world, &a, &b); widest = std::max(widest, b - a); }
+                widest = std::max(widest, 1);
+                const size_t blk = cz * (size_t)widest;
+                if (coll.device) {      // pack this rank's columns, RCCL all-gather on the engine's stream, spread the blocks: nothing leaves the device
+                    ensure(d_xsend, blk); ensure(d_xrecv, blk * (size_t)coll.world);
+                    be.launch("pack_states", (int64_t)blk, PackStates{d_at.p, nq, g_first - 1, g_last - g_first, widest, d_xsend.p});
+                    if (be.allgather_dev(d_xsend.p, (int64_t)(sizeof(GenomeAtK) * blk), d_xrecv.p)) { error = "RCCL all-gather of candidate states failed: " + be.error(); return -4; }
+                    be.launch("unpack_states", (int64_t)(cz * nqz), UnpackStates{d_xrecv.p, nq, coll.world, widest, (int64_t)ncand, d_at.p});
+                } else {
+                    std::vector<GenomeAtK> all(cz * nqz);
+                    be.d2h(all.data(), d_at.p, sizeof(GenomeAtK) * all.size());
+                    std::vector<GenomeAtK> send(blk), recv(blk * (size_t)coll.world);
+                    const size_t mine = (size_t)(g_last - g_first);
+                    for (size_t c = 0; c < cz; c++)
+                        for (size_t x = 0; x < mine; x++) send[c * (size_t)widest + x] = all[c * nqz + (size_t)(g_first - 1) + x];
+                    if (coll.allgather(coll.ctx, send.data(), (int64_t)(sizeof(GenomeAtK) * send.size()), recv.data())) { error = "all-gather of candidate states failed"; return -4; }
+                    for (int r = 0; r < coll.world; r++) {
+                        int a, b; shard_range(ngen, r, coll.world, &a, &b);
+                        const GenomeAtK* src = recv.data() + (size_t)r * send.size();
+                        for (size_t c = 0; c < cz; c++)
+                            for (int x = 0; x < b - a; x++) all[c * nqz + (size_t)(a - 1 + x)] = src[c * (size_t)widest + (size_t)x];
+                    }
+                    be.h2d(d_at.p, all.data(), sizeof(GenomeAtK) * all.size());
                 }
+                be.mark("fold");
+                at = d_at.p;
             }
-            be.mark("download");
-            out->flagsb = pool->take(4 * nokz);
-            be.d2h_async(out->flagsb.p, p_flags, 4 * nokz);
-            if (!keep_rows) {
-                out->startb = pool->take(4 * nokz * ngz); out->strandb = pool->take(nokz * ngz);
-                be.d2h_async(out->startb.p, p_start, 4 * nokz * ngz);
-                be.d2h_async(out->strandb.p, p_strand, nokz * ngz);
+            be.launch_wave("fold_candidates", xcd_grid((int64_t)ncand),
+                           FoldCandidates{d_R.p, scand, ngen, at, skey, sval, d_lo.p, d_state.p, d_rep.p, lbits, d_cbase.p, d_coarse.p,
+                                          d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_ok.p, (int64_t)ncand, ncand_p});
+
+            // -- accepted candidates, compacted on the device and downloaded straight into the result's blocks
+            be.mark("compact");
+            ensure(d_okcnt, (size_t)ncand + 1); ensure(d_okpos, (size_t)ncand + 1);
+            be.launch("ok_count", (int64_t)ncand + 1, OkCount{d_ok.p, ncand_p, d_okcnt.p});
+            be.exclusive_scan(d_okcnt.p, d_okpos.p, (size_t)ncand + 1);
+            const int64_t* nok_p = d_okpos.p + ncand;      // the accepted count, where the device keeps it
+            int64_t nok = 0;
+            if (exact) be.d2h(&nok, nok_p, 8);                                    // round trip 3: accepted count
+            // capacity of the accepted rows: the count itself when it is known, else every candidate could be accepted
+            const size_t nokz = exact ? (size_t)nok : (size_t)ncand, nqz2 = (size_t)nq, ngz = (size_t)ngen;
+            ensure(d_creg, std::max<size_t>(nokz, 1)); ensure(d_ck, std::max<size_t>(nokz, 1)); ensure(d_clon, std::max<size_t>(nokz, 1));
+            std::vector<int32_t> reg_h(nokz);
+            out->release();
+            out->kb = pool->take(4 * nokz); out->lonb = pool->take(4 * nokz);
+            out->rows = want_rows; out->dirty_known = false; out->table_id = 0; out->store_base = -1;
+            const int64_t ms_before = ms_count, rg_before = rg_count, lay_before = layout_rows;
+            bool anchor_call = false;
+            if (!want_rows) {
+                ensure(d_csp, std::max<size_t>(nokz * nqz2, 1)); ensure(d_cfwd, std::max<size_t>(nokz * nqz2, 1));
+                be.launch("compact_sp", (int64_t)ncand * nq,
+                          CompactSp{scand, d_ok.p, d_okpos.p, nq, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_creg.p, d_ck.p, d_clon.p, d_csp.p, d_cfwd.p, ncand_p});
+                be.mark("download");
+                out->spb = pool->take(4 * nokz * nqz2); out->fwdb = pool->take(nokz * nqz2);
+                be.d2h_async(out->spb.p, d_csp.p, 4 * nokz * nqz2);
+                be.d2h_async(out->fwdb.p, d_cfwd.p, nokz * nqz2);
+            } else {
+                // Resident mode (pm_session_rows(s, 2)): the rows of the anchor call, and of every search of regions of the region store,
+                // stay on the device as rows of the MUM store -- the host receives the per-row scalars only (flags, k, length).  The
+                // anchor call's rows are the session's anchor table (= rows [0, A) of the store) in either mode.  The compaction
+                // writes such rows straight into the store (a copy of the 60 MB anchor table is half a millisecond).
+                anchor_call = nreg == 1 && !gb && (exact ? nok >= dirty_min : anchor_guess);
+                const bool keep_rows = resident && (anchor_call || from_store);
+                const bool to_store = anchor_call || keep_rows;
+                int32_t* p_start; uint8_t* p_strand; int32_t* p_lon; uint32_t* p_flags;
+                if (to_store) {
+                    if (anchor_call) { ms_count = 0; rg_count = 0; layout_rows = -1; }
+                    const size_t base = (size_t)ms_count, upto = base + nokz;
+                    ensure_keep(d_anchor_start, std::max<size_t>(upto * ngz, 1), base * ngz); ensure_keep(d_ms_strand, std::max<size_t>(upto * ngz, 1), base * ngz);
+                    ensure_keep(d_anchor_lon, std::max<size_t>(upto, 1), base); ensure_keep(d_anchor_flags, std::max<size_t>(upto, 1), base);
+                    ensure_keep(d_ms_shift, std::max<size_t>(upto, 1), base); ensure_keep(d_ms_len, std::max<size_t>(upto, 1), base); ensure_keep(d_ms_state, std::max<size_t>(upto, 1), base);
+                    p_start = d_anchor_start.p + base * ngz; p_strand = d_ms_strand.p + base * ngz; p_lon = d_anchor_lon.p + base; p_flags = d_anchor_flags.p + base;
+                    out->store_base = (int64_t)base;
+                    ms_count = (int64_t)upto;      // (capacity: set to base + the accepted count once that is known)
+                } else {
+                    ensure(d_csp, std::max<size_t>(nokz * ngz, 1)); ensure(d_cfwd, std::max<size_t>(nokz * ngz, 1)); ensure(d_cflags, std::max<size_t>(nokz, 1));
+                    p_start = d_csp.p; p_strand = d_cfwd.p; p_lon = d_clon.p; p_flags = d_cflags.p;
+                }
+                const bool long_list = nreg == 1 && (exact ? nok >= dirty_min : anchor_guess);
+                if (long_list) ensure(d_dirty, nokz);
+                {      // the flags of the rows (OR-ed into), the cheap overlap test's marks, shift and state of the new store rows: one launch
+                    const ClearJob jobs[] = {{p_flags, 4 * nokz, 0}, {long_list ? d_dirty.p : nullptr, long_list ? 4 * nokz : 0, 0},
+                                             {to_store ? d_ms_shift.p + (ms_count - (int64_t)nokz) : nullptr, to_store ? 4 * nokz : 0, 0},
+                                             {to_store ? d_ms_state.p + (ms_count - (int64_t)nokz) : nullptr, to_store ? nokz : 0, 0}};
+                    be.clear_many(jobs, 4);
+                }
+                be.launch("compact_candidates", (int64_t)ncand * ngen,
+                          CompactCandidates{scand, d_ok.p, d_okpos.p, ngen, d_ok_k.p, d_ok_lon.p, d_osp.p, d_ofwd.p, d_starts.p, d_lens.p, d_glen,
+                                            d_creg.p, d_ck.p, p_lon, p_start, p_strand, p_flags, ncand_p});
+                if (long_list) {     // a long list of one region (the anchor call): the cheap overlap test on the device
+                    const int64_t nblocks = ((int64_t)nokz + kDirtyBlock - 1) / kDirtyBlock, groups = (ngen + 63) / 64;
+                    ensure(d_bmax, (size_t)nblocks * ngz); ensure(d_bmin, (size_t)nblocks * ngz);
+                    be.launch_wave("dirty_extent", nblocks * groups, DirtyExtent{p_start, p_lon, p_flags, nok_p, ngen, d_bmax.p, d_bmin.p});
+                    be.launch_wave("dirty_prefix", groups, DirtyPrefix{nblocks, ngen, d_bmax.p, d_bmin.p});
+                    be.launch_wave("dirty_mark", nblocks * groups, DirtyMark{p_start, p_lon, nok_p, ngen, d_bmax.p, d_bmin.p, p_flags, d_dirty.p});
+                    be.launch("dirty_merge", (int64_t)nokz, DirtyMerge{d_dirty.p, p_flags, nok_p});
+                    out->dirty_known = true;
+                }
+                if (to_store) {
+                    be.d2d(d_ms_len.p + (ms_count - (int64_t)nokz), p_lon, 4 * nokz);
+                    if (anchor_call) out->table_id = ++table_counter;
+                }
+                be.mark("download");
+                out->flagsb = pool->take(4 * nokz);
+                be.d2h_async(out->flagsb.p, p_flags, 4 * nokz);
+                if (!keep_rows) {
+                    out->startb = pool->take(4 * nokz * ngz); out->strandb = pool->take(nokz * ngz);
+                    be.d2h_async(out->startb.p, p_start, 4 * nokz * ngz);
+                    be.d2h_async(out->strandb.p, p_strand, nokz * ngz);
+                }
+                be.d2h_async(out->lonb.p, p_lon, 4 * nokz);
             }
-            be.d2h_async(out->lonb.p, p_lon, 4 * nokz);
+            if (!want_rows) be.d2h_async(out->lonb.p, d_clon.p, 4 * nokz);
+            be.d2h_async(reg_h.data(), d_creg.p, 4 * nokz);
+            be.d2h_async(out->kb.p, d_ck.p, 4 * nokz);
+            int64_t counts_h[2] = {ncand_i, nok};
+            if (!exact) { be.d2h_async(&counts_h[0], ncand_p, 8); be.d2h_async(&counts_h[1], nok_p, 8); }
+            be.mark(nullptr);
+            be.sync();                                                         // round trip 4: the results (and, where the call did not wait for them, the two counts)
+            if (!exact) {
+                ncand_i = counts_h[0]; nok = counts_h[1];
+                const bool fits = (uint64_t)ncand_i <= ncand && anchor_call == (nreg == 1 && !gb && nok >= dirty_min);
+                if (!fits) {      // the capacity was too small, or the list is not the long list it was taken for: again, with the counts
+                    ms_count = ms_before; rg_count = rg_before; layout_rows = lay_before;
+                    tail_repeats++;
+                    be.mark("candidates");
+                    continue;
+                }
+                last_candidates = ncand_i;
+                if (out->store_base >= 0) ms_count = out->store_base + nok;
+            }
+            tail_hint[shape] = TailHint{std::max<int64_t>(ncand_i, 1), nok};
+            last_accepted = nok;
+            if (anchor_call) { anchor_table_rows = nok; anchor_table_id = out->table_id; }
+            for (int64_t w = 0; w < nok; w++) out->off[(size_t)reg_h[(size_t)w] + 1]++;
+            for (int64_t r = 0; r < nreg; r++) out->off[(size_t)r + 1] += out->off[(size_t)r];
+            out->total = out->off[(size_t)nreg];
+            if (out->table_id && out->store_base == 0) anchor_flags_h.assign(out->flags(), out->flags() + nok);      // (settle() lists the flagged rows from it)
+            break;
         }
-        if (!want_rows) be.d2h_async(out->lonb.p, d_clon.p, 4 * nokz);
-        be.d2h_async(reg_h.data(), d_creg.p, 4 * nokz);
-        be.d2h_async(out->kb.p, d_ck.p, 4 * nokz);
-        be.mark(nullptr);
-        be.sync();                                                         // round trip 4: the results
-        for (size_t w = 0; w < nokz; w++) out->off[(size_t)reg_h[w] + 1]++;
-        for (int64_t r = 0; r < nreg; r++) out->off[(size_t)r + 1] += out->off[(size_t)r];
-        out->total = out->off[(size_t)nreg];
-        if (out->table_id && out->store_base == 0) anchor_flags_h.assign(out->flags(), out->flags() + nokz);      // (settle() lists the flagged rows from it)
         collect_timing();
         return 0;
     }
@@ -1295,6 +1348,8 @@ public:
     int64_t dirty_min = 4096;
     int64_t flagged_div = 8;      // store_settle: above one flagged row in flagged_div the tangled rows are counted before the list is taken (1: never declined)
     int64_t tangled_max = 1 << 17;   // ... and the list declined (PM_EAGAIN) with more tangled rows than this
+    bool fast_tail = true;        // a call whose rows stay on the device does not wait for its candidate and accepted counts (run_once); false: it does (tests, before/after measurements)
+    int64_t tail_repeats = 0;     // tails repeated the exact way (a capacity too small, an anchor list that turned out short)
     bool tangle_rounds = true;    // tangled rows settled in rounds (TangleOwner / TangleSettle) before the one wavefront that takes what is left; false: that wavefront takes them all (tests)
     bool group_small = true;      // the events of a recursion batch's small regions once per distinct piece (GroupedPairEvents)
     int64_t last_grouped = 0;
@@ -1312,6 +1367,7 @@ public:
         if (key == "flagged_div" && value >= 1) { flagged_div = value; return true; }
         if (key == "tangled_max" && value >= 0) { tangled_max = value; return true; }
         if (key == "tangle_rounds") { tangle_rounds = value != 0; return true; }
+        if (key == "fast_tail") { fast_tail = value != 0; return true; }
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
         if (key == "master_seg") { master_seg = value != 0; return true; }
         if (key == "stage_gate") { force_gate = value != 0; return true; }
@@ -1374,6 +1430,9 @@ private:
     int64_t total_words = 0;
     Packed P{};
     size_t ev_cap_hint = 0, cand_cap_hint = 0, rest_cap_hint[2] = {0, 0}, grp_cap_hint = 0;
+    struct TailHint { int64_t ncand = 0, nok = 0; };
+    int64_t units_hint[2] = {0, 0};      // work units of the last store search of a shape
+    TailHint tail_hint[2];      // candidates / accepted rows of the last call of a shape ([1]: one region = an anchor call): capacities of the next one's tail
     Buf<uint8_t> d_gflag; Buf<int64_t> d_glo;
     Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase;
     Buf<uint64_t> d_slots; Buf<uint32_t> d_filter, d_repeated; Buf<int32_t> d_next, d_rep, d_run, d_epm;

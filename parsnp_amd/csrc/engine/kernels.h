@@ -633,6 +633,7 @@ struct FillUnits {
     Packed P; const int64_t* starts; const int64_t* lens; int32_t ngen;
     const int64_t* off; const int64_t* count; int64_t npairs; UnitRec* units;
     PM_HD void operator()(int64_t tid) const {
+        if (tid >= off[npairs]) return;                  // (a launch over a capacity: past the units there are)
         int64_t pair = upper_slot(off, npairs, tid);     // the last pair whose first unit is <= tid owns it
         const int64_t r = pair / (ngen - 1); const int g = (int)(pair % (ngen - 1)) + 1;
         const int64_t m = lens[r * ngen + g], qs = starts[r * ngen + g];
@@ -675,6 +676,7 @@ struct SeedExtend {
     const uint64_t* slots; const uint32_t* filter; const int32_t* next; const int32_t* rep; const uint32_t* repeated;
     uint64_t* ev_key; uint64_t* ev_val; uint64_t* ev_counters; uint64_t slice_cap; int lbits; uint32_t* err; int64_t budget;
     RestItem* queue; uint64_t* queue_count; uint64_t queue_cap;      // samples handed to SeedRest: kSlices sub-queues of queue_cap items
+    const int64_t* nunits_live;      // the units there are (the launch may cover a capacity: a search of store regions does not wait for the count)
     PM_HD void operator()(int64_t tid) const {
         int64_t unit = tid >> 6; int lane = (int)(tid & 63);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -682,6 +684,7 @@ struct SeedExtend {
         // is fetched with scalar loads instead of 64-lane vector loads of one address
         unit = (int64_t)__builtin_amdgcn_readfirstlane((int)unit);
 #endif
+        if (unit >= *nunits_live) return;
         const UnitRec rec = units[unit];
         const int32_t pair = rec.pair;
         const RegionInfo& ri = R[rec.region];

@@ -120,6 +120,8 @@ int CoreRun::open(const std::string& ini_path) {
     if (const char* v = test_hook("PM_STAGE_GATE")) (void)pm_session_tune(session, "stage_gate", atol(v));
     if (const char* v = test_hook("PM_CLUSTER_UNSURE")) (void)pm_session_tune(session, "cluster_unsure", atol(v));
     if (const char* v = test_hook("PM_CHAIN_TIE")) (void)pm_session_tune(session, "chain_tie", atol(v));
+    if (const char* v = test_hook("PM_FAST_TAIL")) (void)pm_session_tune(session, "fast_tail", atol(v));
+    if (const char* v = test_hook("PM_TANGLE_ROUNDS")) (void)pm_session_tune(session, "tangle_rounds", atol(v));
     upload_s = now_s() - t1;
     return 0;
 }

@@ -22,7 +22,7 @@ if has rearr; then
 fi
 if has prof; then      # per-kernel times of config 3 with inversions and of config 5 (rocprofv3 --kernel-trace --stats, a few steps each)
   for wl in ${PROF_WL:-bact200inv rearr500}; do
-    P=$O/prof_$wl; rm -rf $P; mkdir -p $P
+    P=$GRAFT_REPO_ROOT/$O/prof_$wl; rm -rf $P; mkdir -p $P
     ( cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats -d $P -o ks -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 3 --warmup 1 --cpu-sample 0 --other-configs off > $P/bench.json 2> $P/err.log )
     python - "$P" "$wl" <<'PY'
 import glob, sqlite3, sys, re, os

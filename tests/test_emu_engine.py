@@ -238,7 +238,7 @@ def test_resident_route(emu, tmp_path, name, flagged_div, expect):
 
 
 @pytest.mark.parametrize("name", ["pop12x400k", "viral50"])
-@pytest.mark.parametrize("variant", ["host_list_logic", "reported_tie", "split_settle", "one_stage", "gate_closed", "clusters_unsure"])
+@pytest.mark.parametrize("variant", ["host_list_logic", "reported_tie", "split_settle", "one_stage", "gate_closed", "clusters_unsure", "exact_tail", "serial_tangle"])
 def test_resident_route_variants(emu, tmp_path, name, variant):
     """the entry points the shipped route no longer calls, and its fall-backs: phases C-D by the host's list logic over
     pm_store_judge / _unmark / _fill (PARSNP_NO_DEVICE_CHAIN: pm_store_chain_* switched off; PM_CHAIN_TIE: the device reports two
@@ -247,7 +247,7 @@ def test_resident_route_variants(emu, tmp_path, name, variant):
     rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
     log = str(tmp_path / "route.log")
     env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_RESIDENT_LOG=log, PARSNP_CHECK_ZERO="1")
-    env.update({"host_list_logic": {"PARSNP_NO_DEVICE_CHAIN": "1"}, "reported_tie": {"PM_CHAIN_TIE": "1"}, "split_settle": {"PARSNP_SPLIT_SETTLE": "1"}, "one_stage": {"PARSNP_ONE_STAGE": "1"}, "gate_closed": {"PM_STAGE_GATE": "1"}, "clusters_unsure": {"PM_CLUSTER_UNSURE": "1"}}[variant])
+    env.update({"host_list_logic": {"PARSNP_NO_DEVICE_CHAIN": "1"}, "reported_tie": {"PM_CHAIN_TIE": "1"}, "split_settle": {"PARSNP_SPLIT_SETTLE": "1"}, "one_stage": {"PARSNP_ONE_STAGE": "1"}, "gate_closed": {"PM_STAGE_GATE": "1"}, "clusters_unsure": {"PM_CLUSTER_UNSURE": "1"}, "exact_tail": {"PM_FAST_TAIL": "0"}, "serial_tangle": {"PM_TANGLE_ROUNDS": "0"}}[variant])
     out = str(tmp_path / "out")
     rc, _ = driver.run_core(emu[1], rp, qs, out, env=env, threads=4, **kw)
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
@@ -255,7 +255,7 @@ def test_resident_route_variants(emu, tmp_path, name, variant):
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == want["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == want["log"]
     route = open(log).read()
-    assert "resident=1" in route and ("chain=1" in route) == (variant in ("split_settle", "one_stage", "gate_closed", "clusters_unsure")), route
+    assert "resident=1" in route and ("chain=1" in route) == (variant in ("split_settle", "one_stage", "gate_closed", "clusters_unsure", "exact_tail", "serial_tangle")), route
     if variant == "clusters_unsure" and name != "viral50":      # the collinear test of the clusters reported failure: ClustersCollide found them disjoint, the generations ran
         assert "exact=0" not in route, route
 

@@ -296,7 +296,7 @@ def test_parsnp_core_resident_route(libs, tmp_path, name, flagged_div, expect):
 
 
 @pytest.mark.parametrize("name", ["pop12x400k", "pop20x1m"])
-@pytest.mark.parametrize("variant", ["one_call_forms", "host_list_logic", "reported_tie", "split_settle", "one_stage", "gate_closed", "clusters_unsure"])
+@pytest.mark.parametrize("variant", ["one_call_forms", "host_list_logic", "reported_tie", "split_settle", "one_stage", "gate_closed", "clusters_unsure", "exact_tail", "serial_tangle"])
 def test_parsnp_core_resident_route_variants(libs, tmp_path, name, variant):
     """phases C-D from the device in one call (pm_store_chain_*: sort, chaining with the ratio test in the reference's float /
     double mix, LCB filter, second pass, fillers) and validation + seed regions in one call (pm_store_settle_seeds), against the
@@ -305,14 +305,14 @@ def test_parsnp_core_resident_route_variants(libs, tmp_path, name, variant):
     rp, qs, kw = test_host_logic.harsh_inputs(name, str(tmp_path))
     log = str(tmp_path / "route.log")
     env = dict(os.environ, PARSNP_PARALLEL_MIN="8", PARSNP_FREE_MIN="2", PM_DIRTY_MIN="8", PARSNP_RESIDENT_LOG=log, PARSNP_CHECK_ZERO="1")
-    env.update({"one_call_forms": {}, "host_list_logic": {"PARSNP_NO_DEVICE_CHAIN": "1"}, "reported_tie": {"PM_CHAIN_TIE": "1"}, "split_settle": {"PARSNP_SPLIT_SETTLE": "1"}, "one_stage": {"PARSNP_ONE_STAGE": "1"}, "gate_closed": {"PM_STAGE_GATE": "1"}, "clusters_unsure": {"PM_CLUSTER_UNSURE": "1"}}[variant])
+    env.update({"one_call_forms": {}, "host_list_logic": {"PARSNP_NO_DEVICE_CHAIN": "1"}, "reported_tie": {"PM_CHAIN_TIE": "1"}, "split_settle": {"PARSNP_SPLIT_SETTLE": "1"}, "one_stage": {"PARSNP_ONE_STAGE": "1"}, "gate_closed": {"PM_STAGE_GATE": "1"}, "clusters_unsure": {"PM_CLUSTER_UNSURE": "1"}, "exact_tail": {"PM_FAST_TAIL": "0"}, "serial_tangle": {"PM_TANGLE_ROUNDS": "0"}}[variant])
     out = str(tmp_path / "out")
     rc, _ = driver.run_core(CORE_HOOKS_BIN, rp, qs, out, env=env, threads=8, **kw)
     assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
     assert xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")) == E2E[name]["xmfa_md5"]
     assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == E2E[name]["log"]
     route = open(log).read()
-    assert "resident=1" in route and ("chain=1" in route) == (variant in ("one_call_forms", "split_settle", "one_stage", "gate_closed", "clusters_unsure")), route
+    assert "resident=1" in route and ("chain=1" in route) == (variant in ("one_call_forms", "split_settle", "one_stage", "gate_closed", "clusters_unsure", "exact_tail", "serial_tangle")), route
     if variant == "clusters_unsure":      # the collinear test of the clusters reported failure: ClustersCollide found them disjoint, the generations ran
         assert "exact=0" not in route, route
 
