@@ -136,9 +136,13 @@ int64_t pm_result_table_id(const pm_result* r);
  *   "dirty_min"    shortest one-region candidate list that gets the overlap / order flags and stays on the device as the
  *                  anchor table (default 4096)
  *   "flagged_div"  pm_store_settle takes an anchor table of which at most one row in flagged_div is flagged (overlaps an earlier
- *                  one by the cheap running-extent test: default 8) as it is; above three rows in four it answers PM_EAGAIN;
- *                  in between it counts the TANGLED rows (flagged rows that overlap one another: settled in list order by one
- *                  wavefront) and answers PM_EAGAIN with more than "tangled_max" of them (default 2048).  1: never PM_EAGAIN (tests)
+ *                  one by the cheap running-extent test: default 8) as it is; above that it counts the TANGLED rows first (flagged rows
+ *                  that overlap one another: settled in list order where they meet, in rounds) and answers PM_EAGAIN with more than
+ *                  "tangled_max" of them (default 131072).  1: never PM_EAGAIN (tests)
+ *   "tangle_rounds" 0: the tangled rows are settled by ONE wavefront in list order instead of in rounds (default 1; the same result)
+ *   "fast_tail"    0: a search whose rows stay on the device waits for its unit, candidate and accepted counts before it sizes the
+ *                  launches that need them, as every other search does (default 1: capacities from the last call of the shape, the
+ *                  kernels read the live counts, the counts come back with the results; the same result)
  *   "atomic_marks" != 0: pm_store_settle marks the layout with atomic ORs even where the list's order allows plain stores (tests)
  *   "group_small"  0: the events of a recursion batch's small regions are found pair by pair and sorted with the others, instead of
  *                  once per distinct query piece (default 1; both give the same events, tests compare the two)
@@ -181,9 +185,9 @@ typedef struct { int64_t key, ref_start, ref_len; int32_t slength, parent; } pm_
 int64_t pm_result_store_base(const pm_result* r);      /* first store row of a result whose rows stayed resident, else -1 */
 /* setMums1, second half, for the anchor table `table_id` into an EMPTY layout (:1781-1841): rows that overlap nothing earlier
  * are settled and marked at once; the flagged ones (PM_ROW_DIRTY) are trimmed against those marks (Aligner::trim) -- side by
- * side where they meet no other flagged row, in list order where they do.  rows[c] for every row of the table.  PM_EAGAIN for a
- * heavily rearranged set (more than three rows in four flagged, or -- above one in eight -- more than 2048 tangled ones: the
- * exact overlap test and the threads of the host route decide; a population with a few inversions is taken). */
+ * side where they meet no other flagged row, in list order where they do (rounds: a tangled row is settled once the tangled
+ * rows before it that share a 64-base word with it are).  rows[c] for every row of the table.  PM_EAGAIN only above
+ * "tangled_max" tangled rows (the exact overlap test and the threads of the host route decide); rearranged sets are taken. */
 int pm_store_settle(pm_session* s, int64_t table_id, pm_row_info* rows);
 int pm_store_info(pm_session* s, int64_t first, int64_t count, pm_row_info* out);
 /* setInitialClusters' seed regions (:2150-2172): determineRegion on both sides of every accepted anchor (anchors[]: their store
@@ -201,7 +205,7 @@ int pm_store_regions_equal(pm_session* s, const int32_t* a, const int32_t* b, in
 int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsize, int64_t n, int64_t* first_row, int64_t* offsets);
 /* One generation of doWork (:173-317).  The caller lists the waiting regions in the reference's order (reference start), with the
  * store rows of their candidates, cut into clusters (cluster c = regions [cluster_first[c], cluster_first[c + 1])) that it has
- * found pairwise disjoint in every genome; the clusters are validated side by side, each in order: candidates settled against
+ * formed on the reference (maximal runs that overlap or touch there); the clusters are validated side by side, each in order: candidates settled against
  * the layout and marked (setMums1 second half), the neighbour regions of every new MUM longer than q appended to the region
  * store (:215-254; pm_store_new_regions lists them parent by parent, in push order; one equal to a region still waiting in its
  * cluster is dropped as the work list would, :294-306).  The caller clusters on the reference only; what the other genomes do

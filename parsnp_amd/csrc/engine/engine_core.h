@@ -369,11 +369,18 @@ public:
         // the host never saw the rows of a store search: the unit count is the device's.  The call used to wait for it (8 bytes); now it
         // launches over a CAPACITY from the last call of the shape, the kernels read the live count, and the count comes back with the
         // event counters (a capacity that was too small repeats the event search, like a full event buffer)
+        // (which call of the step this is: the anchor call is number 0, the searches of store regions follow it -- a step that repeats
+        // makes the same calls in the same order, and the capacities of a call come from the same call of the step before)
+        if (!gb && nreg == 1) call_ordinal = 0; else if (gb) call_ordinal++;
+        const size_t ord = gb || nreg == 1 ? (size_t)call_ordinal : (size_t)-1;      // (-1: a batch of the host route -- it waits for its counts)
+        if (ord != (size_t)-1 && call_hints.size() <= ord) call_hints.resize(ord + 1);
+        CallHint none;
+        CallHint& hint = ord != (size_t)-1 ? call_hints[ord] : none;
         bool units_known = !gb;
-        if (gb && !(fast_tail && units_hint[nreg == 1] > 0)) {
+        if (gb && !(fast_tail && hint.units > 0)) {
             be.d2h(&nunits, d_uoff.p + npairs, 8);
             units_known = true;
-        } else if (gb) nunits = units_hint[nreg == 1] + units_hint[nreg == 1] / 4 + 64;
+        } else if (gb) nunits = hint.units + hint.units / 8 + 64;
         if (nunits >= (1ll << 31)) { error = "too many work units in one batch"; return -5; }
         if (gb) ev_guess += (size_t)nunits * 16;
 
@@ -460,7 +467,7 @@ public:
         if (from_store) { last_alg[0] = (double)alg_raw[0] / 4.0; last_alg[1] = (double)alg_raw[1] / 2.0; last_alg[2] = (double)alg_raw[2] / 2.0; }
         if (errbits & kErrRows) { error = "region outside its genome"; return -2; }
         rest_cap_hint[nreg == 1] = queue_cap;
-        if (gb) units_hint[nreg == 1] = std::max<int64_t>(nunits_live, 1);
+        if (gb) hint.units = std::max<int64_t>(nunits_live, 1);
         last_rest = (int64_t)nrest;
         ev_cap_hint = (size_t)(nev + nev / 4);
         if (grouping) grp_cap_hint = (size_t)(ngrp + ngrp / 4);
@@ -559,9 +566,8 @@ public:
         // store searches) no longer does: launches and buffers take CAPACITIES from what the last call of the same shape needed,
         // every kernel reads the live count from device memory, and both counts come back with the results, in the call's one last
         // wait.  A capacity that turns out too small (or an anchor list that turns out short) repeats the tail the exact way.
-        const int shape = nreg == 1 ? 1 : 0;
-        const bool anchor_guess = nreg == 1 && !gb && tail_hint[shape].nok >= dirty_min;
-        const bool may_skip_waits = !sharded && want_rows && resident && tail_hint[shape].ncand > 0 && (from_store || anchor_guess) && fast_tail;
+        const bool anchor_guess = nreg == 1 && !gb && hint.nok >= dirty_min;
+        const bool may_skip_waits = !sharded && want_rows && resident && hint.ncand > 0 && (from_store || anchor_guess) && fast_tail;
         for (int attempt = may_skip_waits ? 0 : 1;; attempt++) {
             const bool exact = attempt > 0;
             int64_t ncand_i = 0;
@@ -569,10 +575,10 @@ public:
             if (verdict < 0) { budget_exceeded = true; error = "per-thread work budget exceeded on some rank (degenerate repeat structure in a region)"; return -5; }
             if (exact) {
                 last_candidates = ncand_i;
-                if (ncand_i == 0) { tail_hint[shape] = TailHint{1, 0}; if (resident && from_store) out->store_base = ms_count; be.mark(nullptr); collect_timing(); return 0; }
+                if (ncand_i == 0) { hint.ncand = 1; hint.nok = 0; if (resident && from_store) out->store_base = ms_count; be.mark(nullptr); collect_timing(); return 0; }
             }
             // capacity of the candidate list: the count itself when it is known
-            const uint64_t ncand = exact ? (uint64_t)ncand_i : (uint64_t)(tail_hint[shape].ncand + tail_hint[shape].ncand / 4 + 1024);
+            const uint64_t ncand = exact ? (uint64_t)ncand_i : (uint64_t)(hint.ncand + hint.ncand / 8 + 256);
             ensure(d_cand, (size_t)ncand);
             be.launch("cand_write", nwv * 64, CandWrite{d_R.p, nreg, d_posbase.p, d_wmask.p, d_woff.p, d_cand.p, ncand});
             const uint64_t* scand = d_cand.p;        // in (region, k) order by construction
@@ -719,7 +725,7 @@ public:
                 last_candidates = ncand_i;
                 if (out->store_base >= 0) ms_count = out->store_base + nok;
             }
-            tail_hint[shape] = TailHint{std::max<int64_t>(ncand_i, 1), nok};
+            hint.ncand = std::max<int64_t>(ncand_i, 1); hint.nok = nok;
             last_accepted = nok;
             if (anchor_call) { anchor_table_rows = nok; anchor_table_id = out->table_id; }
             for (int64_t w = 0; w < nok; w++) out->off[(size_t)reg_h[(size_t)w] + 1]++;
@@ -1430,9 +1436,11 @@ private:
     int64_t total_words = 0;
     Packed P{};
     size_t ev_cap_hint = 0, cand_cap_hint = 0, rest_cap_hint[2] = {0, 0}, grp_cap_hint = 0;
-    struct TailHint { int64_t ncand = 0, nok = 0; };
-    int64_t units_hint[2] = {0, 0};      // work units of the last store search of a shape
-    TailHint tail_hint[2];      // candidates / accepted rows of the last call of a shape ([1]: one region = an anchor call): capacities of the next one's tail
+    // what call number `i` of the last step needed (i = 0: the anchor call; then the searches of store regions in their order): the
+    // capacities call i of this step launches over instead of waiting for its counts
+    struct CallHint { int64_t units = 0, ncand = 0, nok = 0; };
+    std::vector<CallHint> call_hints;
+    int64_t call_ordinal = 0;      // candidates / accepted rows of the last call of a shape ([1]: one region = an anchor call): capacities of the next one's tail
     Buf<uint8_t> d_gflag; Buf<int64_t> d_glo;
     Buf<RegionInfo> d_R; Buf<int64_t> d_starts, d_lens, d_posbase;
     Buf<uint64_t> d_slots; Buf<uint32_t> d_filter, d_repeated; Buf<int32_t> d_next, d_rep, d_run, d_epm;
