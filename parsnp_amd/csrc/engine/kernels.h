@@ -792,8 +792,9 @@ struct SeedExtend {
         // other's memory latency.
         enum : uint8_t { kNone = 0, kProbe = 1, kFwd = 2, kRev = 4 };      // what to do with a sample after the window phase
         uint8_t todo[kPer]; int32_t left[kPer], right[kPer];
+        bool any_fast = false;       // the lane holds reference windows: [base - 32, base + 64) against the query's [j0 - 32, j0 + 64)
+        int32_t first_diff = 64;     // ... and this is the first base of [j0, j0 + 64) that differs from the reference on that diagonal (64: none)
         {
-            bool any_fast = false;
             bool fast[kPer];
 #pragma unroll
             for (int u = 0; u < kPer; u++) {
@@ -816,6 +817,8 @@ struct SeedExtend {
                 rw1 = funnel(r1, r2, shr);
                 d0 = diff_of(qw0, rw0); d1 = diff_of(qw1, rw1); d2 = diff_of(qw2, rw2);
                 rwords = (uint64_t)rep0 | ((uint64_t)rep1 << 32);
+                first_diff = eq_up(d1, 0);
+                if (first_diff == 32) first_diff += eq_up(d2, 0);
             }
             bool fwd_here = false;       // the previous sample of this lane was confirmed as a forward seed on this diagonal
 #pragma unroll
@@ -869,8 +872,13 @@ struct SeedExtend {
         };
 #pragma unroll
         for (int u = 0; u < kPer; u++) { qs[u] = 0; ql[u] = -1; }
+        // Forward seeds, step 1: everything but the part of a right arm that leaves the lane's windows.  (After a confirmed forward
+        // seed the lane's next sample on the diagonal is never a first one, so at most ONE sample of a lane has such an arm.)
+        int32_t f_l[kPer], f_maxr[kPer], f_rt[kPer], f_rep[kPer];
+        int pend = -1;               // the sample whose right arm is equal as far as the windows reach, and may go on
 #pragma unroll
         for (int u = 0; u < kPer; u++) {
+            f_l[u] = 0; f_maxr[u] = 0; f_rt[u] = 0; f_rep[u] = 0;
             if (todo[u] == kNone) continue;
             const int64_t j = j0 + (int64_t)u * stride;
             if (todo[u] & kProbe) {
@@ -890,18 +898,93 @@ struct SeedExtend {
             }
             const int32_t l = base + u * stride;
             if (todo[u] & kFwd) {
-                const int32_t lf = left[u];
-                const int32_t rep_l0 = rep[ri.posbase + l - lf];          // in flight while the right arm is compared
+                f_l[u] = l;
+                f_rep[u] = rep[ri.posbase + l - left[u]];          // in flight while the right arm is settled
                 const int64_t mr = m - j - K; const int32_t rr = ri.nR - l - K;
-                const int32_t maxr = (int32_t)(mr < rr ? mr : rr);
+                f_maxr[u] = (int32_t)(mr < rr ? mr : rr);
                 const int32_t reach = 64 - u * stride - K;          // bases after the K-mer that the windows hold
-                int32_t rt = right[u];
-                if (rt >= reach && maxr > reach) rt = reach + lce_fwd64(P, qbase + j + K + reach, rbase + l + K + reach, maxr - reach);
-                if (rt > maxr) rt = maxr;
-                const int32_t len = lf + K + rt;
-                if (len >= ri.minlen && len > rep_l0) emit(0, l - lf, j - lf, len);      // len <= rep': not unique in R
+                f_rt[u] = right[u];
+                if (right[u] >= reach && f_maxr[u] > reach) { f_rt[u] = reach; pend = u; }
             }
             if (todo[u] & kRev) hand_over(s0 + u, l);
+        }
+        // Step 2: the arms that go on.  The windows of the lanes of a wavefront that lie on ONE diagonal tile the unit's stretch of
+        // the query, 20 t ... 20 t + 64 for lane t at stride 10 -- so where a lane's arm ends is something the lanes after it have
+        // already compared: a segmented suffix minimum over the lanes (segments = runs of lanes on the same diagonal; a lane reports
+        // the first difference of ITS kPer * stride bases, the last lane of a run that of all its 64) gives every lane the first
+        // difference at or after the start of its successor's stretch, six shuffle steps for all arms of the wavefront.  An arm
+        // that outruns its run (the unit ends, an indel) is finished from memory by the WHOLE wavefront, a lane per 32 bases with
+        // coalesced loads -- instead of 64 bases per round and lane (every round six scattered loads for all 64 lanes, ~40 of
+        // the kernel's 56 vector memory instructions per wavefront: rounds 3-5).
+        int32_t more = 0;            // equal bases after the windows' end
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (follow) {
+            constexpr int32_t kOpenEnd = 1 << 20, kNoDiff = 0x7fffffff;
+            const int32_t own = kPer * stride;
+            const int32_t pj = lane * own;                                     // the lane's j0, from the unit's first sample
+            const int32_t dg = any_fast ? base - (int32_t)j0 : (int32_t)0x80000000 + lane;      // (no windows: a run of its own)
+            const int32_t dg_next = __shfl_down(dg, 1, 64);
+            const bool run_end = lane == 63 || dg_next != dg;
+            int32_t v = first_diff < (run_end ? 64 : own) ? pj + first_diff : run_end ? kOpenEnd + pj + 64 : kNoDiff;
+            int closed = run_end ? 1 : 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int32_t ov = __shfl_down(v, d, 64); const int oc = __shfl_down(closed, d, 64);
+                if (!closed && lane + d < 64) { if (ov < v) v = ov; closed = oc; }
+            }
+            // everything from the sample's K-mer to the end of the lane's windows is equal, so the first difference at or after the
+            // successor's stretch is the arm's end
+            int32_t nxt = __shfl_down(v, 1, 64);
+            if (run_end) nxt = kOpenEnd + pj + 64;
+            int32_t cont = -1, capleft = 0;      // where (query offset in the piece) an arm goes on from memory, and how far at most
+            if (pend >= 0) {
+                const int32_t room = f_maxr[pend] - f_rt[pend];                // > 0
+                if (nxt < kOpenEnd) more = nxt - (pj + 64);
+                else {
+                    more = nxt - kOpenEnd - (pj + 64);                         // equal as far as the run's windows reach
+                    if (more < room) { cont = (int32_t)(j0 - pj) + (nxt - kOpenEnd); capleft = room - more; }
+                }
+            }
+            unsigned long long need = __ballot(cont >= 0);
+            while (need) {
+                const int src = __ffsll((long long)need) - 1;
+                need &= need - 1;
+                const int32_t c0 = __builtin_amdgcn_readlane(cont, src), dgs = __builtin_amdgcn_readlane(dg, src), cap = __builtin_amdgcn_readlane(capleft, src);
+                int32_t n = 0;
+                for (;;) {
+                    const int32_t o = n + lane * 32;
+                    int c = 32;
+                    if (o < cap) {
+                        Win wa, wb;
+                        window(P.blk, qbase + c0 + o, &wa.b, &wa.m);
+                        window(P.blk, rbase + c0 + dgs + o, &wb.b, &wb.m);
+                        c = match_fwd(wa, wb);
+                    }
+                    const unsigned long long stop = __ballot(c < 32);
+                    if (stop) { const int f = __ffsll((long long)stop) - 1; n += f * 32 + __builtin_amdgcn_readlane(c, f); break; }
+                    n += 64 * 32;
+                    if (n >= cap) break;
+                }
+                if (lane == src) more += n;
+            }
+        }
+#else
+        if (pend >= 0) {
+            const int64_t j = j0 + (int64_t)pend * stride;
+            const int32_t reach = 64 - pend * stride - K;
+            more = lce_fwd64(P, qbase + j + K + reach, rbase + f_l[pend] + K + reach, f_maxr[pend] - reach);
+        }
+#endif
+        // Step 3: the events
+#pragma unroll
+        for (int u = 0; u < kPer; u++) {
+            if (!(todo[u] & kFwd)) continue;
+            const int64_t j = j0 + (int64_t)u * stride;
+            const int32_t lf = left[u];
+            int32_t rt = f_rt[u] + (u == pend ? more : 0);
+            if (rt > f_maxr[u]) rt = f_maxr[u];
+            const int32_t len = lf + K + rt;
+            if (len >= ri.minlen && len > f_rep[u]) emit(0, f_l[u] - lf, j - lf, len);      // len <= rep': not unique in R
         }
         {
             // (a sub-queue per workgroup, as for the events: one counter for the launch's ~10^6 wavefronts is a 20 ms queue)
