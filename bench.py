@@ -446,7 +446,7 @@ def main():
             for tab in (phases, totals):
                 if "grouped_events" in tab:
                     tab["seed_extend"] = tab.get("seed_extend", 0.0) + tab.pop("grouped_events")
-            counts = ("budget_retries", "events", "rest_samples", "n_positions", "n_candidates", "n_accepted", "n_grouped", "exact_cluster_tests", "deferred_regions", "tail_repeats")          # counts that travel in the timing list, not times
+            counts = ("budget_retries", "events", "rest_samples", "n_positions", "n_candidates", "n_accepted", "n_grouped", "exact_cluster_tests", "deferred_regions", "tail_repeats", "outside_writes")          # counts that travel in the timing list, not times
             kernels = {k: v for k, v in totals.items() if k not in ("setup", "download", "units", "call_wall") + counts}
             dom = max(kernels, key=kernels.get) if kernels else None
             launches = sum(r["finder_calls"] for r in reports) / len(reports)          # engine launches per step

@@ -317,6 +317,7 @@ int pm_last_timing(const pm_session* cs, int* count, const char** names, float* 
     s->timing.push_back(pm::PhaseTime{"n_candidates", (float)s->engine->last_candidates});
     s->timing.push_back(pm::PhaseTime{"n_accepted", (float)s->engine->last_accepted});
     s->timing.push_back(pm::PhaseTime{"n_grouped", (float)s->engine->last_grouped});
+    if (s->engine->outside_writes) { s->timing.push_back(pm::PhaseTime{"outside_writes", (float)s->engine->outside_writes}); s->engine->outside_writes = 0; }      // accepted members outside their region, checked against the order (OutsideWriteCheck)
     if (s->engine->exact_cluster_tests) { s->timing.push_back(pm::PhaseTime{"exact_cluster_tests", (float)s->engine->exact_cluster_tests}); s->engine->exact_cluster_tests = 0; }      // generations validated with the exact test of their clusters (inversions)
     if (s->engine->tail_repeats) { s->timing.push_back(pm::PhaseTime{"tail_repeats", (float)s->engine->tail_repeats}); s->engine->tail_repeats = 0; }      // searches that repeated a part because a capacity from the last step was too small
     if (s->engine->deferred_regions) { s->timing.push_back(pm::PhaseTime{"deferred_regions", (float)s->engine->deferred_regions}); s->engine->deferred_regions = 0; }      // regions a generation left waiting (their cluster met an earlier one, or a child sorted first)

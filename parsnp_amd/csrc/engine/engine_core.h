@@ -1037,6 +1037,12 @@ public:
         foreign_cap = std::min<size_t>((size_t)1 << 16, ((size_t)32 << 20) / (8 * (size_t)ngen));
         ensure(d_foreign, foreign_cap); ensure(d_foreign_masks, foreign_cap * (size_t)ngen); ensure(d_foreign_count, 2);
         ensure_keep(d_ms_key, (size_t)ms_count, (size_t)ms_key_rows); ms_key_rows = ms_count;
+        // what every region was processed with (0: it waits), and the accepted members outside their region of this call (OutsideWriteCheck)
+        if (rg_pkey_init > rg_count) rg_pkey_init = 0;
+        ensure_keep(d_rg_pkey, cap, (size_t)rg_pkey_init);
+        if (rg_pkey_init < rg_count) { be.memset(d_rg_pkey.p + rg_pkey_init, 0, 8 * (size_t)(rg_count - rg_pkey_init)); rg_pkey_init = rg_count; }
+        constexpr size_t kOutwCap = 4096; constexpr int64_t kOutwWaves = 256;
+        ensure(d_outw, kOutwCap); ensure(d_outw_count, 2);
         const int64_t na = stage_first > 0 ? stage_first : ncl;
         uint64_t head[4] = {(uint64_t)rg_count, 0, 0, 0};       // [0] the region counter, [1] the trouble word, [2] the gate of the second stage, [3] collinear test failed
         if (info_count > 0) {      // the scalars of the candidates just decided come back with the same round trip
@@ -1050,6 +1056,7 @@ public:
         auto generation = [&](bool exact) {
             be.h2d(d_rg_count.p, head, 32);
             be.memset(d_v_done.p, 0, 4 * (size_t)ncl);
+            be.memset(d_outw_count.p, 0, 16);
             const uint8_t* defer = nullptr;
             if (exact) {
                 be.memset(d_v_defer.p, 0, (size_t)ncl);
@@ -1071,18 +1078,24 @@ public:
             be.launch_wave("cluster_validate", xcd_grid(na),
                            ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
                                            d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), na, 0, nullptr, d_rg_count.p + 3,
-                                           d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation_no, d_recwords.p, defer, d_v_done.p});
+                                           d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation_no, d_recwords.p, defer, d_v_done.p,
+                                           d_rg_pkey.p, d_outw.p, d_outw_count.p, (uint64_t)kOutwCap});
             if (stage_first > 0) {
                 be.launch("stage_gate", 1, StageGate{d_rg_count.p, (uint64_t)rg_count, force_gate ? 1 : 0});
                 be.launch_wave("cluster_validate", xcd_grid(ncl - na),
                                ClusterValidate{store_view(), layout_view(d_image.p), P, d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_count.p, (uint64_t)cap,
                                                d_list.p, d_v_row0.p, d_list2.p, d_v_first.p, q, (uint32_t*)(d_rg_count.p + 1), ncl - na, na, d_rg_count.p + 2, d_rg_count.p + 3,
-                                               d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation_no + 1, d_recwords.p, defer, d_v_done.p});
+                                               d_foreign.p, d_foreign_count.p, (uint64_t)foreign_cap, d_foreign_masks.p, d_ms_key.p, generation_no + 1, d_recwords.p, defer, d_v_done.p,
+                                               d_rg_pkey.p, d_outw.p, d_outw_count.p, (uint64_t)kOutwCap});
             }
+            be.launch_wave("outside_write_check", kOutwWaves,
+                           OutsideWriteCheck{store_view(), d_rg_start.p, d_rg_len.p, d_rg_info.p, d_rg_pkey.p, d_rg_count.p, (uint64_t)cap, d_list.p, d_outw.p, d_outw_count.p, (uint64_t)kOutwCap,
+                                             d_ms_key.p, anchor_table_rows, (uint32_t*)(d_rg_count.p + 1), kOutwWaves});
             if (info_count > 0) be.launch("store_info", info_count, StoreInfoOut{store_view(), info_first, d_rowinfo.p});
             be.mark(nullptr);
             if (info_count > 0) be.d2h_async(info, d_rowinfo.p, sizeof(RowInfo) * (size_t)info_count);
             be.d2h_async(&foreign_seen, d_foreign_count.p, 8);
+            be.d2h_async(&outside_writes_call, d_outw_count.p, 8);
             be.d2h_async(done_h.data(), d_v_done.p, 4 * (size_t)ncl);
             be.d2h(head, d_rg_count.p, 32);
         };
@@ -1098,6 +1111,7 @@ public:
             generation(true);
         }
         *trouble = (uint32_t)head[1];
+        outside_writes += (int64_t)outside_writes_call;
         const bool ran2 = stage_first > 0 && head[2] == 0;
         if (second_stage_ran) *second_stage_ran = ran2 ? 1 : 0;
         for (int64_t cl = 0; cl < ncl; cl++) {
@@ -1365,6 +1379,7 @@ public:
     bool force_chain_tie = false;         // (tests) store_chain_begin reports two MUMs with one reference start
     bool force_unsure = false;            // (tests) store_validate's collinear test of the clusters reports failure: the exact test decides
     bool order_debug = false;             // the order check prints its counts (noted candidates, candidates left to the scan) to stderr
+    int64_t outside_writes = 0;           // accepted reverse-strand members outside their region that OutsideWriteCheck looked at
     int64_t exact_cluster_tests = 0;      // generations validated with the exact test of their clusters (ClusterExtents ... ClusterDefer)
     int64_t deferred_regions = 0;         // regions a validation call left on the caller's work list (their cluster met an earlier one, or a child sorted first)
     bool clusters_out_of_order = false;   // a generation of this session failed the collinear test of its clusters: the exact test is asked at once from then on
@@ -1462,6 +1477,7 @@ private:
     Buf<int64_t> d_sd_cnt, d_sd_off; Buf<uint8_t> d_sd_keep;      // store_settle_seeds
     Buf<uint64_t> d_t_rem; Buf<uint8_t> d_t_done;      // settle_launch: tangled rows left, settled flags per flagged row
     Buf<int32_t> d_v_done, d_owner; Buf<uint8_t> d_v_defer, d_v_involved;      // store_validate: regions processed per cluster; the exact test of the clusters
+    Buf<int64_t> d_rg_pkey; Buf<OutsideWrite> d_outw; Buf<uint64_t> d_outw_count; int64_t rg_pkey_init = 0; uint64_t outside_writes_call = 0;      // store_validate: OutsideWriteCheck
     Buf<ForeignRead> d_foreign; Buf<uint64_t> d_foreign_count, d_foreign_masks; Buf<int64_t> d_ms_key;       // store_validate / store_order_check: candidates with a member outside their region
     size_t foreign_cap = 0; int64_t ms_key_rows = 0; uint64_t foreign_seen = 0;      // foreign_seen: the device's counter as of the last validation call
     static constexpr size_t kHitCap = 256;      // noted candidates that the bounds of ForeignBound do not decide

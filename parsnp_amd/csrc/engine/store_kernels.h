@@ -1332,6 +1332,72 @@ struct ForeignDecideHits {
         if (verdict_differs(S, P, c, dl, len) && wave_leader()) atomic_or32(trouble, bit);
     }
 };
+// An ACCEPTED reverse-strand member outside its region (fuzz and the rearranged sets: a few bases left by the trimming that pass the
+// sequence check somewhere else in the genome) WRITES marks into another cluster's territory.  That is harmless exactly when nobody
+// whom the reference's order serves differently can see the mark: the gap between two marks it falls into is dead ground -- no
+// region of the store covers it -- or every region r that does cover it in that genome is on the right side of the order:
+//   * r was walked out (region_extent) by a MUM that the reference processes before this one, or by one of the own cluster (which
+//     one wavefront works through in the reference's order): its extent is what the reference's is;
+//   * r has been processed, in an earlier generation and with a smaller order key (it, and whatever of its rows lay there, came
+//     first in the reference as well), or in this cluster;
+//   * or r still waits and sorts after this region (it will see the mark, as in the reference).
+// A candidate of another region that READS there through an outside member of its own is the order check's business (ForeignRead).
+// ClusterValidate lists the writes (OutsideWrite), OutsideWriteCheck runs over (write, 64 regions of the store) items behind the
+// generation's validation and raises trouble bit 1 where none of that holds: the route is left, as it was for EVERY such write
+// until round 6.  rg_pkey[r]: 0 = region r waits, else the order key it was processed with + 3.
+struct OutsideWrite { int32_t row, region, x0, x1; int64_t key; };
+constexpr int kOutsideChunk = 64;
+struct OutsideWriteCheck {
+    Store S; const int64_t* rg_start; const int64_t* rg_len; const RegInfo* info; const int64_t* rg_pkey; const uint64_t* rg_count; uint64_t rg_cap;
+    const int32_t* now_region; const OutsideWrite* list; const uint64_t* count; uint64_t cap; const int64_t* row_key; int64_t anchor_rows;
+    uint32_t* trouble; int64_t waves;
+    PM_HD void wave(int64_t w) const {
+        const int64_t nev = (int64_t)(*count < cap ? *count : cap);
+        if (nev == 0) return;
+        const int n = S.ngen;
+        const int64_t nreg = (int64_t)(*rg_count < rg_cap ? *rg_count : rg_cap);
+        const int64_t chunks = (nreg + kOutsideChunk - 1) / kOutsideChunk;
+        for (int64_t x = w; x < nev * chunks; x += waves) {
+            const OutsideWrite e = list[x / chunks];
+            const int64_t r_lo = (x % chunks) * kOutsideChunk, r_hi = r_lo + kOutsideChunk < nreg ? r_lo + kOutsideChunk : nreg;
+            const int64_t c = e.row;
+            const int32_t dl = S.shift[c], len = S.len[c];
+            const int64_t* Rs = rg_start + (int64_t)e.region * n; const int64_t* Rl = rg_len + (int64_t)e.region * n;
+            const int64_t ref0 = Rs[0];
+            // the order keys of the own cluster's regions: (reference start, this generation)
+            auto own_cluster = [&](int64_t k) {
+                if (k == e.key) return true;
+                if (k < 0 || e.key < 0 || ((k ^ e.key) & 4095)) return false;
+                for (int32_t y = e.x0; y < e.x1; y++) if (rg_start[(int64_t)now_region[y] * n] == (k >> 12)) return true;
+                return false;
+            };
+            auto wrong_side = [&](int64_t k) {      // k: the key something was processed with -- not before this region, or beside it
+                if (own_cluster(k)) return false;
+                return k > e.key || (k >= 0 && e.key >= 0 && ((k ^ e.key) & 4095) == 0);
+            };
+            uint32_t bad = 0;
+            lanes_for(0, n, [&](int j) {
+                if (bad || S.strand[c * n + j]) return;
+                const int64_t a = (int64_t)S.start[c * n + j] + dl;
+                if (!(a < Rs[j] - 1 || a + len > Rs[j] + Rl[j] + 1)) return;
+                const int64_t lo = a - 1, hi = a + len + 1;
+                for (int64_t r = r_lo; r < r_hi && !bad; r++) {
+                    if (r == e.region) continue;
+                    const int64_t s = rg_start[r * n + j], t = s + rg_len[r * n + j];
+                    if (s >= hi || t <= lo) continue;
+                    const RegInfo ri = info[r];
+                    if (ri.key < 0) continue;                                   // (dropped: equal to a region of its cluster)
+                    const int64_t pk = ri.parent < anchor_rows ? -2 : row_key[ri.parent];      // (an anchor's walks precede every region)
+                    if (pk >= -1 && wrong_side(pk)) { bad = 1; break; }
+                    const int64_t mine = rg_pkey[r];
+                    if (mine == 0) { if (ri.ref_start <= ref0) bad = 1; }
+                    else if (wrong_side(mine - 3)) bad = 1;
+                }
+            });
+            if (wave_or_u32(bad) && wave_leader()) atomic_or32(trouble, 2u);
+        }
+    }
+};
 struct ClusterValidate {
     Store S; Layout L; Packed P;
     int64_t* rg_start; int64_t* rg_len; RegInfo* info; uint64_t* rg_count; uint64_t rg_cap;
@@ -1346,6 +1412,7 @@ struct ClusterValidate {
     uint8_t* rec;                              // one byte per image word: the recursion has marked there
     const uint8_t* defer;                      // != nullptr: [cluster] != 0 -- it meets an earlier cluster in some genome and waits (ClusterDefer)
     int32_t* done;                             // [cluster]: how many of its regions were processed (the rest stay on the caller's work list)
+    int64_t* rg_pkey; OutsideWrite* outw; uint64_t* outw_count; uint64_t outw_cap;      // accepted members outside their region (OutsideWriteCheck)
     PM_HD void wave(int64_t w) const {
         if ((gate && *gate) || (unsure && *unsure && !defer)) return;      // (the collinear test failed and nobody has said which clusters may run)
         const int64_t cl = cl0 + xcd_item(w, ncl);
@@ -1364,6 +1431,7 @@ struct ClusterValidate {
             const int64_t row0 = now_row0[x]; const int32_t cnt = now_cnt[x];
             if (cnt >= (1 << 22)) { if (wave_leader()) atomic_or32(trouble, 4u); return; }
             const int64_t okey = order_key(rs[0], generation);
+            if (wave_leader()) rg_pkey[rid] = okey + 3;
             for (int64_t c = row0; c < row0 + cnt; c++) {
                 const uint32_t f = S.flags[c];
                 int32_t dl, len;
@@ -1397,7 +1465,13 @@ struct ClusterValidate {
                         const int64_t a = (int64_t)S.start[c * n + j] + dl;
                         if (a < rs[j] - 1 || a + len > rs[j] + rl[j] + 1) out = 1;
                     });
-                    if (wave_or_u32(out) && wave_leader()) atomic_or32(trouble, 2u);
+                    if (wave_or_u32(out)) {      // listed: harmless unless somebody on the wrong side of the order can see the marks
+                        int32_t at = 0;
+                        if (wave_leader()) at = (int32_t)atomic_add64(outw_count, 1);
+                        at = wave_bcast_i32(at, 0);
+                        if ((uint64_t)at >= outw_cap) { if (wave_leader()) atomic_or32(trouble, 2u); }
+                        else if (wave_leader()) outw[at] = OutsideWrite{(int32_t)c, (int32_t)rid, (int32_t)x0, (int32_t)x1, okey};
+                    }
                 }
                 if (acc) lanes_for(0, n, [&](int j) { const int64_t a = (int64_t)S.start[c * n + j] + dl; img_set_range(L, j, a, a + len); rec_set(rec, L.word_off[j], L.nbits[j], a, a + len); });
                 if (wave_leader()) {
@@ -1433,7 +1507,7 @@ struct ClusterValidate {
                         });
                         dup = wave_or_u32(diff) == 0;
                     }
-                    if (wave_leader()) info[slot] = RegInfo{dup ? -1 : ((x << 24) | (int64_t)seq), ks, kl, smin, (int32_t)c};
+                    if (wave_leader()) { info[slot] = RegInfo{dup ? -1 : ((x << 24) | (int64_t)seq), ks, kl, smin, (int32_t)c}; rg_pkey[slot] = 0; }
                     seq++;
                     if (!dup && (pending_min < 0 || ks < pending_min)) pending_min = ks;
                 }

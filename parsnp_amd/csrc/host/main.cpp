@@ -131,17 +131,21 @@ int main(int argc, char* argv[]) {
     if (const char* tf = getenv("PARSNP_TIMING")) {
         FILE* f = fopen(tf, "w");
         if (f) {
+            double outside_writes = 0;      // accepted reverse-strand members outside their region that stayed on the resident route
+            for (const auto& kv : rep.host.engine_ms) if (kv.first == "outside_writes") outside_writes = kv.second;
+            std::string why = rep.resident_why;      // (plain words; quotes and backslashes would break the JSON)
+            for (char& ch : why) if (ch == '"' || ch == '\\') ch = ' ';
             fprintf(f,
                     "{\"provider\": \"%s\", \"genomes\": %zu, \"queries\": %d, \"ingest_s\": %.6f, \"upload_s\": %.6f, \"path_s\": %.6f, "
                     "\"anchor_s\": %.6f, \"extend_s\": %.6f, \"filter_s\": %.6f, \"lcb_s\": %.6f, \"output_s\": %.6f, \"total_s\": %.6f, "
                     "\"finder_s\": %.6f, \"finder_calls\": %ld, \"finder_regions\": %ld, \"regions_processed\": %ld, \"cache_hits\": %ld, "
                     "\"cache_misses\": %ld, \"spec_rounds\": %ld, \"anchors\": %ld, \"mums\": %ld, \"lcbs\": %ld, \"core_bp\": %ld, "
-                    "\"gap_note\": %s, \"tie_fallbacks\": %ld, \"literal_iterations\": %ld, \"parallel_candidates\": %ld, \"parallel_dirty\": %ld, \"t_validate\": %.6f, \"t_neighbour\": %.6f, \"t_sweep\": %.6f, \"t_replay\": %.6f, \"t_key\": %.6f, \"resident\": %ld, \"resident_retry\": %ld, \"device_chain\": %ld, \"h2d_bytes\": %.0f, \"d2h_bytes\": %.0f}\n",
+                    "\"gap_note\": %s, \"tie_fallbacks\": %ld, \"literal_iterations\": %ld, \"parallel_candidates\": %ld, \"parallel_dirty\": %ld, \"t_validate\": %.6f, \"t_neighbour\": %.6f, \"t_sweep\": %.6f, \"t_replay\": %.6f, \"t_key\": %.6f, \"resident\": %ld, \"resident_retry\": %ld, \"device_chain\": %ld, \"h2d_bytes\": %.0f, \"d2h_bytes\": %.0f, \"outside_writes\": %.0f, \"resident_why\": \"%s\"}\n",
                     pm_provider(), run.genomes.size(), run.qfiles, run.ingest_s, run.upload_s, rep.path_s, rep.anchor_s, rep.extend_s, rep.filter_s,
                     rep.lcb_s, output_s, now_s() - t_begin, rep.finder_s, rep.finder_calls, rep.finder_regions, rep.regions_processed,
                     rep.cache_hits, rep.cache_misses, rep.spec_rounds, rep.anchors, rep.mums, rep.lcbs, rep.core_bp, gap_note ? "true" : "false",
                     rep.host.tie_fallbacks, rep.host.literal_iterations, rep.host.parallel_candidates, rep.host.parallel_dirty, rep.host.t_validate, rep.host.t_neighbour, rep.host.t_sweep, rep.host.t_replay, rep.host.t_key,
-                    rep.host.resident, rep.host.resident_retry, rep.host.device_chain, rep.h2d_bytes, rep.d2h_bytes);
+                    rep.host.resident, rep.host.resident_retry, rep.host.device_chain, rep.h2d_bytes, rep.d2h_bytes, outside_writes, why.c_str());
             fclose(f);
         }
     }

@@ -314,7 +314,7 @@ bool Aligner::resident_extend() {
         collect_engine_timing();
         if (trouble) {
             res_.failed = true;
-            res_.why = (trouble & 2) ? "a reverse-strand member outside its region was accepted"
+            res_.why = (trouble & 2) ? "a reverse-strand member was accepted outside its region where the reference's order shows"
                      : "a region with too many candidates, or more candidates with a member outside their region than the engine notes";
             stats.generation_handover = gi;
             return false;

@@ -34,6 +34,7 @@ if os.environ.get("PARSNP_FUZZ_CORE") == "emu":
 first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (24, 160)
 n_big = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 bad = []
+routes = {}
 
 
 def one(seed, big):
@@ -48,7 +49,17 @@ def one(seed, big):
             kw["threads"] = 3
         rp, qs = F.write(str(base / "in"), ref, gs, contigs, seed)
         a = F.run(F.REFBIN, rp, qs, str(base / "ref"), kw)
+        os.environ["PARSNP_TIMING"] = str(base / "timing.json")      # which route the run took (the summary line at the end)
         b = F.run(core, rp, qs, str(base / "mine"), kw)
+        os.environ.pop("PARSNP_TIMING", None)
+        try:
+            import json
+            tj = json.load(open(base / "timing.json"))
+            routes[(tj.get("resident"), tj.get("resident_why") or "")] = routes.get((tj.get("resident"), tj.get("resident_why") or ""), 0) + 1
+            routes["outside_writes"] = routes.get("outside_writes", 0) + int(tj.get("outside_writes", 0))
+            if tj.get("outside_writes", 0) and tj.get("resident"): routes["resident runs with outside writes"] = routes.get("resident runs with outside writes", 0) + 1
+        except Exception:   # noqa: BLE001
+            pass
         if a != b:
             bad.append((seed, big, kw))
             print("MISMATCH", seed, big, kw, flush=True)
@@ -62,4 +73,5 @@ print("small sets done:", last - first, "mismatches:", len(bad), flush=True)
 for seed in range(n_big):
     one(seed, True)
 print("all done:", last - first + n_big, "runs, mismatches:", bad, flush=True)
+print("routes:", routes, flush=True)
 sys.exit(1 if bad else 0)

@@ -14,7 +14,7 @@ try:
     env = dict(os.environ, OMP_WAIT_POLICY="passive", PARSNP_DEBUG_TIMERS="1")
     rc, _ = driver.run_core(CORE_BIN, rp, qs, os.path.join(d, "out"), env=env, threads=int(sys.argv[2]) if len(sys.argv) > 2 else 24, timing=os.path.join(d, "t.json"))
     tj = json.load(open(os.path.join(d, "t.json"))) if os.path.exists(os.path.join(d, "t.json")) else {}
-    print("rc", rc, {k: tj.get(k) for k in ("resident", "resident_why", "resident_retry", "device_chain", "chain_why", "anchors", "mums", "lcbs")})
+    print("rc", rc, {k: tj.get(k) for k in ("resident", "resident_why", "resident_retry", "device_chain", "outside_writes", "anchors", "mums", "lcbs", "total_s", "extend_s")})
     err = open(os.path.join(d, "out", "parsnp-aligner.err")).read().splitlines()
     for l in err:
         if l.startswith("[resident") or "route" in l:
