@@ -1289,9 +1289,9 @@ public:
         if (cap > 1) be.launch_wave("chain_fill", (int64_t)cap - 1, ChainFill{S, layout_view(d_image.p, false), P, d_ch_row2.p, n2, d_ch_head.p, hdr});
         be.launch("chain_out", (int64_t)cap, ChainOut{d_ch_row2.p, n2, d_ch_head.p, d_ch_hpos.p, d_ch_outrow.p, d_ch_outhead.p, hdr});
         be.mark(nullptr);
-        be.d2h_async(chain_host, hdr, 8 * (size_t)kChWords);
-        be.d2h_async(chain_host + 8 * (size_t)kChWords, d_ch_outrow.p, 4 * cap);
-        be.d2h_async(chain_host + 8 * (size_t)kChWords + 4 * cap, d_ch_outhead.p, cap);
+        be.d2h_async_pinned(chain_host, hdr, 8 * (size_t)kChWords);
+        be.d2h_async_pinned(chain_host + 8 * (size_t)kChWords, d_ch_outrow.p, 4 * cap);
+        be.d2h_async_pinned(chain_host + 8 * (size_t)kChWords + 4 * cap, d_ch_outhead.p, cap);
         chain_event = be.event_record();
         chain_pending = true;
         return 0;

@@ -124,6 +124,7 @@ struct HipBackend {
         if (tmp) (void)hipFree(tmp);
         if (stage_p) (void)hipHostFree(stage_p);
         if (ring) (void)hipHostFree(ring);
+        if (dring) (void)hipHostFree(dring);
         if (comm) (void)Rccl::get().CommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -231,17 +232,38 @@ struct HipBackend {
         if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "hipMemcpy H2D"); check(hipStreamSynchronize(stream), "sync");
         if (copy_log()) fprintf(stderr, "[copy] h2d       %9zu B %8.1f us\n", n, now_us() - t0);
     }
-    void d2h(void* d, const void* s, size_t n) {
-        const double t0 = copy_log() ? now_us() : 0;
-        bytes_d2h += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H"); check(hipStreamSynchronize(stream), "sync");
-        if (copy_log()) fprintf(stderr, "[copy] d2h       %9zu B %8.1f us (with the queued work before it)\n", n, now_us() - t0);
-    }
+    // Downloads.  The callers' result blocks are ordinary memory (host_alloc), and a hipMemcpyAsync into ordinary memory is not
+    // asynchronous: the runtime waits for the stream, copies into a staging block of its own and from there to the destination, one
+    // copy after the other -- the six result arrays of a search cost six round trips of ~30 us with the device idle (rocprofv3
+    // --kernel-trace, round 6: 34 copies, 0.7 ms per step).  So a download lands in a page-locked ring, queued behind the kernels
+    // like any other command, and sync() -- the one wait of a call -- moves what has arrived to where the caller wants it.
+    uint8_t* dring = nullptr; size_t dring_at = 0; static constexpr size_t kDRing = (size_t)48 << 20;
+    struct Landing { void* dst; const uint8_t* at; size_t n; };
+    std::vector<Landing> landings;
+    void land() { for (const Landing& l : landings) memcpy(l.dst, l.at, l.n); landings.clear(); dring_at = 0; }
     void d2h_async(void* d, const void* s, size_t n) {
         const double t0 = copy_log() ? now_us() : 0;
-        bytes_d2h += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H");
+        bytes_d2h += n;
+        if (!n) return;
+        const size_t need = (n + 255) & ~(size_t)255;
+        if (!dring && hipHostMalloc((void**)&dring, kDRing, hipHostMallocDefault) != hipSuccess) dring = nullptr;
+        if (dring && dring_at + need <= kDRing) {
+            check(hipMemcpyAsync(dring + dring_at, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H (ring)");
+            landings.push_back(Landing{d, dring + dring_at, n});
+            dring_at += need;
+        } else check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H");      // (too large for the ring: the runtime stages it)
         if (copy_log()) fprintf(stderr, "[copy] d2h_async %9zu B %8.1f us\n", n, now_us() - t0);
     }
-    void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+    // ... into a block that IS page-locked (the chain's result block): straight there, for a caller that waits on an event
+    void d2h_async_pinned(void* d, const void* s, size_t n) {
+        bytes_d2h += n; if (n) check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "hipMemcpy D2H (pinned)");
+    }
+    void d2h(void* d, const void* s, size_t n) {
+        const double t0 = copy_log() ? now_us() : 0;
+        d2h_async(d, s, n); sync();
+        if (copy_log()) fprintf(stderr, "[copy] d2h       %9zu B %8.1f us (with the queued work before it)\n", n, now_us() - t0);
+    }
+    void sync() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); land(); }
     // an event on the engine's stream that any host thread may wait for (the slices of a row table in flight)
     void* event_record() {
         hipEvent_t e = nullptr;

@@ -267,6 +267,9 @@ bool Aligner::resident_extend() {
         first->push_back((int64_t)list.size());
     };
     static const bool two_stages = test_hook("PARSNP_ONE_STAGE") == nullptr;      // test hook: every generation its own call
+    struct Commit { std::vector<pm_region_info> now; std::vector<int32_t> now_id; std::vector<uint8_t> ran; std::vector<int64_t> r0; std::vector<int32_t> rc; int gi; size_t second_stage_from; };
+    std::vector<Commit> commits;
+    size_t accepted_ahead = 0;      // MUMs of the generations not committed yet
     while (!gen.empty()) {
         std::vector<pm_region_info> now; std::vector<int32_t> now_id;
         std::vector<int64_t> first;
@@ -342,27 +345,35 @@ bool Aligner::resident_extend() {
         for (int64_t i = 0; i < nkids; i++) { gen.push_back(ki[i]); gen_id.push_back(kid[i]); }
         stats.t_validate += now_s() - tv;
         lap("validate");
+        // The MUM records of this generation (commit) are host work nobody on the device waits for: they are written when the last
+        // generation has queued phases C-D, beside them (until round 6 every generation committed at once -- the anchors' 80 000
+        // records with the first one, 0.2 ms with the device idle)
+        size_t more = 0;
+        for (size_t i = 0; i < now.size(); i++)
+            for (int64_t c = r0[i]; ran[i] && c < r0[i] + rc_[i]; c++) more += (info[(size_t)c].state_flags & PM_ST_ACCEPTED) != 0;
+        accepted_ahead += more;
+        commits.push_back(Commit{std::move(now), std::move(now_id), std::move(ran), std::move(r0), std::move(rc_), gi, stage_first > 0 ? (size_t)first[(size_t)stage_first] : (size_t)-1});
         if (gen.empty()) {
             // the last generation: the accepted rows of the store are the run's MUM list.  Phases C-D are queued on the device now
-            // (resident_chain() collects them) and run beside the commit below
-            size_t more = 0;
-            for (size_t i = 0; i < now.size(); i++)
-                for (int64_t c = r0[i]; ran[i] && c < r0[i] + rc_[i]; c++) more += (info[(size_t)c].state_flags & PM_ST_ACCEPTED) != 0;
-            resident_chain_begin(mums.size() + more);
+            // (resident_chain() collects them) and run beside the commits below
+            resident_chain_begin(mums.size() + accepted_ahead);
             lap("chain queued");
         }
-        resident_records();      // the anchors' records first: the recursion's MUMs follow them in the pool
+        gi += stage_first > 0 ? 2 : 1;
+    }
+    resident_records();      // the anchors' records first: the recursion's MUMs follow them in the pool
+    for (Commit& cm : commits) {
         // commit in list order (:215-254 push the MUMs of a region in candidate order)
         long processed = 0;
-        for (size_t i = 0; i < now.size(); i++) {
-            if (!ran[i]) continue;
+        for (size_t i = 0; i < cm.now.size(); i++) {
+            if (!cm.ran[i]) continue;
             processed++;
             if (const char* dump = test_hook("PARSNP_DUMP_VALIDATION"))      // test hook: what the device decided for every candidate of every region
                 if (FILE* f = fopen(dump, "a")) {
-                    fprintf(f, "region %ld+%ld (generation %d):", (long)now[i].ref_start, (long)now[i].ref_len, gi);
-                    for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) fprintf(f, " [%d len %d shift %d state %02x flags %x]", info[(size_t)c].start0, info[(size_t)c].len, info[(size_t)c].shift, info[(size_t)c].state_flags & 0xffu, info[(size_t)c].state_flags >> 8);
+                    fprintf(f, "region %ld+%ld (generation %d):", (long)cm.now[i].ref_start, (long)cm.now[i].ref_len, cm.gi);
+                    for (int64_t c = cm.r0[i]; c < cm.r0[i] + cm.rc[i]; c++) fprintf(f, " [%d len %d shift %d state %02x flags %x]", info[(size_t)c].start0, info[(size_t)c].len, info[(size_t)c].shift, info[(size_t)c].state_flags & 0xffu, info[(size_t)c].state_flags >> 8);
                     fprintf(f, "\n");
-                    for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) {
+                    for (int64_t c = cm.r0[i]; c < cm.r0[i] + cm.rc[i]; c++) {
                         std::vector<int32_t> st(n); std::vector<uint8_t> fw(n);
                         const int32_t row = (int32_t)c;
                         if (pm_store_rows(session_, &row, 0, 1, 1, st.data(), fw.data()) == PM_OK) {
@@ -373,25 +384,24 @@ bool Aligner::resident_extend() {
                     }
                     fclose(f);
                 }
-            for (int64_t c = r0[i]; c < r0[i] + rc_[i]; c++) {
+            for (int64_t c = cm.r0[i]; c < cm.r0[i] + cm.rc[i]; c++) {
                 const uint32_t st = info[(size_t)c].state_flags & 0xffu;
                 if (st & PM_ST_BUILT) next_id_++;
                 if (!(st & PM_ST_ACCEPTED)) continue;
                 Mum m;
-                m.id = next_id_ - 1; m.length = info[(size_t)c].len; m.slength = now[i].slength; m.row = (int32_t)c;
+                m.id = next_id_ - 1; m.length = info[(size_t)c].len; m.slength = cm.now[i].slength; m.row = (int32_t)c;
                 pool.push_back(m); res_.start0.push_back(info[(size_t)c].start0);
                 // (generation of the region: the second stage of a two-stage call is one later; 0 = the first pushed seed, processed before anything is sorted)
-                const int g = gi + (stage_first > 0 && i >= (size_t)first[(size_t)stage_first] ? 1 : 0);
+                const int g = cm.gi + (i >= cm.second_stage_from ? 1 : 0);
                 res_.found_key.resize(pool.size(), -1);
-                res_.found_key.back() = g <= 0 ? -1 : (int64_t)now[i].ref_start * 4096 + (g < 4095 ? g : 4095);
+                res_.found_key.back() = g <= 0 ? -1 : (int64_t)cm.now[i].ref_start * 4096 + (g < 4095 ? g : 4095);
                 mums.push_back((int)pool.size() - 1);
             }
             stats.regions_processed++; stats.cache_hits++;
         }
-        stats.generations += stage_first > 0 ? 2 : 1; stats.generation_regions += processed;
-        lap("commit");
-        gi += stage_first > 0 ? 2 : 1;
+        stats.generations += cm.second_stage_from != (size_t)-1 ? 2 : 1; stats.generation_regions += processed;
     }
+    lap("commit");
     if (!res_.chain_queued && !mums.empty()) resident_chain_begin(mums.size());      // (no seed region at all: the anchors are the list)
     if (!res_.chain_queued && gi > 0) {
         // candidates that read marks outside their region, decided again in the reference's order (a queued chain does this itself)
