@@ -270,6 +270,7 @@ StepReport CoreRun::step_once(bool resident) {
         if (say(7)) printf("        LCBs created, elapsed time: %.0lf seconds\n\n", difftime(end, start));
     }
     r.path_s = now_s() - t0;
+    if (getenv("PARSNP_DEBUG_TIMERS")) fprintf(stderr, "[step] anchors + recursion + lists %.6f s (anchor %.6f, extend %.6f, lcb %.6f; engine calls %.6f)\n", r.path_s, a.stats.anchor_s, a.stats.extend_s, a.stats.lcb_s, a.stats.finder_s);
     const Stats& s = a.stats;
     r.anchor_s = s.anchor_s; r.extend_s = s.extend_s; r.filter_s = s.filter_s; r.lcb_s = s.lcb_s; r.finder_s = s.finder_s;
     r.alg_bytes = s.alg_bytes; r.alg_bytes_kernel = s.alg_bytes_kernel; r.alg_bytes_query = s.alg_bytes_query; r.finder_calls = s.finder_calls; r.finder_regions = s.finder_regions; r.regions_processed = s.regions_processed;

@@ -55,7 +55,7 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
     if (reqs.size() != 1 || !reqs[0].plain) { res_.why = "chunked reference"; return false; }      // (p): the p-loop is the host route's
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double tl = now_s();
-    auto lap = [&](const char* what) { if (dbg) { const double t = now_s(); fprintf(stderr, "[resident anchors] %-14s %.4f s\n", what, t - tl); tl = t; } };
+    auto lap = [&](const char* what) { if (dbg) { const double t = now_s(); fprintf(stderr, "[resident anchors] %-14s %.6f s\n", what, t - tl); tl = t; } };
     resident_try_ = true;
     std::vector<Raw> raw;
     run_batch(reqs, &raw, true);
@@ -150,6 +150,7 @@ void Aligner::resident_records() {
     res_.records_done = true;
     const size_t nacc = res_.anchor_accepted, count = res_.anchor_info.size();
     pool.resize(nacc); res_.start0.resize(nacc);
+    res_.of_row.assign(count, -1);      // store row -> MUM record (resident_chain reads the device's list through it)
     size_t at = 0;
     long dirty = 0, tangled = 0;
     for (size_t c = 0; c < count; c++) {
@@ -161,6 +162,7 @@ void Aligner::resident_records() {
         m.id = next_id_ - 1; m.length = r.len; m.slength = res_.anchor_slength; m.row = (int32_t)c;
         m.dirty = (st & PM_ST_FLAGGED) != 0; m.touched = r.len != res_.anchor_lon[c];
         pool[at] = m; res_.start0[at] = r.start0;
+        res_.of_row[c] = (int32_t)at;
         at++;
         dirty += m.dirty; tangled += (st & PM_ST_TANGLED) != 0;
     }
@@ -207,7 +209,7 @@ bool Aligner::resident_extend() {
     };
     int gi = 0;
     double tl = now_s();
-    auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[resident generation %d] %-12s %.4f s\n", gi, what, t - tl); tl = t; } };
+    auto lap = [&](const char* what) { if (dbg) { double t = now_s(); fprintf(stderr, "[resident generation %d] %-12s %.6f s\n", gi, what, t - tl); tl = t; } };
     // The work list of a generation (:291-306), in two steps around the search of its new regions.
     // sort_unique: sorted by reference start, a region equal to another one with its reference start dropped.  Regions that share a
     // reference start and DIFFER stay, next to each other -- inside an inverted block of some genome the right neighbour of one anchor
@@ -278,6 +280,7 @@ bool Aligner::resident_extend() {
         std::vector<pm_region_info> rest; std::vector<int32_t> rest_id;
         if (gi == 0) {                  // the first pushed seed, before anything is sorted (:194-195 precede :291-292); every seed's search in ONE call
             search(gen, gen_id);
+            lap("search call");
             now.push_back(gen.front()); now_id.push_back(gen_id.front());
             first = {0};
             gen.erase(gen.begin()); gen_id.erase(gen_id.begin());
@@ -299,7 +302,7 @@ bool Aligner::resident_extend() {
             cluster(now, 0, &first);
             gen.clear(); gen_id.clear();
         }
-        lap("search");
+        lap(gi == 0 ? "lists" : "search");
         std::vector<int64_t> r0(now.size()); std::vector<int32_t> rc_(now.size());
         for (size_t i = 0; i < now.size(); i++) { r0[i] = row0[(size_t)now_id[i]]; rc_[i] = cnt[(size_t)now_id[i]]; }
         uint32_t trouble = 0; int64_t nkids = 0;
@@ -314,7 +317,9 @@ bool Aligner::resident_extend() {
         int rc = pm_store_validate(session_, now_id.data(), r0.data(), rc_.data(), (int64_t)now.size(), first.data(), ncl, (int32_t)prm.q, &trouble, &nkids,
                                    hi > lo ? lo : 0, hi > lo ? hi - lo : 0, hi > lo ? info.data() + lo : nullptr, stage_first, &second_ran, (int32_t)gi, done.data());
         if (rc != PM_OK) engine_error("validation of a generation on the device failed", rc);
+        lap("validate call");
         collect_engine_timing();
+        lap("timing");
         if (trouble) {
             res_.failed = true;
             res_.why = (trouble & 2) ? "a reverse-strand member was accepted outside its region where the reference's order shows"
@@ -391,6 +396,8 @@ bool Aligner::resident_extend() {
                 Mum m;
                 m.id = next_id_ - 1; m.length = info[(size_t)c].len; m.slength = cm.now[i].slength; m.row = (int32_t)c;
                 pool.push_back(m); res_.start0.push_back(info[(size_t)c].start0);
+                if (res_.of_row.size() <= (size_t)c) res_.of_row.resize((size_t)c + 1 + (size_t)c / 8, -1);
+                res_.of_row[(size_t)c] = (int32_t)pool.size() - 1;
                 // (generation of the region: the second stage of a two-stage call is one later; 0 = the first pushed seed, processed before anything is sorted)
                 const int g = cm.gi + (i >= cm.second_stage_from ? 1 : 0);
                 res_.found_key.resize(pool.size(), -1);
@@ -437,6 +444,8 @@ bool Aligner::resident_chain() {
     pm_chain_info ci; const int32_t* rows = nullptr; const uint8_t* heads = nullptr;
     const int rc = pm_store_chain_end(session_, &ci, &rows, &heads);
     if (rc != PM_OK) engine_error("phases C-D on the device failed", rc);
+    const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
+    if (dbg) fprintf(stderr, "[resident chain] wait         %.6f s\n", now_s() - t0);
     collect_engine_timing();
     if (ci.n_in != (int64_t)mums.size()) fatal("the device's MUM list and the host's differ");
     if (ci.trouble & 4) { res_.failed = true; res_.why = kOrderWhy; return false; }
@@ -456,29 +465,35 @@ bool Aligner::resident_chain() {
         return false;
     }
     if (ci.trouble & 2) fatal("inter-cluster region bookkeeping would overrun in the reference");
-    // store row -> MUM record
-    int32_t top = 0;
-    for (const Mum& m : pool) if (m.row > top) top = m.row;
-    std::vector<int32_t> of((size_t)top + 1, -1);
-    for (size_t i = 0; i < pool.size(); i++) of[(size_t)pool[i].row] = (int32_t)i;
+    // store row -> MUM record (res_.of_row: written with the records, beside phases C-D on the device)
+    const std::vector<int32_t>& of = res_.of_row;
+    const int64_t top = (int64_t)of.size() - 1;
     mums.resize((size_t)ci.n_mums);
     lcbs.clear();
     lcbs.reserve((size_t)(ci.n_fillers + ci.n_lcbs));
     for (int64_t f = 0; f < ci.n_fillers; f++) { Lcb c; c.type = 0; c.length = 2; lcbs.push_back(std::move(c)); }      // (their rows: nothing reads them)
     if (ci.n_mums > ci.n_in || (ci.n_mums > 0 && !heads[0])) fatal("the device's MUM list does not begin with an LCB head, or is longer than the list it came from");
-    for (int64_t x = 0; x < ci.n_mums; x++) {
-        if (rows[x] < 0 || rows[x] > top || of[(size_t)rows[x]] < 0) fatal("the device's MUM list names a row the host does not hold");
-        const int idx = of[(size_t)rows[x]];
-        mums[(size_t)x] = idx;
-        if (heads[x]) { Lcb c; c.type = 1; c.length = 0; c.start.assign(1, key0(idx)); lcbs.push_back(std::move(c)); }
-        Lcb& c = lcbs.back();
-        c.mums.push_back(idx); c.length += pool[(size_t)idx].length;
-        c.end.assign(1, key0(idx) + pool[(size_t)idx].length);
+    for (int64_t x = 0; x < ci.n_mums;) {      // LCB by LCB: from a head to the MUM before the next one
+        int64_t y = x + 1;
+        while (y < ci.n_mums && !heads[y]) y++;
+        Lcb c; c.type = 1; c.length = 0;
+        c.mums.resize((size_t)(y - x));
+        for (int64_t z = x; z < y; z++) {
+            if (rows[z] < 0 || rows[z] > top || of[(size_t)rows[z]] < 0) fatal("the device's MUM list names a row the host does not hold");
+            const int idx = of[(size_t)rows[z]];
+            mums[(size_t)z] = idx; c.mums[(size_t)(z - x)] = idx;
+            c.length += pool[(size_t)idx].length;
+        }
+        c.start.assign(1, key0(c.mums.front()));
+        c.end.assign(1, key0(c.mums.back()) + pool[(size_t)c.mums.back()].length);
+        lcbs.push_back(std::move(c));
+        x = y;
     }
     if ((int64_t)lcbs.size() != ci.n_fillers + ci.n_lcbs) fatal("the device's LCB count and its head flags differ");
     filtered += ci.mums_dissolved; filtered_lcbs += ci.lcbs_dissolved;
     unique_order = true;
     stats.lcb_s += now_s() - t0;
+    if (dbg) fprintf(stderr, "[resident chain] with lists   %.6f s\n", now_s() - t0);
     stats.device_chain = 1;
     return true;
 }

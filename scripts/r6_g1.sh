@@ -1,2 +1,2 @@
-bash scripts/r6_step.sh tests bench inv
+bash scripts/r6_step.sh bench rearr
 timeout 600 python -m pytest tests/test_gpu_big.py -m gpu -x -q -k "baseline_size" 2>&1 | tail -3
