@@ -146,6 +146,9 @@ int64_t pm_result_table_id(const pm_result* r);
  *   "atomic_marks" != 0: pm_store_settle marks the layout with atomic ORs even where the list's order allows plain stores (tests)
  *   "group_small"  0: the events of a recursion batch's small regions are found pair by pair and sorted with the others, instead of
  *                  once per distinct query piece (default 1; both give the same events, tests compare the two)
+ *   "bucket_sort"  0: the events of a search are gathered and radix-sorted by (pair, l, strand) and the readers' table of events per
+ *                  256-position block comes from a pass over the sorted keys (rounds 1-5), instead of a counting sort by (pair, block)
+ *                  buckets whose scanned counts ARE that table (default 1; the same events in the same order up to equal keys)
  *   "master_seg"   0: Master.EP by the round-4 kernel (every lane tests every staged event: MasterEP) instead of from the genomes'
  *                  segments (MasterEPSeg; default 1; the same values, tests compare the two)
  *   "stage_gate"   != 0: the second stage of a two-stage pm_store_validate is never run (tests: the caller forms it again)

@@ -404,6 +404,7 @@ public:
         uint64_t ngrp = 0;
         if (grouping) { ensure(d_gflag, (size_t)nreg); ensure(d_glo, (size_t)npairs); }
         int64_t nunits_live = nunits;
+        uint64_t worst_slice = 0;      // events of the fullest sub-buffer
         for (bool again = false;; again = true) {
             ensure(d_units, (size_t)std::max<int64_t>(nunits, 1));
             be.launch("fill_units", nunits, FillUnits{P, d_starts.p, d_lens.p, ngen, d_uoff.p, d_ucount.p, npairs, d_units.p});
@@ -453,6 +454,7 @@ public:
             }
             errbits = (uint32_t)counts[(size_t)kSlices * kSliceStride];
             ngrp = grouping ? counts[kGrpSlot] : 0;
+            worst_slice = worst;
             if (worst <= slice_cap && qworst <= queue_cap && ngrp <= grp_cap) break;
             if (ngrp > grp_cap) grp_cap = (size_t)(ngrp + ngrp / 8 + 64);
             if (worst > slice_cap) slice_cap = (size_t)(worst + worst / 8 + 64);
@@ -483,14 +485,31 @@ public:
         ensure_keep(d_evkey3, std::max<size_t>(ngrp + nev, 1), (size_t)ngrp); ensure_keep(d_evval3, std::max<size_t>(ngrp + nev, 1), (size_t)ngrp);
         const int keybits = bits_for((uint64_t)npairs) + lbits + 1;
         uint64_t *skey = d_evkey3.p, *sval = d_evval3.p;
-        if (nev > 0) {
+        // the events in order: by buckets (pair, 256-position block) whose scanned counts are the readers' coarse table as well, or
+        // (tune bucket_sort = 0: rounds 1-5) gathered, radix-sorted, and the table from a pass over the sorted keys
+        const int64_t nbuckets = (int64_t)nq * nchunks;
+        const bool by_buckets = bucket_sort && nev > 0 && nbuckets < ((int64_t)1 << 31);
+        ensure(d_lo, (size_t)npairs + 1);
+        if (by_buckets) {
+            ensure(d_bcount, (size_t)nbuckets + 1); ensure(d_bbegin, (size_t)nbuckets + 1); ensure(d_pbase, (size_t)npairs);
+            int shift = 6;
+            while (((uint64_t)1 << shift) < worst_slice) shift++;      // (the fullest slice's count: known since the wait above)
+            be.memset(d_bcount.p, 0, 8 * ((size_t)nbuckets + 1));
+            be.launch("pair_bucket_base", npairs, PairBucketBase{nq, d_cbase.p, d_pbase.p});
+            be.launch("event_bucket_count", (int64_t)kSlices << shift, EventBucketCount{d_evkey.p, d_counter.p, (uint64_t)slice_cap, shift, lbits, d_pbase.p, d_bcount.p});
+            be.exclusive_scan(d_bcount.p, d_bbegin.p, (size_t)nbuckets + 1);
+            be.launch("event_place", (int64_t)kSlices << shift,
+                      EventPlace{d_evkey.p, d_evval.p, d_counter.p, (uint64_t)slice_cap, shift, lbits, d_pbase.p, d_bbegin.p, d_bcount.p, d_evkey3.p + ngrp, d_evval3.p + ngrp});
+            be.launch("event_order", nbuckets, EventOrder{d_bbegin.p, nbuckets, d_evkey3.p + ngrp, d_evval3.p + ngrp});
+        } else if (nev > 0) {
             be.launch("compact_events", (int64_t)nev, CompactEvents{d_evkey.p, d_evval.p, d_sliceoff.p, (uint64_t)slice_cap, d_evkey2.p, d_evval2.p});
             be.sort_pairs(d_evkey2.p, d_evkey3.p + ngrp, d_evval2.p, d_evval3.p + ngrp, (size_t)nev, keybits);
         }
         be.mark("scan");
-        ensure(d_lo, (size_t)npairs + 1);
+        const int64_t nev_sorted = (int64_t)nev;
         nev += ngrp;
-        be.launch("pair_bounds", npairs, PairBounds{skey, (int64_t)nev, lbits, npairs, d_lo.p, (int64_t)ngrp});
+        if (by_buckets) be.launch("coarse_from_buckets", centries, CoarseFromBuckets{d_bbegin.p, d_cbase.p, nreg, nq, (int64_t)ngrp, d_coarse.p, d_lo.p, npairs, nev_sorted});
+        else be.launch("pair_bounds", npairs, PairBounds{skey, (int64_t)nev, lbits, npairs, d_lo.p, (int64_t)ngrp});
         if (grouping) be.launch("grouped_bounds", npairs, GroupedBounds{d_gflag.p, d_glo.p, nq, d_lo.p});
         // (the grouped events came with their states: the scan runs over the sorted part, its event numbers relative to it)
         ensure_keep(d_state, std::max<size_t>(nev, 1), (size_t)ngrp); ensure_keep(d_emax, std::max<size_t>(nev, 1), (size_t)ngrp);
@@ -538,7 +557,9 @@ public:
 
         // -- Master.EP, candidates
         be.mark("master_ep");
-        be.launch("coarse_fill", (int64_t)nev, CoarseFill{skey, (int64_t)nev, lbits, d_lo.p, d_R.p, d_cbase.p, nq, d_coarse.p});
+        // (by buckets: the table came with the order -- but for the grouped regions' pairs, whose events never were in a bucket)
+        if (!by_buckets) be.launch("coarse_fill", (int64_t)nev, CoarseFill{skey, (int64_t)nev, lbits, d_lo.p, d_R.p, d_cbase.p, nq, d_coarse.p});
+        else if (ngrp > 0) be.launch("coarse_fill", (int64_t)ngrp, CoarseFill{skey, (int64_t)ngrp, lbits, d_lo.p, d_R.p, d_cbase.p, nq, d_coarse.p});
         if (master_seg) be.launch_wave("master_ep_seg", xcd_grid(nchunks), MasterEPSeg{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, grouping ? d_gflag.p : nullptr, nchunks});
         else be.launch_wave("master_ep", xcd_grid(nchunks), MasterEP{d_R.p, nreg, ngen, skey, d_lo.p, d_emax.p, lbits, d_epm.p, d_cbase.p, d_coarse.p, g_first, g_last, grouping ? d_gflag.p : nullptr, nchunks});
         int32_t verdict = 0;
@@ -1374,6 +1395,7 @@ public:
     bool group_small = true;      // the events of a recursion batch's small regions once per distinct piece (GroupedPairEvents)
     int64_t last_grouped = 0;
     bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
+    bool bucket_sort = true;              // the events put in order by (pair, 256-position block) buckets (EventBucketCount ... CoarseFromBuckets); false: gathered and radix-sorted
     bool master_seg = true;               // Master.EP from the genomes' segments (MasterEPSeg); false: every lane against every staged event (MasterEP)
     bool force_gate = false;              // (tests) the second stage of a two-stage store_validate never runs
     bool force_chain_tie = false;         // (tests) store_chain_begin reports two MUMs with one reference start
@@ -1391,6 +1413,7 @@ public:
         if (key == "fast_tail") { fast_tail = value != 0; return true; }
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
         if (key == "master_seg") { master_seg = value != 0; return true; }
+        if (key == "bucket_sort") { bucket_sort = value != 0; return true; }
         if (key == "stage_gate") { force_gate = value != 0; return true; }
         if (key == "chain_tie") { force_chain_tie = value != 0; return true; }
         if (key == "cluster_unsure") { force_unsure = value != 0; return true; }
@@ -1464,6 +1487,7 @@ private:
     Buf<int64_t> d_lo, d_cov; Buf<EventAtK> d_state; Buf<PairState> d_wsummary; Buf<int32_t> d_emax;
     Buf<uint64_t> d_cand; Buf<GenomeAtK> d_at; Buf<uint8_t> d_ok; Buf<int32_t> d_ok_k, d_ok_lon, d_osp; Buf<uint8_t> d_ofwd;
     Buf<uint64_t> d_wmask; Buf<int64_t> d_wcount, d_woff;
+    Buf<int64_t> d_bcount, d_bbegin, d_pbase;      // the event buckets: counts, where each begins, every pair's first
     Buf<int64_t> d_okcnt, d_okpos, d_cbase; Buf<int32_t> d_coarse; Buf<int32_t> d_creg, d_ck, d_clon, d_csp; Buf<uint8_t> d_cfwd;
     Buf<uint32_t> d_cflags, d_dirty; Buf<int32_t> d_bmax, d_bmin;
     Buf<GenomeAtK> d_xsend, d_xrecv; Buf<uint8_t> d_hsend, d_hrecv;

@@ -1278,6 +1278,129 @@ struct CompactEvents {
     }
 };
 
+// ------------------------------------------------------------------------------------------ the events in order, without a sort
+// The readers of the events want a pair's events contiguous and in reference order, and a table of how many of them lie before
+// every 256-position block (coarse[]).  A radix sort of 64-bit keys delivered the first (four passes over 16 bytes per event,
+// 0.55 ms for the anchor call's 7.7 M events at 200 x 5 Mb) and a pass over the sorted keys the second.  But the table IS a
+// counting sort's histogram: a pair's events of one block -- two on average, bounded by what 256 reference positions can start --
+// form a BUCKET, the buckets numbered pair by pair, block by block.  So (round 6):
+//   EventBucketCount  one atomic add per event on its bucket's counter (the counters of a unit's events are neighbours);
+//   exclusive scan    over the 3.9 M counters: where every bucket begins in the final array;
+//   EventPlace        every event to its bucket (a second atomic gives it a place there), 16 bytes written once;
+//   EventOrder        a thread per bucket puts its few events in key order (insertion; a long bucket -- a degenerate repeat -- by
+//                     Shell's gaps);
+//   CoarseFromBuckets the block-major table of the readers and the pairs' bounds, from the scanned counters.
+// Bucket numbering: region r has blocks_r = cbase[r + 1] - cbase[r] - 1 blocks; its pairs' buckets begin at nq * (cbase[r] - r),
+// genome g's at + g * blocks_r.
+// tid = pair: its first bucket (the divisions once per pair instead of twice per event)
+struct PairBucketBase {
+    int32_t nq; const int64_t* cbase; int64_t* pbase;
+    PM_HD void operator()(int64_t pair) const {
+        const int64_t r = pair / nq; const int64_t g = pair % nq;
+        pbase[pair] = (int64_t)nq * (cbase[r] - r) + g * (cbase[r + 1] - cbase[r] - 1);
+    }
+};
+PM_HD int64_t bucket_of_key(uint64_t k, int lbits, const int64_t* pbase) {
+    return pbase[k >> (lbits + 1)] + (int64_t)(((k >> 1) & ((1ull << lbits) - 1)) >> 8);
+}
+// tid = (slice, index in the slice): slice = tid >> shift, over 2^shift >= the fullest slice's count (>= 64: a wavefront reads one
+// slice).  Neighbouring entries of a slice are the events of one wavefront of the search in lane order -- runs of one bucket -- so
+// the first lane of a run adds for all of it (a third of the atomics; the host emulation adds one by one).
+struct EventBucketCount {
+    const uint64_t* key_in; const uint64_t* counters; uint64_t slice_cap; int shift; int lbits; const int64_t* pbase; int64_t* count;
+    PM_HD void operator()(int64_t tid) const {
+        const uint64_t sl = (uint64_t)tid >> shift, idx = (uint64_t)tid & ((1ull << shift) - 1);
+        const bool active = idx < counters[sl * kSliceStride];
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int lane = (int)__lane_id();
+        const int64_t b = active ? bucket_of_key(key_in[sl * slice_cap + idx], lbits, pbase) : -1;
+        const int64_t prev = ((int64_t)__shfl_up((int)(b >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)b, 1, 64);
+        const bool head = active && (lane == 0 || prev != b);
+        const unsigned long long heads = __ballot(head), act = __ballot(active);
+        if (!head) return;
+        const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+        const int upto = above ? __ffsll((long long)above) - 1 : __popcll(act);
+        atomic_add64((uint64_t*)&count[b], (uint64_t)(upto - lane));
+#else
+        if (active) atomic_add64((uint64_t*)&count[bucket_of_key(key_in[sl * slice_cap + idx], lbits, pbase)], 1);
+#endif
+    }
+};
+struct EventPlace {
+    const uint64_t* key_in; const uint64_t* val_in; const uint64_t* counters; uint64_t slice_cap; int shift; int lbits; const int64_t* pbase;
+    const int64_t* begin; int64_t* count; uint64_t* key_out; uint64_t* val_out;      // count: what EventBucketCount left (taken down to 0 here)
+    PM_HD void operator()(int64_t tid) const {
+        const uint64_t sl = (uint64_t)tid >> shift, idx = (uint64_t)tid & ((1ull << shift) - 1);
+        const bool active = idx < counters[sl * kSliceStride];
+        const uint64_t src = sl * slice_cap + idx;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int lane = (int)__lane_id();
+        const uint64_t k = active ? key_in[src] : 0;
+        const int64_t b = active ? bucket_of_key(k, lbits, pbase) : -1;
+        const int64_t prev = ((int64_t)__shfl_up((int)(b >> 32), 1, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)b, 1, 64);
+        const bool head = active && (lane == 0 || prev != b);
+        const unsigned long long heads = __ballot(head), act = __ballot(active);
+        int64_t first = 0;      // the run's first place (the places of a bucket are handed out from its end)
+        if (head) {
+            const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+            const int upto = above ? __ffsll((long long)above) - 1 : __popcll(act);
+            const int64_t run = upto - lane;
+            first = begin[b] + (int64_t)atomic_add64((uint64_t*)&count[b], (uint64_t)(-run)) - run;
+        }
+        const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1));      // the heads at or before this lane
+        const int mine = below ? 63 - __clzll((long long)below) : 0;
+        first = ((int64_t)__shfl((int)(first >> 32), mine, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)first, mine, 64);
+        if (!active) return;
+        const int64_t at = first + (lane - mine);
+        key_out[at] = k; val_out[at] = val_in[src];
+#else
+        if (!active) return;
+        const uint64_t k = key_in[src];
+        const int64_t b = bucket_of_key(k, lbits, pbase);
+        const int64_t at = begin[b] + (int64_t)atomic_add64((uint64_t*)&count[b], ~0ull) - 1;      // (the last free place of the bucket)
+        key_out[at] = k; val_out[at] = val_in[src];
+#endif
+    }
+};
+// tid = bucket
+struct EventOrder {
+    const int64_t* begin; int64_t nbuckets; uint64_t* key; uint64_t* val;
+    PM_HD void operator()(int64_t b) const {
+        const int64_t a = begin[b], n = begin[b + 1] - a;
+        if (n < 2) return;
+        uint64_t* k = key + a; uint64_t* v = val + a;
+        if (n == 2) {
+            const uint64_t k0 = k[0], k1 = k[1];
+            if (k1 < k0) { const uint64_t v0 = v[0], v1 = v[1]; k[0] = k1; k[1] = k0; v[0] = v1; v[1] = v0; }
+            return;
+        }
+        int64_t gap = 1;
+        while (gap < n / 3) gap = 3 * gap + 1;      // (n <= 4: plain insertion)
+        for (; gap >= 1; gap /= 3)
+            for (int64_t i = gap; i < n; i++) {
+                const uint64_t kk = k[i], vv = v[i];
+                int64_t j = i;
+                while (j >= gap && k[j - gap] > kk) { k[j] = k[j - gap]; v[j] = v[j - gap]; j -= gap; }
+                k[j] = kk; v[j] = vv;
+            }
+    }
+};
+// tid = entry of the block-major table: (row of the batch, genome)
+struct CoarseFromBuckets {
+    const int64_t* begin; const int64_t* cbase; int64_t nregions; int32_t nq; int64_t base; int32_t* coarse; int64_t* lo; int64_t npairs; int64_t total;
+    PM_HD void operator()(int64_t tid) const {
+        const int64_t row = tid / nq; const int64_t g = tid % nq;
+        int64_t a = 0, z = nregions;
+        while (z - a > 1) { const int64_t mid = (a + z) >> 1; if (cbase[mid] <= row) a = mid; else z = mid; }
+        const int64_t r = a, b = row - cbase[r], blocks = cbase[r + 1] - cbase[r] - 1;
+        const int64_t first = (int64_t)nq * (cbase[r] - r) + g * blocks;
+        const int64_t f = begin[first];
+        coarse[tid] = (int32_t)(begin[first + b] - f);      // (row `blocks`: the next pair's first bucket = the pair's count)
+        if (b == 0) lo[r * nq + g] = base + f;
+        if (tid == 0) lo[npairs] = base + total;
+    }
+};
+
 // ------------------------------------------------------------------------------------------ per-pair scan
 // After sorting by (pair, l, strand): first event of every pair
 struct PairBounds {

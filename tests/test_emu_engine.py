@@ -62,7 +62,35 @@ def test_master_ep_both_kernels(libs):
     assert total > 200
 
 
-def batch_case(rng, E, O, n_regions=40, glen=3000, nq=4, big_minsize=False):
+def test_event_order_both_ways(libs):
+    """the events put in order by buckets (EventBucketCount ... CoarseFromBuckets, shipped: every other test here runs it) and by
+    the gather + radix sort of rounds 1-5 (tune bucket_sort = 0): the same candidates as the restatement -- whole genomes with
+    repeats (long buckets: Shell's gaps), regions of several 256-position blocks, batches with grouped small regions beside them"""
+    E, O = libs
+    rng = np.random.default_rng(77)
+    total = 0
+    for it in range(40):
+        if it % 8 == 0:
+            unit = random_seq(rng, 40)
+            ref = random_seq(rng, 600) + unit * 12 + random_seq(rng, 500)      # a tandem repeat: many events of one block
+            qs = [mutate(rng, ref, sub=0.02, indel=0.003) for _ in range(6)]
+        else:
+            ref, qs = adversarial_case(rng, 10, 900, int(rng.integers(1, 5)))
+        minsize = int(rng.integers(4, 14))
+        want = oracles.restatement_multi_mum(O, [ref] + qs, minsize, 1)
+        for how in (1, 0):
+            with Session(E, [ref] + qs) as s:
+                s.tune("bucket_sort", how)
+                got = s.whole(minsize)
+            assert same(want, got), (it, how, minsize)
+        total += len(want[0])
+    assert total > 200
+    for how in (1, 0):      # batches: regions above 128 bases (sorted part) beside small ones (grouped part)
+        rng2 = np.random.default_rng(19)
+        assert sum(batch_case(rng2, E, O, tune=("bucket_sort", how)) for _ in range(4)) > 30
+
+
+def batch_case(rng, E, O, n_regions=40, glen=3000, nq=4, big_minsize=False, tune=None):
     ref = random_seq(rng, glen)
     qs = []
     for g in range(nq):
@@ -85,6 +113,8 @@ def batch_case(rng, E, O, n_regions=40, glen=3000, nq=4, big_minsize=False):
             starts[r, g] = st; lens[r, g] = ln
         mins[r] = int(rng.integers(14, 30)) if big_minsize else int(rng.integers(3, 14))
     with Session(E, seqs) as s:
+        if tune:
+            s.tune(*tune)
         got = s.multi_mum_batch(starts, lens, mins)
     n = 0
     for r in range(n_regions):

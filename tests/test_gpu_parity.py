@@ -76,6 +76,20 @@ def test_master_ep_both_kernels(libs):
     assert len(got[0][0]) > 1000 and T.same(got[0], got[1])
 
 
+def test_event_order_both_ways(libs):
+    """the events put in order by (pair, block) buckets (shipped) and by the gather + radix sort of rounds 1-5 (tune bucket_sort = 0)
+    on the device: the emulation's cases, and both on a 200 kb population (thousands of candidates, 780 blocks per pair)"""
+    H, O = libs
+    T.test_event_order_both_ways((H, O))
+    ref, gs = synth.make("pop6x200k")
+    got = []
+    for how in (1, 0):
+        with Session(H, [ref] + gs) as s:
+            s.tune("bucket_sort", how)
+            got.append(s.whole(19))
+    assert len(got[0][0]) > 1000 and T.same(got[0], got[1])
+
+
 def test_batched_regions(libs):
     H, O = libs
     rng = np.random.default_rng(17)
