@@ -533,11 +533,13 @@ def main():
             # the phase on the engine's stream; reproducible from profiles/<round>/kernel_stats.csv (the kernels of a phase are named)
             ev, npos, ncand, nacc = totals.get("events", 0.0), totals.get("n_positions", 0.0), totals.get("n_candidates", 0.0), totals.get("n_accepted", 0.0)
             ngen = G + 1
+            buckets = npos / 256.0 * G      # (pair, 256-position block) buckets of a step's searches
             models = {
                 "seed_extend": ("SeedExtend + SeedRest + GroupedPairEvents + SmallPairEvents", alg_step, "(m + n)/2 per (region, query genome) + 64 B per sampled K-mer + 16 B per event"),
-                "sort": ("SliceOffsets + CompactEvents + rocPRIM radix sort (onesweep)", 64.0 * ev, "gather 32 B + one read and one write of the 16-byte record per event (a radix sort of 32-bit keys makes 4 such passes)"),
-                "scan": ("PairBounds + WaveSummary + WaveScan", 60.0 * ev, "16 B read twice (summary pass, scan pass) + 28 B of resolved state written per event"),
-                "master_ep": ("CoarseFill + MasterEP", 12.0 * ev + 4.0 * npos, "12 B per event + 4 B per reference position"),
+                "sort": ("EventBucketCount + exclusive scan + EventPlace + EventOrder (the events in order by (pair, 256-position block) buckets; tune bucket_sort = 0: CompactEvents + rocPRIM radix sort)",
+                         56.0 * ev + 24.0 * buckets, "per event the key read for the count (8 B), the record read and written once (32 B) and read again by its bucket's thread (16 B); per bucket its counter written, scanned and read (24 B)"),
+                "scan": ("CoarseFromBuckets + WaveSummary + WaveScan", 60.0 * ev + 12.0 * buckets, "16 B read twice (summary pass, scan pass) + 28 B of resolved state written per event; 8 B in, 4 B out per bucket for the readers' table"),
+                "master_ep": ("MasterEPSeg (+ CoarseFill over the grouped events)", 12.0 * ev + 4.0 * npos, "12 B per event + 4 B per reference position"),
                 "fold": ("FoldCandidates", 69.0 * ncand * G, "per (candidate, query genome): 28 B running state + 2 x (16 B winner + 4 B repeat length) in, 5 B out"),
                 "compact": ("CompactCandidates + Dirty* + store append", (5.0 * ncand * G) + 3 * 5.0 * nacc * ngen, "5 B in per (candidate, genome); 5 B per (accepted row, genome) out, once more read by the overlap flags and once copied into the MUM store"),
                 "settle": ("SettleClean + StoreMark + Collide* + SettleFlagged / Tangled", 20.0 * reports[-1]["anchors"] * ngen + 3 * (n_ref + 1) * ngen / 8.0, "4 B row entry + two 8-byte words per (anchor, genome) + three images of 1 bit per base cleared"),

@@ -37,8 +37,8 @@ def short(name):
 # phase are the sums over these (traffic_phases.json); a rocPRIM kernel belongs to the phase that calls the primitive most
 PHASES = {
     "seed_extend": ["SeedExtend", "SeedRest", "GroupedPairEvents", "SmallPairEvents"],
-    "sort": ["SliceOffsets", "CompactEvents", "EventBucket", "EventPlace", "EventOrder", "rocprim_radix_sort_onesweep", "rocprim_radix_sort_block_sort", "rocprim_merge_sort_block_merge", "rocprim_merge_sort_block_sort"],
-    "scan": ["PairBounds", "GroupedBounds", "WaveSummary", "WaveScan"],
+    "sort": ["SliceOffsets", "CompactEvents", "PairBucketBase", "EventBucketCount", "EventPlace", "EventOrder", "rocprim_radix_sort_onesweep", "rocprim_radix_sort_block_sort", "rocprim_merge_sort_block_merge", "rocprim_merge_sort_block_sort"],
+    "scan": ["PairBounds", "GroupedBounds", "CoarseFromBuckets", "WaveSummary", "WaveScan"],
     "master_ep": ["CoarseFill", "MasterEPSeg", "MasterEP"],
     "fold": ["FoldCandidates", "CandMark", "CandWrite"],
     "compact": ["OkCount", "CompactCandidates", "CompactSp", "DirtyExtent", "DirtyPrefix", "DirtyMark", "DirtyMerge"],
@@ -47,7 +47,7 @@ PHASES = {
     "index": ["IndexInsert"],
     "repeat": ["RunLength", "RepeatLength"],
     "seeds": ["ChainFlag", "AnchorList", "SeedCount", "SeedPlace", "SeedWalk"],
-    "validate": ["ClustersDisjoint", "ClusterExtents", "ClusterInvolved", "ClusterDefer", "ClusterValidate", "StageGate"],
+    "validate": ["ClustersDisjoint", "ClusterExtents", "ClusterInvolved", "ClusterDefer", "ClusterValidate", "OutsideWriteCheck", "StageGate"],
     "chain": ["ForeignBound", "ForeignScan", "ForeignDecideHits", "ChainKeys", "ChainJudge", "ChainJudgeReverse", "ChainHeads", "ChainLcbSum", "ChainDissolve", "ChainUnmark", "ChainCompact", "ChainFill", "ChainOut"],
 }
 

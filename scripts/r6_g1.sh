@@ -1,3 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "event_order or test_events or random_regions or batched" 2>&1 | tail -2
-bash scripts/r6_step.sh bench
-PROF_WL=bact200 bash scripts/r6_step.sh prof 2>&1 | grep -E "Event|Coarse|PairBucket|rocprim|config" | head
+timeout 2000 python -m pytest tests/test_gpu_big.py -m gpu -x -q -k "config5_full" 2>&1 | tail -5

@@ -85,7 +85,7 @@ def config4_flow(core_bin, d, population_kw, part_size, n_parts, threads, golden
     return res
 
 
-def config5_flow(core_bin, d, workload, override, threads, ranks, min_lcbs=20, min_reverse=10, sharded_env=None):
+def config5_flow(core_bin, d, workload, override, threads, ranks, min_lcbs=20, min_reverse=10, sharded_env=None, golden=None):
     """`workload` (population model + rearrangements) --no-partition through `core_bin`: XMFA self-consistency (one row per
     genome in every block, MUM columns, every record spells its genome interval, reverse-strand records present),
     run-to-run determinism, and the same bytes from the sharded form of the run -- `ranks` ranks, each with its block of the
@@ -99,10 +99,21 @@ def config5_flow(core_bin, d, workload, override, threads, ranks, min_lcbs=20, m
     for rep in range(2):
         out = os.path.join(d, "out%d" % rep)
         t = time.time()
-        rc, _ = driver.run_core(core_bin, rp, qs, out, threads=threads, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
+        timing = os.path.join(d, "timing%d.json" % rep)
+        rc, _ = driver.run_core(core_bin, rp, qs, out, threads=threads, env=dict(os.environ, OMP_WAIT_POLICY="passive"), timing=timing)
         walls.append(time.time() - t)
         assert rc == 0, open(os.path.join(out, "parsnp-aligner.err")).read()[-2000:]
         sums.append(xmfa_util.md5(os.path.join(out, "parsnpAligner.xmfa")))
+        if golden and rep == 0:
+            # the REFERENCE binary's bytes at this size (tests/golden/e2e_big.json: oracle/_ref/parsnp_core_ref, 67 minutes in the build
+            # container), from the device-resident route
+            import json
+            tj = json.load(open(timing))
+            assert tj["resident"] == 1 and tj["resident_retry"] == 0, tj
+            assert len(qs) == golden["n_queries"]
+            assert xmfa_util.log_counters(os.path.join(out, "parsnpAligner.log")) == golden["log"]
+            assert sums[0] == golden["xmfa_md5"], "the XMFA differs from the reference binary's"
+            say("config 5: the reference binary's bytes (md5 %s), resident route" % sums[0])
         assert "NOTE" not in open(os.path.join(out, "parsnpAligner.log")).read()
         say("config 5: run %d, whole process %.1f s" % (rep, walls[-1]))
     assert sums[0] == sums[1]

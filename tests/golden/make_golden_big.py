@@ -6,6 +6,7 @@ oracle/Makefile).  Build container only; each run is tens of minutes to an hour 
   bact200      BASELINE config 3: 200 x 5 Mb, population model seed 5, --no-partition
   bact2000_p0  BASELINE config 4: partition 0 (250 genomes, Random(42) order) of 2000 x 5 Mb, seed 6
   rearr50      BASELINE config 5 cut to its first 50 genomes: 5 % segregating sites, 10 % of every genome rearranged
+  rearr500     BASELINE config 5 in full (500 genomes; 67 minutes of the reference binary on 3 cores, a 2.47 GB XMFA)
 
 Writes xmfa md5, MUM/LCB signature, log counters and the reference's own phase timers into tests/golden/e2e_big.json
 (merged with what is there).  The inputs are regenerated from the same seeds by tests/test_gpu_big.py on the GPU box."""

@@ -98,10 +98,11 @@ def test_config4_all_partitions_and_merge():
 
 def test_config5_full_500_genomes():
     """BASELINE config 5 in full (flows.config5_flow: 500 x 5 Mb, 5 % segregating sites, 10 % of every genome rearranged,
-    --no-partition on one GPU, then the same run sharded over 4 ranks that share the GPU and exchange over gloo)."""
+    --no-partition on one GPU: since round 6 against the REFERENCE binary's golden at this size -- whole-XMFA md5 (2.47 GB) + log
+    counters, from the device-resident route --, then the same run sharded over 4 ranks that share the GPU and exchange over gloo)."""
     import flows
     d = _big_scratch(30)
     try:
-        flows.config5_flow(CORE_BIN, d, "rearr500", {}, threads=24, ranks=4, min_lcbs=5000, min_reverse=1000)
+        flows.config5_flow(CORE_BIN, d, "rearr500", {}, threads=24, ranks=4, min_lcbs=5000, min_reverse=1000, golden=BIG.get("rearr500"))
     finally:
         shutil.rmtree(d, ignore_errors=True)
