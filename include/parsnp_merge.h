@@ -27,7 +27,8 @@ extern "C" {
 int parsnp_partition_merge(int n_xmfas, const char* const* xmfa_paths, const char* out_path, long min_interval_size, int threads,
                            int keep_trimmed, long* clusters, long* sequences, long* ref_bases, char* err, long err_cap);
 
-/* Where the last merge of this process could depend on the insertion aligner (the reference re-aligns runs of columns that are
+/* Where the last merge OF THE CALLING THREAD could depend on the insertion aligner (the counts are kept per call: merges may run
+ * side by side in one process) (the reference re-aligns runs of columns that are
  * insertions relative to the reference with spoa.poa, partition.py:386; this library with the gap aligner of the XMFA writer):
  * runs of such columns; those that collected bases from more than one sequence (a single sequence is its own alignment either
  * way); those among them whose sequences are not all the same string; and the merged columns of the shared runs. */

@@ -326,13 +326,14 @@ struct Part { XFile x; std::vector<TBlock> trimmed; std::map<int, int> new_index
 //   shared          ... that collected bases from MORE THAN ONE sequence (one sequence is its own alignment either way)
 //   shared_diverse  ... whose sequences are not all the same string (identical strings align column by column in any aligner)
 //   shared_columns  merged columns of the shared runs
-std::atomic<long> g_ins_runs{0}, g_ins_shared{0}, g_ins_shared_diverse{0}, g_ins_shared_columns{0};
+// (one set per merge, handed to the workers of that merge: two merges may run side by side in one process)
+struct InsertionCounts { std::atomic<long> runs{0}, shared{0}, shared_diverse{0}, shared_columns{0}; };
 
 // merge_blocks, :320-433: the same trimmed cluster of every partition -> one block.  Columns in which every partition's
 // reference row holds a base are concatenated partition after partition (the reference row from the first); a run of
 // columns in which some reference row holds a gap is an insertion: its bases are collected per sequence and aligned
 // among themselves.
-void merge_cluster(const std::vector<Part>& parts, size_t cluster, std::string* text) {
+void merge_cluster(const std::vector<Part>& parts, size_t cluster, std::string* text, InsertionCounts* ins) {
     struct Out { int name; const TRec* t; int strand; std::string seq; };
     std::vector<Out> rows;
     std::vector<std::vector<size_t>> row_of(parts.size());      // per partition and record: index into rows, or npos (skipped reference)
@@ -369,12 +370,12 @@ void merge_cluster(const std::vector<Part>& parts, size_t cluster, std::string* 
         size_t width = 0;
         if (!ok) { aligned = seqs; }
         for (const std::string& s : aligned) width = std::max(width, s.size());
-        g_ins_runs++;
+        ins->runs++;
         if (seqs.size() > 1) {
-            g_ins_shared++; g_ins_shared_columns += (long)width;
+            ins->shared++; ins->shared_columns += (long)width;
             bool same = true;
             for (const std::string& s : seqs) same = same && s == seqs[0];
-            if (!same) g_ins_shared_diverse++;
+            if (!same) ins->shared_diverse++;
         }
         if (!ok) for (std::string& s : aligned) s.append(width - s.size(), '-');
         for (size_t k = 0; k < gap_order.size(); k++) rows[gap_order[k]].seq += aligned[k];
@@ -450,7 +451,7 @@ struct MergeStats { long clusters = 0, sequences = 0, intervals = 0, ref_bases =
 MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::string& out_path, long min_interval_size, int threads, bool keep_trimmed) {
     if (xmfas.empty()) throw std::runtime_error("no partition to merge");
     if (threads < 1) threads = 1;
-    g_ins_runs = 0; g_ins_shared = 0; g_ins_shared_diverse = 0; g_ins_shared_columns = 0;
+    InsertionCounts ins;
     const bool dbg = getenv("PARSNP_DEBUG_TIMERS") != nullptr;
     double tl = wall_s();
     auto lap = [&](const char* what) { if (dbg) { const double t = wall_s(); fprintf(stderr, "[merge] %-12s %.3f s\n", what, t - tl); tl = t; } };
@@ -541,14 +542,14 @@ MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::str
         const size_t c1 = std::min(nclusters, c0 + batch);
         std::vector<std::string> text(c1 - c0), errs(c1 - c0);
         parallel_items((long)(c1 - c0), threads, [&](long k) {
-            try { merge_cluster(parts, c0 + (size_t)k, &text[(size_t)k]); } catch (const std::exception& e) { errs[(size_t)k] = e.what(); }
+            try { merge_cluster(parts, c0 + (size_t)k, &text[(size_t)k], &ins); } catch (const std::exception& e) { errs[(size_t)k] = e.what(); }
         });
         for (const std::string& e : errs) if (!e.empty()) { close(fd); throw std::runtime_error(e); }
         for (const std::string& t : text) write_all(fd, t);
     }
     close(fd);
     lap("merge + write");
-    st.ins_runs = g_ins_runs; st.ins_shared = g_ins_shared; st.ins_shared_diverse = g_ins_shared_diverse; st.ins_shared_columns = g_ins_shared_columns;
+    st.ins_runs = ins.runs; st.ins_shared = ins.shared; st.ins_shared_diverse = ins.shared_diverse; st.ins_shared_columns = ins.shared_columns;
     return st;
 }
 
@@ -556,7 +557,7 @@ MergeStats partition_merge(const std::vector<std::string>& xmfas, const std::str
 
 // C entry (include/parsnp_merge.h): what the reference driver does between "Computing intersection of all partition
 // LCBs..." and the end of merge_xmfas (parsnp:1601-1615).  Returns 0, or 1 with a message in err.
-static long g_last_ins[4] = {0, 0, 0, 0};
+static thread_local long g_last_ins[4] = {0, 0, 0, 0};      // of the calling thread's last merge
 extern "C" void parsnp_partition_merge_insertions(long* runs, long* shared, long* shared_diverse, long* shared_columns) {
     if (runs) *runs = g_last_ins[0];
     if (shared) *shared = g_last_ins[1];

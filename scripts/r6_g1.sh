@@ -1,1 +1,3 @@
-timeout 2000 python -m pytest tests/test_gpu_big.py -m gpu -x -q -k "config5_full" 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "test_events or random_regions or mers_anchor" 2>&1 | tail -2
+bash scripts/r6_step.sh bench
+PROF_WL=bact200 bash scripts/r6_step.sh prof 2>&1 | grep -E "SeedExtend|SeedRest" | head
