@@ -230,9 +230,12 @@ constexpr uint64_t kEmpty = ~0ull;
 constexpr int kPer = PM_PER;           // SeedExtend: adjacent query samples per lane (they share the lane's sequence windows)
 constexpr int kUnitSamples = 64 * kPer;   // query samples per work unit
 #ifndef PM_LEAD
-#define PM_LEAD 8
+#define PM_LEAD 4
 #endif
-constexpr int kLead = PM_LEAD;         // SeedExtend: one lane in kLead (a leader) probes the index, the others follow its hit
+// SeedExtend: one lane in kLead (a leader) probes the index, the others follow its hit.  (8 until round 6: after an indel the samples up
+// to the next leader are off their leader's diagonal and go to SeedRest one by one -- 5.5 M of the anchor call's 100 M samples at
+// 200 x 5 Mb; with a leader every 4 lanes 3.3 M, with one every 2 lanes 2.0 M: event search 1.94 / 1.82 / 1.87 ms per step)
+constexpr int kLead = PM_LEAD;
 // (A lane whose first K-mer is not at the predicted position trying one base to either side in the windows it holds was measured
 // in round 4 and removed in round 5: SeedRest's queue halves, 0.50 -> 0.29 ms, but SeedExtend -- bound by instruction issue -- pays
 // 129 more vector instructions in nearly every wavefront, 1.78 -> 1.99 ms.  History: up to commit 682a045.)
