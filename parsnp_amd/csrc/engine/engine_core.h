@@ -805,6 +805,19 @@ public:
         if (int rc = need_resident(table_id)) return rc;
         begin_store_call();
         const int64_t rows = anchor_table_rows;
+        // (the clears are queued first: the device wipes 2 x 126 MB while the host looks through the list's flags)
+        const size_t words = layout_geometry();
+        ensure(d_image, words);
+        be.mark("settle");
+        ensure(d_foreign_count, 2);
+        be.memset(d_foreign_count.p, 0, 16);      // (candidates noted for store_order_check: none yet)
+        ms_key_rows = 0; foreign_seen = 0;
+        be.memset(d_image.p, 0, 8 * words);
+        ensure(d_recwords, words);
+        be.memset(d_recwords.p, 0, words);      // (where the recursion marks: ClusterValidate, for the order check)
+        const Store S = store_view();
+        const Layout L = layout_view(d_image.p);
+        be.launch_wave("settle_clean", rows, SettleClean{S, P});
         std::vector<int32_t> fl;
         for (int64_t c = 0; c < rows; c++) { const uint32_t f = anchor_flags_h[(size_t)c]; if (!(f & (kRowBad | kRowOutside)) && (f & kRowDirty)) fl.push_back((int32_t)c); }
         // The cheap running-extent test flags every row of an inverted or moved block, whether it overlaps anything or not: a
@@ -816,22 +829,10 @@ public:
         // first (one 8-byte read-back) and the list is declined above tangled_max of them (PM_EAGAIN: the host route's exact overlap
         // test and threads).  flagged_div = 1: never declined (tests).
         const bool many_flagged = flagged_div > 1 && fl.size() * (size_t)flagged_div > (size_t)rows;
-        const size_t words = layout_geometry();
-        ensure(d_image, words);
         // do the rows that can be accepted untrimmed lie in list order in every genome (none starts before the end of an earlier
         // row: the engine's kRowEarly bit)?  Then their marks need no atomics (StoreMarkOrdered)
         bool ordered = true;
         for (int64_t c = 0; c < rows && ordered; c++) { const uint32_t f = anchor_flags_h[(size_t)c]; ordered = !((f & kRowEarly) && !(f & (kRowBad | kRowOutside | kRowDirty))); }
-        be.mark("settle");
-        ensure(d_foreign_count, 2);
-        be.memset(d_foreign_count.p, 0, 16);      // (candidates noted for store_order_check: none yet)
-        ms_key_rows = 0; foreign_seen = 0;
-        be.memset(d_image.p, 0, 8 * words);
-        ensure(d_recwords, words);
-        be.memset(d_recwords.p, 0, words);      // (where the recursion marks: ClusterValidate, for the order check)
-        const Store S = store_view();
-        const Layout L = layout_view(d_image.p);
-        be.launch_wave("settle_clean", rows, SettleClean{S, P});
         if (ordered && !force_atomic_marks) be.launch_wave("store_mark_ordered", ((rows + kMarkRows - 1) / kMarkRows) * ((ngen + 63) / 64), StoreMarkOrdered{S, L, rows});
         else be.launch("store_mark", rows * ngen, StoreMark{S, L, 0, (uint8_t)(kStAccepted | kStFlagged), kStAccepted});
         be.launch("layout_sentinel", (int64_t)ngen, LayoutSentinel{d_lay_off.p, d_lay_bits.p, d_image.p});

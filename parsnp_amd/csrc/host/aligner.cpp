@@ -346,6 +346,15 @@ void Aligner::collect_engine_timing() {
     int cnt = 64; const char* names[64]; float ms[64];
     if (pm_last_timing(session_, &cnt, names, ms) != PM_OK) return;
     if (timing_first_call_) stats.anchor_ms.clear();
+    if (getenv("PARSNP_DEBUG_TIMERS")) {      // one line per engine call: its wall time and its device phases
+        double wall = 0, dev = 0;
+        for (int i = 0; i < cnt; i++) {
+            if (!strcmp(names[i], "call_wall")) wall = ms[i];
+            else if (strncmp(names[i], "alg_", 4) && strncmp(names[i], "n_", 2) && strcmp(names[i], "events") && strcmp(names[i], "rest_samples") && strcmp(names[i], "budget_retries") &&
+                     strcmp(names[i], "exact_cluster_tests") && strcmp(names[i], "deferred_regions") && strcmp(names[i], "tail_repeats") && strcmp(names[i], "outside_writes")) dev += ms[i];
+        }
+        fprintf(stderr, "[engine call] wall %.3f ms, device phases %.3f ms\n", wall, dev);
+    }
     for (int i = 0; i < cnt; i++) {
         // (counts that travel in the timing list: the algorithmic bytes of a search whose rows only the engine held)
         if (!strcmp(names[i], "alg_survey")) { stats.alg_bytes += ms[i]; continue; }

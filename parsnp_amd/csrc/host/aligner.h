@@ -364,7 +364,7 @@ private:
         std::vector<uint64_t> image;                                           // the layout, fetched for parsnp.unalign
         std::vector<pm_row_info> anchor_info; const int32_t* anchor_lon = nullptr; long anchor_slength = 0; size_t anchor_accepted = 0;   // what resident_records() writes the anchors' MUM records from
         bool records_done = true;
-        std::vector<int32_t> of_row;      // store row -> index of its MUM record in the pool (-1: none)
+        std::vector<int32_t> of_row, len_of_row;      // store row -> index of its MUM record in the pool (-1: none), and its length
         bool chain_queued = false;                                             // pm_store_chain_begin is in flight (resident_chain() collects it)
         std::string chain_why;                                                 // why phases C-D fell back to the host's list logic
     } res_;

@@ -150,7 +150,7 @@ void Aligner::resident_records() {
     res_.records_done = true;
     const size_t nacc = res_.anchor_accepted, count = res_.anchor_info.size();
     pool.resize(nacc); res_.start0.resize(nacc);
-    res_.of_row.assign(count, -1);      // store row -> MUM record (resident_chain reads the device's list through it)
+    res_.of_row.assign(count, -1); res_.len_of_row.assign(count, 0);      // store row -> MUM record (resident_chain reads the device's list through it)
     size_t at = 0;
     long dirty = 0, tangled = 0;
     for (size_t c = 0; c < count; c++) {
@@ -162,7 +162,7 @@ void Aligner::resident_records() {
         m.id = next_id_ - 1; m.length = r.len; m.slength = res_.anchor_slength; m.row = (int32_t)c;
         m.dirty = (st & PM_ST_FLAGGED) != 0; m.touched = r.len != res_.anchor_lon[c];
         pool[at] = m; res_.start0[at] = r.start0;
-        res_.of_row[c] = (int32_t)at;
+        res_.of_row[c] = (int32_t)at; res_.len_of_row[c] = (int32_t)r.len;
         at++;
         dirty += m.dirty; tangled += (st & PM_ST_TANGLED) != 0;
     }
@@ -396,8 +396,8 @@ bool Aligner::resident_extend() {
                 Mum m;
                 m.id = next_id_ - 1; m.length = info[(size_t)c].len; m.slength = cm.now[i].slength; m.row = (int32_t)c;
                 pool.push_back(m); res_.start0.push_back(info[(size_t)c].start0);
-                if (res_.of_row.size() <= (size_t)c) res_.of_row.resize((size_t)c + 1 + (size_t)c / 8, -1);
-                res_.of_row[(size_t)c] = (int32_t)pool.size() - 1;
+                if (res_.of_row.size() <= (size_t)c) { res_.of_row.resize((size_t)c + 1 + (size_t)c / 8, -1); res_.len_of_row.resize(res_.of_row.size(), 0); }
+                res_.of_row[(size_t)c] = (int32_t)pool.size() - 1; res_.len_of_row[(size_t)c] = (int32_t)info[(size_t)c].len;
                 // (generation of the region: the second stage of a two-stage call is one later; 0 = the first pushed seed, processed before anything is sorted)
                 const int g = cm.gi + (i >= cm.second_stage_from ? 1 : 0);
                 res_.found_key.resize(pool.size(), -1);
@@ -467,6 +467,7 @@ bool Aligner::resident_chain() {
     if (ci.trouble & 2) fatal("inter-cluster region bookkeeping would overrun in the reference");
     // store row -> MUM record (res_.of_row: written with the records, beside phases C-D on the device)
     const std::vector<int32_t>& of = res_.of_row;
+    const std::vector<int32_t>& len_of = res_.len_of_row;
     const int64_t top = (int64_t)of.size() - 1;
     mums.resize((size_t)ci.n_mums);
     lcbs.clear();
@@ -476,17 +477,21 @@ bool Aligner::resident_chain() {
     for (int64_t x = 0; x < ci.n_mums;) {      // LCB by LCB: from a head to the MUM before the next one
         int64_t y = x + 1;
         while (y < ci.n_mums && !heads[y]) y++;
-        Lcb c; c.type = 1; c.length = 0;
+        lcbs.emplace_back();
+        Lcb& c = lcbs.back(); c.type = 1;
         c.mums.resize((size_t)(y - x));
+        int* out = c.mums.data(); int* all = mums.data() + x;
+        long total = 0;
         for (int64_t z = x; z < y; z++) {
-            if (rows[z] < 0 || rows[z] > top || of[(size_t)rows[z]] < 0) fatal("the device's MUM list names a row the host does not hold");
-            const int idx = of[(size_t)rows[z]];
-            mums[(size_t)z] = idx; c.mums[(size_t)(z - x)] = idx;
-            c.length += pool[(size_t)idx].length;
+            const int32_t row = rows[z];
+            if (row < 0 || row > top || of[(size_t)row] < 0) fatal("the device's MUM list names a row the host does not hold");
+            const int idx = of[(size_t)row];
+            out[z - x] = idx; all[z - x] = idx;
+            total += len_of[(size_t)row];
         }
+        c.length = total;
         c.start.assign(1, key0(c.mums.front()));
         c.end.assign(1, key0(c.mums.back()) + pool[(size_t)c.mums.back()].length);
-        lcbs.push_back(std::move(c));
         x = y;
     }
     if ((int64_t)lcbs.size() != ci.n_fillers + ci.n_lcbs) fatal("the device's LCB count and its head flags differ");
