@@ -285,7 +285,7 @@ public:
             ri.K = ri.minlen < kMaxK ? ri.minlen : kMaxK;
             ri.stride = ri.minlen - ri.K + 1;
             int64_t slots = 16;
-            while (2 * slots < 3 * (int64_t)ri.nR) slots <<= 1;   // load factor <= 2/3
+            while (slots < slot_factor * (int64_t)ri.nR) slots <<= 1;   // load factor <= 1 / slot_factor (x2: the next power of two)
             ri.tmask = (uint32_t)(slots - 1);
             ri.tbase = tsize; tsize += slots;
             int64_t fbits = 64;
@@ -1089,10 +1089,15 @@ public:
                     ensure(d_once, words); ensure(d_twice, words); ensure(d_owner, words);
                     if (d_once.p != b1 || d_twice.p != b2) { be.memset(d_once.p, 0, 8 * words); be.memset(d_twice.p, 0, 8 * words); }      // (kept all zero between calls)
                     if (d_owner.p != b3) be.memset(d_owner.p, 0, 4 * words);
-                    be.launch_wave("cluster_extents", cn, ClusterExtents{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_twice.p, d_owner.p, c0, 1});
-                    be.launch_wave("cluster_involved", cn, ClusterInvolved{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_twice.p, false), d_owner.p, d_v_involved.p, c0});
-                    be.launch_wave("cluster_defer", cn, ClusterDefer{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, d_lay_off.p, d_lay_bits.p, d_owner.p, d_v_involved.p, d_v_defer.p, c0});
-                    be.launch_wave("cluster_extents", cn, ClusterExtents{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_twice.p, d_owner.p, c0, 0});
+                    // two passes over the same scratch images: what the clusters' REGIONS touch, then what their CANDIDATES touch (a
+                    // member outside its region reads, and may mark, where another cluster's candidates mark)
+                    for (int pass = 0; pass < 2; pass++) {
+                        const ClusterRows cr{store_view(), d_v_row0.p, d_list2.p, pass == 0 ? 1 : 0};
+                        be.launch_wave("cluster_extents", cn, ClusterExtents{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_twice.p, d_owner.p, c0, 1, cr});
+                        be.launch_wave("cluster_involved", cn, ClusterInvolved{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_twice.p, false), d_owner.p, d_v_involved.p, c0, cr});
+                        be.launch_wave("cluster_defer", cn, ClusterDefer{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, d_lay_off.p, d_lay_bits.p, d_owner.p, d_v_involved.p, d_v_defer.p, c0, cr});
+                        be.launch_wave("cluster_extents", cn, ClusterExtents{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_twice.p, d_owner.p, c0, 0, cr});
+                    }
                 }
                 defer = d_v_defer.p;
                 exact_cluster_tests++;
@@ -1396,6 +1401,7 @@ public:
     bool group_small = true;      // the events of a recursion batch's small regions once per distinct piece (GroupedPairEvents)
     int64_t last_grouped = 0;
     bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
+    int slot_factor = 2;                  // index slots per reference position, before rounding up to a power of two (a measurement switch)
     bool bucket_sort = true;              // the events put in order by (pair, 256-position block) buckets (EventBucketCount ... CoarseFromBuckets); false: gathered and radix-sorted
     bool master_seg = true;               // Master.EP from the genomes' segments (MasterEPSeg); false: every lane against every staged event (MasterEP)
     bool force_gate = false;              // (tests) the second stage of a two-stage store_validate never runs
@@ -1415,6 +1421,7 @@ public:
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
         if (key == "master_seg") { master_seg = value != 0; return true; }
         if (key == "bucket_sort") { bucket_sort = value != 0; return true; }
+        if (key == "slot_factor") { slot_factor = value < 1 ? 1 : (int)value; return true; }
         if (key == "stage_gate") { force_gate = value != 0; return true; }
         if (key == "chain_tie") { force_chain_tie = value != 0; return true; }
         if (key == "cluster_unsure") { force_unsure = value != 0; return true; }
