@@ -146,6 +146,9 @@ int64_t pm_result_table_id(const pm_result* r);
  *   "atomic_marks" != 0: pm_store_settle marks the layout with atomic ORs even where the list's order allows plain stores (tests)
  *   "group_small"  0: the events of a recursion batch's small regions are found pair by pair and sorted with the others, instead of
  *                  once per distinct query piece (default 1; both give the same events, tests compare the two)
+ *   "slot_factor"  index slots per reference position before rounding up to a power of two (default 2: load <= 1/2; 1 = rounds 1-5,
+ *                  load <= 2/3 -- the wavefronts of IndexInsert and of the probes run as long as their longest probe sequence);
+ *   "filter_factor" presence-filter bits per reference position before rounding up (default 8; 4 ... 32 measured: flat)
  *   "bucket_sort"  0: the events of a search are gathered and radix-sorted by (pair, l, strand) and the readers' table of events per
  *                  256-position block comes from a pass over the sorted keys (rounds 1-5), instead of a counting sort by (pair, block)
  *                  buckets whose scanned counts ARE that table (default 1; the same events in the same order up to equal keys)

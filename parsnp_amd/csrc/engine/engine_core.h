@@ -289,7 +289,7 @@ public:
             ri.tmask = (uint32_t)(slots - 1);
             ri.tbase = tsize; tsize += slots;
             int64_t fbits = 64;
-            while (fbits < 8 * (int64_t)ri.nR) fbits <<= 1;
+            while (fbits < filter_factor * (int64_t)ri.nR) fbits <<= 1;
             ri.fmask = (uint32_t)(fbits - 1); ri.fbase = fwords; fwords += fbits / 32; ri.pad_ = 0;
             ri.posbase = npos; posbase[(size_t)r] = npos; npos += ri.nR;
             cbase[(size_t)r + 1] = cbase[(size_t)r] + (((int64_t)ri.nR + kChunkPos - 1) >> kCoarseShift) + 1;
@@ -1401,6 +1401,7 @@ public:
     bool group_small = true;      // the events of a recursion batch's small regions once per distinct piece (GroupedPairEvents)
     int64_t last_grouped = 0;
     bool force_atomic_marks = false;      // (tests) store_settle marks with atomic ORs although the list is in order
+    int filter_factor = 8;                // presence-filter bits per reference position, before rounding up to a power of two
     int slot_factor = 2;                  // index slots per reference position, before rounding up to a power of two (a measurement switch)
     bool bucket_sort = true;              // the events put in order by (pair, 256-position block) buckets (EventBucketCount ... CoarseFromBuckets); false: gathered and radix-sorted
     bool master_seg = true;               // Master.EP from the genomes' segments (MasterEPSeg); false: every lane against every staged event (MasterEP)
@@ -1421,6 +1422,7 @@ public:
         if (key == "atomic_marks") { force_atomic_marks = value != 0; return true; }
         if (key == "master_seg") { master_seg = value != 0; return true; }
         if (key == "bucket_sort") { bucket_sort = value != 0; return true; }
+        if (key == "filter_factor") { filter_factor = value < 1 ? 1 : (int)value; return true; }
         if (key == "slot_factor") { slot_factor = value < 1 ? 1 : (int)value; return true; }
         if (key == "stage_gate") { force_gate = value != 0; return true; }
         if (key == "chain_tie") { force_chain_tie = value != 0; return true; }

@@ -1,3 +1,3 @@
-for i in 1 2 3 4 5 6 7 8 9 10 11 12 13 14 15 16 17 18 19 20; do python scripts/why_route.py rearr50 2>&1 | grep -E "^rc" | cut -c1-120; done | sort | uniq -c
-bash scripts/r6_step.sh tests inv rearr
-timeout 600 python -m pytest tests/test_gpu_big.py -m gpu -x -q -k "baseline_size" 2>&1 | tail -2
+for t in 8 16 32 4 8 16; do timeout 300 python bench.py --steps 100 --warmup 5 --cpu-sample 0 --other-configs off --tune filter_factor=$t 2>/dev/null | tail -1 | python -c "
+import json,sys,statistics
+d=json.loads(sys.stdin.read()); e=d['engine_ms']; print('filter_factor=$t', d['ms_per_step'], 'median', statistics.median(d['step_ms']), 'index', e['index'], 'repeat', e['repeat'], 'seed', e['seed_extend'], 'rest', e['rest_samples'])"; done
