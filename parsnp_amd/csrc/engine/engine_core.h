@@ -356,7 +356,7 @@ public:
             be.launch_wave("alg_bytes", (nreg * nq + kAlgPairs - 1) / kAlgPairs, AlgBytes{d_R.p, d_lens.p, ngen, nreg * nq, d_alg.p});
         }
         be.mark("index");
-        be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p, d_filter.p});
+        be.launch("index_insert", npos, IndexInsert{P, d_R.p, nreg, d_posbase.p, d_slots.p, d_next.p, d_filter.p, d_rep.p});
         be.mark("repeat");
         ensure(d_run, (size_t)std::max<int64_t>(npos, 1));
         be.launch("run_length", npos, RunLength{P, d_R.p, nreg, d_posbase.p, d_run.p});

@@ -444,12 +444,14 @@ PM_HD uint32_t filter_mask(uint64_t hv, uint32_t bit) { return (1u << (bit & 31)
 struct IndexInsert {
     Packed P; const RegionInfo* R; int64_t nregions; const int64_t* posbase;   // posbase[nregions+1]
     uint64_t* slots; int32_t* next; uint32_t* filter;
+    int32_t* home;      // [position]: the slot of its K-mer in the region's slice (-1: no K-mer starts there) -- RepeatLength reads its slot
+                        // from there instead of hashing and probing again (it is rep[], which RepeatLength then overwrites)
     PM_HD void operator()(int64_t tid) const {
         int64_t r = upper_slot(posbase, nregions, tid);
         const RegionInfo& ri = R[r];
         int32_t l = (int32_t)(tid - ri.posbase);
         next[tid] = -1;
-        if (l + ri.K > ri.nR) return;
+        if (l + ri.K > ri.nR) { home[tid] = -1; return; }
         const int64_t base = P.goff[0] + ri.ref_pos;
         const uint64_t tag = canonical_tag(kmer_tag(P, base + l, ri.K), ri.K);
         const uint64_t hv = hash_tag(tag);
@@ -466,13 +468,13 @@ struct IndexInsert {
             uint64_t seen = *slot;      // (a look first: the CAS at once was measured, 0.69 instead of 0.47 ms for the 5 Mb reference)
             if (seen == kEmpty) {
                 seen = atomic_cas64(slot, kEmpty, fp | (uint64_t)l);
-                if (seen == kEmpty) return;                       // first occurrence of this K-mer
+                if (seen == kEmpty) { home[tid] = (int32_t)h; return; }      // first occurrence of this K-mer
             }
             if ((seen & 0xffffffff00000000ull) == fp && canonical_tag(kmer_tag(P, base + slot_head(seen), ri.K), ri.K) == tag) {
                 for (;;) {                                          // push onto this K-mer's chain
                     next[tid] = slot_head(seen);
                     uint64_t prev = atomic_cas64(slot, seen, fp | kMulti | (uint64_t)l);
-                    if (prev == seen) return;
+                    if (prev == seen) { home[tid] = (int32_t)h; return; }
                     seen = prev;                                    // another occurrence got in first: same K-mer, new head
                 }
             }
@@ -539,11 +541,11 @@ struct RepeatLength {
         int32_t l = (int32_t)(tid - ri.posbase);
         int32_t best = 0;
         bool shared = false;      // the canonical K-mer at l occurs elsewhere in R (in either orientation)
-        if (l + ri.K <= ri.nR) {
+        const int32_t h = rep[tid];      // (IndexInsert left the K-mer's slot here)
+        if (l + ri.K <= ri.nR && h >= 0) {
             int64_t base = P.goff[0] + ri.ref_pos;
-            uint64_t tag = canonical_tag(kmer_tag(P, base + l, ri.K), ri.K);
-            uint64_t slot = index_lookup(P, ri, slots, filter, tag);
-            if (slot != kEmpty && (slot & kMulti)) {
+            const uint64_t slot = slots[ri.tbase + h];
+            if (slot & kMulti) {
                 shared = true;
                 int64_t work = 0;
                 const int32_t r1 = run[tid];
