@@ -1089,15 +1089,17 @@ public:
                     ensure(d_once, words); ensure(d_twice, words); ensure(d_owner, words);
                     if (d_once.p != b1 || d_twice.p != b2) { be.memset(d_once.p, 0, 8 * words); be.memset(d_twice.p, 0, 8 * words); }      // (kept all zero between calls)
                     if (d_owner.p != b3) be.memset(d_owner.p, 0, 4 * words);
-                    // two passes over the same scratch images: what the clusters' REGIONS touch, then what their CANDIDATES touch (a
-                    // member outside its region reads, and may mark, where another cluster's candidates mark)
-                    for (int pass = 0; pass < 2; pass++) {
-                        const ClusterRows cr{store_view(), d_v_row0.p, d_list2.p, pass == 0 ? 1 : 0};
-                        be.launch_wave("cluster_extents", cn, ClusterExtents{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_twice.p, d_owner.p, c0, 1, cr});
-                        be.launch_wave("cluster_involved", cn, ClusterInvolved{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_twice.p, false), d_owner.p, d_v_involved.p, c0, cr});
-                        be.launch_wave("cluster_defer", cn, ClusterDefer{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, d_lay_off.p, d_lay_bits.p, d_owner.p, d_v_involved.p, d_v_defer.p, c0, cr});
-                        be.launch_wave("cluster_extents", cn, ClusterExtents{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_twice.p, d_owner.p, c0, 0, cr});
-                    }
+                    be.launch_wave("cluster_extents", cn, ClusterExtents{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_twice.p, d_owner.p, c0, 1});
+                    be.launch_wave("cluster_involved", cn, ClusterInvolved{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_twice.p, false), d_owner.p, d_v_involved.p, c0});
+                    be.launch_wave("cluster_defer", cn, ClusterDefer{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, d_lay_off.p, d_lay_bits.p, d_owner.p, d_v_involved.p, d_v_defer.p, c0});
+                    be.launch_wave("cluster_extents", cn, ClusterExtents{ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_twice.p, d_owner.p, c0, 0});
+                    // ... and where a candidate's member outside its region reads beside a cluster that may mark there (the same scratch arrays,
+                    // wiped in between; `twice` lends its memory to the second owner array)
+                    int32_t* owner2 = (int32_t*)d_twice.p;
+                    be.launch_wave("reader_mark", cn, ReaderMark{store_view(), d_v_row0.p, d_list2.p, ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_owner.p, owner2, c0, 1});
+                    be.launch_wave("marker_look", cn, MarkerLook{store_view(), d_v_row0.p, d_list2.p, ngen, d_v_first.p, layout_view(d_once.p, false), d_owner.p, owner2, d_v_defer.p, c0});
+                    be.launch_wave("reader_look", cn, ReaderLook{store_view(), d_v_row0.p, d_list2.p, ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, d_lay_off.p, d_lay_bits.p, owner2, d_v_defer.p, c0});
+                    be.launch_wave("reader_mark", cn, ReaderMark{store_view(), d_v_row0.p, d_list2.p, ngen, d_rg_start.p, d_rg_len.p, d_list.p, d_v_first.p, layout_view(d_once.p), d_owner.p, owner2, c0, 0});
                 }
                 defer = d_v_defer.p;
                 exact_cluster_tests++;

@@ -1379,8 +1379,25 @@ struct EventOrder {
             if (k1 < k0) { const uint64_t v0 = v[0], v1 = v[1]; k[0] = k1; k[1] = k0; v[0] = v1; v[1] = v0; }
             return;
         }
+        if (n <= 8) {      // in registers: the bucket's events once in, a fixed network of 19 exchanges, once out
+            uint64_t rk[8], rv[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { rk[i] = i < n ? k[i] : ~0ull; rv[i] = i < n ? v[i] : 0; }
+#define PM_CX(a, b) { const bool sw = rk[b] < rk[a]; const uint64_t ka = sw ? rk[b] : rk[a], kb = sw ? rk[a] : rk[b], va = sw ? rv[b] : rv[a], vb = sw ? rv[a] : rv[b]; rk[a] = ka; rk[b] = kb; rv[a] = va; rv[b] = vb; }
+            PM_CX(0, 1) PM_CX(2, 3) PM_CX(4, 5) PM_CX(6, 7)
+            PM_CX(0, 2) PM_CX(1, 3) PM_CX(4, 6) PM_CX(5, 7)
+            PM_CX(1, 2) PM_CX(5, 6) PM_CX(0, 4) PM_CX(3, 7)
+            PM_CX(1, 5) PM_CX(2, 6)
+            PM_CX(1, 4) PM_CX(3, 6)
+            PM_CX(2, 4) PM_CX(3, 5)
+            PM_CX(3, 4)
+#undef PM_CX
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (i < n) { k[i] = rk[i]; v[i] = rv[i]; }
+            return;
+        }
         int64_t gap = 1;
-        while (gap < n / 3) gap = 3 * gap + 1;      // (n <= 4: plain insertion)
+        while (gap < n / 3) gap = 3 * gap + 1;
         for (; gap >= 1; gap /= 3)
             for (int64_t i = gap; i < n; i++) {
                 const uint64_t kk = k[i], vv = v[i];

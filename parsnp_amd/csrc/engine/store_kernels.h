@@ -1042,62 +1042,15 @@ template <class F> PM_HD void cluster_pieces(int32_t ngen, const int64_t* rg_sta
     }
     clip(ca, cb);
 }
-// ... and, in a second pass over the same scratch images, what its CANDIDATES touch.  A reverse-strand member is flipped against the
-// whole genome (TMum.cpp:33-35) and usually lands somewhere else in it, where the candidate's trimming READS the marks.  Beside a
-// cluster that may MARK there in the same generation that read is a race (what is marked depends on how far the other wavefront
-// has come: 50 x 5 Mb rearranged left the route in one run of twelve).  Marks come from candidates, so the pass ORs every member
-// interval of every candidate that can be built (one base of margin either side) into the images: where two clusters' candidates
-// meet -- which, the clusters' regions being disjoint, takes a member outside its region -- the later cluster waits.  (Taking the
-// REGIONS a member outside could fall into serialised a rearranged set: a candidate of 500 genomes has hundreds of such members.)
-struct ClusterRows { Store S; const int64_t* now_row0; const int32_t* now_cnt; int regions; };      // regions != 0: the pass over the regions
-constexpr int kRowPieces = 12;
-template <class F> PM_HD void cluster_row_pieces(const ClusterRows& R, int32_t ngen, const int32_t* now_region, int64_t p0, int64_t p1, int j, int64_t nbits, F f) {
-    if (R.regions) return;
-    int64_t total = 0;
-    for (int64_t x = p0; x < p1; x++) total += R.now_cnt[x];
-    auto clip = [&](int64_t a, int64_t b) { if (a < 0) a = 0; if (b > nbits) b = nbits; if (a < b) f(a, b); };
-    if (total > kRowPieces) {      // (a cluster of many candidates: piece by piece -- it may meet itself, which only costs it the look at the owners)
-        for (int64_t x = p0; x < p1; x++) {
-            const int64_t row0 = R.now_row0[x];
-            for (int64_t c = row0; c < row0 + R.now_cnt[x]; c++) {
-                if (R.S.flags[c] & (kRowBad | kRowOutside)) continue;
-                const int64_t a = (int64_t)R.S.start[c * ngen + j] - 1;
-                clip(a, a + R.S.lon[c] + 2);
-            }
-        }
-        return;
-    }
-    // the lane sorts the candidates' intervals of its genome and hands every maximal run of overlapping ones over once: overlapping
-    // candidates of one region are the rule, and a cluster must not meet itself
-    int64_t a[kRowPieces], b[kRowPieces];
-    int cnt = 0;
-    for (int64_t x = p0; x < p1; x++) {
-        const int64_t row0 = R.now_row0[x];
-        for (int64_t c = row0; c < row0 + R.now_cnt[x]; c++) {
-            if (R.S.flags[c] & (kRowBad | kRowOutside)) continue;
-            const int64_t s = (int64_t)R.S.start[c * ngen + j] - 1, e = s + R.S.lon[c] + 2;
-            int k = cnt++;
-            while (k > 0 && a[k - 1] > s) { a[k] = a[k - 1]; b[k] = b[k - 1]; k--; }
-            a[k] = s; b[k] = e;
-        }
-    }
-    if (!cnt) return;
-    int64_t ca = a[0], cb = b[0];
-    for (int i = 1; i < cnt; i++) {
-        if (a[i] <= cb) { if (b[i] > cb) cb = b[i]; }
-        else { clip(ca, cb); ca = a[i]; cb = b[i]; }
-    }
-    clip(ca, cb);
-}
 struct ClusterExtents {
     int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first;
-    Layout once; uint64_t* twice; int32_t* owner; int64_t cl0; int mark; ClusterRows rows;
+    Layout once; uint64_t* twice; int32_t* owner; int64_t cl0; int mark;
     PM_HD void wave(int64_t w) const {
         const int64_t cl = cl0 + w;
         const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
         lanes_for(1, ngen, [&](int j) {
             const int64_t base = once.word_off[j];
-            auto piece = [&](int64_t a, int64_t b) {
+            cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, once.nbits[j], [&](int64_t a, int64_t b) {
                 while (a < b) {
                     const int f = (int)(a & 63);
                     const int64_t span = (64 - f) < (b - a) ? (64 - f) : (b - a);
@@ -1108,51 +1061,150 @@ struct ClusterExtents {
                     } else { once.image[base + (a >> 6)] = 0; twice[base + (a >> 6)] = 0; owner[base + (a >> 6)] = 0; }
                     a += span;
                 }
-            };
-            if (rows.regions) cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, once.nbits[j], piece);
-            cluster_row_pieces(rows, ngen, now_region, p0, p1, j, once.nbits[j], piece);
+            });
         });
     }
 };
 struct ClusterInvolved {
     int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first;
-    Layout twice; int32_t* owner; uint8_t* involved; int64_t cl0; ClusterRows rows;
+    Layout twice; int32_t* owner; uint8_t* involved; int64_t cl0;
     PM_HD void wave(int64_t w) const {
         const int64_t cl = cl0 + w;
         const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
         uint32_t hit = 0;
         lanes_for(1, ngen, [&](int j) {
-            auto look = [&](int64_t a, int64_t b) { if (!hit && img_any(twice, j, a, b)) hit = 1; };
-            if (rows.regions) cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, twice.nbits[j], look);
-            cluster_row_pieces(rows, ngen, now_region, p0, p1, j, twice.nbits[j], look);
+            cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, twice.nbits[j], [&](int64_t a, int64_t b) { if (!hit && img_any(twice, j, a, b)) hit = 1; });
         });
         hit = wave_or_u32(hit);
         if (wave_leader()) involved[cl] = hit ? 1 : 0;
         if (!hit) return;
         const int32_t mine = 0x7fffffff - (int32_t)cl;
         lanes_for(1, ngen, [&](int j) {
-            auto own = [&](int64_t a, int64_t b) { for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6); wd++) atomic_max32(&owner[twice.word_off[j] + wd], mine); };
-            if (rows.regions) cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, twice.nbits[j], own);
-            cluster_row_pieces(rows, ngen, now_region, p0, p1, j, twice.nbits[j], own);
+            cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, twice.nbits[j], [&](int64_t a, int64_t b) {
+                for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6); wd++) atomic_max32(&owner[twice.word_off[j] + wd], mine);
+            });
         });
     }
 };
 struct ClusterDefer {
     int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first;
-    const int64_t* word_off; const int64_t* nbits; const int32_t* owner; const uint8_t* involved; uint8_t* defer; int64_t cl0; ClusterRows rows;
+    const int64_t* word_off; const int64_t* nbits; const int32_t* owner; const uint8_t* involved; uint8_t* defer; int64_t cl0;
     PM_HD void wave(int64_t w) const {
         const int64_t cl = cl0 + w;
-        if (!involved[cl]) { if (wave_leader() && rows.regions) defer[cl] = 0; return; }
+        if (!involved[cl]) { if (wave_leader()) defer[cl] = 0; return; }
         const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
         const int32_t mine = 0x7fffffff - (int32_t)cl;
         uint32_t earlier = 0;
         lanes_for(1, ngen, [&](int j) {
-            auto look = [&](int64_t a, int64_t b) { for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6) && !earlier; wd++) if (owner[word_off[j] + wd] > mine) earlier = 1; };
-            if (rows.regions) cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, nbits[j], look);
-            cluster_row_pieces(rows, ngen, now_region, p0, p1, j, nbits[j], look);
+            cluster_pieces(ngen, rg_start, rg_len, now_region, p0, p1, j, nbits[j], [&](int64_t a, int64_t b) {
+                for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6) && !earlier; wd++) if (owner[word_off[j] + wd] > mine) earlier = 1;
+            });
         });
         earlier = wave_or_u32(earlier);
-        if (wave_leader() && (rows.regions || earlier)) defer[cl] = earlier ? 1 : 0;      // (the pass over the candidates adds to what the pass over the regions decided)
+        if (wave_leader()) defer[cl] = earlier ? 1 : 0;
+    }
+};
+// ... and what its CANDIDATES touch outside their regions.  A reverse-strand member is flipped against the whole genome
+// (TMum.cpp:33-35) and usually lands somewhere else in it, where the candidate's trimming READS the marks.  Beside a cluster that
+// may MARK there in the same generation that read is a race (what is marked depends on how far the other wavefront has come:
+// 50 x 5 Mb rearranged left the route in one run of twelve).  Marks come from candidates, so:
+//   ReaderMark   every cluster ORs the members outside their region of its reverse-strand candidates (one base of margin) into the
+//                scratch image `once` and writes its number into their words (`owner`, the smallest wins): the READERS, few;
+//   MarkerLook   every cluster looks under EVERY member of every candidate it can build (the places it may mark; reads only): bits
+//                of a reader there = the two clusters meet.  A reader with a smaller number: this cluster waits.  Else it leaves its
+//                own number in the word (`owner2`) ...
+//   ReaderLook   ... where the reader finds it: a marker with a smaller number, the reader waits.
+//   ReaderMark with mark = 0 wipes the words (the scratch arrays are kept all zero between calls).
+// (Taking the REGIONS a member outside could fall into serialised a rearranged set -- a candidate of 500 genomes has hundreds of
+// such members, 55 -> 73 ms per step --, and putting all candidates' members through the atomics of ClusterExtents cost 4.5 ms.)
+template <class F> PM_HD void cluster_reader_pieces(const Store& S, const int64_t* now_row0, const int32_t* now_cnt, int32_t ngen, const int64_t* rg_start, const int64_t* rg_len,
+                                                    const int32_t* now_region, int64_t p0, int64_t p1, int j, int64_t nbits, F f) {
+    for (int64_t x = p0; x < p1; x++) {
+        const int64_t r = now_region[x];
+        const int64_t rs = rg_start[r * ngen + j], re = rs + rg_len[r * ngen + j];
+        const int64_t row0 = now_row0[x];
+        for (int64_t c = row0; c < row0 + now_cnt[x]; c++) {
+            const uint32_t fl = S.flags[c];
+            if (!(fl & kRowReverse) || (fl & (kRowBad | kRowOutside)) || S.strand[c * ngen + j]) continue;
+            int64_t a = S.start[c * ngen + j], b = a + S.lon[c];
+            if (!(a < rs - 1 || b > re + 1)) continue;
+            a -= 1; b += 1;
+            if (a < 0) a = 0;
+            if (b > nbits) b = nbits;
+            if (a < b) f(a, b);
+        }
+    }
+}
+struct ReaderMark {
+    Store S; const int64_t* now_row0; const int32_t* now_cnt; int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first;
+    Layout once; int32_t* owner; int32_t* owner2; int64_t cl0; int mark;
+    PM_HD void wave(int64_t w) const {
+        const int64_t cl = cl0 + w;
+        const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
+        const int32_t mine = 0x7fffffff - (int32_t)cl;
+        lanes_for(1, ngen, [&](int j) {
+            const int64_t base = once.word_off[j];
+            cluster_reader_pieces(S, now_row0, now_cnt, ngen, rg_start, rg_len, now_region, p0, p1, j, once.nbits[j], [&](int64_t a, int64_t b) {
+                while (a < b) {
+                    const int f = (int)(a & 63);
+                    const int64_t span = (64 - f) < (b - a) ? (64 - f) : (b - a);
+                    const int64_t wd = base + (a >> 6);
+                    if (mark) { atomic_or64(&once.image[wd], (span == 64 ? ~0ull : ((1ull << span) - 1)) << f); atomic_max32(&owner[wd], mine); }
+                    else { once.image[wd] = 0; owner[wd] = 0; owner2[wd] = 0; }
+                    a += span;
+                }
+            });
+        });
+    }
+};
+struct MarkerLook {
+    Store S; const int64_t* now_row0; const int32_t* now_cnt; int32_t ngen; const int64_t* cluster_first;
+    Layout once; const int32_t* owner; int32_t* owner2; uint8_t* defer; int64_t cl0;
+    PM_HD void wave(int64_t w) const {
+        const int64_t cl = cl0 + w;
+        const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
+        const int32_t mine = 0x7fffffff - (int32_t)cl;
+        uint32_t earlier = 0;
+        lanes_for(1, ngen, [&](int j) {
+            const int64_t base = once.word_off[j], nb = once.nbits[j];
+            for (int64_t x = p0; x < p1; x++) {
+                const int64_t row0 = now_row0[x];
+                for (int64_t c = row0; c < row0 + now_cnt[x]; c++) {
+                    if (S.flags[c] & (kRowBad | kRowOutside)) continue;
+                    int64_t a = (int64_t)S.start[c * ngen + j] - 1, b = a + S.lon[c] + 2;
+                    if (a < 0) a = 0;
+                    if (b > nb) b = nb;
+                    while (a < b) {
+                        const int f = (int)(a & 63);
+                        const int64_t span = (64 - f) < (b - a) ? (64 - f) : (b - a);
+                        const int64_t wd = base + (a >> 6);
+                        if (once.image[wd] & ((span == 64 ? ~0ull : ((1ull << span) - 1)) << f)) {
+                            const int32_t o = owner[wd];
+                            if (o > mine) earlier = 1;
+                            else if (o < mine) atomic_max32(&owner2[wd], mine);
+                        }
+                        a += span;
+                    }
+                }
+            }
+        });
+        if (wave_or_u32(earlier) && wave_leader()) defer[cl] = 1;
+    }
+};
+struct ReaderLook {
+    Store S; const int64_t* now_row0; const int32_t* now_cnt; int32_t ngen; const int64_t* rg_start; const int64_t* rg_len; const int32_t* now_region; const int64_t* cluster_first;
+    const int64_t* word_off; const int64_t* nbits; const int32_t* owner2; uint8_t* defer; int64_t cl0;
+    PM_HD void wave(int64_t w) const {
+        const int64_t cl = cl0 + w;
+        const int64_t p0 = cluster_first[cl], p1 = cluster_first[cl + 1];
+        const int32_t mine = 0x7fffffff - (int32_t)cl;
+        uint32_t earlier = 0;
+        lanes_for(1, ngen, [&](int j) {
+            cluster_reader_pieces(S, now_row0, now_cnt, ngen, rg_start, rg_len, now_region, p0, p1, j, nbits[j], [&](int64_t a, int64_t b) {
+                for (int64_t wd = a >> 6; wd <= ((b - 1) >> 6) && !earlier; wd++) if (owner2[word_off[j] + wd] > mine) earlier = 1;
+            });
+        });
+        if (wave_or_u32(earlier) && wave_leader()) defer[cl] = 1;
     }
 };
 // A reverse-strand member is flipped against the WHOLE genome (TMum.cpp:33-35): inside a sub-region it usually lands far outside

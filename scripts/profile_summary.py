@@ -47,7 +47,7 @@ PHASES = {
     "index": ["IndexInsert"],
     "repeat": ["RunLength", "RepeatLength"],
     "seeds": ["ChainFlag", "AnchorList", "SeedCount", "SeedPlace", "SeedWalk"],
-    "validate": ["ClustersDisjoint", "ClusterExtents", "ClusterInvolved", "ClusterDefer", "ClusterValidate", "OutsideWriteCheck", "StageGate"],
+    "validate": ["ClustersDisjoint", "ClusterExtents", "ClusterInvolved", "ClusterDefer", "ReaderMark", "MarkerLook", "ReaderLook", "ClusterValidate", "OutsideWriteCheck", "StageGate"],
     "chain": ["ForeignBound", "ForeignScan", "ForeignDecideHits", "ChainKeys", "ChainJudge", "ChainJudgeReverse", "ChainHeads", "ChainLcbSum", "ChainDissolve", "ChainUnmark", "ChainCompact", "ChainFill", "ChainOut"],
 }
 
