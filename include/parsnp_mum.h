@@ -218,14 +218,16 @@ int pm_store_search(pm_session* s, const int32_t* regions, const int32_t* minsiz
  * to the clusters is the call's business, and its answer is done[c] (n_clusters values): how many regions of cluster c were
  * processed.  All of them where the cluster meets no EARLIER cluster in any genome (clusters in reference order follow each
  * other with a base between in every genome -- or, where a genome holds them in another order, their extents are tested
- * exactly); NONE where it does: the reference (doWork pops the smallest reference start, and children lie inside their parents)
+ * exactly, and so is what their CANDIDATES touch: a member outside its region reads where another cluster may mark); NONE where it does: the reference (doWork pops the smallest reference start, and children lie inside their parents)
  * finishes the earlier cluster and everything it leads to first, so the cluster must wait -- the caller keeps its regions on
  * the work list for the next generation, where the question is put again; the FIRST FEW where a child of a processed region
  * sorts before (or ties with) the next waiting region of the cluster: the rest waits as well, the next generation sorts it
  * with the children (:291-292).  Every call processes at least the first region of its first cluster.  done == NULL: a caller
  * that cannot keep regions waiting -- either case is then reported as trouble (bits 3 / 0) instead.
  * *trouble != 0: the reference's order would show and the caller must discard the run and take the host route -- bit 1 (2): a
- * reverse-strand member outside its region (TMum.cpp:33-35 flips it against the whole genome) was accepted there; bit 2 (4): a
+ * reverse-strand member outside its region (TMum.cpp:33-35 flips it against the whole genome) was accepted where a region on the
+ * wrong side of the order covers its marks (one walked out or processed by a MUM the reference takes LATER, or one that still
+ * waits and sorts EARLIER; an accepted member whose marks fall on ground no such region covers is harmless and stays); bit 2 (4): a
  * region with 2^22 candidates or more, or more candidates with a member outside their region (or one longer than 64 bases) than
  * the engine notes for pm_store_order_check; bits 0 (1) and 3 (8): only with done == NULL, see above.
  * info_count > 0: the per-row scalars (pm_store_info) of store rows [info_first, info_first + info_count) -- the candidates
