@@ -91,6 +91,7 @@ def issue_fraction(pdir):
     cycles = g("GRBM_GUI_ACTIVE")
     return {"valu_instructions": int(valu_total), "dispatch_cycles": int(cycles), "simds": simds, "cycles_per_valu": round(1.0 / ipc, 3),
             "valu_per_wave": int(g("SQ_INSTS_VALU") / max(1.0, g("SQ_WAVES"))),
+            "vmem_rd_per_wave": int(round(g("SQ_INSTS_VMEM_RD") / max(1.0, g("SQ_WAVES")))), "vmem_wr_per_wave": int(round(g("SQ_INSTS_VMEM_WR") / max(1.0, g("SQ_WAVES")))),
             "issue_frac": round(valu_total / simds / ipc / cycles, 4),
             "wait_frac": round(g("SQ_WAIT_ANY") / max(1.0, g("SQ_WAVE_CYCLES")), 4),
             "source": "profiles/%s/sq_seed_extend.json + calibration.json" % PROFILE_ROUND}
@@ -489,17 +490,17 @@ def main():
                 # kernel does not live under the byte roof: `limiter` / `issue_frac` say what it waits for.
                 issue = issue_fraction(pdir)
                 if issue and issue.get("issue_frac") is not None:
-                    limiter = ("a chain of dependent scattered reads under half-used issue slots, not byte bandwidth: the anchor dispatch of SeedExtend issues %d "
-                               "vector instructions per 128-sample wavefront (SQ counters of this build, profiles/%s/sq_seed_extend.json); at the measured %.2f cycles "
-                               "per wave64 int32 VALU instruction and SIMD (scripts/valu_calib.hip, profiles/%s/calibration.json; the guide's figure is 2) they occupy "
-                               "%.0f %% of the dispatch's cycles (`issue_frac`; round 4 assumed 4 cycles and called it 85 %%), while %.0f %% of the wave-cycles of its 8 "
-                               "wavefronts per SIMD are spent waiting -- unit record, query blocks, the leaders' filter word and slot, reference blocks, repeat length: "
-                               "five round trips in a row per wavefront, ~56 vector memory instructions of 64 scattered lanes each.  SeedRest waits on dependent scattered "
-                               "reads outright; GroupedPairEvents / SmallPairEvents are register and LDS arithmetic."
-                               % (issue["valu_per_wave"], PROFILE_ROUND, issue["cycles_per_valu"], PROFILE_ROUND, 100 * issue["issue_frac"], 100 * issue.get("wait_frac", 0)))
+                    limiter = ("integer issue and the request rate of the memory system under it, not byte bandwidth: the anchor dispatch of SeedExtend issues %d vector, "
+                               "%d vector-memory-read and %d vector-memory-write instructions per 128-sample wavefront (SQ counters of this build, profiles/%s/sq_seed_extend.json; "
+                               "round 5: 1 200 / 56 / 5 -- the right arms are resolved over the wavefront's lanes since round 6); at the measured %.2f cycles per wave64 int32 VALU "
+                               "instruction and SIMD (scripts/valu_calib.hip, profiles/%s/calibration.json) they occupy %.0f %% of the dispatch's cycles (`issue_frac`), while %.0f %% of the "
+                               "wave-cycles of its wavefronts are spent waiting.  One round trip less in the leaders' chain changed nothing, half the index load factor did (a wavefront "
+                               "runs as long as its longest probe sequence).  SeedRest waits on dependent scattered reads outright; GroupedPairEvents / SmallPairEvents are register and LDS arithmetic."
+                               % (issue["valu_per_wave"], issue.get("vmem_rd_per_wave", 0), issue.get("vmem_wr_per_wave", 0), PROFILE_ROUND, issue["cycles_per_valu"], PROFILE_ROUND,
+                                  100 * issue["issue_frac"], 100 * issue.get("wait_frac", 0)))
                 else:
-                    limiter = ("dependent scattered reads under half-used issue slots (SQ counters of round 4: 1 201 vector + 402 scalar instructions per 128-sample wavefront "
-                               "of SeedExtend, 62 % of its wave-cycles waiting); no SQ pass of this build on file, so no issue fraction is quoted")
+                    limiter = ("integer issue under dependent scattered reads (SQ counters of round 6: 828 vector + 25 vector memory instructions per 128-sample wavefront "
+                               "of SeedExtend, 57 % of its wave-cycles waiting); no SQ pass of this build on file, so no issue fraction is quoted")
                 frac_traffic = round(traffic_gbs / HBM_PEAK_GBS, 5) if traffic_gbs else None
                 roof = {"bound": "hbm",      # (the contract's two rooflines; what the kernel really waits for: `limiter`, `issue_frac`)
                         "limiter": limiter,
