@@ -352,7 +352,7 @@ def main():
             step_ms = []
             for _ in range(args.steps):
                 ts = time.perf_counter()
-                rep = run.step()
+                rep = run.step(intervals=dist is not None and not sharded)      # (the LCBs' reference intervals only where the exchange step reads them)
                 step_ms.append(round(1e3 * (time.perf_counter() - ts), 2))
                 if dist is not None and not sharded:
                     # partition mode's exchange step: every rank's LCB reference intervals are all-gathered (RCCL) and

@@ -18,6 +18,8 @@ class CoreRun:
         self.L.pc_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         self.L.pc_step.argtypes = [C.c_void_p]
         self.L.pc_step.restype = C.c_char_p
+        self.L.pc_step_brief.argtypes = [C.c_void_p]
+        self.L.pc_step_brief.restype = C.c_char_p
         self.L.pc_write.argtypes = [C.c_void_p]
         self.L.pc_close.argtypes = [C.c_void_p]
         h = C.c_void_p()
@@ -26,8 +28,9 @@ class CoreRun:
             raise RuntimeError("parsnp_core could not start (exit code %d)" % rc)
         self.h = h
 
-    def step(self):
-        return json.loads(self.L.pc_step(self.h).decode())
+    def step(self, intervals=True):
+        """one pass of phases A-D -> the report; intervals=False leaves out `lcb_ref_intervals` (partition mode's exchange reads them)"""
+        return json.loads((self.L.pc_step if intervals else self.L.pc_step_brief)(self.h).decode())
 
     def write(self):
         return self.L.pc_write(self.h)

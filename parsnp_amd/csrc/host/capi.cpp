@@ -49,7 +49,12 @@ int pc_tune(pc_run* r, const char* key, long long value) { return pm_session_tun
 // calcmumi on an opened run: writes <outdir>/all.mumi (rank 0 of a sharded run should be the only one to call pc_write)
 int pc_mumi(pc_run* r) { return r->run.mumi(); }
 // one pass of phases A-D; returns a JSON report (valid until the next call on this handle)
-const char* pc_step(pc_run* r) {
+// (pc_step_brief: the same without the LCBs' reference intervals -- 800 pairs of numbers that only partition mode's exchange step
+// reads; a caller that times steps should not pay for printing and parsing them)
+static const char* step_report(pc_run* r, bool intervals);
+const char* pc_step(pc_run* r) { return step_report(r, true); }
+const char* pc_step_brief(pc_run* r) { return step_report(r, false); }
+static const char* step_report(pc_run* r, bool intervals) {
     r->last = r->run.step();
     const StepReport& s = r->last;
     std::ostringstream o;
@@ -80,6 +85,7 @@ const char* pc_step(pc_run* r) {
     o << ", \"lcb_ref_intervals\": [";
     bool first = true;
     for (const Lcb& c : r->run.align->lcbs) {
+        if (!intervals) break;
         if (c.type != 1 || c.mums.empty()) continue;
         o << (first ? "" : ", ") << "[" << c.start[0] + 1 << ", " << c.end[0] << "]";
         first = false;

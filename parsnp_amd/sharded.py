@@ -82,7 +82,7 @@ class ShardedRun:
             sys.stderr.write("all-gather failed: %r\n" % (e,))
             return 1
 
-    def step(self):
+    def step(self, intervals=True):      # (intervals: CoreRun.step's switch; a sharded run always reports them)
         return json.loads(self.L.pc_step(self.h).decode())
 
     def mumi(self):
