@@ -1071,12 +1071,13 @@ struct SeedRest {
             if (len >= ri.minlen && len > rep_l0) emit(0, l - left, j - left, len);      // len <= rep': not unique in R
         };
         // every reference position of a slot's chain against one sample: the entries share the canonical K-mer, not the orientation
-        auto walk = [&](int64_t j, uint64_t tag, uint64_t gat, uint64_t slot, int32_t skip) {
+        auto walk = [&](int64_t j, uint64_t tag, uint64_t gat, uint64_t slot, int32_t skip, uint64_t head_rt) {
             const bool multi = (slot & kMulti) != 0;
-            for (int32_t l = slot_head(slot); l >= 0; l = multi ? next[ri.posbase + l] : -1) {
+            const int32_t head = slot_head(slot);
+            for (int32_t l = head; l >= 0; l = multi ? next[ri.posbase + l] : -1) {
                 if (++work > budget) { atomic_or32(err, kErrWork); return; }
                 if (l == skip) continue;                    // (already handled from the registers)
-                const uint64_t rt = kmer_tag(P, rbase + l, K);
+                const uint64_t rt = l == head ? head_rt : kmer_tag(P, rbase + l, K);      // (the head's K-mer was read to confirm the slot)
                 if (rt == tag) forward_seed(j, l);
                 if (rt == gat) reverse_seed(j, l);
             }
@@ -1086,12 +1087,13 @@ struct SeedRest {
             const uint64_t ctag = gat < tag ? gat : tag;
             uint64_t slot = index_probe(ri, slots, filter, ctag);
             if (slot == kEmpty) return;
-            const uint64_t rt = kmer_tag(P, rbase + slot_head(slot), K);
+            uint64_t rt = kmer_tag(P, rbase + slot_head(slot), K);
             if (rt != tag && rt != gat) {                   // another K-mer with the same 32-bit fingerprint (2^-32): the confirmed lookup
                 slot = index_lookup(P, ri, slots, filter, ctag);
                 if (slot == kEmpty) return;
+                rt = kmer_tag(P, rbase + slot_head(slot), K);
             }
-            walk(j, tag, gat, slot, -1);
+            walk(j, tag, gat, slot, -1, rt);
         };
 
         if (live) {
