@@ -179,9 +179,9 @@ StepReport CoreRun::step() {
     r.resident_why = why;
     if (const char* log = test_hook("PARSNP_RESIDENT_LOG"))      // test hook: which route every step took
         if (FILE* f = fopen(log, "a")) {
-            double exact = 0;
-            for (const auto& kv : r.host.engine_ms) if (kv.first == "exact_cluster_tests") exact = kv.second;
-            fprintf(f, "resident=%ld retry=%ld chain=%ld exact=%ld generations=%ld deferred=%ld ties=%ld anchors=%ld mums=%ld why=%s\n", r.host.resident, r.host.resident_retry, r.host.device_chain, (long)exact, r.host.generations, r.host.regions_deferred, r.host.tie_runs, r.anchors, r.mums, why.c_str()); fclose(f);
+            double exact = 0, outside = 0;
+            for (const auto& kv : r.host.engine_ms) { if (kv.first == "exact_cluster_tests") exact = kv.second; if (kv.first == "outside_writes") outside = kv.second; }
+            fprintf(f, "resident=%ld retry=%ld chain=%ld exact=%ld generations=%ld deferred=%ld ties=%ld outside=%ld anchors=%ld mums=%ld why=%s\n", r.host.resident, r.host.resident_retry, r.host.device_chain, (long)exact, r.host.generations, r.host.regions_deferred, r.host.tie_runs, (long)outside, r.anchors, r.mums, why.c_str()); fclose(f);
         }
     return r;
 }

@@ -57,7 +57,11 @@ def one(seed, big):
             tj = json.load(open(base / "timing.json"))
             routes[(tj.get("resident"), tj.get("resident_why") or "")] = routes.get((tj.get("resident"), tj.get("resident_why") or ""), 0) + 1
             routes["outside_writes"] = routes.get("outside_writes", 0) + int(tj.get("outside_writes", 0))
-            if tj.get("outside_writes", 0) and tj.get("resident"): routes["resident runs with outside writes"] = routes.get("resident runs with outside writes", 0) + 1
+            if tj.get("outside_writes", 0) and tj.get("resident"):
+                routes["resident runs with outside writes"] = routes.get("resident runs with outside writes", 0) + 1
+                print("seed", seed, big, "stayed on the route with", tj.get("outside_writes"), "accepted member(s) outside their region", flush=True)
+            if "accepted outside its region" in (tj.get("resident_why") or ""):
+                print("seed", seed, big, "left the route:", tj.get("resident_why"), flush=True)
         except Exception:   # noqa: BLE001
             pass
         if a != b:

@@ -269,6 +269,39 @@ def test_order_of_reads_outside_a_region_on_gpu(tmp_path, monkeypatch, route):
     order_case(CORE_HOOKS_BIN, tmp_path, monkeypatch, route)
 
 
+def outside_write_case(core, tmp_path, monkeypatch, seed, stays):
+    """round 6: an ACCEPTED reverse-strand member outside its region (TMum.cpp:33-35 flips it against the whole genome) no longer
+    ends the resident route by itself: its marks are checked against the regions of the store (OutsideWriteCheck) and the route is
+    left only where a region on the wrong side of the reference's order covers them.  Seed 7030 of the round's emulation campaign
+    holds one that is harmless -- the run stays and gives the reference's bytes --, seed 7174 one that is not: the step is repeated
+    on the host route, the reference's bytes again."""
+    for k, v in dict(PM_DIRTY_MIN="2", PARSNP_PARALLEL_MIN="2", PARSNP_FREE_MIN="1", PARSNP_CHECK_ZERO="1", PM_FLAGGED_DIV="1", PARSNP_CHECK_NEIGHBOURS="1",
+                     PARSNP_RESIDENT_LOG=str(tmp_path / "route.log")).items():
+        monkeypatch.setenv(k, v)
+    ref, gs, kw, contigs = random_case(seed, False)
+    kw["threads"] = 3
+    rp, qs = write(str(tmp_path / "in"), ref, gs, contigs, seed)
+    a = run(REFBIN, rp, qs, str(tmp_path / "ref"), kw)
+    b = run(core, rp, qs, str(tmp_path / "mine"), kw)
+    assert a == b
+    log = open(str(tmp_path / "route.log")).read()
+    if stays:
+        assert "resident=1" in log and "retry=0" in log and "outside=1" in log, log
+    else:
+        assert "retry=1" in log and "accepted outside its region" in log, log
+
+
+@pytest.mark.parametrize("seed,stays", [(7030, True), (7174, False)])
+def test_writes_outside_a_region(emu, tmp_path, monkeypatch, seed, stays):
+    outside_write_case(emu[1], tmp_path, monkeypatch, seed, stays)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,stays", [(7030, True), (7174, False)])
+def test_writes_outside_a_region_on_gpu(tmp_path, monkeypatch, seed, stays):
+    outside_write_case(CORE_HOOKS_BIN, tmp_path, monkeypatch, seed, stays)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_host_route_over_device_rows(emu, tmp_path, monkeypatch, seed):
     """the same side by side for the HOST route over the kernel emulation (PARSNP_NO_RESIDENT: what a step falls back to),
