@@ -748,7 +748,10 @@ struct RegionsEqual {
 //      ordered, and `glo[pair]` is where they start -- no gather, no sort.
 // A region with a side longer than 128 bases, more than kGrpPieces distinct pieces, or more than kGrpEvents events of one
 // (piece, strand) leaves its flag at 0 and writes nothing: SmallPairEvents, launched after this kernel, takes it.
-constexpr int kGrpEvents = 16;
+#ifndef PM_GRP_EVENTS
+#define PM_GRP_EVENTS 8      // (16 until round 6: 4 KB of LDS per wavefront less, 14 instead of 10 wavefronts per CU; no region of the three bench workloads holds more)
+#endif
+constexpr int kGrpEvents = PM_GRP_EVENTS;
 constexpr int kGrpPieces = 32;
 constexpr int kGrpGenomes = 1024;      // (the piece numbers of one region's genomes sit in LDS)
 struct GroupedPairEvents {
