@@ -288,7 +288,9 @@ def outside_write_case(core, tmp_path, monkeypatch, seed, stays):
     if stays:
         assert "resident=1" in log and "retry=0" in log and "outside=1" in log, log
     else:
-        assert "retry=1" in log and "accepted outside its region" in log, log
+        # (the emulation, one thread at a time, always gets as far as the write; on the device the candidate's READ outside its region
+        # may come first in time and fail the order check instead: either way the route is left and the host route answers)
+        assert "retry=1" in log and ("accepted outside its region" in log or "decided differently by the reference's order" in log), log
 
 
 @pytest.mark.parametrize("seed,stays", [(7030, True), (7174, False)])
