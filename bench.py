@@ -619,7 +619,7 @@ def main():
                            "genomes_per_gpu": G if not sharded else round(G / world, 2), "genome_bp": n_ref, "host_threads": args.host_threads, "tune": args.tune or None, "host_cpus_usable": usable_cpus(), "numa_node": numa_node, "parallelism": ("sharded x%d (engine RCCL: all-reduce(min) + all-gather per engine call)" % world) if sharded else "partition-per-gpu x%d" % world},
                 "n_ranks_seen_by_rccl": rccl_ranks, "per_rank": per_rank,
                 "sharded_strong": sharded_strong,
-                "step_ms": step_ms[:40], "host_cores_busy": round(host_cores_busy, 2),
+                "step_ms": step_ms[:40], "step_ms_quantiles": [sorted(step_ms)[int(q * (len(step_ms) - 1))] for q in (0.0, 0.1, 0.5, 0.9, 0.99, 1.0)], "step_ms_slowest": [dict(step=i, ms=x, path_ms=round(1e3 * reports[i]["path_s"], 2), anchor_ms=round(1e3 * reports[i]["anchor_s"], 2), extend_ms=round(1e3 * reports[i]["extend_s"], 2), lcb_ms=round(1e3 * reports[i]["lcb_s"], 2), setup_ms=round(1e3 * reports[i]["setup_s"], 2), call_wall=round(reports[i]["engine_ms"].get("call_wall", 0), 2), phases={k: round(v, 2) for k, v in reports[i]["engine_ms"].items() if isinstance(v, float) and v > 0.5 and v < 100 and k != "call_wall"}) for x, i in sorted(((x, i) for i, x in enumerate(step_ms)), reverse=True)[:6]], "host_cores_busy": round(host_cores_busy, 2),
                 # what the engine moved over the host link per step (pm_session_traffic: every copy it issued), and which route the
                 # steps took (resident: MUM rows, layout and regions stayed on the device, parsnp_amd/csrc/host/resident.cpp)
                 "pcie_bytes_per_step": {"h2d": int(sum(r.get("h2d_bytes", 0) for r in reports) / len(reports)),

@@ -468,7 +468,7 @@ public:
         }
         if (from_store) { last_alg[0] = (double)alg_raw[0] / 4.0; last_alg[1] = (double)alg_raw[1] / 2.0; last_alg[2] = (double)alg_raw[2] / 2.0; }
         if (errbits & kErrRows) { error = "region outside its genome"; return -2; }
-        rest_cap_hint[nreg == 1] = queue_cap;
+        rest_cap_hint[nreg == 1] = queue_cap - 64;      // (the margin is added again by the next call: storing it with the margin let the queues grow by 64 items a call, and every ~20 steps the 100 MB block was reallocated -- an 8-16 ms step)
         if (gb) hint.units = std::max<int64_t>(nunits_live, 1);
         last_rest = (int64_t)nrest;
         ev_cap_hint = (size_t)(nev + nev / 4);
