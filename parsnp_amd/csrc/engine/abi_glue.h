@@ -100,6 +100,7 @@ int pm_multi_mum_batch(pm_session* s, int64_t n_regions, const int64_t* starts, 
     try {
         std::unique_ptr<pm_result> r(new pm_result);
         const auto w0 = std::chrono::steady_clock::now();
+        s->backend->drop_landings();      // (downloads a failed call queued and never waited for must not land in its dead blocks)
         int rc = s->engine->run(n_regions, starts, lens, minsize, &r->r);
         if (rc) return fail(rc, s->engine->error);
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
@@ -134,6 +135,7 @@ int64_t pm_result_store_base(const pm_result* r) { return r ? r->r.store_base : 
 #define PM_STORE_CALL(expr)                                                                                                             \
     try {                                                                                                                               \
         const auto w0 = std::chrono::steady_clock::now();                                                                               \
+        s->backend->drop_landings();                                                                                                    \
         const int rc = (expr);                                                                                                          \
         if (rc) return fail(rc, s->engine->error);                                                                                      \
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());                                                               \
@@ -168,6 +170,7 @@ int pm_store_settle_seeds(pm_session* s, int64_t table_id, int32_t q, pm_row_inf
     *n_regions = 0;
     try {
         const auto w0 = std::chrono::steady_clock::now();
+        s->backend->drop_landings();      // (downloads a failed call queued and never waited for must not land in its dead blocks)
         const int rc = s->engine->store_settle_seeds(table_id, q, (pm::RowInfo*)rows, &s->new_regions, &s->new_region_ids);
         if (rc) return fail(rc, s->engine->error);
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());
@@ -194,6 +197,7 @@ int pm_store_validate(pm_session* s, const int32_t* regions, const int64_t* row_
     *n_children = 0;
     try {
         const auto w0 = std::chrono::steady_clock::now();
+        s->backend->drop_landings();      // (downloads a failed call queued and never waited for must not land in its dead blocks)
         const int rc = s->engine->store_validate(regions, row_first, row_count, n_regions, cluster_first, n_clusters, q, trouble, &s->new_regions, &s->new_region_ids, info_first, info_count, (pm::RowInfo*)info, stage_first, second_stage_ran, generation, done);
         if (rc) return fail(rc, s->engine->error);
         if (!s->backend->ok()) return fail(PM_EHIP, s->backend->error());

@@ -241,6 +241,8 @@ struct HipBackend {
     struct Landing { void* dst; const uint8_t* at; size_t n; };
     std::vector<Landing> landings;
     void land() { for (const Landing& l : landings) memcpy(l.dst, l.at, l.n); landings.clear(); dring_at = 0; }
+    // at the start of every call of the C ABI: what an earlier call queued and never waited for (it returned an error) is forgotten
+    void drop_landings() { if (!landings.empty()) { (void)hipStreamSynchronize(stream); landings.clear(); dring_at = 0; } }
     void d2h_async(void* d, const void* s, size_t n) {
         const double t0 = copy_log() ? now_us() : 0;
         bytes_d2h += n;

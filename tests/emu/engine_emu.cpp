@@ -22,6 +22,7 @@ struct HostBackend {
     void d2h(void* d, const void* s, size_t n) { bytes_d2h += n; memcpy(d, s, n); }
     void d2h_async(void* d, const void* s, size_t n) { bytes_d2h += n; memcpy(d, s, n); }
     void d2h_async_pinned(void* d, const void* s, size_t n) { d2h_async(d, s, n); }
+    void drop_landings() {}
     void d2d(void* d, const void* s, size_t n) { memcpy(d, s, n); }
     void bind() {}
     void* pinned_alloc(size_t n) { return malloc(n ? n : 1); }
