@@ -866,11 +866,22 @@ public:
                 ensure(d_owner, words);
                 if (d_owner.p != before) be.memset(d_owner.p, 0, 4 * words);      // (kept all zero between calls)
             }
-            for (int round = 0; round < (tangle_rounds ? kTangleRounds : 0); round++) {
+            // as many rounds as the last step of the session needed, + 1 (a round that settles nothing costs three launches of 4 us;
+            // what the rounds leave is the serial wavefront's either way): every round notes how many rows it left
+            int rounds = tangle_rounds ? kTangleRounds : 0;
+            if (rounds && tangle_ran > 0) {
+                int last = 0;
+                for (int r = 1; r < tangle_ran; r++) if (tangle_left[r] < tangle_left[r - 1]) last = r;
+                rounds = std::min(kTangleRounds, last + 2);
+            }
+            ensure(d_t_left, kTangleRounds);
+            for (int round = 0; round < rounds; round++) {
                 be.launch_wave("tangle_owner", (int64_t)fl.size(), TangleOwner{S, d_list.p, d_lay_off.p, d_lay_bits.p, d_owner.p, d_t_done.p, d_t_rem.p});
                 be.launch_wave("tangle_settle", (int64_t)fl.size(), TangleSettle{S, layout_view(d_image.p, false), P, d_list.p, d_owner.p, d_t_done.p, d_t_rem.p});
-                be.launch_wave("tangle_clear", (int64_t)fl.size(), TangleClear{S, d_list.p, d_lay_off.p, d_lay_bits.p, d_owner.p, d_t_done.p});
+                be.launch_wave("tangle_clear", (int64_t)fl.size(), TangleClear{S, d_list.p, d_lay_off.p, d_lay_bits.p, d_owner.p, d_t_done.p, d_t_rem.p, d_t_left.p + round});
             }
+            tangle_ran = 0;
+            if (rounds) { be.d2h_async(tangle_left, d_t_left.p, 8 * (size_t)rounds); tangle_ran = rounds; }      // (lands with the call's results)
             be.launch_wave("settle_tangled", 1, SettleTangled{S, L, P, d_list.p, (int64_t)fl.size(), d_t_done.p, d_t_rem.p});
         }
         layout_rows = rows;
@@ -1513,6 +1524,7 @@ private:
     Buf<int64_t> d_sd_cnt, d_sd_off; Buf<uint8_t> d_sd_keep;      // store_settle_seeds
     Buf<uint64_t> d_t_rem; Buf<uint8_t> d_t_done;      // settle_launch: tangled rows left, settled flags per flagged row
     Buf<int32_t> d_v_done, d_owner; Buf<uint8_t> d_v_defer, d_v_involved;      // store_validate: regions processed per cluster; the exact test of the clusters
+    Buf<uint64_t> d_t_left; uint64_t tangle_left[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int tangle_ran = 0;      // settle_launch: what each round of the tangled rows left, last step
     Buf<int64_t> d_rg_pkey; Buf<OutsideWrite> d_outw; Buf<uint64_t> d_outw_count; int64_t rg_pkey_init = 0; uint64_t outside_writes_call = 0;      // store_validate: OutsideWriteCheck
     Buf<ForeignRead> d_foreign; Buf<uint64_t> d_foreign_count, d_foreign_masks; Buf<int64_t> d_ms_key;       // store_validate / store_order_check: candidates with a member outside their region
     size_t foreign_cap = 0; int64_t ms_key_rows = 0; uint64_t foreign_seen = 0;      // foreign_seen: the device's counter as of the last validation call

@@ -528,7 +528,9 @@ struct TangleSettle {
 };
 struct TangleClear {
     Store S; const int32_t* list; const int64_t* word_off; const int64_t* nbits; int32_t* owner; uint8_t* t_done;
+    const uint64_t* remaining; uint64_t* left_after;      // [0] of the launch notes how many tangled rows the round left (the caller sizes the next step's rounds by it)
     PM_HD void wave(int64_t i) const {
+        if (i == 0 && wave_leader()) *left_after = *remaining;
         const int64_t c = list[i];
         if (!(S.state[c] & kStTangled) || t_done[i] == 2) return;
         const int n = S.ngen;
