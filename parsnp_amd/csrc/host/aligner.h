@@ -290,6 +290,7 @@ struct AlignerMemory {
     bool layout_clean = false;               // `layout` holds the sentinels and nothing else: the run that used it never wrote to it (the resident route)
     std::vector<Bitmap> scratch;             // validate_parallel's scratch bitmaps (each stripe thread clears and fills its own)
     std::vector<int64_t> batch_starts, batch_lens;   // run_batch's flat request arrays
+    std::vector<pm_row_info> anchor_info_store;      // resident route: the block the anchors' per-row scalars arrive in, kept between runs (1.3 MB: not zero-filled per step)
     std::vector<Mum> pool_store, candidates;         // storage of Aligner::pool / validate_parallel's candidate records between runs
     std::vector<int> minlen_flat[2]; std::string minlen_expr[2];   // Aligner::min_length for lengths below 2^16, by expression (mums, anchors)
     // extend_generations: a candidate with a reverse-strand member outside its region, with the marks it saw in every genome's
@@ -362,7 +363,7 @@ private:
         std::vector<pm_region_info> gen_info; std::vector<int32_t> gen_id;     // the seed regions, in push order
         std::vector<int32_t> fallback_start; std::vector<uint8_t> fallback_strand;   // rows fetched for the host route
         std::vector<uint64_t> image;                                           // the layout, fetched for parsnp.unalign
-        std::vector<pm_row_info> anchor_info; const int32_t* anchor_lon = nullptr; long anchor_slength = 0; size_t anchor_accepted = 0;   // what resident_records() writes the anchors' MUM records from
+        std::vector<pm_row_info> anchor_info; size_t anchor_rows = 0; const int32_t* anchor_lon = nullptr; long anchor_slength = 0; size_t anchor_accepted = 0;   // what resident_records() writes the anchors' MUM records from
         bool records_done = true;
         std::vector<int32_t> of_row, len_of_row;      // store row -> index of its MUM record in the pool (-1: none), and its length
         bool chain_queued = false;                                             // pm_store_chain_begin is in flight (resident_chain() collects it)

@@ -64,12 +64,13 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
     Raw& a = raw[0];
     const int64_t table = pm_result_table_id(a.owner.get());
     const bool kept = table != 0 && pm_result_store_base(a.owner.get()) == 0;      // the rows stayed on the device
-    std::vector<pm_row_info> info;
+    std::vector<pm_row_info> info = std::move(memory_->anchor_info_store);      // (its storage is kept between runs)
+    memory_->anchor_info_store.clear();
     int rc = PM_EAGAIN;
     static const bool fused = test_hook("PARSNP_SPLIT_SETTLE") == nullptr;
     int64_t nreg = 0;
     if (kept) {
-        info.resize(a.count);
+        if (info.size() < a.count) info.resize(a.count);
         const double ts = now_s();
         // validation and seed regions in one call (one round trip); the test hook takes the two calls it replaces
         if (fused) rc = pm_store_settle_seeds(session_, table, (int32_t)prm.q, info.data(), &nreg);
@@ -108,7 +109,7 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
     }
     found->resize(nacc);
     for (size_t i = 0; i < nacc; i++) (*found)[i] = (int)i;
-    res_.anchor_info = std::move(info); res_.anchor_lon = a.lon; res_.anchor_slength = whole.slength; res_.anchor_accepted = nacc; res_.records_done = false;
+    res_.anchor_info = std::move(info); res_.anchor_rows = a.count; res_.anchor_lon = a.lon; res_.anchor_slength = whole.slength; res_.anchor_accepted = nacc; res_.records_done = false;
     stats.parallel_candidates += (long)a.count;
     stats.regions_processed++;
     lap("records");
@@ -148,7 +149,7 @@ bool Aligner::resident_anchors(const Region& whole, std::vector<int>* found) {
 void Aligner::resident_records() {
     if (res_.records_done) return;
     res_.records_done = true;
-    const size_t nacc = res_.anchor_accepted, count = res_.anchor_info.size();
+    const size_t nacc = res_.anchor_accepted, count = res_.anchor_rows;
     pool.resize(nacc); res_.start0.resize(nacc);
     res_.of_row.assign(count, -1); res_.len_of_row.assign(count, 0);      // store row -> MUM record (resident_chain reads the device's list through it)
     size_t at = 0;
@@ -167,7 +168,7 @@ void Aligner::resident_records() {
         dirty += m.dirty; tangled += (st & PM_ST_TANGLED) != 0;
     }
     stats.parallel_dirty += dirty; stats.parallel_tangled += tangled;
-    std::vector<pm_row_info>().swap(res_.anchor_info);
+    memory_->anchor_info_store = std::move(res_.anchor_info); res_.anchor_info.clear();      // (the storage goes back for the next run)
 }
 
 static const char* const kOrderWhy = "a candidate with a reverse-strand member outside its region is decided differently by the reference's order";
